@@ -1,0 +1,262 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of ``oracle/liboracle.so`` (the scalar C restatement of Flock's
+NEXMark generator and of the DataFusion operators behind q1/q2/q3/q5/q8).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package, and only as the checker.  ``flock_amd`` never does.
+
+Reference call sites restated: flock/src/datasource/nexmark/{event,config,generator}.rs
+(generator) and flock-function/src/aws/actor.rs:54-79 (`collect`, one window per call).
+NEXMark result parity is *unpinned* by the reference's own tests (they only print);
+see oracle/nexmark_ops.c for how this oracle is pinned transitively.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+BASE_TIME = 1_436_918_400_000  # config.rs:20
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (idempotent)."""
+    srcs = [os.path.join(_HERE, f) for f in ("nexmark_gen.c", "nexmark_ops.c", "nexmark_exp2_table.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class _Stream(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_event_id", C.c_uint64), ("eps", C.c_uint64), ("base_time", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        u64, vp = C.c_uint64, C.c_void_p
+        _lib.oracle_nexmark_counts.argtypes = [u64, u64, u64, vp, vp, vp]
+        _lib.oracle_nexmark_counts.restype = None
+        _lib.oracle_nexmark_gen_bids.argtypes = [vp, u64, u64, vp, vp, vp, vp]
+        _lib.oracle_nexmark_gen_bids.restype = u64
+        _lib.oracle_nexmark_gen_auctions.argtypes = [vp, u64, u64] + [vp] * 11
+        _lib.oracle_nexmark_gen_auctions.restype = u64
+        _lib.oracle_nexmark_gen_persons.argtypes = [vp, u64, u64] + [vp] * 12
+        _lib.oracle_nexmark_gen_persons.restype = u64
+        _lib.oracle_q1_project.argtypes = [vp, u64, vp]
+        _lib.oracle_q1_project.restype = None
+        _lib.oracle_q2_filter.argtypes = [vp, vp, u64, C.c_int64, vp, vp]
+        _lib.oracle_q2_filter.restype = u64
+        _lib.oracle_q3_join.argtypes = [vp, vp, u64, C.c_int64, vp, vp, vp, u64, vp, C.c_int, vp, vp]
+        _lib.oracle_q3_join.restype = u64
+        _lib.oracle_q5_hot_items.argtypes = [vp, u64, vp, vp, u64]
+        _lib.oracle_q5_hot_items.restype = u64
+        _lib.oracle_count_by_key.argtypes = [vp, u64, vp, vp, u64]
+        _lib.oracle_count_by_key.restype = u64
+        _lib.oracle_q8_join.argtypes = [vp, vp, vp, u64, vp, u64, vp]
+        _lib.oracle_q8_join.restype = u64
+        _lib.oracle_take_utf8.argtypes = [vp, vp, vp, u64, vp, vp]
+        _lib.oracle_take_utf8.restype = u64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Utf8:
+    """Arrow Utf8 column: int32 offsets (rows + 1) + bytes."""
+
+    offsets: np.ndarray
+    data: np.ndarray
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def to_pylist(self):
+        b = self.data.tobytes()
+        o = self.offsets
+        return [b[o[i]:o[i + 1]].decode() for i in range(len(self))]
+
+    def slice(self, lo, hi):
+        o = self.offsets[lo:hi + 1]
+        return Utf8((o - o[0]).astype(np.int32), self.data[o[0]:o[-1]])
+
+
+# ---------------------------------------------------------------- generator
+@dataclass
+class NexmarkStream:
+    """One generator's event stream (threads = 1 per source function,
+    flock-function/src/aws/nexmark/source.rs:44-48)."""
+
+    seed: int = 0
+    first_event_id: int = 0
+    eps: int = 1000
+    base_time: int = BASE_TIME
+
+    def _c(self):
+        return _Stream(self.seed, self.first_event_id, self.eps, self.base_time)
+
+    def counts(self, n0, n1):
+        p, a, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().oracle_nexmark_counts(self.first_event_id, n0, n1, C.byref(p), C.byref(a), C.byref(b))
+        return p.value, a.value, b.value
+
+    def bids(self, n0, n1, columns=("auction", "bidder", "price", "b_date_time")):
+        _, _, nb = self.counts(n0, n1)
+        out = {
+            "auction": np.empty(nb, np.int32) if "auction" in columns else None,
+            "bidder": np.empty(nb, np.int32) if "bidder" in columns else None,
+            "price": np.empty(nb, np.int32) if "price" in columns else None,
+            "b_date_time": np.empty(nb, np.int64) if "b_date_time" in columns else None,
+        }
+        s = self._c()
+        rows = lib().oracle_nexmark_gen_bids(C.byref(s), n0, n1, *(_p(out[k]) for k in ("auction", "bidder", "price", "b_date_time")))
+        assert rows == nb
+        return {k: v for k, v in out.items() if v is not None}
+
+    def auctions(self, n0, n1, strings=False):
+        _, na, _ = self.counts(n0, n1)
+        cols = {k: np.empty(na, np.int32) for k in ("a_id", "initial_bid", "reserve", "seller", "category")}
+        cols["a_date_time"] = np.empty(na, np.int64)
+        cols["expires"] = np.empty(na, np.int64)
+        io = ib = do = db = None
+        if strings:
+            io, ib = np.empty(na + 1, np.int32), np.empty(max(na * 19, 1), np.uint8)
+            do, db = np.empty(na + 1, np.int32), np.empty(max(na * 99, 1), np.uint8)
+        s = self._c()
+        rows = lib().oracle_nexmark_gen_auctions(
+            C.byref(s), n0, n1, _p(cols["a_id"]), _p(cols["initial_bid"]), _p(cols["reserve"]), _p(cols["a_date_time"]),
+            _p(cols["expires"]), _p(cols["seller"]), _p(cols["category"]), _p(io), _p(ib), _p(do), _p(db))
+        assert rows == na
+        if strings:
+            cols["item_name"] = Utf8(io, ib[: io[-1]].copy())
+            cols["description"] = Utf8(do, db[: do[-1]].copy())
+        return cols
+
+    def persons(self, n0, n1, filler=False):
+        np_, _, _ = self.counts(n0, n1)
+        cols = {"p_id": np.empty(np_, np.int32), "p_date_time": np.empty(np_, np.int64)}
+        no, nb = np.empty(np_ + 1, np.int32), np.empty(max(np_ * 14, 1), np.uint8)
+        co, cb = np.empty(np_ + 1, np.int32), np.empty(max(np_ * 13, 1), np.uint8)
+        so, sb = np.empty(np_ + 1, np.int32), np.empty(max(np_ * 2, 1), np.uint8)
+        eo = eb = cco = ccb = None
+        if filler:
+            eo, eb = np.empty(np_ + 1, np.int32), np.empty(max(np_ * 15, 1), np.uint8)
+            cco, ccb = np.empty(np_ + 1, np.int32), np.empty(max(np_ * 19, 1), np.uint8)
+        s = self._c()
+        rows = lib().oracle_nexmark_gen_persons(
+            C.byref(s), n0, n1, _p(cols["p_id"]), _p(cols["p_date_time"]), _p(no), _p(nb), _p(eo), _p(eb),
+            _p(cco), _p(ccb), _p(co), _p(cb), _p(so), _p(sb))
+        assert rows == np_
+        cols["name"] = Utf8(no, nb[: no[-1]].copy())
+        cols["city"] = Utf8(co, cb[: co[-1]].copy())
+        cols["state"] = Utf8(so, sb[: so[-1]].copy())
+        if filler:
+            cols["email_address"] = Utf8(eo, eb[: eo[-1]].copy())
+            cols["credit_card"] = Utf8(cco, ccb[: cco[-1]].copy())
+        return cols
+
+
+# ---------------------------------------------------------------- operators (one window per call)
+def q1_project(price: np.ndarray) -> np.ndarray:
+    price = np.ascontiguousarray(price, np.int32)
+    out = np.empty(len(price), np.float64)
+    lib().oracle_q1_project(_p(price), len(price), _p(out))
+    return out
+
+
+def q2_filter(auction: np.ndarray, price: np.ndarray, modulus: int = 123):
+    auction = np.ascontiguousarray(auction, np.int32)
+    price = np.ascontiguousarray(price, np.int32)
+    oa, op = np.empty(len(auction), np.int32), np.empty(len(auction), np.int32)
+    m = lib().oracle_q2_filter(_p(auction), _p(price), len(auction), modulus, _p(oa), _p(op))
+    return oa[:m].copy(), op[:m].copy()
+
+
+def q3_join(seller, category, p_id, state: Utf8, category_lit=10, state_lits=("or", "id", "ca")):
+    """Returns (auction_row, person_row) int64 pairs in DataFusion probe order."""
+    seller = np.ascontiguousarray(seller, np.int32)
+    category = np.ascontiguousarray(category, np.int32)
+    p_id = np.ascontiguousarray(p_id, np.int32)
+    lits = (C.c_char_p * len(state_lits))(*[s.encode() for s in state_lits])
+    args = (_p(seller), _p(category), len(seller), category_lit, _p(p_id), _p(state.offsets), _p(state.data),
+            len(p_id), C.cast(lits, C.c_void_p), len(state_lits))
+    n = lib().oracle_q3_join(*args, None, None)
+    ar, pr = np.empty(n, np.int64), np.empty(n, np.int64)
+    n2 = lib().oracle_q3_join(*args, _p(ar), _p(pr))
+    assert n2 == n
+    return ar, pr
+
+
+def q5_hot_items(auction: np.ndarray):
+    """(auction Int32, num UInt64) rows with num == MAX(num); ties kept."""
+    auction = np.ascontiguousarray(auction, np.int32)
+    cap = 1024
+    while True:
+        oa, on = np.empty(cap, np.int32), np.empty(cap, np.uint64)
+        n = lib().oracle_q5_hot_items(_p(auction), len(auction), _p(oa), _p(on), cap)
+        if n <= cap:
+            return oa[:n].copy(), on[:n].copy()
+        cap = int(n)
+
+
+def count_by_key(key: np.ndarray):
+    key = np.ascontiguousarray(key, np.int32)
+    n = lib().oracle_count_by_key(_p(key), len(key), None, None, 0)
+    ok, oc = np.empty(n, np.int32), np.empty(n, np.uint64)
+    lib().oracle_count_by_key(_p(key), len(key), _p(ok), _p(oc), n)
+    return ok, oc
+
+
+def q8_join(p_id, name: Utf8, seller):
+    """Row indices (into the window's person rows) of the output, in row order."""
+    p_id = np.ascontiguousarray(p_id, np.int32)
+    seller = np.ascontiguousarray(seller, np.int32)
+    out = np.empty(len(p_id), np.int64)
+    n = lib().oracle_q8_join(_p(p_id), _p(name.offsets), _p(name.data), len(p_id), _p(seller), len(seller), _p(out))
+    return out[:n].copy()
+
+
+def take_utf8(col: Utf8, rows: np.ndarray) -> Utf8:
+    rows = np.ascontiguousarray(rows, np.int64)
+    off = np.empty(len(rows) + 1, np.int32)
+    nbytes = lib().oracle_take_utf8(_p(col.offsets), _p(col.data), _p(rows), len(rows), _p(off), None)
+    data = np.empty(max(nbytes, 1), np.uint8)
+    lib().oracle_take_utf8(_p(col.offsets), _p(col.data), _p(rows), len(rows), _p(off), _p(data))
+    return Utf8(off, data[:nbytes])
+
+
+# ---------------------------------------------------------------- window schedules
+def elementwise_windows(seconds):
+    """One window per 1-s epoch (flock-function/src/aws/window/elementwise.rs:46)."""
+    return [(e, e + 1) for e in range(seconds)]
+
+
+def tumbling_windows(seconds, size):
+    """flock-function/src/aws/window/tumbling.rs:55-57."""
+    return [(t * size, t * size + size) for t in range(seconds // size)]
+
+
+def hopping_windows(seconds, size, hop):
+    """Only full windows (flock-function/src/aws/window/hopping.rs:54-57)."""
+    out = []
+    for t in range(0, seconds, hop):
+        if t + size > seconds:
+            break
+        out.append((t, t + size))
+    return out

@@ -1,0 +1,223 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (never imported by flock_amd).
+
+Pure-Python, row-at-a-time restatement of the DataFusion physical operators that
+Flock's hot path executes (FilterExec, ProjectionExec, HashAggregateExec,
+HashJoinExec(Inner), SortExec, GlobalLimitExec, CoalesceBatchesExec,
+RepartitionExec).  Small cases only.  Its job is to be *pinned* against every
+operator-level golden vector the reference's tests hold at the
+`ExecutionContext::execute` boundary, and then to pin the scalar C oracle
+(oracle/nexmark_ops.c) and the HIP kernels on NEXMark windows:
+
+    reference goldens  ->  generic_ops.py  ->  nexmark_ops.c  ->  HIP kernels
+    (context.rs:493-503, 579-589; launcher/local.rs:223-231; transmute.rs:298-393)
+
+A table is ``dict[str, list]`` (column name -> python values), a batch list is a
+list of tables.  The operator arithmetic itself is upstream DataFusion ~6.x
+(un-vendored dependency, flock/Cargo.toml:21); semantics restated per
+SURVEY.md appendix D.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Dict, List, Sequence, Tuple
+
+Table = Dict[str, list]
+
+
+def num_rows(t: Table) -> int:
+    return len(next(iter(t.values()))) if t else 0
+
+
+def rows(t: Table) -> List[tuple]:
+    return list(zip(*t.values())) if t else []
+
+
+def concat(batches: Sequence[Table]) -> Table:
+    out: Table = {k: [] for k in batches[0]}
+    for b in batches:
+        for k in out:
+            out[k].extend(b[k])
+    return out
+
+
+# -- FilterExec: keep rows whose predicate is True (NULL -> dropped), order preserved -------------
+def filter_exec(t: Table, pred: Callable[[dict], bool]) -> Table:
+    names = list(t)
+    keep = [i for i, r in enumerate(rows(t)) if pred(dict(zip(names, r))) is True]
+    return {k: [v[i] for i in keep] for k, v in t.items()}
+
+
+# -- ProjectionExec ---------------------------------------------------------------------------------
+def projection_exec(t: Table, exprs: Sequence[Tuple[str, Callable[[dict], object]]]) -> Table:
+    names = list(t)
+    rs = [dict(zip(names, r)) for r in rows(t)]
+    return {out: [f(r) for r in rs] for out, f in exprs}
+
+
+# -- HashAggregateExec (Partial+Final collapsed: the split is result-neutral) ------------------------
+def _agg_init(kind):
+    return {"count": 0, "max": None, "min": None, "sum": None, "avg": (0, 0.0)}[kind]
+
+
+def _agg_update(kind, st, v):
+    if v is None:
+        return st
+    if kind == "count":
+        return st + 1
+    if kind == "max":
+        return v if st is None or v > st else st
+    if kind == "min":
+        return v if st is None or v < st else st
+    if kind == "sum":
+        return v if st is None else st + v
+    if kind == "avg":  # state = (UInt64 count, Float64 sum)
+        return (st[0] + 1, st[1] + float(v))
+    raise ValueError(kind)
+
+
+def _agg_final(kind, st):
+    if kind == "avg":
+        return None if st[0] == 0 else st[1] / st[0]
+    return st
+
+
+def hash_aggregate_exec(t: Table, group_by: Sequence[str],
+                        aggs: Sequence[Tuple[str, str, str | None]]) -> Table:
+    """aggs = [(out_name, kind, input_col or None for COUNT(*))].  Groups come out in
+    first-appearance order; an ungrouped aggregate over empty input yields one row."""
+    names = list(t)
+    groups: "OrderedDict[tuple, list]" = OrderedDict()
+    if not group_by:
+        groups[()] = [_agg_init(k) for _, k, _ in aggs]
+    for r in rows(t):
+        d = dict(zip(names, r))
+        key = tuple(d[g] for g in group_by)
+        st = groups.get(key)
+        if st is None:
+            st = groups[key] = [_agg_init(k) for _, k, _ in aggs]
+        for i, (_, kind, col) in enumerate(aggs):
+            st[i] = _agg_update(kind, st[i], 1 if col is None else d[col])
+    out: Table = {g: [] for g in group_by}
+    for name, _, _ in aggs:
+        out[name] = []
+    for key, st in groups.items():
+        for g, v in zip(group_by, key):
+            out[g].append(v)
+        for (name, kind, _), s in zip(aggs, st):
+            out[name].append(_agg_final(kind, s))
+    return out
+
+
+# -- HashJoinExec(Inner, Partitioned): build LEFT, probe RIGHT in row order, left cols ++ right cols --
+def hash_join_inner(left: Table, right: Table, on: Sequence[Tuple[str, str]]) -> Table:
+    ln, rn = list(left), list(right)
+    build: Dict[tuple, list] = {}
+    lrows = rows(left)
+    for i, r in enumerate(lrows):
+        d = dict(zip(ln, r))
+        key = tuple(d[l] for l, _ in on)
+        if any(k is None for k in key):
+            continue
+        build.setdefault(key, []).append(i)
+    out: Table = {k: [] for k in ln + rn}
+    for r in rows(right):
+        d = dict(zip(rn, r))
+        key = tuple(d[rc] for _, rc in on)
+        for i in build.get(key, ()):
+            for k, v in zip(ln, lrows[i]):
+                out[k].append(v)
+            for k, v in zip(rn, r):
+                out[k].append(v)
+    return out
+
+
+# -- SortExec / GlobalLimitExec ------------------------------------------------------------------
+def sort_exec(t: Table, by: Sequence[Tuple[str, bool]]) -> Table:
+    idx = list(range(num_rows(t)))
+    for col, desc in reversed(list(by)):
+        idx.sort(key=lambda i: t[col][i], reverse=desc)
+    return {k: [v[i] for i in idx] for k, v in t.items()}
+
+
+def limit_exec(t: Table, n: int) -> Table:
+    return {k: v[:n] for k, v in t.items()}
+
+
+# -- CoalesceBatchesExec(target): buffer until >= target rows, then concat (transmute.rs:38-71) ------
+def coalesce_batches(batches: Sequence[Table], target: int) -> List[Table]:
+    out, buf, n = [], [], 0
+    for b in batches:
+        if num_rows(b) == 0:
+            continue
+        buf.append(b)
+        n += num_rows(b)
+        if n >= target:
+            out.append(concat(buf))
+            buf, n = [], 0
+    if buf:
+        out.append(concat(buf))
+    return out
+
+
+# -- RepartitionExec --------------------------------------------------------------------------------
+def repartition_round_robin(partitions: Sequence[Sequence[Table]], n: int) -> List[List[Table]]:
+    """RoundRobinBatch(n): every input partition deals its batches i % n (transmute.rs:74-109)."""
+    out: List[List[Table]] = [[] for _ in range(n)]
+    for part in partitions:
+        for i, b in enumerate(part):
+            out[i % n].append(b)
+    return out
+
+
+def repartition_hash(partitions: Sequence[Sequence[Table]], key: str, n: int,
+                     hash_fn: Callable[[object], int] = hash) -> List[List[Table]]:
+    """Hash(exprs, n): row -> hash(key) % n.  The destination of a key is an
+    implementation detail (ahash-version dependent) and unobservable in query results;
+    only the row multiset is a contract (transmute.rs:381-390)."""
+    out: List[List[Table]] = [[] for _ in range(n)]
+    for part in partitions:
+        for b in part:
+            dest = [hash_fn(v) % n for v in b[key]]
+            for p in range(n):
+                sel = [i for i, d in enumerate(dest) if d == p]
+                if sel:
+                    out[p].append({k: [v[i] for i in sel] for k, v in b.items()})
+    return out
+
+
+# -- the five NEXMark plans on top of the generic operators ------------------------------------------
+def nexmark_q1(bid: Table) -> Table:
+    return projection_exec(bid, [("auction", lambda r: r["auction"]), ("bidder", lambda r: r["bidder"]),
+                                 ("price", lambda r: 0.908 * float(r["price"])),
+                                 ("b_date_time", lambda r: r["b_date_time"])])
+
+
+def nexmark_q2(bid: Table) -> Table:
+    def trunc_mod(a, m):  # Rust / arrow `%` on i64: truncated remainder
+        q = abs(a) // abs(m)
+        q = q if (a >= 0) == (m >= 0) else -q
+        return a - q * m
+    f = filter_exec({"auction": bid["auction"], "price": bid["price"]}, lambda r: trunc_mod(r["auction"], 123) == 0)
+    return projection_exec(f, [("auction", lambda r: r["auction"]), ("price", lambda r: r["price"])])
+
+
+def nexmark_q3(auction: Table, person: Table) -> Table:
+    a = filter_exec({k: auction[k] for k in ("a_id", "seller", "category")}, lambda r: r["category"] == 10)
+    p = filter_exec({k: person[k] for k in ("p_id", "name", "city", "state")},
+                    lambda r: r["state"] == "or" or r["state"] == "id" or r["state"] == "ca")
+    j = hash_join_inner(a, p, [("seller", "p_id")])
+    return {k: j[k] for k in ("name", "city", "state", "a_id")}
+
+
+def nexmark_q5(bid: Table) -> Table:
+    counts = hash_aggregate_exec({"auction": bid["auction"]}, ["auction"], [("num", "count", None)])
+    maxn = hash_aggregate_exec({"num": counts["num"]}, [], [("maxn", "max", "num")])
+    j = hash_join_inner(counts, maxn, [("num", "maxn")])
+    return {"auction": j["auction"], "num": j["num"]}
+
+
+def nexmark_q8(person: Table, auction: Table) -> Table:
+    p = hash_aggregate_exec({k: person[k] for k in ("p_id", "name")}, ["p_id", "name"], [])
+    a = hash_aggregate_exec({"seller": auction["seller"]}, ["seller"], [])
+    j = hash_join_inner(p, a, [("p_id", "seller")])
+    return {"p_id": j["p_id"], "name": j["name"]}

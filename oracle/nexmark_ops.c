@@ -1,0 +1,226 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under flock_amd/ may include,
+ * link or call this file.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it (as the checker, never as the thing measured).
+ *
+ * Scalar CPU restatement of the DataFusion operators Flock runs for NEXMark
+ * q1/q2/q3/q5/q8, one call = one window (= one `actor::collect`,
+ * flock-function/src/aws/actor.rs:54-79).  The arithmetic itself lives in the
+ * un-vendored git dependency `datafusion` (flock-lab/arrow-datafusion, branch
+ * `flock`, unpinned; flock/Cargo.toml:21) which is ABSENT from /root/reference,
+ * so each function restates upstream DataFusion ~6.x semantics and anchors on
+ * the reference's plans / call sites:
+ *   q1  benchmarks/src/nexmark/query/q1.sql, q1_plan.fmt:1; planner.rs:90
+ *   q2  q2.sql, q2_plan.fmt:1-3; flock/src/distributed_plan/planner.rs:120-124
+ *   q3  q3.sql, q3_plan.fmt:1-6; planner.rs:152-171; playground/.../nexmark/q3.dag
+ *   q5  q5.sql, q5_plan.fmt:1-13; playground/.../nexmark/q5.dag
+ *   q8  q8.sql, q8_plan.fmt:1-10; playground/.../nexmark/q8.dag
+ * PARITY PINNING: the reference's NEXMark tests only print (queries/q1.rs:57-60,
+ * q2.rs:58-61, q3.rs:83-86, q5.rs:107-110, q8.rs:98-101) -> NEXMark outputs are
+ * "parity unpinned" by the reference.  This file is pinned transitively:
+ * tests/test_oracle_goldens.py checks the generic Python operators in
+ * oracle/generic_ops.py against every operator golden the reference holds
+ * (context.rs:493-503, 579-589; launcher/local.rs:223-231; transmute.rs:298-393)
+ * and tests/test_oracle_cross.py checks this C file == generic_ops == pyarrow
+ * on seeded NEXMark windows.
+ *
+ * ASSUMPTIONS restated from upstream DataFusion, not readable here:
+ *   A1 FilterExec keeps input row order; predicate NULL -> dropped (no NULLs in NEXMark).
+ *   A2 `Int32 % Int64 literal` is evaluated as CAST(col AS Int64) % lit, truncated remainder.
+ *   A3 `0.908 * price` = Float64 literal * CAST(Int32 AS Float64): one IEEE-754 multiply.
+ *   A4 Inner HashJoin builds LEFT, probes RIGHT, emits left cols ++ right cols, every pair.
+ *   A5 COUNT(*) -> UInt64; MAX keeps type; GROUP BY without aggregates = DISTINCT.
+ *   A6 q5 keeps ties (inner join on num = maxn); empty window -> MAX is NULL -> no rows.
+ *   A7 Utf8 equality is bytewise and case-sensitive.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- q1: ProjectionExec [auction, bidder, 0.908 * CAST(price AS Float64), b_date_time] ------------- */
+void oracle_q1_project(const int32_t *price, uint64_t n, double *out_price) {
+    const volatile double k = 0.908; /* volatile: forbid constant-folded FMA contraction */
+    for (uint64_t i = 0; i < n; ++i) out_price[i] = k * (double)price[i];
+}
+
+/* ---- q2: FilterExec CAST(auction AS Int64) % 123 = 0 -> [auction, price], input order kept ---------- */
+uint64_t oracle_q2_filter(const int32_t *auction, const int32_t *price, uint64_t n, int64_t modulus,
+                          int32_t *out_auction, int32_t *out_price) {
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if ((int64_t)auction[i] % modulus == 0) {
+            if (out_auction) { out_auction[m] = auction[i]; out_price[m] = price[i]; }
+            ++m;
+        }
+    }
+    return m;
+}
+
+/* ---- tiny open-addressing multimap on int32 keys ----------------------------------------------------- */
+typedef struct {
+    uint64_t cap, mask;
+    int32_t *key;
+    int64_t *head; /* first row (insertion order chain) or -1 */
+    int64_t *tail;
+    uint8_t *used;
+} i32map;
+
+static uint64_t hash32(int32_t k) {
+    uint64_t x = (uint32_t)k; x *= 0x9E3779B97F4A7C15ull; return x >> 20;
+}
+static int map_init(i32map *m, uint64_t n) {
+    uint64_t cap = 16; while (cap < n * 2 + 1) cap <<= 1;
+    m->cap = cap; m->mask = cap - 1;
+    m->key = (int32_t *)malloc(cap * sizeof(int32_t));
+    m->head = (int64_t *)malloc(cap * sizeof(int64_t));
+    m->tail = (int64_t *)malloc(cap * sizeof(int64_t));
+    m->used = (uint8_t *)calloc(cap, 1);
+    return m->key && m->head && m->tail && m->used ? 0 : -1;
+}
+static void map_free(i32map *m) { free(m->key); free(m->head); free(m->tail); free(m->used); }
+static uint64_t map_slot(const i32map *m, int32_t k, int *found) {
+    uint64_t s = hash32(k) & m->mask;
+    while (m->used[s]) { if (m->key[s] == k) { *found = 1; return s; } s = (s + 1) & m->mask; }
+    *found = 0; return s;
+}
+
+/* ---- q3: filter(auction.category = 10) JOIN filter(person.state in {or,id,ca}) ON seller = p_id ------
+ * Build LEFT = filtered auctions keyed by seller, probe RIGHT = filtered persons in row order (A4).
+ * Emits (auction_row, person_row) pairs; out arrays may be NULL to count only. */
+uint64_t oracle_q3_join(const int32_t *seller, const int32_t *category, uint64_t n_auction, int64_t category_lit,
+                        const int32_t *p_id, const int32_t *state_off, const char *state_bytes, uint64_t n_person,
+                        const char *const *state_lits, int n_lits,
+                        int64_t *out_auction_row, int64_t *out_person_row) {
+    i32map m; if (map_init(&m, n_auction)) return (uint64_t)-1;
+    int64_t *next = (int64_t *)malloc((n_auction ? n_auction : 1) * sizeof(int64_t));
+    for (uint64_t i = 0; i < n_auction; ++i) {
+        if ((int64_t)category[i] != category_lit) continue;
+        int f; uint64_t s = map_slot(&m, seller[i], &f);
+        next[i] = -1;
+        if (!f) { m.used[s] = 1; m.key[s] = seller[i]; m.head[s] = m.tail[s] = (int64_t)i; }
+        else { next[m.tail[s]] = (int64_t)i; m.tail[s] = (int64_t)i; }
+    }
+    uint64_t out = 0;
+    for (uint64_t j = 0; j < n_person; ++j) {
+        int32_t b = state_off[j], e = state_off[j + 1];
+        int pass = 0;
+        for (int l = 0; l < n_lits && !pass; ++l) {
+            size_t ll = strlen(state_lits[l]);
+            pass = ((size_t)(e - b) == ll) && memcmp(state_bytes + b, state_lits[l], ll) == 0;
+        }
+        if (!pass) continue;
+        int f; uint64_t s = map_slot(&m, p_id[j], &f);
+        if (!f) continue;
+        for (int64_t r = m.head[s]; r >= 0; r = next[r]) {
+            if (out_auction_row) { out_auction_row[out] = r; out_person_row[out] = (int64_t)j; }
+            ++out;
+        }
+    }
+    free(next); map_free(&m);
+    return out;
+}
+
+/* ---- q5: COUNT(*) GROUP BY auction; MAX(num); rows with num = maxn (ties kept, A6) -------------------
+ * Output order: first appearance of the key in the window.  Returns rows written (<= cap) or needed. */
+uint64_t oracle_q5_hot_items(const int32_t *auction, uint64_t n, int32_t *out_auction, uint64_t *out_num, uint64_t cap) {
+    if (n == 0) return 0;
+    i32map m; if (map_init(&m, n < (1u << 22) ? n : (n / 4 + (1u << 22)))) return (uint64_t)-1;
+    /* head[] doubles as the UInt64 counter, tail[] as first-appearance rank */
+    uint64_t distinct = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        int f; uint64_t s = map_slot(&m, auction[i], &f);
+        if (!f) {
+            if (distinct * 2 + 2 > m.cap) { /* grow */
+                i32map g; uint64_t want = m.cap; if (map_init(&g, want)) { map_free(&m); return (uint64_t)-1; }
+                for (uint64_t t = 0; t < m.cap; ++t) if (m.used[t]) {
+                    int ff; uint64_t u = map_slot(&g, m.key[t], &ff);
+                    g.used[u] = 1; g.key[u] = m.key[t]; g.head[u] = m.head[t]; g.tail[u] = m.tail[t];
+                }
+                map_free(&m); m = g; s = map_slot(&m, auction[i], &f);
+            }
+            m.used[s] = 1; m.key[s] = auction[i]; m.head[s] = 0; m.tail[s] = (int64_t)distinct++;
+        }
+        m.head[s] += 1;
+    }
+    uint64_t maxn = 0;
+    for (uint64_t t = 0; t < m.cap; ++t) if (m.used[t] && (uint64_t)m.head[t] > maxn) maxn = (uint64_t)m.head[t];
+    /* collect winners ordered by first appearance */
+    uint64_t nw = 0;
+    for (uint64_t t = 0; t < m.cap; ++t) if (m.used[t] && (uint64_t)m.head[t] == maxn) ++nw;
+    if (out_auction && nw <= cap) {
+        int64_t *rank = (int64_t *)malloc(nw * sizeof(int64_t));
+        uint64_t *slot = (uint64_t *)malloc(nw * sizeof(uint64_t));
+        uint64_t w = 0;
+        for (uint64_t t = 0; t < m.cap; ++t) if (m.used[t] && (uint64_t)m.head[t] == maxn) { rank[w] = m.tail[t]; slot[w++] = t; }
+        for (uint64_t a = 1; a < nw; ++a) { /* insertion sort: winners are few */
+            int64_t r = rank[a]; uint64_t sl = slot[a]; uint64_t b = a;
+            while (b > 0 && rank[b - 1] > r) { rank[b] = rank[b - 1]; slot[b] = slot[b - 1]; --b; }
+            rank[b] = r; slot[b] = sl;
+        }
+        for (uint64_t a = 0; a < nw; ++a) { out_auction[a] = m.key[slot[a]]; out_num[a] = maxn; }
+        free(rank); free(slot);
+    }
+    map_free(&m);
+    return nw;
+}
+
+/* Full group-by result (auction, COUNT) in first-appearance order: the `AuctionBids` sub-query. */
+uint64_t oracle_count_by_key(const int32_t *key, uint64_t n, int32_t *out_key, uint64_t *out_count, uint64_t cap) {
+    i32map m; if (map_init(&m, n)) return (uint64_t)-1;
+    uint64_t distinct = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        int f; uint64_t s = map_slot(&m, key[i], &f);
+        if (!f) { m.used[s] = 1; m.key[s] = key[i]; m.head[s] = 0; m.tail[s] = (int64_t)distinct++; }
+        m.head[s] += 1;
+    }
+    if (out_key && distinct <= cap)
+        for (uint64_t t = 0; t < m.cap; ++t) if (m.used[t]) { out_key[m.tail[t]] = m.key[t]; out_count[m.tail[t]] = (uint64_t)m.head[t]; }
+    map_free(&m);
+    return distinct;
+}
+
+/* ---- q8: DISTINCT (p_id, name) JOIN DISTINCT seller ON p_id = seller -> [p_id, name] ------------------
+ * Emits the first-occurrence person row of every distinct (p_id, name) whose p_id is a seller, in row order. */
+uint64_t oracle_q8_join(const int32_t *p_id, const int32_t *name_off, const char *name_bytes, uint64_t n_person,
+                        const int32_t *seller, uint64_t n_auction, int64_t *out_person_row) {
+    i32map sellers; if (map_init(&sellers, n_auction)) return (uint64_t)-1;
+    for (uint64_t i = 0; i < n_auction; ++i) {
+        int f; uint64_t s = map_slot(&sellers, seller[i], &f);
+        if (!f) { sellers.used[s] = 1; sellers.key[s] = seller[i]; sellers.head[s] = sellers.tail[s] = (int64_t)i; }
+    }
+    /* distinct (p_id, name): chain of first-occurrence rows per p_id */
+    i32map pm; if (map_init(&pm, n_person)) { map_free(&sellers); return (uint64_t)-1; }
+    int64_t *next = (int64_t *)malloc((n_person ? n_person : 1) * sizeof(int64_t));
+    uint64_t out = 0;
+    for (uint64_t j = 0; j < n_person; ++j) {
+        int f; uint64_t s = map_slot(&pm, p_id[j], &f);
+        int dup = 0;
+        next[j] = -1;
+        if (!f) { pm.used[s] = 1; pm.key[s] = p_id[j]; pm.head[s] = pm.tail[s] = (int64_t)j; }
+        else {
+            int32_t lj = name_off[j + 1] - name_off[j];
+            for (int64_t r = pm.head[s]; r >= 0 && !dup; r = next[r]) {
+                int32_t lr = name_off[r + 1] - name_off[r];
+                dup = lr == lj && memcmp(name_bytes + name_off[r], name_bytes + name_off[j], (size_t)lj) == 0;
+            }
+            if (!dup) { next[pm.tail[s]] = (int64_t)j; pm.tail[s] = (int64_t)j; }
+        }
+        if (dup) continue;
+        int fs; map_slot(&sellers, p_id[j], &fs);
+        if (fs) { if (out_person_row) out_person_row[out] = (int64_t)j; ++out; }
+    }
+    free(next); map_free(&pm); map_free(&sellers);
+    return out;
+}
+
+/* Variable-width take: gather Utf8 rows into a fresh (offsets, bytes) pair; returns bytes written. */
+uint64_t oracle_take_utf8(const int32_t *off, const char *bytes, const int64_t *rows, uint64_t n,
+                          int32_t *out_off, char *out_bytes) {
+    int32_t o = 0; out_off[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        int32_t b = off[rows[i]], e = off[rows[i] + 1];
+        if (out_bytes) memcpy(out_bytes + o, bytes + b, (size_t)(e - b));
+        o += e - b; out_off[i + 1] = o;
+    }
+    return (uint64_t)o;
+}
