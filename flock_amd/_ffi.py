@@ -1,0 +1,131 @@
+"""ctypes binding of libflockgpu.so (include/flockgpu.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a symbol is absent the
+import fails loudly.  (The CPU oracle under ``oracle/`` is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflockgpu.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_PLAN = range(7)
+H2D, D2H, D2D = 1, 2, 3
+ABI_VERSION = 1
+
+
+class FlockGpuError(RuntimeError):
+    """Mirror of FlockError::Execution (flock/src/error.rs:66-68) for the GPU engine."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"flockgpu status {code}: {message}")
+        self.code = code
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class BidCols(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("bidder", C.c_void_p), ("price", C.c_void_p),
+                ("b_date_time", C.c_void_p), ("rows", C.c_int64)]
+
+
+class AuctionCols(C.Structure):
+    _fields_ = [("a_id", C.c_void_p), ("seller", C.c_void_p), ("category", C.c_void_p), ("rows", C.c_int64)]
+
+
+class Utf8(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("data", C.c_void_p)]
+
+
+class PersonCols(C.Structure):
+    _fields_ = [("p_id", C.c_void_p), ("name", Utf8), ("city", Utf8), ("state", Utf8), ("rows", C.c_int64)]
+
+
+class Windows(C.Structure):
+    _fields_ = [("pane_row_offsets", C.POINTER(C.c_int64)), ("n_panes", C.c_int32),
+                ("win_pane_lo", C.POINTER(C.c_int32)), ("win_pane_hi", C.POINTER(C.c_int32)),
+                ("n_windows", C.c_int32)]
+
+
+class Q2Result(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("price", C.c_void_p), ("win_out_offsets", C.POINTER(C.c_int64)),
+                ("rows", C.c_int64)]
+
+
+class Q3Result(C.Structure):
+    _fields_ = [("name", Utf8), ("city", Utf8), ("state", Utf8), ("a_id", C.c_void_p),
+                ("auction_row", C.c_void_p), ("person_row", C.c_void_p),
+                ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64),
+                ("name_bytes", C.c_int64), ("city_bytes", C.c_int64), ("state_bytes", C.c_int64)]
+
+
+class Q5Result(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("num", C.c_void_p), ("win_out_offsets", C.POINTER(C.c_int64)),
+                ("win_max", C.POINTER(C.c_uint64)), ("win_groups", C.POINTER(C.c_uint64)), ("rows", C.c_int64)]
+
+
+class Q8Result(C.Structure):
+    _fields_ = [("p_id", C.c_void_p), ("name", Utf8), ("person_row", C.c_void_p),
+                ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("name_bytes", C.c_int64)]
+
+
+class NexmarkStream(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_event_id", C.c_uint64), ("eps", C.c_uint64), ("base_time", C.c_uint64)]
+
+
+# every symbol include/flockgpu.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+SYMBOLS = {
+    "flockgpu_abi_version": (_i, []),
+    "flockgpu_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "flockgpu_ctx_destroy": (None, [_vp]),
+    "flockgpu_last_error": (C.c_char_p, [_vp]),
+    "flockgpu_ctx_synchronize": (_i, [_vp]),
+    "flockgpu_malloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "flockgpu_free": (_i, [_vp, _vp]),
+    "flockgpu_memcpy": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
+    "flockgpu_profile_enable": (_i, [_vp, _i]),
+    "flockgpu_profile_reset": (_i, [_vp]),
+    "flockgpu_profile_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
+    "flockgpu_q1_project": (_i, [_vp, C.POINTER(BidCols), C.c_double, _vp]),
+    "flockgpu_q2_filter": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), _i64, C.POINTER(Q2Result)]),
+    "flockgpu_q3_join": (_i, [_vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),
+                              C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),
+    "flockgpu_q5_hot_items": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
+    "flockgpu_q8_join": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
+                              C.POINTER(Windows), C.POINTER(Q8Result)]),
+    "flockgpu_nexmark_counts": (_i, [C.POINTER(NexmarkStream), _u64, _u64, C.POINTER(_u64), C.POINTER(_u64),
+                                     C.POINTER(_u64)]),
+    "flockgpu_nexmark_gen_bids": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp]),
+    "flockgpu_nexmark_gen_auctions": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp]),
+    "flockgpu_nexmark_gen_persons": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libflockgpu.so and binds every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m flock_amd.build` (hipcc, gfx950). "
+            "flock_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise ImportError(f"libflockgpu.so does not export {name}")
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.flockgpu_abi_version() != ABI_VERSION:
+        raise ImportError("libflockgpu.so ABI version mismatch: rebuild the library")
+    _lib = lib
+    return lib

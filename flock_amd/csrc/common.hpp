@@ -1,0 +1,212 @@
+// Internal to libflockgpu: context, device arena, launch + profiling helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/flockgpu.h"
+
+namespace flockgpu {
+
+struct DeviceBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct KernelStat {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingEvent {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace flockgpu
+
+struct flockgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cus = 256;
+    std::string last_error;
+    // grow-only named device buffers (hash-table arenas, outputs, scan state) reused across calls
+    std::map<std::string, flockgpu::DeviceBuf> arena;
+    // pinned host staging for small D2H / H2D metadata
+    std::map<std::string, flockgpu::DeviceBuf> pinned;
+    // host-side result vectors handed out through the result structs
+    std::map<std::string, std::vector<int64_t>> host_i64;
+    std::map<std::string, std::vector<uint64_t>> host_u64;
+    // adaptive hash-table sizing hints (rows per distinct key observed last call)
+    double q5_rows_per_group = 8.0;
+    double q8_rows_per_seller = 4.0;
+    // profiling
+    bool profiling = false;
+    std::vector<flockgpu::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, flockgpu::KernelStat> stats;
+};
+
+namespace flockgpu {
+
+inline int fail(flockgpu_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return code;
+}
+
+#define FG_HIP(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return ::flockgpu::fail((ctx), FLOCKGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr,               \
+                                    hipGetErrorString(e_), __FILE__, __LINE__);                             \
+    } while (0)
+
+#define FG_TRY(expr)                      \
+    do {                                  \
+        int rc_ = (expr);                 \
+        if (rc_ != FLOCKGPU_OK) return rc_; \
+    } while (0)
+
+// Grow-only device buffer.  Contents are NOT preserved across a grow.
+inline int arena_get(flockgpu_ctx *ctx, const char *name, size_t bytes, void **out) {
+    DeviceBuf &b = ctx->arena[name];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.ptr) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_HIP, "sync before arena grow: %s", hipGetErrorString(e));
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8;  // slack so that slowly growing windows do not reallocate every call
+        want = (want + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&b.ptr, want);
+        if (e != hipSuccess) {
+            b.ptr = nullptr;
+            return fail(ctx, FLOCKGPU_ERR_OOM, "arena '%s': hipMalloc(%zu) failed: %s", name, want, hipGetErrorString(e));
+        }
+        b.cap = want;
+    }
+    *out = b.ptr;
+    return FLOCKGPU_OK;
+}
+
+template <typename T>
+inline int arena_get_t(flockgpu_ctx *ctx, const char *name, size_t count, T **out) {
+    void *p = nullptr;
+    int rc = arena_get(ctx, name, count * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+
+inline int pinned_get(flockgpu_ctx *ctx, const char *name, size_t bytes, void **out) {
+    DeviceBuf &b = ctx->pinned[name];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        if (b.ptr) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipHostFree(b.ptr);
+        }
+        size_t want = (bytes * 2 + 255) & ~size_t(255);
+        hipError_t e = hipHostMalloc(&b.ptr, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            b.ptr = nullptr;
+            b.cap = 0;
+            return fail(ctx, FLOCKGPU_ERR_OOM, "pinned '%s': hipHostMalloc(%zu) failed: %s", name, want, hipGetErrorString(e));
+        }
+        b.cap = want;
+    }
+    *out = b.ptr;
+    return FLOCKGPU_OK;
+}
+
+template <typename T>
+inline int pinned_get_t(flockgpu_ctx *ctx, const char *name, size_t count, T **out) {
+    void *p = nullptr;
+    int rc = pinned_get(ctx, name, count * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+
+// Bracket one kernel launch with events when profiling is on.
+struct LaunchScope {
+    flockgpu_ctx *ctx;
+    const char *name;
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchScope(flockgpu_ctx *c, const char *n) : ctx(c), name(n) {
+        if (!ctx->profiling) return;
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->event_pool.empty()) {
+                e = ctx->event_pool.back();
+                ctx->event_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        start = take();
+        stop = take();
+        (void)hipEventRecord(start, ctx->stream);
+    }
+    ~LaunchScope() {
+        if (!ctx->profiling) return;
+        (void)hipEventRecord(stop, ctx->stream);
+        ctx->pending.push_back({name, start, stop});
+    }
+};
+
+inline int check_launch(flockgpu_ctx *ctx, const char *name) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e));
+    return FLOCKGPU_OK;
+}
+
+inline void profile_drain(flockgpu_ctx *ctx) {
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            KernelStat &s = ctx->stats[p.name];
+            s.launches += 1;
+            s.total_ms += ms;
+        }
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->pending.clear();
+}
+
+inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Validates a window schedule against a relation of `rows` rows.
+inline int check_windows(flockgpu_ctx *ctx, const flockgpu_windows *w, int64_t rows, const char *what) {
+    if (!w || w->n_panes < 0 || w->n_windows < 0 || !w->pane_row_offsets)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: null / negative window schedule", what);
+    if (w->pane_row_offsets[0] < 0 || w->pane_row_offsets[w->n_panes] > rows)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: pane offsets [%lld, %lld] outside relation of %lld rows", what,
+                    (long long)w->pane_row_offsets[0], (long long)w->pane_row_offsets[w->n_panes], (long long)rows);
+    for (int p = 0; p < w->n_panes; ++p)
+        if (w->pane_row_offsets[p + 1] < w->pane_row_offsets[p])
+            return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: pane offsets decrease at pane %d", what, p);
+    for (int i = 0; i < w->n_windows; ++i)
+        if (w->win_pane_lo[i] < 0 || w->win_pane_hi[i] < w->win_pane_lo[i] || w->win_pane_hi[i] > w->n_panes)
+            return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: window %d pane range [%d, %d) invalid", what, i,
+                        w->win_pane_lo[i], w->win_pane_hi[i]);
+    return FLOCKGPU_OK;
+}
+
+}  // namespace flockgpu

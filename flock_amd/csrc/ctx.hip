@@ -1,0 +1,126 @@
+// libflockgpu: context, error reporting, per-kernel HIP-event profiling.
+#include "common.hpp"
+
+using namespace flockgpu;
+
+extern "C" {
+
+int flockgpu_abi_version(void) { return FLOCKGPU_ABI_VERSION; }
+
+int flockgpu_ctx_create(int device, void *hip_stream, flockgpu_ctx **out) {
+    if (!out) return FLOCKGPU_ERR_INVALID;
+    *out = nullptr;
+    flockgpu_ctx *ctx = new (std::nothrow) flockgpu_ctx();
+    if (!ctx) return FLOCKGPU_ERR_OOM;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        if (hip_stream) {
+            ctx->stream = static_cast<hipStream_t>(hip_stream);
+        } else {
+            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            ctx->owns_stream = (e == hipSuccess);
+        }
+    }
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    }
+    if (e != hipSuccess) {
+        // keep the ctx alive so the caller can read the message, but report the failure
+        ctx->last_error = std::string("flockgpu_ctx_create: ") + hipGetErrorString(e);
+        *out = ctx;
+        return FLOCKGPU_ERR_HIP;
+    }
+    *out = ctx;
+    return FLOCKGPU_OK;
+}
+
+void flockgpu_ctx_destroy(flockgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    profile_drain(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &kv : ctx->arena)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto &kv : ctx->pinned)
+        if (kv.second.ptr) (void)hipHostFree(kv.second.ptr);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *flockgpu_last_error(const flockgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int flockgpu_ctx_synchronize(flockgpu_ctx *ctx) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_malloc(flockgpu_ctx *ctx, size_t bytes, void **out_device_ptr) {
+    if (!ctx || !out_device_ptr) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    *out_device_ptr = nullptr;
+    hipError_t e = hipMalloc(out_device_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_OOM, "flockgpu_malloc(%zu): %s", bytes, hipGetErrorString(e));
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_free(flockgpu_ctx *ctx, void *device_ptr) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!device_ptr) return FLOCKGPU_OK;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_HIP(ctx, hipFree(device_ptr));
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_memcpy(flockgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int kind) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (bytes == 0) return FLOCKGPU_OK;
+    if (!dst || !src) return fail(ctx, FLOCKGPU_ERR_INVALID, "flockgpu_memcpy: null pointer");
+    hipMemcpyKind k = kind == FLOCKGPU_H2D ? hipMemcpyHostToDevice
+                      : kind == FLOCKGPU_D2H ? hipMemcpyDeviceToHost
+                      : kind == FLOCKGPU_D2D ? hipMemcpyDeviceToDevice : hipMemcpyDefault;
+    if (k == hipMemcpyDefault) return fail(ctx, FLOCKGPU_ERR_INVALID, "flockgpu_memcpy: bad kind %d", kind);
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    FG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_profile_enable(flockgpu_ctx *ctx, int on) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    ctx->profiling = on != 0;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_profile_reset(flockgpu_ctx *ctx) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    ctx->stats.clear();
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_profile_read(flockgpu_ctx *ctx, flockgpu_kernel_stat *out, int cap, int *n) {
+    if (!ctx || !n) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    int i = 0;
+    for (auto &kv : ctx->stats) {
+        if (out && i < cap) {
+            std::memset(out[i].name, 0, sizeof out[i].name);
+            std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+            out[i].launches = kv.second.launches;
+            out[i].total_ms = kv.second.total_ms;
+        }
+        ++i;
+    }
+    *n = i;
+    return FLOCKGPU_OK;
+}
+
+}  // extern "C"

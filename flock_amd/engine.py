@@ -1,0 +1,289 @@
+"""Host-side driver of libflockgpu: the GPU twin of the reference's per-window operator execution.
+
+One :class:`GpuContext` = one HIP stream + device arena (the unit `actor::collect`
+would own, flock-function/src/aws/actor.rs:54-79).  Column data lives in HBM as torch
+tensors (torch is only the allocator / stream provider here); every operator call goes
+through the C ABI of include/flockgpu.h.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FlockGpuError
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ------------------------------------------------------------------ device column containers
+@dataclass
+class DeviceUtf8:
+    """Arrow Utf8 column in HBM: int32 offsets (rows + 1) + uint8 bytes."""
+    offsets: "object"
+    data: "object"
+
+    def ffi(self) -> _ffi.Utf8:
+        return _ffi.Utf8(self.offsets.data_ptr(), self.data.data_ptr())
+
+
+@dataclass
+class Bids:
+    auction: "object" = None
+    bidder: "object" = None
+    price: "object" = None
+    b_date_time: "object" = None
+    rows: int = 0
+
+    def ffi(self) -> _ffi.BidCols:
+        p = lambda t: None if t is None else t.data_ptr()
+        return _ffi.BidCols(p(self.auction), p(self.bidder), p(self.price), p(self.b_date_time), self.rows)
+
+
+@dataclass
+class Auctions:
+    a_id: "object" = None
+    seller: "object" = None
+    category: "object" = None
+    rows: int = 0
+
+    def ffi(self) -> _ffi.AuctionCols:
+        p = lambda t: None if t is None else t.data_ptr()
+        return _ffi.AuctionCols(p(self.a_id), p(self.seller), p(self.category), self.rows)
+
+
+@dataclass
+class Persons:
+    p_id: "object" = None
+    name: Optional[DeviceUtf8] = None
+    city: Optional[DeviceUtf8] = None
+    state: Optional[DeviceUtf8] = None
+    rows: int = 0
+
+    def ffi(self) -> _ffi.PersonCols:
+        z = _ffi.Utf8(None, None)
+        u = lambda c: z if c is None else c.ffi()
+        return _ffi.PersonCols(None if self.p_id is None else self.p_id.data_ptr(), u(self.name), u(self.city),
+                               u(self.state), self.rows)
+
+
+@dataclass
+class WindowSchedule:
+    """Row panes + windows over one relation (include/flockgpu.h `flockgpu_windows`)."""
+    pane_row_offsets: np.ndarray  # int64, n_panes + 1
+    win_pane_lo: np.ndarray       # int32, n_windows
+    win_pane_hi: np.ndarray       # int32, n_windows
+
+    def __post_init__(self):
+        self.pane_row_offsets = np.ascontiguousarray(self.pane_row_offsets, np.int64)
+        self.win_pane_lo = np.ascontiguousarray(self.win_pane_lo, np.int32)
+        self.win_pane_hi = np.ascontiguousarray(self.win_pane_hi, np.int32)
+
+    @property
+    def n_windows(self) -> int:
+        return len(self.win_pane_lo)
+
+    def ffi(self) -> _ffi.Windows:
+        return _ffi.Windows(self.pane_row_offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(self.pane_row_offsets) - 1,
+                            self.win_pane_lo.ctypes.data_as(C.POINTER(C.c_int32)),
+                            self.win_pane_hi.ctypes.data_as(C.POINTER(C.c_int32)), len(self.win_pane_lo))
+
+    def window_rows(self, w: int):
+        return int(self.pane_row_offsets[self.win_pane_lo[w]]), int(self.pane_row_offsets[self.win_pane_hi[w]])
+
+    @staticmethod
+    def single(rows: int) -> "WindowSchedule":
+        """One window over the whole relation = one `collect` call of the reference."""
+        return WindowSchedule(np.array([0, rows]), np.array([0]), np.array([1]))
+
+
+# ------------------------------------------------------------------ results (host copies on demand)
+@dataclass
+class Q2Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q2Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        return (self.ctx.d2h(self.raw.auction, self.rows, np.int32), self.ctx.d2h(self.raw.price, self.rows, np.int32),
+                self.offsets())
+
+
+@dataclass
+class Q3Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q3Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        n = self.rows
+        u = lambda c, nb: (self.ctx.d2h(c.offsets, n + 1, np.int32), self.ctx.d2h(c.data, int(nb), np.uint8))
+        return {
+            "name": u(self.raw.name, self.raw.name_bytes), "city": u(self.raw.city, self.raw.city_bytes),
+            "state": u(self.raw.state, self.raw.state_bytes), "a_id": self.ctx.d2h(self.raw.a_id, n, np.int32),
+            "auction_row": self.ctx.d2h(self.raw.auction_row, n, np.int32),
+            "person_row": self.ctx.d2h(self.raw.person_row, n, np.int32), "offsets": self.offsets(),
+        }
+
+
+@dataclass
+class Q5Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q5Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def win_max(self):
+        return np.ctypeslib.as_array(self.raw.win_max, (max(self.n_windows, 1),))[: self.n_windows].copy()
+
+    def win_groups(self):
+        return np.ctypeslib.as_array(self.raw.win_groups, (max(self.n_windows, 1),))[: self.n_windows].copy()
+
+    def to_host(self):
+        return (self.ctx.d2h(self.raw.auction, self.rows, np.int32), self.ctx.d2h(self.raw.num, self.rows, np.uint64),
+                self.offsets())
+
+
+@dataclass
+class Q8Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q8Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        n = self.rows
+        return {
+            "p_id": self.ctx.d2h(self.raw.p_id, n, np.int32),
+            "name": (self.ctx.d2h(self.raw.name.offsets, n + 1, np.int32),
+                     self.ctx.d2h(self.raw.name.data, int(self.raw.name_bytes), np.uint8)),
+            "person_row": self.ctx.d2h(self.raw.person_row, n, np.int32), "offsets": self.offsets(),
+        }
+
+
+# ------------------------------------------------------------------ the context
+class GpuContext:
+    """Owns a `flockgpu_ctx`.  `stream` defaults to torch's current stream on `device`."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, own_stream: bool = False):
+        self._lib = _ffi.load()
+        self.device = device
+        if stream is None and not own_stream:
+            torch = _torch()
+            if not torch.cuda.is_available():
+                raise FlockGpuError(_ffi.ERR_HIP, "no HIP device visible: flock_amd has no CPU fallback")
+            torch.cuda.set_device(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        rc = self._lib.flockgpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        self._h = h
+        if rc != _ffi.OK:
+            msg = self._lib.flockgpu_last_error(h).decode() if h else "ctx_create failed"
+            if h:
+                self._lib.flockgpu_ctx_destroy(h)
+            self._h = None
+            raise FlockGpuError(rc, msg)
+
+    # -- plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.flockgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _ffi.OK:
+            raise FlockGpuError(rc, self._lib.flockgpu_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(self._lib.flockgpu_ctx_synchronize(self._h))
+
+    def d2h(self, dev_ptr, count: int, dtype) -> np.ndarray:
+        out = np.empty(count, dtype)
+        if count:
+            self._check(self._lib.flockgpu_memcpy(self._h, out.ctypes.data_as(C.c_void_p), dev_ptr, out.nbytes, _ffi.D2H))
+        return out
+
+    def profile(self, on: bool):
+        self._check(self._lib.flockgpu_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.flockgpu_profile_reset(self._h))
+
+    def profile_read(self) -> dict:
+        n = C.c_int(0)
+        buf = (_ffi.KernelStat * 64)()
+        self._check(self._lib.flockgpu_profile_read(self._h, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
+                for i in range(min(n.value, 64))}
+
+    # -- operators
+    def q1_project(self, bids: Bids, factor: float = 0.908):
+        """q1 ProjectionExec (planner.rs:90): returns the Float64 `price` column (device tensor);
+        auction / bidder / b_date_time pass through untouched (zero-copy like the reference's Arc clones)."""
+        torch = _torch()
+        out = torch.empty(bids.rows, dtype=torch.float64, device=f"cuda:{self.device}")
+        b = bids.ffi()
+        self._check(self._lib.flockgpu_q1_project(self._h, C.byref(b), factor, out.data_ptr()))
+        return out
+
+    def q2_filter(self, bids: Bids, windows: WindowSchedule, modulus: int = 123) -> Q2Out:
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q2Result()
+        self._check(self._lib.flockgpu_q2_filter(self._h, C.byref(b), C.byref(w), modulus, C.byref(r)))
+        return Q2Out(self, r, windows.n_windows)
+
+    def q3_join(self, auctions: Auctions, auction_windows: WindowSchedule, persons: Persons,
+                person_windows: WindowSchedule, category: int = 10, states: Sequence[str] = ("or", "id", "ca")) -> Q3Out:
+        a, aw, p, pw, r = auctions.ffi(), auction_windows.ffi(), persons.ffi(), person_windows.ffi(), _ffi.Q3Result()
+        lits = (C.c_char_p * len(states))(*[s.encode() for s in states])
+        self._check(self._lib.flockgpu_q3_join(self._h, C.byref(a), C.byref(aw), C.byref(p), C.byref(pw), category, lits,
+                                               len(states), C.byref(r)))
+        return Q3Out(self, r, auction_windows.n_windows)
+
+    def q5_hot_items(self, bids: Bids, windows: WindowSchedule) -> Q5Out:
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5Result()
+        self._check(self._lib.flockgpu_q5_hot_items(self._h, C.byref(b), C.byref(w), C.byref(r)))
+        return Q5Out(self, r, windows.n_windows)
+
+    def q8_join(self, persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
+                auction_windows: WindowSchedule) -> Q8Out:
+        p, pw, a, aw, r = persons.ffi(), person_windows.ffi(), auctions.ffi(), auction_windows.ffi(), _ffi.Q8Result()
+        self._check(self._lib.flockgpu_q8_join(self._h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
+        return Q8Out(self, r, person_windows.n_windows)

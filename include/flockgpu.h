@@ -1,0 +1,199 @@
+/* flockgpu.h -- C ABI of libflockgpu, the MI355X (gfx950) execution kernel for Flock's
+ * per-batch DataFusion hot path (filter, projection, hash-join, hash-aggregate over NEXMark
+ * RecordBatches).  Plain C, plain pointers and sizes: this is exactly what a Rust
+ * `extern "C"` block in flock/src/runtime would bind (INTEGRATION.md shows the stub).
+ *
+ * Every entry point returns an int status (FLOCKGPU_OK = 0); nothing throws or aborts across
+ * the ABI; `flockgpu_last_error(ctx)` returns the message of the last failure on that ctx.
+ * (The reference stringifies DataFusion errors into FlockError::Execution and then
+ * unwraps them, flock/src/runtime/context.rs:181,189 -- i.e. an operator error kills the
+ * Lambda; here it is a status code the host can turn into FlockError::Execution.)
+ *
+ * Threading: a ctx (stream + device arena) is used by one thread at a time; different ctxs
+ * may be used concurrently from arbitrary threads (the reference runs each plan on its own
+ * tokio task, context.rs:178).  No global mutable state.
+ *
+ * Memory: all column pointers in the `*_cols` views are DEVICE pointers (HBM) laid out
+ * exactly like the corresponding Arrow buffers (values; int32 offsets + bytes for Utf8;
+ * all NEXMark fields are non-nullable, event.rs:130-149,220-245,336-352).  They are
+ * BORROWED for the duration of the call and never written (the reference asserts inputs
+ * survive execution, datasource/nexmark/queries/q5.rs:127-131).  Result buffers are owned
+ * by the ctx arena and stay valid until the next call of the same query on that ctx or
+ * flockgpu_ctx_destroy.
+ */
+#ifndef FLOCKGPU_H
+#define FLOCKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOCKGPU_ABI_VERSION 1
+
+enum {
+    FLOCKGPU_OK = 0,
+    FLOCKGPU_ERR_INVALID = 1,     /* bad argument                                            */
+    FLOCKGPU_ERR_HIP = 2,         /* a HIP runtime call failed (message has the hipError)     */
+    FLOCKGPU_ERR_OOM = 3,         /* device arena allocation failed                           */
+    FLOCKGPU_ERR_UNSUPPORTED = 4, /* plan shape / size outside what the kernels implement     */
+    FLOCKGPU_ERR_CAPACITY = 5,    /* hash table overflow after the retry budget               */
+    FLOCKGPU_ERR_PLAN = 6         /* plan JSON could not be parsed / matched                  */
+};
+
+typedef struct flockgpu_ctx flockgpu_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* `hip_stream` may be NULL (the ctx creates its own non-blocking stream) or an existing
+ * hipStream_t the caller launches on (e.g. torch's current stream). */
+int flockgpu_ctx_create(int device, void *hip_stream, flockgpu_ctx **out);
+void flockgpu_ctx_destroy(flockgpu_ctx *ctx);
+const char *flockgpu_last_error(const flockgpu_ctx *ctx);
+int flockgpu_ctx_synchronize(flockgpu_ctx *ctx);
+int flockgpu_abi_version(void);
+
+/* ---- plain memory helpers (hosts without their own HIP binding) --------------------------------- */
+enum { FLOCKGPU_H2D = 1, FLOCKGPU_D2H = 2, FLOCKGPU_D2D = 3 };
+int flockgpu_malloc(flockgpu_ctx *ctx, size_t bytes, void **out_device_ptr);
+int flockgpu_free(flockgpu_ctx *ctx, void *device_ptr);
+/* Copies on the ctx stream and waits for completion. */
+int flockgpu_memcpy(flockgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int kind);
+
+/* Per-kernel HIP-event timing (bench.py's roofline leg).  When enabled, every kernel launch of
+ * the ctx is bracketed by hipEvents on the ctx stream; totals are read back per kernel name. */
+int flockgpu_profile_enable(flockgpu_ctx *ctx, int on);
+int flockgpu_profile_reset(flockgpu_ctx *ctx);
+/* Fills up to `cap` entries; returns the number of distinct kernels seen in *n. */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} flockgpu_kernel_stat;
+int flockgpu_profile_read(flockgpu_ctx *ctx, flockgpu_kernel_stat *out, int cap, int *n);
+
+/* ---- column views (device pointers, Arrow buffer layout) -------------------------------------- */
+typedef struct { /* Bid::schema, event.rs:336-352 */
+    const int32_t *auction, *bidder, *price;
+    const int64_t *b_date_time;
+    int64_t rows;
+} flockgpu_bid_cols;
+
+typedef struct { /* Auction::schema projection used by q3/q8 (q3_plan.fmt:4, q8_plan.fmt:10) */
+    const int32_t *a_id, *seller, *category;
+    int64_t rows;
+} flockgpu_auction_cols;
+
+typedef struct { /* Arrow Utf8: offsets has rows+1 entries */
+    const int32_t *offsets;
+    const uint8_t *data;
+} flockgpu_utf8;
+
+typedef struct { /* Person::schema projection used by q3/q8 (q3_plan.fmt:6, q8_plan.fmt:6) */
+    const int32_t *p_id;
+    flockgpu_utf8 name, city, state;
+    int64_t rows;
+} flockgpu_person_cols;
+
+/* A window schedule over one relation: `n_panes + 1` row offsets (HOST pointer) delimit
+ * consecutive, disjoint panes of rows; window w covers panes [win_pane_lo[w], win_pane_hi[w]).
+ *   ElementWise  (window/elementwise.rs:46)   : pane = 1-s epoch, window = 1 pane
+ *   Tumbling(s)  (window/tumbling.rs:55-57)   : pane = s epochs,  window = 1 pane
+ *   Hopping(w,h) (window/hopping.rs:54-57)    : pane = gcd(w,h) epochs, window = w/gcd panes, stride h/gcd
+ * One call executes every window of the schedule = the reference's per-window loop of
+ * `actor::collect` (flock-function/src/aws/actor.rs:54-79) batched into a few launches. */
+typedef struct {
+    const int64_t *pane_row_offsets; /* host, n_panes + 1, non-decreasing */
+    int32_t n_panes;
+    const int32_t *win_pane_lo; /* host, n_windows */
+    const int32_t *win_pane_hi; /* host, n_windows */
+    int32_t n_windows;
+} flockgpu_windows;
+
+/* ---- q1: ProjectionExec [auction, bidder, 0.908 * CAST(price AS Float64) AS price, b_date_time]
+ * (planner.rs:90, q1_plan.fmt:1).  Pass-through columns are zero-copy in the reference (Arc
+ * clones); the kernel materialises only the computed Float64 column.  `factor` = the literal. */
+int flockgpu_q1_project(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, double factor,
+                        double *out_price /* device, bid->rows */);
+
+/* ---- q2: FilterExec CAST(auction AS Int64) % modulus = 0 -> CoalesceBatches -> Projection
+ * [auction, price] (planner.rs:120-124, q2_plan.fmt:1-3).  Stable: input row order is kept.
+ * out_*: device buffers in the ctx arena; win_out_offsets: HOST array of n_windows + 1 row
+ * offsets into out_* (arena-owned).  Requires single-pane windows (ElementWise). */
+typedef struct {
+    const int32_t *auction, *price;   /* device */
+    const int64_t *win_out_offsets;   /* host, n_windows + 1 */
+    int64_t rows;
+} flockgpu_q2_result;
+int flockgpu_q2_filter(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                       int64_t modulus, flockgpu_q2_result *out);
+
+/* ---- q3: Filter(category = lit) on auction, Filter(state = l0 OR state = l1 OR ...) on person,
+ * HashJoinExec(Inner, seller = p_id), Projection [name, city, state, a_id]
+ * (planner.rs:152-171, q3_plan.fmt:1-6).  `auction_win` / `person_win` describe the same
+ * n_windows windows over the two relations.  Output rows are grouped by window, ordered by
+ * auction row inside a window (row order across partitions is not a contract in the reference:
+ * results compare as sorted multisets, test_util.rs:61-90). */
+typedef struct {
+    flockgpu_utf8 name, city, state;  /* device */
+    const int32_t *a_id;              /* device */
+    const int32_t *auction_row, *person_row; /* device: matching input row pairs */
+    const int64_t *win_out_offsets;   /* host, n_windows + 1 */
+    int64_t rows;
+    int64_t name_bytes, city_bytes, state_bytes;
+} flockgpu_q3_result;
+int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                     const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                     int64_t category_lit, const char *const *state_lits, int n_state_lits,
+                     flockgpu_q3_result *out);
+
+/* ---- q5: COUNT(*) GROUP BY auction; MAX(num); rows with num = maxn, ties kept
+ * (q5.sql, q5_plan.fmt:1-13, q5.dag).  Hopping windows share panes: every bid is read once.
+ * Output: per window, (auction Int32, num UInt64) rows sorted by auction. */
+typedef struct {
+    const int32_t *auction;           /* device */
+    const uint64_t *num;              /* device */
+    const int64_t *win_out_offsets;   /* host, n_windows + 1 */
+    const uint64_t *win_max;          /* host, n_windows: MAX(num) per window (0 = empty window) */
+    const uint64_t *win_groups;       /* host, n_windows: number of distinct auctions per window */
+    int64_t rows;
+} flockgpu_q5_result;
+int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                          flockgpu_q5_result *out);
+
+/* ---- q8: DISTINCT (p_id, name) JOIN DISTINCT seller ON p_id = seller -> [p_id, name]
+ * (q8.sql, q8_plan.fmt:1-10, q8.dag).  Output grouped by window, ordered by person row. */
+typedef struct {
+    const int32_t *p_id;              /* device */
+    flockgpu_utf8 name;               /* device */
+    const int32_t *person_row;        /* device */
+    const int64_t *win_out_offsets;   /* host, n_windows + 1 */
+    int64_t rows;
+    int64_t name_bytes;
+} flockgpu_q8_result;
+int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                     const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                     flockgpu_q8_result *out);
+
+/* ---- device-side NEXMark source (flock/src/datasource/nexmark/{event,config,generator}.rs restated,
+ * deviations D1-D4 documented in DESIGN.md).  Generates the columns the five plans scan for event
+ * numbers [n0, n1) of a stream straight into HBM; any output pointer may be NULL to skip it. */
+typedef struct {
+    uint64_t seed, first_event_id, eps, base_time;
+} flockgpu_nexmark_stream;
+int flockgpu_nexmark_counts(const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                            uint64_t *n_person, uint64_t *n_auction, uint64_t *n_bid);
+int flockgpu_nexmark_gen_bids(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                              int32_t *auction, int32_t *bidder, int32_t *price, int64_t *b_date_time);
+int flockgpu_nexmark_gen_auctions(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                                  int32_t *a_id, int32_t *seller, int32_t *category);
+/* Persons: offsets arrays have rows + 1 entries; byte buffers must hold rows*14 / rows*13 / rows*2. */
+int flockgpu_nexmark_gen_persons(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                                 int32_t *p_id, int32_t *name_off, uint8_t *name_bytes, int32_t *city_off,
+                                 uint8_t *city_bytes, int32_t *state_off, uint8_t *state_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOCKGPU_H */

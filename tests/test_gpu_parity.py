@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+Bit-exact: all outputs are integer / byte / index work, and q1's f64 column is one IEEE multiply.
+Row order: q2 is compared exactly (FilterExec keeps input order); join / aggregate outputs are
+compared as sorted multisets per window (the reference's convention, flock/src/test_util.rs:61-90)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _utf8(u):
+    from flock_amd import DeviceUtf8
+    data = u.data if len(u.data) else np.zeros(16, np.uint8)
+    return DeviceUtf8(_dev(u.offsets), _dev(data))
+
+
+def _host_stream(seed, eps, seconds, first=0):
+    s = oracle.NexmarkStream(seed=seed, eps=eps, first_event_id=first)
+    n = eps * seconds
+    return s, s.bids(0, n), s.auctions(0, n), s.persons(0, n)
+
+
+def _gpu_stream(ctx, seed, eps, seconds, window, first=0):
+    from flock_amd import NEXMarkSource
+    return NEXMarkSource(seconds, eps, window, seed=seed, first_event_id=first).generate_data(ctx)
+
+
+def _str_rows(off, data, rows=None):
+    b = data.tobytes()
+    idx = range(len(off) - 1) if rows is None else rows
+    return [b[off[i]:off[i + 1]] for i in idx]
+
+
+CASES = [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 12), (5, 1_000_000, 2)]
+
+
+# ------------------------------------------------------------------ generator: device == oracle, bit for bit
+@pytest.mark.parametrize("seed,eps,seconds", CASES)
+@pytest.mark.parametrize("first", [0, 123_450])
+def test_device_generator_matches_oracle(ctx, seed, eps, seconds, first):
+    from flock_amd import Window
+    g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise(), first)
+    _, b, a, p = _host_stream(seed, eps, seconds, first)
+    for k in ("auction", "bidder", "price", "b_date_time"):
+        assert np.array_equal(getattr(g.bids, k).cpu().numpy(), b[k]), k
+    for k in ("a_id", "seller", "category"):
+        assert np.array_equal(getattr(g.auctions, k).cpu().numpy(), a[k]), k
+    assert np.array_equal(g.persons.p_id.cpu().numpy(), p["p_id"])
+    for k in ("name", "city", "state"):
+        col = getattr(g.persons, k)
+        off = col.offsets.cpu().numpy()
+        assert np.array_equal(off, p[k].offsets), k
+        assert np.array_equal(col.data.cpu().numpy()[: off[-1]], p[k].data), k
+
+
+# ------------------------------------------------------------------ q1 / q2
+@pytest.mark.parametrize("seed,eps,seconds", CASES)
+def test_q1_projection_bit_exact(ctx, seed, eps, seconds):
+    from flock_amd import Window, run_query
+    g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise())
+    got = run_query(ctx, 1, g).cpu().numpy()
+    want = oracle.q1_project(g.bids.price.cpu().numpy())
+    assert got.dtype == np.float64 and got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("seed,eps,seconds", CASES)
+def test_q2_filter_exact_per_epoch(ctx, seed, eps, seconds):
+    from flock_amd import Window, run_query
+    g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise())
+    a, p, off = run_query(ctx, 2, g).to_host()
+    ha, hp = g.bids.auction.cpu().numpy(), g.bids.price.cpu().numpy()
+    sched = g.window_schedule("bid")
+    assert len(off) == seconds + 1 and off[0] == 0
+    for w in range(seconds):
+        lo, hi = sched.window_rows(w)
+        wa, wp = oracle.q2_filter(ha[lo:hi], hp[lo:hi])
+        assert np.array_equal(a[off[w]:off[w + 1]], wa), w
+        assert np.array_equal(p[off[w]:off[w + 1]], wp), w
+    assert off[-1] == len(a)
+
+
+def test_q2_bursty_selectivity_and_other_moduli(ctx):
+    # hot auction id == 0 (mod m) makes >50 % of a window pass; also negative ids / moduli (truncated remainder)
+    from flock_amd import Bids, WindowSchedule
+    rng = np.random.default_rng(3)
+    n = 300_000
+    auction = rng.integers(-5000, 5000, n).astype(np.int32)
+    auction[1000:200_000:2] = 1230                     # burst
+    auction[5] = np.iinfo(np.int32).min
+    price = rng.integers(100, 10**8, n).astype(np.int32)
+    bids = Bids(auction=_dev(auction), price=_dev(price), rows=n)
+    offs = np.array([0, 17, 17, 4099, 150_001, n])     # ragged, unaligned, one empty window
+    sched = WindowSchedule(offs, np.arange(5), np.arange(1, 6))
+    for m in (123, 7, 1, -123, 2**31, 2**40):
+        a, p, off = ctx.q2_filter(bids, sched, modulus=m).to_host()
+        for w in range(5):
+            wa, wp = oracle.q2_filter(auction[offs[w]:offs[w + 1]], price[offs[w]:offs[w + 1]], modulus=m)
+            assert np.array_equal(a[off[w]:off[w + 1]], wa), (m, w)
+            assert np.array_equal(p[off[w]:off[w + 1]], wp), (m, w)
+
+
+def test_q2_overlapping_windows_and_empty_input(ctx):
+    from flock_amd import Bids, FlockGpuError, WindowSchedule
+    auction = (np.arange(10_000, dtype=np.int32) * 3) % 1000
+    price = np.arange(10_000, dtype=np.int32)
+    bids = Bids(auction=_dev(auction), price=_dev(price), rows=10_000)
+    sched = WindowSchedule(np.array([0, 2500, 5000, 7500, 10_000]), np.array([0, 1, 2]), np.array([2, 3, 4]))
+    a, p, off = ctx.q2_filter(bids, sched).to_host()
+    for w, (lo, hi) in enumerate([(0, 5000), (2500, 7500), (5000, 10_000)]):
+        wa, wp = oracle.q2_filter(auction[lo:hi], price[lo:hi])
+        assert np.array_equal(a[off[w]:off[w + 1]], wa) and np.array_equal(p[off[w]:off[w + 1]], wp)
+    empty = Bids(auction=_dev(np.zeros(4, np.int32)), price=_dev(np.zeros(4, np.int32)), rows=0)
+    r = ctx.q2_filter(empty, WindowSchedule(np.array([0, 0]), np.array([0]), np.array([1])))
+    assert r.rows == 0 and r.offsets().tolist() == [0, 0]
+    with pytest.raises(FlockGpuError):
+        ctx.q2_filter(bids, sched, modulus=0)        # DataFusion raises divide-by-zero
+    with pytest.raises(FlockGpuError):
+        ctx.q2_filter(bids, WindowSchedule(np.array([0, 20_000]), np.array([0]), np.array([1])))
+
+
+# ------------------------------------------------------------------ q3
+@pytest.mark.parametrize("seed,eps,seconds", CASES)
+def test_q3_join_per_epoch(ctx, seed, eps, seconds):
+    from flock_amd import Window, run_query
+    g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise())
+    out = run_query(ctx, 3, g).to_host()
+    _, _, a, p = _host_stream(seed, eps, seconds)
+    sa, sp = g.window_schedule("auction"), g.window_schedule("person")
+    names, cities, states = (_str_rows(p[k].offsets, p[k].data) for k in ("name", "city", "state"))
+    g_name, g_city, g_state = (_str_rows(*out[k]) for k in ("name", "city", "state"))
+    off, total = out["offsets"], 0
+    for w in range(seconds):
+        (alo, ahi), (plo, phi) = sa.window_rows(w), sp.window_rows(w)
+        ar, pr = oracle.q3_join(a["seller"][alo:ahi], a["category"][alo:ahi], p["p_id"][plo:phi], p["state"].slice(plo, phi))
+        want = sorted((names[plo + j], cities[plo + j], states[plo + j], int(a["a_id"][alo + i])) for i, j in zip(ar, pr))
+        sl = slice(off[w], off[w + 1])
+        got = sorted(zip(g_name[sl], g_city[sl], g_state[sl], out["a_id"][sl].tolist()))
+        assert got == want, w
+        # the row-pair view must agree too, and stay inside the window
+        assert sorted(zip((out["auction_row"][sl] - alo).tolist(), (out["person_row"][sl] - plo).tolist())) == sorted(zip(ar.tolist(), pr.tolist()))
+        total += len(want)
+    assert total == off[-1] == len(out["a_id"])
+    if eps >= 5000:
+        assert total > 0
+
+
+def test_q3_duplicate_keys_emit_every_pair(ctx):
+    from flock_amd import Auctions, Persons, WindowSchedule
+    rng = np.random.default_rng(11)
+    na, npn = 20_000, 3_000
+    seller = rng.integers(0, 50, na).astype(np.int32)            # heavy duplicates on the probe side
+    category = rng.integers(10, 12, na).astype(np.int32)
+    a_id = np.arange(na, dtype=np.int32) + 1000
+    p_id = rng.integers(0, 60, npn).astype(np.int32)             # and on the build side
+    st = rng.choice(np.array([b"or", b"OR", b"id", b"ca", b"wa", b"o", b"cal"], dtype=object), npn)
+    s_off = np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32)
+    s_data = np.frombuffer(b"".join(st), np.uint8).copy()
+    state = oracle.Utf8(s_off, s_data)
+    name = oracle.Utf8(np.arange(npn + 1, dtype=np.int32) * 3, np.frombuffer(b"".join(b"n%02d" % (i % 100) for i in range(npn)), np.uint8).copy())
+    aw = WindowSchedule(np.array([0, 7001, 7001, na]), np.arange(3), np.arange(1, 4))
+    pw = WindowSchedule(np.array([0, 1000, 1003, npn]), np.arange(3), np.arange(1, 4))
+    out = ctx.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw,
+                      Persons(_dev(p_id), _utf8(name), _utf8(name), _utf8(state), npn), pw).to_host()
+    off = out["offsets"]
+    for w in range(3):
+        (alo, ahi), (plo, phi) = aw.window_rows(w), pw.window_rows(w)
+        ar, pr = oracle.q3_join(seller[alo:ahi], category[alo:ahi], p_id[plo:phi], state.slice(plo, phi))
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip((out["auction_row"][sl] - alo).tolist(), (out["person_row"][sl] - plo).tolist())) == sorted(zip(ar.tolist(), pr.tolist())), w
+    assert off[2] - off[1] == 0 and off[-1] > 10_000
+
+
+# ------------------------------------------------------------------ q5
+def _q5_check(ctx, g, sched, auction_host):
+    a, n, off = ctx.q5_hot_items(g, sched).to_host()
+    assert n.dtype == np.uint64 and a.dtype == np.int32
+    for w in range(sched.n_windows):
+        lo, hi = sched.window_rows(w)
+        wa, wn = oracle.q5_hot_items(auction_host[lo:hi])
+        assert sorted(zip(a[off[w]:off[w + 1]].tolist(), n[off[w]:off[w + 1]].tolist())) == sorted(zip(wa.tolist(), wn.tolist())), w
+    return a, n, off
+
+
+@pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 23), (42, 50_000, 27), (5, 1_000_000, 20)])
+def test_q5_hopping_windows(ctx, seed, eps, seconds):
+    from flock_amd import Window, query_window
+    g = _gpu_stream(ctx, seed, eps, seconds, query_window(5))
+    sched = g.window_schedule("bid")
+    assert sched.n_windows == len(oracle.hopping_windows(seconds, 10, 5))
+    _q5_check(ctx, g.bids, sched, g.bids.auction.cpu().numpy())
+    # a second call reuses the arena and the learned table size
+    _q5_check(ctx, g.bids, sched, g.bids.auction.cpu().numpy())
+    # other window shapes on the same data: tumbling and a 3-pane hop
+    _q5_check(ctx, g.bids, g.window_schedule("bid", Window.tumbling(7)), g.bids.auction.cpu().numpy())
+    _q5_check(ctx, g.bids, g.window_schedule("bid", Window.hopping(6, 2)), g.bids.auction.cpu().numpy())
+
+
+def test_q5_ties_uniform_keys_and_extremes(ctx):
+    from flock_amd import Bids, WindowSchedule
+    rng = np.random.default_rng(5)
+    n = 400_000
+    cases = {
+        "all_distinct": np.arange(n, dtype=np.int32),                       # every key ties with count 1
+        "one_key": np.full(n, 77, np.int32),
+        "uniform": rng.integers(-2**31, 2**31 - 1, n).astype(np.int32),     # LDS table overflows -> spill path
+        "two_way_tie": np.tile(np.array([5, -9], np.int32), n // 2),
+        "with_zero_key": np.where(rng.random(n) < 0.5, 0, rng.integers(0, 4, n)).astype(np.int32),
+    }
+    offs = np.array([0, 1, 8193, 200_000, 200_000, n])
+    sched = WindowSchedule(offs, np.arange(5), np.arange(1, 6))
+    for name, auction in cases.items():
+        a, nn, off = _q5_check(ctx, Bids(auction=_dev(auction), rows=n), sched, auction)
+        assert off[4] == off[3], name          # empty window -> MAX is NULL -> no rows
+
+
+# ------------------------------------------------------------------ q8
+@pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 10)])
+def test_q8_tumbling_windows(ctx, seed, eps, seconds):
+    from flock_amd import query_window, run_query
+    g = _gpu_stream(ctx, seed, eps, seconds, query_window(8))
+    out = run_query(ctx, 8, g).to_host()
+    _, _, a, p = _host_stream(seed, eps, seconds)
+    sp, sa = g.window_schedule("person"), g.window_schedule("auction")
+    names = _str_rows(p["name"].offsets, p["name"].data)
+    g_names = _str_rows(*out["name"])
+    off = out["offsets"]
+    assert sp.n_windows == seconds // 10
+    for w in range(sp.n_windows):
+        (plo, phi), (alo, ahi) = sp.window_rows(w), sa.window_rows(w)
+        rows = oracle.q8_join(p["p_id"][plo:phi], p["name"].slice(plo, phi), a["seller"][alo:ahi])
+        want = sorted((int(p["p_id"][plo + r]), names[plo + r]) for r in rows)
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, w
+    assert off[-1] == len(out["p_id"]) > 0
+
+
+def test_q8_duplicates_collapse(ctx):
+    from flock_amd import Auctions, Persons, WindowSchedule
+    rng = np.random.default_rng(2)
+    npn, na = 50_000, 80_000
+    p_id = rng.integers(0, 5000, npn).astype(np.int32)
+    tag = rng.integers(0, 3, npn)
+    nm = [b"x%d" % t if t else b"" for t in tag]                 # same id + same name -> duplicate; empty names too
+    n_off = np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32)
+    name = oracle.Utf8(n_off, np.frombuffer(b"".join(nm) or b"\0", np.uint8).copy())
+    seller = rng.integers(2000, 9000, na).astype(np.int32)
+    pw = WindowSchedule(np.array([0, 20_000, npn]), np.arange(2), np.arange(1, 3))
+    aw = WindowSchedule(np.array([0, 30_000, na]), np.arange(2), np.arange(1, 3))
+    out = ctx.q8_join(Persons(_dev(p_id), _utf8(name), None, None, npn), pw,
+                      Auctions(None, _dev(seller), None, na), aw).to_host()
+    g_names = _str_rows(*out["name"])
+    off = out["offsets"]
+    for w in range(2):
+        (plo, phi), (alo, ahi) = pw.window_rows(w), aw.window_rows(w)
+        rows = oracle.q8_join(p_id[plo:phi], name.slice(plo, phi), seller[alo:ahi])
+        want = sorted((int(p_id[plo + r]), nm[plo + r]) for r in rows)
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, w
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+def test_full_size_properties(ctx):
+    """1e8-event stream (configs q2/q3 of BASELINE.json): checks that need no CPU pass over all rows."""
+    from flock_amd import NEXMarkSource, Window, run_query
+    seconds, eps = 100, 1_000_000
+    g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=99).generate_data(ctx, bid_columns=("auction", "price"))
+    # q2: idempotence (filtering the filtered rows again keeps everything) + stability (sorted row positions)
+    r2 = run_query(ctx, 2, g)
+    a, p, off = r2.to_host()
+    assert (a.astype(np.int64) % 123 == 0).all() and len(a) == off[-1]
+    cnt = int((g.bids.auction.to(dtype=__import__("torch").int64) % 123 == 0).sum().item())
+    assert cnt == len(a)
+    # q5: sum over the window's groups is implied by max <= rows, winners' count equals win_max, groups > 0
+    r5 = ctx.q5_hot_items(g.bids, g.window_schedule("bid", Window.hopping(10, 5)))
+    wa, wn, woff = r5.to_host()
+    mx = r5.win_max()
+    assert len(mx) == 19 and (mx > 0).all() and (r5.win_groups() > 0).all()
+    for w in range(19):
+        assert (wn[woff[w]:woff[w + 1]] == mx[w]).all() and woff[w + 1] > woff[w]
+    # spot-check 2 windows against the oracle
+    sched = g.window_schedule("bid", Window.hopping(10, 5))
+    host_auction = g.bids.auction.cpu().numpy()
+    for w in (0, 18):
+        lo, hi = sched.window_rows(w)
+        oa, on = oracle.q5_hot_items(host_auction[lo:hi])
+        assert sorted(zip(wa[woff[w]:woff[w + 1]].tolist(), wn[woff[w]:woff[w + 1]].tolist())) == sorted(zip(oa.tolist(), on.tolist()))
+    # q3 / q8: every output row satisfies the predicates and the join condition (checked on the row pairs)
+    o3 = run_query(ctx, 3, g).to_host()
+    seller = g.auctions.seller.cpu().numpy()
+    cat = g.auctions.category.cpu().numpy()
+    pid = g.persons.p_id.cpu().numpy()
+    assert (cat[o3["auction_row"]] == 10).all() and (seller[o3["auction_row"]] == pid[o3["person_row"]]).all()
+    assert set(_str_rows(*o3["state"])) <= {b"or", b"id", b"ca"} and len(o3["a_id"]) > 0
+    assert (np.diff(o3["auction_row"].astype(np.int64)) >= 0).all()          # order-preserving expansion
+    o8 = run_query(ctx, 8, g).to_host()
+    assert len(np.unique(o8["p_id"])) == len(o8["p_id"]) > 0                   # DISTINCT
+    assert (np.diff(o8["person_row"].astype(np.int64)) > 0).all()
