@@ -3,15 +3,21 @@
 // (benchmarks/src/nexmark/query/q5.sql, q5_plan.fmt:1-13, playground/.../nexmark/q5.dag).
 //
 // HBM-bound integer work, no MFMA.  One pass over the `auction` column (4 B / bid):
-//   * rows are cut into 8192-row tiles that never straddle a pane (pane = gcd(window, hop) seconds);
-//   * each workgroup pre-aggregates its tile in an LDS open-addressing table (packed {key:32,count:32}
-//     slots, ds_cmpst_b64 / ds_add_u64); before touching LDS every wave collapses the current hot key
-//     with ballot + popcount (half of all bids hit one auction id, event.rs:355-359);
-//   * the tile's distinct (key, count) pairs are flushed with one 64-bit global atomic each into the
-//     table of EVERY window that contains the pane (pane sharing: a bid is read once although it
-//     belongs to window/hop windows);  MAX(num) falls out of the flush for free: counts only grow, so
-//     the maximum over all fetch_add results is the final maximum;
-//   * a second small kernel scans the window tables for count == max.
+//   range  : a sampling kernel (4 cache lines per tile, <1 % of the column) estimates every pane's key range;
+//            the host turns it into a per-window direct-address counter array [base, base + range) when the
+//            ranges are affordable ("dense" group-by; NEXMark ids are dense and time-ordered).  Keys that fall
+//            outside the estimate -- or every key when the ranges are not affordable -- go to a per-window
+//            open-addressing hash table instead, so the result is exact for any input.
+//   count  : rows are cut into 8192-row tiles that never straddle a pane (pane = gcd(window, hop) seconds).
+//            A workgroup pre-aggregates its tile in LDS: a direct-mapped histogram over [tile min, tile max]
+//            when that span fits (ds_add_u32, no CAS), else an LDS hash table.  Half of all bids hit one
+//            auction id (event.rs:355-359): each wave keeps that id and its count in scalar registers
+//            (ballot + s_bcnt1) and only sends the other keys to LDS, so the hot key costs no LDS conflicts.
+//            The tile's distinct (key, count) pairs are then added with fire-and-forget global atomics to the
+//            counters of EVERY window that contains the pane (pane sharing: a bid is read once although it
+//            belongs to window/hop windows).  Adjacent tiles touch adjacent counters, so the atomics coalesce.
+//   max    : per-window maximum and group count over counters + hash table.
+//   select : rows whose count equals the window maximum.
 #include <algorithm>
 
 #include "scan.hpp"
@@ -22,12 +28,23 @@ namespace {
 
 constexpr int kQ5Iters = 8;
 constexpr int kQ5Tile = kBlock * 4 * kQ5Iters;  // 8192 rows
+constexpr int kHist = 4096;                     // direct-mapped LDS histogram bins (u32)
+constexpr int kHistPad = 64;                    // one scratch bin per lane for "not mine" adds
+constexpr int kSlots = kHist / 2;               // the same LDS viewed as packed {key:32,count:32} hash slots
 constexpr int kSlotBits = 11;
-constexpr int kSlots = 1 << kSlotBits;          // 2048 x 8 B = 16 KiB LDS
+static_assert(kSlots == (1 << kSlotBits), "slot bits");
 constexpr int kLdsMaxProbe = 24;
 constexpr uint32_t kFib = 0x9E3779B1u;
+constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 
-__device__ __forceinline__ bool lds_insert(uint64_t *tab, uint32_t key, uint32_t c) {
+struct WinDesc {
+    int64_t base;      // first key of the direct-address range
+    uint64_t cnt_off;  // offset of the window's counters in the counter arena (u32 units)
+    uint32_t range;    // number of counters (0: every key of this window goes to the hash table)
+    uint32_t pad;
+};
+
+__device__ __forceinline__ bool lds_hash_insert(uint64_t *tab, uint32_t key, uint32_t c) {
     uint32_t s = (key * kFib) >> (32 - kSlotBits);
     const uint64_t mine = ((uint64_t)key << 32) | c;
 #pragma unroll 1
@@ -46,8 +63,8 @@ __device__ __forceinline__ bool lds_insert(uint64_t *tab, uint32_t key, uint32_t
     return false;
 }
 
-// Returns the key's new count in this window (0 on table overflow, which also raises *err).
-__device__ __forceinline__ uint32_t global_insert(uint64_t *tab, uint32_t cap, uint32_t key, uint32_t c, uint32_t *err) {
+// Window hash table (packed {key:32,count:32}, 0 = empty; counts >= 1 so a live slot is never 0).
+__device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t key, uint32_t c, uint32_t *err) {
     uint32_t s = (uint32_t)(((uint64_t)(key * kFib) * cap) >> 32);
     const uint64_t mine = ((uint64_t)key << 32) | c;
 #pragma unroll 1
@@ -57,147 +74,406 @@ __device__ __forceinline__ uint32_t global_insert(uint64_t *tab, uint32_t cap, u
             uint64_t expected = 0;
             if (__hip_atomic_compare_exchange_strong(&tab[s], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT))
-                return c;
+                return;
             cur = expected;
         }
         if ((uint32_t)(cur >> 32) == key) {
-            const uint64_t old = __hip_atomic_fetch_add(&tab[s], (uint64_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return (uint32_t)old + c;
+            __hip_atomic_fetch_add(&tab[s], (uint64_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
         s = (s + 1 == cap) ? 0 : s + 1;
     }
     atomicOr(err, 1u);
-    return 0;
 }
 
-template <bool COLLAPSE>
-__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
-                                                          const int32_t *__restrict__ pane_win_ptr,
-                                                          const int32_t *__restrict__ pane_win_idx, uint64_t *tables,
-                                                          uint32_t cap, uint64_t *win_max, uint32_t *err) {
-    __shared__ uint64_t lds[kSlots];
-    __shared__ uint32_t s_spill;  // keys that did not fit the LDS table go straight to the global tables
-    for (int s = threadIdx.x; s < kSlots; s += kBlock) lds[s] = 0;
-    if (threadIdx.x == 0) s_spill = 0;
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kQ5Tile);
-    const int32_t wp0 = pane_win_ptr[tr.seg], wp1 = pane_win_ptr[tr.seg + 1];
-    __syncthreads();
-    if (wp0 == wp1) return;  // pane belongs to no (full) window
+// Adds one aggregated (key, count) pair of a tile to every window that contains the tile's pane.
+__device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, int32_t wp0, int32_t wp1,
+                                          const int32_t *__restrict__ pane_win_idx, const WinDesc *__restrict__ wins,
+                                          uint32_t *counters, uint64_t *tables, uint32_t cap, uint32_t *err) {
+    for (int wi = wp0; wi < wp1; ++wi) {
+        const int32_t w = pane_win_idx[wi];
+        const WinDesc d = wins[w];
+        const uint64_t idx = (uint64_t)((int64_t)key - d.base);
+        if (idx < (uint64_t)d.range)
+            __hip_atomic_fetch_add(&counters[d.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            table_add(tables + (size_t)w * cap, cap, (uint32_t)key, c, err);
+    }
+}
 
-    const int lane = lane_id();
-    int32_t k[kQ5Iters][4];
+// ---- pane key-range estimate: kRangeBlocks x 256 lanes x 4 strided 16-byte samples per pane (<1 % of a pane) ------
+constexpr int kRangeBlocks = 8;
+__global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restrict__ auction, int64_t n_rows,
+                                                          const int64_t *__restrict__ seg_off, int32_t *pane_min,
+                                                          int32_t *pane_max) {
+    __shared__ int32_t s_red[8];
+    const int32_t pane = blockIdx.y;
+    const int64_t sb = seg_off[2 * pane], se = seg_off[2 * pane + 1];
+    const int64_t groups = (se - (sb & ~int64_t(3)) + 3) >> 2;  // aligned 4-row groups covering the pane
+    const int64_t n_samples = (int64_t)kRangeBlocks * kBlock * 4;
+    const int64_t stride = groups > n_samples ? groups / n_samples : 1;
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
 #pragma unroll
-    for (int it = 0; it < kQ5Iters; ++it) {
-        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-        if (r0 + 4 <= n_rows) {
+    for (int i = 0; i < 4; ++i) {
+        const int64_t g = ((int64_t)(i * kRangeBlocks + blockIdx.x) * kBlock + threadIdx.x) * stride;
+        const int64_t r0 = (sb & ~int64_t(3)) + g * 4;
+        if (g < groups && r0 + 4 <= n_rows) {
             const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
-            k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
-        } else {
+            const int32_t k[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) k[it][j] = (r0 + j < n_rows) ? auction[r0 + j] : 0;
+            for (int j = 0; j < 4; ++j)
+                if (r0 + j >= sb && r0 + j < se) {
+                    mn = min(mn, k[j]);
+                    mx = max(mx, k[j]);
+                }
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (lane_id() == 0) {
+        s_red[threadIdx.x >> 6] = mn;
+        s_red[4 + (threadIdx.x >> 6)] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        if (mn <= mx) {
+            atomicMin(&pane_min[pane], mn);
+            atomicMax(&pane_max[pane], mx);
+        }
+    }
+}
+
+// ---- count ---------------------------------------------------------------------------------------------
+struct FlushArgs {
+    int32_t wp0, wp1;
+    const int32_t *pane_win_idx;
+    const WinDesc *wins;
+    uint32_t *counters;
+    uint64_t *tables;
+    uint32_t cap;
+    uint32_t *err;
+};
+
+__device__ __noinline__ void emit_pair_slow(int32_t key, uint32_t c, const FlushArgs &f) {
+    emit_pair(key, c, f.wp0, f.wp1, f.pane_win_idx, f.wins, f.counters, f.tables, f.cap, f.err);
+}
+
+// Fast path: the tile's keys span fewer than kHist ids -> direct-mapped LDS histogram, no CAS anywhere.
+template <bool FULL>
+__device__ __forceinline__ void tile_direct(const int32_t (&k)[kQ5Iters][4], const TileRange &tr, int32_t mn, uint32_t span,
+                                            uint32_t *hist, const FlushArgs &f) {
+    const int lane = lane_id();
+    // hot key of this wave, kept in scalar registers across iterations
+    int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
+    uint32_t hot_cnt = 0;
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
         bool v[4];
-        uint32_t c[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = (r0 + j >= tr.lo) && (r0 + j < tr.hi);
-            c[j] = 1;
-        }
-        if (COLLAPSE) {
-            // wave-level collapse of the hot key: take the first live key of the wave as candidate
-            const uint64_t live = __ballot(v[0]);
+        for (int j = 0; j < 4; ++j) v[j] = FULL || (r0 + j >= tr.lo && r0 + j < tr.hi);
+        uint64_t b0 = __ballot(v[0] && k[it][0] == hot);
+        if (__popcll((unsigned long long)b0) < kHotMin) {
+            // the candidate went cold: park its count, then try this iteration's first two distinct keys
+            if (hot_cnt) {
+                if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+                hot_cnt = 0;
+            }
+            const uint64_t live = FULL ? ~0ull : __ballot(v[0]);
             if (live) {
-                const int src = __ffsll((unsigned long long)live) - 1;
-                const int32_t hot = __shfl(k[it][0], src, 64);
-                uint32_t cnt = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool m = v[j] && k[it][j] == hot;
-                    cnt += (uint32_t)__popcll((unsigned long long)__ballot(m));
-                    v[j] = v[j] && !m;
-                }
-                if (lane == src && !lds_insert(lds, (uint32_t)hot, cnt)) {
-                    // cannot happen for a sane table size, but stay correct: spill
-                    atomicAdd(&s_spill, 1u);
-                    for (int wi = wp0; wi < wp1; ++wi) {
-                        const int32_t w = pane_win_idx[wi];
-                        const uint32_t nc = global_insert(tables + (size_t)w * cap, cap, (uint32_t)hot, cnt, err);
-                        atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)nc);
+                const int l1 = __ffsll((unsigned long long)live) - 1;
+                const int32_t c1 = __builtin_amdgcn_readlane(k[it][0], l1);
+                const uint64_t m1 = __ballot(v[0] && k[it][0] == c1);
+                hot = c1;
+                b0 = m1;
+                const uint64_t rest = live & ~m1;
+                if (__popcll((unsigned long long)m1) < kHotMin && rest) {
+                    const int l2 = __ffsll((unsigned long long)rest) - 1;
+                    const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                    const uint64_t m2 = __ballot(v[0] && k[it][0] == c2);
+                    if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                        hot = c2;
+                        b0 = m2;
                     }
                 }
             }
         }
-        // lane-local merge of equal keys
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool is_hot = v[j] && k[it][j] == hot;
+            const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
+            hot_cnt += (uint32_t)__popcll((unsigned long long)b);
+            // branch-free: lanes with nothing to add hit their private scratch bin
+            const uint32_t bin = (is_hot || !v[j]) ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
+        const uint32_t c = hist[s];
+        if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f.wp0, f.wp1, f.pane_win_idx, f.wins, f.counters, f.tables, f.cap, f.err);
+    }
+}
+
+// Slow path (keys of the tile are spread wider than the histogram): LDS hash table; keys are re-read (L2-hot)
+// in a rolled loop to keep this path small.
+__device__ __forceinline__ void tile_hash(const int32_t *__restrict__ auction, TileRange tr, uint64_t *slots, FlushArgs f) {
+    const int lane = lane_id();
+#pragma unroll 1
+    for (int it = 0; it < kQ5Iters; ++it) {
+        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+        int32_t k[4];
+        bool v[4];
+        uint32_t c[4] = {1, 1, 1, 1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = r0 + j >= tr.lo && r0 + j < tr.hi;
+            k[j] = v[j] ? auction[r0 + j] : 0;
+        }
+        const uint64_t live = __ballot(v[0]);
+        if (live) {  // wave-level collapse of the wave's first key
+            const int src = __ffsll((unsigned long long)live) - 1;
+            const int32_t hot = __builtin_amdgcn_readlane(k[0], src);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool m = v[j] && k[j] == hot;
+                cnt += (uint32_t)__popcll((unsigned long long)__ballot(m));
+                v[j] = v[j] && !m;
+            }
+            if (lane == src && !lds_hash_insert(slots, (uint32_t)hot, cnt)) emit_pair_slow(hot, cnt, f);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = i + 1; j < 4; ++j)
-                if (v[i] && v[j] && k[it][i] == k[it][j]) {
+                if (v[i] && v[j] && k[i] == k[j]) {
                     c[i] += c[j];
                     v[j] = false;
                 }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (v[j] && !lds_insert(lds, (uint32_t)k[it][j], c[j])) {
-                atomicAdd(&s_spill, 1u);
-                for (int wi = wp0; wi < wp1; ++wi) {
-                    const int32_t w = pane_win_idx[wi];
-                    const uint32_t nc = global_insert(tables + (size_t)w * cap, cap, (uint32_t)k[it][j], c[j], err);
-                    atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)nc);
-                }
-            }
-        }
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j)
+            if (v[j] && !lds_hash_insert(slots, (uint32_t)k[j], c[j])) emit_pair_slow(k[j], c[j], f);
     }
     __syncthreads();
-    // flush the tile's distinct keys into every window table that contains this pane
-    for (int wi = wp0; wi < wp1; ++wi) {
-        const int32_t w = pane_win_idx[wi];
-        uint64_t *tab = tables + (size_t)w * cap;
-        uint32_t best = 0;
-#pragma unroll
-        for (int s = threadIdx.x; s < kSlots; s += kBlock) {
-            const uint64_t e = lds[s];
-            if (e) {
-                const uint32_t nc = global_insert(tab, cap, (uint32_t)(e >> 32), (uint32_t)e, err);
-                best = nc > best ? nc : best;
-            }
-        }
-        best = wave_max_u32(best);
-        if (lane == 0 && best > 0) {
-            const uint64_t seen = __hip_atomic_load(&win_max[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint64_t)best > seen) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
-        }
+#pragma unroll 1
+    for (int s = threadIdx.x; s < kSlots; s += kBlock) {
+        const uint64_t e = slots[s];
+        if (e) emit_pair_slow((int32_t)(uint32_t)(e >> 32), (uint32_t)e, f);
     }
 }
 
-// Scan every window table: count groups, append (window, key) of the rows whose count equals the window max.
-__global__ __launch_bounds__(kBlock) void q5_select_kernel(const uint64_t *__restrict__ tables, uint32_t cap,
-                                                           const uint64_t *__restrict__ win_max, uint64_t *win_groups,
-                                                           uint32_t *cursor, uint32_t out_cap, int32_t *out_win,
-                                                           int32_t *out_key) {
+// Ragged tiles (first / last tile of a pane): small rolled-loop version of the same logic.
+__device__ __forceinline__ void tile_generic(const int32_t *__restrict__ auction, TileRange tr, uint32_t *hist, int32_t *s_red,
+                                          FlushArgs f) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+#pragma unroll 1
+    for (int64_t r = tr.lo + threadIdx.x; r < tr.hi; r += kBlock) {
+        const int32_t key = auction[r];
+        mn = min(mn, key);
+        mx = max(mx, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[4 + wave] = mx;
+    }
+    __syncthreads();
+    mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+    if (span >= (uint32_t)kHist) {
+        tile_hash(auction, tr, reinterpret_cast<uint64_t *>(hist), f);
+        return;
+    }
+#pragma unroll 1
+    for (int64_t r0 = tr.lo; r0 < tr.hi; r0 += kBlock) {
+        const int64_t r = r0 + threadIdx.x;
+        const bool v = r < tr.hi;
+        const int32_t key = v ? auction[r] : 0;
+        const uint64_t live = __ballot(v);
+        const int src = __ffsll((unsigned long long)live) - 1;  // lane 0 of a live wave is always live
+        if (live) {
+            const int32_t hot = __builtin_amdgcn_readlane(key, src);
+            const bool m = v && key == hot;
+            const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(m));
+            if (lane == src) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], cnt);
+            else if (v && !m) atomicAdd(&hist[(uint32_t)key - (uint32_t)mn], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
+        const uint32_t c = hist[s];
+        if (c) emit_pair_slow((int32_t)((uint32_t)mn + s), c, f);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
+                                                          const int32_t *__restrict__ pane_win_ptr,
+                                                          const int32_t *__restrict__ pane_win_idx,
+                                                          const WinDesc *__restrict__ wins, uint32_t *counters,
+                                                          uint64_t *tables, uint32_t cap, uint32_t *err,
+                                                          int32_t *slow_list) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
+    __shared__ int32_t s_red[8];
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(hist);
+        for (int s = threadIdx.x; s < (kHist + kHistPad) / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
+    }
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kQ5Tile);
+    FlushArgs f;
+    f.wp0 = pane_win_ptr[tr.seg];
+    f.wp1 = pane_win_ptr[tr.seg + 1];
+    f.pane_win_idx = pane_win_idx;
+    f.wins = wins;
+    f.counters = counters;
+    f.tables = tables;
+    f.cap = cap;
+    f.err = err;
+    if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
+    const bool full = tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile;
+    if (!full) {  // ragged first / last tile of a pane: left to q5_count_slow_kernel
+        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
+        return;
+    }
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int32_t k[kQ5Iters][4];
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+#pragma unroll
+    for (int it = 0; it < kQ5Iters; ++it) {
+        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+        const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+        k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
+    }
+#pragma unroll
+    for (int it = 0; it < kQ5Iters; ++it) {
+        mn = min(mn, min(min(k[it][0], k[it][1]), min(k[it][2], k[it][3])));
+        mx = max(mx, max(max(k[it][0], k[it][1]), max(k[it][2], k[it][3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[4 + wave] = mx;
+    }
+    __syncthreads();  // also orders the zeroing of `hist`
+    mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+    if (span >= (uint32_t)kHist) {  // keys spread wider than the histogram: hash path in q5_count_slow_kernel
+        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
+        return;
+    }
+    tile_direct<true>(k, tr, mn, span, hist, f);
+}
+
+// Tiles the fast kernel declined (ragged, or keys spread wider than the LDS histogram).
+__global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__restrict__ auction, SegTiles st,
+                                                               const int32_t *__restrict__ pane_win_ptr,
+                                                               const int32_t *__restrict__ pane_win_idx,
+                                                               const WinDesc *__restrict__ wins, uint32_t *counters,
+                                                               uint64_t *tables, uint32_t cap, uint32_t *err,
+                                                               const int32_t *__restrict__ slow_list) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
+    __shared__ int32_t s_red[8];
+    const int32_t n = slow_list[0];
+    for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();  // previous tile's flush is done with `hist`
+        for (int s = threadIdx.x; s < kHist + kHistPad; s += kBlock) hist[s] = 0;
+        const TileRange tr = locate_tile(st, slow_list[1 + i], kQ5Tile);
+        FlushArgs f;
+        f.wp0 = pane_win_ptr[tr.seg];
+        f.wp1 = pane_win_ptr[tr.seg + 1];
+        f.pane_win_idx = pane_win_idx;
+        f.wins = wins;
+        f.counters = counters;
+        f.tables = tables;
+        f.cap = cap;
+        f.err = err;
+        __syncthreads();
+        tile_generic(auction, tr, hist, s_red, f);
+    }
+}
+
+// ---- max + group count, then select ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void q5_max_kernel(const WinDesc *__restrict__ wins, const uint32_t *__restrict__ counters,
+                                                        const uint64_t *__restrict__ tables, uint32_t cap, uint64_t *win_max,
+                                                        uint64_t *win_groups) {
     const int32_t w = blockIdx.y;
+    const WinDesc d = wins[w];
+    const uint32_t *cnt = counters + d.cnt_off;
+    uint32_t best = 0, groups = 0;
+    const uint32_t n4 = d.range / 4;  // ranges are multiples of 4, cnt_off too
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
+        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
+        best = max(max(best, c.x), max(max(c.y, c.z), c.w));
+        groups += (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0);
+    }
     const uint64_t *tab = tables + (size_t)w * cap;
-    const uint32_t mx = (uint32_t)win_max[w];
-    uint32_t groups = 0;
     for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) {
         const uint64_t e = tab[s];
         if (e) {
             ++groups;
-            if ((uint32_t)e == mx) {
+            best = max(best, (uint32_t)e);
+        }
+    }
+    best = wave_max_u32(best);
+    const uint64_t g = wave_sum_u64(groups);
+    if (lane_id() == 0) {
+        if (best) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
+        if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void q5_select_kernel(const WinDesc *__restrict__ wins, const uint32_t *__restrict__ counters,
+                                                           const uint64_t *__restrict__ tables, uint32_t cap,
+                                                           const uint64_t *__restrict__ win_max, uint32_t *cursor,
+                                                           uint32_t out_cap, int32_t *out_win, int32_t *out_key) {
+    const int32_t w = blockIdx.y;
+    const uint32_t mx = (uint32_t)win_max[w];
+    if (mx == 0) return;  // empty window: MAX is NULL, the inner join emits nothing
+    const WinDesc d = wins[w];
+    const uint32_t *cnt = counters + d.cnt_off;
+    const uint32_t n4 = d.range / 4;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
+        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
+        const uint32_t v[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (v[j] == mx) {
                 const uint32_t p = atomicAdd(cursor, 1u);
                 if (p < out_cap) {
                     out_win[p] = w;
-                    out_key[p] = (int32_t)(e >> 32);
+                    out_key[p] = (int32_t)(d.base + (int64_t)i * 4 + j);
                 }
+            }
+    }
+    const uint64_t *tab = tables + (size_t)w * cap;
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) {
+        const uint64_t e = tab[s];
+        if (e && (uint32_t)e == mx) {
+            const uint32_t p = atomicAdd(cursor, 1u);
+            if (p < out_cap) {
+                out_win[p] = w;
+                out_key[p] = (int32_t)(uint32_t)(e >> 32);
             }
         }
     }
-    const uint64_t g = wave_sum_u64(groups);
-    if (lane_id() == 0 && g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
 }
 
 }  // namespace
@@ -217,14 +493,15 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
 
     // pane -> windows CSR, window row counts
     std::vector<int32_t> ptr(n_panes + 1, 0), idx;
-    int64_t max_win_rows = 0;
+    int64_t max_win_rows = 0, covered_rows = 0;
     for (int w = 0; w < n_win; ++w) {
         for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p) ++ptr[p + 1];
         const int64_t rows = win->pane_row_offsets[win->win_pane_hi[w]] - win->pane_row_offsets[win->win_pane_lo[w]];
         max_win_rows = std::max(max_win_rows, rows);
+        covered_rows += rows;
     }
     if (max_win_rows >= (int64_t(1) << 32))
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: a window holds >= 2^32 rows (packed 32-bit counters)");
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: a window holds >= 2^32 rows (32-bit counters)");
     for (int p = 0; p < n_panes; ++p) ptr[p + 1] += ptr[p];
     idx.resize(ptr[n_panes]);
     {
@@ -251,6 +528,57 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     if (!idx.empty())
         FG_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
 
+    // ---- key-range estimate per pane -> direct-address ranges per window
+    int32_t *d_rng = nullptr, *h_rng = nullptr;  // [0, n_panes) min, [n_panes, 2 n_panes) max
+    FG_TRY(arena_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &d_rng));
+    FG_TRY(pinned_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &h_rng));
+    std::vector<WinDesc> wins((size_t)std::max(n_win, 1));
+    uint64_t cnt_total = 0;
+    bool dense = false;
+    if (st.n_tiles > 0 && n_win > 0) {
+        FG_HIP(ctx, hipMemsetAsync(d_rng, 0x7F, sizeof(int32_t) * n_panes, ctx->stream));             // min = 0x7f7f7f7f
+        FG_HIP(ctx, hipMemsetAsync(d_rng + n_panes, 0x80, sizeof(int32_t) * n_panes, ctx->stream));   // max = 0x80808080
+        {
+            LaunchScope ls(ctx, "q5_range_kernel");
+            hipLaunchKernelGGL(q5_range_kernel, dim3(kRangeBlocks, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream,
+                               bid->auction, bid->rows, st.seg_off, d_rng, d_rng + n_panes);
+        }
+        FG_TRY(check_launch(ctx, "q5_range_kernel"));
+        FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * 2 * n_panes, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dense = true;
+        for (int w = 0; w < n_win && dense; ++w) {
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p)
+                if (se[p] > sb[p] && h_rng[p] <= h_rng[n_panes + p]) {
+                    lo = std::min<int64_t>(lo, h_rng[p]);
+                    hi = std::max<int64_t>(hi, h_rng[n_panes + p]);
+                }
+            WinDesc &d = wins[w];
+            d.base = 0; d.range = 0; d.cnt_off = cnt_total; d.pad = 0;
+            if (lo > hi) continue;  // empty window
+            const int64_t span = hi - lo, margin = std::max<int64_t>(4096, span / 16);
+            const int64_t range = ((span + 2 * margin + 1) + 3) & ~int64_t(3);
+            if (range >= (int64_t(1) << 31)) { dense = false; break; }
+            d.base = lo - margin;
+            d.range = (uint32_t)range;
+            cnt_total += (uint64_t)range;
+        }
+        // affordable = the counters cost no more than a few passes over the input
+        if (dense && cnt_total * 4 > std::max<uint64_t>(uint64_t(256) << 20, (uint64_t)covered_rows * 4 * 2)) dense = false;
+    }
+    if (!dense) {
+        cnt_total = 0;
+        for (auto &d : wins) { d.base = 0; d.range = 0; d.cnt_off = 0; d.pad = 0; }
+    }
+    WinDesc *d_wins = nullptr, *h_wins = nullptr;
+    FG_TRY(arena_get_t(ctx, "q5.wins", wins.size(), &d_wins));
+    FG_TRY(pinned_get_t(ctx, "q5.wins", wins.size(), &h_wins));
+    std::copy(wins.begin(), wins.end(), h_wins);
+    FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *counters = nullptr;
+    FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+
     // device scalars: [0 .. n_win) win_max, [n_win .. 2 n_win) win_groups, then cursor + err (as 2 x u32)
     const size_t n_meta = (size_t)2 * n_win + 1;
     uint64_t *d_meta = nullptr, *h_meta = nullptr;
@@ -258,8 +586,9 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     FG_TRY(pinned_get_t(ctx, "q5.meta", n_meta, &h_meta));
     uint32_t *d_cursor = reinterpret_cast<uint32_t *>(d_meta + 2 * n_win), *d_err = d_cursor + 1;
 
+    // hash tables: only stragglers in dense mode; every group otherwise (sized from the density seen last call)
     double rpg = ctx->q5_rows_per_group < 1.0 ? 1.0 : ctx->q5_rows_per_group;
-    uint64_t cap64 = std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
+    uint64_t cap64 = dense ? 4096 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
     uint32_t out_cap = 1u << 16;
     std::vector<int32_t> h_win, h_key;
     uint32_t n_sel = 0;
@@ -273,20 +602,40 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         FG_TRY(arena_get_t(ctx, "q5.sel_win", out_cap, &o_win));
         FG_TRY(arena_get_t(ctx, "q5.sel_key", out_cap, &o_key));
         FG_HIP(ctx, hipMemsetAsync(tables, 0, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
+        if (cnt_total) FG_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t) * cnt_total, ctx->stream));
         FG_HIP(ctx, hipMemsetAsync(d_meta, 0, sizeof(uint64_t) * n_meta, ctx->stream));
+        int32_t *slow_list = nullptr;
+        FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
+        FG_HIP(ctx, hipMemsetAsync(slow_list, 0, sizeof(int32_t), ctx->stream));
         if (st.n_tiles > 0 && n_win > 0) {
-            LaunchScope ls(ctx, "q5_count_kernel");
-            hipLaunchKernelGGL(q5_count_kernel<true>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
-                               bid->rows, st, d_ptr, d_idx, tables, cap, d_meta, d_err);
+            {
+                LaunchScope ls(ctx, "q5_count_kernel");
+                hipLaunchKernelGGL(q5_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
+                                   bid->rows, st, d_ptr, d_idx, d_wins, counters, tables, cap, d_err, slow_list);
+            }
+            FG_TRY(check_launch(ctx, "q5_count_kernel"));
+            LaunchScope ls(ctx, "q5_count_slow_kernel");
+            const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
+            hipLaunchKernelGGL(q5_count_slow_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, bid->auction, st, d_ptr, d_idx,
+                               d_wins, counters, tables, cap, d_err, slow_list);
         }
-        FG_TRY(check_launch(ctx, "q5_count_kernel"));
+        FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
         if (n_win > 0) {
-            LaunchScope ls(ctx, "q5_select_kernel");
-            const unsigned gx = (unsigned)std::min<int64_t>(div_up(cap, kBlock * 8), 256);
-            hipLaunchKernelGGL(q5_select_kernel, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, tables, cap, d_meta,
-                               d_meta + n_win, d_cursor, out_cap, o_win, o_key);
+            const uint64_t per_win = std::max<uint64_t>(cap, n_win ? cnt_total / n_win / 4 : 0);
+            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 4), 1), 64);
+            {
+                LaunchScope ls(ctx, "q5_max_kernel");
+                hipLaunchKernelGGL(q5_max_kernel, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins, counters,
+                                   tables, cap, d_meta, d_meta + n_win);
+            }
+            FG_TRY(check_launch(ctx, "q5_max_kernel"));
+            {
+                LaunchScope ls(ctx, "q5_select_kernel");
+                hipLaunchKernelGGL(q5_select_kernel, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins, counters,
+                                   tables, cap, d_meta, d_cursor, out_cap, o_win, o_key);
+            }
+            FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
-        FG_TRY(check_launch(ctx, "q5_select_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_meta, d_meta, sizeof(uint64_t) * n_meta, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
@@ -307,7 +656,7 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         }
         break;
     }
-    // remember how dense the groups were so the next call sizes its tables right away
+    // remember how dense the groups were so the next sparse call sizes its tables right away
     {
         double best = 1e30;
         for (int w = 0; w < n_win; ++w) {

@@ -31,12 +31,30 @@ struct TileRange {
 };
 
 __device__ __forceinline__ TileRange locate_tile(const SegTiles &st, int32_t tile, int32_t tile_rows) {
-    // upper_bound(tile_first, tile) - 1 ; tile_first is small (<= a few thousand entries) and L2-resident
-    int32_t lo = 0, hi = st.n_seg;  // invariant: tile_first[lo] <= tile < tile_first[hi]
-    while (hi - lo > 1) {
-        int32_t mid = (lo + hi) >> 1;
-        if (st.tile_first[mid] <= tile) lo = mid; else hi = mid;
+    // upper_bound(tile_first, tile) - 1.  Windows of a schedule hold (nearly) equal row counts, so an
+    // interpolated guess is right or off by one: two dependent scalar loads instead of log2(n_seg) -- the
+    // block cannot issue its first column load before it knows its rows.
+    int32_t lo = (int32_t)(((int64_t)tile * st.n_seg) / st.n_tiles);
+    if (st.tile_first[lo] <= tile) {
+        int32_t step = 1;  // gallop right
+        int32_t hi = lo + 1;
+        while (hi < st.n_seg && st.tile_first[hi] <= tile) { lo = hi; hi = hi + step > st.n_seg ? st.n_seg : hi + step; step <<= 1; }
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (st.tile_first[mid] <= tile) lo = mid; else hi = mid;
+        }
+    } else {
+        int32_t step = 1;  // gallop left
+        int32_t hi = lo;
+        lo = lo - 1;
+        while (lo > 0 && st.tile_first[lo] > tile) { hi = lo; lo = lo - step < 0 ? 0 : lo - step; step <<= 1; }
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (st.tile_first[mid] <= tile) lo = mid; else hi = mid;
+        }
     }
+    // empty segments share their tile_first with the next one: take the last segment that starts at or before
+    while (lo + 1 < st.n_seg && st.tile_first[lo + 1] <= tile) ++lo;
     TileRange r;
     r.seg = lo;
     const int64_t sb = st.seg_off[2 * lo], se = st.seg_off[2 * lo + 1];
