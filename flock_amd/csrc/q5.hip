@@ -3,20 +3,21 @@
 // (benchmarks/src/nexmark/query/q5.sql, q5_plan.fmt:1-13, playground/.../nexmark/q5.dag).
 //
 // HBM-bound integer work, no MFMA.  One pass over the `auction` column (4 B / bid):
-//   range  : a sampling kernel (4 cache lines per tile, <1 % of the column) estimates every pane's key range;
-//            the host turns it into a per-window direct-address counter array [base, base + range) when the
-//            ranges are affordable ("dense" group-by; NEXMark ids are dense and time-ordered).  Keys that fall
-//            outside the estimate -- or every key when the ranges are not affordable -- go to a per-window
-//            open-addressing hash table instead, so the result is exact for any input.
-//   count  : rows are cut into 8192-row tiles that never straddle a pane (pane = gcd(window, hop) seconds).
-//            A workgroup pre-aggregates its tile in LDS: a direct-mapped histogram over [tile min, tile max]
-//            when that span fits (ds_add_u32, no CAS), else an LDS hash table.  Half of all bids hit one
-//            auction id (event.rs:355-359): each wave keeps that id and its count in scalar registers
+//   range  : a sampling kernel (<1 % of the column) estimates every pane's key range (pane = gcd(window, hop)
+//            seconds of rows); the host turns it into one direct-address counter array [base, base + range) per
+//            PANE when the ranges are affordable ("dense" group-by: NEXMark ids are dense and time-ordered).
+//            Keys outside a pane's estimate -- or every key when the ranges are not affordable -- go to a
+//            per-WINDOW open-addressing hash table instead, so the result is exact for any input.
+//   count  : rows are cut into 8192-row tiles that never straddle a pane.  A workgroup pre-aggregates its tile in
+//            LDS: a direct-mapped histogram over [tile min, tile max] (ds_add_u32, no CAS).  Half of all bids hit
+//            one auction id (event.rs:355-359): each wave keeps that id and its count in scalar registers
 //            (ballot + s_bcnt1) and only sends the other keys to LDS, so the hot key costs no LDS conflicts.
-//            The tile's distinct (key, count) pairs are then added with fire-and-forget global atomics to the
-//            counters of EVERY window that contains the pane (pane sharing: a bid is read once although it
-//            belongs to window/hop windows).  Adjacent tiles touch adjacent counters, so the atomics coalesce.
-//   max    : per-window maximum and group count over counters + hash table.
+//            The tile's distinct (key, count) pairs are added with ONE fire-and-forget global atomic each to the
+//            pane's counters (pane sharing: a bid is read once and counted once although it belongs to
+//            window/hop windows).  Adjacent tiles touch adjacent counters, so the atomics coalesce.
+//            Ragged tiles and tiles whose keys spread wider than the histogram are queued for a small second
+//            kernel with the general LDS-hash path.
+//   max    : per window, count(key) = sum of its panes' counters + its hash table; maximum and group count.
 //   select : rows whose count equals the window maximum.
 #include <algorithm>
 
@@ -36,11 +37,19 @@ static_assert(kSlots == (1 << kSlotBits), "slot bits");
 constexpr int kLdsMaxProbe = 24;
 constexpr uint32_t kFib = 0x9E3779B1u;
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
+constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
+
+struct PaneDesc {
+    int64_t base;      // first key of the pane's direct-address range (multiple of 4)
+    uint64_t cnt_off;  // offset of the pane's counters in the counter arena (u32 units, multiple of 4)
+    uint32_t range;    // number of counters (multiple of 4; 0: every key of this pane goes to the hash tables)
+    uint32_t pad;
+};
 
 struct WinDesc {
-    int64_t base;      // first key of the direct-address range
-    uint64_t cnt_off;  // offset of the window's counters in the counter arena (u32 units)
-    uint32_t range;    // number of counters (0: every key of this window goes to the hash table)
+    int64_t base;      // union of the window's pane ranges (multiple of 4)
+    uint32_t range;    // multiple of 4; 0 when the window has no direct-address panes
+    int32_t pane_lo, pane_hi;
     uint32_t pad;
 };
 
@@ -64,7 +73,7 @@ __device__ __forceinline__ bool lds_hash_insert(uint64_t *tab, uint32_t key, uin
 }
 
 // Window hash table (packed {key:32,count:32}, 0 = empty; counts >= 1 so a live slot is never 0).
-__device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t key, uint32_t c, uint32_t *err) {
+__device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t key, uint32_t c, uint32_t *used, uint32_t *err) {
     uint32_t s = (uint32_t)(((uint64_t)(key * kFib) * cap) >> 32);
     const uint64_t mine = ((uint64_t)key << 32) | c;
 #pragma unroll 1
@@ -73,8 +82,10 @@ __device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t 
         if (cur == 0) {
             uint64_t expected = 0;
             if (__hip_atomic_compare_exchange_strong(&tab[s], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicAdd(used, 1u);
                 return;
+            }
             cur = expected;
         }
         if ((uint32_t)(cur >> 32) == key) {
@@ -86,18 +97,40 @@ __device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t 
     atomicOr(err, 1u);
 }
 
-// Adds one aggregated (key, count) pair of a tile to every window that contains the tile's pane.
-__device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, int32_t wp0, int32_t wp1,
-                                          const int32_t *__restrict__ pane_win_idx, const WinDesc *__restrict__ wins,
-                                          uint32_t *counters, uint64_t *tables, uint32_t cap, uint32_t *err) {
-    for (int wi = wp0; wi < wp1; ++wi) {
-        const int32_t w = pane_win_idx[wi];
-        const WinDesc d = wins[w];
-        const uint64_t idx = (uint64_t)((int64_t)key - d.base);
-        if (idx < (uint64_t)d.range)
-            __hip_atomic_fetch_add(&counters[d.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            table_add(tables + (size_t)w * cap, cap, (uint32_t)key, c, err);
+__device__ __forceinline__ uint32_t table_find(const uint64_t *tab, uint32_t cap, uint32_t key) {
+    uint32_t s = (uint32_t)(((uint64_t)(key * kFib) * cap) >> 32);
+#pragma unroll 1
+    for (uint32_t probe = 0, lim = cap < 2048u ? cap : 2048u; probe < lim; ++probe) {
+        const uint64_t cur = tab[s];
+        if (cur == 0) return 0;
+        if ((uint32_t)(cur >> 32) == key) return (uint32_t)cur;
+        s = (s + 1 == cap) ? 0 : s + 1;
+    }
+    return 0;
+}
+
+struct FlushArgs {
+    PaneDesc pane;             // the tile's pane
+    int32_t wp0, wp1;          // CSR range of the windows that contain the pane
+    const int32_t *pane_win_idx;
+    uint32_t *counters;
+    uint64_t *tables;
+    uint32_t cap;
+    uint32_t *tab_used;        // per window: live slots of its hash table
+    uint32_t *err;
+};
+
+// Adds one aggregated (key, count) pair of a tile: one atomic on the pane's counters, or -- for a key outside the
+// pane's estimated range -- one hash-table update per window that contains the pane.
+__device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, const FlushArgs &f) {
+    const uint64_t idx = (uint64_t)((int64_t)key - f.pane.base);
+    if (idx < (uint64_t)f.pane.range) {
+        __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (int wi = f.wp0; wi < f.wp1; ++wi) {
+        const int32_t w = f.pane_win_idx[wi];
+        table_add(f.tables + (size_t)w * f.cap, f.cap, (uint32_t)key, c, &f.tab_used[w], f.err);
     }
 }
 
@@ -148,183 +181,12 @@ __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restr
     }
 }
 
-// ---- count ---------------------------------------------------------------------------------------------
-struct FlushArgs {
-    int32_t wp0, wp1;
-    const int32_t *pane_win_idx;
-    const WinDesc *wins;
-    uint32_t *counters;
-    uint64_t *tables;
-    uint32_t cap;
-    uint32_t *err;
-};
-
-__device__ __noinline__ void emit_pair_slow(int32_t key, uint32_t c, const FlushArgs &f) {
-    emit_pair(key, c, f.wp0, f.wp1, f.pane_win_idx, f.wins, f.counters, f.tables, f.cap, f.err);
-}
-
-// Fast path: the tile's keys span fewer than kHist ids -> direct-mapped LDS histogram, no CAS anywhere.
-template <bool FULL>
-__device__ __forceinline__ void tile_direct(const int32_t (&k)[kQ5Iters][4], const TileRange &tr, int32_t mn, uint32_t span,
-                                            uint32_t *hist, const FlushArgs &f) {
-    const int lane = lane_id();
-    // hot key of this wave, kept in scalar registers across iterations
-    int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
-    uint32_t hot_cnt = 0;
-#pragma unroll
-    for (int it = 0; it < kQ5Iters; ++it) {
-        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-        bool v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = FULL || (r0 + j >= tr.lo && r0 + j < tr.hi);
-        uint64_t b0 = __ballot(v[0] && k[it][0] == hot);
-        if (__popcll((unsigned long long)b0) < kHotMin) {
-            // the candidate went cold: park its count, then try this iteration's first two distinct keys
-            if (hot_cnt) {
-                if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
-                hot_cnt = 0;
-            }
-            const uint64_t live = FULL ? ~0ull : __ballot(v[0]);
-            if (live) {
-                const int l1 = __ffsll((unsigned long long)live) - 1;
-                const int32_t c1 = __builtin_amdgcn_readlane(k[it][0], l1);
-                const uint64_t m1 = __ballot(v[0] && k[it][0] == c1);
-                hot = c1;
-                b0 = m1;
-                const uint64_t rest = live & ~m1;
-                if (__popcll((unsigned long long)m1) < kHotMin && rest) {
-                    const int l2 = __ffsll((unsigned long long)rest) - 1;
-                    const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
-                    const uint64_t m2 = __ballot(v[0] && k[it][0] == c2);
-                    if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
-                        hot = c2;
-                        b0 = m2;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool is_hot = v[j] && k[it][j] == hot;
-            const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
-            hot_cnt += (uint32_t)__popcll((unsigned long long)b);
-            // branch-free: lanes with nothing to add hit their private scratch bin
-            const uint32_t bin = (is_hot || !v[j]) ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
-            atomicAdd(&hist[bin], 1u);
-        }
-    }
-    if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
-    __syncthreads();
-    for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
-        const uint32_t c = hist[s];
-        if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f.wp0, f.wp1, f.pane_win_idx, f.wins, f.counters, f.tables, f.cap, f.err);
-    }
-}
-
-// Slow path (keys of the tile are spread wider than the histogram): LDS hash table; keys are re-read (L2-hot)
-// in a rolled loop to keep this path small.
-__device__ __forceinline__ void tile_hash(const int32_t *__restrict__ auction, TileRange tr, uint64_t *slots, FlushArgs f) {
-    const int lane = lane_id();
-#pragma unroll 1
-    for (int it = 0; it < kQ5Iters; ++it) {
-        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-        int32_t k[4];
-        bool v[4];
-        uint32_t c[4] = {1, 1, 1, 1};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = r0 + j >= tr.lo && r0 + j < tr.hi;
-            k[j] = v[j] ? auction[r0 + j] : 0;
-        }
-        const uint64_t live = __ballot(v[0]);
-        if (live) {  // wave-level collapse of the wave's first key
-            const int src = __ffsll((unsigned long long)live) - 1;
-            const int32_t hot = __builtin_amdgcn_readlane(k[0], src);
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool m = v[j] && k[j] == hot;
-                cnt += (uint32_t)__popcll((unsigned long long)__ballot(m));
-                v[j] = v[j] && !m;
-            }
-            if (lane == src && !lds_hash_insert(slots, (uint32_t)hot, cnt)) emit_pair_slow(hot, cnt, f);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 4; ++j)
-                if (v[i] && v[j] && k[i] == k[j]) {
-                    c[i] += c[j];
-                    v[j] = false;
-                }
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j)
-            if (v[j] && !lds_hash_insert(slots, (uint32_t)k[j], c[j])) emit_pair_slow(k[j], c[j], f);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int s = threadIdx.x; s < kSlots; s += kBlock) {
-        const uint64_t e = slots[s];
-        if (e) emit_pair_slow((int32_t)(uint32_t)(e >> 32), (uint32_t)e, f);
-    }
-}
-
-// Ragged tiles (first / last tile of a pane): small rolled-loop version of the same logic.
-__device__ __forceinline__ void tile_generic(const int32_t *__restrict__ auction, TileRange tr, uint32_t *hist, int32_t *s_red,
-                                          FlushArgs f) {
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
-#pragma unroll 1
-    for (int64_t r = tr.lo + threadIdx.x; r < tr.hi; r += kBlock) {
-        const int32_t key = auction[r];
-        mn = min(mn, key);
-        mx = max(mx, key);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, 64));
-        mx = max(mx, __shfl_xor(mx, o, 64));
-    }
-    if (lane == 0) {
-        s_red[wave] = mn;
-        s_red[4 + wave] = mx;
-    }
-    __syncthreads();
-    mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-    const uint32_t span = (uint32_t)mx - (uint32_t)mn;
-    if (span >= (uint32_t)kHist) {
-        tile_hash(auction, tr, reinterpret_cast<uint64_t *>(hist), f);
-        return;
-    }
-#pragma unroll 1
-    for (int64_t r0 = tr.lo; r0 < tr.hi; r0 += kBlock) {
-        const int64_t r = r0 + threadIdx.x;
-        const bool v = r < tr.hi;
-        const int32_t key = v ? auction[r] : 0;
-        const uint64_t live = __ballot(v);
-        const int src = __ffsll((unsigned long long)live) - 1;  // lane 0 of a live wave is always live
-        if (live) {
-            const int32_t hot = __builtin_amdgcn_readlane(key, src);
-            const bool m = v && key == hot;
-            const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(m));
-            if (lane == src) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], cnt);
-            else if (v && !m) atomicAdd(&hist[(uint32_t)key - (uint32_t)mn], 1u);
-        }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
-        const uint32_t c = hist[s];
-        if (c) emit_pair_slow((int32_t)((uint32_t)mn + s), c, f);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
+// ---- count: fast kernel (full tiles whose keys fit the LDS histogram) -------------------------------------------
+__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, SegTiles st,
+                                                          const PaneDesc *__restrict__ panes,
                                                           const int32_t *__restrict__ pane_win_ptr,
-                                                          const int32_t *__restrict__ pane_win_idx,
-                                                          const WinDesc *__restrict__ wins, uint32_t *counters,
-                                                          uint64_t *tables, uint32_t cap, uint32_t *err,
+                                                          const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
+                                                          uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
                                                           int32_t *slow_list) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
     __shared__ int32_t s_red[8];
@@ -336,27 +198,28 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     FlushArgs f;
     f.wp0 = pane_win_ptr[tr.seg];
     f.wp1 = pane_win_ptr[tr.seg + 1];
-    f.pane_win_idx = pane_win_idx;
-    f.wins = wins;
-    f.counters = counters;
-    f.tables = tables;
-    f.cap = cap;
-    f.err = err;
     if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
-    const bool full = tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile;
-    if (!full) {  // ragged first / last tile of a pane: left to q5_count_slow_kernel
+    if (tr.lo != tr.tile_begin || tr.hi != tr.tile_begin + kQ5Tile) {  // ragged first / last tile of a pane
         if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
         return;
     }
+    f.pane = panes[tr.seg];
+    f.pane_win_idx = pane_win_idx;
+    f.counters = counters;
+    f.tables = tables;
+    f.cap = cap;
+    f.tab_used = tab_used;
+    f.err = err;
+
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     int32_t k[kQ5Iters][4];
-    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
         const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
         k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
     }
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         mn = min(mn, min(min(k[it][0], k[it][1]), min(k[it][2], k[it][3])));
@@ -375,103 +238,193 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
     mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
     const uint32_t span = (uint32_t)mx - (uint32_t)mn;
-    if (span >= (uint32_t)kHist) {  // keys spread wider than the histogram: hash path in q5_count_slow_kernel
+    if (span >= (uint32_t)kHist) {  // keys spread wider than the histogram: general path in q5_count_slow_kernel
         if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
         return;
     }
-    tile_direct<true>(k, tr, mn, span, hist, f);
+
+    // hot key of this wave, kept in scalar registers across iterations
+    int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
+    uint32_t hot_cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kQ5Iters; ++it) {
+        uint64_t b0 = __ballot(k[it][0] == hot);
+        if (__popcll((unsigned long long)b0) < kHotMin) {
+            // the candidate went cold: park its count, then try this iteration's first two distinct keys
+            if (hot_cnt) {
+                if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+                hot_cnt = 0;
+            }
+            const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
+            const uint64_t m1 = __ballot(k[it][0] == c1);
+            hot = c1;
+            b0 = m1;
+            if (__popcll((unsigned long long)m1) < kHotMin && ~m1) {
+                const int l2 = __ffsll((unsigned long long)~m1) - 1;
+                const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                const uint64_t m2 = __ballot(k[it][0] == c2);
+                if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                    hot = c2;
+                    b0 = m2;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool is_hot = k[it][j] == hot;
+            const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
+            hot_cnt += (uint32_t)__popcll((unsigned long long)b);
+            // branch-free: lanes holding the hot key hit their private scratch bin instead
+            const uint32_t bin = is_hot ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
+        const uint32_t c = hist[s];
+        if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
+    }
 }
 
-// Tiles the fast kernel declined (ragged, or keys spread wider than the LDS histogram).
+// ---- count: general kernel for the tiles the fast kernel declined ------------------------------------------------
 __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__restrict__ auction, SegTiles st,
+                                                               const PaneDesc *__restrict__ panes,
                                                                const int32_t *__restrict__ pane_win_ptr,
-                                                               const int32_t *__restrict__ pane_win_idx,
-                                                               const WinDesc *__restrict__ wins, uint32_t *counters,
-                                                               uint64_t *tables, uint32_t cap, uint32_t *err,
-                                                               const int32_t *__restrict__ slow_list) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
-    __shared__ int32_t s_red[8];
+                                                               const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
+                                                               uint64_t *tables, uint32_t cap, uint32_t *tab_used,
+                                                               uint32_t *err, const int32_t *__restrict__ slow_list) {
+    __shared__ __attribute__((aligned(16))) uint64_t slots[kSlots];
+    const int lane = lane_id();
     const int32_t n = slow_list[0];
     for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        __syncthreads();  // previous tile's flush is done with `hist`
-        for (int s = threadIdx.x; s < kHist + kHistPad; s += kBlock) hist[s] = 0;
+        __syncthreads();  // previous tile's flush is done with `slots`
+        for (int s = threadIdx.x; s < kSlots; s += kBlock) slots[s] = 0;
         const TileRange tr = locate_tile(st, slow_list[1 + i], kQ5Tile);
         FlushArgs f;
+        f.pane = panes[tr.seg];
         f.wp0 = pane_win_ptr[tr.seg];
         f.wp1 = pane_win_ptr[tr.seg + 1];
         f.pane_win_idx = pane_win_idx;
-        f.wins = wins;
         f.counters = counters;
         f.tables = tables;
         f.cap = cap;
+        f.tab_used = tab_used;
         f.err = err;
         __syncthreads();
-        tile_generic(auction, tr, hist, s_red, f);
+#pragma unroll 1
+        for (int64_t r0 = tr.lo; r0 < tr.hi; r0 += kBlock) {
+            const int64_t r = r0 + threadIdx.x;
+            const bool v = r < tr.hi;
+            const int32_t key = v ? auction[r] : 0;
+            const uint64_t live = __ballot(v);
+            if (!live) continue;
+            // wave-level collapse of the wave's first key, the rest one LDS hash insert per lane
+            const int src = __ffsll((unsigned long long)live) - 1;
+            const int32_t hot = __builtin_amdgcn_readlane(key, src);
+            const bool m = v && key == hot;
+            const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(m));
+            if (lane == src) {
+                if (!lds_hash_insert(slots, (uint32_t)hot, cnt)) emit_pair(hot, cnt, f);
+            } else if (v && !m) {
+                if (!lds_hash_insert(slots, (uint32_t)key, 1u)) emit_pair(key, 1u, f);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = threadIdx.x; s < kSlots; s += kBlock) {
+            const uint64_t e = slots[s];
+            if (e) emit_pair((int32_t)(uint32_t)(e >> 32), (uint32_t)e, f);
+        }
     }
 }
 
 // ---- max + group count, then select ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void q5_max_kernel(const WinDesc *__restrict__ wins, const uint32_t *__restrict__ counters,
-                                                        const uint64_t *__restrict__ tables, uint32_t cap, uint64_t *win_max,
-                                                        uint64_t *win_groups) {
-    const int32_t w = blockIdx.y;
-    const WinDesc d = wins[w];
-    const uint32_t *cnt = counters + d.cnt_off;
-    uint32_t best = 0, groups = 0;
-    const uint32_t n4 = d.range / 4;  // ranges are multiples of 4, cnt_off too
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
-        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
-        best = max(max(best, c.x), max(max(c.y, c.z), c.w));
-        groups += (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0);
-    }
-    const uint64_t *tab = tables + (size_t)w * cap;
-    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) {
-        const uint64_t e = tab[s];
-        if (e) {
-            ++groups;
-            best = max(best, (uint32_t)e);
+// count(window, key) = sum over the window's panes of counters[key - pane.base] + the window's hash-table entry.
+// Bases and ranges are multiples of 4, so an aligned 4-key group is entirely inside or outside a pane's range.
+__device__ __forceinline__ uint4 window_counts4(const WinDesc &d, const PaneDesc *s_panes, int n_panes,
+                                                const uint32_t *__restrict__ counters, int64_t k0) {
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int p = 0; p < n_panes; ++p) {
+        const PaneDesc pd = s_panes[p];
+        const uint64_t idx = (uint64_t)(k0 - pd.base);
+        if (idx < (uint64_t)pd.range) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(counters + pd.cnt_off + idx);
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
         }
     }
-    best = wave_max_u32(best);
-    const uint64_t g = wave_sum_u64(groups);
-    if (lane_id() == 0) {
-        if (best) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
-        if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
-    }
+    return acc;
 }
 
-__global__ __launch_bounds__(kBlock) void q5_select_kernel(const WinDesc *__restrict__ wins, const uint32_t *__restrict__ counters,
-                                                           const uint64_t *__restrict__ tables, uint32_t cap,
-                                                           const uint64_t *__restrict__ win_max, uint32_t *cursor,
-                                                           uint32_t out_cap, int32_t *out_win, int32_t *out_key) {
+template <bool SELECT>
+__global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restrict__ wins, const PaneDesc *__restrict__ panes,
+                                                         const uint32_t *__restrict__ counters,
+                                                         const uint64_t *__restrict__ tables, uint32_t cap,
+                                                         const uint32_t *__restrict__ tab_used, uint64_t *win_max,
+                                                         uint64_t *win_groups, uint32_t *cursor, uint32_t out_cap,
+                                                         int32_t *out_win, int32_t *out_key) {
+    __shared__ PaneDesc s_panes[kMaxWinPanes];
     const int32_t w = blockIdx.y;
-    const uint32_t mx = (uint32_t)win_max[w];
-    if (mx == 0) return;  // empty window: MAX is NULL, the inner join emits nothing
     const WinDesc d = wins[w];
-    const uint32_t *cnt = counters + d.cnt_off;
+    const int n_panes = d.range ? d.pane_hi - d.pane_lo : 0;
+    if ((int)threadIdx.x < n_panes) s_panes[threadIdx.x] = panes[d.pane_lo + threadIdx.x];
+    __syncthreads();
+    const uint64_t *tab = tables + (size_t)w * cap;
+    const bool has_tab = tab_used[w] != 0;
+    const uint32_t mx = SELECT ? (uint32_t)win_max[w] : 0;
+    if (SELECT && mx == 0) return;  // empty window: MAX is NULL, the inner join emits nothing
+    uint32_t best = 0, groups = 0;
     const uint32_t n4 = d.range / 4;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
-        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
-        const uint32_t v[4] = {c.x, c.y, c.z, c.w};
+        const int64_t k0 = d.base + (int64_t)i * 4;
+        const uint4 c4 = window_counts4(d, s_panes, n_panes, counters, k0);
+        uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+        if (has_tab) {  // keys of the union range that some pane sent to the hash table
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (v[j] == mx) {
-                const uint32_t p = atomicAdd(cursor, 1u);
-                if (p < out_cap) {
-                    out_win[p] = w;
-                    out_key[p] = (int32_t)(d.base + (int64_t)i * 4 + j);
+            for (int j = 0; j < 4; ++j) c[j] += table_find(tab, cap, (uint32_t)(int32_t)(k0 + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (SELECT) {
+                if (c[j] == mx) {
+                    const uint32_t p = atomicAdd(cursor, 1u);
+                    if (p < out_cap) {
+                        out_win[p] = w;
+                        out_key[p] = (int32_t)(k0 + j);
+                    }
                 }
+            } else {
+                best = max(best, c[j]);
+                groups += c[j] != 0;
             }
+        }
     }
-    const uint64_t *tab = tables + (size_t)w * cap;
-    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) {
-        const uint64_t e = tab[s];
-        if (e && (uint32_t)e == mx) {
-            const uint32_t p = atomicAdd(cursor, 1u);
-            if (p < out_cap) {
-                out_win[p] = w;
-                out_key[p] = (int32_t)(uint32_t)(e >> 32);
+    if (has_tab) {  // table entries whose key lies outside the union range are complete on their own
+        for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) {
+            const uint64_t e = tab[s];
+            if (!e) continue;
+            const int64_t key = (int32_t)(uint32_t)(e >> 32);
+            if ((uint64_t)(key - d.base) < (uint64_t)d.range) continue;  // already counted above
+            if (SELECT) {
+                if ((uint32_t)e == mx) {
+                    const uint32_t p = atomicAdd(cursor, 1u);
+                    if (p < out_cap) {
+                        out_win[p] = w;
+                        out_key[p] = (int32_t)key;
+                    }
+                }
+            } else {
+                best = max(best, (uint32_t)e);
+                ++groups;
             }
+        }
+    }
+    if (!SELECT) {
+        best = wave_max_u32(best);
+        const uint64_t g = wave_sum_u64(groups);
+        if (lane_id() == 0) {
+            if (best) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
+            if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
         }
     }
 }
@@ -494,15 +447,19 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     // pane -> windows CSR, window row counts
     std::vector<int32_t> ptr(n_panes + 1, 0), idx;
     int64_t max_win_rows = 0, covered_rows = 0;
+    int max_win_panes = 0;
     for (int w = 0; w < n_win; ++w) {
         for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p) ++ptr[p + 1];
         const int64_t rows = win->pane_row_offsets[win->win_pane_hi[w]] - win->pane_row_offsets[win->win_pane_lo[w]];
         max_win_rows = std::max(max_win_rows, rows);
-        covered_rows += rows;
+        max_win_panes = std::max(max_win_panes, win->win_pane_hi[w] - win->win_pane_lo[w]);
     }
     if (max_win_rows >= (int64_t(1) << 32))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: a window holds >= 2^32 rows (32-bit counters)");
-    for (int p = 0; p < n_panes; ++p) ptr[p + 1] += ptr[p];
+    for (int p = 0; p < n_panes; ++p) {
+        if (ptr[p + 1]) covered_rows += win->pane_row_offsets[p + 1] - win->pane_row_offsets[p];
+        ptr[p + 1] += ptr[p];
+    }
     idx.resize(ptr[n_panes]);
     {
         std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
@@ -528,14 +485,17 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     if (!idx.empty())
         FG_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
 
-    // ---- key-range estimate per pane -> direct-address ranges per window
+    // ---- key-range estimate per pane -> direct-address range per pane, union range per window
     int32_t *d_rng = nullptr, *h_rng = nullptr;  // [0, n_panes) min, [n_panes, 2 n_panes) max
     FG_TRY(arena_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &d_rng));
     FG_TRY(pinned_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &h_rng));
+    std::vector<PaneDesc> panes((size_t)std::max(n_panes, 1));
     std::vector<WinDesc> wins((size_t)std::max(n_win, 1));
-    uint64_t cnt_total = 0;
-    bool dense = false;
-    if (st.n_tiles > 0 && n_win > 0) {
+    for (auto &p : panes) p = PaneDesc{0, 0, 0, 0};
+    for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
+    uint64_t cnt_total = 0, scan_total = 0;
+    bool dense = st.n_tiles > 0 && n_win > 0 && max_win_panes <= kMaxWinPanes;
+    if (dense) {
         FG_HIP(ctx, hipMemsetAsync(d_rng, 0x7F, sizeof(int32_t) * n_panes, ctx->stream));             // min = 0x7f7f7f7f
         FG_HIP(ctx, hipMemsetAsync(d_rng + n_panes, 0x80, sizeof(int32_t) * n_panes, ctx->stream));   // max = 0x80808080
         {
@@ -546,49 +506,61 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         FG_TRY(check_launch(ctx, "q5_range_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * 2 * n_panes, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        dense = true;
+        for (int p = 0; p < n_panes && dense; ++p) {
+            if (ptr[p + 1] == ptr[p] || se[p] <= sb[p] || h_rng[p] > h_rng[n_panes + p]) continue;  // unused / empty pane
+            const int64_t lo = h_rng[p], hi = h_rng[n_panes + p];
+            const int64_t span = hi - lo, margin = std::max<int64_t>(4096, span / 16);
+            const int64_t base = (lo - margin) & ~int64_t(3);
+            const int64_t range = ((hi + margin + 1 - base) + 3) & ~int64_t(3);
+            if (range >= (int64_t(1) << 31)) { dense = false; break; }
+            panes[p] = PaneDesc{base, cnt_total, (uint32_t)range, 0};
+            cnt_total += (uint64_t)range;
+        }
         for (int w = 0; w < n_win && dense; ++w) {
             int64_t lo = INT64_MAX, hi = INT64_MIN;
             for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p)
-                if (se[p] > sb[p] && h_rng[p] <= h_rng[n_panes + p]) {
-                    lo = std::min<int64_t>(lo, h_rng[p]);
-                    hi = std::max<int64_t>(hi, h_rng[n_panes + p]);
+                if (panes[p].range) {
+                    lo = std::min(lo, panes[p].base);
+                    hi = std::max(hi, panes[p].base + (int64_t)panes[p].range);
                 }
-            WinDesc &d = wins[w];
-            d.base = 0; d.range = 0; d.cnt_off = cnt_total; d.pad = 0;
-            if (lo > hi) continue;  // empty window
-            const int64_t span = hi - lo, margin = std::max<int64_t>(4096, span / 16);
-            const int64_t range = ((span + 2 * margin + 1) + 3) & ~int64_t(3);
-            if (range >= (int64_t(1) << 31)) { dense = false; break; }
-            d.base = lo - margin;
-            d.range = (uint32_t)range;
-            cnt_total += (uint64_t)range;
+            if (lo >= hi) continue;
+            if (hi - lo >= (int64_t(1) << 31)) { dense = false; break; }
+            wins[w].base = lo;
+            wins[w].range = (uint32_t)(hi - lo);
+            scan_total += (uint64_t)(hi - lo);
         }
-        // affordable = the counters cost no more than a few passes over the input
-        if (dense && cnt_total * 4 > std::max<uint64_t>(uint64_t(256) << 20, (uint64_t)covered_rows * 4 * 2)) dense = false;
+        // affordable = counters + their scans cost no more than a few passes over the input
+        const uint64_t budget = std::max<uint64_t>(uint64_t(256) << 20, (uint64_t)covered_rows * 4 * 2);
+        if (dense && (cnt_total * 4 > budget || scan_total * 4 > 2 * budget)) dense = false;
     }
     if (!dense) {
         cnt_total = 0;
-        for (auto &d : wins) { d.base = 0; d.range = 0; d.cnt_off = 0; d.pad = 0; }
+        for (auto &p : panes) p = PaneDesc{0, 0, 0, 0};
+        for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
     }
+    PaneDesc *d_panes = nullptr, *h_panes = nullptr;
     WinDesc *d_wins = nullptr, *h_wins = nullptr;
+    FG_TRY(arena_get_t(ctx, "q5.panes", panes.size(), &d_panes));
+    FG_TRY(pinned_get_t(ctx, "q5.panes", panes.size(), &h_panes));
     FG_TRY(arena_get_t(ctx, "q5.wins", wins.size(), &d_wins));
     FG_TRY(pinned_get_t(ctx, "q5.wins", wins.size(), &h_wins));
+    std::copy(panes.begin(), panes.end(), h_panes);
     std::copy(wins.begin(), wins.end(), h_wins);
+    FG_HIP(ctx, hipMemcpyAsync(d_panes, h_panes, panes.size() * sizeof(PaneDesc), hipMemcpyHostToDevice, ctx->stream));
     FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
     uint32_t *counters = nullptr;
     FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
 
-    // device scalars: [0 .. n_win) win_max, [n_win .. 2 n_win) win_groups, then cursor + err (as 2 x u32)
-    const size_t n_meta = (size_t)2 * n_win + 1;
+    // device scalars: [0, n_win) win_max, [n_win, 2 n_win) win_groups, then cursor + err (2 x u32), then tab_used (u32 x n_win)
+    const size_t n_meta = (size_t)2 * n_win + 1 + ((size_t)n_win + 1) / 2 + 1;
     uint64_t *d_meta = nullptr, *h_meta = nullptr;
     FG_TRY(arena_get_t(ctx, "q5.meta", n_meta, &d_meta));
     FG_TRY(pinned_get_t(ctx, "q5.meta", n_meta, &h_meta));
-    uint32_t *d_cursor = reinterpret_cast<uint32_t *>(d_meta + 2 * n_win), *d_err = d_cursor + 1;
+    uint32_t *d_cursor = reinterpret_cast<uint32_t *>(d_meta + 2 * n_win), *d_err = d_cursor + 1, *d_used = d_cursor + 2;
 
     // hash tables: only stragglers in dense mode; every group otherwise (sized from the density seen last call)
     double rpg = ctx->q5_rows_per_group < 1.0 ? 1.0 : ctx->q5_rows_per_group;
-    uint64_t cap64 = dense ? 4096 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
+    uint64_t cap64 = dense ? 1024 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
     uint32_t out_cap = 1u << 16;
     std::vector<int32_t> h_win, h_key;
     uint32_t n_sel = 0;
@@ -598,41 +570,44 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         const uint32_t cap = (uint32_t)cap64;
         uint64_t *tables = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.tables", (size_t)cap * std::max(n_win, 1), &tables));
-        int32_t *o_win = nullptr, *o_key = nullptr;
+        int32_t *o_win = nullptr, *o_key = nullptr, *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.sel_win", out_cap, &o_win));
         FG_TRY(arena_get_t(ctx, "q5.sel_key", out_cap, &o_key));
+        FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         FG_HIP(ctx, hipMemsetAsync(tables, 0, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
         if (cnt_total) FG_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t) * cnt_total, ctx->stream));
         FG_HIP(ctx, hipMemsetAsync(d_meta, 0, sizeof(uint64_t) * n_meta, ctx->stream));
-        int32_t *slow_list = nullptr;
-        FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         FG_HIP(ctx, hipMemsetAsync(slow_list, 0, sizeof(int32_t), ctx->stream));
         if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
-                hipLaunchKernelGGL(q5_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
-                                   bid->rows, st, d_ptr, d_idx, d_wins, counters, tables, cap, d_err, slow_list);
+                hipLaunchKernelGGL(q5_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, st,
+                                   d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
-            LaunchScope ls(ctx, "q5_count_slow_kernel");
-            const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
-            hipLaunchKernelGGL(q5_count_slow_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, bid->auction, st, d_ptr, d_idx,
-                               d_wins, counters, tables, cap, d_err, slow_list);
+            {
+                LaunchScope ls(ctx, "q5_count_slow_kernel");
+                const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
+                hipLaunchKernelGGL(q5_count_slow_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, bid->auction, st, d_panes,
+                                   d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list);
+            }
+            FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
         }
-        FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
         if (n_win > 0) {
-            const uint64_t per_win = std::max<uint64_t>(cap, n_win ? cnt_total / n_win / 4 : 0);
-            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 4), 1), 64);
+            const uint64_t per_win = std::max<uint64_t>(cap, scan_total / n_win / 4);
+            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
-                hipLaunchKernelGGL(q5_max_kernel, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins, counters,
-                                   tables, cap, d_meta, d_meta + n_win);
+                hipLaunchKernelGGL(q5_scan_kernel<false>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
+                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, d_cursor, out_cap, o_win,
+                                   o_key);
             }
             FG_TRY(check_launch(ctx, "q5_max_kernel"));
             {
                 LaunchScope ls(ctx, "q5_select_kernel");
-                hipLaunchKernelGGL(q5_select_kernel, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins, counters,
-                                   tables, cap, d_meta, d_cursor, out_cap, o_win, o_key);
+                hipLaunchKernelGGL(q5_scan_kernel<true>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
+                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, d_cursor, out_cap, o_win,
+                                   o_key);
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
@@ -651,8 +626,9 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         h_win.resize(n_sel);
         h_key.resize(n_sel);
         if (n_sel) {
-            FG_HIP(ctx, hipMemcpy(h_win.data(), o_win, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost));
-            FG_HIP(ctx, hipMemcpy(h_key.data(), o_key, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost));
+            FG_HIP(ctx, hipMemcpyAsync(h_win.data(), o_win, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(h_key.data(), o_key, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         break;
     }

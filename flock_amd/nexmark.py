@@ -90,6 +90,13 @@ class NEXMarkStream:
     def window_schedule(self, relation: str, window: Optional[Window] = None) -> WindowSchedule:
         s = self.source
         window = window or s.window
+        cache = self.__dict__.setdefault("_schedules", {})
+        if (relation, window) not in cache:
+            cache[(relation, window)] = self._build_schedule(relation, window)
+        return cache[(relation, window)]
+
+    def _build_schedule(self, relation: str, window: Window) -> WindowSchedule:
+        s = self.source
         epochs = window_epochs(window, s.seconds)
         off = self.epoch_row_offsets(relation)
         pane = gcd(window.size, window.hop) if window.kind == "hopping" else window.size
@@ -123,11 +130,14 @@ class NEXMarkSource:
 
     def epoch_row_offsets(self, relation: str) -> np.ndarray:
         idx = {"person": 0, "auction": 1, "bid": 2}[relation]
-        # closed form: events [0, e * eps) hold c(e) rows of the relation
-        out = np.empty(self.seconds + 1, np.int64)
-        for e in range(self.seconds + 1):
-            out[e] = self.counts(0, e * self.eps)[idx]
-        return out
+        cache = self.__dict__.setdefault("_epoch_offsets", {})
+        if relation not in cache:
+            # closed form: events [0, e * eps) hold c(e) rows of the relation
+            out = np.empty(self.seconds + 1, np.int64)
+            for e in range(self.seconds + 1):
+                out[e] = self.counts(0, e * self.eps)[idx]
+            cache[relation] = out
+        return cache[relation]
 
     def generate_data(self, ctx: GpuContext, relations=("bid", "auction", "person"),
                       bid_columns=("auction", "bidder", "price", "b_date_time")) -> NEXMarkStream:
