@@ -104,6 +104,17 @@ SYMBOLS = {
     "flockgpu_nexmark_gen_bids": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp]),
     "flockgpu_nexmark_gen_auctions": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp]),
     "flockgpu_nexmark_gen_persons": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # include/flockgpu_plan.h (ArrowSchema / ArrowArray travel as raw pointers)
+    "flockgpu_plan_create": (_i, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_vp)]),
+    "flockgpu_plan_destroy": (None, [_vp]),
+    "flockgpu_plan_recognise": (_i, [C.c_char_p, C.c_size_t, C.POINTER(_i)]),
+    "flockgpu_plan_query": (_i, [_vp]),
+    "flockgpu_plan_num_inputs": (_i, [_vp]),
+    "flockgpu_plan_input_name": (C.c_char_p, [_vp, _i]),
+    "flockgpu_plan_input_matches": (_i, [_vp, _i, _vp]),
+    "flockgpu_plan_feed": (_i, [_vp, _i, _vp, C.POINTER(_vp), _i]),
+    "flockgpu_plan_execute": (_i, [_vp, _vp, _vp]),
+    "flockgpu_plan_reset": (_i, [_vp]),
 }
 
 _lib = None

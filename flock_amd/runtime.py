@@ -1,0 +1,160 @@
+"""`ExecutionContext` -- the GPU twin of flock/src/runtime/context.rs, over the plan-level C ABI.
+
+Same surface and argument meaning as the reference:
+
+    ctx = ExecutionContext(plans=[plan_json, ...], name="SX72HzqFz1Qij4bP-00-00")
+    ctx.feed_data_sources(sources)      # sources[relation][partition][batch]   (context.rs:257-325)
+    batches = ctx.execute()             # -> [plan][batch]                      (context.rs:172-191)
+    parts = ctx.execute_partitioned()   # -> [plan][partition][batch]           (context.rs:197-216)
+    ctx.clean_data_sources()            #                                       (context.rs:227-254)
+
+`collect(ctx, streams)` restates `actor::collect` (flock-function/src/aws/actor.rs:54-79).  Plans are the
+serde_json text of the reference's physical plans; data are pyarrow RecordBatches handed over through the
+Arrow C Data Interface (what arrow-rs would export as FFI_ArrowArray).  A plan the engine does not recognise
+raises `FlockGpuError` with status FLOCKGPU_ERR_UNSUPPORTED (the reference host would keep DataFusion for it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import List, Optional, Sequence, Union
+
+from . import _ffi
+from ._ffi import FlockGpuError
+from .engine import GpuContext
+
+_ARROW_SCHEMA_BYTES, _ARROW_ARRAY_BYTES = 72, 80
+
+
+def _pa():
+    import pyarrow as pa
+    return pa
+
+
+class _Plan:
+    def __init__(self, gpu: GpuContext, text: str):
+        self.gpu, self.text = gpu, text
+        self._lib = _ffi.load()
+        raw = text.encode()
+        h = C.c_void_p()
+        gpu._check(self._lib.flockgpu_plan_create(gpu._h, raw, len(raw), C.byref(h)))
+        self.h = h
+        self.query = self._lib.flockgpu_plan_query(h)
+        self.inputs = [self._lib.flockgpu_plan_input_name(h, i).decode() for i in range(self._lib.flockgpu_plan_num_inputs(h))]
+        self.tree = json.loads(text)
+
+    def close(self):
+        if self.h:
+            self._lib.flockgpu_plan_destroy(self.h)
+            self.h = None
+
+    def matches(self, i: int, schema) -> bool:
+        buf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        schema._export_to_c(C.addressof(buf))
+        ok = self._lib.flockgpu_plan_input_matches(self.h, i, C.cast(buf, C.c_void_p)) == 1
+        _pa().Schema._import_from_c(C.addressof(buf))  # takes ownership back and releases
+        return ok
+
+    def feed(self, i: int, batches: Sequence):
+        pa = _pa()
+        batches = [b for b in batches if b is not None]
+        if not batches:
+            return
+        sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        batches[0].schema._export_to_c(C.addressof(sbuf))
+        abufs = [C.create_string_buffer(_ARROW_ARRAY_BYTES) for _ in batches]
+        for b, ab in zip(batches, abufs):
+            b._export_to_c(C.addressof(ab))
+        ptrs = (C.c_void_p * len(batches))(*[C.addressof(ab) for ab in abufs])
+        try:
+            rc = self._lib.flockgpu_plan_feed(self.h, i, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
+        finally:
+            # the library only borrowed the batches: re-import to release the exported structs
+            schema = pa.Schema._import_from_c(C.addressof(sbuf))
+            for ab in abufs:
+                pa.RecordBatch._import_from_c(C.addressof(ab), schema)
+        self.gpu._check(rc)
+
+    def execute(self):
+        pa = _pa()
+        sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        abuf = C.create_string_buffer(_ARROW_ARRAY_BYTES)
+        self.gpu._check(self._lib.flockgpu_plan_execute(self.h, C.cast(sbuf, C.c_void_p), C.cast(abuf, C.c_void_p)))
+        return pa.RecordBatch._import_from_c(C.addressof(abuf), C.addressof(sbuf))
+
+    def reset(self):
+        self.gpu._check(self._lib.flockgpu_plan_reset(self.h))
+
+
+class ExecutionContext:
+    """Cloud execution context of one function: plans + name (context.rs:103-131)."""
+
+    def __init__(self, plans: Sequence[Union[str, dict]], name: str = "flockgpu-00", gpu: Optional[GpuContext] = None,
+                 device: int = 0):
+        self.name = name
+        self._gpu = gpu or GpuContext(device)
+        self._owns_gpu = gpu is None
+        self.plans: List[_Plan] = [_Plan(self._gpu, p if isinstance(p, str) else json.dumps(p)) for p in plans]
+
+    # -- context.rs:257-325
+    def feed_data_sources(self, sources):
+        """`sources[relation][partition][batch]`.  Every plan leaf takes the first remaining source whose first
+        non-empty batch matches the leaf's columns by name (compare_schema, context.rs:402-416); a leaf without
+        a match stays an empty relation (context.rs:305-314)."""
+        sources = [list(s) for s in sources]
+        for plan in self.plans:
+            for i in range(len(plan.inputs)):
+                found = None
+                for si, partitions in enumerate(sources):
+                    first = next((b for part in partitions for b in part), None)
+                    if first is None:
+                        continue
+                    if plan.matches(i, first.schema):
+                        found = si
+                        break
+                if found is not None:
+                    partitions = sources.pop(found)
+                    plan.feed(i, [b for part in partitions for b in part])
+
+    # -- context.rs:172-191
+    def execute(self):
+        return [[plan.execute()] for plan in self.plans]
+
+    # -- context.rs:197-216: a GPU stage is one output partition (hash partition placement is unobservable, section 8 a6)
+    def execute_partitioned(self):
+        return [[[plan.execute()]] for plan in self.plans]
+
+    # -- context.rs:227-254
+    def clean_data_sources(self):
+        for plan in self.plans:
+            plan.reset()
+
+    # -- context.rs:328-337
+    def is_shuffling(self) -> bool:
+        def shuffling(t):
+            return (t.get("execution_plan") == "coalesce_batches_exec"
+                    and isinstance(t.get("input"), dict) and t["input"].get("execution_plan") == "repartition_exec")
+        return bool(self.plans) and all(shuffling(p.tree) for p in self.plans)
+
+    def schema(self, index: int):
+        """Output schema of plan `index` (context.rs:222-224): taken from an execution over the current inputs."""
+        return self.plans[index].execute().schema
+
+    def close(self):
+        for p in self.plans:
+            p.close()
+        if self._owns_gpu:
+            self._gpu.close()
+
+
+def collect(ctx: ExecutionContext, streams):
+    """`actor::collect` (flock-function/src/aws/actor.rs:54-79): feed -> execute -> clean."""
+    ctx.feed_data_sources(streams)
+    if ctx.is_shuffling():
+        out = ctx.execute_partitioned()
+        assert len(out) == 1
+        out = out[0]
+    else:
+        out = ctx.execute()
+    ctx.clean_data_sources()
+    return out

@@ -1,0 +1,216 @@
+"""The drop-in boundary: serde_json physical plan + Arrow RecordBatches in, RecordBatches out
+(include/flockgpu_plan.h, flock_amd/runtime.py) -- written like the reference's own tests of
+ExecutionContext (flock/src/runtime/context.rs:420-593): build batches, feed_data_sources, execute, compare."""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLANS = os.path.join(ROOT, "tests", "golden", "plans")
+
+
+def _plan(q):
+    return open(os.path.join(PLANS, f"q{q}.json")).read()
+
+
+# ------------------------------------------------------------------ CPU: plan recognition is host logic
+def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
+    from flock_amd import _ffi, build
+    build.build()
+    lib = _ffi.load()
+    for q in (1, 2, 3, 5, 8):
+        t = _plan(q).encode()
+        got = C.c_int(0)
+        assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK
+        assert got.value == q
+    t = open(os.path.join(PLANS, "unsupported_simple_select.json")).read().encode()
+    got = C.c_int(0)
+    assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.ERR_UNSUPPORTED
+    assert lib.flockgpu_plan_recognise(b"{not json", 9, C.byref(got)) == _ffi.ERR_PLAN
+    # a q2-shaped plan with a different predicate operator is not q2
+    bad = json.loads(_plan(2))
+    bad["input"]["input"]["predicate"]["op"] = "Lt"
+    t = json.dumps(bad).encode()
+    assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.ERR_UNSUPPORTED
+    # literals are lifted from the plan, not hard-wired: modulus 7 is still a q2
+    ok = json.loads(_plan(2))
+    ok["input"]["input"]["predicate"]["left"]["right"]["value"] = {"Int64": 7}
+    t = json.dumps(ok).encode()
+    assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK and got.value == 2
+
+
+def test_plan_fixtures_match_the_generator():
+    # tests/golden/plans/*.json are produced by tools/make_plan_fixtures.py (committed with the fixtures)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(ROOT, "tools", "make_plan_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for name, fn in (("q1", mk.q1), ("q2", mk.q2), ("q3", mk.q3), ("q5", mk.q5), ("q8", mk.q8)):
+        assert json.load(open(os.path.join(PLANS, name + ".json"))) == json.loads(json.dumps(fn())), name
+
+
+# ------------------------------------------------------------------ GPU
+def _utf8(u):
+    return pa.StringArray.from_buffers(len(u), pa.py_buffer(u.offsets.tobytes()), pa.py_buffer(u.data.tobytes()))
+
+
+TS = pa.timestamp("ms")
+
+
+def _bid_batches(s, n0, n1, chunk):
+    out = []
+    for a in range(n0, n1, chunk):
+        b = s.bids(a, min(a + chunk, n1))
+        out.append(pa.record_batch([pa.array(b["auction"]), pa.array(b["bidder"]), pa.array(b["price"]),
+                                    pa.array(b["b_date_time"]).cast(TS)], names=["auction", "bidder", "price", "b_date_time"]))
+    return out
+
+
+def _auction_batches(s, n0, n1, chunk):
+    out = []
+    for a in range(n0, n1, chunk):
+        c = s.auctions(a, min(a + chunk, n1), strings=True)
+        out.append(pa.record_batch(
+            [pa.array(c["a_id"]), _utf8(c["item_name"]), _utf8(c["description"]), pa.array(c["initial_bid"]),
+             pa.array(c["reserve"]), pa.array(c["a_date_time"]).cast(TS), pa.array(c["expires"]).cast(TS),
+             pa.array(c["seller"]), pa.array(c["category"])],
+            names=["a_id", "item_name", "description", "initial_bid", "reserve", "a_date_time", "expires", "seller", "category"]))
+    return out
+
+
+def _person_batches(s, n0, n1, chunk):
+    out = []
+    for a in range(n0, n1, chunk):
+        c = s.persons(a, min(a + chunk, n1), filler=True)
+        out.append(pa.record_batch(
+            [pa.array(c["p_id"]), _utf8(c["name"]), _utf8(c["email_address"]), _utf8(c["credit_card"]), _utf8(c["city"]),
+             _utf8(c["state"]), pa.array(c["p_date_time"]).cast(TS)],
+            names=["p_id", "name", "email_address", "credit_card", "city", "state", "p_date_time"]))
+    return out
+
+
+def _partitions(batches, n):
+    """chunk batches into partitions like select_event_to_batches does (nexmark.rs:205-220)"""
+    return [batches[i::n] for i in range(n)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from flock_amd import GpuContext
+    g = GpuContext(0)
+    yield g
+    g.close()
+
+
+@pytest.mark.gpu
+def test_q1_q2_through_execution_context(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=4, eps=20_000)
+    ctx = ExecutionContext([_plan(1)], name="q1-00", gpu=gpu)
+    ctx2 = ExecutionContext([_plan(2)], name="q2-00", gpu=gpu)
+    for epoch in range(3):                                     # ElementWise: one collect per epoch
+        n0, n1 = epoch * 20_000, (epoch + 1) * 20_000
+        batches = _bid_batches(s, n0, n1, 3_000)               # several ragged batches, 2 partitions
+        host = s.bids(n0, n1)
+        out = collect(ctx, [_partitions(batches, 2)])
+        assert len(out) == 1 and len(out[0]) == 1
+        rb = out[0][0]
+        assert rb.schema.names == ["auction", "bidder", "price", "b_date_time"]
+        assert rb.schema.types == [pa.int32(), pa.int32(), pa.float64(), TS]        # q1_plan.fmt:1
+        # batches were dealt round-robin to partitions and flattened partition-major: compare as multisets of rows
+        got = sorted(zip(rb["auction"].to_pylist(), rb["bidder"].to_pylist(), rb["price"].to_numpy().view(np.int64).tolist(),
+                         rb["b_date_time"].cast(pa.int64()).to_pylist()))
+        want = sorted(zip(host["auction"].tolist(), host["bidder"].tolist(),
+                          oracle.q1_project(host["price"]).view(np.int64).tolist(), host["b_date_time"].tolist()))
+        assert got == want
+        # q2 with ONE partition keeps the input order exactly (FilterExec preserves order)
+        rb2 = collect(ctx2, [[batches]])[0][0]
+        wa, wp = oracle.q2_filter(host["auction"], host["price"])
+        assert rb2.schema.names == ["auction", "price"] and rb2.schema.types == [pa.int32(), pa.int32()]
+        assert rb2["auction"].to_numpy().tolist() == wa.tolist() and rb2["price"].to_numpy().tolist() == wp.tolist()
+    # inputs must survive execution unchanged (datasource/nexmark/queries/q5.rs:127-131)
+    again = _bid_batches(s, 40_000, 60_000, 3_000)
+    assert all(a.equals(b) for a, b in zip(batches, again))
+    ctx.close()
+    ctx2.close()
+
+
+@pytest.mark.gpu
+def test_q3_q8_two_sources_matched_by_schema(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=8, eps=50_000)
+    n = 100_000
+    ab, pb = _auction_batches(s, 0, n, 17_000), _person_batches(s, 0, n, 23_000)
+    a, p = s.auctions(0, n), s.persons(0, n)
+    names, cities, states = p["name"].to_pylist(), p["city"].to_pylist(), p["state"].to_pylist()
+    ctx3 = ExecutionContext([_plan(3)], name="q3-00", gpu=gpu)
+    # sources arrive as (persons, auctions) -- select_event_to_batches order for q3/q8 (nexmark.rs:188-193);
+    # the leaves find their relation by column names, not by position
+    rb = collect(ctx3, [[pb], [ab]])[0][0]
+    assert rb.schema.names == ["name", "city", "state", "a_id"]
+    assert rb.schema.types == [pa.string(), pa.string(), pa.string(), pa.int32()]       # q3_plan.fmt:1
+    ar, pr = oracle.q3_join(a["seller"], a["category"], p["p_id"], p["state"])
+    want = sorted((names[j], cities[j], states[j], int(a["a_id"][i])) for i, j in zip(ar, pr))
+    got = sorted(zip(rb["name"].to_pylist(), rb["city"].to_pylist(), rb["state"].to_pylist(), rb["a_id"].to_pylist()))
+    assert got == want and len(got) > 0
+    ctx8 = ExecutionContext([_plan(8)], name="q8-00", gpu=gpu)
+    rb = collect(ctx8, [[pb], [ab]])[0][0]
+    assert rb.schema.names == ["p_id", "name"] and rb.schema.types == [pa.int32(), pa.string()]
+    rows = oracle.q8_join(p["p_id"], p["name"], a["seller"])
+    assert sorted(zip(rb["p_id"].to_pylist(), rb["name"].to_pylist())) == sorted((int(p["p_id"][r]), names[r]) for r in rows)
+    # clean_data_sources really empties the leaves: an invocation with only persons joins nothing
+    assert collect(ctx3, [[pb]])[0][0].num_rows == 0
+    ctx3.close()
+    ctx8.close()
+
+
+@pytest.mark.gpu
+def test_q5_hopping_windows_through_collect(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=6, eps=10_000)
+    seconds, size, hop = 9, 4, 2
+    ctx = ExecutionContext([_plan(5)], name="q5-00", gpu=gpu)
+    epochs = [_bid_batches(s, e * 10_000, (e + 1) * 10_000, 4_000) for e in range(seconds)]
+    host = [s.bids(e * 10_000, (e + 1) * 10_000)["auction"] for e in range(seconds)]
+    for lo, hi in oracle.hopping_windows(seconds, size, hop):               # hopping.rs:54-74: one collect per window
+        window = [b for e in range(lo, hi) for b in epochs[e]]
+        rb = collect(ctx, [[window]])[0][0]
+        assert rb.schema.names == ["auction", "num"] and rb.schema.types == [pa.int32(), pa.uint64()]   # q5_plan.fmt:1
+        assert rb.schema.field("num").nullable
+        oa, on = oracle.q5_hot_items(np.concatenate(host[lo:hi]))
+        assert sorted(zip(rb["auction"].to_pylist(), rb["num"].to_pylist())) == sorted(zip(oa.tolist(), on.tolist()))
+    # empty window: MAX is NULL, inner join emits nothing
+    assert collect(ctx, [[[]]])[0][0].num_rows == 0
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_unsupported_plan_and_bad_input_raise(gpu):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext
+    with pytest.raises(FlockGpuError) as e:
+        ExecutionContext([open(os.path.join(PLANS, "unsupported_simple_select.json")).read()], gpu=gpu)
+    assert e.value.code == _ffi.ERR_UNSUPPORTED
+    ctx = ExecutionContext([_plan(2)], gpu=gpu)
+    wrong_type = pa.record_batch([pa.array([1, 2], pa.int64()), pa.array([3, 4], pa.int32())], names=["auction", "price"])
+    with pytest.raises(FlockGpuError) as e:
+        ctx.feed_data_sources([[[wrong_type]]])
+    assert e.value.code == _ffi.ERR_UNSUPPORTED
+    with_null = pa.record_batch([pa.array([1, None], pa.int32()), pa.array([3, 4], pa.int32())], names=["auction", "price"])
+    with pytest.raises(FlockGpuError):
+        ctx.feed_data_sources([[[with_null]]])
+    # sliced batches (non-zero Arrow offset) are read at their offset
+    big = pa.record_batch([pa.array(np.arange(1000, dtype=np.int32) * 41), pa.array(np.arange(1000, dtype=np.int32))], names=["auction", "price"])
+    ctx.clean_data_sources()
+    ctx.feed_data_sources([[[big.slice(100, 700)]]])
+    rb = ctx.execute()[0][0]
+    wa, wp = oracle.q2_filter(np.arange(100, 800, dtype=np.int32) * 41, np.arange(100, 800, dtype=np.int32))
+    assert rb["auction"].to_numpy().tolist() == wa.tolist() and rb["price"].to_numpy().tolist() == wp.tolist()
+    ctx.close()
