@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0
 # query -> (dominant kernel, algorithmic bytes per input row of that kernel's relation)
 DOMINANT = {
     5: ("q5_count_kernel", 4.0, "bid"),        # auction column, each bid read once (pane sharing)
-    2: ("q2_filter_kernel", 8.0, "bid"),       # auction + price (+ 8 B per selected row, added at run time)
+    2: ("q2_flag_kernel", 4.0, "bid"),         # the filter pass proper: auction column once (price / output: q2_emit_kernel)
     3: ("q3_probe_kernel", 8.0, "auction"),    # seller + category per auction row (filter/probe phase)
     8: ("q8_sellers_kernel", 4.0, "auction"),  # seller per auction row
 }
@@ -100,8 +100,6 @@ def roofline(q, stats, stream, res):
         return None
     rows = {"bid": lambda: stream.bids.rows, "auction": lambda: stream.auctions.rows}[rel]()
     alg_bytes = bpr * rows
-    if q == 2:
-        alg_bytes += 8.0 * res.rows
     avg_ms = st["total_ms"] / st["launches"]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None

@@ -18,11 +18,12 @@ __global__ __launch_bounds__(kBlock) void gather_i32_kernel(const int32_t *__res
 // out_off[i + 1] = sum_{k <= i} len(rows[k]);  out_off[0] = 0.  Single pass chained scan.
 __global__ __launch_bounds__(kBlock) void utf8_offsets_kernel(const int32_t *__restrict__ src_off,
                                                               const int32_t *__restrict__ rows, int64_t n,
-                                                              uint64_t *status, uint32_t *ticket,
+                                                              uint64_t *status, uint32_t *err, int32_t n_tiles,
                                                               int32_t *__restrict__ out_off, uint64_t *total) {
-    __shared__ uint64_t s_scan[kWavesPerBlock + 1];
-    __shared__ int32_t s_tile;
-    const int32_t tile = take_ticket(ticket, &s_tile);
+    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
+    StripedScan sc;
+#pragma unroll 1
+    for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
     const int64_t i0 = (int64_t)tile * kLenTile + (int64_t)threadIdx.x * kLenItems;
     uint32_t len[kLenItems];
     uint32_t mine = 0;
@@ -38,14 +39,15 @@ __global__ __launch_bounds__(kBlock) void utf8_offsets_kernel(const int32_t *__r
     const uint32_t incl = wave_incl_scan_u32(mine);
     const uint32_t wave_total = __shfl(incl, 63, 64);
     uint64_t tile_base, tile_total;
-    uint64_t pos = block_chained_offset(status, tile, wave_total, s_scan, &tile_base, &tile_total) + (incl - mine);
+    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err) + (incl - mine);
     if (tile == 0 && threadIdx.x == 0) out_off[0] = 0;
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
         pos += len[k];
         if (i0 + k < n) out_off[i0 + k + 1] = (int32_t)pos;
     }
-    if (threadIdx.x == 0 && (int64_t)(tile + 1) * kLenTile >= n) *total = tile_base + tile_total;
+    if (threadIdx.x == 0 && tile == n_tiles - 1) *total = tile_base + tile_total;
+    }  // tile loop
 }
 
 // One lane per output value; short strings (NEXMark names / cities / states are <= 14 bytes).
@@ -62,10 +64,12 @@ __global__ __launch_bounds__(kBlock) void utf8_copy_kernel(const int32_t *__rest
 }
 
 
-__global__ __launch_bounds__(kBlock) void scan_i32_kernel(int32_t *data, int64_t n, uint64_t *status, uint32_t *ticket) {
-    __shared__ uint64_t s_scan[kWavesPerBlock + 1];
-    __shared__ int32_t s_tile;
-    const int32_t tile = take_ticket(ticket, &s_tile);
+__global__ __launch_bounds__(kBlock) void scan_i32_kernel(int32_t *data, int64_t n, uint64_t *status, uint32_t *err,
+                                                          int32_t n_tiles) {
+    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
+    StripedScan sc;
+#pragma unroll 1
+    for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
     const int64_t i0 = (int64_t)tile * kLenTile + (int64_t)threadIdx.x * kLenItems;
     uint32_t v[kLenItems], mine = 0;
 #pragma unroll
@@ -76,17 +80,66 @@ __global__ __launch_bounds__(kBlock) void scan_i32_kernel(int32_t *data, int64_t
     const uint32_t incl = wave_incl_scan_u32(mine);
     const uint32_t wave_total = __shfl(incl, 63, 64);
     uint64_t tile_base, tile_total;
-    uint64_t pos = block_chained_offset(status, tile, wave_total, s_scan, &tile_base, &tile_total) + (incl - mine);
+    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err) + (incl - mine);
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
         pos += v[k];
         if (i0 + k < n) data[i0 + k] = (int32_t)pos;
     }
+    }  // tile loop
+}
+
+
+__global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *__restrict__ counts, int32_t n_tiles,
+                                                              uint64_t *__restrict__ tile_base,
+                                                              const int32_t *__restrict__ tile_first, int32_t n_seg,
+                                                              int64_t *__restrict__ seg_out_off) {
+    __shared__ uint64_t s_wave[kScanBlock / 64];
+    __shared__ uint64_t s_carry;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int32_t t0 = 0; t0 < n_tiles; t0 += kScanBlock) {
+        const int32_t t = t0 + (int32_t)threadIdx.x;
+        uint64_t c = 0;
+        if (t < n_tiles) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(counts + (size_t)t * kWavesPerBlock);
+            c = (uint64_t)w.x + w.y + w.z + w.w;
+        }
+        const uint64_t incl = wave_incl_scan_u64(c);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (t < n_tiles) tile_base[t] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_base[n_tiles] = s_carry;
+    __syncthreads();  // the block reads back its own global stores below (same CU, write-through L1)
+    if (seg_out_off)
+        for (int32_t s = threadIdx.x; s <= n_seg; s += kScanBlock) {
+            const int32_t t = tile_first[s];  // empty segments share the next segment's first tile
+            seg_out_off[s] = (int64_t)(t >= n_tiles ? s_carry : __hip_atomic_load(&tile_base[t], __ATOMIC_RELAXED,
+                                                                                  __HIP_MEMORY_SCOPE_AGENT));
+        }
 }
 
 }  // namespace
 
 namespace flockgpu {
+
+int launch_tile_scan(flockgpu_ctx *ctx, const uint32_t *counts, int32_t n_tiles, uint64_t *tile_base,
+                            const int32_t *tile_first, int32_t n_seg, int64_t *seg_out_off) {
+    {
+        LaunchScope ls(ctx, "tile_scan_kernel");
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, ctx->stream, counts, n_tiles, tile_base,
+                           tile_first, n_seg, seg_out_off);
+    }
+    return check_launch(ctx, "tile_scan_kernel");
+}
+
 
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n) {
     if (n <= 0) return FLOCKGPU_OK;
@@ -95,9 +148,11 @@ int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64
     FG_TRY(arena_get_t(ctx, name, (size_t)tiles + 2, &status));
     FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)tiles + 2), ctx->stream));
     {
+        unsigned grid = 1;
+        FG_TRY(persistent_grid(ctx, scan_i32_kernel, "scan_i32_kernel", tiles, &grid));
         LaunchScope ls(ctx, "scan_i32_kernel");
-        hipLaunchKernelGGL(scan_i32_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, data, n, status,
-                           reinterpret_cast<uint32_t *>(status + tiles));
+        hipLaunchKernelGGL(scan_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, data, n, status,
+                           reinterpret_cast<uint32_t *>(status + tiles), (int32_t)tiles);
     }
     return check_launch(ctx, "scan_i32_kernel");
 }
@@ -130,18 +185,23 @@ int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, c
     }
     const int64_t tiles = div_up(n, kLenTile);
     uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, k_st.c_str(), (size_t)tiles + 3, &status));  // + ticket + total
+    FG_TRY(arena_get_t(ctx, k_st.c_str(), (size_t)tiles + 3, &status));  // + error word + total
     FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)tiles + 3), ctx->stream));
     uint64_t *d_total = status + tiles + 1;
     {
+        unsigned grid = 1;
+        FG_TRY(persistent_grid(ctx, utf8_offsets_kernel, "utf8_offsets_kernel", tiles, &grid));
         LaunchScope ls(ctx, "utf8_offsets_kernel");
-        hipLaunchKernelGGL(utf8_offsets_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n,
-                           status, reinterpret_cast<uint32_t *>(status + tiles), o_off, d_total);
+        hipLaunchKernelGGL(utf8_offsets_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n, status,
+                           reinterpret_cast<uint32_t *>(status + tiles), (int32_t)tiles, o_off, d_total);
     }
     FG_TRY(check_launch(ctx, "utf8_offsets_kernel"));
-    uint64_t h_total = 0;
-    FG_HIP(ctx, hipMemcpyAsync(&h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t *h_words = nullptr;  // [0] = error word, [1] = total
+    FG_TRY(pinned_get_t(ctx, "gather_utf8.words", 2, &h_words));
+    FG_HIP(ctx, hipMemcpyAsync(h_words, status + tiles, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((uint32_t)h_words[0]) return fail(ctx, FLOCKGPU_ERR_HIP, "%s: chained scan stalled", name);
+    const uint64_t h_total = h_words[1];
     if (h_total > 0x7fffffffull)
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)", name);
     uint8_t *o_b = nullptr;

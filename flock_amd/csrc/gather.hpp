@@ -12,16 +12,6 @@ int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
                 flockgpu_utf8 *out, int64_t *n_bytes);
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
 }  // namespace flockgpu
 
 namespace flockgpu {

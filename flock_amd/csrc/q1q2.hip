@@ -9,97 +9,124 @@ using namespace flockgpu;
 
 namespace {
 
-constexpr int kQ2Iters = 4;                      // 4 x (4 rows per lane) = 16 rows per thread
-constexpr int kQ2Tile = kBlock * 4 * kQ2Iters;   // 4096 rows per workgroup
+constexpr int kQ2Iters = 8;                      // 8 x (4 rows per lane) = 32 rows per thread
+constexpr int kQ2Tile = kBlock * 4 * kQ2Iters;   // 8192 rows per tile
 constexpr int kQ2WaveRows = kQ2Tile / kWavesPerBlock;
 
-// Truncated remainder `CAST(a AS Int64) % m == rem` without a hardware divide:
-// Lemire's fastmod on |a| (32 bit) with a 64-bit magic, sign restored afterwards.
+// `CAST(a AS Int64) % m == 0` (truncated remainder; the plan compares with the literal 0, planner.rs:122)
+// without a divide: a is divisible by m  <=>  |a| is divisible by d = |m| = 2^k * o (o odd)
+// <=>  ror32(|a| * inverse(o) mod 2^32, k) <= floor((2^32 - 1) / d)   (Granlund-Montgomery / Lemire-Kaser).
+// One 32-bit multiply per row instead of the 128-bit product a fastmod remainder needs.
 struct ModPred {
-    uint64_t magic;  // floor((2^64 - 1) / d) + 1
-    uint32_t d;      // |m| when it fits 32 bits
-    int32_t rem;
-    int32_t wide;    // |m| >= 2^32  ->  a % m == a
-    int32_t never;   // rem does not fit Int32 / has impossible sign  ->  always false
+    uint32_t inv;    // o^-1 mod 2^32
+    uint32_t lim;    // floor((2^32 - 1) / d)
+    uint32_t shift;  // k
+    int32_t wide;    // |m| >= 2^32  ->  a % m == a, zero only for a == 0
 };
 
-__device__ __forceinline__ bool mod_eq(int32_t a, const ModPred &p) {
-    if (p.wide) return a == p.rem;
-    const uint32_t n = a < 0 ? (uint32_t)(-(int64_t)a) : (uint32_t)a;
-    const uint64_t low = p.magic * (uint64_t)n;
-    const uint32_t r = (uint32_t)__umul64hi(low, (uint64_t)p.d);
-    const int32_t sr = a < 0 ? -(int32_t)r : (int32_t)r;
-    return sr == p.rem;
+__device__ __forceinline__ bool mod_is_zero(int32_t a, const ModPred &p) {
+    const uint32_t n = a < 0 ? 0u - (uint32_t)a : (uint32_t)a;
+    if (p.wide) return n == 0;
+    const uint32_t q = n * p.inv;
+    return __funnelshift_r(q, q, p.shift) <= p.lim;
 }
 
 __device__ __forceinline__ void load4(const int32_t *__restrict__ col, int64_t r0, int64_t n_rows, int32_t (&v)[4]) {
-    if (r0 + 4 <= n_rows) {
+    if (r0 >= 0 && r0 + 4 <= n_rows) {
         const int4 t = *reinterpret_cast<const int4 *>(col + r0);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (r0 + j < n_rows) ? col[r0 + j] : 0;
+        for (int j = 0; j < 4; ++j) v[j] = (r0 + j >= 0 && r0 + j < n_rows) ? col[r0 + j] : 0;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void q2_filter_kernel(const int32_t *__restrict__ auction,
-                                                           const int32_t *__restrict__ price, int64_t n_rows,
-                                                           SegTiles st, ModPred pred, uint64_t *status,
-                                                           uint32_t *ticket, int32_t *__restrict__ out_auction,
-                                                           int32_t *__restrict__ out_price, int64_t *seg_out_off) {
-    __shared__ uint64_t s_scan[kWavesPerBlock + 1];
-    __shared__ int32_t s_tile;
-    const int32_t tile = take_ticket(ticket, &s_tile);
+// Loads the tile's `auction` values: lane l of wave w holds rows  w*2048 + it*256 + 4l .. +3  (relative to
+// tile_begin), i.e. every load instruction of a wave covers 1 KiB of consecutive bytes.
+__device__ __forceinline__ void q2_load_tile(const int32_t *__restrict__ auction, int64_t n_rows, const TileRange &tr,
+                                             int32_t (&a)[kQ2Iters][4]) {
+    const int64_t wbase = tr.tile_begin + (int64_t)(threadIdx.x >> 6) * kQ2WaveRows + lane_id() * 4;
+    if (tr.tile_begin + kQ2Tile <= n_rows) {  // block-uniform: no row of the tile is past the column
+#pragma unroll
+        for (int it = 0; it < kQ2Iters; ++it) {
+            const int4 t = *reinterpret_cast<const int4 *>(auction + wbase + it * 256);
+            a[it][0] = t.x; a[it][1] = t.y; a[it][2] = t.z; a[it][3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kQ2Iters; ++it) load4(auction, wbase + it * 256, n_rows, a[it]);
+    }
+}
+
+// q2 runs as count -> scan -> emit (scan.hpp):
+//   q2_flag_kernel : streams `auction` once (the only pass over the column), evaluates the predicate and leaves
+//                    ONE 32-bit word of row flags per lane (bit it*4+j, 1 KiB per 8192-row tile, coalesced) plus one
+//                    count per wave.  No LDS, no barrier, no dependence between workgroups: a pure HBM stream.
+//   tile_scan      : tile bases + per-window output offsets.
+//   q2_emit_kernel : per tile with survivors: flag words -> ranks -> the survivors' row numbers into an LDS list
+//                    in row order -> the block copies (auction, price) of the listed rows, lane i taking survivor
+//                    i, so the gathers are issued back to back and the stores are coalesced.  `price` is only
+//                    ever touched for surviving rows (their `auction` values are L2 / MALL hits).
+__global__ __launch_bounds__(kBlock) void q2_flag_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
+                                                         ModPred pred, uint32_t *__restrict__ flag_words,
+                                                         uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kQ2Tile);
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int64_t wbase = tr.tile_begin + (int64_t)wave * kQ2WaveRows + lane * 4;
-
     int32_t a[kQ2Iters][4];
+    q2_load_tile(auction, n_rows, tr, a);
+    // rows of the tile that belong to the window, relative to tile_begin: [rel_lo, rel_hi)
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int32_t rel0 = wave * kQ2WaveRows + lane * 4;
+    uint32_t flags = 0;
 #pragma unroll
-    for (int it = 0; it < kQ2Iters; ++it) load4(auction, wbase + it * 256, n_rows, a[it]);
-
-    uint32_t flags = 0;               // bit (it*4 + j)
-    uint32_t lane_rank[kQ2Iters];     // selected rows of this iteration in lower lanes
-    uint32_t it_total[kQ2Iters];
-    uint32_t wave_total = 0;
-#pragma unroll
-    for (int it = 0; it < kQ2Iters; ++it) {
-        const int64_t r0 = wbase + it * 256;
-        uint32_t rank = 0, total = 0;
+    for (int it = 0; it < kQ2Iters; ++it)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t r = r0 + j;
-            const bool f = r >= tr.lo && r < tr.hi && !pred.never && mod_eq(a[it][j], pred);
-            const uint64_t b = __ballot(f);
-            rank += mbcnt(b);
-            total += (uint32_t)__popcll((unsigned long long)b);
+            const int32_t rel = rel0 + it * 256 + j;
+            const bool f = mod_is_zero(a[it][j], pred) && rel >= rel_lo && rel < rel_hi;
             flags |= (f ? 1u : 0u) << (it * 4 + j);
         }
-        lane_rank[it] = rank;
-        it_total[it] = total;
-        wave_total += total;
-    }
+    flag_words[(size_t)tile * kBlock + threadIdx.x] = flags;
+    const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
+    if (lane == 63) counts[(size_t)tile * kWavesPerBlock + wave] = incl;
+}
 
-    uint64_t tile_base, tile_total;
-    uint64_t pos = block_chained_offset(status, tile, wave_total, s_scan, &tile_base, &tile_total);
-    if (threadIdx.x == 0) {
-        if (tile == st.tile_first[tr.seg]) seg_out_off[tr.seg] = (int64_t)tile_base;
-        if (tile == st.n_tiles - 1) seg_out_off[st.n_seg] = (int64_t)(tile_base + tile_total);
-    }
-    if (wave_total == 0) return;
+__global__ __launch_bounds__(kBlock) void q2_emit_kernel(const int32_t *__restrict__ auction,
+                                                         const int32_t *__restrict__ price, SegTiles st,
+                                                         const uint32_t *__restrict__ flag_words,
+                                                         const uint32_t *__restrict__ counts,
+                                                         const uint64_t *__restrict__ tile_base,
+                                                         int32_t *__restrict__ out_auction,
+                                                         int32_t *__restrict__ out_price) {
+    __shared__ uint16_t s_list[kQ2Tile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    const uint32_t total = wc.x + wc.y + wc.z + wc.w;
+    if (total == 0) return;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t flags = flag_words[(size_t)tile * kBlock + threadIdx.x];
+    uint32_t p = (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u);
+    const int32_t rel0 = wave * kQ2WaveRows + lane * 4;
 #pragma unroll
     for (int it = 0; it < kQ2Iters; ++it) {
-        uint64_t p = pos + lane_rank[it];
-        const int64_t r0 = wbase + it * 256;
+        const uint32_t f4 = (flags >> (it * 4)) & 15u;
+        if (!__ballot(f4 != 0)) continue;  // wave-uniform
+        const uint32_t c = (uint32_t)__popc(f4);
+        const uint32_t incl = wave_incl_scan_u32(c);
+        uint32_t q = p + incl - c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (flags & (1u << (it * 4 + j))) {
-                out_auction[p] = a[it][j];
-                out_price[p] = price[r0 + j];   // price is only touched for surviving rows
-                ++p;
-            }
-        }
-        pos += it_total[it];
+        for (int j = 0; j < 4; ++j)
+            if (f4 & (1u << j)) s_list[q++] = (uint16_t)(rel0 + it * 256 + j);
+        p += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __syncthreads();
+    const TileRange tr = locate_tile(st, tile, kQ2Tile);
+    const uint64_t base = tile_base[tile];
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const int64_t r = tr.tile_begin + s_list[i];
+        out_auction[base + i] = auction[r];
+        out_price[base + i] = price[r];
     }
 }
 
@@ -169,37 +196,45 @@ int flockgpu_q2_filter(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const fl
     int32_t *o_a = nullptr, *o_p = nullptr;
     FG_TRY(arena_get_t(ctx, "q2.out_auction", (size_t)worst, &o_a));
     FG_TRY(arena_get_t(ctx, "q2.out_price", (size_t)worst, &o_p));
-    uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, "q2.status", (size_t)st.n_tiles + 2, &status));  // [n_tiles] doubles as the ticket
+    uint32_t *flag_words = nullptr, *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    FG_TRY(arena_get_t(ctx, "q2.flag_words", (size_t)st.n_tiles * kBlock, &flag_words));
+    FG_TRY(arena_get_t(ctx, "q2.counts", (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, "q2.tile_base", (size_t)st.n_tiles + 1, &tile_base));
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q2.seg_out_off", (size_t)n_win + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "q2.seg_out_off", (size_t)n_win + 1, &h_off));
-    FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)st.n_tiles + 2), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
 
     ModPred pred{};
     const uint64_t am = modulus < 0 ? (uint64_t)0 - (uint64_t)modulus : (uint64_t)modulus;
-    pred.rem = 0;  // the plan compares with literal 0 (planner.rs:122)
     if (am >> 32) {
         pred.wide = 1;
     } else {
-        pred.d = (uint32_t)am;
-        pred.magic = 0xFFFFFFFFFFFFFFFFull / am + 1;
+        uint32_t d = (uint32_t)am, k = 0;
+        while (!(d & 1u)) { d >>= 1; ++k; }
+        uint32_t inv = d;  // Newton: 3 correct bits, doubled per step
+        for (int i = 0; i < 5; ++i) inv *= 2u - d * inv;
+        pred.inv = inv;
+        pred.shift = k;
+        pred.lim = 0xFFFFFFFFu / (uint32_t)am;
     }
     if (st.n_tiles > 0) {
-        LaunchScope ls(ctx, "q2_filter_kernel");
-        hipLaunchKernelGGL(q2_filter_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
-                           bid->price, bid->rows, st, pred, status, reinterpret_cast<uint32_t *>(status + st.n_tiles),
-                           o_a, o_p, d_off);
+        LaunchScope ls(ctx, "q2_flag_kernel");
+        hipLaunchKernelGGL(q2_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
+                           bid->rows, st, pred, flag_words, counts);
     }
-    FG_TRY(check_launch(ctx, "q2_filter_kernel"));
+    FG_TRY(check_launch(ctx, "q2_flag_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    if (st.n_tiles > 0) {
+        LaunchScope ls(ctx, "q2_emit_kernel");
+        hipLaunchKernelGGL(q2_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
+                           bid->price, st, flag_words, counts, tile_base, o_a, o_p);
+    }
+    FG_TRY(check_launch(ctx, "q2_emit_kernel"));
     FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> &offs = ctx->host_i64["q2.win_out_offsets"];
     offs.assign(h_off, h_off + n_win + 1);
-    if (st.n_tiles == 0) offs[n_win] = 0;
-    for (int w = n_win - 1; w >= 0; --w)
-        if (offs[w] < 0) offs[w] = offs[w + 1];  // empty windows have no tile to write their offset
     out->auction = o_a;
     out->price = o_p;
     out->win_out_offsets = offs.data();

@@ -66,15 +66,16 @@ __global__ __launch_bounds__(kBlock) void q3_probe_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ category, int64_t n_rows,
                                                           int64_t category_lit, SegTiles st, const uint64_t *tables,
                                                           uint32_t cap, const int32_t *__restrict__ next, uint64_t *status,
-                                                          uint32_t *ticket, int32_t *__restrict__ out_auction_row,
+                                                          uint32_t *err, int32_t *__restrict__ out_auction_row,
                                                           int32_t *__restrict__ out_person_row, uint64_t out_cap,
                                                           int64_t *seg_out_off) {
-    __shared__ uint64_t s_scan[kWavesPerBlock + 1];
-    __shared__ int32_t s_tile;
-    const int32_t tile = take_ticket(ticket, &s_tile);
+    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
+    StripedScan sc;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+#pragma unroll 1
+    for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
     const TileRange tr = locate_tile(st, tile, kProbeTile);
     const uint64_t *tab = tables + (size_t)tr.seg * cap;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
     const int64_t wbase = tr.tile_begin + (int64_t)wave * kProbeWaveRows + lane * 4;
 
     int32_t head[kProbeIters][4];
@@ -117,12 +118,12 @@ __global__ __launch_bounds__(kBlock) void q3_probe_kernel(const int32_t *__restr
         wave_total += it_total[it];
     }
     uint64_t tile_base, tile_total;
-    uint64_t pos = block_chained_offset(status, tile, wave_total, s_scan, &tile_base, &tile_total);
+    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err);
     if (threadIdx.x == 0) {
         if (tile == st.tile_first[tr.seg]) seg_out_off[tr.seg] = (int64_t)tile_base;
         if (tile == st.n_tiles - 1) seg_out_off[st.n_seg] = (int64_t)(tile_base + tile_total);
     }
-    if (wave_total == 0) return;
+    if (wave_total == 0) continue;
 #pragma unroll
     for (int it = 0; it < kProbeIters; ++it) {
         uint64_t p = pos + lane_rank[it];
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(kBlock) void q3_probe_kernel(const int32_t *__restr
         }
         pos += it_total[it];
     }
+    }  // tile loop
 }
 
 }  // namespace
@@ -196,14 +198,13 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
     FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
     uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, "q3.status", (size_t)st_a.n_tiles + 4, &status));  // + ticket, err, pair total
+    FG_TRY(arena_get_t(ctx, "q3.status", (size_t)st_a.n_tiles + 4, &status));  // + spare, err, pair total
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.seg_out_off", (size_t)n_win + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "q3.seg_out_off", (size_t)n_win + 2, &h_off));
     FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
     FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)st_a.n_tiles + 4), ctx->stream));
     FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
-    uint32_t *d_ticket = reinterpret_cast<uint32_t *>(status + st_a.n_tiles);
     uint32_t *d_err = reinterpret_cast<uint32_t *>(status + st_a.n_tiles + 1);
 
     if (st_p.n_tiles > 0) {
@@ -226,17 +227,21 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
         }
         if (st_a.n_tiles > 0) {
+            unsigned grid = 1;
+            FG_TRY(persistent_grid(ctx, q3_probe_kernel, "q3_probe_kernel", st_a.n_tiles, &grid));
             LaunchScope ls(ctx, "q3_probe_kernel");
-            hipLaunchKernelGGL(q3_probe_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
-                               auction->seller, auction->category, auction->rows, category_lit, st_a, tables, cap, next,
-                               status, d_ticket, o_ar, o_pr, out_cap, d_off);
+            hipLaunchKernelGGL(q3_probe_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
+                               auction->category, auction->rows, category_lit, st_a, tables, cap, next, status, d_err, o_ar,
+                               o_pr, out_cap, d_off);
         }
         FG_TRY(check_launch(ctx, "q3_probe_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (*reinterpret_cast<uint32_t *>(h_off + n_win + 1))
+        if (const uint32_t h_err = *reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
+            if (h_err & 2u) return fail(ctx, FLOCKGPU_ERR_HIP, "q3: chained scan stalled");
             return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
+        }
         n_pairs = st_a.n_tiles == 0 ? 0 : (uint64_t)h_off[n_win];
         if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");
         if (n_pairs <= out_cap) break;

@@ -77,12 +77,13 @@ __global__ __launch_bounds__(kBlock) void q8_persons_kernel(const int32_t *__res
                                                             const int32_t *__restrict__ name_off,
                                                             const uint8_t *__restrict__ name, SegTiles st,
                                                             uint32_t *ptabs, uint32_t pcap, const uint64_t *sets,
-                                                            uint32_t scap, uint64_t *status, uint32_t *ticket,
+                                                            uint32_t scap, uint64_t *status,
                                                             int32_t *__restrict__ out_person_row, int64_t *seg_out_off,
                                                             uint32_t *err) {
-    __shared__ uint64_t s_scan[kWavesPerBlock + 1];
-    __shared__ int32_t s_tile;
-    const int32_t tile = take_ticket(ticket, &s_tile);
+    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
+    StripedScan sc;
+#pragma unroll 1
+    for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
     const TileRange tr = locate_tile(st, tile, kPersonTile);
     uint32_t *ptab = ptabs + (size_t)tr.seg * pcap;
     const uint64_t *set = sets + (size_t)tr.seg * scap;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void q8_persons_kernel(const int32_t *__res
         flags |= (keep ? 1u : 0u) << it;
     }
     uint64_t tile_base, tile_total;
-    uint64_t pos = block_chained_offset(status, tile, wave_total, s_scan, &tile_base, &tile_total);
+    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err);
     if (threadIdx.x == 0) {
         if (tile == st.tile_first[tr.seg]) seg_out_off[tr.seg] = (int64_t)tile_base;
         if (tile == st.n_tiles - 1) seg_out_off[st.n_seg] = (int64_t)(tile_base + tile_total);
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void q8_persons_kernel(const int32_t *__res
         if (flags & (1u << it)) out_person_row[pos + lane_rank[it]] = (int32_t)(wbase + it * 64);
         pos += it_total[it];
     }
+    }  // tile loop
 }
 
 }  // namespace
@@ -182,8 +184,7 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
     const uint32_t pcap = (uint32_t)pcap64;
     uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, "q8.status", (size_t)st_p.n_tiles + 3, &status));  // + ticket, err
-    uint32_t *d_ticket = reinterpret_cast<uint32_t *>(status + st_p.n_tiles);
+    FG_TRY(arena_get_t(ctx, "q8.status", (size_t)st_p.n_tiles + 3, &status));  // + spare, err
     uint32_t *d_err = reinterpret_cast<uint32_t *>(status + st_p.n_tiles + 1);
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.seg_out_off", (size_t)n_win + 1, &d_off));
@@ -213,16 +214,19 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         }
         FG_TRY(check_launch(ctx, "q8_sellers_kernel"));
         if (st_p.n_tiles > 0) {
+            unsigned grid = 1;
+            FG_TRY(persistent_grid(ctx, q8_persons_kernel, "q8_persons_kernel", st_p.n_tiles, &grid));
             LaunchScope ls(ctx, "q8_persons_kernel");
-            hipLaunchKernelGGL(q8_persons_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->name.offsets, person->name.data, st_p, ptabs, pcap, sets, scap, status, d_ticket, o_pr,
-                               d_off, d_err);
+            hipLaunchKernelGGL(q8_persons_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id,
+                               person->name.offsets, person->name.data, st_p, ptabs, pcap, sets, scap, status, o_pr, d_off,
+                               d_err);
         }
         FG_TRY(check_launch(ctx, "q8_persons_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (*reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
+        if (const uint32_t h_err = *reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
+            if (h_err & 2u) return fail(ctx, FLOCKGPU_ERR_HIP, "q8: chained scan stalled");
             scap64 *= 4;
             continue;
         }

@@ -113,6 +113,21 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (gfx9 family, wave64): 8 VALU
+// instructions, no LDS crossbar traffic (a __shfl_up ladder is 6 ds_bpermute + index math).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    const int xi = (int)x;
+    int v = xi;
+    v += __builtin_amdgcn_update_dpp(0, xi, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, xi, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, xi, 0x113, 0xf, 0xf, false);  // row_shr:3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t)v;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -122,12 +137,24 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-// ---- chained scan (single pass, decoupled look-back) ---------------------------------------------
-// status[t]: bits 63..62 = state, low 62 bits = value.  The word IS the flag (one naturally aligned 8-byte
-// relaxed agent-scope store / load, CDNA guide G16 form R2), so no release/acquire fences are needed.
-// Tiles take their index from an atomic ticket, so every predecessor of a running tile is itself running
-// (or done) and publishes its aggregate before it waits on anything: no dependence on dispatch order.
-constexpr uint64_t kStInvalid = 0ull, kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStMask = 3ull << 62;
+// ---- striped single-pass scan --------------------------------------------------------------------------
+// Order-preserving compaction needs the number of selected rows before every tile.  The kernels are
+// PERSISTENT: the grid G is no larger than what is resident at once (persistent_grid below) and block b walks
+// tiles b, b + G, b + 2G, ... in increasing order.  Every tile publishes its aggregate
+//   status[tile] = kStValid | count      (one naturally aligned 8-byte relaxed agent-scope store: the data is
+//                                         the flag, CDNA guide G16 form R2 -- no fences)
+// as soon as it is known, and the block keeps its own running prefix in registers:
+//   prefix(tile) = prefix(prev) + count(prev) + sum of count(t) for prev < t < tile,
+// i.e. it reads the G - 1 aggregates BETWEEN its previous tile and this one, all with independent loads spread
+// over the 256 lanes (one memory round trip), instead of walking a chain of predecessors.  Nothing waits on a
+// prefix, only on aggregates, and an aggregate depends on nothing but the tile's own rows -- so there is no
+// serial propagation (the classic decoupled look-back advanced 64 tiles per ~2 us round trip here and capped q2
+// at 1.4 TB/s; a global atomic ticket per tile tops out at ~88/us on one word, MI355X_MICROARCH.md "dequeue").
+// Deadlock freedom: a tile only waits on lower-numbered tiles; the lowest unpublished tile's block is either not
+// yet started (it will be: the grid is resident) or finishing an earlier tile whose predecessors are all
+// published.  Dispatch order and placement do not matter.
+constexpr uint64_t kStValid = 1ull << 63, kStValueMask = kStValid - 1;
+constexpr uint32_t kScanSpinLimit = 1u << 22;  // a few seconds; a dead predecessor becomes an error, not a hang
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -136,46 +163,19 @@ __device__ __forceinline__ void st_status(uint64_t *p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Executed by ONE full wave of the block.  Returns the exclusive prefix (sum of the aggregates of tiles
-// 0..tile-1) and publishes this tile's inclusive prefix.
-__device__ __forceinline__ uint64_t chained_scan_lookback(uint64_t *status, int32_t tile, uint64_t aggregate) {
-    const int lane = lane_id();
-    if (tile == 0) {
-        if (lane == 0) st_status(&status[0], kStPrefix | aggregate);
-        return 0;
-    }
-    if (lane == 0) st_status(&status[tile], kStAggregate | aggregate);
-    uint64_t excl = 0;
-    int32_t base = tile - 1;
-    for (;;) {
-        const int32_t t = base - lane;
-        uint64_t s = kStPrefix;  // virtual tiles below 0: prefix 0
-        if (t >= 0) {
-            s = ld_status(&status[t]);
-            while ((s & kStMask) == kStInvalid) {
-                __builtin_amdgcn_s_sleep(1);
-                s = ld_status(&status[t]);
-            }
-        }
-        const uint64_t is_prefix = __ballot((s & kStMask) == kStPrefix);
-        const uint64_t val = s & ~kStMask;
-        if (is_prefix) {
-            const int first = __ffsll((unsigned long long)is_prefix) - 1;  // nearest predecessor holding a prefix
-            excl += wave_sum_u64(lane <= first ? val : 0ull);
-            break;
-        }
-        excl += wave_sum_u64(val);  // 64 aggregates, keep looking further back
-        base -= 64;
-    }
-    if (lane == 0) st_status(&status[tile], kStPrefix | (excl + aggregate));
-    return excl;
-}
+// Per-block scan state of a persistent tile loop (uniform across the block).
+struct StripedScan {
+    int32_t prev_tile = -1;
+    uint64_t running = 0;  // prefix(prev_tile) + count(prev_tile)
+};
 
-// Block-wide: every wave contributes `wave_total`; returns the exclusive offset of this wave's first
-// element in the global output and leaves the tile's global base in *tile_base.
-// `smem` must hold kWavesPerBlock + 1 uint64.
-__device__ __forceinline__ uint64_t block_chained_offset(uint64_t *status, int32_t tile, uint64_t wave_total,
-                                                         uint64_t *smem, uint64_t *tile_base, uint64_t *tile_total) {
+// Block-wide, once per tile of the persistent loop.  Every wave contributes `wave_total`; returns the
+// exclusive offset of this wave's first element in the global output, the tile's global base in *tile_base and
+// its count in *tile_total.  `smem` must hold 2 * kWavesPerBlock uint64; the two barriers inside also order
+// its reuse by the next iteration.  `err` gets bit 1 when a predecessor never shows up.
+__device__ __forceinline__ uint64_t block_striped_offset(uint64_t *status, StripedScan &sc, int32_t tile,
+                                                         uint64_t wave_total, uint64_t *smem, uint64_t *tile_base,
+                                                         uint64_t *tile_total, uint32_t *err) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     if (lane == 0) smem[wave] = wave_total;
     __syncthreads();
@@ -186,22 +186,75 @@ __device__ __forceinline__ uint64_t block_chained_offset(uint64_t *status, int32
         if (w < wave) mine += v;
         total += v;
     }
-    if (wave == 0) {
-        const uint64_t excl = chained_scan_lookback(status, tile, total);
-        if (lane == 0) smem[kWavesPerBlock] = excl;
+    if (threadIdx.x == 0) st_status(&status[tile], kStValid | total);  // publish before waiting on anyone
+    uint64_t acc = 0;
+    for (int32_t t = sc.prev_tile + 1 + (int32_t)threadIdx.x; t < tile; t += kBlock) {
+        uint64_t s = ld_status(&status[t]);
+        uint32_t spins = 0;
+        while (!(s & kStValid)) {
+            __builtin_amdgcn_s_sleep(1);
+            s = ld_status(&status[t]);
+            if (++spins > kScanSpinLimit) {
+                atomicOr(err, 2u);
+                s = kStValid;
+            }
+        }
+        acc += s & kStValueMask;
     }
+    acc = wave_sum_u64(acc);
+    if (lane == 0) smem[kWavesPerBlock + wave] = acc;
     __syncthreads();
-    const uint64_t base = smem[kWavesPerBlock];
+    uint64_t between = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) between += smem[kWavesPerBlock + w];
+    const uint64_t base = sc.running + between;
+    sc.running = base + total;
+    sc.prev_tile = tile;
     *tile_base = base;
     *tile_total = total;
     return base + mine;
 }
 
-// one ticket per block, broadcast through LDS
-__device__ __forceinline__ int32_t take_ticket(uint32_t *counter, int32_t *smem_slot) {
-    if (threadIdx.x == 0) *smem_slot = (int32_t)atomicAdd(counter, 1u);
-    __syncthreads();
-    return *smem_slot;
+// ---- count -> scan -> emit --------------------------------------------------------------------------------
+// The order-preserving operators that replaced the striped scan run as three launches with NO dependence between
+// workgroups inside a launch (nothing to deadlock, no residency assumption, every launch a plain streaming grid):
+//   count : one workgroup per tile writes one count per wave            counts[tile * kWavesPerBlock + wave]
+//   scan  : ONE workgroup turns the counts into exclusive tile bases     tile_base[n_tiles + 1]
+//           and the per-segment (window) output offsets                  seg_out_off[n_seg + 1]
+//   emit  : one workgroup per tile writes its rows at tile_base[tile] + (counts of its lower waves) + rank
+// The scan kernel touches 16 B per tile (2 MB for 1e9 rows) and costs a few microseconds.
+constexpr int kScanBlock = 1024;
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Host: launches the scan (defined in gather.hip).  counts: n_tiles * kWavesPerBlock uint32 (16-byte aligned);
+// tile_base: n_tiles + 1; seg_out_off (may be null): n_seg + 1.
+int launch_tile_scan(flockgpu_ctx *ctx, const uint32_t *counts, int32_t n_tiles, uint64_t *tile_base,
+                     const int32_t *tile_first, int32_t n_seg, int64_t *seg_out_off);
+
+// Host: grid of a persistent striped-scan kernel = min(n_tiles, blocks that are certainly co-resident).
+// The occupancy API over-reports by one block per CU only where SGPRs are the limit, at 7-8 blocks per CU
+// (MI355X_MICROARCH.md "Residency"); at most 4 blocks per CU are used here, where the answer (VGPR / LDS
+// limited) is exact.  16 waves per CU with >= 8 x 16-byte loads in flight per lane is well past what it takes
+// to stream HBM at full rate.  Should a block nevertheless not be resident, kScanSpinLimit turns the wait into
+// an error status instead of a hang.
+template <typename Kernel>
+inline int persistent_grid(flockgpu_ctx *ctx, Kernel kernel, const char *name, int64_t n_tiles, unsigned *grid) {
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0);
+    if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_HIP, "occupancy query of %s failed: %s", name, hipGetErrorString(e));
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    const int64_t cap = (int64_t)per_cu * ctx->num_cus;
+    *grid = (unsigned)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap);
+    return FLOCKGPU_OK;
 }
 
 }  // namespace flockgpu

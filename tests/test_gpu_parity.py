@@ -106,7 +106,7 @@ def test_q2_bursty_selectivity_and_other_moduli(ctx):
     bids = Bids(auction=_dev(auction), price=_dev(price), rows=n)
     offs = np.array([0, 17, 17, 4099, 150_001, n])     # ragged, unaligned, one empty window
     sched = WindowSchedule(offs, np.arange(5), np.arange(1, 6))
-    for m in (123, 7, 1, -123, 2**31, 2**40):
+    for m in (123, 7, 1, -123, 124, 96, -64, 2**31, 2**31 - 1, 2**40):
         a, p, off = ctx.q2_filter(bids, sched, modulus=m).to_host()
         for w in range(5):
             wa, wp = oracle.q2_filter(auction[offs[w]:offs[w + 1]], price[offs[w]:offs[w + 1]], modulus=m)
