@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0
 DOMINANT = {
     5: ("q5_count_kernel", 4.0, "bid"),        # auction column, each bid read once (pane sharing)
     2: ("q2_flag_kernel", 4.0, "bid"),         # the filter pass proper: auction column once (price / output: q2_emit_kernel)
-    3: ("q3_probe_kernel", 8.0, "auction"),    # seller + category per auction row (filter/probe phase)
-    8: ("q8_sellers_kernel", 4.0, "auction"),  # seller per auction row
+    3: ("q3_probe_flag_kernel", 8.0, "auction"),    # seller + category per auction row (filter/probe phase)
+    8: ("q8_sellers_bitmap_kernel", 4.0, "auction"),  # seller per auction row
 }
 
 

@@ -1,13 +1,160 @@
-// Device-side take(): fixed-width gather and Utf8 gather (lengths -> chained scan -> byte copy).
+// Shared device-side primitives (gather.hpp): tile scan, flag words -> rows, per-window key statistics,
+// take() for fixed-width and Utf8 columns, in-place prefix sums.  Every multi-tile operation is
+// count -> scan -> emit (scan.hpp): no workgroup ever waits on another one inside a launch.
 #include "gather.hpp"
+
+#include <algorithm>
 
 using namespace flockgpu;
 
 namespace {
 
-constexpr int kLenItems = 8;
-constexpr int kLenTile = kBlock * kLenItems;  // 2048 rows per workgroup
+// ---- tile scan: ONE workgroup, every access coalesced, all loads of a pass in flight together -----------------
+// Pass = kScanRounds x 1024 tiles: thread t holds tiles  k*1024 + t  (k = 0..15).  Per round a wave scan; the
+// 16 x 16 wave totals are scanned by wave 0; three barriers per pass.
+constexpr int kScanRounds = 16;
+__global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *__restrict__ counts, int32_t n_tiles,
+                                                              uint64_t *__restrict__ tile_base,
+                                                              const int32_t *__restrict__ tile_first, int32_t n_seg,
+                                                              int64_t *__restrict__ seg_out_off) {
+    constexpr int kWaves = kScanBlock / 64;
+    __shared__ uint64_t s_tot[kScanRounds * kWaves];  // [round][wave] totals, then their exclusive prefix
+    __shared__ uint64_t s_carry;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    for (int32_t p0 = 0; p0 < n_tiles; p0 += kScanRounds * kScanBlock) {
+        uint64_t c[kScanRounds], incl[kScanRounds];
+#pragma unroll
+        for (int k = 0; k < kScanRounds; ++k) {
+            const int32_t t = p0 + k * kScanBlock + (int32_t)threadIdx.x;
+            c[k] = 0;
+            if (t < n_tiles) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(counts + (size_t)t * kWavesPerBlock);
+                c[k] = (uint64_t)w.x + w.y + w.z + w.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kScanRounds; ++k) {
+            incl[k] = 0;
+            if (p0 + k * kScanBlock < n_tiles) incl[k] = wave_incl_scan_u64(c[k]);  // block-uniform
+            if (lane == 63) s_tot[k * kWaves + wave] = incl[k];
+        }
+        __syncthreads();  // (also publishes s_carry)
+        const uint64_t carry = s_carry;
+        if (wave == 0) {  // exclusive scan of the 256 totals: 4 per lane
+            uint64_t v[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = s_tot[lane * 4 + i];
+                sum += v[i];
+            }
+            uint64_t run = wave_incl_scan_u64(sum) - sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s_tot[lane * 4 + i] = run;
+                run += v[i];
+            }
+            if (lane == 63) s_carry = carry + run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanRounds; ++k) {
+            const int32_t t = p0 + k * kScanBlock + (int32_t)threadIdx.x;
+            if (t < n_tiles) tile_base[t] = carry + s_tot[k * kWaves + wave] + incl[k] - c[k];
+        }
+        __syncthreads();  // s_tot is rewritten by the next pass
+    }
+    __syncthreads();
+    const uint64_t total = s_carry;
+    if (threadIdx.x == 0) tile_base[n_tiles] = total;
+    if (!seg_out_off) return;
+    // the workgroup reads back its own global stores (made before the barriers above) with L1-bypassing loads
+    for (int32_t s = threadIdx.x; s <= n_seg; s += kScanBlock) {
+        const int32_t t = tile_first[s];  // an empty segment shares the next segment's first tile
+        seg_out_off[s] = (int64_t)(t >= n_tiles ? total
+                                                : __hip_atomic_load(&tile_base[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
 
+// ---- flag words -> global row numbers ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void emit_rows_kernel(SegTiles st, const uint32_t *__restrict__ flag_words,
+                                                           const uint32_t *__restrict__ counts,
+                                                           const uint64_t *__restrict__ tile_base,
+                                                           int32_t *__restrict__ out_rows) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const uint64_t base = tile_base[tile];
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
+}
+
+// ---- exact per-segment min / max + "strictly increasing" ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void segment_stats_kernel(const int32_t *__restrict__ col, int64_t n_rows, SegTiles st,
+                                                               int32_t *seg_min, int32_t *seg_max, int32_t *seg_sorted) {
+    __shared__ int32_t s_red[3 * kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    int32_t a[kFlagIters][4];
+    load_flag_tile(col, n_rows, tr, a);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+    bool sorted = true;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        // predecessor of this lane's first row: the previous lane's last row, or (lane 0) the row before in memory
+        int32_t prev = __shfl_up(a[it][3], 1, 64);
+        const int32_t rel = rel0 + it * 256;
+        if (lane == 0) {
+            const int64_t r = tr.tile_begin + rel - 1;
+            prev = (rel > rel_lo && r >= 0 && r < n_rows) ? col[r] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (rel + j >= rel_lo && rel + j < rel_hi) {
+                mn = min(mn, a[it][j]);
+                mx = max(mx, a[it][j]);
+                if (rel + j > rel_lo && a[it][j] <= prev) sorted = false;  // the segment's first row has no predecessor
+            }
+            prev = a[it][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    const bool wave_sorted = __ballot(!sorted) == 0;
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[kWavesPerBlock + wave] = mx;
+        s_red[2 * kWavesPerBlock + wave] = wave_sorted ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && tr.hi > tr.lo) {
+        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        atomicMin(&seg_min[tr.seg], mn);
+        atomicMax(&seg_max[tr.seg], mx);
+        if (!(s_red[8] & s_red[9] & s_red[10] & s_red[11])) atomicAnd(&seg_sorted[tr.seg], 0);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_stats_kernel(int32_t *seg_min, int32_t *seg_max, int32_t *seg_sorted, int32_t n) {
+    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (i < n) {
+        seg_min[i] = 0x7fffffff;
+        seg_max[i] = (int32_t)0x80000000;
+        seg_sorted[i] = 1;
+    }
+}
+
+// ---- fixed-width take ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gather_i32_kernel(const int32_t *__restrict__ src,
                                                             const int32_t *__restrict__ rows, int64_t n,
                                                             int32_t *__restrict__ out) {
@@ -15,62 +162,146 @@ __global__ __launch_bounds__(kBlock) void gather_i32_kernel(const int32_t *__res
         out[i] = src[rows[i]];
 }
 
-// out_off[i + 1] = sum_{k <= i} len(rows[k]);  out_off[0] = 0.  Single pass chained scan.
-__global__ __launch_bounds__(kBlock) void utf8_offsets_kernel(const int32_t *__restrict__ src_off,
-                                                              const int32_t *__restrict__ rows, int64_t n,
-                                                              uint64_t *status, uint32_t *err, int32_t n_tiles,
-                                                              int32_t *__restrict__ out_off, uint64_t *total) {
-    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
-    StripedScan sc;
-#pragma unroll 1
-    for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
-    const int64_t i0 = (int64_t)tile * kLenTile + (int64_t)threadIdx.x * kLenItems;
-    uint32_t len[kLenItems];
+// ---- Utf8 take: lengths (count) -> tile scan -> offsets + bytes (emit) --------------------------------------------
+// Tile = 2048 values; value  it*256 + tid  of the tile belongs to thread tid (it = 0..7): the row list and the
+// source offsets are read coalesced.  counts[tile*4 + wave] = bytes of the wave's values.
+constexpr int kLenItems = 8;
+constexpr int kLenTile = kBlock * kLenItems;
+constexpr int kStageBytes = 48 * 1024;  // LDS staging buffer of the emit kernel (tiles beyond it copy directly)
+
+__global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restrict__ src_off,
+                                                          const int32_t *__restrict__ rows, int64_t n,
+                                                          uint32_t *__restrict__ counts) {
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
     uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < kLenItems; ++k) {
-        len[k] = 0;
-        if (i0 + k < n) {
-            const int32_t r = rows[i0 + k];
-            len[k] = (uint32_t)(src_off[r + 1] - src_off[r]);
+    for (int k = 0; k < kLenItems; ++k)
+        if (i0 + k * kBlock < n) {
+            const int32_t r = rows[i0 + k * kBlock];
+            mine += (uint32_t)(src_off[r + 1] - src_off[r]);
         }
-        mine += len[k];
-    }
     const uint32_t incl = wave_incl_scan_u32(mine);
-    const uint32_t wave_total = __shfl(incl, 63, 64);
-    uint64_t tile_base, tile_total;
-    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err) + (incl - mine);
-    if (tile == 0 && threadIdx.x == 0) out_off[0] = 0;
+    if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
+}
+
+// Writes out_off and the bytes.  The tile's bytes form ONE contiguous range of the output, so they are assembled
+// in LDS (byte writes are cheap there) and streamed out with aligned 16-byte stores; byte-granular global stores
+// made this kernel 10x slower than everything else in q8.
+__global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__restrict__ src_off,
+                                                           const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
+                                                           int64_t n, const uint32_t *__restrict__ counts,
+                                                           const uint64_t *__restrict__ tile_base,
+                                                           int32_t *__restrict__ out_off, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];  // bytes of (iteration, wave)
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
+    const uint32_t tile_bytes = wc.x + wc.y + wc.z + wc.w;
+    const uint64_t base = tile_base[blockIdx.x];
+    int32_t b[kLenItems];
+    uint32_t len[kLenItems], excl[kLenItems];
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
-        pos += len[k];
-        if (i0 + k < n) out_off[i0 + k + 1] = (int32_t)pos;
+        b[k] = 0;
+        len[k] = 0;
+        if (i0 + k * kBlock < n) {
+            const int32_t r = rows[i0 + k * kBlock];
+            b[k] = src_off[r];
+            len[k] = (uint32_t)(src_off[r + 1] - b[k]);
+        }
+        const uint32_t incl = wave_incl_scan_u32(len[k]);
+        excl[k] = incl - len[k];
+        if (lane == 63) s_it[k * kWavesPerBlock + wave] = incl;
     }
-    if (threadIdx.x == 0 && tile == n_tiles - 1) *total = tile_base + tile_total;
-    }  // tile loop
+    __syncthreads();
+    // byte offset of (iteration k, wave) inside the tile: values are ordered iteration-major, then thread
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (w == wave) excl[k] += run;
+            run += s_it[k * kWavesPerBlock + w];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k)
+        if (i0 + k * kBlock < n) out_off[i0 + k * kBlock + 1] = (int32_t)(base + excl[k] + len[k]);
+    if (tile_bytes == 0) return;
+    const uint32_t phase = (uint32_t)(base & 15);  // LDS byte i holds output byte (base - phase) + i
+    const bool staged = phase + tile_bytes <= (uint32_t)kStageBytes;  // block-uniform
+    // The source is read through aligned 4-byte words (a string starts at any byte): the first four words of
+    // every value are requested together, before any of them is used -- one memory round trip for the whole
+    // tile instead of one per word.  (A word index is clamped to the string's last word: no read past its end.)
+    uint32_t w4[kLenItems][4];
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + (uint32_t)b[k];
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3));
+        const uint32_t last = len[k] ? (uint32_t)(((addr & 3) + len[k] - 1) >> 2) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[k][i] = len[k] ? w[min((uint32_t)i, last)] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+        if (len[k] == 0) continue;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + (uint32_t)b[k];
+        const uint32_t sh = (uint32_t)(addr & 3) * 8;
+        // bytes 0..12 of the string, realigned: d[i] = bytes 4i .. 4i+3
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[i] = __funnelshift_r(w4[k][i], w4[k][i + 1], sh);
+        d[3] = w4[k][3] >> sh;
+        uint8_t *dst = staged ? s_stage + phase + excl[k] : out + base + excl[k];
+        const uint32_t head = 16 - (sh >> 3);  // bytes available from the four words
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if ((uint32_t)c < len[k] && (uint32_t)c < head) dst[c] = (uint8_t)(d[c >> 2] >> (8 * (c & 3)));
+        if (len[k] > head) {  // long string: the rest word by word
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3)) + 4;
+            uint32_t done = head, cur = 0, have = 0;
+            while (done < len[k]) {
+                if (have == 0) {
+                    cur = *w++;
+                    have = 4;
+                }
+                dst[done++] = (uint8_t)cur;
+                cur >>= 8;
+                --have;
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    uint8_t *gout = out + (base - phase);  // 16-byte aligned
+    const uint32_t end = phase + tile_bytes;
+    for (uint32_t o = threadIdx.x * 16; o < end; o += kBlock * 16) {
+        if (o >= phase && o + 16 <= end) {
+            *reinterpret_cast<uint4 *>(gout + o) = *reinterpret_cast<const uint4 *>(s_stage + o);
+        } else {  // first / last chunk is shared with the neighbouring tile: only this tile's bytes
+            for (uint32_t c = (o < phase ? phase : o); c < o + 16 && c < end; ++c) gout[c] = s_stage[c];
+        }
+    }
 }
 
-// One lane per output value; short strings (NEXMark names / cities / states are <= 14 bytes).
-__global__ __launch_bounds__(kBlock) void utf8_copy_kernel(const int32_t *__restrict__ src_off,
-                                                           const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
-                                                           int64_t n, const int32_t *__restrict__ out_off,
-                                                           uint8_t *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int32_t r = rows[i];
-        const int32_t b = src_off[r], e = src_off[r + 1];
-        uint8_t *dst = out + out_off[i];
-        for (int32_t k = 0; k < e - b; ++k) dst[k] = src[b + k];
-    }
+// ---- in-place inclusive scan: tile sums -> tile scan -> apply -----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void scan_sum_kernel(const int32_t *__restrict__ data, int64_t n,
+                                                          uint32_t *__restrict__ counts) {
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + (int64_t)threadIdx.x * kLenItems;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) mine += (i0 + k < n) ? (uint32_t)data[i0 + k] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(mine);
+    if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
 }
 
-
-__global__ __launch_bounds__(kBlock) void scan_i32_kernel(int32_t *data, int64_t n, uint64_t *status, uint32_t *err,
-                                                          int32_t n_tiles) {
-    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
-    StripedScan sc;
-#pragma unroll 1
-    for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
-    const int64_t i0 = (int64_t)tile * kLenTile + (int64_t)threadIdx.x * kLenItems;
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(int32_t *data, int64_t n, const uint32_t *__restrict__ counts,
+                                                            const uint64_t *__restrict__ tile_base) {
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + (int64_t)threadIdx.x * kLenItems;
+    const int wave = threadIdx.x >> 6;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
     uint32_t v[kLenItems], mine = 0;
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
@@ -78,52 +309,13 @@ __global__ __launch_bounds__(kBlock) void scan_i32_kernel(int32_t *data, int64_t
         mine += v[k];
     }
     const uint32_t incl = wave_incl_scan_u32(mine);
-    const uint32_t wave_total = __shfl(incl, 63, 64);
-    uint64_t tile_base, tile_total;
-    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err) + (incl - mine);
+    uint64_t pos = tile_base[blockIdx.x] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u) +
+                   (incl - mine);
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
         pos += v[k];
         if (i0 + k < n) data[i0 + k] = (int32_t)pos;
     }
-    }  // tile loop
-}
-
-
-__global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *__restrict__ counts, int32_t n_tiles,
-                                                              uint64_t *__restrict__ tile_base,
-                                                              const int32_t *__restrict__ tile_first, int32_t n_seg,
-                                                              int64_t *__restrict__ seg_out_off) {
-    __shared__ uint64_t s_wave[kScanBlock / 64];
-    __shared__ uint64_t s_carry;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int32_t t0 = 0; t0 < n_tiles; t0 += kScanBlock) {
-        const int32_t t = t0 + (int32_t)threadIdx.x;
-        uint64_t c = 0;
-        if (t < n_tiles) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(counts + (size_t)t * kWavesPerBlock);
-            c = (uint64_t)w.x + w.y + w.z + w.w;
-        }
-        const uint64_t incl = wave_incl_scan_u64(c);
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint64_t before = s_carry;
-        for (int w = 0; w < wave; ++w) before += s_wave[w];
-        if (t < n_tiles) tile_base[t] = before + incl - c;
-        __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) s_carry = before + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_base[n_tiles] = s_carry;
-    __syncthreads();  // the block reads back its own global stores below (same CU, write-through L1)
-    if (seg_out_off)
-        for (int32_t s = threadIdx.x; s <= n_seg; s += kScanBlock) {
-            const int32_t t = tile_first[s];  // empty segments share the next segment's first tile
-            seg_out_off[s] = (int64_t)(t >= n_tiles ? s_carry : __hip_atomic_load(&tile_base[t], __ATOMIC_RELAXED,
-                                                                                  __HIP_MEMORY_SCOPE_AGENT));
-        }
 }
 
 }  // namespace
@@ -131,7 +323,7 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *_
 namespace flockgpu {
 
 int launch_tile_scan(flockgpu_ctx *ctx, const uint32_t *counts, int32_t n_tiles, uint64_t *tile_base,
-                            const int32_t *tile_first, int32_t n_seg, int64_t *seg_out_off) {
+                     const int32_t *tile_first, int32_t n_seg, int64_t *seg_out_off) {
     {
         LaunchScope ls(ctx, "tile_scan_kernel");
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, ctx->stream, counts, n_tiles, tile_base,
@@ -140,21 +332,52 @@ int launch_tile_scan(flockgpu_ctx *ctx, const uint32_t *counts, int32_t n_tiles,
     return check_launch(ctx, "tile_scan_kernel");
 }
 
+int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
+                      const uint64_t *tile_base, int32_t *out_rows) {
+    if (st.n_tiles <= 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "emit_rows_kernel");
+        hipLaunchKernelGGL(emit_rows_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, st, flag_words,
+                           counts, tile_base, out_rows);
+    }
+    return check_launch(ctx, "emit_rows_kernel");
+}
+
+int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, const SegTiles &st, int32_t *d_min,
+                      int32_t *d_max, int32_t *d_sorted) {
+    if (st.n_seg <= 0) return FLOCKGPU_OK;
+    hipLaunchKernelGGL(fill_stats_kernel, dim3((unsigned)div_up(st.n_seg, kBlock)), dim3(kBlock), 0, ctx->stream, d_min,
+                       d_max, d_sorted, st.n_seg);
+    FG_TRY(check_launch(ctx, "fill_stats_kernel"));
+    if (st.n_tiles <= 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "segment_stats_kernel");
+        hipLaunchKernelGGL(segment_stats_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, col, n_rows, st,
+                           d_min, d_max, d_sorted);
+    }
+    return check_launch(ctx, "segment_stats_kernel");
+}
 
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n) {
     if (n <= 0) return FLOCKGPU_OK;
     const int64_t tiles = div_up(n, kLenTile);
-    uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, name, (size_t)tiles + 2, &status));
-    FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)tiles + 2), ctx->stream));
+    if (tiles > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
+    const std::string k_c = std::string(name) + ".counts", k_b = std::string(name) + ".base";
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    FG_TRY(arena_get_t(ctx, k_c.c_str(), (size_t)tiles * kWavesPerBlock, &counts));
+    FG_TRY(arena_get_t(ctx, k_b.c_str(), (size_t)tiles + 1, &tile_base));
     {
-        unsigned grid = 1;
-        FG_TRY(persistent_grid(ctx, scan_i32_kernel, "scan_i32_kernel", tiles, &grid));
-        LaunchScope ls(ctx, "scan_i32_kernel");
-        hipLaunchKernelGGL(scan_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, data, n, status,
-                           reinterpret_cast<uint32_t *>(status + tiles), (int32_t)tiles);
+        LaunchScope ls(ctx, "scan_sum_kernel");
+        hipLaunchKernelGGL(scan_sum_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, data, n, counts);
     }
-    return check_launch(ctx, "scan_i32_kernel");
+    FG_TRY(check_launch(ctx, "scan_sum_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, (int32_t)tiles, tile_base, nullptr, 0, nullptr));
+    {
+        LaunchScope ls(ctx, "scan_apply_kernel");
+        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, data, n, counts, tile_base);
+    }
+    return check_launch(ctx, "scan_apply_kernel");
 }
 
 int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out) {
@@ -167,55 +390,68 @@ int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64
     return check_launch(ctx, "gather_i32_kernel");
 }
 
-int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
-                flockgpu_utf8 *out, int64_t *n_bytes) {
-    const std::string k_off = std::string(name) + ".off", k_bytes = std::string(name) + ".bytes",
-                      k_st = std::string(name) + ".scan";
+int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
+                      Utf8Gather *g) {
+    g->name = name;
+    g->src = src;
+    g->rows = rows;
+    g->n = n;
+    g->tiles = n > 0 ? div_up(n, kLenTile) : 0;
+    const std::string k_t = g->name + ".total";
+    FG_TRY(pinned_get_t(ctx, k_t.c_str(), 1, &g->h_total));
+    *g->h_total = 0;
+    if (n <= 0) return FLOCKGPU_OK;
+    if (g->tiles > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
+    const std::string k_c = g->name + ".counts", k_b = g->name + ".base";
+    FG_TRY(arena_get_t(ctx, k_c.c_str(), (size_t)g->tiles * kWavesPerBlock, &g->counts));
+    FG_TRY(arena_get_t(ctx, k_b.c_str(), (size_t)g->tiles + 1, &g->tile_base));
+    {
+        LaunchScope ls(ctx, "utf8_len_kernel");
+        hipLaunchKernelGGL(utf8_len_kernel, dim3((unsigned)g->tiles), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n,
+                           g->counts);
+    }
+    FG_TRY(check_launch(ctx, "utf8_len_kernel"));
+    FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)g->tiles, g->tile_base, nullptr, 0, nullptr));
+    FG_HIP(ctx, hipMemcpyAsync(g->h_total, g->tile_base + g->tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    return FLOCKGPU_OK;
+}
+
+int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes) {
+    const std::string k_off = g.name + ".off", k_bytes = g.name + ".bytes";
     int32_t *o_off = nullptr;
-    FG_TRY(arena_get_t(ctx, k_off.c_str(), (size_t)n + 1, &o_off));
+    uint8_t *o_b = nullptr;
+    FG_TRY(arena_get_t(ctx, k_off.c_str(), (size_t)std::max<int64_t>(g.n, 0) + 1, &o_off));
     out->offsets = o_off;
     out->data = nullptr;
     *n_bytes = 0;
-    if (n <= 0) {
+    if (g.n <= 0) {
         FG_HIP(ctx, hipMemsetAsync(o_off, 0, sizeof(int32_t), ctx->stream));
-        uint8_t *o_b = nullptr;
         FG_TRY(arena_get_t(ctx, k_bytes.c_str(), 16, &o_b));
         out->data = o_b;
         return FLOCKGPU_OK;
     }
-    const int64_t tiles = div_up(n, kLenTile);
-    uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, k_st.c_str(), (size_t)tiles + 3, &status));  // + error word + total
-    FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)tiles + 3), ctx->stream));
-    uint64_t *d_total = status + tiles + 1;
+    const uint64_t total = *g.h_total;
+    if (total > 0x7fffffffull)
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)",
+                    g.name.c_str());
+    FG_TRY(arena_get_t(ctx, k_bytes.c_str(), (size_t)total + 16, &o_b));
     {
-        unsigned grid = 1;
-        FG_TRY(persistent_grid(ctx, utf8_offsets_kernel, "utf8_offsets_kernel", tiles, &grid));
-        LaunchScope ls(ctx, "utf8_offsets_kernel");
-        hipLaunchKernelGGL(utf8_offsets_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n, status,
-                           reinterpret_cast<uint32_t *>(status + tiles), (int32_t)tiles, o_off, d_total);
+        LaunchScope ls(ctx, "utf8_emit_kernel");
+        hipLaunchKernelGGL(utf8_emit_kernel, dim3((unsigned)g.tiles), dim3(kBlock), 0, ctx->stream, g.src.offsets, g.src.data,
+                           g.rows, g.n, g.counts, g.tile_base, o_off, o_b);
     }
-    FG_TRY(check_launch(ctx, "utf8_offsets_kernel"));
-    uint64_t *h_words = nullptr;  // [0] = error word, [1] = total
-    FG_TRY(pinned_get_t(ctx, "gather_utf8.words", 2, &h_words));
-    FG_HIP(ctx, hipMemcpyAsync(h_words, status + tiles, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if ((uint32_t)h_words[0]) return fail(ctx, FLOCKGPU_ERR_HIP, "%s: chained scan stalled", name);
-    const uint64_t h_total = h_words[1];
-    if (h_total > 0x7fffffffull)
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)", name);
-    uint8_t *o_b = nullptr;
-    FG_TRY(arena_get_t(ctx, k_bytes.c_str(), (size_t)h_total + 16, &o_b));
-    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 8);
-    {
-        LaunchScope ls(ctx, "utf8_copy_kernel");
-        hipLaunchKernelGGL(utf8_copy_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src.offsets, src.data, rows, n,
-                           o_off, o_b);
-    }
-    FG_TRY(check_launch(ctx, "utf8_copy_kernel"));
+    FG_TRY(check_launch(ctx, "utf8_emit_kernel"));
     out->data = o_b;
-    *n_bytes = (int64_t)h_total;
+    *n_bytes = (int64_t)total;
     return FLOCKGPU_OK;
+}
+
+int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
+                flockgpu_utf8 *out, int64_t *n_bytes) {
+    Utf8Gather g;
+    FG_TRY(gather_utf8_begin(ctx, name, src, rows, n, &g));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return gather_utf8_finish(ctx, g, out, n_bytes);
 }
 
 }  // namespace flockgpu

@@ -1,20 +1,51 @@
-// take() for fixed-width and Utf8 columns on the device (the `take` calls DataFusion's HashJoinExec issues
-// to materialise join output).  Utf8 needs lengths -> exclusive scan -> byte copy.
+// Shared device-side primitives of the operator kernels (defined in gather.hip):
+//   * tile scan (count -> scan -> emit, scan.hpp)
+//   * flag words -> row list
+//   * exact per-window key range + sortedness of an int32 column
+//   * take() for fixed-width and Utf8 columns (the `take` calls DataFusion's HashJoinExec issues to materialise
+//     join output).  Utf8: lengths -> tile scan -> offsets + byte copy in one kernel.
 #pragma once
+#include <string>
+
 #include "scan.hpp"
 
 namespace flockgpu {
 
+// out_rows[tile_base[tile] + i] = global row number of the i-th flagged row of the tile (row order).
+// flag_words / counts as written by store_flags_and_counts (scan.hpp) over kFlagTile-row tiles of `st`.
+int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
+                      const uint64_t *tile_base, int32_t *out_rows);
+
+// Exact per-segment minimum / maximum of `col` and whether the segment is strictly increasing (sorted and
+// duplicate-free).  d_min / d_max / d_sorted: device arrays of st.n_seg entries, initialised by the call
+// (INT32_MAX / INT32_MIN / 1); empty segments keep those values.  `st` must use kFlagTile-row tiles.
+int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, const SegTiles &st, int32_t *d_min,
+                      int32_t *d_max, int32_t *d_sorted);
+
 int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out);
 
-// Gathers `n` Utf8 values.  out_off (n + 1 entries) and out_bytes live in the ctx arena under `name`;
-// *n_bytes receives the total byte count (host value; the call synchronises the stream).
+// Gathers `n` Utf8 values in two phases so that several columns share ONE host synchronisation:
+//   begin  : lengths -> tile scan; queues the D2H copy of the total byte count (the host needs it to size the
+//            byte buffer; Arrow Utf8 offsets are int32, so it must also be checked against 2^31)
+//   -- the caller synchronises the stream once --
+//   finish : offsets + bytes.  out_off (n + 1 entries) and out_bytes live in the ctx arena under `name`.
+struct Utf8Gather {
+    std::string name;
+    flockgpu_utf8 src{};
+    const int32_t *rows = nullptr;
+    int64_t n = 0, tiles = 0;
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    uint64_t *h_total = nullptr;  // pinned
+};
+int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
+                      Utf8Gather *g);
+int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes);
+// begin + synchronise + finish for a single column.
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
                 flockgpu_utf8 *out, int64_t *n_bytes);
 
-}  // namespace flockgpu
-
-namespace flockgpu {
-// In-place inclusive scan of n int32 values (single-pass chained scan); `name` keys the scan-state arena buffer.
+// In-place inclusive scan of n int32 values; `name` keys the scan-state arena buffers.
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n);
+
 }  // namespace flockgpu

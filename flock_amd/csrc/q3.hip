@@ -3,13 +3,21 @@
 //   -> Projection [name, city, state, a_id]
 // (benchmarks/src/nexmark/query/q3.sql, q3_plan.fmt:1-6, flock/src/distributed_plan/planner.rs:152-171).
 //
-// All windows of a schedule run in THREE launches (build, probe, gathers), not three per epoch: a tile never
-// straddles a window and every window owns a region of one global hash table, so per-epoch work of a few
-// hundred KB does not become launch-latency bound (SURVEY.md section 7 "hard parts").
-//   build : persons -> state filter (byte compare on the Utf8 buffers) -> multimap insert keyed p_id
-//   probe : auctions -> category filter -> lookup seller -> order-preserving expansion of the matching
-//           (auction_row, person_row) pairs via the single-pass chained scan
-//   gather: take() of a_id and of the three Utf8 columns
+// All windows of a schedule run in a handful of launches, not a handful per epoch: a tile never straddles a
+// window and every window owns a region of one global table, so per-epoch work of a few hundred KB does not become
+// launch-latency bound (SURVEY.md section 7 "hard parts").  Every step is a plain streaming grid or
+// count -> scan -> emit (scan.hpp); no workgroup waits on another one.
+//   stats : exact [min, max] of p_id per window and whether the window's p_ids are strictly increasing
+//   DENSE path (every window's p_ids strictly increasing -- hence unique -- and their range affordable; NEXMark ids
+//   are dense and time-ordered): the join table is a direct-address array  table[p_id - min] = person row  per
+//   window (a perfect hash: no probing, no atomics, 4 B per id, L2 / MALL resident)
+//     build : persons -> state filter (byte compare on the Utf8 buffers) -> one plain store per surviving person
+//     probe : auctions -> category filter -> one table load per surviving auction -> row flags (flag tiles)
+//     emit  : flag words -> (auction_row, person_row, a_id) in auction order
+//   GENERAL path (duplicate / unsorted / sparse p_ids): multimap keyed p_id (one 64-bit CAS slot {key, head row} +
+//   chain array) built from the filtered persons; the probe counts, then emits, every matching pair.
+//   take  : the three Utf8 columns of the matching persons (lengths -> scan -> offsets + bytes), one host
+//           synchronisation for all three.
 // DataFusion builds on the LEFT (auction) side; which side is hashed is unobservable in the result multiset,
 // so the smaller, key-unique side is built here while duplicates on either side still produce every pair.
 #include <algorithm>
@@ -28,11 +36,11 @@ struct Utf8Lits {  // literals of the `state = lit OR ...` chain, each <= 8 byte
     int32_t n;
 };
 
-constexpr int kBuildItems = 8;
-constexpr int kBuildTile = kBlock * kBuildItems;  // 2048 persons per workgroup
-constexpr int kProbeIters = 2;
-constexpr int kProbeTile = kBlock * 4 * kProbeIters;  // 2048 auctions per workgroup
-constexpr int kProbeWaveRows = kProbeTile / kWavesPerBlock;
+struct WinTable {
+    int32_t base;     // min p_id of the window
+    uint32_t range;   // max - min + 1 (0: the window has no persons)
+    uint64_t off;     // offset of the window's entries in the table arena
+};
 
 __device__ __forceinline__ bool utf8_in(const int32_t *__restrict__ off, const uint8_t *__restrict__ data, int64_t row,
                                         const Utf8Lits &lits) {
@@ -47,100 +55,145 @@ __device__ __forceinline__ bool utf8_in(const int32_t *__restrict__ off, const u
     return hit;
 }
 
+// ---- build (both paths): one lane per person row, flag-tile row layout -----------------------------------------
+template <bool kDense>
 __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restrict__ p_id,
                                                           const int32_t *__restrict__ state_off,
                                                           const uint8_t *__restrict__ state_data, SegTiles st, Utf8Lits lits,
+                                                          const WinTable *__restrict__ wins, int32_t *direct,
                                                           uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err) {
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kBuildTile);
-    uint64_t *tab = tables + (size_t)tr.seg * cap;
-#pragma unroll
-    for (int it = 0; it < kBuildItems; ++it) {
-        const int64_t r = tr.tile_begin + it * kBlock + threadIdx.x;
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    WinTable wt{};
+    if (kDense) wt = wins[tr.seg];
+    uint64_t *tab = kDense ? nullptr : tables + (size_t)tr.seg * cap;
+#pragma unroll 1
+    for (int e = 0; e < kFlagIters * 4; ++e) {
+        const int64_t r = wbase + (e >> 2) * 256 + (e & 3);
         if (r < tr.lo || r >= tr.hi) continue;
         if (!utf8_in(state_off, state_data, r, lits)) continue;
-        if (!multimap_insert(tab, cap, next, p_id[r], (int32_t)r)) atomicOr(err, 1u);
+        if (kDense) {
+            direct[wt.off + (uint32_t)(p_id[r] - wt.base)] = (int32_t)r;
+        } else if (!multimap_insert(tab, cap, next, p_id[r], (int32_t)r)) {
+            atomicOr(err, 1u);
+        }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void q3_probe_kernel(const int32_t *__restrict__ seller,
-                                                          const int32_t *__restrict__ category, int64_t n_rows,
-                                                          int64_t category_lit, SegTiles st, const uint64_t *tables,
-                                                          uint32_t cap, const int32_t *__restrict__ next, uint64_t *status,
-                                                          uint32_t *err, int32_t *__restrict__ out_auction_row,
-                                                          int32_t *__restrict__ out_person_row, uint64_t out_cap,
-                                                          int64_t *seg_out_off) {
-    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
-    StripedScan sc;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-#pragma unroll 1
-    for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
-    const TileRange tr = locate_tile(st, tile, kProbeTile);
-    const uint64_t *tab = tables + (size_t)tr.seg * cap;
-    const int64_t wbase = tr.tile_begin + (int64_t)wave * kProbeWaveRows + lane * 4;
-
-    int32_t head[kProbeIters][4];
-    uint32_t cnt[kProbeIters][4];
-    uint32_t lane_rank[kProbeIters], it_total[kProbeIters], wave_total = 0;
+// ---- dense probe: flags, then (auction_row, person_row, a_id) ----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__restrict__ seller,
+                                                               const int32_t *__restrict__ category, int64_t n_rows,
+                                                               int64_t category_lit, SegTiles st,
+                                                               const WinTable *__restrict__ wins,
+                                                               const int32_t *__restrict__ direct,
+                                                               uint32_t *__restrict__ flag_words,
+                                                               uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const WinTable wt = wins[tr.seg];
+    int32_t s[kFlagIters][4], c[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, s);
+    load_flag_tile(category, n_rows, tr, c);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+    const int32_t *tab = direct + wt.off;
+    uint32_t flags = 0;
 #pragma unroll
-    for (int it = 0; it < kProbeIters; ++it) {
-        const int64_t r0 = wbase + it * 256;
-        int32_t s4[4], c4[4];
-        if (r0 + 4 <= n_rows) {
-            const int4 a = *reinterpret_cast<const int4 *>(seller + r0);
-            const int4 b = *reinterpret_cast<const int4 *>(category + r0);
-            s4[0] = a.x; s4[1] = a.y; s4[2] = a.z; s4[3] = a.w;
-            c4[0] = b.x; c4[1] = b.y; c4[2] = b.z; c4[3] = b.w;
-        } else {
+    for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s4[j] = (r0 + j < n_rows) ? seller[r0 + j] : 0;
-                c4[j] = (r0 + j < n_rows) ? category[r0 + j] : 0;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const uint32_t idx = (uint32_t)s[it][j] - (uint32_t)wt.base;
+            bool f = false;
+            if (rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range) f = tab[idx] >= 0;
+            flags |= (f ? 1u : 0u) << (it * 4 + j);
         }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+
+__global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__restrict__ seller,
+                                                               const int32_t *__restrict__ a_id, SegTiles st,
+                                                               const uint32_t *__restrict__ flag_words,
+                                                               const uint32_t *__restrict__ counts,
+                                                               const uint64_t *__restrict__ tile_base,
+                                                               const WinTable *__restrict__ wins,
+                                                               const int32_t *__restrict__ direct,
+                                                               int32_t *__restrict__ out_auction_row,
+                                                               int32_t *__restrict__ out_person_row,
+                                                               int32_t *__restrict__ out_a_id) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const WinTable wt = wins[tr.seg];
+    const uint64_t base = tile_base[tile];
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const int64_t r = tr.tile_begin + s_list[i];
+        out_auction_row[base + i] = (int32_t)r;
+        out_person_row[base + i] = direct[wt.off + (uint32_t)(seller[r] - wt.base)];
+        out_a_id[base + i] = a_id[r];
+    }
+}
+
+// ---- general probe: every (auction, person) pair of a key, counted then emitted in auction order ------------------
+template <bool kEmit>
+__global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t *__restrict__ seller,
+                                                                  const int32_t *__restrict__ category,
+                                                                  const int32_t *__restrict__ a_id, int64_t n_rows,
+                                                                  int64_t category_lit, SegTiles st, const uint64_t *tables,
+                                                                  uint32_t cap, const int32_t *__restrict__ next,
+                                                                  uint32_t *counts, const uint64_t *__restrict__ tile_base,
+                                                                  int32_t *__restrict__ out_auction_row,
+                                                                  int32_t *__restrict__ out_person_row,
+                                                                  int32_t *__restrict__ out_a_id) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const uint64_t *tab = tables + (size_t)tr.seg * cap;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint64_t pos = 0;
+    if (kEmit) {
+        const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+        if (wc.x + wc.y + wc.z + wc.w == 0) return;
+        pos = tile_base[tile] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u);
+    }
+    uint32_t wave_total = 0;
+#pragma unroll 1
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+        int32_t s4[4], c4[4], head[4];
+        load4_i32(seller, r0, n_rows, s4);
+        load4_i32(category, r0, n_rows, c4);
         uint32_t mine = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r0 + j;
-            head[it][j] = -1;
-            cnt[it][j] = 0;
+            head[j] = -1;
             if (r >= tr.lo && r < tr.hi && (int64_t)c4[j] == category_lit) {
-                const int32_t h = multimap_find(tab, cap, s4[j]);
-                head[it][j] = h;
-                uint32_t n = 0;
-                for (int32_t p = h; p >= 0; p = next[p]) ++n;
-                cnt[it][j] = n;
-                mine += n;
+                head[j] = multimap_find(tab, cap, s4[j]);
+                for (int32_t p = head[j]; p >= 0; p = next[p]) ++mine;
             }
         }
         const uint32_t incl = wave_incl_scan_u32(mine);
-        lane_rank[it] = incl - mine;
-        it_total[it] = __shfl(incl, 63, 64);
-        wave_total += it_total[it];
-    }
-    uint64_t tile_base, tile_total;
-    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err);
-    if (threadIdx.x == 0) {
-        if (tile == st.tile_first[tr.seg]) seg_out_off[tr.seg] = (int64_t)tile_base;
-        if (tile == st.n_tiles - 1) seg_out_off[st.n_seg] = (int64_t)(tile_base + tile_total);
-    }
-    if (wave_total == 0) continue;
+        const uint32_t it_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (kEmit && it_total) {
+            uint64_t p = pos + (incl - mine);
 #pragma unroll
-    for (int it = 0; it < kProbeIters; ++it) {
-        uint64_t p = pos + lane_rank[it];
-        const int64_t r0 = wbase + it * 256;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            for (int32_t q = head[it][j]; q >= 0; q = next[q]) {
-                if (p < out_cap) {  // a too-small pair buffer is detected by the host from the scan total
+            for (int j = 0; j < 4; ++j)
+                for (int32_t q = head[j]; q >= 0; q = next[q]) {
                     out_auction_row[p] = (int32_t)(r0 + j);
                     out_person_row[p] = q;
+                    out_a_id[p] = a_id[r0 + j];
+                    ++p;
                 }
-                ++p;
-            }
         }
-        pos += it_total[it];
+        pos += it_total;
+        wave_total += it_total;
     }
-    }  // tile loop
+    if (!kEmit && lane == 0) counts[(size_t)tile * kWavesPerBlock + wave] = wave_total;
 }
 
 }  // namespace
@@ -163,8 +216,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         return fail(ctx, FLOCKGPU_ERR_INVALID, "q3: null auction column");
     if (person->rows > 0 && (!person->p_id || !person->state.offsets || !person->name.offsets || !person->city.offsets))
         return fail(ctx, FLOCKGPU_ERR_INVALID, "q3: null person column");
-    if ((reinterpret_cast<uintptr_t>(auction->seller) & 15) || (reinterpret_cast<uintptr_t>(auction->category) & 15))
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: auction columns must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(auction->seller) & 15) || (reinterpret_cast<uintptr_t>(auction->category) & 15) ||
+        (reinterpret_cast<uintptr_t>(person->p_id) & 15))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: seller, category and p_id columns must be 16-byte aligned");
     if (n_state_lits < 0 || n_state_lits > kMaxLits) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: more than 8 literals");
     Utf8Lits lits{};
     lits.n = n_state_lits;
@@ -187,77 +241,134 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         max_person_rows = std::max(max_person_rows, pe[w] - pb[w]);
     }
     SegTiles st_a, st_p;
-    FG_TRY(build_seg_tiles(ctx, "q3.auction", ab.data(), ae.data(), n_win, kProbeTile, &st_a));
-    FG_TRY(build_seg_tiles(ctx, "q3.person", pb.data(), pe.data(), n_win, kBuildTile, &st_p));
+    FG_TRY(build_seg_tiles(ctx, "q3.auction", ab.data(), ae.data(), n_win, kFlagTile, &st_a));
+    FG_TRY(build_seg_tiles(ctx, "q3.person", pb.data(), pe.data(), n_win, kFlagTile, &st_p));
 
-    const uint64_t cap64 = std::max<uint64_t>(64, (uint64_t)max_person_rows * 3 / 2 + 8);
-    if (cap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: window too large for one table region");
-    const uint32_t cap = (uint32_t)cap64;
-    uint64_t *tables = nullptr;
-    int32_t *next = nullptr;
-    FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
-    FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
-    uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, "q3.status", (size_t)st_a.n_tiles + 4, &status));  // + spare, err, pair total
+    // per-window key statistics of the persons: {min, max, sorted} x n_win
+    int32_t *d_stats = nullptr, *h_stats = nullptr;
+    FG_TRY(arena_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
+    FG_TRY(pinned_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
+    FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
+    if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    bool dense = true;
+    uint64_t n_entries = 0;
+    std::vector<WinTable> wins(std::max(n_win, 1));
+    for (int w = 0; w < n_win && dense; ++w) {
+        wins[w] = WinTable{0, 0, n_entries};
+        if (pe[w] == pb[w]) continue;
+        const int64_t mn = h_stats[w], mx = h_stats[n_win + w], range = mx - mn + 1;
+        if (!h_stats[2 * n_win + w] || range > 8 * (pe[w] - pb[w]) + 1024) {
+            dense = false;
+            break;
+        }
+        wins[w].base = (int32_t)mn;
+        wins[w].range = (uint32_t)range;
+        n_entries += (uint64_t)range;
+    }
+
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    FG_TRY(arena_get_t(ctx, "q3.counts", (size_t)st_a.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, "q3.tile_base", (size_t)st_a.n_tiles + 1, &tile_base));
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.seg_out_off", (size_t)n_win + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "q3.seg_out_off", (size_t)n_win + 2, &h_off));
-    FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)st_a.n_tiles + 4), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
-    uint32_t *d_err = reinterpret_cast<uint32_t *>(status + st_a.n_tiles + 1);
+    uint32_t *d_err = nullptr;
+    FG_TRY(arena_get_t(ctx, "q3.err", 4, &d_err));
 
-    if (st_p.n_tiles > 0) {
-        LaunchScope ls(ctx, "q3_build_kernel");
-        hipLaunchKernelGGL(q3_build_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                           person->state.offsets, person->state.data, st_p, lits, tables, cap, next, d_err);
-    }
-    FG_TRY(check_launch(ctx, "q3_build_kernel"));
-    // The pair buffers are sized optimistically (one match per auction row: p_id is unique in NEXMark); the
-    // chained scan's grand total tells the host when a hot build key needed more, and the probe is redone.
-    uint64_t out_cap = 16;
-    for (int w = 0; w < n_win; ++w) out_cap += (uint64_t)(ae[w] - ab[w]);
-    int32_t *o_ar = nullptr, *o_pr = nullptr, *o_aid = nullptr;
-    uint64_t n_pairs = 0;
-    for (int attempt = 0;; ++attempt) {
-        FG_TRY(arena_get_t(ctx, "q3.out_auction_row", (size_t)out_cap, &o_ar));
-        FG_TRY(arena_get_t(ctx, "q3.out_person_row", (size_t)out_cap, &o_pr));
-        if (attempt > 0) {
-            FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)st_a.n_tiles + 1), ctx->stream));
-            FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
+    // dense-path state
+    WinTable *d_wins = nullptr;
+    int32_t *direct = nullptr;
+    uint32_t *flag_words = nullptr;
+    // general-path state
+    uint64_t *tables = nullptr;
+    int32_t *next = nullptr;
+    uint32_t cap = 0;
+
+    if (dense) {
+        WinTable *h_wins = nullptr;
+        FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)std::max(n_win, 1), &d_wins));
+        FG_TRY(pinned_get_t(ctx, "q3.wins", (size_t)std::max(n_win, 1), &h_wins));
+        std::copy(wins.begin(), wins.begin() + n_win, h_wins);
+        FG_TRY(arena_get_t(ctx, "q3.direct", (size_t)n_entries + 4, &direct));
+        FG_TRY(arena_get_t(ctx, "q3.flag_words", (size_t)st_a.n_tiles * kBlock, &flag_words));
+        if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, sizeof(WinTable) * n_win, hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(direct, 0xFF, sizeof(int32_t) * ((size_t)n_entries + 4), ctx->stream));
+        if (st_p.n_tiles > 0) {
+            LaunchScope ls(ctx, "q3_build_kernel");
+            hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
+                               person->state.offsets, person->state.data, st_p, lits, d_wins, direct, nullptr, 0u, nullptr,
+                               d_err);
         }
+        FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
-            unsigned grid = 1;
-            FG_TRY(persistent_grid(ctx, q3_probe_kernel, "q3_probe_kernel", st_a.n_tiles, &grid));
-            LaunchScope ls(ctx, "q3_probe_kernel");
-            hipLaunchKernelGGL(q3_probe_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
-                               auction->category, auction->rows, category_lit, st_a, tables, cap, next, status, d_err, o_ar,
-                               o_pr, out_cap, d_off);
+            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            hipLaunchKernelGGL(q3_probe_flag_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                               auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct,
+                               flag_words, counts);
         }
-        FG_TRY(check_launch(ctx, "q3_probe_kernel"));
-        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_TRY(check_launch(ctx, "q3_probe_flag_kernel"));
+    } else {
+        const uint64_t cap64 = std::max<uint64_t>(64, (uint64_t)max_person_rows * 3 / 2 + 8);
+        if (cap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: window too large for one table region");
+        cap = (uint32_t)cap64;
+        FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
+        FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
+        FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+        if (st_p.n_tiles > 0) {
+            LaunchScope ls(ctx, "q3_build_kernel");
+            hipLaunchKernelGGL(q3_build_kernel<false>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
+                               person->state.offsets, person->state.data, st_p, lits, nullptr, nullptr, tables, cap, next,
+                               d_err);
+        }
+        FG_TRY(check_launch(ctx, "q3_build_kernel"));
+        if (st_a.n_tiles > 0) {
+            LaunchScope ls(ctx, "q3_probe_count_kernel");
+            hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                               auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
+                               next, counts, nullptr, nullptr, nullptr, nullptr);
+        }
+        FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (const uint32_t h_err = *reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
-            if (h_err & 2u) return fail(ctx, FLOCKGPU_ERR_HIP, "q3: chained scan stalled");
-            return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
-        }
-        n_pairs = st_a.n_tiles == 0 ? 0 : (uint64_t)h_off[n_win];
-        if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");
-        if (n_pairs <= out_cap) break;
-        if (attempt > 0) return fail(ctx, FLOCKGPU_ERR_HIP, "q3: pair count changed between probes");
-        out_cap = n_pairs + 16;
     }
-    FG_TRY(arena_get_t(ctx, "q3.out_a_id", (size_t)n_pairs + 1, &o_aid));
-    FG_TRY(gather_i32(ctx, auction->a_id, o_ar, (int64_t)n_pairs, o_aid));
-    FG_TRY(gather_utf8(ctx, "q3.out_name", person->name, o_pr, (int64_t)n_pairs, &out->name, &out->name_bytes));
-    FG_TRY(gather_utf8(ctx, "q3.out_city", person->city, o_pr, (int64_t)n_pairs, &out->city, &out->city_bytes));
-    FG_TRY(gather_utf8(ctx, "q3.out_state", person->state, o_pr, (int64_t)n_pairs, &out->state, &out->state_bytes));
+    FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!dense && *reinterpret_cast<uint32_t *>(h_off + n_win + 1))
+        return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
     std::vector<int64_t> &offs = ctx->host_i64["q3.win_out_offsets"];
-    offs.assign(h_off, h_off + n_win + 1);  // (read before the gathers reuse nothing of h_off)
-    if (st_a.n_tiles == 0) offs[n_win] = 0;
-    for (int w = n_win - 1; w >= 0; --w)
-        if (offs[w] < 0) offs[w] = offs[w + 1];
+    offs.assign(h_off, h_off + n_win + 1);
+    const uint64_t n_pairs = (uint64_t)offs[n_win];
+    if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");
+
+    int32_t *o_ar = nullptr, *o_pr = nullptr, *o_aid = nullptr;
+    FG_TRY(arena_get_t(ctx, "q3.out_auction_row", (size_t)n_pairs + 1, &o_ar));
+    FG_TRY(arena_get_t(ctx, "q3.out_person_row", (size_t)n_pairs + 1, &o_pr));
+    FG_TRY(arena_get_t(ctx, "q3.out_a_id", (size_t)n_pairs + 1, &o_aid));
+    if (st_a.n_tiles > 0 && n_pairs > 0) {
+        if (dense) {
+            LaunchScope ls(ctx, "q3_emit_dense_kernel");
+            hipLaunchKernelGGL(q3_emit_dense_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
+                               auction->a_id, st_a, flag_words, counts, tile_base, d_wins, direct, o_ar, o_pr, o_aid);
+        } else {
+            LaunchScope ls(ctx, "q3_probe_emit_kernel");
+            hipLaunchKernelGGL(q3_probe_general_kernel<true>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                               auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
+                               next, counts, tile_base, o_ar, o_pr, o_aid);
+        }
+        FG_TRY(check_launch(ctx, "q3 emit"));
+    }
+    Utf8Gather g_name, g_city, g_state;
+    FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)n_pairs, &g_name));
+    FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)n_pairs, &g_city));
+    FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)n_pairs, &g_state));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(gather_utf8_finish(ctx, g_name, &out->name, &out->name_bytes));
+    FG_TRY(gather_utf8_finish(ctx, g_city, &out->city, &out->city_bytes));
+    FG_TRY(gather_utf8_finish(ctx, g_state, &out->state, &out->state_bytes));
     out->a_id = o_aid;
     out->auction_row = o_ar;
     out->person_row = o_pr;

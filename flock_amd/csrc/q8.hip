@@ -3,13 +3,19 @@
 //   ON p_id = seller  ->  [p_id, name]
 // (benchmarks/src/nexmark/query/q8.sql, q8_plan.fmt:1-10, playground/.../nexmark/q8.dag).
 //
-//   sellers : auctions -> DISTINCT seller as a hash set per window.  75 % of the rows of a tile carry the
-//             current hot seller (event.rs:255-259): each wave drops lanes whose key equals the wave's first
-//             key, and an already-present key costs one L2 load, no atomic.
-//   persons : persons -> DISTINCT (p_id, name): claim a slot keyed by p_id with the row index; a loser of the
-//             claim compares its full key (p_id and name bytes) with the winner's and is dropped when equal.
-//             Surviving rows probe the seller set; survivors are compacted in row order by the chained scan.
-//   gather  : take() of p_id and name.
+// HBM-bound integer work, no MFMA.  Every step is count -> scan -> emit or a plain streaming grid (scan.hpp).
+//
+// stats   : exact [min, max] of p_id per window and whether the window's p_ids are strictly increasing.
+// DENSE path (every window strictly increasing = already DISTINCT, key range affordable -- NEXMark ids are dense
+// and time-ordered):
+//   sellers : DISTINCT seller as a BITMAP over the window's [min p_id, max p_id] (a seller outside that range can
+//             never join).  A tile's keys span a few thousand ids, so the workgroup ORs them into an LDS bitmap
+//             (the hot seller -- 3/4 of all auctions, event.rs:255-259 -- is collapsed per wave and never reaches
+//             LDS) and flushes the non-zero words with fire-and-forget atomicOr: ~1 global atomic per 16 ids.
+//   persons : one bit test per person; the 32 row flags of a lane go out as one word (flag tiles, scan.hpp).
+// GENERAL path (any window with unsorted / duplicate p_ids, or a sparse key range): DISTINCT seller as a hash set,
+//   DISTINCT (p_id, name) by claiming a slot keyed p_id and comparing full keys with the claimant.
+// Both paths leave flag words; tile scan -> row list -> take() of p_id and name finish the query.
 #include <algorithm>
 
 #include "gather.hpp"
@@ -19,38 +25,168 @@ using namespace flockgpu;
 
 namespace {
 
-constexpr int kSellerIters = 4;
-constexpr int kSellerTile = kBlock * 4 * kSellerIters;  // 4096 auctions per workgroup
-constexpr int kPersonItems = 8;
-constexpr int kPersonTile = kBlock * kPersonItems;      // 2048 persons per workgroup
-constexpr int kPersonWaveRows = kPersonTile / kWavesPerBlock;
+struct WinBitmap {
+    int32_t base;       // first key of the window's bitmap (multiple of 32 at or below min p_id)
+    uint32_t n_bits;    // 0: the window has no persons
+    uint64_t word_off;  // offset of the window's words in the bitmap arena
+};
 
-__global__ __launch_bounds__(kBlock) void q8_sellers_kernel(const int32_t *__restrict__ seller, int64_t n_rows, SegTiles st,
-                                                            uint64_t *sets, uint32_t cap, uint32_t *err) {
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kSellerTile);
-    uint64_t *set = sets + (size_t)tr.seg * cap;
+constexpr int kBmLdsWords = 1024;  // 32768 ids: the span an LDS-staged tile may cover
+
+// ---- dense path -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitmap_or_global(uint32_t *gw, uint32_t bits) {
+    // a stale read can only miss bits (bits are never cleared), which costs a redundant atomic, never a lost one
+    if ((*gw & bits) != bits) __hip_atomic_fetch_or(gw, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t *__restrict__ seller, int64_t n_rows,
+                                                                   SegTiles st, const WinBitmap *__restrict__ wins,
+                                                                   uint32_t *bitmaps) {
+    __shared__ uint32_t s_bm[kBmLdsWords];
+    __shared__ uint32_t s_red[2 * kWavesPerBlock];
+    for (int s = threadIdx.x; s < kBmLdsWords; s += kBlock) s_bm[s] = 0;
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const WinBitmap wb = wins[tr.seg];
+    if (wb.n_bits == 0) return;
+    int32_t a[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, a);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    // bit index of every key (-1 = row outside the window or key outside the bitmap)
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
 #pragma unroll
-    for (int it = 0; it < kSellerIters; ++it) {
-        const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-        int32_t k[4];
-        if (r0 + 4 <= n_rows) {
-            const int4 t = *reinterpret_cast<const int4 *>(seller + r0);
-            k[0] = t.x; k[1] = t.y; k[2] = t.z; k[3] = t.w;
-        } else {
+    for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) k[j] = (r0 + j < n_rows) ? seller[r0 + j] : 0;
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
+            const bool ok = rel >= rel_lo && rel < rel_hi && idx < wb.n_bits && idx < 0x7fffffffu;
+            a[it][j] = ok ? (int32_t)idx : -1;
+            if (ok) {
+                mn = min(mn, idx);
+                mx = max(mx, idx);
+            }
         }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    }
+    if (lane == 0) {
+        s_red[wave] = mn;
+        s_red[kWavesPerBlock + wave] = mx;
+    }
+    __syncthreads();  // also orders the zeroing of s_bm
+    mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    if (mn == 0xFFFFFFFFu) return;  // no key of the tile can join
+    const uint32_t w0 = mn >> 5, n_words = (mx >> 5) - w0 + 1;
+    uint32_t *gbm = bitmaps + wb.word_off;
+    const bool staged = n_words <= (uint32_t)kBmLdsWords;  // block-uniform
+    int32_t hot = -2;  // wave-uniform: the key most lanes hold right now (3/4 of the auctions name ONE seller)
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        // Lanes holding the hot key drop it; one lane sets its bit.  48 lanes OR-ing the same LDS word in one
+        // instruction serialise, and a candidate taken from lane 0 alone is wrong one time in four -- so the
+        // candidate is kept while it still covers >= 16 lanes and otherwise re-elected from two lanes.
+        uint64_t m = __ballot(a[it][0] == hot);
+        if (__popcll((unsigned long long)m) < 16) {
+            const uint64_t live = __ballot(a[it][0] >= 0);
+            hot = -2;
+            m = 0;
+            if (live) {
+                const int l1 = __ffsll((unsigned long long)live) - 1;
+                const int32_t c1 = __builtin_amdgcn_readlane(a[it][0], l1);
+                const uint64_t m1 = __ballot(a[it][0] == c1);
+                hot = c1;
+                m = m1;
+                const uint64_t rest = live & ~m1;
+                if (__popcll((unsigned long long)m1) < 16 && rest) {
+                    const int l2 = __ffsll((unsigned long long)rest) - 1;
+                    const int32_t c2 = __builtin_amdgcn_readlane(a[it][0], l2);
+                    const uint64_t m2 = __ballot(a[it][0] == c2);
+                    if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                        hot = c2;
+                        m = m2;
+                    }
+                }
+            }
+        }
+        const int src = m ? __ffsll((unsigned long long)m) - 1 : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t v = a[it][j];
+            if (v == hot && !(lane == src && j == 0)) v = -1;
+            if (v < 0) continue;
+            const uint32_t idx = (uint32_t)v, bit = 1u << (idx & 31);
+            if (staged) {
+                uint32_t *w = &s_bm[(idx >> 5) - w0];
+                // a set bit stays set: testing first spares the atomic (and its same-word serialisation)
+                if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)) atomicOr(w, bit);
+            } else {
+                bitmap_or_global(gbm + (idx >> 5), bit);
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_words; s += kBlock) {
+        const uint32_t bits = s_bm[s];
+        if (bits) bitmap_or_global(gbm + w0 + s, bits);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *__restrict__ p_id, int64_t n_rows,
+                                                                 SegTiles st, const WinBitmap *__restrict__ wins,
+                                                                 const uint32_t *__restrict__ bitmaps,
+                                                                 uint32_t *__restrict__ flag_words,
+                                                                 uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const WinBitmap wb = wins[tr.seg];
+    int32_t a[kFlagIters][4];
+    load_flag_tile(p_id, n_rows, tr, a);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+    const uint32_t *gbm = bitmaps + wb.word_off;
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
+            bool f = false;
+            if (rel >= rel_lo && rel < rel_hi && idx < wb.n_bits) f = (gbm[idx >> 5] >> (idx & 31)) & 1u;
+            flags |= (f ? 1u : 0u) << (it * 4 + j);
+        }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+
+// ---- general path -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void q8_sellers_set_kernel(const int32_t *__restrict__ seller, int64_t n_rows,
+                                                                SegTiles st, uint64_t *sets, uint32_t cap, uint32_t *err) {
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    uint64_t *set = sets + (size_t)tr.seg * cap;
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    const int lane = lane_id();
+#pragma unroll 1
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+        int32_t k[4];
+        load4_i32(seller, r0, n_rows, k);
         bool v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (r0 + j >= tr.lo) && (r0 + j < tr.hi);
-        // wave collapse of the hot seller: only the first live lane keeps it
         const uint64_t live = __ballot(v[0]);
         if (live) {
             const int src = __ffsll((unsigned long long)live) - 1;
             const int32_t hot = __shfl(k[0], src, 64);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (v[j] && k[j] == hot && !(lane_id() == src && j == 0)) v[j] = false;
+                if (v[j] && k[j] == hot && !(lane == src && j == 0)) v[j] = false;
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -73,73 +209,49 @@ __device__ __forceinline__ bool same_person(const int32_t *__restrict__ p_id, co
     return true;
 }
 
-__global__ __launch_bounds__(kBlock) void q8_persons_kernel(const int32_t *__restrict__ p_id,
-                                                            const int32_t *__restrict__ name_off,
-                                                            const uint8_t *__restrict__ name, SegTiles st,
-                                                            uint32_t *ptabs, uint32_t pcap, const uint64_t *sets,
-                                                            uint32_t scap, uint64_t *status,
-                                                            int32_t *__restrict__ out_person_row, int64_t *seg_out_off,
-                                                            uint32_t *err) {
-    __shared__ uint64_t s_scan[2 * kWavesPerBlock];
-    StripedScan sc;
-#pragma unroll 1
-    for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
-    const TileRange tr = locate_tile(st, tile, kPersonTile);
+__global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_t *__restrict__ p_id,
+                                                                    const int32_t *__restrict__ name_off,
+                                                                    const uint8_t *__restrict__ name, SegTiles st,
+                                                                    uint32_t *ptabs, uint32_t pcap, const uint64_t *sets,
+                                                                    uint32_t scap, uint32_t *__restrict__ flag_words,
+                                                                    uint32_t *__restrict__ counts, uint32_t *err) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
     uint32_t *ptab = ptabs + (size_t)tr.seg * pcap;
     const uint64_t *set = sets + (size_t)tr.seg * scap;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int64_t wbase = tr.tile_begin + (int64_t)wave * kPersonWaveRows + lane;
-
-    uint32_t flags = 0, lane_rank[kPersonItems], it_total[kPersonItems], wave_total = 0;
-#pragma unroll
-    for (int it = 0; it < kPersonItems; ++it) {
-        const int64_t r = wbase + it * 64;
-        bool keep = false;
-        if (r >= tr.lo && r < tr.hi) {
-            const int32_t key = p_id[r];
-            // DISTINCT (p_id, name): first claimant of a slot represents its key
-            uint32_t s = slot_of((uint32_t)key, pcap);
-            bool unique = false, done = false;
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint32_t flags = 0;
 #pragma unroll 1
-            for (uint32_t probe = 0, lim = probe_limit(pcap); probe < lim && !done; ++probe) {
-                uint32_t cur = __hip_atomic_load(&ptab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == kEmpty32) {
-                    uint32_t expected = kEmpty32;
-                    if (__hip_atomic_compare_exchange_strong(&ptab[s], &expected, (uint32_t)r, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        unique = true;
-                        done = true;
-                        break;
-                    }
-                    cur = expected;
-                }
-                if (same_person(p_id, name_off, name, r, (int64_t)cur)) {
-                    done = true;  // duplicate of an earlier claimant
+    for (int e = 0; e < kFlagIters * 4; ++e) {
+        const int64_t r = wbase + (e >> 2) * 256 + (e & 3);
+        if (r < tr.lo || r >= tr.hi) continue;
+        const int32_t key = p_id[r];
+        // DISTINCT (p_id, name): the first claimant of a slot represents its key
+        uint32_t s = slot_of((uint32_t)key, pcap);
+        bool unique = false, done = false;
+#pragma unroll 1
+        for (uint32_t probe = 0, lim = probe_limit(pcap); probe < lim && !done; ++probe) {
+            uint32_t cur = __hip_atomic_load(&ptab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kEmpty32) {
+                uint32_t expected = kEmpty32;
+                if (__hip_atomic_compare_exchange_strong(&ptab[s], &expected, (uint32_t)r, __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    unique = true;
+                    done = true;
                     break;
                 }
-                s = (s + 1 == pcap) ? 0 : s + 1;
+                cur = expected;
             }
-            if (!done) atomicOr(err, 1u);
-            keep = unique && multimap_find(set, scap, key) >= 0;
+            if (same_person(p_id, name_off, name, r, (int64_t)cur)) {
+                done = true;  // duplicate of an earlier claimant
+                break;
+            }
+            s = (s + 1 == pcap) ? 0 : s + 1;
         }
-        const uint64_t b = __ballot(keep);
-        lane_rank[it] = mbcnt(b);
-        it_total[it] = (uint32_t)__popcll((unsigned long long)b);
-        wave_total += it_total[it];
-        flags |= (keep ? 1u : 0u) << it;
+        if (!done) atomicOr(err, 1u);
+        if (unique && multimap_find(set, scap, key) >= 0) flags |= 1u << e;
     }
-    uint64_t tile_base, tile_total;
-    uint64_t pos = block_striped_offset(status, sc, tile, wave_total, s_scan, &tile_base, &tile_total, err);
-    if (threadIdx.x == 0) {
-        if (tile == st.tile_first[tr.seg]) seg_out_off[tr.seg] = (int64_t)tile_base;
-        if (tile == st.n_tiles - 1) seg_out_off[st.n_seg] = (int64_t)(tile_base + tile_total);
-    }
-#pragma unroll
-    for (int it = 0; it < kPersonItems; ++it) {
-        if (flags & (1u << it)) out_person_row[pos + lane_rank[it]] = (int32_t)(wbase + it * 64);
-        pos += it_total[it];
-    }
-    }  // tile loop
+    store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
 }  // namespace
@@ -160,8 +272,8 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     if (auction->rows > 0 && !auction->seller) return fail(ctx, FLOCKGPU_ERR_INVALID, "q8: null seller column");
     if (person->rows > 0 && (!person->p_id || !person->name.offsets || !person->name.data))
         return fail(ctx, FLOCKGPU_ERR_INVALID, "q8: null person column");
-    if (reinterpret_cast<uintptr_t>(auction->seller) & 15)
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: seller column must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(auction->seller) & 15) || (reinterpret_cast<uintptr_t>(person->p_id) & 15))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: seller and p_id columns must be 16-byte aligned");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = auction_win->n_windows;
 
@@ -177,68 +289,115 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         out_cap += pe[w] - pb[w];
     }
     SegTiles st_a, st_p;
-    FG_TRY(build_seg_tiles(ctx, "q8.auction", ab.data(), ae.data(), n_win, kSellerTile, &st_a));
-    FG_TRY(build_seg_tiles(ctx, "q8.person", pb.data(), pe.data(), n_win, kPersonTile, &st_p));
+    FG_TRY(build_seg_tiles(ctx, "q8.auction", ab.data(), ae.data(), n_win, kFlagTile, &st_a));
+    FG_TRY(build_seg_tiles(ctx, "q8.person", pb.data(), pe.data(), n_win, kFlagTile, &st_p));
 
-    const uint64_t pcap64 = std::max<uint64_t>(64, (uint64_t)max_p * 3 / 2 + 8);
-    if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
-    const uint32_t pcap = (uint32_t)pcap64;
-    uint64_t *status = nullptr;
-    FG_TRY(arena_get_t(ctx, "q8.status", (size_t)st_p.n_tiles + 3, &status));  // + spare, err
-    uint32_t *d_err = reinterpret_cast<uint32_t *>(status + st_p.n_tiles + 1);
+    // per-window key statistics of the persons: {min, max, sorted} x n_win
+    int32_t *d_stats = nullptr, *h_stats = nullptr;
+    FG_TRY(arena_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
+    FG_TRY(pinned_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
+    FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
+    if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    bool dense = true;
+    uint64_t bm_words = 0;
+    std::vector<WinBitmap> wins(std::max(n_win, 1));
+    for (int w = 0; w < n_win && dense; ++w) {
+        wins[w] = WinBitmap{0, 0, bm_words};
+        if (pe[w] == pb[w]) continue;
+        const int64_t mn = h_stats[w], mx = h_stats[n_win + w];
+        const int64_t base = mn & ~int64_t(31), bits = mx - base + 1;
+        if (!h_stats[2 * n_win + w] || bits > 64 * (pe[w] - pb[w]) + 4096 || bits >= (int64_t(1) << 31)) {
+            dense = false;
+            break;
+        }
+        wins[w].base = (int32_t)base;
+        wins[w].n_bits = (uint32_t)bits;
+        bm_words += (uint64_t)div_up(bits, 32);
+    }
+
+    uint32_t *flag_words = nullptr, *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    FG_TRY(arena_get_t(ctx, "q8.flag_words", (size_t)st_p.n_tiles * kBlock, &flag_words));
+    FG_TRY(arena_get_t(ctx, "q8.counts", (size_t)st_p.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, "q8.tile_base", (size_t)st_p.n_tiles + 1, &tile_base));
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.seg_out_off", (size_t)n_win + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "q8.seg_out_off", (size_t)n_win + 2, &h_off));
-    uint32_t *ptabs = nullptr;
-    FG_TRY(arena_get_t(ctx, "q8.person_tables", (size_t)pcap * std::max(n_win, 1), &ptabs));
+
+    if (dense) {
+        WinBitmap *d_wins = nullptr, *h_wins = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.wins", (size_t)std::max(n_win, 1), &d_wins));
+        FG_TRY(pinned_get_t(ctx, "q8.wins", (size_t)std::max(n_win, 1), &h_wins));
+        std::copy(wins.begin(), wins.begin() + n_win, h_wins);
+        uint32_t *bitmaps = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.bitmaps", (size_t)bm_words + 4, &bitmaps));
+        if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, sizeof(WinBitmap) * n_win, hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(bitmaps, 0, sizeof(uint32_t) * ((size_t)bm_words + 4), ctx->stream));
+        if (st_a.n_tiles > 0) {
+            LaunchScope ls(ctx, "q8_sellers_bitmap_kernel");
+            hipLaunchKernelGGL(q8_sellers_bitmap_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                               auction->seller, auction->rows, st_a, d_wins, bitmaps);
+        }
+        FG_TRY(check_launch(ctx, "q8_sellers_bitmap_kernel"));
+        if (st_p.n_tiles > 0) {
+            LaunchScope ls(ctx, "q8_persons_flag_kernel");
+            hipLaunchKernelGGL(q8_persons_flag_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
+                               person->rows, st_p, d_wins, bitmaps, flag_words, counts);
+        }
+        FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
+    } else {
+        const uint64_t pcap64 = std::max<uint64_t>(64, (uint64_t)max_p * 3 / 2 + 8);
+        if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
+        const uint32_t pcap = (uint32_t)pcap64;
+        uint32_t *ptabs = nullptr, *d_err = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.person_tables", (size_t)pcap * std::max(n_win, 1), &ptabs));
+        FG_TRY(arena_get_t(ctx, "q8.err", 4, &d_err));
+        // the seller sets are sized from the distinct-seller density seen last time; a full set redoes the batch
+        uint64_t scap64 = std::max<uint64_t>(64, (uint64_t)((double)max_a / std::max(1.0, ctx->q8_rows_per_seller) * 2.0) + 64);
+        for (int attempt = 0;; ++attempt) {
+            if (attempt > 6 || scap64 >= (uint64_t(1) << 31))
+                return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q8: seller set capacity %llu still overflows", (unsigned long long)scap64);
+            const uint32_t scap = (uint32_t)scap64;
+            uint64_t *sets = nullptr;
+            FG_TRY(arena_get_t(ctx, "q8.seller_sets", (size_t)scap * std::max(n_win, 1), &sets));
+            FG_HIP(ctx, hipMemsetAsync(sets, 0xFF, sizeof(uint64_t) * (size_t)scap * n_win, ctx->stream));
+            FG_HIP(ctx, hipMemsetAsync(ptabs, 0xFF, sizeof(uint32_t) * (size_t)pcap * n_win, ctx->stream));
+            FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+            if (st_a.n_tiles > 0) {
+                LaunchScope ls(ctx, "q8_sellers_set_kernel");
+                hipLaunchKernelGGL(q8_sellers_set_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                                   auction->seller, auction->rows, st_a, sets, scap, d_err);
+            }
+            FG_TRY(check_launch(ctx, "q8_sellers_set_kernel"));
+            if (st_p.n_tiles > 0) {
+                LaunchScope ls(ctx, "q8_persons_general_kernel");
+                hipLaunchKernelGGL(q8_persons_general_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream,
+                                   person->p_id, person->name.offsets, person->name.data, st_p, ptabs, pcap, sets, scap,
+                                   flag_words, counts, d_err);
+            }
+            FG_TRY(check_launch(ctx, "q8_persons_general_kernel"));
+            FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (*reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
+                scap64 *= 4;
+                continue;
+            }
+            if (attempt > 0) ctx->q8_rows_per_seller = std::max(1.0, (double)max_a * 2.0 / (double)scap64);
+            break;
+        }
+    }
+
+    FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
     int32_t *o_pr = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.out_person_row", (size_t)out_cap, &o_pr));
-
-    // the seller sets are sized from the distinct-seller density seen last time; a full set redoes the window batch
-    uint64_t scap64 = std::max<uint64_t>(64, (uint64_t)((double)max_a / std::max(1.0, ctx->q8_rows_per_seller) * 2.0) + 64);
-    int64_t n_out = 0;
-    for (int attempt = 0;; ++attempt) {
-        if (attempt > 6 || scap64 >= (uint64_t(1) << 31))
-            return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q8: seller set capacity %llu still overflows", (unsigned long long)scap64);
-        const uint32_t scap = (uint32_t)scap64;
-        uint64_t *sets = nullptr;
-        FG_TRY(arena_get_t(ctx, "q8.seller_sets", (size_t)scap * std::max(n_win, 1), &sets));
-        FG_HIP(ctx, hipMemsetAsync(sets, 0xFF, sizeof(uint64_t) * (size_t)scap * n_win, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(ptabs, 0xFF, sizeof(uint32_t) * (size_t)pcap * n_win, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint64_t) * ((size_t)st_p.n_tiles + 3), ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(d_off, 0xFF, sizeof(int64_t) * ((size_t)n_win + 1), ctx->stream));
-        if (st_a.n_tiles > 0) {
-            LaunchScope ls(ctx, "q8_sellers_kernel");
-            hipLaunchKernelGGL(q8_sellers_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
-                               auction->rows, st_a, sets, scap, d_err);
-        }
-        FG_TRY(check_launch(ctx, "q8_sellers_kernel"));
-        if (st_p.n_tiles > 0) {
-            unsigned grid = 1;
-            FG_TRY(persistent_grid(ctx, q8_persons_kernel, "q8_persons_kernel", st_p.n_tiles, &grid));
-            LaunchScope ls(ctx, "q8_persons_kernel");
-            hipLaunchKernelGGL(q8_persons_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->name.offsets, person->name.data, st_p, ptabs, pcap, sets, scap, status, o_pr, d_off,
-                               d_err);
-        }
-        FG_TRY(check_launch(ctx, "q8_persons_kernel"));
-        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (const uint32_t h_err = *reinterpret_cast<uint32_t *>(h_off + n_win + 1)) {
-            if (h_err & 2u) return fail(ctx, FLOCKGPU_ERR_HIP, "q8: chained scan stalled");
-            scap64 *= 4;
-            continue;
-        }
-        n_out = st_p.n_tiles == 0 ? 0 : h_off[n_win];
-        if (attempt > 0) ctx->q8_rows_per_seller = std::max(1.0, (double)max_a * 2.0 / (double)scap64);
-        break;
-    }
+    FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> &offs = ctx->host_i64["q8.win_out_offsets"];
     offs.assign(h_off, h_off + n_win + 1);
-    if (st_p.n_tiles == 0) offs[n_win] = 0;
-    for (int w = n_win - 1; w >= 0; --w)
-        if (offs[w] < 0) offs[w] = offs[w + 1];
+    const int64_t n_out = offs[n_win];
 
     int32_t *o_pid = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.out_p_id", (size_t)n_out + 1, &o_pid));
