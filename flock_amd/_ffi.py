@@ -74,6 +74,10 @@ class Q8Result(C.Structure):
                 ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("name_bytes", C.c_int64)]
 
 
+class PartitionResult(C.Structure):
+    _fields_ = [("row", C.c_void_p), ("part_win_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
+
+
 class NexmarkStream(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_event_id", C.c_uint64), ("eps", C.c_uint64), ("base_time", C.c_uint64)]
 
@@ -99,6 +103,11 @@ SYMBOLS = {
     "flockgpu_q5_hot_items": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
     "flockgpu_q8_join": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
                               C.POINTER(Windows), C.POINTER(Q8Result)]),
+    "flockgpu_partition_by_key": (_i, [_vp, _vp, _i64, C.POINTER(Windows), C.c_int32, C.POINTER(PartitionResult)]),
+    "flockgpu_take_i32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "flockgpu_take_i64": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "flockgpu_take_utf8": (_i, [_vp, C.POINTER(Utf8), _vp, _i64, C.c_int32, C.POINTER(Utf8), C.POINTER(_i64)]),
+    "flockgpu_inclusive_scan_i32": (_i, [_vp, _vp, _i64]),
     "flockgpu_nexmark_counts": (_i, [C.POINTER(NexmarkStream), _u64, _u64, C.POINTER(_u64), C.POINTER(_u64),
                                      C.POINTER(_u64)]),
     "flockgpu_nexmark_gen_bids": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp]),

@@ -18,7 +18,9 @@ int flockgpu_ctx_create(int device, void *hip_stream, flockgpu_ctx **out) {
         if (hip_stream) {
             ctx->stream = static_cast<hipStream_t>(hip_stream);
         } else {
-            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            // a blocking stream: ordered against the legacy default stream, which is what a host that passes no
+            // stream (e.g. torch on its default stream) allocates, fills and reads its buffers on
+            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault);
             ctx->owns_stream = (e == hipSuccess);
         }
     }

@@ -163,11 +163,12 @@ __global__ __launch_bounds__(kBlock) void gather_i32_kernel(const int32_t *__res
 }
 
 // ---- Utf8 take: lengths (count) -> tile scan -> offsets + bytes (emit) --------------------------------------------
-// Tile = 2048 values; value  it*256 + tid  of the tile belongs to thread tid (it = 0..7): the row list and the
+// Tile = 1024 values; value  it*256 + tid  of the tile belongs to thread tid (it = 0..3): the row list and the
 // source offsets are read coalesced.  counts[tile*4 + wave] = bytes of the wave's values.
-constexpr int kLenItems = 8;
+constexpr int kLenItems = 4;
 constexpr int kLenTile = kBlock * kLenItems;
-constexpr int kStageBytes = 48 * 1024;  // LDS staging buffer of the emit kernel (tiles beyond it copy directly)
+constexpr int kStageBytes = 18 * 1024;  // LDS staging buffer of the emit kernel: 18 B per value on average, 8 workgroups
+                                        // per CU (tiles beyond it copy directly, byte by byte)
 
 __global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restrict__ src_off,
                                                           const int32_t *__restrict__ rows, int64_t n,
@@ -287,24 +288,27 @@ __global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__rest
 }
 
 // ---- in-place inclusive scan: tile sums -> tile scan -> apply -----------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;  // thread t: values t*8 .. t*8+7
+
 __global__ __launch_bounds__(kBlock) void scan_sum_kernel(const int32_t *__restrict__ data, int64_t n,
                                                           uint32_t *__restrict__ counts) {
-    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + (int64_t)threadIdx.x * kLenItems;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < kLenItems; ++k) mine += (i0 + k < n) ? (uint32_t)data[i0 + k] : 0u;
+    for (int k = 0; k < kScanItems; ++k) mine += (i0 + k < n) ? (uint32_t)data[i0 + k] : 0u;
     const uint32_t incl = wave_incl_scan_u32(mine);
     if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
 }
 
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(int32_t *data, int64_t n, const uint32_t *__restrict__ counts,
                                                             const uint64_t *__restrict__ tile_base) {
-    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + (int64_t)threadIdx.x * kLenItems;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     const int wave = threadIdx.x >> 6;
     const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
-    uint32_t v[kLenItems], mine = 0;
+    uint32_t v[kScanItems], mine = 0;
 #pragma unroll
-    for (int k = 0; k < kLenItems; ++k) {
+    for (int k = 0; k < kScanItems; ++k) {
         v[k] = (i0 + k < n) ? (uint32_t)data[i0 + k] : 0u;
         mine += v[k];
     }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(int32_t *data, int64
     uint64_t pos = tile_base[blockIdx.x] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u) +
                    (incl - mine);
 #pragma unroll
-    for (int k = 0; k < kLenItems; ++k) {
+    for (int k = 0; k < kScanItems; ++k) {
         pos += v[k];
         if (i0 + k < n) data[i0 + k] = (int32_t)pos;
     }
@@ -360,7 +364,7 @@ int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, con
 
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n) {
     if (n <= 0) return FLOCKGPU_OK;
-    const int64_t tiles = div_up(n, kLenTile);
+    const int64_t tiles = div_up(n, kScanTile);
     if (tiles > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
     const std::string k_c = std::string(name) + ".counts", k_b = std::string(name) + ".base";
     uint32_t *counts = nullptr;

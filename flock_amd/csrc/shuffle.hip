@@ -1,0 +1,222 @@
+// Key-partitioned exchange step of the distributed plans, device side:
+//   RepartitionExec: Hash([seller] | [p_id] | [auction], n)   (flock/src/distributed_plan/planner.rs:152-171,
+//   playground/src/distributed_plan/shuffle_writer.rs:106-148, q5.dag / q8.dag)
+// The reference computes  create_hashes(ahash seeds 0,0,0,0) % n  per row and `take`s the rows of every
+// destination; which destination a key lands on is unobservable in the query result,
+// so a fixed integer mix is used here instead of ahash.
+//
+// flockgpu_partition_by_key: rows of every window -> row numbers grouped by (destination, window), input order
+// kept inside a group; count -> scan -> emit over (destination, tile) pairs (scan.hpp), so the send buffers of
+// the all-to-all are contiguous per destination and per window inside a destination.
+// flockgpu_take_*: the `take` that builds the send buffers / regroups the received rows.
+#include <algorithm>
+
+#include "gather.hpp"
+
+using namespace flockgpu;
+
+namespace {
+
+constexpr int kMaxParts = 64;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finaliser
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t part_of(int32_t key, uint32_t n_parts) {
+    return (uint32_t)(((uint64_t)mix32((uint32_t)key) * n_parts) >> 32);
+}
+
+// Destination of each of the lane's 32 rows, one byte each (0xFF = row outside the window), four per word.
+__device__ __forceinline__ void tile_parts(const int32_t *__restrict__ keys, int64_t n_rows, const TileRange &tr,
+                                           uint32_t n_parts, uint32_t (&d)[kFlagIters]) {
+    int32_t a[kFlagIters][4];
+    load_flag_tile(keys, n_rows, tr, a);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        d[it] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const uint32_t p = (rel >= rel_lo && rel < rel_hi) ? part_of(a[it][j], n_parts) : 0xFFu;
+            d[it] |= p << (8 * j);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t flags_of(const uint32_t (&d)[kFlagIters], uint32_t part) {
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) flags |= (((d[it] >> (8 * j)) & 0xFFu) == part ? 1u : 0u) << (it * 4 + j);
+    return flags;
+}
+
+// counts[((part * n_tiles) + tile) * 4 + wave]
+__global__ __launch_bounds__(kBlock) void partition_count_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
+                                                                 uint32_t n_parts, uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    uint32_t d[kFlagIters];
+    tile_parts(keys, n_rows, tr, n_parts, d);
+    const int wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (uint32_t part = 0; part < n_parts; ++part) {
+        const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags_of(d, part)));
+        if (lane_id() == 63) counts[((size_t)part * st.n_tiles + tile) * kWavesPerBlock + wave] = incl;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
+                                                                uint32_t n_parts, const uint32_t *__restrict__ counts,
+                                                                const uint64_t *__restrict__ tile_base,
+                                                                int32_t *__restrict__ out_rows) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    uint32_t d[kFlagIters];
+    tile_parts(keys, n_rows, tr, n_parts, d);
+#pragma unroll 1
+    for (uint32_t part = 0; part < n_parts; ++part) {
+        const size_t slot = (size_t)part * st.n_tiles + tile;
+        const uint4 wc = *reinterpret_cast<const uint4 *>(counts + slot * kWavesPerBlock);
+        if (wc.x + wc.y + wc.z + wc.w == 0) continue;  // block-uniform
+        const uint32_t total = build_flag_list(flags_of(d, part), wc, s_list);
+        __syncthreads();
+        const uint64_t base = tile_base[slot];
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
+        __syncthreads();  // s_list is rewritten for the next destination
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_i64_kernel(const int64_t *__restrict__ src, const int32_t *__restrict__ rows,
+                                                            int64_t n, int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = src[rows[i]];
+}
+
+}  // namespace
+
+extern "C" {
+
+int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win,
+                              int32_t n_parts, flockgpu_partition_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!out || rows < 0 || (rows > 0 && !keys)) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: null argument");
+    if (n_parts < 1 || n_parts > kMaxParts)
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: n_parts must be in [1, %d]", kMaxParts);
+    FG_TRY(check_windows(ctx, win, rows, "partition"));
+    if (reinterpret_cast<uintptr_t>(keys) & 15) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: key column must be 16-byte aligned");
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: relations are limited to 2^31 rows per call");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_win = win->n_windows;
+    std::vector<int64_t> sb(n_win), se(n_win);
+    int64_t covered = 0;
+    for (int w = 0; w < n_win; ++w) {
+        sb[w] = win->pane_row_offsets[win->win_pane_lo[w]];
+        se[w] = win->pane_row_offsets[win->win_pane_hi[w]];
+        covered += se[w] - sb[w];
+    }
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, "partition", sb.data(), se.data(), n_win, kFlagTile, &st));
+    const int64_t slots = (int64_t)st.n_tiles * n_parts;
+    if (slots > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: too many (destination, tile) pairs");
+    const size_t n_groups = (size_t)n_parts * n_win;
+
+    // first pseudo-tile of every (destination, window) group: destination-major
+    int32_t *d_first = nullptr, *h_first = nullptr;
+    FG_TRY(arena_get_t(ctx, "partition.first", n_groups + 1, &d_first));
+    FG_TRY(pinned_get_t(ctx, "partition.first", n_groups + 1, &h_first));
+    {
+        int64_t tiles = 0;
+        std::vector<int32_t> tf(n_win + 1);
+        for (int w = 0; w < n_win; ++w) {
+            tf[w] = (int32_t)tiles;
+            if (se[w] > sb[w]) tiles += div_up(se[w] - (sb[w] & ~int64_t(3)), kFlagTile);
+        }
+        for (int p = 0; p < n_parts; ++p)
+            for (int w = 0; w < n_win; ++w) h_first[(size_t)p * n_win + w] = (int32_t)((int64_t)p * st.n_tiles + tf[w]);
+        h_first[n_groups] = (int32_t)slots;
+    }
+    FG_HIP(ctx, hipMemcpyAsync(d_first, h_first, sizeof(int32_t) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
+
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    int64_t *d_off = nullptr, *h_off = nullptr;
+    int32_t *o_rows = nullptr;
+    FG_TRY(arena_get_t(ctx, "partition.counts", (size_t)slots * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, "partition.tile_base", (size_t)slots + 1, &tile_base));
+    FG_TRY(arena_get_t(ctx, "partition.group_off", n_groups + 1, &d_off));
+    FG_TRY(pinned_get_t(ctx, "partition.group_off", n_groups + 1, &h_off));
+    FG_TRY(arena_get_t(ctx, "partition.rows", (size_t)covered + 1, &o_rows));
+    if (st.n_tiles > 0) {
+        LaunchScope ls(ctx, "partition_count_kernel");
+        hipLaunchKernelGGL(partition_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st,
+                           (uint32_t)n_parts, counts);
+    }
+    FG_TRY(check_launch(ctx, "partition_count_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, (int32_t)slots, tile_base, d_first, (int32_t)n_groups, d_off));
+    if (st.n_tiles > 0) {
+        LaunchScope ls(ctx, "partition_emit_kernel");
+        hipLaunchKernelGGL(partition_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st,
+                           (uint32_t)n_parts, counts, tile_base, o_rows);
+    }
+    FG_TRY(check_launch(ctx, "partition_emit_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * (n_groups + 1), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> &offs = ctx->host_i64["partition.group_offsets"];
+    offs.assign(h_off, h_off + n_groups + 1);
+    out->row = o_rows;
+    out->part_win_offsets = offs.data();
+    out->rows = offs[n_groups];
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_take_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!src || !rows || !out))) return fail(ctx, FLOCKGPU_ERR_INVALID, "take_i32: null argument");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    return gather_i32(ctx, src, rows, n, out);
+}
+
+int flockgpu_take_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!src || !rows || !out))) return fail(ctx, FLOCKGPU_ERR_INVALID, "take_i64: null argument");
+    if (n == 0) return FLOCKGPU_OK;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "gather_i64_kernel");
+        hipLaunchKernelGGL(gather_i64_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src, rows, n, out);
+    }
+    return check_launch(ctx, "gather_i64_kernel");
+}
+
+int flockgpu_take_utf8(flockgpu_ctx *ctx, const flockgpu_utf8 *src, const int32_t *rows, int64_t n, int32_t slot,
+                       flockgpu_utf8 *out, int64_t *out_bytes) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!src || !out || !out_bytes || n < 0 || (n > 0 && (!rows || !src->offsets || !src->data)))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "take_utf8: null argument");
+    if (slot < 0 || slot > 15) return fail(ctx, FLOCKGPU_ERR_INVALID, "take_utf8: slot must be in [0, 15]");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    char name[32];
+    snprintf(name, sizeof name, "take_utf8.%d", slot);
+    return gather_utf8(ctx, name, *src, rows, n, out, out_bytes);
+}
+
+int flockgpu_inclusive_scan_i32(flockgpu_ctx *ctx, int32_t *data, int64_t n) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (n < 0 || (n > 0 && !data)) return fail(ctx, FLOCKGPU_ERR_INVALID, "inclusive_scan_i32: null argument");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    return inclusive_scan_i32(ctx, "abi.scan", data, n);
+}
+
+}  // extern "C"

@@ -287,3 +287,48 @@ class GpuContext:
         p, pw, a, aw, r = persons.ffi(), person_windows.ffi(), auctions.ffi(), auction_windows.ffi(), _ffi.Q8Result()
         self._check(self._lib.flockgpu_q8_join(self._h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
         return Q8Out(self, r, person_windows.n_windows)
+
+    # -- exchange building blocks (include/flockgpu.h "key-partitioned exchange")
+    def partition_by_key(self, keys, windows: WindowSchedule, n_parts: int):
+        """Row numbers grouped by (partition, window) + the [n_parts, n_windows] row counts.
+        Returns (rows: int32 device tensor, counts: np.ndarray[int64])."""
+        torch = _torch()
+        w, r = windows.ffi(), _ffi.PartitionResult()
+        self._check(self._lib.flockgpu_partition_by_key(self._h, keys.data_ptr(), keys.numel(), C.byref(w), n_parts, C.byref(r)))
+        n_groups = n_parts * windows.n_windows
+        off = np.ctypeslib.as_array(r.part_win_offsets, (n_groups + 1,)).copy()
+        rows = torch.empty(int(r.rows), dtype=torch.int32, device=f"cuda:{self.device}")
+        if r.rows:
+            self._check(self._lib.flockgpu_memcpy(self._h, rows.data_ptr(), r.row, int(r.rows) * 4, _ffi.D2D))
+        return rows, np.diff(off).reshape(n_parts, windows.n_windows)
+
+    def take(self, src, rows):
+        """out[i] = src[rows[i]] for an int32 / int64 device tensor."""
+        torch = _torch()
+        out = torch.empty(rows.numel(), dtype=src.dtype, device=src.device)
+        fn = {torch.int32: self._lib.flockgpu_take_i32, torch.int64: self._lib.flockgpu_take_i64}[src.dtype]
+        self._check(fn(self._h, src.data_ptr(), rows.data_ptr(), rows.numel(), out.data_ptr()))
+        return out
+
+    def take_utf8(self, src: DeviceUtf8, rows, slot: int = 0) -> DeviceUtf8:
+        torch = _torch()
+        s, o, nb = src.ffi(), _ffi.Utf8(), C.c_int64(0)
+        n = rows.numel()
+        self._check(self._lib.flockgpu_take_utf8(self._h, C.byref(s), rows.data_ptr(), n, slot, C.byref(o), C.byref(nb)))
+        dev = f"cuda:{self.device}"
+        off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        data = torch.empty(max(nb.value, 16), dtype=torch.uint8, device=dev)
+        self._check(self._lib.flockgpu_memcpy(self._h, off.data_ptr(), o.offsets, (n + 1) * 4, _ffi.D2D))
+        if nb.value:
+            self._check(self._lib.flockgpu_memcpy(self._h, data.data_ptr(), o.data, nb.value, _ffi.D2D))
+        return DeviceUtf8(off, data)
+
+    def offsets_from_lengths(self, lengths) -> "object":
+        """Arrow Utf8 offsets (n + 1, int32) from value lengths (n, int32)."""
+        torch = _torch()
+        n = lengths.numel()
+        off = torch.zeros(n + 1, dtype=torch.int32, device=lengths.device)
+        if n:
+            off[1:] = lengths
+            self._check(self._lib.flockgpu_inclusive_scan_i32(self._h, off.data_ptr() + 4, n))
+        return off

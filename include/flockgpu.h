@@ -46,8 +46,8 @@ enum {
 typedef struct flockgpu_ctx flockgpu_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
-/* `hip_stream` may be NULL (the ctx creates its own non-blocking stream) or an existing
- * hipStream_t the caller launches on (e.g. torch's current stream). */
+/* `hip_stream` may be NULL (the ctx creates its own stream, ordered against the legacy default
+ * stream like any blocking HIP stream) or an existing hipStream_t the caller launches on. */
 int flockgpu_ctx_create(int device, void *hip_stream, flockgpu_ctx **out);
 void flockgpu_ctx_destroy(flockgpu_ctx *ctx);
 const char *flockgpu_last_error(const flockgpu_ctx *ctx);
@@ -175,6 +175,33 @@ typedef struct {
 int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
                      const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
                      flockgpu_q8_result *out);
+
+/* ---- key-partitioned exchange (the RepartitionExec Hash([key], n) step of the distributed plans,
+ * flock/src/distributed_plan/planner.rs:152-171; row routing restated from
+ * playground/src/distributed_plan/shuffle_writer.rs:106-148).  The reference hashes with ahash seeds (0,0,0,0);
+ * which partition a key lands on is unobservable in query results, so a fixed integer mix is used:
+ *   part(key) = (murmur3_fmix32((uint32_t)key) * n_parts) >> 32.
+ * Result: the row numbers of every row that lies inside a window, grouped by (partition, window) -- partition
+ * major -- with input order kept inside a group, so that `take` over them yields send buffers that are contiguous
+ * per destination (one all-to-all chunk) and per window inside a destination.  part_win_offsets is a HOST array of
+ * n_parts * n_windows + 1 offsets into `row` (arena-owned, valid until the next call on this ctx). */
+typedef struct {
+    const int32_t *row;              /* device */
+    const int64_t *part_win_offsets; /* host */
+    int64_t rows;
+} flockgpu_partition_result;
+int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys /* device, 16-byte aligned */, int64_t rows,
+                              const flockgpu_windows *win, int32_t n_parts, flockgpu_partition_result *out);
+
+/* `take` (arrow::compute::take as used by shuffle_writer.rs:131-141 and by HashJoinExec): out[i] = src[rows[i]].
+ * All pointers are device pointers; `out` of the fixed-width variants is caller-allocated (n entries).
+ * take_utf8 writes into ctx-arena buffers keyed by `slot` (0..15: one slot per column that must stay alive). */
+int flockgpu_take_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out);
+int flockgpu_take_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out);
+int flockgpu_take_utf8(flockgpu_ctx *ctx, const flockgpu_utf8 *src, const int32_t *rows, int64_t n, int32_t slot,
+                       flockgpu_utf8 *out, int64_t *out_bytes);
+/* In-place inclusive prefix sum (rebuilds Arrow Utf8 offsets from received value lengths). */
+int flockgpu_inclusive_scan_i32(flockgpu_ctx *ctx, int32_t *data /* device */, int64_t n);
 
 /* ---- device-side NEXMark source (flock/src/datasource/nexmark/{event,config,generator}.rs restated,
  * deviations D1-D4 documented in DESIGN.md).  Generates the columns the five plans scan for event

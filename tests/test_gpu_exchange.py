@@ -1,0 +1,139 @@
+"""GPU side of the key-partitioned exchange: the HIP partition / take kernels against the numpy restatement used by the
+CPU gloo tests (tests/test_distributed.py), and the exchange-mode queries end to end through RCCL on one rank."""
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+from test_distributed import NumpyOps, _strs, mix32, part_of  # noqa: F401  (same stand-ins as the CPU tests)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def world1():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _utf8(u):
+    from flock_amd import DeviceUtf8
+    data = u.data if len(u.data) >= 16 else np.concatenate([u.data, np.zeros(16 - len(u.data), np.uint8)])
+    return DeviceUtf8(_dev(u.offsets), _dev(data))
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8, 64])
+def test_partition_matches_restatement(ctx, n_parts):
+    import torch
+    from flock_amd import WindowSchedule
+    rng = np.random.default_rng(n_parts)
+    n = 200_003
+    keys = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    keys[1000:60_000] = 4242                                     # hot key: one destination gets a burst
+    offs = np.array([0, 5, 5, 8200, 8200 + 8192 * 3, 150_001, n])  # ragged, unaligned, empty, multi-tile windows
+    sched = WindowSchedule(offs, np.array([0, 1, 2, 3, 5]), np.array([1, 2, 3, 5, 6]))   # window 3 spans two panes
+    rows, counts = ctx.partition_by_key(_dev(keys), sched, n_parts)
+    want_rows, want_counts = NumpyOps().partition(torch.from_numpy(keys), sched, n_parts)
+    assert np.array_equal(counts, want_counts)
+    assert np.array_equal(rows.cpu().numpy(), want_rows.numpy())
+
+
+def test_partition_empty_and_errors(ctx):
+    from flock_amd import FlockGpuError, WindowSchedule
+    rows, counts = ctx.partition_by_key(_dev(np.zeros(4, np.int32))[:0], WindowSchedule(np.array([0, 0]), np.array([0]), np.array([1])), 4)
+    assert rows.numel() == 0 and counts.tolist() == [[0], [0], [0], [0]]
+    with pytest.raises(FlockGpuError):
+        ctx.partition_by_key(_dev(np.zeros(16, np.int32)), WindowSchedule.single(16), 0)
+    with pytest.raises(FlockGpuError):
+        ctx.partition_by_key(_dev(np.zeros(16, np.int32)), WindowSchedule.single(16), 65)
+
+
+def test_take_matches_numpy(ctx):
+    rng = np.random.default_rng(5)
+    src32 = rng.integers(-2**31, 2**31 - 1, 100_000, dtype=np.int64).astype(np.int32)
+    src64 = rng.integers(-2**62, 2**62, 100_000, dtype=np.int64)
+    rows = rng.integers(0, 100_000, 250_001).astype(np.int32)
+    assert np.array_equal(ctx.take(_dev(src32), _dev(rows)).cpu().numpy(), src32[rows])
+    assert np.array_equal(ctx.take(_dev(src64), _dev(rows)).cpu().numpy(), src64[rows])
+    # Utf8 incl. empty strings, strings longer than the 16-byte fast path and longer than a staging buffer
+    vals = [b"", b"a", b"or", b"x" * 13, b"y" * 16, b"z" * 17, b"w" * 40, bytes(range(1, 200)), b"q" * 30_000]
+    pick = rng.integers(0, len(vals), 5000)
+    strs = [vals[i] for i in pick]
+    off = np.concatenate(([0], np.cumsum([len(s) for s in strs]))).astype(np.int32)
+    col = oracle.Utf8(off, np.frombuffer(b"".join(strs), np.uint8).copy())
+    take_rows = rng.integers(0, 5000, 12_345).astype(np.int32)
+    got = ctx.take_utf8(_utf8(col), _dev(take_rows))
+    want = oracle.take_utf8(col, take_rows)
+    assert np.array_equal(got.offsets.cpu().numpy(), want.offsets)
+    assert np.array_equal(got.data.cpu().numpy()[: len(want.data)], want.data)
+    empty = ctx.take_utf8(_utf8(col), _dev(take_rows)[:0])
+    assert empty.offsets.cpu().numpy().tolist() == [0]
+    lens = _dev(np.diff(want.offsets).astype(np.int32))
+    assert np.array_equal(ctx.offsets_from_lengths(lens).cpu().numpy(), want.offsets)
+
+
+def test_exchange_queries_one_rank(ctx, world1):
+    """q3 / q5 / q8 through partition -> take -> RCCL all_to_all -> regroup -> local operator, world size 1."""
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.distributed import q3_exchange, q5_exchange, q8_exchange
+    seed, eps, seconds = 21, 20_000, 20
+    g = NEXMarkSource(seconds, eps, Window.tumbling(10), seed=seed).generate_data(ctx)
+    host = oracle.NexmarkStream(seed=seed, eps=eps)
+    n = eps * seconds
+    au, pe, bi = host.auctions(0, n), host.persons(0, n), host.bids(0, n, columns=("auction",))["auction"]
+
+    o8 = q8_exchange(ctx, g.persons, g.window_schedule("person"), g.auctions, g.window_schedule("auction")).to_host()
+    sp, sa = g.window_schedule("person"), g.window_schedule("auction")
+    names = _strs(*o8["name"])
+    for w in range(2):
+        (plo, phi), (alo, ahi) = sp.window_rows(w), sa.window_rows(w)
+        rows = oracle.q8_join(pe["p_id"][plo:phi], pe["name"].slice(plo, phi), au["seller"][alo:ahi])
+        want = sorted(zip(pe["p_id"][plo:phi][rows].tolist(), _strs(pe["name"].offsets, pe["name"].data, [plo + r for r in rows])))
+        sl = slice(o8["offsets"][w], o8["offsets"][w + 1])
+        assert sorted(zip(o8["p_id"][sl].tolist(), names[sl])) == want and want
+
+    ew = Window.element_wise()
+    o3 = q3_exchange(ctx, g.auctions, g.window_schedule("auction", ew), g.persons, g.window_schedule("person", ew)).to_host()
+    sa, sp = g.window_schedule("auction", ew), g.window_schedule("person", ew)
+    nm, ci, stt = _strs(*o3["name"]), _strs(*o3["city"]), _strs(*o3["state"])
+    total = 0
+    for w in range(seconds):
+        (alo, ahi), (plo, phi) = sa.window_rows(w), sp.window_rows(w)
+        ar, pr = oracle.q3_join(au["seller"][alo:ahi], au["category"][alo:ahi], pe["p_id"][plo:phi], pe["state"].slice(plo, phi))
+        rows = [plo + int(r) for r in pr]
+        want = sorted(zip(_strs(pe["name"].offsets, pe["name"].data, rows), _strs(pe["city"].offsets, pe["city"].data, rows),
+                          _strs(pe["state"].offsets, pe["state"].data, rows), au["a_id"][alo:ahi][ar].tolist()))
+        sl = slice(o3["offsets"][w], o3["offsets"][w + 1])
+        assert sorted(zip(nm[sl], ci[sl], stt[sl], o3["a_id"][sl].tolist())) == want
+        total += len(want)
+    assert total > 0
+
+    hop = Window.hopping(10, 5)
+    sb = g.window_schedule("bid", hop)
+    r5 = q5_exchange(ctx, g.bids, sb)
+    for w in range(sb.n_windows):
+        lo, hi = sb.window_rows(w)
+        oa, on = oracle.q5_hot_items(bi[lo:hi])
+        sl = slice(r5.offsets[w], r5.offsets[w + 1])
+        assert sorted(zip(r5.auction[sl].tolist(), r5.num[sl].tolist())) == sorted(zip(oa.tolist(), on.tolist()))
+        assert int(r5.win_max[w]) == int(on[0])
