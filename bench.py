@@ -9,12 +9,16 @@ Workload at N=1 (BASELINE.json configs[3], the largest single-GPU configuration 
 on): q5 hot-items over 1.0e9 synthetic bids (1087 s x 1e6 events/s, Hopping(10 s, 5 s) -> 216 windows).
 With N ranks every rank owns its own slice of the global event stream (first_event_id = rank * events):
 NEXMark windows are independent units, so the path shards with no data-path collective ("weak").
-q2 / q3 / q8 (BASELINE.json configs[1], [2], [4]) are reported alongside in "also".
+`--mode exchange` runs the key-partitioned variant instead (flock_amd/distributed.py: every window striped
+across the ranks, hash repartition on the join / group key + RCCL all-to-all, as the reference's distributed
+plans do); the total work is then fixed ("strong").
+q2 / q3 / q8 (BASELINE.json configs[1], [2], [4]), q3 at 1e9 events and a PCIe-inclusive q5 run are reported
+alongside in "also" at N=1.
 
-roofline: dominant kernel's ALGORITHMIC bytes (q5 = 4 B per bid with pane
-sharing) / its average launch duration measured with HIP events on the launch stream inside the
-timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  cpu_baseline: the scalar C oracle (a port:
-the Rust/DataFusion reference cannot be built here) on a bounded sample of the same windows.
+roofline: dominant kernel's ALGORITHMIC bytes / its average launch duration measured
+with HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).
+cpu_baseline: the scalar C oracle (a port: the Rust/DataFusion reference cannot be built here), one window per
+thread on the host cores of this box, on a bounded sample of the same windows.
 """
 from __future__ import annotations
 
@@ -29,13 +33,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
 
-# query -> (dominant kernel, algorithmic bytes per input row of that kernel's relation)
+# query -> (dominant kernel, algorithmic bytes per input row of that kernel's relation, relation)
 DOMINANT = {
-    5: ("q5_count_kernel", 4.0, "bid"),        # auction column, each bid read once (pane sharing)
-    2: ("q2_flag_kernel", 4.0, "bid"),         # the filter pass proper: auction column once (price / output: q2_emit_kernel)
-    3: ("q3_probe_flag_kernel", 8.0, "auction"),    # seller + category per auction row (filter/probe phase)
-    8: ("q8_sellers_bitmap_kernel", 4.0, "auction"),  # seller per auction row
+    5: ("q5_count_kernel", 4.0, "bid"),                # auction column, each bid read once (pane sharing)
+    2: ("q2_flag_kernel", 4.0, "bid"),                 # the filter pass proper: auction column once
+    3: ("q3_probe_flag_kernel", 8.0, "auction"),       # seller + category per auction row (filter/probe phase)
+    8: ("q8_sellers_bitmap_kernel", 4.0, "auction"),   # seller per auction row
 }
+DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
 
 def parse():
@@ -46,13 +51,12 @@ def parse():
     ap.add_argument("--query", type=int, default=5, choices=[2, 3, 5, 8])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
-    ap.add_argument("--no-also", action="store_true", help="skip the q2/q3/q8 side measurements")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-windows", type=int, default=10)
+    ap.add_argument("--mode", choices=["windows", "exchange"], default="windows",
+                    help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all")
+    ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
     return ap.parse_args()
-
-
-DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
 
 def relations_for(q):
@@ -72,19 +76,65 @@ def make_stream(ctx, q, seconds, eps, rank):
     return src.generate_data(ctx, relations=relations_for(q), bid_columns=cols)
 
 
-def run_steps(ctx, q, stream, steps, warmup, barrier):
+# ------------------------------------------------------------------ exchange mode: every window striped over the ranks
+class Striped:
+    """This rank's stripe of every pane of a stream (setup, untimed): rows [lo + n*r/G, lo + n*(r+1)/G) of each pane."""
+
+    def __init__(self, ctx, q, stream, rank, world):
+        import numpy as np
+        import torch
+        from flock_amd import Auctions, Bids, Persons, WindowSchedule, query_window
+        self.q, self.window = q, query_window(q)
+        dev = f"cuda:{ctx.device}"
+
+        def stripe(relation):
+            full = stream.window_schedule(relation, self.window)
+            po = full.pane_row_offsets
+            lo = po[:-1] + np.diff(po) * rank // world
+            hi = po[:-1] + np.diff(po) * (rank + 1) // world
+            idx = torch.cat([torch.arange(int(a), int(b), dtype=torch.int32, device=dev) for a, b in zip(lo, hi)])
+            off = np.concatenate(([0], np.cumsum(hi - lo)))
+            return idx, WindowSchedule(off, full.win_pane_lo, full.win_pane_hi)
+
+        self.bids = self.auctions = self.persons = None
+        self.sched = {}
+        if q == 5:
+            idx, self.sched["bid"] = stripe("bid")
+            self.bids = Bids(auction=ctx.take(stream.bids.auction, idx), rows=int(idx.numel()))
+        else:
+            idx, self.sched["auction"] = stripe("auction")
+            a = stream.auctions
+            self.auctions = Auctions(ctx.take(a.a_id, idx), ctx.take(a.seller, idx), ctx.take(a.category, idx), int(idx.numel()))
+            idx, self.sched["person"] = stripe("person")
+            p = stream.persons
+            self.persons = Persons(ctx.take(p.p_id, idx), ctx.take_utf8(p.name, idx, 12), ctx.take_utf8(p.city, idx, 13),
+                                   ctx.take_utf8(p.state, idx, 14), int(idx.numel()))
+        torch.cuda.synchronize()
+
+    def rows(self):
+        return self.bids.rows if self.q == 5 else self.auctions.rows + self.persons.rows
+
+    def run(self, ctx):
+        from flock_amd import distributed as D
+        if self.q == 8:
+            return D.q8_exchange(ctx, self.persons, self.sched["person"], self.auctions, self.sched["auction"])
+        if self.q == 3:
+            return D.q3_exchange(ctx, self.auctions, self.sched["auction"], self.persons, self.sched["person"])
+        return D.q5_exchange(ctx, self.bids, self.sched["bid"])
+
+
+def run_steps(ctx, step, steps, warmup, barrier):
     import torch
-    from flock_amd import run_query
     res = None
     for _ in range(warmup):
-        res = run_query(ctx, q, stream)
+        res = step()
     ctx.profile_reset()
     ctx.profile(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = run_query(ctx, q, stream)
+        res = step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -93,13 +143,12 @@ def run_steps(ctx, q, stream, steps, warmup, barrier):
     return dt, stats, res
 
 
-def roofline(q, stats, stream, res):
+def roofline(q, stats, rel_rows):
     name, bpr, rel = DOMINANT[q]
     st = stats.get(name)
     if not st or not st["launches"]:
         return None
-    rows = {"bid": lambda: stream.bids.rows, "auction": lambda: stream.auctions.rows}[rel]()
-    alg_bytes = bpr * rows
+    alg_bytes = bpr * rel_rows[rel]
     avg_ms = st["total_ms"] / st["launches"]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
@@ -115,29 +164,106 @@ def roofline(q, stats, stream, res):
             "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
 
 
-def cpu_baseline(q, stream, n_windows):
-    """Scalar C oracle (kind = "port") on the first windows of the same workload, host cores of this box."""
+def rel_rows_of(stream):
+    return {"bid": stream.bids.rows if stream.bids else 0, "auction": stream.auctions.rows if stream.auctions else 0}
+
+
+# ------------------------------------------------------------------ CPU baseline (oracle, kind = "port")
+def cpu_baseline(q, stream, threads):
+    """The scalar C oracle on the first windows of the same workload, one window per thread (ctypes releases the
+    GIL, so the threads run on separate host cores).  Bounded sample: ~10-30 s of CPU work."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     import oracle
     from flock_amd import query_window
     w = query_window(q)
-    if q == 5:
+    threads = threads or min(32, os.cpu_count() or 1)
+    oracle.lib()
+    if q in (2, 5):
         sched = stream.window_schedule("bid", w)
-        n_windows = min(n_windows, sched.n_windows)
-        lo0, _ = sched.window_rows(0)
-        _, hi1 = sched.window_rows(n_windows - 1)
-        host = stream.bids.auction[lo0:hi1].cpu().numpy()
-        t0 = time.perf_counter()
-        for i in range(n_windows):
+        budget_rows = 2.0e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here)
+        n_win, rows = 0, 0
+        while n_win < sched.n_windows and (rows < budget_rows or n_win < threads):
+            lo, hi = sched.window_rows(n_win)
+            rows += hi - lo
+            n_win += 1
+        lo0, hi1 = sched.window_rows(0)[0], sched.window_rows(n_win - 1)[1]
+        auction = stream.bids.auction[lo0:hi1].cpu().numpy()
+        price = stream.bids.price[lo0:hi1].cpu().numpy() if q == 2 else None
+
+        def one(i):
             lo, hi = sched.window_rows(i)
-            oracle.q5_hot_items(host[lo - lo0:hi - lo0])
-        dt = time.perf_counter() - t0
-        rows = hi1 - lo0
-        sample = f"first {n_windows} Hopping(10,5) windows = {rows} bids (each bid counted once)"
+            if q == 5:
+                oracle.q5_hot_items(auction[lo - lo0:hi - lo0])
+            else:
+                oracle.q2_filter(auction[lo - lo0:hi - lo0], price[lo - lo0:hi - lo0])
+        unique_rows = hi1 - lo0
+        what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} bids (each bid counted once)"
     else:
-        return None
-    return {"value": round(rows / dt, 1), "unit": "rows/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": round(dt, 2), "host_cores_available": os.cpu_count()}
+        sa, sp = stream.window_schedule("auction", w), stream.window_schedule("person", w)
+        n_win = min(sa.n_windows, max(threads, 100 if q == 3 else 32))
+        alo, ahi = sa.window_rows(0)[0], sa.window_rows(n_win - 1)[1]
+        plo, phi = sp.window_rows(0)[0], sp.window_rows(n_win - 1)[1]
+        seller = stream.auctions.seller[alo:ahi].cpu().numpy()
+        category = stream.auctions.category[alo:ahi].cpu().numpy()
+        p_id = stream.persons.p_id[plo:phi].cpu().numpy()
+
+        def host_utf8(col):
+            off = col.offsets[plo:phi + 1].cpu().numpy()
+            data = col.data[int(off[0]):int(off[-1])].cpu().numpy()
+            return oracle.Utf8((off - off[0]).astype(np.int32), data)
+        text = host_utf8(stream.persons.state if q == 3 else stream.persons.name)
+
+        def one(i):
+            (a0, a1), (p0, p1) = sa.window_rows(i), sp.window_rows(i)
+            if q == 3:
+                oracle.q3_join(seller[a0 - alo:a1 - alo], category[a0 - alo:a1 - alo], p_id[p0 - plo:p1 - plo],
+                               text.slice(p0 - plo, p1 - plo))
+            else:
+                oracle.q8_join(p_id[p0 - plo:p1 - plo], text.slice(p0 - plo, p1 - plo), seller[a0 - alo:a1 - alo])
+        unique_rows = (ahi - alo) + (phi - plo)
+        what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} auction + person rows"
+    one(0)  # warm (page-in)
+    passes, dt = 0, 0.0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        while dt < 0.6 and passes < 200:          # ~20 s of CPU work at 32 threads
+            list(pool.map(one, range(n_win)))
+            passes += 1
+            dt = time.perf_counter() - t0
+    return {"value": round(unique_rows * passes / dt, 1), "unit": "rows/s", "cores": min(threads, n_win), "kind": "port",
+            "sample": what + f", one window per thread, {threads} threads, {passes} pass(es)", "seconds": round(dt, 2),
+            "cpu_seconds": round(dt * min(threads, n_win), 1), "host_cores_available": os.cpu_count()}
+
+
+# ------------------------------------------------------------------ PCIe-inclusive side measurement
+def pcie_inclusive_q5(ctx, eps, seconds=100):
+    """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query.  PCIe-bound;
+    reported beside `value`, never as `value`."""
+    import torch
+    from flock_amd import Bids, NEXMarkSource, Window
+    w = Window.hopping(10, 5)
+    g = NEXMarkSource(seconds, eps, w, seed=7).generate_data(ctx, relations=("bid",), bid_columns=("auction",))
+    sched = g.window_schedule("bid", w)
+    host = g.bids.auction.cpu().pin_memory()
+    dev = torch.empty_like(g.bids.auction)
+
+    def step():
+        dev.copy_(host, non_blocking=True)
+        torch.cuda.current_stream().synchronize()   # the ctx stream is ordered against the default stream anyway
+        return ctx.q5_hot_items(Bids(auction=dev, rows=g.bids.rows), sched)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(g.bids.rows / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "input_rows": int(g.bids.rows),
+            "h2d_GBps_floor": round(g.bids.rows * 4 / dt / 1e9, 1),
+            "note": "pinned host auction column copied H2D every step, then q5 (copy and query not overlapped)"}
 
 
 def main():
@@ -150,9 +276,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: flock_amd has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.mode == "exchange":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    if world > 1:
         tok = torch.zeros(1, device=f"cuda:{local}")
 
         def barrier():
@@ -162,13 +290,25 @@ def main():
         def barrier():
             pass
 
-    from flock_amd import GpuContext
+    from flock_amd import GpuContext, query_window, run_query
     ctx = GpuContext(local)
     q = args.query
+    if args.mode == "exchange" and q == 2:
+        raise SystemExit("q2 has no exchange step (embarrassingly parallel)")
     seconds = args.seconds or DEFAULT_SECONDS[q]
-    stream = make_stream(ctx, q, seconds, args.eps, rank)
-    dt, stats, res = run_steps(ctx, q, stream, args.steps, args.warmup, barrier)
-    rows = input_rows(q, stream)
+    if args.mode == "exchange":
+        full = make_stream(ctx, q, seconds, args.eps, 0)          # the SAME stream on every rank ...
+        striped = Striped(ctx, q, full, rank, world)              # ... of which this rank keeps its stripe of every pane
+        rel_rows = {"bid": striped.bids.rows if striped.bids else 0, "auction": striped.auctions.rows if striped.auctions else 0}
+        rows = striped.rows()
+        del full
+        torch.cuda.empty_cache()
+        dt, stats, res = run_steps(ctx, lambda: striped.run(ctx), args.steps, args.warmup, barrier)
+        stream = None
+    else:
+        stream = make_stream(ctx, q, seconds, args.eps, rank)
+        rel_rows, rows = rel_rows_of(stream), input_rows(q, stream)
+        dt, stats, res = run_steps(ctx, lambda: run_query(ctx, q, stream), args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt, float(rows)], dtype=torch.float64, device=f"cuda:{local}")
         tmax = t.clone()
@@ -180,47 +320,66 @@ def main():
 
     out = None
     if rank == 0:
-        from flock_amd import query_window
         w = query_window(q)
+        n_windows = getattr(res, "n_windows", None) or (len(res.offsets) - 1)
+        n_result = int(res.rows) if hasattr(res, "rows") else int(len(res.auction))
+        windows = args.mode == "windows"
         out = {
             "metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": round(rows_all * args.steps / dt_max, 1),
             "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s per GPU",
-                       "query": f"q{q}", "input_rows_per_gpu": int(rows), "windows_per_gpu": res.n_windows,
-                       "parallelism": f"window-sharded x{world} (no data-path collective)",
-                       "result_rows": int(res.rows)},
-            "roofline": roofline(q, stats, stream, res),
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if windows else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s"
+                                   + (" per GPU" if windows else f" striped over {world} GPU(s)"),
+                       "query": f"q{q}", "input_rows_per_gpu": int(rows), "windows_per_gpu": int(n_windows),
+                       "parallelism": (f"window-sharded x{world} (no data-path collective)" if windows
+                                       else f"key-partitioned x{world} (hash repartition + RCCL all-to-all)"),
+                       "result_rows": n_result},
+            "roofline": roofline(q, stats, rel_rows),
+            "cpu_baseline": None,
         }
-    if rank == 0:
-        out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_windows) if (world == 1 and not args.no_cpu) else None
-    # side measurements (N = 1 only): the other BASELINE configs, each with its own roofline
-    if rank == 0 and world == 1 and not args.no_also:
+        if world == 1 and not args.no_cpu and stream is not None:
+            out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
+    # side measurements (N = 1 only): the other BASELINE configs, each with its own roofline and CPU leg
+    if rank == 0 and world == 1 and not args.no_also and args.mode == "windows":
         also = {}
         del stream, res
         torch.cuda.empty_cache()
-        for q2 in (2, 3, 8, 5):
-            if q2 == q:
+        steps2 = max(2, min(args.steps, 3))
+        for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q3", 3, DEFAULT_SECONDS[3]), ("q8", 8, DEFAULT_SECONDS[8]),
+                                ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000)):
+            if q2 == q and secs == seconds:
                 continue
             try:
-                s2 = make_stream(ctx, q2, DEFAULT_SECONDS[q2], args.eps, 0)
-                d2, st2, r2 = run_steps(ctx, q2, s2, max(2, min(args.steps, 3)), 1, lambda: None)
-                steps2 = max(2, min(args.steps, 3))
-                also[f"q{q2}"] = {"value": round(input_rows(q2, s2) * steps2 / d2, 1), "unit": "rows/s",
-                                  "ms_per_step": round(d2 / steps2 * 1e3, 3), "input_rows": int(input_rows(q2, s2)),
-                                  "windows": r2.n_windows, "result_rows": int(r2.rows),
-                                  "seconds_of_events": DEFAULT_SECONDS[q2], "roofline": roofline(q2, st2, s2, r2)}
+                s2 = make_stream(ctx, q2, secs, args.eps, 0)
+                d2, st2, r2 = run_steps(ctx, lambda: run_query(ctx, q2, s2), steps2, 1, lambda: None)
+                also[label] = {"value": round(input_rows(q2, s2) * steps2 / d2, 1), "unit": "rows/s",
+                               "ms_per_step": round(d2 / steps2 * 1e3, 3), "input_rows": int(input_rows(q2, s2)),
+                               "windows": r2.n_windows, "result_rows": int(r2.rows), "seconds_of_events": secs,
+                               "roofline": roofline(q2, st2, rel_rows_of(s2))}
+                if not args.no_cpu and secs == DEFAULT_SECONDS[q2]:
+                    also[label]["cpu_baseline"] = cpu_baseline(q2, s2, args.cpu_threads)
                 del s2, r2
                 torch.cuda.empty_cache()
             except Exception as e:  # a side measurement must never hide the headline
-                also[f"q{q2}"] = {"error": str(e)}
+                also[label] = {"error": repr(e)}
+        try:
+            also["q5_pcie_inclusive"] = pcie_inclusive_q5(ctx, args.eps)
+        except Exception as e:
+            also["q5_pcie_inclusive"] = {"error": repr(e)}
         out["also"] = also
+    ctx.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio, which is flushed at exit: flush it now so that the JSON line
+    # is the LAST line of rank 0's stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
         print(json.dumps(out), flush=True)
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *_
                                                               int64_t *__restrict__ seg_out_off) {
     constexpr int kWaves = kScanBlock / 64;
     __shared__ uint64_t s_tot[kScanRounds * kWaves];  // [round][wave] totals, then their exclusive prefix
-    __shared__ uint64_t s_carry;
+    __shared__ uint64_t s_carry, s_next;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     for (int32_t p0 = 0; p0 < n_tiles; p0 += kScanRounds * kScanBlock) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *_
                 s_tot[lane * 4 + i] = run;
                 run += v[i];
             }
-            if (lane == 63) s_carry = carry + run;
+            if (lane == 63) s_next = carry + run;  // not s_carry: the other waves may not have read it yet
         }
         __syncthreads();
 #pragma unroll
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(const uint32_t *_
             const int32_t t = p0 + k * kScanBlock + (int32_t)threadIdx.x;
             if (t < n_tiles) tile_base[t] = carry + s_tot[k * kWaves + wave] + incl[k] - c[k];
         }
-        __syncthreads();  // s_tot is rewritten by the next pass
+        __syncthreads();  // s_tot is rewritten by the next pass; everyone has read s_carry
+        if (threadIdx.x == 0) s_carry = s_next;  // published by the next barrier
     }
     __syncthreads();
     const uint64_t total = s_carry;

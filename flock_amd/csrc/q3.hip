@@ -42,40 +42,63 @@ struct WinTable {
     uint64_t off;     // offset of the window's entries in the table arena
 };
 
-__device__ __forceinline__ bool utf8_in(const int32_t *__restrict__ off, const uint8_t *__restrict__ data, int64_t row,
-                                        const Utf8Lits &lits) {
-    const int32_t b = off[row], e = off[row + 1];
-    const uint32_t len = (uint32_t)(e - b);
-    if (len > 8) return false;
-    uint64_t v = 0;
-    for (uint32_t k = 0; k < len; ++k) v |= (uint64_t)data[b + k] << (8 * k);
+// ---- build (both paths): flag-tile row layout, four consecutive persons per lane and iteration ---------------------
+// Up to 8 bytes of a Utf8 value as a little-endian word, read through three aligned 4-byte words whose indices are
+// clamped to the value's last word (no read past its end); all loads are unconditional so that the loads of
+// the 32 rows of a lane overlap instead of queueing behind per-row branches.
+__device__ __forceinline__ uint64_t utf8_head8(const uint8_t *__restrict__ data, int32_t b, uint32_t len) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + (uint32_t)b;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3));
+    const uint32_t sh = (uint32_t)(addr & 3) * 8;
+    const uint32_t last = len ? (uint32_t)(((addr & 3) + len - 1) >> 2) : 0u;
+    const uint32_t w0 = w[0], w1 = w[min(1u, last)], w2 = w[min(2u, last)];
+    const uint64_t lo = __funnelshift_r(w0, w1, sh), hi = __funnelshift_r(w1, w2, sh);
+    const uint64_t v = lo | (hi << 32);
+    return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1));
+}
+
+__device__ __forceinline__ bool lits_hit(uint64_t v, uint32_t len, const Utf8Lits &lits) {
     bool hit = false;
 #pragma unroll
     for (int l = 0; l < kMaxLits; ++l) hit = hit || (l < lits.n && lits.len[l] == len && lits.bytes[l] == v);
     return hit;
 }
 
-// ---- build (both paths): one lane per person row, flag-tile row layout -----------------------------------------
 template <bool kDense>
 __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restrict__ p_id,
                                                           const int32_t *__restrict__ state_off,
-                                                          const uint8_t *__restrict__ state_data, SegTiles st, Utf8Lits lits,
-                                                          const WinTable *__restrict__ wins, int32_t *direct,
+                                                          const uint8_t *__restrict__ state_data, int64_t n_rows, SegTiles st,
+                                                          Utf8Lits lits, const WinTable *__restrict__ wins, int32_t *direct,
                                                           uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err) {
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
     const int64_t wbase = tr.tile_begin + flag_rel0();
     WinTable wt{};
     if (kDense) wt = wins[tr.seg];
     uint64_t *tab = kDense ? nullptr : tables + (size_t)tr.seg * cap;
-#pragma unroll 1
-    for (int e = 0; e < kFlagIters * 4; ++e) {
-        const int64_t r = wbase + (e >> 2) * 256 + (e & 3);
-        if (r < tr.lo || r >= tr.hi) continue;
-        if (!utf8_in(state_off, state_data, r, lits)) continue;
-        if (kDense) {
-            direct[wt.off + (uint32_t)(p_id[r] - wt.base)] = (int32_t)r;
-        } else if (!multimap_insert(tab, cap, next, p_id[r], (int32_t)r)) {
-            atomicOr(err, 1u);
+    int32_t key[kFlagIters][4];
+    load_flag_tile(p_id, n_rows, tr, key);
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+        // offsets of rows r0 .. r0+4 (clamped to the column: rows past its end are masked below)
+        int32_t off[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int64_t r = r0 + j;
+            off[j] = state_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j;
+            const bool in = r >= tr.lo && r < tr.hi;
+            const uint32_t len = in ? (uint32_t)(off[j + 1] - off[j]) : 0u;
+            const uint64_t v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);  // len 0: nothing is read past the buffer
+            if (!(in && len <= 8 && lits_hit(v, len, lits))) continue;
+            if (kDense) {
+                direct[wt.off + (uint32_t)(key[it][j] - wt.base)] = (int32_t)r;
+            } else if (!multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
+                atomicOr(err, 1u);
+            }
         }
     }
 }
@@ -104,8 +127,10 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
         for (int j = 0; j < 4; ++j) {
             const int32_t rel = rel0 + it * 256 + j;
             const uint32_t idx = (uint32_t)s[it][j] - (uint32_t)wt.base;
-            bool f = false;
-            if (rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range) f = tab[idx] >= 0;
+            const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range;
+            // unconditional load from a clamped index: a load under a per-row branch is waited for before the next
+            // row is looked at, i.e. one memory round trip per surviving row instead of one per tile
+            const bool f = need & (tab[need ? idx : 0u] >= 0);
             flags |= (f ? 1u : 0u) << (it * 4 + j);
         }
     store_flags_and_counts(flags, tile, flag_words, counts);
@@ -299,8 +324,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->state.offsets, person->state.data, st_p, lits, d_wins, direct, nullptr, 0u, nullptr,
-                               d_err);
+                               person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct, nullptr,
+                               0u, nullptr, d_err);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
@@ -321,8 +346,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL(q3_build_kernel<false>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->state.offsets, person->state.data, st_p, lits, nullptr, nullptr, tables, cap, next,
-                               d_err);
+                               person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, tables,
+                               cap, next, d_err);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {

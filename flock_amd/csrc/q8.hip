@@ -158,8 +158,9 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
         for (int j = 0; j < 4; ++j) {
             const int32_t rel = rel0 + it * 256 + j;
             const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
-            bool f = false;
-            if (rel >= rel_lo && rel < rel_hi && idx < wb.n_bits) f = (gbm[idx >> 5] >> (idx & 31)) & 1u;
+            const bool in = rel >= rel_lo && rel < rel_hi && idx < wb.n_bits;
+            // unconditional load from a clamped index: loads under per-row branches queue behind each other
+            const bool f = in & ((gbm[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);
             flags |= (f ? 1u : 0u) << (it * 4 + j);
         }
     store_flags_and_counts(flags, tile, flag_words, counts);

@@ -67,11 +67,40 @@ class GpuOps:
         return self.ctx.offsets_from_lengths(lengths)
 
 
+_MAX_PEER_BYTES = 1 << 30   # RCCL / c10d transfers above 2 GiB per peer arrive corrupted: stay well below
+
+
 def _all_to_all(send, send_splits, recv_splits, group):
-    """One variable-size all-to-all of a 1-D buffer (RCCL `ncclSend/ncclRecv` group under the hood)."""
+    """One variable-size all-to-all of a 1-D buffer (RCCL `ncclSend/ncclRecv` group under the hood), cut into
+    rounds of at most 1 GiB per peer.  Round k moves elements [k*C, (k+1)*C) of every (source, destination) run; C is
+    a constant, so both ends derive the same per-round splits from their own counts, and the number of rounds is
+    agreed with one all_reduce(MAX)."""
     torch = _torch()
-    out = torch.empty(int(sum(recv_splits)), dtype=send.dtype, device=send.device)
-    _dist().all_to_all_single(out, send.contiguous(), [int(x) for x in recv_splits], [int(x) for x in send_splits], group=group)
+    dist = _dist()
+    send_splits = np.asarray(send_splits, np.int64)
+    recv_splits = np.asarray(recv_splits, np.int64)
+    out = torch.empty(int(recv_splits.sum()), dtype=send.dtype, device=send.device)
+    send = send.contiguous()
+    chunk = max(1, _MAX_PEER_BYTES // send.element_size())
+    biggest = torch.tensor([max(int(send_splits.max(initial=0)), int(recv_splits.max(initial=0)))], dtype=torch.int64,
+                           device=send.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(biggest.item()) // chunk))
+    if rounds == 1:
+        dist.all_to_all_single(out, send, [int(x) for x in recv_splits], [int(x) for x in send_splits], group=group)
+        return out
+    s_off = np.concatenate(([0], np.cumsum(send_splits)))
+    r_off = np.concatenate(([0], np.cumsum(recv_splits)))
+    for k in range(rounds):
+        s_len = np.clip(send_splits - k * chunk, 0, chunk)
+        r_len = np.clip(recv_splits - k * chunk, 0, chunk)
+        s_buf = torch.cat([send[int(s_off[d] + k * chunk): int(s_off[d] + k * chunk + s_len[d])] for d in range(len(s_len))])
+        r_buf = torch.empty(int(r_len.sum()), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(r_buf, s_buf, [int(x) for x in r_len], [int(x) for x in s_len], group=group)
+        pos = 0
+        for src in range(len(r_len)):
+            out[int(r_off[src] + k * chunk): int(r_off[src] + k * chunk + r_len[src])] = r_buf[pos: pos + int(r_len[src])]
+            pos += int(r_len[src])
     return out
 
 

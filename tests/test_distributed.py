@@ -274,3 +274,25 @@ def test_regroup_index_orders_by_window_then_source():
     idx, win_off = regroup_index(recv, "cpu")
     # received buffer: s0w0 s0w0 s0w2 | s1w0 s1w1 s1w1 s1w1
     assert idx.tolist() == [0, 1, 3, 4, 5, 6, 2] and win_off.tolist() == [0, 3, 6, 7]
+
+
+def _chunked_rank(rank, world):
+    import flock_amd.distributed as D
+    D._MAX_PEER_BYTES = 64            # 16 int32 per peer and round: forces several rounds with ragged tails
+    rng = np.random.default_rng(rank)
+    send_splits = np.array([37, 5]) if rank == 0 else np.array([0, 50])
+    recv_splits = np.array([37, 0]) if rank == 0 else np.array([5, 50])
+    send = torch.from_numpy(rng.integers(0, 1000, int(send_splits.sum())).astype(np.int32))
+    got = D._all_to_all(send, send_splits, recv_splits, None)
+    everything = [None] * world
+    dist.all_gather_object(everything, (send.tolist(), send_splits.tolist()))
+    want = []
+    for src in range(world):
+        data, splits = everything[src]
+        off = int(np.sum(splits[:rank]))
+        want += data[off: off + splits[rank]]
+    assert got.tolist() == want
+
+
+def test_all_to_all_is_cut_into_rounds_world2():
+    _run(_chunked_rank)

@@ -137,3 +137,21 @@ def test_exchange_queries_one_rank(ctx, world1):
         sl = slice(r5.offsets[w], r5.offsets[w + 1])
         assert sorted(zip(r5.auction[sl].tolist(), r5.num[sl].tolist())) == sorted(zip(oa.tolist(), on.tolist()))
         assert int(r5.win_max[w]) == int(on[0])
+
+
+def test_scans_beyond_one_pass(ctx):
+    """More than 16384 tiles: the single-workgroup tile scan runs several passes with a carry."""
+    import torch
+    from flock_amd import WindowSchedule
+    rng = np.random.default_rng(9)
+    lens = rng.integers(0, 21, 40_000_000).astype(np.int32)            # 19.5k scan tiles of 2048 values
+    got = ctx.offsets_from_lengths(_dev(lens)).cpu().numpy()
+    want = np.concatenate(([0], np.cumsum(lens, dtype=np.int64))).astype(np.int32)
+    assert np.array_equal(got, want)
+    n = 20_000_003                                                     # 2442 tiles x 8 destinations = 19.5k pseudo-tiles
+    keys = rng.integers(0, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    offs = np.array([0, 7_000_001, 7_000_001, n])
+    sched = WindowSchedule(offs, np.arange(3), np.arange(1, 4))
+    rows, counts = ctx.partition_by_key(_dev(keys), sched, 8)
+    want_rows, want_counts = NumpyOps().partition(torch.from_numpy(keys), sched, 8)
+    assert np.array_equal(counts, want_counts) and np.array_equal(rows.cpu().numpy(), want_rows.numpy())
