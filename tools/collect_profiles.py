@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Copies the rocprofv3 summaries of tools/gpu_profile.sh from gpurun_out/prof/ into profiles/<tag>/ and rebuilds
+profiles/traffic.json (corrected HBM bytes per launch of every query's dominant kernel, MI355X_MICROARCH.md HBM
+section: FETCH_SIZE counts half of a 16 B / lane coalesced stream on gfx950 -> x2; WRITE_SIZE 1:1)."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+for f in sorted(os.listdir(src)):
+    shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+DOMINANT = {5: "q5_count_kernel", 2: "q2_flag_kernel", 3: "q3_probe_flag_kernel", 8: "q8_sellers_bitmap_kernel"}
+traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, "
+                       "tools/gpu_profile.sh): bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 reports half of a 16 B/lane coalesced stream, "
+                       "MI355X_MICROARCH.md HBM section) + WRITE_SIZE_KB * 1024.  Source CSVs: profiles/%s/q*_pmc_*.csv" % tag}
+for q, kern in DOMINANT.items():
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = os.path.join(dst, f"q{q}_pmc_{c}.csv")
+        if not os.path.exists(p):
+            continue
+        for r in csv.DictReader(open(p)):
+            if kern + "(" in r["kernel"]:
+                vals[c] = float(r[f"avg_{c}_KB"])
+    if len(vals) == 2:
+        traffic[kern] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+        traffic[kern + "_detail"] = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))

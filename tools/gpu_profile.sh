@@ -1,0 +1,37 @@
+#!/bin/bash
+# gpurun helper: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE PMC passes (each in its own run, as
+# MI355X_MICROARCH.md prescribes) for every query's bench line.  Summaries land in gpurun_out/prof/.
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+summarise() {  # $1 = rocprof output dir, $2 = counter, $3 = out csv
+python - "$1" "$2" "$3" <<'PY'
+import csv, glob, sys, collections
+d, counter, out = sys.argv[1:4]
+acc = collections.OrderedDict()
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != counter: continue
+        k = r["Kernel_Name"]
+        a = acc.setdefault(k, [0, 0.0])
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+with open(out, "w") as o:
+    o.write("kernel,launches,avg_%s_KB\n" % counter)
+    for k, (n, v) in acc.items():
+        o.write('"%s",%d,%.3f\n' % (k, n, v / n))
+PY
+}
+for q in ${QUERIES:-5 2 8 3}; do
+  extra=""; [ "$q" = "3" ] && extra="--seconds 1000"
+  cmd="python bench.py --query $q $extra --steps 3 --warmup 1 --no-also --no-cpu"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $cmd > "$OUT/q${q}_stats_run.log" 2>&1
+  f=$(find /tmp/prof_q$q -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/q${q}_kernel_stats.csv"
+  grep '^{' "$OUT/q${q}_stats_run.log" | tail -1 > "$OUT/q${q}_bench_under_rocprof.json"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${c}_q$q -- $cmd > "$OUT/q${q}_${c}_run.log" 2>&1
+    summarise /tmp/pmc_${c}_q$q $c "$OUT/q${q}_pmc_${c}.csv"
+  done
+  rm -f "$OUT"/q${q}_*_run.log
+done
+ls -la "$OUT"
