@@ -273,6 +273,85 @@ def test_q8_duplicates_collapse(ctx):
         assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, w
 
 
+# ------------------------------------------------------------------ dense / general path selection (q3, q8)
+def _sorted_keys(rng, n, spread, lo=-50_000):
+    """n strictly increasing int32 keys with an average gap of `spread`."""
+    return (lo + np.cumsum(rng.integers(1, 2 * spread, n))).astype(np.int32)
+
+
+@pytest.mark.parametrize("case", ["dense_gaps", "wide_tiles", "sparse", "unsorted", "mixed_windows"])
+def test_q8_every_path_is_exact(ctx, case):
+    """Strictly increasing p_ids over an affordable range take the bitmap path (staged in LDS, or direct when a tile's
+    keys span more than 32768 ids); sparse / unsorted keys, or any window of them, take the hash path.  Sellers may
+    lie outside every window's key range, be negative, or be absent; windows may be empty on either side."""
+    from flock_amd import Auctions, Persons, WindowSchedule
+    rng = np.random.default_rng({"dense_gaps": 1, "wide_tiles": 2, "sparse": 3, "unsorted": 4, "mixed_windows": 5}[case])
+    npn, na = 60_000, 150_000
+    spread = {"dense_gaps": 2, "wide_tiles": 30, "sparse": 40_000, "unsorted": 2, "mixed_windows": 2}[case]
+    p_id = _sorted_keys(rng, npn, spread)
+    if case == "unsorted":
+        p_id[20_500:20_600] = p_id[20_500:20_600][::-1]
+    if case == "mixed_windows":
+        p_id[45_000:] = rng.integers(0, 2**31 - 1, npn - 45_000).astype(np.int32)      # last window: random keys
+    nm = [b"p%d" % (i % 977) for i in range(npn)]
+    name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32),
+                       np.frombuffer(b"".join(nm), np.uint8).copy())
+    seller = rng.choice(p_id, na).astype(np.int32)
+    seller[::7] = rng.integers(-2**31, 2**31 - 1, len(seller[::7])).astype(np.int32)    # strangers
+    seller[1000:40_000:3] = p_id[777]                                                    # a hot seller
+    pw = WindowSchedule(np.array([0, 20_000, 20_000, 45_000, npn]), np.arange(4), np.arange(1, 5))   # window 1: no persons
+    aw = WindowSchedule(np.array([0, 70_001, 90_000, 90_000, na]), np.arange(4), np.arange(1, 5))    # window 2: no auctions
+    out = ctx.q8_join(Persons(_dev(p_id), _utf8(name), None, None, npn), pw, Auctions(None, _dev(seller), None, na), aw).to_host()
+    g_names, off = _str_rows(*out["name"]), out["offsets"]
+    total = 0
+    for w in range(4):
+        (plo, phi), (alo, ahi) = pw.window_rows(w), aw.window_rows(w)
+        rows = oracle.q8_join(p_id[plo:phi], name.slice(plo, phi), seller[alo:ahi])
+        want = sorted((int(p_id[plo + r]), nm[plo + r]) for r in rows)
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, (case, w)
+        total += len(want)
+    assert total == len(out["p_id"]) and total > 1000 and off[2] == off[1] and off[3] == off[2]
+
+
+@pytest.mark.parametrize("case", ["dense_gaps", "sparse", "unsorted", "mixed_windows"])
+def test_q3_every_path_is_exact(ctx, case):
+    from flock_amd import Auctions, Persons, WindowSchedule
+    rng = np.random.default_rng({"dense_gaps": 11, "sparse": 13, "unsorted": 14, "mixed_windows": 15}[case])
+    npn, na = 40_000, 120_000
+    spread = {"dense_gaps": 3, "sparse": 50_000, "unsorted": 2, "mixed_windows": 2}[case]
+    p_id = _sorted_keys(rng, npn, spread)
+    if case == "unsorted":
+        p_id[100:120] = p_id[100:120][::-1]
+    if case == "mixed_windows":
+        p_id[30_000:] = rng.integers(0, 50, npn - 30_000).astype(np.int32)               # duplicates in the last window
+    st = rng.choice(np.array([b"or", b"OR", b"id", b"ca", b"wa", b"", b"orx", b"california"], dtype=object), npn)
+    state = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32),
+                        np.frombuffer(b"".join(st), np.uint8).copy())
+    nm = [b"n%d" % (i % 313) for i in range(npn)]
+    name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32),
+                       np.frombuffer(b"".join(nm), np.uint8).copy())
+    seller = rng.choice(p_id, na).astype(np.int32)
+    seller[::5] = rng.integers(-2**31, 2**31 - 1, len(seller[::5])).astype(np.int32)
+    category = rng.integers(9, 12, na).astype(np.int32)
+    a_id = (np.arange(na) * 7 + 3).astype(np.int32)
+    pw = WindowSchedule(np.array([0, 10_000, 10_000, 30_000, npn]), np.arange(4), np.arange(1, 5))
+    aw = WindowSchedule(np.array([0, 50_001, 60_000, 60_000, na]), np.arange(4), np.arange(1, 5))
+    out = ctx.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw,
+                      Persons(_dev(p_id), _utf8(name), _utf8(name), _utf8(state), npn), pw).to_host()
+    off = out["offsets"]
+    g_state, g_name = _str_rows(*out["state"]), _str_rows(*out["name"])
+    total = 0
+    for w in range(4):
+        (alo, ahi), (plo, phi) = aw.window_rows(w), pw.window_rows(w)
+        ar, pr = oracle.q3_join(seller[alo:ahi], category[alo:ahi], p_id[plo:phi], state.slice(plo, phi))
+        sl = slice(off[w], off[w + 1])
+        want = sorted((nm[plo + j], st[plo + j], int(a_id[alo + i])) for i, j in zip(ar, pr))
+        assert sorted(zip(g_name[sl], g_state[sl], out["a_id"][sl].tolist())) == want, (case, w)
+        total += len(ar)
+    assert total == len(out["a_id"]) and total > 1000
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_full_size_properties(ctx):
     """1e8-event stream (configs q2/q3 of BASELINE.json): checks that need no CPU pass over all rows."""
@@ -310,3 +389,73 @@ def test_full_size_properties(ctx):
     o8 = run_query(ctx, 8, g).to_host()
     assert len(np.unique(o8["p_id"])) == len(o8["p_id"]) > 0                   # DISTINCT
     assert (np.diff(o8["person_row"].astype(np.int64)) > 0).all()
+
+
+def test_baseline_sizes_properties(ctx):
+    """BASELINE.json's full sizes (q5: 1e9 bids, q8 / q3: 1e9 events), checked through properties that need no CPU pass
+    over all rows: winners verified against an independent device-side count (torch.bincount) on sampled windows and
+    against the oracle on two of them; q8 / q3 outputs verified against torch set operations on sampled windows."""
+    import torch
+    from flock_amd import NEXMarkSource, Window, query_window, run_query
+    eps = 1_000_000
+    g = NEXMarkSource(1087, eps, query_window(5), seed=20260925).generate_data(ctx, relations=("bid",), bid_columns=("auction",))
+    assert g.bids.rows == 1_000_040_000
+    sched = g.window_schedule("bid")
+    r5 = run_query(ctx, 5, g)
+    a, n, off = r5.to_host()
+    mx, groups = r5.win_max(), r5.win_groups()
+    assert sched.n_windows == 216 and len(off) == 217 and (np.diff(off) >= 1).all() and (mx > 0).all()
+    for w in (0, 1, 57, 108, 214, 215):
+        lo, hi = sched.window_rows(w)
+        keys = g.bids.auction[lo:hi].to(torch.int64)
+        base = int(keys.min())
+        cnt = torch.bincount(keys - base)
+        assert int(cnt.max()) == int(mx[w]) and int((cnt > 0).sum()) == int(groups[w])
+        winners = (torch.nonzero(cnt == cnt.max()).flatten() + base).cpu().numpy()
+        sl = slice(off[w], off[w + 1])
+        assert np.array_equal(np.sort(a[sl]), winners) and (n[sl] == mx[w]).all()
+    for w in (3, 200):
+        lo, hi = sched.window_rows(w)
+        oa, on = oracle.q5_hot_items(g.bids.auction[lo:hi].cpu().numpy())
+        assert sorted(zip(a[off[w]:off[w + 1]].tolist(), n[off[w]:off[w + 1]].tolist())) == sorted(zip(oa.tolist(), on.tolist()))
+    del g, r5
+    torch.cuda.empty_cache()
+
+    g = NEXMarkSource(1000, eps, query_window(8), seed=20260925).generate_data(ctx, relations=("auction", "person"))
+    assert g.auctions.rows + g.persons.rows == 80_000_000
+    sp, sa = g.window_schedule("person"), g.window_schedule("auction")
+    o8 = run_query(ctx, 8, g)
+    h8 = o8.to_host()
+    off = h8["offsets"]
+    assert (np.diff(h8["person_row"].astype(np.int64)) > 0).all() and off[-1] == len(h8["p_id"])
+    for w in (0, 49, 99):
+        (plo, phi), (alo, ahi) = sp.window_rows(w), sa.window_rows(w)
+        pid = g.persons.p_id[plo:phi]
+        keep = torch.isin(pid, torch.unique(g.auctions.seller[alo:ahi]))
+        assert torch.unique(pid).numel() == pid.numel()                       # DISTINCT is the identity on this input
+        assert np.array_equal(h8["p_id"][off[w]:off[w + 1]], pid[keep].cpu().numpy())
+        assert np.array_equal(h8["person_row"][off[w]:off[w + 1]] - plo, torch.nonzero(keep).flatten().cpu().numpy())
+    # names of the first window against the oracle's take
+    rows0 = h8["person_row"][off[0]:off[1]].astype(np.int64)
+    pe_off = g.persons.name.offsets[: sp.window_rows(0)[1] + 1].cpu().numpy()
+    pe_dat = g.persons.name.data[: int(pe_off[-1])].cpu().numpy()
+    want = oracle.take_utf8(oracle.Utf8(pe_off, pe_dat), rows0)
+    got_off, got_dat = h8["name"]
+    assert np.array_equal(got_off[: len(rows0) + 1], want.offsets) and np.array_equal(got_dat[: len(want.data)], want.data)
+
+    ew = Window.element_wise()
+    o3 = run_query(ctx, 3, g, ew).to_host()
+    sa3, sp3 = g.window_schedule("auction", ew), g.window_schedule("person", ew)
+    seller, cat, pid = g.auctions.seller, g.auctions.category, g.persons.p_id
+    ar, pr = torch.from_numpy(o3["auction_row"].astype(np.int64)).cuda(), torch.from_numpy(o3["person_row"].astype(np.int64)).cuda()
+    assert bool((cat[ar] == 10).all()) and bool((seller[ar] == pid[pr]).all()) and len(o3["a_id"]) > 1_000_000
+    assert set(_str_rows(*o3["state"])[:200_000]) <= {b"or", b"id", b"ca"}
+    st_off = g.persons.state.offsets
+    for w in (0, 500, 999):                                                  # exact pair count per sampled window
+        (alo, ahi), (plo, phi) = sa3.window_rows(w), sp3.window_rows(w)
+        so = st_off[plo:phi + 1].cpu().numpy()
+        sd = g.persons.state.data[int(so[0]):int(so[-1])].cpu().numpy()
+        oa, op = oracle.q3_join(seller[alo:ahi].cpu().numpy(), cat[alo:ahi].cpu().numpy(), pid[plo:phi].cpu().numpy(),
+                                oracle.Utf8((so - so[0]).astype(np.int32), sd))
+        sl = slice(o3["offsets"][w], o3["offsets"][w + 1])
+        assert sorted(zip((o3["auction_row"][sl] - alo).tolist(), (o3["person_row"][sl] - plo).tolist())) == sorted(zip(oa.tolist(), op.tolist()))
