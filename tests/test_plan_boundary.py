@@ -214,3 +214,26 @@ def test_unsupported_plan_and_bad_input_raise(gpu):
     wa, wp = oracle.q2_filter(np.arange(100, 800, dtype=np.int32) * 41, np.arange(100, 800, dtype=np.int32))
     assert rb["auction"].to_numpy().tolist() == wa.tolist() and rb["price"].to_numpy().tolist() == wp.tolist()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_reference_granules_equal_whole_window_batches(gpu):
+    """a12 (nexmark.rs:183-193): batches at the reference's granules (178 329 bid rows, 14 860 person / auction rows per
+    batch) and "the whole window as one batch" must give the same rows (q2: same order; q3 / q8: same multiset)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    eps = 1_000_000
+    s = oracle.NexmarkStream(seed=12, eps=eps)
+    bid_ev, auc_ev, per_ev = 178_329 * 50 // 46 + 1, 14_860 * 50 // 3 + 1, 14_860 * 50
+    ctx2 = ExecutionContext([_plan(2)], name="q2-g", gpu=gpu)
+    fine, whole = _bid_batches(s, 0, eps, bid_ev), _bid_batches(s, 0, eps, eps)
+    assert len(fine) >= 5 and len(whole) == 1 and max(b.num_rows for b in fine) <= 178_400
+    a, b = collect(ctx2, [[fine]])[0][0], collect(ctx2, [[whole]])[0][0]
+    assert a.equals(b) and a.num_rows > 0
+    ctx2.close()
+    for q in (3, 8):
+        ctx = ExecutionContext([_plan(q)], name=f"q{q}-g", gpu=gpu)
+        fine = collect(ctx, [[_person_batches(s, 0, eps, per_ev)], [_auction_batches(s, 0, eps, auc_ev)]])[0][0]
+        whole = collect(ctx, [[_person_batches(s, 0, eps, eps)], [_auction_batches(s, 0, eps, eps)]])[0][0]
+        rows = lambda rb: sorted(zip(*[rb[c].to_pylist() for c in rb.schema.names]))
+        assert rows(fine) == rows(whole) and fine.num_rows > 0
+        ctx.close()
