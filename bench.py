@@ -39,8 +39,9 @@ DOMINANT = {
     2: ("q2_flag_kernel", 4.0, "bid"),                 # the filter pass proper: auction column once
     3: ("q3_probe_flag_kernel", 8.0, "auction"),       # seller + category per auction row (filter/probe phase)
     8: ("q8_sellers_bitmap_kernel", 4.0, "auction"),   # seller per auction row
+    7: ("q7_max_kernel", 4.0, "bid"),                  # price column once (SURVEY.md section 8(f) "next" query)
 }
-DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
+DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
 
 def parse():
@@ -48,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 5, 8])
+    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 5, 7, 8])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
     ap.add_argument("--mode", choices=["windows", "exchange"], default="windows",
@@ -60,11 +61,11 @@ def parse():
 
 
 def relations_for(q):
-    return {2: ("bid",), 5: ("bid",), 3: ("auction", "person"), 8: ("auction", "person")}[q]
+    return {2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person")}[q]
 
 
 def input_rows(q, stream):
-    if q in (2, 5):
+    if q in (2, 5, 7):
         return stream.bids.rows
     return stream.auctions.rows + stream.persons.rows
 
@@ -72,7 +73,7 @@ def input_rows(q, stream):
 def make_stream(ctx, q, seconds, eps, rank):
     from flock_amd import NEXMarkSource, query_window
     src = NEXMarkSource(seconds, eps, query_window(q), seed=20260925, first_event_id=rank * seconds * eps)
-    cols = ("auction", "price") if q == 2 else ("auction",)
+    cols = {2: ("auction", "price"), 7: ("auction", "bidder", "price", "b_date_time")}.get(q, ("auction",))
     return src.generate_data(ctx, relations=relations_for(q), bid_columns=cols)
 
 
@@ -179,7 +180,7 @@ def cpu_baseline(q, stream, threads):
     w = query_window(q)
     threads = threads or min(32, os.cpu_count() or 1)
     oracle.lib()
-    if q in (2, 5):
+    if q in (2, 5, 7):
         sched = stream.window_schedule("bid", w)
         budget_rows = 2.0e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here)
         n_win, rows = 0, 0
@@ -189,12 +190,14 @@ def cpu_baseline(q, stream, threads):
             n_win += 1
         lo0, hi1 = sched.window_rows(0)[0], sched.window_rows(n_win - 1)[1]
         auction = stream.bids.auction[lo0:hi1].cpu().numpy()
-        price = stream.bids.price[lo0:hi1].cpu().numpy() if q == 2 else None
+        price = stream.bids.price[lo0:hi1].cpu().numpy() if q in (2, 7) else None
 
         def one(i):
             lo, hi = sched.window_rows(i)
             if q == 5:
                 oracle.q5_hot_items(auction[lo - lo0:hi - lo0])
+            elif q == 7:
+                oracle.q7_highest_bid(price[lo - lo0:hi - lo0])
             else:
                 oracle.q2_filter(auction[lo - lo0:hi - lo0], price[lo - lo0:hi - lo0])
         unique_rows = hi1 - lo0
@@ -347,7 +350,8 @@ def main():
         torch.cuda.empty_cache()
         steps2 = max(2, min(args.steps, 3))
         for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q3", 3, DEFAULT_SECONDS[3]), ("q8", 8, DEFAULT_SECONDS[8]),
-                                ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000)):
+                                ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000), ("q2_1e9_bids", 2, 1087),
+                                ("q7_next", 7, DEFAULT_SECONDS[7])):
             if q2 == q and secs == seconds:
                 continue
             try:

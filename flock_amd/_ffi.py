@@ -69,6 +69,11 @@ class Q5Result(C.Structure):
                 ("win_max", C.POINTER(C.c_uint64)), ("win_groups", C.POINTER(C.c_uint64)), ("rows", C.c_int64)]
 
 
+class Q7Result(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("price", C.c_void_p), ("bidder", C.c_void_p), ("b_date_time", C.c_void_p),
+                ("win_out_offsets", C.POINTER(C.c_int64)), ("win_max", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
+
+
 class Q8Result(C.Structure):
     _fields_ = [("p_id", C.c_void_p), ("name", Utf8), ("person_row", C.c_void_p),
                 ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("name_bytes", C.c_int64)]
@@ -101,6 +106,7 @@ SYMBOLS = {
     "flockgpu_q3_join": (_i, [_vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),
                               C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),
     "flockgpu_q5_hot_items": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
+    "flockgpu_q7_highest_bid": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q7Result)]),
     "flockgpu_q8_join": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
                               C.POINTER(Windows), C.POINTER(Q8Result)]),
     "flockgpu_partition_by_key": (_i, [_vp, _vp, _i64, C.POINTER(Windows), C.c_int32, C.POINTER(PartitionResult)]),

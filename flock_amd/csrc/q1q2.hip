@@ -3,6 +3,8 @@
 //   q2: FilterExec CAST(auction AS Int64) % 123 = 0 -> CoalesceBatches -> Projection     (planner.rs:120-124)
 // Both are HBM-bound integer/byte scans: 16-byte coalesced lane loads, wave64 ballot + mbcnt ranks,
 // single-pass chained scan for the stable (input-order) compaction.  No MFMA, no LDS staging needed.
+#include <algorithm>
+
 #include "scan.hpp"
 
 using namespace flockgpu;
@@ -70,26 +72,36 @@ __device__ __forceinline__ void q2_load_tile(const int32_t *__restrict__ auction
 __global__ __launch_bounds__(kBlock) void q2_flag_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
                                                          ModPred pred, uint32_t *__restrict__ flag_words,
                                                          uint32_t *__restrict__ counts) {
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kQ2Tile);
-    int32_t a[kQ2Iters][4];
-    q2_load_tile(auction, n_rows, tr, a);
-    // rows of the tile that belong to the window, relative to tile_begin: [rel_lo, rel_hi)
-    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    int32_t tile = (int32_t)blockIdx.x;
+    if (tile >= st.n_tiles) return;
+    TileRange tr = locate_tile(st, tile, kQ2Tile);
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int32_t rel0 = wave * kQ2WaveRows + lane * 4;
-    uint32_t flags = 0;
+#pragma unroll 1
+    for (;;) {  // tiles b, b + G, ...: the next descriptor is requested while this tile's rows are in flight (scan.hpp)
+        int32_t a[kQ2Iters][4];
+        q2_load_tile(auction, n_rows, tr, a);
+        const int32_t next = tile + (int32_t)gridDim.x;
+        TileRange trn = tr;
+        if (next < st.n_tiles) trn = locate_tile(st, next, kQ2Tile);
+        // rows of the tile that belong to the window, relative to tile_begin: [rel_lo, rel_hi)
+        const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+        uint32_t flags = 0;
 #pragma unroll
-    for (int it = 0; it < kQ2Iters; ++it)
+        for (int it = 0; it < kQ2Iters; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t rel = rel0 + it * 256 + j;
-            const bool f = mod_is_zero(a[it][j], pred) && rel >= rel_lo && rel < rel_hi;
-            flags |= (f ? 1u : 0u) << (it * 4 + j);
-        }
-    flag_words[(size_t)tile * kBlock + threadIdx.x] = flags;
-    const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
-    if (lane == 63) counts[(size_t)tile * kWavesPerBlock + wave] = incl;
+            for (int j = 0; j < 4; ++j) {
+                const int32_t rel = rel0 + it * 256 + j;
+                const bool f = mod_is_zero(a[it][j], pred) && rel >= rel_lo && rel < rel_hi;
+                flags |= (f ? 1u : 0u) << (it * 4 + j);
+            }
+        flag_words[(size_t)tile * kBlock + threadIdx.x] = flags;
+        const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
+        if (lane == 63) counts[(size_t)tile * kWavesPerBlock + wave] = incl;
+        if (next >= st.n_tiles) break;
+        tile = next;
+        tr = trn;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void q2_emit_kernel(const int32_t *__restrict__ auction,
@@ -220,8 +232,9 @@ int flockgpu_q2_filter(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const fl
     }
     if (st.n_tiles > 0) {
         LaunchScope ls(ctx, "q2_flag_kernel");
-        hipLaunchKernelGGL(q2_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction,
-                           bid->rows, st, pred, flag_words, counts);
+        const unsigned grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+        hipLaunchKernelGGL(q2_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bid->auction, bid->rows, st, pred,
+                           flag_words, counts);
     }
     FG_TRY(check_launch(ctx, "q2_flag_kernel"));
     FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));

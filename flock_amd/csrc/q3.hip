@@ -111,29 +111,39 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
                                                                const int32_t *__restrict__ direct,
                                                                uint32_t *__restrict__ flag_words,
                                                                uint32_t *__restrict__ counts) {
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const WinTable wt = wins[tr.seg];
-    int32_t s[kFlagIters][4], c[kFlagIters][4];
-    load_flag_tile(seller, n_rows, tr, s);
-    load_flag_tile(category, n_rows, tr, c);
-    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    int32_t tile = (int32_t)blockIdx.x;
+    if (tile >= st.n_tiles) return;
+    TileRange tr = locate_tile(st, tile, kFlagTile);
     const int32_t rel0 = flag_rel0();
-    const int32_t *tab = direct + wt.off;
-    uint32_t flags = 0;
+#pragma unroll 1
+    for (;;) {  // tiles b, b + G, ... with the next descriptor requested early (scan.hpp)
+        int32_t s[kFlagIters][4], c[kFlagIters][4];
+        load_flag_tile(seller, n_rows, tr, s);
+        load_flag_tile(category, n_rows, tr, c);
+        const WinTable wt = wins[tr.seg];
+        const int32_t next = tile + (int32_t)gridDim.x;
+        TileRange trn = tr;
+        if (next < st.n_tiles) trn = locate_tile(st, next, kFlagTile);
+        const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+        const int32_t *tab = direct + wt.off;
+        uint32_t flags = 0;
 #pragma unroll
-    for (int it = 0; it < kFlagIters; ++it)
+        for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t rel = rel0 + it * 256 + j;
-            const uint32_t idx = (uint32_t)s[it][j] - (uint32_t)wt.base;
-            const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range;
-            // unconditional load from a clamped index: a load under a per-row branch is waited for before the next
-            // row is looked at, i.e. one memory round trip per surviving row instead of one per tile
-            const bool f = need & (tab[need ? idx : 0u] >= 0);
-            flags |= (f ? 1u : 0u) << (it * 4 + j);
-        }
-    store_flags_and_counts(flags, tile, flag_words, counts);
+            for (int j = 0; j < 4; ++j) {
+                const int32_t rel = rel0 + it * 256 + j;
+                const uint32_t idx = (uint32_t)s[it][j] - (uint32_t)wt.base;
+                const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range;
+                // unconditional load from a clamped index: a load under a per-row branch is waited for before the
+                // next row is looked at, i.e. one memory round trip per surviving row instead of one per tile
+                const bool f = need & (tab[need ? idx : 0u] >= 0);
+                flags |= (f ? 1u : 0u) << (it * 4 + j);
+            }
+        store_flags_and_counts(flags, tile, flag_words, counts);
+        if (next >= st.n_tiles) break;
+        tile = next;
+        tr = trn;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__restrict__ seller,
@@ -330,9 +340,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
-            hipLaunchKernelGGL(q3_probe_flag_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
-                               auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct,
-                               flag_words, counts);
+            const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+            hipLaunchKernelGGL(q3_probe_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
+                               auction->category, auction->rows, category_lit, st_a, d_wins, direct, flag_words, counts);
         }
         FG_TRY(check_launch(ctx, "q3_probe_flag_kernel"));
     } else {

@@ -143,27 +143,37 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
                                                                  const uint32_t *__restrict__ bitmaps,
                                                                  uint32_t *__restrict__ flag_words,
                                                                  uint32_t *__restrict__ counts) {
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const WinBitmap wb = wins[tr.seg];
-    int32_t a[kFlagIters][4];
-    load_flag_tile(p_id, n_rows, tr, a);
-    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    int32_t tile = (int32_t)blockIdx.x;
+    if (tile >= st.n_tiles) return;
+    TileRange tr = locate_tile(st, tile, kFlagTile);
     const int32_t rel0 = flag_rel0();
-    const uint32_t *gbm = bitmaps + wb.word_off;
-    uint32_t flags = 0;
+#pragma unroll 1
+    for (;;) {  // tiles b, b + G, ... with the next descriptor requested early (scan.hpp)
+        int32_t a[kFlagIters][4];
+        load_flag_tile(p_id, n_rows, tr, a);
+        const WinBitmap wb = wins[tr.seg];
+        const int32_t next = tile + (int32_t)gridDim.x;
+        TileRange trn = tr;
+        if (next < st.n_tiles) trn = locate_tile(st, next, kFlagTile);
+        const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+        const uint32_t *gbm = bitmaps + wb.word_off;
+        uint32_t flags = 0;
 #pragma unroll
-    for (int it = 0; it < kFlagIters; ++it)
+        for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t rel = rel0 + it * 256 + j;
-            const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
-            const bool in = rel >= rel_lo && rel < rel_hi && idx < wb.n_bits;
-            // unconditional load from a clamped index: loads under per-row branches queue behind each other
-            const bool f = in & ((gbm[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);
-            flags |= (f ? 1u : 0u) << (it * 4 + j);
-        }
-    store_flags_and_counts(flags, tile, flag_words, counts);
+            for (int j = 0; j < 4; ++j) {
+                const int32_t rel = rel0 + it * 256 + j;
+                const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
+                const bool in = rel >= rel_lo && rel < rel_hi && idx < wb.n_bits;
+                // unconditional load from a clamped index: loads under per-row branches queue behind each other
+                const bool f = in & ((gbm[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);
+                flags |= (f ? 1u : 0u) << (it * 4 + j);
+            }
+        store_flags_and_counts(flags, tile, flag_words, counts);
+        if (next >= st.n_tiles) break;
+        tile = next;
+        tr = trn;
+    }
 }
 
 // ---- general path -----------------------------------------------------------------------------------------------
@@ -344,8 +354,9 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         FG_TRY(check_launch(ctx, "q8_sellers_bitmap_kernel"));
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q8_persons_flag_kernel");
-            hipLaunchKernelGGL(q8_persons_flag_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->rows, st_p, d_wins, bitmaps, flag_words, counts);
+            const unsigned grid = (unsigned)std::min<int64_t>(st_p.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+            hipLaunchKernelGGL(q8_persons_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows,
+                               st_p, d_wins, bitmaps, flag_words, counts);
         }
         FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
     } else {

@@ -39,6 +39,12 @@ __device__ __forceinline__ TileRange locate_tile(const SegTiles &st, int32_t til
     return st.tiles[tile];
 }
 
+// Grid of the streaming kernels that walk tiles b, b + G, b + 2G, ... (independent tiles: nothing waits on another
+// workgroup) and request the NEXT tile's descriptor before they reduce the current one, so a tile's column loads
+// never queue behind a dependent descriptor load and no workgroup launch sits between two tiles.  Measured on the
+// q7 max pass over 1e9 bids: one tile per workgroup 0.92 ms, 4 / 8 / 12 / 16 workgroups per CU 0.87 / 0.82 / 0.78 / 0.80 ms.
+constexpr int kStreamBlocksPerCu = 12;
+
 // Host: builds the (begin,end) pairs, the tile prefix and the tile descriptors for `n_seg` segments and uploads
 // them (async on the ctx stream through pinned staging).  `name` keys the arena buffers.  A schedule identical to
 // the one uploaded by the previous call under the same name is reused as is (no upload, no synchronisation): a

@@ -171,6 +171,29 @@ class Q5Out:
 
 
 @dataclass
+class Q7Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q7Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def win_max(self):
+        return np.ctypeslib.as_array(self.raw.win_max, (max(self.n_windows, 1),))[: self.n_windows].copy()
+
+    def to_host(self):
+        n = self.rows
+        return {"auction": self.ctx.d2h(self.raw.auction, n, np.int32), "price": self.ctx.d2h(self.raw.price, n, np.int32),
+                "bidder": self.ctx.d2h(self.raw.bidder, n, np.int32), "b_date_time": self.ctx.d2h(self.raw.b_date_time, n, np.int64),
+                "offsets": self.offsets()}
+
+
+@dataclass
 class Q8Out:
     ctx: "GpuContext"
     raw: _ffi.Q8Result
@@ -281,6 +304,12 @@ class GpuContext:
         b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5Result()
         self._check(self._lib.flockgpu_q5_hot_items(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q5Out(self, r, windows.n_windows)
+
+    def q7_highest_bid(self, bids: Bids, windows: WindowSchedule) -> Q7Out:
+        """q7 (q7.sql): the bids that reach the window's MAX(price); ties kept, input order."""
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q7Result()
+        self._check(self._lib.flockgpu_q7_highest_bid(self._h, C.byref(b), C.byref(w), C.byref(r)))
+        return Q7Out(self, r, windows.n_windows)
 
     def q8_join(self, persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
                 auction_windows: WindowSchedule) -> Q8Out:

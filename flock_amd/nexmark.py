@@ -184,6 +184,8 @@ def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window:
                            stream.window_schedule("person", window))
     if query_number == 5:
         return ctx.q5_hot_items(stream.bids, stream.window_schedule("bid", window))
+    if query_number == 7:
+        return ctx.q7_highest_bid(stream.bids, stream.window_schedule("bid", window))
     if query_number == 8:
         return ctx.q8_join(stream.persons, stream.window_schedule("person", window), stream.auctions,
                            stream.window_schedule("auction", window))

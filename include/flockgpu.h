@@ -162,6 +162,21 @@ typedef struct {
 int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
                           flockgpu_q5_result *out);
 
+/* ---- q7 (SURVEY.md section 8(f) "next" query): bid JOIN (SELECT MAX(price) AS maxprice FROM bid) ON price = maxprice,
+ * Projection [auction, price, bidder, b_date_time] (benchmarks/src/nexmark/query/q7.sql, q7_plan.fmt), per
+ * Tumbling(10 s) window (benchmarks/src/nexmark/main.rs:119).  Every row that reaches the window's maximum is returned
+ * (ties kept), in input order; an empty window (MAX = NULL) returns nothing.  win_max: HOST array, the maximum per
+ * window (INT32_MIN for an empty window). */
+typedef struct {
+    const int32_t *auction, *price, *bidder; /* device */
+    const int64_t *b_date_time;              /* device */
+    const int64_t *win_out_offsets;          /* host, n_windows + 1 */
+    const int64_t *win_max;                  /* host, n_windows */
+    int64_t rows;
+} flockgpu_q7_result;
+int flockgpu_q7_highest_bid(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                            flockgpu_q7_result *out);
+
 /* ---- q8: DISTINCT (p_id, name) JOIN DISTINCT seller ON p_id = seller -> [p_id, name]
  * (q8.sql, q8_plan.fmt:1-10, q8.dag).  Output grouped by window, ordered by person row. */
 typedef struct {

@@ -223,6 +223,16 @@ def count_by_key(key: np.ndarray):
     return ok, oc
 
 
+def q7_highest_bid(price: np.ndarray) -> np.ndarray:
+    """Row indices of the q7 output for one window, in input order: bid JOIN (SELECT MAX(price) ...) ON price = maxprice
+    (benchmarks/src/nexmark/query/q7.sql, q7_plan.fmt).  Every row reaching the maximum is returned (inner join on
+    equality); MAX over an empty window is NULL, so the join is empty."""
+    price = np.ascontiguousarray(price, np.int32)
+    if len(price) == 0:
+        return np.zeros(0, np.int64)
+    return np.nonzero(price == price.max())[0].astype(np.int64)
+
+
 def q8_join(p_id, name: Utf8, seller):
     """Row indices (into the window's person rows) of the output, in row order."""
     p_id = np.ascontiguousarray(p_id, np.int32)

@@ -228,6 +228,57 @@ def test_q5_ties_uniform_keys_and_extremes(ctx):
         assert off[4] == off[3], name          # empty window -> MAX is NULL -> no rows
 
 
+# ------------------------------------------------------------------ q7 (first "next" query, SURVEY.md section 8 f)
+@pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 20)])
+def test_q7_tumbling_windows(ctx, seed, eps, seconds):
+    from flock_amd import query_window, run_query
+    g = _gpu_stream(ctx, seed, eps, seconds, query_window(7))
+    r = run_query(ctx, 7, g)
+    out, mx = r.to_host(), r.win_max()
+    _, b, _, _ = _host_stream(seed, eps, seconds)
+    sched = g.window_schedule("bid")
+    off = out["offsets"]
+    assert sched.n_windows == seconds // 10
+    for w in range(sched.n_windows):
+        lo, hi = sched.window_rows(w)
+        rows = oracle.q7_highest_bid(b["price"][lo:hi]) + lo
+        sl = slice(off[w], off[w + 1])
+        for k in ("auction", "price", "bidder", "b_date_time"):
+            assert np.array_equal(out[k][sl], b[k][rows]), (w, k)            # input order is kept: exact equality
+        assert int(mx[w]) == int(b["price"][lo:hi].max())
+    assert off[-1] == len(out["price"]) > 0
+
+
+def test_q7_ties_negatives_and_empty_windows(ctx):
+    from flock_amd import Bids, FlockGpuError, WindowSchedule
+    rng = np.random.default_rng(8)
+    n = 100_003
+    price = rng.integers(-1000, 1000, n).astype(np.int32)
+    price[40_000:40_500] = 5000                       # 500-way tie across tile boundaries in window 2
+    price[3] = price[16] = 999_999                    # tie inside window 0, whose rows start unaligned
+    price[90_000:] = np.iinfo(np.int32).min           # window 4: every row is the (minimal) maximum
+    auction = rng.integers(0, 10**6, n).astype(np.int32)
+    bidder = rng.integers(0, 10**6, n).astype(np.int32)
+    when = rng.integers(0, 2**62, n)
+    bids = Bids(_dev(auction), _dev(bidder), _dev(price), _dev(when), n)
+    offs = np.array([1, 17, 17, 60_001, 90_000, n])   # ragged, unaligned, one empty window
+    sched = WindowSchedule(offs, np.arange(5), np.arange(1, 6))
+    r = ctx.q7_highest_bid(bids, sched)
+    out, off = r.to_host(), r.offsets()
+    for w in range(5):
+        lo, hi = sched.window_rows(w)
+        rows = oracle.q7_highest_bid(price[lo:hi]) + lo
+        sl = slice(off[w], off[w + 1])
+        assert np.array_equal(out["auction"][sl], auction[rows]) and np.array_equal(out["price"][sl], price[rows])
+        assert np.array_equal(out["bidder"][sl], bidder[rows]) and np.array_equal(out["b_date_time"][sl], when[rows])
+    assert off[2] == off[1] and off[5] - off[4] == n - 90_000 and off[3] - off[2] == 500
+    empty = ctx.q7_highest_bid(Bids(_dev(auction)[:0], _dev(bidder)[:0], _dev(price)[:0], _dev(when)[:0], 0),
+                               WindowSchedule(np.array([0, 0]), np.array([0]), np.array([1])))
+    assert empty.rows == 0 and empty.offsets().tolist() == [0, 0]
+    with pytest.raises(FlockGpuError):
+        ctx.q7_highest_bid(Bids(auction=_dev(auction), price=_dev(price), rows=n), sched)     # q7 projects all four columns
+
+
 # ------------------------------------------------------------------ q8
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 10)])
 def test_q8_tumbling_windows(ctx, seed, eps, seconds):
