@@ -361,10 +361,13 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
                                                          const uint32_t *__restrict__ counters,
                                                          const uint64_t *__restrict__ tables, uint32_t cap,
                                                          const uint32_t *__restrict__ tab_used, uint64_t *win_max,
-                                                         uint64_t *win_groups, uint32_t *cursor, uint32_t out_cap,
-                                                         int32_t *out_win, int32_t *out_key) {
+                                                         uint64_t *win_groups, uint32_t *block_max, uint32_t *cursor,
+                                                         uint32_t out_cap, int32_t *out_win, int32_t *out_key) {
     __shared__ PaneDesc s_panes[kMaxWinPanes];
     const int32_t w = blockIdx.y;
+    // select visits the same keys as the same block of the max pass did: a block whose maximum is not the window's
+    // holds no winner and skips its share of the counters
+    if (SELECT && block_max[(size_t)w * gridDim.x + blockIdx.x] != (uint32_t)win_max[w]) return;
     const WinDesc d = wins[w];
     const int n_panes = d.range ? d.pane_hi - d.pane_lo : 0;
     if ((int)threadIdx.x < n_panes) s_panes[threadIdx.x] = panes[d.pane_lo + threadIdx.x];
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
         best = wave_max_u32(best);
         const uint64_t g = wave_sum_u64(groups);
         if (lane_id() == 0) {
+            if (best) atomicMax(&block_max[(size_t)w * gridDim.x + blockIdx.x], best);
             if (best) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
             if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
         }
@@ -596,18 +600,21 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         if (n_win > 0) {
             const uint64_t per_win = std::max<uint64_t>(cap, scan_total / n_win / 4);
             const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
+            uint32_t *block_max = nullptr;
+            FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * n_win, &block_max));
+            FG_HIP(ctx, hipMemsetAsync(block_max, 0, sizeof(uint32_t) * (size_t)gx * n_win, ctx->stream));
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<false>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
-                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, d_cursor, out_cap, o_win,
-                                   o_key);
+                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap,
+                                   o_win, o_key);
             }
             FG_TRY(check_launch(ctx, "q5_max_kernel"));
             {
                 LaunchScope ls(ctx, "q5_select_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<true>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
-                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, d_cursor, out_cap, o_win,
-                                   o_key);
+                                   d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap,
+                                   o_win, o_key);
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
