@@ -618,7 +618,15 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
+        // one synchronisation for the scalars AND the winners: a window has one winner unless counts tie, so the first
+        // kSpecWinners entries are copied back speculatively together with the scalars
+        constexpr uint32_t kSpecWinners = 4096;
+        int32_t *h_swin = nullptr, *h_skey = nullptr;
+        FG_TRY(pinned_get_t(ctx, "q5.spec_win", kSpecWinners, &h_swin));
+        FG_TRY(pinned_get_t(ctx, "q5.spec_key", kSpecWinners, &h_skey));
         FG_HIP(ctx, hipMemcpyAsync(h_meta, d_meta, sizeof(uint64_t) * n_meta, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_swin, o_win, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_skey, o_key, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
         n_sel = tail[0];
@@ -632,7 +640,10 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         }
         h_win.resize(n_sel);
         h_key.resize(n_sel);
-        if (n_sel) {
+        if (n_sel <= kSpecWinners) {
+            std::copy(h_swin, h_swin + n_sel, h_win.begin());
+            std::copy(h_skey, h_skey + n_sel, h_key.begin());
+        } else {
             FG_HIP(ctx, hipMemcpyAsync(h_win.data(), o_win, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
             FG_HIP(ctx, hipMemcpyAsync(h_key.data(), o_key, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
             FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -675,10 +686,9 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     uint64_t *d_on = nullptr;
     FG_TRY(arena_get_t(ctx, "q5.out_auction", (size_t)n_sel + 1, &d_oa));
     FG_TRY(arena_get_t(ctx, "q5.out_num", (size_t)n_sel + 1, &d_on));
-    if (n_sel) {
+    if (n_sel) {  // stream-ordered uploads from pinned staging (rewritten only after the next call's first synchronisation)
         FG_HIP(ctx, hipMemcpyAsync(d_oa, h_oa, sizeof(int32_t) * n_sel, hipMemcpyHostToDevice, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(d_on, h_on, sizeof(uint64_t) * n_sel, hipMemcpyHostToDevice, ctx->stream));
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     out->auction = d_oa;
     out->num = d_on;
