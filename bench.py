@@ -40,8 +40,10 @@ DOMINANT = {
     3: ("q3_probe_flag_kernel", 8.0, "auction"),       # seller + category per auction row (filter/probe phase)
     8: ("q8_sellers_bitmap_kernel", 4.0, "auction"),   # seller per auction row
     7: ("q7_max_kernel", 4.0, "bid"),                  # price column once (SURVEY.md section 8(f) "next" query)
+    9: ("aq_final_kernel", 16.0, "bid"),               # auction + price + b_date_time per bid ("next" query)
+    4: ("aq_final_kernel", 16.0, "bid"),
 }
-DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
+DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
 
 def parse():
@@ -49,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 5, 7, 8])
+    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
     ap.add_argument("--mode", choices=["windows", "exchange"], default="windows",
@@ -61,20 +63,24 @@ def parse():
 
 
 def relations_for(q):
-    return {2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person")}[q]
+    return {2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person"), 4: ("bid", "auction"),
+            9: ("bid", "auction")}[q]
 
 
 def input_rows(q, stream):
     if q in (2, 5, 7):
         return stream.bids.rows
+    if q in (4, 9):
+        return stream.bids.rows + stream.auctions.rows
     return stream.auctions.rows + stream.persons.rows
 
 
 def make_stream(ctx, q, seconds, eps, rank):
     from flock_amd import NEXMarkSource, query_window
     src = NEXMarkSource(seconds, eps, query_window(q), seed=20260925, first_event_id=rank * seconds * eps)
-    cols = {2: ("auction", "price"), 7: ("auction", "bidder", "price", "b_date_time")}.get(q, ("auction",))
-    return src.generate_data(ctx, relations=relations_for(q), bid_columns=cols)
+    all4 = ("auction", "bidder", "price", "b_date_time")
+    cols = {2: ("auction", "price"), 7: all4, 9: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
+    return src.generate_data(ctx, relations=relations_for(q), bid_columns=cols, auction_times=q in (4, 9))
 
 
 # ------------------------------------------------------------------ exchange mode: every window striped over the ranks
@@ -202,6 +208,25 @@ def cpu_baseline(q, stream, threads):
                 oracle.q2_filter(auction[lo - lo0:hi - lo0], price[lo - lo0:hi - lo0])
         unique_rows = hi1 - lo0
         what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} bids (each bid counted once)"
+    elif q in (4, 9):
+        sa, sb = stream.window_schedule("auction", w), stream.window_schedule("bid", w)
+        n_win = min(sa.n_windows, max(threads, 32))
+        alo, ahi = sa.window_rows(0)[0], sa.window_rows(n_win - 1)[1]
+        blo, bhi = sb.window_rows(0)[0], sb.window_rows(n_win - 1)[1]
+        A = {k: getattr(stream.auctions, k)[alo:ahi].cpu().numpy() for k in ("a_id", "category", "a_date_time", "expires")}
+        B = {k: getattr(stream.bids, k)[blo:bhi].cpu().numpy() for k in ("auction", "price", "b_date_time")}
+
+        def one(i):
+            (a0, a1), (b0, b1) = sa.window_rows(i), sb.window_rows(i)
+            sa_, sb_ = slice(a0 - alo, a1 - alo), slice(b0 - blo, b1 - blo)
+            if q == 9:
+                oracle.q9_winning_bids(A["a_id"][sa_], A["a_date_time"][sa_], A["expires"][sa_], B["auction"][sb_],
+                                       B["price"][sb_], B["b_date_time"][sb_])
+            else:
+                oracle.q4_avg_final_by_category(A["a_id"][sa_], A["category"][sa_], A["a_date_time"][sa_], A["expires"][sa_],
+                                                B["auction"][sb_], B["price"][sb_], B["b_date_time"][sb_])
+        unique_rows = (ahi - alo) + (bhi - blo)
+        what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} auction + bid rows (numpy restatement)"
     else:
         sa, sp = stream.window_schedule("auction", w), stream.window_schedule("person", w)
         n_win = min(sa.n_windows, max(threads, 100 if q == 3 else 32))
@@ -351,7 +376,7 @@ def main():
         steps2 = max(2, min(args.steps, 3))
         for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q3", 3, DEFAULT_SECONDS[3]), ("q8", 8, DEFAULT_SECONDS[8]),
                                 ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000), ("q2_1e9_bids", 2, 1087),
-                                ("q7_next", 7, DEFAULT_SECONDS[7])):
+                                ("q7_next", 7, DEFAULT_SECONDS[7]), ("q9_next", 9, DEFAULT_SECONDS[9]), ("q4_next", 4, DEFAULT_SECONDS[4])):
             if q2 == q and secs == seconds:
                 continue
             try:

@@ -74,6 +74,21 @@ class Q7Result(C.Structure):
                 ("win_out_offsets", C.POINTER(C.c_int64)), ("win_max", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
 
 
+class AuctionTimeCols(C.Structure):
+    _fields_ = [("a_id", C.c_void_p), ("category", C.c_void_p), ("a_date_time", C.c_void_p), ("expires", C.c_void_p),
+                ("rows", C.c_int64)]
+
+
+class Q9Result(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("price", C.c_void_p), ("bidder", C.c_void_p), ("b_date_time", C.c_void_p),
+                ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
+
+
+class Q4Result(C.Structure):
+    _fields_ = [("category", C.c_void_p), ("avg_final", C.c_void_p), ("win_out_offsets", C.POINTER(C.c_int64)),
+                ("rows", C.c_int64)]
+
+
 class Q8Result(C.Structure):
     _fields_ = [("p_id", C.c_void_p), ("name", Utf8), ("person_row", C.c_void_p),
                 ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("name_bytes", C.c_int64)]
@@ -107,6 +122,10 @@ SYMBOLS = {
                               C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),
     "flockgpu_q5_hot_items": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
     "flockgpu_q7_highest_bid": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q7Result)]),
+    "flockgpu_q9_winning_bids": (_i, [_vp, C.POINTER(AuctionTimeCols), C.POINTER(Windows), C.POINTER(BidCols),
+                                      C.POINTER(Windows), C.POINTER(Q9Result)]),
+    "flockgpu_q4_avg_final_by_category": (_i, [_vp, C.POINTER(AuctionTimeCols), C.POINTER(Windows), C.POINTER(BidCols),
+                                               C.POINTER(Windows), C.POINTER(Q4Result)]),
     "flockgpu_q8_join": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
                               C.POINTER(Windows), C.POINTER(Q8Result)]),
     "flockgpu_partition_by_key": (_i, [_vp, _vp, _i64, C.POINTER(Windows), C.c_int32, C.POINTER(PartitionResult)]),
@@ -118,6 +137,7 @@ SYMBOLS = {
                                      C.POINTER(_u64)]),
     "flockgpu_nexmark_gen_bids": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp]),
     "flockgpu_nexmark_gen_auctions": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp]),
+    "flockgpu_nexmark_gen_auction_times": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp]),
     "flockgpu_nexmark_gen_persons": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/flockgpu_plan.h (ArrowSchema / ArrowArray travel as raw pointers)
     "flockgpu_plan_create": (_i, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_vp)]),

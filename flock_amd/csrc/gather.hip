@@ -93,6 +93,31 @@ __global__ __launch_bounds__(kBlock) void emit_rows_kernel(SegTiles st, const ui
     for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
 }
 
+__global__ __launch_bounds__(kBlock) void emit_bids_kernel(const int32_t *__restrict__ auction, const int32_t *__restrict__ price,
+                                                           const int32_t *__restrict__ bidder,
+                                                           const int64_t *__restrict__ b_date_time, SegTiles st,
+                                                           const uint32_t *__restrict__ flag_words,
+                                                           const uint32_t *__restrict__ counts,
+                                                           const uint64_t *__restrict__ tile_base, int32_t *__restrict__ o_auction,
+                                                           int32_t *__restrict__ o_price, int32_t *__restrict__ o_bidder,
+                                                           int64_t *__restrict__ o_time) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const uint64_t base = tile_base[tile];
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const int64_t r = tr.tile_begin + s_list[i];
+        o_auction[base + i] = auction[r];
+        o_price[base + i] = price[r];
+        o_bidder[base + i] = bidder[r];
+        o_time[base + i] = b_date_time[r];
+    }
+}
+
 // ---- exact per-segment min / max + "strictly increasing" ---------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void segment_stats_kernel(const int32_t *__restrict__ col, int64_t n_rows, SegTiles st,
                                                                int32_t *seg_min, int32_t *seg_max, int32_t *seg_sorted) {
@@ -346,6 +371,18 @@ int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *fla
                            counts, tile_base, out_rows);
     }
     return check_launch(ctx, "emit_rows_kernel");
+}
+
+int emit_flagged_bids(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
+                      const uint64_t *tile_base, const flockgpu_bid_cols &bid, int32_t *o_auction, int32_t *o_price,
+                      int32_t *o_bidder, int64_t *o_time) {
+    if (st.n_tiles <= 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "emit_bids_kernel");
+        hipLaunchKernelGGL(emit_bids_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid.auction, bid.price,
+                           bid.bidder, bid.b_date_time, st, flag_words, counts, tile_base, o_auction, o_price, o_bidder, o_time);
+    }
+    return check_launch(ctx, "emit_bids_kernel");
 }
 
 int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, const SegTiles &st, int32_t *d_min,

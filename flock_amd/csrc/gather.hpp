@@ -16,6 +16,12 @@ namespace flockgpu {
 int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
                       const uint64_t *tile_base, int32_t *out_rows);
 
+// Copies (auction, price, bidder, b_date_time) of every flagged bid row to out_*[tile_base[tile] + i], row order kept
+// (the Projection [auction, price, bidder, b_date_time] of q7 / q9 over the rows that survive the join).
+int emit_flagged_bids(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
+                      const uint64_t *tile_base, const flockgpu_bid_cols &bid, int32_t *o_auction, int32_t *o_price,
+                      int32_t *o_bidder, int64_t *o_time);
+
 // Exact per-segment minimum / maximum of `col` and whether the segment is strictly increasing (sorted and
 // duplicate-free).  d_min / d_max / d_sorted: device arrays of st.n_seg entries, initialised by the call
 // (INT32_MAX / INT32_MIN / 1); empty segments keep those values.  `st` must use kFlagTile-row tiles.

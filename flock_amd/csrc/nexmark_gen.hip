@@ -116,6 +116,22 @@ __global__ __launch_bounds__(kBlock) void gen_auctions_kernel(flockgpu_nexmark_s
     }
 }
 
+// a_date_time / expires of the auctions (event.rs:297-310 next_length, restated like oracle/nexmark_gen.c)
+__global__ __launch_bounds__(kBlock) void gen_auction_times_kernel(flockgpu_nexmark_stream s, uint64_t g0, uint64_t rows,
+                                                                   int64_t *__restrict__ a_date_time, int64_t *__restrict__ expires) {
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < rows; j += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t g = g0 + j;
+        const uint64_t id = (g / kAuctionProp) * kDenom + 1 + g % kAuctionProp;
+        const uint64_t base = ev_base(s.seed, id);
+        const uint64_t time = s.base_time + (id * 1000ull) / s.eps;
+        const uint64_t events_for_auctions = (kInFlightAuctions * kDenom) / kAuctionProp;
+        const uint64_t horizon = s.base_time + ((id + events_for_auctions) * 1000ull) / s.eps - time;
+        const uint64_t span = horizon * 2 > 1 ? horizon * 2 : 1;
+        if (a_date_time) a_date_time[j] = (int64_t)time;
+        if (expires) expires[j] = (int64_t)(time + 1 + uni(draw(base, 5), span));
+    }
+}
+
 // pass 1: ids + string lengths (written at offsets[j + 1]); pass 2 (after the scans): bytes
 __global__ __launch_bounds__(kBlock) void gen_persons_len_kernel(flockgpu_nexmark_stream s, uint64_t g0, uint64_t rows,
                                                                  int32_t *__restrict__ p_id, int32_t *__restrict__ name_off,
@@ -210,6 +226,21 @@ int flockgpu_nexmark_gen_auctions(flockgpu_ctx *ctx, const flockgpu_nexmark_stre
                            seller, category);
     }
     return check_launch(ctx, "gen_auctions_kernel");
+}
+
+int flockgpu_nexmark_gen_auction_times(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                                       int64_t *a_date_time, int64_t *expires) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!s || n1 < n0 || s->eps == 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "gen_auction_times: bad stream / range");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t g0 = auctions_before(s->first_event_id + n0), rows = auctions_before(s->first_event_id + n1) - g0;
+    if (rows == 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "gen_auction_times_kernel");
+        hipLaunchKernelGGL(gen_auction_times_kernel, dim3(grid_for(ctx, rows)), dim3(kBlock), 0, ctx->stream, *s, g0, rows,
+                           a_date_time, expires);
+    }
+    return check_launch(ctx, "gen_auction_times_kernel");
 }
 
 int flockgpu_nexmark_gen_persons(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1, int32_t *p_id,

@@ -7,7 +7,8 @@
 //   max  : per tile the maximum of its rows (kept: tile_max[tile]) and, by atomicMax, the window's maximum
 //   flag : only tiles whose maximum IS the window's maximum can hold result rows -- every other tile writes zero
 //          counts without reading a byte; the few remaining tiles re-read their 32 KiB and flag `price = maxprice`
-//   scan / emit : as q2 -- the four columns of the surviving rows, input order kept (ties are all returned)
+//   scan / emit : as q2 -- the four columns of the surviving rows (gather.hip: emit_bids_kernel), input order kept,
+//                 ties all returned
 // An empty window has MAX = NULL and the inner join emits nothing.
 #include <algorithm>
 
@@ -88,31 +89,6 @@ __global__ __launch_bounds__(kBlock) void q7_flag_kernel(const int32_t *__restri
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
-__global__ __launch_bounds__(kBlock) void q7_emit_kernel(const int32_t *__restrict__ auction, const int32_t *__restrict__ price,
-                                                         const int32_t *__restrict__ bidder,
-                                                         const int64_t *__restrict__ b_date_time, SegTiles st,
-                                                         const uint32_t *__restrict__ flag_words,
-                                                         const uint32_t *__restrict__ counts,
-                                                         const uint64_t *__restrict__ tile_base, int32_t *__restrict__ o_auction,
-                                                         int32_t *__restrict__ o_price, int32_t *__restrict__ o_bidder,
-                                                         int64_t *__restrict__ o_time) {
-    __shared__ uint16_t s_list[kFlagTile];
-    const int32_t tile = (int32_t)blockIdx.x;
-    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
-    if (wc.x + wc.y + wc.z + wc.w == 0) return;
-    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
-    __syncthreads();
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const uint64_t base = tile_base[tile];
-    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
-        const int64_t r = tr.tile_begin + s_list[i];
-        o_auction[base + i] = auction[r];
-        o_price[base + i] = price[r];
-        o_bidder[base + i] = bidder[r];
-        o_time[base + i] = b_date_time[r];
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t *p, int32_t v, int32_t n) {
     const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (i < n) p[i] = v;
@@ -185,12 +161,7 @@ int flockgpu_q7_highest_bid(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, con
     FG_TRY(arena_get_t(ctx, "q7.out_price", (size_t)n_out + 1, &o_p));
     FG_TRY(arena_get_t(ctx, "q7.out_bidder", (size_t)n_out + 1, &o_b));
     FG_TRY(arena_get_t(ctx, "q7.out_time", (size_t)n_out + 1, &o_t));
-    if (st.n_tiles > 0 && n_out > 0) {
-        LaunchScope ls(ctx, "q7_emit_kernel");
-        hipLaunchKernelGGL(q7_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, bid->price,
-                           bid->bidder, bid->b_date_time, st, flag_words, counts, tile_base, o_a, o_p, o_b, o_t);
-    }
-    FG_TRY(check_launch(ctx, "q7_emit_kernel"));
+    if (n_out > 0) FG_TRY(emit_flagged_bids(ctx, st, flag_words, counts, tile_base, *bid, o_a, o_p, o_b, o_t));
     out->auction = o_a;
     out->price = o_p;
     out->bidder = o_b;

@@ -52,6 +52,12 @@ class Auctions:
     seller: "object" = None
     category: "object" = None
     rows: int = 0
+    a_date_time: "object" = None   # q4 / q9 only
+    expires: "object" = None       # q4 / q9 only
+
+    def ffi_times(self) -> _ffi.AuctionTimeCols:
+        p = lambda t: None if t is None else t.data_ptr()
+        return _ffi.AuctionTimeCols(p(self.a_id), p(self.category), p(self.a_date_time), p(self.expires), self.rows)
 
     def ffi(self) -> _ffi.AuctionCols:
         p = lambda t: None if t is None else t.data_ptr()
@@ -194,6 +200,45 @@ class Q7Out:
 
 
 @dataclass
+class Q9Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q9Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        n = self.rows
+        return {"auction": self.ctx.d2h(self.raw.auction, n, np.int32), "price": self.ctx.d2h(self.raw.price, n, np.int32),
+                "bidder": self.ctx.d2h(self.raw.bidder, n, np.int32), "b_date_time": self.ctx.d2h(self.raw.b_date_time, n, np.int64),
+                "offsets": self.offsets()}
+
+
+@dataclass
+class Q4Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q4Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        n = self.rows
+        return {"category": self.ctx.d2h(self.raw.category, n, np.int32), "avg": self.ctx.d2h(self.raw.avg_final, n, np.float64),
+                "offsets": self.offsets()}
+
+
+@dataclass
 class Q8Out:
     ctx: "GpuContext"
     raw: _ffi.Q8Result
@@ -310,6 +355,21 @@ class GpuContext:
         b, w, r = bids.ffi(), windows.ffi(), _ffi.Q7Result()
         self._check(self._lib.flockgpu_q7_highest_bid(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q7Out(self, r, windows.n_windows)
+
+    def q9_winning_bids(self, auctions: Auctions, auction_windows: WindowSchedule, bids: Bids,
+                        bid_windows: WindowSchedule) -> Q9Out:
+        """q9 (q9.sql): the bids whose price is their auction's MAX(price) over the bids inside [a_date_time, expires]."""
+        a, aw, b, bw, r = auctions.ffi_times(), auction_windows.ffi(), bids.ffi(), bid_windows.ffi(), _ffi.Q9Result()
+        self._check(self._lib.flockgpu_q9_winning_bids(self._h, C.byref(a), C.byref(aw), C.byref(b), C.byref(bw), C.byref(r)))
+        return Q9Out(self, r, auction_windows.n_windows)
+
+    def q4_avg_final_by_category(self, auctions: Auctions, auction_windows: WindowSchedule, bids: Bids,
+                                 bid_windows: WindowSchedule) -> Q4Out:
+        """q4 (q4.sql): AVG over the auctions' final prices, per category."""
+        a, aw, b, bw, r = auctions.ffi_times(), auction_windows.ffi(), bids.ffi(), bid_windows.ffi(), _ffi.Q4Result()
+        self._check(self._lib.flockgpu_q4_avg_final_by_category(self._h, C.byref(a), C.byref(aw), C.byref(b), C.byref(bw),
+                                                                C.byref(r)))
+        return Q4Out(self, r, auction_windows.n_windows)
 
     def q8_join(self, persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
                 auction_windows: WindowSchedule) -> Q8Out:

@@ -46,7 +46,7 @@ class Window:
         return Window("hopping", size, hop)
 
 
-def query_window(query_number: int) -> Window:
+def query_window(query_number: int) -> Window:  # noqa: C901
     """benchmarks/src/nexmark/main.rs:115-123."""
     if query_number in (0, 1, 2, 3, 4, 6, 9, 10, 13):
         return Window.element_wise()
@@ -140,7 +140,7 @@ class NEXMarkSource:
         return cache[relation]
 
     def generate_data(self, ctx: GpuContext, relations=("bid", "auction", "person"),
-                      bid_columns=("auction", "bidder", "price", "b_date_time")) -> NEXMarkStream:
+                      bid_columns=("auction", "bidder", "price", "b_date_time"), auction_times=False) -> NEXMarkStream:
         """`generate_data` (nexmark.rs:357-389) straight into HBM columns."""
         import torch
         dev = f"cuda:{ctx.device}"
@@ -160,6 +160,11 @@ class NEXMarkSource:
             auctions = Auctions(*(torch.empty(na, dtype=torch.int32, device=dev) for _ in range(3)), na)
             ctx._check(lib.flockgpu_nexmark_gen_auctions(ctx._h, C.byref(s), 0, n1, ptr(auctions.a_id),
                                                          ptr(auctions.seller), ptr(auctions.category)))
+            if auction_times:   # q4 / q9 scan [a_id, a_date_time, expires (, category)] (q9_plan.fmt)
+                auctions.a_date_time = torch.empty(na, dtype=torch.int64, device=dev)
+                auctions.expires = torch.empty(na, dtype=torch.int64, device=dev)
+                ctx._check(lib.flockgpu_nexmark_gen_auction_times(ctx._h, C.byref(s), 0, n1, ptr(auctions.a_date_time),
+                                                                  ptr(auctions.expires)))
         if "person" in relations:
             mk = lambda width: DeviceUtf8(torch.empty(np_ + 1, dtype=torch.int32, device=dev),
                                           torch.empty(max(np_ * width, 16), dtype=torch.uint8, device=dev))
@@ -184,6 +189,9 @@ def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window:
                            stream.window_schedule("person", window))
     if query_number == 5:
         return ctx.q5_hot_items(stream.bids, stream.window_schedule("bid", window))
+    if query_number in (4, 9):
+        fn = ctx.q4_avg_final_by_category if query_number == 4 else ctx.q9_winning_bids
+        return fn(stream.auctions, stream.window_schedule("auction", window), stream.bids, stream.window_schedule("bid", window))
     if query_number == 7:
         return ctx.q7_highest_bid(stream.bids, stream.window_schedule("bid", window))
     if query_number == 8:

@@ -177,6 +177,37 @@ typedef struct {
 int flockgpu_q7_highest_bid(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
                             flockgpu_q7_result *out);
 
+/* ---- q4 / q9 (SURVEY.md section 8(f) "next" queries), per ElementWise window (benchmarks/src/nexmark/main.rs:117):
+ *   Q  = SELECT a_id [, category], MAX(price) AS final FROM auction INNER JOIN bid ON a_id = auction
+ *        WHERE b_date_time BETWEEN a_date_time AND expires GROUP BY a_id [, category]
+ *   q9 = bid JOIN Q ON auction = id AND price = final -> [auction, bidder, price, b_date_time]  (q9.sql, q9_plan.fmt)
+ *   q4 = SELECT category, AVG(final) FROM Q GROUP BY category -> [category Int32, AVG Float64]   (q4.sql)
+ * Auction ids must be strictly increasing over a dense range inside every window (the generator's order);
+ * otherwise FLOCKGPU_ERR_UNSUPPORTED and the host keeps its own engine for that input.  q9 rows keep input order;
+ * q4 rows are ordered by category inside a window. */
+typedef struct { /* Auction::schema projection of q4 / q9 (q9_plan.fmt: [0, 5, 6]; q4 adds category) */
+    const int32_t *a_id, *category; /* category may be NULL for q9 */
+    const int64_t *a_date_time, *expires;
+    int64_t rows;
+} flockgpu_auction_time_cols;
+typedef struct {
+    const int32_t *auction, *price, *bidder; /* device */
+    const int64_t *b_date_time;              /* device */
+    const int64_t *win_out_offsets;          /* host, n_windows + 1 */
+    int64_t rows;
+} flockgpu_q9_result;
+typedef struct {
+    const int32_t *category;        /* device */
+    const double *avg_final;        /* device */
+    const int64_t *win_out_offsets; /* host, n_windows + 1 */
+    int64_t rows;
+} flockgpu_q4_result;
+int flockgpu_q9_winning_bids(flockgpu_ctx *ctx, const flockgpu_auction_time_cols *auction, const flockgpu_windows *auction_win,
+                             const flockgpu_bid_cols *bid, const flockgpu_windows *bid_win, flockgpu_q9_result *out);
+int flockgpu_q4_avg_final_by_category(flockgpu_ctx *ctx, const flockgpu_auction_time_cols *auction,
+                                      const flockgpu_windows *auction_win, const flockgpu_bid_cols *bid,
+                                      const flockgpu_windows *bid_win, flockgpu_q4_result *out);
+
 /* ---- q8: DISTINCT (p_id, name) JOIN DISTINCT seller ON p_id = seller -> [p_id, name]
  * (q8.sql, q8_plan.fmt:1-10, q8.dag).  Output grouped by window, ordered by person row. */
 typedef struct {
@@ -230,6 +261,8 @@ int flockgpu_nexmark_gen_bids(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *
                               int32_t *auction, int32_t *bidder, int32_t *price, int64_t *b_date_time);
 int flockgpu_nexmark_gen_auctions(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
                                   int32_t *a_id, int32_t *seller, int32_t *category);
+int flockgpu_nexmark_gen_auction_times(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
+                                       int64_t *a_date_time, int64_t *expires);
 /* Persons: offsets arrays have rows + 1 entries; byte buffers must hold rows*14 / rows*13 / rows*2. */
 int flockgpu_nexmark_gen_persons(flockgpu_ctx *ctx, const flockgpu_nexmark_stream *s, uint64_t n0, uint64_t n1,
                                  int32_t *p_id, int32_t *name_off, uint8_t *name_bytes, int32_t *city_off,

@@ -233,6 +233,61 @@ def q7_highest_bid(price: np.ndarray) -> np.ndarray:
     return np.nonzero(price == price.max())[0].astype(np.int64)
 
 
+def _auction_bid_pairs(a_id, a_date_time, expires, b_auction, b_date_time):
+    """(auction_row, bid_row) pairs of  auction INNER JOIN bid ON a_id = auction  WHERE b_date_time BETWEEN a_date_time AND
+    expires  (q4.sql / q9.sql inner query; any number of duplicate keys on either side)."""
+    a_id = np.asarray(a_id, np.int64)
+    b_auction = np.asarray(b_auction, np.int64)
+    order = np.argsort(a_id, kind="stable")
+    keys = a_id[order]
+    lo, hi = np.searchsorted(keys, b_auction, "left"), np.searchsorted(keys, b_auction, "right")
+    n = hi - lo
+    bid_row = np.repeat(np.arange(len(b_auction)), n)
+    pos = np.arange(int(n.sum())) - np.repeat(np.cumsum(n) - n, n) + np.repeat(lo, n)
+    auc_row = order[pos]
+    when = np.asarray(b_date_time, np.int64)[bid_row]
+    keep = (when >= np.asarray(a_date_time, np.int64)[auc_row]) & (when <= np.asarray(expires, np.int64)[auc_row])
+    return auc_row[keep], bid_row[keep]
+
+
+def _group_max(keys: np.ndarray, values: np.ndarray):
+    """(distinct keys ascending, MAX(values) per key)."""
+    uniq, inv = np.unique(keys, return_inverse=True, axis=0)
+    best = np.full(len(uniq), np.iinfo(np.int64).min, np.int64)
+    np.maximum.at(best, inv.reshape(-1), values)
+    return uniq, best
+
+
+def q9_winning_bids(a_id, a_date_time, expires, b_auction, b_price, b_date_time) -> np.ndarray:
+    """Bid rows (input order) of q9 for one window (benchmarks/src/nexmark/query/q9.sql, q9_plan.fmt):
+    Q = MAX(price) GROUP BY a_id over the filtered join; result = bids with (auction, price) = (Q.id, Q.final) --
+    the outer join does not repeat the BETWEEN."""
+    ar, br = _auction_bid_pairs(a_id, a_date_time, expires, b_auction, b_date_time)
+    b_price, b_auction = np.asarray(b_price, np.int64), np.asarray(b_auction, np.int64)
+    if len(ar) == 0:
+        return np.zeros(0, np.int64)
+    ids, final = _group_max(np.asarray(a_id, np.int64)[ar], b_price[br])
+    pos = np.searchsorted(ids, b_auction)
+    pos[pos == len(ids)] = 0
+    keep = (ids[pos] == b_auction) & (final[pos] == b_price)
+    return np.nonzero(keep)[0].astype(np.int64)
+
+
+def q4_avg_final_by_category(a_id, category, a_date_time, expires, b_auction, b_price, b_date_time):
+    """(category Int32, AVG(final) Float64) rows of q4 for one window, ordered by category (q4.sql; stages in
+    flock/src/distributed_plan/planner.rs:218-256).  Inner groups are (a_id, category); AVG = Float64 sum / UInt64 count
+     -- the sums here are integers far below 2^53, so the division is the only rounding."""
+    ar, br = _auction_bid_pairs(a_id, a_date_time, expires, b_auction, b_date_time)
+    if len(ar) == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.float64)
+    a_id, category, b_price = np.asarray(a_id, np.int64), np.asarray(category, np.int64), np.asarray(b_price, np.int64)
+    groups, final = _group_max(np.stack([category[ar], a_id[ar]], axis=1), b_price[br])   # sorted by (category, a_id)
+    cats, start = np.unique(groups[:, 0], return_index=True)
+    sums = np.add.reduceat(final, start)
+    counts = np.diff(np.append(start, len(final)))
+    return cats.astype(np.int32), sums.astype(np.float64) / counts.astype(np.float64)
+
+
 def q8_join(p_id, name: Utf8, seller):
     """Row indices (into the window's person rows) of the output, in row order."""
     p_id = np.ascontiguousarray(p_id, np.int32)

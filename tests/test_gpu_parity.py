@@ -279,6 +279,81 @@ def test_q7_ties_negatives_and_empty_windows(ctx):
         ctx.q7_highest_bid(Bids(auction=_dev(auction), price=_dev(price), rows=n), sched)     # q7 projects all four columns
 
 
+# ------------------------------------------------------------------ q4 / q9 ("next" queries: join + BETWEEN + MAX / AVG)
+def _gpu_stream_times(ctx, seed, eps, seconds, window):
+    from flock_amd import NEXMarkSource
+    return NEXMarkSource(seconds, eps, window, seed=seed).generate_data(ctx, relations=("bid", "auction"), auction_times=True)
+
+
+@pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 5), (7, 5000, 4), (42, 50_000, 6), (5, 1_000_000, 2)])
+def test_q4_q9_per_epoch(ctx, seed, eps, seconds):
+    from flock_amd import Window, run_query
+    g = _gpu_stream_times(ctx, seed, eps, seconds, Window.element_wise())
+    s = oracle.NexmarkStream(seed=seed, eps=eps)
+    a, b = s.auctions(0, eps * seconds), s.bids(0, eps * seconds)
+    assert np.array_equal(g.auctions.a_date_time.cpu().numpy(), a["a_date_time"])      # device generator == oracle
+    assert np.array_equal(g.auctions.expires.cpu().numpy(), a["expires"])
+    o9, o4 = run_query(ctx, 9, g).to_host(), run_query(ctx, 4, g).to_host()
+    sa, sb = g.window_schedule("auction"), g.window_schedule("bid")
+    total = 0
+    for w in range(seconds):
+        (alo, ahi), (blo, bhi) = sa.window_rows(w), sb.window_rows(w)
+        args = (a["a_id"][alo:ahi], a["a_date_time"][alo:ahi], a["expires"][alo:ahi], b["auction"][blo:bhi], b["price"][blo:bhi],
+                b["b_date_time"][blo:bhi])
+        rows = oracle.q9_winning_bids(*args) + blo
+        sl = slice(o9["offsets"][w], o9["offsets"][w + 1])
+        for k in ("auction", "price", "bidder", "b_date_time"):
+            assert np.array_equal(o9[k][sl], b[k][rows]), (w, k)                        # input order: exact equality
+        cats, avg = oracle.q4_avg_final_by_category(a["a_id"][alo:ahi], a["category"][alo:ahi], *args[1:])
+        sl4 = slice(o4["offsets"][w], o4["offsets"][w + 1])
+        assert np.array_equal(o4["category"][sl4], cats) and o4["avg"][sl4].tobytes() == avg.tobytes()   # Float64 bits
+        total += len(rows)
+    assert total == len(o9["price"]) and (total > 0 or eps < 5000)
+
+
+def test_q4_q9_edge_cases(ctx):
+    """Ties, bids outside [a_date_time, expires], bids on auctions of other windows, negative prices, wide tiles (a tile's
+    auction rows spanning more than the LDS table), empty windows on either side, and the unsupported (unsorted) input."""
+    from flock_amd import Auctions, Bids, FlockGpuError, WindowSchedule
+    rng = np.random.default_rng(17)
+    na, nb = 50_000, 400_000
+    a_id = (1000 + np.cumsum(rng.integers(1, 4, na))).astype(np.int32)           # strictly increasing, gaps
+    a_time = np.sort(rng.integers(0, 10_000, na)).astype(np.int64)
+    expires = a_time + rng.integers(0, 50, na)
+    category = rng.integers(-3, 9, na).astype(np.int32)                          # 12 values: registers AND the LDS accumulators
+    pick = rng.integers(0, na, nb)                                               # uniform over all auctions: wide tiles
+    pick[5000:30_000:2] = 123                                                    # a hot auction
+    auction = a_id[pick].astype(np.int32)
+    when = a_time[pick] + rng.integers(-10, 70, nb)                              # some before a_date_time, some after expires
+    auction[::9] = rng.integers(-2**31, 2**31 - 1, len(auction[::9])).astype(np.int32)
+    price = rng.integers(-500, 500, nb).astype(np.int32)                         # many ties
+    bidder = rng.integers(0, 10**6, nb).astype(np.int32)
+    aw = WindowSchedule(np.array([0, 20_001, 20_001, 35_000, na]), np.arange(4), np.arange(1, 5))    # window 1: no auctions
+    bw = WindowSchedule(np.array([3, 150_000, 200_000, 200_000, nb]), np.arange(4), np.arange(1, 5))  # window 2: no bids
+    auc = Auctions(a_id=_dev(a_id), category=_dev(category), rows=na, a_date_time=_dev(a_time), expires=_dev(expires))
+    bids = Bids(_dev(auction), _dev(bidder), _dev(price), _dev(when), nb)
+    o9, o4 = ctx.q9_winning_bids(auc, aw, bids, bw).to_host(), ctx.q4_avg_final_by_category(auc, aw, bids, bw).to_host()
+    total = 0
+    for w in range(4):
+        (alo, ahi), (blo, bhi) = aw.window_rows(w), bw.window_rows(w)
+        args = (a_time[alo:ahi], expires[alo:ahi], auction[blo:bhi], price[blo:bhi], when[blo:bhi])
+        rows = oracle.q9_winning_bids(a_id[alo:ahi], *args) + blo
+        sl = slice(o9["offsets"][w], o9["offsets"][w + 1])
+        assert np.array_equal(o9["auction"][sl], auction[rows]) and np.array_equal(o9["price"][sl], price[rows]), w
+        assert np.array_equal(o9["bidder"][sl], bidder[rows]) and np.array_equal(o9["b_date_time"][sl], when[rows]), w
+        cats, avg = oracle.q4_avg_final_by_category(a_id[alo:ahi], category[alo:ahi], *args)
+        sl4 = slice(o4["offsets"][w], o4["offsets"][w + 1])
+        assert np.array_equal(o4["category"][sl4], cats) and o4["avg"][sl4].tobytes() == avg.tobytes(), w
+        total += len(rows)
+    assert total > 1000 and o9["offsets"][2] == o9["offsets"][1] and o9["offsets"][3] == o9["offsets"][2]
+    shuffled = a_id.copy()
+    shuffled[10:20] = shuffled[10:20][::-1]
+    with pytest.raises(FlockGpuError) as e:
+        ctx.q9_winning_bids(Auctions(a_id=_dev(shuffled), rows=na, a_date_time=_dev(a_time), expires=_dev(expires)), aw, bids, bw)
+    from flock_amd import _ffi
+    assert e.value.code == _ffi.ERR_UNSUPPORTED
+
+
 # ------------------------------------------------------------------ q8
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 10)])
 def test_q8_tumbling_windows(ctx, seed, eps, seconds):

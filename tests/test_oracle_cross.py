@@ -123,3 +123,36 @@ def test_empty_windows():
     st = oracle.Utf8(np.zeros(1, np.int32), np.empty(0, np.uint8))
     assert len(oracle.q3_join(e, e, e, st)[0]) == 0
     assert len(oracle.q8_join(e, st, e)) == 0
+
+
+# ---------------------------------------------------------------- "next" queries (SURVEY.md section 8 f): q4, q7, q9
+@pytest.mark.parametrize("seed,eps,seconds", SEEDS)
+def test_q4_q7_q9_against_pyarrow(seed, eps, seconds):
+    """The numpy restatements of q4 / q7 / q9 against pyarrow's join / filter / group_by (independent engine)."""
+    total9 = 0
+    for e in range(seconds):
+        (b, a, _), _ = _tables(seed, eps, e * eps, (e + 1) * eps)
+        # q7: rows reaching MAX(price)
+        rows = oracle.q7_highest_bid(b["price"])
+        mx = pc.max(pa.array(b["price"])).as_py()
+        assert rows.tolist() == [i for i, p in enumerate(b["price"].tolist()) if p == mx]
+        # inner query Q through pyarrow: join, BETWEEN, MAX GROUP BY
+        ta = pa.table({"a_id": a["a_id"], "category": a["category"], "a_date_time": a["a_date_time"], "expires": a["expires"]})
+        tb = pa.table({"auction": b["auction"], "price": b["price"], "b_date_time": b["b_date_time"],
+                       "row": np.arange(len(b["price"]))})
+        j = ta.join(tb, keys="a_id", right_keys="auction", join_type="inner")
+        j = j.filter(pc.and_(pc.greater_equal(j["b_date_time"], j["a_date_time"]), pc.less_equal(j["b_date_time"], j["expires"])))
+        q = j.group_by(["a_id", "category"]).aggregate([("price", "max")])
+        # q9: bids whose (auction, price) = (id, final)
+        back = tb.join(q.select(["a_id", "price_max"]), keys=["auction", "price"], right_keys=["a_id", "price_max"], join_type="inner")
+        want9 = sorted(back["row"].to_pylist())
+        got9 = oracle.q9_winning_bids(a["a_id"], a["a_date_time"], a["expires"], b["auction"], b["price"], b["b_date_time"])
+        assert got9.tolist() == want9
+        total9 += len(want9)
+        # q4: AVG(final) GROUP BY category -- Float64 bits
+        q4 = q.group_by("category").aggregate([("price_max", "mean")]).sort_by("category")
+        cats, avg = oracle.q4_avg_final_by_category(a["a_id"], a["category"], a["a_date_time"], a["expires"], b["auction"],
+                                                    b["price"], b["b_date_time"])
+        assert cats.tolist() == q4["category"].to_pylist()
+        assert avg.tobytes() == q4["price_max_mean"].to_numpy().astype(np.float64).tobytes()
+    assert total9 > 0
