@@ -188,9 +188,9 @@ def cpu_baseline(q, stream, threads):
     oracle.lib()
     if q in (2, 5, 7):
         sched = stream.window_schedule("bid", w)
-        budget_rows = 2.0e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here)
+        budget_rows = 1.5e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here)
         n_win, rows = 0, 0
-        while n_win < sched.n_windows and (rows < budget_rows or n_win < threads):
+        while n_win < sched.n_windows and (rows < budget_rows or (q != 5 and n_win < threads)):
             lo, hi = sched.window_rows(n_win)
             rows += hi - lo
             n_win += 1
