@@ -457,8 +457,21 @@ bool recognise(const JValue *root, flockgpu_plan *pl, std::string *why) {
                 return true;
             }
         }
+        // ---- q7 ("next" query): bid JOIN (MAX(price) AS maxprice over bid) ON price = maxprice
+        if (lk == "price" && rk == "maxprice") {
+            Agg mx;
+            if (match_leaf(L, "auction", "price") && match_leaf(L, "bidder", "b_date_time") && match_agg(R, &mx) && mx.group.empty() &&
+                mx.kinds == std::vector<std::string>{"max"} && match_leaf(mx.input, "price")) {
+                pl->query = 7;
+                Leaf b;
+                b.relation = "bid";
+                b.cols = {col("auction", "i"), col("bidder", "i"), col("price", "i"), col("b_date_time", "tsm:")};
+                pl->leaves = {b, b};  // the SQL scans `bid` twice; whichever leaf is fed holds the relation
+                return true;
+            }
+        }
     }
-    *why = "plan shape is not NEXMark q1/q2/q3/q5/q8";
+    *why = "plan shape is not NEXMark q1/q2/q3/q5/q7/q8";
     return false;
 }
 
@@ -858,6 +871,30 @@ int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, s
         make_struct_array(out_batch, r.rows);
         add_array_child(out_batch, r.rows, h_a, nullptr);
         add_array_child(out_batch, r.rows, h_n, nullptr);
+        return FLOCKGPU_OK;
+    }
+    if (plan->query == 7) {
+        Leaf &b = plan->leaves[0].rows ? plan->leaves[0] : plan->leaves[1];
+        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), static_cast<const int32_t *>(b.cols[1].values),
+                             static_cast<const int32_t *>(b.cols[2].values), static_cast<const int64_t *>(b.cols[3].values), b.rows};
+        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
+        flockgpu_q7_result r{};
+        FG_TRY(flockgpu_q7_highest_bid(ctx, &bc, &w, &r));
+        void *h_a, *h_p, *h_b, *h_t;
+        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
+        FG_TRY(d2h_alloc(ctx, r.price, (size_t)r.rows * 4, &h_p));
+        FG_TRY(d2h_alloc(ctx, r.bidder, (size_t)r.rows * 4, &h_b));
+        FG_TRY(d2h_alloc(ctx, r.b_date_time, (size_t)r.rows * 8, &h_t));
+        make_schema(out_schema, "+s", "", false);
+        add_schema_child(out_schema, "i", "auction", false);   // q7_plan.fmt:1
+        add_schema_child(out_schema, "i", "price", false);
+        add_schema_child(out_schema, "i", "bidder", false);
+        add_schema_child(out_schema, "tsm:", "b_date_time", false);
+        make_struct_array(out_batch, r.rows);
+        add_array_child(out_batch, r.rows, h_a, nullptr);
+        add_array_child(out_batch, r.rows, h_p, nullptr);
+        add_array_child(out_batch, r.rows, h_b, nullptr);
+        add_array_child(out_batch, r.rows, h_t, nullptr);
         return FLOCKGPU_OK;
     }
     if (plan->query == 8) {

@@ -25,7 +25,7 @@ def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
     from flock_amd import _ffi, build
     build.build()
     lib = _ffi.load()
-    for q in (1, 2, 3, 5, 8):
+    for q in (1, 2, 3, 5, 7, 8):
         t = _plan(q).encode()
         got = C.c_int(0)
         assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK
@@ -52,7 +52,7 @@ def test_plan_fixtures_match_the_generator():
     spec = importlib.util.spec_from_file_location("mk", os.path.join(ROOT, "tools", "make_plan_fixtures.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
-    for name, fn in (("q1", mk.q1), ("q2", mk.q2), ("q3", mk.q3), ("q5", mk.q5), ("q8", mk.q8)):
+    for name, fn in (("q1", mk.q1), ("q2", mk.q2), ("q3", mk.q3), ("q5", mk.q5), ("q8", mk.q8), ("q7", mk.q7)):
         assert json.load(open(os.path.join(PLANS, name + ".json"))) == json.loads(json.dumps(fn())), name
 
 
@@ -237,3 +237,25 @@ def test_reference_granules_equal_whole_window_batches(gpu):
         rows = lambda rb: sorted(zip(*[rb[c].to_pylist() for c in rb.schema.names]))
         assert rows(fine) == rows(whole) and fine.num_rows > 0
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_q7_tumbling_window_through_collect(gpu):
+    """q7 ("next" query) through the plan-level ABI: one `collect` per Tumbling(10 s) window (tumbling.rs:55-57)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=9, eps=5_000)
+    ctx = ExecutionContext([_plan(7)], name="q7-00", gpu=gpu)
+    for w in range(2):
+        n0, n1 = w * 50_000, (w + 1) * 50_000
+        rb = collect(ctx, [[_bid_batches(s, n0, n1, 7_000)]])[0][0]
+        host = s.bids(n0, n1)
+        rows = oracle.q7_highest_bid(host["price"])
+        assert rb.schema.names == ["auction", "price", "bidder", "b_date_time"]
+        assert rb.schema.types == [pa.int32(), pa.int32(), pa.int32(), TS]                       # q7_plan.fmt:1
+        assert rb["auction"].to_numpy().tolist() == host["auction"][rows].tolist()
+        assert rb["price"].to_numpy().tolist() == host["price"][rows].tolist()
+        assert rb["bidder"].to_numpy().tolist() == host["bidder"][rows].tolist()
+        assert rb["b_date_time"].cast(pa.int64()).to_numpy().tolist() == host["b_date_time"][rows].tolist()
+        assert rb.num_rows >= 1
+    assert collect(ctx, [[[]]])[0][0].num_rows == 0                                              # MAX of nothing is NULL
+    ctx.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/plans/q{1,2,3,5,8}.json: the physical plans of the five NEXMark target queries in the
+"""Writes tests/golden/plans/q{1,2,3,5,7,8}.json: the physical plans of the five NEXMark target queries (and q7) in the
 serde_json dialect of the reference's DataFusion fork.
 
 The fork's serialiser cannot be run here (no Rust toolchain), so the plans are AUTHORED from
@@ -163,9 +163,26 @@ def q8():
     return proj(coalesce(j), grp_p, pf)
 
 
+def q7():
+    # benchmarks/src/nexmark/query/q7.sql + q7_plan.fmt (SURVEY.md section 8(f) "next" query):
+    # Projection [auction, price, bidder, b_date_time] <- HashJoin(price = maxprice)
+    #   left : bid                       right: Projection maxprice <- MAX(price) (Partial -> CoalescePartitions -> Final) <- bid
+    mx = [{"aggregate_expr": "max", "name": "MAX(bid.price)", "data_type": "Int32", "nullable": True, "expr": col("price", 2)}]
+    partial = agg(rr(memory(BID, [0, 1, 2, 3], "bid")), "Partial", [], mx, BID, [field("MAX(bid.price)[max]", "Int32", True)])
+    final = agg({"execution_plan": "coalesce_partitions_exec", "input": partial}, "Final", [], mx, BID,
+                [field("MAX(bid.price)", "Int32", True)])
+    maxp = [field("maxprice", "Int32", True)]
+    right = proj(proj(final, [(col("MAX(bid.price)", 0), "maxprice")], maxp), [(col("maxprice", 0), "maxprice")], maxp)
+    left = coalesce(hashp(rr(memory(BID, [0, 1, 2, 3], "bid")), [col("price", 2)]))
+    j = join(left, coalesce(hashp(right, [col("maxprice", 0)])), [(("price", 2), ("maxprice", 0))], BID + maxp)
+    out = [field("auction", "Int32"), field("price", "Int32"), field("bidder", "Int32"), field("b_date_time", TS)]
+    return proj(coalesce(j), [(col("auction", 0), "auction"), (col("price", 2), "price"), (col("bidder", 1), "bidder"),
+                              (col("b_date_time", 3), "b_date_time")], out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8)):
+    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
