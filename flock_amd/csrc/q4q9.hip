@@ -67,6 +67,11 @@ __device__ __forceinline__ int32_t auction_row_of(int32_t key, const WinTable &w
     return ok ? row : -1;
 }
 
+// kIters x 1024 bids per tile: lane l of wave w holds rows  w*256*kIters + it*256 + 4l .. 4l+3  (the flag-tile layout
+// with fewer iterations: (row, price) of every bid stay in registers between the two phases, and 4 iterations instead
+// of 8 keep the kernel at 6 instead of 4 workgroups per CU).
+constexpr int kFinalIters = 4;
+constexpr int kFinalTile = kBlock * 4 * kFinalIters;
 __global__ __launch_bounds__(kBlock) void aq_final_kernel(const int32_t *__restrict__ b_auction,
                                                           const int32_t *__restrict__ b_price,
                                                           const int64_t *__restrict__ b_time, int64_t n_bids, SegTiles st,
@@ -77,16 +82,16 @@ __global__ __launch_bounds__(kBlock) void aq_final_kernel(const int32_t *__restr
     __shared__ int32_t s_red[2 * kWavesPerBlock];
     for (int s = threadIdx.x; s < kSpan; s += kBlock) s_max[s] = kNone;
     const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const TileRange tr = locate_tile(st, tile, kFinalTile);
     const WinTable wt = wins[tr.seg];
     if (wt.range == 0) return;  // the window has no auctions: nothing can join
     const int32_t *tab = direct + wt.off;
-    const int64_t wbase = tr.tile_begin + flag_rel0();
+    const int64_t wbase = tr.tile_begin + (int64_t)(threadIdx.x >> 6) * (kFinalTile / kWavesPerBlock) + lane_id() * 4;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    int32_t row[kFlagIters][4], price[kFlagIters][4];
+    int32_t row[kFinalIters][4], price[kFinalIters][4];
     int32_t mn = 0x7fffffff, mx = -1;
 #pragma unroll
-    for (int it = 0; it < kFlagIters; ++it) {
+    for (int it = 0; it < kFinalIters; ++it) {
         const int64_t r0 = wbase + it * 256;
         int32_t key[4];
         load4_i32(b_auction, r0, n_bids, key);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void aq_final_kernel(const int32_t *__restr
     // the hot auction of this wave: its maximum is kept per lane in a register and folded in once
     int32_t hot = -2, hot_max = kNone;
 #pragma unroll
-    for (int it = 0; it < kFlagIters; ++it) {
+    for (int it = 0; it < kFinalIters; ++it) {
         uint64_t m = __ballot(row[it][0] == hot);
         if (__popcll((unsigned long long)m) < 16) {  // re-elect (see q8_sellers_bitmap_kernel)
             if (hot >= 0) {  // park the outgoing candidate's maximum
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t *p, int32_t v,
 
 // Everything q4 and q9 share: tables, finals.  Leaves device state in `s`.
 struct Shared {
-    SegTiles st_a, st_b;
+    SegTiles st_a, st_b, st_bf;  // auctions, bids (flag tiles), bids (tiles of the final pass)
     WinTable *d_wins = nullptr;
     int32_t *direct = nullptr, *final_price = nullptr;
     int n_win = 0;
@@ -322,6 +327,7 @@ int compute_finals(flockgpu_ctx *ctx, const char *who, const flockgpu_auction_ti
     }
     FG_TRY(build_seg_tiles(ctx, "aq.auction", ab.data(), ae.data(), n_win, kFlagTile, &s->st_a));
     FG_TRY(build_seg_tiles(ctx, "aq.bid", bb.data(), be.data(), n_win, kFlagTile, &s->st_b));
+    FG_TRY(build_seg_tiles(ctx, "aq.bid_final", bb.data(), be.data(), n_win, kFinalTile, &s->st_bf));
     int32_t *d_stats = nullptr, *h_stats = nullptr;
     FG_TRY(arena_get_t(ctx, "aq.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
     FG_TRY(pinned_get_t(ctx, "aq.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
@@ -361,10 +367,10 @@ int compute_finals(flockgpu_ctx *ctx, const char *who, const flockgpu_auction_ti
                            auction->rows, s->st_a, s->d_wins, s->direct, s->final_price);
     }
     FG_TRY(check_launch(ctx, "aq_build_kernel"));
-    if (s->st_b.n_tiles > 0) {
+    if (s->st_bf.n_tiles > 0) {
         LaunchScope ls(ctx, "aq_final_kernel");
-        hipLaunchKernelGGL(aq_final_kernel, dim3((unsigned)s->st_b.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, bid->price,
-                           bid->b_date_time, bid->rows, s->st_b, s->d_wins, s->direct, auction->a_date_time, auction->expires,
+        hipLaunchKernelGGL(aq_final_kernel, dim3((unsigned)s->st_bf.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, bid->price,
+                           bid->b_date_time, bid->rows, s->st_bf, s->d_wins, s->direct, auction->a_date_time, auction->expires,
                            s->final_price);
     }
     return check_launch(ctx, "aq_final_kernel");
