@@ -42,8 +42,9 @@ DOMINANT = {
     7: ("q7_max_kernel", 4.0, "bid"),                  # price column once (SURVEY.md section 8(f) "next" query)
     9: ("aq_final_kernel", 16.0, "bid"),               # auction + price + b_date_time per bid ("next" query)
     4: ("aq_final_kernel", 16.0, "bid"),
+    13: ("q13_probe_count_kernel", 4.0, "bid"),        # auction per bid, probed against the LDS copy of the side table
 }
-DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
+DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300, 13: 1087}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
 
 def parse():
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9])
+    ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9, 13])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
     ap.add_argument("--mode", choices=["windows", "exchange"], default="windows",
@@ -64,11 +65,11 @@ def parse():
 
 def relations_for(q):
     return {2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person"), 4: ("bid", "auction"),
-            9: ("bid", "auction")}[q]
+            9: ("bid", "auction"), 13: ("bid",)}[q]
 
 
 def input_rows(q, stream):
-    if q in (2, 5, 7):
+    if q in (2, 5, 7, 13):
         return stream.bids.rows
     if q in (4, 9):
         return stream.bids.rows + stream.auctions.rows
@@ -79,7 +80,7 @@ def make_stream(ctx, q, seconds, eps, rank):
     from flock_amd import NEXMarkSource, query_window
     src = NEXMarkSource(seconds, eps, query_window(q), seed=20260925, first_event_id=rank * seconds * eps)
     all4 = ("auction", "bidder", "price", "b_date_time")
-    cols = {2: ("auction", "price"), 7: all4, 9: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
+    cols = {2: ("auction", "price"), 7: all4, 9: all4, 13: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
     return src.generate_data(ctx, relations=relations_for(q), bid_columns=cols, auction_times=q in (4, 9))
 
 
@@ -208,6 +209,19 @@ def cpu_baseline(q, stream, threads):
                 oracle.q2_filter(auction[lo - lo0:hi - lo0], price[lo - lo0:hi - lo0])
         unique_rows = hi1 - lo0
         what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} bids (each bid counted once)"
+    elif q == 13:
+        from flock_amd import synthetic_side_input
+        sched = stream.window_schedule("bid", w)
+        n_win = min(sched.n_windows, max(threads, 64))
+        lo0, hi1 = sched.window_rows(0)[0], sched.window_rows(n_win - 1)[1]
+        auction = stream.bids.auction[lo0:hi1].cpu().numpy()
+        side_key = stream.__dict__["_side_input"][0].cpu().numpy()
+
+        def one(i):
+            lo, hi = sched.window_rows(i)
+            oracle.q13_side_join(auction[lo - lo0:hi - lo0], side_key)
+        unique_rows = hi1 - lo0
+        what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} bids against {len(side_key)} side rows (numpy restatement)"
     elif q in (4, 9):
         sa, sb = stream.window_schedule("auction", w), stream.window_schedule("bid", w)
         n_win = min(sa.n_windows, max(threads, 32))
@@ -376,7 +390,8 @@ def main():
         steps2 = max(2, min(args.steps, 3))
         for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q3", 3, DEFAULT_SECONDS[3]), ("q8", 8, DEFAULT_SECONDS[8]),
                                 ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000), ("q2_1e9_bids", 2, 1087),
-                                ("q7_next", 7, DEFAULT_SECONDS[7]), ("q9_next", 9, DEFAULT_SECONDS[9]), ("q4_next", 4, DEFAULT_SECONDS[4])):
+                                ("q7_next", 7, DEFAULT_SECONDS[7]), ("q9_next", 9, DEFAULT_SECONDS[9]), ("q4_next", 4, DEFAULT_SECONDS[4]),
+                                ("q13_next", 13, DEFAULT_SECONDS[13])):
             if q2 == q and secs == seconds:
                 continue
             try:

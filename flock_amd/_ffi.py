@@ -89,6 +89,12 @@ class Q4Result(C.Structure):
                 ("rows", C.c_int64)]
 
 
+class Q13Result(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("bidder", C.c_void_p), ("price", C.c_void_p), ("b_date_time", C.c_void_p),
+                ("value", C.c_void_p), ("bid_row", C.c_void_p), ("side_row", C.c_void_p),
+                ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
+
+
 class Q8Result(C.Structure):
     _fields_ = [("p_id", C.c_void_p), ("name", Utf8), ("person_row", C.c_void_p),
                 ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("name_bytes", C.c_int64)]
@@ -126,6 +132,7 @@ SYMBOLS = {
                                       C.POINTER(Windows), C.POINTER(Q9Result)]),
     "flockgpu_q4_avg_final_by_category": (_i, [_vp, C.POINTER(AuctionTimeCols), C.POINTER(Windows), C.POINTER(BidCols),
                                                C.POINTER(Windows), C.POINTER(Q4Result)]),
+    "flockgpu_q13_side_join": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), _vp, _vp, _i64, C.POINTER(Q13Result)]),
     "flockgpu_q8_join": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
                               C.POINTER(Windows), C.POINTER(Q8Result)]),
     "flockgpu_partition_by_key": (_i, [_vp, _vp, _i64, C.POINTER(Windows), C.c_int32, C.POINTER(PartitionResult)]),

@@ -188,6 +188,12 @@ __global__ __launch_bounds__(kBlock) void gather_i32_kernel(const int32_t *__res
         out[i] = src[rows[i]];
 }
 
+__global__ __launch_bounds__(kBlock) void gather_i64_kernel(const int64_t *__restrict__ src, const int32_t *__restrict__ rows,
+                                                            int64_t n, int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = src[rows[i]];
+}
+
 // ---- Utf8 take: lengths (count) -> tile scan -> offsets + bytes (emit) --------------------------------------------
 // Tile = 1024 values; value  it*256 + tid  of the tile belongs to thread tid (it = 0..3): the row list and the
 // source offsets are read coalesced.  counts[tile*4 + wave] = bytes of the wave's values.
@@ -430,6 +436,16 @@ int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64
         hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src, rows, n, out);
     }
     return check_launch(ctx, "gather_i32_kernel");
+}
+
+int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "gather_i64_kernel");
+        hipLaunchKernelGGL(gather_i64_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src, rows, n, out);
+    }
+    return check_launch(ctx, "gather_i64_kernel");
 }
 
 int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

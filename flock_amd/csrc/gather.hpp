@@ -29,6 +29,7 @@ int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, con
                       int32_t *d_max, int32_t *d_sorted);
 
 int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out);
+int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out);
 
 // Gathers `n` Utf8 values in two phases so that several columns share ONE host synchronisation:
 //   begin  : lengths -> tile scan; queues the D2H copy of the total byte count (the host needs it to size the

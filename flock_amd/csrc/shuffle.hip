@@ -97,12 +97,6 @@ __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *_
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gather_i64_kernel(const int64_t *__restrict__ src, const int32_t *__restrict__ rows,
-                                                            int64_t n, int64_t *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        out[i] = src[rows[i]];
-}
-
 }  // namespace
 
 extern "C" {
@@ -190,14 +184,8 @@ int flockgpu_take_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows
 int flockgpu_take_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     if (n < 0 || (n > 0 && (!src || !rows || !out))) return fail(ctx, FLOCKGPU_ERR_INVALID, "take_i64: null argument");
-    if (n == 0) return FLOCKGPU_OK;
     FG_HIP(ctx, hipSetDevice(ctx->device));
-    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 8);
-    {
-        LaunchScope ls(ctx, "gather_i64_kernel");
-        hipLaunchKernelGGL(gather_i64_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src, rows, n, out);
-    }
-    return check_launch(ctx, "gather_i64_kernel");
+    return gather_i64(ctx, src, rows, n, out);
 }
 
 int flockgpu_take_utf8(flockgpu_ctx *ctx, const flockgpu_utf8 *src, const int32_t *rows, int64_t n, int32_t slot,

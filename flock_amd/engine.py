@@ -239,6 +239,27 @@ class Q4Out:
 
 
 @dataclass
+class Q13Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q13Result
+    n_windows: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.win_out_offsets, (self.n_windows + 1,)).copy()
+
+    def to_host(self):
+        n, d = self.rows, self.ctx.d2h
+        return {"auction": d(self.raw.auction, n, np.int32), "bidder": d(self.raw.bidder, n, np.int32),
+                "price": d(self.raw.price, n, np.int32), "b_date_time": d(self.raw.b_date_time, n, np.int64),
+                "value": d(self.raw.value, n, np.int32), "bid_row": d(self.raw.bid_row, n, np.int32),
+                "side_row": d(self.raw.side_row, n, np.int32), "offsets": self.offsets()}
+
+
+@dataclass
 class Q8Out:
     ctx: "GpuContext"
     raw: _ffi.Q8Result
@@ -370,6 +391,13 @@ class GpuContext:
         self._check(self._lib.flockgpu_q4_avg_final_by_category(self._h, C.byref(a), C.byref(aw), C.byref(b), C.byref(bw),
                                                                 C.byref(r)))
         return Q4Out(self, r, auction_windows.n_windows)
+
+    def q13_side_join(self, bids: Bids, windows: WindowSchedule, side_key, side_value) -> Q13Out:
+        """q13 (q13.sql): bid JOIN side_input ON auction = key; side_key / side_value are int32 device tensors."""
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q13Result()
+        self._check(self._lib.flockgpu_q13_side_join(self._h, C.byref(b), C.byref(w), side_key.data_ptr(), side_value.data_ptr(),
+                                                     side_key.numel(), C.byref(r)))
+        return Q13Out(self, r, windows.n_windows)
 
     def q8_join(self, persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
                 auction_windows: WindowSchedule) -> Q8Out:

@@ -176,7 +176,19 @@ class NEXMarkSource:
         return NEXMarkStream(self, bids, auctions, persons)
 
 
-def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window: Optional[Window] = None):
+def synthetic_side_input(ctx: GpuContext, stream: NEXMarkStream, stride: int = 6007):
+    """A bounded q13 side input for a generated stream: key = every `stride`-th auction id the stream's bids can name,
+    value = a function of the key.  (The reference reads the table from a user-supplied CSV in S3,
+    benchmarks/src/nexmark/main.rs:44,353-361; its content is not part of the repository.)"""
+    import torch
+    n_auctions = stream.source.counts(0, stream.source.seconds * stream.source.eps)[1]
+    first = 1000 + (stream.source.counts(0, 0)[1] if stream.source.first_event_id == 0 else 0)
+    key = torch.arange(first - first % stride + stride, first + n_auctions + stride, stride, dtype=torch.int32,
+                       device=f"cuda:{ctx.device}")
+    return key, key * 7 + 1
+
+
+def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window: Optional[Window] = None, side_input=None):
     """Executes every window of the query's schedule (the per-invocation batch loop of
     flock-function: window launcher + `actor::collect`) and returns the engine's result object."""
     window = window or query_window(query_number)
@@ -192,6 +204,10 @@ def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window:
     if query_number in (4, 9):
         fn = ctx.q4_avg_final_by_category if query_number == 4 else ctx.q9_winning_bids
         return fn(stream.auctions, stream.window_schedule("auction", window), stream.bids, stream.window_schedule("bid", window))
+    if query_number == 13:
+        if side_input is None:
+            side_input = stream.__dict__.setdefault("_side_input", synthetic_side_input(ctx, stream))
+        return ctx.q13_side_join(stream.bids, stream.window_schedule("bid", window), *side_input)
     if query_number == 7:
         return ctx.q7_highest_bid(stream.bids, stream.window_schedule("bid", window))
     if query_number == 8:

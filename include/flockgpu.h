@@ -208,6 +208,22 @@ int flockgpu_q4_avg_final_by_category(flockgpu_ctx *ctx, const flockgpu_auction_
                                       const flockgpu_windows *auction_win, const flockgpu_bid_cols *bid,
                                       const flockgpu_windows *bid_win, flockgpu_q4_result *out);
 
+/* ---- q13 (SURVEY.md section 8(f) "next" query): bid JOIN side_input ON auction = key ->
+ * [auction, bidder, price, b_date_time, value] (benchmarks/src/nexmark/query/q13.sql, q13_plan.fmt; side_input schema
+ * flock/src/datasource/nexmark/event.rs:375-388), per ElementWise window.  The side input (device pointers, any keys,
+ * duplicates allowed) is the same for every window.  Rows are ordered by bid row; bid_row / side_row name the joined
+ * input rows. */
+typedef struct {
+    const int32_t *auction, *bidder, *price; /* device */
+    const int64_t *b_date_time;              /* device */
+    const int32_t *value;                    /* device */
+    const int32_t *bid_row, *side_row;       /* device */
+    const int64_t *win_out_offsets;          /* host, n_windows + 1 */
+    int64_t rows;
+} flockgpu_q13_result;
+int flockgpu_q13_side_join(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                           const int32_t *side_key, const int32_t *side_value, int64_t side_rows, flockgpu_q13_result *out);
+
 /* ---- q8: DISTINCT (p_id, name) JOIN DISTINCT seller ON p_id = seller -> [p_id, name]
  * (q8.sql, q8_plan.fmt:1-10, q8.dag).  Output grouped by window, ordered by person row. */
 typedef struct {

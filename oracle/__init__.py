@@ -233,6 +233,20 @@ def q7_highest_bid(price: np.ndarray) -> np.ndarray:
     return np.nonzero(price == price.max())[0].astype(np.int64)
 
 
+def q13_side_join(b_auction, side_key):
+    """(bid_row, side_row) pairs of  bid JOIN side_input ON auction = key  for one window, ordered by bid row
+    (benchmarks/src/nexmark/query/q13.sql); duplicate keys on the side input produce one pair each."""
+    side_key = np.asarray(side_key, np.int64)
+    b_auction = np.asarray(b_auction, np.int64)
+    order = np.argsort(side_key, kind="stable")
+    keys = side_key[order]
+    lo, hi = np.searchsorted(keys, b_auction, "left"), np.searchsorted(keys, b_auction, "right")
+    n = hi - lo
+    bid_row = np.repeat(np.arange(len(b_auction)), n)
+    pos = np.arange(int(n.sum())) - np.repeat(np.cumsum(n) - n, n) + np.repeat(lo, n)
+    return bid_row.astype(np.int64), order[pos].astype(np.int64)
+
+
 def _auction_bid_pairs(a_id, a_date_time, expires, b_auction, b_date_time):
     """(auction_row, bid_row) pairs of  auction INNER JOIN bid ON a_id = auction  WHERE b_date_time BETWEEN a_date_time AND
     expires  (q4.sql / q9.sql inner query; any number of duplicate keys on either side)."""

@@ -354,6 +354,38 @@ def test_q4_q9_edge_cases(ctx):
     assert e.value.code == _ffi.ERR_UNSUPPORTED
 
 
+# ------------------------------------------------------------------ q13 ("next" query: bounded side-input join)
+@pytest.mark.parametrize("n_side,dups", [(0, False), (1, False), (5000, True), (8191, False), (20_000, True)])
+def test_q13_side_input_join(ctx, n_side, dups):
+    """Side tables that fit the LDS copy (<= 16384 slots) and ones that do not; duplicate keys; keys no bid has."""
+    from flock_amd import Window
+    seed, eps, seconds = 31, 200_000, 3
+    g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise())
+    _, b, _, _ = _host_stream(seed, eps, seconds)
+    rng = np.random.default_rng(n_side + 1)
+    lo_k, hi_k = int(b["auction"].min()) - 50, int(b["auction"].max()) + 50
+    key = rng.integers(lo_k, hi_k, n_side).astype(np.int32) if dups else \
+        rng.choice(np.arange(lo_k, hi_k, dtype=np.int64), n_side, replace=False).astype(np.int32)
+    value = rng.integers(-2**31, 2**31 - 1, n_side).astype(np.int32)
+    side_k = _dev(key) if n_side else _dev(np.zeros(4, np.int32))[:0]
+    side_v = _dev(value) if n_side else _dev(np.zeros(4, np.int32))[:0]
+    sched = g.window_schedule("bid")
+    out = ctx.q13_side_join(g.bids, sched, side_k, side_v).to_host()
+    off, total = out["offsets"], 0
+    for w in range(seconds):
+        lo, hi = sched.window_rows(w)
+        br, sr = oracle.q13_side_join(b["auction"][lo:hi], key)
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip((out["bid_row"][sl] - lo).tolist(), out["side_row"][sl].tolist())) == sorted(zip(br.tolist(), sr.tolist())), w
+        assert (np.diff(out["bid_row"][sl].astype(np.int64)) >= 0).all()              # bid order is kept
+        rows = out["bid_row"][sl]
+        for k in ("auction", "bidder", "price", "b_date_time"):
+            assert np.array_equal(out[k][sl], b[k][rows]), (w, k)
+        assert np.array_equal(out["value"][sl], value[out["side_row"][sl]])
+        total += len(br)
+    assert total == len(out["value"]) and (total > 0 or n_side <= 1)
+
+
 # ------------------------------------------------------------------ q8
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 10)])
 def test_q8_tumbling_windows(ctx, seed, eps, seconds):
