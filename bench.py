@@ -278,6 +278,40 @@ def cpu_baseline(q, stream, threads):
             "cpu_seconds": round(dt * min(threads, n_win), 1), "host_cores_available": os.cpu_count()}
 
 
+# ------------------------------------------------------------------ Yahoo Streaming Benchmark
+def ysb_side(ctx, eps, steps, no_cpu, threads, seconds=50):
+    """ysb.sql over 5e7 ad events (50 s x 1e6 events/s, Tumbling(10 s)); 100 campaigns x 10 ads as in the reference's
+    generator defaults.  (36-byte ad ids: 5.96e7 events are the most one Arrow Utf8 column with int32 offsets can hold.)"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from flock_amd.ysb import YSBSource, run_ysb
+    g = YSBSource(seconds, eps, seed=20260925).generate_data(ctx)
+    dt, stats, res = run_steps(ctx, lambda: run_ysb(ctx, g), steps, 1, lambda: None)
+    st = stats.get("ysb_count_kernel")
+    alg = float(g.event_type.offsets[-1].item()) + 4.0 * g.rows + 40.0 * g.rows   # event_type bytes + offsets, ad_id bytes + offsets
+    avg_ms = st["total_ms"] / st["launches"]
+    out = {"value": round(g.rows * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(g.rows),
+           "windows": res.n_windows, "result_rows": int(res.rows), "seconds_of_events": seconds,
+           "roofline": {"bound": "hbm", "kernel": "ysb_count_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg), "launches": st["launches"],
+                        "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}}
+    if not no_cpu:
+        import oracle
+        threads = threads or min(32, os.cpu_count() or 1)
+        n = 200_000                                       # events per CPU task (row-at-a-time Python restatement)
+        c_ad, camp = oracle.ysb_campaigns(20260925, 100, 10)
+        tasks = [oracle.ysb_events(20260925, i * n, n, 1000) for i in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(lambda t: oracle.ysb_campaign_counts(t[0], t[1], c_ad, camp), tasks))
+        d = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n * threads / d, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+                               "sample": f"{threads} x {n} events, Python dict restatement (GIL-bound: effectively one core)",
+                               "seconds": round(d, 2)}
+    return out
+
+
 # ------------------------------------------------------------------ PCIe-inclusive side measurement
 def pcie_inclusive_q5(ctx, eps, seconds=100):
     """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query.  PCIe-bound;
@@ -407,6 +441,10 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # a side measurement must never hide the headline
                 also[label] = {"error": repr(e)}
+        try:
+            also["ysb_next"] = ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)
+        except Exception as e:
+            also["ysb_next"] = {"error": repr(e)}
         try:
             also["q5_pcie_inclusive"] = pcie_inclusive_q5(ctx, args.eps)
         except Exception as e:

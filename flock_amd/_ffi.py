@@ -104,6 +104,19 @@ class PartitionResult(C.Structure):
     _fields_ = [("row", C.c_void_p), ("part_win_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
 
 
+class YsbEventCols(C.Structure):
+    _fields_ = [("ad_id", Utf8), ("event_type", Utf8), ("rows", C.c_int64)]
+
+
+class YsbCampaignCols(C.Structure):
+    _fields_ = [("c_ad_id", Utf8), ("campaign_id", Utf8), ("rows", C.c_int64)]
+
+
+class YsbResult(C.Structure):
+    _fields_ = [("campaign_id", Utf8), ("count", C.c_void_p), ("win_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64),
+                ("campaign_bytes", C.c_int64)]
+
+
 class NexmarkStream(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_event_id", C.c_uint64), ("eps", C.c_uint64), ("base_time", C.c_uint64)]
 
@@ -140,6 +153,10 @@ SYMBOLS = {
     "flockgpu_take_i64": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "flockgpu_take_utf8": (_i, [_vp, C.POINTER(Utf8), _vp, _i64, C.c_int32, C.POINTER(Utf8), C.POINTER(_i64)]),
     "flockgpu_inclusive_scan_i32": (_i, [_vp, _vp, _i64]),
+    "flockgpu_ysb_campaign_counts": (_i, [_vp, C.POINTER(YsbEventCols), C.POINTER(Windows), C.POINTER(YsbCampaignCols), C.c_char_p,
+                                          C.POINTER(YsbResult)]),
+    "flockgpu_ysb_gen_campaigns": (_i, [_vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "flockgpu_ysb_gen_events": (_i, [_vp, _u64, _u64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "flockgpu_nexmark_counts": (_i, [C.POINTER(NexmarkStream), _u64, _u64, C.POINTER(_u64), C.POINTER(_u64),
                                      C.POINTER(_u64)]),
     "flockgpu_nexmark_gen_bids": (_i, [_vp, C.POINTER(NexmarkStream), _u64, _u64, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,345 @@
+// Yahoo Streaming Benchmark for gfx950, per Tumbling(10 s) window
+// (benchmarks/src/ysb/main.rs:91):
+//   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = 'view'
+//   GROUP BY campaign_id                      (benchmarks/src/ysb/ysb.sql; stages flock/src/distributed_plan/planner.rs:298-346)
+// A Utf8-KEYED join and group-by: both keys are 36-byte UUID strings (flock/src/datasource/ysb/event.rs:24-87).
+//
+// HBM-bound byte work, no MFMA.  The campaign table is small and static; the stream is the ad events:
+//   dict   : DISTINCT campaign_id over the campaign rows (slot claim by string hash + full string compare): every campaign
+//            row learns its group = the row that claimed its campaign_id
+//   build  : multimap keyed c_ad_id (string hash -> slot {hash, head row}, chain through next[]), full compare on probe
+//   count  : one lane per ad event: `event_type = 'view'` (length + bytes), hash of ad_id, probe, compare the 36 bytes,
+//            group of the matching campaign row -> LDS histogram over the campaign rows, flushed per tile with one
+//            atomic per touched group.  Strings are read through aligned 4-byte words, all loads of a value
+//            requested together (clamped indices), 40 bytes on the fast path.
+//   output : groups with a non-zero count per window, `take` of their campaign_id.
+#include <algorithm>
+
+#include "gather.hpp"
+
+using namespace flockgpu;
+
+namespace {
+
+constexpr int kWords = 10;            // fast path: values of up to 40 bytes
+constexpr uint32_t kEmptySlot = ~0u;
+constexpr int kEvItems = 8;
+constexpr int kEvTile = kBlock * kEvItems;  // 2048 events per workgroup; event  it*256 + tid  belongs to thread tid
+constexpr int kHistGroups = 8192;           // campaign rows whose counts an LDS histogram can hold
+
+// A Utf8 value as little-endian 32-bit words w[0 .. ceil(len/4)) (bytes past the end zeroed); len <= 4*kWords.
+struct StrWords {
+    uint32_t w[kWords];
+    uint32_t len;
+};
+
+// `safe_end`: bytes of the column buffer that may be read (its length rounded up to a whole dword).  A value that lies at
+// least 48 bytes before it is fetched with THREE 16-byte loads (dword-aligned vector loads) instead of eleven dword loads:
+// one lane per row means every load instruction of a wave touches ~18 cache lines, so the instruction count is what the
+// texture path pays for.  Values at the very end of the buffer take clamped dword loads (never past their last word).
+__device__ __forceinline__ StrWords load_str(const uint8_t *__restrict__ data, int32_t b, uint32_t len, int64_t safe_end) {
+    StrWords s;
+    s.len = len;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(data) + (uint32_t)b;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3));
+    const uint32_t sh = (uint32_t)(addr & 3) * 8;
+    uint32_t a[kWords + 2];
+    if ((int64_t)((uint32_t)b & ~3u) + 48 <= safe_end) {
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(p), v1 = *reinterpret_cast<const uint4 *>(p + 4),
+                    v2 = *reinterpret_cast<const uint4 *>(p + 8);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        a[8] = v2.x; a[9] = v2.y; a[10] = v2.z; a[11] = v2.w;
+    } else {
+        const uint32_t last = len ? (uint32_t)(((addr & 3) + len - 1) >> 2) : 0u;
+#pragma unroll
+        for (int i = 0; i <= kWords; ++i) a[i] = p[min((uint32_t)i, last)];
+    }
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) {
+        uint32_t v = __funnelshift_r(a[i], a[i + 1], sh);
+        const uint32_t have = len > 4u * i ? len - 4u * i : 0u;  // bytes of this word inside the value
+        v = have >= 4 ? v : (have ? (v & ((1u << (8 * have)) - 1)) : 0u);
+        s.w[i] = v;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uint32_t hash_words(const StrWords &s) {
+    uint32_t h = 0x811C9DC5u ^ s.len;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) {
+        h = (h ^ s.w[i]) * 0x9E3779B1u;
+        h = (h << 13) | (h >> 19);
+    }
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ bool same_words(const StrWords &a, const StrWords &b) {
+    bool eq = a.len == b.len;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) eq = eq && a.w[i] == b.w[i];
+    return eq;
+}
+
+__device__ __forceinline__ StrWords row_str(const flockgpu_utf8 &c, int64_t row, int64_t safe_end) {
+    const int32_t b = c.offsets[row];
+    return load_str(c.data, b, (uint32_t)(c.offsets[row + 1] - b), safe_end);
+}
+
+__device__ __forceinline__ uint32_t slot_for(uint32_t h, uint32_t cap) { return (uint32_t)(((uint64_t)h * cap) >> 32); }
+
+// rep[r] = the campaign row that claimed r's campaign_id (DISTINCT campaign_id).
+__global__ __launch_bounds__(kBlock) void ysb_dict_kernel(flockgpu_utf8 campaign_id, int32_t n, uint32_t *table, uint32_t cap,
+                                                          int32_t *__restrict__ rep, uint32_t *err) {
+    const int32_t r = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (r >= n) return;
+    const int64_t safe_end = ((int64_t)campaign_id.offsets[n] + 3) & ~int64_t(3);
+    const StrWords me = row_str(campaign_id, r, safe_end);
+    if (me.len > 4u * kWords) {  // only the first 40 bytes are compared: longer values are not supported
+        atomicOr(err, 2u);
+        rep[r] = r;
+        return;
+    }
+    uint32_t s = slot_for(hash_words(me), cap);
+    for (uint32_t probe = 0; probe < cap; ++probe) {
+        uint32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptySlot) {
+            uint32_t expected = kEmptySlot;
+            if (__hip_atomic_compare_exchange_strong(&table[s], &expected, (uint32_t)r, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                rep[r] = r;
+                return;
+            }
+            cur = expected;
+        }
+        if (same_words(me, row_str(campaign_id, (int32_t)cur, safe_end))) {
+            rep[r] = (int32_t)cur;
+            return;
+        }
+        s = (s + 1 == cap) ? 0 : s + 1;
+    }
+    atomicOr(err, 1u);
+}
+
+// Multimap keyed c_ad_id: slot = head row of the chain of rows with this string; next[] links the duplicates.
+__global__ __launch_bounds__(kBlock) void ysb_build_kernel(flockgpu_utf8 c_ad_id, int32_t n, uint32_t *table, uint32_t cap,
+                                                           int32_t *next, uint32_t *err) {
+    const int32_t r = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (r >= n) return;
+    const int64_t safe_end = ((int64_t)c_ad_id.offsets[n] + 3) & ~int64_t(3);
+    const StrWords me = row_str(c_ad_id, r, safe_end);
+    if (me.len > 4u * kWords) {
+        atomicOr(err, 2u);
+        next[r] = -1;
+        return;
+    }
+    uint32_t s = slot_for(hash_words(me), cap);
+    for (uint32_t probe = 0; probe < cap; ++probe) {
+        uint32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptySlot) {
+            next[r] = -1;
+            uint32_t expected = kEmptySlot;
+            if (__hip_atomic_compare_exchange_strong(&table[s], &expected, (uint32_t)r, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                return;
+            cur = expected;
+        }
+        // the slot is owned by a row: same string -> become the new head of its chain, else keep probing.  The owner's
+        // string never changes (only rows with an EQUAL string replace it), so comparing with the current head is enough.
+        if (same_words(me, row_str(c_ad_id, (int32_t)cur, safe_end))) {
+            for (;;) {
+                next[r] = (int32_t)cur;
+                uint32_t expected = cur;
+                if (__hip_atomic_compare_exchange_strong(&table[s], &expected, (uint32_t)r, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT))
+                    return;
+                cur = expected;
+            }
+        }
+        s = (s + 1 == cap) ? 0 : s + 1;
+    }
+    atomicOr(err, 1u);
+}
+
+struct EvLit {  // the literal of `event_type = lit`, up to 40 bytes
+    uint32_t w[kWords];
+    uint32_t len;
+};
+
+// counts[seg * n_camp + group] += matches.  kLdsHist: the block pre-aggregates in LDS (n_camp <= kHistGroups).
+template <bool kLdsHist>
+__global__ __launch_bounds__(kBlock) void ysb_count_kernel(flockgpu_utf8 ad_id, flockgpu_utf8 event_type, SegTiles st, EvLit lit,
+                                                           flockgpu_utf8 c_ad_id, const uint32_t *__restrict__ table, uint32_t cap,
+                                                           const int32_t *__restrict__ next, const int32_t *__restrict__ rep,
+                                                           int32_t n_camp, int64_t n_events, unsigned long long *counts,
+                                                           uint32_t *err) {
+    extern __shared__ uint32_t s_hist[];
+    const int64_t end_et = ((int64_t)event_type.offsets[n_events] + 3) & ~int64_t(3);
+    const int64_t end_ad = ((int64_t)ad_id.offsets[n_events] + 3) & ~int64_t(3);
+    const int64_t end_c = ((int64_t)c_ad_id.offsets[n_camp] + 3) & ~int64_t(3);
+    if (kLdsHist) {
+        for (int s = threadIdx.x; s < n_camp; s += kBlock) s_hist[s] = 0;
+        __syncthreads();
+    }
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kEvTile);
+    unsigned long long *wc = counts + (size_t)tr.seg * n_camp;
+#pragma unroll 1
+    for (int it = 0; it < kEvItems; ++it) {
+        const int64_t r = tr.tile_begin + it * kBlock + threadIdx.x;
+        if (r < tr.lo || r >= tr.hi) continue;
+        const int32_t eb = event_type.offsets[r];
+        const uint32_t elen = (uint32_t)(event_type.offsets[r + 1] - eb);
+        if (elen != lit.len) continue;
+        if (elen > 4u * kWords) { atomicOr(err, 2u); continue; }
+        const StrWords ev = load_str(event_type.data, eb, elen, end_et);
+        bool is = true;
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) is = is && ev.w[i] == lit.w[i];
+        if (!is) continue;
+        const int32_t ab = ad_id.offsets[r];
+        const uint32_t alen = (uint32_t)(ad_id.offsets[r + 1] - ab);
+        if (alen > 4u * kWords) { atomicOr(err, 2u); continue; }
+        const StrWords key = load_str(ad_id.data, ab, alen, end_ad);
+        uint32_t s = slot_for(hash_words(key), cap);
+        for (uint32_t probe = 0; probe < cap; ++probe) {
+            const uint32_t cur = table[s];
+            if (cur == kEmptySlot) break;
+            if (same_words(key, row_str(c_ad_id, (int32_t)cur, end_c))) {
+                for (int32_t c = (int32_t)cur; c >= 0; c = next[c]) {  // one output row per matching campaign row
+                    const int32_t g = rep[c];
+                    if (kLdsHist) atomicAdd(&s_hist[g], 1u);
+                    else atomicAdd(&wc[g], 1ull);
+                }
+                break;
+            }
+            s = (s + 1 == cap) ? 0 : s + 1;
+        }
+    }
+    if (!kLdsHist) return;
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_camp; s += kBlock) {
+        const uint32_t c = s_hist[s];
+        if (c) atomicAdd(&wc[s], (unsigned long long)c);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int flockgpu_ysb_campaign_counts(flockgpu_ctx *ctx, const flockgpu_ysb_event_cols *events, const flockgpu_windows *win,
+                                 const flockgpu_ysb_campaign_cols *campaigns, const char *event_type_lit,
+                                 flockgpu_ysb_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!events || !campaigns || !out || !event_type_lit || events->rows < 0 || campaigns->rows < 0)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "ysb: null argument");
+    FG_TRY(check_windows(ctx, win, events->rows, "ysb"));
+    if (events->rows > 0 && (!events->ad_id.offsets || !events->ad_id.data || !events->event_type.offsets || !events->event_type.data))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "ysb: null event column");
+    if (campaigns->rows > 0 && (!campaigns->c_ad_id.offsets || !campaigns->c_ad_id.data || !campaigns->campaign_id.offsets ||
+                                !campaigns->campaign_id.data))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "ysb: null campaign column");
+    if (campaigns->rows >= (int64_t(1) << 30) || events->rows >= (int64_t(1) << 31))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "ysb: relations are limited to 2^31 / 2^30 rows per call");
+    EvLit lit{};
+    lit.len = (uint32_t)std::strlen(event_type_lit);
+    if (lit.len > 4u * kWords) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "ysb: literal longer than %d bytes", 4 * kWords);
+    for (uint32_t i = 0; i < lit.len; ++i) lit.w[i / 4] |= (uint32_t)(uint8_t)event_type_lit[i] << (8 * (i % 4));
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_win = win->n_windows;
+    const int32_t n_camp = (int32_t)campaigns->rows;
+    std::vector<int64_t> sb(n_win), se(n_win);
+    for (int w = 0; w < n_win; ++w) {
+        sb[w] = win->pane_row_offsets[win->win_pane_lo[w]];
+        se[w] = win->pane_row_offsets[win->win_pane_hi[w]];
+    }
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, "ysb", sb.data(), se.data(), n_win, kEvTile, &st));
+
+    const uint32_t cap = (uint32_t)std::max<int64_t>(64, (int64_t)n_camp * 2 + 1);
+    uint32_t *dict = nullptr, *table = nullptr, *d_err = nullptr;
+    int32_t *rep = nullptr, *next = nullptr;
+    FG_TRY(arena_get_t(ctx, "ysb.dict", (size_t)cap, &dict));
+    FG_TRY(arena_get_t(ctx, "ysb.table", (size_t)cap, &table));
+    FG_TRY(arena_get_t(ctx, "ysb.rep", (size_t)n_camp + 1, &rep));
+    FG_TRY(arena_get_t(ctx, "ysb.next", (size_t)n_camp + 1, &next));
+    FG_TRY(arena_get_t(ctx, "ysb.err", 4, &d_err));
+    const size_t n_counts = (size_t)std::max(n_win, 1) * std::max(n_camp, 1);
+    unsigned long long *d_counts = nullptr, *h_counts = nullptr;
+    FG_TRY(arena_get_t(ctx, "ysb.counts", n_counts, &d_counts));
+    FG_TRY(pinned_get_t(ctx, "ysb.counts", n_counts + 1, &h_counts));
+    FG_HIP(ctx, hipMemsetAsync(dict, 0xFF, sizeof(uint32_t) * cap, ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(table, 0xFF, sizeof(uint32_t) * cap, ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * n_counts, ctx->stream));
+    if (n_camp > 0) {
+        const unsigned gb = (unsigned)div_up(n_camp, kBlock);
+        {
+            LaunchScope ls(ctx, "ysb_dict_kernel");
+            hipLaunchKernelGGL(ysb_dict_kernel, dim3(gb), dim3(kBlock), 0, ctx->stream, campaigns->campaign_id, n_camp, dict, cap, rep,
+                               d_err);
+        }
+        FG_TRY(check_launch(ctx, "ysb_dict_kernel"));
+        {
+            LaunchScope ls(ctx, "ysb_build_kernel");
+            hipLaunchKernelGGL(ysb_build_kernel, dim3(gb), dim3(kBlock), 0, ctx->stream, campaigns->c_ad_id, n_camp, table, cap, next,
+                               d_err);
+        }
+        FG_TRY(check_launch(ctx, "ysb_build_kernel"));
+    }
+    if (st.n_tiles > 0 && n_camp > 0) {
+        LaunchScope ls(ctx, "ysb_count_kernel");
+        if (n_camp <= kHistGroups)
+            hipLaunchKernelGGL(ysb_count_kernel<true>, dim3((unsigned)st.n_tiles), dim3(kBlock), sizeof(uint32_t) * n_camp, ctx->stream,
+                               events->ad_id, events->event_type, st, lit, campaigns->c_ad_id, table, cap, next, rep, n_camp, events->rows,
+                               d_counts, d_err);
+        else
+            hipLaunchKernelGGL(ysb_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, events->ad_id,
+                               events->event_type, st, lit, campaigns->c_ad_id, table, cap, next, rep, n_camp, events->rows, d_counts, d_err);
+    }
+    FG_TRY(check_launch(ctx, "ysb_count_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(unsigned long long) * n_counts, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_counts + n_counts, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t h_err = *reinterpret_cast<uint32_t *>(h_counts + n_counts);
+    if (h_err & 2u) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "ysb: a key or event_type value is longer than %d bytes", 4 * kWords);
+    if (h_err & 1u) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "ysb: campaign table overflow");
+
+    // groups with a non-zero count, window by window, in order of their representative campaign row
+    std::vector<int64_t> &offs = ctx->host_i64["ysb.win_out_offsets"];
+    offs.assign((size_t)n_win + 1, 0);
+    std::vector<int32_t> rows;
+    std::vector<uint64_t> cnts;
+    for (int w = 0; w < n_win; ++w) {
+        for (int32_t g = 0; g < n_camp; ++g) {
+            const unsigned long long c = h_counts[(size_t)w * n_camp + g];
+            if (c) {
+                rows.push_back(g);
+                cnts.push_back(c);
+            }
+        }
+        offs[w + 1] = (int64_t)rows.size();
+    }
+    const size_t n_out = rows.size();
+    int32_t *d_rows = nullptr, *h_rows = nullptr;
+    uint64_t *d_cnt = nullptr, *h_cnt = nullptr;
+    FG_TRY(arena_get_t(ctx, "ysb.out_rows", n_out + 1, &d_rows));
+    FG_TRY(pinned_get_t(ctx, "ysb.out_rows", n_out + 1, &h_rows));
+    FG_TRY(arena_get_t(ctx, "ysb.out_count", n_out + 1, &d_cnt));
+    FG_TRY(pinned_get_t(ctx, "ysb.out_count", n_out + 1, &h_cnt));
+    std::copy(rows.begin(), rows.end(), h_rows);
+    std::copy(cnts.begin(), cnts.end(), h_cnt);
+    if (n_out) {
+        FG_HIP(ctx, hipMemcpyAsync(d_rows, h_rows, sizeof(int32_t) * n_out, hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(d_cnt, h_cnt, sizeof(uint64_t) * n_out, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FG_TRY(gather_utf8(ctx, "ysb.out_campaign", campaigns->campaign_id, d_rows, (int64_t)n_out, &out->campaign_id, &out->campaign_bytes));
+    out->count = d_cnt;
+    out->win_out_offsets = offs.data();
+    out->rows = (int64_t)n_out;
+    return FLOCKGPU_OK;
+}
+
+}  // extern "C"

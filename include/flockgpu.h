@@ -265,6 +265,38 @@ int flockgpu_take_utf8(flockgpu_ctx *ctx, const flockgpu_utf8 *src, const int32_
 /* In-place inclusive prefix sum (rebuilds Arrow Utf8 offsets from received value lengths). */
 int flockgpu_inclusive_scan_i32(flockgpu_ctx *ctx, int32_t *data /* device */, int64_t n);
 
+/* ---- Yahoo Streaming Benchmark: per Tumbling(10 s) window (benchmarks/src/ysb/main.rs:91)
+ *   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = lit
+ *   GROUP BY campaign_id         (benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346)
+ * Columns are the projections of AdEvent / Campaign the query scans (flock/src/datasource/ysb/event.rs:24-87), Arrow Utf8.
+ * Keys and the literal may be up to 40 bytes (UUIDs are 36); longer values -> FLOCKGPU_ERR_UNSUPPORTED.  Output rows:
+ * (campaign_id Utf8, COUNT UInt64) of every campaign with at least one matching event, grouped by window. */
+typedef struct {
+    flockgpu_utf8 ad_id, event_type;
+    int64_t rows;
+} flockgpu_ysb_event_cols;
+typedef struct {
+    flockgpu_utf8 c_ad_id, campaign_id;
+    int64_t rows;
+} flockgpu_ysb_campaign_cols;
+typedef struct {
+    flockgpu_utf8 campaign_id;      /* device */
+    const uint64_t *count;          /* device */
+    const int64_t *win_out_offsets; /* host, n_windows + 1 */
+    int64_t rows;
+    int64_t campaign_bytes;
+} flockgpu_ysb_result;
+int flockgpu_ysb_campaign_counts(flockgpu_ctx *ctx, const flockgpu_ysb_event_cols *events, const flockgpu_windows *win,
+                                 const flockgpu_ysb_campaign_cols *campaigns, const char *event_type_lit,
+                                 flockgpu_ysb_result *out);
+/* Device-side YSB source (flock/src/datasource/ysb/generator.rs:38-101 restated; every value is a pure function of
+ * (seed, index): ysb_gen.hip).  Offsets arrays have rows + 1 entries; ad-id / campaign-id byte buffers hold 36 bytes per
+ * row, the event_type buffer up to 8 bytes per event. */
+int flockgpu_ysb_gen_campaigns(flockgpu_ctx *ctx, uint64_t seed, int64_t n_campaigns, int64_t ads, int32_t *c_ad_id_off,
+                               uint8_t *c_ad_id_bytes, int32_t *campaign_off, uint8_t *campaign_bytes);
+int flockgpu_ysb_gen_events(flockgpu_ctx *ctx, uint64_t seed, uint64_t first_event, int64_t n_events, int64_t n_ads,
+                            int32_t *ad_id_off, uint8_t *ad_id_bytes, int32_t *event_type_off, uint8_t *event_type_bytes);
+
 /* ---- device-side NEXMark source (flock/src/datasource/nexmark/{event,config,generator}.rs restated,
  * deviations D1-D4 documented in DESIGN.md).  Generates the columns the five plans scan for event
  * numbers [n0, n1) of a stream straight into HBM; any output pointer may be NULL to skip it. */

@@ -339,3 +339,82 @@ def hopping_windows(seconds, size, hop):
             break
         out.append((t, t + size))
     return out
+
+
+# ---------------------------------------------------------------- Yahoo Streaming Benchmark (SURVEY.md section 8 f, rank 4)
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(x):
+    x = np.asarray(x, np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _ysb_uuid(seed: int, tag: int, idx) -> np.ndarray:
+    """36-byte version-4 UUID strings uuid(tag, i) of flock_amd/csrc/ysb_gen.hip, one row of bytes per index."""
+    idx = np.asarray(idx, np.uint64)
+    with np.errstate(over="ignore"):
+        hi = _mix64(_mix64(np.uint64(seed) ^ (np.uint64(tag) * np.uint64(0xA24BAED4963EE407))) + (idx + np.uint64(1)) * np.uint64(0x9FB21C651E98DF25))
+        lo = _mix64(hi ^ np.uint64(0xC2B2AE3D27D4EB4F))
+    hi = (hi & ~np.uint64(0xF000)) | np.uint64(0x4000)
+    lo = (lo & ~(np.uint64(3) << np.uint64(62))) | (np.uint64(2) << np.uint64(62))
+    out = np.empty((len(idx), 36), np.uint8)
+    hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+    o = 0
+    for nib in range(32):
+        if nib in (8, 12, 16, 20):
+            out[:, o] = ord("-")
+            o += 1
+        v = hi if nib < 16 else lo
+        out[:, o] = hexd[((v >> np.uint64(60 - 4 * (nib & 15))) & np.uint64(15)).astype(np.int64)]
+        o += 1
+    return out
+
+
+def _ysb_draw(seed: int, n, k: int):
+    with np.errstate(over="ignore"):
+        return _mix64(_mix64(np.uint64(seed) ^ (np.asarray(n, np.uint64) * np.uint64(0xD6E8FEB86659FD93))) + np.uint64((k + 1) * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF))
+
+
+def _ysb_uni(r, n: int):
+    return ((r >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)
+
+
+def ysb_campaigns(seed: int, n_campaigns: int, ads: int):
+    """(c_ad_id, campaign_id) Utf8 columns of the campaign table (generator.rs:46-56 restated, see ysb_gen.hip)."""
+    rows = n_campaigns * ads
+    i = np.arange(rows, dtype=np.uint64)
+    off = (np.arange(rows + 1) * 36).astype(np.int32)
+    return Utf8(off, _ysb_uuid(seed, 1, i).reshape(-1)), Utf8(off.copy(), _ysb_uuid(seed, 2, i // np.uint64(ads)).reshape(-1))
+
+
+def ysb_events(seed: int, first: int, n: int, n_ads: int):
+    """(ad_id, event_type) Utf8 columns of ad events [first, first + n) (generator.rs:76-96 restated)."""
+    idx = np.arange(first, first + n, dtype=np.uint64)
+    ad = _ysb_uuid(seed, 1, _ysb_uni(_ysb_draw(seed, idx, 0), n_ads))
+    kinds = [b"view", b"click", b"purchase"]
+    t = _ysb_uni(_ysb_draw(seed, idx, 1), 3).astype(np.int64)
+    lens = np.array([4, 5, 8])[t]
+    et_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    et = np.frombuffer(b"".join(kinds[k] for k in t.tolist()), np.uint8).copy() if n else np.zeros(0, np.uint8)
+    return Utf8((np.arange(n + 1) * 36).astype(np.int32), ad.reshape(-1)), Utf8(et_off, et)
+
+
+def ysb_campaign_counts(ad_id: Utf8, event_type: Utf8, c_ad_id: Utf8, campaign_id: Utf8, lit: bytes = b"view"):
+    """{campaign_id bytes: COUNT(*)} of ysb.sql for one window (benchmarks/src/ysb/ysb.sql): filter event_type = lit,
+    inner join ad_id = c_ad_id (every matching campaign row counts), group by campaign_id."""
+    def rows(u):
+        b = u.data.tobytes()
+        return [b[u.offsets[i]:u.offsets[i + 1]] for i in range(len(u))]
+    by_ad = {}
+    for a, c in zip(rows(c_ad_id), rows(campaign_id)):
+        by_ad.setdefault(a, []).append(c)
+    out = {}
+    for a, t in zip(rows(ad_id), rows(event_type)):
+        if t == lit:
+            for c in by_ad.get(a, ()):
+                out[c] = out.get(c, 0) + 1
+    return out

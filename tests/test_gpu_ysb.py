@@ -1,0 +1,90 @@
+"""Yahoo Streaming Benchmark on the GPU vs the CPU restatement: the device generator
+regenerates the oracle's bytes, and the Utf8-keyed join + group-by is exact -- per window, as {campaign_id: count}."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _utf8(u):
+    from flock_amd import DeviceUtf8
+    data = u.data if len(u.data) >= 16 else np.concatenate([u.data, np.zeros(16 - len(u.data), np.uint8)])
+    return DeviceUtf8(_dev(u.offsets), _dev(data))
+
+
+def _col(strings):
+    off = np.concatenate(([0], np.cumsum([len(s) for s in strings]))).astype(np.int32)
+    return oracle.Utf8(off, np.frombuffer(b"".join(strings) or b"\0", np.uint8).copy()[: int(off[-1])] if off[-1] else np.zeros(0, np.uint8))
+
+
+def _result_dicts(out):
+    off, data = out["campaign_id"]
+    b = data.tobytes()
+    names = [b[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    wo = out["offsets"]
+    return [dict(zip(names[wo[w]:wo[w + 1]], out["count"][wo[w]:wo[w + 1]].tolist())) for w in range(len(wo) - 1)]
+
+
+@pytest.mark.parametrize("seed,eps,seconds,campaigns,ads", [(1, 1000, 30, 100, 10), (9, 20_000, 20, 7, 3), (4, 200_000, 10, 1000, 10)])
+def test_ysb_generator_and_query(ctx, seed, eps, seconds, campaigns, ads):
+    from flock_amd.ysb import YSBSource, run_ysb
+    g = YSBSource(seconds, eps, campaigns=campaigns, ads=ads, seed=seed).generate_data(ctx)
+    c_ad, camp = oracle.ysb_campaigns(seed, campaigns, ads)
+    ad, et = oracle.ysb_events(seed, 0, seconds * eps, campaigns * ads)
+    for dev, host in ((g.c_ad_id, c_ad), (g.campaign_id, camp), (g.ad_id, ad), (g.event_type, et)):   # generator: device == oracle
+        assert np.array_equal(dev.offsets.cpu().numpy(), host.offsets)
+        assert np.array_equal(dev.data.cpu().numpy()[: len(host.data)], host.data)
+    got = _result_dicts(run_ysb(ctx, g).to_host())
+    assert len(got) == seconds // 10
+    for w in range(seconds // 10):
+        lo, hi = w * 10 * eps, (w + 1) * 10 * eps
+        want = oracle.ysb_campaign_counts(ad.slice(lo, hi), et.slice(lo, hi), c_ad, camp)
+        assert got[w] == want and len(want) > 0, w
+
+
+def test_ysb_duplicates_unknown_ads_and_odd_strings(ctx):
+    """Duplicate c_ad_id rows (every match counts), one campaign_id shared by far-apart rows, ads no campaign has, empty and
+    maximum-length (40-byte) keys, an event_type that only shares a prefix with the literal, ragged / empty windows; and
+    the unsupported case (a 41-byte key)."""
+    from flock_amd import FlockGpuError, WindowSchedule, _ffi
+    from flock_amd.ysb import campaign_counts
+    rng = np.random.default_rng(3)
+    keys = [b"", b"k", b"x" * 40, b"ad-0001", b"ad-0002", b"ad-0002", b"AD-0002", b"y" * 39 + b"a", b"y" * 39 + b"b"]
+    camps = [b"c-empty", b"c1", b"c-long", b"c1", b"c2", b"c3", b"c2", b"", b"c1"]
+    c_ad, camp = _col(keys), _col(camps)
+    pool = keys + [b"nobody", b"x" * 39, b"ad-0003"]
+    n = 30_000
+    ev_keys = [pool[i] for i in rng.integers(0, len(pool), n)]
+    ev_types = [[b"view", b"click", b"purchase", b"vie", b"views", b""][i] for i in rng.integers(0, 6, n)]
+    ad, et = _col(ev_keys), _col(ev_types)
+    offs = np.array([0, 5, 5, 12_345, n])
+    sched = WindowSchedule(offs, np.arange(4), np.arange(1, 5))
+    got = _result_dicts(campaign_counts(ctx, _utf8(ad), _utf8(et), n, sched, _utf8(c_ad), _utf8(camp), len(keys)).to_host())
+    for w in range(4):
+        want = oracle.ysb_campaign_counts(ad.slice(offs[w], offs[w + 1]), et.slice(offs[w], offs[w + 1]), c_ad, camp)
+        assert got[w] == want, w
+    assert got[1] == {} and sum(got[3].values()) > 1000 and b"" in got[3]
+    for lit in ("click", "", "purchase"):
+        got = _result_dicts(campaign_counts(ctx, _utf8(ad), _utf8(et), n, sched, _utf8(c_ad), _utf8(camp), len(keys), lit).to_host())
+        assert got[3] == oracle.ysb_campaign_counts(ad.slice(offs[3], n), et.slice(offs[3], n), c_ad, camp, lit.encode())
+    with pytest.raises(FlockGpuError) as e:
+        campaign_counts(ctx, _utf8(ad), _utf8(et), n, sched, _utf8(_col([b"z" * 41])), _utf8(_col([b"c"])), 1)
+    assert e.value.code == _ffi.ERR_UNSUPPORTED
+    empty = campaign_counts(ctx, _utf8(ad), _utf8(et), 0, WindowSchedule(np.array([0, 0]), np.array([0]), np.array([1])), _utf8(c_ad),
+                            _utf8(camp), len(keys))
+    assert empty.rows == 0 and empty.offsets().tolist() == [0, 0]
