@@ -8,10 +8,11 @@
 //   dict   : DISTINCT campaign_id over the campaign rows (slot claim by string hash + full string compare): every campaign
 //            row learns its group = the row that claimed its campaign_id
 //   build  : multimap keyed c_ad_id (string hash -> slot {hash, head row}, chain through next[]), full compare on probe
-//   count  : one lane per ad event: `event_type = 'view'` (length + bytes), hash of ad_id, probe, compare the 36 bytes,
-//            group of the matching campaign row -> LDS histogram over the campaign rows, flushed per tile with one
-//            atomic per touched group.  Strings are read through aligned 4-byte words, all loads of a value
-//            requested together (clamped indices), 40 bytes on the fast path.
+//   pack   : the multimap re-laid as 64-byte slots {key bytes, head row, its group, its chain link}: one read per probe
+//   count  : per 2048-event tile, (1) `event_type = 'view'` for eight rows per lane, (2) the rows that passed compacted
+//            in LDS and probed two per lane: hash of ad_id, slot read, compare the 36 bytes -> LDS histogram over the
+//            campaign rows, flushed per tile with one atomic per touched group.  Strings are read through dword-aligned
+//            16-byte loads, all loads of a value requested together, 40 bytes on the fast path.
 //   output : groups with a non-zero count per window, `take` of their campaign_id.
 #include <algorithm>
 
@@ -168,53 +169,157 @@ struct EvLit {  // the literal of `event_type = lit`, up to 40 bytes
     uint32_t len;
 };
 
+// One probe = one 64-byte read: the key of the slot's chain, its head row, that row's group and its chain link all sit
+// in the slot, so the event side never chases  table -> offsets -> bytes -> next -> rep  (five dependent loads).
+struct __align__(16) KeySlot {
+    uint32_t w[kWords];
+    uint32_t len;
+    int32_t head;   // head campaign row of the chain with this c_ad_id, -1 = empty slot
+    int32_t group;  // rep[head]
+    int32_t link;   // next[head]
+    uint32_t pad[2];
+};
+static_assert(sizeof(KeySlot) == 64, "one slot per 64 bytes");
+
+__global__ __launch_bounds__(kBlock) void ysb_pack_kernel(flockgpu_utf8 c_ad_id, int32_t n, const uint32_t *__restrict__ table,
+                                                          uint32_t cap, const int32_t *__restrict__ next,
+                                                          const int32_t *__restrict__ rep, KeySlot *__restrict__ slots) {
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= cap) return;
+    KeySlot k{};
+    k.head = -1;
+    const uint32_t cur = table[s];
+    if (cur != kEmptySlot) {
+        const int64_t safe_end = ((int64_t)c_ad_id.offsets[n] + 3) & ~int64_t(3);
+        const StrWords me = row_str(c_ad_id, (int32_t)cur, safe_end);
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) k.w[i] = me.w[i];
+        k.len = me.len;
+        k.head = (int32_t)cur;
+        k.group = rep[cur];
+        k.link = next[cur];
+    }
+    slots[s] = k;
+}
+
+// `event_type = lit` for one row: the first 12 bytes of the value through ONE 16-byte load (the YSB literals are 4-8 bytes;
+// adjacent rows share cache lines), longer literals through the general word loader.
+template <bool kShortLit>
+__device__ __forceinline__ bool event_is(const flockgpu_utf8 &event_type, int64_t row, const EvLit &lit, int64_t safe_end) {
+    const int32_t eb = event_type.offsets[row];
+    const uint32_t elen = (uint32_t)(event_type.offsets[row + 1] - eb);
+    if (kShortLit) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(event_type.data) + (uint32_t)eb;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3));
+        const uint32_t sh = (uint32_t)(addr & 3) * 8;
+        uint32_t a[4];
+        if ((int64_t)((uint32_t)eb & ~3u) + 16 <= safe_end) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p);
+            a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+        } else {
+            const uint32_t last = elen ? (uint32_t)(((addr & 3) + elen - 1) >> 2) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = p[min((uint32_t)i, last)];
+        }
+        bool is = elen == lit.len;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint32_t v = __funnelshift_r(a[i], a[i + 1], sh);
+            const uint32_t have = elen > 4u * i ? elen - 4u * i : 0u;
+            v = have >= 4 ? v : (have ? (v & ((1u << (8 * have)) - 1)) : 0u);
+            is = is && v == lit.w[i];
+        }
+        return is;
+    } else {
+        if (elen != lit.len) return false;  // lit.len <= 40, so the loader never sees a longer value
+        const StrWords ev = load_str(event_type.data, eb, elen, safe_end);
+        bool is = true;
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) is = is && ev.w[i] == lit.w[i];
+        return is;
+    }
+}
+
 // counts[seg * n_camp + group] += matches.  kLdsHist: the block pre-aggregates in LDS (n_camp <= kHistGroups).
-template <bool kLdsHist>
+// Two phases per 2048-event tile, so that neither runs under the other's divergence:
+//   1. the filter, eight rows per lane, all loads independent of each other (clamped rows, no load under a branch);
+//   2. the rows that passed, compacted into an LDS list, taken two per lane at a time: ad_id bytes (three 16-byte loads),
+//      hash, one 64-byte slot read per probe, LDS histogram.
+template <bool kLdsHist, bool kShortLit>
 __global__ __launch_bounds__(kBlock) void ysb_count_kernel(flockgpu_utf8 ad_id, flockgpu_utf8 event_type, SegTiles st, EvLit lit,
-                                                           flockgpu_utf8 c_ad_id, const uint32_t *__restrict__ table, uint32_t cap,
+                                                           const KeySlot *__restrict__ slots, uint32_t cap,
                                                            const int32_t *__restrict__ next, const int32_t *__restrict__ rep,
                                                            int32_t n_camp, int64_t n_events, unsigned long long *counts,
                                                            uint32_t *err) {
     extern __shared__ uint32_t s_hist[];
+    __shared__ uint16_t s_list[kEvTile];
+    __shared__ uint32_t s_wave_total[kWavesPerBlock];
     const int64_t end_et = ((int64_t)event_type.offsets[n_events] + 3) & ~int64_t(3);
     const int64_t end_ad = ((int64_t)ad_id.offsets[n_events] + 3) & ~int64_t(3);
-    const int64_t end_c = ((int64_t)c_ad_id.offsets[n_camp] + 3) & ~int64_t(3);
-    if (kLdsHist) {
+    if (kLdsHist)
         for (int s = threadIdx.x; s < n_camp; s += kBlock) s_hist[s] = 0;
-        __syncthreads();
-    }
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kEvTile);
     unsigned long long *wc = counts + (size_t)tr.seg * n_camp;
-#pragma unroll 1
+
+    uint32_t mask = 0;
+#pragma unroll
     for (int it = 0; it < kEvItems; ++it) {
         const int64_t r = tr.tile_begin + it * kBlock + threadIdx.x;
-        if (r < tr.lo || r >= tr.hi) continue;
-        const int32_t eb = event_type.offsets[r];
-        const uint32_t elen = (uint32_t)(event_type.offsets[r + 1] - eb);
-        if (elen != lit.len) continue;
-        if (elen > 4u * kWords) { atomicOr(err, 2u); continue; }
-        const StrWords ev = load_str(event_type.data, eb, elen, end_et);
-        bool is = true;
+        const bool in = r >= tr.lo && r < tr.hi;
+        const bool is = event_is<kShortLit>(event_type, in ? r : tr.lo, lit, end_et);
+        mask |= (uint32_t)(in && is) << it;
+    }
+    const uint32_t cnt = (uint32_t)__popc(mask);
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) s_wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - cnt, n_pass = 0;
 #pragma unroll
-        for (int i = 0; i < kWords; ++i) is = is && ev.w[i] == lit.w[i];
-        if (!is) continue;
-        const int32_t ab = ad_id.offsets[r];
-        const uint32_t alen = (uint32_t)(ad_id.offsets[r + 1] - ab);
-        if (alen > 4u * kWords) { atomicOr(err, 2u); continue; }
-        const StrWords key = load_str(ad_id.data, ab, alen, end_ad);
-        uint32_t s = slot_for(hash_words(key), cap);
-        for (uint32_t probe = 0; probe < cap; ++probe) {
-            const uint32_t cur = table[s];
-            if (cur == kEmptySlot) break;
-            if (same_words(key, row_str(c_ad_id, (int32_t)cur, end_c))) {
-                for (int32_t c = (int32_t)cur; c >= 0; c = next[c]) {  // one output row per matching campaign row
-                    const int32_t g = rep[c];
-                    if (kLdsHist) atomicAdd(&s_hist[g], 1u);
-                    else atomicAdd(&wc[g], 1ull);
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        const uint32_t t = s_wave_total[w];
+        base += w < wave ? t : 0u;
+        n_pass += t;
+    }
+    for (uint32_t m = mask; m; m &= m - 1) s_list[base++] = (uint16_t)((__ffs(m) - 1) * kBlock + threadIdx.x);
+    __syncthreads();
+
+    constexpr int kPair = 2;
+    for (uint32_t i0 = 0; i0 < n_pass; i0 += kPair * kBlock) {
+        StrWords key[kPair];
+        bool live[kPair];
+#pragma unroll
+        for (int u = 0; u < kPair; ++u) {
+            const uint32_t i = i0 + u * kBlock + threadIdx.x;
+            live[u] = i < n_pass;
+            const int64_t r = tr.tile_begin + s_list[live[u] ? i : 0u];
+            const int32_t ab = ad_id.offsets[r];
+            key[u] = load_str(ad_id.data, ab, (uint32_t)(ad_id.offsets[r + 1] - ab), end_ad);
+        }
+#pragma unroll
+        for (int u = 0; u < kPair; ++u) {
+            if (!live[u]) continue;
+            if (key[u].len > 4u * kWords) { atomicOr(err, 2u); continue; }
+            uint32_t s = slot_for(hash_words(key[u]), cap);
+            for (uint32_t probe = 0; probe < cap; ++probe) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(slots + s);
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                if ((int32_t)q2.w < 0) break;  // head: empty slot
+                const uint32_t *k = key[u].w;
+                const bool eq = q0.x == k[0] && q0.y == k[1] && q0.z == k[2] && q0.w == k[3] && q1.x == k[4] && q1.y == k[5] &&
+                                q1.z == k[6] && q1.w == k[7] && q2.x == k[8] && q2.y == k[9] && q2.z == key[u].len;
+                if (eq) {
+                    int32_t g = (int32_t)q3.x;
+                    for (int32_t c = (int32_t)q3.y;; c = next[c]) {  // one output row per matching campaign row
+                        if (kLdsHist) atomicAdd(&s_hist[g], 1u);
+                        else atomicAdd(&wc[g], 1ull);
+                        if (c < 0) break;
+                        g = rep[c];
+                    }
+                    break;
                 }
-                break;
+                s = (s + 1 == cap) ? 0 : s + 1;
             }
-            s = (s + 1 == cap) ? 0 : s + 1;
         }
     }
     if (!kLdsHist) return;
@@ -290,14 +395,21 @@ int flockgpu_ysb_campaign_counts(flockgpu_ctx *ctx, const flockgpu_ysb_event_col
         FG_TRY(check_launch(ctx, "ysb_build_kernel"));
     }
     if (st.n_tiles > 0 && n_camp > 0) {
+        KeySlot *slots = nullptr;
+        FG_TRY(arena_get_t(ctx, "ysb.slots", (size_t)cap, &slots));
+        {
+            LaunchScope ls(ctx, "ysb_pack_kernel");
+            hipLaunchKernelGGL(ysb_pack_kernel, dim3((unsigned)div_up((int64_t)cap, kBlock)), dim3(kBlock), 0, ctx->stream,
+                               campaigns->c_ad_id, n_camp, table, cap, next, rep, slots);
+        }
+        FG_TRY(check_launch(ctx, "ysb_pack_kernel"));
         LaunchScope ls(ctx, "ysb_count_kernel");
-        if (n_camp <= kHistGroups)
-            hipLaunchKernelGGL(ysb_count_kernel<true>, dim3((unsigned)st.n_tiles), dim3(kBlock), sizeof(uint32_t) * n_camp, ctx->stream,
-                               events->ad_id, events->event_type, st, lit, campaigns->c_ad_id, table, cap, next, rep, n_camp, events->rows,
-                               d_counts, d_err);
-        else
-            hipLaunchKernelGGL(ysb_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, events->ad_id,
-                               events->event_type, st, lit, campaigns->c_ad_id, table, cap, next, rep, n_camp, events->rows, d_counts, d_err);
+        const bool lds = n_camp <= kHistGroups, short_lit = lit.len <= 12;
+        const size_t shmem = lds ? sizeof(uint32_t) * n_camp : 0;
+        auto kernel = lds ? (short_lit ? ysb_count_kernel<true, true> : ysb_count_kernel<true, false>)
+                          : (short_lit ? ysb_count_kernel<false, true> : ysb_count_kernel<false, false>);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), shmem, ctx->stream, events->ad_id, events->event_type, st,
+                           lit, slots, cap, next, rep, n_camp, events->rows, d_counts, d_err);
     }
     FG_TRY(check_launch(ctx, "ysb_count_kernel"));
     FG_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(unsigned long long) * n_counts, hipMemcpyDeviceToHost, ctx->stream));

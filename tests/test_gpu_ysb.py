@@ -88,3 +88,27 @@ def test_ysb_duplicates_unknown_ads_and_odd_strings(ctx):
     empty = campaign_counts(ctx, _utf8(ad), _utf8(et), 0, WindowSchedule(np.array([0, 0]), np.array([0]), np.array([1])), _utf8(c_ad),
                             _utf8(camp), len(keys))
     assert empty.rows == 0 and empty.offsets().tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("n_camp_rows", [50, 9000])
+def test_ysb_long_literals_and_wide_campaign_tables(ctx, n_camp_rows):
+    """Literals beyond the 12-byte single-load filter (13, 20 and 40 bytes, and values that differ from them only in the
+    last byte), with the campaign table both inside and beyond what the LDS histogram holds (8192 rows)."""
+    from flock_amd import WindowSchedule
+    from flock_amd.ysb import campaign_counts
+    rng = np.random.default_rng(n_camp_rows)
+    keys = [b"ad-%06d" % i for i in range(n_camp_rows)]
+    camps = [b"campaign-%04d" % (i % 997) for i in range(n_camp_rows)]
+    c_ad, camp = _col(keys), _col(camps)
+    types = [b"impression-13", b"impression-14", b"impression-served-ok", b"impression-served-no", b"t" * 40, b"t" * 39 + b"u", b"view"]
+    n = 40_000
+    ad = _col([keys[i] if i < n_camp_rows else b"ad-unknown" for i in rng.integers(0, n_camp_rows + n_camp_rows // 4 + 1, n)])
+    et = _col([types[i] for i in rng.integers(0, len(types), n)])
+    offs = np.array([0, 17_001, n])
+    sched = WindowSchedule(offs, np.arange(2), np.arange(1, 3))
+    for lit in (types[0], types[2], types[4], b"view"):
+        got = _result_dicts(campaign_counts(ctx, _utf8(ad), _utf8(et), n, sched, _utf8(c_ad), _utf8(camp), n_camp_rows,
+                                            lit.decode()).to_host())
+        for w in range(2):
+            want = oracle.ysb_campaign_counts(ad.slice(offs[w], offs[w + 1]), et.slice(offs[w], offs[w + 1]), c_ad, camp, lit)
+            assert got[w] == want and sum(want.values()) > 1000, (lit, w)
