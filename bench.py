@@ -312,6 +312,46 @@ def ysb_side(ctx, eps, steps, no_cpu, threads, seconds=50):
     return out
 
 
+# ------------------------------------------------------------------ q11, user sessions
+def q11_side(ctx, eps, steps, no_cpu, seconds=109):
+    """q11.sql under Window::Session(10 s) over 1e8 bids (109 s x 1e6 events/s): the session launcher's whole walk in one call."""
+    from flock_amd import NEXMarkSource
+    from flock_amd.nexmark import BASE_TIME, Window, run_query
+    w = Window.session(10)
+    g = NEXMarkSource(seconds, eps, w, seed=20260926).generate_data(ctx, relations=("bid",), bid_columns=("bidder", "b_date_time"))
+    dt, stats, res = run_steps(ctx, lambda: run_query(ctx, 11, g, w), steps, 1, lambda: None)
+    n = g.bids.rows
+    st = stats.get("sort_emit_kernel")
+    out = {"value": round(n * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(n),
+           "epochs": seconds, "result_rows": int(res.rows), "sessions_total": int(res.sessions_total)}
+    if st and st["launches"]:
+        # a radix pass reads key + row number and writes both (16 B / row; the first pass of the bid sort makes the row
+        # numbers itself: 12 B); launches = passes of the bid sort + passes of the (much smaller) session sort
+        avg_ms = st["total_ms"] / st["launches"]
+        per_step = st["launches"] // max(steps, 1)
+        passes = max(per_step - 1, 1)                     # the session sort is one pass for < 256 epochs
+        alg = (16.0 * passes - 4.0) * n + 16.0 * res.sessions_total
+        alg_per_launch = alg / per_step
+        out["roofline"] = {"bound": "hbm", "kernel": "sort_emit_kernel", "achieved": round(alg_per_launch / (avg_ms * 1e-3) / 1e9, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_per_launch),
+                           "launches": st["launches"],
+                           "kernels_ms_per_step": {k: round(v["total_ms"] / max(steps, 1), 4) for k, v in stats.items()}}
+    if not no_cpu:
+        import oracle
+        sample = min(seconds, 20)
+        off = g.epoch_row_offsets("bid")[: sample + 1]
+        bidder = g.bids.bidder[: off[-1]].cpu().numpy()
+        ts = g.bids.b_date_time[: off[-1]].cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.q11_user_sessions_columnar(bidder, ts, off, 10, BASE_TIME)
+        d = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(int(off[-1]) / d, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+                               "sample": f"first {sample} epochs = {int(off[-1])} bids, whole-column numpy restatement of the walk",
+                               "seconds": round(d, 2)}
+    return out
+
+
 # ------------------------------------------------------------------ PCIe-inclusive side measurement
 def pcie_inclusive_q5(ctx, eps, seconds=100):
     """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query.  PCIe-bound;
@@ -441,6 +481,10 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # a side measurement must never hide the headline
                 also[label] = {"error": repr(e)}
+        try:
+            also["q11_next"] = q11_side(ctx, args.eps, steps2, args.no_cpu)
+        except Exception as e:
+            also["q11_next"] = {"error": repr(e)}
         try:
             also["ysb_next"] = ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)
         except Exception as e:

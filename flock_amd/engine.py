@@ -200,6 +200,30 @@ class Q7Out:
 
 
 @dataclass
+class Q11Out:
+    ctx: "GpuContext"
+    raw: _ffi.Q11Result
+    n_epochs: int
+
+    @property
+    def rows(self):
+        return int(self.raw.rows)
+
+    @property
+    def sessions_total(self):
+        return int(self.raw.sessions_total)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.raw.epoch_out_offsets, (self.n_epochs + 1,)).copy()
+
+    def to_host(self):
+        n = self.rows
+        return {"bidder": self.ctx.d2h(self.raw.bidder, n, np.int32), "bid_count": self.ctx.d2h(self.raw.bid_count, n, np.uint64),
+                "start_time": self.ctx.d2h(self.raw.start_time, n, np.int64), "end_time": self.ctx.d2h(self.raw.end_time, n, np.int64),
+                "offsets": self.offsets()}
+
+
+@dataclass
 class Q9Out:
     ctx: "GpuContext"
     raw: _ffi.Q9Result
@@ -376,6 +400,22 @@ class GpuContext:
         b, w, r = bids.ffi(), windows.ffi(), _ffi.Q7Result()
         self._check(self._lib.flockgpu_q7_highest_bid(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q7Out(self, r, windows.n_windows)
+
+    def q11_user_sessions(self, bids: Bids, epoch_row_offsets, timeout_s: int, base_time_ms: int) -> Q11Out:
+        """q11 (q11.sql under Window::Session, flock-function/src/aws/window/session.rs): the bidder sessions closed in every
+        epoch of the run; epoch t = rows [epoch_row_offsets[t], epoch_row_offsets[t+1])."""
+        off = np.ascontiguousarray(epoch_row_offsets, dtype=np.int64)
+        b, r = bids.ffi(), _ffi.Q11Result()
+        self._check(self._lib.flockgpu_q11_user_sessions(self._h, C.byref(b), off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1,
+                                                         int(timeout_s), int(base_time_ms), C.byref(r)))
+        return Q11Out(self, r, len(off) - 1)
+
+    def group_rows_by_key(self, keys, n=None):
+        """Stable grouping of rows by an int32 device column: (sorted keys, row numbers) as host arrays' device views."""
+        n = int(keys.numel() if n is None else n)
+        k, v = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.flockgpu_group_rows_by_key(self._h, keys.data_ptr(), n, C.byref(k), C.byref(v)))
+        return self.d2h(k.value, n, np.int32), self.d2h(v.value, n, np.int32)
 
     def q9_winning_bids(self, auctions: Auctions, auction_windows: WindowSchedule, bids: Bids,
                         bid_windows: WindowSchedule) -> Q9Out:

@@ -45,6 +45,11 @@ class Window:
     def hopping(size: int, hop: int):
         return Window("hopping", size, hop)
 
+    @staticmethod
+    def session(timeout_seconds: int):
+        """stream/window.rs:137 `session_window`: size = the inactivity timeout."""
+        return Window("session", timeout_seconds, timeout_seconds)
+
 
 def query_window(query_number: int) -> Window:  # noqa: C901
     """benchmarks/src/nexmark/main.rs:115-123."""
@@ -54,7 +59,9 @@ def query_window(query_number: int) -> Window:  # noqa: C901
         return Window.hopping(10, 5)
     if query_number in (7, 8):
         return Window.tumbling(10)
-    raise NotImplementedError(f"window of q{query_number} (session / global) is outside the hot-path scope")
+    if query_number == 11:
+        return Window.session(10)
+    raise NotImplementedError(f"window of q{query_number} (global, processing time) is outside the hot-path scope")
 
 
 def window_epochs(window: Window, seconds: int):
@@ -210,6 +217,10 @@ def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window:
         return ctx.q13_side_join(stream.bids, stream.window_schedule("bid", window), *side_input)
     if query_number == 7:
         return ctx.q7_highest_bid(stream.bids, stream.window_schedule("bid", window))
+    if query_number == 11:   # the session launcher's whole walk over the epochs (window/session.rs:185-262)
+        if window.kind != "session":
+            raise ValueError("q11 runs under Window::Session")
+        return ctx.q11_user_sessions(stream.bids, stream.epoch_row_offsets("bid"), window.size, BASE_TIME)
     if query_number == 8:
         return ctx.q8_join(stream.persons, stream.window_schedule("person", window), stream.auctions,
                            stream.window_schedule("auction", window))

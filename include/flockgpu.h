@@ -265,6 +265,33 @@ int flockgpu_take_utf8(flockgpu_ctx *ctx, const flockgpu_utf8 *src, const int32_
 /* In-place inclusive prefix sum (rebuilds Arrow Utf8 offsets from received value lengths). */
 int flockgpu_inclusive_scan_i32(flockgpu_ctx *ctx, int32_t *data /* device */, int64_t n);
 
+/* ---- q11, user sessions: Window::Session(timeout) keyed by bidder
+ * (benchmarks/src/nexmark/main.rs:120,346-349), the launcher's session walk over a run of epochs
+ * (flock-function/src/aws/window/session.rs:64-178,205-262) and, per closed session,
+ *   SELECT bidder, COUNT(*) AS bid_count, MIN(b_date_time) AS start_time, MAX(b_date_time) AS end_time
+ *   FROM bid GROUP BY bidder                                        (benchmarks/src/nexmark/query/q11.sql)
+ * Epoch t = rows [epoch_row_offsets[t], epoch_row_offsets[t+1]) of `bid` (only bidder and b_date_time are read;
+ * b_date_time must be >= 0).  A bidder's bids of one epoch join its open session unless the first of them lies more
+ * than `timeout_s` whole seconds after the session's last bid; after every epoch t the sessions whose last bid is more
+ * than `timeout_s` whole seconds older than  base_time_ms/1000 + t  are closed.  Output: the sessions closed in epoch t
+ * are rows [epoch_out_offsets[t], epoch_out_offsets[t+1]), ordered by bidder; two sessions of one bidder closed in
+ * the same epoch are one row (the query groups by bidder); sessions still open after the last epoch are not reported. */
+typedef struct {
+    int32_t *bidder;                  /* device, ctx-owned */
+    uint64_t *bid_count;              /* COUNT(*) -> UInt64 */
+    int64_t *start_time, *end_time;   /* Timestamp(ms) */
+    const int64_t *epoch_out_offsets; /* host, n_epochs + 1 */
+    int64_t rows;
+    int64_t sessions_total;           /* every session found, reported or not */
+} flockgpu_q11_result;
+int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const int64_t *epoch_row_offsets /* host */,
+                               int32_t n_epochs, int32_t timeout_s, int64_t base_time_ms, flockgpu_q11_result *out);
+
+/* Rows grouped by key, arrival order kept inside a key -- the `repartition(.., HashDiff([key], distinct))` of the session
+ * and global windows (flock-function/src/aws/window/session.rs:242-250): out_keys[i] = keys[out_rows[i]], ascending,
+ * stable.  `keys` is a 16-byte aligned device column; the outputs are ctx-owned device arrays of `rows` entries. */
+int flockgpu_group_rows_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, int32_t **out_keys, int32_t **out_rows);
+
 /* ---- Yahoo Streaming Benchmark: per Tumbling(10 s) window (benchmarks/src/ysb/main.rs:91)
  *   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = lit
  *   GROUP BY campaign_id         (benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346)

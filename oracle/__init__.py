@@ -418,3 +418,89 @@ def ysb_campaign_counts(ad_id: Utf8, event_type: Utf8, c_ad_id: Utf8, campaign_i
             for c in by_ad.get(a, ()):
                 out[c] = out.get(c, 0) + 1
     return out
+
+
+# ---- q11: user sessions ---------------------------------------------------------------------------------------------
+def q11_user_sessions(bidder, b_date_time, epoch_row_offsets, timeout_s, base_time_ms):
+    """The session launcher's walk, literally (flock-function/src/aws/window/session.rs), then q11.sql over what every
+    epoch closes.  Returns one dict per epoch: {bidder: (bid_count, start_time, end_time)}.
+
+    :242-250  the epoch's bids are split into one partition per distinct bidder (arrival order kept)
+    :64-134   add_partitions_to_session_windows: a partition joins the bidder's open session unless the whole second of its
+              FIRST bid is more than `timeout` after the whole second of the session's LAST bid -- then the old session is
+              handed out and the partition starts a new one
+    :144-178  find_timeout_session_windows: afterwards every open session whose last bid's whole second is more than
+              `timeout` behind  BASE_TIME/1000 + epoch  is handed out
+    :263-310  the sessions handed out in one epoch go to the query together (coalesce_windows): q11.sql groups by bidder,
+              so two sessions of one bidder closed in the same epoch are one row
+    Sessions still open after the last epoch are never handed out.  Timestamps are >= 0 (Rust's `/` truncates)."""
+    bidder = np.asarray(bidder)
+    ts = np.asarray(b_date_time, dtype=np.int64)
+    off = np.asarray(epoch_row_offsets, dtype=np.int64)
+    windows = {}  # bidder -> list of partitions (row-number arrays)
+    out = []
+    for t in range(len(off) - 1):
+        lo, hi = int(off[t]), int(off[t + 1])
+        b = bidder[lo:hi]
+        order = np.argsort(b, kind="stable")
+        sb = b[order]
+        starts = np.flatnonzero(np.r_[True, sb[1:] != sb[:-1]]) if hi > lo else np.zeros(0, np.int64)
+        ends = np.r_[starts[1:], len(sb)] if hi > lo else starts
+        closed = []
+        for s0, e0 in zip(starts.tolist(), ends.tolist()):
+            rows = lo + order[s0:e0]
+            key = int(sb[s0])
+            if key in windows:
+                last_s = int(ts[windows[key][-1][-1]]) // 1000
+                if int(ts[rows[0]]) // 1000 - last_s > timeout_s:
+                    closed.append(windows.pop(key))
+            windows.setdefault(key, []).append(rows)
+        clock = base_time_ms // 1000 + t
+        for key in [k for k, parts in windows.items() if clock - int(ts[parts[-1][-1]]) // 1000 > timeout_s]:
+            closed.append(windows.pop(key))
+        res = {}
+        for parts in closed:
+            rows = np.concatenate(parts)
+            key, c, mn, mx = int(bidder[rows[0]]), len(rows), int(ts[rows].min()), int(ts[rows].max())
+            if key in res:
+                c0, mn0, mx0 = res[key]
+                c, mn, mx = c + c0, min(mn, mn0), max(mx, mx0)
+            res[key] = (c, mn, mx)
+        out.append(res)
+    return out
+
+
+def q11_user_sessions_columnar(bidder, b_date_time, epoch_row_offsets, timeout_s, base_time_ms):
+    """The same result through whole-column numpy passes (the CPU baseline of bench.py; checked against the literal walk
+    above in tests/test_oracle_q11.py): every decision of the walk only compares two neighbouring partitions of one bidder.
+    Returns (epoch_out_offsets, bidder, bid_count, start_time, end_time), rows of an epoch ordered by bidder."""
+    bidder = np.asarray(bidder)
+    ts = np.asarray(b_date_time, dtype=np.int64)
+    off = np.asarray(epoch_row_offsets, dtype=np.int64)
+    n_epochs, lo, hi = len(off) - 1, int(off[0]), int(off[-1])
+    n = hi - lo
+    empty = (np.zeros(n_epochs + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.int64))
+    if n == 0:
+        return empty
+    order = np.argsort(bidder[lo:hi], kind="stable")
+    k, t = bidder[lo:hi][order], ts[lo:hi][order]
+    ep = np.searchsorted(off - lo, order, side="right") - 1
+    sec = t // 1000
+    clock = np.maximum(ep, sec - base_time_ms // 1000 + timeout_s + 1)  # first epoch in which the time-out check fires
+    same = (k[:-1] == k[1:]) & ((ep[:-1] == ep[1:]) | ((clock[:-1] >= ep[1:]) & (sec[1:] - sec[:-1] <= timeout_s)))
+    starts = np.r_[0, np.flatnonzero(~same) + 1]
+    ends = np.r_[starts[1:], n]
+    last = ends - 1
+    nxt = np.minimum(ends, n - 1)
+    follows = (ends < n) & (k[nxt] == k[last])
+    close = np.where(follows, np.minimum(clock[last], ep[nxt]), np.where(clock[last] <= n_epochs - 1, clock[last], -1))
+    cnt = (ends - starts).astype(np.uint64)
+    mn, mx, who = np.minimum.reduceat(t, starts), np.maximum.reduceat(t, starts), k[starts]
+    absorbed = np.r_[False, (who[1:] == who[:-1]) & (close[1:] == close[:-1]) & (close[1:] >= 0)]
+    head = np.flatnonzero(~absorbed)
+    cnt, mn, mx = np.add.reduceat(cnt, head), np.minimum.reduceat(mn, head), np.maximum.reduceat(mx, head)
+    who, close = who[head], close[head]
+    keep = close >= 0
+    o = np.argsort(close[keep], kind="stable")
+    out_off = np.searchsorted(close[keep][o], np.arange(n_epochs + 1), side="left").astype(np.int64)
+    return out_off, who[keep][o].astype(np.int32), cnt[keep][o], mn[keep][o], mx[keep][o]
