@@ -22,7 +22,7 @@ with open(out, "w") as o:
         o.write('"%s",%d,%.3f\n' % (k, n, v / n))
 PY
 }
-for q in ${QUERIES:-5 2 8 3 7}; do
+for q in ${QUERIES:-5 2 8 3 7 9 13}; do
   extra=""; [ "$q" = "3" ] && extra="--seconds 1000"
   cmd="python bench.py --query $q $extra --steps 3 --warmup 1 --no-also --no-cpu"
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $cmd > "$OUT/q${q}_stats_run.log" 2>&1
