@@ -265,16 +265,6 @@ __global__ __launch_bounds__(kBlock) void q11_merge_kernel(const int32_t *__rest
     f_max[s] = (int64_t)mx;
 }
 
-// off[e] = first position of the epoch-sorted sessions whose key is >= e, e = 0 .. n_epochs
-__global__ __launch_bounds__(kBlock) void q11_epoch_offsets_kernel(const int32_t *__restrict__ sorted_key, int64_t n_sessions,
-                                                                   int32_t n_epochs, int64_t *__restrict__ off) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i > n_sessions) return;
-    const int32_t prev = i > 0 ? sorted_key[i - 1] : -1;
-    const int32_t cur = i < n_sessions ? sorted_key[i] : n_epochs;
-    for (int32_t e = prev + 1; e <= cur && e <= n_epochs; ++e) off[e] = i;
-}
-
 __global__ __launch_bounds__(kBlock) void q11_take_u64_kernel(const uint64_t *__restrict__ src, const int32_t *__restrict__ rows,
                                                               int64_t n, uint64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -399,12 +389,7 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q11.out_off", (size_t)n_epochs + 2, &d_off));
     FG_TRY(pinned_get_t(ctx, "q11.out_off", (size_t)n_epochs + 2, &h_off));
-    {
-        LaunchScope ls(ctx, "q11_epoch_offsets_kernel");
-        hipLaunchKernelGGL(q11_epoch_offsets_kernel, dim3((unsigned)div_up(n_sessions + 1, kBlock)), dim3(kBlock), 0, ctx->stream, ok,
-                           n_sessions, n_epochs, d_off);
-    }
-    FG_TRY(check_launch(ctx, "q11_epoch_offsets_kernel"));
+    FG_TRY(sorted_key_offsets(ctx, ok, n_sessions, n_epochs, d_off));
     FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_epochs + 1), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     offs.assign(h_off, h_off + n_epochs + 1);

@@ -21,7 +21,7 @@
 //   select : rows whose count equals the window maximum.
 #include <algorithm>
 
-#include "scan.hpp"
+#include "sort.hpp"
 
 using namespace flockgpu;
 
@@ -53,7 +53,8 @@ struct WinDesc {
     uint32_t pad;
 };
 
-__device__ __forceinline__ bool lds_hash_insert(uint64_t *tab, uint32_t key, uint32_t c) {
+// 0: no room within kLdsMaxProbe slots, 1: added to the key's slot, 2: claimed a new slot
+__device__ __forceinline__ int lds_hash_insert(uint64_t *tab, uint32_t key, uint32_t c) {
     uint32_t s = (key * kFib) >> (32 - kSlotBits);
     const uint64_t mine = ((uint64_t)key << 32) | c;
 #pragma unroll 1
@@ -61,15 +62,15 @@ __device__ __forceinline__ bool lds_hash_insert(uint64_t *tab, uint32_t key, uin
         uint64_t cur = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == 0) {
             cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[s]), 0ull, (unsigned long long)mine);
-            if (cur == 0) return true;
+            if (cur == 0) return 2;
         }
         if ((uint32_t)(cur >> 32) == key) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&tab[s]), (unsigned long long)c);
-            return true;
+            return 1;
         }
         s = (s + 1) & (kSlots - 1);
     }
-    return false;
+    return 0;
 }
 
 // Window hash table (packed {key:32,count:32}, 0 = empty; counts >= 1 so a live slot is never 0).
@@ -83,7 +84,9 @@ __device__ __forceinline__ void table_add(uint64_t *tab, uint32_t cap, uint32_t 
             uint64_t expected = 0;
             if (__hip_atomic_compare_exchange_strong(&tab[s], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
-                atomicAdd(used, 1u);
+                // `used` only says "this window has table entries": a counter here is one same-address atomic per new
+                // group (1e8 distinct keys: 150 ms of serialised atomics); a cached read + rare store is free
+                if (*used == 0) *used = 1u;
                 return;
             }
             cur = expected;
@@ -116,7 +119,7 @@ struct FlushArgs {
     uint32_t *counters;
     uint64_t *tables;
     uint32_t cap;
-    uint32_t *tab_used;        // per window: live slots of its hash table
+    uint32_t *tab_used;        // per window: non-zero once its hash table holds an entry
     uint32_t *err;
 };
 
@@ -288,6 +291,13 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
 }
 
 // ---- count: general kernel for the tiles the fast kernel declined ------------------------------------------------
+// num[i] = MAX of the window the i-th ordered winner belongs to
+__global__ __launch_bounds__(kBlock) void q5_winner_num_kernel(const int32_t *__restrict__ win, const uint64_t *__restrict__ win_max,
+                                                               int64_t n, uint64_t *__restrict__ num) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) num[i] = win_max[win[i]];
+}
+
 __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__restrict__ auction, SegTiles st,
                                                                const PaneDesc *__restrict__ panes,
                                                                const int32_t *__restrict__ pane_win_ptr,
@@ -295,11 +305,13 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
                                                                uint64_t *tables, uint32_t cap, uint32_t *tab_used,
                                                                uint32_t *err, const int32_t *__restrict__ slow_list) {
     __shared__ __attribute__((aligned(16))) uint64_t slots[kSlots];
+    __shared__ uint32_t s_fill;  // slots claimed so far (approximate while lanes race: only steers the bypass)
     const int lane = lane_id();
     const int32_t n = slow_list[0];
     for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
         __syncthreads();  // previous tile's flush is done with `slots`
         for (int s = threadIdx.x; s < kSlots; s += kBlock) slots[s] = 0;
+        if (threadIdx.x == 0) s_fill = 0;
         const TileRange tr = locate_tile(st, slow_list[1 + i], kQ5Tile);
         FlushArgs f;
         f.pane = panes[tr.seg];
@@ -312,6 +324,41 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
         f.tab_used = tab_used;
         f.err = err;
         __syncthreads();
+        if (f.pane.range) {
+            // Direct-address pane whose tile is ragged or spreads wider than the LDS histogram (keys in no particular
+            // order): one global atomic per row on the pane's counters; the lanes that share the first lane's key add once.
+            // An LDS hash in front only pays when a tile repeats keys, and it overflows first when it does not.
+            int32_t k[kQ5Iters][4];
+#pragma unroll
+            for (int it = 0; it < kQ5Iters; ++it) {
+                const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+                if (r0 >= tr.lo && r0 + 4 <= tr.hi) {
+                    const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+                    k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) k[it][j] = (r0 + j >= tr.lo && r0 + j < tr.hi) ? auction[r0 + j] : 0;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < kQ5Iters; ++it) {
+                const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool v = r0 + j >= tr.lo && r0 + j < tr.hi;
+                    const uint64_t live = __ballot(v);
+                    if (!live) continue;
+                    const int32_t hot = __builtin_amdgcn_readlane(k[it][j], __ffsll((unsigned long long)live) - 1);
+                    const uint64_t m = __ballot(v && k[it][j] == hot);
+                    if (v && k[it][j] == hot) {
+                        if (mbcnt(m) == 0) emit_pair(hot, (uint32_t)__popcll((unsigned long long)m), f);
+                    } else if (v) {
+                        emit_pair(k[it][j], 1u, f);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll 1
         for (int64_t r0 = tr.lo; r0 < tr.hi; r0 += kBlock) {
             const int64_t r = r0 + threadIdx.x;
@@ -324,10 +371,17 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
             const int32_t hot = __builtin_amdgcn_readlane(key, src);
             const bool m = v && key == hot;
             const uint32_t cnt = (uint32_t)__popcll((unsigned long long)__ballot(m));
+            // a tile of (nearly) distinct keys fills the LDS table after a quarter of its rows: from then on a probe
+            // sequence only finds foreign keys, so the rest of the tile goes straight to the window tables
+            const bool full = *(volatile uint32_t *)&s_fill >= (uint32_t)(kSlots * 3 / 4);
             if (lane == src) {
-                if (!lds_hash_insert(slots, (uint32_t)hot, cnt)) emit_pair(hot, cnt, f);
+                const int r = full ? 0 : lds_hash_insert(slots, (uint32_t)hot, cnt);
+                if (r == 0) emit_pair(hot, cnt, f);
+                else if (r == 2) atomicAdd(&s_fill, 1u);
             } else if (v && !m) {
-                if (!lds_hash_insert(slots, (uint32_t)key, 1u)) emit_pair(key, 1u, f);
+                const int r = full ? 0 : lds_hash_insert(slots, (uint32_t)key, 1u);
+                if (r == 0) emit_pair(key, 1u, f);
+                else if (r == 2) atomicAdd(&s_fill, 1u);
             }
         }
         __syncthreads();
@@ -389,9 +443,16 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (SELECT) {
-                if (c[j] == mx) {
-                    const uint32_t p = atomicAdd(cursor, 1u);
-                    if (p < out_cap) {
+                // one cursor bump per wave: when every group ties for the MAX each lane is a winner
+                const bool hit = c[j] == mx;
+                const uint64_t b = __ballot(hit);
+                if (b) {
+                    const int leader = __ffsll((unsigned long long)b) - 1;
+                    uint32_t base = 0;
+                    if (lane_id() == leader) base = atomicAdd(cursor, (uint32_t)__popcll((unsigned long long)b));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    const uint32_t p = base + mbcnt(b);
+                    if (hit && p < out_cap) {
                         out_win[p] = w;
                         out_key[p] = (int32_t)(k0 + j);
                     }
@@ -568,6 +629,7 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     uint32_t out_cap = 1u << 16;
     std::vector<int32_t> h_win, h_key;
     uint32_t n_sel = 0;
+    const int32_t *sel_win = nullptr, *sel_key = nullptr;  // set when the winners stay on the device
     for (int attempt = 0;; ++attempt) {
         if (attempt > 8 || cap64 >= (uint64_t(1) << 31))
             return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q5: hash table capacity %llu still overflows", (unsigned long long)cap64);
@@ -643,10 +705,9 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         if (n_sel <= kSpecWinners) {
             std::copy(h_swin, h_swin + n_sel, h_win.begin());
             std::copy(h_skey, h_skey + n_sel, h_key.begin());
-        } else {
-            FG_HIP(ctx, hipMemcpyAsync(h_win.data(), o_win, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
-            FG_HIP(ctx, hipMemcpyAsync(h_key.data(), o_key, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
-            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else {  // many ties: ordered on the device below
+            sel_win = o_win;
+            sel_key = o_key;
         }
         break;
     }
@@ -660,17 +721,57 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         }
         if (best < 1e30) ctx->q5_rows_per_group = best;
     }
-    // order the winners by (window, auction) and hand them back on the device
-    std::vector<uint32_t> order(n_sel);
-    for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return h_win[a] != h_win[b] ? h_win[a] < h_win[b] : h_key[a] < h_key[b];
-    });
     std::vector<int64_t> &offs = ctx->host_i64["q5.win_out_offsets"];
     std::vector<uint64_t> &wmax = ctx->host_u64["q5.win_max"], &wgrp = ctx->host_u64["q5.win_groups"];
     offs.assign((size_t)n_win + 1, 0);
     wmax.assign(h_meta, h_meta + n_win);
     wgrp.assign(h_meta + n_win, h_meta + 2 * n_win);
+    if (sel_key) {
+        // Every group of a window can tie for its MAX (equal counts): then the result is as large as the group set, and
+        // (window, auction) order comes from two stable radix sorts on the device -- by auction, then by window --
+        // instead of a host sort of millions of pairs.
+        int32_t *d_mm = nullptr, *h_mm = nullptr, *k1 = nullptr, *w_in = nullptr, *w2 = nullptr, *d_oa = nullptr;
+        uint32_t *v1 = nullptr, *v2 = nullptr;
+        uint64_t *d_on = nullptr;
+        int64_t *d_off = nullptr, *h_off = nullptr;
+        FG_TRY(arena_get_t(ctx, "q5.ord_minmax", 4, &d_mm));
+        FG_TRY(pinned_get_t(ctx, "q5.ord_minmax", 4, &h_mm));
+        FG_TRY(key_min_max(ctx, sel_key, n_sel, d_mm));
+        FG_HIP(ctx, hipMemcpyAsync(h_mm, d_mm, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int bits = 1, wbits = 1;
+        while (bits < 32 && (((uint64_t)((int64_t)h_mm[1] - (int64_t)h_mm[0])) >> bits)) ++bits;
+        while (wbits < 31 && ((uint32_t)n_win >> wbits)) ++wbits;
+        FG_TRY(radix_sort_pairs(ctx, "q5.ord_key", sel_key, nullptr, n_sel, h_mm[0], bits, &k1, &v1));
+        FG_TRY(arena_get_t(ctx, "q5.ord_win_in", (size_t)n_sel + 4, &w_in));
+        FG_TRY(gather_i32(ctx, sel_win, reinterpret_cast<const int32_t *>(v1), n_sel, w_in));
+        FG_TRY(radix_sort_pairs(ctx, "q5.ord_win", w_in, v1, n_sel, 0, wbits, &w2, &v2));
+        FG_TRY(arena_get_t(ctx, "q5.out_auction", (size_t)n_sel + 1, &d_oa));
+        FG_TRY(arena_get_t(ctx, "q5.out_num", (size_t)n_sel + 1, &d_on));
+        FG_TRY(arena_get_t(ctx, "q5.ord_off", (size_t)n_win + 2, &d_off));
+        FG_TRY(pinned_get_t(ctx, "q5.ord_off", (size_t)n_win + 2, &h_off));
+        FG_TRY(gather_i32(ctx, sel_key, reinterpret_cast<const int32_t *>(v2), n_sel, d_oa));
+        hipLaunchKernelGGL(q5_winner_num_kernel, dim3((unsigned)div_up((int64_t)n_sel, kBlock)), dim3(kBlock), 0, ctx->stream, w2,
+                           d_meta, (int64_t)n_sel, d_on);
+        FG_TRY(check_launch(ctx, "q5_winner_num_kernel"));
+        FG_TRY(sorted_key_offsets(ctx, w2, n_sel, n_win, d_off));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        offs.assign(h_off, h_off + n_win + 1);
+        out->auction = d_oa;
+        out->num = d_on;
+        out->win_out_offsets = offs.data();
+        out->win_max = wmax.data();
+        out->win_groups = wgrp.data();
+        out->rows = n_sel;
+        return FLOCKGPU_OK;
+    }
+    // few winners (the usual case): order them by (window, auction) on the host and hand them back on the device
+    std::vector<uint32_t> order(n_sel);
+    for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return h_win[a] != h_win[b] ? h_win[a] < h_win[b] : h_key[a] < h_key[b];
+    });
     int32_t *h_oa = nullptr;
     uint64_t *h_on = nullptr;
     FG_TRY(pinned_get_t(ctx, "q5.out_auction", (size_t)n_sel + 1, &h_oa));

@@ -182,6 +182,15 @@ __global__ __launch_bounds__(kBlock) void key_min_max_kernel(const int32_t *__re
     }
 }
 
+__global__ __launch_bounds__(kBlock) void sorted_key_offsets_kernel(const int32_t *__restrict__ sorted_key, int64_t n, int32_t n_keys,
+                                                                    int64_t *__restrict__ off) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i > n) return;
+    const int32_t prev = i > 0 ? sorted_key[i - 1] : -1;
+    const int32_t cur = i < n ? sorted_key[i] : n_keys;
+    for (int32_t k = prev + 1; k <= cur && k <= n_keys; ++k) off[k] = i;
+}
+
 __global__ void init_min_max_kernel(int32_t *minmax) {
     minmax[0] = 0x7fffffff;
     minmax[1] = (int32_t)0x80000000;
@@ -202,6 +211,15 @@ int key_min_max(flockgpu_ctx *ctx, const int32_t *keys, int64_t n, int32_t *d_mi
         hipLaunchKernelGGL(key_min_max_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, keys, n, d_minmax);
     }
     return check_launch(ctx, "key_min_max_kernel");
+}
+
+int sorted_key_offsets(flockgpu_ctx *ctx, const int32_t *sorted_key, int64_t n, int32_t n_keys, int64_t *d_off) {
+    {
+        LaunchScope ls(ctx, "sorted_key_offsets_kernel");
+        hipLaunchKernelGGL(sorted_key_offsets_kernel, dim3((unsigned)div_up(n + 1, kBlock)), dim3(kBlock), 0, ctx->stream, sorted_key, n,
+                           n_keys, d_off);
+    }
+    return check_launch(ctx, "sorted_key_offsets_kernel");
 }
 
 int radix_sort_pairs(flockgpu_ctx *ctx, const char *name, const int32_t *keys, const uint32_t *vals, int64_t n, int32_t bias,

@@ -14,4 +14,7 @@ int radix_sort_pairs(flockgpu_ctx *ctx, const char *name, const int32_t *keys, c
 // Minimum and maximum of keys[0 .. n) into d_minmax[0], d_minmax[1] (device, initialised by the call).
 int key_min_max(flockgpu_ctx *ctx, const int32_t *keys, int64_t n, int32_t *d_minmax);
 
+// d_off[k] = first position of the ascending `sorted_key` (values in [0, n_keys]) whose key is >= k, k = 0 .. n_keys.
+int sorted_key_offsets(flockgpu_ctx *ctx, const int32_t *sorted_key, int64_t n, int32_t n_keys, int64_t *d_off);
+
 }  // namespace flockgpu
