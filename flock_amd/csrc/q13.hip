@@ -83,8 +83,90 @@ __device__ __forceinline__ bool q13_maybe(const KeyBitmap &bm, int32_t key) {
     return in & ((bm.words[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);  // unconditional load from a clamped index
 }
 
-// COUNT pass: streams `auction` once (next tile's keys prefetched), tests the bitmap, probes the rows that may join and
-// leaves, per lane, one byte of "this row has pairs" flags and, per wave, the number of pairs.
+// COUNT pass: streams `auction` once (next tile's keys prefetched), tests the bitmap, probes the rows that
+// may join and leaves, per lane, one byte of "this row has pairs" flags and, per wave, the number of pairs.
+template <bool kLds>
+__device__ __forceinline__ void q13_probe_tile(const TileRange &tr, int32_t tile, const int32_t (&k)[2][4], const uint32_t *s_key,
+                                               const uint32_t *s_occ, const uint64_t *__restrict__ table, uint32_t cap,
+                                               const int32_t *__restrict__ next, const KeyBitmap &bm, uint32_t *__restrict__ counts,
+                                               uint8_t *__restrict__ flags8) {
+    constexpr int kWaveRows = kProbeTile / kProbeWaves;  // 512
+    constexpr int kIters = kWaveRows / 256;              // 2
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t wbase = tr.tile_begin + (int64_t)wave * kWaveRows + lane * 4;
+    // Bitmap test of the wave's 512 rows.  Bids arrive roughly in auction order, so the rows of a wave name a narrow
+    // id range: when it fits 64 bitmap words, lane l fetches word (first + l) ONCE and every row reads its word from
+    // the owning lane (ds_bpermute) -- eight texture-path loads per lane become one.  Wider ranges test row by row.
+    uint32_t maybe = 0;
+    if (bm.words) {
+        uint32_t imin = ~0u, imax = 0;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = wbase + it * 256 + j;
+                const uint32_t idx = (uint32_t)k[it][j] - (uint32_t)bm.base;
+                if (r >= tr.lo && r < tr.hi && idx < bm.n_bits) {
+                    imin = min(imin, idx);
+                    imax = max(imax, idx);
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            imin = min(imin, (uint32_t)__shfl_xor((int)imin, o, 64));
+            imax = max(imax, (uint32_t)__shfl_xor((int)imax, o, 64));
+        }
+        if (imin <= imax) {  // (wave-uniform) some row of the wave lies inside the bitmap's range
+            const uint32_t w0 = imin >> 5, w1 = imax >> 5;
+            if (w1 - w0 < 64u) {
+                const uint32_t word = bm.words[min(w0 + (uint32_t)lane, w1)];
+#pragma unroll
+                for (int it = 0; it < kIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t r = wbase + it * 256 + j;
+                        const uint32_t idx = (uint32_t)k[it][j] - (uint32_t)bm.base;
+                        const bool in = r >= tr.lo && r < tr.hi && idx < bm.n_bits;
+                        const uint32_t wv = (uint32_t)__shfl((int)word, in ? (int)((idx >> 5) - w0) : 0, 64);
+                        maybe |= (in ? (wv >> (idx & 31)) & 1u : 0u) << (it * 4 + j);
+                    }
+            } else {
+#pragma unroll
+                for (int it = 0; it < kIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t r = wbase + it * 256 + j;
+                        maybe |= (uint32_t)(r >= tr.lo && r < tr.hi && q13_maybe(bm, k[it][j])) << (it * 4 + j);
+                    }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = wbase + it * 256 + j;
+                maybe |= (uint32_t)(r >= tr.lo && r < tr.hi) << (it * 4 + j);
+            }
+    }
+    uint32_t mine = 0, bits = 0;
+#pragma unroll
+    for (int it = 0; it < kIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((maybe >> (it * 4 + j)) & 1u) {
+                const int32_t head = kLds ? find_lds(s_key, s_occ, table, cap, k[it][j]) : find_global(table, cap, k[it][j]);
+                uint32_t n = 0;
+                for (int32_t p = head; p >= 0; p = next[p]) ++n;
+                mine += n;
+                bits |= (n ? 1u : 0u) << (it * 4 + j);
+            }
+        }
+    flags8[(size_t)tile * kProbeBlock + threadIdx.x] = (uint8_t)bits;
+    const uint32_t incl = wave_incl_scan_u32(mine);
+    if (lane == 63) counts[(size_t)tile * kProbeWaves + wave] = incl;
+}
+
 template <bool kLds>
 __global__ __launch_bounds__(kProbeBlock) void q13_probe_count_kernel(const int32_t *__restrict__ auction, int64_t n_rows,
                                                                       SegTiles st, const uint64_t *__restrict__ table,
@@ -105,12 +187,15 @@ __global__ __launch_bounds__(kProbeBlock) void q13_probe_count_kernel(const int3
     const int wave = threadIdx.x >> 6, lane = lane_id();
     constexpr int kWaveRows = kProbeTile / kProbeWaves;  // 512
     constexpr int kIters = kWaveRows / 256;              // 2
+    // One tile in hand, the next one requested.  (Two in hand + two in flight needed 81 VGPRs: one 16-wave workgroup per
+    // CU instead of two, no faster.)
     int32_t tile = (int32_t)blockIdx.x;
     if (tile >= st.n_tiles) return;
     TileRange tr = locate_tile(st, tile, kProbeTile);
     int32_t k[kIters][4], kn[kIters][4];
+    const int64_t lane_off = (int64_t)wave * kWaveRows + lane * 4;
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) load4_i32(auction, tr.tile_begin + (int64_t)wave * kWaveRows + lane * 4 + it * 256, n_rows, k[it]);
+    for (int it = 0; it < kIters; ++it) load4_i32(auction, tr.tile_begin + lane_off + it * 256, n_rows, k[it]);
 #pragma unroll 1
     for (;;) {
         const int32_t nxt = tile + (int32_t)gridDim.x;
@@ -118,27 +203,9 @@ __global__ __launch_bounds__(kProbeBlock) void q13_probe_count_kernel(const int3
         if (nxt < st.n_tiles) {
             trn = locate_tile(st, nxt, kProbeTile);
 #pragma unroll
-            for (int it = 0; it < kIters; ++it)
-                load4_i32(auction, trn.tile_begin + (int64_t)wave * kWaveRows + lane * 4 + it * 256, n_rows, kn[it]);
+            for (int it = 0; it < kIters; ++it) load4_i32(auction, trn.tile_begin + lane_off + it * 256, n_rows, kn[it]);
         }
-        const int64_t wbase = tr.tile_begin + (int64_t)wave * kWaveRows + lane * 4;
-        uint32_t mine = 0, bits = 0;
-#pragma unroll
-        for (int it = 0; it < kIters; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t r = wbase + it * 256 + j;
-                if (r >= tr.lo && r < tr.hi && q13_maybe(bm, k[it][j])) {
-                    const int32_t head = kLds ? find_lds(s_key, s_occ, table, cap, k[it][j]) : find_global(table, cap, k[it][j]);
-                    uint32_t n = 0;
-                    for (int32_t p = head; p >= 0; p = next[p]) ++n;
-                    mine += n;
-                    bits |= (n ? 1u : 0u) << (it * 4 + j);
-                }
-            }
-        flags8[(size_t)tile * kProbeBlock + threadIdx.x] = (uint8_t)bits;
-        const uint32_t incl = wave_incl_scan_u32(mine);
-        if (lane == 63) counts[(size_t)tile * kProbeWaves + wave] = incl;
+        q13_probe_tile<kLds>(tr, tile, k, s_key, s_occ, table, cap, next, bm, counts, flags8);
         if (nxt >= st.n_tiles) break;
         tile = nxt;
         tr = trn;

@@ -38,6 +38,7 @@ constexpr int kLdsMaxProbe = 24;
 constexpr uint32_t kFib = 0x9E3779B1u;
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
+constexpr uint32_t kWideTile = 0x40000000u;     // slow-list tag: declined for its key spread (not for being ragged)
 
 struct PaneDesc {
     int64_t base;      // first key of the pane's direct-address range (multiple of 4)
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
     const uint32_t span = (uint32_t)mx - (uint32_t)mn;
     if (span >= (uint32_t)kHist) {  // keys spread wider than the histogram: general path in q5_count_slow_kernel
-        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
+        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)(blockIdx.x | kWideTile);
         return;
     }
 
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
         __syncthreads();  // previous tile's flush is done with `slots`
         for (int s = threadIdx.x; s < kSlots; s += kBlock) slots[s] = 0;
         if (threadIdx.x == 0) s_fill = 0;
-        const TileRange tr = locate_tile(st, slow_list[1 + i], kQ5Tile);
+        const uint32_t entry = (uint32_t)slow_list[1 + i];
+        const TileRange tr = locate_tile(st, (int32_t)(entry & ~kWideTile), kQ5Tile);
         FlushArgs f;
         f.pane = panes[tr.seg];
         f.wp0 = pane_win_ptr[tr.seg];
@@ -324,10 +326,11 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
         f.tab_used = tab_used;
         f.err = err;
         __syncthreads();
-        if (f.pane.range) {
-            // Direct-address pane whose tile is ragged or spreads wider than the LDS histogram (keys in no particular
-            // order): one global atomic per row on the pane's counters; the lanes that share the first lane's key add once.
-            // An LDS hash in front only pays when a tile repeats keys, and it overflows first when it does not.
+        if (f.pane.range && (entry & kWideTile)) {
+            // Direct-address pane, tile spread wider than the LDS histogram (keys in no particular order): one global
+            // atomic per row on the pane's counters; the lanes that share the first lane's key add once.  An LDS hash
+            // in front only pays when a tile repeats keys, and it overflows first when it does not.  (Ragged tiles of
+            // ordered data keep the LDS hash below: few distinct keys.)
             int32_t k[kQ5Iters][4];
 #pragma unroll
             for (int it = 0; it < kQ5Iters; ++it) {
