@@ -392,7 +392,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: flock_amd has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1 or args.mode == "exchange":
+    force_side = os.environ.get("FLOCK_BENCH_EXCHANGE_SIDE") == "1"   # run the N > 1 side measurement at N = 1 (testing)
+    if world > 1 or args.mode == "exchange" or force_side:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
@@ -457,7 +458,7 @@ def main():
         if world == 1 and not args.no_cpu and stream is not None:
             out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
     # side measurements (N = 1 only): the other BASELINE configs, each with its own roofline and CPU leg
-    if rank == 0 and world == 1 and not args.no_also and args.mode == "windows":
+    if rank == 0 and world == 1 and not args.no_also and args.mode == "windows" and not force_side:
         also = {}
         del stream, res
         torch.cuda.empty_cache()
@@ -494,6 +495,55 @@ def main():
         except Exception as e:
             also["q5_pcie_inclusive"] = {"error": repr(e)}
         out["also"] = also
+    # side measurement at N > 1: the SAME headline relations key-partitioned across the ranks (BASELINE configs 4 and 5:
+    # hash repartition + RCCL all-to-all + per-rank operators + winner merge), strong scaling.  The main line above is the
+    # window-sharded job; this shows what the exchange step costs on the same node.  A watchdog prints the main line and
+    # leaves if a collective does not come back, so that the side measurement can never take the headline with it.
+    if (world > 1 or force_side) and not args.no_also and args.mode == "windows":
+        try:
+            import threading
+
+            def bail():
+                if rank == 0 and out is not None:
+                    out["also"] = {"exchange": {"error": "watchdog: exchange side measurement did not finish"}}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            dog = threading.Timer(240.0, bail)
+            dog.daemon = True
+            dog.start()
+            ex = {}
+            try:
+                del stream, res
+            except Exception:
+                pass
+            torch.cuda.empty_cache()
+            steps2 = max(2, min(args.steps, 3))
+            for label, q2, secs in (("q5_exchange", 5, DEFAULT_SECONDS[5]), ("q8_exchange", 8, DEFAULT_SECONDS[8])):
+                try:
+                    full = make_stream(ctx, q2, secs, args.eps, 0)
+                    st = Striped(ctx, q2, full, rank, world)
+                    del full
+                    torch.cuda.empty_cache()
+                    d2, st2, r2 = run_steps(ctx, lambda: st.run(ctx), steps2, 1, barrier)
+                    t = torch.tensor([d2, float(st.rows())], dtype=torch.float64, device=f"cuda:{local}")
+                    tmax = t.clone()
+                    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    ex[label] = {"value": round(float(t[1]) * steps2 / float(tmax[0]), 1), "unit": "rows/s", "scaling": "strong",
+                                 "ms_per_step": round(float(tmax[0]) / steps2 * 1e3, 3), "input_rows_all_gpus": int(float(t[1])),
+                                 "parallelism": f"key-partitioned x{world} (hash repartition + RCCL all-to-all)",
+                                 "result_rows_rank0": int(r2.rows) if hasattr(r2, "rows") else None,
+                                 "kernels_ms_rank0": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st2.items()}}
+                    del st, r2
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    ex[label] = {"error": repr(e)}
+            dog.cancel()
+            if rank == 0 and out is not None:
+                out["also"] = ex
+        except Exception as e:  # never let the side measurement take the headline with it
+            if rank == 0 and out is not None:
+                out["also"] = {"exchange": {"error": repr(e)}}
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()
