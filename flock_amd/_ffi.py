@@ -138,6 +138,7 @@ SYMBOLS = {
     "flockgpu_free": (_i, [_vp, _vp]),
     "flockgpu_memcpy": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
     "flockgpu_profile_enable": (_i, [_vp, _i]),
+    "flockgpu_profile_only": (_i, [_vp, C.c_char_p]),
     "flockgpu_profile_reset": (_i, [_vp]),
     "flockgpu_profile_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     "flockgpu_q1_project": (_i, [_vp, C.POINTER(BidCols), C.c_double, _vp]),

@@ -49,6 +49,7 @@ struct flockgpu_ctx {
     double q8_rows_per_seller = 4.0;
     // profiling
     bool profiling = false;
+    std::string profile_only;  // when set: only launches of this kernel are bracketed
     std::vector<flockgpu::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, flockgpu::KernelStat> stats;
@@ -147,8 +148,10 @@ struct LaunchScope {
     flockgpu_ctx *ctx;
     const char *name;
     hipEvent_t start = nullptr, stop = nullptr;
+    bool on = false;
     LaunchScope(flockgpu_ctx *c, const char *n) : ctx(c), name(n) {
-        if (!ctx->profiling) return;
+        on = ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only == n);
+        if (!on) return;
         auto take = [&]() {
             hipEvent_t e = nullptr;
             if (!ctx->event_pool.empty()) {
@@ -164,7 +167,7 @@ struct LaunchScope {
         (void)hipEventRecord(start, ctx->stream);
     }
     ~LaunchScope() {
-        if (!ctx->profiling) return;
+        if (!on) return;
         (void)hipEventRecord(stop, ctx->stream);
         ctx->pending.push_back({name, start, stop});
     }

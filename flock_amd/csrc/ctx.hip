@@ -99,6 +99,14 @@ int flockgpu_profile_enable(flockgpu_ctx *ctx, int on) {
     return FLOCKGPU_OK;
 }
 
+int flockgpu_profile_only(flockgpu_ctx *ctx, const char *kernel_name) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    ctx->profile_only = kernel_name ? kernel_name : "";
+    return FLOCKGPU_OK;
+}
+
 int flockgpu_profile_reset(flockgpu_ctx *ctx) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -202,9 +202,11 @@ constexpr int kLenTile = kBlock * kLenItems;
 constexpr int kStageBytes = 18 * 1024;  // LDS staging buffer of the emit kernel: 18 B per value on average, 8 workgroups
                                         // per CU (tiles beyond it copy directly, byte by byte)
 
+// d_n (may be null): the row list's length when only the device knows it yet; n is then an upper bound.
 __global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restrict__ src_off,
                                                           const int32_t *__restrict__ rows, int64_t n,
-                                                          uint32_t *__restrict__ counts) {
+                                                          const uint64_t *__restrict__ d_n, uint32_t *__restrict__ counts) {
+    if (d_n) n = min(n, (int64_t)*d_n);
     const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
     uint32_t mine = 0;
 #pragma unroll
@@ -449,7 +451,7 @@ int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64
 }
 
 int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
-                      Utf8Gather *g) {
+                      Utf8Gather *g, const uint64_t *d_n) {
     g->name = name;
     g->src = src;
     g->rows = rows;
@@ -465,13 +467,18 @@ int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &
     FG_TRY(arena_get_t(ctx, k_b.c_str(), (size_t)g->tiles + 1, &g->tile_base));
     {
         LaunchScope ls(ctx, "utf8_len_kernel");
-        hipLaunchKernelGGL(utf8_len_kernel, dim3((unsigned)g->tiles), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n,
+        hipLaunchKernelGGL(utf8_len_kernel, dim3((unsigned)g->tiles), dim3(kBlock), 0, ctx->stream, src.offsets, rows, n, d_n,
                            g->counts);
     }
     FG_TRY(check_launch(ctx, "utf8_len_kernel"));
     FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)g->tiles, g->tile_base, nullptr, 0, nullptr));
     FG_HIP(ctx, hipMemcpyAsync(g->h_total, g->tile_base + g->tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     return FLOCKGPU_OK;
+}
+
+void gather_utf8_narrow(Utf8Gather *g, int64_t n) {
+    g->n = n;
+    g->tiles = n > 0 ? div_up(n, kLenTile) : 0;
 }
 
 int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes) {

@@ -45,8 +45,12 @@ struct Utf8Gather {
     uint64_t *tile_base = nullptr;
     uint64_t *h_total = nullptr;  // pinned
 };
+// d_n (device, may be null): the true length of `rows` when the host does not know it yet -- `n` is then an upper
+// bound (buffers and grid are sized for it) and, once the host has read the true length, gather_utf8_narrow() sets it
+// before finish.  The tiles of the bound beyond the true length count zero bytes.
 int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
-                      Utf8Gather *g);
+                      Utf8Gather *g, const uint64_t *d_n = nullptr);
+void gather_utf8_narrow(Utf8Gather *g, int64_t n);
 int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes);
 // begin + synchronise + finish for a single column.
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

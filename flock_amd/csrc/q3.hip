@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
             const uint64_t v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);  // len 0: nothing is read past the buffer
             if (!(in && len <= 8 && lits_hit(v, len, lits))) continue;
             if (kDense) {
-                direct[wt.off + (uint32_t)(key[it][j] - wt.base)] = (int32_t)r;
+                const uint32_t idx = (uint32_t)key[it][j] - (uint32_t)wt.base;
+                if (idx < wt.range) direct[wt.off + idx] = (int32_t)r;  // (range 0: the layout pass declined the dense path)
             } else if (!multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
                 atomicOr(err, 1u);
             }
@@ -231,6 +232,59 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
     if (!kEmit && lane == 0) counts[(size_t)tile * kWavesPerBlock + wave] = wave_total;
 }
 
+// Dense-path layout decided ON THE DEVICE from the exact per-window key statistics, so that the host does not wait for
+// them: window w gets a direct-address table over [min, max] when its p_id are strictly increasing and the range is at
+// most 8 x its rows + 1024 (the host sized the arena for exactly that bound).  One window that does not qualify
+// declines the whole call: every range becomes 0 (nothing is built, nothing joins) and info[1] = 0 tells the host,
+// at its single synchronisation, to run the general path instead.
+__global__ __launch_bounds__(kBlock) void q3_layout_kernel(const int32_t *__restrict__ stats, const int64_t *__restrict__ seg_off,
+                                                           int32_t n_win, WinTable *__restrict__ wins, uint64_t *__restrict__ info) {
+    __shared__ uint64_t s_wave[kWavesPerBlock];
+    __shared__ uint64_t s_carry;
+    int ok = 1;
+    for (int32_t w = threadIdx.x; w < n_win; w += kBlock) {
+        const int64_t rows = seg_off[2 * w + 1] - seg_off[2 * w];
+        if (rows <= 0) continue;
+        const int64_t range = (int64_t)stats[n_win + w] - (int64_t)stats[w] + 1;
+        if (!stats[2 * n_win + w] || range > 8 * rows + 1024) ok = 0;
+    }
+    ok = __syncthreads_and(ok);
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int32_t w0 = 0; w0 < n_win; w0 += kBlock) {
+        const int32_t w = w0 + (int32_t)threadIdx.x;
+        uint64_t range = 0;
+        int32_t base = 0;
+        if (ok && w < n_win && seg_off[2 * w + 1] > seg_off[2 * w]) {
+            base = stats[w];
+            range = (uint64_t)((int64_t)stats[n_win + w] - (int64_t)base + 1);
+        }
+        const uint64_t incl = wave_incl_scan_u64(range);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t off = s_carry + incl - range;
+        for (int v = 0; v < wave; ++v) off += s_wave[v];
+        if (w < n_win) wins[w] = WinTable{base, (uint32_t)range, off};
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_carry = off + range;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[0] = s_carry;  // entries in use
+        info[1] = (uint64_t)ok;
+    }
+}
+
+// direct[0 .. info[0]) = -1; the grid covers the arena's bound, workgroups past the entries in use leave at once
+__global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restrict__ direct, const uint64_t *__restrict__ info) {
+    const uint64_t n = info[0] + 4;
+    const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i + 4 <= n) *reinterpret_cast<int4 *>(direct + i) = make_int4(-1, -1, -1, -1);
+    else
+        for (uint64_t k = i; k < n; ++k) direct[k] = -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -279,29 +333,11 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     FG_TRY(build_seg_tiles(ctx, "q3.auction", ab.data(), ae.data(), n_win, kFlagTile, &st_a));
     FG_TRY(build_seg_tiles(ctx, "q3.person", pb.data(), pe.data(), n_win, kFlagTile, &st_p));
 
-    // per-window key statistics of the persons: {min, max, sorted} x n_win
+    // per-window key statistics of the persons: {min, max, sorted} x n_win (exact, on the device)
     int32_t *d_stats = nullptr, *h_stats = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
     FG_TRY(pinned_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
     FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
-    if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-
-    bool dense = true;
-    uint64_t n_entries = 0;
-    std::vector<WinTable> wins(std::max(n_win, 1));
-    for (int w = 0; w < n_win && dense; ++w) {
-        wins[w] = WinTable{0, 0, n_entries};
-        if (pe[w] == pb[w]) continue;
-        const int64_t mn = h_stats[w], mx = h_stats[n_win + w], range = mx - mn + 1;
-        if (!h_stats[2 * n_win + w] || range > 8 * (pe[w] - pb[w]) + 1024) {
-            dense = false;
-            break;
-        }
-        wins[w].base = (int32_t)mn;
-        wins[w].range = (uint32_t)range;
-        n_entries += (uint64_t)range;
-    }
 
     uint32_t *counts = nullptr;
     uint64_t *tile_base = nullptr;
@@ -312,25 +348,48 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     FG_TRY(pinned_get_t(ctx, "q3.seg_out_off", (size_t)n_win + 2, &h_off));
     uint32_t *d_err = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.err", 4, &d_err));
+    std::vector<int64_t> &offs = ctx->host_i64["q3.win_out_offsets"];
+    int32_t *o_ar = nullptr, *o_pr = nullptr, *o_aid = nullptr;
+    Utf8Gather g_name, g_city, g_state;
+    uint64_t n_pairs = 0;
 
-    // dense-path state
-    WinTable *d_wins = nullptr;
-    int32_t *direct = nullptr;
-    uint32_t *flag_words = nullptr;
-    // general-path state
-    uint64_t *tables = nullptr;
-    int32_t *next = nullptr;
-    uint32_t cap = 0;
-
-    if (dense) {
-        WinTable *h_wins = nullptr;
-        FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)std::max(n_win, 1), &d_wins));
-        FG_TRY(pinned_get_t(ctx, "q3.wins", (size_t)std::max(n_win, 1), &h_wins));
-        std::copy(wins.begin(), wins.begin() + n_win, h_wins);
-        FG_TRY(arena_get_t(ctx, "q3.direct", (size_t)n_entries + 4, &direct));
+    // The dense path is SPECULATED: whether the persons qualify (strictly increasing p_id over an affordable range in
+    // every window -- what the generator and any id-ordered source produce) is decided by a device pass, the whole
+    // pipeline is queued behind it, and the host learns the verdict together with the pair counts and the string byte
+    // totals in ONE synchronisation (three before: statistics, pair counts, byte totals; ~60 us each at 1e8 events where
+    // the kernels take 90 us).  After a call that did not qualify the statistics are read first, as before.
+    std::vector<int64_t> &regime = ctx->host_i64["q3.dense_regime"];
+    if (regime.empty()) regime.push_back(1);
+    bool try_dense = n_win > 0;
+    if (try_dense && !regime[0]) {
+        FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int w = 0; w < n_win && try_dense; ++w) {
+            if (pe[w] == pb[w]) continue;
+            const int64_t range = (int64_t)h_stats[n_win + w] - (int64_t)h_stats[w] + 1;
+            if (!h_stats[2 * n_win + w] || range > 8 * (pe[w] - pb[w]) + 1024) try_dense = false;
+        }
+    }
+    if (try_dense) {
+        const size_t bound_entries = (size_t)8 * (size_t)person->rows + (size_t)1024 * n_win + 8;
+        const size_t bound_pairs = (size_t)auction->rows;  // one person per key: an auction joins at most one
+        WinTable *d_wins = nullptr;
+        int32_t *direct = nullptr;
+        uint32_t *flag_words = nullptr;
+        uint64_t *d_info = nullptr, *h_info = nullptr;
+        FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)n_win, &d_wins));
+        FG_TRY(arena_get_t(ctx, "q3.direct", bound_entries, &direct));
         FG_TRY(arena_get_t(ctx, "q3.flag_words", (size_t)st_a.n_tiles * kBlock, &flag_words));
-        if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, sizeof(WinTable) * n_win, hipMemcpyHostToDevice, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(direct, 0xFF, sizeof(int32_t) * ((size_t)n_entries + 4), ctx->stream));
+        FG_TRY(arena_get_t(ctx, "q3.layout_info", 2, &d_info));
+        FG_TRY(pinned_get_t(ctx, "q3.layout_info", 2, &h_info));
+        FG_TRY(arena_get_t(ctx, "q3.out_auction_row", bound_pairs + 1, &o_ar));
+        FG_TRY(arena_get_t(ctx, "q3.out_person_row", bound_pairs + 1, &o_pr));
+        FG_TRY(arena_get_t(ctx, "q3.out_a_id", bound_pairs + 1, &o_aid));
+        hipLaunchKernelGGL(q3_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_stats, st_p.seg_off, n_win, d_wins, d_info);
+        FG_TRY(check_launch(ctx, "q3_layout_kernel"));
+        hipLaunchKernelGGL(q3_fill_direct_kernel, dim3((unsigned)div_up((int64_t)bound_entries, kBlock * 4)), dim3(kBlock), 0,
+                           ctx->stream, direct, d_info);
+        FG_TRY(check_launch(ctx, "q3_fill_direct_kernel"));
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
@@ -345,10 +404,38 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
                                auction->category, auction->rows, category_lit, st_a, d_wins, direct, flag_words, counts);
         }
         FG_TRY(check_launch(ctx, "q3_probe_flag_kernel"));
-    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
+        if (st_a.n_tiles > 0) {
+            LaunchScope ls(ctx, "q3_emit_dense_kernel");
+            hipLaunchKernelGGL(q3_emit_dense_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
+                               auction->a_id, st_a, flag_words, counts, tile_base, d_wins, direct, o_ar, o_pr, o_aid);
+        }
+        FG_TRY(check_launch(ctx, "q3_emit_dense_kernel"));
+        const uint64_t *d_pairs = tile_base + st_a.n_tiles;
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)bound_pairs, &g_name, d_pairs));
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)bound_pairs, &g_city, d_pairs));
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)bound_pairs, &g_state, d_pairs));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        regime[0] = h_info[1] ? 1 : 0;
+        if (h_info[1]) {
+            offs.assign(h_off, h_off + n_win + 1);
+            n_pairs = (uint64_t)offs[n_win];
+            gather_utf8_narrow(&g_name, (int64_t)n_pairs);
+            gather_utf8_narrow(&g_city, (int64_t)n_pairs);
+            gather_utf8_narrow(&g_state, (int64_t)n_pairs);
+        } else {
+            try_dense = false;  // some window's persons are unsorted, duplicated or too sparse: general path below
+        }
+    }
+    if (!try_dense) {
+        regime[0] = 0;
         const uint64_t cap64 = std::max<uint64_t>(64, (uint64_t)max_person_rows * 3 / 2 + 8);
         if (cap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: window too large for one table region");
-        cap = (uint32_t)cap64;
+        const uint32_t cap = (uint32_t)cap64;
+        uint64_t *tables = nullptr;
+        int32_t *next = nullptr;
         FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
         FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
         FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
@@ -368,39 +455,29 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
         FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
-    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!dense && *reinterpret_cast<uint32_t *>(h_off + n_win + 1))
-        return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
-    std::vector<int64_t> &offs = ctx->host_i64["q3.win_out_offsets"];
-    offs.assign(h_off, h_off + n_win + 1);
-    const uint64_t n_pairs = (uint64_t)offs[n_win];
-    if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");
-
-    int32_t *o_ar = nullptr, *o_pr = nullptr, *o_aid = nullptr;
-    FG_TRY(arena_get_t(ctx, "q3.out_auction_row", (size_t)n_pairs + 1, &o_ar));
-    FG_TRY(arena_get_t(ctx, "q3.out_person_row", (size_t)n_pairs + 1, &o_pr));
-    FG_TRY(arena_get_t(ctx, "q3.out_a_id", (size_t)n_pairs + 1, &o_aid));
-    if (st_a.n_tiles > 0 && n_pairs > 0) {
-        if (dense) {
-            LaunchScope ls(ctx, "q3_emit_dense_kernel");
-            hipLaunchKernelGGL(q3_emit_dense_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
-                               auction->a_id, st_a, flag_words, counts, tile_base, d_wins, direct, o_ar, o_pr, o_aid);
-        } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*reinterpret_cast<uint32_t *>(h_off + n_win + 1))
+            return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
+        offs.assign(h_off, h_off + n_win + 1);
+        n_pairs = (uint64_t)offs[n_win];
+        if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");
+        FG_TRY(arena_get_t(ctx, "q3.out_auction_row", (size_t)n_pairs + 1, &o_ar));
+        FG_TRY(arena_get_t(ctx, "q3.out_person_row", (size_t)n_pairs + 1, &o_pr));
+        FG_TRY(arena_get_t(ctx, "q3.out_a_id", (size_t)n_pairs + 1, &o_aid));
+        if (st_a.n_tiles > 0 && n_pairs > 0) {
             LaunchScope ls(ctx, "q3_probe_emit_kernel");
             hipLaunchKernelGGL(q3_probe_general_kernel<true>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
                                auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
                                next, counts, tile_base, o_ar, o_pr, o_aid);
         }
-        FG_TRY(check_launch(ctx, "q3 emit"));
+        FG_TRY(check_launch(ctx, "q3_probe_emit_kernel"));
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)n_pairs, &g_name));
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)n_pairs, &g_city));
+        FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)n_pairs, &g_state));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    Utf8Gather g_name, g_city, g_state;
-    FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)n_pairs, &g_name));
-    FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)n_pairs, &g_city));
-    FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)n_pairs, &g_state));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FG_TRY(gather_utf8_finish(ctx, g_name, &out->name, &out->name_bytes));
     FG_TRY(gather_utf8_finish(ctx, g_city, &out->city, &out->city_bytes));
     FG_TRY(gather_utf8_finish(ctx, g_state, &out->state, &out->state_bytes));

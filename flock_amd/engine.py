@@ -357,6 +357,10 @@ class GpuContext:
     def profile(self, on: bool):
         self._check(self._lib.flockgpu_profile_enable(self._h, 1 if on else 0))
 
+    def profile_only(self, kernel_name=None):
+        """Bracket only launches of `kernel_name` (None: all kernels)."""
+        self._check(self._lib.flockgpu_profile_only(self._h, kernel_name.encode() if kernel_name else None))
+
     def profile_reset(self):
         self._check(self._lib.flockgpu_profile_reset(self._h))
 

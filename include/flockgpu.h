@@ -64,6 +64,9 @@ int flockgpu_memcpy(flockgpu_ctx *ctx, void *dst, const void *src, size_t bytes,
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  When enabled, every kernel launch of
  * the ctx is bracketed by hipEvents on the ctx stream; totals are read back per kernel name. */
 int flockgpu_profile_enable(flockgpu_ctx *ctx, int on);
+/* Restricts the bracketing to launches of one kernel (NULL: every kernel again).  Two event records per launch are
+ * markers on the stream: bracketing all ~20 launches of a small-batch query costs as much as its kernels. */
+int flockgpu_profile_only(flockgpu_ctx *ctx, const char *kernel_name);
 int flockgpu_profile_reset(flockgpu_ctx *ctx);
 /* Fills up to `cap` entries; returns the number of distinct kernels seen in *n. */
 typedef struct {
