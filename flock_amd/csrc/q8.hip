@@ -265,6 +265,58 @@ __global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
+// Dense-path layout decided on the device (as q3.hip's q3_layout_kernel): window w gets a bitmap over
+// [min p_id & ~31, max p_id] when its p_id are strictly increasing and the bitmap has at most 64 x rows + 4096 bits (the
+// bound the host sized the arena for).  A window that does not qualify declines the whole call: every n_bits becomes
+// 0 (no seller is recorded, no person flagged) and info[1] = 0 sends the host to the general path.
+__global__ __launch_bounds__(kBlock) void q8_layout_kernel(const int32_t *__restrict__ stats, const int64_t *__restrict__ seg_off,
+                                                           int32_t n_win, WinBitmap *__restrict__ wins, uint64_t *__restrict__ info) {
+    __shared__ uint64_t s_wave[kWavesPerBlock];
+    __shared__ uint64_t s_carry;
+    int ok = 1;
+    for (int32_t w = threadIdx.x; w < n_win; w += kBlock) {
+        const int64_t rows = seg_off[2 * w + 1] - seg_off[2 * w];
+        if (rows <= 0) continue;
+        const int64_t base = (int64_t)stats[w] & ~int64_t(31), bits = (int64_t)stats[n_win + w] - base + 1;
+        if (!stats[2 * n_win + w] || bits > 64 * rows + 4096 || bits >= (int64_t(1) << 31)) ok = 0;
+    }
+    ok = __syncthreads_and(ok);
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int32_t w0 = 0; w0 < n_win; w0 += kBlock) {
+        const int32_t w = w0 + (int32_t)threadIdx.x;
+        int64_t base = 0, bits = 0;
+        if (ok && w < n_win && seg_off[2 * w + 1] > seg_off[2 * w]) {
+            base = (int64_t)stats[w] & ~int64_t(31);
+            bits = (int64_t)stats[n_win + w] - base + 1;
+        }
+        const uint64_t words = (uint64_t)((bits + 31) >> 5);
+        const uint64_t incl = wave_incl_scan_u64(words);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t off = s_carry + incl - words;
+        for (int v = 0; v < wave; ++v) off += s_wave[v];
+        if (w < n_win) wins[w] = WinBitmap{(int32_t)base, (uint32_t)bits, off};
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_carry = off + words;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[0] = s_carry;  // bitmap words in use
+        info[1] = (uint64_t)ok;
+    }
+}
+
+// bitmaps[0 .. info[0] + 4) = 0; the grid covers the arena's bound
+__global__ __launch_bounds__(kBlock) void q8_zero_bitmaps_kernel(uint32_t *__restrict__ bitmaps, const uint64_t *__restrict__ info) {
+    const uint64_t n = info[0] + 4;
+    const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i + 4 <= n) *reinterpret_cast<uint4 *>(bitmaps + i) = make_uint4(0, 0, 0, 0);
+    else
+        for (uint64_t k = i; k < n; ++k) bitmaps[k] = 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,30 +355,11 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     FG_TRY(build_seg_tiles(ctx, "q8.auction", ab.data(), ae.data(), n_win, kFlagTile, &st_a));
     FG_TRY(build_seg_tiles(ctx, "q8.person", pb.data(), pe.data(), n_win, kFlagTile, &st_p));
 
-    // per-window key statistics of the persons: {min, max, sorted} x n_win
+    // per-window key statistics of the persons: {min, max, sorted} x n_win (exact, on the device)
     int32_t *d_stats = nullptr, *h_stats = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
     FG_TRY(pinned_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
     FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
-    if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-
-    bool dense = true;
-    uint64_t bm_words = 0;
-    std::vector<WinBitmap> wins(std::max(n_win, 1));
-    for (int w = 0; w < n_win && dense; ++w) {
-        wins[w] = WinBitmap{0, 0, bm_words};
-        if (pe[w] == pb[w]) continue;
-        const int64_t mn = h_stats[w], mx = h_stats[n_win + w];
-        const int64_t base = mn & ~int64_t(31), bits = mx - base + 1;
-        if (!h_stats[2 * n_win + w] || bits > 64 * (pe[w] - pb[w]) + 4096 || bits >= (int64_t(1) << 31)) {
-            dense = false;
-            break;
-        }
-        wins[w].base = (int32_t)base;
-        wins[w].n_bits = (uint32_t)bits;
-        bm_words += (uint64_t)div_up(bits, 32);
-    }
 
     uint32_t *flag_words = nullptr, *counts = nullptr;
     uint64_t *tile_base = nullptr;
@@ -336,16 +369,41 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     int64_t *d_off = nullptr, *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.seg_out_off", (size_t)n_win + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "q8.seg_out_off", (size_t)n_win + 2, &h_off));
+    int32_t *o_pr = nullptr;
+    FG_TRY(arena_get_t(ctx, "q8.out_person_row", (size_t)out_cap, &o_pr));  // at most every person of every window
+    std::vector<int64_t> &offs = ctx->host_i64["q8.win_out_offsets"];
+    Utf8Gather g_name;
+    int64_t n_out = 0;
 
-    if (dense) {
-        WinBitmap *d_wins = nullptr, *h_wins = nullptr;
-        FG_TRY(arena_get_t(ctx, "q8.wins", (size_t)std::max(n_win, 1), &d_wins));
-        FG_TRY(pinned_get_t(ctx, "q8.wins", (size_t)std::max(n_win, 1), &h_wins));
-        std::copy(wins.begin(), wins.begin() + n_win, h_wins);
+    // As in q3: the dense path is speculated -- a device pass lays the bitmaps out, everything up to the name lengths is
+    // queued behind it, and the verdict, the row counts and the byte total reach the host in ONE synchronisation
+    // (four before).  After a call that did not qualify the statistics are read first.
+    std::vector<int64_t> &regime = ctx->host_i64["q8.dense_regime"];
+    if (regime.empty()) regime.push_back(1);
+    bool try_dense = n_win > 0;
+    if (try_dense && !regime[0]) {
+        FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int w = 0; w < n_win && try_dense; ++w) {
+            if (pe[w] == pb[w]) continue;
+            const int64_t base = (int64_t)h_stats[w] & ~int64_t(31), bits = (int64_t)h_stats[n_win + w] - base + 1;
+            if (!h_stats[2 * n_win + w] || bits > 64 * (pe[w] - pb[w]) + 4096 || bits >= (int64_t(1) << 31)) try_dense = false;
+        }
+    }
+    if (try_dense) {
+        const size_t bound_words = (size_t)2 * (size_t)person->rows + (size_t)130 * n_win + 8;
+        WinBitmap *d_wins = nullptr;
         uint32_t *bitmaps = nullptr;
-        FG_TRY(arena_get_t(ctx, "q8.bitmaps", (size_t)bm_words + 4, &bitmaps));
-        if (n_win > 0) FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, sizeof(WinBitmap) * n_win, hipMemcpyHostToDevice, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(bitmaps, 0, sizeof(uint32_t) * ((size_t)bm_words + 4), ctx->stream));
+        uint64_t *d_info = nullptr, *h_info = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.wins", (size_t)n_win, &d_wins));
+        FG_TRY(arena_get_t(ctx, "q8.bitmaps", bound_words, &bitmaps));
+        FG_TRY(arena_get_t(ctx, "q8.layout_info", 2, &d_info));
+        FG_TRY(pinned_get_t(ctx, "q8.layout_info", 2, &h_info));
+        hipLaunchKernelGGL(q8_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_stats, st_p.seg_off, n_win, d_wins, d_info);
+        FG_TRY(check_launch(ctx, "q8_layout_kernel"));
+        hipLaunchKernelGGL(q8_zero_bitmaps_kernel, dim3((unsigned)div_up((int64_t)bound_words, kBlock * 4)), dim3(kBlock), 0,
+                           ctx->stream, bitmaps, d_info);
+        FG_TRY(check_launch(ctx, "q8_zero_bitmaps_kernel"));
         if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q8_sellers_bitmap_kernel");
             hipLaunchKernelGGL(q8_sellers_bitmap_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
@@ -359,7 +417,23 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
                                st_p, d_wins, bitmaps, flag_words, counts);
         }
         FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
-    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
+        FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
+        FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, out_cap - 16, &g_name, tile_base + st_p.n_tiles));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        regime[0] = h_info[1] ? 1 : 0;
+        if (h_info[1]) {
+            offs.assign(h_off, h_off + n_win + 1);
+            n_out = offs[n_win];
+            gather_utf8_narrow(&g_name, n_out);
+        } else {
+            try_dense = false;
+        }
+    }
+    if (!try_dense) {
+        regime[0] = 0;
         const uint64_t pcap64 = std::max<uint64_t>(64, (uint64_t)max_p * 3 / 2 + 8);
         if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
         const uint32_t pcap = (uint32_t)pcap64;
@@ -399,23 +473,19 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
             if (attempt > 0) ctx->q8_rows_per_seller = std::max(1.0, (double)max_a * 2.0 / (double)scap64);
             break;
         }
+        FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
+        FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
+        FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, out_cap - 16, &g_name, tile_base + st_p.n_tiles));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        offs.assign(h_off, h_off + n_win + 1);
+        n_out = offs[n_win];
+        gather_utf8_narrow(&g_name, n_out);
     }
-
-    FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
-    int32_t *o_pr = nullptr;
-    FG_TRY(arena_get_t(ctx, "q8.out_person_row", (size_t)out_cap, &o_pr));
-    FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
-    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> &offs = ctx->host_i64["q8.win_out_offsets"];
-    offs.assign(h_off, h_off + n_win + 1);
-    const int64_t n_out = offs[n_win];
-
     int32_t *o_pid = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.out_p_id", (size_t)n_out + 1, &o_pid));
     FG_TRY(gather_i32(ctx, person->p_id, o_pr, n_out, o_pid));
-    FG_TRY(gather_utf8(ctx, "q8.out_name", person->name, o_pr, n_out, &out->name, &out->name_bytes));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(gather_utf8_finish(ctx, g_name, &out->name, &out->name_bytes));
     out->p_id = o_pid;
     out->person_row = o_pr;
     out->win_out_offsets = offs.data();
