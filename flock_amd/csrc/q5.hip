@@ -487,12 +487,28 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
         }
     }
     if (!SELECT) {
+        // one update per WORKGROUP: every wave of every workgroup of a window bumping win_max[w] / win_groups[w] is a
+        // same-address atomic chain (the pass took 0.10 / 0.18 / 0.75 ms with 8 / 64 / 256 workgroups per window)
+        __shared__ uint32_t s_best[kWavesPerBlock];
+        __shared__ uint64_t s_groups[kWavesPerBlock];
         best = wave_max_u32(best);
         const uint64_t g = wave_sum_u64(groups);
         if (lane_id() == 0) {
-            if (best) atomicMax(&block_max[(size_t)w * gridDim.x + blockIdx.x], best);
-            if (best) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)best);
-            if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
+            s_best[threadIdx.x >> 6] = best;
+            s_groups[threadIdx.x >> 6] = g;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t b = 0;
+            uint64_t gs = 0;
+#pragma unroll
+            for (int v = 0; v < kWavesPerBlock; ++v) {
+                b = max(b, s_best[v]);
+                gs += s_groups[v];
+            }
+            if (b) block_max[(size_t)w * gridDim.x + blockIdx.x] = b;  // this workgroup's own slot
+            if (b) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)b);
+            if (gs) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)gs);
         }
     }
 }
@@ -664,6 +680,8 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         }
         if (n_win > 0) {
             const uint64_t per_win = std::max<uint64_t>(cap, scan_total / n_win / 4);
+            // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
+            // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
             const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
             uint32_t *block_max = nullptr;
             FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * n_win, &block_max));
