@@ -26,7 +26,7 @@ for q, kern in DOMINANT.items():
         if not os.path.exists(p):
             continue
         for r in csv.DictReader(open(p)):
-            if kern + "(" in r["kernel"]:
+            if kern + "(" in r["kernel"] or kern + "<" in r["kernel"]:
                 vals[c] = float(r[f"avg_{c}_KB"])
     if len(vals) == 2:
         traffic[kern] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
