@@ -117,6 +117,10 @@ class YsbResult(C.Structure):
                 ("campaign_bytes", C.c_int64)]
 
 
+class Q5PartialResult(C.Structure):
+    _fields_ = [("auction", C.c_void_p), ("count", C.c_void_p), ("pane_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
+
+
 class Q11Result(C.Structure):
     _fields_ = [("bidder", C.c_void_p), ("bid_count", C.c_void_p), ("start_time", C.c_void_p), ("end_time", C.c_void_p),
                 ("epoch_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64), ("sessions_total", C.c_int64)]
@@ -159,6 +163,8 @@ SYMBOLS = {
     "flockgpu_take_i64": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "flockgpu_take_utf8": (_i, [_vp, C.POINTER(Utf8), _vp, _i64, C.c_int32, C.POINTER(Utf8), C.POINTER(_i64)]),
     "flockgpu_inclusive_scan_i32": (_i, [_vp, _vp, _i64]),
+    "flockgpu_q5_partial_counts": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5PartialResult)]),
+    "flockgpu_q5_hot_items_weighted": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Windows), C.POINTER(Q5Result)]),
     "flockgpu_q11_user_sessions": (_i, [_vp, C.POINTER(BidCols), C.POINTER(_i64), _i, _i, _i64, C.POINTER(Q11Result)]),
     "flockgpu_group_rows_by_key": (_i, [_vp, _vp, _i64, C.POINTER(_vp), C.POINTER(_vp)]),
     "flockgpu_ysb_campaign_counts": (_i, [_vp, C.POINTER(YsbEventCols), C.POINTER(Windows), C.POINTER(YsbCampaignCols), C.c_char_p,

@@ -186,8 +186,11 @@ __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restr
 }
 
 // ---- count: fast kernel (full tiles whose keys fit the LDS histogram) -------------------------------------------
-__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, SegTiles st,
-                                                          const PaneDesc *__restrict__ panes,
+// kWeighted: every row carries a count (the FinalPartitioned side of q5.dag: rows are the partial groups another
+// partition sent); keys are then (nearly) distinct inside a tile, so no hot-key bookkeeping.
+template <bool kWeighted>
+__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, const uint32_t *__restrict__ weight,
+                                                          SegTiles st, const PaneDesc *__restrict__ panes,
                                                           const int32_t *__restrict__ pane_win_ptr,
                                                           const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                           uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
@@ -246,6 +249,23 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
         if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)(blockIdx.x | kWideTile);
         return;
     }
+    if (kWeighted) {
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+            const uint4 w4 = *reinterpret_cast<const uint4 *>(weight + r0);
+            atomicAdd(&hist[(uint32_t)k[it][0] - (uint32_t)mn], w4.x);
+            atomicAdd(&hist[(uint32_t)k[it][1] - (uint32_t)mn], w4.y);
+            atomicAdd(&hist[(uint32_t)k[it][2] - (uint32_t)mn], w4.z);
+            atomicAdd(&hist[(uint32_t)k[it][3] - (uint32_t)mn], w4.w);
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
+            const uint32_t c = hist[s];
+            if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
+        }
+        return;
+    }
 
     // hot key of this wave, kept in scalar registers across iterations
     int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
@@ -299,7 +319,9 @@ __global__ __launch_bounds__(kBlock) void q5_winner_num_kernel(const int32_t *__
     if (i < n) num[i] = win_max[win[i]];
 }
 
-__global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__restrict__ auction, SegTiles st,
+template <bool kWeighted>
+__global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__restrict__ auction,
+                                                               const uint32_t *__restrict__ weight, SegTiles st,
                                                                const PaneDesc *__restrict__ panes,
                                                                const int32_t *__restrict__ pane_win_ptr,
                                                                const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
@@ -326,6 +348,27 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
         f.tab_used = tab_used;
         f.err = err;
         __syncthreads();
+        if (kWeighted) {  // one (key, count) row per lane and trip: LDS hash while it has room, else straight out
+#pragma unroll 1
+            for (int64_t r0 = tr.lo; r0 < tr.hi; r0 += kBlock) {
+                const int64_t r = r0 + threadIdx.x;
+                if (r >= tr.hi) continue;
+                const int32_t key = auction[r];
+                const uint32_t w = weight[r];
+                if (w == 0) continue;
+                const bool full = *(volatile uint32_t *)&s_fill >= (uint32_t)(kSlots * 3 / 4);
+                const int rc = (full || f.pane.range) ? 0 : lds_hash_insert(slots, (uint32_t)key, w);
+                if (rc == 0) emit_pair(key, w, f);
+                else if (rc == 2) atomicAdd(&s_fill, 1u);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int s2 = threadIdx.x; s2 < kSlots; s2 += kBlock) {
+                const uint64_t e = slots[s2];
+                if (e) emit_pair((int32_t)(uint32_t)(e >> 32), (uint32_t)e, f);
+            }
+            continue;
+        }
         if (f.pane.range && (entry & kWideTile)) {
             // Direct-address pane, tile spread wider than the LDS histogram (keys in no particular order): one global
             // atomic per row on the pane's counters; the lanes that share the first lane's key add once.  An LDS hash
@@ -513,18 +556,75 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
     }
 }
 
+// ---- partial aggregation (q5.dag: HashAggregateExec mode=Partial, the stage BEFORE the hash repartition) ---------------
+// After the count pass with "window = pane", the groups of pane p are its non-zero direct-address counters plus the
+// live slots of its straggler table.  Both are compacted with the flag-tile machinery over ONE flat index space:
+// [0, cnt_total) = the counter arena, [tab0, tab0 + n_panes * cap) = the tables; segment 2p = pane p's counters,
+// segment 2p + 1 = its table, so a pane's groups come out contiguous.
+__global__ __launch_bounds__(kBlock) void q5_partial_flag_kernel(SegTiles sx, const uint32_t *__restrict__ counters,
+                                                                 const uint64_t *__restrict__ tables, int64_t tab0,
+                                                                 uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(sx, tile, kFlagTile);
+    const int32_t rel0 = flag_rel0();
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = tr.tile_begin + rel0 + it * 256 + j;
+            bool live = false;
+            if (i >= tr.lo && i < tr.hi) live = (tr.seg & 1) ? tables[i - tab0] != 0 : counters[i] != 0;
+            flags |= (uint32_t)live << (it * 4 + j);
+        }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+
+__global__ __launch_bounds__(kBlock) void q5_partial_emit_kernel(SegTiles sx, const uint32_t *__restrict__ flag_words,
+                                                                 const uint32_t *__restrict__ counts,
+                                                                 const uint64_t *__restrict__ tile_base,
+                                                                 const uint32_t *__restrict__ counters,
+                                                                 const uint64_t *__restrict__ tables, int64_t tab0,
+                                                                 const PaneDesc *__restrict__ panes, int32_t *__restrict__ out_key,
+                                                                 uint32_t *__restrict__ out_count) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const TileRange tr = locate_tile(sx, tile, kFlagTile);
+    const uint64_t base = tile_base[tile];
+    if (tr.seg & 1) {
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+            const uint64_t e = tables[tr.tile_begin + s_list[i] - tab0];
+            out_key[base + i] = (int32_t)(uint32_t)(e >> 32);
+            out_count[base + i] = (uint32_t)e;
+        }
+    } else {
+        const PaneDesc pd = panes[tr.seg >> 1];
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+            const int64_t idx = tr.tile_begin + s_list[i];
+            out_key[base + i] = (int32_t)(pd.base + (idx - (int64_t)pd.cnt_off));
+            out_count[base + i] = counters[idx];
+        }
+    }
+}
+
 }  // namespace
 
-extern "C" {
 
-int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
-                          flockgpu_q5_result *out) {
-    if (!ctx) return FLOCKGPU_ERR_INVALID;
-    if (!bid || !out || bid->rows < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5: null argument");
-    FG_TRY(check_windows(ctx, win, bid->rows, "q5"));
-    if (bid->rows > 0 && !bid->auction) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5: null auction column");
-    if (reinterpret_cast<uintptr_t>(bid->auction) & 15)
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: auction column must be 16-byte aligned");
+
+// The three entry points share one driver:
+//   hot items          : rows = bids, weight = nullptr, `out` set
+//   weighted hot items : rows = partial groups (auction, count) received from the other partitions, `out` set
+//   partial counts     : window = pane, `part` set: count pass, then the groups of every pane are compacted out
+static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *weight, int64_t rows, const flockgpu_windows *win,
+                  flockgpu_q5_result *out, flockgpu_q5_partial_result *part) {
+    FG_TRY(check_windows(ctx, win, rows, "q5"));
+    if (rows > 0 && !auction) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5: null auction column");
+    if ((reinterpret_cast<uintptr_t>(auction) & 15) || (reinterpret_cast<uintptr_t>(weight) & 15))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: auction / count columns must be 16-byte aligned");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = win->n_windows, n_panes = win->n_panes;
 
@@ -585,7 +685,7 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         {
             LaunchScope ls(ctx, "q5_range_kernel");
             hipLaunchKernelGGL(q5_range_kernel, dim3(kRangeBlocks, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream,
-                               bid->auction, bid->rows, st.seg_off, d_rng, d_rng + n_panes);
+                               auction, rows, st.seg_off, d_rng, d_rng + n_panes);
         }
         FG_TRY(check_launch(ctx, "q5_range_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * 2 * n_panes, hipMemcpyDeviceToHost, ctx->stream));
@@ -666,17 +766,73 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
         if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
-                hipLaunchKernelGGL(q5_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, st,
-                                   d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list);
+                hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0,
+                                   ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
+                                   slow_list);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
             {
                 LaunchScope ls(ctx, "q5_count_slow_kernel");
                 const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
-                hipLaunchKernelGGL(q5_count_slow_kernel, dim3(gs), dim3(kBlock), 0, ctx->stream, bid->auction, st, d_panes,
-                                   d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list);
+                hipLaunchKernelGGL(weight ? q5_count_slow_kernel<true> : q5_count_slow_kernel<false>, dim3(gs), dim3(kBlock), 0,
+                                   ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
+                                   slow_list);
             }
             FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
+        }
+        if (part) {  // Partial stage: hand out the groups of every pane (window w == pane w)
+            const int64_t tab0 = ((int64_t)cnt_total + 3) & ~int64_t(3);
+            std::vector<int64_t> xb((size_t)2 * n_win), xe((size_t)2 * n_win);
+            for (int w = 0; w < n_win; ++w) {
+                xb[2 * w] = (int64_t)panes[w].cnt_off;
+                xe[2 * w] = (int64_t)panes[w].cnt_off + (int64_t)panes[w].range;
+                xb[2 * w + 1] = tab0 + (int64_t)w * cap;
+                xe[2 * w + 1] = xb[2 * w + 1] + cap;
+            }
+            SegTiles sx;
+            FG_TRY(build_seg_tiles(ctx, "q5.partial", xb.data(), xe.data(), 2 * n_win, kFlagTile, &sx));
+            uint32_t *x_flags = nullptr, *x_counts = nullptr;
+            uint64_t *x_base = nullptr;
+            int64_t *d_xoff = nullptr, *h_xoff = nullptr;
+            FG_TRY(arena_get_t(ctx, "q5.partial_flags", (size_t)sx.n_tiles * kBlock + 4, &x_flags));
+            FG_TRY(arena_get_t(ctx, "q5.partial_counts", (size_t)sx.n_tiles * kWavesPerBlock + 4, &x_counts));
+            FG_TRY(arena_get_t(ctx, "q5.partial_base", (size_t)sx.n_tiles + 1, &x_base));
+            FG_TRY(arena_get_t(ctx, "q5.partial_off", (size_t)2 * n_win + 1, &d_xoff));
+            FG_TRY(pinned_get_t(ctx, "q5.partial_off", (size_t)2 * n_win + 1, &h_xoff));
+            if (sx.n_tiles > 0) {
+                LaunchScope ls(ctx, "q5_partial_flag_kernel");
+                hipLaunchKernelGGL(q5_partial_flag_kernel, dim3((unsigned)sx.n_tiles), dim3(kBlock), 0, ctx->stream, sx, counters, tables,
+                                   tab0, x_flags, x_counts);
+            }
+            FG_TRY(check_launch(ctx, "q5_partial_flag_kernel"));
+            FG_TRY(launch_tile_scan(ctx, x_counts, sx.n_tiles, x_base, sx.tile_first, sx.n_seg, d_xoff));
+            FG_HIP(ctx, hipMemcpyAsync(h_xoff, d_xoff, sizeof(int64_t) * ((size_t)2 * n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(h_meta, d_meta, sizeof(uint64_t) * n_meta, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win)[1]) {  // a pane's straggler table filled up
+                cap64 *= 4;
+                continue;
+            }
+            const int64_t n_out = h_xoff[2 * n_win];
+            if (n_out >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5 partial: more than 2^31 groups");
+            int32_t *p_key = nullptr;
+            uint32_t *p_cnt = nullptr;
+            FG_TRY(arena_get_t(ctx, "q5.partial_key", (size_t)n_out + 4, &p_key));
+            FG_TRY(arena_get_t(ctx, "q5.partial_cnt", (size_t)n_out + 4, &p_cnt));
+            if (sx.n_tiles > 0 && n_out > 0) {
+                LaunchScope ls(ctx, "q5_partial_emit_kernel");
+                hipLaunchKernelGGL(q5_partial_emit_kernel, dim3((unsigned)sx.n_tiles), dim3(kBlock), 0, ctx->stream, sx, x_flags, x_counts,
+                                   x_base, counters, tables, tab0, d_panes, p_key, p_cnt);
+            }
+            FG_TRY(check_launch(ctx, "q5_partial_emit_kernel"));
+            std::vector<int64_t> &poffs = ctx->host_i64["q5.partial_pane_offsets"];
+            poffs.resize((size_t)n_win + 1);
+            for (int w = 0; w <= n_win; ++w) poffs[w] = h_xoff[2 * w];
+            part->auction = p_key;
+            part->count = p_cnt;
+            part->pane_out_offsets = poffs.data();
+            part->rows = n_out;
+            return FLOCKGPU_OK;
         }
         if (n_win > 0) {
             const uint64_t per_win = std::max<uint64_t>(cap, scan_total / n_win / 4);
@@ -819,6 +975,36 @@ int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const
     out->win_groups = wgrp.data();
     out->rows = n_sel;
     return FLOCKGPU_OK;
+}
+
+extern "C" {
+
+int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                          flockgpu_q5_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!bid || !out || bid->rows < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5: null argument");
+    return q5_run(ctx, bid->auction, nullptr, bid->rows, win, out, nullptr);
+}
+
+int flockgpu_q5_hot_items_weighted(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *count, int64_t rows,
+                                   const flockgpu_windows *win, flockgpu_q5_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!out || rows < 0 || (rows > 0 && (!auction || !count))) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 weighted: null argument");
+    return q5_run(ctx, auction, count ? count : reinterpret_cast<const uint32_t *>(auction), rows, win, out, nullptr);
+}
+
+int flockgpu_q5_partial_counts(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                               flockgpu_q5_partial_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!bid || !out || !win || bid->rows < 0 || win->n_panes < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 partial: null argument");
+    std::vector<int32_t> lo((size_t)std::max(win->n_panes, 1)), hi(lo.size());
+    for (int p = 0; p < win->n_panes; ++p) {
+        lo[p] = p;
+        hi[p] = p + 1;
+    }
+    const flockgpu_windows panes{win->pane_row_offsets, win->n_panes, lo.data(), hi.data(), win->n_panes};
+    *out = flockgpu_q5_partial_result{};
+    return q5_run(ctx, bid->auction, nullptr, bid->rows, &panes, nullptr, out);
 }
 
 }  // extern "C"

@@ -17,8 +17,8 @@ The reference scales the path in two ways (SURVEY.md section 8 e), both mirrored
    the result stays sharded by key.  Messages: one buffer per column per step (xGMI is point-to-point, 7 links per
    GPU: few large transfers, never one per window).  q5 shuffles PANES (each bid moves once although it belongs to
    two hopping windows), aggregates the keys it owns, and needs one more collective: `all_reduce(MAX)` of the
-   per-window maxima (8 bytes per window) before the `num = maxn` filter.  (The reference also pre-aggregates
-   before the repartition -- `HashAggregateExec: mode=Partial`, q5.dag -- which only reduces traffic; not done here.)
+   per-window maxima (8 bytes per window) before the `num = maxn` filter.  As in q5.dag the repartition is preceded by
+   `HashAggregateExec: mode=Partial`: what crosses the fabric are the (auction, count) groups of every pane, not the bids.
 
 The local device operations are injected (`LocalOps`) so that the exchange logic itself -- split sizes, regrouping,
 window bookkeeping -- is covered by world-size-2 `gloo` tests on CPU tensors (tests/test_distributed.py), with the
@@ -65,6 +65,17 @@ class GpuOps:
 
     def offsets_from_lengths(self, lengths):
         return self.ctx.offsets_from_lengths(lengths)
+
+    def q5_partial(self, auction, schedule: WindowSchedule):
+        """(auction, count, pane_out_offsets): the groups of every pane (q5.dag HashAggregateExec mode=Partial)."""
+        from .engine import Bids
+        return self.ctx.q5_partial_counts(Bids(auction=auction, rows=int(auction.numel())), schedule)
+
+    def q5_weighted(self, auction, count, schedule: WindowSchedule):
+        """(auction, num, offsets, win_max) host arrays: FinalPartitioned + MAX + join over (auction, count) rows."""
+        r = self.ctx.q5_hot_items_weighted(auction, count, schedule)
+        a, n, off = r.to_host()
+        return a, n, off, r.win_max()
 
 
 _MAX_PEER_BYTES = 1 << 30   # RCCL / c10d transfers above 2 GiB per peer arrive corrupted: stay well below
@@ -221,17 +232,17 @@ def keep_global_winners(auction, num, offsets, local_max, gmax):
 
 
 def q5_exchange(ctx: GpuContext, bids, windows: WindowSchedule, group=None, ops=None) -> Q5Shard:
-    """q5 with the repartition of q5.dag: bids hash-partitioned on `auction` (pane by pane), local COUNT / MAX /
-    filter over the owned keys, all_reduce(MAX) across the partitions."""
-    from .engine import Bids
+    """q5 as q5.dag runs it: HashAggregateExec(Partial) on this rank's rows, pane by pane -> the (auction, count) groups
+    hash-partitioned on `auction` (each group moves once although its pane belongs to two hopping windows; a bid's
+    4 bytes never cross the fabric, only its group's 8) -> FinalPartitioned COUNT / MAX / filter over the owned keys ->
+    all_reduce(MAX) across the partitions."""
     ops = ops or GpuOps(ctx)
-    n_panes = len(windows.pane_row_offsets) - 1
-    pane_sched = WindowSchedule(windows.pane_row_offsets, np.arange(n_panes), np.arange(1, n_panes + 1))
-    cols, recv = shuffle_relation(ops, {"auction": bids.auction}, "auction", pane_sched, group)
+    keys, cnts, pane_off = ops.q5_partial(bids.auction, windows)
+    n_panes = len(pane_off) - 1
+    pane_sched = WindowSchedule(pane_off, np.arange(n_panes), np.arange(1, n_panes + 1))
+    cols, recv = shuffle_relation(ops, {"auction": keys, "count": cnts}, "auction", pane_sched, group)
     recv_sched = WindowSchedule(recv.pane_row_offsets, windows.win_pane_lo, windows.win_pane_hi)
-    r = ctx.q5_hot_items(Bids(auction=cols["auction"], rows=int(cols["auction"].numel())), recv_sched)
-    a, n, off = r.to_host()
-    local_max = r.win_max()
+    a, n, off, local_max = ops.q5_weighted(cols["auction"], cols["count"], recv_sched)
     gmax = global_window_max(local_max, cols["auction"].device, group)
     a, n, off = keep_global_winners(a, n, off, local_max, gmax)
     return Q5Shard(a, n, off, gmax)

@@ -399,6 +399,28 @@ class GpuContext:
         self._check(self._lib.flockgpu_q5_hot_items(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q5Out(self, r, windows.n_windows)
 
+    def q5_partial_counts(self, bids: Bids, windows: WindowSchedule):
+        """q5.dag's Partial stage: COUNT(*) GROUP BY auction per PANE of the schedule.  Returns (auction int32 tensor, count
+        int32 tensor holding uint32 counts, pane_out_offsets np.int64[n_panes + 1])."""
+        torch = _torch()
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5PartialResult()
+        self._check(self._lib.flockgpu_q5_partial_counts(self._h, C.byref(b), C.byref(w), C.byref(r)))
+        n, n_panes = int(r.rows), len(windows.pane_row_offsets) - 1
+        dev = f"cuda:{self.device}"
+        key = torch.empty(n, dtype=torch.int32, device=dev)
+        cnt = torch.empty(n, dtype=torch.int32, device=dev)
+        if n:
+            self._check(self._lib.flockgpu_memcpy(self._h, key.data_ptr(), r.auction, n * 4, _ffi.D2D))
+            self._check(self._lib.flockgpu_memcpy(self._h, cnt.data_ptr(), r.count, n * 4, _ffi.D2D))
+        return key, cnt, np.ctypeslib.as_array(r.pane_out_offsets, (n_panes + 1,)).copy()
+
+    def q5_hot_items_weighted(self, auction, count, windows: WindowSchedule) -> Q5Out:
+        """q5.dag's FinalPartitioned stage + MAX + join over (auction, count) rows (count: int32 tensor of uint32 bits)."""
+        w, r = windows.ffi(), _ffi.Q5Result()
+        self._check(self._lib.flockgpu_q5_hot_items_weighted(self._h, auction.data_ptr(), count.data_ptr(), auction.numel(), C.byref(w),
+                                                             C.byref(r)))
+        return Q5Out(self, r, windows.n_windows)
+
     def q7_highest_bid(self, bids: Bids, windows: WindowSchedule) -> Q7Out:
         """q7 (q7.sql): the bids that reach the window's MAX(price); ties kept, input order."""
         b, w, r = bids.ffi(), windows.ffi(), _ffi.Q7Result()

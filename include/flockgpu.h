@@ -165,6 +165,23 @@ typedef struct {
 int flockgpu_q5_hot_items(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
                           flockgpu_q5_result *out);
 
+/* q5 as the two stages of q5.dag around the hash repartition (the key-partitioned exchange of a multi-GPU run):
+ *   partial  : HashAggregateExec mode=Partial gby=[auction] COUNT(1), PER PANE -- the groups of pane p are rows
+ *              [pane_out_offsets[p], pane_out_offsets[p+1]) of (auction, count); windows are not used, only the panes
+ *   weighted : the FinalPartitioned side + MAX + join of flockgpu_q5_hot_items over rows that each carry a count (the
+ *              partial groups this partition received); the sum of `count` over a window must stay below 2^32.
+ * partial on N row-stripes, repartition of the groups by auction, weighted on what arrives == hot_items on all rows. */
+typedef struct {
+    const int32_t *auction;            /* device, ctx-owned */
+    const uint32_t *count;             /* device, ctx-owned */
+    const int64_t *pane_out_offsets;   /* host, n_panes + 1 */
+    int64_t rows;
+} flockgpu_q5_partial_result;
+int flockgpu_q5_partial_counts(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                               flockgpu_q5_partial_result *out);
+int flockgpu_q5_hot_items_weighted(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *count, int64_t rows,
+                                   const flockgpu_windows *win, flockgpu_q5_result *out);
+
 /* ---- q7 (SURVEY.md section 8(f) "next" query): bid JOIN (SELECT MAX(price) AS maxprice FROM bid) ON price = maxprice,
  * Projection [auction, price, bidder, b_date_time] (benchmarks/src/nexmark/query/q7.sql, q7_plan.fmt), per
  * Tumbling(10 s) window (benchmarks/src/nexmark/main.rs:119).  Every row that reaches the window's maximum is returned

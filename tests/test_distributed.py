@@ -63,6 +63,35 @@ class NumpyOps:
         off[1:] = torch.cumsum(lengths, 0)
         return off
 
+    def q5_partial(self, auction, schedule: WindowSchedule):
+        a = auction.numpy()
+        po = schedule.pane_row_offsets
+        keys, cnts, off = [], [], [0]
+        for p in range(len(po) - 1):
+            k, c = np.unique(a[po[p]:po[p + 1]], return_counts=True)
+            keys.append(k.astype(np.int32))
+            cnts.append(c.astype(np.int32))
+            off.append(off[-1] + len(k))
+        cat = lambda xs: torch.from_numpy(np.concatenate(xs) if xs else np.zeros(0, np.int32))
+        return cat(keys), cat(cnts), np.array(off, np.int64)
+
+    def q5_weighted(self, auction, count, schedule: WindowSchedule):
+        a, c = auction.numpy(), count.numpy().astype(np.uint32)
+        oa, on, off, mx = [], [], [0], []
+        for w in range(schedule.n_windows):
+            lo, hi = schedule.window_rows(w)
+            k, inv = np.unique(a[lo:hi], return_inverse=True)
+            tot = np.zeros(len(k), np.uint64)
+            np.add.at(tot, inv, c[lo:hi].astype(np.uint64))
+            m = tot.max() if len(tot) else 0
+            sel = tot == m if m else np.zeros(len(k), bool)
+            oa.append(k[sel].astype(np.int32))
+            on.append(tot[sel])
+            off.append(off[-1] + int(sel.sum()))
+            mx.append(int(m))
+        return (np.concatenate(oa) if oa else np.zeros(0, np.int32), np.concatenate(on) if on else np.zeros(0, np.uint64),
+                np.array(off, np.int64), np.array(mx, np.uint64))
+
 
 # ---------------------------------------------------------------- harness
 def _free_port():
@@ -218,34 +247,29 @@ def test_q3_join_shuffle_world2():
 
 
 def _q5_rank(rank, world):
-    from flock_amd.distributed import global_window_max, keep_global_winners, shuffle_relation
+    """q5_exchange itself (partial groups -> hash repartition -> weighted final -> all_reduce(MAX)) with numpy stand-ins
+    for the device steps."""
+    from flock_amd import Bids
+    from flock_amd.distributed import q5_exchange
     s = oracle.NexmarkStream(seed=SEED + 2, eps=EPS)
     b = s.bids(0, EPS * SECONDS, columns=("auction",))["auction"]
     b_off = lambda e: s.counts(0, e * EPS)[2]
     wins = oracle.hopping_windows(SECONDS, 10, 5)
     panes = [(e, e + 5) for e in range(0, SECONDS, 5)]
     rows, pane_sched = _local_rows(b_off, panes, rank, world)
-    cols, recv = shuffle_relation(NumpyOps(), {"auction": torch.from_numpy(b[rows])}, "auction", pane_sched)
-    a = cols["auction"].numpy()
-    loc_a, loc_n, off, loc_max = [], [], [0], []
-    for (e0, e1) in wins:
-        lo, hi = recv.window_rows(e0 // 5)[0], recv.window_rows(e1 // 5 - 1)[1]
-        oa, on = oracle.q5_hot_items(a[lo:hi])
-        loc_a.append(oa)
-        loc_n.append(on)
-        off.append(off[-1] + len(oa))
-        loc_max.append(int(on[0]) if len(on) else 0)
-    loc_max = np.array(loc_max, np.uint64)
-    gmax = global_window_max(loc_max, "cpu")
-    ka, kn, koff = keep_global_winners(np.concatenate(loc_a), np.concatenate(loc_n), np.array(off), loc_max, gmax)
+    sched = WindowSchedule(pane_sched.pane_row_offsets, np.array([e0 // 5 for e0, _ in wins], np.int32),
+                           np.array([e1 // 5 for _, e1 in wins], np.int32))
+    local = torch.from_numpy(b[rows])
+    shard = q5_exchange(None, Bids(auction=local, rows=len(rows)), sched, ops=NumpyOps())
     gathered = [None] * world
-    dist.all_gather_object(gathered, [sorted(zip(ka[koff[w]:koff[w + 1]].tolist(), kn[koff[w]:koff[w + 1]].tolist()))
+    dist.all_gather_object(gathered, [sorted(zip(shard.auction[shard.offsets[w]:shard.offsets[w + 1]].tolist(),
+                                                 shard.num[shard.offsets[w]:shard.offsets[w + 1]].tolist()))
                                       for w in range(len(wins))])
     for w, (e0, e1) in enumerate(wins):
         oa, on = oracle.q5_hot_items(b[b_off(e0):b_off(e1)])
         got = sorted(sum((gathered[r][w] for r in range(world)), []))
         assert got == sorted(zip(oa.tolist(), on.tolist())), f"q5 window {w}"
-        assert int(gmax[w]) == int(on[0])
+        assert int(shard.win_max[w]) == int(on[0])
 
 
 def test_q5_repartition_and_global_max_world2():

@@ -155,3 +155,74 @@ def test_scans_beyond_one_pass(ctx):
     rows, counts = ctx.partition_by_key(_dev(keys), sched, 8)
     want_rows, want_counts = NumpyOps().partition(torch.from_numpy(keys), sched, 8)
     assert np.array_equal(counts, want_counts) and np.array_equal(rows.cpu().numpy(), want_rows.numpy())
+
+
+# ------------------------------------------------------------------ q5.dag's two aggregation stages around the repartition
+def _q5_cases(rng, n):
+    return {
+        "generator": oracle.NexmarkStream(seed=11, eps=20_000).bids(0, 50 * 20_000, columns=("auction",))["auction"][:n],
+        "uniform_narrow": rng.integers(1000, 9000, n).astype(np.int32),          # wider than the LDS histogram: direct path
+        "uniform_int32": rng.integers(-2**31, 2**31 - 1, n).astype(np.int32),    # hash tables only
+        "few_keys": rng.integers(0, 7, n).astype(np.int32),
+        "sorted_runs": (np.arange(n) // 13 - 5).astype(np.int32),
+    }
+
+
+@pytest.mark.parametrize("case", ["generator", "uniform_narrow", "uniform_int32", "few_keys", "sorted_runs"])
+def test_q5_partial_then_weighted_equals_hot_items(ctx, case):
+    """partial counts per pane == np.unique per pane; weighted hot items over those groups (all panes, hopping windows) ==
+    hot items over the rows; and the same with the groups of two row-stripes concatenated pane by pane (what a partition
+    receives from two sources: a key may arrive twice inside a pane)."""
+    import torch
+    from flock_amd import Bids, WindowSchedule
+    rng = np.random.default_rng(7)
+    n = 600_000
+    a = _q5_cases(rng, n)[case]
+    n = len(a)
+    pane_off = np.array([0, 3, 3, 100_001, 250_000, 250_000 + 8192 * 20, n])
+    lo, hi = np.array([0, 1, 2, 3, 0], np.int32), np.array([2, 3, 4, 6, 6], np.int32)   # overlapping windows, one over everything
+    sched = WindowSchedule(pane_off, lo, hi)
+    key, cnt, poff = ctx.q5_partial_counts(Bids(auction=_dev(a), rows=n), sched)
+    k, c = key.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32)
+    for p in range(len(pane_off) - 1):
+        wk, wc = np.unique(a[pane_off[p]:pane_off[p + 1]], return_counts=True)
+        got = sorted(zip(k[poff[p]:poff[p + 1]].tolist(), c[poff[p]:poff[p + 1]].tolist()))
+        assert got == list(zip(wk.tolist(), wc.tolist())), (case, p)
+    want = ctx.q5_hot_items(Bids(auction=_dev(a), rows=n), sched)
+    wa, wn, woff = want.to_host()
+    got = ctx.q5_hot_items_weighted(key, cnt, WindowSchedule(poff, lo, hi))
+    ga, gn, goff = got.to_host()
+    assert np.array_equal(ga, wa) and np.array_equal(gn, wn) and np.array_equal(goff, woff)
+    assert np.array_equal(got.win_max(), want.win_max()) and np.array_equal(got.win_groups(), want.win_groups())
+    for w in range(len(lo)):   # ... and against the oracle
+        oa, on = oracle.q5_hot_items(a[pane_off[lo[w]]:pane_off[hi[w]]])
+        o = np.argsort(oa)   # ties: the engine orders a window's winners by auction
+        assert np.array_equal(ga[goff[w]:goff[w + 1]], oa[o]) and np.array_equal(gn[goff[w]:goff[w + 1]], on[o]), (case, w)
+    # two stripes of every pane, aggregated separately, concatenated pane by pane
+    mid = (pane_off[:-1] + pane_off[1:]) // 2
+    idx0 = np.concatenate([np.arange(pane_off[p], mid[p]) for p in range(len(mid))])
+    idx1 = np.concatenate([np.arange(mid[p], pane_off[p + 1]) for p in range(len(mid))])
+    parts = []
+    for idx, off in ((idx0, np.r_[0, np.cumsum(mid - pane_off[:-1])]), (idx1, np.r_[0, np.cumsum(pane_off[1:] - mid)])):
+        kk, cc, po = ctx.q5_partial_counts(Bids(auction=_dev(a[idx]), rows=len(idx)), WindowSchedule(off, lo, hi))
+        parts.append((kk.cpu().numpy(), cc.cpu().numpy(), po))
+    cat_k = np.concatenate([np.r_[parts[0][0][parts[0][2][p]:parts[0][2][p + 1]], parts[1][0][parts[1][2][p]:parts[1][2][p + 1]]]
+                            for p in range(len(mid))])
+    cat_c = np.concatenate([np.r_[parts[0][1][parts[0][2][p]:parts[0][2][p + 1]], parts[1][1][parts[1][2][p]:parts[1][2][p + 1]]]
+                            for p in range(len(mid))])
+    cat_off = parts[0][2] + parts[1][2]
+    g2 = ctx.q5_hot_items_weighted(_dev(cat_k.astype(np.int32)), _dev(cat_c.astype(np.int32)), WindowSchedule(cat_off, lo, hi))
+    ga2, gn2, goff2 = g2.to_host()
+    assert np.array_equal(ga2, wa) and np.array_equal(gn2, wn) and np.array_equal(goff2, woff), case
+
+
+def test_q5_exchange_world1_uses_partial_groups(ctx, world1):
+    """q5_exchange end to end on one rank through RCCL: identical to the single-GPU operator."""
+    from flock_amd import Bids, NEXMarkSource, Window
+    from flock_amd.distributed import q5_exchange
+    w = Window.hopping(10, 5)
+    g = NEXMarkSource(40, 30_000, w, seed=5).generate_data(ctx, relations=("bid",), bid_columns=("auction",))
+    sched = g.window_schedule("bid", w)
+    shard = q5_exchange(ctx, g.bids, sched)
+    a, n, off = ctx.q5_hot_items(g.bids, sched).to_host()
+    assert np.array_equal(shard.auction, a) and np.array_equal(shard.num, n) and np.array_equal(shard.offsets, off)
