@@ -34,9 +34,11 @@ constexpr int kSpan = 4096;                     // auction rows an LDS-staged ti
 constexpr int kMaxCategories = 64;              // per-window category range handled by the LDS accumulators
 
 struct WinTable {
-    int32_t base;    // min a_id of the window
-    uint32_t range;  // max - min + 1 (0: the window has no auctions)
-    uint64_t off;    // offset of the window's entries in the table arena
+    int32_t base;       // min a_id of the window
+    uint32_t range;     // max - min + 1 (0: the window has no auctions)
+    uint64_t off;       // offset of the window's entries in the table arena
+    int32_t first_row;  // row of the window's first auction
+    int32_t gapless;    // range == rows: ids are consecutive, so  row = first_row + (a_id - base)  without any lookup
 };
 
 __global__ __launch_bounds__(kBlock) void aq_build_kernel(const int32_t *__restrict__ a_id, int64_t n_rows, SegTiles st,
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void aq_build_kernel(const int32_t *__restr
 __device__ __forceinline__ int32_t auction_row_of(int32_t key, const WinTable &wt, const int32_t *__restrict__ tab, bool in) {
     const uint32_t idx = (uint32_t)key - (uint32_t)wt.base;
     const bool ok = in && idx < wt.range;
+    if (wt.gapless) return ok ? wt.first_row + (int32_t)idx : -1;  // (block-uniform) the generator's consecutive ids
     const int32_t row = tab[ok ? idx : 0u];
     return ok ? row : -1;
 }
@@ -97,12 +100,18 @@ __global__ __launch_bounds__(kBlock) void aq_final_kernel(const int32_t *__restr
         load4_i32(b_auction, r0, n_bids, key);
         load4_i32(b_price, r0, n_bids, price[it]);
         int64_t when[4];
+        if (r0 >= 0 && r0 + 4 <= n_bids) {  // four timestamps = two 16-byte loads (r0 is a multiple of 4)
+            const longlong2 w01 = *reinterpret_cast<const longlong2 *>(b_time + r0),
+                            w23 = *reinterpret_cast<const longlong2 *>(b_time + r0 + 2);
+            when[0] = w01.x; when[1] = w01.y; when[2] = w23.x; when[3] = w23.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) when[j] = (r0 + j >= 0 && r0 + j < n_bids) ? b_time[r0 + j] : 0;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r0 + j;
-            const bool in = r >= tr.lo && r < tr.hi;
-            when[j] = b_time[in ? r : tr.lo];  // tr.lo is a valid row whenever the tile has rows
-            row[it][j] = auction_row_of(key[j], wt, tab, in);
+            row[it][j] = auction_row_of(key[j], wt, tab, r >= tr.lo && r < tr.hi);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -314,8 +323,8 @@ int compute_finals(flockgpu_ctx *ctx, const char *who, const flockgpu_auction_ti
     if (bid->rows > 0 && (!bid->auction || !bid->price || !bid->b_date_time))
         return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: null bid column", who);
     if ((reinterpret_cast<uintptr_t>(auction->a_id) & 15) || (reinterpret_cast<uintptr_t>(bid->auction) & 15) ||
-        (reinterpret_cast<uintptr_t>(bid->price) & 15))
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: a_id, auction and price columns must be 16-byte aligned", who);
+        (reinterpret_cast<uintptr_t>(bid->price) & 15) || (reinterpret_cast<uintptr_t>(bid->b_date_time) & 15))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: a_id, auction, price and b_date_time columns must be 16-byte aligned", who);
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = s->n_win = auction_win->n_windows;
     std::vector<int64_t> ab(n_win), ae(n_win), bb(n_win), be(n_win);
@@ -337,7 +346,7 @@ int compute_finals(flockgpu_ctx *ctx, const char *who, const flockgpu_auction_ti
     uint64_t n_entries = 0;
     std::vector<WinTable> wins(std::max(n_win, 1));
     for (int w = 0; w < n_win; ++w) {
-        wins[w] = WinTable{0, 0, n_entries};
+        wins[w] = WinTable{0, 0, n_entries, 0, 0};
         if (ae[w] == ab[w]) continue;
         const int64_t mn = h_stats[w], mx = h_stats[n_win + w], range = mx - mn + 1;
         if (!h_stats[2 * n_win + w] || range > 8 * (ae[w] - ab[w]) + 1024)
@@ -346,6 +355,8 @@ int compute_finals(flockgpu_ctx *ctx, const char *who, const flockgpu_auction_ti
                         "a_id is left to the host engine)", who, w);
         wins[w].base = (int32_t)mn;
         wins[w].range = (uint32_t)range;
+        wins[w].first_row = (int32_t)ab[w];
+        wins[w].gapless = range == ae[w] - ab[w];
         n_entries += (uint64_t)range;
     }
     WinTable *h_wins = nullptr;
