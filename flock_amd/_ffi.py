@@ -117,6 +117,17 @@ class YsbResult(C.Structure):
                 ("campaign_bytes", C.c_int64)]
 
 
+class JsonField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32)]
+
+
+class JsonColumn(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("utf8", Utf8), ("utf8_bytes", C.c_int64)]
+
+
+JSON_INT32, JSON_INT64, JSON_UTF8 = 0, 1, 2
+
+
 class Q5PartialResult(C.Structure):
     _fields_ = [("auction", C.c_void_p), ("count", C.c_void_p), ("pane_out_offsets", C.POINTER(C.c_int64)), ("rows", C.c_int64)]
 
@@ -163,6 +174,7 @@ SYMBOLS = {
     "flockgpu_take_i64": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "flockgpu_take_utf8": (_i, [_vp, C.POINTER(Utf8), _vp, _i64, C.c_int32, C.POINTER(Utf8), C.POINTER(_i64)]),
     "flockgpu_inclusive_scan_i32": (_i, [_vp, _vp, _i64]),
+    "flockgpu_json_lines_decode": (_i, [_vp, _vp, _i64, C.POINTER(JsonField), _i, C.POINTER(JsonColumn), C.POINTER(_i64)]),
     "flockgpu_q5_partial_counts": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5PartialResult)]),
     "flockgpu_q5_hot_items_weighted": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Windows), C.POINTER(Q5Result)]),
     "flockgpu_q11_user_sessions": (_i, [_vp, C.POINTER(BidCols), C.POINTER(_i64), _i, _i, _i64, C.POINTER(Q11Result)]),

@@ -1,0 +1,596 @@
+// Newline-delimited JSON -> Arrow columns on gfx950 (SURVEY.md section 8(f) rank 3, and the decode step of row a12):
+// the reference keeps every epoch's events as serde_json lines (flock/src/datasource/nexmark/generator.rs:79-93) and turns
+// them into RecordBatches with arrow's json::Reader at the granule (`event_bytes_to_batch`, flock/src/transmute.rs:255-266,
+// called from nexmark.rs:180-205) -- by the survey's own account the reference's real bottleneck.  HBM-bound byte work,
+// no MFMA.
+//
+//   lines   : count -> scan -> emit over 16 KiB tiles of the text: every raw 0x0A ends a line (JSON strings cannot hold one)
+//   parse   : 256 lines per workgroup; their bytes are one contiguous range, staged in LDS with 16-byte loads; one lane
+//             walks one line: keys matched against the schema's field names, integers parsed exactly (sign, overflow),
+//             strings delimited with escape awareness, unknown keys skipped with a depth-counting value skipper.
+//             Int32 / Int64 (Timestamp) columns are written directly (row = line: coalesced); for a Utf8 field the lane
+//             records where the value's bytes lie in the INPUT (start, end) and whether it holds escapes
+//   strings : a field without escapes is exactly a `take` of byte ranges of the input, so it reuses the Utf8 gather
+//             (lengths -> tile scan -> LDS-staged emit, gather.hip) with (start, end) pairs as the "offsets"; a field
+//             with escapes goes through an unescaping copy (one lane per value)
+// Numbers with a fraction or an exponent, blank lines, keys with escapes and rows that lack a schema field are reported
+// as errors with their line number (the generator's lines never have them): FLOCKGPU_ERR_UNSUPPORTED / _INVALID.
+#include <algorithm>
+#include <cstring>
+
+#include "gather.hpp"
+
+using namespace flockgpu;
+
+namespace {
+
+constexpr int kMaxFields = 16;
+constexpr int kMaxName = 32;
+constexpr int kNlBytes = 64;                    // bytes per lane in the newline passes
+constexpr int kNlTile = kBlock * kNlBytes;      // 16 KiB
+constexpr int kParseLines = kBlock;             // lines per workgroup
+constexpr int kStageBytes = 40 * 1024;          // LDS staging of a workgroup's lines (3 workgroups per CU)
+
+enum : int32_t { kInt32 = 0, kInt64 = 1, kUtf8 = 2 };
+enum : uint32_t { kErrSyntax = 1, kErrNumber = 2, kErrMissing = 3, kErrBlank = 4, kErrKeyEscape = 5, kErrRange = 6 };
+
+struct JsonSpec {
+    int32_t n;
+    int32_t type[kMaxFields];
+    int32_t name_len[kMaxFields];
+    char name[kMaxFields][kMaxName];
+};
+
+struct JsonOut {
+    void *values[kMaxFields];    // int32 / int64 columns
+    int32_t *pairs[kMaxFields];  // Utf8: (start, end) of the raw value in the input, 2 per row
+    int32_t *ulen[kMaxFields];   // Utf8: length after unescaping
+};
+
+// ---- line index --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t newline_mask(const uint8_t *__restrict__ bytes, int64_t n, int64_t p0) {
+    uint64_t m = 0;
+    if (p0 + kNlBytes <= n) {
+#pragma unroll
+        for (int q = 0; q < kNlBytes / 16; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + p0 + q * 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) m |= (uint64_t)(((w[i] >> (8 * b)) & 0xFFu) == 0x0Au) << (q * 16 + i * 4 + b);
+        }
+    } else {
+        for (int i = 0; i < kNlBytes; ++i)
+            if (p0 + i < n && bytes[p0 + i] == 0x0A) m |= uint64_t(1) << i;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(kBlock) void json_newline_count_kernel(const uint8_t *__restrict__ bytes, int64_t n,
+                                                                   uint32_t *__restrict__ counts) {
+    const int64_t p0 = (int64_t)blockIdx.x * kNlTile + (int64_t)threadIdx.x * kNlBytes;
+    const uint32_t c = (uint32_t)__popcll((unsigned long long)newline_mask(bytes, n, p0));
+    const uint32_t incl = wave_incl_scan_u32(c);
+    if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
+}
+
+// line_start[k + 1] = position after the k-th newline
+__global__ __launch_bounds__(kBlock) void json_newline_emit_kernel(const uint8_t *__restrict__ bytes, int64_t n,
+                                                                  const uint32_t *__restrict__ counts,
+                                                                  const uint64_t *__restrict__ tile_base,
+                                                                  int32_t *__restrict__ line_start) {
+    const int64_t p0 = (int64_t)blockIdx.x * kNlTile + (int64_t)threadIdx.x * kNlBytes;
+    uint64_t m = newline_mask(bytes, n, p0);
+    const uint32_t c = (uint32_t)__popcll((unsigned long long)m);
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
+    const int wave = threadIdx.x >> 6;
+    uint64_t k = tile_base[blockIdx.x] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u) +
+                 wave_incl_scan_u32(c) - c;
+    for (; m; m &= m - 1) line_start[++k] = (int32_t)(p0 + (__ffsll((unsigned long long)m) - 1) + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+}
+
+// ---- one line ------------------------------------------------------------------------------------------------------
+template <bool kLds>
+struct Text {
+    const uint8_t *g;       // the input
+    const uint8_t *s;       // LDS copy of [s_base, ...)
+    int32_t s_base;
+    __device__ __forceinline__ uint32_t at(int32_t p) const { return kLds ? s[p - s_base] : g[p]; }
+};
+
+__device__ __forceinline__ bool is_ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+__device__ __forceinline__ int hex_of(uint32_t c) {
+    return c >= '0' && c <= '9' ? (int)c - '0' : c >= 'a' && c <= 'f' ? (int)c - 'a' + 10 : c >= 'A' && c <= 'F' ? (int)c - 'A' + 10 : -1;
+}
+
+// p at the opening quote.  Returns the position after the closing quote, or -1; [*b, *e) = raw bytes between the quotes,
+// *ulen = bytes after unescaping, *esc = the value holds a backslash.
+template <bool kLds>
+__device__ int32_t scan_string(const Text<kLds> &t, int32_t p, int32_t end, int32_t *b, int32_t *e, int32_t *ulen, bool *esc) {
+    ++p;
+    *b = p;
+    int32_t len = 0;
+    bool any = false;
+    while (p < end) {
+        const uint32_t c = t.at(p);
+        if (c == '"') {
+            *e = p;
+            *ulen = len;
+            *esc = any;
+            return p + 1;
+        }
+        if (c < 0x20) return -1;  // raw control characters are not allowed inside a JSON string
+        if (c == '\\') {
+            any = true;
+            if (p + 1 >= end) return -1;
+            const uint32_t d = t.at(p + 1);
+            if (d == 'u') {
+                if (p + 6 > end) return -1;
+                int cp = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const int h = hex_of(t.at(p + 2 + i));
+                    if (h < 0) return -1;
+                    cp = cp * 16 + h;
+                }
+                p += 6;
+                if (cp >= 0xD800 && cp < 0xDC00) {  // high surrogate: must be followed by \uDC00..DFFF
+                    if (p + 6 > end || t.at(p) != '\\' || t.at(p + 1) != 'u') return -1;
+                    int lo = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        const int h = hex_of(t.at(p + 2 + i));
+                        if (h < 0) return -1;
+                        lo = lo * 16 + h;
+                    }
+                    if (lo < 0xDC00 || lo > 0xDFFF) return -1;
+                    p += 6;
+                    len += 4;
+                } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                    return -1;
+                } else {
+                    len += cp < 0x80 ? 1 : cp < 0x800 ? 2 : 3;
+                }
+                continue;
+            }
+            if (!(d == '"' || d == '\\' || d == '/' || d == 'b' || d == 'f' || d == 'n' || d == 'r' || d == 't')) return -1;
+            p += 2;
+            ++len;
+            continue;
+        }
+        ++p;
+        ++len;
+    }
+    return -1;
+}
+
+// Skips any JSON value starting at p (after white space); returns the position after it or -1.
+template <bool kLds>
+__device__ int32_t skip_value(const Text<kLds> &t, int32_t p, int32_t end) {
+    if (p >= end) return -1;
+    uint32_t c = t.at(p);
+    if (c == '"') {
+        int32_t b, e, u;
+        bool esc;
+        return scan_string(t, p, end, &b, &e, &u, &esc);
+    }
+    if (c == '{' || c == '[') {
+        int depth = 0;
+        while (p < end) {
+            c = t.at(p);
+            if (c == '"') {
+                int32_t b, e, u;
+                bool esc;
+                p = scan_string(t, p, end, &b, &e, &u, &esc);
+                if (p < 0) return -1;
+                continue;
+            }
+            if (c == '{' || c == '[') ++depth;
+            if (c == '}' || c == ']') {
+                if (--depth == 0) return p + 1;
+            }
+            ++p;
+        }
+        return -1;
+    }
+    // number / true / false / null: up to the next delimiter
+    const int32_t p0 = p;
+    while (p < end) {
+        c = t.at(p);
+        if (c == ',' || c == '}' || c == ']' || is_ws(c)) break;
+        ++p;
+    }
+    return p > p0 ? p : -1;
+}
+
+template <bool kLds>
+__device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, const JsonSpec &spec, int64_t row, const JsonOut &out) {
+    while (end > p && is_ws(t.at(end - 1))) --end;
+    while (p < end && is_ws(t.at(p))) ++p;
+    if (p >= end) return kErrBlank;
+    if (t.at(p) != '{') return kErrSyntax;
+    ++p;
+    uint32_t seen = 0;
+    while (p < end && is_ws(t.at(p))) ++p;
+    const bool empty_object = p < end && t.at(p) == '}';
+    if (empty_object) ++p;
+    while (!empty_object) {  // one member per trip; leaves through the closing brace
+        while (p < end && is_ws(t.at(p))) ++p;
+        if (p >= end) return kErrSyntax;
+        if (t.at(p) != '"') return kErrSyntax;
+        int32_t kb, ke, ku;
+        bool kesc;
+        p = scan_string(t, p, end, &kb, &ke, &ku, &kesc);
+        if (p < 0) return kErrSyntax;
+        if (kesc) return kErrKeyEscape;
+        int f = -1;
+        for (int i = 0; i < spec.n; ++i) {
+            if (spec.name_len[i] != ke - kb) continue;
+            bool same = true;
+            for (int j = 0; j < ke - kb; ++j) same = same && t.at(kb + j) == (uint32_t)(uint8_t)spec.name[i][j];
+            if (same) {
+                f = i;
+                break;
+            }
+        }
+        while (p < end && is_ws(t.at(p))) ++p;
+        if (p >= end || t.at(p) != ':') return kErrSyntax;
+        ++p;
+        while (p < end && is_ws(t.at(p))) ++p;
+        if (p >= end) return kErrSyntax;
+        if (f < 0) {
+            p = skip_value(t, p, end);
+            if (p < 0) return kErrSyntax;
+        } else if (spec.type[f] == kUtf8) {
+            if (t.at(p) != '"') return kErrSyntax;
+            int32_t b, e, u;
+            bool esc;
+            p = scan_string(t, p, end, &b, &e, &u, &esc);
+            if (p < 0) return kErrSyntax;
+            out.pairs[f][2 * row] = b;
+            out.pairs[f][2 * row + 1] = e;
+            out.ulen[f][row] = esc ? -u - 1 : u;  // negative: needs unescaping (length = -(v + 1))
+            seen |= 1u << f;
+        } else {
+            bool neg = false;
+            if (t.at(p) == '-') {
+                neg = true;
+                ++p;
+            }
+            if (p >= end || t.at(p) < '0' || t.at(p) > '9') return kErrSyntax;  // not a number at all (a string, true, null ...)
+            uint64_t v = 0;
+            int digits = 0;
+            while (p < end) {
+                const uint32_t c = t.at(p);
+                if (c < '0' || c > '9') break;
+                if (++digits > 19) return kErrRange;
+                v = v * 10 + (c - '0');
+                ++p;
+            }
+            if (p < end) {
+                const uint32_t c = t.at(p);
+                if (!(c == ',' || c == '}' || is_ws(c))) return kErrNumber;  // fraction / exponent: not an integer literal
+            }
+            if (v > (uint64_t)0x7fffffffffffffffull + (neg ? 1u : 0u)) return kErrRange;
+            const int64_t sv = neg ? (int64_t)(0 - v) : (int64_t)v;
+            if (spec.type[f] == kInt32) {
+                if (sv < -2147483648ll || sv > 2147483647ll) return kErrRange;
+                reinterpret_cast<int32_t *>(out.values[f])[row] = (int32_t)sv;
+            } else {
+                reinterpret_cast<int64_t *>(out.values[f])[row] = sv;
+            }
+            seen |= 1u << f;
+        }
+        while (p < end && is_ws(t.at(p))) ++p;
+        if (p >= end) return kErrSyntax;
+        if (t.at(p) == ',') {  // a member must follow: the next trip insists on a key
+            ++p;
+            continue;
+        }
+        if (t.at(p) == '}') {
+            ++p;
+            break;
+        }
+        return kErrSyntax;
+    }
+    if (p != end) return kErrSyntax;  // trailing bytes after the object
+    if (seen != (spec.n >= 32 ? ~0u : (1u << spec.n) - 1u)) return kErrMissing;
+    return 0;
+}
+
+// err[0] = first bad line + 1 (0: none) as atomicMin over (line + 1) stored inverted, err[1] = its code
+__global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__restrict__ bytes, int64_t n_bytes,
+                                                            const int32_t *__restrict__ line_start, int64_t n_lines, JsonSpec spec,
+                                                            JsonOut out, unsigned long long *err) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    const int64_t l0 = (int64_t)blockIdx.x * kParseLines;
+    const int64_t l1 = min(l0 + kParseLines, n_lines);
+    const int32_t b0 = line_start[l0], b1 = min((int64_t)line_start[l1], n_bytes);
+    const int32_t a0 = b0 & ~15;
+    const bool staged = b1 - a0 <= kStageBytes;  // block-uniform
+    if (staged) {
+        for (int32_t o = a0 + (int32_t)threadIdx.x * 16; o < b1; o += kBlock * 16) {
+            if ((int64_t)o + 16 <= n_bytes) {
+                *reinterpret_cast<uint4 *>(s_stage + (o - a0)) = *reinterpret_cast<const uint4 *>(bytes + o);
+            } else {
+                for (int32_t i = o; i < b1; ++i) s_stage[i - a0] = bytes[i];
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t line = l0 + threadIdx.x;
+    if (line >= n_lines) return;
+    const int32_t p = line_start[line];
+    const int32_t e = min((int64_t)line_start[line + 1] - 1, n_bytes);  // without the newline
+    uint32_t rc;
+    if (staged) {
+        const Text<true> t{bytes, s_stage, a0};
+        rc = parse_line(t, p, e, spec, line, out);
+    } else {
+        const Text<false> t{bytes, nullptr, 0};
+        rc = parse_line(t, p, e, spec, line, out);
+    }
+    if (rc) atomicMin(err, ((unsigned long long)line << 8) | rc);
+}
+
+// Utf8 field after the parse: len[i] = |ulen[i]| (unescaped length), any = some value needs unescaping
+__global__ __launch_bounds__(kBlock) void json_string_lengths_kernel(const int32_t *__restrict__ ulen, int64_t n, int32_t *__restrict__ len,
+                                                                     uint32_t *any) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool esc = false;
+    if (i < n) {
+        const int32_t u = ulen[i];
+        esc = u < 0;
+        len[i + 1] = esc ? -(u + 1) : u;
+    }
+    if (i == 0) len[0] = 0;
+    if (__ballot(esc) && lane_id() == 0) atomicOr(any, 1u);
+}
+
+__device__ __forceinline__ int utf8_put(uint8_t *dst, int cp) {
+    if (cp < 0x80) {
+        dst[0] = (uint8_t)cp;
+        return 1;
+    }
+    if (cp < 0x800) {
+        dst[0] = (uint8_t)(0xC0 | (cp >> 6));
+        dst[1] = (uint8_t)(0x80 | (cp & 0x3F));
+        return 2;
+    }
+    if (cp < 0x10000) {
+        dst[0] = (uint8_t)(0xE0 | (cp >> 12));
+        dst[1] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F));
+        dst[2] = (uint8_t)(0x80 | (cp & 0x3F));
+        return 3;
+    }
+    dst[0] = (uint8_t)(0xF0 | (cp >> 18));
+    dst[1] = (uint8_t)(0x80 | ((cp >> 12) & 0x3F));
+    dst[2] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F));
+    dst[3] = (uint8_t)(0x80 | (cp & 0x3F));
+    return 4;
+}
+
+// Byte a single-character escape stands for (the character after the backslash; `"`, `\` and `/` stand for themselves).
+__device__ __attribute__((noinline)) uint32_t escape_value(uint32_t d) {
+    uint32_t v = d;
+    if (d == 'b') v = 8;
+    if (d == 'f') v = 12;
+    if (d == 'n') v = 10;
+    if (d == 'r') v = 13;
+    if (d == 't') v = 9;
+    return v;
+}
+
+// The unescaping copy of a field that holds escapes: one lane per value (offsets already scanned).  (One store site and
+// one advance per trip: the first version, with a store in each branch, faulted on "\b\f"-like values -- two different
+// single-character escapes in a row -- although the same source ran clean on the host under ASan.)
+__global__ __launch_bounds__(kBlock) void json_unescape_kernel(const uint8_t *bytes, const int32_t *pairs, const int32_t *off, int64_t n,
+                                                               uint8_t *dst) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t p = pairs[2 * i];
+    const int32_t e = pairs[2 * i + 1];
+    int64_t o = off[i];
+    while (p < e) {
+        uint32_t c = bytes[p];
+        int32_t adv = 1;
+        if (c == '\\') {
+            const uint32_t d = bytes[p + 1];
+            adv = 2;
+            if (d == 'u') {
+                int cp = 0;
+                for (int k = 0; k < 4; ++k) cp = cp * 16 + hex_of(bytes[p + 2 + k]);
+                adv = 6;
+                if (cp >= 0xD800 && cp < 0xDC00) {
+                    int lo = 0;
+                    for (int k = 0; k < 4; ++k) lo = lo * 16 + hex_of(bytes[p + 8 + k]);
+                    adv = 12;
+                    cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                }
+                if (cp >= 0x80) {  // multi-byte: everything but the last byte here, the last one at the common store
+                    uint8_t tmp[4];
+                    const int len = utf8_put(tmp, cp);
+                    for (int k = 0; k + 1 < len; ++k) dst[o++] = tmp[k];
+                    c = tmp[len - 1];
+                } else {
+                    c = (uint32_t)cp;
+                }
+            } else {
+                c = escape_value(d);
+            }
+        }
+        dst[o++] = (uint8_t)c;
+        p += adv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void json_even_rows_kernel(int32_t *__restrict__ rows, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) rows[i] = (int32_t)(2 * i);
+}
+
+}  // namespace
+
+extern "C" {
+
+int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n_bytes, const flockgpu_json_field *fields,
+                               int32_t n_fields, flockgpu_json_column *out, int64_t *rows) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!fields || !out || !rows || n_bytes < 0 || n_fields < 1 || (n_bytes > 0 && !json))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "json: null argument");
+    if (n_fields > kMaxFields) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "json: more than %d fields", kMaxFields);
+    if (n_bytes >= (int64_t(1) << 31) - 16)
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "json: at most 2^31 bytes of text per call (Arrow Utf8 offsets are int32)");
+    if (reinterpret_cast<uintptr_t>(json) & 15) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "json: the text must be 16-byte aligned");
+    JsonSpec spec{};
+    spec.n = n_fields;
+    for (int f = 0; f < n_fields; ++f) {
+        if (!fields[f].name || fields[f].type < kInt32 || fields[f].type > kUtf8) return fail(ctx, FLOCKGPU_ERR_INVALID, "json: bad field %d", f);
+        const size_t len = std::strlen(fields[f].name);
+        if (len == 0 || len >= (size_t)kMaxName) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "json: field name longer than %d bytes", kMaxName - 1);
+        spec.type[f] = fields[f].type;
+        spec.name_len[f] = (int32_t)len;
+        std::memcpy(spec.name[f], fields[f].name, len);
+    }
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    for (int f = 0; f < n_fields; ++f) out[f] = flockgpu_json_column{};
+    *rows = 0;
+
+    // ---- line index
+    const int64_t tiles = div_up(std::max<int64_t>(n_bytes, 1), kNlTile);
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr, *h_total = nullptr;
+    uint8_t *h_last = nullptr;
+    FG_TRY(arena_get_t(ctx, "json.nl_counts", (size_t)tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, "json.nl_base", (size_t)tiles + 1, &tile_base));
+    FG_TRY(pinned_get_t(ctx, "json.nl_total", 2, &h_total));
+    h_last = reinterpret_cast<uint8_t *>(h_total + 1);
+    if (n_bytes == 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "json_newline_count_kernel");
+        hipLaunchKernelGGL(json_newline_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, json, n_bytes, counts);
+    }
+    FG_TRY(check_launch(ctx, "json_newline_count_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, (int32_t)tiles, tile_base, nullptr, 0, nullptr));
+    FG_HIP(ctx, hipMemcpyAsync(h_total, tile_base + tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_last, json + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n_newlines = (int64_t)*h_total;
+    const bool open_tail = *h_last != 0x0A;  // the last line has no newline
+    const int64_t n_lines = n_newlines + (open_tail ? 1 : 0);
+    int32_t *line_start = nullptr;
+    FG_TRY(arena_get_t(ctx, "json.line_start", (size_t)n_lines + 2, &line_start));
+    {
+        LaunchScope ls(ctx, "json_newline_emit_kernel");
+        hipLaunchKernelGGL(json_newline_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, json, n_bytes, counts, tile_base,
+                           line_start);
+    }
+    FG_TRY(check_launch(ctx, "json_newline_emit_kernel"));
+    if (open_tail) {  // a virtual newline at n_bytes closes the last line
+        const int32_t v = (int32_t)(n_bytes + 1);
+        int32_t *h_v = nullptr;
+        FG_TRY(pinned_get_t(ctx, "json.tail", 1, &h_v));
+        *h_v = v;
+        FG_HIP(ctx, hipMemcpyAsync(line_start + n_lines, h_v, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+
+    // ---- parse
+    JsonOut jo{};
+    for (int f = 0; f < n_fields; ++f) {
+        char name[48];
+        if (spec.type[f] == kUtf8) {
+            snprintf(name, sizeof name, "json.pairs.%d", f);
+            FG_TRY(arena_get_t(ctx, name, (size_t)2 * n_lines + 4, &jo.pairs[f]));
+            snprintf(name, sizeof name, "json.ulen.%d", f);
+            FG_TRY(arena_get_t(ctx, name, (size_t)n_lines + 4, &jo.ulen[f]));
+        } else {
+            snprintf(name, sizeof name, "json.values.%d", f);
+            void *p = nullptr;
+            FG_TRY(arena_get(ctx, name, ((size_t)n_lines + 4) * (spec.type[f] == kInt32 ? 4 : 8), &p));
+            jo.values[f] = p;
+        }
+    }
+    unsigned long long *d_err = nullptr, *h_err = nullptr;
+    uint32_t *d_any = nullptr, *h_any = nullptr;
+    FG_TRY(arena_get_t(ctx, "json.err", 1, &d_err));
+    FG_TRY(pinned_get_t(ctx, "json.err", 1, &h_err));
+    FG_TRY(arena_get_t(ctx, "json.any_escape", kMaxFields, &d_any));
+    FG_TRY(pinned_get_t(ctx, "json.any_escape", kMaxFields, &h_any));
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0xFF, sizeof(unsigned long long), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_any, 0, sizeof(uint32_t) * kMaxFields, ctx->stream));
+    if (n_lines > 0) {
+        LaunchScope ls(ctx, "json_parse_kernel");
+        hipLaunchKernelGGL(json_parse_kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), 0, ctx->stream, json, n_bytes,
+                           line_start, n_lines, spec, jo, d_err);
+    }
+    FG_TRY(check_launch(ctx, "json_parse_kernel"));
+
+    // ---- strings: lengths -> offsets
+    int32_t *soff[kMaxFields] = {};
+    for (int f = 0; f < n_fields; ++f) {
+        if (spec.type[f] != kUtf8) continue;
+        char name[48];
+        snprintf(name, sizeof name, "json.str_off.%d", f);
+        FG_TRY(arena_get_t(ctx, name, (size_t)n_lines + 4, &soff[f]));
+        if (n_lines > 0) {
+            hipLaunchKernelGGL(json_string_lengths_kernel, dim3((unsigned)div_up(n_lines, kBlock)), dim3(kBlock), 0, ctx->stream, jo.ulen[f],
+                               n_lines, soff[f], d_any + f);
+            FG_TRY(check_launch(ctx, "json_string_lengths_kernel"));
+        }
+    }
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_any, d_any, sizeof(uint32_t) * kMaxFields, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*h_err != ~0ull) {
+        const long long line = (long long)(*h_err >> 8);
+        const uint32_t code = (uint32_t)(*h_err & 0xFF);
+        static const char *what[] = {"", "malformed JSON", "number with a fraction / exponent (integer literal expected)",
+                                     "a schema field is missing", "blank line", "escape sequence in a key", "integer out of range"};
+        return fail(ctx, code == kErrNumber || code == kErrBlank || code == kErrKeyEscape ? FLOCKGPU_ERR_UNSUPPORTED : FLOCKGPU_ERR_INVALID,
+                    "json: line %lld: %s", line + 1, what[code < 7 ? code : 1]);
+    }
+    int32_t *even = nullptr;
+    bool have_even = false;
+    for (int f = 0; f < n_fields; ++f) {
+        if (spec.type[f] != kUtf8) {
+            out[f].values = jo.values[f];
+            continue;
+        }
+        char name[48];
+        if (!h_any[f]) {  // a plain take of byte ranges of the input
+            if (!have_even) {
+                FG_TRY(arena_get_t(ctx, "json.even_rows", (size_t)n_lines + 4, &even));
+                if (n_lines > 0) {
+                    hipLaunchKernelGGL(json_even_rows_kernel, dim3((unsigned)div_up(n_lines, kBlock)), dim3(kBlock), 0, ctx->stream, even, n_lines);
+                    FG_TRY(check_launch(ctx, "json_even_rows_kernel"));
+                }
+                have_even = true;
+            }
+            snprintf(name, sizeof name, "json.utf8.%d", f);
+            flockgpu_utf8 src{jo.pairs[f], json};
+            FG_TRY(gather_utf8(ctx, name, src, even, n_lines, &out[f].utf8, &out[f].utf8_bytes));
+        } else {
+            FG_TRY(inclusive_scan_i32(ctx, "json.str_scan", soff[f], n_lines + 1));
+            int32_t *h_tot = nullptr;
+            FG_TRY(pinned_get_t(ctx, "json.str_total", 1, &h_tot));
+            FG_HIP(ctx, hipMemcpyAsync(h_tot, soff[f] + n_lines, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            uint8_t *dst = nullptr;
+            snprintf(name, sizeof name, "json.str_bytes.%d", f);
+            FG_TRY(arena_get_t(ctx, name, (size_t)*h_tot + 16, &dst));
+            if (n_lines > 0) {
+                LaunchScope ls(ctx, "json_unescape_kernel");
+                hipLaunchKernelGGL(json_unescape_kernel, dim3((unsigned)div_up(n_lines, kBlock)), dim3(kBlock), 0, ctx->stream, json, jo.pairs[f],
+                                   soff[f], n_lines, dst);
+            }
+            FG_TRY(check_launch(ctx, "json_unescape_kernel"));
+            out[f].utf8.offsets = soff[f];
+            out[f].utf8.data = dst;
+            out[f].utf8_bytes = *h_tot;
+        }
+    }
+    *rows = n_lines;
+    return FLOCKGPU_OK;
+}
+
+}  // extern "C"

@@ -399,6 +399,36 @@ class GpuContext:
         self._check(self._lib.flockgpu_q5_hot_items(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q5Out(self, r, windows.n_windows)
 
+    def json_lines_decode(self, text, fields):
+        """Newline-delimited JSON (uint8 device tensor) -> columns: `fields` = [(name, "int32" | "int64" | "utf8")].
+        Returns {name: int32 / int64 device tensor | DeviceUtf8} and the row count (`event_bytes_to_batch`,
+        flock/src/transmute.rs:255-266, on the device)."""
+        torch = _torch()
+        kinds = {"int32": _ffi.JSON_INT32, "int64": _ffi.JSON_INT64, "utf8": _ffi.JSON_UTF8}
+        spec = (_ffi.JsonField * len(fields))(*[_ffi.JsonField(n.encode(), kinds[t]) for n, t in fields])
+        cols = (_ffi.JsonColumn * len(fields))()
+        rows = C.c_int64(0)
+        self._check(self._lib.flockgpu_json_lines_decode(self._h, text.data_ptr(), text.numel(), spec, len(fields), cols, C.byref(rows)))
+        n, dev, out = rows.value, f"cuda:{self.device}", {}
+        for (name, t), c in zip(fields, cols):
+            if t == "utf8":
+                off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                data = torch.empty(max(int(c.utf8_bytes), 16), dtype=torch.uint8, device=dev)
+                if n:
+                    self._check(self._lib.flockgpu_memcpy(self._h, off.data_ptr(), c.utf8.offsets, (n + 1) * 4, _ffi.D2D))
+                else:
+                    off.zero_()
+                if c.utf8_bytes:
+                    self._check(self._lib.flockgpu_memcpy(self._h, data.data_ptr(), c.utf8.data, int(c.utf8_bytes), _ffi.D2D))
+                out[name] = DeviceUtf8(off, data)
+            else:
+                dt, w = (torch.int32, 4) if t == "int32" else (torch.int64, 8)
+                col = torch.empty(n, dtype=dt, device=dev)
+                if n:
+                    self._check(self._lib.flockgpu_memcpy(self._h, col.data_ptr(), c.values, n * w, _ffi.D2D))
+                out[name] = col
+        return out, n
+
     def q5_partial_counts(self, bids: Bids, windows: WindowSchedule):
         """q5.dag's Partial stage: COUNT(*) GROUP BY auction per PANE of the schedule.  Returns (auction int32 tensor, count
         int32 tensor holding uint32 counts, pane_out_offsets np.int64[n_panes + 1])."""

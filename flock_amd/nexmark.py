@@ -183,6 +183,23 @@ class NEXMarkSource:
         return NEXMarkStream(self, bids, auctions, persons)
 
 
+# Arrow schemas of the three relations as the json::Reader sees them (flock/src/datasource/nexmark/event.rs:130-149,
+# 220-245, 336-352): usize -> Int32, Epoch -> Timestamp(ms) (Int64 here), String -> Utf8.
+NEXMARK_JSON_SCHEMAS = {
+    "bid": [("auction", "int32"), ("bidder", "int32"), ("price", "int32"), ("b_date_time", "int64")],
+    "auction": [("a_id", "int32"), ("item_name", "utf8"), ("description", "utf8"), ("initial_bid", "int32"), ("reserve", "int32"),
+                ("a_date_time", "int64"), ("expires", "int64"), ("seller", "int32"), ("category", "int32")],
+    "person": [("p_id", "int32"), ("name", "utf8"), ("email_address", "utf8"), ("credit_card", "utf8"), ("city", "utf8"),
+               ("state", "utf8"), ("p_date_time", "int64")],
+}
+
+
+def event_bytes_to_columns(ctx: GpuContext, text, relation: str):
+    """`event_bytes_to_batch(&event.<relation>, NEXMARK_<RELATION>, ..)` (nexmark.rs:180-205) on the device: the epoch's
+    serde_json lines (uint8 device tensor) -> the relation's columns.  Returns ({name: column}, rows)."""
+    return ctx.json_lines_decode(text, NEXMARK_JSON_SCHEMAS[relation])
+
+
 def synthetic_side_input(ctx: GpuContext, stream: NEXMarkStream, stride: int = 6007):
     """A bounded q13 side input for a generated stream: key = every `stride`-th auction id the stream's bids can name,
     value = a function of the key.  (The reference reads the table from a user-supplied CSV in S3,

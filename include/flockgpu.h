@@ -312,6 +312,28 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
  * stable.  `keys` is a 16-byte aligned device column; the outputs are ctx-owned device arrays of `rows` entries. */
 int flockgpu_group_rows_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, int32_t **out_keys, int32_t **out_rows);
 
+/* ---- JSON lines -> columns (the decode step of `select_event_to_batches`,
+ * flock/src/datasource/nexmark/nexmark.rs:180-205): the reference keeps an epoch's events as newline-delimited
+ * serde_json objects (generator.rs:79-93) and decodes them with arrow's json::Reader against the relation's schema
+ * (`event_bytes_to_batch`, flock/src/transmute.rs:255-266).  Every line is one object; members are matched to `fields`
+ * by name in any order, other members are skipped; row = line.  Int32 / Int64 fields take JSON integer literals (a
+ * Timestamp(ms) column is Int64 here), Utf8 fields take strings (all escapes, \uXXXX surrogate pairs included).
+ * Errors name the first offending line: a missing field, malformed JSON or an integer outside the type ->
+ * FLOCKGPU_ERR_INVALID; a number with a fraction / exponent, a blank line, an escape inside a KEY ->
+ * FLOCKGPU_ERR_UNSUPPORTED.  `json`: device text, 16-byte aligned, below 2^31 bytes per call. */
+enum { FLOCKGPU_JSON_INT32 = 0, FLOCKGPU_JSON_INT64 = 1, FLOCKGPU_JSON_UTF8 = 2 };
+typedef struct {
+    const char *name; /* host, at most 31 bytes */
+    int32_t type;     /* FLOCKGPU_JSON_* */
+} flockgpu_json_field;
+typedef struct {
+    void *values;       /* device, ctx-owned: int32_t / int64_t per row (NULL for a Utf8 field) */
+    flockgpu_utf8 utf8; /* device, ctx-owned: offsets (rows + 1) and bytes of a Utf8 field */
+    int64_t utf8_bytes;
+} flockgpu_json_column;
+int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json /* device */, int64_t n_bytes, const flockgpu_json_field *fields,
+                               int32_t n_fields, flockgpu_json_column *out /* n_fields */, int64_t *rows);
+
 /* ---- Yahoo Streaming Benchmark: per Tumbling(10 s) window (benchmarks/src/ysb/main.rs:91)
  *   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = lit
  *   GROUP BY campaign_id         (benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346)

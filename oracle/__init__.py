@@ -504,3 +504,48 @@ def q11_user_sessions_columnar(bidder, b_date_time, epoch_row_offsets, timeout_s
     o = np.argsort(close[keep], kind="stable")
     out_off = np.searchsorted(close[keep][o], np.arange(n_epochs + 1), side="left").astype(np.int64)
     return out_off, who[keep][o].astype(np.int32), cnt[keep][o], mn[keep][o], mx[keep][o]
+
+
+# ---- JSON lines <-> columns (the reference's event buffers and `event_bytes_to_batch`) ------------------------------------
+def nexmark_json_lines(relation: str, cols: dict) -> bytes:
+    """The epoch buffer the reference's generator builds (flock/src/datasource/nexmark/generator.rs:79-93):
+    serde_json::to_vec of every event + b"\n"; struct field order of event.rs:103-117 / 189-207 / 315-323, compact
+    separators, integers as decimal literals, Epoch newtype as its integer."""
+    import json
+    order = {"bid": ["auction", "bidder", "price", "b_date_time"],
+             "auction": ["a_id", "item_name", "description", "initial_bid", "reserve", "a_date_time", "expires", "seller", "category"],
+             "person": ["p_id", "name", "email_address", "credit_card", "city", "state", "p_date_time"]}[relation]
+    n = len(cols[order[0]])
+    strs = {}
+    for k in order:
+        if isinstance(cols[k], Utf8):
+            b, off = cols[k].data.tobytes(), cols[k].offsets
+            strs[k] = [b[off[i]:off[i + 1]].decode() for i in range(n)]
+    out = []
+    for i in range(n):
+        obj = {k: (strs[k][i] if k in strs else int(cols[k][i])) for k in order}
+        out.append(json.dumps(obj, separators=(",", ":"), ensure_ascii=False).encode())
+    return b"".join(line + b"\n" for line in out)
+
+
+def json_lines_decode(data: bytes, fields):
+    """`event_bytes_to_batch` (flock/src/transmute.rs:255-266: arrow json::Reader over the buffer, one object per line):
+    fields = [(name, "int32" | "int64" | "utf8")] -> {name: np.ndarray | Utf8}.  Python's json module is the decoder."""
+    import json
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    objs = [json.loads(line) for line in lines]
+    out = {}
+    for name, t in fields:
+        if t == "utf8":
+            vals = [o[name].encode() for o in objs]
+            off = np.zeros(len(vals) + 1, np.int32)
+            np.cumsum([len(v) for v in vals], out=off[1:])
+            out[name] = Utf8(off, np.frombuffer(b"".join(vals), np.uint8).copy())
+        else:
+            for o in objs:
+                if not isinstance(o[name], int) or isinstance(o[name], bool):
+                    raise ValueError(f"{name}: integer literal expected")
+            out[name] = np.array([o[name] for o in objs], np.int32 if t == "int32" else np.int64)
+    return out

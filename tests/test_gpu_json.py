@@ -1,0 +1,122 @@
+"""JSON lines -> columns on the GPU (`event_bytes_to_batch`) vs the oracle's decoder (Python's
+json module): the generator's three relations, free-form objects (any member order, white space, unknown members of any
+shape, every escape incl. surrogate pairs), the error cases, and sizes that leave the LDS staging."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+from test_oracle_json import SCHEMAS, _events
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _dev_bytes(b):
+    import torch
+    t = torch.zeros(len(b) + 16, dtype=torch.uint8, device="cuda")   # 16-byte aligned allocation; only len(b) bytes are text
+    if len(b):
+        t[: len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    return t[: len(b)]
+
+
+def _check(cols, want, fields, n):
+    for name, t in fields:
+        if t == "utf8":
+            off = cols[name].offsets.cpu().numpy()
+            data = cols[name].data.cpu().numpy()
+            assert np.array_equal(off, want[name].offsets), name
+            assert np.array_equal(data[: off[-1]], want[name].data[: off[-1]]), name
+        else:
+            assert np.array_equal(cols[name].cpu().numpy(), want[name]), name
+            assert len(want[name]) == n
+
+
+@pytest.mark.parametrize("relation,n_events", [("bid", 4000), ("auction", 4000), ("person", 4000), ("bid", 1_000_000), ("person", 300_000),
+                                               ("auction", 300_000)])
+def test_generated_relations(ctx, relation, n_events):
+    from flock_amd.nexmark import event_bytes_to_columns
+    cols = _events(relation, n_events)
+    text = oracle.nexmark_json_lines(relation, cols)
+    got, n = event_bytes_to_columns(ctx, _dev_bytes(text), relation)
+    assert n == len(cols[SCHEMAS[relation][0][0]]) and n > 0
+    _check(got, cols, SCHEMAS[relation], n)
+    # no newline after the last line: same rows
+    got2, n2 = event_bytes_to_columns(ctx, _dev_bytes(text[:-1]), relation)
+    assert n2 == n
+    _check(got2, cols, SCHEMAS[relation], n)
+
+
+def test_free_form_objects_and_escapes(ctx):
+    rng = np.random.default_rng(5)
+    fields = [("k", "int32"), ("t", "int64"), ("s", "utf8"), ("u", "utf8")]
+    specials = ['', 'plain', 'quote " inside', 'back\\slash', 'tab\there', 'nl\nnl', 'uni é ü ß', 'cjk 漢字', 'emoji \U0001F600 end',
+                '/slash/', '\b\f\r', 'x' * 300, 'ctl \x01\x1f']
+    lines = []
+    for i in range(5000):
+        o = {"k": int(rng.integers(-2**31, 2**31)), "t": int(rng.integers(-2**62, 2**62)), "s": specials[i % len(specials)],
+             "u": "row%d" % i}
+        extra = {"z": [1, {"a": "}]\\\""}, [None, True, 1.5e3]], "y": {"n": {"m": "\n"}}, "w": -0.25, "v": None, "k2": "k"}
+        items = list(o.items()) + [(k, extra[k]) for k in list(extra)[: i % 6]]
+        order = rng.permutation(len(items))
+        body = (", " if i % 3 else ",").join("%s%s:%s%s" % (json.dumps(items[j][0]), " " * (i % 2), "\t" * (i % 4 == 1),
+                                                                 json.dumps(items[j][1], ensure_ascii=bool(i % 2))) for j in order)
+        lines.append((" " * (i % 3) + "{" + " " * (i % 2) + body + "}" + ("\r" if i % 5 == 0 else "")).encode())
+    text = b"\n".join(lines) + b"\n"
+    want = oracle.json_lines_decode(text, fields)
+    got, n = ctx.json_lines_decode(_dev_bytes(text), fields)
+    assert n == 5000
+    _check(got, want, fields, n)
+    # the same rows without any escape in field "u": that field takes the plain byte-range gather, "s" the unescaping copy
+    assert got["u"].offsets[-1].item() == sum(len("row%d" % i) for i in range(5000))
+    # last-one-wins for a repeated key is what a map-building decoder does as well
+    dup = b'{"k":1,"t":2,"s":"a","u":"b","k":7}\n'
+    assert oracle.json_lines_decode(dup, fields)["k"].tolist() == [7]
+    assert ctx.json_lines_decode(_dev_bytes(dup), fields)[0]["k"].cpu().tolist() == [7]
+
+
+def test_lines_longer_than_the_staging_buffer(ctx):
+    fields = [("id", "int32"), ("blob", "utf8")]
+    rng = np.random.default_rng(9)
+    lines = [json.dumps({"blob": "".join(chr(97 + int(c)) for c in rng.integers(0, 26, int(rng.integers(0, 900)))), "id": i},
+                        separators=(",", ":")).encode() for i in range(3000)]
+    text = b"\n".join(lines)
+    want = oracle.json_lines_decode(text, fields)
+    got, n = ctx.json_lines_decode(_dev_bytes(text), fields)
+    assert n == 3000
+    _check(got, want, fields, n)
+
+
+@pytest.mark.parametrize("bad,code", [
+    (b'{"a":1,"b":"x"}\n{"a":2}\n', "INVALID"),                        # missing field
+    (b'{"a":1,"b":"x"}\n{"a":2,"b":"y"\n', "INVALID"),                 # unterminated object
+    (b'{"a":1.5,"b":"x"}\n', "UNSUPPORTED"),                           # fraction
+    (b'{"a":1e3,"b":"x"}\n', "UNSUPPORTED"),                           # exponent
+    (b'{"a":1,"b":"x"}\n\n{"a":2,"b":"y"}\n', "UNSUPPORTED"),          # blank line
+    (b'{"a":3000000000,"b":"x"}\n', "INVALID"),                        # does not fit Int32
+    (b'{"a":1,"b":"bad \\q escape"}\n', "INVALID"),
+    (b'{"a":1,"b":"lone \\ud800 surrogate"}\n', "INVALID"),
+    (b'{"a":1,"b":"x",}\n', "INVALID"),
+    (b'{"a":1,"b":"x"} trailing\n', "INVALID"),
+    (b'{"a":"1","b":"x"}\n', "INVALID"),                               # string where an integer is expected
+    (b'{"\\u0061":1,"b":"x"}\n', "UNSUPPORTED"),                       # escape in a key
+])
+def test_errors_name_the_line(ctx, bad, code):
+    from flock_amd import FlockGpuError, _ffi
+    with pytest.raises(FlockGpuError) as e:
+        ctx.json_lines_decode(_dev_bytes(bad), [("a", "int32"), ("b", "utf8")])
+    assert e.value.code == getattr(_ffi, "ERR_" + code), str(e.value)
+    assert "line" in str(e.value)
+
+
+def test_empty_text(ctx):
+    got, n = ctx.json_lines_decode(_dev_bytes(b""), [("a", "int32"), ("b", "utf8")])
+    assert n == 0 and got["a"].numel() == 0 and got["b"].offsets.cpu().tolist() == [0]
