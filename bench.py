@@ -369,6 +369,60 @@ def q11_side(ctx, eps, steps, no_cpu, seconds=109):
     return out
 
 
+# ------------------------------------------------------------------ JSON lines -> columns
+def json_side(ctx, steps, no_cpu, block_events=200_000, copies=100):
+    """`event_bytes_to_batch` over bid lines: the serde_json lines of 1.84e5 generated bids, laid end to end 100 times
+    (1.84e7 lines, ~1.4 GB: a call takes at most 2^31 bytes), decoded into the four Bid columns."""
+    import io
+    import numpy as np
+    import torch
+    import oracle
+    from flock_amd.nexmark import NEXMARK_JSON_SCHEMAS
+    s = oracle.NexmarkStream(seed=20260926, eps=1_000_000)
+    cols = s.bids(0, block_events)
+    block = oracle.nexmark_json_lines("bid", cols)
+    n_block = len(cols["auction"])
+    host = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    text = torch.zeros(len(block) * copies + 16, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+    text[: len(block) * copies] = host.cuda().repeat(copies)
+    text = text[: len(block) * copies]
+    fields = NEXMARK_JSON_SCHEMAS["bid"]
+    dt, stats, (got, n) = run_steps(ctx, lambda: ctx.json_lines_decode(text, fields), steps, 1, lambda: None, "json_parse_kernel")
+    # size-independent check: every copy of the block decodes to the block's columns
+    ok = n == n_block * copies
+    for name, _ in fields:
+        c = got[name].reshape(copies, n_block)
+        ok = ok and bool((c == torch.from_numpy(cols[name]).to(c.device)).all())
+    if not ok:
+        raise RuntimeError("json decode differs from the generated columns")
+    n_bytes = int(text.numel())
+    st = stats.get("json_parse_kernel")
+    out = {"value": round(n * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(n),
+           "input_bytes": n_bytes, "text_GBps": round(n_bytes * steps / dt / 1e9, 1)}
+    if st and st["launches"]:
+        avg_ms = st["total_ms"] / st["launches"]
+        alg = n_bytes + 20.0 * n                       # the text once + the four output columns
+        out["roofline"] = {"bound": "hbm", "kernel": "json_parse_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                           "launches": st["launches"],
+                           "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
+    if not no_cpu:
+        try:
+            import pyarrow.json as pj
+            sample = block * 10
+            t0 = time.perf_counter()
+            tb = pj.read_json(io.BytesIO(sample))
+            d = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(tb.num_rows / d, 1), "unit": "rows/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"{tb.num_rows} lines ({len(sample)} bytes) through Arrow C++'s JSON reader (pyarrow.json, its "
+                                             "own thread pool) -- the arrow-rs json::Reader of the reference is single-threaded per call",
+                                   "seconds": round(d, 3)}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 # ------------------------------------------------------------------ PCIe-inclusive side measurement
 def pcie_inclusive_q5(ctx, eps, seconds=100):
     """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query.  PCIe-bound;
@@ -503,6 +557,10 @@ def main():
             also["q11_next"] = q11_side(ctx, args.eps, steps2, args.no_cpu)
         except Exception as e:
             also["q11_next"] = {"error": repr(e)}
+        try:
+            also["json_ingest_next"] = json_side(ctx, steps2, args.no_cpu)
+        except Exception as e:
+            also["json_ingest_next"] = {"error": repr(e)}
         try:
             also["ysb_next"] = ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)
         except Exception as e:

@@ -29,7 +29,7 @@ constexpr int kMaxName = 32;
 constexpr int kNlBytes = 64;                    // bytes per lane in the newline passes
 constexpr int kNlTile = kBlock * kNlBytes;      // 16 KiB
 constexpr int kParseLines = kBlock;             // lines per workgroup
-constexpr int kStageBytes = 40 * 1024;          // LDS staging of a workgroup's lines (3 workgroups per CU)
+constexpr int kStageBytes = 48 * 1024;          // most LDS a workgroup stages its lines in
 
 enum : int32_t { kInt32 = 0, kInt64 = 1, kUtf8 = 2 };
 enum : uint32_t { kErrSyntax = 1, kErrNumber = 2, kErrMissing = 3, kErrBlank = 4, kErrKeyEscape = 5, kErrRange = 6 };
@@ -211,6 +211,7 @@ __device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, cons
     if (t.at(p) != '{') return kErrSyntax;
     ++p;
     uint32_t seen = 0;
+    int next_f = 0;
     while (p < end && is_ws(t.at(p))) ++p;
     const bool empty_object = p < end && t.at(p) == '}';
     if (empty_object) ++p;
@@ -224,12 +225,15 @@ __device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, cons
         if (p < 0) return kErrSyntax;
         if (kesc) return kErrKeyEscape;
         int f = -1;
-        for (int i = 0; i < spec.n; ++i) {
+        for (int k = 0; k < spec.n; ++k) {  // members usually arrive in schema order: start at the field after the last match
+            int i = next_f + k;
+            i = i >= spec.n ? i - spec.n : i;
             if (spec.name_len[i] != ke - kb) continue;
             bool same = true;
             for (int j = 0; j < ke - kb; ++j) same = same && t.at(kb + j) == (uint32_t)(uint8_t)spec.name[i][j];
             if (same) {
                 f = i;
+                next_f = i + 1 == spec.n ? 0 : i + 1;
                 break;
             }
         }
@@ -301,13 +305,16 @@ __device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, cons
 // err[0] = first bad line + 1 (0: none) as atomicMin over (line + 1) stored inverted, err[1] = its code
 __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__restrict__ bytes, int64_t n_bytes,
                                                             const int32_t *__restrict__ line_start, int64_t n_lines, JsonSpec spec,
-                                                            JsonOut out, unsigned long long *err) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+                                                            JsonOut out, int32_t stage_bytes, unsigned long long *err) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];  // stage_bytes of dynamic LDS
+    __shared__ JsonSpec s_spec;  // lanes index the field names with their own (i, j): from LDS, not from the kernel arguments
+    for (int i = threadIdx.x; i < (int)(sizeof(JsonSpec) / 4); i += kBlock)
+        reinterpret_cast<uint32_t *>(&s_spec)[i] = reinterpret_cast<const uint32_t *>(&spec)[i];
     const int64_t l0 = (int64_t)blockIdx.x * kParseLines;
     const int64_t l1 = min(l0 + kParseLines, n_lines);
     const int32_t b0 = line_start[l0], b1 = min((int64_t)line_start[l1], n_bytes);
     const int32_t a0 = b0 & ~15;
-    const bool staged = b1 - a0 <= kStageBytes;  // block-uniform
+    const bool staged = b1 - a0 <= stage_bytes;  // block-uniform
     if (staged) {
         for (int32_t o = a0 + (int32_t)threadIdx.x * 16; o < b1; o += kBlock * 16) {
             if ((int64_t)o + 16 <= n_bytes) {
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
                 for (int32_t i = o; i < b1; ++i) s_stage[i - a0] = bytes[i];
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     const int64_t line = l0 + threadIdx.x;
     if (line >= n_lines) return;
     const int32_t p = line_start[line];
@@ -325,10 +332,10 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
     uint32_t rc;
     if (staged) {
         const Text<true> t{bytes, s_stage, a0};
-        rc = parse_line(t, p, e, spec, line, out);
+        rc = parse_line(t, p, e, s_spec, line, out);
     } else {
         const Text<false> t{bytes, nullptr, 0};
-        rc = parse_line(t, p, e, spec, line, out);
+        rc = parse_line(t, p, e, s_spec, line, out);
     }
     if (rc) atomicMin(err, ((unsigned long long)line << 8) | rc);
 }
@@ -520,8 +527,13 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
     FG_HIP(ctx, hipMemsetAsync(d_any, 0, sizeof(uint32_t) * kMaxFields, ctx->stream));
     if (n_lines > 0) {
         LaunchScope ls(ctx, "json_parse_kernel");
-        hipLaunchKernelGGL(json_parse_kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), 0, ctx->stream, json, n_bytes,
-                           line_start, n_lines, spec, jo, d_err);
+        // LDS per workgroup follows the text: 1.25 x the average bytes of 256 lines (+ alignment slack), so short lines
+        // (bids: 74 B -> 24 KB, six workgroups per CU) do not pay for the longest relation; a workgroup whose lines do
+        // not fit reads them from global memory instead.
+        int64_t want = (n_bytes / n_lines + 1) * kParseLines * 5 / 4 + 64;
+        const int32_t stage_bytes = (int32_t)std::min<int64_t>(kStageBytes, (want + 1023) & ~int64_t(1023));
+        hipLaunchKernelGGL(json_parse_kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), (size_t)stage_bytes, ctx->stream,
+                           json, n_bytes, line_start, n_lines, spec, jo, stage_bytes, d_err);
     }
     FG_TRY(check_launch(ctx, "json_parse_kernel"));
 
