@@ -4,9 +4,11 @@
 // called from nexmark.rs:180-205) -- by the survey's own account the reference's real bottleneck.  HBM-bound byte work,
 // no MFMA.
 //
-//   lines   : count -> scan -> emit over 16 KiB tiles of the text: every raw 0x0A ends a line (JSON strings cannot hold one)
+//   lines   : count -> scan -> emit over 16 KiB tiles of the text: every raw 0x0A ends a line (JSON strings cannot hold one);
+//             the count pass keeps a 64-bit newline mask per 64 bytes, which is all the emit pass reads
 //   parse   : 256 lines per workgroup; their bytes are one contiguous range, staged in LDS with 16-byte loads; one lane
-//             walks one line: keys matched against the schema's field names, integers parsed exactly (sign, overflow),
+//             walks one line -- first against the exact shape serde_json writes (`"name":value` in schema order, no white
+//             space, no escapes: straight-line checks), and only if that fails through the general parser: keys matched against the schema's field names, integers parsed exactly (sign, overflow),
 //             strings delimited with escape awareness, unknown keys skipped with a depth-counting value skipper.
 //             Int32 / Int64 (Timestamp) columns are written directly (row = line: coalesced); for a Utf8 field the lane
 //             records where the value's bytes lie in the INPUT (start, end) and whether it holds escapes
@@ -67,21 +69,24 @@ __device__ __forceinline__ uint64_t newline_mask(const uint8_t *__restrict__ byt
     return m;
 }
 
+// The lane's 64-bit newline mask is kept (1/8 of the text): the emit pass reads the masks, not the text again.
 __global__ __launch_bounds__(kBlock) void json_newline_count_kernel(const uint8_t *__restrict__ bytes, int64_t n,
-                                                                   uint32_t *__restrict__ counts) {
+                                                                   uint64_t *__restrict__ masks, uint32_t *__restrict__ counts) {
     const int64_t p0 = (int64_t)blockIdx.x * kNlTile + (int64_t)threadIdx.x * kNlBytes;
-    const uint32_t c = (uint32_t)__popcll((unsigned long long)newline_mask(bytes, n, p0));
+    const uint64_t m = newline_mask(bytes, n, p0);
+    masks[(size_t)blockIdx.x * kBlock + threadIdx.x] = m;
+    const uint32_t c = (uint32_t)__popcll((unsigned long long)m);
     const uint32_t incl = wave_incl_scan_u32(c);
     if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
 }
 
 // line_start[k + 1] = position after the k-th newline
-__global__ __launch_bounds__(kBlock) void json_newline_emit_kernel(const uint8_t *__restrict__ bytes, int64_t n,
+__global__ __launch_bounds__(kBlock) void json_newline_emit_kernel(const uint64_t *__restrict__ masks,
                                                                   const uint32_t *__restrict__ counts,
                                                                   const uint64_t *__restrict__ tile_base,
                                                                   int32_t *__restrict__ line_start) {
     const int64_t p0 = (int64_t)blockIdx.x * kNlTile + (int64_t)threadIdx.x * kNlBytes;
-    uint64_t m = newline_mask(bytes, n, p0);
+    uint64_t m = masks[(size_t)blockIdx.x * kBlock + threadIdx.x];
     const uint32_t c = (uint32_t)__popcll((unsigned long long)m);
     const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
     const int wave = threadIdx.x >> 6;
@@ -302,6 +307,58 @@ __device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, cons
     return 0;
 }
 
+// The shape serde_json writes (generator.rs:81-91): {"name":value,...} with the members in schema order, no white space,
+// and -- for the generator's strings -- no escapes.  Straight-line checks against the literal `"name":` of every field;
+// anything else (other order, white space, escapes, unknown members, long or out-of-range numbers) returns false and
+// the line goes through parse_line, which also produces the error codes.  Columns written here before a `false` are
+// simply rewritten by it.
+template <bool kLds>
+__device__ bool parse_line_fast(const Text<kLds> &t, int32_t p, int32_t end, const JsonSpec &spec, int64_t row, const JsonOut &out) {
+    if (p >= end || t.at(p) != '{') return false;
+    ++p;
+    for (int f = 0; f < spec.n; ++f) {
+        const int32_t nl = spec.name_len[f];
+        if (p + nl + 4 > end || t.at(p) != '"' || t.at(p + nl + 1) != '"' || t.at(p + nl + 2) != ':') return false;
+        bool same = true;
+        for (int j = 0; j < nl; ++j) same = same && t.at(p + 1 + j) == (uint32_t)(uint8_t)spec.name[f][j];
+        if (!same) return false;
+        p += nl + 3;
+        if (spec.type[f] == kUtf8) {
+            if (t.at(p) != '"') return false;
+            const int32_t b = ++p;
+            uint32_t c = 0;
+            while (p < end && (c = t.at(p)) != '"' && c != '\\' && c >= 0x20) ++p;
+            if (p >= end || c != '"') return false;
+            out.pairs[f][2 * row] = b;
+            out.pairs[f][2 * row + 1] = p;
+            out.ulen[f][row] = p - b;
+            ++p;
+        } else {
+            const bool neg = t.at(p) == '-';
+            p += neg;
+            uint64_t v = 0;
+            int digits = 0;
+            uint32_t c;
+            while (p < end && (c = t.at(p) - '0') <= 9u) {
+                v = v * 10 + c;
+                ++digits;
+                ++p;
+            }
+            if (digits == 0 || digits > 18) return false;
+            const int64_t sv = neg ? -(int64_t)v : (int64_t)v;
+            if (spec.type[f] == kInt32) {
+                if (sv < -2147483648ll || sv > 2147483647ll) return false;
+                reinterpret_cast<int32_t *>(out.values[f])[row] = (int32_t)sv;
+            } else {
+                reinterpret_cast<int64_t *>(out.values[f])[row] = sv;
+            }
+        }
+        if (p >= end || t.at(p) != (uint32_t)(f + 1 == spec.n ? '}' : ',')) return false;
+        ++p;
+    }
+    return p == end;
+}
+
 // err[0] = first bad line + 1 (0: none) as atomicMin over (line + 1) stored inverted, err[1] = its code
 __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__restrict__ bytes, int64_t n_bytes,
                                                             const int32_t *__restrict__ line_start, int64_t n_lines, JsonSpec spec,
@@ -332,10 +389,10 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
     uint32_t rc;
     if (staged) {
         const Text<true> t{bytes, s_stage, a0};
-        rc = parse_line(t, p, e, s_spec, line, out);
+        rc = parse_line_fast(t, p, e, s_spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
     } else {
         const Text<false> t{bytes, nullptr, 0};
-        rc = parse_line(t, p, e, s_spec, line, out);
+        rc = parse_line_fast(t, p, e, s_spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
     }
     if (rc) atomicMin(err, ((unsigned long long)line << 8) | rc);
 }
@@ -470,12 +527,14 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
     uint8_t *h_last = nullptr;
     FG_TRY(arena_get_t(ctx, "json.nl_counts", (size_t)tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, "json.nl_base", (size_t)tiles + 1, &tile_base));
+    uint64_t *masks = nullptr;
+    FG_TRY(arena_get_t(ctx, "json.nl_masks", (size_t)tiles * kBlock, &masks));
     FG_TRY(pinned_get_t(ctx, "json.nl_total", 2, &h_total));
     h_last = reinterpret_cast<uint8_t *>(h_total + 1);
     if (n_bytes == 0) return FLOCKGPU_OK;
     {
         LaunchScope ls(ctx, "json_newline_count_kernel");
-        hipLaunchKernelGGL(json_newline_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, json, n_bytes, counts);
+        hipLaunchKernelGGL(json_newline_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, json, n_bytes, masks, counts);
     }
     FG_TRY(check_launch(ctx, "json_newline_count_kernel"));
     FG_TRY(launch_tile_scan(ctx, counts, (int32_t)tiles, tile_base, nullptr, 0, nullptr));
@@ -489,7 +548,7 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
     FG_TRY(arena_get_t(ctx, "json.line_start", (size_t)n_lines + 2, &line_start));
     {
         LaunchScope ls(ctx, "json_newline_emit_kernel");
-        hipLaunchKernelGGL(json_newline_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, json, n_bytes, counts, tile_base,
+        hipLaunchKernelGGL(json_newline_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, masks, counts, tile_base,
                            line_start);
     }
     FG_TRY(check_launch(ctx, "json_newline_emit_kernel"));
