@@ -42,7 +42,7 @@ DOMINANT = {
     7: ("q7_max_kernel", 4.0, "bid"),                  # price column once (SURVEY.md section 8(f) "next" query)
     9: ("aq_final_kernel", 16.0, "bid"),               # auction + price + b_date_time per bid ("next" query)
     4: ("aq_final_kernel", 16.0, "bid"),
-    13: ("q13_probe_count_kernel", 4.0, "bid"),        # auction per bid, probed against the LDS copy of the side table
+    13: ("q13_flag_kernel", 4.0, "bid"),               # auction per bid: bitmap test, the few candidates probe the table
 }
 DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300, 13: 1087}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 

@@ -263,6 +263,136 @@ __global__ __launch_bounds__(kProbeBlock) void q13_probe_emit_kernel(const int32
     }
 }
 
+// ---- the bitmap path: standard flag tiles --------------------------------------------------------------------------
+// With the membership bitmap almost every bid is rejected by one bit test, so the hash table is probed a few times per
+// tile only and needs no LDS copy: the count pass becomes a plain streaming kernel in the flag-tile geometry (256 lanes,
+// 32 rows per lane, tiles walked with the next descriptor requested early, as q2 / q7), the per-tile fixed costs (range
+// reduction for the shared bitmap words, scan, stores) are paid per 32 rows of a lane instead of per 8.
+__global__ __launch_bounds__(kBlock) void q13_flag_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
+                                                          const uint64_t *__restrict__ table, uint32_t cap,
+                                                          const int32_t *__restrict__ next, KeyBitmap bm,
+                                                          uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    int32_t tile = (int32_t)blockIdx.x;
+    if (tile >= st.n_tiles) return;
+    TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int32_t rel0 = flag_rel0();
+    const int lane = lane_id();
+#pragma unroll 1
+    for (;;) {
+        int32_t a[kFlagIters][4];
+        load_flag_tile(auction, n_rows, tr, a);
+        const int32_t nxt = tile + (int32_t)gridDim.x;
+        TileRange trn = tr;
+        if (nxt < st.n_tiles) trn = locate_tile(st, nxt, kFlagTile);
+        const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+        // range of the wave's 2048 rows inside the bitmap
+        uint32_t imin = ~0u, imax = 0;
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t rel = rel0 + it * 256 + j;
+                const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)bm.base;
+                if (rel >= rel_lo && rel < rel_hi && idx < bm.n_bits) {
+                    imin = min(imin, idx);
+                    imax = max(imax, idx);
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            imin = min(imin, (uint32_t)__shfl_xor((int)imin, o, 64));
+            imax = max(imax, (uint32_t)__shfl_xor((int)imax, o, 64));
+        }
+        uint32_t maybe = 0;
+        if (imin <= imax) {  // (wave-uniform)
+            const uint32_t w0 = imin >> 5, w1 = imax >> 5;
+            if (w1 - w0 < 64u) {
+                const uint32_t word = bm.words[min(w0 + (uint32_t)lane, w1)];
+#pragma unroll
+                for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t rel = rel0 + it * 256 + j;
+                        const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)bm.base;
+                        const bool in = rel >= rel_lo && rel < rel_hi && idx < bm.n_bits;
+                        const uint32_t wv = (uint32_t)__shfl((int)word, in ? (int)((idx >> 5) - w0) : 0, 64);
+                        maybe |= (in ? (wv >> (idx & 31)) & 1u : 0u) << (it * 4 + j);
+                    }
+            } else {
+#pragma unroll
+                for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int32_t rel = rel0 + it * 256 + j;
+                        maybe |= (uint32_t)(rel >= rel_lo && rel < rel_hi && q13_maybe(bm, a[it][j])) << (it * 4 + j);
+                    }
+            }
+        }
+        uint32_t flags = 0, mine = 0;
+        if (__ballot(maybe != 0)) {  // (wave-uniform) some row of the wave may join
+#pragma unroll
+            for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((maybe >> (it * 4 + j)) & 1u) {
+                        uint32_t n = 0;
+                        for (int32_t p = find_global(table, cap, a[it][j]); p >= 0; p = next[p]) ++n;
+                        mine += n;
+                        flags |= (n ? 1u : 0u) << (it * 4 + j);
+                    }
+        }
+        flag_words[(size_t)tile * kBlock + threadIdx.x] = flags;
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane == 63) counts[(size_t)tile * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
+        if (nxt >= st.n_tiles) break;
+        tile = nxt;
+        tr = trn;
+    }
+}
+
+// pairs of the flagged rows, in row order (wave, iteration, lane, j)
+__global__ __launch_bounds__(kBlock) void q13_flag_emit_kernel(const int32_t *__restrict__ auction, SegTiles st,
+                                                               const uint64_t *__restrict__ table, uint32_t cap,
+                                                               const int32_t *__restrict__ next, const uint32_t *__restrict__ counts,
+                                                               const uint32_t *__restrict__ flag_words,
+                                                               const uint64_t *__restrict__ tile_base, int32_t *__restrict__ out_bid_row,
+                                                               int32_t *__restrict__ out_side_row) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t flags = flag_words[(size_t)tile * kBlock + threadIdx.x];
+    if (!__ballot(flags != 0)) return;  // wave-uniform
+    const int wave = threadIdx.x >> 6;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint64_t pos = tile_base[tile] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u);
+#pragma unroll 1
+    for (int it = 0; it < kFlagIters; ++it) {
+        const uint32_t f4 = (flags >> (it * 4)) & 15u;
+        if (!__ballot(f4 != 0)) continue;
+        int32_t head[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            head[j] = -1;
+            if (f4 & (1u << j)) {
+                head[j] = find_global(table, cap, auction[wbase + it * 256 + j]);
+                for (int32_t p = head[j]; p >= 0; p = next[p]) ++mine;
+            }
+        }
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        uint64_t p = pos + (incl - mine);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int32_t q = head[j]; q >= 0; q = next[q]) {
+                out_bid_row[p] = (int32_t)(wbase + it * 256 + j);
+                out_side_row[p] = q;
+                ++p;
+            }
+        pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+}
+
 // tile totals for the generic tile scan (which sums kWavesPerBlock = 4 counts per tile): 16 wave counts -> 4
 __global__ __launch_bounds__(kBlock) void fold_counts_kernel(const uint32_t *__restrict__ c16, int32_t n_tiles,
                                                              uint32_t *__restrict__ c4) {
@@ -359,10 +489,20 @@ int flockgpu_q13_side_join(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, cons
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * per_cu));
     uint8_t *flags8 = nullptr;
     FG_TRY(arena_get_t(ctx, "q13.flags8", (size_t)st.n_tiles * kProbeBlock + 16, &flags8));
-    if (lds && lds_bytes > 64 * 1024)
+    const bool flag_path = bm.words != nullptr;  // bitmap: plain flag tiles, no LDS table
+    uint32_t *flag_words = nullptr;
+    if (flag_path) FG_TRY(arena_get_t(ctx, "q13.flag_words", (size_t)st.n_tiles * kBlock + 4, &flag_words));
+    if (flag_path && st.n_tiles > 0) {
+        LaunchScope ls(ctx, "q13_flag_kernel");
+        const unsigned g = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+        hipLaunchKernelGGL(q13_flag_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, bid->auction, bid->rows, st, table, cap, next, bm,
+                           flag_words, c4);
+    }
+    FG_TRY(check_launch(ctx, "q13_flag_kernel"));
+    if (!flag_path && lds && lds_bytes > 64 * 1024)
         FG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&q13_probe_count_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (st.n_tiles > 0) {
+    if (!flag_path && st.n_tiles > 0) {
         LaunchScope ls(ctx, "q13_probe_count_kernel");
         if (lds)
             hipLaunchKernelGGL(q13_probe_count_kernel<true>, dim3(grid), dim3(kProbeBlock), lds_bytes, ctx->stream, bid->auction,
@@ -372,7 +512,7 @@ int flockgpu_q13_side_join(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, cons
                                st, table, cap, next, bm, c16, flags8);
     }
     FG_TRY(check_launch(ctx, "q13_probe_count_kernel"));
-    if (st.n_tiles > 0) {
+    if (!flag_path && st.n_tiles > 0) {
         hipLaunchKernelGGL(fold_counts_kernel, dim3((unsigned)div_up((int64_t)st.n_tiles * kWavesPerBlock, kBlock)), dim3(kBlock), 0,
                            ctx->stream, c16, st.n_tiles, c4);
         FG_TRY(check_launch(ctx, "fold_counts_kernel"));
@@ -396,12 +536,16 @@ int flockgpu_q13_side_join(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, cons
     FG_TRY(arena_get_t(ctx, "q13.out_time", (size_t)n_out + 1, &o_t));
     FG_TRY(arena_get_t(ctx, "q13.out_value", (size_t)n_out + 1, &o_v));
     if (st.n_tiles > 0 && n_out > 0) {
-        {
+        if (flag_path) {
+            LaunchScope ls(ctx, "q13_flag_emit_kernel");
+            hipLaunchKernelGGL(q13_flag_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->auction, st, table, cap,
+                               next, c4, flag_words, tile_base, o_br, o_sr);
+        } else {
             LaunchScope ls(ctx, "q13_probe_emit_kernel");
             hipLaunchKernelGGL(q13_probe_emit_kernel, dim3(grid), dim3(kProbeBlock), 0, ctx->stream, bid->auction, st, table, cap,
                                next, c16, flags8, tile_base, o_br, o_sr);
         }
-        FG_TRY(check_launch(ctx, "q13_probe_emit_kernel"));
+        FG_TRY(check_launch(ctx, "q13 emit"));
         FG_TRY(gather_i32(ctx, bid->auction, o_br, n_out, o_a));
         FG_TRY(gather_i32(ctx, bid->bidder, o_br, n_out, o_b));
         FG_TRY(gather_i32(ctx, bid->price, o_br, n_out, o_p));

@@ -140,7 +140,7 @@ def test_exchange_queries_one_rank(ctx, world1):
 
 
 def test_scans_beyond_one_pass(ctx):
-    """More than 16384 tiles: the single-workgroup tile scan runs several passes with a carry."""
+    """More than 16384 tiles: the tile scan runs chunk by chunk (chunk-local bases, scan of the chunk totals, fix-up)."""
     import torch
     from flock_amd import WindowSchedule
     rng = np.random.default_rng(9)
