@@ -15,7 +15,7 @@ os.makedirs(dst, exist_ok=True)
 for f in sorted(os.listdir(src)):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 DOMINANT = {5: "q5_count_kernel", 2: "q2_flag_kernel", 3: "q3_probe_flag_kernel", 8: "q8_sellers_bitmap_kernel", 7: "q7_max_kernel", 9: "aq_final_kernel",
-            13: "q13_probe_count_kernel"}
+            13: "q13_flag_kernel"}
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, "
                        "tools/gpu_profile.sh): bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 reports half of a 16 B/lane coalesced stream, "
                        "MI355X_MICROARCH.md HBM section) + WRITE_SIZE_KB * 1024.  Source CSVs: profiles/%s/q*_pmc_*.csv" % tag}

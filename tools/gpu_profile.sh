@@ -35,3 +35,12 @@ for q in ${QUERIES:-5 2 8 3 7 9 13}; do
   rm -f "$OUT"/q${q}_*_run.log
 done
 ls -la "$OUT"
+# the "next" rows that bench.py only reports under `also` (q11, YSB, JSON ingest, q4, the 1e9 variants): one kernel-stats run
+# of the whole default bench
+if [ "${FULL:-1}" = "1" ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_all -- python bench.py --steps 3 --warmup 1 --no-cpu > "$OUT/all_stats_run.log" 2>&1
+  f=$(find /tmp/prof_all -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/all_kernel_stats.csv"
+  grep '^{' "$OUT/all_stats_run.log" | tail -1 > "$OUT/all_bench_under_rocprof.json"
+  rm -f "$OUT/all_stats_run.log"
+fi
+ls -la "$OUT" | tail -8
