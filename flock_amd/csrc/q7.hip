@@ -23,7 +23,7 @@ constexpr int32_t kNoMax = (int32_t)0x80000000;
 // Persistent: block b reduces tiles b, b + G, ...; the NEXT tile's descriptor is requested before the current tile's
 // rows are reduced, so the column loads of a tile never wait for a dependent descriptor load.
 __global__ __launch_bounds__(kBlock) void q7_max_kernel(const int32_t *__restrict__ price, int64_t n_rows, SegTiles st,
-                                                        int32_t *__restrict__ tile_max, int32_t *win_max) {
+                                                        int32_t *__restrict__ tile_max) {
     __shared__ int32_t s_red[2][kWavesPerBlock];
     int32_t tile = (int32_t)blockIdx.x;
     if (tile >= st.n_tiles) return;
@@ -53,13 +53,27 @@ __global__ __launch_bounds__(kBlock) void q7_max_kernel(const int32_t *__restric
         if (threadIdx.x == 0) {
             mx = max(max(s_red[par][0], s_red[par][1]), max(s_red[par][2], s_red[par][3]));
             tile_max[tile] = mx;
-            if (tr.hi > tr.lo) atomicMax(&win_max[tr.seg], mx);
         }
         if (next >= st.n_tiles) break;
         tile = next;
         tr = trn;
         par ^= 1;
     }
+}
+
+// win_max[w] = maximum over the window's tiles: one workgroup per window over tile_max (a window's ~1100 tiles of a
+// 1e9-bid run would otherwise be as many atomics on one address, issued by workgroups that run at the same time).
+__global__ __launch_bounds__(kBlock) void q7_window_max_kernel(const int32_t *__restrict__ tile_max, const int32_t *__restrict__ tile_first,
+                                                               int32_t *__restrict__ win_max) {
+    __shared__ int32_t s_red[kWavesPerBlock];
+    const int32_t w = (int32_t)blockIdx.x;
+    int32_t mx = kNoMax;
+    for (int32_t t = tile_first[w] + (int32_t)threadIdx.x; t < tile_first[w + 1]; t += kBlock) mx = max(mx, tile_max[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) win_max[w] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
 __global__ __launch_bounds__(kBlock) void q7_flag_kernel(const int32_t *__restrict__ price, int64_t n_rows, SegTiles st,
@@ -135,10 +149,11 @@ int flockgpu_q7_highest_bid(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, con
         {
             LaunchScope ls(ctx, "q7_max_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
-            hipLaunchKernelGGL(q7_max_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bid->price, bid->rows, st, tile_max,
-                               d_wmax);
+            hipLaunchKernelGGL(q7_max_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bid->price, bid->rows, st, tile_max);
         }
         FG_TRY(check_launch(ctx, "q7_max_kernel"));
+        hipLaunchKernelGGL(q7_window_max_kernel, dim3((unsigned)n_win), dim3(kBlock), 0, ctx->stream, tile_max, st.tile_first, d_wmax);
+        FG_TRY(check_launch(ctx, "q7_window_max_kernel"));
         {
             LaunchScope ls(ctx, "q7_flag_kernel");
             hipLaunchKernelGGL(q7_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, bid->price, bid->rows, st,
