@@ -117,6 +117,10 @@ class YsbResult(C.Structure):
                 ("campaign_bytes", C.c_int64)]
 
 
+class IpcBuffer(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes", C.c_int64)]
+
+
 class JsonField(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_int32)]
 
@@ -174,6 +178,7 @@ SYMBOLS = {
     "flockgpu_take_i64": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "flockgpu_take_utf8": (_i, [_vp, C.POINTER(Utf8), _vp, _i64, C.c_int32, C.POINTER(Utf8), C.POINTER(_i64)]),
     "flockgpu_inclusive_scan_i32": (_i, [_vp, _vp, _i64]),
+    "flockgpu_ipc_pack_body": (_i, [_vp, C.POINTER(IpcBuffer), _i, _vp, _i64, C.POINTER(_i64)]),
     "flockgpu_json_lines_decode": (_i, [_vp, _vp, _i64, C.POINTER(JsonField), _i, C.POINTER(JsonColumn), C.POINTER(_i64)]),
     "flockgpu_q5_partial_counts": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5PartialResult)]),
     "flockgpu_q5_hot_items_weighted": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Windows), C.POINTER(Q5Result)]),

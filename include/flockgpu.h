@@ -334,6 +334,19 @@ typedef struct {
 int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json /* device */, int64_t n_bytes, const flockgpu_json_field *fields,
                                int32_t n_fields, flockgpu_json_column *out /* n_fields */, int64_t *rows);
 
+/* ---- Arrow IPC body assembly: the body of the Arrow Flight data the reference builds for
+ * every output batch (`flight_data_from_arrow_batch`, flock/src/transmute.rs:155-170,190-205; `Payload`,
+ * flock/src/runtime/payload.rs:118-192) = the batch's buffers in field order, each padded with zeros to 8 bytes.
+ * `buffers[i]` are device buffers (bytes = 0: an absent validity bitmap, contributes nothing); `out` is a device buffer
+ * of `out_capacity` bytes (NULL: only the size is returned).  The header next to it is written on the host
+ * (flock_amd/payload.py); compression stays on the CPU as in the reference (flock/src/encoding.rs:57-100). */
+typedef struct {
+    const void *data; /* device */
+    int64_t bytes;
+} flockgpu_ipc_buffer;
+int flockgpu_ipc_pack_body(flockgpu_ctx *ctx, const flockgpu_ipc_buffer *buffers, int32_t n_buffers, uint8_t *out /* device */,
+                           int64_t out_capacity, int64_t *out_bytes);
+
 /* ---- Yahoo Streaming Benchmark: per Tumbling(10 s) window (benchmarks/src/ysb/main.rs:91)
  *   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = lit
  *   GROUP BY campaign_id         (benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346)
