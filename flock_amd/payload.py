@@ -187,13 +187,33 @@ def schema_from_bytes(data: bytes):
     return pa.ipc.read_schema(pa.py_buffer(b"\xff\xff\xff\xff" + struct.pack("<i", len(data) + pad) + data + b"\0" * pad))
 
 
-def _layout(batch: DeviceBatch):
-    """Buffers of the batch in IPC order: per field a (absent) validity bitmap, then offsets / values."""
+def flight_data_sizes(rows: int, columns: Sequence[Tuple[str, Optional[int]]], validity: bool = True) -> Tuple[int, int]:
+    """(header bytes, body bytes) of a batch's Arrow Flight data from its shape alone: columns = (type, total value bytes of
+    a Utf8 column).  validity = True is the reference's writer (arrow-rs of its day writes an all-ones bitmap of
+    ceil(rows / 8) bytes for EVERY field, `write_array_data`); its two size goldens (payload.rs:309, :402) equal these
+    numbers minus 8 bytes of flatbuffer layout in the header (tests/test_payload.py)."""
+    pad = lambda n: (n + 7) & ~7
+    width = {"int8": 1, "int32": 4, "int64": 8, "uint64": 8, "float64": 8, "timestamp_ms": 8}
+    body, n_buf = 0, 0
+    for kind, value_bytes in columns:
+        body += pad((rows + 7) // 8) if validity else 0
+        if kind == "utf8":
+            body += pad(4 * (rows + 1)) + pad(value_bytes)
+            n_buf += 3
+        else:
+            body += pad(width[kind] * rows)
+            n_buf += 2
+    return len(record_batch_header(rows, [(rows, 0)] * len(columns), [(0, 0)] * n_buf, body)), body
+
+
+def _layout(batch: DeviceBatch, validity_bits=None):
+    """Buffers of the batch in IPC order: per field the validity bitmap (an all-ones device buffer when `validity_bits` is
+    given -- what the reference's writer emits --, else absent, as Arrow C++ writes non-nullable data), then offsets / values."""
     from .engine import DeviceUtf8
     bufs, nodes = [], []
     for (name, kind), col in zip(batch.fields, batch.columns):
         nodes.append((batch.rows, 0))
-        bufs.append((None, 0))                                        # non-nullable: validity bitmap of length 0
+        bufs.append((validity_bits, (batch.rows + 7) // 8) if validity_bits is not None else (None, 0))
         if kind == "utf8":
             assert isinstance(col, DeviceUtf8)
             n_bytes = int(col.offsets[batch.rows].item()) if batch.rows else 0
@@ -204,14 +224,18 @@ def _layout(batch: DeviceBatch):
     return nodes, bufs
 
 
-def batch_to_flight_data(ctx, batch: DeviceBatch, keep_view: bool = False):
+def batch_to_flight_data(ctx, batch: DeviceBatch, keep_view: bool = False, validity: bool = False):
     """(data_header, data_body) of `flight_data_from_arrow_batch` for a device batch: body packed on the device, one D2H
     into pinned memory.  keep_view: return the body as a numpy view of the context's pinned buffer (valid until the next
-    call) instead of a bytes copy -- what a caller that compresses it right away wants."""
+    call) instead of a bytes copy -- what a caller that compresses it right away wants.  validity: write an all-ones
+    bitmap per field like the reference's arrow-rs writer (default: absent, like Arrow C++; readers accept both)."""
     import ctypes as C
     import torch
     from . import _ffi
-    nodes, bufs = _layout(batch)
+    ones = None
+    if validity:   # all-ones bitmap, shared by every field (the last byte's spare bits are 1 as well, as `with_bitset` leaves them)
+        ones = torch.full(((batch.rows + 7) // 8 + 16,), 255, dtype=torch.uint8, device=f"cuda:{ctx.device}")
+    nodes, bufs = _layout(batch, ones)
     arr = (_ffi.IpcBuffer * len(bufs))(*[_ffi.IpcBuffer(t.data_ptr() if t is not None and n else None, n) for t, n in bufs])
     total = C.c_int64(0)
     ctx._check(ctx._lib.flockgpu_ipc_pack_body(ctx._h, arr, len(bufs), None, 0, C.byref(total)))
@@ -337,14 +361,14 @@ def _kind_of(t) -> str:
 
 
 def to_payload(ctx, batch1: Sequence[DeviceBatch], batch2: Sequence[DeviceBatch], uuid: Uuid, sync: bool,
-               encoding: Optional[Encoding] = None) -> Payload:
+               encoding: Optional[Encoding] = None, validity: bool = False) -> Payload:
     """`to_payload` (transmute.rs:176-216) for batches in HBM."""
     encoding = encoding or Encoding()
 
     def frames(batches):
         out = []
         for b in batches:
-            header, body = batch_to_flight_data(ctx, b, keep_view=encoding.name != "None")
+            header, body = batch_to_flight_data(ctx, b, keep_view=encoding.name != "None", validity=validity)
             out.append(DataFrame(encoding.compress(header), encoding.compress(body)))
         return out
     p = Payload(uuid=uuid, encoding=encoding, datasource={"Payload": bool(sync)})

@@ -96,6 +96,21 @@ def test_payload_json_has_the_serde_shape():
     assert P.Payload().is_empty_data()
 
 
+def test_reference_size_goldens():
+    """The two Arrow Flight sizes the reference asserts (payload.rs:309: 1856 for 37 UK cities; :402: 3453248 for 21275
+    citibike trips) follow from the batch shapes alone (tests/golden/payload_sizes.json, tools/make_payload_golden.py): body
+    with one all-ones validity bitmap per field, as its arrow-rs writer emits, + a header that is 8 bytes shorter than the
+    one written here (flatbuffer layout) -- the same 8 bytes for 3 fields / 7 buffers and for 15 fields / 36 buffers."""
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "payload_sizes.json")))
+    for name, case in g.items():
+        cols = [(c["type"], c["value_bytes"]) for c in case["columns"]]
+        header, body = P.flight_data_sizes(case["rows"], cols, validity=True)
+        assert header + body - 8 == case["reference_flight_data_size"], name
+        h2, b2 = P.flight_data_sizes(case["rows"], cols, validity=False)
+        assert h2 == header and b2 < body
+
+
 # ---------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -135,6 +150,12 @@ def test_device_batches_through_a_payload(ctx, n, encoding):
     header, body = pay.encoding.decompress(pay.data[0].header), pay.encoding.decompress(pay.data[0].body)
     assert body == pa.ipc.read_message(b1.serialize()).body.to_pybytes()
     assert pa.ipc.read_record_batch(pa.ipc.read_message(pa.py_buffer(P.encapsulate(header, body))), P.schema_from_bytes(pay.schema)).equals(b1)
+    # the reference writer's variant (an all-ones validity bitmap per field) is read by Arrow just the same
+    h3, b3 = P.batch_to_flight_data(ctx, _device_batch(b1), validity=True)
+    assert len(b3) == len(body) + len(b1.schema) * ((((n + 7) // 8) + 7) & ~7)
+    assert pa.ipc.read_record_batch(pa.ipc.read_message(pa.py_buffer(P.encapsulate(h3, b3))), b1.schema).equals(b1)
+    back = P.flight_data_to_batch(ctx, h3, b3, _device_batch(b1).fields)
+    assert back.rows == n and (n == 0 or back.columns[0].cpu().numpy().tobytes() == np.frombuffer(b1.columns[0].buffers()[1], np.uint8)[: 4 * n].tobytes())
     # over the wire and back onto the device
     got1, got2 = P.Payload.from_json(pay.to_json()).to_record_batch(ctx)
     for got, want in ((got1[0], b1), (got1[1], b1), (got2[0], b2)):
