@@ -48,6 +48,7 @@ struct flockgpu_ctx {
     double q5_rows_per_group = 8.0;
     double q8_rows_per_seller = 4.0;
     // profiling
+    hipEvent_t sync_event = nullptr;  // for waits that must not include work queued after a copy (created on first use)
     bool profiling = false;
     std::string profile_only;  // when set: only launches of this kernel are bracketed
     std::vector<flockgpu::PendingEvent> pending;

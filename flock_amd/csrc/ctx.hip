@@ -44,6 +44,7 @@ void flockgpu_ctx_destroy(flockgpu_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     profile_drain(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->sync_event) (void)hipEventDestroy(ctx->sync_event);
     for (auto &kv : ctx->arena)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto &kv : ctx->pinned)

@@ -679,6 +679,10 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
     uint64_t cnt_total = 0, scan_total = 0;
     bool dense = st.n_tiles > 0 && n_win > 0 && max_win_panes <= kMaxWinPanes;
+    std::vector<int64_t> &last_cnt = ctx->host_i64["q5.last_cnt_total"];
+    if (last_cnt.empty()) last_cnt.push_back(0);
+    uint64_t pre_cleared = 0;
+    const uint32_t *pre_ptr = nullptr;
     if (dense) {
         FG_HIP(ctx, hipMemsetAsync(d_rng, 0x7F, sizeof(int32_t) * n_panes, ctx->stream));             // min = 0x7f7f7f7f
         FG_HIP(ctx, hipMemsetAsync(d_rng + n_panes, 0x80, sizeof(int32_t) * n_panes, ctx->stream));   // max = 0x80808080
@@ -689,7 +693,19 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         FG_TRY(check_launch(ctx, "q5_range_kernel"));
         FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * 2 * n_panes, hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!ctx->sync_event) FG_HIP(ctx, hipEventCreateWithFlags(&ctx->sync_event, hipEventDisableTiming));
+        FG_HIP(ctx, hipEventRecord(ctx->sync_event, ctx->stream));   // the host waits for the ranges only, not for the clear below
+        // While the host waits for the ranges the device would sit idle: the counter arena is cleared NOW, for as many
+        // counters as the previous call used (a stream of equal batches uses about as many); what this call needs beyond
+        // that is cleared after the synchronisation.
+        if (last_cnt[0] > 0) {
+            uint32_t *early = nullptr;
+            FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)last_cnt[0] + 4, &early));
+            FG_HIP(ctx, hipMemsetAsync(early, 0, sizeof(uint32_t) * (size_t)last_cnt[0], ctx->stream));
+            pre_cleared = (uint64_t)last_cnt[0];
+            pre_ptr = early;
+        }
+        FG_HIP(ctx, hipEventSynchronize(ctx->sync_event));
         for (int p = 0; p < n_panes && dense; ++p) {
             if (ptr[p + 1] == ptr[p] || se[p] <= sb[p] || h_rng[p] > h_rng[n_panes + p]) continue;  // unused / empty pane
             const int64_t lo = h_rng[p], hi = h_rng[n_panes + p];
@@ -734,6 +750,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
     uint32_t *counters = nullptr;
     FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+    last_cnt[0] = (int64_t)cnt_total;
 
     // device scalars: [0, n_win) win_max, [n_win, 2 n_win) win_groups, then cursor + err (2 x u32), then tab_used (u32 x n_win)
     const size_t n_meta = (size_t)2 * n_win + 1 + ((size_t)n_win + 1) / 2 + 1;
@@ -760,7 +777,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         FG_TRY(arena_get_t(ctx, "q5.sel_key", out_cap, &o_key));
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         FG_HIP(ctx, hipMemsetAsync(tables, 0, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
-        if (cnt_total) FG_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t) * cnt_total, ctx->stream));
+        if (cnt_total) {
+            // (the early clear counts only for the first attempt and only if the arena did not move)
+            const uint64_t done = (attempt == 0 && pre_ptr == counters) ? std::min(pre_cleared, cnt_total) : 0;
+            if (cnt_total > done)
+                FG_HIP(ctx, hipMemsetAsync(counters + done, 0, sizeof(uint32_t) * (cnt_total - done), ctx->stream));
+        }
         FG_HIP(ctx, hipMemsetAsync(d_meta, 0, sizeof(uint64_t) * n_meta, ctx->stream));
         FG_HIP(ctx, hipMemsetAsync(slow_list, 0, sizeof(int32_t), ctx->stream));
         if (st.n_tiles > 0 && n_win > 0) {
