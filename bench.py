@@ -371,16 +371,18 @@ def q11_side(ctx, eps, steps, no_cpu, seconds=109):
 
 # ------------------------------------------------------------------ JSON lines -> columns
 def json_side(ctx, steps, no_cpu, block_events=200_000, copies=100):
-    """`event_bytes_to_batch` over bid lines: the serde_json lines of 1.84e5 generated bids, laid end to end 100 times
+    """`event_bytes_to_batch` over bid lines: the serde_json lines of 1.84e5 bids of the device generator, laid end to end 100 times
     (1.84e7 lines, ~1.4 GB: a call takes at most 2^31 bytes), decoded into the four Bid columns."""
     import io
     import numpy as np
     import torch
-    import oracle
+    from flock_amd import NEXMarkSource, Window
     from flock_amd.nexmark import NEXMARK_JSON_SCHEMAS
-    s = oracle.NexmarkStream(seed=20260926, eps=1_000_000)
-    cols = s.bids(0, block_events)
-    block = oracle.nexmark_json_lines("bid", cols)
+    g = NEXMarkSource(1, block_events, Window.element_wise(), seed=20260926).generate_data(ctx, relations=("bid",))
+    cols = {k: getattr(g.bids, k).cpu().numpy() for k in ("auction", "bidder", "price", "b_date_time")}
+    # the lines serde_json writes for these bids (generator.rs:89-93): struct field order, compact separators
+    block = b"".join(b'{"auction":%d,"bidder":%d,"price":%d,"b_date_time":%d}\n' % row
+                     for row in zip(cols["auction"].tolist(), cols["bidder"].tolist(), cols["price"].tolist(), cols["b_date_time"].tolist()))
     n_block = len(cols["auction"])
     host = torch.frombuffer(bytearray(block), dtype=torch.uint8)
     text = torch.zeros(len(block) * copies + 16, dtype=torch.uint8, device=f"cuda:{ctx.device}")
