@@ -457,6 +457,19 @@ bool recognise(const JValue *root, flockgpu_plan *pl, std::string *why) {
                 return true;
             }
         }
+        // ---- q13 ("next" query): bid JOIN side_input ON auction = key  (q13.sql; the side input is a bounded table)
+        if (lk == "auction" && rk == "key") {
+            if (match_leaf(L, "auction", "price") && match_leaf(L, "bidder", "b_date_time") && match_leaf(R, "key", "value")) {
+                pl->query = 13;
+                Leaf b, sd;
+                b.relation = "bid";
+                b.cols = {col("auction", "i"), col("bidder", "i"), col("price", "i"), col("b_date_time", "tsm:")};
+                sd.relation = "side_input";
+                sd.cols = {col("key", "i"), col("value", "i")};
+                pl->leaves = {b, sd};
+                return true;
+            }
+        }
         // ---- q7 ("next" query): bid JOIN (MAX(price) AS maxprice over bid) ON price = maxprice
         if (lk == "price" && rk == "maxprice") {
             Agg mx;
@@ -471,7 +484,7 @@ bool recognise(const JValue *root, flockgpu_plan *pl, std::string *why) {
             }
         }
     }
-    *why = "plan shape is not NEXMark q1/q2/q3/q5/q7/q8";
+    *why = "plan shape is not NEXMark q1/q2/q3/q5/q7/q8/q13";
     return false;
 }
 
@@ -895,6 +908,34 @@ int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, s
         add_array_child(out_batch, r.rows, h_p, nullptr);
         add_array_child(out_batch, r.rows, h_b, nullptr);
         add_array_child(out_batch, r.rows, h_t, nullptr);
+        return FLOCKGPU_OK;
+    }
+    if (plan->query == 13) {
+        Leaf &b = plan->leaves[0], &sd = plan->leaves[1];
+        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), static_cast<const int32_t *>(b.cols[1].values),
+                             static_cast<const int32_t *>(b.cols[2].values), static_cast<const int64_t *>(b.cols[3].values), b.rows};
+        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
+        flockgpu_q13_result r{};
+        FG_TRY(flockgpu_q13_side_join(ctx, &bc, &w, static_cast<const int32_t *>(sd.cols[0].values),
+                                      static_cast<const int32_t *>(sd.cols[1].values), sd.rows, &r));
+        void *h_a, *h_b, *h_p, *h_t, *h_v;
+        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
+        FG_TRY(d2h_alloc(ctx, r.bidder, (size_t)r.rows * 4, &h_b));
+        FG_TRY(d2h_alloc(ctx, r.price, (size_t)r.rows * 4, &h_p));
+        FG_TRY(d2h_alloc(ctx, r.b_date_time, (size_t)r.rows * 8, &h_t));
+        FG_TRY(d2h_alloc(ctx, r.value, (size_t)r.rows * 4, &h_v));
+        make_schema(out_schema, "+s", "", false);
+        add_schema_child(out_schema, "i", "auction", false);   // q13_plan.fmt:1
+        add_schema_child(out_schema, "i", "bidder", false);
+        add_schema_child(out_schema, "i", "price", false);
+        add_schema_child(out_schema, "tsm:", "b_date_time", false);
+        add_schema_child(out_schema, "i", "value", false);
+        make_struct_array(out_batch, r.rows);
+        add_array_child(out_batch, r.rows, h_a, nullptr);
+        add_array_child(out_batch, r.rows, h_b, nullptr);
+        add_array_child(out_batch, r.rows, h_p, nullptr);
+        add_array_child(out_batch, r.rows, h_t, nullptr);
+        add_array_child(out_batch, r.rows, h_v, nullptr);
         return FLOCKGPU_OK;
     }
     if (plan->query == 8) {

@@ -12,7 +12,8 @@
  *           "binary_expr" | "literal" | "cast_expr" | "try_cast_expr"; fixtures under flock/src/tests/data/plan/)
  *   data  = Arrow RecordBatches through the Arrow C Data Interface (what arrow-rs exports as
  *           FFI_ArrowArray / FFI_ArrowSchema): one struct array per RecordBatch.
- * The engine recognises the plan shapes of NEXMark q1, q2, q3, q5 and q8 and
+ * The engine recognises the plan shapes of NEXMark q1, q2, q3, q5 and q8, of the "next"
+ * queries q7 and q13 (section 8(f): q13's side input is fed as the plan's second relation), and
  * returns FLOCKGPU_ERR_UNSUPPORTED for anything else, so the host can keep its DataFusion path for those.
  * Transparent nodes (RepartitionExec, CoalesceBatchesExec, CoalescePartitions/MergeExec, renaming
  * ProjectionExec) and the Partial/Final split of HashAggregateExec have no effect on the row multiset and are
@@ -67,10 +68,10 @@ typedef struct flockgpu_plan flockgpu_plan;
 int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out);
 void flockgpu_plan_destroy(flockgpu_plan *plan);
 /* Host-only: parses + matches a plan without a device context.  *query receives 1/2/3/5/8; returns
- * FLOCKGPU_OK, FLOCKGPU_ERR_PLAN (bad JSON) or FLOCKGPU_ERR_UNSUPPORTED (not one of the five shapes). */
+ * FLOCKGPU_OK, FLOCKGPU_ERR_PLAN (bad JSON) or FLOCKGPU_ERR_UNSUPPORTED (not one of the recognised shapes). */
 int flockgpu_plan_recognise(const char *plan_json, size_t len, int *query);
 
-/* NEXMark query number the plan was recognised as (1, 2, 3, 5, 8). */
+/* NEXMark query number the plan was recognised as (1, 2, 3, 5, 7, 8, 13). */
 int flockgpu_plan_query(const flockgpu_plan *plan);
 /* Leaves of the plan (MemoryExec), in the order feed expects them; the name is the relation whose columns the
  * leaf scans ("bid", "auction", "person"), found the way feed_data_sources does: by column-name set

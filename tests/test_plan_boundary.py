@@ -25,7 +25,7 @@ def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
     from flock_amd import _ffi, build
     build.build()
     lib = _ffi.load()
-    for q in (1, 2, 3, 5, 7, 8):
+    for q in (1, 2, 3, 5, 7, 8, 13):
         t = _plan(q).encode()
         got = C.c_int(0)
         assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK
@@ -52,7 +52,7 @@ def test_plan_fixtures_match_the_generator():
     spec = importlib.util.spec_from_file_location("mk", os.path.join(ROOT, "tools", "make_plan_fixtures.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
-    for name, fn in (("q1", mk.q1), ("q2", mk.q2), ("q3", mk.q3), ("q5", mk.q5), ("q8", mk.q8), ("q7", mk.q7)):
+    for name, fn in (("q1", mk.q1), ("q2", mk.q2), ("q3", mk.q3), ("q5", mk.q5), ("q8", mk.q8), ("q7", mk.q7), ("q13", mk.q13)):
         assert json.load(open(os.path.join(PLANS, name + ".json"))) == json.loads(json.dumps(fn())), name
 
 
@@ -258,4 +258,33 @@ def test_q7_tumbling_window_through_collect(gpu):
         assert rb["b_date_time"].cast(pa.int64()).to_numpy().tolist() == host["b_date_time"][rows].tolist()
         assert rb.num_rows >= 1
     assert collect(ctx, [[[]]])[0][0].num_rows == 0                                              # MAX of nothing is NULL
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_q13_side_input_join_through_collect(gpu):
+    """q13 ("next" query) through the plan-level ABI: per ElementWise epoch, bid JOIN side_input ON auction = key; the side
+    input is fed as the plan's second relation (the reference registers it as a MemTable, benchmarks/src/nexmark/main.rs:353-385)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=21, eps=20_000)
+    key = np.arange(1000, 1400, 7, dtype=np.int32)
+    key = np.concatenate([key, key[:5]])                                   # duplicate keys: a bid joins every matching side row
+    value = (key * 3 + np.arange(len(key))).astype(np.int32)
+    side = [pa.record_batch([pa.array(key), pa.array(value)], names=["key", "value"])]
+    ctx = ExecutionContext([_plan(13)], name="q13-00", gpu=gpu)
+    total = 0
+    for e in range(2):
+        n0, n1 = e * 20_000, (e + 1) * 20_000
+        rb = collect(ctx, [[_bid_batches(s, n0, n1, 6_000)], [side]])[0][0]
+        host = s.bids(n0, n1)
+        bid_rows, side_rows = oracle.q13_side_join(host["auction"], key)
+        assert rb.schema.names == ["auction", "bidder", "price", "b_date_time", "value"]
+        assert rb.schema.types == [pa.int32(), pa.int32(), pa.int32(), TS, pa.int32()]          # q13_plan.fmt:1
+        got = sorted(zip(rb["auction"].to_pylist(), rb["bidder"].to_pylist(), rb["price"].to_pylist(),
+                         rb["b_date_time"].cast(pa.int64()).to_pylist(), rb["value"].to_pylist()))
+        want = sorted(zip(host["auction"][bid_rows].tolist(), host["bidder"][bid_rows].tolist(), host["price"][bid_rows].tolist(),
+                          host["b_date_time"][bid_rows].tolist(), value[side_rows].tolist()))
+        assert got == want
+        total += len(want)
+    assert total > 100
     ctx.close()

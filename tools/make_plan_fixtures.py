@@ -180,9 +180,22 @@ def q7():
                               (col("b_date_time", 3), "b_date_time")], out)
 
 
+def q13():
+    # benchmarks/src/nexmark/query/q13.sql + q13_plan.fmt (SURVEY.md section 8(f) "next" query):
+    # Projection [auction, bidder, price, b_date_time, value] <- HashJoin(auction = key)
+    #   left : bid (hash-repartitioned on auction)      right: side_input [key, value] (hash-repartitioned on key)
+    side = [field("key", "Int32"), field("value", "Int32")]
+    left = coalesce(hashp(rr(memory(BID, [0, 1, 2, 3], "bid")), [col("auction", 0)]))
+    right = coalesce(hashp(rr(memory(side, [0, 1], "side_input")), [col("key", 0)]))
+    j = join(left, right, [(("auction", 0), ("key", 0))], BID + side)
+    out = BID + [field("value", "Int32")]
+    return proj(coalesce(j), [(col("auction", 0), "auction"), (col("bidder", 1), "bidder"), (col("price", 2), "price"),
+                              (col("b_date_time", 3), "b_date_time"), (col("value", 5), "value")], out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7)):
+    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
