@@ -69,7 +69,10 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ state_off,
                                                           const uint8_t *__restrict__ state_data, int64_t n_rows, SegTiles st,
                                                           Utf8Lits lits, const WinTable *__restrict__ wins, int32_t *direct,
-                                                          uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err) {
+                                                          uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err, int y_shift) {
+    // A relation of a few hundred tiles (2e6 persons at 1e8 events: 245) leaves most CUs without a workgroup, and one
+    // workgroup walks its tile's eight iterations of dependent loads (offsets -> bytes) alone: blockIdx.y splits the
+    // iterations of a tile over 8 >> y_shift workgroups (rows are independent: nothing is produced per tile).
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
     const int64_t wbase = tr.tile_begin + flag_rel0();
     WinTable wt{};
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
     load_flag_tile(p_id, n_rows, tr, key);
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it) {
+        if ((it >> y_shift) != (int)blockIdx.y) continue;  // (block-uniform)
         const int64_t r0 = wbase + it * 256;
         // offsets of rows r0 .. r0+4 (clamped to the column: rows past its end are masked below)
         int32_t off[5];
@@ -358,6 +362,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     // pipeline is queued behind it, and the host learns the verdict together with the pair counts and the string byte
     // totals in ONE synchronisation (three before: statistics, pair counts, byte totals; ~60 us each at 1e8 events where
     // the kernels take 90 us).  After a call that did not qualify the statistics are read first, as before.
+    // iterations of a person tile per build workgroup: all eight when the tiles alone fill the chip, else two
+    const int build_y_shift = st_p.n_tiles >= (int64_t)ctx->num_cus * 4 ? 3 : 1;
     std::vector<int64_t> &regime = ctx->host_i64["q3.dense_regime"];
     if (regime.empty()) regime.push_back(1);
     bool try_dense = n_win > 0;
@@ -392,9 +398,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(check_launch(ctx, "q3_fill_direct_kernel"));
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
-            hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct, nullptr,
-                               0u, nullptr, d_err);
+            hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
+                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct,
+                               nullptr, 0u, nullptr, d_err, build_y_shift);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
@@ -442,9 +448,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
-            hipLaunchKernelGGL(q3_build_kernel<false>, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id,
-                               person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, tables,
-                               cap, next, d_err);
+            hipLaunchKernelGGL(q3_build_kernel<false>, dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
+                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr,
+                               tables, cap, next, d_err, build_y_shift);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
