@@ -1012,7 +1012,7 @@ int flockgpu_q5_hot_items_weighted(flockgpu_ctx *ctx, const int32_t *auction, co
                                    const flockgpu_windows *win, flockgpu_q5_result *out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     if (!out || rows < 0 || (rows > 0 && (!auction || !count))) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 weighted: null argument");
-    return q5_run(ctx, auction, count ? count : reinterpret_cast<const uint32_t *>(auction), rows, win, out, nullptr);
+    return q5_run(ctx, auction, count, rows, win, out, nullptr);  // (rows == 0 with null columns: the plain path over no rows)
 }
 
 int flockgpu_q5_partial_counts(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
