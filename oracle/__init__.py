@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         _lib.oracle_q8_join.restype = u64
         _lib.oracle_take_utf8.argtypes = [vp, vp, vp, u64, vp, vp]
         _lib.oracle_take_utf8.restype = u64
+        _lib.oracle_hash_utf8_rows.argtypes = [vp, vp, vp, u64, vp]
+        _lib.oracle_hash_utf8_rows.restype = None
     return _lib
 
 
@@ -318,6 +320,50 @@ def take_utf8(col: Utf8, rows: np.ndarray) -> Utf8:
     data = np.empty(max(nbytes, 1), np.uint8)
     lib().oracle_take_utf8(_p(col.offsets), _p(col.data), _p(rows), len(rows), _p(off), _p(data))
     return Utf8(off, data[:nbytes])
+
+
+# ---------------------------------------------------------------- result fingerprints (tests/golden/nexmark_hashes.json)
+def _fmix64(x):
+    x = np.asarray(x, np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def column_hashes(col, rows=None) -> np.ndarray:
+    """64-bit hash per value of one column (optionally of `col.take(rows)`): integers as their int64 value, Utf8 by bytes."""
+    if isinstance(col, Utf8):
+        n = len(col) if rows is None else len(rows)
+        out = np.empty(n, np.uint64)
+        r = None if rows is None else np.ascontiguousarray(rows, np.int64)
+        off, data = np.ascontiguousarray(col.offsets, np.int32), np.ascontiguousarray(col.data, np.uint8)
+        lib().oracle_hash_utf8_rows(_p(off), _p(data) if len(data) else None, _p(r), n, _p(out))
+        return out
+    v = np.asarray(col)
+    if rows is not None:
+        v = v[np.asarray(rows, np.int64)]
+    if v.dtype.kind == "f":
+        v = np.ascontiguousarray(v, np.float64).view(np.int64)       # the BITS of a Float64 column
+    with np.errstate(over="ignore"):
+        return _fmix64(v.astype(np.int64).view(np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+
+
+def row_hashes(columns) -> np.ndarray:
+    """Hash per result row: the per-column hashes chained left to right (column order matters, row order does not).
+    An entry is a column, or (column, rows) for `column.take(rows)` -- join outputs name rows of two relations."""
+    r = None
+    for c in columns:
+        h = column_hashes(*c) if isinstance(c, tuple) else column_hashes(c)
+        r = _fmix64((np.uint64(0x243F6A8885A308D3) if r is None else r) ^ h)
+    return r
+
+
+def multiset_fingerprint(columns) -> str:
+    """'rows:sum64' of one window's result rows -- equal for equal row multisets whatever the order."""
+    h = row_hashes(columns)
+    with np.errstate(over="ignore"):
+        return f"{len(h)}:{int(h.sum(dtype=np.uint64)):016x}"
 
 
 # ---------------------------------------------------------------- window schedules

@@ -224,3 +224,24 @@ uint64_t oracle_take_utf8(const int32_t *off, const char *bytes, const int64_t *
     }
     return (uint64_t)o;
 }
+
+/* ---- result fingerprints (tests/golden/nexmark_hashes.json) ------------------------------------------
+ * Per-row 64-bit hash of a Utf8 column's values (FNV-1a over the bytes, length folded in, then a
+ * splitmix64 finaliser); `rows` == NULL hashes rows 0..n-1, otherwise rows[i] (a take).  The hash of a
+ * result ROW chains these per-column hashes in oracle/__init__.py (row_hashes), and a window's
+ * fingerprint is (row count, sum of row hashes mod 2^64): order-free, the reference's own comparison
+ * convention for join / aggregate outputs (flock/src/test_util.rs:61-90 sorts before comparing). */
+static uint64_t fmix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+void oracle_hash_utf8_rows(const int32_t *off, const unsigned char *bytes, const int64_t *rows, uint64_t n,
+                           uint64_t *out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        int64_t r = rows ? rows[i] : (int64_t)i;
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (int32_t b = off[r]; b < off[r + 1]; ++b) { h ^= bytes[b]; h *= 0x100000001B3ull; }
+        out[i] = fmix64(h + (uint64_t)(off[r + 1] - off[r]) * 0x9E3779B97F4A7C15ull);
+    }
+}

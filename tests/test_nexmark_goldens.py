@@ -1,0 +1,119 @@
+"""tests/golden/nexmark_hashes.json (minted by tools/make_nexmark_goldens.py from oracle == pyarrow agreement,
+SURVEY.md section 8c) against (CPU) the oracle re-run on the small configurations and (GPU, -m gpu) the HIP path on EVERY
+window of EVERY configuration, BASELINE.json's full sizes included: q2 1e8 bids (109 windows), q3 1e8 / 1e9 events
+(100 / 1000 windows), q5 1e9 bids (216 windows), q8 1e9 events (100 windows)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "nexmark_hashes.json")))
+
+
+def _parse(k):
+    q, seed, eps, seconds = k.split("/")
+    return int(q[1:]), int(seed.split("=")[1]), int(eps.split("=")[1]), int(seconds.split("=")[1])
+
+
+SMALL = [k for k in sorted(GOLDEN) if _parse(k)[2] * _parse(k)[3] <= 5_000_000]
+ALL = sorted(GOLDEN, key=lambda k: (_parse(k)[2] * _parse(k)[3], k))
+
+
+def test_golden_file_covers_the_baseline_configs():
+    for k, windows in (("q2/seed=20260925/eps=1000000/seconds=109", 109), ("q3/seed=20260925/eps=1000000/seconds=100", 100),
+                       ("q3/seed=20260925/eps=1000000/seconds=1000", 1000), ("q5/seed=20260925/eps=1000000/seconds=1087", 216),
+                       ("q8/seed=20260925/eps=1000000/seconds=1000", 100)):
+        assert GOLDEN[k]["windows"] == windows == len(GOLDEN[k]["fingerprints"]), k
+        assert GOLDEN[k]["result_rows"] > 0
+
+
+@pytest.mark.parametrize("k", SMALL)
+def test_oracle_reproduces_the_small_goldens(k):
+    """Re-mints the small entries in memory (oracle AND pyarrow, asserted equal inside) and compares with the frozen file."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_nexmark_goldens as m
+    q, seed, eps, seconds = _parse(k)
+    got = m.mint(q, seed, eps, seconds, threads=4)
+    assert got == GOLDEN[k]
+
+
+def test_fingerprint_is_order_free_and_column_order_sensitive():
+    u = oracle.Utf8(np.array([0, 2, 4, 6], np.int32), np.frombuffer(b"orcaid", np.uint8).copy())
+    a = np.array([1, 2, 3], np.int32)
+    perm = np.array([2, 0, 1])
+    assert oracle.multiset_fingerprint([u, a]) == oracle.multiset_fingerprint([(u, perm), a[perm]])
+    assert oracle.multiset_fingerprint([u, a]) != oracle.multiset_fingerprint([u, a[perm]])
+    assert oracle.multiset_fingerprint([a, a[perm]]) != oracle.multiset_fingerprint([a[perm], a])
+    assert oracle.multiset_fingerprint([a[:0]]) == "0:0000000000000000"
+
+
+# ------------------------------------------------------------------ GPU: the HIP path against every frozen window
+def _segment_fingerprints(row_hash, off):
+    out = []
+    with np.errstate(over="ignore"):
+        cs = np.concatenate(([np.uint64(0)], np.cumsum(row_hash, dtype=np.uint64)))
+    for w in range(len(off) - 1):
+        lo, hi = int(off[w]), int(off[w + 1])
+        out.append(f"{hi - lo}:{int(cs[hi] - cs[lo]) & 0xFFFFFFFFFFFFFFFF:016x}")
+    return out
+
+
+def _u(pair, n):
+    off, data = pair
+    return oracle.Utf8(off[: n + 1], data)
+
+
+def hip_fingerprints(ctx, q, seed, eps, seconds):
+    """Per-window fingerprints of the HIP path's OUTPUT COLUMNS (C ABI -> host copies), hashed with the checker's hash."""
+    import torch
+    from flock_amd import NEXMarkSource, query_window, run_query
+    rel = {1: ("bid",), 2: ("bid",), 5: ("bid",), 3: ("auction", "person"), 8: ("auction", "person")}[q]
+    cols = {1: ("auction", "bidder", "price", "b_date_time"), 2: ("auction", "price"), 5: ("auction",)}.get(q, ("auction",))
+    g = NEXMarkSource(seconds, eps, query_window(q), seed=seed).generate_data(ctx, relations=rel, bid_columns=cols)
+    out = run_query(ctx, q, g)
+    if q == 1:
+        off = g.window_schedule("bid").pane_row_offsets
+        b = g.bids
+        h = oracle.row_hashes([b.auction.cpu().numpy(), b.bidder.cpu().numpy(), out.cpu().numpy(), b.b_date_time.cpu().numpy()])
+    elif q == 2:
+        a, p, off = out.to_host()
+        h = oracle.row_hashes([a, p])
+    elif q == 5:
+        a, n, off = out.to_host()
+        assert n.dtype == np.uint64                          # q5_plan.fmt:1 `num: UInt64`
+        h = oracle.row_hashes([a, n.astype(np.int64)])
+    elif q == 3:
+        o = out.to_host()
+        off, n = o["offsets"], len(o["a_id"])
+        h = oracle.row_hashes([_u(o["name"], n), _u(o["city"], n), _u(o["state"], n), o["a_id"]]) if n else np.zeros(0, np.uint64)
+    else:
+        o = out.to_host()
+        off, n = o["offsets"], len(o["p_id"])
+        h = oracle.row_hashes([o["p_id"], _u(o["name"], n)]) if n else np.zeros(0, np.uint64)
+    del g, out
+    torch.cuda.empty_cache()
+    return _segment_fingerprints(h if h is not None else np.zeros(0, np.uint64), off)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", ALL)
+def test_hip_path_reproduces_every_frozen_window(ctx, k):
+    q, seed, eps, seconds = _parse(k)
+    got = hip_fingerprints(ctx, q, seed, eps, seconds)
+    want = GOLDEN[k]["fingerprints"]
+    assert len(got) == len(want) == GOLDEN[k]["windows"]
+    bad = [w for w in range(len(want)) if got[w] != want[w]]
+    assert not bad, f"{k}: {len(bad)} windows differ, first {bad[:5]}: {[(got[w], want[w]) for w in bad[:3]]}"
