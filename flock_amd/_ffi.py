@@ -204,6 +204,15 @@ SYMBOLS = {
     "flockgpu_plan_input_matches": (_i, [_vp, _i, _vp]),
     "flockgpu_plan_feed": (_i, [_vp, _i, _vp, C.POINTER(_vp), _i]),
     "flockgpu_plan_execute": (_i, [_vp, _vp, _vp]),
+    "flockgpu_plan_execute_partitioned": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "flockgpu_plan_explain": (_i, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "flockgpu_plan_description": (C.c_char_p, [_vp]),
+    "flockgpu_plan_is_shuffling": (_i, [_vp]),
+    "flockgpu_plan_output_partitions": (_i, [_vp]),
+    "flockgpu_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "flockgpu_host_free": (_i, [_vp]),
+    "flockgpu_host_register": (_i, [_vp, C.c_size_t]),
+    "flockgpu_host_unregister": (_i, [_vp]),
     "flockgpu_plan_reset": (_i, [_vp]),
 }
 
@@ -219,6 +228,13 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m flock_amd.build` (hipcc, gfx950). "
             "flock_amd has no CPU fallback.")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 / librccl under the same SONAMEs as
+    # /opt/rocm's, and whichever is mapped first serves both.  torch is this host's allocator and stream provider, so its
+    # runtime must be the one (loading /opt/rocm's first left `torch.cuda` without a device on the GPU boxes).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name, None)

@@ -1,491 +1,510 @@
-// Plan-level C ABI (include/flockgpu_plan.h): serde_json physical plan in, Arrow C Data Interface batches in/out.
-// Host-side code only; the compute goes through the flockgpu_q*_ entry points (one window = everything fed).
+// Plan-level C ABI (include/flockgpu_plan.h): serde_json physical plan in, Arrow C Data Interface batches in / out.
+//   feed_data_sources  flock/src/runtime/context.rs:257-325   -> flockgpu_plan_feed (pinned or staged H2D, no host wait)
+//   execute            flock/src/runtime/context.rs:172-191   -> flockgpu_plan_execute
+//   execute_partitioned context.rs:197-216 (chosen by is_shuffling, context.rs:328-337; flock-function/src/aws/actor.rs:60-66)
+//                                                             -> flockgpu_plan_execute_partitioned
+//   clean_data_sources context.rs:227-254                     -> flockgpu_plan_reset
+// The plan is parsed into the operator tree of plan_ir.hpp.  Sub-trees that are one of the NEXMark pipelines run as the
+// fused kernels of flockgpu.h (q2 filter, q3 / q8 / q13 joins, q5 / q7 aggregates, the Partial COUNT of q5.dag);
+// every other node -- the STAGE plans either side of a `RepartitionExec Hash` -- runs on the generic operators of
+// relops.hpp.  Host-side code only; all compute goes through those two layers.
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 
 #include "../../include/flockgpu_plan.h"
-#include "common.hpp"
+#include "plan_ir.hpp"
 
 using namespace flockgpu;
+using namespace flockgpu::ir;
 
 namespace {
 
-// ------------------------------------------------------------------ minimal JSON
-struct JValue;
-using JPtr = std::shared_ptr<JValue>;
-struct JValue {
-    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
-    bool b = false;
-    double num = 0;
-    int64_t inum = 0;
-    bool is_int = false;
-    std::string str;
-    std::vector<JPtr> arr;
-    std::vector<std::pair<std::string, JPtr>> obj;
-    const JValue *get(const char *key) const {
-        for (auto &kv : obj)
-            if (kv.first == key) return kv.second.get();
-        return nullptr;
+// ------------------------------------------------------------------ pinned host memory, pooled
+// Output batches live in pinned host memory (one block per execute); blocks return to a process-wide pool when the
+// consumer calls the Arrow release callback (possibly from another thread, possibly after the ctx is gone).
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void *>> free_blocks;
+    size_t held = 0;
+    static constexpr size_t kMaxHeld = size_t(2) << 30;
+    void *get(size_t bytes, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].first >= bytes && free_blocks[i].first <= bytes * 2 + (1 << 20) &&
+                    (best == free_blocks.size() || free_blocks[i].first < free_blocks[best].first))
+                    best = i;
+            if (best != free_blocks.size()) {
+                auto b = free_blocks[best];
+                free_blocks.erase(free_blocks.begin() + (long)best);
+                held -= b.first;
+                *cap = b.first;
+                return b.second;
+            }
+        }
+        size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
+        want = (want + 4095) & ~size_t(4095);
+        void *p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *cap = want;
+        return p;
     }
-    std::string s(const char *key) const {
-        const JValue *v = get(key);
-        return v && v->kind == Str ? v->str : std::string();
+    void put(void *p, size_t cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (held + cap <= kMaxHeld) {
+                free_blocks.emplace_back(cap, p);
+                held += cap;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinnedPool &pool() {
+    static PinnedPool *p = new PinnedPool();  // never destroyed: release callbacks may run during process exit
+    return *p;
+}
+struct HostBlock {  // shared by the partitions of one execute
+    void *ptr = nullptr;
+    size_t cap = 0;
+    ~HostBlock() {
+        if (ptr) pool().put(ptr, cap);
     }
 };
 
-struct JParser {
-    const char *p, *end;
-    std::string err;
-    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
-    bool fail(const char *m) { if (err.empty()) err = m; return false; }
-    bool parse_string(std::string &out) {
-        if (p >= end || *p != '"') return fail("expected string");
-        ++p;
-        while (p < end && *p != '"') {
-            if (*p == '\\') {
-                if (++p >= end) return fail("bad escape");
-                switch (*p) {
-                    case 'n': out += '\n'; break;
-                    case 't': out += '\t'; break;
-                    case 'r': out += '\r'; break;
-                    case 'b': out += '\b'; break;
-                    case 'f': out += '\f'; break;
-                    case 'u': {
-                        if (end - p < 5) return fail("bad \\u escape");
-                        unsigned v = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
-                        if (v < 0x80) out += (char)v;
-                        else if (v < 0x800) { out += (char)(0xC0 | (v >> 6)); out += (char)(0x80 | (v & 0x3F)); }
-                        else { out += (char)(0xE0 | (v >> 12)); out += (char)(0x80 | ((v >> 6) & 0x3F)); out += (char)(0x80 | (v & 0x3F)); }
-                        p += 4;
-                        break;
-                    }
-                    default: out += *p;
-                }
-                ++p;
-            } else {
-                out += *p++;
-            }
-        }
-        if (p >= end) return fail("unterminated string");
-        ++p;
-        return true;
-    }
-    bool parse(JPtr &out, int depth = 0) {
-        if (depth > 200) return fail("plan nested too deep");
-        ws();
-        if (p >= end) return fail("unexpected end");
-        out = std::make_shared<JValue>();
-        if (*p == '{') {
-            out->kind = JValue::Obj;
-            ++p; ws();
-            if (p < end && *p == '}') { ++p; return true; }
-            for (;;) {
-                ws();
-                std::string key;
-                if (!parse_string(key)) return false;
-                ws();
-                if (p >= end || *p != ':') return fail("expected ':'");
-                ++p;
-                JPtr v;
-                if (!parse(v, depth + 1)) return false;
-                out->obj.emplace_back(std::move(key), v);
-                ws();
-                if (p < end && *p == ',') { ++p; continue; }
-                if (p < end && *p == '}') { ++p; return true; }
-                return fail("expected ',' or '}'");
-            }
-        }
-        if (*p == '[') {
-            out->kind = JValue::Arr;
-            ++p; ws();
-            if (p < end && *p == ']') { ++p; return true; }
-            for (;;) {
-                JPtr v;
-                if (!parse(v, depth + 1)) return false;
-                out->arr.push_back(v);
-                ws();
-                if (p < end && *p == ',') { ++p; continue; }
-                if (p < end && *p == ']') { ++p; return true; }
-                return fail("expected ',' or ']'");
-            }
-        }
-        if (*p == '"') { out->kind = JValue::Str; return parse_string(out->str); }
-        if (!strncmp(p, "true", std::min<size_t>(4, end - p)) && end - p >= 4) { out->kind = JValue::Bool; out->b = true; p += 4; return true; }
-        if (!strncmp(p, "false", std::min<size_t>(5, end - p)) && end - p >= 5) { out->kind = JValue::Bool; p += 5; return true; }
-        if (!strncmp(p, "null", std::min<size_t>(4, end - p)) && end - p >= 4) { p += 4; return true; }
-        const char *q = p;
-        bool is_int = true;
-        if (q < end && (*q == '-' || *q == '+')) ++q;
-        while (q < end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '-' || *q == '+')) {
-            if (*q == '.' || *q == 'e' || *q == 'E') is_int = false;
-            ++q;
-        }
-        if (q == p) return fail("unexpected character");
-        std::string tok(p, q);
-        out->kind = JValue::Num;
-        out->num = strtod(tok.c_str(), nullptr);
-        out->is_int = is_int;
-        if (is_int) out->inum = strtoll(tok.c_str(), nullptr, 10);
-        p = q;
-        return true;
-    }
+// ------------------------------------------------------------------ tables
+struct TCol {
+    DevColumn c;
+    bool present = false;
 };
-
-// ------------------------------------------------------------------ plan recognition
-const std::string &tag(const JValue *n) {
-    static const std::string empty;
-    const JValue *t = n ? n->get("execution_plan") : nullptr;
-    return t && t->kind == JValue::Str ? t->str : empty;
-}
-const std::string &etag(const JValue *e) {
-    static const std::string empty;
-    const JValue *t = e ? e->get("physical_expr") : nullptr;
-    return t && t->kind == JValue::Str ? t->str : empty;
-}
-// cast_expr / try_cast_expr are value-preserving for the widening casts the planner inserts (planner.rs:90,122,155)
-const JValue *uncast(const JValue *e) {
-    while (e && (etag(e) == "cast_expr" || etag(e) == "try_cast_expr")) e = e->get("expr");
-    return e;
-}
-bool is_column(const JValue *e, std::string *name) {
-    e = uncast(e);
-    if (etag(e) != "column") return false;
-    if (name) *name = e->s("name");
-    return true;
-}
-// literal{"value": {"Int64": 123}} (also accepts a bare number / string)
-bool literal_i64(const JValue *e, int64_t *v) {
-    e = uncast(e);
-    if (etag(e) != "literal") return false;
-    const JValue *val = e->get("value");
-    if (!val) return false;
-    if (val->kind == JValue::Obj && val->obj.size() == 1) val = val->obj[0].second.get();
-    if (val->kind != JValue::Num || !val->is_int) return false;
-    *v = val->inum;
-    return true;
-}
-bool literal_f64(const JValue *e, double *v) {
-    e = uncast(e);
-    if (etag(e) != "literal") return false;
-    const JValue *val = e->get("value");
-    if (!val) return false;
-    if (val->kind == JValue::Obj && val->obj.size() == 1) val = val->obj[0].second.get();
-    if (val->kind != JValue::Num) return false;
-    *v = val->num;
-    return true;
-}
-bool literal_utf8(const JValue *e, std::string *v) {
-    e = uncast(e);
-    if (etag(e) != "literal") return false;
-    const JValue *val = e->get("value");
-    if (!val) return false;
-    if (val->kind == JValue::Obj && val->obj.size() == 1) val = val->obj[0].second.get();
-    if (val->kind != JValue::Str) return false;
-    *v = val->str;
-    return true;
-}
-bool is_binary(const JValue *e, const char *op, const JValue **l, const JValue **r) {
-    if (etag(e) != "binary_expr" || e->s("op") != op) return false;
-    *l = e->get("left");
-    *r = e->get("right");
-    return *l && *r;
-}
-bool projection_is_passthrough(const JValue *n) {
-    const JValue *ex = n->get("expr");
-    if (!ex || ex->kind != JValue::Arr) return false;
-    for (auto &pair : ex->arr) {
-        if (pair->kind != JValue::Arr || pair->arr.empty()) return false;
-        if (etag(pair->arr[0].get()) != "column") return false;
-    }
-    return true;
-}
-// Skips nodes that do not change the row multiset.
-const JValue *strip(const JValue *n) {
-    for (;;) {
-        const std::string &t = tag(n);
-        if (t == "coalesce_batches_exec" || t == "repartition_exec" || t == "merge_exec" ||
-            t == "coalesce_partitions_exec" || (t == "projection_exec" && projection_is_passthrough(n))) {
-            n = n->get("input");
-            continue;
-        }
-        return n;
-    }
-}
-std::vector<std::string> leaf_columns(const JValue *mem) {
-    std::vector<std::string> all, out;
-    const JValue *schema = mem->get("schema");
-    const JValue *fields = schema ? schema->get("fields") : nullptr;
-    if (fields && fields->kind == JValue::Arr)
-        for (auto &f : fields->arr) all.push_back(f->s("name"));
-    const JValue *proj = mem->get("projection");
-    if (proj && proj->kind == JValue::Arr && !proj->arr.empty()) {
-        for (auto &i : proj->arr)
-            if (i->kind == JValue::Num && i->inum >= 0 && (size_t)i->inum < all.size()) out.push_back(all[i->inum]);
-        // fixtures of older fork revisions list only the projected fields: indices then exceed the list
-        if (out.size() != proj->arr.size()) out = all;
-    } else {
-        out = all;
-    }
-    return out;
-}
-// Logical aggregate = Final/FinalPartitioned over (transparent nodes over) Partial with the same grouping, or a
-// single-stage aggregate.  Returns the aggregate's input (below the Partial stage).
-struct Agg {
-    std::vector<std::string> group;
-    std::vector<std::string> kinds;  // "count", "max", ...
-    const JValue *input = nullptr;
-};
-bool match_agg(const JValue *n, Agg *a) {
-    n = strip(n);
-    if (tag(n) != "hash_aggregate_exec") return false;
-    auto groups = [](const JValue *x) {
-        std::vector<std::string> g;
-        const JValue *ge = x->get("group_expr");
-        if (ge && ge->kind == JValue::Arr)
-            for (auto &pair : ge->arr) {
-                std::string name;
-                if (pair->kind == JValue::Arr && !pair->arr.empty() && is_column(pair->arr[0].get(), &name)) g.push_back(name);
-                else g.push_back("?");
-            }
-        return g;
-    };
-    a->group = groups(n);
-    a->kinds.clear();
-    const JValue *ae = n->get("aggr_expr");
-    if (ae && ae->kind == JValue::Arr)
-        for (auto &x : ae->arr) a->kinds.push_back(x->s("aggregate_expr"));
-    const std::string mode = n->s("mode");
-    const JValue *in = strip(n->get("input"));
-    if ((mode == "Final" || mode == "FinalPartitioned") && tag(in) == "hash_aggregate_exec" && in->s("mode") == "Partial") {
-        if (groups(in).size() != a->group.size()) return false;
-        in = strip(in->get("input"));
-    }
-    a->input = in;
-    return true;
-}
-const JValue *match_leaf(const JValue *n, const char *need_a, const char *need_b = nullptr) {
-    n = strip(n);
-    if (tag(n) != "memory_exec") return nullptr;
-    auto cols = leaf_columns(n);
-    auto has = [&](const char *c) { return !c || std::find(cols.begin(), cols.end(), c) != cols.end(); };
-    return has(need_a) && has(need_b) ? n : nullptr;
-}
-
-struct HostCol {  // concatenated host copy (pass-through columns of q1)
-    std::vector<uint8_t> bytes;
-};
-struct DevCol {
-    std::string name;
-    std::string format;       // Arrow format string expected: "i", "l"/"tsm:", "u"
-    bool keep_host = false;   // q1 pass-through
-    // device copies, filled by feed
-    void *values = nullptr;   // fixed width values or Utf8 bytes
-    int32_t *offsets = nullptr;
-    int64_t bytes = 0;        // Utf8 bytes so far
-    HostCol host;
-};
-struct Leaf {
-    std::string relation;
-    std::vector<DevCol> cols;
+struct Table {
+    std::vector<TCol> cols;
     int64_t rows = 0;
 };
+
+struct DevBuf {  // a leaf column on the device, grown by feeds
+    void *values = nullptr;  // fixed-width values or Utf8 bytes
+    int32_t *offsets = nullptr;
+    int64_t bytes = 0;
+};
+struct LeafData {
+    std::vector<DevBuf> cols;
+    int64_t rows = 0;
+};
+
+enum Fused { kNone = 0, kQ2, kQ3, kQ5, kQ7, kQ8, kQ13, kPartialCount };
+struct FusedInfo {
+    Fused kind = kNone;
+    int leaf_a = -1, leaf_b = -1;     // the scans below
+    std::vector<int> a_cols, b_cols;  // leaf columns handed to the fused entry point, in its argument order (-1: unused)
+    std::vector<int> out_map;         // node output column -> fused output slot (-1: not produced)
+    int64_t lit = 0;                  // q2 modulus / q3 category
+    std::vector<std::string> strs;    // q3 state literals
+};
+
+constexpr int kStageChunks = 4;
+constexpr size_t kStageChunk = size_t(8) << 20;
 
 }  // namespace
 
 struct flockgpu_plan {
     flockgpu_ctx *ctx = nullptr;
-    int query = 0;
-    std::vector<Leaf> leaves;
-    // parameters lifted from the plan
-    double q1_factor = 0.908;
-    std::string q1_out_name = "price";
-    int64_t q2_modulus = 123;
-    int64_t q3_category = 10;
-    std::vector<std::string> q3_states;
+    ir::Plan ir;
+    std::vector<LeafData> leaves;
+    std::vector<FusedInfo> fused;  // by node id
+    int query = 0;                 // NEXMark query number when the whole plan is one fused pipeline, else 0
+    std::string description;
+    bool generic_only = false;
+    // pageable feeds go through a ring of pinned chunks: the host copies into chunk k + 1 while chunk k is in flight
+    void *stage[kStageChunks] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stage_done[kStageChunks] = {nullptr, nullptr, nullptr, nullptr};
+    int stage_next = 0;
+    int64_t fed_bytes = 0;
 };
 
 namespace {
 
-DevCol col(const char *name, const char *fmt, bool keep_host = false) {
-    DevCol c;
-    c.name = name;
-    c.format = fmt;
-    c.keep_host = keep_host;
-    return c;
+// ------------------------------------------------------------------ fused-pipeline recognition (structure only)
+struct Peeled {
+    const Node *n = nullptr;
+    std::vector<int> map;  // output column of the peeled-from node -> column of n (-1: computed)
+};
+// Follows projections that only select / rename columns and hash repartitions (no effect on the row multiset).
+Peeled peel(const Node *n) {
+    Peeled p;
+    p.n = n;
+    p.map.resize(n->schema.size());
+    for (size_t i = 0; i < p.map.size(); ++i) p.map[i] = (int)i;
+    for (;;) {
+        if (p.n->kind == NKind::Repartition) {
+            p.n = p.n->in[0].get();
+            continue;
+        }
+        if (p.n->kind == NKind::Project) {
+            bool pure = true;
+            for (auto &e : p.n->proj) pure = pure && e.first->kind == EKind::Col;
+            if (!pure) return p;
+            for (auto &m : p.map)
+                if (m >= 0) m = p.n->proj[(size_t)m].first->col;
+            p.n = p.n->in[0].get();
+            continue;
+        }
+        return p;
+    }
+}
+const Expr *uncast(const Expr *e) {
+    while (e && e->kind == EKind::Cast && (e->cast_to == ColType::I64 || e->cast_to == ColType::F64)) e = e->l.get();
+    return e;
+}
+bool is_bin(const Expr *e, const char *op) { return e && e->kind == EKind::Bin && e->s == op; }
+
+// Logical aggregate: Final / FinalPartitioned over (peeled) Partial with the same shape, or a single stage.
+// Returns the node below the lowest aggregate stage and the group / argument columns in ITS schema.
+struct LogicalAgg {
+    const Node *below = nullptr;
+    std::vector<int> group;
+    std::vector<std::string> fns;
+    std::vector<int> args;
+};
+bool logical_agg(const Node *n, LogicalAgg *out) {
+    if (n->kind != NKind::Aggregate) return false;
+    const Node *low = n;
+    if (n->mode != "Partial") {
+        Peeled p = peel(n->in[0].get());
+        if (p.n->kind == NKind::Aggregate && p.n->mode == "Partial" && p.n->group.size() == n->group.size() && p.n->aggs.size() == n->aggs.size()) {
+            // the final stage must read the partial stage's columns in place
+            for (size_t g = 0; g < n->group.size(); ++g)
+                if (p.map[(size_t)n->group[g]] != (int)g) return false;
+            for (size_t a = 0; a < n->aggs.size(); ++a) {
+                if (p.map[(size_t)n->aggs[a].arg] != (int)(n->group.size() + a) || p.n->aggs[a].fn != n->aggs[a].fn) return false;
+            }
+            low = p.n;
+        } else {
+            return false;  // a lone final stage (a stage plan): generic
+        }
+    }
+    out->below = low->in[0].get();
+    out->group = low->group;
+    for (auto &a : low->aggs) {
+        out->fns.push_back(a.fn);
+        out->args.push_back(a.arg);
+    }
+    return true;
+}
+const Node *as_scan(const Node *n, std::vector<int> *map) {
+    Peeled p = peel(n);
+    if (p.n->kind != NKind::Scan) return nullptr;
+    if (map) *map = p.map;
+    return p.n;
+}
+bool req_subset(const Node *n, const std::vector<int> &allowed) {
+    for (size_t i = 0; i < n->required.size(); ++i)
+        if (n->required[i] && std::find(allowed.begin(), allowed.end(), (int)i) == allowed.end()) return false;
+    return true;
 }
 
-// Recognises the five NEXMark stage shapes.  Returns false (UNSUPPORTED) for everything else.
-bool recognise(const JValue *root, flockgpu_plan *pl, std::string *why) {
-    const JValue *top = root;
-    // the root projection carries the computed / selected columns; keep it unless it is pure pass-through
-    const JValue *n = strip(top);
-    const std::string &t = tag(n);
-
-    // ---- q1: Projection [auction, bidder, 0.908 * CAST(price AS Float64) AS price, b_date_time] over bid
-    if (tag(top) == "projection_exec" && !projection_is_passthrough(top)) {
-        const JValue *in = strip(top->get("input"));
-        const JValue *ex = top->get("expr");
-        if (tag(in) == "memory_exec" && ex && ex->kind == JValue::Arr && ex->arr.size() == 4) {
-            std::vector<std::string> names;
-            bool ok = true;
-            int computed = -1;
-            for (size_t i = 0; i < 4 && ok; ++i) {
-                const JValue *pair = ex->arr[i].get();
-                if (pair->kind != JValue::Arr || pair->arr.size() < 2) { ok = false; break; }
-                const JValue *e = pair->arr[0].get();
-                std::string cname;
-                const JValue *l, *r;
-                if (etag(e) == "column") {
-                    names.push_back(e->s("name"));
-                } else if (is_binary(e, "Multiply", &l, &r)) {
-                    double f;
-                    if (literal_f64(l, &f) && is_column(r, &cname)) { pl->q1_factor = f; }
-                    else if (literal_f64(r, &f) && is_column(l, &cname)) { pl->q1_factor = f; }
-                    else ok = false;
-                    names.push_back(cname);
-                    computed = (int)i;
-                    pl->q1_out_name = pair->arr[1]->str;
-                } else ok = false;
-            }
-            if (ok && computed == 2 && names[0] == "auction" && names[1] == "bidder" && names[2] == "price" &&
-                names[3] == "b_date_time") {
-                pl->query = 1;
-                Leaf lf;
-                lf.relation = "bid";
-                lf.cols = {col("auction", "i", true), col("bidder", "i", true), col("price", "i"), col("b_date_time", "tsm:", true)};
-                pl->leaves = {lf};
-                return true;
-            }
-        }
-    }
-    // ---- q2: Projection [auction, price] <- Filter CAST(auction AS Int64) % m = 0 <- bid
-    if (t == "filter_exec") {
-        const JValue *pred = n->get("predicate"), *l, *r, *ml, *mr;
-        const JValue *leaf = match_leaf(n->get("input"), "auction", "price");
-        int64_t m, rem;
-        std::string cname;
-        if (leaf && is_binary(pred, "Eq", &l, &r) && is_binary(uncast(l), "Modulo", &ml, &mr) && is_column(ml, &cname) &&
-            cname == "auction" && literal_i64(mr, &m) && literal_i64(r, &rem) && rem == 0) {
-            pl->query = 2;
-            pl->q2_modulus = m;
-            Leaf lf;
-            lf.relation = "bid";
-            lf.cols = {col("auction", "i"), col("price", "i")};
-            pl->leaves = {lf};
-            return true;
-        }
-    }
-    if (t == "hash_join_exec") {
-        const JValue *on = n->get("on");
-        std::string lk, rk;
-        if (on && on->kind == JValue::Arr && on->arr.size() == 1 && on->arr[0]->kind == JValue::Arr && on->arr[0]->arr.size() == 2) {
-            auto keyname = [](const JValue *k) {
-                if (k->kind == JValue::Str) return k->str;  // older fork revision: bare names
-                return k->s("name");
-            };
-            lk = keyname(on->arr[0]->arr[0].get());
-            rk = keyname(on->arr[0]->arr[1].get());
-        }
-        if (n->s("join_type") != "Inner") { *why = "only Inner joins"; return false; }
-        const JValue *L = strip(n->get("left")), *R = strip(n->get("right"));
-        // ---- q3: Filter(category = 10)(auction) JOIN Filter(state = .. OR ..)(person) ON seller = p_id
-        if (lk == "seller" && rk == "p_id" && tag(L) == "filter_exec" && tag(R) == "filter_exec") {
-            const JValue *al = match_leaf(L->get("input"), "seller", "category");
-            const JValue *pr = match_leaf(R->get("input"), "p_id", "state");
-            const JValue *l, *r;
-            std::string cname;
-            int64_t cat;
-            bool ok = al && pr && is_binary(L->get("predicate"), "Eq", &l, &r) && is_column(l, &cname) && cname == "category" &&
-                      literal_i64(r, &cat);
-            std::vector<std::string> states;
-            if (ok) {
-                // flatten the OR chain of `state = literal`
-                std::vector<const JValue *> stack{R->get("predicate")};
-                while (!stack.empty() && ok) {
-                    const JValue *e = stack.back();
-                    stack.pop_back();
-                    const JValue *a, *b;
-                    std::string lit;
-                    if (is_binary(e, "Or", &a, &b)) { stack.push_back(b); stack.push_back(a); }
-                    else if (is_binary(e, "Eq", &a, &b) && is_column(a, &cname) && cname == "state" && literal_utf8(b, &lit)) states.push_back(lit);
-                    else ok = false;
+void recognise_fused(flockgpu_plan *pl, const Node *n) {
+    for (auto &c : n->in) recognise_fused(pl, c.get());
+    FusedInfo &fi = pl->fused[(size_t)n->id];
+    if (pl->generic_only) return;
+    auto leaf_schema = [&](const Node *scan) -> const std::vector<Field> & { return pl->ir.leaves[(size_t)scan->leaf].schema; };
+    if (n->kind == NKind::Filter) {
+        // ---- q2: [cast] col % m = 0 over a scan; the engine emits (that column, one more Int32 column)
+        std::vector<int> map;
+        const Node *scan = as_scan(n->in[0].get(), &map);
+        const Expr *p = n->pred.get();
+        if (scan && is_bin(p, "Eq") && uncast(p->r.get())->kind == EKind::LitI && uncast(p->r.get())->i == 0) {
+            const Expr *m = uncast(p->l.get());
+            if (is_bin(m, "Modulo") && uncast(m->l.get())->kind == EKind::Col && uncast(m->r.get())->kind == EKind::LitI) {
+                const int kc = uncast(m->l.get())->col;
+                const int64_t mod = uncast(m->r.get())->i;
+                int other = -1, extra = 0;
+                for (size_t i = 0; i < n->required.size(); ++i)
+                    if (n->required[i] && (int)i != kc) { other = (int)i; ++extra; }
+                const bool ok_types = n->schema[(size_t)kc].type == ColType::I32 && (other < 0 || n->schema[(size_t)other].type == ColType::I32);
+                if (mod != 0 && extra <= 1 && ok_types && map[(size_t)kc] >= 0 && (other < 0 || map[(size_t)other] >= 0)) {
+                    fi.kind = kQ2;
+                    fi.leaf_a = scan->leaf;
+                    fi.a_cols = {map[(size_t)kc], other < 0 ? map[(size_t)kc] : map[(size_t)other]};
+                    fi.out_map.assign(n->schema.size(), -1);
+                    fi.out_map[(size_t)kc] = 0;
+                    if (other >= 0) fi.out_map[(size_t)other] = 1;
+                    fi.lit = mod;
                 }
             }
-            if (ok && !states.empty()) {
-                pl->query = 3;
-                pl->q3_category = cat;
-                pl->q3_states = states;
-                Leaf a, p;
-                a.relation = "auction";
-                a.cols = {col("a_id", "i"), col("seller", "i"), col("category", "i")};
-                p.relation = "person";
-                p.cols = {col("p_id", "i"), col("name", "u"), col("city", "u"), col("state", "u")};
-                pl->leaves = {a, p};
-                return true;
-            }
         }
-        // ---- q8: DISTINCT(p_id, name)(person) JOIN DISTINCT(seller)(auction) ON p_id = seller
-        if (lk == "p_id" && rk == "seller") {
-            Agg la, ra;
-            if (match_agg(L, &la) && match_agg(R, &ra) && la.kinds.empty() && ra.kinds.empty() &&
-                la.group == std::vector<std::string>{"p_id", "name"} && ra.group == std::vector<std::string>{"seller"} &&
-                match_leaf(la.input, "p_id", "name") && match_leaf(ra.input, "seller")) {
-                pl->query = 8;
-                Leaf p, a;
-                p.relation = "person";
-                p.cols = {col("p_id", "i"), col("name", "u")};
-                a.relation = "auction";
-                a.cols = {col("seller", "i")};
-                pl->leaves = {p, a};
-                return true;
-            }
+        return;
+    }
+    if (n->kind == NKind::Aggregate) {
+        // ---- Partial COUNT GROUP BY one Int32 column of a scan (stage 0 of q5.dag)
+        std::vector<int> map;
+        const Node *scan = as_scan(n->in[0].get(), &map);
+        if (scan && n->mode == "Partial" && n->group.size() == 1 && n->aggs.size() == 1 && n->aggs[0].fn == "count" &&
+            n->in[0]->schema[(size_t)n->group[0]].type == ColType::I32 && map[(size_t)n->group[0]] >= 0) {
+            fi.kind = kPartialCount;
+            fi.leaf_a = scan->leaf;
+            fi.a_cols = {map[(size_t)n->group[0]]};
+            fi.out_map = {0, 1};
         }
-        // ---- q5: (COUNT(*) GROUP BY auction) JOIN (MAX(num) over the same counts) ON num = maxn
-        if (lk == "num" && rk == "maxn") {
-            Agg cnt, mx, cnt2;
-            if (match_agg(L, &cnt) && cnt.group == std::vector<std::string>{"auction"} && cnt.kinds == std::vector<std::string>{"count"} &&
-                match_leaf(cnt.input, "auction") && match_agg(R, &mx) && mx.group.empty() && mx.kinds == std::vector<std::string>{"max"} &&
-                match_agg(mx.input, &cnt2) && cnt2.group == std::vector<std::string>{"auction"} &&
-                cnt2.kinds == std::vector<std::string>{"count"} && match_leaf(cnt2.input, "auction")) {
-                pl->query = 5;
-                Leaf b;
-                b.relation = "bid";
-                b.cols = {col("auction", "i")};
-                // the SQL scans `bid` twice (no CSE in the reference): both leaves read the same relation
-                pl->leaves = {b, b};
-                return true;
+        return;
+    }
+    if (n->kind != NKind::Join) return;
+    const Node *L = n->in[0].get(), *R = n->in[1].get();
+    const size_t nl = L->schema.size();
+    const Field &lk = L->schema[(size_t)n->on_l], &rk = R->schema[(size_t)n->on_r];
+    // ---- q3: Filter(int col = lit)(scan) JOIN Filter(utf8 col = a OR ...)(scan) on Int32 keys
+    {
+        Peeled pl_ = peel(L), pr = peel(R);
+        if (pl_.n->kind == NKind::Filter && pr.n->kind == NKind::Filter && lk.type == ColType::I32 && rk.type == ColType::I32) {
+            std::vector<int> lmap, rmap;
+            const Node *ls = as_scan(pl_.n->in[0].get(), &lmap), *rs = as_scan(pr.n->in[0].get(), &rmap);
+            const Expr *lp = pl_.n->pred.get();
+            bool ok = ls && rs && is_bin(lp, "Eq") && uncast(lp->l.get())->kind == EKind::Col && uncast(lp->r.get())->kind == EKind::LitI;
+            int cat_col = -1, state_col = -1;
+            std::vector<std::string> states;
+            if (ok) {
+                cat_col = uncast(lp->l.get())->col;
+                ok = pl_.n->schema[(size_t)cat_col].type == ColType::I32;
+                std::vector<const Expr *> stack{pr.n->pred.get()};
+                while (!stack.empty() && ok) {
+                    const Expr *e = stack.back();
+                    stack.pop_back();
+                    if (is_bin(e, "Or")) { stack.push_back(e->r.get()); stack.push_back(e->l.get()); }
+                    else if (is_bin(e, "Eq") && e->l->kind == EKind::Col && e->r->kind == EKind::LitS && (state_col < 0 || state_col == e->l->col) &&
+                             pr.n->schema[(size_t)e->l->col].type == ColType::UTF8) { state_col = e->l->col; states.push_back(e->r->s); }
+                    else ok = false;
+                }
+                ok = ok && !states.empty() && states.size() <= 8;
             }
-        }
-        // ---- q13 ("next" query): bid JOIN side_input ON auction = key  (q13.sql; the side input is a bounded table)
-        if (lk == "auction" && rk == "key") {
-            if (match_leaf(L, "auction", "price") && match_leaf(L, "bidder", "b_date_time") && match_leaf(R, "key", "value")) {
-                pl->query = 13;
-                Leaf b, sd;
-                b.relation = "bid";
-                b.cols = {col("auction", "i"), col("bidder", "i"), col("price", "i"), col("b_date_time", "tsm:")};
-                sd.relation = "side_input";
-                sd.cols = {col("key", "i"), col("value", "i")};
-                pl->leaves = {b, sd};
-                return true;
-            }
-        }
-        // ---- q7 ("next" query): bid JOIN (MAX(price) AS maxprice over bid) ON price = maxprice
-        if (lk == "price" && rk == "maxprice") {
-            Agg mx;
-            if (match_leaf(L, "auction", "price") && match_leaf(L, "bidder", "b_date_time") && match_agg(R, &mx) && mx.group.empty() &&
-                mx.kinds == std::vector<std::string>{"max"} && match_leaf(mx.input, "price")) {
-                pl->query = 7;
-                Leaf b;
-                b.relation = "bid";
-                b.cols = {col("auction", "i"), col("bidder", "i"), col("price", "i"), col("b_date_time", "tsm:")};
-                pl->leaves = {b, b};  // the SQL scans `bid` twice; whichever leaf is fed holds the relation
-                return true;
+            if (ok) {
+                // required outputs: at most one Int32 column of the left side (-> the a_id slot), Utf8 columns of the right
+                // side: the filter column (-> state slot) and up to two more (-> name, city slots)
+                int a_id = -1;
+                std::vector<int> texts;
+                for (size_t i = 0; i < n->required.size() && ok; ++i) {
+                    if (!n->required[i]) continue;
+                    if (i < nl) {
+                        const int c = pl_.map[i];
+                        if (c < 0 || pl_.n->schema[(size_t)c].type != ColType::I32 || (a_id >= 0 && a_id != c)) ok = false;
+                        else a_id = c;
+                    } else {
+                        const int c = pr.map[i - nl];
+                        if (c < 0 || pr.n->schema[(size_t)c].type != ColType::UTF8) ok = false;
+                        else if (c != state_col && std::find(texts.begin(), texts.end(), c) == texts.end()) texts.push_back(c);
+                    }
+                }
+                ok = ok && texts.size() <= 2;
+                const int lkey = pl_.map[(size_t)n->on_l], rkey = pr.map[(size_t)n->on_r];
+                ok = ok && lkey >= 0 && rkey >= 0;
+                if (ok) {
+                    if (a_id < 0) a_id = lkey;
+                    while (texts.size() < 2) texts.push_back(state_col);
+                    auto to_leaf = [](const std::vector<int> &m, int c) { return m[(size_t)c]; };
+                    fi.kind = kQ3;
+                    fi.leaf_a = ls->leaf;
+                    fi.leaf_b = rs->leaf;
+                    fi.a_cols = {to_leaf(lmap, a_id), to_leaf(lmap, lkey), to_leaf(lmap, cat_col)};            // a_id, seller, category
+                    fi.b_cols = {to_leaf(rmap, rkey), to_leaf(rmap, texts[0]), to_leaf(rmap, texts[1]), to_leaf(rmap, state_col)};  // p_id, name, city, state
+                    ok = std::all_of(fi.a_cols.begin(), fi.a_cols.end(), [](int c) { return c >= 0; }) &&
+                         std::all_of(fi.b_cols.begin(), fi.b_cols.end(), [](int c) { return c >= 0; });
+                    fi.out_map.assign(n->schema.size(), -1);
+                    for (size_t i = 0; i < n->required.size(); ++i) {
+                        if (!n->required[i]) continue;
+                        if (i < nl) fi.out_map[i] = 3;  // a_id slot
+                        else {
+                            const int c = pr.map[i - nl];
+                            fi.out_map[i] = c == state_col ? 2 : (c == texts[0] ? 0 : 1);
+                        }
+                    }
+                    fi.lit = uncast(lp->r.get())->i;
+                    fi.strs = states;
+                    if (!ok) fi = FusedInfo{};
+                    else return;
+                }
             }
         }
     }
-    *why = "plan shape is not NEXMark q1/q2/q3/q5/q7/q8/q13";
-    return false;
+    // ---- q8: DISTINCT (Int32, Utf8)(scan) JOIN DISTINCT (Int32)(scan)
+    {
+        Peeled pl_ = peel(L), pr = peel(R);
+        LogicalAgg la, ra;
+        if (logical_agg(pl_.n, &la) && logical_agg(pr.n, &ra) && la.fns.empty() && ra.fns.empty() && la.group.size() == 2 && ra.group.size() == 1) {
+            std::vector<int> lmap, rmap;
+            const Node *ls = as_scan(la.below, &lmap), *rs = as_scan(ra.below, &rmap);
+            const int lkey = pl_.map[(size_t)n->on_l], rkey = pr.map[(size_t)n->on_r];
+            if (ls && rs && lkey == 0 && rkey == 0 && la.below->schema[(size_t)la.group[0]].type == ColType::I32 &&
+                la.below->schema[(size_t)la.group[1]].type == ColType::UTF8 && ra.below->schema[(size_t)ra.group[0]].type == ColType::I32 &&
+                lmap[(size_t)la.group[0]] >= 0 && lmap[(size_t)la.group[1]] >= 0 && rmap[(size_t)ra.group[0]] >= 0) {
+                bool ok = true;
+                fi.out_map.assign(n->schema.size(), -1);
+                for (size_t i = 0; i < n->required.size() && ok; ++i) {
+                    if (!n->required[i]) continue;
+                    const int c = i < nl ? pl_.map[i] : pr.map[i - nl];
+                    if (c < 0) ok = false;
+                    else fi.out_map[i] = i < nl ? c : 0;  // the seller column equals p_id on every output row
+                }
+                if (ok) {
+                    fi.kind = kQ8;
+                    fi.leaf_a = ls->leaf;
+                    fi.leaf_b = rs->leaf;
+                    fi.a_cols = {lmap[(size_t)la.group[0]], lmap[(size_t)la.group[1]]};
+                    fi.b_cols = {rmap[(size_t)ra.group[0]]};
+                    return;
+                }
+                fi = FusedInfo{};
+            }
+        }
+    }
+    // ---- q5: (COUNT GROUP BY k)(scan) JOIN (MAX over the same counts) ON count = max
+    {
+        Peeled pl_ = peel(L), pr = peel(R);
+        LogicalAgg cnt, mx, cnt2;
+        if (logical_agg(pl_.n, &cnt) && cnt.group.size() == 1 && cnt.fns == std::vector<std::string>{"count"} && logical_agg(pr.n, &mx) &&
+            mx.group.empty() && mx.fns == std::vector<std::string>{"max"}) {
+            Peeled below = peel(mx.below);
+            std::vector<int> lmap, rmap;
+            const Node *ls = as_scan(cnt.below, &lmap);
+            if (ls && logical_agg(below.n, &cnt2) && cnt2.group.size() == 1 && cnt2.fns == std::vector<std::string>{"count"} &&
+                below.map[(size_t)mx.args[0]] == 1 /* MAX over the count column */) {
+                const Node *rs = as_scan(cnt2.below, &rmap);
+                const int lkey = pl_.map[(size_t)n->on_l];
+                if (rs && lkey == 1 && pr.map[(size_t)n->on_r] == 0 && cnt.below->schema[(size_t)cnt.group[0]].type == ColType::I32 &&
+                    lmap[(size_t)cnt.group[0]] >= 0 && rmap[(size_t)cnt2.group[0]] >= 0 &&
+                    leaf_schema(ls)[(size_t)lmap[(size_t)cnt.group[0]]].name == leaf_schema(rs)[(size_t)rmap[(size_t)cnt2.group[0]]].name) {
+                    bool ok = true;
+                    fi.out_map.assign(n->schema.size(), -1);
+                    for (size_t i = 0; i < n->required.size() && ok; ++i) {
+                        if (!n->required[i]) continue;
+                        const int c = i < nl ? pl_.map[i] : pr.map[i - nl];
+                        if (c < 0) ok = false;
+                        else fi.out_map[i] = i < nl ? c : 1;  // maxn equals num on every output row
+                    }
+                    if (ok) {
+                        fi.kind = kQ5;
+                        fi.leaf_a = ls->leaf;
+                        fi.leaf_b = rs->leaf;  // the SQL scans the relation twice; whichever leaf was fed holds it
+                        fi.a_cols = {lmap[(size_t)cnt.group[0]]};
+                        fi.b_cols = {rmap[(size_t)cnt2.group[0]]};
+                        return;
+                    }
+                    fi = FusedInfo{};
+                }
+            }
+        }
+    }
+    // ---- q7: bid JOIN (MAX(price) over bid) ON price = maxprice; q13: bid JOIN side_input ON auction = key
+    {
+        std::vector<int> lmap, rmap;
+        const Node *ls = as_scan(L, &lmap);
+        auto names_are = [&](const Node *scan, std::initializer_list<const char *> want) {
+            const auto &s = leaf_schema(scan);
+            if (s.size() != want.size()) return false;
+            size_t i = 0;
+            for (const char *w : want)
+                if (s[i++].name != w) return false;
+            return true;
+        };
+        const bool bid4 = ls && names_are(ls, {"auction", "bidder", "price", "b_date_time"}) && leaf_schema(ls)[0].type == ColType::I32 &&
+                          leaf_schema(ls)[1].type == ColType::I32 && leaf_schema(ls)[2].type == ColType::I32 && leaf_schema(ls)[3].type == ColType::I64;
+        bool lmap_id = bid4;
+        for (size_t i = 0; lmap_id && i < lmap.size(); ++i) lmap_id = lmap[i] == (int)i;
+        if (lmap_id && lmap.size() == 4) {
+            Peeled pr = peel(R);
+            LogicalAgg mx;
+            const bool all_bid = n->required[0] && n->required[1] && n->required[2] && n->required[3];  // the entry points read all four
+            if (all_bid && n->on_l == 2 && logical_agg(pr.n, &mx) && mx.group.empty() && mx.fns == std::vector<std::string>{"max"} && pr.map[(size_t)n->on_r] == 0) {
+                const Node *rs = as_scan(mx.below, &rmap);
+                if (rs && rmap[(size_t)mx.args[0]] >= 0 && leaf_schema(rs)[(size_t)rmap[(size_t)mx.args[0]]].name == "price" &&
+                    leaf_schema(rs)[(size_t)rmap[(size_t)mx.args[0]]].type == ColType::I32) {
+                    fi.kind = kQ7;
+                    fi.leaf_a = ls->leaf;
+                    fi.leaf_b = rs->leaf;
+                    fi.out_map = {0, 1, 2, 3, 2};  // maxprice equals price on every output row
+                    return;
+                }
+            }
+            const Node *rs = as_scan(R, &rmap);
+            if (all_bid && n->required.size() == 6 && n->required[5] && n->on_l == 0 && rs && names_are(rs, {"key", "value"}) && n->on_r == 0 && rmap == std::vector<int>{0, 1} &&
+                leaf_schema(rs)[0].type == ColType::I32 && leaf_schema(rs)[1].type == ColType::I32) {
+                fi.kind = kQ13;
+                fi.leaf_a = ls->leaf;
+                fi.leaf_b = rs->leaf;
+                fi.out_map = {0, 1, 2, 3, 0, 4};  // key equals auction
+                return;
+            }
+        }
+    }
+}
+
+const char *fused_name(Fused f) {
+    switch (f) {
+        case kQ2: return "fused q2 filter (q1q2.hip)";
+        case kQ3: return "fused q3 filter + hash join (q3.hip)";
+        case kQ5: return "fused q5 count / max / select (q5.hip)";
+        case kQ7: return "fused q7 max + select (q7.hip)";
+        case kQ8: return "fused q8 distinct + join (q8.hip)";
+        case kQ13: return "fused q13 side-input join (q13.hip)";
+        case kPartialCount: return "fused Partial COUNT (q5.hip)";
+        default: return "generic (relops.hip)";
+    }
+}
+void describe(const flockgpu_plan *pl, const Node *n, int depth, std::ostringstream &os) {
+    static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition"};
+    os << std::string((size_t)depth * 2, ' ') << kinds[(int)n->kind];
+    if (n->kind == NKind::Aggregate) os << "(" << n->mode << ")";
+    if (n->kind == NKind::Repartition) os << "(Hash, " << n->n_parts << ")";
+    if (n->kind == NKind::Scan) os << "(" << pl->ir.leaves[(size_t)n->leaf].relation << ")";
+    os << " [";
+    for (size_t i = 0; i < n->schema.size(); ++i) os << (i ? ", " : "") << n->schema[i].name << ":" << type_name(n->schema[i]);
+    os << "]";
+    const Fused f = pl->fused[(size_t)n->id].kind;
+    if (n->kind != NKind::Scan && n->kind != NKind::Project && n->kind != NKind::Repartition) os << "  <- " << fused_name(f);
+    os << "\n";
+    if (f != kNone) return;  // the fused pipeline swallows the sub-tree
+    for (auto &c : n->in) describe(pl, c.get(), depth + 1, os);
+}
+
+// The whole plan is one NEXMark pipeline when, below pure projections, its root is a fused node (or q1's projection).
+int classify(const flockgpu_plan *pl) {
+    const Node *r = pl->ir.root.get();
+    if (r->kind == NKind::Project) {
+        int computed = 0;
+        for (auto &e : r->proj) computed += e.first->kind != EKind::Col;
+        if (computed == 1 && peel(r->in[0].get()).n->kind == NKind::Scan) return 1;
+    }
+    const Node *n = peel(r).n;
+    switch (pl->fused[(size_t)n->id].kind) {
+        case kQ2: return 2;
+        case kQ3: return 3;
+        case kQ5: return 5;
+        case kQ7: return 7;
+        case kQ8: return 8;
+        case kQ13: return 13;
+        default: return 0;
+    }
+}
+
+int parse_and_build(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan *pl) {
+    JParser jp{plan_json, plan_json + len, {}};
+    JPtr root;
+    if (!jp.parse(root) || root->kind != JValue::Obj)
+        return fail(ctx, FLOCKGPU_ERR_PLAN, "plan: JSON error: %s", jp.err.empty() ? "not an object" : jp.err.c_str());
+    if (!build_plan(root.get(), &pl->ir)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan: %s", pl->ir.why.c_str());
+    const char *g = getenv("FLOCKGPU_PLAN_GENERIC");
+    pl->generic_only = g && atoi(g) != 0;
+    pl->fused.assign((size_t)pl->ir.n_nodes, FusedInfo{});
+    recognise_fused(pl, pl->ir.root.get());
+    pl->query = classify(pl);
+    std::ostringstream os;
+    describe(pl, pl->ir.root.get(), 0, os);
+    pl->description = os.str();
+    pl->leaves.resize(pl->ir.leaves.size());
+    for (size_t i = 0; i < pl->leaves.size(); ++i) pl->leaves[i].cols.resize(pl->ir.leaves[i].schema.size());
+    return FLOCKGPU_OK;
 }
 
 // ------------------------------------------------------------------ feeding
@@ -494,57 +513,562 @@ int find_child(const ArrowSchema *schema, const std::string &name) {
         if (schema->children[i] && schema->children[i]->name && name == schema->children[i]->name) return (int)i;
     return -1;
 }
-bool format_ok(const std::string &want, const char *got) {
+bool format_ok(const Field &f, const char *got) {
     if (!got) return false;
-    if (want == "tsm:") return !strncmp(got, "tsm:", 4) || !strcmp(got, "l");
-    return want == got;
+    if (f.is_ts) return !strncmp(got, "tsm:", 4) || !strcmp(got, "l");
+    switch (f.type) {
+        case ColType::I32: return !strcmp(got, "i");
+        case ColType::I64: return !strcmp(got, "l") || !strncmp(got, "tsm:", 4);
+        case ColType::U64: return !strcmp(got, "L");
+        case ColType::F64: return !strcmp(got, "g");
+        default: return !strcmp(got, "u");
+    }
 }
-size_t width_of(const std::string &fmt) { return fmt == "i" ? 4 : 8; }
+const char *format_of(const DevColumn &c) {
+    if (c.is_ts) return "tsm:";
+    switch (c.type) {
+        case ColType::I32: return "i";
+        case ColType::I64: return "l";
+        case ColType::U64: return "L";
+        case ColType::F64: return "g";
+        default: return "u";
+    }
+}
 
-struct Grow {  // device buffer that keeps its contents when it grows (append-only feeding)
-    static int ensure(flockgpu_ctx *ctx, const std::string &key, size_t keep_bytes, size_t want_bytes, void **ptr) {
-        DeviceBuf &b = ctx->arena[key];
-        if (b.cap >= want_bytes && b.ptr) { *ptr = b.ptr; return FLOCKGPU_OK; }
-        size_t cap = std::max<size_t>(want_bytes + want_bytes / 2, 1024);
-        cap = (cap + 255) & ~size_t(255);
-        void *np = nullptr;
-        hipError_t e = hipMalloc(&np, cap);
-        if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_OOM, "plan feed: hipMalloc(%zu): %s", cap, hipGetErrorString(e));
-        if (b.ptr) {
-            if (keep_bytes) {
-                e = hipMemcpyAsync(np, b.ptr, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream);
-                if (e != hipSuccess) { (void)hipFree(np); return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: grow copy: %s", hipGetErrorString(e)); }
-            }
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(b.ptr);
+std::string leaf_key(const flockgpu_plan *pl, int leaf, int col, const char *what) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "plan%p.l%d.c%d.%s", (const void *)pl, leaf, col, what);
+    return buf;
+}
+std::string node_key(const flockgpu_plan *pl, const Node *n, const char *what, int i = 0) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "plan%p.n%d.%s%d", (const void *)pl, n->id, what, i);
+    return buf;
+}
+
+// Device buffer that keeps its contents when it grows (append-only feeding).
+int grow(flockgpu_ctx *ctx, const std::string &key, size_t keep_bytes, size_t want_bytes, void **ptr) {
+    DeviceBuf &b = ctx->arena[key];
+    if (b.cap >= want_bytes && b.ptr) { *ptr = b.ptr; return FLOCKGPU_OK; }
+    size_t cap = std::max<size_t>(want_bytes + want_bytes / 2, 1024);
+    cap = (cap + 255) & ~size_t(255);
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, cap);
+    if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_OOM, "plan feed: hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+    if (b.ptr) {
+        if (keep_bytes) {
+            e = hipMemcpyAsync(np, b.ptr, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(np); return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: grow copy: %s", hipGetErrorString(e)); }
         }
-        b.ptr = np;
-        b.cap = cap;
-        *ptr = np;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.ptr);
+    }
+    b.ptr = np;
+    b.cap = cap;
+    *ptr = np;
+    return FLOCKGPU_OK;
+}
+
+bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory: the query fails and leaves a sticky error behind
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Host -> device on the plan's stream without a host wait: pinned (registered) memory is handed to the DMA engine as
+// it is; pageable memory is copied chunk by chunk into the plan's pinned ring, the host filling chunk k + 1 while chunk k
+// is in flight (hipMemcpyAsync from pageable memory would block the caller for the whole transfer instead).
+int h2d(flockgpu_plan *pl, void *dst, const void *src, size_t bytes) {
+    flockgpu_ctx *ctx = pl->ctx;
+    if (!bytes) return FLOCKGPU_OK;
+    pl->fed_bytes += (int64_t)bytes;
+    if (host_is_pinned(src)) {
+        FG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return FLOCKGPU_OK;
+    }
+    for (size_t done = 0; done < bytes;) {
+        const int k = pl->stage_next;
+        pl->stage_next = (k + 1) % kStageChunks;
+        if (!pl->stage[k]) {
+            FG_HIP(ctx, hipHostMalloc(&pl->stage[k], kStageChunk, hipHostMallocDefault));
+            FG_HIP(ctx, hipEventCreateWithFlags(&pl->stage_done[k], hipEventDisableTiming));
+        } else {
+            FG_HIP(ctx, hipEventSynchronize(pl->stage_done[k]));
+        }
+        const size_t n = std::min(kStageChunk, bytes - done);
+        std::memcpy(pl->stage[k], static_cast<const uint8_t *>(src) + done, n);
+        FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, pl->stage[k], n, hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipEventRecord(pl->stage_done[k], ctx->stream));
+        done += n;
+    }
+    return FLOCKGPU_OK;
+}
+
+bool validity_has_nulls(const ArrowArray *a, int64_t offset, int64_t n) {
+    if (a->null_count == 0 || a->n_buffers < 1 || !a->buffers[0]) return false;
+    if (a->null_count > 0) return true;
+    const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);  // null_count == -1: not computed, look at the bitmap
+    for (int64_t i = offset; i < offset + n; ++i)
+        if (!((bits[i >> 3] >> (i & 7)) & 1)) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------ execution
+struct Exec {
+    flockgpu_plan *pl;
+    flockgpu_ctx *ctx;
+
+    // A relation the SQL scans twice (q5 and q7 read `bid` in both join inputs, q5_plan.fmt:6,13) has two MemoryExec leaves
+    // but arrives as ONE source, which feed_data_sources hands to the first matching leaf (context.rs:273-300) -- the
+    // second would stay empty.  An unfed leaf therefore reads the fed leaf that scans the same columns.
+    int resolve_leaf(int leaf) const {
+        if (pl->leaves[(size_t)leaf].rows > 0) return leaf;
+        const Leaf &me = pl->ir.leaves[(size_t)leaf];
+        for (size_t o = 0; o < pl->leaves.size(); ++o) {
+            if ((int)o == leaf || pl->leaves[o].rows == 0) continue;
+            const Leaf &other = pl->ir.leaves[o];
+            bool ok = true;
+            for (size_t c = 0; c < me.schema.size() && ok; ++c) {
+                if (!me.needed[c]) continue;
+                ok = false;
+                for (size_t d = 0; d < other.schema.size(); ++d)
+                    if (other.schema[d].name == me.schema[c].name && other.schema[d].type == me.schema[c].type && other.needed[d]) ok = true;
+            }
+            if (ok) return (int)o;
+        }
+        return leaf;
+    }
+    int leaf_column(int leaf, int src_leaf, int col) const {  // column `col` of `leaf`, as an index into `src_leaf`
+        if (leaf == src_leaf) return col;
+        const Leaf &me = pl->ir.leaves[(size_t)leaf], &other = pl->ir.leaves[(size_t)src_leaf];
+        for (size_t d = 0; d < other.schema.size(); ++d)
+            if (other.schema[d].name == me.schema[(size_t)col].name) return (int)d;
+        return -1;
+    }
+
+    int scan_table(const Node *n, Table *t) {
+        const int src = resolve_leaf(n->leaf);
+        const LeafData &ld = pl->leaves[(size_t)src];
+        const Leaf &lf = pl->ir.leaves[(size_t)n->leaf];
+        t->rows = ld.rows;
+        t->cols.resize(n->schema.size());
+        for (size_t i = 0; i < n->schema.size(); ++i) {
+            TCol &tc = t->cols[i];
+            tc.c.type = lf.schema[i].type;
+            tc.c.is_ts = lf.schema[i].is_ts;
+            tc.c.nullable = lf.schema[i].nullable;
+            if (!lf.needed[i]) continue;
+            tc.present = true;
+            const DevBuf &b = ld.cols[(size_t)leaf_column(n->leaf, src, (int)i)];
+            if (tc.c.type == ColType::UTF8 && !b.offsets) {  // never fed: an empty relation still has a one-entry offsets array
+                void *p = nullptr;
+                FG_TRY(arena_get(ctx, leaf_key(pl, n->leaf, (int)i, "empty").c_str(), 64, &p));
+                FG_HIP(ctx, hipMemsetAsync(p, 0, 64, ctx->stream));
+                tc.c.offsets = static_cast<int32_t *>(p);
+                tc.c.values = static_cast<uint8_t *>(p) + 16;
+            } else if (!b.values) {
+                void *p = nullptr;
+                FG_TRY(arena_get(ctx, leaf_key(pl, n->leaf, (int)i, "empty").c_str(), 64, &p));
+                tc.c.values = p;
+            } else {
+                tc.c.values = b.values;
+                tc.c.offsets = b.offsets;
+                tc.c.bytes = b.bytes;
+            }
+        }
+        return FLOCKGPU_OK;
+    }
+
+    // leaf column as a typed device pointer (fused entry points)
+    template <typename T>
+    const T *leaf_col(int leaf, int col) {
+        if (col < 0) return nullptr;
+        return static_cast<const T *>(pl->leaves[(size_t)leaf].cols[(size_t)col].values);
+    }
+    int leaf_utf8(int leaf, int col, flockgpu_utf8 *out) {
+        const DevBuf &b = pl->leaves[(size_t)leaf].cols[(size_t)col];
+        if (b.offsets) {
+            *out = flockgpu_utf8{b.offsets, static_cast<const uint8_t *>(b.values)};
+            return FLOCKGPU_OK;
+        }
+        void *p = nullptr;
+        FG_TRY(arena_get(ctx, leaf_key(pl, leaf, col, "empty").c_str(), 64, &p));
+        FG_HIP(ctx, hipMemsetAsync(p, 0, 64, ctx->stream));
+        *out = flockgpu_utf8{static_cast<int32_t *>(p), static_cast<uint8_t *>(p) + 16};
+        return FLOCKGPU_OK;
+    }
+    static flockgpu_windows whole(int64_t rows, int64_t (&off)[2], int32_t (&lo)[1], int32_t (&hi)[1]) {
+        off[0] = 0; off[1] = rows; lo[0] = 0; hi[0] = 1;
+        return flockgpu_windows{off, 1, lo, hi, 1};
+    }
+    static TCol dev_col(ColType t, const void *values, const int32_t *offsets = nullptr, int64_t bytes = 0, bool ts = false) {
+        TCol c;
+        c.present = true;
+        c.c.type = t;
+        c.c.is_ts = ts;
+        c.c.values = values;
+        c.c.offsets = offsets;
+        c.c.bytes = bytes;
+        return c;
+    }
+    // slots produced by a fused entry point -> the node's output columns
+    void place(const Node *n, const FusedInfo &fi, const std::vector<TCol> &slots, int64_t rows, Table *t) {
+        t->rows = rows;
+        t->cols.assign(n->schema.size(), TCol{});
+        for (size_t i = 0; i < n->schema.size(); ++i) {
+            t->cols[i].c.type = n->schema[i].type;
+            t->cols[i].c.is_ts = n->schema[i].is_ts;
+            if (fi.out_map[i] < 0 || !n->required[i]) continue;
+            t->cols[i] = slots[(size_t)fi.out_map[i]];
+            t->cols[i].c.is_ts = n->schema[i].is_ts;
+            t->cols[i].c.nullable = n->schema[i].nullable;
+        }
+    }
+
+    int run_fused(const Node *n, const FusedInfo &fi, Table *t) {
+        int64_t off_a[2], off_b[2];
+        int32_t lo_a[1], hi_a[1], lo_b[1], hi_b[1];
+        const LeafData &A = pl->leaves[(size_t)fi.leaf_a];
+        switch (fi.kind) {
+            case kQ2: {
+                flockgpu_bid_cols bc{leaf_col<int32_t>(fi.leaf_a, fi.a_cols[0]), nullptr, leaf_col<int32_t>(fi.leaf_a, fi.a_cols[1]), nullptr, A.rows};
+                flockgpu_windows w = whole(A.rows, off_a, lo_a, hi_a);
+                flockgpu_q2_result r{};
+                FG_TRY(flockgpu_q2_filter(ctx, &bc, &w, fi.lit, &r));
+                place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::I32, r.price)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kPartialCount: {
+                flockgpu_bid_cols bc{leaf_col<int32_t>(fi.leaf_a, fi.a_cols[0]), nullptr, nullptr, nullptr, A.rows};
+                flockgpu_windows w = whole(A.rows, off_a, lo_a, hi_a);
+                flockgpu_q5_partial_result r{};
+                FG_TRY(flockgpu_q5_partial_counts(ctx, &bc, &w, &r));
+                // node-owned copies: a second Partial COUNT of the same plan reuses the entry point's ctx-level buffers
+                uint64_t *wide = nullptr;
+                int32_t *keys = nullptr;
+                FG_TRY(arena_get_t(ctx, node_key(pl, n, "cnt").c_str(), (size_t)r.rows + 2, &wide));
+                FG_TRY(arena_get_t(ctx, node_key(pl, n, "key").c_str(), (size_t)r.rows + 4, &keys));
+                FG_TRY(widen_u32_to_u64(ctx, r.count, r.rows, wide));
+                if (r.rows) FG_HIP(ctx, hipMemcpyAsync(keys, r.auction, sizeof(int32_t) * (size_t)r.rows, hipMemcpyDeviceToDevice, ctx->stream));
+                place(n, fi, {dev_col(ColType::I32, keys), dev_col(ColType::U64, wide)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kQ3: {
+                const LeafData &B = pl->leaves[(size_t)fi.leaf_b];
+                flockgpu_auction_cols ac{leaf_col<int32_t>(fi.leaf_a, fi.a_cols[0]), leaf_col<int32_t>(fi.leaf_a, fi.a_cols[1]),
+                                         leaf_col<int32_t>(fi.leaf_a, fi.a_cols[2]), A.rows};
+                flockgpu_person_cols pc{};
+                pc.p_id = leaf_col<int32_t>(fi.leaf_b, fi.b_cols[0]);
+                FG_TRY(leaf_utf8(fi.leaf_b, fi.b_cols[1], &pc.name));
+                FG_TRY(leaf_utf8(fi.leaf_b, fi.b_cols[2], &pc.city));
+                FG_TRY(leaf_utf8(fi.leaf_b, fi.b_cols[3], &pc.state));
+                pc.rows = B.rows;
+                flockgpu_windows aw = whole(A.rows, off_a, lo_a, hi_a), pw = whole(B.rows, off_b, lo_b, hi_b);
+                std::vector<const char *> lits;
+                for (auto &s : fi.strs) lits.push_back(s.c_str());
+                flockgpu_q3_result r{};
+                FG_TRY(flockgpu_q3_join(ctx, &ac, &aw, &pc, &pw, fi.lit, lits.data(), (int)lits.size(), &r));
+                place(n, fi,
+                      {dev_col(ColType::UTF8, r.name.data, r.name.offsets, r.name_bytes), dev_col(ColType::UTF8, r.city.data, r.city.offsets, r.city_bytes),
+                       dev_col(ColType::UTF8, r.state.data, r.state.offsets, r.state_bytes), dev_col(ColType::I32, r.a_id)},
+                      r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kQ5: {
+                // both leaves scan the same relation; whichever was fed holds it (feed_data_sources gives it to the first match)
+                const bool first = A.rows > 0 || pl->leaves[(size_t)fi.leaf_b].rows == 0;
+                const int leaf = first ? fi.leaf_a : fi.leaf_b, col = first ? fi.a_cols[0] : fi.b_cols[0];
+                const int64_t rows = pl->leaves[(size_t)leaf].rows;
+                flockgpu_bid_cols bc{leaf_col<int32_t>(leaf, col), nullptr, nullptr, nullptr, rows};
+                flockgpu_windows w = whole(rows, off_a, lo_a, hi_a);
+                flockgpu_q5_result r{};
+                FG_TRY(flockgpu_q5_hot_items(ctx, &bc, &w, &r));
+                place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::U64, r.num)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kQ7: {
+                const bool first = A.rows > 0 || pl->leaves[(size_t)fi.leaf_b].rows == 0;
+                const int leaf = first ? fi.leaf_a : fi.leaf_b;
+                const Leaf &lf = pl->ir.leaves[(size_t)leaf];
+                auto by_name = [&](const char *nm) {
+                    for (size_t i = 0; i < lf.schema.size(); ++i)
+                        if (lf.schema[i].name == nm) return (int)i;
+                    return -1;
+                };
+                const int64_t rows = pl->leaves[(size_t)leaf].rows;
+                flockgpu_bid_cols bc{leaf_col<int32_t>(leaf, by_name("auction")), leaf_col<int32_t>(leaf, by_name("bidder")),
+                                     leaf_col<int32_t>(leaf, by_name("price")), leaf_col<int64_t>(leaf, by_name("b_date_time")), rows};
+                if (rows > 0 && (!bc.auction || !bc.bidder || !bc.price || !bc.b_date_time))
+                    return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: the fed bid relation lacks a column of [auction, bidder, price, b_date_time]");
+                flockgpu_windows w = whole(rows, off_a, lo_a, hi_a);
+                flockgpu_q7_result r{};
+                FG_TRY(flockgpu_q7_highest_bid(ctx, &bc, &w, &r));
+                place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::I32, r.bidder), dev_col(ColType::I32, r.price),
+                              dev_col(ColType::I64, r.b_date_time, nullptr, 0, true)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kQ13: {
+                const LeafData &B = pl->leaves[(size_t)fi.leaf_b];
+                flockgpu_bid_cols bc{leaf_col<int32_t>(fi.leaf_a, 0), leaf_col<int32_t>(fi.leaf_a, 1), leaf_col<int32_t>(fi.leaf_a, 2),
+                                     leaf_col<int64_t>(fi.leaf_a, 3), A.rows};
+                flockgpu_windows w = whole(A.rows, off_a, lo_a, hi_a);
+                flockgpu_q13_result r{};
+                FG_TRY(flockgpu_q13_side_join(ctx, &bc, &w, leaf_col<int32_t>(fi.leaf_b, 0), leaf_col<int32_t>(fi.leaf_b, 1), B.rows, &r));
+                place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::I32, r.bidder), dev_col(ColType::I32, r.price),
+                              dev_col(ColType::I64, r.b_date_time, nullptr, 0, true), dev_col(ColType::I32, r.value)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            case kQ8: {
+                const LeafData &B = pl->leaves[(size_t)fi.leaf_b];
+                flockgpu_person_cols pc{};
+                pc.p_id = leaf_col<int32_t>(fi.leaf_a, fi.a_cols[0]);
+                FG_TRY(leaf_utf8(fi.leaf_a, fi.a_cols[1], &pc.name));
+                pc.rows = A.rows;
+                flockgpu_auction_cols ac{nullptr, leaf_col<int32_t>(fi.leaf_b, fi.b_cols[0]), nullptr, B.rows};
+                flockgpu_windows pw = whole(A.rows, off_a, lo_a, hi_a), aw = whole(B.rows, off_b, lo_b, hi_b);
+                flockgpu_q8_result r{};
+                FG_TRY(flockgpu_q8_join(ctx, &pc, &pw, &ac, &aw, &r));
+                place(n, fi, {dev_col(ColType::I32, r.p_id), dev_col(ColType::UTF8, r.name.data, r.name.offsets, r.name_bytes)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
+            default:
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown fused pipeline");
+        }
+    }
+
+    // ---- predicates
+    static bool cmp_of(const std::string &op, CmpOp *out, bool flip) {
+        static const struct { const char *n; CmpOp a, flipped; } t[] = {
+            {"Eq", CmpOp::EQ, CmpOp::EQ}, {"NotEq", CmpOp::NE, CmpOp::NE}, {"Lt", CmpOp::LT, CmpOp::GT},
+            {"LtEq", CmpOp::LE, CmpOp::GE}, {"Gt", CmpOp::GT, CmpOp::LT}, {"GtEq", CmpOp::GE, CmpOp::LE}};
+        for (auto &e : t)
+            if (op == e.n) { *out = flip ? e.flipped : e.a; return true; }
+        return false;
+    }
+    int eval_pred(const Node *n, const Expr *e, const Table &in, int *next, uint8_t **out) {
+        uint8_t *mask = nullptr;
+        FG_TRY(arena_get_t(ctx, node_key(pl, n, "mask", (*next)++).c_str(), (size_t)in.rows + 16, &mask));
+        *out = mask;
+        if (e->kind != EKind::Bin) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate is not a comparison");
+        if (e->s == "And" || e->s == "Or") {
+            uint8_t *a = nullptr, *b = nullptr;
+            FG_TRY(eval_pred(n, e->l.get(), in, next, &a));
+            FG_TRY(eval_pred(n, e->r.get(), in, next, &b));
+            return mask_combine(ctx, a, b, in.rows, e->s == "And", mask);
+        }
+        const Expr *l = uncast(e->l.get()), *r = uncast(e->r.get());
+        bool flip = false;
+        if (l->kind == EKind::LitI || l->kind == EKind::LitS) { std::swap(l, r); flip = true; }
+        CmpOp op;
+        if (!cmp_of(e->s, &op, flip)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: operator '%s' in a predicate", e->s.c_str());
+        auto column = [&](const Expr *x) -> const TCol * { return x->kind == EKind::Col && in.cols[(size_t)x->col].present ? &in.cols[(size_t)x->col] : nullptr; };
+        if (l->kind == EKind::Col && r->kind == EKind::LitI && column(l)) return mask_cmp_lit(ctx, column(l)->c, in.rows, op, r->i, mask);
+        if (l->kind == EKind::Col && r->kind == EKind::LitS && column(l) && (op == CmpOp::EQ || op == CmpOp::NE))
+            return mask_utf8_eq(ctx, column(l)->c, in.rows, r->s, op == CmpOp::NE, mask);
+        if (l->kind == EKind::Col && r->kind == EKind::Col && column(l) && column(r)) return mask_cmp_col(ctx, column(l)->c, column(r)->c, in.rows, op, mask);
+        if (is_bin(l, "Modulo") && r->kind == EKind::LitI) {
+            const Expr *c = uncast(l->l.get()), *m = uncast(l->r.get());
+            if (c->kind == EKind::Col && m->kind == EKind::LitI && column(c)) return mask_mod_cmp(ctx, column(c)->c, in.rows, m->i, op, r->i, mask);
+        }
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate shape is not supported");
+    }
+
+    int take_table(const Node *n, const Table &in, const std::vector<char> &required, const int32_t *rows, int64_t n_rows, int first_out, Table *out) {
+        for (size_t i = 0; i < in.cols.size(); ++i) {
+            TCol &o = out->cols[(size_t)first_out + i];
+            o.c.type = in.cols[i].c.type;
+            o.c.is_ts = in.cols[i].c.is_ts;
+            o.c.nullable = in.cols[i].c.nullable;
+            if (!required[(size_t)first_out + i] || !in.cols[i].present) continue;
+            FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
+            o.present = true;
+        }
+        return FLOCKGPU_OK;
+    }
+
+    int key_i64(const Node *n, const TCol &c, int64_t rows, const char *what, int64_t **out) {
+        if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+        FG_TRY(arena_get_t(ctx, node_key(pl, n, what).c_str(), (size_t)rows + 2, out));
+        return widen_to_i64(ctx, c.c, rows, *out);
+    }
+
+    int exec(const Node *n, Table *t) {
+        const FusedInfo &fi = pl->fused[(size_t)n->id];
+        if (fi.kind != kNone) return run_fused(n, fi, t);
+        switch (n->kind) {
+            case NKind::Scan:
+                return scan_table(n, t);
+            case NKind::Repartition:
+                return exec(n->in[0].get(), t);  // placement is unobservable in one process; the root case is handled by the caller
+            case NKind::Filter: {
+                Table in;
+                FG_TRY(exec(n->in[0].get(), &in));
+                uint8_t *mask = nullptr;
+                int next = 0;
+                FG_TRY(eval_pred(n, n->pred.get(), in, &next, &mask));
+                int32_t *rows = nullptr;
+                int64_t n_out = 0;
+                FG_TRY(mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in.rows, &rows, &n_out));
+                t->rows = n_out;
+                t->cols.assign(n->schema.size(), TCol{});
+                return take_table(n, in, n->required, rows, n_out, 0, t);
+            }
+            case NKind::Project: {
+                Table in;
+                FG_TRY(exec(n->in[0].get(), &in));
+                t->rows = in.rows;
+                t->cols.assign(n->schema.size(), TCol{});
+                for (size_t i = 0; i < n->proj.size(); ++i) {
+                    const Expr *e = n->proj[i].first.get();
+                    TCol &o = t->cols[i];
+                    o.c.type = n->schema[i].type;
+                    o.c.is_ts = n->schema[i].is_ts;
+                    if (!n->required[i]) continue;
+                    if (e->kind == EKind::Col) {
+                        o = in.cols[(size_t)e->col];
+                        continue;
+                    }
+                    // literal * CAST(Int32 column AS Float64): q1's currency conversion (planner.rs:90), one IEEE multiply
+                    const Expr *l = e->l.get(), *r = e->r.get();
+                    if (l->kind != EKind::LitF && l->kind != EKind::LitI) std::swap(l, r);
+                    const Expr *c = uncast(r);
+                    if (!is_bin(e, "Multiply") || (l->kind != EKind::LitF && l->kind != EKind::LitI) || c->kind != EKind::Col ||
+                        in.cols[(size_t)c->col].c.type != ColType::I32 || !in.cols[(size_t)c->col].present)
+                        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: computed projection other than `literal * Int32 column`");
+                    double *d = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "f64", (int)i).c_str(), (size_t)in.rows + 2, &d));
+                    flockgpu_bid_cols bc{nullptr, nullptr, static_cast<const int32_t *>(in.cols[(size_t)c->col].c.values), nullptr, in.rows};
+                    FG_TRY(flockgpu_q1_project(ctx, &bc, l->kind == EKind::LitF ? l->f : (double)l->i, d));
+                    o = dev_col(ColType::F64, d);
+                }
+                return FLOCKGPU_OK;
+            }
+            case NKind::Aggregate:
+                return exec_aggregate(n, t);
+            case NKind::Join: {
+                Table L, R;
+                FG_TRY(exec(n->in[0].get(), &L));
+                FG_TRY(exec(n->in[1].get(), &R));
+                t->cols.assign(n->schema.size(), TCol{});
+                const TCol &lk = L.cols[(size_t)n->on_l], &rk = R.cols[(size_t)n->on_r];
+                if ((lk.c.type == ColType::U64) != (rk.c.type == ColType::U64) || lk.c.type == ColType::UTF8 || rk.c.type == ColType::UTF8 ||
+                    lk.c.type == ColType::F64 || rk.c.type == ColType::F64)
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join keys must be integer columns of one signedness");
+                int64_t nl = L.rows, nr = R.rows;
+                if (lk.c.all_null) nl = 0;  // NULL keys never match
+                if (rk.c.all_null) nr = 0;
+                int64_t *kl = nullptr, *kr = nullptr;
+                FG_TRY(key_i64(n, lk, nl, "kl", &kl));
+                FG_TRY(key_i64(n, rk, nr, "kr", &kr));
+                int32_t *lrows = nullptr, *rrows = nullptr;
+                int64_t pairs = 0;
+                FG_TRY(join_key64(ctx, node_key(pl, n, "join").c_str(), kl, nl, kr, nr, &lrows, &rrows, &pairs));
+                t->rows = pairs;
+                FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
+                return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+            }
+        }
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown node");
+    }
+
+    int exec_aggregate(const Node *n, Table *t) {
+        Table in;
+        FG_TRY(exec(n->in[0].get(), &in));
+        const bool is_final = n->mode != "Partial";
+        t->cols.assign(n->schema.size(), TCol{});
+        for (size_t i = 0; i < n->schema.size(); ++i) {
+            t->cols[i].c.type = n->schema[i].type;
+            t->cols[i].c.is_ts = n->schema[i].is_ts;
+            t->cols[i].c.nullable = n->schema[i].nullable;
+        }
+        // ---- no GROUP BY: MAX of one integer column -> one row (NULL over no input)
+        if (n->group.empty()) {
+            const ColType at = n->aggs.size() == 1 && n->aggs[0].arg >= 0 ? in.cols[(size_t)n->aggs[0].arg].c.type : ColType::UTF8;
+            if (n->aggs.size() != 1 || n->aggs[0].fn != "max" || at == ColType::UTF8 || at == ColType::F64 || !in.cols[(size_t)n->aggs[0].arg].present)
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: global aggregate other than MAX over an integer column");
+            const TCol &a = in.cols[(size_t)n->aggs[0].arg];
+            int64_t mx = 0;
+            int any = 0;
+            if (!a.c.all_null) FG_TRY(reduce_max(ctx, a.c, in.rows, &mx, &any));
+            int64_t *d = nullptr, *h = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "max").c_str(), 2, &d));
+            FG_TRY(pinned_get_t(ctx, node_key(pl, n, "max").c_str(), 2, &h));
+            if (at == ColType::I32) *reinterpret_cast<int32_t *>(h) = (int32_t)mx;
+            else h[0] = mx;
+            FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+            t->rows = 1;
+            t->cols[0] = dev_col(at, d, nullptr, 0, a.c.is_ts);
+            t->cols[0].c.nullable = true;
+            t->cols[0].c.all_null = !any;
+            return FLOCKGPU_OK;
+        }
+        // ---- DISTINCT (Int32, Utf8)
+        if (n->group.size() == 2 && n->aggs.empty()) {
+            const TCol &k = in.cols[(size_t)n->group[0]], &s = in.cols[(size_t)n->group[1]];
+            if (k.c.type != ColType::I32 || s.c.type != ColType::UTF8 || !k.present || !s.present)
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Utf8)");
+            int32_t *rows = nullptr;
+            int64_t n_out = 0;
+            FG_TRY(distinct_i32_utf8(ctx, node_key(pl, n, "dist").c_str(), static_cast<const int32_t *>(k.c.values),
+                                     flockgpu_utf8{s.c.offsets, static_cast<const uint8_t *>(s.c.values)}, in.rows, &rows, &n_out));
+            t->rows = n_out;
+            FG_TRY(take_column(ctx, node_key(pl, n, "take", 0).c_str(), k.c, rows, n_out, &t->cols[0].c));
+            FG_TRY(take_column(ctx, node_key(pl, n, "take", 1).c_str(), s.c, rows, n_out, &t->cols[1].c));
+            t->cols[0].present = t->cols[1].present = true;
+            return FLOCKGPU_OK;
+        }
+        // ---- GROUP BY one integer column: COUNT (Partial: rows; Final: sum of the partial counts) or no aggregate
+        if (n->group.size() != 1 || n->aggs.size() > 1 || (n->aggs.size() == 1 && n->aggs[0].fn != "count"))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY shape outside {k | COUNT}, {k}, {k, text}, {| MAX}");
+        const TCol &k = in.cols[(size_t)n->group[0]];
+        int64_t *keys = nullptr;
+        FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
+        const uint64_t *values = nullptr;
+        if (!n->aggs.empty() && is_final) {
+            const TCol &st = in.cols[(size_t)n->aggs[0].arg];
+            if (st.c.type != ColType::U64 || !st.present) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: COUNT state column must be UInt64");
+            values = static_cast<const uint64_t *>(st.c.values);
+        }
+        GroupResult g;
+        FG_TRY(group_by_key64(ctx, node_key(pl, n, "grp").c_str(), keys, values, n->aggs.empty() ? AggKind::NONE : AggKind::SUM, in.rows, &g));
+        t->rows = g.n_groups;
+        if (k.c.type == ColType::I32) {
+            int32_t *nk = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk").c_str(), (size_t)g.n_groups + 4, &nk));
+            FG_TRY(narrow_i64_to_i32(ctx, g.keys, g.n_groups, nk));
+            t->cols[0] = dev_col(ColType::I32, nk);
+        } else {
+            t->cols[0] = dev_col(k.c.type, g.keys, nullptr, 0, k.c.is_ts);
+        }
+        t->cols[0].c.nullable = n->schema[0].nullable;
+        if (!n->aggs.empty()) {
+            t->cols[1] = dev_col(ColType::U64, g.agg);
+            t->cols[1].c.nullable = true;
+        }
         return FLOCKGPU_OK;
     }
 };
 
-std::string key_of(const flockgpu_plan *pl, int leaf, const DevCol &c, const char *what) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "plan%p.%d.%s.%s", (const void *)pl, leaf, c.name.c_str(), what);
-    return buf;
-}
-
 // ------------------------------------------------------------------ Arrow export
-struct ExportPriv {
-    std::vector<void *> owned;                    // malloc'd buffers
-    std::vector<const void *> buffers;            // this node's buffer pointers
+struct BatchPriv {
+    std::shared_ptr<HostBlock> block;
+    std::vector<const void *> buffers;
     std::vector<ArrowArray *> child_ptrs;
     std::vector<std::unique_ptr<ArrowArray>> children;
+    std::vector<std::unique_ptr<BatchPriv>> child_priv;
 };
-void release_array(ArrowArray *a) {
+void release_child(ArrowArray *a) {
+    if (a) a->release = nullptr;  // memory belongs to the parent struct array
+}
+void release_batch(ArrowArray *a) {
     if (!a || !a->release) return;
-    ExportPriv *p = static_cast<ExportPriv *>(a->private_data);
+    BatchPriv *p = static_cast<BatchPriv *>(a->private_data);
     if (p) {
         for (auto &c : p->children)
             if (c && c->release) c->release(c.get());
-        for (void *o : p->owned) free(o);
         delete p;
     }
     a->release = nullptr;
@@ -583,60 +1107,118 @@ void add_schema_child(ArrowSchema *parent, const char *format, const char *name,
     parent->children = p->child_ptrs.data();
     parent->n_children = (int64_t)p->child_ptrs.size();
 }
-void make_struct_array(ArrowArray *a, int64_t length) {
-    ExportPriv *p = new ExportPriv();
-    std::memset(a, 0, sizeof *a);
-    a->length = length;
-    p->buffers = {nullptr};  // validity
-    a->n_buffers = 1;
-    a->buffers = p->buffers.data();
-    a->release = release_array;
-    a->private_data = p;
+void export_schema(const Node *root, ArrowSchema *out) {
+    make_schema(out, "+s", "", false);
+    for (auto &f : root->schema) {
+        DevColumn c;
+        c.type = f.type;
+        c.is_ts = f.is_ts;
+        add_schema_child(out, format_of(c), f.name.c_str(), f.nullable);
+    }
 }
-// takes ownership of the malloc'd buffers
-void add_array_child(ArrowArray *parent, int64_t length, void *values, void *offsets /*nullable*/) {
-    ExportPriv *pp = static_cast<ExportPriv *>(parent->private_data);
-    pp->children.emplace_back(new ArrowArray());
-    ArrowArray *c = pp->children.back().get();
-    ExportPriv *p = new ExportPriv();
-    std::memset(c, 0, sizeof *c);
-    c->length = length;
-    if (offsets) {
-        p->buffers = {nullptr, offsets, values};
-        p->owned = {offsets, values};
+
+// Copies the table's buffers into ONE pinned block (async, then a single synchronisation) and exposes `n_parts`
+// record batches over it: batch p = rows [part_off[p], part_off[p + 1]) through the Arrow `offset` field of its children.
+int export_batches(flockgpu_ctx *ctx, const Table &t, const std::vector<int64_t> &part_off, ArrowArray *out_batches) {
+    const int n_parts = (int)part_off.size() - 1;
+    struct Slot { size_t at = 0, bytes = 0; const void *dev = nullptr; };
+    std::vector<Slot> values(t.cols.size()), offsets(t.cols.size()), validity(t.cols.size());
+    size_t total = 0;
+    auto reserve = [&](Slot &s, const void *dev, size_t bytes) {
+        s.at = total;
+        s.bytes = bytes;
+        s.dev = dev;
+        total += (bytes + 63) & ~size_t(63);
+    };
+    for (size_t i = 0; i < t.cols.size(); ++i) {
+        const TCol &c = t.cols[i];
+        if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: output column %zu was not materialised", i);
+        if (c.c.type == ColType::UTF8) {
+            reserve(offsets[i], c.c.offsets, (size_t)(t.rows + 1) * 4);
+            reserve(values[i], c.c.values, (size_t)std::max<int64_t>(c.c.bytes, 0));
+        } else {
+            reserve(values[i], c.c.values, (size_t)t.rows * col_width(c.c.type));
+        }
+        if (c.c.all_null) reserve(validity[i], nullptr, (size_t)(t.rows + 7) / 8);
+    }
+    auto block = std::make_shared<HostBlock>();
+    block->ptr = pool().get(std::max<size_t>(total, 64), &block->cap);
+    if (!block->ptr) return fail(ctx, FLOCKGPU_ERR_OOM, "plan execute: pinned host allocation of %zu bytes failed", total);
+    uint8_t *base = static_cast<uint8_t *>(block->ptr);
+    for (auto *group : {&values, &offsets})
+        for (auto &s : *group)
+            if (s.bytes && s.dev) FG_HIP(ctx, hipMemcpyAsync(base + s.at, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    for (auto &s : validity)
+        if (s.bytes) std::memset(base + s.at, 0, s.bytes);
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < n_parts; ++p) {
+        ArrowArray *a = &out_batches[p];
+        BatchPriv *bp = new BatchPriv();
+        bp->block = block;
+        std::memset(a, 0, sizeof *a);
+        const int64_t lo = part_off[(size_t)p], len = part_off[(size_t)p + 1] - lo;
+        a->length = len;
+        bp->buffers = {nullptr};
+        a->n_buffers = 1;
+        a->buffers = bp->buffers.data();
+        for (size_t i = 0; i < t.cols.size(); ++i) {
+            const TCol &c = t.cols[i];
+            bp->children.emplace_back(new ArrowArray());
+            bp->child_priv.emplace_back(new BatchPriv());
+            ArrowArray *ch = bp->children.back().get();
+            BatchPriv *cp = bp->child_priv.back().get();
+            std::memset(ch, 0, sizeof *ch);
+            ch->length = len;
+            ch->offset = lo;
+            const void *valid = c.c.all_null ? base + validity[i].at : nullptr;
+            ch->null_count = c.c.all_null ? len : 0;
+            if (c.c.type == ColType::UTF8) cp->buffers = {valid, base + offsets[i].at, base + values[i].at};
+            else cp->buffers = {valid, base + values[i].at};
+            ch->n_buffers = (int64_t)cp->buffers.size();
+            ch->buffers = cp->buffers.data();
+            ch->release = release_child;
+            bp->child_ptrs.push_back(ch);
+        }
+        a->children = bp->child_ptrs.data();
+        a->n_children = (int64_t)bp->child_ptrs.size();
+        a->release = release_batch;
+        a->private_data = bp;
+    }
+    return FLOCKGPU_OK;
+}
+
+int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, ArrowArray *out_batches, int capacity, int *n_out) {
+    flockgpu_ctx *ctx = plan->ctx;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const Node *root = plan->ir.root.get();
+    Exec ex{plan, ctx};
+    Table t;
+    std::vector<int64_t> part_off;
+    if (partitioned && root->kind == NKind::Repartition) {
+        if (root->n_parts > capacity) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: %d output partitions, room for %d", root->n_parts, capacity);
+        Table in;
+        FG_TRY(ex.exec(root->in[0].get(), &in));
+        // RepartitionExec Hash(exprs, n): equal keys must meet in one partition; hashing the first key column already
+        // guarantees that, and which partition a key lands on is unobservable
+        const TCol &k = in.cols[(size_t)root->hash_cols[0]];
+        int64_t *keys = nullptr;
+        FG_TRY(ex.key_i64(root, k, in.rows, "pk", &keys));
+        int32_t *rows = nullptr;
+        FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, in.rows, root->n_parts, &rows, &part_off));
+        t.rows = in.rows;
+        t.cols.assign(root->schema.size(), TCol{});
+        FG_TRY(ex.take_table(root, in, std::vector<char>(root->schema.size(), 1), rows, in.rows, 0, &t));
     } else {
-        p->buffers = {nullptr, values};
-        p->owned = {values};
+        FG_TRY(ex.exec(root, &t));
+        part_off = {0, t.rows};
     }
-    c->n_buffers = (int64_t)p->buffers.size();
-    c->buffers = p->buffers.data();
-    c->release = release_array;
-    c->private_data = p;
-    pp->child_ptrs.push_back(c);
-    parent->children = pp->child_ptrs.data();
-    parent->n_children = (int64_t)pp->child_ptrs.size();
-}
-
-int d2h_alloc(flockgpu_ctx *ctx, const void *dev, size_t bytes, void **out) {
-    void *h = malloc(bytes ? bytes : 8);
-    if (!h) return fail(ctx, FLOCKGPU_ERR_OOM, "plan execute: malloc(%zu)", bytes);
-    if (bytes) {
-        hipError_t e = hipMemcpyAsync(h, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { free(h); return fail(ctx, FLOCKGPU_ERR_HIP, "plan execute: D2H: %s", hipGetErrorString(e)); }
-    }
-    *out = h;
+    if ((int)part_off.size() - 1 > capacity) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: no room for the output batch");
+    FG_TRY(export_batches(ctx, t, part_off, out_batches));
+    plan->fed_bytes = 0;  // export synchronised the stream: every borrowed buffer has been read
+    export_schema(root, out_schema);
+    *n_out = (int)part_off.size() - 1;
     return FLOCKGPU_OK;
 }
-int host_dup(flockgpu_ctx *ctx, const std::vector<uint8_t> &src, void **out) {
-    void *h = malloc(src.size() ? src.size() : 8);
-    if (!h) return fail(ctx, FLOCKGPU_ERR_OOM, "plan execute: malloc(%zu)", src.size());
-    if (!src.empty()) std::memcpy(h, src.data(), src.size());
-    *out = h;
-    return FLOCKGPU_OK;
-}
-
-flockgpu_utf8 dev_utf8(const DevCol &c) { return flockgpu_utf8{c.offsets, static_cast<const uint8_t *>(c.values)}; }
 
 }  // namespace
 
@@ -646,28 +1228,29 @@ int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, f
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     if (!plan_json || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_create: null argument");
     *out = nullptr;
-    JParser jp{plan_json, plan_json + len, {}};
-    JPtr root;
-    if (!jp.parse(root) || root->kind != JValue::Obj)
-        return fail(ctx, FLOCKGPU_ERR_PLAN, "plan_create: JSON error: %s", jp.err.empty() ? "not an object" : jp.err.c_str());
     std::unique_ptr<flockgpu_plan> pl(new flockgpu_plan());
     pl->ctx = ctx;
-    std::string why;
-    if (!recognise(root.get(), pl.get(), &why)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_create: %s", why.c_str());
+    FG_TRY(parse_and_build(ctx, plan_json, len, pl.get()));
     *out = pl.release();
     return FLOCKGPU_OK;
 }
 
 int flockgpu_plan_recognise(const char *plan_json, size_t len, int *query) {
     if (!plan_json || !query) return FLOCKGPU_ERR_INVALID;
-    JParser jp{plan_json, plan_json + len, {}};
-    JPtr root;
-    if (!jp.parse(root) || root->kind != JValue::Obj) return FLOCKGPU_ERR_PLAN;
     flockgpu_plan pl;
-    std::string why;
-    if (!recognise(root.get(), &pl, &why)) return FLOCKGPU_ERR_UNSUPPORTED;
+    const int rc = parse_and_build(nullptr, plan_json, len, &pl);
+    if (rc != FLOCKGPU_OK) return rc;
     *query = pl.query;
     return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_explain(const char *plan_json, size_t len, char *out, size_t capacity) {
+    if (!plan_json || !out || !capacity) return FLOCKGPU_ERR_INVALID;
+    flockgpu_plan pl;
+    const int rc = parse_and_build(nullptr, plan_json, len, &pl);
+    const std::string text = rc == FLOCKGPU_OK ? pl.description : (rc == FLOCKGPU_ERR_UNSUPPORTED ? "unsupported: " + pl.ir.why : std::string("plan JSON error"));
+    snprintf(out, capacity, "%s", text.c_str());
+    return rc;
 }
 
 void flockgpu_plan_destroy(flockgpu_plan *plan) {
@@ -684,281 +1267,216 @@ void flockgpu_plan_destroy(flockgpu_plan *plan) {
             ++it;
         }
     }
+    // host-side caches keyed by the same names (tile schedules of scan.hpp) describe buffers that no longer exist
+    for (auto it = ctx->host_i64.begin(); it != ctx->host_i64.end();) it = it->first.compare(0, strlen(prefix), prefix) == 0 ? ctx->host_i64.erase(it) : std::next(it);
+    for (auto it = ctx->host_u64.begin(); it != ctx->host_u64.end();) it = it->first.compare(0, strlen(prefix), prefix) == 0 ? ctx->host_u64.erase(it) : std::next(it);
+    for (auto it = ctx->pinned.begin(); it != ctx->pinned.end();) {
+        if (it->first.compare(0, strlen(prefix), prefix) == 0) {
+            if (it->second.ptr) (void)hipHostFree(it->second.ptr);
+            it = ctx->pinned.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    for (int k = 0; k < kStageChunks; ++k) {
+        if (plan->stage[k]) (void)hipHostFree(plan->stage[k]);
+        if (plan->stage_done[k]) (void)hipEventDestroy(plan->stage_done[k]);
+    }
     delete plan;
 }
 
 int flockgpu_plan_query(const flockgpu_plan *plan) { return plan ? plan->query : 0; }
-int flockgpu_plan_num_inputs(const flockgpu_plan *plan) { return plan ? (int)plan->leaves.size() : 0; }
+const char *flockgpu_plan_description(const flockgpu_plan *plan) { return plan ? plan->description.c_str() : nullptr; }
+int flockgpu_plan_num_inputs(const flockgpu_plan *plan) { return plan ? (int)plan->ir.leaves.size() : 0; }
 const char *flockgpu_plan_input_name(const flockgpu_plan *plan, int input) {
-    if (!plan || input < 0 || input >= (int)plan->leaves.size()) return nullptr;
-    return plan->leaves[input].relation.c_str();
+    if (!plan || input < 0 || input >= (int)plan->ir.leaves.size()) return nullptr;
+    return plan->ir.leaves[(size_t)input].relation.c_str();
 }
 int flockgpu_plan_input_matches(const flockgpu_plan *plan, int input, const struct ArrowSchema *schema) {
-    if (!plan || !schema || input < 0 || input >= (int)plan->leaves.size()) return 0;
-    for (auto &c : plan->leaves[input].cols)
-        if (find_child(schema, c.name) < 0) return 0;
+    if (!plan || !schema || input < 0 || input >= (int)plan->ir.leaves.size()) return 0;
+    const Leaf &lf = plan->ir.leaves[(size_t)input];
+    for (size_t c = 0; c < lf.schema.size(); ++c)
+        if (lf.needed[c] && find_child(schema, lf.schema[c].name) < 0) return 0;
     return 1;
 }
+int flockgpu_plan_output_partitions(const flockgpu_plan *plan) {
+    if (!plan) return 0;
+    return plan->ir.root->kind == NKind::Repartition ? plan->ir.root->n_parts : 1;
+}
+int flockgpu_plan_is_shuffling(const flockgpu_plan *plan) { return plan && plan->ir.root->kind == NKind::Repartition ? 1 : 0; }
 
-int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema,
-                       const struct ArrowArray *const *batches, int n_batches) {
+int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema, const struct ArrowArray *const *batches,
+                       int n_batches) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     flockgpu_ctx *ctx = plan->ctx;
-    if (!schema || input < 0 || input >= (int)plan->leaves.size() || n_batches < 0 || (n_batches && !batches))
+    if (!schema || input < 0 || input >= (int)plan->ir.leaves.size() || n_batches < 0 || (n_batches && !batches))
         return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: bad argument");
     FG_HIP(ctx, hipSetDevice(ctx->device));
-    Leaf &lf = plan->leaves[input];
-    std::vector<int> child(lf.cols.size());
-    for (size_t c = 0; c < lf.cols.size(); ++c) {
-        child[c] = find_child(schema, lf.cols[c].name);
-        if (child[c] < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' missing from the fed schema", lf.cols[c].name.c_str());
-        if (!format_ok(lf.cols[c].format, schema->children[child[c]]->format))
-            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' has Arrow format '%s', expected '%s'",
-                        lf.cols[c].name.c_str(), schema->children[child[c]]->format, lf.cols[c].format.c_str());
+    const Leaf &lf = plan->ir.leaves[(size_t)input];
+    LeafData &ld = plan->leaves[(size_t)input];
+    std::vector<int> child(lf.schema.size(), -1);
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (!lf.needed[c]) continue;
+        child[c] = find_child(schema, lf.schema[c].name);
+        if (child[c] < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' missing from the fed schema", lf.schema[c].name.c_str());
+        if (!format_ok(lf.schema[c], schema->children[child[c]]->format))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' has Arrow format '%s', the plan scans %s", lf.schema[c].name.c_str(),
+                        schema->children[child[c]]->format, type_name(lf.schema[c]));
     }
-    std::vector<int32_t> rebased;
+    // validate everything before the first copy, so that a rejected feed leaves the leaf as it was
+    int64_t add_rows = 0;
+    std::vector<int64_t> add_bytes(lf.schema.size(), 0);
+    std::vector<std::vector<int64_t>> keep((size_t)n_batches);  // per batch: the rows that survive NULL dropping (empty: all)
+    std::vector<char> filtered((size_t)n_batches, 0);
     for (int b = 0; b < n_batches; ++b) {
         const ArrowArray *rb = batches[b];
         if (!rb || rb->n_children < schema->n_children) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: batch %d does not match the schema", b);
         const int64_t n = rb->length;
         if (n == 0) continue;
-        if (lf.rows + n >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: more than 2^31 rows per relation");
-        for (size_t c = 0; c < lf.cols.size(); ++c) {
-            DevCol &dc = lf.cols[c];
+        for (size_t c = 0; c < lf.schema.size(); ++c) {
+            if (child[c] < 0) continue;
             const ArrowArray *a = rb->children[child[c]];
-            if (!a || a->length != n) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' length mismatch", dc.name.c_str());
-            if (a->null_count > 0) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs (NEXMark fields are non-nullable)", dc.name.c_str());
+            if (!a || a->length < rb->offset + n) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' is shorter than its batch", lf.schema[c].name.c_str());
+            if (lf.schema[c].type == ColType::UTF8) {
+                if (a->n_buffers < 3 || !a->buffers[1]) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: Utf8 column '%s' without 3 buffers", lf.schema[c].name.c_str());
+            } else if (a->n_buffers < 2 || !a->buffers[1]) {
+                return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' without a data buffer", lf.schema[c].name.c_str());
+            }
             const int64_t off = a->offset + rb->offset;
-            if (dc.format == "u") {
-                if (a->n_buffers < 3) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: Utf8 column '%s' without 3 buffers", dc.name.c_str());
-                const int32_t *src_off = static_cast<const int32_t *>(a->buffers[1]) + off;
+            if (!validity_has_nulls(a, off, n)) continue;
+            // NULLs: acceptable only where dropping the row cannot change the result (join keys, MAX arguments, compared columns)
+            if (!lf.null_droppable[c])
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs that would reach the output (NEXMark fields are non-nullable)",
+                            lf.schema[c].name.c_str());
+            const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);
+            std::vector<int64_t> &k = keep[(size_t)b];
+            if (!filtered[(size_t)b]) {
+                k.resize((size_t)n);
+                for (int64_t i = 0; i < n; ++i) k[(size_t)i] = i;
+                filtered[(size_t)b] = 1;
+            }
+            size_t w = 0;
+            for (int64_t i : k)
+                if ((bits[(off + i) >> 3] >> ((off + i) & 7)) & 1) k[w++] = i;
+            k.resize(w);
+        }
+        const int64_t n_keep = filtered[(size_t)b] ? (int64_t)keep[(size_t)b].size() : n;
+        for (size_t c = 0; c < lf.schema.size(); ++c) {
+            if (child[c] < 0 || lf.schema[c].type != ColType::UTF8) continue;
+            const ArrowArray *a = rb->children[child[c]];
+            const int32_t *so = static_cast<const int32_t *>(a->buffers[1]) + a->offset + rb->offset;
+            if (!filtered[(size_t)b]) add_bytes[c] += (int64_t)so[n] - so[0];
+            else for (int64_t i : keep[(size_t)b]) add_bytes[c] += so[i + 1] - so[i];
+        }
+        add_rows += n_keep;
+    }
+    if (ld.rows + add_rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: more than 2^31 rows per relation");
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (child[c] < 0) continue;
+        DevBuf &dc = ld.cols[c];
+        void *p = nullptr;
+        if (lf.schema[c].type == ColType::UTF8) {
+            if (dc.bytes + add_bytes[c] >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: Utf8 column exceeds 2^31 bytes");
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "off"), (size_t)(ld.rows + 1) * 4, (size_t)(ld.rows + add_rows + 1) * 4 + 16, &p));
+            if (!dc.offsets) FG_HIP(ctx, hipMemsetAsync(p, 0, 4, ctx->stream));
+            dc.offsets = static_cast<int32_t *>(p);
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "bytes"), (size_t)dc.bytes, (size_t)(dc.bytes + add_bytes[c]) + 16, &p));
+            dc.values = p;
+        } else {
+            const size_t w = col_width(lf.schema[c].type);
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "val"), (size_t)ld.rows * w, (size_t)(ld.rows + add_rows) * w + 16, &p));
+            dc.values = p;
+        }
+    }
+    std::vector<uint8_t> tmp_vals, tmp_bytes;
+    std::vector<int32_t> tmp_off;
+    for (int b = 0; b < n_batches; ++b) {
+        const ArrowArray *rb = batches[b];
+        int64_t n = rb->length;
+        if (n == 0) continue;
+        const bool filt = filtered[(size_t)b] != 0;
+        const std::vector<int64_t> &k = keep[(size_t)b];
+        for (size_t c = 0; c < lf.schema.size(); ++c) {
+            if (child[c] < 0) continue;
+            DevBuf &dc = ld.cols[c];
+            const ArrowArray *a = rb->children[child[c]];
+            const int64_t off = a->offset + rb->offset;
+            if (lf.schema[c].type == ColType::UTF8) {
+                const int32_t *so = static_cast<const int32_t *>(a->buffers[1]) + off;
                 const uint8_t *src = static_cast<const uint8_t *>(a->buffers[2]);
-                const int64_t b0 = src_off[0], nbytes = (int64_t)src_off[n] - b0;
-                if (dc.bytes + nbytes >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: Utf8 column exceeds 2^31 bytes");
-                void *p = nullptr;
-                FG_TRY(Grow::ensure(ctx, key_of(plan, input, dc, "off"), (size_t)(lf.rows + 1) * 4, (size_t)(lf.rows + n + 1) * 4, &p));
-                dc.offsets = static_cast<int32_t *>(p);
-                FG_TRY(Grow::ensure(ctx, key_of(plan, input, dc, "bytes"), (size_t)dc.bytes, (size_t)(dc.bytes + nbytes) + 16, &p));
-                dc.values = p;
-                rebased.resize((size_t)n + 1);
-                for (int64_t i = 0; i <= n; ++i) rebased[i] = (int32_t)(src_off[i] - b0 + dc.bytes);
-                // offsets[rows .. rows + n] (the shared boundary entry is rewritten with the same value)
-                FG_HIP(ctx, hipMemcpyAsync(dc.offsets + lf.rows, rebased.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-                if (nbytes) FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dc.values) + dc.bytes, src + b0, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
-                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `rebased` is reused for the next column
+                int64_t b0 = so[0], nbytes = (int64_t)so[n] - b0, rows_in = n;
+                if (filt) {  // the surviving rows, compacted on the host (small: the outputs of aggregate stages)
+                    tmp_off.assign(1, 0);
+                    tmp_bytes.clear();
+                    for (int64_t i : k) {
+                        tmp_bytes.insert(tmp_bytes.end(), src + so[i], src + so[i + 1]);
+                        tmp_off.push_back((int32_t)tmp_bytes.size());
+                    }
+                    so = tmp_off.data();
+                    src = tmp_bytes.data();
+                    b0 = 0;
+                    nbytes = (int64_t)tmp_bytes.size();
+                    rows_in = (int64_t)k.size();
+                }
+                // offsets[rows + 1 .. rows + n] = source offsets rebased onto the column's byte cursor, on the device
+                FG_TRY(h2d(plan, dc.offsets + ld.rows + 1, so + 1, (size_t)rows_in * 4));
+                FG_TRY(add_i32(ctx, dc.offsets + ld.rows + 1, rows_in, (int32_t)(dc.bytes - b0)));
+                if (nbytes) FG_TRY(h2d(plan, static_cast<uint8_t *>(dc.values) + dc.bytes, src + b0, (size_t)nbytes));
                 dc.bytes += nbytes;
             } else {
-                const size_t w = width_of(dc.format);
-                if (a->n_buffers < 2) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: column '%s' without a data buffer", dc.name.c_str());
+                const size_t w = col_width(lf.schema[c].type);
                 const uint8_t *src = static_cast<const uint8_t *>(a->buffers[1]) + (size_t)off * w;
-                void *p = nullptr;
-                FG_TRY(Grow::ensure(ctx, key_of(plan, input, dc, "val"), (size_t)lf.rows * w, (size_t)(lf.rows + n) * w + 16, &p));
-                dc.values = p;
-                FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dc.values) + (size_t)lf.rows * w, src, (size_t)n * w, hipMemcpyHostToDevice, ctx->stream));
-                if (dc.keep_host) dc.host.bytes.insert(dc.host.bytes.end(), src, src + (size_t)n * w);
+                int64_t rows_in = n;
+                if (filt) {
+                    tmp_vals.resize(k.size() * w);
+                    for (size_t i = 0; i < k.size(); ++i) std::memcpy(tmp_vals.data() + i * w, src + (size_t)k[i] * w, w);
+                    src = tmp_vals.data();
+                    rows_in = (int64_t)k.size();
+                }
+                FG_TRY(h2d(plan, static_cast<uint8_t *>(dc.values) + (size_t)ld.rows * w, src, (size_t)rows_in * w));
             }
         }
-        lf.rows += n;
+        ld.rows += filt ? (int64_t)k.size() : n;
     }
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FLOCKGPU_OK;
+    return FLOCKGPU_OK;  // no host wait: the copies are ordered before the plan's kernels on the ctx stream
 }
 
 int flockgpu_plan_reset(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
-    for (auto &lf : plan->leaves) {
-        lf.rows = 0;
-        for (auto &c : lf.cols) {
-            c.bytes = 0;
-            c.host.bytes.clear();
-        }
+    // borrowed pinned buffers may still be read by the DMA engine: the caller is about to drop them
+    if (plan->fed_bytes) (void)hipStreamSynchronize(plan->ctx->stream);
+    plan->fed_bytes = 0;
+    for (auto &ld : plan->leaves) {
+        ld.rows = 0;
+        for (auto &c : ld.cols) c.bytes = 0;
     }
     return FLOCKGPU_OK;
 }
 
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
-    flockgpu_ctx *ctx = plan->ctx;
-    if (!out_schema || !out_batch) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_execute: null output");
-    FG_HIP(ctx, hipSetDevice(ctx->device));
-    auto whole = [](int64_t rows, int64_t (&off)[2], int32_t (&lo)[1], int32_t (&hi)[1]) {
-        off[0] = 0; off[1] = rows; lo[0] = 0; hi[0] = 1;
-        return flockgpu_windows{off, 1, lo, hi, 1};
-    };
-    auto dummy_utf8 = [&](DevCol &c) -> int {  // an unfed Utf8 column still needs a one-entry offsets array
-        if (c.offsets) return FLOCKGPU_OK;
-        void *p = nullptr;
-        FG_TRY(Grow::ensure(ctx, key_of(plan, 0, c, "empty"), 0, 64, &p));
-        FG_HIP(ctx, hipMemsetAsync(p, 0, 64, ctx->stream));
-        c.offsets = static_cast<int32_t *>(p);
-        c.values = static_cast<uint8_t *>(p) + 16;
-        return FLOCKGPU_OK;
-    };
-    int64_t off_a[2], off_b[2];
-    int32_t lo_a[1], hi_a[1], lo_b[1], hi_b[1];
-
-    if (plan->query == 1) {
-        Leaf &b = plan->leaves[0];
-        double *d_out = nullptr;
-        FG_TRY(arena_get_t(ctx, "plan.q1.out", (size_t)b.rows + 2, &d_out));
-        flockgpu_bid_cols bc{nullptr, nullptr, static_cast<const int32_t *>(b.cols[2].values), nullptr, b.rows};
-        FG_TRY(flockgpu_q1_project(ctx, &bc, plan->q1_factor, d_out));
-        void *h_price, *h_a, *h_b, *h_t;
-        FG_TRY(d2h_alloc(ctx, d_out, (size_t)b.rows * 8, &h_price));
-        FG_TRY(host_dup(ctx, b.cols[0].host.bytes, &h_a));
-        FG_TRY(host_dup(ctx, b.cols[1].host.bytes, &h_b));
-        FG_TRY(host_dup(ctx, b.cols[3].host.bytes, &h_t));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "auction", false);
-        add_schema_child(out_schema, "i", "bidder", false);
-        add_schema_child(out_schema, "g", plan->q1_out_name.c_str(), false);
-        add_schema_child(out_schema, "tsm:", "b_date_time", false);
-        make_struct_array(out_batch, b.rows);
-        add_array_child(out_batch, b.rows, h_a, nullptr);
-        add_array_child(out_batch, b.rows, h_b, nullptr);
-        add_array_child(out_batch, b.rows, h_price, nullptr);
-        add_array_child(out_batch, b.rows, h_t, nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 2) {
-        Leaf &b = plan->leaves[0];
-        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), nullptr, static_cast<const int32_t *>(b.cols[1].values), nullptr, b.rows};
-        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
-        flockgpu_q2_result r{};
-        FG_TRY(flockgpu_q2_filter(ctx, &bc, &w, plan->q2_modulus, &r));
-        void *h_a, *h_p;
-        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
-        FG_TRY(d2h_alloc(ctx, r.price, (size_t)r.rows * 4, &h_p));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "auction", false);
-        add_schema_child(out_schema, "i", "price", false);
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h_a, nullptr);
-        add_array_child(out_batch, r.rows, h_p, nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 3) {
-        Leaf &a = plan->leaves[0], &p = plan->leaves[1];
-        for (int c = 1; c < 4; ++c) FG_TRY(dummy_utf8(p.cols[c]));
-        flockgpu_auction_cols ac{static_cast<const int32_t *>(a.cols[0].values), static_cast<const int32_t *>(a.cols[1].values),
-                                 static_cast<const int32_t *>(a.cols[2].values), a.rows};
-        flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values), dev_utf8(p.cols[1]), dev_utf8(p.cols[2]), dev_utf8(p.cols[3]), p.rows};
-        flockgpu_windows aw = whole(a.rows, off_a, lo_a, hi_a), pw = whole(p.rows, off_b, lo_b, hi_b);
-        std::vector<const char *> lits;
-        for (auto &s : plan->q3_states) lits.push_back(s.c_str());
-        flockgpu_q3_result r{};
-        FG_TRY(flockgpu_q3_join(ctx, &ac, &aw, &pc, &pw, plan->q3_category, lits.data(), (int)lits.size(), &r));
-        void *h[7];
-        FG_TRY(d2h_alloc(ctx, r.name.offsets, (size_t)(r.rows + 1) * 4, &h[0]));
-        FG_TRY(d2h_alloc(ctx, r.name.data, (size_t)r.name_bytes, &h[1]));
-        FG_TRY(d2h_alloc(ctx, r.city.offsets, (size_t)(r.rows + 1) * 4, &h[2]));
-        FG_TRY(d2h_alloc(ctx, r.city.data, (size_t)r.city_bytes, &h[3]));
-        FG_TRY(d2h_alloc(ctx, r.state.offsets, (size_t)(r.rows + 1) * 4, &h[4]));
-        FG_TRY(d2h_alloc(ctx, r.state.data, (size_t)r.state_bytes, &h[5]));
-        FG_TRY(d2h_alloc(ctx, r.a_id, (size_t)r.rows * 4, &h[6]));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "u", "name", false);
-        add_schema_child(out_schema, "u", "city", false);
-        add_schema_child(out_schema, "u", "state", false);
-        add_schema_child(out_schema, "i", "a_id", false);
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h[1], h[0]);
-        add_array_child(out_batch, r.rows, h[3], h[2]);
-        add_array_child(out_batch, r.rows, h[5], h[4]);
-        add_array_child(out_batch, r.rows, h[6], nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 5) {
-        // both leaves scan `bid`; whichever was fed holds the relation (feed_data_sources gives it to the first match)
-        Leaf &b = plan->leaves[0].rows ? plan->leaves[0] : plan->leaves[1];
-        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), nullptr, nullptr, nullptr, b.rows};
-        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
-        flockgpu_q5_result r{};
-        FG_TRY(flockgpu_q5_hot_items(ctx, &bc, &w, &r));
-        void *h_a, *h_n;
-        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
-        FG_TRY(d2h_alloc(ctx, r.num, (size_t)r.rows * 8, &h_n));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "auction", false);
-        add_schema_child(out_schema, "L", "num", true);  // COUNT(*) -> UInt64, nullable in the schema (q5_plan.fmt:1)
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h_a, nullptr);
-        add_array_child(out_batch, r.rows, h_n, nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 7) {
-        Leaf &b = plan->leaves[0].rows ? plan->leaves[0] : plan->leaves[1];
-        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), static_cast<const int32_t *>(b.cols[1].values),
-                             static_cast<const int32_t *>(b.cols[2].values), static_cast<const int64_t *>(b.cols[3].values), b.rows};
-        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
-        flockgpu_q7_result r{};
-        FG_TRY(flockgpu_q7_highest_bid(ctx, &bc, &w, &r));
-        void *h_a, *h_p, *h_b, *h_t;
-        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
-        FG_TRY(d2h_alloc(ctx, r.price, (size_t)r.rows * 4, &h_p));
-        FG_TRY(d2h_alloc(ctx, r.bidder, (size_t)r.rows * 4, &h_b));
-        FG_TRY(d2h_alloc(ctx, r.b_date_time, (size_t)r.rows * 8, &h_t));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "auction", false);   // q7_plan.fmt:1
-        add_schema_child(out_schema, "i", "price", false);
-        add_schema_child(out_schema, "i", "bidder", false);
-        add_schema_child(out_schema, "tsm:", "b_date_time", false);
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h_a, nullptr);
-        add_array_child(out_batch, r.rows, h_p, nullptr);
-        add_array_child(out_batch, r.rows, h_b, nullptr);
-        add_array_child(out_batch, r.rows, h_t, nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 13) {
-        Leaf &b = plan->leaves[0], &sd = plan->leaves[1];
-        flockgpu_bid_cols bc{static_cast<const int32_t *>(b.cols[0].values), static_cast<const int32_t *>(b.cols[1].values),
-                             static_cast<const int32_t *>(b.cols[2].values), static_cast<const int64_t *>(b.cols[3].values), b.rows};
-        flockgpu_windows w = whole(b.rows, off_a, lo_a, hi_a);
-        flockgpu_q13_result r{};
-        FG_TRY(flockgpu_q13_side_join(ctx, &bc, &w, static_cast<const int32_t *>(sd.cols[0].values),
-                                      static_cast<const int32_t *>(sd.cols[1].values), sd.rows, &r));
-        void *h_a, *h_b, *h_p, *h_t, *h_v;
-        FG_TRY(d2h_alloc(ctx, r.auction, (size_t)r.rows * 4, &h_a));
-        FG_TRY(d2h_alloc(ctx, r.bidder, (size_t)r.rows * 4, &h_b));
-        FG_TRY(d2h_alloc(ctx, r.price, (size_t)r.rows * 4, &h_p));
-        FG_TRY(d2h_alloc(ctx, r.b_date_time, (size_t)r.rows * 8, &h_t));
-        FG_TRY(d2h_alloc(ctx, r.value, (size_t)r.rows * 4, &h_v));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "auction", false);   // q13_plan.fmt:1
-        add_schema_child(out_schema, "i", "bidder", false);
-        add_schema_child(out_schema, "i", "price", false);
-        add_schema_child(out_schema, "tsm:", "b_date_time", false);
-        add_schema_child(out_schema, "i", "value", false);
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h_a, nullptr);
-        add_array_child(out_batch, r.rows, h_b, nullptr);
-        add_array_child(out_batch, r.rows, h_p, nullptr);
-        add_array_child(out_batch, r.rows, h_t, nullptr);
-        add_array_child(out_batch, r.rows, h_v, nullptr);
-        return FLOCKGPU_OK;
-    }
-    if (plan->query == 8) {
-        Leaf &p = plan->leaves[0], &a = plan->leaves[1];
-        FG_TRY(dummy_utf8(p.cols[1]));
-        flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values), dev_utf8(p.cols[1]), {nullptr, nullptr}, {nullptr, nullptr}, p.rows};
-        flockgpu_auction_cols ac{nullptr, static_cast<const int32_t *>(a.cols[0].values), nullptr, a.rows};
-        flockgpu_windows pw = whole(p.rows, off_a, lo_a, hi_a), aw = whole(a.rows, off_b, lo_b, hi_b);
-        flockgpu_q8_result r{};
-        FG_TRY(flockgpu_q8_join(ctx, &pc, &pw, &ac, &aw, &r));
-        void *h_id, *h_off, *h_bytes;
-        FG_TRY(d2h_alloc(ctx, r.p_id, (size_t)r.rows * 4, &h_id));
-        FG_TRY(d2h_alloc(ctx, r.name.offsets, (size_t)(r.rows + 1) * 4, &h_off));
-        FG_TRY(d2h_alloc(ctx, r.name.data, (size_t)r.name_bytes, &h_bytes));
-        make_schema(out_schema, "+s", "", false);
-        add_schema_child(out_schema, "i", "p_id", false);
-        add_schema_child(out_schema, "u", "name", false);
-        make_struct_array(out_batch, r.rows);
-        add_array_child(out_batch, r.rows, h_id, nullptr);
-        add_array_child(out_batch, r.rows, h_bytes, h_off);
-        return FLOCKGPU_OK;
-    }
-    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_execute: unknown query %d", plan->query);
+    if (!out_schema || !out_batch) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute: null output");
+    int n = 0;
+    return run_plan(plan, false, out_schema, out_batch, 1, &n);
 }
+
+int flockgpu_plan_execute_partitioned(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batches, int capacity,
+                                      int *n_partitions) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    if (!out_schema || !out_batches || !n_partitions || capacity < 1) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute_partitioned: bad argument");
+    return run_plan(plan, true, out_schema, out_batches, capacity, n_partitions);
+}
+
+int flockgpu_host_alloc(size_t bytes, void **out) {
+    if (!out) return FLOCKGPU_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) == hipSuccess ? FLOCKGPU_OK : FLOCKGPU_ERR_OOM;
+}
+int flockgpu_host_free(void *ptr) { return !ptr || hipHostFree(ptr) == hipSuccess ? FLOCKGPU_OK : FLOCKGPU_ERR_HIP; }
+int flockgpu_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return FLOCKGPU_ERR_INVALID;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? FLOCKGPU_OK : FLOCKGPU_ERR_HIP;
+}
+int flockgpu_host_unregister(void *ptr) { return ptr && hipHostUnregister(ptr) == hipSuccess ? FLOCKGPU_OK : FLOCKGPU_ERR_HIP; }
 
 }  // extern "C"

@@ -1,0 +1,521 @@
+// Physical-plan IR of the plan-level C ABI (include/flockgpu_plan.h): the serde_json text of the reference's
+// `Arc<dyn ExecutionPlan>` (flock/src/runtime/context.rs:477-480; dialect: SURVEY.md appendix C, fixtures
+// flock/src/tests/data/plan/*.json) parsed into a small operator tree with derived schemas.  Host-side only.
+//
+// Kept nodes: memory_exec (Scan), filter_exec, projection_exec, hash_aggregate_exec, hash_join_exec and
+// repartition_exec with Hash partitioning.  coalesce_batches_exec, repartition_exec RoundRobinBatch, merge_exec /
+// coalesce_partitions_exec change neither the row multiset nor the schema and are dropped.
+// Anything else (sort_exec, global_limit_exec, unknown expressions / types) makes the plan UNSUPPORTED: the host keeps
+// its own engine for it.
+#pragma once
+#include <set>
+#include <sstream>
+
+#include "plan_json.hpp"
+#include "relops.hpp"
+
+namespace flockgpu {
+namespace ir {
+
+struct Field {
+    std::string name;
+    ColType type = ColType::I32;
+    bool is_ts = false;
+    bool nullable = false;
+};
+
+enum class EKind { Col, LitI, LitF, LitS, Bin, Cast };
+struct Expr {
+    EKind kind = EKind::Col;
+    int col = -1;  // Col: index into the input schema
+    int64_t i = 0;
+    double f = 0;
+    std::string s;   // LitS value / Bin operator (Rust enum ident: Eq, NotEq, Lt, LtEq, Gt, GtEq, And, Or, Modulo, Multiply)
+    ColType cast_to = ColType::I64;
+    std::unique_ptr<Expr> l, r;  // Bin operands; Cast operand in l
+};
+
+enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition };
+struct Agg {
+    std::string fn;  // "count" | "max" | ...
+    int arg = -1;    // input column of the argument (Partial / single stage); -1: a literal (COUNT(UInt8(1)))
+    std::string name;
+    ColType type = ColType::U64;
+};
+struct Node {
+    NKind kind = NKind::Scan;
+    int id = 0;
+    std::vector<std::unique_ptr<Node>> in;
+    std::vector<Field> schema;
+    int leaf = -1;                  // Scan: index into Plan::leaves
+    std::unique_ptr<Expr> pred;     // Filter
+    std::vector<std::pair<std::unique_ptr<Expr>, std::string>> proj;  // Project
+    std::string mode;               // Aggregate: Partial | Final | FinalPartitioned
+    std::vector<int> group;         // Aggregate: input columns of the group keys
+    std::vector<Agg> aggs;
+    int on_l = -1, on_r = -1;       // Join: key columns (left input, right input)
+    std::vector<int> hash_cols;     // Repartition
+    int n_parts = 0;
+    std::vector<char> required;     // per output column: needed by an ancestor (or by the plan output)
+};
+
+struct Leaf {
+    std::vector<Field> schema;  // the columns the MemoryExec scans (after its projection)
+    std::string relation;       // bid | auction | person | side_input | "" (guessed from the column names)
+    std::vector<char> needed;   // per column: read by the plan (others are never uploaded)
+    // per column: a row whose value here is NULL can be dropped at the scan without changing the plan's result (the column
+    // only feeds inner-join keys, MAX arguments or comparisons) -- how the NULL `maxn` of an empty partition is ingested
+    std::vector<char> null_droppable;
+};
+
+struct Plan {
+    std::unique_ptr<Node> root;
+    std::vector<Leaf> leaves;
+    int n_nodes = 0;
+    std::string why;  // reason when unsupported
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+inline const std::string &tag(const JValue *n) {
+    static const std::string empty;
+    const JValue *t = n ? n->get("execution_plan") : nullptr;
+    return t && t->kind == JValue::Str ? t->str : empty;
+}
+inline const std::string &etag(const JValue *e) {
+    static const std::string empty;
+    const JValue *t = e ? e->get("physical_expr") : nullptr;
+    return t && t->kind == JValue::Str ? t->str : empty;
+}
+
+inline bool parse_type(const JValue *dt, ColType *t, bool *is_ts) {
+    *is_ts = false;
+    if (!dt) return false;
+    if (dt->kind == JValue::Str) {
+        if (dt->str == "Int32") { *t = ColType::I32; return true; }
+        if (dt->str == "Int64") { *t = ColType::I64; return true; }
+        if (dt->str == "UInt64") { *t = ColType::U64; return true; }
+        if (dt->str == "Float64") { *t = ColType::F64; return true; }
+        if (dt->str == "Utf8") { *t = ColType::UTF8; return true; }
+        return false;
+    }
+    if (dt->kind == JValue::Obj && dt->obj.size() == 1 && dt->obj[0].first == "Timestamp") {
+        const JValue *a = dt->obj[0].second.get();
+        if (a->kind == JValue::Arr && !a->arr.empty() && a->arr[0]->kind == JValue::Str && a->arr[0]->str == "Millisecond") {
+            *t = ColType::I64;
+            *is_ts = true;
+            return true;
+        }
+    }
+    return false;
+}
+
+inline const char *type_name(const Field &f) {
+    if (f.is_ts) return "Timestamp(ms)";
+    switch (f.type) {
+        case ColType::I32: return "Int32";
+        case ColType::I64: return "Int64";
+        case ColType::U64: return "UInt64";
+        case ColType::F64: return "Float64";
+        default: return "Utf8";
+    }
+}
+
+struct Builder {
+    Plan *plan;
+    std::string err;
+    bool fail(const std::string &m) {
+        if (err.empty()) err = m;
+        return false;
+    }
+
+    bool fields_of(const JValue *schema, std::vector<Field> *out) {
+        const JValue *fields = schema ? schema->get("fields") : nullptr;
+        if (!fields || fields->kind != JValue::Arr) return fail("node without schema.fields");
+        for (auto &f : fields->arr) {
+            Field fd;
+            fd.name = f->s("name");
+            const JValue *nl = f->get("nullable");
+            fd.nullable = nl && nl->kind == JValue::Bool && nl->b;
+            if (!parse_type(f->get("data_type"), &fd.type, &fd.is_ts)) return fail("column '" + fd.name + "': data type outside {Int32, Int64, UInt64, Float64, Utf8, Timestamp(ms)}");
+            out->push_back(fd);
+        }
+        return true;
+    }
+
+    // column{name[,index]} against `schema`: by index when it names the same column, else by name (older fork
+    // revisions serialise the name only)
+    int resolve(const JValue *e, const std::vector<Field> &schema) {
+        const std::string name = e->s("name");
+        const JValue *ix = e->get("index");
+        if (ix && ix->kind == JValue::Num && ix->is_int && ix->inum >= 0 && (size_t)ix->inum < schema.size() &&
+            (name.empty() || schema[(size_t)ix->inum].name == name))
+            return (int)ix->inum;
+        for (size_t i = 0; i < schema.size(); ++i)
+            if (schema[i].name == name) return (int)i;
+        // qualified name ("bid.price", "CountBids.num") against an unqualified schema
+        const size_t dot = name.rfind('.');
+        if (dot != std::string::npos)
+            for (size_t i = 0; i < schema.size(); ++i)
+                if (schema[i].name == name.substr(dot + 1)) return (int)i;
+        return -1;
+    }
+
+    std::unique_ptr<Expr> expr(const JValue *e, const std::vector<Field> &schema) {
+        std::unique_ptr<Expr> x(new Expr());
+        const std::string &t = etag(e);
+        if (t == "column") {
+            x->kind = EKind::Col;
+            x->col = resolve(e, schema);
+            if (x->col < 0) { fail("column '" + e->s("name") + "' not in the input schema"); return nullptr; }
+            return x;
+        }
+        if (t == "literal") {
+            const JValue *val = e->get("value");
+            std::string kind;
+            if (val && val->kind == JValue::Obj && val->obj.size() == 1) {
+                kind = val->obj[0].first;
+                val = val->obj[0].second.get();
+            }
+            if (!val) { fail("literal without value"); return nullptr; }
+            if (val->kind == JValue::Str) { x->kind = EKind::LitS; x->s = val->str; return x; }
+            if (val->kind == JValue::Num) {
+                if (val->is_int && kind.find("Float") == std::string::npos) { x->kind = EKind::LitI; x->i = val->inum; }
+                else { x->kind = EKind::LitF; x->f = val->num; }
+                return x;
+            }
+            fail("literal of an unsupported kind");
+            return nullptr;
+        }
+        if (t == "cast_expr" || t == "try_cast_expr") {
+            x->kind = EKind::Cast;
+            bool ts = false;
+            if (!parse_type(e->get("cast_type"), &x->cast_to, &ts)) { fail("cast to an unsupported type"); return nullptr; }
+            x->l = expr(e->get("expr"), schema);
+            return x->l ? std::move(x) : nullptr;
+        }
+        if (t == "binary_expr") {
+            x->kind = EKind::Bin;
+            x->s = e->s("op");
+            x->l = expr(e->get("left"), schema);
+            x->r = expr(e->get("right"), schema);
+            return x->l && x->r ? std::move(x) : nullptr;
+        }
+        fail("physical_expr '" + t + "' is not supported");
+        return nullptr;
+    }
+
+    static std::string guess_relation(const std::vector<Field> &f) {
+        auto has = [&](const char *n) { return std::any_of(f.begin(), f.end(), [&](const Field &x) { return x.name == n; }); };
+        if (has("auction") || has("bidder") || has("price")) return "bid";
+        if (has("a_id") || has("seller") || has("category")) return "auction";
+        if (has("p_id") || has("state") || has("city")) return "person";
+        if (has("key") && has("value")) return "side_input";
+        return "";
+    }
+
+    std::unique_ptr<Node> node(const JValue *j, int depth = 0) {
+        if (!j || j->kind != JValue::Obj || depth > 64) { fail("malformed plan node"); return nullptr; }
+        const std::string &t = tag(j);
+        // transparent nodes
+        if (t == "coalesce_batches_exec" || t == "merge_exec" || t == "coalesce_partitions_exec") return node(j->get("input"), depth + 1);
+        std::unique_ptr<Node> n(new Node());
+        if (t == "repartition_exec") {
+            const JValue *part = j->get("partitioning");
+            const JValue *hash = part ? part->get("Hash") : nullptr;
+            if (!hash) return node(j->get("input"), depth + 1);  // RoundRobinBatch(n)
+            if (hash->kind != JValue::Arr || hash->arr.size() != 2 || hash->arr[0]->kind != JValue::Arr || hash->arr[1]->kind != JValue::Num) {
+                fail("malformed Hash partitioning");
+                return nullptr;
+            }
+            n->kind = NKind::Repartition;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            n->schema = in->schema;
+            for (auto &e : hash->arr[0]->arr) {
+                if (etag(e.get()) != "column") { fail("Hash partitioning on a computed expression"); return nullptr; }
+                const int c = resolve(e.get(), n->schema);
+                if (c < 0) { fail("Hash partitioning column not in the schema"); return nullptr; }
+                n->hash_cols.push_back(c);
+            }
+            n->n_parts = (int)hash->arr[1]->inum;
+            if (n->hash_cols.empty() || n->n_parts < 1) { fail("Hash partitioning without columns / partitions"); return nullptr; }
+            n->in.push_back(std::move(in));
+        } else if (t == "memory_exec") {
+            n->kind = NKind::Scan;
+            std::vector<Field> all;
+            if (!fields_of(j->get("schema"), &all)) return nullptr;
+            const JValue *proj = j->get("projection");
+            if (proj && proj->kind == JValue::Arr && !proj->arr.empty()) {
+                bool ok = true;
+                for (auto &i : proj->arr) {
+                    if (i->kind == JValue::Num && i->inum >= 0 && (size_t)i->inum < all.size()) n->schema.push_back(all[(size_t)i->inum]);
+                    else ok = false;
+                }
+                // fixtures of older fork revisions list only the projected fields: indices then exceed the list
+                if (!ok) n->schema = all;
+            } else {
+                n->schema = all;
+            }
+            Leaf lf;
+            lf.schema = n->schema;
+            lf.relation = guess_relation(lf.schema);
+            n->leaf = (int)plan->leaves.size();
+            plan->leaves.push_back(lf);
+        } else if (t == "filter_exec") {
+            n->kind = NKind::Filter;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            n->schema = in->schema;
+            n->pred = expr(j->get("predicate"), n->schema);
+            if (!n->pred) return nullptr;
+            n->in.push_back(std::move(in));
+        } else if (t == "projection_exec") {
+            n->kind = NKind::Project;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            const JValue *ex = j->get("expr");
+            if (!ex || ex->kind != JValue::Arr) { fail("projection_exec without expr"); return nullptr; }
+            for (auto &pair : ex->arr) {
+                if (pair->kind != JValue::Arr || pair->arr.size() < 2 || pair->arr[1]->kind != JValue::Str) { fail("malformed projection expr"); return nullptr; }
+                auto e = expr(pair->arr[0].get(), in->schema);
+                if (!e) return nullptr;
+                Field f;
+                f.name = pair->arr[1]->str;
+                if (e->kind == EKind::Col) {
+                    const Field &src = in->schema[(size_t)e->col];
+                    f.type = src.type; f.is_ts = src.is_ts; f.nullable = src.nullable;
+                } else if (e->kind == EKind::Bin && e->s == "Multiply") {
+                    f.type = ColType::F64;
+                } else {
+                    fail("projection expression other than a column or `literal * column`");
+                    return nullptr;
+                }
+                n->proj.emplace_back(std::move(e), f.name);
+                n->schema.push_back(f);
+            }
+            n->in.push_back(std::move(in));
+        } else if (t == "hash_aggregate_exec") {
+            n->kind = NKind::Aggregate;
+            n->mode = j->s("mode");
+            if (n->mode != "Partial" && n->mode != "Final" && n->mode != "FinalPartitioned") { fail("aggregate mode '" + n->mode + "'"); return nullptr; }
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            const bool is_final = n->mode != "Partial";
+            const JValue *ge = j->get("group_expr");
+            size_t gi = 0;
+            if (ge && ge->kind == JValue::Arr)
+                for (auto &pair : ge->arr) {
+                    if (pair->kind != JValue::Arr || pair->arr.size() < 2) { fail("malformed group_expr"); return nullptr; }
+                    // the final stage reads the group keys by POSITION from the partial stage's output
+                    // (DataFusion's merge expressions); the partial / single stage evaluates the expression
+                    int c = -1;
+                    if (is_final && gi < in->schema.size()) c = (int)gi;
+                    else if (etag(pair->arr[0].get()) == "column") c = resolve(pair->arr[0].get(), in->schema);
+                    if (c < 0) { fail("GROUP BY on something other than an input column"); return nullptr; }
+                    n->group.push_back(c);
+                    Field f = in->schema[(size_t)c];
+                    f.name = pair->arr[1]->kind == JValue::Str ? pair->arr[1]->str : f.name;
+                    n->schema.push_back(f);
+                    ++gi;
+                }
+            const JValue *ae = j->get("aggr_expr");
+            size_t ai = 0;
+            if (ae && ae->kind == JValue::Arr)
+                for (auto &x : ae->arr) {
+                    Agg a;
+                    a.fn = x->s("aggregate_expr");
+                    a.name = x->s("name");
+                    bool ts = false;
+                    if (!parse_type(x->get("data_type"), &a.type, &ts)) { fail("aggregate '" + a.name + "' of an unsupported type"); return nullptr; }
+                    if (is_final) {
+                        a.arg = (int)(n->group.size() + ai);  // state column, by position
+                        if ((size_t)a.arg >= in->schema.size()) { fail("final aggregate without its state column"); return nullptr; }
+                    } else {
+                        const JValue *arg = x->get("expr");
+                        if (arg && etag(arg) == "column") {
+                            a.arg = resolve(arg, in->schema);
+                            if (a.arg < 0) { fail("aggregate argument not in the input schema"); return nullptr; }
+                        } else if (a.fn != "count") {
+                            fail("aggregate '" + a.fn + "' over a computed expression");
+                            return nullptr;
+                        }
+                    }
+                    if (a.fn != "count" && a.fn != "max") { fail("aggregate function '" + a.fn + "' (supported: count, max)"); return nullptr; }
+                    Field f;
+                    f.name = is_final ? a.name : a.name + "[" + a.fn + "]";
+                    f.type = a.fn == "count" ? ColType::U64 : a.type;
+                    f.nullable = true;
+                    n->aggs.push_back(a);
+                    n->schema.push_back(f);
+                    ++ai;
+                }
+            n->in.push_back(std::move(in));
+        } else if (t == "hash_join_exec") {
+            n->kind = NKind::Join;
+            if (j->s("join_type") != "Inner") { fail("only Inner joins"); return nullptr; }
+            auto l = node(j->get("left"), depth + 1);
+            if (!l) return nullptr;
+            auto r = node(j->get("right"), depth + 1);
+            if (!r) return nullptr;
+            const JValue *on = j->get("on");
+            if (!on || on->kind != JValue::Arr || on->arr.size() != 1 || on->arr[0]->kind != JValue::Arr || on->arr[0]->arr.size() != 2) {
+                fail("join on other than one key pair");
+                return nullptr;
+            }
+            auto keycol = [&](const JValue *k, const std::vector<Field> &schema) {
+                if (k->kind == JValue::Str) {  // older fork revision: bare names
+                    for (size_t i = 0; i < schema.size(); ++i)
+                        if (schema[i].name == k->str) return (int)i;
+                    return -1;
+                }
+                return resolve(k, schema);
+            };
+            n->on_l = keycol(on->arr[0]->arr[0].get(), l->schema);
+            n->on_r = keycol(on->arr[0]->arr[1].get(), r->schema);
+            if (n->on_l < 0 || n->on_r < 0) { fail("join key not in the input schemas"); return nullptr; }
+            n->schema = l->schema;
+            n->schema.insert(n->schema.end(), r->schema.begin(), r->schema.end());
+            n->in.push_back(std::move(l));
+            n->in.push_back(std::move(r));
+        } else {
+            fail("execution_plan '" + t + "' is not supported");
+            return nullptr;
+        }
+        n->id = plan->n_nodes++;
+        return n;
+    }
+};
+
+inline void expr_cols(const Expr *e, std::set<int> *out) {
+    if (!e) return;
+    if (e->kind == EKind::Col) out->insert(e->col);
+    expr_cols(e->l.get(), out);
+    expr_cols(e->r.get(), out);
+}
+
+// Marks, top-down, the output columns of every node that something above it reads; leaves learn which of their
+// columns have to reach the device at all.
+inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
+    n->required = req;
+    auto need = [](std::vector<char> &v, int c) { if (c >= 0 && (size_t)c < v.size()) v[(size_t)c] = 1; };
+    switch (n->kind) {
+        case NKind::Scan: {
+            Leaf &lf = p->leaves[(size_t)n->leaf];
+            if (lf.needed.size() != n->schema.size()) lf.needed.assign(n->schema.size(), 0);
+            for (size_t i = 0; i < req.size(); ++i) lf.needed[i] |= req[i];
+            break;
+        }
+        case NKind::Filter: {
+            std::vector<char> r = req;
+            std::set<int> cs;
+            expr_cols(n->pred.get(), &cs);
+            for (int c : cs) need(r, c);
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
+        case NKind::Project: {
+            std::vector<char> r(n->in[0]->schema.size(), 0);
+            for (size_t i = 0; i < n->proj.size(); ++i)
+                if (req[i]) {
+                    std::set<int> cs;
+                    expr_cols(n->proj[i].first.get(), &cs);
+                    for (int c : cs) need(r, c);
+                }
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
+        case NKind::Aggregate: {
+            std::vector<char> r(n->in[0]->schema.size(), 0);
+            for (int c : n->group) need(r, c);
+            for (auto &a : n->aggs) need(r, a.arg);
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
+        case NKind::Join: {
+            const size_t nl = n->in[0]->schema.size();
+            std::vector<char> l(req.begin(), req.begin() + nl), r(req.begin() + nl, req.end());
+            need(l, n->on_l);
+            need(r, n->on_r);
+            mark_required(p, n->in[0].get(), l);
+            mark_required(p, n->in[1].get(), r);
+            break;
+        }
+        case NKind::Repartition: {
+            std::vector<char> r = req;
+            for (int c : n->hash_cols) need(r, c);
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
+    }
+}
+
+// droppable[c]: dropping the rows of `n`'s output whose column c is NULL leaves the plan's result unchanged.
+inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> &droppable) {
+    switch (n->kind) {
+        case NKind::Scan: {
+            Leaf &lf = p->leaves[(size_t)n->leaf];
+            if (lf.null_droppable.size() != n->schema.size()) lf.null_droppable.assign(n->schema.size(), 1);
+            for (size_t i = 0; i < droppable.size(); ++i) lf.null_droppable[i] &= droppable[i];
+            break;
+        }
+        case NKind::Filter: {
+            std::vector<char> d = droppable;
+            // comparisons with NULL are NULL, and a NULL predicate drops the row -- through AND, not through OR
+            std::vector<const Expr *> stack{n->pred.get()};
+            while (!stack.empty()) {
+                const Expr *e = stack.back();
+                stack.pop_back();
+                if (e->kind == EKind::Bin && e->s == "And") { stack.push_back(e->l.get()); stack.push_back(e->r.get()); continue; }
+                if (e->kind == EKind::Bin && e->s != "Or") {
+                    std::set<int> cs;
+                    expr_cols(e, &cs);
+                    for (int c : cs) d[(size_t)c] = 1;
+                }
+            }
+            mark_null_droppable(p, n->in[0].get(), d);
+            break;
+        }
+        case NKind::Project: {
+            std::vector<char> d(n->in[0]->schema.size(), 0);
+            for (size_t i = 0; i < n->proj.size(); ++i)
+                if (droppable[i] && n->proj[i].first->kind == EKind::Col) d[(size_t)n->proj[i].first->col] = 1;
+            mark_null_droppable(p, n->in[0].get(), d);
+            break;
+        }
+        case NKind::Aggregate: {
+            std::vector<char> d(n->in[0]->schema.size(), 0);
+            if (n->group.empty())  // MAX ignores NULLs; over nothing but NULLs it is NULL, as over no rows
+                for (auto &a : n->aggs)
+                    if (a.fn == "max" && a.arg >= 0) d[(size_t)a.arg] = 1;
+            mark_null_droppable(p, n->in[0].get(), d);
+            break;
+        }
+        case NKind::Join: {
+            const size_t nl = n->in[0]->schema.size();
+            std::vector<char> l(droppable.begin(), droppable.begin() + nl), r(droppable.begin() + nl, droppable.end());
+            l[(size_t)n->on_l] = 1;  // NULL keys never match in an inner join
+            r[(size_t)n->on_r] = 1;
+            mark_null_droppable(p, n->in[0].get(), l);
+            mark_null_droppable(p, n->in[1].get(), r);
+            break;
+        }
+        case NKind::Repartition:
+            mark_null_droppable(p, n->in[0].get(), droppable);
+            break;
+    }
+}
+
+inline bool build_plan(const JValue *root, Plan *plan) {
+    Builder b{plan, {}};
+    plan->root = b.node(root);
+    if (!plan->root) {
+        plan->why = b.err.empty() ? "unsupported plan" : b.err;
+        return false;
+    }
+    mark_required(plan, plan->root.get(), std::vector<char>(plan->root->schema.size(), 1));
+    mark_null_droppable(plan, plan->root.get(), std::vector<char>(plan->root->schema.size(), 0));
+    return true;
+}
+
+}  // namespace ir
+}  // namespace flockgpu

@@ -1,0 +1,584 @@
+// Generic relational operators over device columns (relops.hpp): the plan interpreter's fallback for plan nodes that no
+// fused NEXMark pipeline covers -- the stage plans either side of a hash repartition.  One lane per row, 64-bit
+// normalised keys, global-memory hash tables; exact for any input.
+#include <algorithm>
+
+#include "relops.hpp"
+
+using namespace flockgpu;
+
+namespace {
+
+constexpr int64_t kEmptyKey = INT64_MIN;  // hash-table sentinel; the key INT64_MIN itself lives in the extra slot `cap`
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+inline unsigned grid_for(flockgpu_ctx *ctx, int64_t n) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 16));
+}
+
+__device__ __forceinline__ int64_t load_as_i64(const void *v, int32_t type, int64_t i) {
+    return type == (int32_t)ColType::I32 ? (int64_t) static_cast<const int32_t *>(v)[i] : static_cast<const int64_t *>(v)[i];
+}
+// U64 columns compare as unsigned; everything else as signed
+__device__ __forceinline__ bool cmp_i64(int64_t a, int64_t b, int32_t op, bool uns) {
+    if (uns) {
+        const uint64_t x = (uint64_t)a, y = (uint64_t)b;
+        switch (op) {
+            case 0: return x == y;
+            case 1: return x != y;
+            case 2: return x < y;
+            case 3: return x <= y;
+            case 4: return x > y;
+            default: return x >= y;
+        }
+    }
+    switch (op) {
+        case 0: return a == b;
+        case 1: return a != b;
+        case 2: return a < b;
+        case 3: return a <= b;
+        case 4: return a > b;
+        default: return a >= b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void widen_kernel(const void *__restrict__ v, int32_t type, int64_t n, int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = load_as_i64(v, type, i);
+}
+__global__ __launch_bounds__(kBlock) void widen_u32_kernel(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = in[i];
+}
+__global__ __launch_bounds__(kBlock) void mask_cmp_lit_kernel(const void *__restrict__ v, int32_t type, int64_t n, int32_t op,
+                                                              int64_t lit, int64_t modulus, uint8_t *__restrict__ mask) {
+    const bool uns = type == (int32_t)ColType::U64;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int64_t x = load_as_i64(v, type, i);
+        if (modulus) x = x % modulus;  // truncated remainder, as Rust's / Arrow's `%` on Int64
+        mask[i] = cmp_i64(x, lit, op, uns && !modulus) ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void mask_cmp_col_kernel(const void *__restrict__ a, int32_t ta, const void *__restrict__ b, int32_t tb,
+                                                              int64_t n, int32_t op, uint8_t *__restrict__ mask) {
+    const bool uns = ta == (int32_t)ColType::U64 && tb == (int32_t)ColType::U64;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        mask[i] = cmp_i64(load_as_i64(a, ta, i), load_as_i64(b, tb, i), op, uns) ? 1 : 0;
+}
+struct Lit48 {
+    uint8_t b[48];
+};
+__global__ __launch_bounds__(kBlock) void mask_utf8_eq_kernel(const int32_t *__restrict__ off, const uint8_t *__restrict__ bytes, int64_t n,
+                                                              Lit48 lit, int32_t len, int32_t negate, uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int32_t b0 = off[i], l = off[i + 1] - b0;
+        bool eq = l == len;
+        for (int32_t k = 0; eq && k < len; ++k) eq = bytes[b0 + k] == lit.b[k];
+        mask[i] = (eq != (negate != 0)) ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void mask_combine_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t n,
+                                                              int32_t is_and, uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = is_and ? (a[i] & b[i]) : (a[i] | b[i]);
+}
+// mask bytes -> flag words in the flag-tile geometry (scan.hpp): the lane's four consecutive rows are one 32-bit load
+__global__ __launch_bounds__(kBlock) void mask_flag_kernel(const uint8_t *__restrict__ mask, int64_t n_rows, SegTiles st,
+                                                           uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j;
+            const bool on = r >= tr.lo && r < tr.hi && mask[r] != 0;
+            flags |= (uint32_t)on << (it * 4 + j);
+        }
+    }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+
+// ---- group by
+__global__ __launch_bounds__(kBlock) void group_init_kernel(int64_t *__restrict__ tk, uint64_t *__restrict__ ta, int32_t *__restrict__ tf,
+                                                            int64_t slots) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
+        tk[i] = kEmptyKey;
+        ta[i] = 0;
+        tf[i] = 0x7fffffff;
+    }
+}
+// slot of `key` in an open-addressing table of `cap` (power of two) slots, claiming an empty one; -1: table full
+__device__ __forceinline__ int64_t claim_slot(int64_t *tk, uint64_t cap, int64_t key) {
+    if (key == kEmptyKey) return (int64_t)cap;
+    uint64_t s = mix64((uint64_t)key) & (cap - 1);
+    for (uint64_t probe = 0; probe < cap; ++probe) {
+        int64_t cur = __hip_atomic_load(&tk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptyKey) {
+            int64_t expected = kEmptyKey;
+            if (__hip_atomic_compare_exchange_strong(&tk[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                return (int64_t)s;
+            cur = expected;
+        }
+        if (cur == key) return (int64_t)s;
+        s = (s + 1) & (cap - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ int64_t find_slot(const int64_t *tk, uint64_t cap, int64_t key) {
+    if (key == kEmptyKey) return (int64_t)cap;
+    uint64_t s = mix64((uint64_t)key) & (cap - 1);
+    for (uint64_t probe = 0; probe < cap; ++probe) {
+        const int64_t cur = tk[s];
+        if (cur == kEmptyKey) return -1;
+        if (cur == key) return (int64_t)s;
+        s = (s + 1) & (cap - 1);
+    }
+    return -1;
+}
+__global__ __launch_bounds__(kBlock) void group_insert_kernel(const int64_t *__restrict__ keys, const uint64_t *__restrict__ values,
+                                                              int32_t kind, int64_t n, int64_t *tk, uint64_t *ta, int32_t *tf, uint64_t cap,
+                                                              uint32_t *err) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t key = keys[i];
+        const int64_t s = claim_slot(tk, cap, key);
+        if (s < 0) {
+            atomicOr(err, 1u);
+            continue;
+        }
+        if (s == (int64_t)cap) tk[s] = key;  // the dedicated slot of the sentinel key
+        atomicMin(&tf[s], (int32_t)i);
+        const uint64_t v = values ? values[i] : 1ull;
+        if (kind == (int32_t)AggKind::SUM) atomicAdd(reinterpret_cast<unsigned long long *>(&ta[s]), (unsigned long long)v);
+        else if (kind == (int32_t)AggKind::MAX) atomicMax(reinterpret_cast<unsigned long long *>(&ta[s]), (unsigned long long)v);
+    }
+}
+__global__ __launch_bounds__(kBlock) void live_slot_mask_kernel(const int32_t *__restrict__ tf, int64_t slots, uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) mask[i] = tf[i] != 0x7fffffff;
+}
+
+// ---- distinct (int32, Utf8)
+__device__ __forceinline__ bool same_pair(const int32_t *key, const int32_t *off, const uint8_t *bytes, int32_t a, int32_t b) {
+    if (key[a] != key[b]) return false;
+    const int32_t la = off[a + 1] - off[a], lb = off[b + 1] - off[b];
+    if (la != lb) return false;
+    const uint8_t *pa = bytes + off[a], *pb = bytes + off[b];
+    for (int32_t k = 0; k < la; ++k)
+        if (pa[k] != pb[k]) return false;
+    return true;
+}
+__global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t *__restrict__ p, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void distinct_insert_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ off,
+                                                                 const uint8_t *__restrict__ bytes, int64_t n, int32_t *table, uint64_t cap,
+                                                                 uint8_t *__restrict__ is_rep) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)key[i];
+        for (int32_t b = off[i]; b < off[i + 1]; ++b) h = (h ^ bytes[b]) * 0x100000001B3ull;
+        uint64_t s = mix64(h) & (cap - 1);
+        uint8_t rep = 0;
+        for (uint64_t probe = 0; probe < cap; ++probe) {
+            int32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                int32_t expected = -1;
+                if (__hip_atomic_compare_exchange_strong(&table[s], &expected, (int32_t)i, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {
+                    rep = 1;
+                    break;
+                }
+                cur = expected;
+            }
+            if (same_pair(key, off, bytes, cur, (int32_t)i)) break;
+            s = (s + 1) & (cap - 1);
+        }
+        is_rep[i] = rep;
+    }
+}
+
+// ---- max: per-workgroup maxima (signed or unsigned order), folded on the host
+__global__ __launch_bounds__(kBlock) void max_kernel(const void *__restrict__ v, int32_t type, int64_t n, int64_t *__restrict__ block_out) {
+    __shared__ int64_t s_m[kWavesPerBlock];
+    const bool uns = type == (int32_t)ColType::U64;
+    int64_t m = uns ? 0 : INT64_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t x = load_as_i64(v, type, i);
+        if (cmp_i64(x, m, 4, uns)) m = x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t t = __shfl_xor(m, o, 64);
+        if (cmp_i64(t, m, 4, uns)) m = t;
+    }
+    if (lane_id() == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w)
+            if (cmp_i64(s_m[w], m, 4, uns)) m = s_m[w];
+        block_out[blockIdx.x] = m;
+    }
+}
+
+// ---- join
+__global__ __launch_bounds__(kBlock) void join_init_kernel(int64_t *__restrict__ tk, int32_t *__restrict__ head, int64_t slots) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
+        tk[i] = kEmptyKey;
+        head[i] = -1;
+    }
+}
+__global__ __launch_bounds__(kBlock) void join_build_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t *tk, int32_t *head,
+                                                            int32_t *__restrict__ next, uint64_t cap, uint32_t *err) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t key = keys[i];
+        const int64_t s = claim_slot(tk, cap, key);
+        if (s < 0) {
+            atomicOr(err, 1u);
+            continue;
+        }
+        if (s == (int64_t)cap) tk[s] = key;
+        next[i] = atomicExch(&head[s], (int32_t)i);  // push front: the chain is walked only after the kernel boundary
+    }
+}
+template <bool kEmit>
+__global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__restrict__ keys, int64_t n, const int64_t *__restrict__ tk,
+                                                            const int32_t *__restrict__ head, const int32_t *__restrict__ next, uint64_t cap,
+                                                            int32_t *__restrict__ counts, int32_t *__restrict__ out_left,
+                                                            int32_t *__restrict__ out_right) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t s = find_slot(tk, cap, keys[i]);
+        int32_t c = 0;
+        if (s >= 0) {
+            // (inclusive scan in `counts` when emitting: this row's pairs end at counts[i])
+            int64_t at = 0;
+            if (kEmit) {
+                int32_t m = 0;
+                for (int32_t r = head[s]; r >= 0; r = next[r]) ++m;
+                at = (int64_t)counts[i] - m;
+            }
+            for (int32_t r = head[s]; r >= 0; r = next[r]) {
+                if (kEmit) {
+                    out_left[at + c] = r;
+                    out_right[at + c] = (int32_t)i;
+                }
+                ++c;
+            }
+        }
+        if (!kEmit) counts[i] = c;
+    }
+}
+__global__ __launch_bounds__(kBlock) void fold_key_kernel(const int64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t k = (uint64_t)keys[i];
+        out[i] = (int32_t)(uint32_t)(k ^ (k >> 32));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void narrow_kernel(const int64_t *__restrict__ in, int64_t n, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (int32_t)in[i];
+}
+__global__ __launch_bounds__(kBlock) void add_i32_kernel(int32_t *__restrict__ d, int64_t n, int32_t delta) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) d[i] += delta;
+}
+
+uint64_t pow2_at_least(uint64_t v) {
+    uint64_t c = 1024;
+    while (c < v) c <<= 1;
+    return c;
+}
+
+#define RELOPS_LAUNCH(ctx, name, kernel, n, ...)                                                                      \
+    do {                                                                                                              \
+        {                                                                                                             \
+            LaunchScope ls_((ctx), name);                                                                             \
+            hipLaunchKernelGGL(kernel, dim3(grid_for((ctx), (n))), dim3(kBlock), 0, (ctx)->stream, __VA_ARGS__);      \
+        }                                                                                                             \
+        FG_TRY(check_launch((ctx), name));                                                                            \
+    } while (0)
+
+}  // namespace
+
+namespace flockgpu {
+
+int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out) {
+    if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "key column must be an integer column");
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "widen_kernel", widen_kernel, rows, col.values, (int32_t)col.type, rows, out);
+    return FLOCKGPU_OK;
+}
+
+int widen_u32_to_u64(flockgpu_ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "widen_u32_kernel", widen_u32_kernel, n, in, n, out);
+    return FLOCKGPU_OK;
+}
+
+int narrow_i64_to_i32(flockgpu_ctx *ctx, const int64_t *in, int64_t n, int32_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "narrow_kernel", narrow_kernel, n, in, n, out);
+    return FLOCKGPU_OK;
+}
+
+int add_i32(flockgpu_ctx *ctx, int32_t *data, int64_t n, int32_t delta) {
+    if (n <= 0 || delta == 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "add_i32_kernel", add_i32_kernel, n, data, n, delta);
+    return FLOCKGPU_OK;
+}
+
+int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, int64_t lit, uint8_t *mask) {
+    if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "comparison needs an integer column");
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "mask_cmp_lit_kernel", mask_cmp_lit_kernel, rows, col.values, (int32_t)col.type, rows, (int32_t)op, lit, (int64_t)0, mask);
+    return FLOCKGPU_OK;
+}
+
+int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask) {
+    if (col.type == ColType::UTF8 || col.type == ColType::F64 || col.type == ColType::U64)
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "modulo needs a signed integer column");
+    if (modulus == 0) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "modulo by zero (the reference raises a DataFusion error)");
+    if (rows <= 0) return FLOCKGPU_OK;
+    // x % -1 == 0 for every x (and INT64_MIN % -1 traps in hardware): the remainder by |m| has the same value
+    const int64_t m = modulus == INT64_MIN ? modulus : (modulus < 0 ? -modulus : modulus);
+    RELOPS_LAUNCH(ctx, "mask_cmp_lit_kernel", mask_cmp_lit_kernel, rows, col.values, (int32_t)col.type, rows, (int32_t)op, lit, m, mask);
+    return FLOCKGPU_OK;
+}
+
+int mask_cmp_col(flockgpu_ctx *ctx, const DevColumn &a, const DevColumn &b, int64_t rows, CmpOp op, uint8_t *mask) {
+    auto bad = [](const DevColumn &c) { return c.type == ColType::UTF8 || c.type == ColType::F64; };
+    if (bad(a) || bad(b) || ((a.type == ColType::U64) != (b.type == ColType::U64)))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "column comparison needs two integer columns of the same signedness");
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "mask_cmp_col_kernel", mask_cmp_col_kernel, rows, a.values, (int32_t)a.type, b.values, (int32_t)b.type, rows, (int32_t)op, mask);
+    return FLOCKGPU_OK;
+}
+
+int mask_utf8_eq(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, const std::string &lit, bool negate, uint8_t *mask) {
+    if (col.type != ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "string comparison needs a Utf8 column");
+    if (lit.size() > sizeof(Lit48)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "Utf8 literal longer than %zu bytes", sizeof(Lit48));
+    if (rows <= 0) return FLOCKGPU_OK;
+    Lit48 l{};
+    std::memcpy(l.b, lit.data(), lit.size());
+    RELOPS_LAUNCH(ctx, "mask_utf8_eq_kernel", mask_utf8_eq_kernel, rows, col.offsets, static_cast<const uint8_t *>(col.values), rows, l,
+                  (int32_t)lit.size(), (int32_t)negate, mask);
+    return FLOCKGPU_OK;
+}
+
+int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t rows, bool is_and, uint8_t *out) {
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "mask_combine_kernel", mask_combine_kernel, rows, a, b, rows, (int32_t)is_and, out);
+    return FLOCKGPU_OK;
+}
+
+int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64_t rows, int32_t **out_rows, int64_t *n_out) {
+    const std::string base = name;
+    int32_t *o_rows = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".rows").c_str(), (size_t)std::max<int64_t>(rows, 0) + 4, &o_rows));
+    *out_rows = o_rows;
+    *n_out = 0;
+    if (rows <= 0) return FLOCKGPU_OK;
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^31 rows", name);
+    int64_t sb = 0, se = rows;
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, (base + ".tiles").c_str(), &sb, &se, 1, kFlagTile, &st));
+    uint32_t *flags = nullptr, *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    int64_t *d_off = nullptr, *h_off = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".flags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
+    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
+    FG_TRY(arena_get_t(ctx, (base + ".off").c_str(), 2, &d_off));
+    FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
+    {
+        LaunchScope ls(ctx, "mask_flag_kernel");
+        hipLaunchKernelGGL(mask_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, mask, rows, st, flags, counts);
+    }
+    FG_TRY(check_launch(ctx, "mask_flag_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = h_off[1];
+    return FLOCKGPU_OK;
+}
+
+int take_column(flockgpu_ctx *ctx, const char *name, const DevColumn &src, const int32_t *rows, int64_t n, DevColumn *out) {
+    *out = src;
+    out->values = nullptr;
+    out->offsets = nullptr;
+    out->bytes = 0;
+    if (src.type == ColType::UTF8) {
+        flockgpu_utf8 u{}, s{src.offsets, static_cast<const uint8_t *>(src.values)};
+        int64_t nbytes = 0;
+        FG_TRY(gather_utf8(ctx, name, s, rows, n, &u, &nbytes));
+        out->values = u.data;
+        out->offsets = u.offsets;
+        out->bytes = nbytes;
+        return FLOCKGPU_OK;
+    }
+    void *p = nullptr;
+    FG_TRY(arena_get(ctx, (std::string(name) + ".val").c_str(), (size_t)std::max<int64_t>(n, 0) * col_width(src.type) + 16, &p));
+    out->values = p;
+    if (src.type == ColType::I32) return gather_i32(ctx, static_cast<const int32_t *>(src.values), rows, n, static_cast<int32_t *>(p));
+    return gather_i64(ctx, static_cast<const int64_t *>(src.values), rows, n, static_cast<int64_t *>(p));
+}
+
+int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const uint64_t *values, AggKind kind, int64_t rows,
+                   GroupResult *out) {
+    *out = GroupResult{};
+    const std::string base = name;
+    if (rows >= (int64_t(1) << 30)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^30 rows in a generic GROUP BY", name);
+    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
+    const int64_t slots = (int64_t)cap + 1;
+    int64_t *tk = nullptr;
+    uint64_t *ta = nullptr;
+    int32_t *tf = nullptr;
+    uint8_t *live = nullptr;
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
+    FG_TRY(arena_get_t(ctx, (base + ".ta").c_str(), (size_t)slots, &ta));
+    FG_TRY(arena_get_t(ctx, (base + ".tf").c_str(), (size_t)slots, &tf));
+    FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    RELOPS_LAUNCH(ctx, "group_init_kernel", group_init_kernel, slots, tk, ta, tf, slots);
+    if (rows > 0)
+        RELOPS_LAUNCH(ctx, "group_insert_kernel", group_insert_kernel, rows, keys, values, (int32_t)kind, rows, tk, ta, tf, cap, d_err);
+    RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
+    int32_t *slot_rows = nullptr;
+    int64_t n_groups = 0;
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
+    if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
+    int64_t *ok = nullptr;
+    uint64_t *oa = nullptr;
+    int32_t *of = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".ok").c_str(), (size_t)n_groups + 2, &ok));
+    FG_TRY(arena_get_t(ctx, (base + ".oa").c_str(), (size_t)n_groups + 2, &oa));
+    FG_TRY(arena_get_t(ctx, (base + ".of").c_str(), (size_t)n_groups + 4, &of));
+    FG_TRY(gather_i64(ctx, tk, slot_rows, n_groups, ok));
+    FG_TRY(gather_i64(ctx, reinterpret_cast<const int64_t *>(ta), slot_rows, n_groups, reinterpret_cast<int64_t *>(oa)));
+    FG_TRY(gather_i32(ctx, tf, slot_rows, n_groups, of));
+    out->n_groups = n_groups;
+    out->keys = ok;
+    out->agg = oa;
+    out->first_row = of;
+    return FLOCKGPU_OK;
+}
+
+int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, const flockgpu_utf8 &text, int64_t rows, int32_t **out_rows,
+                      int64_t *n_out) {
+    const std::string base = name;
+    if (rows >= (int64_t(1) << 30)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^30 rows in a generic DISTINCT", name);
+    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
+    int32_t *table = nullptr;
+    uint8_t *rep = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".table").c_str(), (size_t)cap, &table));
+    FG_TRY(arena_get_t(ctx, (base + ".rep").c_str(), (size_t)std::max<int64_t>(rows, 0) + 16, &rep));
+    RELOPS_LAUNCH(ctx, "fill_i32_kernel", fill_i32_kernel, (int64_t)cap, table, (int64_t)cap, (int32_t)-1);
+    if (rows > 0)
+        RELOPS_LAUNCH(ctx, "distinct_insert_kernel", distinct_insert_kernel, rows, key, text.offsets, text.data, rows, table, cap, rep);
+    return mask_to_rows(ctx, (base + ".sel").c_str(), rep, rows, out_rows, n_out);
+}
+
+int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out, int *any) {
+    *out = 0;
+    *any = rows > 0;
+    if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "MAX needs an integer column");
+    if (rows <= 0) return FLOCKGPU_OK;
+    const unsigned blocks = std::min<unsigned>(grid_for(ctx, rows), 1024);
+    int64_t *d = nullptr, *h = nullptr;
+    FG_TRY(arena_get_t(ctx, "relops.max", 1024, &d));
+    FG_TRY(pinned_get_t(ctx, "relops.max", 1024, &h));
+    {
+        LaunchScope ls(ctx, "max_kernel");
+        hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, (int32_t)col.type, rows, d);
+    }
+    FG_TRY(check_launch(ctx, "max_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool uns = col.type == ColType::U64;
+    int64_t m = h[0];
+    for (unsigned b = 1; b < blocks; ++b)
+        if (uns ? (uint64_t)h[b] > (uint64_t)m : h[b] > m) m = h[b];
+    *out = m;
+    return FLOCKGPU_OK;
+}
+
+int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
+               int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs) {
+    const std::string base = name;
+    *n_pairs = 0;
+    *left_rows = *right_rows = nullptr;
+    if (n_left >= (int64_t(1) << 30) || n_right >= (int64_t(1) << 31))
+        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relation too large for the generic join", name);
+    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(n_left, 1) * 2);
+    const int64_t slots = (int64_t)cap + 1;
+    int64_t *tk = nullptr;
+    int32_t *head = nullptr, *next = nullptr, *counts = nullptr, *h_tot = nullptr;
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
+    FG_TRY(arena_get_t(ctx, (base + ".head").c_str(), (size_t)slots, &head));
+    FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
+    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".tot").c_str(), 4, &h_tot));
+    int32_t *ol = nullptr, *orr = nullptr;
+    if (n_left <= 0 || n_right <= 0) {
+        FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
+        FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), 4, &orr));
+        *left_rows = ol;
+        *right_rows = orr;
+        return FLOCKGPU_OK;
+    }
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    RELOPS_LAUNCH(ctx, "join_init_kernel", join_init_kernel, slots, tk, head, slots);
+    RELOPS_LAUNCH(ctx, "join_build_kernel", join_build_kernel, n_left, left, n_left, tk, head, next, cap, d_err);
+    RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
+                  (int32_t *)nullptr);
+    FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
+    FG_HIP(ctx, hipMemcpyAsync(h_tot, counts + (n_right - 1), sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
+    const int64_t total = (int64_t)(uint32_t)h_tot[0];
+    if (total >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output exceeds 2^31 rows", name);
+    FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)total + 4, &ol));
+    FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)total + 4, &orr));
+    if (total > 0)
+        RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<true>, n_right, right, n_right, tk, head, next, cap, counts, ol, orr);
+    *left_rows = ol;
+    *right_rows = orr;
+    *n_pairs = total;
+    return FLOCKGPU_OK;
+}
+
+int partition_rows_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, int32_t n_parts, int32_t **out_rows,
+                         std::vector<int64_t> *part_offsets) {
+    const std::string base = name;
+    part_offsets->assign((size_t)n_parts + 1, 0);
+    *out_rows = nullptr;
+    int32_t *folded = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".fold").c_str(), (size_t)std::max<int64_t>(rows, 0) + 4, &folded));
+    if (rows > 0) RELOPS_LAUNCH(ctx, "fold_key_kernel", fold_key_kernel, rows, keys, rows, folded);
+    int64_t off[2] = {0, rows};
+    int32_t lo = 0, hi = 1;
+    const flockgpu_windows w{off, 1, &lo, &hi, 1};
+    flockgpu_partition_result r{};
+    FG_TRY(flockgpu_partition_by_key(ctx, folded, rows, &w, n_parts, &r));
+    // the partition result is overwritten by the next partition call on this ctx: keep a copy under this node's name
+    int32_t *keep = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".prow").c_str(), (size_t)std::max<int64_t>(r.rows, 0) + 4, &keep));
+    if (r.rows > 0) FG_HIP(ctx, hipMemcpyAsync(keep, r.row, sizeof(int32_t) * (size_t)r.rows, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int32_t p = 0; p <= n_parts; ++p) (*part_offsets)[p] = r.part_win_offsets[p];
+    *out_rows = keep;
+    return FLOCKGPU_OK;
+}
+
+}  // namespace flockgpu

@@ -1,0 +1,83 @@
+// Generic relational operators over device columns, used by the plan interpreter (plan.hip) for every plan node that
+// is not covered by one of the fused NEXMark pipelines: the STAGE plans either side of a `RepartitionExec Hash`
+// (flock/src/distributed_plan/planner.rs:152-171, playground/.../nexmark/q{3,5,8}.dag; split rule
+// flock/src/distributed_plan/stage.rs:269-367).  These run on the small, already filtered / aggregated relations of a
+// stage, so they are written for generality (one lane per row, 64-bit normalised keys), not for the HBM roofline; the
+// raw-row passes keep their fused kernels (q2 / q3 / q5 / q8 .hip).
+//
+// Semantics restated from upstream DataFusion ~6.x (not readable in the reference tree):
+//   FilterExec keeps input order; HashAggregateExec groups compare by value (Utf8 bytewise); COUNT -> UInt64;
+//   MAX ignores NULLs, an empty input gives NULL; inner HashJoinExec emits every matching pair, NULL keys never match.
+#pragma once
+#include <string>
+
+#include "gather.hpp"
+
+namespace flockgpu {
+
+enum class ColType : int32_t { I32 = 0, I64 = 1, U64 = 2, F64 = 3, UTF8 = 4 };
+inline size_t col_width(ColType t) { return t == ColType::I32 ? 4 : 8; }
+
+struct DevColumn {
+    ColType type = ColType::I32;
+    bool is_ts = false;     // Timestamp(Millisecond): Int64 storage, exported as "tsm:"
+    bool nullable = false;  // schema flag only
+    bool all_null = false;  // the single row of a global aggregate over no input (MAX -> NULL)
+    const void *values = nullptr;      // fixed width values, or Utf8 bytes
+    const int32_t *offsets = nullptr;  // Utf8 only, rows + 1 entries
+    int64_t bytes = 0;                 // Utf8 only
+};
+
+enum class CmpOp : int32_t { EQ = 0, NE = 1, LT = 2, LE = 3, GT = 4, GE = 5 };
+enum class AggKind : int32_t { NONE = 0, SUM = 1, MAX = 2 };
+
+// keys of an integer column as int64 (I32 sign-extended; I64 / U64 bit pattern): out[rows]
+int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);
+
+// ---- predicates: one byte per row (1 = true)
+int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, int64_t lit, uint8_t *mask);
+int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask);
+int mask_cmp_col(flockgpu_ctx *ctx, const DevColumn &a, const DevColumn &b, int64_t rows, CmpOp op, uint8_t *mask);
+int mask_utf8_eq(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, const std::string &lit, bool negate, uint8_t *mask);
+int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t rows, bool is_and, uint8_t *out);
+// rows with mask != 0, in order.  *out_rows: ctx-owned (arena key `name`), n_out through ONE synchronisation.
+int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64_t rows, int32_t **out_rows, int64_t *n_out);
+
+// ---- take
+int take_column(flockgpu_ctx *ctx, const char *name, const DevColumn &src, const int32_t *rows, int64_t n, DevColumn *out);
+
+// ---- GROUP BY one integer key (as int64): distinct keys + SUM / MAX of `values` (null: SUM counts rows) per key.
+// Outputs are ctx-owned: keys[n_groups], agg[n_groups], first_row[n_groups] (smallest input row of the group).
+struct GroupResult {
+    int64_t n_groups = 0;
+    int64_t *keys = nullptr;
+    uint64_t *agg = nullptr;
+    int32_t *first_row = nullptr;
+};
+int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const uint64_t *values, AggKind kind, int64_t rows,
+                   GroupResult *out);
+// GROUP BY (int32 key, Utf8 value) without aggregates = DISTINCT over both columns: the first row of every distinct pair,
+// ascending.
+int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, const flockgpu_utf8 &text, int64_t rows,
+                      int32_t **out_rows, int64_t *n_out);
+// MAX of an integer column (signed, or unsigned for UInt64) as its 64-bit pattern, on the host; *any = 0 when there is no row.
+int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out, int *any);
+
+// ---- inner equi-join on one 64-bit key: every (left_row, right_row) pair with equal keys, ordered by right row
+// (the probe side), then by left row.  Builds on the left (DataFusion's build side).
+int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
+               int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
+
+// ---- hash partition: rows grouped by destination (input order kept): dest = (fmix32(fold(key)) * n) >> 32, the
+// mix of flockgpu_partition_by_key.  part_offsets: host, n_parts + 1.
+int partition_rows_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, int32_t n_parts, int32_t **out_rows,
+                         std::vector<int64_t> *part_offsets);
+
+// u32 -> u64 (COUNT partial states are UInt64 in the reference's schemas)
+int widen_u32_to_u64(flockgpu_ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out);
+// int64 -> int32 (group keys go back to the type of their column)
+int narrow_i64_to_i32(flockgpu_ctx *ctx, const int64_t *in, int64_t n, int32_t *out);
+// data[i] += delta for i in [0, n): Utf8 offsets of an appended batch rebased onto the column's byte cursor
+int add_i32(flockgpu_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
+
+}  // namespace flockgpu

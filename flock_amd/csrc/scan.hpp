@@ -53,8 +53,11 @@ inline int build_seg_tiles(flockgpu_ctx *ctx, const char *name, const int64_t *s
                            int32_t n_seg, int32_t tile_rows, SegTiles *out) {
     std::string k_off = std::string(name) + ".seg_off", k_tf = std::string(name) + ".tile_first",
                 k_td = std::string(name) + ".tile_desc";
-    std::vector<int64_t> &cached = ctx->host_i64[k_off];  // begin/end pairs + {tile_rows, n_tiles} of the last upload
-    bool same = cached.size() == size_t(2) * n_seg + 2 && cached[size_t(2) * n_seg] == tile_rows;
+    // begin/end pairs + {tile_rows, n_tiles, the three device buffers} of the last upload: the schedule on the device is
+    // reused only while it sits in the very buffers it was uploaded to (an arena entry can be freed and re-created --
+    // flockgpu_plan_destroy does -- or regrown in between)
+    std::vector<int64_t> &cached = ctx->host_i64[k_off];
+    bool same = cached.size() == size_t(2) * n_seg + 5 && cached[size_t(2) * n_seg] == tile_rows;
     for (int32_t s = 0; same && s < n_seg; ++s) same = cached[2 * s] == seg_begin[s] && cached[2 * s + 1] == seg_end[s];
     int64_t tiles = 0;
     if (same) {
@@ -64,6 +67,8 @@ inline int build_seg_tiles(flockgpu_ctx *ctx, const char *name, const int64_t *s
             if (seg_end[s] > seg_begin[s]) tiles += div_up(seg_end[s] - (seg_begin[s] & ~int64_t(3)), tile_rows);
         if (tiles > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
     }
+    const std::vector<int64_t> before = cached;
+    cached.clear();  // invalid until this call has the buffers (an allocation below may fail half-way) and the upload is queued
     int64_t *d_off = nullptr;
     int32_t *d_tf = nullptr;
     TileRange *d_td = nullptr;
@@ -75,8 +80,13 @@ inline int build_seg_tiles(flockgpu_ctx *ctx, const char *name, const int64_t *s
     out->tiles = d_td;
     out->n_seg = n_seg;
     out->n_tiles = (int32_t)tiles;
-    if (same) return FLOCKGPU_OK;
-    cached.clear();  // invalid until the upload below is queued
+    const int64_t where[3] = {(int64_t)reinterpret_cast<uintptr_t>(d_off), (int64_t)reinterpret_cast<uintptr_t>(d_tf),
+                              (int64_t)reinterpret_cast<uintptr_t>(d_td)};
+    if (same && before[size_t(2) * n_seg + 2] == where[0] && before[size_t(2) * n_seg + 3] == where[1] &&
+        before[size_t(2) * n_seg + 4] == where[2]) {
+        cached = before;
+        return FLOCKGPU_OK;
+    }
     int64_t *h_off = nullptr;
     int32_t *h_tf = nullptr;
     TileRange *h_td = nullptr;
@@ -101,6 +111,7 @@ inline int build_seg_tiles(flockgpu_ctx *ctx, const char *name, const int64_t *s
     cached.assign(h_off, h_off + size_t(2) * n_seg);
     cached.push_back(tile_rows);
     cached.push_back(tiles);
+    cached.insert(cached.end(), where, where + 3);
     return FLOCKGPU_OK;
 }
 

@@ -8,7 +8,8 @@ Same surface and argument meaning as the reference:
     parts = ctx.execute_partitioned()   # -> [plan][partition][batch]           (context.rs:197-216)
     ctx.clean_data_sources()            #                                       (context.rs:227-254)
 
-`collect(ctx, streams)` restates `actor::collect` (flock-function/src/aws/actor.rs:54-79).  Plans are the
+`collect(ctx, streams)` restates `actor::collect` (flock-function/src/aws/actor.rs:54-79); `explain(plan)` shows the
+operator tree the engine built and what executes each node.  Plans are the
 serde_json text of the reference's physical plans; data are pyarrow RecordBatches handed over through the
 Arrow C Data Interface (what arrow-rs would export as FFI_ArrowArray).  A plan the engine does not recognise
 raises `FlockGpuError` with status FLOCKGPU_ERR_UNSUPPORTED (the reference host would keep DataFusion for it).
@@ -41,7 +42,10 @@ class _Plan:
         self.h = h
         self.query = self._lib.flockgpu_plan_query(h)
         self.inputs = [self._lib.flockgpu_plan_input_name(h, i).decode() for i in range(self._lib.flockgpu_plan_num_inputs(h))]
-        self.tree = json.loads(text)
+        self.description = self._lib.flockgpu_plan_description(h).decode()
+        self.is_shuffling = bool(self._lib.flockgpu_plan_is_shuffling(h))
+        self.partitions = self._lib.flockgpu_plan_output_partitions(h)
+        self._fed = []   # the library borrows fed buffers until execute / reset returns (flockgpu_plan.h)
 
     def close(self):
         if self.h:
@@ -66,6 +70,7 @@ class _Plan:
         for b, ab in zip(batches, abufs):
             b._export_to_c(C.addressof(ab))
         ptrs = (C.c_void_p * len(batches))(*[C.addressof(ab) for ab in abufs])
+        self._fed.append(batches)
         try:
             rc = self._lib.flockgpu_plan_feed(self.h, i, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
         finally:
@@ -82,8 +87,20 @@ class _Plan:
         self.gpu._check(self._lib.flockgpu_plan_execute(self.h, C.cast(sbuf, C.c_void_p), C.cast(abuf, C.c_void_p)))
         return pa.RecordBatch._import_from_c(C.addressof(abuf), C.addressof(sbuf))
 
+    def execute_partitioned(self):
+        """[partition] -> RecordBatch: the plan's hash partitions when it is a shuffling stage, else one batch."""
+        pa = _pa()
+        cap = max(self.partitions, 1)
+        sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        abufs = C.create_string_buffer(_ARROW_ARRAY_BYTES * cap)
+        n = C.c_int(0)
+        self.gpu._check(self._lib.flockgpu_plan_execute_partitioned(self.h, C.cast(sbuf, C.c_void_p), C.cast(abufs, C.c_void_p), cap, C.byref(n)))
+        schema = pa.Schema._import_from_c(C.addressof(sbuf))
+        return [pa.RecordBatch._import_from_c(C.addressof(abufs) + p * _ARROW_ARRAY_BYTES, schema) for p in range(n.value)]
+
     def reset(self):
         self.gpu._check(self._lib.flockgpu_plan_reset(self.h))
+        self._fed = []
 
 
 class ExecutionContext:
@@ -120,9 +137,9 @@ class ExecutionContext:
     def execute(self):
         return [[plan.execute()] for plan in self.plans]
 
-    # -- context.rs:197-216: a GPU stage is one output partition (hash partition placement is unobservable, section 8 a6)
+    # -- context.rs:197-216: [plan][partition][batch]; a shuffling stage returns its P hash partitions
     def execute_partitioned(self):
-        return [[[plan.execute()]] for plan in self.plans]
+        return [[[b] for b in plan.execute_partitioned()] for plan in self.plans]
 
     # -- context.rs:227-254
     def clean_data_sources(self):
@@ -131,10 +148,8 @@ class ExecutionContext:
 
     # -- context.rs:328-337
     def is_shuffling(self) -> bool:
-        def shuffling(t):
-            return (t.get("execution_plan") == "coalesce_batches_exec"
-                    and isinstance(t.get("input"), dict) and t["input"].get("execution_plan") == "repartition_exec")
-        return bool(self.plans) and all(shuffling(p.tree) for p in self.plans)
+        """Every plan ends in `CoalesceBatchesExec <- RepartitionExec Hash` (a RoundRobin repartition shuffles nothing)."""
+        return bool(self.plans) and all(p.is_shuffling for p in self.plans)
 
     def schema(self, index: int):
         """Output schema of plan `index` (context.rs:222-224): taken from an execution over the current inputs."""
@@ -145,6 +160,17 @@ class ExecutionContext:
             p.close()
         if self._owns_gpu:
             self._gpu.close()
+
+
+def explain(plan: Union[str, dict]) -> str:
+    """Host-only: the operator tree of `plan` with derived schemas and the executor of every node (no GPU needed)."""
+    raw = (plan if isinstance(plan, str) else json.dumps(plan)).encode()
+    buf = C.create_string_buffer(1 << 16)
+    rc = _ffi.load().flockgpu_plan_explain(raw, len(raw), buf, len(buf))
+    text = buf.value.decode()
+    if rc != 0:
+        raise FlockGpuError(rc, text)
+    return text
 
 
 def collect(ctx: ExecutionContext, streams):

@@ -1,0 +1,168 @@
+"""Query-stage splitting of a physical plan, on its serde_json form -- the host-side step that turns one plan into the
+stage plans the distributed mode ships to its functions.
+
+`build_query_dag` restates `flock/src/distributed_plan/stage.rs:269-367` (`build_query_dag_from_serde_json`, reached
+through `DistributedPlanner::plan_query_stages`, flock/src/distributed_plan/planner.rs:48-63): walk down the `input` chain
+from the root;
+  * `hash_aggregate_exec` in mode Final / FinalPartitioned: everything above and including it becomes a stage whose new
+    leaf is an empty `memory_exec` with the schema of the cut-off input; the walk continues on the cut-off input;
+  * `hash_join_exec`: the current plan (join with two empty `memory_exec` leaves) becomes a stage, its `left` and `right`
+    inputs become the two plans of the stage below -- and the walk stops there (stage.rs:335-336);
+  * `sort_exec`: like a final aggregate;
+  * everything else: descend.
+A stage plan whose root is `coalesce_batches_exec <- repartition_exec Hash` is a shuffling stage
+(`ExecutionContext::is_shuffling`, flock/src/runtime/context.rs:328-337): the function runs `execute_partitioned` and sends
+partition j to member j of the next function group (flock-function/src/aws/actor.rs:60-66,425-543).
+
+`split_at_repartitions` is the finer rule of the playground's ShuffleWriter plans
+(playground/src/distributed_plan/nexmark/q{3,5,8}.dag): a cut at EVERY hash repartition and at every
+CoalescePartitions (gather), so that no stage repartitions in its middle and every stage can run once per partition.
+
+Both return a list of `Stage`s, leaves first; `Stage.inputs[i]` names the stage that feeds the i-th `memory_exec` leaf
+(in the plan's leaf order, the order `feed_data_sources` walks: breadth-first), or None for a leaf fed by a base relation.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+
+@dataclass
+class Stage:
+    plan: dict
+    inputs: List[Optional[int]] = field(default_factory=list)   # per memory_exec leaf (BFS order): producing stage or None
+
+    @property
+    def is_shuffling(self) -> bool:
+        t = self.plan
+        return (t.get("execution_plan") == "coalesce_batches_exec" and isinstance(t.get("input"), dict)
+                and t["input"].get("execution_plan") == "repartition_exec" and "Hash" in t["input"].get("partitioning", {}))
+
+
+def node_schema(n: dict) -> dict:
+    """Output schema of a plan node (the `schema()` the splitter asks DataFusion for, stage.rs:289,321-324)."""
+    kind = n.get("execution_plan")
+    if kind == "memory_exec":
+        fields = n["schema"]["fields"]
+        proj = n.get("projection")
+        if proj and all(isinstance(i, int) and 0 <= i < len(fields) for i in proj):
+            fields = [fields[i] for i in proj]
+        return {"fields": copy.deepcopy(fields), "metadata": {}}
+    if kind in ("projection_exec", "hash_aggregate_exec", "hash_join_exec") and "schema" in n:
+        return copy.deepcopy(n["schema"])
+    if "input" in n:
+        return node_schema(n["input"])
+    raise ValueError(f"no schema for plan node {kind!r}")
+
+
+def _empty_memory(schema: dict) -> dict:
+    """`MemoryExec::try_new(&[], schema, None)` serialised (stage.rs:287-291)."""
+    return {"execution_plan": "memory_exec", "schema": schema, "projection": None}
+
+
+def leaves_bfs(plan: dict) -> List[dict]:
+    """memory_exec leaves in the breadth-first order feed_data_sources visits them (context.rs:262-300)."""
+    out, queue = [], [plan]
+    while queue:
+        n = queue.pop(0)
+        kids = [n[k] for k in ("input", "left", "right") if isinstance(n.get(k), dict)]
+        if n.get("execution_plan") == "memory_exec":
+            out.append(n)
+        queue.extend(kids)
+    return out
+
+
+def build_query_dag(plan: dict) -> List[Stage]:
+    """stage.rs:269-367 on the JSON tree.  Returns stages leaves-first; the last one is the plan's root stage."""
+    root = copy.deepcopy(plan)
+    stages_top_down: List[tuple] = []     # (plan, marker leaf objects in it that the NEXT entries feed)
+    node = root
+    while True:
+        kind = node.get("execution_plan")
+        if kind == "hash_aggregate_exec" and node.get("mode") in ("Final", "FinalPartitioned") or kind == "sort_exec":
+            below = node["input"]
+            leaf = _empty_memory(node_schema(below))
+            node["input"] = leaf
+            stages_top_down.append((root, [leaf], 1))
+            root = node = below
+            continue
+        if kind == "hash_aggregate_exec" and node.get("mode") != "Partial":
+            raise ValueError("Failed to parse aggregate mode for HashAggregateExec")     # stage.rs:300-305
+        if kind == "hash_join_exec":
+            left, right = node["left"], node["right"]
+            ll, rl = _empty_memory(node_schema(left)), _empty_memory(node_schema(right))
+            node["left"], node["right"] = ll, rl
+            stages_top_down.append((root, [ll, rl], 2))
+            stages_top_down.append((left, [], 0))
+            stages_top_down.append((right, [], 0))
+            root = None
+            break
+        if not isinstance(node.get("input"), dict):
+            break
+        node = node["input"]
+    if root is not None:
+        stages_top_down.append((root, [], 0))
+    # leaves first
+    order = list(reversed(range(len(stages_top_down))))
+    index_of = {top: i for i, top in enumerate(order)}
+    stages: List[Stage] = []
+    for top in order:
+        plan_t, markers, n_children = stages_top_down[top]
+        feeders = [index_of[top + 1 + k] for k in range(n_children)]
+        ins = []
+        for lf in leaves_bfs(plan_t):
+            hit = [feeders[k] for k, m in enumerate(markers) if m is lf]
+            ins.append(hit[0] if hit else None)
+        stages.append(Stage(plan_t, ins))
+    return stages
+
+
+def split_at_repartitions(plan: dict) -> List[Stage]:
+    """A cut at every `repartition_exec` Hash (the playground's ShuffleWriter stages, q3.dag / q5.dag / q8.dag): the
+    sub-tree `coalesce_batches_exec? <- repartition_exec Hash <- X` becomes its own shuffling stage and is replaced by an
+    empty memory_exec of its schema.  A Hash repartition directly under the plan's root stays where it is."""
+    stages: List[Stage] = []
+
+    def is_hash(n):
+        return isinstance(n, dict) and n.get("execution_plan") == "repartition_exec" and "Hash" in n.get("partitioning", {})
+
+    def is_gather(n):   # CoalescePartitionsExec / MergeExec: every partition of the input meets in ONE consumer
+        return isinstance(n, dict) and n.get("execution_plan") in ("coalesce_partitions_exec", "merge_exec")
+
+    def cut(n: dict, is_root: bool) -> dict:
+        """Returns `n` with every shuffling sub-tree below it replaced by a marker leaf."""
+        n = dict(n)
+        for key in ("input", "left", "right"):
+            child = n.get(key)
+            if not isinstance(child, dict):
+                continue
+            sub = child
+            wrapped = sub.get("execution_plan") == "coalesce_batches_exec" and is_hash(sub.get("input"))
+            if is_gather(sub):
+                # the input of a gather runs once per partition and is not shuffled again (q5.dag: `ShuffleWriterExec: None`
+                # above the Partial MAX); the gather itself stays in the consumer, which then sees every partition's rows
+                idx = emit(cut(sub["input"], True))
+                leaf = _empty_memory(node_schema(sub["input"]))
+                leaf["__stage__"] = idx
+                n[key] = dict(sub, input=leaf)
+            elif (wrapped or is_hash(sub)) and not (is_root and n.get("execution_plan") == "coalesce_batches_exec"):
+                stage_plan = cut(sub, True) if wrapped else {"execution_plan": "coalesce_batches_exec", "input": cut(sub, True),
+                                                              "target_batch_size": 4096}
+                idx = emit(stage_plan)
+                leaf = _empty_memory(node_schema(sub))
+                leaf["__stage__"] = idx
+                n[key] = leaf
+            else:
+                n[key] = cut(child, is_root and n.get("execution_plan") == "coalesce_batches_exec")
+        return n
+
+    def emit(stage_plan: dict) -> int:
+        ins = []
+        for lf in leaves_bfs(stage_plan):
+            ins.append(lf.pop("__stage__", None))
+        stages.append(Stage(stage_plan, ins))
+        return len(stages) - 1
+
+    emit(cut(copy.deepcopy(plan), True))
+    return stages

@@ -1,8 +1,9 @@
 /* flockgpu_plan.h -- plan-level C ABI: the drop-in for one `actor::collect` call
  * (flock-function/src/aws/actor.rs:54-79), i.e. for
- *   ExecutionContext::feed_data_sources   flock/src/runtime/context.rs:257-325
- *   ExecutionContext::execute             flock/src/runtime/context.rs:172-191
- *   ExecutionContext::clean_data_sources  flock/src/runtime/context.rs:227-254
+ *   ExecutionContext::feed_data_sources    flock/src/runtime/context.rs:257-325
+ *   ExecutionContext::execute              flock/src/runtime/context.rs:172-191
+ *   ExecutionContext::execute_partitioned  flock/src/runtime/context.rs:197-216  (chosen by is_shuffling, :328-337)
+ *   ExecutionContext::clean_data_sources   flock/src/runtime/context.rs:227-254
  * over ONE physical plan of `CloudExecutionPlan.execution_plans` (flock/src/runtime/plan.rs:35-43).
  *
  * Hand-off formats are the reference's own:
@@ -12,16 +13,28 @@
  *           "binary_expr" | "literal" | "cast_expr" | "try_cast_expr"; fixtures under flock/src/tests/data/plan/)
  *   data  = Arrow RecordBatches through the Arrow C Data Interface (what arrow-rs exports as
  *           FFI_ArrowArray / FFI_ArrowSchema): one struct array per RecordBatch.
- * The engine recognises the plan shapes of NEXMark q1, q2, q3, q5 and q8, of the "next"
- * queries q7 and q13 (section 8(f): q13's side input is fed as the plan's second relation), and
- * returns FLOCKGPU_ERR_UNSUPPORTED for anything else, so the host can keep its DataFusion path for those.
- * Transparent nodes (RepartitionExec, CoalesceBatchesExec, CoalescePartitions/MergeExec, renaming
- * ProjectionExec) and the Partial/Final split of HashAggregateExec have no effect on the row multiset and are
- * folded away.
  *
- * Input batches are BORROWED for the duration of flockgpu_plan_feed (never released, never written); the
- * output batch is owned by the caller and freed through its Arrow `release` callback.  Host buffers cross
- * PCIe here; device-resident callers use the flockgpu_q*_ entry points of flockgpu.h instead.
+ * What runs: the plan is parsed into an operator tree (scan, filter, projection, hash aggregate, inner hash join, hash
+ * repartition; Int32 / Int64 / UInt64 / Float64 / Utf8 / Timestamp(ms) columns).  Sub-trees that are one of the NEXMark
+ * pipelines -- q1, q2, q3, q5, q7, q8, q13 as whole-query plans, and the Partial COUNT of q5's stage 0 -- run as the fused
+ * kernels of flockgpu.h; every other supported node runs on generic device operators, which is how the STAGE plans of
+ * the distributed mode execute: the plans either side of a `RepartitionExec Hash` (flock/src/distributed_plan/planner.rs:
+ * 152-171, playground/src/distributed_plan/nexmark/q{3,5,8}.dag, split rule flock/src/distributed_plan/stage.rs:269-367),
+ * e.g. q3's filter -> Hash([seller]) stage and its join stage, q5's Partial / FinalPartitioned COUNT, MAX and join
+ * stages, q8's DISTINCT stages.  A plan whose ROOT is a hash repartition is a shuffling stage (context.rs:328-337):
+ * flockgpu_plan_execute_partitioned returns its P hash partitions, partition j going to ring member j
+ * (flock-function/src/aws/actor.rs:425-543).  Transparent nodes (RepartitionExec RoundRobinBatch, CoalesceBatchesExec,
+ * CoalescePartitions / MergeExec) change neither the row multiset nor the schema and are folded away.
+ * Anything else -- sort / limit, other aggregates, other types, outer joins -- returns FLOCKGPU_ERR_UNSUPPORTED so the
+ * host keeps its DataFusion path for that plan.  The root projection is honoured: output columns come back in the
+ * plan's order under the plan's names.
+ *
+ * Memory: input batches are BORROWED from flockgpu_plan_feed until the next flockgpu_plan_execute* or flockgpu_plan_reset
+ * returns (the reference's MemoryExec owns them for exactly that span), never released, never written.  Buffers in
+ * pinned host memory (flockgpu_host_alloc / flockgpu_host_register) go to the DMA engine as they are; pageable buffers are
+ * staged through the plan's pinned ring, chunk by chunk, while the previous chunk is in flight.  Feed never waits for
+ * the device.  Output batches live in pinned host memory owned by the caller and are freed through their Arrow
+ * `release` callback; one execute = one device synchronisation.
  */
 #ifndef FLOCKGPU_PLAN_H
 #define FLOCKGPU_PLAN_H
@@ -64,33 +77,53 @@ struct ArrowArray {
 
 typedef struct flockgpu_plan flockgpu_plan;
 
-/* Parses the plan JSON and matches it against the supported shapes. */
+/* Parses the plan JSON and builds the operator tree.  FLOCKGPU_ERR_PLAN: not JSON; FLOCKGPU_ERR_UNSUPPORTED: a node,
+ * expression or type the engine does not execute (flockgpu_last_error names it). */
 int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out);
 void flockgpu_plan_destroy(flockgpu_plan *plan);
-/* Host-only: parses + matches a plan without a device context.  *query receives 1/2/3/5/8; returns
- * FLOCKGPU_OK, FLOCKGPU_ERR_PLAN (bad JSON) or FLOCKGPU_ERR_UNSUPPORTED (not one of the recognised shapes). */
+/* Host-only: parses a plan without a device context.  *query receives the NEXMark query number (1, 2, 3, 5, 7, 8, 13)
+ * when the whole plan is one fused pipeline, 0 for any other executable plan (stage plans, generic operator trees). */
 int flockgpu_plan_recognise(const char *plan_json, size_t len, int *query);
+/* Host-only: the operator tree with derived schemas and, per node, what executes it (a fused pipeline or the generic
+ * operators), as text.  Returns the status flockgpu_plan_create would; on UNSUPPORTED the text says why. */
+int flockgpu_plan_explain(const char *plan_json, size_t len, char *out, size_t capacity);
 
-/* NEXMark query number the plan was recognised as (1, 2, 3, 5, 7, 8, 13). */
 int flockgpu_plan_query(const flockgpu_plan *plan);
+const char *flockgpu_plan_description(const flockgpu_plan *plan); /* the text of flockgpu_plan_explain */
 /* Leaves of the plan (MemoryExec), in the order feed expects them; the name is the relation whose columns the
- * leaf scans ("bid", "auction", "person"), found the way feed_data_sources does: by column-name set
- * (compare_schema, context.rs:402-416). */
+ * leaf scans ("bid", "auction", "person", "side_input", or "" when the columns name none of them), found the way
+ * feed_data_sources does: by column-name set (compare_schema, context.rs:402-416). */
 int flockgpu_plan_num_inputs(const flockgpu_plan *plan);
 const char *flockgpu_plan_input_name(const flockgpu_plan *plan, int input);
-/* 1 when every column name the leaf `input` needs is present in `schema` (a struct schema). */
+/* 1 when every column the plan READS from leaf `input` is present in `schema` (a struct schema). */
 int flockgpu_plan_input_matches(const flockgpu_plan *plan, int input, const struct ArrowSchema *schema);
+/* is_shuffling (context.rs:328-337): 1 when the plan's root is a hash repartition; its partition count (else 1). */
+int flockgpu_plan_is_shuffling(const flockgpu_plan *plan);
+int flockgpu_plan_output_partitions(const flockgpu_plan *plan);
 
-/* feed_data_sources for one leaf: all batches of all partitions of the relation, flattened.  May be called once
- * per leaf; an unfed leaf is an empty relation (context.rs:305-314). */
+/* feed_data_sources for one leaf: all batches of all partitions of the relation, flattened.  May be called more than
+ * once per leaf (rows append); an unfed leaf is an empty relation (context.rs:305-314).  Only the columns the plan reads
+ * are copied.  A rejected feed (missing column, wrong type, NULLs) leaves the leaf unchanged. */
 int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema,
                        const struct ArrowArray *const *batches, int n_batches);
 
-/* execute(): runs the fused pipeline on everything fed so far as ONE window and exports one RecordBatch. */
+/* execute(): runs the plan on everything fed so far as ONE window and exports one RecordBatch. */
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch);
+/* execute_partitioned(): `out_batches` has room for `capacity` record batches; *n_partitions of them are filled: the
+ * plan's hash partitions when it is a shuffling stage (rows of equal key in one partition), else one batch.  The
+ * batches share one pinned block; each is released on its own. */
+int flockgpu_plan_execute_partitioned(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batches,
+                                      int capacity, int *n_partitions);
 
 /* clean_data_sources(): drops the inputs, keeps device arenas and hash-table sizing for the next invocation. */
 int flockgpu_plan_reset(flockgpu_plan *plan);
+
+/* Pinned host memory for the host's Arrow buffers ("Arrow buffers pinned and hipMemcpyAsync'd"): allocate buffers
+ * with flockgpu_host_alloc, or register existing ones for as long as they are fed. */
+int flockgpu_host_alloc(size_t bytes, void **out);
+int flockgpu_host_free(void *ptr);
+int flockgpu_host_register(void *ptr, size_t bytes);
+int flockgpu_host_unregister(void *ptr);
 
 #ifdef __cplusplus
 }

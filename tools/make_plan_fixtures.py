@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/plans/q{1,2,3,5,7,8}.json: the physical plans of the five NEXMark target queries (and q7) in the
+"""Writes tests/golden/plans/*.json: the physical plans of the five NEXMark target queries (and q7, q13) in the
 serde_json dialect of the reference's DataFusion fork.
 
 The fork's serialiser cannot be run here (no Rust toolchain), so the plans are AUTHORED from
@@ -199,11 +199,18 @@ def main():
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
-    # the three reference fixtures' shapes that are NOT one of the five queries must be rejected (UNSUPPORTED):
-    # a copy of their *shape* (not of the reference files) is authored here for the negative test
-    unsupported = proj(rr(memory([field("c1", "Int64")], [0], None)), [(col("c1", 0), "c1")], [field("c1", "Int64")])
-    with open(os.path.join(OUT, "unsupported_simple_select.json"), "w") as f:
-        json.dump(unsupported, f, indent=1, sort_keys=True)
+    # shapes of the reference's own fixtures (flock/src/tests/data/plan/simple_select.json, join.json), authored here in the
+    # same dialect (not copies of the reference files): a pure projection of an Int64 column -- executable by the generic
+    # operators -- and a plan that ends in sort + limit, which the engine must hand back as UNSUPPORTED
+    simple = proj(rr(memory([field("c1", "Int64")], [0], None)), [(col("c1", 0), "c1")], [field("c1", "Int64")])
+    with open(os.path.join(OUT, "simple_select.json"), "w") as f:
+        json.dump(simple, f, indent=1, sort_keys=True)
+        f.write("\n")
+    sort_limit = {"execution_plan": "global_limit_exec", "limit": 3,
+                  "input": {"execution_plan": "sort_exec", "input": simple,
+                            "expr": [{"expr": col("c1", 0), "options": {"descending": False, "nulls_first": False}}]}}
+    with open(os.path.join(OUT, "unsupported_sort_limit.json"), "w") as f:
+        json.dump(sort_limit, f, indent=1, sort_keys=True)
         f.write("\n")
     print("wrote", sorted(os.listdir(OUT)))
 
