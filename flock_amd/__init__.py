@@ -6,9 +6,9 @@ No CPU fallback exists: without libflockgpu.so (built by `python -m flock_amd.bu
 operator call raises.
 """
 from ._ffi import FlockGpuError, LIB_PATH, load  # noqa: F401
-from .engine import (Auctions, Bids, DeviceUtf8, GpuContext, Persons, WindowSchedule)  # noqa: F401
+from .engine import (Auctions, Bids, Comm, DeviceUtf8, GpuContext, Persons, WindowSchedule)  # noqa: F401
 from .nexmark import (NEXMarkSource, NEXMarkStream, Window, query_window, run_query, synthetic_side_input,  # noqa: F401
                       window_epochs)
 
-__all__ = ["FlockGpuError", "GpuContext", "Bids", "Auctions", "Persons", "DeviceUtf8", "WindowSchedule",
+__all__ = ["FlockGpuError", "GpuContext", "Bids", "Auctions", "Persons", "DeviceUtf8", "WindowSchedule", "Comm",
            "NEXMarkSource", "NEXMarkStream", "Window", "query_window", "run_query", "window_epochs", "load", "LIB_PATH"]

@@ -209,6 +209,20 @@ SYMBOLS = {
     "flockgpu_plan_description": (C.c_char_p, [_vp]),
     "flockgpu_plan_is_shuffling": (_i, [_vp]),
     "flockgpu_plan_output_partitions": (_i, [_vp]),
+    # include/flockgpu_comm.h
+    "flockgpu_comm_unique_id": (_i, [C.c_char_p]),
+    "flockgpu_comm_init_rank": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "flockgpu_comm_init_local": (_i, [_i, C.POINTER(_vp)]),
+    "flockgpu_comm_destroy": (None, [_vp]),
+    "flockgpu_comm_rank": (_i, [_vp]),
+    "flockgpu_comm_size": (_i, [_vp]),
+    "flockgpu_comm_transport": (C.c_char_p, [_vp]),
+    "flockgpu_comm_barrier": (_i, [_vp, _vp]),
+    "flockgpu_q5_hot_items_exchange": (_i, [_vp, _vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
+    "flockgpu_q3_join_exchange": (_i, [_vp, _vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),
+                                       C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),
+    "flockgpu_q8_join_exchange": (_i, [_vp, _vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
+                                       C.POINTER(Windows), C.POINTER(Q8Result)]),
     "flockgpu_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
     "flockgpu_host_free": (_i, [_vp]),
     "flockgpu_host_register": (_i, [_vp, C.c_size_t]),

@@ -1,0 +1,637 @@
+// Multi-GPU entry (include/flockgpu_comm.h): the RepartitionExec Hash([key], n) of the reference's distributed plans as an
+// in-library all-to-all.  Two transports behind one interface:
+//   rccl  : one process per GPU; ncclSend / ncclRecv pairs inside ncclGroupStart / End on the ctx stream (xGMI is
+//           point-to-point: one message per peer per column buffer, never one per window), counts exchanged the same way
+//   local : n ranks = n host threads of one process; buffers move with device-to-device copies on each rank's stream,
+//           the ranks meet at host barriers (also how the exchange logic is exercised on a one-GPU box)
+// Everything above the transport -- partition, send order, counts, regroup, the q3 / q5 / q8 drivers -- is shared.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+
+#include "../../include/flockgpu_comm.h"
+#include "relops.hpp"
+
+using namespace flockgpu;
+
+namespace {
+
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send_ptr;            // per rank: base of the buffer being exchanged
+    std::vector<const int64_t *> send_off;         // per rank: n + 1 byte offsets of its per-destination runs
+    std::vector<const int64_t *> counts;           // per rank: host array of n * m values
+    std::vector<uint64_t *> reduce;                // per rank: host array being max-reduced
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++waiting == n) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+constexpr int64_t kMaxPeerBytes = int64_t(1) << 30;  // RCCL transfers above 2 GiB per peer arrived corrupted (round 1): stay well below
+
+}  // namespace
+
+struct flockgpu_comm {
+    int n = 1, rank = 0;
+    bool is_rccl = false;
+    ncclComm_t nccl = nullptr;
+    std::shared_ptr<LocalGroup> local;
+};
+
+namespace {
+
+#define FG_NCCL(ctx, expr)                                                                                               \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                                        \
+        if (r_ != ncclSuccess)                                                                                           \
+            return fail((ctx), FLOCKGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// recv[s * m + j] = what rank s sent to this rank = its send[me * m + j].  Host arrays; synchronises.
+int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, int m, int64_t *recv) {
+    const int n = c->n;
+    if (n == 1) {
+        std::copy(send, send + m, recv);
+        return FLOCKGPU_OK;
+    }
+    if (!c->is_rccl) {
+        LocalGroup &g = *c->local;
+        g.counts[(size_t)c->rank] = send;
+        g.barrier();
+        for (int s = 0; s < n; ++s) std::copy(g.counts[(size_t)s] + (size_t)c->rank * m, g.counts[(size_t)s] + (size_t)(c->rank + 1) * m, recv + (size_t)s * m);
+        g.barrier();  // nobody rewrites its send array before everyone has read it
+        return FLOCKGPU_OK;
+    }
+    int64_t *d = nullptr, *h = nullptr;
+    FG_TRY(arena_get_t(ctx, "comm.counts", (size_t)2 * n * m + 2, &d));
+    FG_TRY(pinned_get_t(ctx, "comm.counts", (size_t)2 * n * m + 2, &h));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned staging may still be in flight from the previous exchange
+    std::copy(send, send + (size_t)n * m, h);
+    FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(int64_t) * (size_t)n * m, hipMemcpyHostToDevice, ctx->stream));
+    FG_NCCL(ctx, ncclGroupStart());
+    for (int p = 0; p < n; ++p) {
+        FG_NCCL(ctx, ncclSend(d + (size_t)p * m, (size_t)m, ncclInt64, p, c->nccl, ctx->stream));
+        FG_NCCL(ctx, ncclRecv(d + (size_t)(n + p) * m, (size_t)m, ncclInt64, p, c->nccl, ctx->stream));
+    }
+    FG_NCCL(ctx, ncclGroupEnd());
+    FG_HIP(ctx, hipMemcpyAsync(h + (size_t)n * m, d + (size_t)n * m, sizeof(int64_t) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::copy(h + (size_t)n * m, h + (size_t)2 * n * m, recv);
+    return FLOCKGPU_OK;
+}
+
+// Variable-size all-to-all of one device buffer: bytes [send_off[p], send_off[p+1]) go to rank p, bytes from rank s land at
+// [recv_off[s], recv_off[s+1]).  Offsets are host arrays of n + 1 entries.  Stream-ordered (rccl) / synchronising (local).
+int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off) {
+    const int n = c->n;
+    const uint8_t *s8 = static_cast<const uint8_t *>(send);
+    uint8_t *r8 = static_cast<uint8_t *>(recv);
+    if (n == 1) {
+        if (send_off[1] > send_off[0]) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[0], s8 + send_off[0], (size_t)(send_off[1] - send_off[0]), hipMemcpyDeviceToDevice, ctx->stream));
+        return FLOCKGPU_OK;
+    }
+    if (!c->is_rccl) {
+        LocalGroup &g = *c->local;
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // this rank's send buffer is complete
+        g.send_ptr[(size_t)c->rank] = send;
+        g.send_off[(size_t)c->rank] = send_off;
+        g.barrier();
+        for (int s = 0; s < n; ++s) {
+            const int64_t *so = g.send_off[(size_t)s];
+            const int64_t bytes = so[c->rank + 1] - so[c->rank];
+            if (bytes != recv_off[s + 1] - recv_off[s]) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s,
+                                                                    (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
+            if (bytes) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream));
+        }
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        g.barrier();  // every rank has pulled its runs: send buffers may be reused
+        return FLOCKGPU_OK;
+    }
+    // rounds of at most kMaxPeerBytes per (source, destination) pair: both ends of a pair know its size from the counts
+    // exchange, so they post the same sequence of sends / receives for it -- no agreement on a global round count needed
+    int64_t biggest = 0;
+    for (int p = 0; p < n; ++p) biggest = std::max({biggest, send_off[p + 1] - send_off[p], recv_off[p + 1] - recv_off[p]});
+    const uint64_t rounds = (uint64_t)std::max<int64_t>(1, div_up(biggest, kMaxPeerBytes));
+    for (uint64_t k = 0; k < rounds; ++k) {
+        FG_NCCL(ctx, ncclGroupStart());
+        for (int p = 0; p < n; ++p) {
+            const int64_t sb = send_off[p + 1] - send_off[p], rb = recv_off[p + 1] - recv_off[p];
+            const int64_t s0 = std::min<int64_t>(sb, (int64_t)k * kMaxPeerBytes), s1 = std::min<int64_t>(sb, (int64_t)(k + 1) * kMaxPeerBytes);
+            const int64_t r0 = std::min<int64_t>(rb, (int64_t)k * kMaxPeerBytes), r1 = std::min<int64_t>(rb, (int64_t)(k + 1) * kMaxPeerBytes);
+            if (s1 > s0) FG_NCCL(ctx, ncclSend(s8 + send_off[p] + s0, (size_t)(s1 - s0), ncclUint8, p, c->nccl, ctx->stream));
+            if (r1 > r0) FG_NCCL(ctx, ncclRecv(r8 + recv_off[p] + r0, (size_t)(r1 - r0), ncclUint8, p, c->nccl, ctx->stream));
+        }
+        FG_NCCL(ctx, ncclGroupEnd());
+    }
+    return FLOCKGPU_OK;
+}
+
+// host array of m values, max over the ranks (synchronises)
+int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, uint64_t *vals, int m) {
+    const int n = c->n;
+    if (n == 1 || m == 0) return FLOCKGPU_OK;
+    if (!c->is_rccl) {
+        LocalGroup &g = *c->local;
+        g.reduce[(size_t)c->rank] = vals;
+        g.barrier();
+        std::vector<uint64_t> mx(vals, vals + m);
+        for (int s = 0; s < n; ++s)
+            for (int j = 0; j < m; ++j) mx[(size_t)j] = std::max(mx[(size_t)j], g.reduce[(size_t)s][j]);
+        g.barrier();  // everyone has read the inputs
+        std::copy(mx.begin(), mx.end(), vals);
+        g.barrier();
+        return FLOCKGPU_OK;
+    }
+    uint64_t *d = nullptr, *h = nullptr;
+    FG_TRY(arena_get_t(ctx, "comm.reduce", (size_t)m + 2, &d));
+    FG_TRY(pinned_get_t(ctx, "comm.reduce", (size_t)m + 2, &h));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::copy(vals, vals + m, h);
+    FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(uint64_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    FG_NCCL(ctx, ncclAllReduce(d, d, (size_t)m, ncclUint64, ncclMax, c->nccl, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(uint64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::copy(h, h + m, vals);
+    return FLOCKGPU_OK;
+}
+
+// ------------------------------------------------------------------ device helpers of the shuffle
+// bytes of the Utf8 values each destination run will carry: sums[d] += len(src[rows[i]]) for the rows i of run d
+__global__ __launch_bounds__(kBlock) void run_bytes_kernel(const int32_t *__restrict__ src_off, const int32_t *__restrict__ rows, int64_t n,
+                                                           const int64_t *__restrict__ run_start, int32_t n_runs, unsigned long long *sums) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        int32_t d = -1;
+        unsigned long long len = 0;
+        if (i < n) {
+            d = 0;
+            while (d + 1 < n_runs && run_start[d + 1] <= i) ++d;
+            const int32_t r = rows[i];
+            len = (unsigned long long)(src_off[r + 1] - src_off[r]);
+        }
+        // a wave's 64 consecutive rows nearly always lie in one run: one atomic per wave, not 64 on the same address
+        const int32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__ballot(d != d0) == 0) {
+            const unsigned long long tot = wave_sum_u64(len);
+            if (lane_id() == 0 && d0 >= 0 && tot) atomicAdd(&sums[d0], tot);
+        } else if (d >= 0 && len) {
+            atomicAdd(&sums[d], len);
+        }
+    }
+}
+// out[dst[w] + i] = in[src[w] + i] for i < len[w]: the kept windows' winners, closed up
+__global__ __launch_bounds__(kBlock) void copy_runs_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, const int64_t *__restrict__ len,
+                                                           const int32_t *__restrict__ in_a, const uint64_t *__restrict__ in_n, int32_t *__restrict__ out_a,
+                                                           uint64_t *__restrict__ out_n) {
+    const int w = blockIdx.x;
+    const int64_t s = src[w], d = dst[w], l = len[w];
+    for (int64_t i = threadIdx.x; i < l; i += kBlock) {
+        out_a[d + i] = in_a[s + i];
+        out_n[d + i] = in_n[s + i];
+    }
+}
+// Utf8 end offsets of a gathered column, made relative to the byte start of their run (out[i] = off[i + 1] - off[start of run]) on the
+// sender; on the receiver the byte position of the run in the received buffer is added back (delta per run)
+__global__ __launch_bounds__(kBlock) void run_rebase_kernel(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ run_start,
+                                                            const int64_t *__restrict__ run_delta, int32_t n_runs, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t d = 0;
+        while (d + 1 < n_runs && run_start[d + 1] <= i) ++d;
+        out[i] = (int32_t)((int64_t)in[i] + run_delta[d]);
+    }
+}
+// index[i] = position in the received (source-major) buffer of the i-th row in (window, source) order
+__global__ __launch_bounds__(kBlock) void regroup_index_kernel(const int64_t *__restrict__ out_start, const int64_t *__restrict__ src_start,
+                                                               int32_t n_runs, int64_t n, int32_t *__restrict__ index) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t lo = 0, hi = n_runs;  // out_start[lo] <= i < out_start[hi]
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (out_start[mid] <= i) lo = mid; else hi = mid;
+        }
+        index[i] = (int32_t)(src_start[lo] + (i - out_start[lo]));
+    }
+}
+
+inline unsigned grid_for(flockgpu_ctx *ctx, int64_t n) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 16));
+}
+
+// host array -> device (stream-ordered, through pinned staging owned by `name`)
+template <typename T>
+int upload(flockgpu_ctx *ctx, const std::string &name, const T *host, size_t n, T **dev) {
+    T *h = nullptr;
+    FG_TRY(arena_get_t(ctx, name.c_str(), n + 2, dev));
+    FG_TRY(pinned_get_t(ctx, name.c_str(), n + 2, &h));
+    std::copy(host, host + n, h);
+    FG_HIP(ctx, hipMemcpyAsync(*dev, h, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+    return FLOCKGPU_OK;
+}
+
+struct XCol {  // a column to shuffle: fixed width (4 or 8 bytes per row) or Utf8
+    const void *values = nullptr;
+    const int32_t *offsets = nullptr;  // Utf8 only
+    int width = 4;                     // 4 | 8; ignored for Utf8
+    bool utf8() const { return offsets != nullptr; }
+};
+struct XRecv {
+    std::vector<DevColumn> cols;     // received columns, (window, source) order
+    std::vector<int64_t> win_off;    // n_win + 1 row offsets of the windows
+    int64_t rows = 0;
+};
+
+// RepartitionExec Hash([key], n_ranks) for one relation: every row of every window goes to rank part(key).
+// `name` keys the arena buffers (they must outlive the operator that consumes the result).
+int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &name, const std::vector<XCol> &cols, int key_col, int64_t rows,
+                      const flockgpu_windows *win, XRecv *out) {
+    const int n = c->n, n_win = win->n_windows;
+    // the pinned staging of `upload` below is rewritten by the next exchange under this name: everything queued from it is done
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    flockgpu_partition_result part{};
+    FG_TRY(flockgpu_partition_by_key(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part));  // synchronises
+    const int64_t *pw = part.part_win_offsets;  // n * n_win + 1, destination-major
+    const int64_t n_send = part.rows;
+    std::vector<int64_t> run_start((size_t)n + 1);
+    for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
+    int64_t *d_run_start = nullptr;
+    FG_TRY(upload(ctx, name + ".run_start", run_start.data(), (size_t)n + 1, &d_run_start));
+
+    // ---- send order: fixed-width columns are gathered right away; Utf8 columns share one synchronisation
+    struct Sent {
+        const void *values = nullptr;
+        flockgpu_utf8 u{};
+        int64_t bytes = 0;
+        Utf8Gather g;
+        unsigned long long *d_run_bytes = nullptr, *h_run_bytes = nullptr;
+    };
+    std::vector<Sent> sent(cols.size());
+    int n_utf8 = 0;
+    for (size_t i = 0; i < cols.size(); ++i) {
+        const XCol &col = cols[i];
+        const std::string key = name + ".send" + std::to_string(i);
+        if (col.utf8()) {
+            ++n_utf8;
+            FG_TRY(gather_utf8_begin(ctx, key.c_str(), flockgpu_utf8{col.offsets, static_cast<const uint8_t *>(col.values)}, part.row, n_send, &sent[i].g));
+            FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
+            FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
+            FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
+            if (n_send > 0) {
+                hipLaunchKernelGGL(run_bytes_kernel, dim3(grid_for(ctx, n_send)), dim3(kBlock), 0, ctx->stream, col.offsets, part.row, n_send, d_run_start, n,
+                                   sent[i].d_run_bytes);
+                FG_TRY(check_launch(ctx, "run_bytes_kernel"));
+            }
+            FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            void *p = nullptr;
+            FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
+            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), part.row, n_send, static_cast<int32_t *>(p)));
+            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), part.row, n_send, static_cast<int64_t *>(p)));
+            sent[i].values = p;
+        }
+    }
+    if (n_utf8) {
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < cols.size(); ++i)
+            if (cols[i].utf8()) FG_TRY(gather_utf8_finish(ctx, sent[i].g, &sent[i].u, &sent[i].bytes));
+    }
+
+    // ---- counts: rows per (destination, window) + bytes per Utf8 column per destination, one message per peer
+    const int m = n_win + n_utf8;
+    std::vector<int64_t> send_counts((size_t)n * m), recv_counts((size_t)n * m);
+    for (int d = 0; d < n; ++d) {
+        for (int w = 0; w < n_win; ++w) send_counts[(size_t)d * m + w] = pw[(size_t)d * n_win + w + 1] - pw[(size_t)d * n_win + w];
+        int u = 0;
+        for (size_t i = 0; i < cols.size(); ++i)
+            if (cols[i].utf8()) send_counts[(size_t)d * m + n_win + u++] = (int64_t)sent[i].h_run_bytes[d];
+    }
+    FG_TRY(exchange_counts(ctx, c, send_counts.data(), m, recv_counts.data()));
+
+    // ---- received layout: source-major runs; windows want (window, source) order
+    std::vector<int64_t> recv_rows_off((size_t)n + 1, 0);
+    for (int s = 0; s < n; ++s) {
+        int64_t r = 0;
+        for (int w = 0; w < n_win; ++w) r += recv_counts[(size_t)s * m + w];
+        recv_rows_off[(size_t)s + 1] = recv_rows_off[(size_t)s] + r;
+    }
+    const int64_t n_recv = recv_rows_off[(size_t)n];
+    if (n_recv >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: a rank would receive more than 2^31 rows");
+    const int n_runs = n * n_win;
+    std::vector<int64_t> out_start((size_t)n_runs + 1), src_start((size_t)n_runs + 1);
+    out->win_off.assign((size_t)n_win + 1, 0);
+    {
+        std::vector<int64_t> src_pos((size_t)n);  // running position inside each source's chunk
+        for (int s = 0; s < n; ++s) src_pos[(size_t)s] = recv_rows_off[(size_t)s];
+        int64_t pos = 0;
+        for (int w = 0; w < n_win; ++w) {
+            out->win_off[(size_t)w] = pos;
+            for (int s = 0; s < n; ++s) {
+                const int64_t cnt = recv_counts[(size_t)s * m + w];
+                out_start[(size_t)w * n + s] = pos;
+                src_start[(size_t)w * n + s] = src_pos[(size_t)s];
+                src_pos[(size_t)s] += cnt;
+                pos += cnt;
+            }
+        }
+        out_start[(size_t)n_runs] = src_start[(size_t)n_runs] = pos;
+        out->win_off[(size_t)n_win] = pos;
+    }
+    int64_t *d_out_start = nullptr, *d_src_start = nullptr;
+    int32_t *d_index = nullptr;
+    FG_TRY(upload(ctx, name + ".out_start", out_start.data(), out_start.size(), &d_out_start));
+    FG_TRY(upload(ctx, name + ".src_start", src_start.data(), src_start.size(), &d_src_start));
+    FG_TRY(arena_get_t(ctx, (name + ".index").c_str(), (size_t)n_recv + 4, &d_index));
+    if (n_recv > 0) {
+        hipLaunchKernelGGL(regroup_index_kernel, dim3(grid_for(ctx, n_recv)), dim3(kBlock), 0, ctx->stream, d_out_start, d_src_start, n_runs, n_recv, d_index);
+        FG_TRY(check_launch(ctx, "regroup_index_kernel"));
+    }
+
+    // ---- one all-to-all per column buffer, then the regrouping take
+    out->cols.assign(cols.size(), DevColumn{});
+    out->rows = n_recv;
+    std::vector<int64_t> so((size_t)n + 1), ro((size_t)n + 1);
+    int u = 0;
+    // Utf8 regroup takes share one synchronisation as well
+    std::vector<Utf8Gather> regroup(cols.size());
+    std::vector<flockgpu_utf8> recv_u(cols.size());
+    for (size_t i = 0; i < cols.size(); ++i) {
+        const XCol &col = cols[i];
+        const std::string key = name + ".recv" + std::to_string(i);
+        if (!col.utf8()) {
+            void *raw = nullptr, *fin = nullptr;
+            FG_TRY(arena_get(ctx, (key + ".raw").c_str(), (size_t)n_recv * col.width + 16, &raw));
+            FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_recv * col.width + 16, &fin));
+            for (int p = 0; p <= n; ++p) {
+                so[(size_t)p] = run_start[(size_t)p] * col.width;
+                ro[(size_t)p] = recv_rows_off[(size_t)p] * col.width;
+            }
+            FG_TRY(all_to_all(ctx, c, sent[i].values, so.data(), raw, ro.data()));
+            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(raw), d_index, n_recv, static_cast<int32_t *>(fin)));
+            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(raw), d_index, n_recv, static_cast<int64_t *>(fin)));
+            out->cols[i].type = col.width == 4 ? ColType::I32 : ColType::I64;
+            out->cols[i].values = fin;
+            continue;
+        }
+        // Utf8: the rows' END offsets travel relative to the start of their run, the bytes as they are
+        std::vector<int64_t> send_delta((size_t)n), recv_delta((size_t)n), sb((size_t)n + 1, 0), rb((size_t)n + 1, 0);
+        for (int p = 0; p < n; ++p) {
+            sb[(size_t)p + 1] = sb[(size_t)p] + (int64_t)sent[i].h_run_bytes[p];
+            rb[(size_t)p + 1] = rb[(size_t)p] + recv_counts[(size_t)p * m + n_win + u];
+            send_delta[(size_t)p] = -sb[(size_t)p];
+            recv_delta[(size_t)p] = rb[(size_t)p];
+        }
+        ++u;
+        if (rb[(size_t)n] >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: a received Utf8 column exceeds 2^31 bytes");
+        int64_t *d_sd = nullptr, *d_rd = nullptr, *d_rro = nullptr;
+        FG_TRY(upload(ctx, key + ".sdelta", send_delta.data(), (size_t)n, &d_sd));
+        FG_TRY(upload(ctx, key + ".rdelta", recv_delta.data(), (size_t)n, &d_rd));
+        FG_TRY(upload(ctx, key + ".rrows", recv_rows_off.data(), (size_t)n + 1, &d_rro));
+        int32_t *ends_send = nullptr, *off_recv = nullptr;
+        uint8_t *bytes_recv = nullptr;
+        FG_TRY(arena_get_t(ctx, (key + ".ends").c_str(), (size_t)n_send + 4, &ends_send));
+        FG_TRY(arena_get_t(ctx, (key + ".rawoff").c_str(), (size_t)n_recv + 4, &off_recv));
+        FG_TRY(arena_get_t(ctx, (key + ".rawbytes").c_str(), (size_t)rb[(size_t)n] + 16, &bytes_recv));
+        if (n_send > 0) {
+            hipLaunchKernelGGL(run_rebase_kernel, dim3(grid_for(ctx, n_send)), dim3(kBlock), 0, ctx->stream, sent[i].u.offsets + 1, n_send, d_run_start, d_sd, n, ends_send);
+            FG_TRY(check_launch(ctx, "run_rebase_kernel"));
+        }
+        for (int p = 0; p <= n; ++p) {
+            so[(size_t)p] = run_start[(size_t)p] * 4;
+            ro[(size_t)p] = (recv_rows_off[(size_t)p]) * 4;
+        }
+        FG_HIP(ctx, hipMemsetAsync(off_recv, 0, 4, ctx->stream));
+        FG_TRY(all_to_all(ctx, c, ends_send, so.data(), off_recv + 1, ro.data()));
+        FG_TRY(all_to_all(ctx, c, sent[i].u.data, sb.data(), bytes_recv, rb.data()));
+        if (n_recv > 0) {
+            hipLaunchKernelGGL(run_rebase_kernel, dim3(grid_for(ctx, n_recv)), dim3(kBlock), 0, ctx->stream, off_recv + 1, n_recv, d_rro, d_rd, n, off_recv + 1);
+            FG_TRY(check_launch(ctx, "run_rebase_kernel"));
+        }
+        recv_u[i] = flockgpu_utf8{off_recv, bytes_recv};
+        FG_TRY(gather_utf8_begin(ctx, key.c_str(), recv_u[i], d_index, n_recv, &regroup[i]));
+    }
+    if (n_utf8) {
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < cols.size(); ++i) {
+            if (!cols[i].utf8()) continue;
+            flockgpu_utf8 fin{};
+            int64_t nbytes = 0;
+            FG_TRY(gather_utf8_finish(ctx, regroup[i], &fin, &nbytes));
+            out->cols[i].type = ColType::UTF8;
+            out->cols[i].values = fin.data;
+            out->cols[i].offsets = fin.offsets;
+            out->cols[i].bytes = nbytes;
+        }
+    }
+    return FLOCKGPU_OK;
+}
+
+flockgpu_windows single_pane_windows(const std::vector<int64_t> &win_off, std::vector<int32_t> &lo, std::vector<int32_t> &hi) {
+    const int n_win = (int)win_off.size() - 1;
+    lo.resize((size_t)std::max(n_win, 1));
+    hi.resize(lo.size());
+    for (int w = 0; w < n_win; ++w) {
+        lo[(size_t)w] = w;
+        hi[(size_t)w] = w + 1;
+    }
+    return flockgpu_windows{win_off.data(), n_win, lo.data(), hi.data(), n_win};
+}
+
+int check_comm(flockgpu_ctx *ctx, const flockgpu_comm *c, const char *what) {
+    if (!c) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: null communicator", what);
+    if (c->n > 64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 64 ranks", what);
+    return FLOCKGPU_OK;
+}
+// schedules whose windows are single panes [w, w + 1) (ElementWise / Tumbling): what the join shuffles need
+int check_single_panes(flockgpu_ctx *ctx, const flockgpu_windows *w, const char *what) {
+    for (int i = 0; i < w->n_windows; ++i)
+        if (w->win_pane_hi[i] != w->win_pane_lo[i] + 1) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: the join shuffle needs single-pane windows", what);
+    return FLOCKGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flockgpu_comm_unique_id(uint8_t out_id[FLOCKGPU_COMM_ID_BYTES]) {
+    static_assert(FLOCKGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!out_id) return FLOCKGPU_ERR_INVALID;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return FLOCKGPU_ERR_HIP;
+    std::memcpy(out_id, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_comm_init_rank(flockgpu_ctx *ctx, const uint8_t id[FLOCKGPU_COMM_ID_BYTES], int n_ranks, int rank, flockgpu_comm **out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, FLOCKGPU_ERR_INVALID, "comm_init_rank: bad argument");
+    *out = nullptr;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<flockgpu_comm> c(new flockgpu_comm());
+    c->n = n_ranks;
+    c->rank = rank;
+    c->is_rccl = true;
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+    FG_NCCL(ctx, ncclCommInitRank(&c->nccl, n_ranks, uid, rank));
+    *out = c.release();
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_comm_init_local(int n_ranks, flockgpu_comm **out) {
+    if (!out || n_ranks < 1 || n_ranks > 64) return FLOCKGPU_ERR_INVALID;
+    auto g = std::make_shared<LocalGroup>();
+    g->n = n_ranks;
+    g->send_ptr.assign((size_t)n_ranks, nullptr);
+    g->send_off.assign((size_t)n_ranks, nullptr);
+    g->counts.assign((size_t)n_ranks, nullptr);
+    g->reduce.assign((size_t)n_ranks, nullptr);
+    for (int r = 0; r < n_ranks; ++r) {
+        out[r] = new flockgpu_comm();
+        out[r]->n = n_ranks;
+        out[r]->rank = r;
+        out[r]->local = g;
+    }
+    return FLOCKGPU_OK;
+}
+
+void flockgpu_comm_destroy(flockgpu_comm *comm) {
+    if (!comm) return;
+    if (comm->nccl) (void)ncclCommDestroy(comm->nccl);
+    delete comm;
+}
+int flockgpu_comm_rank(const flockgpu_comm *comm) { return comm ? comm->rank : -1; }
+int flockgpu_comm_size(const flockgpu_comm *comm) { return comm ? comm->n : 0; }
+const char *flockgpu_comm_transport(const flockgpu_comm *comm) { return !comm ? "" : (comm->is_rccl ? "rccl" : "local"); }
+
+int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_TRY(check_comm(ctx, comm, "barrier"));
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t one = 1;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return all_reduce_max(ctx, comm, &one, 1);
+}
+
+int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                                   flockgpu_q5_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_TRY(check_comm(ctx, comm, "q5 exchange"));
+    if (!bid || !win || !out || bid->rows < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 exchange: null argument");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_panes = win->n_panes, n_win = win->n_windows;
+    // stage 0 (q5.dag): HashAggregateExec mode=Partial on this rank's rows, pane by pane
+    flockgpu_q5_partial_result part{};
+    FG_TRY(flockgpu_q5_partial_counts(ctx, bid, win, &part));
+    // RepartitionExec Hash([auction], n): the groups of every pane, one "window" per pane
+    std::vector<int32_t> lo, hi;
+    std::vector<int64_t> pane_off(part.pane_out_offsets, part.pane_out_offsets + n_panes + 1);
+    const flockgpu_windows panes = single_pane_windows(pane_off, lo, hi);
+    XRecv got;
+    FG_TRY(exchange_relation(ctx, comm, "xq5", {XCol{part.auction, nullptr, 4}, XCol{part.count, nullptr, 4}}, 0, part.rows, &panes, &got));
+    // stage 1: FinalPartitioned COUNT + MAX + join over the groups this rank owns (windows over the received panes)
+    const flockgpu_windows recv_win{got.win_off.data(), n_panes, win->win_pane_lo, win->win_pane_hi, n_win};
+    flockgpu_q5_result local{};
+    FG_TRY(flockgpu_q5_hot_items_weighted(ctx, static_cast<const int32_t *>(got.cols[0].values), static_cast<const uint32_t *>(got.cols[1].values),
+                                          got.rows, &recv_win, &local));
+    // MAX across the partitions (q5.dag: Partial MAX per partition -> CoalescePartitions -> Final MAX), 8 bytes per window
+    std::vector<uint64_t> &gmax = ctx->host_u64["xq5.win_max"];
+    gmax.assign(local.win_max, local.win_max + n_win);
+    FG_TRY(all_reduce_max(ctx, comm, gmax.data(), n_win));
+    // the join num = maxn: windows whose local maximum is below the global one keep none of their rows.  Winners of a
+    // window are contiguous; keep-runs are copied down on the device.
+    std::vector<int64_t> &offs = ctx->host_i64["xq5.win_out_offsets"];
+    offs.assign((size_t)n_win + 1, 0);
+    std::vector<int64_t> runs((size_t)3 * std::max(n_win, 1), 0);  // src | dst | len per window
+    int64_t pos = 0;
+    for (int w = 0; w < n_win; ++w) {
+        const int64_t a = local.win_out_offsets[w], b = local.win_out_offsets[w + 1];
+        const bool keep = b > a && gmax[(size_t)w] > 0 && local.win_max[w] == gmax[(size_t)w];
+        offs[(size_t)w] = pos;
+        runs[(size_t)w] = a;
+        runs[(size_t)n_win + w] = pos;
+        runs[(size_t)2 * n_win + w] = keep ? b - a : 0;
+        if (keep) pos += b - a;
+    }
+    offs[(size_t)n_win] = pos;
+    int32_t *o_a = nullptr;
+    uint64_t *o_n = nullptr;
+    int64_t *d_runs = nullptr;
+    FG_TRY(arena_get_t(ctx, "xq5.out_auction", (size_t)pos + 2, &o_a));
+    FG_TRY(arena_get_t(ctx, "xq5.out_num", (size_t)pos + 2, &o_n));
+    if (n_win > 0 && pos > 0) {
+        FG_TRY(upload(ctx, "xq5.runs", runs.data(), runs.size(), &d_runs));
+        hipLaunchKernelGGL(copy_runs_kernel, dim3((unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_runs, d_runs + n_win, d_runs + 2 * n_win, local.auction,
+                           local.num, o_a, o_n);
+        FG_TRY(check_launch(ctx, "copy_runs_kernel"));
+    }
+    std::vector<uint64_t> &grp = ctx->host_u64["xq5.win_groups"];
+    grp.assign(local.win_groups, local.win_groups + n_win);
+    out->auction = o_a;
+    out->num = o_n;
+    out->win_out_offsets = offs.data();
+    out->win_max = gmax.data();
+    out->win_groups = grp.data();
+    out->rows = pos;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_q3_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                              const flockgpu_person_cols *person, const flockgpu_windows *person_win, int64_t category_lit,
+                              const char *const *state_lits, int n_state_lits, flockgpu_q3_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_TRY(check_comm(ctx, comm, "q3 exchange"));
+    if (!auction || !person || !auction_win || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3 exchange: null argument");
+    FG_TRY(check_single_panes(ctx, auction_win, "q3 exchange"));
+    FG_TRY(check_single_panes(ctx, person_win, "q3 exchange"));
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    XRecv a, p;
+    FG_TRY(exchange_relation(ctx, comm, "xq3a", {XCol{auction->a_id, nullptr, 4}, XCol{auction->seller, nullptr, 4}, XCol{auction->category, nullptr, 4}}, 1,
+                             auction->rows, auction_win, &a));
+    FG_TRY(exchange_relation(ctx, comm, "xq3p",
+                             {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}, XCol{person->city.data, person->city.offsets, 0},
+                              XCol{person->state.data, person->state.offsets, 0}},
+                             0, person->rows, person_win, &p));
+    std::vector<int32_t> alo, ahi, plo, phi;
+    const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
+    auto u = [](const DevColumn &c) { return flockgpu_utf8{c.offsets, static_cast<const uint8_t *>(c.values)}; };
+    const flockgpu_auction_cols ac{static_cast<const int32_t *>(a.cols[0].values), static_cast<const int32_t *>(a.cols[1].values),
+                                   static_cast<const int32_t *>(a.cols[2].values), a.rows};
+    const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values), u(p.cols[1]), u(p.cols[2]), u(p.cols[3]), p.rows};
+    return flockgpu_q3_join(ctx, &ac, &aw, &pc, &pw, category_lit, state_lits, n_state_lits, out);
+}
+
+int flockgpu_q8_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                              const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win, flockgpu_q8_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    FG_TRY(check_comm(ctx, comm, "q8 exchange"));
+    if (!auction || !person || !auction_win || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q8 exchange: null argument");
+    FG_TRY(check_single_panes(ctx, auction_win, "q8 exchange"));
+    FG_TRY(check_single_panes(ctx, person_win, "q8 exchange"));
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    XRecv a, p;
+    FG_TRY(exchange_relation(ctx, comm, "xq8p", {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}}, 0, person->rows, person_win, &p));
+    FG_TRY(exchange_relation(ctx, comm, "xq8a", {XCol{auction->seller, nullptr, 4}}, 0, auction->rows, auction_win, &a));
+    std::vector<int32_t> alo, ahi, plo, phi;
+    const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
+    const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values),
+                                  flockgpu_utf8{p.cols[1].offsets, static_cast<const uint8_t *>(p.cols[1].values)}, {nullptr, nullptr}, {nullptr, nullptr}, p.rows};
+    const flockgpu_auction_cols ac{nullptr, static_cast<const int32_t *>(a.cols[0].values), nullptr, a.rows};
+    return flockgpu_q8_join(ctx, &pc, &pw, &ac, &aw, out);
+}
+
+}  // extern "C"

@@ -306,6 +306,59 @@ class Q8Out:
         }
 
 
+# ------------------------------------------------------------------ communicators (include/flockgpu_comm.h)
+class Comm:
+    """One rank's handle of a flockgpu communicator."""
+
+    def __init__(self, h, lib):
+        self.h, self._lib = h, lib
+
+    @property
+    def rank(self) -> int:
+        return self._lib.flockgpu_comm_rank(self.h)
+
+    @property
+    def size(self) -> int:
+        return self._lib.flockgpu_comm_size(self.h)
+
+    @property
+    def transport(self) -> str:
+        return self._lib.flockgpu_comm_transport(self.h).decode()
+
+    def close(self):
+        if self.h:
+            self._lib.flockgpu_comm_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def local(n_ranks: int):
+        """n_ranks handles for ranks that are threads of this process (flockgpu_comm_init_local)."""
+        lib = _ffi.load()
+        hs = (C.c_void_p * n_ranks)()
+        rc = lib.flockgpu_comm_init_local(n_ranks, hs)
+        if rc != _ffi.OK:
+            raise FlockGpuError(rc, "flockgpu_comm_init_local failed")
+        return [Comm(C.c_void_p(h), lib) for h in hs]
+
+    @staticmethod
+    def from_torch_distributed(ctx: "GpuContext", group=None):
+        """One process per GPU: rank 0 draws the RCCL id, torch.distributed (the host's own channel) ships its 128 bytes,
+        every rank calls flockgpu_comm_init_rank collectively."""
+        import torch.distributed as dist
+        lib = _ffi.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = lib.flockgpu_comm_unique_id(buf)
+            if rc != _ffi.OK:
+                raise FlockGpuError(rc, "flockgpu_comm_unique_id failed")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = C.c_void_p()
+        ctx._check(lib.flockgpu_comm_init_rank(ctx._h, box[0], world, rank, C.byref(h)))
+        return Comm(h, lib)
+
+
 # ------------------------------------------------------------------ the context
 class GpuContext:
     """Owns a `flockgpu_ctx`.  `stream` defaults to torch's current stream on `device`."""
@@ -500,6 +553,29 @@ class GpuContext:
         p, pw, a, aw, r = persons.ffi(), person_windows.ffi(), auctions.ffi(), auction_windows.ffi(), _ffi.Q8Result()
         self._check(self._lib.flockgpu_q8_join(self._h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
         return Q8Out(self, r, person_windows.n_windows)
+
+    # -- in-library exchange (include/flockgpu_comm.h): every window striped over the ranks of `comm`
+    def q5_hot_items_exchange(self, comm: "Comm", bids: Bids, windows: WindowSchedule) -> Q5Out:
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5Result()
+        self._check(self._lib.flockgpu_q5_hot_items_exchange(self._h, comm.h, C.byref(b), C.byref(w), C.byref(r)))
+        return Q5Out(self, r, windows.n_windows)
+
+    def q3_join_exchange(self, comm: "Comm", auctions: Auctions, auction_windows: WindowSchedule, persons: Persons,
+                         person_windows: WindowSchedule, category: int = 10, states: Sequence[str] = ("or", "id", "ca")) -> Q3Out:
+        a, aw, p, pw, r = auctions.ffi(), auction_windows.ffi(), persons.ffi(), person_windows.ffi(), _ffi.Q3Result()
+        lits = (C.c_char_p * len(states))(*[s.encode() for s in states])
+        self._check(self._lib.flockgpu_q3_join_exchange(self._h, comm.h, C.byref(a), C.byref(aw), C.byref(p), C.byref(pw), category,
+                                                        lits, len(states), C.byref(r)))
+        return Q3Out(self, r, auction_windows.n_windows)
+
+    def q8_join_exchange(self, comm: "Comm", persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
+                         auction_windows: WindowSchedule) -> Q8Out:
+        p, pw, a, aw, r = persons.ffi(), person_windows.ffi(), auctions.ffi(), auction_windows.ffi(), _ffi.Q8Result()
+        self._check(self._lib.flockgpu_q8_join_exchange(self._h, comm.h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
+        return Q8Out(self, r, person_windows.n_windows)
+
+    def comm_barrier(self, comm: "Comm"):
+        self._check(self._lib.flockgpu_comm_barrier(self._h, comm.h))
 
     # -- exchange building blocks (include/flockgpu.h "key-partitioned exchange")
     def partition_by_key(self, keys, windows: WindowSchedule, n_parts: int):

@@ -1,0 +1,75 @@
+/* flockgpu_comm.h -- multi-GPU entry of libflockgpu: the key-partitioned exchange of the reference's distributed plans
+ *   filter / Partial aggregate  ->  RepartitionExec Hash([key], n)  ->  join / FinalPartitioned aggregate
+ * (flock/src/distributed_plan/planner.rs:152-171, playground/src/distributed_plan/nexmark/q{3,5,8}.dag), which the
+ * reference moves between Lambda functions as payloads, partition j to ring member j
+ * (flock-function/src/aws/actor.rs:425-543; there is no collective library in the reference).  Here the ranks are GPUs of
+ * one node and the repartition is ONE variable-size all-to-all per column buffer over xGMI, issued inside the library
+ * (RCCL: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the ctx stream), so a Rust host binds it like any
+ * other entry point.
+ *
+ * One rank = one flockgpu_ctx (one device, one stream, one thread at a time).  Every rank calls the same entry points
+ * in the same order.  Every window of the schedule is striped across the ranks: rank r passes ITS rows of each window.
+ *   partition rows by  dest = (fmix32(key) * n_ranks) >> 32  (count -> scan -> emit, shuffle.hip)
+ *   -> take into send order  -> counts exchange (rows per (destination, window), bytes per Utf8 column)
+ *   -> one all-to-all per column buffer  -> regroup (source, window) runs into windows  -> the single-GPU operator.
+ * The result stays sharded by key: rank r returns the rows whose key it owns.  Which rank owns a key is unobservable
+ * in the union (the reference hashes with ahash).
+ */
+#ifndef FLOCKGPU_COMM_H
+#define FLOCKGPU_COMM_H
+
+#include "flockgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flockgpu_comm flockgpu_comm;
+
+#define FLOCKGPU_COMM_ID_BYTES 128
+
+/* One process per GPU (how bench.py and torchrun launch): rank 0 creates an id, the host ships its 128 bytes to the other
+ * ranks through its own channel (a torch.distributed store, MPI, a socket ...), then EVERY rank calls init_rank --
+ * collectively, as ncclCommInitRank requires.  The communicator runs on the ctx's device and stream. */
+int flockgpu_comm_unique_id(uint8_t out_id[FLOCKGPU_COMM_ID_BYTES]);
+int flockgpu_comm_init_rank(flockgpu_ctx *ctx, const uint8_t id[FLOCKGPU_COMM_ID_BYTES], int n_ranks, int rank,
+                            flockgpu_comm **out);
+/* One process, n_ranks ranks driven by n_ranks host threads (SURVEY.md section 8(b) "single-process, multi-device"):
+ * out[r] is rank r's handle, used with rank r's ctx.  Ranks may sit on different devices or share one (how the exchange
+ * is tested on a one-GPU box); buffers move with device-to-device copies, the ranks meet at host barriers. */
+int flockgpu_comm_init_local(int n_ranks, flockgpu_comm **out /* n_ranks entries */);
+void flockgpu_comm_destroy(flockgpu_comm *comm);
+int flockgpu_comm_rank(const flockgpu_comm *comm);
+int flockgpu_comm_size(const flockgpu_comm *comm);
+/* "rccl" | "local" */
+const char *flockgpu_comm_transport(const flockgpu_comm *comm);
+
+/* ---- q5 as q5.dag runs it: HashAggregateExec(Partial) COUNT on this rank's rows, pane by pane -> the (auction, count)
+ * GROUPS are repartitioned on `auction` (a group moves once although its pane is in two hopping windows; the bids
+ * themselves never cross the fabric) -> FinalPartitioned COUNT, MAX and the num = maxn join over the owned auctions ->
+ * all-reduce(MAX) of the per-window maxima.  out: this rank's winners; win_max is the GLOBAL maximum per window, rows of
+ * windows whose local maximum is below it are dropped; win_groups counts the groups this rank owns. */
+int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_bid_cols *bid,
+                                   const flockgpu_windows *win, flockgpu_q5_result *out);
+
+/* ---- q3 with the join shuffle of planner.rs:152-171: auctions repartitioned on seller, persons on p_id (rows are
+ * filtered AFTER the shuffle by the fused join, so the shuffle also carries the rows the filters drop -- the same rows
+ * the reference's stage 0 would have dropped before its repartition; see flockgpu_plan for the staged form). */
+int flockgpu_q3_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_auction_cols *auction,
+                              const flockgpu_windows *auction_win, const flockgpu_person_cols *person,
+                              const flockgpu_windows *person_win, int64_t category_lit, const char *const *state_lits,
+                              int n_state_lits, flockgpu_q3_result *out);
+
+/* ---- q8 with the join shuffle of q8.dag: persons (p_id, name) repartitioned on p_id, auction sellers on seller, then
+ * the local DISTINCT + DISTINCT + join. */
+int flockgpu_q8_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_person_cols *person,
+                              const flockgpu_windows *person_win, const flockgpu_auction_cols *auction,
+                              const flockgpu_windows *auction_win, flockgpu_q8_result *out);
+
+/* Host barrier + stream synchronisation across the ranks (benchmark bracketing). */
+int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOCKGPU_COMM_H */

@@ -18,7 +18,7 @@ def lib():
 
 def _declared():
     names = set()
-    for hdr in ("flockgpu.h", "flockgpu_plan.h"):
+    for hdr in ("flockgpu.h", "flockgpu_plan.h", "flockgpu_comm.h"):
         p = os.path.join(ROOT, "include", hdr)
         if os.path.exists(p):
             src = re.sub(r"/\*.*?\*/", "", open(p).read(), flags=re.S)

@@ -1,0 +1,178 @@
+"""The in-library exchange (include/flockgpu_comm.h): every window striped over the ranks, partition -> counts exchange ->
+all-to-all -> regroup -> single-GPU operator INSIDE libflockgpu.  Ranks are threads of this process sharing the one GPU of
+the box (transport "local": device-to-device copies + host barriers) for 2 / 3 / 8 ranks, and RCCL itself for one rank;
+the union of the ranks' results must be the oracle's rows for every window (q3 / q5 / q8).  The shared logic above the
+transport is everything but the ncclSend / ncclRecv calls, which the driver's multi-GPU run exercises."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from test_distributed import _strs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _utf8_dev(u):
+    from flock_amd import DeviceUtf8
+    data = u.data if len(u.data) >= 16 else np.concatenate([u.data, np.zeros(16 - len(u.data), np.uint8)])
+    return DeviceUtf8(_dev(u.offsets), _dev(data))
+
+
+def _stripe_rows(pane_off, rank, world):
+    """Rows [lo + n r / G, lo + n (r + 1) / G) of every pane, and the pane offsets of the stripe."""
+    lo = pane_off[:-1] + np.diff(pane_off) * rank // world
+    hi = pane_off[:-1] + np.diff(pane_off) * (rank + 1) // world
+    rows = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if len(lo) else np.zeros(0, np.int64)
+    return rows.astype(np.int64), np.concatenate(([0], np.cumsum(hi - lo)))
+
+
+def _take_utf8(u, rows):
+    return oracle.take_utf8(u, rows)
+
+
+def _run_ranks(world, body):
+    """body(rank, ctx, comm) on `world` threads, each with its own ctx (own stream) on device 0; returns the results."""
+    import torch
+    from flock_amd import Comm, GpuContext
+    comms = Comm.local(world)
+    ctxs = [GpuContext(0, own_stream=True) for _ in range(world)]
+    out, err = [None] * world, [None] * world
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            out[r] = body(r, ctxs[r], comms[r])
+        except BaseException as e:      # noqa: BLE001 -- surfaced below; a dead rank would leave the others at a barrier
+            err[r] = e
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    alive = [t.is_alive() for t in threads]
+    for e in err:
+        if e is not None:
+            raise e
+    assert not any(alive), "a rank is stuck in the exchange"
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+    return out
+
+
+SEED, EPS, SECONDS = 21, 20_000, 20
+
+
+@pytest.fixture(scope="module")
+def host():
+    s = oracle.NexmarkStream(seed=SEED, eps=EPS)
+    n = EPS * SECONDS
+    epoch = {k: np.array([s.counts(0, e * EPS)[i] for e in range(SECONDS + 1)], np.int64) for i, k in enumerate(("person", "auction", "bid"))}
+    return {"au": s.auctions(0, n), "pe": s.persons(0, n), "bid": s.bids(0, n, columns=("auction",))["auction"], "epoch": epoch}
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_q5_exchange_local_ranks(host, world):
+    from flock_amd import Bids, WindowSchedule
+    pane_off = host["epoch"]["bid"][::5]                              # Hopping(10, 5): 5-s panes
+    n_panes = len(pane_off) - 1
+    lo, hi = np.arange(0, n_panes - 1, dtype=np.int32), np.arange(2, n_panes + 1, dtype=np.int32)
+    stripes = []
+    for r in range(world):
+        rows, off = _stripe_rows(pane_off, r, world)
+        stripes.append((Bids(auction=_dev(host["bid"][rows]), rows=len(rows)), WindowSchedule(off, lo, hi)))
+
+    def body(r, ctx, comm):
+        assert comm.rank == r and comm.size == world and comm.transport == "local"
+        res = ctx.q5_hot_items_exchange(comm, *stripes[r])
+        a, n, off = res.to_host()
+        return a, n, off, res.win_max()
+    outs = _run_ranks(world, body)
+    for w in range(len(lo)):
+        oa, on = oracle.q5_hot_items(host["bid"][pane_off[lo[w]]:pane_off[hi[w]]])
+        got = []
+        for a, n, off, mx in outs:
+            got += list(zip(a[off[w]:off[w + 1]].tolist(), n[off[w]:off[w + 1]].tolist()))
+            assert int(mx[w]) == int(on[0])                            # every rank learns the global maximum
+        assert sorted(got) == sorted(zip(oa.tolist(), on.tolist())), w
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_q3_q8_exchange_local_ranks(host, world):
+    from flock_amd import Auctions, Persons, WindowSchedule
+    au, pe, ep = host["au"], host["pe"], host["epoch"]
+
+    def stripes(pane_a, pane_p):
+        out = []
+        n_win = len(pane_a) - 1
+        ids = np.arange(n_win, dtype=np.int32)
+        for r in range(world):
+            ra, oa = _stripe_rows(pane_a, r, world)
+            rp, op = _stripe_rows(pane_p, r, world)
+            a = Auctions(_dev(au["a_id"][ra]), _dev(au["seller"][ra]), _dev(au["category"][ra]), len(ra))
+            p = Persons(_dev(pe["p_id"][rp]), _utf8_dev(_take_utf8(pe["name"], rp)), _utf8_dev(_take_utf8(pe["city"], rp)),
+                        _utf8_dev(_take_utf8(pe["state"], rp)), len(rp))
+            out.append((a, WindowSchedule(oa, ids, ids + 1), p, WindowSchedule(op, ids, ids + 1)))
+        return out
+    # ---- q3: ElementWise windows
+    s3 = stripes(ep["auction"], ep["person"])
+    o3 = _run_ranks(world, lambda r, ctx, comm: ctx.q3_join_exchange(comm, *s3[r]).to_host())
+    total = 0
+    for w in range(SECONDS):
+        alo, ahi, plo, phi = ep["auction"][w], ep["auction"][w + 1], ep["person"][w], ep["person"][w + 1]
+        ar, pr = oracle.q3_join(au["seller"][alo:ahi], au["category"][alo:ahi], pe["p_id"][plo:phi], pe["state"].slice(plo, phi))
+        rows = [plo + int(r) for r in pr]
+        want = sorted(zip(_strs(pe["name"].offsets, pe["name"].data, rows), _strs(pe["city"].offsets, pe["city"].data, rows),
+                          _strs(pe["state"].offsets, pe["state"].data, rows), au["a_id"][alo:ahi][ar].tolist()))
+        got = []
+        for o in o3:
+            sl = slice(o["offsets"][w], o["offsets"][w + 1])
+            got += list(zip(_strs(*o["name"])[sl], _strs(*o["city"])[sl], _strs(*o["state"])[sl], o["a_id"][sl].tolist()))
+        assert sorted(got) == want, w
+        total += len(want)
+    assert total > 0
+    # ---- q8: Tumbling(10 s) windows
+    s8 = stripes(ep["auction"][::10], ep["person"][::10])
+    o8 = _run_ranks(world, lambda r, ctx, comm: ctx.q8_join_exchange(comm, s8[r][2], s8[r][3], s8[r][0], s8[r][1]).to_host())
+    for w in range(SECONDS // 10):
+        alo, ahi, plo, phi = ep["auction"][10 * w], ep["auction"][10 * w + 10], ep["person"][10 * w], ep["person"][10 * w + 10]
+        rows = oracle.q8_join(pe["p_id"][plo:phi], pe["name"].slice(plo, phi), au["seller"][alo:ahi])
+        want = sorted(zip(pe["p_id"][plo:phi][rows].tolist(), _strs(pe["name"].offsets, pe["name"].data, [plo + r for r in rows])))
+        got = []
+        for o in o8:
+            sl = slice(o["offsets"][w], o["offsets"][w + 1])
+            got += list(zip(o["p_id"][sl].tolist(), _strs(*o["name"])[sl]))
+        assert sorted(got) == want and want
+
+
+def test_exchange_through_rccl_one_rank(host):
+    """The RCCL transport end to end (ncclGetUniqueId -> ncclCommInitRank -> send / recv groups) with the one rank a one-GPU
+    box offers: results equal the single-GPU operators'."""
+    import ctypes as C
+    from flock_amd import Bids, Comm, GpuContext, WindowSchedule, _ffi
+    lib = _ffi.load()
+    ctx = GpuContext(0)
+    buf = C.create_string_buffer(128)
+    assert lib.flockgpu_comm_unique_id(buf) == 0
+    h = C.c_void_p()
+    ctx._check(lib.flockgpu_comm_init_rank(ctx._h, buf.raw, 1, 0, C.byref(h)))
+    comm = Comm(h, lib)
+    assert comm.transport == "rccl" and comm.size == 1
+    pane_off = host["epoch"]["bid"][::5]
+    n_panes = len(pane_off) - 1
+    sched = WindowSchedule(pane_off, np.arange(0, n_panes - 1, dtype=np.int32), np.arange(2, n_panes + 1, dtype=np.int32))
+    bids = Bids(auction=_dev(host["bid"]), rows=len(host["bid"]))
+    a, n, off = ctx.q5_hot_items_exchange(comm, bids, sched).to_host()
+    wa, wn, woff = ctx.q5_hot_items(bids, sched).to_host()
+    assert np.array_equal(a, wa) and np.array_equal(n, wn) and np.array_equal(off, woff)
+    ctx.comm_barrier(comm)
+    comm.close()
+    ctx.close()
