@@ -3,22 +3,28 @@
 
 Step = one pass of the hot path over one batch of synthetic input already resident in HBM: every
 window of the query's schedule (benchmarks/src/nexmark/main.rs:115-123) over `seconds` x `eps`
-generated events, executed through the C ABI (include/flockgpu.h).
+generated events, executed through the C ABI (include/flockgpu.h, include/flockgpu_comm.h).
 
-Workload at N=1 (BASELINE.json configs[3], the largest single-GPU configuration the metric is quoted
-on): q5 hot-items over 1.0e9 synthetic bids (1087 s x 1e6 events/s, Hopping(10 s, 5 s) -> 216 windows).
-With N ranks every rank owns its own slice of the global event stream (first_event_id = rank * events):
-NEXMark windows are independent units, so the path shards with no data-path collective ("weak").
-`--mode exchange` runs the key-partitioned variant instead (flock_amd/distributed.py: every window striped
-across the ranks, hash repartition on the join / group key + RCCL all-to-all, as the reference's distributed
-plans do); the total work is then fixed ("strong").
-q2 / q3 / q8 (BASELINE.json configs[1], [2], [4]), q3 at 1e9 events and a PCIe-inclusive q5 run are reported
-alongside in "also" at N=1.
+N = 1 (default): BASELINE.json configs[3], the largest configuration the metric is quoted on that one GPU holds:
+q5 hot-items over 1.0e9 synthetic bids (1087 s x 1e6 events/s, Hopping(10 s, 5 s) -> 216 windows).  The metric names
+"q3 join" beside "q5 agg": the q3 line (configs[2], 1e8 events) sits at top level under "q3", with its own roofline and
+CPU leg.  q2 / q8 (configs[1], [4]), q3 at 1e9 events, the "next" rows, a PCIe-inclusive q5 and a plan-level
+`collect` run are in "also"; "exchange_1rank" shows what the in-library exchange costs over the plain operators.
+
+N > 1 (`torchrun ... bench.py --gpus N`): north_star's configuration -- the SAME 1e9 bids in total, every window striped
+over the N ranks, q5.dag's Partial COUNT -> hash repartition of the groups (RCCL send / recv inside libflockgpu) ->
+FinalPartitioned COUNT / MAX / join -> all-reduce(MAX): "scaling": "strong", value = 1e9 bids / the slowest rank's
+time.  "also" then carries q8 / q3 key-partitioned the same way and the window-sharded q5 (every rank its own slice of
+the stream, no data-path collective: "weak").  `--mode windows` makes the window-sharded job the headline instead.
 
 roofline: dominant kernel's ALGORITHMIC bytes / its average launch duration measured
-with HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).
+with HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md);
+traffic = PMC-derived HBM bytes per launch from profiles/traffic.json (measured in separate rocprofv3 --pmc runs,
+"traffic_source" says so).
 cpu_baseline: the scalar C oracle (a port: the Rust/DataFusion reference cannot be built here), one window per
-thread on the host cores of this box, on a bounded sample of the same windows.
+thread on the host cores of this box, 10 timed passes over a bounded sample of the same windows (the reference's
+recipe: plan once, 10 timed executions, mean -- flock-function/src/aws/arch/source.rs:42-63), plus pyarrow / Acero
+running the same windows as a second, Arrow-native engine.
 """
 from __future__ import annotations
 
@@ -55,8 +61,9 @@ def parse():
     ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9, 13])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
-    ap.add_argument("--mode", choices=["windows", "exchange"], default="windows",
-                    help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all")
+    ap.add_argument("--mode", choices=["auto", "windows", "exchange"], default="auto",
+                    help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all "
+                         "inside libflockgpu; auto = windows at N = 1, exchange at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -122,13 +129,13 @@ class Striped:
     def rows(self):
         return self.bids.rows if self.q == 5 else self.auctions.rows + self.persons.rows
 
-    def run(self, ctx):
-        from flock_amd import distributed as D
+    def run(self, ctx, comm):
+        """The in-library exchange (include/flockgpu_comm.h): partition -> counts -> all-to-all -> regroup -> operator."""
         if self.q == 8:
-            return D.q8_exchange(ctx, self.persons, self.sched["person"], self.auctions, self.sched["auction"])
+            return ctx.q8_join_exchange(comm, self.persons, self.sched["person"], self.auctions, self.sched["auction"])
         if self.q == 3:
-            return D.q3_exchange(ctx, self.auctions, self.sched["auction"], self.persons, self.sched["person"])
-        return D.q5_exchange(ctx, self.bids, self.sched["bid"])
+            return ctx.q3_join_exchange(comm, self.auctions, self.sched["auction"], self.persons, self.sched["person"])
+        return ctx.q5_hot_items_exchange(comm, self.bids, self.sched["bid"])
 
 
 def run_steps(ctx, step, steps, warmup, barrier, only=None):
@@ -184,7 +191,9 @@ def roofline(q, stats, rel_rows):
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, not this one)" if traffic else None,
+            "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes), "launches": st["launches"],
             "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
 
@@ -202,11 +211,12 @@ def cpu_baseline(q, stream, threads):
     import oracle
     from flock_amd import query_window
     w = query_window(q)
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or min(64, os.cpu_count() or 1)
     oracle.lib()
+    acero = None
     if q in (2, 5, 7):
         sched = stream.window_schedule("bid", w)
-        budget_rows = 1.5e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here)
+        budget_rows = 6.0e8 if q == 5 else 1.0e8      # window rows (a bid of two hopping windows counts twice here): 64 windows of q5
         n_win, rows = 0, 0
         while n_win < sched.n_windows and (rows < budget_rows or (q != 5 and n_win < threads)):
             lo, hi = sched.window_rows(n_win)
@@ -226,6 +236,20 @@ def cpu_baseline(q, stream, threads):
                 oracle.q2_filter(auction[lo - lo0:hi - lo0], price[lo - lo0:hi - lo0])
         unique_rows = hi1 - lo0
         what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} bids (each bid counted once)"
+
+        def acero(i):     # the same window through Arrow C++ (pyarrow compute / acero), its own thread pool
+            import pyarrow as pa
+            import pyarrow.compute as pc
+            lo, hi = sched.window_rows(i)
+            if q == 5:
+                t = pa.table({"auction": auction[lo - lo0:hi - lo0]}).group_by("auction").aggregate([([], "count_all")])
+                return t.filter(pc.equal(t["count_all"], pc.max(t["count_all"]))).num_rows
+            if q == 7:
+                pr = pa.array(price[lo - lo0:hi - lo0])
+                return pc.sum(pc.equal(pr, pc.max(pr))).as_py()
+            a64 = pc.cast(pa.array(auction[lo - lo0:hi - lo0]), pa.int64())
+            mask = pc.equal(pc.subtract(a64, pc.multiply(pc.divide(a64, 123), 123)), 0)
+            return pa.table({"auction": auction[lo - lo0:hi - lo0], "price": price[lo - lo0:hi - lo0]}).filter(mask).num_rows
     elif q == 13:
         from flock_amd import synthetic_side_input
         sched = stream.window_schedule("bid", w)
@@ -282,17 +306,57 @@ def cpu_baseline(q, stream, threads):
                 oracle.q8_join(p_id[p0 - plo:p1 - plo], text.slice(p0 - plo, p1 - plo), seller[a0 - alo:a1 - alo])
         unique_rows = (ahi - alo) + (phi - plo)
         what = f"first {n_win} {w.kind}({w.size},{w.hop}) windows = {unique_rows} auction + person rows"
+
+        def acero(i):
+            import pyarrow as pa
+            import pyarrow.compute as pc
+            (a0, a1), (p0, p1) = sa.window_rows(i), sp.window_rows(i)
+            t = text.slice(p0 - plo, p1 - plo)
+            col = pa.Array.from_buffers(pa.utf8(), len(t), [None, pa.py_buffer(t.offsets), pa.py_buffer(t.data)])
+            if q == 3:
+                ta = pa.table({"seller": seller[a0 - alo:a1 - alo], "category": category[a0 - alo:a1 - alo]}).filter(pc.equal(pc.field("category"), 10))
+                tp = pa.table({"p_id": p_id[p0 - plo:p1 - plo], "state": col}).filter(pc.is_in(pc.field("state"), pa.array(["or", "id", "ca"])))
+                return ta.join(tp, keys="seller", right_keys="p_id", join_type="inner").num_rows
+            tp = pa.table({"p_id": p_id[p0 - plo:p1 - plo], "name": col}).group_by(["p_id", "name"]).aggregate([])
+            ts = pa.table({"seller": seller[a0 - alo:a1 - alo]}).group_by("seller").aggregate([])
+            return tp.join(ts, keys="p_id", right_keys="seller", join_type="inner").num_rows
+    numpy_leg = q in (4, 9, 13)            # row-at-a-time / numpy restatements hold the GIL: effectively one core
     one(0)  # warm (page-in)
-    passes, dt = 0, 0.0
-    t0 = time.perf_counter()
+    times = []
+    budget = time.perf_counter() + 20.0
     with ThreadPoolExecutor(max_workers=threads) as pool:
-        while dt < 0.6 and passes < 200:          # ~20 s of CPU work at 32 threads
+        while len(times) < 10 and (len(times) < 3 or time.perf_counter() < budget):   # the reference's recipe: 10 timed executions, mean
+            t0 = time.perf_counter()
             list(pool.map(one, range(n_win)))
-            passes += 1
-            dt = time.perf_counter() - t0
-    return {"value": round(unique_rows * passes / dt, 1), "unit": "rows/s", "cores": min(threads, n_win), "kind": "port",
-            "sample": what + f", one window per thread, {threads} threads, {passes} pass(es)", "seconds": round(dt, 2),
-            "cpu_seconds": round(dt * min(threads, n_win), 1), "host_cores_available": os.cpu_count()}
+            times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    out = {"value": round(unique_rows / mean, 1), "unit": "rows/s", "cores": 1 if numpy_leg else min(threads, n_win),
+           "kind": "port", "sample": what + f", one window per thread, {threads} threads, {len(times)} timed passes (mean)",
+           "seconds": round(sum(times), 2), "pass_seconds": {"mean": round(mean, 4), "min": round(min(times), 4), "max": round(max(times), 4)},
+           "value_best_pass": round(unique_rows / min(times), 1), "cpu_seconds": round(sum(times) * min(threads, n_win), 1),
+           "host_cores_available": os.cpu_count()}
+    if numpy_leg:
+        out["note"] = "numpy restatement under the GIL: one core does the work whatever the thread count; not a parallel CPU engine"
+    if acero is not None:
+        try:
+            import pyarrow as pa
+            n_ac = min(n_win, 8)
+            rows_ac = unique_rows * n_ac / n_win
+            acero(0)
+            t_ac, stop = [], time.perf_counter() + 10.0
+            while len(t_ac) < 10 and (len(t_ac) < 2 or time.perf_counter() < stop):
+                t0 = time.perf_counter()
+                for i in range(n_ac):
+                    acero(i)
+                t_ac.append(time.perf_counter() - t0)
+            m = sum(t_ac) / len(t_ac)
+            out["acero"] = {"value": round(rows_ac / m, 1), "unit": "rows/s", "cores": pa.cpu_count(), "kind": "port",
+                            "sample": f"pyarrow {pa.__version__} compute / acero over the first {n_ac} of those windows, one after the other on "
+                                      f"Arrow's own thread pool, {len(t_ac)} timed passes (mean)",
+                            "pass_seconds": {"mean": round(m, 4), "min": round(min(t_ac), 4), "max": round(max(t_ac), 4)}}
+        except Exception as e:
+            out["acero"] = {"error": repr(e)}
+    return out
 
 
 # ------------------------------------------------------------------ Yahoo Streaming Benchmark
@@ -498,6 +562,80 @@ def pcie_inclusive_q5(ctx, eps, seconds=100):
             "note": "pinned host auction column copied H2D every step, then q5 (copy and query not overlapped)"}
 
 
+def entry_for(ctx, q, seconds, eps, steps, warmup, no_cpu, threads, barrier=lambda: None):
+    """One window-sharded measurement of query `q` on this GPU: value, roofline, CPU legs."""
+    import torch
+    from flock_amd import run_query
+    s = make_stream(ctx, q, seconds, eps, 0)
+    dt, st, r = run_steps(ctx, lambda: run_query(ctx, q, s), steps, warmup, barrier, DOMINANT[q][0])
+    e = {"value": round(input_rows(q, s) * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3),
+         "input_rows": int(input_rows(q, s)), "windows": r.n_windows, "result_rows": int(r.rows), "seconds_of_events": seconds,
+         "roofline": roofline(q, st, rel_rows_of(s))}
+    if not no_cpu and seconds == DEFAULT_SECONDS[q]:
+        e["cpu_baseline"] = cpu_baseline(q, s, threads)
+    del s, r
+    torch.cuda.empty_cache()
+    return e
+
+
+def exchange_entry(ctx, comm, q, seconds, eps, steps, warmup, rank, world, barrier, reduce_max_sum):
+    """Query `q` with every window striped over the ranks of `comm` and repartitioned on its key inside libflockgpu."""
+    import torch
+    from flock_amd import query_window
+    full = make_stream(ctx, q, seconds, eps, 0)               # the SAME stream on every rank ...
+    st = Striped(ctx, q, full, rank, world)                   # ... of which this rank keeps its stripe of every pane
+    del full
+    torch.cuda.empty_cache()
+    rel = {"bid": st.bids.rows if st.bids else 0, "auction": st.auctions.rows if st.auctions else 0}
+    dt, stats, r = run_steps(ctx, lambda: st.run(ctx, comm), steps, warmup, barrier, DOMINANT[q][0])
+    dt_max, rows_all = reduce_max_sum(dt, float(st.rows()))
+    w = query_window(q)
+    e = {"value": round(rows_all * steps / dt_max, 1), "unit": "rows/s", "scaling": "strong", "ms_per_step": round(dt_max / steps * 1e3, 3),
+         "input_rows_all_gpus": int(rows_all), "input_rows_this_rank": int(st.rows()), "windows": int(r.n_windows),
+         "result_rows_rank0": int(r.rows), "seconds_of_events": seconds,
+         "workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {eps} events/s striped over {world} GPU(s)",
+         "parallelism": f"key-partitioned x{world}: hash repartition + {comm.transport} all-to-all inside libflockgpu",
+         "transport": comm.transport, "ranks": comm.size, "roofline": roofline(q, stats, rel),
+         "kernels_ms_rank0": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
+    del st, r
+    torch.cuda.empty_cache()
+    return e
+
+
+def plan_collect_pcie(gpu, eps, steps):
+    """`runtime.collect` over the q5 plan at the reference's granule (178 329-row bid batches, nexmark.rs:183-187): Arrow host
+    batches in -> staged / pinned H2D -> fused q5 -> pinned D2H out, one Hopping(10, 5) window per collect.  PCIe roofline: the
+    bytes that cross the bus (the scanned `auction` column in, the winners out) / 63 GB/s."""
+    import numpy as np
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext, collect
+    plan = open(os.path.join(ROOT, "tests", "golden", "plans", "q5.json")).read()
+    g = NEXMarkSource(10, eps, Window.hopping(10, 5), seed=7).generate_data(gpu, relations=("bid",))
+    cols = {k: getattr(g.bids, k).cpu().numpy() for k in ("auction", "bidder", "price", "b_date_time")}
+    n = len(cols["auction"])
+    gran = 178_329
+    batches = [pa.record_batch([pa.array(cols["auction"][i:i + gran]), pa.array(cols["bidder"][i:i + gran]), pa.array(cols["price"][i:i + gran]),
+                                pa.array(cols["b_date_time"][i:i + gran]).cast(pa.timestamp("ms"))], names=["auction", "bidder", "price", "b_date_time"])
+               for i in range(0, n, gran)]
+    ctx = ExecutionContext([plan], gpu=gpu)
+    out = None
+    for _ in range(2):
+        out = collect(ctx, [[batches]])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = collect(ctx, [[batches]])
+    dt = (time.perf_counter() - t0) / steps
+    ctx.close()
+    moved = 4.0 * n + 12.0 * out[0][0].num_rows
+    return {"value": round(n / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "input_rows": int(n), "batches": len(batches),
+            "granule_rows": gran, "result_rows": int(out[0][0].num_rows),
+            "roofline": {"bound": "pcie", "achieved": round(moved / dt / 1e9, 2), "peak": 63.0, "unit": "GB/s", "frac": round(moved / dt / 1e9 / 63.0, 4),
+                         "algorithmic_bytes_per_step": int(moved)},
+            "note": "pageable pyarrow buffers: staged through the plan's pinned ring (host memcpy + async H2D per 8 MiB chunk); only the column "
+                    "the plan reads crosses the bus; feed -> execute -> clean per window, one device synchronisation per collect"}
+
+
 def main():
     args = parse()
     import torch
@@ -508,166 +646,179 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: flock_amd has no CPU path")
     torch.cuda.set_device(local)
-    force_side = os.environ.get("FLOCK_BENCH_EXCHANGE_SIDE") == "1"   # run the N > 1 side measurement at N = 1 (testing)
-    if world > 1 or args.mode == "exchange" or force_side:
+    mode = args.mode if args.mode != "auto" else ("exchange" if world > 1 else "windows")
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    if world > 1:
         tok = torch.zeros(1, device=f"cuda:{local}")
 
         def barrier():
             dist.all_reduce(tok)
             torch.cuda.synchronize()
+
+        def reduce_max_sum(dt, rows):
+            t = torch.tensor([dt, rows], dtype=torch.float64, device=f"cuda:{local}")
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(tmax[0]), float(t[1])
     else:
         def barrier():
-            pass
+            torch.cuda.synchronize()
 
-    from flock_amd import GpuContext, query_window, run_query
+        def reduce_max_sum(dt, rows):
+            return dt, rows
+
+    from flock_amd import Comm, GpuContext, _ffi, query_window, run_query
     ctx = GpuContext(local)
     q = args.query
-    if args.mode == "exchange" and q == 2:
-        raise SystemExit("q2 has no exchange step (embarrassingly parallel)")
+    if mode == "exchange" and q not in (3, 5, 8):
+        raise SystemExit(f"q{q} has no exchange step")
     seconds = args.seconds or DEFAULT_SECONDS[q]
-    if args.mode == "exchange":
-        full = make_stream(ctx, q, seconds, args.eps, 0)          # the SAME stream on every rank ...
-        striped = Striped(ctx, q, full, rank, world)              # ... of which this rank keeps its stripe of every pane
-        rel_rows = {"bid": striped.bids.rows if striped.bids else 0, "auction": striped.auctions.rows if striped.auctions else 0}
-        rows = striped.rows()
-        del full
-        torch.cuda.empty_cache()
-        dt, stats, res = run_steps(ctx, lambda: striped.run(ctx), args.steps, args.warmup, barrier, DOMINANT[q][0])
-        stream = None
-    else:
+    w = query_window(q)
+
+    # the in-library communicator: RCCL, bootstrapped through torch.distributed (or directly at N = 1)
+    comm, comm_error = None, None
+
+    def make_comm():
+        import ctypes as C
+        if world > 1:
+            return Comm.from_torch_distributed(ctx)
+        lib = _ffi.load()
+        buf = C.create_string_buffer(128)
+        if lib.flockgpu_comm_unique_id(buf) != 0:
+            raise RuntimeError("flockgpu_comm_unique_id failed")
+        h = C.c_void_p()
+        ctx._check(lib.flockgpu_comm_init_rank(ctx._h, buf.raw, 1, 0, C.byref(h)))
+        return Comm(h, lib)
+
+    out, stream, res = None, None, None
+    if mode == "exchange":
+        try:
+            comm = make_comm()
+            head = exchange_entry(ctx, comm, q, seconds, args.eps, args.steps, args.warmup, rank, world, barrier, reduce_max_sum)
+            if rank == 0:
+                out = {"metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": head["value"], "unit": "rows/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+                       "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                       "config": {"workload": head["workload"], "query": f"q{q}", "input_rows_all_gpus": head["input_rows_all_gpus"],
+                                  "input_rows_per_gpu": head["input_rows_this_rank"], "windows": head["windows"], "parallelism": head["parallelism"],
+                                  "collective": {"library": "RCCL (ncclSend / ncclRecv groups inside libflockgpu)", "ranks": head["ranks"],
+                                                 "transport": head["transport"]},
+                                  "result_rows_rank0": head["result_rows_rank0"]},
+                       "roofline": head["roofline"], "cpu_baseline": None, "kernels_ms_rank0": head["kernels_ms_rank0"]}
+        except Exception as e:   # the exchange must never take the run with it: fall back to the window-sharded job
+            comm_error = repr(e)
+            mode = "windows"
+    if mode == "windows":
         stream = make_stream(ctx, q, seconds, args.eps, rank)
         rel_rows, rows = rel_rows_of(stream), input_rows(q, stream)
         dt, stats, res = run_steps(ctx, lambda: run_query(ctx, q, stream), args.steps, args.warmup, barrier, DOMINANT[q][0])
-    if world > 1:
-        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device=f"cuda:{local}")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt_max, rows_all = float(tmax[0]), float(t[1])
-    else:
-        dt_max, rows_all = dt, float(rows)
-
-    out = None
-    if rank == 0:
-        w = query_window(q)
-        n_windows = getattr(res, "n_windows", None) or (len(res.offsets) - 1)
-        n_result = int(res.rows) if hasattr(res, "rows") else int(len(res.auction))
-        windows = args.mode == "windows"
-        out = {
-            "metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": round(rows_all * args.steps / dt_max, 1),
-            "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak" if windows else "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s"
-                                   + (" per GPU" if windows else f" striped over {world} GPU(s)"),
-                       "query": f"q{q}", "input_rows_per_gpu": int(rows), "windows_per_gpu": int(n_windows),
-                       "parallelism": (f"window-sharded x{world} (no data-path collective)" if windows
-                                       else f"key-partitioned x{world} (hash repartition + RCCL all-to-all)"),
-                       "result_rows": n_result},
-            "roofline": roofline(q, stats, rel_rows),
-            "cpu_baseline": None,
-        }
-        if world == 1 and not args.no_cpu and stream is not None:
-            out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
-    # side measurements (N = 1 only): the other BASELINE configs, each with its own roofline and CPU leg
-    if rank == 0 and world == 1 and not args.no_also and args.mode == "windows" and not force_side:
-        also = {}
+        dt_max, rows_all = reduce_max_sum(dt, float(rows))
+        if rank == 0:
+            out = {"metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": round(rows_all * args.steps / dt_max, 1),
+                   "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "int32", "data": "synthetic",
+                   "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s per GPU", "query": f"q{q}",
+                              "input_rows_per_gpu": int(rows), "windows_per_gpu": int(res.n_windows),
+                              "parallelism": f"window-sharded x{world} (no data-path collective)", "result_rows": int(res.rows)},
+                   "roofline": roofline(q, stats, rel_rows), "cpu_baseline": None}
+            if comm_error:
+                out["exchange_error"] = comm_error
+            if world == 1 and not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
         del stream, res
         torch.cuda.empty_cache()
-        steps2 = max(2, min(args.steps, 3))
-        for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q3", 3, DEFAULT_SECONDS[3]), ("q8", 8, DEFAULT_SECONDS[8]),
-                                ("q5", 5, DEFAULT_SECONDS[5]), ("q3_1e9_events", 3, 1000), ("q2_1e9_bids", 2, 1087),
-                                ("q7_next", 7, DEFAULT_SECONDS[7]), ("q9_next", 9, DEFAULT_SECONDS[9]), ("q4_next", 4, DEFAULT_SECONDS[4]),
-                                ("q13_next", 13, DEFAULT_SECONDS[13])):
+
+    steps2 = max(2, min(args.steps, 3))
+    # ---- N = 1: the other BASELINE configs; q3 (named by the metric) at top level
+    if world == 1 and not args.no_also and rank == 0 and out is not None and mode == "windows" and args.mode != "exchange":
+        if q != 3:
+            try:
+                out["q3"] = dict(entry_for(ctx, 3, DEFAULT_SECONDS[3], args.eps, steps2, 1, args.no_cpu, args.cpu_threads),
+                                 workload=f"NEXMark q3 elementwise over {DEFAULT_SECONDS[3]} s x {args.eps} events/s (BASELINE.json configs[2])")
+            except Exception as e:
+                out["q3"] = {"error": repr(e)}
+        also = {}
+        for label, q2, secs in (("q2", 2, DEFAULT_SECONDS[2]), ("q8", 8, DEFAULT_SECONDS[8]), ("q5", 5, DEFAULT_SECONDS[5]),
+                                ("q3_1e9_events", 3, 1000), ("q2_1e9_bids", 2, 1087), ("q7_next", 7, DEFAULT_SECONDS[7]),
+                                ("q9_next", 9, DEFAULT_SECONDS[9]), ("q4_next", 4, DEFAULT_SECONDS[4]), ("q13_next", 13, DEFAULT_SECONDS[13])):
             if q2 == q and secs == seconds:
                 continue
             try:
-                s2 = make_stream(ctx, q2, secs, args.eps, 0)
-                d2, st2, r2 = run_steps(ctx, lambda: run_query(ctx, q2, s2), steps2, 1, lambda: None, DOMINANT[q2][0])
-                also[label] = {"value": round(input_rows(q2, s2) * steps2 / d2, 1), "unit": "rows/s",
-                               "ms_per_step": round(d2 / steps2 * 1e3, 3), "input_rows": int(input_rows(q2, s2)),
-                               "windows": r2.n_windows, "result_rows": int(r2.rows), "seconds_of_events": secs,
-                               "roofline": roofline(q2, st2, rel_rows_of(s2))}
-                if not args.no_cpu and secs == DEFAULT_SECONDS[q2]:
-                    also[label]["cpu_baseline"] = cpu_baseline(q2, s2, args.cpu_threads)
-                del s2, r2
-                torch.cuda.empty_cache()
+                also[label] = entry_for(ctx, q2, secs, args.eps, steps2, 1, args.no_cpu, args.cpu_threads)
             except Exception as e:  # a side measurement must never hide the headline
                 also[label] = {"error": repr(e)}
-        try:
-            also["q11_next"] = q11_side(ctx, args.eps, steps2, args.no_cpu)
-        except Exception as e:
-            also["q11_next"] = {"error": repr(e)}
-        try:
-            also["json_ingest_next"] = json_side(ctx, steps2, args.no_cpu)
-        except Exception as e:
-            also["json_ingest_next"] = {"error": repr(e)}
-        try:
-            also["payload_next"] = payload_side(ctx, steps2, args.no_cpu)
-        except Exception as e:
-            also["payload_next"] = {"error": repr(e)}
-        try:
-            also["ysb_next"] = ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)
-        except Exception as e:
-            also["ysb_next"] = {"error": repr(e)}
-        try:
-            also["q5_pcie_inclusive"] = pcie_inclusive_q5(ctx, args.eps)
-        except Exception as e:
-            also["q5_pcie_inclusive"] = {"error": repr(e)}
-        out["also"] = also
-    # side measurement at N > 1: the SAME headline relations key-partitioned across the ranks (BASELINE configs 4 and 5:
-    # hash repartition + RCCL all-to-all + per-rank operators + winner merge), strong scaling.  The main line above is the
-    # window-sharded job; this shows what the exchange step costs on the same node.  A watchdog prints the main line and
-    # leaves if a collective does not come back, so that the side measurement can never take the headline with it.
-    if (world > 1 or force_side) and not args.no_also and args.mode == "windows":
-        try:
-            import threading
-
-            def bail():
-                if rank == 0 and out is not None:
-                    out["also"] = {"exchange": {"error": "watchdog: exchange side measurement did not finish"}}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-            dog = threading.Timer(240.0, bail)
-            dog.daemon = True
-            dog.start()
-            ex = {}
+        for label, fn in (("q11_next", lambda: q11_side(ctx, args.eps, steps2, args.no_cpu)),
+                          ("json_ingest_next", lambda: json_side(ctx, steps2, args.no_cpu)),
+                          ("payload_next", lambda: payload_side(ctx, steps2, args.no_cpu)),
+                          ("ysb_next", lambda: ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)),
+                          ("q5_pcie_inclusive", lambda: pcie_inclusive_q5(ctx, args.eps)),
+                          ("plan_collect_pcie", lambda: plan_collect_pcie(ctx, args.eps, steps2))):
             try:
-                del stream, res
-            except Exception:
-                pass
-            torch.cuda.empty_cache()
-            steps2 = max(2, min(args.steps, 3))
-            for label, q2, secs in (("q5_exchange", 5, DEFAULT_SECONDS[5]), ("q8_exchange", 8, DEFAULT_SECONDS[8])):
+                also[label] = fn()
+            except Exception as e:
+                also[label] = {"error": repr(e)}
+        # what the exchange costs over the plain operators on one rank (same relations, RCCL communicator of one rank)
+        ex = {}
+        try:
+            comm = comm or make_comm()
+            for label, q2 in (("q5", 5), ("q3", 3), ("q8", 8)):
                 try:
-                    full = make_stream(ctx, q2, secs, args.eps, 0)
-                    st = Striped(ctx, q2, full, rank, world)
-                    del full
-                    torch.cuda.empty_cache()
-                    d2, st2, r2 = run_steps(ctx, lambda: st.run(ctx), steps2, 1, barrier, DOMINANT[q2][0])
-                    t = torch.tensor([d2, float(st.rows())], dtype=torch.float64, device=f"cuda:{local}")
-                    tmax = t.clone()
-                    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    ex[label] = {"value": round(float(t[1]) * steps2 / float(tmax[0]), 1), "unit": "rows/s", "scaling": "strong",
-                                 "ms_per_step": round(float(tmax[0]) / steps2 * 1e3, 3), "input_rows_all_gpus": int(float(t[1])),
-                                 "parallelism": f"key-partitioned x{world} (hash repartition + RCCL all-to-all)",
-                                 "result_rows_rank0": int(r2.rows) if hasattr(r2, "rows") else None,
-                                 "kernels_ms_rank0": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st2.items()}}
-                    del st, r2
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    ex[label] = {"error": repr(e)}
-            dog.cancel()
+                    # (q3 at 1e9 events: at its 1e8-event BASELINE size the whole query is three host synchronisations long)
+                    e = exchange_entry(ctx, comm, q2, 1000 if q2 == 3 else DEFAULT_SECONDS[q2], args.eps, steps2, 1, 0, 1, barrier, reduce_max_sum)
+                    base = out if q2 == q else (also.get("q3_1e9_events") if q2 == 3 else also.get(f"q{q2}"))
+                    if base and "ms_per_step" in base:
+                        e["over_window_sharded_step"] = round(e["ms_per_step"] / base["ms_per_step"], 2)
+                    ex[label] = e
+                except Exception as e2:
+                    ex[label] = {"error": repr(e2)}
+        except Exception as e:
+            ex = {"error": repr(e)}
+        also["exchange_1rank"] = ex
+        out["also"] = also
+    # ---- N > 1: q8 / q3 key-partitioned the same way, and the window-sharded q5 beside the headline.  A watchdog prints the
+    # headline and leaves if a collective does not come back, so that a side measurement can never take it along.
+    if world > 1 and not args.no_also:
+        import threading
+
+        def bail():
             if rank == 0 and out is not None:
-                out["also"] = ex
-        except Exception as e:  # never let the side measurement take the headline with it
-            if rank == 0 and out is not None:
-                out["also"] = {"exchange": {"error": repr(e)}}
+                out["also"] = {"error": "watchdog: side measurements did not finish"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(300.0, bail)
+        dog.daemon = True
+        dog.start()
+        also = {}
+        try:
+            if comm is not None:
+                for label, q2 in (("q8_exchange", 8), ("q3_exchange", 3), ("q5_exchange", 5)):
+                    if q2 == q and mode == "exchange":
+                        continue
+                    try:
+                        also[label] = exchange_entry(ctx, comm, q2, 1000 if q2 == 3 else DEFAULT_SECONDS[q2], args.eps, steps2, 1, rank, world, barrier,
+                                                     reduce_max_sum)
+                    except Exception as e:
+                        also[label] = {"error": repr(e)}
+            if mode == "exchange":
+                s5 = make_stream(ctx, q, seconds, args.eps, rank)
+                d2, st2, r2 = run_steps(ctx, lambda: run_query(ctx, q, s5), steps2, 1, barrier, DOMINANT[q][0])
+                dmax, rall = reduce_max_sum(d2, float(input_rows(q, s5)))
+                also[f"q{q}_window_sharded"] = {"value": round(rall * steps2 / dmax, 1), "unit": "rows/s", "scaling": "weak",
+                                                "ms_per_step": round(dmax / steps2 * 1e3, 3), "input_rows_all_gpus": int(rall),
+                                                "parallelism": f"window-sharded x{world}: every rank its own {seconds} s slice of the stream, no data-path collective",
+                                                "roofline": roofline(q, st2, rel_rows_of(s5))}
+                del s5, r2
+        except Exception as e:
+            also["error"] = repr(e)
+        dog.cancel()
+        if rank == 0 and out is not None:
+            out["also"] = also
+    if comm is not None:
+        comm.close()
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()

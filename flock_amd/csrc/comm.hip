@@ -80,8 +80,7 @@ int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, in
     int64_t *d = nullptr, *h = nullptr;
     FG_TRY(arena_get_t(ctx, "comm.counts", (size_t)2 * n * m + 2, &d));
     FG_TRY(pinned_get_t(ctx, "comm.counts", (size_t)2 * n * m + 2, &h));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned staging may still be in flight from the previous exchange
-    std::copy(send, send + (size_t)n * m, h);
+    std::copy(send, send + (size_t)n * m, h);  // (the staging's previous use was read back under a synchronisation)
     FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(int64_t) * (size_t)n * m, hipMemcpyHostToDevice, ctx->stream));
     FG_NCCL(ctx, ncclGroupStart());
     for (int p = 0; p < n; ++p) {
@@ -160,7 +159,6 @@ int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, uint64_t *vals, int m) {
     uint64_t *d = nullptr, *h = nullptr;
     FG_TRY(arena_get_t(ctx, "comm.reduce", (size_t)m + 2, &d));
     FG_TRY(pinned_get_t(ctx, "comm.reduce", (size_t)m + 2, &h));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::copy(vals, vals + m, h);
     FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(uint64_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
     FG_NCCL(ctx, ncclAllReduce(d, d, (size_t)m, ncclUint64, ncclMax, c->nccl, ctx->stream));
@@ -171,28 +169,27 @@ int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, uint64_t *vals, int m) {
 }
 
 // ------------------------------------------------------------------ device helpers of the shuffle
-// bytes of the Utf8 values each destination run will carry: sums[d] += len(src[rows[i]]) for the rows i of run d
-__global__ __launch_bounds__(kBlock) void run_bytes_kernel(const int32_t *__restrict__ src_off, const int32_t *__restrict__ rows, int64_t n,
-                                                           const int64_t *__restrict__ run_start, int32_t n_runs, unsigned long long *sums) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
-        int32_t d = -1;
-        unsigned long long len = 0;
-        if (i < n) {
-            d = 0;
-            while (d + 1 < n_runs && run_start[d + 1] <= i) ++d;
-            const int32_t r = rows[i];
-            len = (unsigned long long)(src_off[r + 1] - src_off[r]);
-        }
-        // a wave's 64 consecutive rows nearly always lie in one run: one atomic per wave, not 64 on the same address
-        const int32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(d != d0) == 0) {
-            const unsigned long long tot = wave_sum_u64(len);
-            if (lane_id() == 0 && d0 >= 0 && tot) atomicAdd(&sums[d0], tot);
-        } else if (d >= 0 && len) {
-            atomicAdd(&sums[d], len);
-        }
+// bytes of the Utf8 values each destination run will carry: grid (kRunBlocks / n_runs, n_runs), block (x, d) sums the lengths of its share of
+// run d's rows and adds ONE value to sums[d] (one atomic per row -- or per wave -- on n_runs addresses is a serial chain: 3.7 ms
+// for 2e7 rows)
+constexpr int kRunBlocks = 2048;  // workgroups over all runs together: grid.x = kRunBlocks / n_runs shares per run
+__global__ __launch_bounds__(kBlock) void run_bytes_kernel(const int32_t *__restrict__ src_off, const int32_t *__restrict__ rows,
+                                                           const int64_t *__restrict__ run_start, unsigned long long *sums) {
+    __shared__ unsigned long long s_part[kWavesPerBlock];
+    const int d = blockIdx.y;
+    const int64_t lo = run_start[d], hi = run_start[d + 1];
+    unsigned long long len = 0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kBlock) {
+        const int32_t r = rows[i];
+        len += (unsigned long long)(src_off[r + 1] - src_off[r]);
+    }
+    len = wave_sum_u64(len);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) tot += s_part[w];
+        if (tot) atomicAdd(&sums[d], tot);
     }
 }
 // out[dst[w] + i] = in[src[w] + i] for i < len[w]: the kept windows' winners, closed up
@@ -206,6 +203,10 @@ __global__ __launch_bounds__(kBlock) void copy_runs_kernel(const int64_t *__rest
         out_n[d + i] = in_n[s + i];
     }
 }
+// run_start[d] = first send row of destination d = group_off[d * n_win]
+__global__ void pick_run_starts_kernel(const int64_t *__restrict__ group_off, int32_t n_win, int32_t n, int64_t *__restrict__ run_start) {
+    for (int d = threadIdx.x; d <= n; d += 64) run_start[d] = group_off[(int64_t)d * n_win];
+}
 // Utf8 end offsets of a gathered column, made relative to the byte start of their run (out[i] = off[i + 1] - off[start of run]) on the
 // sender; on the receiver the byte position of the run in the received buffer is added back (delta per run)
 __global__ __launch_bounds__(kBlock) void run_rebase_kernel(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ run_start,
@@ -216,16 +217,12 @@ __global__ __launch_bounds__(kBlock) void run_rebase_kernel(const int32_t *__res
         out[i] = (int32_t)((int64_t)in[i] + run_delta[d]);
     }
 }
-// index[i] = position in the received (source-major) buffer of the i-th row in (window, source) order
+// index[i] = position in the received (source-major) buffer of the i-th row in (window, source) order; one workgroup per run
 __global__ __launch_bounds__(kBlock) void regroup_index_kernel(const int64_t *__restrict__ out_start, const int64_t *__restrict__ src_start,
-                                                               int32_t n_runs, int64_t n, int32_t *__restrict__ index) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int32_t lo = 0, hi = n_runs;  // out_start[lo] <= i < out_start[hi]
-        while (hi - lo > 1) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (out_start[mid] <= i) lo = mid; else hi = mid;
-        }
-        index[i] = (int32_t)(src_start[lo] + (i - out_start[lo]));
+                                                               int32_t n_runs, int32_t *__restrict__ index) {
+    for (int32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        const int64_t o = out_start[run], n = out_start[run + 1] - o, s0 = src_start[run];
+        for (int64_t j = threadIdx.x; j < n; j += kBlock) index[o + j] = (int32_t)(s0 + j);
     }
 }
 
@@ -261,18 +258,18 @@ struct XRecv {
 int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &name, const std::vector<XCol> &cols, int key_col, int64_t rows,
                       const flockgpu_windows *win, XRecv *out) {
     const int n = c->n, n_win = win->n_windows;
-    // the pinned staging of `upload` below is rewritten by the next exchange under this name: everything queued from it is done
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    flockgpu_partition_result part{};
-    FG_TRY(flockgpu_partition_by_key(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part));  // synchronises
-    const int64_t *pw = part.part_win_offsets;  // n * n_win + 1, destination-major
-    const int64_t n_send = part.rows;
-    std::vector<int64_t> run_start((size_t)n + 1);
-    for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
+    // ---- partition, send-order gathers and the per-destination Utf8 byte counts are queued back to back; the host waits ONCE
+    // for the group offsets, the Utf8 totals and the run bytes together.  (No wait for the pinned staging of `upload`: the previous
+    // call that used these names ended with the operator's own synchronisation.)
+    const int32_t *part_rows = nullptr;
+    const int64_t *d_group_off = nullptr, *pw = nullptr;  // pw: n * n_win + 1 group offsets, destination-major (pinned, valid after the wait)
+    int64_t n_send = 0;
+    FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send));
     int64_t *d_run_start = nullptr;
-    FG_TRY(upload(ctx, name + ".run_start", run_start.data(), (size_t)n + 1, &d_run_start));
+    FG_TRY(arena_get_t(ctx, (name + ".run_start").c_str(), (size_t)n + 2, &d_run_start));
+    hipLaunchKernelGGL(pick_run_starts_kernel, dim3(1), dim3(64), 0, ctx->stream, d_group_off, n_win, n, d_run_start);
+    FG_TRY(check_launch(ctx, "pick_run_starts_kernel"));
 
-    // ---- send order: fixed-width columns are gathered right away; Utf8 columns share one synchronisation
     struct Sent {
         const void *values = nullptr;
         flockgpu_utf8 u{};
@@ -287,29 +284,31 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         const std::string key = name + ".send" + std::to_string(i);
         if (col.utf8()) {
             ++n_utf8;
-            FG_TRY(gather_utf8_begin(ctx, key.c_str(), flockgpu_utf8{col.offsets, static_cast<const uint8_t *>(col.values)}, part.row, n_send, &sent[i].g));
+            FG_TRY(gather_utf8_begin(ctx, key.c_str(), flockgpu_utf8{col.offsets, static_cast<const uint8_t *>(col.values)}, part_rows, n_send, &sent[i].g));
             FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
             FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
             FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
             if (n_send > 0) {
-                hipLaunchKernelGGL(run_bytes_kernel, dim3(grid_for(ctx, n_send)), dim3(kBlock), 0, ctx->stream, col.offsets, part.row, n_send, d_run_start, n,
+                LaunchScope ls(ctx, "run_bytes_kernel");
+                hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, part_rows, d_run_start,
                                    sent[i].d_run_bytes);
-                FG_TRY(check_launch(ctx, "run_bytes_kernel"));
             }
+            FG_TRY(check_launch(ctx, "run_bytes_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         } else {
             void *p = nullptr;
             FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
-            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), part.row, n_send, static_cast<int32_t *>(p)));
-            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), part.row, n_send, static_cast<int64_t *>(p)));
+            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), part_rows, n_send, static_cast<int32_t *>(p)));
+            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), part_rows, n_send, static_cast<int64_t *>(p)));
             sent[i].values = p;
         }
     }
-    if (n_utf8) {
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < cols.size(); ++i)
-            if (cols[i].utf8()) FG_TRY(gather_utf8_finish(ctx, sent[i].g, &sent[i].u, &sent[i].bytes));
-    }
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < cols.size(); ++i)
+        if (cols[i].utf8()) FG_TRY(gather_utf8_finish(ctx, sent[i].g, &sent[i].u, &sent[i].bytes));
+    std::vector<int64_t> run_start((size_t)n + 1);
+    for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
+    if (run_start[(size_t)n] != n_send) return fail(ctx, FLOCKGPU_ERR_HIP, "exchange: the partition pass covered %lld of %lld rows", (long long)run_start[(size_t)n], (long long)n_send);
 
     // ---- counts: rows per (destination, window) + bytes per Utf8 column per destination, one message per peer
     const int m = n_win + n_utf8;
@@ -356,10 +355,12 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     FG_TRY(upload(ctx, name + ".out_start", out_start.data(), out_start.size(), &d_out_start));
     FG_TRY(upload(ctx, name + ".src_start", src_start.data(), src_start.size(), &d_src_start));
     FG_TRY(arena_get_t(ctx, (name + ".index").c_str(), (size_t)n_recv + 4, &d_index));
-    if (n_recv > 0) {
-        hipLaunchKernelGGL(regroup_index_kernel, dim3(grid_for(ctx, n_recv)), dim3(kBlock), 0, ctx->stream, d_out_start, d_src_start, n_runs, n_recv, d_index);
-        FG_TRY(check_launch(ctx, "regroup_index_kernel"));
+    if (n_recv > 0 && n_runs > 0) {
+        LaunchScope ls(ctx, "regroup_index_kernel");
+        hipLaunchKernelGGL(regroup_index_kernel, dim3((unsigned)std::min<int64_t>(n_runs, (int64_t)ctx->num_cus * 32)), dim3(kBlock), 0, ctx->stream, d_out_start,
+                           d_src_start, n_runs, d_index);
     }
+    FG_TRY(check_launch(ctx, "regroup_index_kernel"));
 
     // ---- one all-to-all per column buffer, then the regrouping take
     out->cols.assign(cols.size(), DevColumn{});
@@ -369,6 +370,7 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     // Utf8 regroup takes share one synchronisation as well
     std::vector<Utf8Gather> regroup(cols.size());
     std::vector<flockgpu_utf8> recv_u(cols.size());
+    std::vector<int64_t> recv_bytes_total(cols.size(), 0);
     for (size_t i = 0; i < cols.size(); ++i) {
         const XCol &col = cols[i];
         const std::string key = name + ".recv" + std::to_string(i);
@@ -422,20 +424,17 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
             FG_TRY(check_launch(ctx, "run_rebase_kernel"));
         }
         recv_u[i] = flockgpu_utf8{off_recv, bytes_recv};
+        recv_bytes_total[i] = rb[(size_t)n];
         FG_TRY(gather_utf8_begin(ctx, key.c_str(), recv_u[i], d_index, n_recv, &regroup[i]));
     }
-    if (n_utf8) {
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < cols.size(); ++i) {
-            if (!cols[i].utf8()) continue;
-            flockgpu_utf8 fin{};
-            int64_t nbytes = 0;
-            FG_TRY(gather_utf8_finish(ctx, regroup[i], &fin, &nbytes));
-            out->cols[i].type = ColType::UTF8;
-            out->cols[i].values = fin.data;
-            out->cols[i].offsets = fin.offsets;
-            out->cols[i].bytes = nbytes;
-        }
+    for (size_t i = 0; i < cols.size(); ++i) {
+        if (!cols[i].utf8()) continue;
+        flockgpu_utf8 fin{};
+        FG_TRY(gather_utf8_finish_known(ctx, regroup[i], recv_bytes_total[i], &fin));  // a permutation keeps the byte total: no host wait
+        out->cols[i].type = ColType::UTF8;
+        out->cols[i].values = fin.data;
+        out->cols[i].offsets = fin.offsets;
+        out->cols[i].bytes = recv_bytes_total[i];
     }
     return FLOCKGPU_OK;
 }

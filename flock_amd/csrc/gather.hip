@@ -593,7 +593,7 @@ void gather_utf8_narrow(Utf8Gather *g, int64_t n) {
     g->tiles = n > 0 ? div_up(n, kLenTile) : 0;
 }
 
-int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes) {
+static int gather_utf8_emit(flockgpu_ctx *ctx, const Utf8Gather &g, uint64_t total, flockgpu_utf8 *out, int64_t *n_bytes) {
     const std::string k_off = g.name + ".off", k_bytes = g.name + ".bytes";
     int32_t *o_off = nullptr;
     uint8_t *o_b = nullptr;
@@ -607,7 +607,6 @@ int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *ou
         out->data = o_b;
         return FLOCKGPU_OK;
     }
-    const uint64_t total = *g.h_total;
     if (total > 0x7fffffffull)
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)",
                     g.name.c_str());
@@ -621,6 +620,15 @@ int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *ou
     out->data = o_b;
     *n_bytes = (int64_t)total;
     return FLOCKGPU_OK;
+}
+
+int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *out, int64_t *n_bytes) {
+    return gather_utf8_emit(ctx, g, g.n > 0 ? *g.h_total : 0, out, n_bytes);
+}
+
+int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out) {
+    int64_t nb = 0;
+    return gather_utf8_emit(ctx, g, (uint64_t)std::max<int64_t>(total_bytes, 0), out, &nb);
 }
 
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

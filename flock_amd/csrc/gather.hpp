@@ -56,6 +56,14 @@ int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *ou
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
                 flockgpu_utf8 *out, int64_t *n_bytes);
 
+// Utf8 gather whose total byte count the caller already knows (a permutation of a column of known size): no host wait.
+int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out);
+
+// flockgpu_partition_by_key without its host wait (shuffle.hip): rows grouped by (destination, window) on the device, the
+// n_parts * n_win + 1 group offsets on the device and queued into pinned memory (valid after the next stream synchronisation).
+int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win, int32_t n_parts,
+                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out);
+
 // In-place inclusive scan of n int32 values; `name` keys the scan-state arena buffers.
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n);
 

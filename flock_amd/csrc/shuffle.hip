@@ -99,12 +99,15 @@ __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *_
 
 }  // namespace
 
-extern "C" {
+namespace flockgpu {
 
-int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win,
-                              int32_t n_parts, flockgpu_partition_result *out) {
+// The partition pass without its host wait: the row numbers grouped by (destination, window) and the n_parts * n_win + 1
+// group offsets -- on the device (*d_group_off) and queued for copy into pinned memory (*h_group_off, valid after the next
+// synchronisation of the ctx stream).  The number of rows written is known up front: every row of every window.
+int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win, int32_t n_parts,
+                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
-    if (!out || rows < 0 || (rows > 0 && !keys)) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: null argument");
+    if (rows < 0 || (rows > 0 && !keys)) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: null argument");
     if (n_parts < 1 || n_parts > kMaxParts)
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: n_parts must be in [1, %d]", kMaxParts);
     FG_TRY(check_windows(ctx, win, rows, "partition"));
@@ -125,11 +128,23 @@ int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t ro
     if (slots > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: too many (destination, tile) pairs");
     const size_t n_groups = (size_t)n_parts * n_win;
 
-    // first pseudo-tile of every (destination, window) group: destination-major
+    // first pseudo-tile of every (destination, window) group: destination-major.  Rebuilt only when the schedule changes
+    // (the pinned staging of the previous upload may still be in flight otherwise).
     int32_t *d_first = nullptr, *h_first = nullptr;
     FG_TRY(arena_get_t(ctx, "partition.first", n_groups + 1, &d_first));
     FG_TRY(pinned_get_t(ctx, "partition.first", n_groups + 1, &h_first));
-    {
+    std::vector<int64_t> &first_key = ctx->host_i64["partition.first_key"];
+    std::vector<int64_t> key_now;
+    key_now.reserve((size_t)2 * n_win + 3);
+    key_now.push_back(n_parts);
+    key_now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_first));
+    key_now.push_back((int64_t)reinterpret_cast<uintptr_t>(st.tiles));
+    for (int w = 0; w < n_win; ++w) {
+        key_now.push_back(sb[w]);
+        key_now.push_back(se[w]);
+    }
+    if (first_key != key_now) {
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         int64_t tiles = 0;
         std::vector<int32_t> tf(n_win + 1);
         for (int w = 0; w < n_win; ++w) {
@@ -139,8 +154,9 @@ int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t ro
         for (int p = 0; p < n_parts; ++p)
             for (int w = 0; w < n_win; ++w) h_first[(size_t)p * n_win + w] = (int32_t)((int64_t)p * st.n_tiles + tf[w]);
         h_first[n_groups] = (int32_t)slots;
+        FG_HIP(ctx, hipMemcpyAsync(d_first, h_first, sizeof(int32_t) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
+        first_key = key_now;
     }
-    FG_HIP(ctx, hipMemcpyAsync(d_first, h_first, sizeof(int32_t) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
 
     uint32_t *counts = nullptr;
     uint64_t *tile_base = nullptr;
@@ -165,10 +181,30 @@ int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t ro
     }
     FG_TRY(check_launch(ctx, "partition_emit_kernel"));
     FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * (n_groups + 1), hipMemcpyDeviceToHost, ctx->stream));
+    *d_rows = o_rows;
+    *d_group_off = d_off;
+    *h_group_off = h_off;
+    *n_out = covered;
+    return FLOCKGPU_OK;
+}
+
+}  // namespace flockgpu
+
+extern "C" {
+
+int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win,
+                              int32_t n_parts, flockgpu_partition_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!out || !win) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: null argument");
+    const int32_t *d_rows = nullptr;
+    const int64_t *d_off = nullptr, *h_off = nullptr;
+    int64_t n_out = 0;
+    FG_TRY(partition_by_key_async(ctx, keys, rows, win, n_parts, &d_rows, &d_off, &h_off, &n_out));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n_groups = (size_t)n_parts * win->n_windows;
     std::vector<int64_t> &offs = ctx->host_i64["partition.group_offsets"];
     offs.assign(h_off, h_off + n_groups + 1);
-    out->row = o_rows;
+    out->row = d_rows;
     out->part_win_offsets = offs.data();
     out->rows = offs[n_groups];
     return FLOCKGPU_OK;
