@@ -150,14 +150,22 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
     ctx.profile_reset()
     ctx.profile_only(only)
     ctx.profile(True)
+    import gc
+    gc.collect()          # a generation-2 collection of this process's heap is a ~40 ms pause: keep it out of the timed steps
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         res = step()
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("FLOCK_BENCH_STEP_TIMES"):
+        print("step wall ms:", [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     stats = ctx.profile_read()
     if only is not None:
         extra = 2

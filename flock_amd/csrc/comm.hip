@@ -274,17 +274,25 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         const void *values = nullptr;
         flockgpu_utf8 u{};
         int64_t bytes = 0;
-        Utf8Gather g;
         unsigned long long *d_run_bytes = nullptr, *h_run_bytes = nullptr;
     };
     std::vector<Sent> sent(cols.size());
     int n_utf8 = 0;
+    std::vector<size_t> ucols;  // the Utf8 columns: gathered together (one row list, one length pass, one scan, one emit)
+    for (size_t i = 0; i < cols.size(); ++i)
+        if (cols[i].utf8()) ucols.push_back(i);
+    if (ucols.size() > 4) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: more than four Utf8 columns in one relation");
+    Utf8MultiGather g_send, g_recv;
+    if (!ucols.empty()) {
+        flockgpu_utf8 srcs[4];
+        for (size_t j = 0; j < ucols.size(); ++j) srcs[j] = flockgpu_utf8{cols[ucols[j]].offsets, static_cast<const uint8_t *>(cols[ucols[j]].values)};
+        FG_TRY(gather_utf8_multi_begin(ctx, (name + ".sendu").c_str(), srcs, (int)ucols.size(), part_rows, n_send, &g_send));
+    }
     for (size_t i = 0; i < cols.size(); ++i) {
         const XCol &col = cols[i];
         const std::string key = name + ".send" + std::to_string(i);
         if (col.utf8()) {
             ++n_utf8;
-            FG_TRY(gather_utf8_begin(ctx, key.c_str(), flockgpu_utf8{col.offsets, static_cast<const uint8_t *>(col.values)}, part_rows, n_send, &sent[i].g));
             FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
             FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
             FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
@@ -304,8 +312,15 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         }
     }
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < cols.size(); ++i)
-        if (cols[i].utf8()) FG_TRY(gather_utf8_finish(ctx, sent[i].g, &sent[i].u, &sent[i].bytes));
+    if (!ucols.empty()) {
+        flockgpu_utf8 outs[4];
+        int64_t nb[4];
+        FG_TRY(gather_utf8_multi_finish(ctx, g_send, outs, nb));
+        for (size_t j = 0; j < ucols.size(); ++j) {
+            sent[ucols[j]].u = outs[j];
+            sent[ucols[j]].bytes = nb[j];
+        }
+    }
     std::vector<int64_t> run_start((size_t)n + 1);
     for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
     if (run_start[(size_t)n] != n_send) return fail(ctx, FLOCKGPU_ERR_HIP, "exchange: the partition pass covered %lld of %lld rows", (long long)run_start[(size_t)n], (long long)n_send);
@@ -368,7 +383,6 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     std::vector<int64_t> so((size_t)n + 1), ro((size_t)n + 1);
     int u = 0;
     // Utf8 regroup takes share one synchronisation as well
-    std::vector<Utf8Gather> regroup(cols.size());
     std::vector<flockgpu_utf8> recv_u(cols.size());
     std::vector<int64_t> recv_bytes_total(cols.size(), 0);
     for (size_t i = 0; i < cols.size(); ++i) {
@@ -425,16 +439,23 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         }
         recv_u[i] = flockgpu_utf8{off_recv, bytes_recv};
         recv_bytes_total[i] = rb[(size_t)n];
-        FG_TRY(gather_utf8_begin(ctx, key.c_str(), recv_u[i], d_index, n_recv, &regroup[i]));
     }
-    for (size_t i = 0; i < cols.size(); ++i) {
-        if (!cols[i].utf8()) continue;
-        flockgpu_utf8 fin{};
-        FG_TRY(gather_utf8_finish_known(ctx, regroup[i], recv_bytes_total[i], &fin));  // a permutation keeps the byte total: no host wait
-        out->cols[i].type = ColType::UTF8;
-        out->cols[i].values = fin.data;
-        out->cols[i].offsets = fin.offsets;
-        out->cols[i].bytes = recv_bytes_total[i];
+    if (!ucols.empty()) {  // the regrouping take of the Utf8 columns: a permutation keeps the byte totals, so no host wait
+        flockgpu_utf8 srcs[4], outs[4];
+        int64_t known[4], nb[4];
+        for (size_t j = 0; j < ucols.size(); ++j) {
+            srcs[j] = recv_u[ucols[j]];
+            known[j] = recv_bytes_total[ucols[j]];
+        }
+        FG_TRY(gather_utf8_multi_begin(ctx, (name + ".recvu").c_str(), srcs, (int)ucols.size(), d_index, n_recv, &g_recv));
+        FG_TRY(gather_utf8_multi_finish(ctx, g_recv, outs, nb, known));
+        for (size_t j = 0; j < ucols.size(); ++j) {
+            DevColumn &o = out->cols[ucols[j]];
+            o.type = ColType::UTF8;
+            o.values = outs[j].data;
+            o.offsets = outs[j].offsets;
+            o.bytes = known[j];
+        }
     }
     return FLOCKGPU_OK;
 }

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kBlock) void gather_i64_kernel(const int64_t *__res
 // source offsets are read coalesced.  counts[tile*4 + wave] = bytes of the wave's values.
 constexpr int kLenItems = 4;
 constexpr int kLenTile = kBlock * kLenItems;
+constexpr int kMaxUtf8Multi = 4;
 constexpr int kStageBytes = 18 * 1024;  // LDS staging buffer of the emit kernel: 18 B per value on average, 8 workgroups
                                         // per CU (tiles beyond it copy directly, byte by byte)
 
@@ -312,21 +313,52 @@ __global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restr
     if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
 }
 
+// The same for up to four columns gathered with ONE row list (the three Utf8 columns of q3's join output; the Utf8 columns of
+// a relation in the exchange): the row numbers are read once, the columns' counts lie one after the other
+// (column c: counts + c * tiles_stride * 4), so that ONE tile scan over k * tiles_stride pseudo-tiles serves all of them.
+struct Utf8Cols {
+    const int32_t *src_off[kMaxUtf8Multi];
+    const uint8_t *src[kMaxUtf8Multi];
+    int32_t *out_off[kMaxUtf8Multi];
+    uint8_t *out[kMaxUtf8Multi];
+    int32_t k;
+};
+__global__ __launch_bounds__(kBlock) void utf8_len_multi_kernel(Utf8Cols cols, const int32_t *__restrict__ rows, int64_t n,
+                                                                const uint64_t *__restrict__ d_n, int64_t tiles_stride,
+                                                                uint32_t *__restrict__ counts) {
+    if (d_n) n = min(n, (int64_t)*d_n);
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
+    int32_t r[kLenItems];
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) r[k] = i0 + k * kBlock < n ? rows[i0 + k * kBlock] : -1;
+#pragma unroll
+    for (int c = 0; c < kMaxUtf8Multi; ++c) {
+        if (c >= cols.k) break;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < kLenItems; ++k)
+            if (r[k] >= 0) mine += (uint32_t)(cols.src_off[c][r[k] + 1] - cols.src_off[c][r[k]]);
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane_id() == 63) counts[((size_t)c * tiles_stride + blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
+    }
+}
+// col_base[c] = tile_base[c * tiles_stride], c = 0 .. k: where column c's bytes start in the scan over all columns
+__global__ void utf8_col_bases_kernel(const uint64_t *__restrict__ tile_base, int64_t tiles_stride, int32_t k, uint64_t *__restrict__ col_base) {
+    if ((int)threadIdx.x <= k) col_base[threadIdx.x] = tile_base[(int64_t)threadIdx.x * tiles_stride];
+}
+
 // Writes out_off and the bytes.  The tile's bytes form ONE contiguous range of the output, so they are assembled
 // in LDS (byte writes are cheap there) and streamed out with aligned 16-byte stores; byte-granular global stores
 // made this kernel 10x slower than everything else in q8.
-__global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__restrict__ src_off,
-                                                           const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
-                                                           int64_t n, const uint32_t *__restrict__ counts,
-                                                           const uint64_t *__restrict__ tile_base,
-                                                           int32_t *__restrict__ out_off, uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
-    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];  // bytes of (iteration, wave)
+__device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src,
+                                               const int32_t *__restrict__ rows, int64_t n, const uint32_t *__restrict__ counts,
+                                               const uint64_t *__restrict__ tile_base, uint64_t col_base, int32_t *__restrict__ out_off,
+                                               uint8_t *__restrict__ out, uint8_t *s_stage, uint32_t *s_it) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
     const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
     const uint32_t tile_bytes = wc.x + wc.y + wc.z + wc.w;
-    const uint64_t base = tile_base[blockIdx.x];
+    const uint64_t base = tile_base[blockIdx.x] - col_base;
     int32_t b[kLenItems];
     uint32_t len[kLenItems], excl[kLenItems];
 #pragma unroll
@@ -412,6 +444,27 @@ __global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__rest
             for (uint32_t c = (o < phase ? phase : o); c < o + 16 && c < end; ++c) gout[c] = s_stage[c];
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__restrict__ src_off,
+                                                           const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
+                                                           int64_t n, const uint32_t *__restrict__ counts,
+                                                           const uint64_t *__restrict__ tile_base,
+                                                           int32_t *__restrict__ out_off, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];  // bytes of (iteration, wave)
+    utf8_emit_tile(src_off, src, rows, n, counts, tile_base, 0, out_off, out, s_stage, s_it);
+}
+// column blockIdx.y of a multi-column gather
+__global__ __launch_bounds__(kBlock) void utf8_emit_multi_kernel(Utf8Cols cols, const int32_t *__restrict__ rows, int64_t n,
+                                                                 int64_t tiles_stride, const uint32_t *__restrict__ counts,
+                                                                 const uint64_t *__restrict__ tile_base) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];
+    const int c = blockIdx.y;
+    const size_t shift = (size_t)c * tiles_stride;
+    utf8_emit_tile(cols.src_off[c], cols.src[c], rows, n, counts + shift * kWavesPerBlock, tile_base + shift, tile_base[shift], cols.out_off[c],
+                   cols.out[c], s_stage, s_it);
 }
 
 // ---- in-place inclusive scan: tile sums -> tile scan -> apply -----------------------------------------------------
@@ -629,6 +682,74 @@ int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *ou
 int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out) {
     int64_t nb = 0;
     return gather_utf8_emit(ctx, g, (uint64_t)std::max<int64_t>(total_bytes, 0), out, &nb);
+}
+
+int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n,
+                            Utf8MultiGather *g, const uint64_t *d_n) {
+    if (k < 1 || k > kMaxUtf8Multi) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: 1 to %d Utf8 columns per gather", name, kMaxUtf8Multi);
+    g->name = name;
+    g->k = k;
+    for (int c = 0; c < k; ++c) g->src[c] = srcs[c];
+    g->rows = rows;
+    g->n = n;
+    g->tiles = g->tiles_stride = n > 0 ? div_up(n, kLenTile) : 0;
+    FG_TRY(pinned_get_t(ctx, (g->name + ".totals").c_str(), (size_t)kMaxUtf8Multi + 1, &g->h_col_base));
+    for (int c = 0; c <= kMaxUtf8Multi; ++c) g->h_col_base[c] = 0;
+    if (n <= 0) return FLOCKGPU_OK;
+    const int64_t all = g->tiles_stride * k;
+    if (all > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
+    uint64_t *d_col_base = nullptr;
+    FG_TRY(arena_get_t(ctx, (g->name + ".counts").c_str(), (size_t)all * kWavesPerBlock, &g->counts));
+    FG_TRY(arena_get_t(ctx, (g->name + ".base").c_str(), (size_t)all + 1, &g->tile_base));
+    FG_TRY(arena_get_t(ctx, (g->name + ".totals").c_str(), (size_t)kMaxUtf8Multi + 1, &d_col_base));
+    Utf8Cols cols{};
+    cols.k = k;
+    for (int c = 0; c < k; ++c) cols.src_off[c] = srcs[c].offsets;
+    {
+        LaunchScope ls(ctx, "utf8_len_kernel");
+        hipLaunchKernelGGL(utf8_len_multi_kernel, dim3((unsigned)g->tiles), dim3(kBlock), 0, ctx->stream, cols, rows, n, d_n, g->tiles_stride, g->counts);
+    }
+    FG_TRY(check_launch(ctx, "utf8_len_multi_kernel"));
+    FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)all, g->tile_base, nullptr, 0, nullptr));
+    hipLaunchKernelGGL(utf8_col_bases_kernel, dim3(1), dim3(64), 0, ctx->stream, g->tile_base, g->tiles_stride, k, d_col_base);
+    FG_TRY(check_launch(ctx, "utf8_col_bases_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(g->h_col_base, d_col_base, sizeof(uint64_t) * ((size_t)k + 1), hipMemcpyDeviceToHost, ctx->stream));
+    return FLOCKGPU_OK;
+}
+
+void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n) {
+    g->n = n;
+    g->tiles = n > 0 ? div_up(n, kLenTile) : 0;  // (the counts keep the stride of the bound they were laid out for)
+}
+
+// known_bytes (may be null): the columns' byte totals when the caller knows them without asking the device
+int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockgpu_utf8 *outs, int64_t *n_bytes, const int64_t *known_bytes) {
+    Utf8Cols cols{};
+    cols.k = g.k;
+    for (int c = 0; c < g.k; ++c) {
+        const std::string k_off = g.name + ".off" + std::to_string(c), k_bytes = g.name + ".bytes" + std::to_string(c);
+        int32_t *o_off = nullptr;
+        uint8_t *o_b = nullptr;
+        const uint64_t total = g.n <= 0 ? 0 : (known_bytes ? (uint64_t)known_bytes[c] : g.h_col_base[c + 1] - g.h_col_base[c]);
+        if (total > 0x7fffffffull)
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)", g.name.c_str());
+        FG_TRY(arena_get_t(ctx, k_off.c_str(), (size_t)std::max<int64_t>(g.n, 0) + 1, &o_off));
+        FG_TRY(arena_get_t(ctx, k_bytes.c_str(), (size_t)total + 16, &o_b));
+        if (g.n <= 0) FG_HIP(ctx, hipMemsetAsync(o_off, 0, sizeof(int32_t), ctx->stream));
+        cols.src_off[c] = g.src[c].offsets;
+        cols.src[c] = g.src[c].data;
+        cols.out_off[c] = o_off;
+        cols.out[c] = o_b;
+        outs[c] = flockgpu_utf8{o_off, o_b};
+        n_bytes[c] = (int64_t)total;
+    }
+    if (g.n <= 0) return FLOCKGPU_OK;
+    {
+        LaunchScope ls(ctx, "utf8_emit_kernel");
+        hipLaunchKernelGGL(utf8_emit_multi_kernel, dim3((unsigned)g.tiles, (unsigned)g.k), dim3(kBlock), 0, ctx->stream, cols, g.rows, g.n, g.tiles_stride,
+                           g.counts, g.tile_base);
+    }
+    return check_launch(ctx, "utf8_emit_multi_kernel");
 }
 
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

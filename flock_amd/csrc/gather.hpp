@@ -56,6 +56,25 @@ int gather_utf8_finish(flockgpu_ctx *ctx, const Utf8Gather &g, flockgpu_utf8 *ou
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,
                 flockgpu_utf8 *out, int64_t *n_bytes);
 
+// Up to four Utf8 columns gathered with ONE row list (q3's name / city / state of the joined persons; the Utf8 columns of a relation
+// in the exchange): one length pass that reads the row numbers once, ONE tile scan over all columns' tiles, one emit launch.
+// Same two-phase protocol as the single-column gather (begin -- one synchronisation, shared with whatever else the caller waits
+// for -- finish); outputs live in the ctx arena under `name`.
+struct Utf8MultiGather {
+    std::string name;
+    int k = 0;
+    flockgpu_utf8 src[4]{};
+    const int32_t *rows = nullptr;
+    int64_t n = 0, tiles = 0, tiles_stride = 0;
+    uint32_t *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    uint64_t *h_col_base = nullptr;  // pinned, k + 1: where each column's bytes start in the scan over all columns
+};
+int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n,
+                            Utf8MultiGather *g, const uint64_t *d_n = nullptr);
+void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n);
+int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockgpu_utf8 *outs, int64_t *n_bytes, const int64_t *known_bytes = nullptr);
+
 // Utf8 gather whose total byte count the caller already knows (a permutation of a column of known size): no host wait.
 int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out);
 

@@ -64,6 +64,22 @@ __device__ __forceinline__ bool lits_hit(uint64_t v, uint32_t len, const Utf8Lit
     return hit;
 }
 
+// Per iteration a wave holds 256 CONSECUTIVE persons (lane l: rows 4l .. 4l+3), so their `state` offsets are one 16-byte load
+// per lane and their bytes one contiguous range of the data buffer: the range is fetched with coalesced 16-byte loads into the
+// wave's LDS slot and every row's value is read from there.  (Before: five dword loads of offsets per lane and three dependent
+// dword loads per ROW -- 22 % of the HBM roofline.)  A range that does not fit the slot (long strings) and chunks that touch the
+// column's ends take the per-row global loads.
+constexpr int kWaveStageBytes = 4096;                      // 16 B per row on average
+constexpr int kWaveStageWords = kWaveStageBytes / 4 + 8;   // + phase (< 16 B) and the words utf8_head8-style reads touch past a value
+
+__device__ __forceinline__ uint64_t lds_head8(const uint32_t *w, uint32_t byte_pos, uint32_t len) {
+    const uint32_t wi = byte_pos >> 2, sh = (byte_pos & 3) * 8;
+    const uint32_t w0 = w[wi], w1 = w[wi + 1], w2 = w[wi + 2];
+    const uint64_t lo = __funnelshift_r(w0, w1, sh), hi = __funnelshift_r(w1, w2, sh);
+    const uint64_t v = lo | (hi << 32);
+    return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1));
+}
+
 template <bool kDense>
 __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restrict__ p_id,
                                                           const int32_t *__restrict__ state_off,
@@ -71,32 +87,59 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                                                           Utf8Lits lits, const WinTable *__restrict__ wins, int32_t *direct,
                                                           uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err, int y_shift) {
     // A relation of a few hundred tiles (2e6 persons at 1e8 events: 245) leaves most CUs without a workgroup, and one
-    // workgroup walks its tile's eight iterations of dependent loads (offsets -> bytes) alone: blockIdx.y splits the
-    // iterations of a tile over 8 >> y_shift workgroups (rows are independent: nothing is produced per tile).
+    // workgroup walks its tile's eight iterations alone: blockIdx.y splits the iterations of a tile over 8 >> y_shift
+    // workgroups (rows are independent: nothing is produced per tile).
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWavesPerBlock][kWaveStageWords];
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
     const int64_t wbase = tr.tile_begin + flag_rel0();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t *stage = s_stage[wave];
     WinTable wt{};
     if (kDense) wt = wins[tr.seg];
     uint64_t *tab = kDense ? nullptr : tables + (size_t)tr.seg * cap;
     int32_t key[kFlagIters][4];
     load_flag_tile(p_id, n_rows, tr, key);
+    const uintptr_t data_addr = reinterpret_cast<uintptr_t>(state_data);
+    const bool off_aligned = (reinterpret_cast<uintptr_t>(state_off) & 15) == 0;
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it) {
         if ((it >> y_shift) != (int)blockIdx.y) continue;  // (block-uniform)
         const int64_t r0 = wbase + it * 256;
-        // offsets of rows r0 .. r0+4 (clamped to the column: rows past its end are masked below)
+        const int64_t chunk0 = r0 - lane * 4;               // the wave's first row of this iteration
         int32_t off[5];
+        const bool inside = off_aligned && chunk0 >= 0 && chunk0 + 256 < n_rows;  // (wave-uniform) all 257 offsets exist
+        if (inside) {
+            const int4 o = *reinterpret_cast<const int4 *>(state_off + r0);  // r0 is a multiple of 4: 16-byte aligned
+            off[0] = o.x; off[1] = o.y; off[2] = o.z; off[3] = o.w;
+            const int32_t last = state_off[chunk0 + 256];   // (one address per wave)
+            const int32_t nxt = __shfl_down(off[0], 1, 64);
+            off[4] = lane == 63 ? last : nxt;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int64_t r = r0 + j;
-            off[j] = state_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+            for (int j = 0; j < 5; ++j) {
+                const int64_t r = r0 + j;
+                off[j] = state_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+            }
+        }
+        const int32_t b0 = __builtin_amdgcn_readfirstlane(off[0]);
+        const int32_t b1 = __builtin_amdgcn_readlane(off[4], 63);
+        const uint32_t phase = (uint32_t)((data_addr + (uint32_t)b0) & 15);
+        const bool staged = inside && b1 >= b0 && (uint32_t)(b1 - b0) + phase <= (uint32_t)kWaveStageBytes;  // (wave-uniform)
+        if (staged) {
+            // a 16-byte aligned chunk that holds at least one byte of the range never crosses a page: reading its tail is safe
+            const uint32_t span = (uint32_t)(b1 - b0) + phase;
+            const uint4 *src = reinterpret_cast<const uint4 *>((data_addr + (uint32_t)b0) & ~uintptr_t(15));
+            for (uint32_t o = lane * 16; b1 > b0 && o < span; o += 64 * 16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(stage) + o) = src[o >> 4];
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r0 + j;
             const bool in = r >= tr.lo && r < tr.hi;
             const uint32_t len = in ? (uint32_t)(off[j + 1] - off[j]) : 0u;
-            const uint64_t v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);  // len 0: nothing is read past the buffer
+            uint64_t v;
+            if (staged) v = lds_head8(stage, in ? (uint32_t)(off[j] - b0) + phase : 0u, len > 8 ? 8u : len);
+            else v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);  // len 0: nothing is read past the buffer
             if (!(in && len <= 8 && lits_hit(v, len, lits))) continue;
             if (kDense) {
                 const uint32_t idx = (uint32_t)key[it][j] - (uint32_t)wt.base;
@@ -105,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                 atomicOr(err, 1u);
             }
         }
+        if (staged) __builtin_amdgcn_wave_barrier();  // the slot is rewritten by the next iteration
     }
 }
 
@@ -354,7 +398,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     FG_TRY(arena_get_t(ctx, "q3.err", 4, &d_err));
     std::vector<int64_t> &offs = ctx->host_i64["q3.win_out_offsets"];
     int32_t *o_ar = nullptr, *o_pr = nullptr, *o_aid = nullptr;
-    Utf8Gather g_name, g_city, g_state;
+    Utf8MultiGather g_text;  // name, city, state of the joined persons: one row list, one length pass, one scan, one emit
+    const flockgpu_utf8 text_cols[3] = {person->name, person->city, person->state};
     uint64_t n_pairs = 0;
 
     // The dense path is SPECULATED: whether the persons qualify (strictly increasing p_id over an affordable range in
@@ -418,9 +463,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
         FG_TRY(check_launch(ctx, "q3_emit_dense_kernel"));
         const uint64_t *d_pairs = tile_base + st_a.n_tiles;
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)bound_pairs, &g_name, d_pairs));
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)bound_pairs, &g_city, d_pairs));
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)bound_pairs, &g_state, d_pairs));
+        FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)bound_pairs, &g_text, d_pairs));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -428,9 +471,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         if (h_info[1]) {
             offs.assign(h_off, h_off + n_win + 1);
             n_pairs = (uint64_t)offs[n_win];
-            gather_utf8_narrow(&g_name, (int64_t)n_pairs);
-            gather_utf8_narrow(&g_city, (int64_t)n_pairs);
-            gather_utf8_narrow(&g_state, (int64_t)n_pairs);
+            gather_utf8_multi_narrow(&g_text, (int64_t)n_pairs);
         } else {
             try_dense = false;  // some window's persons are unsorted, duplicated or too sparse: general path below
         }
@@ -479,14 +520,18 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
                                next, counts, tile_base, o_ar, o_pr, o_aid);
         }
         FG_TRY(check_launch(ctx, "q3_probe_emit_kernel"));
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_name", person->name, o_pr, (int64_t)n_pairs, &g_name));
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_city", person->city, o_pr, (int64_t)n_pairs, &g_city));
-        FG_TRY(gather_utf8_begin(ctx, "q3.out_state", person->state, o_pr, (int64_t)n_pairs, &g_state));
+        FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)n_pairs, &g_text));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    FG_TRY(gather_utf8_finish(ctx, g_name, &out->name, &out->name_bytes));
-    FG_TRY(gather_utf8_finish(ctx, g_city, &out->city, &out->city_bytes));
-    FG_TRY(gather_utf8_finish(ctx, g_state, &out->state, &out->state_bytes));
+    flockgpu_utf8 text_out[3];
+    int64_t text_bytes[3];
+    FG_TRY(gather_utf8_multi_finish(ctx, g_text, text_out, text_bytes));
+    out->name = text_out[0];
+    out->city = text_out[1];
+    out->state = text_out[2];
+    out->name_bytes = text_bytes[0];
+    out->city_bytes = text_bytes[1];
+    out->state_bytes = text_bytes[2];
     out->a_id = o_aid;
     out->auction_row = o_ar;
     out->person_row = o_pr;

@@ -140,9 +140,9 @@ __device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, const FlushAr
 
 // ---- pane key-range estimate: kRangeBlocks x 256 lanes x 4 strided 16-byte samples per pane (<1 % of a pane) ------
 constexpr int kRangeBlocks = 8;
+// Every (pane, block) writes its own sampled extrema (no initialisation, no atomics): rng[(pane * kRangeBlocks + block) * 2 + {0, 1}].
 __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restrict__ auction, int64_t n_rows,
-                                                          const int64_t *__restrict__ seg_off, int32_t *pane_min,
-                                                          int32_t *pane_max) {
+                                                          const int64_t *__restrict__ seg_off, int32_t *__restrict__ rng) {
     __shared__ int32_t s_red[8];
     const int32_t pane = blockIdx.y;
     const int64_t sb = seg_off[2 * pane], se = seg_off[2 * pane + 1];
@@ -176,13 +176,117 @@ __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-        if (mn <= mx) {
-            atomicMin(&pane_min[pane], mn);
-            atomicMax(&pane_max[pane], mx);
-        }
+        int32_t *o = rng + ((size_t)pane * kRangeBlocks + blockIdx.x) * 2;
+        o[0] = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        o[1] = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
     }
+}
+
+// The layout rules, shared by the host (first call, Partial stage, fallback) and the device (speculated calls).
+__host__ __device__ inline bool q5_pane_layout(int64_t lo, int64_t hi, int64_t *base, int64_t *range) {
+    const int64_t span = hi - lo, margin = span / 16 > 4096 ? span / 16 : 4096;
+    *base = (lo - margin) & ~int64_t(3);
+    *range = ((hi + margin + 1 - *base) + 3) & ~int64_t(3);
+    return *range < (int64_t(1) << 31);
+}
+
+// The direct-address layout decided ON THE DEVICE from the sampled pane ranges, so that the host does not wait for them in the
+// middle of the call: PaneDesc per pane (base, counter offset, range), WinDesc per window (union range of its panes).
+// info[0] = counters in use, info[1] = window-range total, info[2] = 1 when the layout is dense, affordable and fits the
+// `capacity` counters the host allocated from the previous call's size; 0 declines the call (every kernel behind returns at
+// once; the host sees it at its single synchronisation and repeats the call the slow way).
+__global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__restrict__ rng, const int32_t *__restrict__ pane_win_ptr,
+                                                           const int64_t *__restrict__ seg_off, int32_t n_panes, int32_t n_win,
+                                                           uint64_t capacity, uint64_t budget_bytes, PaneDesc *__restrict__ panes,
+                                                           WinDesc *__restrict__ wins, uint64_t *__restrict__ info) {
+    __shared__ uint64_t s_wave[kWavesPerBlock];
+    __shared__ uint64_t s_carry;
+    __shared__ int s_ok;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        s_carry = 0;
+        s_ok = 1;
+    }
+    __syncthreads();
+    for (int32_t p0 = 0; p0 < n_panes; p0 += kBlock) {
+        const int32_t p = p0 + (int32_t)threadIdx.x;
+        int64_t base = 0, range = 0;
+        if (p < n_panes && pane_win_ptr[p + 1] != pane_win_ptr[p] && seg_off[2 * p + 1] > seg_off[2 * p]) {
+            int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+            for (int b = 0; b < kRangeBlocks; ++b) {
+                mn = min(mn, rng[((size_t)p * kRangeBlocks + b) * 2]);
+                mx = max(mx, rng[((size_t)p * kRangeBlocks + b) * 2 + 1]);
+            }
+            if (mn <= mx && !q5_pane_layout(mn, mx, &base, &range)) {
+                s_ok = 0;
+                range = 0;
+            }
+        }
+        const uint64_t incl = wave_incl_scan_u64((uint64_t)range);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t off = s_carry + incl - (uint64_t)range;
+        for (int v = 0; v < wave; ++v) off += s_wave[v];
+        if (p < n_panes) panes[p] = PaneDesc{base, off, (uint32_t)range, 0};
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) s_carry = off + (uint64_t)range;
+        __syncthreads();
+    }
+    const uint64_t cnt_total = s_carry;
+    __syncthreads();  // panes[] written above are read below (same workgroup: visible after the barrier)
+    uint64_t scan = 0;
+    for (int32_t w = threadIdx.x; w < n_win; w += kBlock) {
+        WinDesc d = wins[w];
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int32_t p = d.pane_lo; p < d.pane_hi; ++p) {
+            const PaneDesc pd = panes[p];
+            if (pd.range) {
+                lo = lo < pd.base ? lo : pd.base;
+                hi = hi > pd.base + (int64_t)pd.range ? hi : pd.base + (int64_t)pd.range;
+            }
+        }
+        d.base = 0;
+        d.range = 0;
+        if (lo < hi) {
+            if (hi - lo >= (int64_t(1) << 31)) s_ok = 0;
+            else {
+                d.base = lo;
+                d.range = (uint32_t)(hi - lo);
+                scan += (uint64_t)(hi - lo);
+            }
+        }
+        wins[w] = d;
+    }
+    scan = wave_sum_u64(scan);
+    if (lane == 0) s_wave[wave] = scan;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t scan_total = 0;
+        for (int v = 0; v < kWavesPerBlock; ++v) scan_total += s_wave[v];
+        const bool ok = s_ok && cnt_total <= capacity && cnt_total * 4 <= budget_bytes && scan_total * 4 <= 2 * budget_bytes;
+        info[0] = cnt_total;
+        info[1] = scan_total;
+        info[2] = ok ? 1 : 0;
+    }
+}
+
+// One launch instead of five memsets: the counters in use (their number from the device when the layout was made there),
+// the window tables, the scalars, the slow list head and the per-workgroup maxima.
+__global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, const uint64_t *__restrict__ info, uint64_t cnt_host,
+                                                          uint64_t *__restrict__ tables, uint64_t table_words, uint64_t *__restrict__ meta,
+                                                          uint64_t meta_words, int32_t *__restrict__ slow_list, uint32_t *__restrict__ block_max,
+                                                          uint64_t block_max_words) {
+    const uint64_t cnt = info ? (info[2] ? info[0] : 0) : cnt_host;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = i0; i * 4 < cnt + 3; i += stride) reinterpret_cast<uint4 *>(counters)[i] = z;  // (the arena has 4 words of slack)
+    for (uint64_t i = i0; i * 2 < table_words; i += stride) {
+        if (i * 2 + 1 < table_words) reinterpret_cast<uint4 *>(tables)[i] = z;
+        else tables[i * 2] = 0;
+    }
+    for (uint64_t i = i0; i < meta_words; i += stride) meta[i] = 0;
+    for (uint64_t i = i0; i < block_max_words; i += stride) block_max[i] = 0;
+    if (i0 == 0) slow_list[0] = 0;
 }
 
 // ---- count: fast kernel (full tiles whose keys fit the LDS histogram) -------------------------------------------
@@ -194,9 +298,10 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ pane_win_ptr,
                                                           const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                           uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
-                                                          int32_t *slow_list) {
+                                                          int32_t *slow_list, const uint64_t *__restrict__ spec_info) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
     __shared__ int32_t s_red[8];
+    if (spec_info && !spec_info[2]) return;  // the device layout declined this call
     {
         uint4 *z = reinterpret_cast<uint4 *>(hist);
         for (int s = threadIdx.x; s < (kHist + kHistPad) / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
@@ -326,8 +431,10 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
                                                                const int32_t *__restrict__ pane_win_ptr,
                                                                const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                                uint64_t *tables, uint32_t cap, uint32_t *tab_used,
-                                                               uint32_t *err, const int32_t *__restrict__ slow_list) {
+                                                               uint32_t *err, const int32_t *__restrict__ slow_list,
+                                                               const uint64_t *__restrict__ spec_info) {
     __shared__ __attribute__((aligned(16))) uint64_t slots[kSlots];
+    if (spec_info && !spec_info[2]) return;
     __shared__ uint32_t s_fill;  // slots claimed so far (approximate while lanes race: only steers the bypass)
     const int lane = lane_id();
     const int32_t n = slow_list[0];
@@ -462,8 +569,10 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
                                                          const uint64_t *__restrict__ tables, uint32_t cap,
                                                          const uint32_t *__restrict__ tab_used, uint64_t *win_max,
                                                          uint64_t *win_groups, uint32_t *block_max, uint32_t *cursor,
-                                                         uint32_t out_cap, int32_t *out_win, int32_t *out_key) {
+                                                         uint32_t out_cap, int32_t *out_win, int32_t *out_key,
+                                                         const uint64_t *__restrict__ spec_info) {
     __shared__ PaneDesc s_panes[kMaxWinPanes];
+    if (spec_info && !spec_info[2]) return;
     const int32_t w = blockIdx.y;
     // select visits the same keys as the same block of the max pass did: a block whose maximum is not the window's
     // holds no winner and skips its share of the counters
@@ -663,56 +772,61 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     FG_TRY(arena_get_t(ctx, "q5.pane_win_idx", idx.size() + 1, &d_idx));
     FG_TRY(pinned_get_t(ctx, "q5.pane_win_ptr", ptr.size(), &h_ptr));
     FG_TRY(pinned_get_t(ctx, "q5.pane_win_idx", idx.size() + 1, &h_idx));
-    std::copy(ptr.begin(), ptr.end(), h_ptr);
-    std::copy(idx.begin(), idx.end(), h_idx);
-    FG_HIP(ctx, hipMemcpyAsync(d_ptr, h_ptr, ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (!idx.empty())
-        FG_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    {   // the pane -> windows CSR is uploaded only when it (or its buffers) changed: a stream of equal batches re-submits the same schedule
+        std::vector<int64_t> &sig = ctx->host_i64["q5.csr_sig"];
+        std::vector<int64_t> now;
+        now.reserve(ptr.size() + idx.size() + 2);
+        now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_ptr));
+        now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_idx));
+        now.insert(now.end(), ptr.begin(), ptr.end());
+        now.insert(now.end(), idx.begin(), idx.end());
+        if (sig != now) {
+            std::copy(ptr.begin(), ptr.end(), h_ptr);
+            std::copy(idx.begin(), idx.end(), h_idx);
+            FG_HIP(ctx, hipMemcpyAsync(d_ptr, h_ptr, ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            if (!idx.empty())
+                FG_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            sig = now;
+        }
+    }
 
     // ---- key-range estimate per pane -> direct-address range per pane, union range per window
-    int32_t *d_rng = nullptr, *h_rng = nullptr;  // [0, n_panes) min, [n_panes, 2 n_panes) max
-    FG_TRY(arena_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &d_rng));
-    FG_TRY(pinned_get_t(ctx, "q5.pane_range", (size_t)2 * n_panes + 2, &h_rng));
+    int32_t *d_rng = nullptr, *h_rng = nullptr;  // per (pane, sampling block): {min, max}
+    const size_t n_rng = (size_t)2 * kRangeBlocks * std::max(n_panes, 1);
+    FG_TRY(arena_get_t(ctx, "q5.pane_range", n_rng + 2, &d_rng));
+    FG_TRY(pinned_get_t(ctx, "q5.pane_range", n_rng + 2, &h_rng));
     std::vector<PaneDesc> panes((size_t)std::max(n_panes, 1));
     std::vector<WinDesc> wins((size_t)std::max(n_win, 1));
     for (auto &p : panes) p = PaneDesc{0, 0, 0, 0};
     for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
     uint64_t cnt_total = 0, scan_total = 0;
     bool dense = st.n_tiles > 0 && n_win > 0 && max_win_panes <= kMaxWinPanes;
-    std::vector<int64_t> &last_cnt = ctx->host_i64["q5.last_cnt_total"];
-    if (last_cnt.empty()) last_cnt.push_back(0);
-    uint64_t pre_cleared = 0;
-    const uint32_t *pre_ptr = nullptr;
+    // sizes of the previous call of this ctx: {counters, window-range total, usable}.  A stream of equal batches needs about as
+    // many counters as the batch before, so their arena is sized from it and the layout itself is made on the device.
+    std::vector<int64_t> &hint = ctx->host_i64[weight ? "q5.layout_hint.weighted" : "q5.layout_hint"];
+    if (hint.size() != 3) hint.assign(3, 0);
+    // affordable = counters + their scans cost no more than a few passes over the input
+    const uint64_t budget = std::max<uint64_t>(uint64_t(256) << 20, (uint64_t)covered_rows * 4 * 2);
     if (dense) {
-        FG_HIP(ctx, hipMemsetAsync(d_rng, 0x7F, sizeof(int32_t) * n_panes, ctx->stream));             // min = 0x7f7f7f7f
-        FG_HIP(ctx, hipMemsetAsync(d_rng + n_panes, 0x80, sizeof(int32_t) * n_panes, ctx->stream));   // max = 0x80808080
-        {
-            LaunchScope ls(ctx, "q5_range_kernel");
-            hipLaunchKernelGGL(q5_range_kernel, dim3(kRangeBlocks, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream,
-                               auction, rows, st.seg_off, d_rng, d_rng + n_panes);
-        }
-        FG_TRY(check_launch(ctx, "q5_range_kernel"));
-        FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * 2 * n_panes, hipMemcpyDeviceToHost, ctx->stream));
-        if (!ctx->sync_event) FG_HIP(ctx, hipEventCreateWithFlags(&ctx->sync_event, hipEventDisableTiming));
-        FG_HIP(ctx, hipEventRecord(ctx->sync_event, ctx->stream));   // the host waits for the ranges only, not for the clear below
-        // While the host waits for the ranges the device would sit idle: the counter arena is cleared NOW, for as many
-        // counters as the previous call used (a stream of equal batches uses about as many); what this call needs beyond
-        // that is cleared after the synchronisation.
-        if (last_cnt[0] > 0) {
-            uint32_t *early = nullptr;
-            FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)last_cnt[0] + 4, &early));
-            FG_HIP(ctx, hipMemsetAsync(early, 0, sizeof(uint32_t) * (size_t)last_cnt[0], ctx->stream));
-            pre_cleared = (uint64_t)last_cnt[0];
-            pre_ptr = early;
-        }
-        FG_HIP(ctx, hipEventSynchronize(ctx->sync_event));
+        LaunchScope ls(ctx, "q5_range_kernel");
+        hipLaunchKernelGGL(q5_range_kernel, dim3(kRangeBlocks, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, auction, rows, st.seg_off, d_rng);
+    }
+    FG_TRY(check_launch(ctx, "q5_range_kernel"));
+    bool speculate = dense && !part && hint[2] && hint[0] > 0;
+    auto host_layout = [&]() -> int {   // the same rules on the host: first call of a ctx, the Partial stage, a declined speculation
+        FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * n_rng, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        cnt_total = scan_total = 0;
         for (int p = 0; p < n_panes && dense; ++p) {
-            if (ptr[p + 1] == ptr[p] || se[p] <= sb[p] || h_rng[p] > h_rng[n_panes + p]) continue;  // unused / empty pane
-            const int64_t lo = h_rng[p], hi = h_rng[n_panes + p];
-            const int64_t span = hi - lo, margin = std::max<int64_t>(4096, span / 16);
-            const int64_t base = (lo - margin) & ~int64_t(3);
-            const int64_t range = ((hi + margin + 1 - base) + 3) & ~int64_t(3);
-            if (range >= (int64_t(1) << 31)) { dense = false; break; }
+            if (ptr[p + 1] == ptr[p] || se[p] <= sb[p]) continue;  // unused / empty pane
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (int b = 0; b < kRangeBlocks; ++b) {
+                lo = std::min<int64_t>(lo, h_rng[((size_t)p * kRangeBlocks + b) * 2]);
+                hi = std::max<int64_t>(hi, h_rng[((size_t)p * kRangeBlocks + b) * 2 + 1]);
+            }
+            if (lo > hi) continue;
+            int64_t base = 0, range = 0;
+            if (!q5_pane_layout(lo, hi, &base, &range)) { dense = false; break; }
             panes[p] = PaneDesc{base, cnt_total, (uint32_t)range, 0};
             cnt_total += (uint64_t)range;
         }
@@ -729,28 +843,48 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             wins[w].range = (uint32_t)(hi - lo);
             scan_total += (uint64_t)(hi - lo);
         }
-        // affordable = counters + their scans cost no more than a few passes over the input
-        const uint64_t budget = std::max<uint64_t>(uint64_t(256) << 20, (uint64_t)covered_rows * 4 * 2);
         if (dense && (cnt_total * 4 > budget || scan_total * 4 > 2 * budget)) dense = false;
-    }
-    if (!dense) {
-        cnt_total = 0;
-        for (auto &p : panes) p = PaneDesc{0, 0, 0, 0};
-        for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
-    }
+        return FLOCKGPU_OK;
+    };
+    if (dense && !speculate) FG_TRY(host_layout());
     PaneDesc *d_panes = nullptr, *h_panes = nullptr;
     WinDesc *d_wins = nullptr, *h_wins = nullptr;
     FG_TRY(arena_get_t(ctx, "q5.panes", panes.size(), &d_panes));
     FG_TRY(pinned_get_t(ctx, "q5.panes", panes.size(), &h_panes));
     FG_TRY(arena_get_t(ctx, "q5.wins", wins.size(), &d_wins));
     FG_TRY(pinned_get_t(ctx, "q5.wins", wins.size(), &h_wins));
-    std::copy(panes.begin(), panes.end(), h_panes);
-    std::copy(wins.begin(), wins.end(), h_wins);
-    FG_HIP(ctx, hipMemcpyAsync(d_panes, h_panes, panes.size() * sizeof(PaneDesc), hipMemcpyHostToDevice, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+    uint64_t *d_info = nullptr, *h_info = nullptr;  // the device layout's {counters, window-range total, verdict}
+    FG_TRY(arena_get_t(ctx, "q5.layout_info", 4, &d_info));
+    FG_TRY(pinned_get_t(ctx, "q5.layout_info", 4, &h_info));
+    auto upload_layout = [&]() -> int {
+        if (!dense) {
+            cnt_total = scan_total = 0;
+            for (auto &p : panes) p = PaneDesc{0, 0, 0, 0};
+            for (int w = 0; w < n_win; ++w) wins[w] = WinDesc{0, 0, win->win_pane_lo[w], win->win_pane_hi[w], 0};
+        }
+        std::copy(panes.begin(), panes.end(), h_panes);
+        std::copy(wins.begin(), wins.end(), h_wins);
+        FG_HIP(ctx, hipMemcpyAsync(d_panes, h_panes, panes.size() * sizeof(PaneDesc), hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+        return FLOCKGPU_OK;
+    };
     uint32_t *counters = nullptr;
-    FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
-    last_cnt[0] = (int64_t)cnt_total;
+    uint64_t capacity = 0;
+    if (speculate) {
+        // window pane ranges for the device pass (bases / ranges are filled in there); counters for the previous call's size + 1/8
+        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)hint[0] + (size_t)hint[0] / 8 + 4, &counters));
+        capacity = ctx->arena["q5.counters"].cap / sizeof(uint32_t) - 4;
+        std::copy(wins.begin(), wins.end(), h_wins);
+        FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(q5_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes,
+                           d_wins, d_info);
+        FG_TRY(check_launch(ctx, "q5_layout_kernel"));
+        cnt_total = (uint64_t)hint[0];   // (provisional: sizes launches; the true values come back with the results)
+        scan_total = (uint64_t)hint[1];
+    } else {
+        FG_TRY(upload_layout());
+        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+    }
 
     // device scalars: [0, n_win) win_max, [n_win, 2 n_win) win_groups, then cursor + err (2 x u32), then tab_used (u32 x n_win)
     const size_t n_meta = (size_t)2 * n_win + 1 + ((size_t)n_win + 1) / 2 + 1;
@@ -770,27 +904,32 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         if (attempt > 8 || cap64 >= (uint64_t(1) << 31))
             return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q5: hash table capacity %llu still overflows", (unsigned long long)cap64);
         const uint32_t cap = (uint32_t)cap64;
+        const uint64_t *spec_info = speculate ? d_info : nullptr;
         uint64_t *tables = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.tables", (size_t)cap * std::max(n_win, 1), &tables));
         int32_t *o_win = nullptr, *o_key = nullptr, *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.sel_win", out_cap, &o_win));
         FG_TRY(arena_get_t(ctx, "q5.sel_key", out_cap, &o_key));
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
-        FG_HIP(ctx, hipMemsetAsync(tables, 0, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
-        if (cnt_total) {
-            // (the early clear counts only for the first attempt and only if the arena did not move)
-            const uint64_t done = (attempt == 0 && pre_ptr == counters) ? std::min(pre_cleared, cnt_total) : 0;
-            if (cnt_total > done)
-                FG_HIP(ctx, hipMemsetAsync(counters + done, 0, sizeof(uint32_t) * (cnt_total - done), ctx->stream));
+        // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
+        // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
+        const uint64_t per_win = n_win > 0 ? std::max<uint64_t>(cap, scan_total / n_win / 4) : cap;
+        const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
+        uint32_t *block_max = nullptr;
+        FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * std::max(n_win, 1), &block_max));
+        {   // one clear for everything this attempt writes into
+            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, (uint64_t)gx * n_win});
+            const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
+            hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total, tables, (uint64_t)cap * n_win, d_meta,
+                               (uint64_t)n_meta, slow_list, block_max, (uint64_t)gx * n_win);
+            FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
-        FG_HIP(ctx, hipMemsetAsync(d_meta, 0, sizeof(uint64_t) * n_meta, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(slow_list, 0, sizeof(int32_t), ctx->stream));
         if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
                 hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list);
+                                   slow_list, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
             {
@@ -798,7 +937,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                 const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
                 hipLaunchKernelGGL(weight ? q5_count_slow_kernel<true> : q5_count_slow_kernel<false>, dim3(gs), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list);
+                                   slow_list, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
         }
@@ -857,25 +996,18 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             return FLOCKGPU_OK;
         }
         if (n_win > 0) {
-            const uint64_t per_win = std::max<uint64_t>(cap, scan_total / n_win / 4);
-            // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
-            // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
-            const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
-            uint32_t *block_max = nullptr;
-            FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * n_win, &block_max));
-            FG_HIP(ctx, hipMemsetAsync(block_max, 0, sizeof(uint32_t) * (size_t)gx * n_win, ctx->stream));
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<false>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
                                    d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap,
-                                   o_win, o_key);
+                                   o_win, o_key, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_max_kernel"));
             {
                 LaunchScope ls(ctx, "q5_select_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<true>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
                                    d_panes, counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap,
-                                   o_win, o_key);
+                                   o_win, o_key, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
@@ -888,7 +1020,22 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         FG_HIP(ctx, hipMemcpyAsync(h_meta, d_meta, sizeof(uint64_t) * n_meta, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_swin, o_win, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_skey, o_key, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
+        if (speculate) FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (speculate) {
+            if (!h_info[2]) {   // declined (ranges moved beyond the counters the previous call sized, or not dense any more): the slow way
+                speculate = false;
+                hint[2] = 0;
+                FG_TRY(host_layout());
+                FG_TRY(upload_layout());
+                FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+                cap64 = dense ? 1024 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
+                --attempt;
+                continue;
+            }
+            cnt_total = h_info[0];
+            scan_total = h_info[1];
+        }
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
         n_sel = tail[0];
         if (tail[1]) {  // a window table filled up: the group-count hint was too optimistic
@@ -910,6 +1057,9 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         break;
     }
+    hint[0] = (int64_t)cnt_total;   // the next call of this kind sizes its counters from this one and lays them out on the device
+    hint[1] = (int64_t)scan_total;
+    hint[2] = dense ? 1 : 0;
     // remember how dense the groups were so the next sparse call sizes its tables right away
     {
         double best = 1e30;
