@@ -514,9 +514,11 @@ def payload_side(ctx, steps, no_cpu, rows=10_000_000):
             torch.randint(0, 2**40, (rows,), dtype=torch.int64, device=dev, generator=g)]
     batch = P.DeviceBatch([("auction", "int32"), ("bidder", "int32"), ("price", "float64"), ("b_date_time", "timestamp_ms")], cols, rows)
     dt, stats, (header, body) = run_steps(ctx, lambda: P.batch_to_flight_data(ctx, batch, keep_view=True), steps, 1, lambda: None, "ipc_pack_kernel")
-    # size-independent check: the body is the four columns end to end (each a multiple of 8 bytes here)
-    ok = len(body) == 24 * rows and bytes(body[: 4 * rows]) == cols[0].cpu().numpy().tobytes() and \
-        bytes(body[16 * rows:]) == cols[3].cpu().numpy().tobytes() and P.parse_record_batch_header(header)[0] == rows
+    # size-independent check: per field an all-ones validity bitmap (what the reference's writer emits), then the column as it is
+    n_rows, nodes, bufs, body_len = P.parse_record_batch_header(header)
+    ok = n_rows == rows and body_len == len(body) == 24 * rows + 4 * (((rows + 7) // 8 + 7) & ~7) and len(bufs) == 8
+    ok = ok and bytes(body[bufs[1][0]: bufs[1][0] + 4 * rows]) == cols[0].cpu().numpy().tobytes()
+    ok = ok and bytes(body[bufs[7][0]: bufs[7][0] + 8 * rows]) == cols[3].cpu().numpy().tobytes() and bytes(body[:8]) == b"\xff" * 8
     if not ok:
         raise RuntimeError("packed IPC body differs from the columns")
     st = stats.get("ipc_pack_kernel")

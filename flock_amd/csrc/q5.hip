@@ -270,6 +270,25 @@ __global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__rest
     }
 }
 
+// Weighted input (the FinalPartitioned side): a window's counts must stay below 2^32 -- the direct-address counters are
+// uint32 and the packed table slots carry their count in the low half.  Per-pane weight totals, summed per window on the host.
+__global__ __launch_bounds__(kBlock) void q5_pane_weight_kernel(const uint32_t *__restrict__ weight, const int64_t *__restrict__ seg_off,
+                                                                unsigned long long *__restrict__ pane_sum) {
+    __shared__ unsigned long long s_part[kWavesPerBlock];
+    const int pane = blockIdx.y;
+    const int64_t lo = seg_off[2 * pane], hi = seg_off[2 * pane + 1];
+    unsigned long long acc = 0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kBlock) acc += weight[i];
+    acc = wave_sum_u64(acc);
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += s_part[w];
+        if (t) atomicAdd(&pane_sum[pane], t);
+    }
+}
+
 // One launch instead of five memsets: the counters in use (their number from the device when the layout was made there),
 // the window tables, the scalars, the slow list head and the per-workgroup maxima.
 __global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, const uint64_t *__restrict__ info, uint64_t cnt_host,
@@ -893,6 +912,15 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     FG_TRY(pinned_get_t(ctx, "q5.meta", n_meta, &h_meta));
     uint32_t *d_cursor = reinterpret_cast<uint32_t *>(d_meta + 2 * n_win), *d_err = d_cursor + 1, *d_used = d_cursor + 2;
 
+    unsigned long long *d_wsum = nullptr, *h_wsum = nullptr;  // weighted input: per-pane weight totals
+    if (weight && n_panes > 0) {
+        FG_TRY(arena_get_t(ctx, "q5.pane_weight", (size_t)n_panes + 1, &d_wsum));
+        FG_TRY(pinned_get_t(ctx, "q5.pane_weight", (size_t)n_panes + 1, &h_wsum));
+        FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
+        hipLaunchKernelGGL(q5_pane_weight_kernel, dim3(16, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, weight, st.seg_off, d_wsum);
+        FG_TRY(check_launch(ctx, "q5_pane_weight_kernel"));
+        FG_HIP(ctx, hipMemcpyAsync(h_wsum, d_wsum, sizeof(unsigned long long) * (size_t)n_panes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     // hash tables: only stragglers in dense mode; every group otherwise (sized from the density seen last call)
     double rpg = ctx->q5_rows_per_group < 1.0 ? 1.0 : ctx->q5_rows_per_group;
     uint64_t cap64 = dense ? 1024 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
@@ -1035,6 +1063,14 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             }
             cnt_total = h_info[0];
             scan_total = h_info[1];
+        }
+        if (h_wsum) {   // (the copy was queued before the loop: valid after any synchronisation)
+            for (int w = 0; w < n_win; ++w) {
+                unsigned long long tot = 0;
+                for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p) tot += h_wsum[p];
+                if (tot >= (1ull << 32))
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5 weighted: the counts of window %d add up to %llu >= 2^32 (32-bit counters)", w, tot);
+            }
         }
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
         n_sel = tail[0];

@@ -95,12 +95,13 @@ def record_batch_header(n_rows: int, nodes: Sequence[Tuple[int, int]], buffers: 
     """org.apache.arrow.flatbuf.Message { version: V5, header: RecordBatch { length, nodes: [FieldNode(length, null_count)],
     buffers: [Buffer(offset, length)] }, bodyLength } -- what `FlightData.data_header` holds for a record batch.
 
-    Fixed layout (every int64 on an 8-byte boundary):
+    Fixed layout (every int64 on an 8-byte boundary), 80 + 16 * (fields + buffers) bytes -- the size arrow-rs's writer produces,
+    which is what the reference's Flight-size goldens count (payload.rs:309, :402):
         0 root offset | 4 Message vtable (12 B) | 16 Message table | 36 RecordBatch vtable (10 B) | 48 RecordBatch table
-        | 76 nodes vector | buffers vector"""
-    nodes_pos = 76                                   # element count; elements start 8-aligned at 80
-    nodes_end = 80 + 16 * len(nodes)
-    bufs_pos = nodes_end + 4
+        | 68 nodes count, 72 nodes | 4 B pad, buffers count, buffers"""
+    nodes_pos = 68                                   # element count; elements start 8-aligned at 72
+    nodes_end = 72 + 16 * len(nodes)
+    bufs_pos = nodes_end + 4                         # (4 bytes of padding before the count keep the elements 8-aligned)
     total = bufs_pos + 4 + 16 * len(buffers)
     out = bytearray(total)
     struct.pack_into("<I", out, 0, 16)                                   # root -> Message table
@@ -110,7 +111,7 @@ def record_batch_header(n_rows: int, nodes: Sequence[Tuple[int, int]], buffers: 
     struct.pack_into("<iIqI", out, 48, 12, nodes_pos - 52, n_rows, bufs_pos - 64)
     struct.pack_into("<I", out, nodes_pos, len(nodes))
     for i, (length, nulls) in enumerate(nodes):
-        struct.pack_into("<qq", out, 80 + 16 * i, length, nulls)
+        struct.pack_into("<qq", out, 72 + 16 * i, length, nulls)
     struct.pack_into("<I", out, bufs_pos, len(buffers))
     for i, (off, length) in enumerate(buffers):
         struct.pack_into("<qq", out, bufs_pos + 4 + 16 * i, off, length)
@@ -190,8 +191,8 @@ def schema_from_bytes(data: bytes):
 def flight_data_sizes(rows: int, columns: Sequence[Tuple[str, Optional[int]]], validity: bool = True) -> Tuple[int, int]:
     """(header bytes, body bytes) of a batch's Arrow Flight data from its shape alone: columns = (type, total value bytes of
     a Utf8 column).  validity = True is the reference's writer (arrow-rs of its day writes an all-ones bitmap of
-    ceil(rows / 8) bytes for EVERY field, `write_array_data`); its two size goldens (payload.rs:309, :402) equal these
-    numbers minus 8 bytes of flatbuffer layout in the header (tests/test_payload.py)."""
+    ceil(rows / 8) bytes for EVERY field, `write_array_data`); header + body are its two size goldens (payload.rs:309, :402;
+    tests/test_payload.py)."""
     pad = lambda n: (n + 7) & ~7
     width = {"int8": 1, "int32": 4, "int64": 8, "uint64": 8, "float64": 8, "timestamp_ms": 8}
     body, n_buf = 0, 0
@@ -224,11 +225,11 @@ def _layout(batch: DeviceBatch, validity_bits=None):
     return nodes, bufs
 
 
-def batch_to_flight_data(ctx, batch: DeviceBatch, keep_view: bool = False, validity: bool = False):
+def batch_to_flight_data(ctx, batch: DeviceBatch, keep_view: bool = False, validity: bool = True):
     """(data_header, data_body) of `flight_data_from_arrow_batch` for a device batch: body packed on the device, one D2H
     into pinned memory.  keep_view: return the body as a numpy view of the context's pinned buffer (valid until the next
-    call) instead of a bytes copy -- what a caller that compresses it right away wants.  validity: write an all-ones
-    bitmap per field like the reference's arrow-rs writer (default: absent, like Arrow C++; readers accept both)."""
+    call) instead of a bytes copy -- what a caller that compresses it right away wants.  validity (default): an all-ones
+    bitmap per field, the bytes the reference's arrow-rs writer emits; False leaves it out like Arrow C++ (readers accept both)."""
     import ctypes as C
     import torch
     from . import _ffi
@@ -361,7 +362,7 @@ def _kind_of(t) -> str:
 
 
 def to_payload(ctx, batch1: Sequence[DeviceBatch], batch2: Sequence[DeviceBatch], uuid: Uuid, sync: bool,
-               encoding: Optional[Encoding] = None, validity: bool = False) -> Payload:
+               encoding: Optional[Encoding] = None, validity: bool = True) -> Payload:
     """`to_payload` (transmute.rs:176-216) for batches in HBM."""
     encoding = encoding or Encoding()
 

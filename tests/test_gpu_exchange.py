@@ -226,3 +226,19 @@ def test_q5_exchange_world1_uses_partial_groups(ctx, world1):
     shard = q5_exchange(ctx, g.bids, sched)
     a, n, off = ctx.q5_hot_items(g.bids, sched).to_host()
     assert np.array_equal(shard.auction, a) and np.array_equal(shard.num, n) and np.array_equal(shard.offsets, off)
+
+
+def test_q5_weighted_rejects_counts_that_overflow_32_bits(ctx):
+    """rows of the weighted entry carry a count each, so a window can reach 2^32 with few rows; the 32-bit counters
+    (and the count half of the packed table slots) would wrap -- the call must say UNSUPPORTED instead."""
+    from flock_amd import FlockGpuError, WindowSchedule, _ffi
+    n = 64
+    key = _dev(np.arange(1000, 1000 + n, dtype=np.int32))
+    big = _dev(np.full(n, 2**27, np.int32))                                  # (uint32 counts travel as int32 bits)
+    sched = WindowSchedule(np.array([0, n // 2, n]), np.array([0, 0], np.int32), np.array([1, 2], np.int32))   # window 1 = everything: 2^33
+    with pytest.raises(FlockGpuError) as e:
+        ctx.q5_hot_items_weighted(key, big, sched)
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and "2^32" in str(e.value)
+    ok = ctx.q5_hot_items_weighted(key, big, WindowSchedule(np.array([0, 16]), np.array([0], np.int32), np.array([1], np.int32)))   # 16 * 2^27 = 2^31
+    a, cnt, off = ok.to_host()
+    assert len(a) == 16 and (cnt == 2**27).all()

@@ -99,14 +99,13 @@ def test_payload_json_has_the_serde_shape():
 def test_reference_size_goldens():
     """The two Arrow Flight sizes the reference asserts (payload.rs:309: 1856 for 37 UK cities; :402: 3453248 for 21275
     citibike trips) follow from the batch shapes alone (tests/golden/payload_sizes.json, tools/make_payload_golden.py): body
-    with one all-ones validity bitmap per field, as its arrow-rs writer emits, + a header that is 8 bytes shorter than the
-    one written here (flatbuffer layout) -- the same 8 bytes for 3 fields / 7 buffers and for 15 fields / 36 buffers."""
+    with one all-ones validity bitmap per field, as its arrow-rs writer emits, + the 80 + 16 * (fields + buffers)-byte header."""
     import os
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "payload_sizes.json")))
     for name, case in g.items():
         cols = [(c["type"], c["value_bytes"]) for c in case["columns"]]
         header, body = P.flight_data_sizes(case["rows"], cols, validity=True)
-        assert header + body - 8 == case["reference_flight_data_size"], name
+        assert header + body == case["reference_flight_data_size"], name
         h2, b2 = P.flight_data_sizes(case["rows"], cols, validity=False)
         assert h2 == header and b2 < body
 
@@ -144,15 +143,22 @@ def _device_batch(batch):
 @pytest.mark.parametrize("n,encoding", [(0, "Zstd"), (1, "None"), (777, "Zstd"), (200_000, "Lz4"), (50_000, "Snappy")])
 def test_device_batches_through_a_payload(ctx, n, encoding):
     b1, b2 = _batch(n, 1), _batch(max(n // 3, 1), 2)
+    # without validity bitmaps the body is Arrow C++'s body byte for byte, and Arrow reads the header
+    cpp = P.to_payload(ctx, [_device_batch(b1)], [], P.Uuid("q-1-1", 0, 1), True, P.Encoding(encoding), validity=False)
+    header, body = cpp.encoding.decompress(cpp.data[0].header), cpp.encoding.decompress(cpp.data[0].body)
+    assert body == pa.ipc.read_message(b1.serialize()).body.to_pybytes()
+    assert pa.ipc.read_record_batch(pa.ipc.read_message(pa.py_buffer(P.encapsulate(header, body))), P.schema_from_bytes(cpp.schema)).equals(b1)
+    # the default is the reference writer's variant (an all-ones validity bitmap per field): read by Arrow just the same, and
+    # of the size flight_data_sizes predicts (the formula behind the reference's size goldens)
     pay = P.to_payload(ctx, [_device_batch(b1), _device_batch(b1)], [_device_batch(b2)], P.Uuid("q-1-1", 0, 1), True, P.Encoding(encoding))
     assert len(pay.data) == 2 and len(pay.data2) == 1 and pay.datasource == {"Payload": True}
-    # the body is Arrow's body, the header is read by Arrow
-    header, body = pay.encoding.decompress(pay.data[0].header), pay.encoding.decompress(pay.data[0].body)
-    assert body == pa.ipc.read_message(b1.serialize()).body.to_pybytes()
-    assert pa.ipc.read_record_batch(pa.ipc.read_message(pa.py_buffer(P.encapsulate(header, body))), P.schema_from_bytes(pay.schema)).equals(b1)
-    # the reference writer's variant (an all-ones validity bitmap per field) is read by Arrow just the same
-    h3, b3 = P.batch_to_flight_data(ctx, _device_batch(b1), validity=True)
+    h3, b3 = P.batch_to_flight_data(ctx, _device_batch(b1))
+    assert pay.encoding.decompress(pay.data[0].body) == b3 and pay.encoding.decompress(pay.data[0].header) == h3
     assert len(b3) == len(body) + len(b1.schema) * ((((n + 7) // 8) + 7) & ~7)
+    kinds = {pa.int32(): "int32", pa.int64(): "int64", pa.uint64(): "uint64", pa.float64(): "float64", pa.timestamp("ms"): "timestamp_ms"}
+    shape = [("utf8", len(c.buffers()[2]) if c.buffers()[2] is not None else 0) if pa.types.is_string(c.type) else (kinds[c.type], None) for c in b1.columns]
+    if all(k != "utf8" for k, _ in shape) or n == 0:
+        assert (len(h3), len(b3)) == P.flight_data_sizes(n, [(k, v if k != "utf8" else 0) for k, v in shape])
     assert pa.ipc.read_record_batch(pa.ipc.read_message(pa.py_buffer(P.encapsulate(h3, b3))), b1.schema).equals(b1)
     back = P.flight_data_to_batch(ctx, h3, b3, _device_batch(b1).fields)
     assert back.rows == n and (n == 0 or back.columns[0].cpu().numpy().tobytes() == np.frombuffer(b1.columns[0].buffers()[1], np.uint8)[: 4 * n].tobytes())
@@ -186,3 +192,36 @@ def test_query_output_as_payload(ctx):
     (got,), none = P.Payload.from_json(pay.to_json()).to_record_batch(ctx)
     assert none == [] and got.rows == len(a)
     assert np.array_equal(got.columns[0].cpu().numpy(), a) and np.array_equal(got.columns[1].cpu().numpy().view(np.uint64), n)
+
+
+def test_json_lines_size_golden():
+    """payload.rs:365-372: the citibike batch through arrow's json::LineDelimitedWriter is 9436023 bytes -- one compact
+    serde_json object per row and a newline, which is the format the JSON ingest (json.hip) decodes.  The number is recomputed
+    from the reference's CSV by tools/make_payload_golden.py (where the reference tree is present) and frozen next to the literal."""
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "payload_sizes.json")))["citibike"]
+    assert g["json_lines_bytes"] == g["reference_json_lines_bytes"] == 9436023
+    head = open(os.path.join(os.path.dirname(__file__), "golden", "citibike_head.jsonl")).read().splitlines()
+    assert len(head) == 256 and json.loads(head[0])["start station id"] == 3275 and json.loads(head[0])["tripduration"] == "756"
+
+
+@pytest.mark.gpu
+def test_json_ingest_decodes_the_citibike_lines(ctx):
+    """The first 256 citibike rows as those JSON lines through flockgpu_json_lines_decode: the Int32 and Utf8 members against
+    Python's json (Float64 members are skipped: the decoder's types are Int32 / Int64 / Utf8)."""
+    import os
+    import torch
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "citibike_head.jsonl"), "rb").read()
+    want = [json.loads(line) for line in text.splitlines()]
+    fields = [("tripduration", "utf8"), ("start station id", "int32"), ("start station name", "utf8"), ("bikeid", "int32"),
+              ("usertype", "utf8"), ("birth year", "int32"), ("gender", "int32")]
+    dev = torch.frombuffer(bytearray(text + b"\0" * 16), dtype=torch.uint8).cuda()[: len(text)]
+    cols, n = ctx.json_lines_decode(dev, fields)
+    assert n == len(want)
+    for name, kind in fields:
+        if kind == "utf8":
+            off = cols[name].offsets.cpu().numpy()
+            raw = cols[name].data.cpu().numpy()[: off[-1]].tobytes()
+            assert [raw[off[i]:off[i + 1]].decode() for i in range(n)] == [w[name] for w in want], name
+        else:
+            assert cols[name].cpu().numpy().tolist() == [w[name] for w in want], name
