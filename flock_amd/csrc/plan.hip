@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "../../include/flockgpu_plan.h"
 #include "plan_ir.hpp"
@@ -106,8 +107,9 @@ struct FusedInfo {
     std::vector<std::string> strs;    // q3 state literals
 };
 
-constexpr int kStageChunks = 4;
-constexpr size_t kStageChunk = size_t(8) << 20;
+constexpr int kStageLanes = 4;                     // host threads that fill pinned chunks side by side
+constexpr int kStageChunks = kStageLanes * 2;      // two chunks per lane: one is filled while the other is in flight
+constexpr size_t kStageChunk = size_t(4) << 20;
 
 }  // namespace
 
@@ -120,9 +122,11 @@ struct flockgpu_plan {
     std::string description;
     bool generic_only = false;
     // pageable feeds go through a ring of pinned chunks: the host copies into chunk k + 1 while chunk k is in flight
-    void *stage[kStageChunks] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t stage_done[kStageChunks] = {nullptr, nullptr, nullptr, nullptr};
-    int stage_next = 0;
+    void *stage[kStageChunks] = {};
+    hipEvent_t stage_done[kStageChunks] = {};
+    int stage_next[kStageLanes] = {};
+    struct CopyJob { void *dst; const void *src; size_t bytes; };
+    std::vector<CopyJob> jobs;   // the pageable copies of the feed in progress
     int64_t fed_bytes = 0;
 };
 
@@ -578,9 +582,8 @@ bool host_is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
-// Host -> device on the plan's stream without a host wait: pinned (registered) memory is handed to the DMA engine as
-// it is; pageable memory is copied chunk by chunk into the plan's pinned ring, the host filling chunk k + 1 while chunk k
-// is in flight (hipMemcpyAsync from pageable memory would block the caller for the whole transfer instead).
+// Host -> device on the plan's stream without a host wait: pinned (registered) memory is handed to the DMA engine as it is;
+// pageable memory is queued as a copy job and moved by flush_jobs() through the plan's pinned ring.
 int h2d(flockgpu_plan *pl, void *dst, const void *src, size_t bytes) {
     flockgpu_ctx *ctx = pl->ctx;
     if (!bytes) return FLOCKGPU_OK;
@@ -589,21 +592,58 @@ int h2d(flockgpu_plan *pl, void *dst, const void *src, size_t bytes) {
         FG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return FLOCKGPU_OK;
     }
-    for (size_t done = 0; done < bytes;) {
-        const int k = pl->stage_next;
-        pl->stage_next = (k + 1) % kStageChunks;
+    pl->jobs.push_back(flockgpu_plan::CopyJob{dst, src, bytes});
+    return FLOCKGPU_OK;
+}
+
+// One staging lane: its share of the pieces, each copied into one of the lane's two pinned chunks (the host fills one while the
+// other is in flight) and sent with hipMemcpyAsync on the plan's stream.  (hipMemcpyAsync from pageable memory would block the
+// caller for the whole transfer and moves ~10 GB/s; one host thread's memcpy is no faster -- several lanes side by side are.)
+int stage_lane(flockgpu_plan *pl, int lane, const std::vector<flockgpu_plan::CopyJob> &pieces, int n_lanes) {
+    flockgpu_ctx *ctx = pl->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return FLOCKGPU_ERR_HIP;
+    for (size_t i = (size_t)lane; i < pieces.size(); i += (size_t)n_lanes) {
+        const int k = lane * 2 + pl->stage_next[lane];
+        pl->stage_next[lane] ^= 1;
+        if (hipEventSynchronize(pl->stage_done[k]) != hipSuccess) return FLOCKGPU_ERR_HIP;
+        std::memcpy(pl->stage[k], pieces[i].src, pieces[i].bytes);
+        if (hipMemcpyAsync(pieces[i].dst, pl->stage[k], pieces[i].bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FLOCKGPU_ERR_HIP;
+        if (hipEventRecord(pl->stage_done[k], ctx->stream) != hipSuccess) return FLOCKGPU_ERR_HIP;
+    }
+    return FLOCKGPU_OK;
+}
+
+int flush_jobs(flockgpu_plan *pl) {
+    flockgpu_ctx *ctx = pl->ctx;
+    if (pl->jobs.empty()) return FLOCKGPU_OK;
+    std::vector<flockgpu_plan::CopyJob> pieces;
+    size_t total = 0;
+    for (auto &j : pl->jobs)
+        for (size_t done = 0; done < j.bytes; done += kStageChunk) {
+            const size_t n = std::min(kStageChunk, j.bytes - done);
+            pieces.push_back(flockgpu_plan::CopyJob{static_cast<uint8_t *>(j.dst) + done, static_cast<const uint8_t *>(j.src) + done, n});
+            total += n;
+        }
+    pl->jobs.clear();
+    for (int k = 0; k < kStageChunks; ++k)
         if (!pl->stage[k]) {
             FG_HIP(ctx, hipHostMalloc(&pl->stage[k], kStageChunk, hipHostMallocDefault));
             FG_HIP(ctx, hipEventCreateWithFlags(&pl->stage_done[k], hipEventDisableTiming));
-        } else {
-            FG_HIP(ctx, hipEventSynchronize(pl->stage_done[k]));
+            FG_HIP(ctx, hipEventRecord(pl->stage_done[k], ctx->stream));
         }
-        const size_t n = std::min(kStageChunk, bytes - done);
-        std::memcpy(pl->stage[k], static_cast<const uint8_t *>(src) + done, n);
-        FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, pl->stage[k], n, hipMemcpyHostToDevice, ctx->stream));
-        FG_HIP(ctx, hipEventRecord(pl->stage_done[k], ctx->stream));
-        done += n;
+    // small feeds stay on the calling thread; from a few MB on the lanes pay for their start-up
+    const int n_lanes = total < (size_t(2) << 20) ? 1 : (int)std::min<size_t>(kStageLanes, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    if (n_lanes == 1) {
+        if (stage_lane(pl, 0, pieces, 1) != FLOCKGPU_OK) return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: staged host-to-device copy failed");
+        return FLOCKGPU_OK;
     }
+    std::vector<std::thread> workers;
+    std::vector<int> rc((size_t)n_lanes, FLOCKGPU_OK);
+    for (int l = 1; l < n_lanes; ++l) workers.emplace_back([&, l] { rc[(size_t)l] = stage_lane(pl, l, pieces, n_lanes); });
+    rc[0] = stage_lane(pl, 0, pieces, n_lanes);
+    for (auto &w : workers) w.join();
+    for (int r : rc)
+        if (r != FLOCKGPU_OK) return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: staged host-to-device copy failed");
     return FLOCKGPU_OK;
 }
 
@@ -1390,6 +1430,8 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
     }
     std::vector<uint8_t> tmp_vals, tmp_bytes;
     std::vector<int32_t> tmp_off;
+    struct Rebase { int32_t *data; int64_t n; int32_t delta; };
+    std::vector<Rebase> rebases;  // Utf8 offsets are rebased on the device once their copy is queued
     for (int b = 0; b < n_batches; ++b) {
         const ArrowArray *rb = batches[b];
         int64_t n = rb->length;
@@ -1420,8 +1462,9 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
                 }
                 // offsets[rows + 1 .. rows + n] = source offsets rebased onto the column's byte cursor, on the device
                 FG_TRY(h2d(plan, dc.offsets + ld.rows + 1, so + 1, (size_t)rows_in * 4));
-                FG_TRY(add_i32(ctx, dc.offsets + ld.rows + 1, rows_in, (int32_t)(dc.bytes - b0)));
+                rebases.push_back(Rebase{dc.offsets + ld.rows + 1, rows_in, (int32_t)(dc.bytes - b0)});
                 if (nbytes) FG_TRY(h2d(plan, static_cast<uint8_t *>(dc.values) + dc.bytes, src + b0, (size_t)nbytes));
+                if (filt) FG_TRY(flush_jobs(plan));  // the compacted copies live in temporaries that the next column reuses
                 dc.bytes += nbytes;
             } else {
                 const size_t w = col_width(lf.schema[c].type);
@@ -1434,10 +1477,13 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
                     rows_in = (int64_t)k.size();
                 }
                 FG_TRY(h2d(plan, static_cast<uint8_t *>(dc.values) + (size_t)ld.rows * w, src, (size_t)rows_in * w));
+                if (filt) FG_TRY(flush_jobs(plan));
             }
         }
         ld.rows += filt ? (int64_t)k.size() : n;
     }
+    FG_TRY(flush_jobs(plan));  // every pageable buffer of this feed, several staging lanes side by side
+    for (auto &r : rebases) FG_TRY(add_i32(ctx, r.data, r.n, r.delta));  // (stream-ordered behind the copies above)
     return FLOCKGPU_OK;  // no host wait: the copies are ordered before the plan's kernels on the ctx stream
 }
 
