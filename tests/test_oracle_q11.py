@@ -73,3 +73,76 @@ def test_columnar_restatement_matches_the_walk(seed, n_epochs, per_epoch, n_bidd
     assert _columnar_as_dicts(oracle.q11_user_sessions_columnar(bidder, ts, off, timeout, BASE)) == want
     if n_bidders >= 40 and jitter == 0:
         assert sum(len(d) for d in want) > 3
+
+
+def _q11_per_bidder_then_acero(bidder, ts, off, timeout_s, base_ms):
+    """An independent formulation: the launcher part as a PER-BIDDER event simulation (the walk above goes
+    epoch by epoch over all bidders, the columnar restatement compares neighbours of one sorted array), and q11.sql itself --
+    GROUP BY bidder: COUNT(*), MIN(b_date_time), MAX(b_date_time) -- evaluated by Arrow C++'s hash aggregation over the rows each
+    epoch hands out."""
+    import pyarrow as pa
+    n_epochs = len(off) - 1
+    ep = np.searchsorted(off, np.arange(off[-1]), side="right") - 1
+    handed = [[] for _ in range(n_epochs)]                    # per epoch: row arrays of the sessions closed there
+    base_s = base_ms // 1000
+    tbl = pa.table({"bidder": pa.array(bidder), "row": pa.array(np.arange(len(bidder), dtype=np.int64))})
+    groups = tbl.group_by("bidder", use_threads=False).aggregate([("row", "list")])
+    for rows in groups["row_list"].to_pylist():
+        rows = np.asarray(rows, np.int64)                      # arrival order
+        parts = np.split(rows, np.flatnonzero(np.diff(ep[rows])) + 1)
+        open_rows, open_ep = None, None
+        for p in parts:
+            e = int(ep[p[0]])
+            if open_rows is not None:
+                last_s = int(ts[open_rows[-1]]) // 1000
+                t_close = max(open_ep, last_s - base_s + timeout_s + 1)   # first epoch whose time-out check fires
+                if t_close < e:
+                    handed[t_close].append(open_rows)
+                    open_rows = None
+                elif int(ts[p[0]]) // 1000 - last_s > timeout_s:
+                    handed[e].append(open_rows)
+                    open_rows = None
+            open_rows = p if open_rows is None else np.concatenate([open_rows, p])
+            open_ep = e
+        if open_rows is not None:
+            t_close = max(open_ep, int(ts[open_rows[-1]]) // 1000 - base_s + timeout_s + 1)
+            if t_close <= n_epochs - 1:
+                handed[t_close].append(open_rows)
+    out = []
+    for e in range(n_epochs):
+        if not handed[e]:
+            out.append({})
+            continue
+        r = np.concatenate(handed[e])
+        t = pa.table({"bidder": pa.array(bidder[r]), "b_date_time": pa.array(ts[r])})
+        g = t.group_by("bidder").aggregate([("b_date_time", "count"), ("b_date_time", "min"), ("b_date_time", "max")])
+        out.append({int(b): (int(c), int(mn), int(mx)) for b, c, mn, mx in zip(g["bidder"].to_pylist(), g["b_date_time_count"].to_pylist(),
+                                                                              g["b_date_time_min"].to_pylist(), g["b_date_time_max"].to_pylist())})
+    return out
+
+
+@pytest.mark.parametrize("seed,eps,seconds,timeout", [(3, 400, 40, 10), (4, 2000, 25, 2), (5, 150, 60, 5)])
+def test_q11_walk_equals_an_independent_pyarrow_formulation_on_nexmark_bids(seed, eps, seconds, timeout):
+    """Seeded NEXMark bids (the generator's hot / cold bidders and its event-time order), ElementWise epochs of one second."""
+    s = oracle.NexmarkStream(seed=seed, eps=eps)
+    n = eps * seconds
+    cols = s.bids(0, n, columns=("bidder", "b_date_time"))
+    off = np.array([s.counts(0, e * eps)[2] for e in range(seconds + 1)], np.int64)
+    base = int(cols["b_date_time"][0]) // 1000 * 1000
+    want = oracle.q11_user_sessions(cols["bidder"], cols["b_date_time"], off, timeout, base)
+    got = _q11_per_bidder_then_acero(cols["bidder"], cols["b_date_time"], off, timeout, base)
+    assert got == want
+    assert sum(len(d) for d in want) > 10
+    assert _columnar_as_dicts(oracle.q11_user_sessions_columnar(cols["bidder"], cols["b_date_time"], off, timeout, base)) == want
+
+
+def test_q11_independent_formulation_on_late_and_early_bids():
+    rng = np.random.default_rng(11)
+    rows = []
+    for t in range(30):
+        for _ in range(int(rng.integers(0, 30))):
+            rows.append((t, int(rng.integers(100, 130)), max(0, t * 1000 + int(rng.integers(-4000, 3000)))))
+    bidder, ts, off = _bids(rows)
+    off = np.r_[off, np.full(31 - len(off), off[-1])] if len(off) < 31 else off
+    for timeout in (1, 3):
+        assert _q11_per_bidder_then_acero(bidder, ts, off, timeout, BASE) == oracle.q11_user_sessions(bidder, ts, off, timeout, BASE)
