@@ -97,7 +97,7 @@ struct LeafData {
     int64_t rows = 0;
 };
 
-enum Fused { kNone = 0, kQ2, kQ3, kQ5, kQ7, kQ8, kQ13, kPartialCount };
+enum Fused { kNone = 0, kQ2, kQ3, kQ5, kQ7, kQ8, kQ13, kPartialCount, kQ9, kQ4, kYsb };
 struct FusedInfo {
     Fused kind = kNone;
     int leaf_a = -1, leaf_b = -1;     // the scans below
@@ -183,8 +183,11 @@ bool logical_agg(const Node *n, LogicalAgg *out) {
             // the final stage must read the partial stage's columns in place
             for (size_t g = 0; g < n->group.size(); ++g)
                 if (p.map[(size_t)n->group[g]] != (int)g) return false;
+            int state_at = (int)n->group.size();
             for (size_t a = 0; a < n->aggs.size(); ++a) {
-                if (p.map[(size_t)n->aggs[a].arg] != (int)(n->group.size() + a) || p.n->aggs[a].fn != n->aggs[a].fn) return false;
+                if (p.map[(size_t)n->aggs[a].arg] != state_at || p.n->aggs[a].fn != n->aggs[a].fn) return false;
+                if (n->aggs[a].arg2 >= 0 && p.map[(size_t)n->aggs[a].arg2] != state_at + 1) return false;
+                state_at += agg_state_cols(n->aggs[a].fn);
             }
             low = p.n;
         } else {
@@ -209,6 +212,64 @@ bool req_subset(const Node *n, const std::vector<int> &allowed) {
     for (size_t i = 0; i < n->required.size(); ++i)
         if (n->required[i] && std::find(allowed.begin(), allowed.end(), (int)i) == allowed.end()) return false;
     return true;
+}
+
+// Q of q4.sql / q9.sql: MAX(price) per auction [, category] over auction JOIN bid ON a_id = auction WHERE b_date_time BETWEEN
+// a_date_time AND expires (planner.rs:218-256 stages 0-2; BETWEEN arrives as `x >= lo AND x <= hi`).
+struct WinningBids {
+    const Node *auction_scan = nullptr, *bid_scan = nullptr;
+    int a_id = -1, a_dt = -1, a_exp = -1, a_cat = -1;  // columns of the auction leaf
+    int b_auction = -1, b_price = -1, b_dt = -1;       // columns of the bid leaf
+};
+bool match_winning_bids(const Node *agg, bool with_category, WinningBids *w) {
+    LogicalAgg la;
+    if (!logical_agg(agg, &la) || la.fns != std::vector<std::string>{"max"} || la.group.size() != (with_category ? 2u : 1u)) return false;
+    Peeled pf = peel(la.below);
+    if (pf.n->kind != NKind::Filter) return false;
+    Peeled pj = peel(pf.n->in[0].get());
+    if (pj.n->kind != NKind::Join || pj.n->on_l2 >= 0) return false;
+    const Node *J = pj.n;
+    const int nl = (int)J->in[0]->schema.size();
+    auto to_join = [&](int below_col) {  // column of la.below -> column of the join's output
+        const int f = pf.map[(size_t)below_col];
+        return f < 0 ? -1 : pj.map[(size_t)f];
+    };
+    // b_date_time >= a_date_time AND b_date_time <= expires (either order of the conjuncts)
+    const Expr *p = pf.n->pred.get();
+    if (!is_bin(p, "And")) return false;
+    int x = -1, lo = -1, hi = -1;
+    for (const Expr *c : {p->l.get(), p->r.get()}) {
+        if (!c || c->kind != EKind::Bin) return false;
+        const Expr *a = uncast(c->l.get()), *b = uncast(c->r.get());
+        if (a->kind != EKind::Col || b->kind != EKind::Col) return false;
+        int cx, bound;
+        bool is_lo;
+        if (c->s == "GtEq") { cx = a->col; bound = b->col; is_lo = true; }
+        else if (c->s == "LtEq") { cx = a->col; bound = b->col; is_lo = false; }
+        else return false;
+        if (x >= 0 && x != cx) return false;
+        x = cx;
+        (is_lo ? lo : hi) = bound;
+    }
+    if (x < 0 || lo < 0 || hi < 0) return false;
+    x = pj.map[(size_t)x]; lo = pj.map[(size_t)lo]; hi = pj.map[(size_t)hi];
+    const int key = to_join(la.group[0]), cat = with_category ? to_join(la.group[1]) : -1, price = to_join(la.args[0]);
+    if (x < nl || lo < 0 || lo >= nl || hi < 0 || hi >= nl || price < nl || key != J->on_l || (with_category && (cat < 0 || cat >= nl))) return false;
+    std::vector<int> lmap, rmap;
+    w->auction_scan = as_scan(J->in[0].get(), &lmap);
+    w->bid_scan = as_scan(J->in[1].get(), &rmap);
+    if (!w->auction_scan || !w->bid_scan) return false;
+    w->a_id = lmap[(size_t)J->on_l];
+    w->a_dt = lmap[(size_t)lo];
+    w->a_exp = lmap[(size_t)hi];
+    w->a_cat = with_category ? lmap[(size_t)cat] : -1;
+    w->b_auction = rmap[(size_t)J->on_r];
+    w->b_price = rmap[(size_t)(price - nl)];
+    w->b_dt = rmap[(size_t)(x - nl)];
+    auto is = [](const Node *scan, int c, ColType t, bool ts) { return c >= 0 && scan->schema[(size_t)c].type == t && scan->schema[(size_t)c].is_ts == ts; };
+    return is(w->auction_scan, w->a_id, ColType::I32, false) && is(w->auction_scan, w->a_dt, ColType::I64, true) &&
+           is(w->auction_scan, w->a_exp, ColType::I64, true) && (!with_category || is(w->auction_scan, w->a_cat, ColType::I32, false)) &&
+           is(w->bid_scan, w->b_auction, ColType::I32, false) && is(w->bid_scan, w->b_price, ColType::I32, false) && is(w->bid_scan, w->b_dt, ColType::I64, true);
 }
 
 void recognise_fused(flockgpu_plan *pl, const Node *n) {
@@ -253,6 +314,51 @@ void recognise_fused(flockgpu_plan *pl, const Node *n) {
             fi.leaf_a = scan->leaf;
             fi.a_cols = {map[(size_t)n->group[0]]};
             fi.out_map = {0, 1};
+            return;
+        }
+        LogicalAgg top;
+        if (n->mode == "Partial" || !logical_agg(n, &top) || top.group.size() != 1 || top.fns.size() != 1) return;
+        // ---- q4: AVG(final) GROUP BY category over Q (q4.sql; planner.rs:218-256)
+        if (top.fns[0] == "avg") {
+            Peeled pq = peel(top.below);
+            WinningBids w;
+            if (match_winning_bids(pq.n, true, &w) && pq.map[(size_t)top.group[0]] == 1 && pq.map[(size_t)top.args[0]] == 2) {
+                fi.kind = kQ4;
+                fi.leaf_a = w.auction_scan->leaf;
+                fi.leaf_b = w.bid_scan->leaf;
+                fi.a_cols = {w.a_id, w.a_cat, w.a_dt, w.a_exp};
+                fi.b_cols = {w.b_auction, w.b_price, w.b_dt};
+                fi.out_map = {0, 1};
+            }
+            return;
+        }
+        // ---- YSB: COUNT(*) GROUP BY campaign_id over Filter(event_type = lit)(ad_event) JOIN campaign ON ad_id = c_ad_id
+        // (ysb.sql; planner.rs:298-346)
+        if (top.fns[0] == "count" && top.below->schema[(size_t)top.group[0]].type == ColType::UTF8) {
+            Peeled pj = peel(top.below);
+            if (pj.n->kind != NKind::Join || pj.n->on_l2 >= 0) return;
+            const Node *J = pj.n;
+            const int nl = (int)J->in[0]->schema.size();
+            Peeled pl_ = peel(J->in[0].get());
+            std::vector<int> lmap, rmap;
+            const Node *rs = as_scan(J->in[1].get(), &rmap);
+            if (pl_.n->kind != NKind::Filter || !rs) return;
+            const Node *ls = as_scan(pl_.n->in[0].get(), &lmap);
+            const Expr *p = pl_.n->pred.get();
+            if (!ls || !is_bin(p, "Eq") || p->l->kind != EKind::Col || p->r->kind != EKind::LitS || p->r->s.size() > 40) return;
+            const int grp = pj.map[(size_t)top.group[0]];
+            const int ev_key = pl_.map[(size_t)J->on_l];
+            if (grp < nl || ev_key < 0) return;
+            const int ad = lmap[(size_t)ev_key], ty = lmap[(size_t)p->l->col], cad = rmap[(size_t)J->on_r], camp = rmap[(size_t)(grp - nl)];
+            auto text = [](const Node *scan, int c) { return c >= 0 && scan->schema[(size_t)c].type == ColType::UTF8; };
+            if (!text(ls, ad) || !text(ls, ty) || !text(rs, cad) || !text(rs, camp)) return;
+            fi.kind = kYsb;
+            fi.leaf_a = ls->leaf;
+            fi.leaf_b = rs->leaf;
+            fi.a_cols = {ad, ty};
+            fi.b_cols = {cad, camp};
+            fi.strs = {p->r->s};
+            fi.out_map = {0, 1};
         }
         return;
     }
@@ -260,6 +366,34 @@ void recognise_fused(flockgpu_plan *pl, const Node *n) {
     const Node *L = n->in[0].get(), *R = n->in[1].get();
     const size_t nl = L->schema.size();
     const Field &lk = L->schema[(size_t)n->on_l], &rk = R->schema[(size_t)n->on_r];
+    if (n->on_l2 >= 0) {
+        // ---- q9: bid JOIN Q ON auction = id AND price = final (q9.sql, q9_plan.fmt)
+        std::vector<int> lmap;
+        const Node *ls = as_scan(L, &lmap);
+        Peeled pr = peel(R);
+        WinningBids w;
+        if (!ls || !match_winning_bids(pr.n, false, &w)) return;
+        const auto &bs = pl->ir.leaves[(size_t)ls->leaf].schema;
+        static const char *names[4] = {"auction", "bidder", "price", "b_date_time"};
+        bool ok = bs.size() == 4 && lmap.size() == 4 && n->required.size() == 6;
+        for (int i = 0; ok && i < 4; ++i)
+            ok = bs[(size_t)i].name == names[i] && lmap[(size_t)i] == i && n->required[(size_t)i] && bs[(size_t)i].type == (i == 3 ? ColType::I64 : ColType::I32);
+        // the pairs in either order: (auction, id = the group key) and (price, final = the maximum)
+        int k_auction = n->on_l, k_id = pr.map[(size_t)n->on_r], k_price = n->on_l2, k_final = pr.map[(size_t)n->on_r2];
+        if (k_auction == 2) { std::swap(k_auction, k_price); std::swap(k_id, k_final); }
+        ok = ok && k_auction == 0 && k_price == 2 && k_id == 0 && k_final == 1;
+        // the inner bid scan must be the same relation (the SQL scans `bid` twice)
+        const auto &inner = pl->ir.leaves[(size_t)w.bid_scan->leaf].schema;
+        ok = ok && inner[(size_t)w.b_auction].name == "auction" && inner[(size_t)w.b_price].name == "price" && inner[(size_t)w.b_dt].name == "b_date_time";
+        if (ok) {
+            fi.kind = kQ9;
+            fi.leaf_a = w.auction_scan->leaf;
+            fi.leaf_b = ls->leaf;
+            fi.a_cols = {w.a_id, -1, w.a_dt, w.a_exp};
+            fi.out_map = {0, 1, 2, 3, 0, 2};  // id equals auction, final equals price on every output row
+        }
+        return;
+    }
     // ---- q3: Filter(int col = lit)(scan) JOIN Filter(utf8 col = a OR ...)(scan) on Int32 keys
     {
         Peeled pl_ = peel(L), pr = peel(R);
@@ -453,6 +587,9 @@ const char *fused_name(Fused f) {
         case kQ8: return "fused q8 distinct + join (q8.hip)";
         case kQ13: return "fused q13 side-input join (q13.hip)";
         case kPartialCount: return "fused Partial COUNT (q5.hip)";
+        case kQ9: return "fused q9 winning bids (q4q9.hip; generic when the auction ids of a batch are not dense)";
+        case kQ4: return "fused q4 average winning bid by category (q4q9.hip; generic when the auction ids of a batch are not dense)";
+        case kYsb: return "fused YSB filter + join + count (ysb.hip)";
         default: return "generic (relops.hip)";
     }
 }
@@ -488,6 +625,9 @@ int classify(const flockgpu_plan *pl) {
         case kQ7: return 7;
         case kQ8: return 8;
         case kQ13: return 13;
+        case kQ9: return 9;
+        case kQ4: return 4;
+        case kYsb: return 100;  // not a NEXMark number: the Yahoo Streaming Benchmark's one query
         default: return 0;
     }
 }
@@ -874,6 +1014,46 @@ struct Exec {
                 place(n, fi, {dev_col(ColType::I32, r.p_id), dev_col(ColType::UTF8, r.name.data, r.name.offsets, r.name_bytes)}, r.rows, t);
                 return FLOCKGPU_OK;
             }
+            case kQ9:
+            case kQ4: {
+                const bool q9 = fi.kind == kQ9;
+                const LeafData &B = pl->leaves[(size_t)fi.leaf_b];
+                if (B.rows == 0 && A.rows > 0 && q9)  // the bids went to the inner scan's leaf, which holds three of the four columns
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: q9's bids were fed to the inner scan");
+                flockgpu_auction_time_cols ac{leaf_col<int32_t>(fi.leaf_a, fi.a_cols[0]), leaf_col<int32_t>(fi.leaf_a, fi.a_cols[1]),
+                                              leaf_col<int64_t>(fi.leaf_a, fi.a_cols[2]), leaf_col<int64_t>(fi.leaf_a, fi.a_cols[3]), A.rows};
+                flockgpu_bid_cols bc{};
+                if (q9) bc = flockgpu_bid_cols{leaf_col<int32_t>(fi.leaf_b, 0), leaf_col<int32_t>(fi.leaf_b, 1), leaf_col<int32_t>(fi.leaf_b, 2), leaf_col<int64_t>(fi.leaf_b, 3), B.rows};
+                else bc = flockgpu_bid_cols{leaf_col<int32_t>(fi.leaf_b, fi.b_cols[0]), nullptr, leaf_col<int32_t>(fi.leaf_b, fi.b_cols[1]), leaf_col<int64_t>(fi.leaf_b, fi.b_cols[2]), B.rows};
+                flockgpu_windows aw = whole(A.rows, off_a, lo_a, hi_a), bw = whole(B.rows, off_b, lo_b, hi_b);
+                if (q9) {
+                    flockgpu_q9_result r{};
+                    FG_TRY(flockgpu_q9_winning_bids(ctx, &ac, &aw, &bc, &bw, &r));
+                    place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::I32, r.bidder), dev_col(ColType::I32, r.price),
+                                  dev_col(ColType::I64, r.b_date_time, nullptr, 0, true)}, r.rows, t);
+                } else {
+                    flockgpu_q4_result r{};
+                    FG_TRY(flockgpu_q4_avg_final_by_category(ctx, &ac, &aw, &bc, &bw, &r));
+                    place(n, fi, {dev_col(ColType::I32, r.category), dev_col(ColType::F64, r.avg_final)}, r.rows, t);
+                }
+                return FLOCKGPU_OK;
+            }
+            case kYsb: {
+                const LeafData &B = pl->leaves[(size_t)fi.leaf_b];
+                flockgpu_ysb_event_cols ev{};
+                FG_TRY(leaf_utf8(fi.leaf_a, fi.a_cols[0], &ev.ad_id));
+                FG_TRY(leaf_utf8(fi.leaf_a, fi.a_cols[1], &ev.event_type));
+                ev.rows = A.rows;
+                flockgpu_ysb_campaign_cols cc{};
+                FG_TRY(leaf_utf8(fi.leaf_b, fi.b_cols[0], &cc.c_ad_id));
+                FG_TRY(leaf_utf8(fi.leaf_b, fi.b_cols[1], &cc.campaign_id));
+                cc.rows = B.rows;
+                flockgpu_windows w = whole(A.rows, off_a, lo_a, hi_a);
+                flockgpu_ysb_result r{};
+                FG_TRY(flockgpu_ysb_campaign_counts(ctx, &ev, &w, &cc, fi.strs[0].c_str(), &r));
+                place(n, fi, {dev_col(ColType::UTF8, r.campaign_id.data, r.campaign_id.offsets, r.campaign_bytes), dev_col(ColType::U64, r.count)}, r.rows, t);
+                return FLOCKGPU_OK;
+            }
             default:
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown fused pipeline");
         }
@@ -901,10 +1081,12 @@ struct Exec {
         }
         const Expr *l = uncast(e->l.get()), *r = uncast(e->r.get());
         bool flip = false;
-        if (l->kind == EKind::LitI || l->kind == EKind::LitS) { std::swap(l, r); flip = true; }
+        if (l->kind == EKind::LitI || l->kind == EKind::LitS || l->kind == EKind::LitF) { std::swap(l, r); flip = true; }
         CmpOp op;
         if (!cmp_of(e->s, &op, flip)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: operator '%s' in a predicate", e->s.c_str());
         auto column = [&](const Expr *x) -> const TCol * { return x->kind == EKind::Col && in.cols[(size_t)x->col].present ? &in.cols[(size_t)x->col] : nullptr; };
+        if (l->kind == EKind::Col && (r->kind == EKind::LitI || r->kind == EKind::LitF) && column(l) && column(l)->c.type == ColType::F64)
+            return mask_cmp_f64_lit(ctx, column(l)->c, in.rows, op, r->kind == EKind::LitF ? r->f : (double)r->i, mask);
         if (l->kind == EKind::Col && r->kind == EKind::LitI && column(l)) return mask_cmp_lit(ctx, column(l)->c, in.rows, op, r->i, mask);
         if (l->kind == EKind::Col && r->kind == EKind::LitS && column(l) && (op == CmpOp::EQ || op == CmpOp::NE))
             return mask_utf8_eq(ctx, column(l)->c, in.rows, r->s, op == CmpOp::NE, mask);
@@ -937,7 +1119,13 @@ struct Exec {
 
     int exec(const Node *n, Table *t) {
         const FusedInfo &fi = pl->fused[(size_t)n->id];
-        if (fi.kind != kNone) return run_fused(n, fi, t);
+        if (fi.kind != kNone) {
+            const int rc = run_fused(n, fi, t);
+            // q4 / q9's fused kernels need dense, increasing auction ids inside a batch (include/flockgpu.h); any other batch runs
+            // on the generic operators below
+            if (rc != FLOCKGPU_ERR_UNSUPPORTED || (fi.kind != kQ9 && fi.kind != kQ4)) return rc;
+            *t = Table{};
+        }
         switch (n->kind) {
             case NKind::Scan:
                 return scan_table(n, t);
@@ -994,15 +1182,35 @@ struct Exec {
                 FG_TRY(exec(n->in[1].get(), &R));
                 t->cols.assign(n->schema.size(), TCol{});
                 const TCol &lk = L.cols[(size_t)n->on_l], &rk = R.cols[(size_t)n->on_r];
-                if ((lk.c.type == ColType::U64) != (rk.c.type == ColType::U64) || lk.c.type == ColType::UTF8 || rk.c.type == ColType::UTF8 ||
-                    lk.c.type == ColType::F64 || rk.c.type == ColType::F64)
-                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join keys must be integer columns of one signedness");
+                const bool text_keys = lk.c.type == ColType::UTF8 && rk.c.type == ColType::UTF8 && n->on_l2 < 0;
+                if (!text_keys && ((lk.c.type == ColType::U64) != (rk.c.type == ColType::U64) || lk.c.type == ColType::UTF8 || rk.c.type == ColType::UTF8 ||
+                                   lk.c.type == ColType::F64 || rk.c.type == ColType::F64))
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join keys must be integer columns of one signedness, or two Utf8 columns");
                 int64_t nl = L.rows, nr = R.rows;
                 if (lk.c.all_null) nl = 0;  // NULL keys never match
                 if (rk.c.all_null) nr = 0;
                 int64_t *kl = nullptr, *kr = nullptr;
-                FG_TRY(key_i64(n, lk, nl, "kl", &kl));
-                FG_TRY(key_i64(n, rk, nr, "kr", &kr));
+                if (text_keys) {  // equal strings <-> equal dictionary codes (exact: full byte compare inside utf8_codes)
+                    if (!lk.present || !rk.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "kl").c_str(), (size_t)nl + 2, &kl));
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "kr").c_str(), (size_t)nr + 2, &kr));
+                    FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), lk.c, nl, kl, &rk.c, nr, kr));
+                } else if (n->on_l2 >= 0) {  // two Int32 pairs compare as one 64-bit key
+                    const TCol &lk2 = L.cols[(size_t)n->on_l2], &rk2 = R.cols[(size_t)n->on_r2];
+                    if (lk.c.type != ColType::I32 || rk.c.type != ColType::I32 || lk2.c.type != ColType::I32 || rk2.c.type != ColType::I32)
+                        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a two-key join needs Int32 key columns");
+                    if (!lk.present || !rk.present || !lk2.present || !rk2.present)
+                        return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+                    if (lk2.c.all_null) nl = 0;
+                    if (rk2.c.all_null) nr = 0;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "kl").c_str(), (size_t)nl + 2, &kl));
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "kr").c_str(), (size_t)nr + 2, &kr));
+                    FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(lk.c.values), static_cast<const int32_t *>(lk2.c.values), nl, kl));
+                    FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(rk.c.values), static_cast<const int32_t *>(rk2.c.values), nr, kr));
+                } else {
+                    FG_TRY(key_i64(n, lk, nl, "kl", &kl));
+                    FG_TRY(key_i64(n, rk, nr, "kr", &kr));
+                }
                 int32_t *lrows = nullptr, *rrows = nullptr;
                 int64_t pairs = 0;
                 FG_TRY(join_key64(ctx, node_key(pl, n, "join").c_str(), kl, nl, kr, nr, &lrows, &rrows, &pairs));
@@ -1060,22 +1268,91 @@ struct Exec {
             t->cols[0].present = t->cols[1].present = true;
             return FLOCKGPU_OK;
         }
-        // ---- GROUP BY one integer column: COUNT (Partial: rows; Final: sum of the partial counts) or no aggregate
-        if (n->group.size() != 1 || n->aggs.size() > 1 || (n->aggs.size() == 1 && n->aggs[0].fn != "count"))
-            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY shape outside {k | COUNT}, {k}, {k, text}, {| MAX}");
+        // ---- GROUP BY one integer column or two Int32 columns; COUNT / MAX / MIN / SUM / AVG of integer columns.
+        // Partial: accumulators over the rows -> state columns (agg_state_cols); Final: the same accumulators over the states.
+        const bool pair = n->group.size() == 2;
+        if (n->group.empty() || n->group.size() > 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY more than two columns");
         const TCol &k = in.cols[(size_t)n->group[0]];
         int64_t *keys = nullptr;
-        FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
-        const uint64_t *values = nullptr;
-        if (!n->aggs.empty() && is_final) {
-            const TCol &st = in.cols[(size_t)n->aggs[0].arg];
-            if (st.c.type != ColType::U64 || !st.present) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: COUNT state column must be UInt64");
-            values = static_cast<const uint64_t *>(st.c.values);
+        if (pair) {
+            const TCol &k2 = in.cols[(size_t)n->group[1]];
+            if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
+            FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
+        } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
+            if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
+            FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), k.c, in.rows, keys, nullptr, 0, nullptr));
+        } else {
+            if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
+            FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
         }
-        GroupResult g;
-        FG_TRY(group_by_key64(ctx, node_key(pl, n, "grp").c_str(), keys, values, n->aggs.empty() ? AggKind::NONE : AggKind::SUM, in.rows, &g));
+        AggSpec specs[kMaxGroupAggs];
+        int n_specs = 0;
+        struct Out { int first = 0, count = 1; };  // accumulators of aggregate a
+        std::vector<Out> outs;
+        auto int_col = [&](int c, const char *what) -> const TCol * {
+            if (c < 0 || !in.cols[(size_t)c].present || in.cols[(size_t)c].c.type == ColType::UTF8 || in.cols[(size_t)c].c.type == ColType::F64) {
+                fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: %s needs an integer column", what);
+                return nullptr;
+            }
+            return &in.cols[(size_t)c];
+        };
+        for (auto &a : n->aggs) {
+            Out o;
+            o.first = n_specs;
+            o.count = a.fn == "avg" ? 2 : 1;
+            if (n_specs + o.count > kMaxGroupAggs) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: more than %d accumulators in one GROUP BY", kMaxGroupAggs);
+            if (a.fn == "count") {
+                if (is_final) {
+                    const TCol *st = int_col(a.arg, "the COUNT state");
+                    if (!st) return FLOCKGPU_ERR_UNSUPPORTED;
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, st->c.values, st->c.type};
+                } else {
+                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64};
+                }
+            } else if ((a.fn == "max" || a.fn == "min") && a.arg >= 0 && in.cols[(size_t)a.arg].present && in.cols[(size_t)a.arg].c.type == ColType::F64) {
+                specs[n_specs++] = AggSpec{a.fn == "max" ? AggOp::MAX_F64 : AggOp::MIN_F64, in.cols[(size_t)a.arg].c.values, ColType::F64};
+            } else if (a.fn == "max" || a.fn == "min" || a.fn == "sum") {
+                const TCol *v = int_col(a.arg, a.fn.c_str());
+                if (!v) return FLOCKGPU_ERR_UNSUPPORTED;
+                const bool uns = v->c.type == ColType::U64;
+                const AggOp op = a.fn == "sum" ? AggOp::SUM_INT : (a.fn == "max" ? (uns ? AggOp::MAX_U : AggOp::MAX_S) : (uns ? AggOp::MIN_U : AggOp::MIN_S));
+                specs[n_specs++] = AggSpec{op, v->c.values, v->c.type};
+            } else {  // avg: (count, sum)
+                if (is_final) {
+                    const TCol *cnt = int_col(a.arg, "the AVG count state");
+                    if (!cnt) return FLOCKGPU_ERR_UNSUPPORTED;
+                    const TCol &sm = in.cols[(size_t)a.arg2];
+                    if (!sm.present || sm.c.type != ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: the AVG sum state must be Float64");
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, cnt->c.values, cnt->c.type};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_F64, sm.c.values, ColType::F64};
+                } else {
+                    const TCol *v = int_col(a.arg, "AVG");
+                    if (!v) return FLOCKGPU_ERR_UNSUPPORTED;
+                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, v->c.values, v->c.type};
+                }
+            }
+            outs.push_back(o);
+        }
+        GroupResultN g;
+        FG_TRY(group_by_key64_n(ctx, node_key(pl, n, "grp").c_str(), keys, in.rows, specs, n_specs, &g));
         t->rows = g.n_groups;
-        if (k.c.type == ColType::I32) {
+        // ---- key columns
+        if (pair) {
+            int32_t *ka = nullptr, *kb = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk").c_str(), (size_t)g.n_groups + 4, &ka));
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk2").c_str(), (size_t)g.n_groups + 4, &kb));
+            FG_TRY(unpack_i32_pair(ctx, g.keys, g.n_groups, ka, kb));
+            t->cols[0] = dev_col(ColType::I32, ka);
+            t->cols[1] = dev_col(ColType::I32, kb);
+            t->cols[1].c.nullable = n->schema[1].nullable;
+        } else if (k.c.type == ColType::UTF8) {
+            FG_TRY(take_column(ctx, node_key(pl, n, "take", 0).c_str(), k.c, g.first_row, g.n_groups, &t->cols[0].c));
+            t->cols[0].present = true;
+        } else if (k.c.type == ColType::I32) {
             int32_t *nk = nullptr;
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk").c_str(), (size_t)g.n_groups + 4, &nk));
             FG_TRY(narrow_i64_to_i32(ctx, g.keys, g.n_groups, nk));
@@ -1084,9 +1361,48 @@ struct Exec {
             t->cols[0] = dev_col(k.c.type, g.keys, nullptr, 0, k.c.is_ts);
         }
         t->cols[0].c.nullable = n->schema[0].nullable;
-        if (!n->aggs.empty()) {
-            t->cols[1] = dev_col(ColType::U64, g.agg);
-            t->cols[1].c.nullable = true;
+        // ---- aggregate / state columns
+        size_t oc = n->group.size();
+        for (size_t ai = 0; ai < n->aggs.size(); ++ai) {
+            const Agg &a = n->aggs[ai];
+            const Out &o = outs[ai];
+            auto narrow_if_i32 = [&](uint64_t *acc, ColType want, bool ts, size_t col) -> int {
+                if (want == ColType::I32) {
+                    int32_t *v = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "av", (int)col).c_str(), (size_t)g.n_groups + 4, &v));
+                    FG_TRY(narrow_i64_to_i32(ctx, reinterpret_cast<const int64_t *>(acc), g.n_groups, v));
+                    t->cols[col] = dev_col(ColType::I32, v);
+                } else {
+                    t->cols[col] = dev_col(want, acc, nullptr, 0, ts);
+                }
+                t->cols[col].c.nullable = true;
+                return FLOCKGPU_OK;
+            };
+            if (a.fn == "avg") {
+                if (is_final) {
+                    double *avg = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "av", (int)oc).c_str(), (size_t)g.n_groups + 2, &avg));
+                    FG_TRY(avg_finish(ctx, reinterpret_cast<const double *>(g.agg[o.first + 1]), g.agg[o.first], g.n_groups, avg));
+                    t->cols[oc] = dev_col(ColType::F64, avg);
+                    t->cols[oc].c.nullable = true;
+                    oc += 1;
+                } else {
+                    double *sum = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "av", (int)oc + 1).c_str(), (size_t)g.n_groups + 2, &sum));
+                    FG_TRY(i64_to_f64(ctx, reinterpret_cast<const int64_t *>(g.agg[o.first + 1]), g.n_groups, sum));
+                    t->cols[oc] = dev_col(ColType::U64, g.agg[o.first]);
+                    t->cols[oc + 1] = dev_col(ColType::F64, sum);
+                    t->cols[oc].c.nullable = t->cols[oc + 1].c.nullable = true;
+                    oc += 2;
+                }
+            } else {
+                const ColType want = n->schema[oc].type;
+                const bool f64_acc = specs[o.first].op == AggOp::MAX_F64 || specs[o.first].op == AggOp::MIN_F64;
+                if (want == ColType::UTF8 || (want == ColType::F64) != f64_acc)
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: %s of a column into a column of another kind", a.fn.c_str());
+                FG_TRY(narrow_if_i32(g.agg[o.first], want, n->schema[oc].is_ts, oc));
+                oc += 1;
+            }
         }
         return FLOCKGPU_OK;
     }
@@ -1242,7 +1558,13 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
         // guarantees that, and which partition a key lands on is unobservable
         const TCol &k = in.cols[(size_t)root->hash_cols[0]];
         int64_t *keys = nullptr;
-        FG_TRY(ex.key_i64(root, k, in.rows, "pk", &keys));
+        if (k.c.type == ColType::UTF8) {
+            if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+            FG_TRY(arena_get_t(ctx, node_key(plan, root, "pk").c_str(), (size_t)in.rows + 2, &keys));
+            FG_TRY(hash_utf8_i64(ctx, k.c, in.rows, keys));
+        } else {
+            FG_TRY(ex.key_i64(root, k, in.rows, "pk", &keys));
+        }
         int32_t *rows = nullptr;
         FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, in.rows, root->n_parts, &rows, &part_off));
         t.rows = in.rows;

@@ -37,11 +37,15 @@ struct Expr {
 
 enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition };
 struct Agg {
-    std::string fn;  // "count" | "max" | ...
-    int arg = -1;    // input column of the argument (Partial / single stage); -1: a literal (COUNT(UInt8(1)))
+    std::string fn;  // "count" | "max" | "min" | "sum" | "avg"
+    int arg = -1;    // Partial: input column of the argument (-1: a literal, COUNT(UInt8(1))); Final: the first state column
+    int arg2 = -1;   // Final AVG: its second state column (the sum; `arg` is the count)
     std::string name;
-    ColType type = ColType::U64;
+    ColType type = ColType::U64;  // type of the finished aggregate
 };
+// State columns a Partial stage emits per aggregate, as DataFusion ~6 lays them out (Accumulator::state / state_fields,
+// SURVEY.md appendix D): COUNT -> [count UInt64]; MAX / MIN / SUM -> [value]; AVG -> [count UInt64, sum Float64].
+inline int agg_state_cols(const std::string &fn) { return fn == "avg" ? 2 : 1; }
 struct Node {
     NKind kind = NKind::Scan;
     int id = 0;
@@ -54,6 +58,7 @@ struct Node {
     std::vector<int> group;         // Aggregate: input columns of the group keys
     std::vector<Agg> aggs;
     int on_l = -1, on_r = -1;       // Join: key columns (left input, right input)
+    int on_l2 = -1, on_r2 = -1;     // Join: second key pair (q9: auction = id AND price = final), -1 when there is one
     std::vector<int> hash_cols;     // Repartition
     int n_parts = 0;
     std::vector<char> required;     // per output column: needed by an ancestor (or by the plan output)
@@ -210,6 +215,8 @@ struct Builder {
         if (has("a_id") || has("seller") || has("category")) return "auction";
         if (has("p_id") || has("state") || has("city")) return "person";
         if (has("key") && has("value")) return "side_input";
+        if (has("ad_id") || has("event_type")) return "ad_event";
+        if (has("c_ad_id") || has("campaign_id")) return "campaign";
         return "";
     }
 
@@ -319,7 +326,7 @@ struct Builder {
                     ++gi;
                 }
             const JValue *ae = j->get("aggr_expr");
-            size_t ai = 0;
+            int state_at = (int)n->group.size();  // Final: position of the next aggregate's first state column
             if (ae && ae->kind == JValue::Arr)
                 for (auto &x : ae->arr) {
                     Agg a;
@@ -327,9 +334,15 @@ struct Builder {
                     a.name = x->s("name");
                     bool ts = false;
                     if (!parse_type(x->get("data_type"), &a.type, &ts)) { fail("aggregate '" + a.name + "' of an unsupported type"); return nullptr; }
+                    if (a.fn != "count" && a.fn != "max" && a.fn != "min" && a.fn != "sum" && a.fn != "avg") {
+                        fail("aggregate function '" + a.fn + "' (supported: count, max, min, sum, avg)");
+                        return nullptr;
+                    }
                     if (is_final) {
-                        a.arg = (int)(n->group.size() + ai);  // state column, by position
-                        if ((size_t)a.arg >= in->schema.size()) { fail("final aggregate without its state column"); return nullptr; }
+                        a.arg = state_at;  // state columns, by position
+                        if (a.fn == "avg") a.arg2 = state_at + 1;
+                        state_at += agg_state_cols(a.fn);
+                        if ((size_t)state_at > in->schema.size()) { fail("final aggregate without its state column"); return nullptr; }
                     } else {
                         const JValue *arg = x->get("expr");
                         if (arg && etag(arg) == "column") {
@@ -340,14 +353,27 @@ struct Builder {
                             return nullptr;
                         }
                     }
-                    if (a.fn != "count" && a.fn != "max") { fail("aggregate function '" + a.fn + "' (supported: count, max)"); return nullptr; }
+                    if (a.fn == "count") a.type = ColType::U64;
+                    if (a.fn == "avg") a.type = ColType::F64;
                     Field f;
-                    f.name = is_final ? a.name : a.name + "[" + a.fn + "]";
-                    f.type = a.fn == "count" ? ColType::U64 : a.type;
                     f.nullable = true;
+                    if (is_final) {
+                        f.name = a.name;
+                        f.type = a.type;
+                        n->schema.push_back(f);
+                    } else if (a.fn == "avg") {
+                        f.name = a.name + "[count]";
+                        f.type = ColType::U64;
+                        n->schema.push_back(f);
+                        f.name = a.name + "[sum]";
+                        f.type = ColType::F64;
+                        n->schema.push_back(f);
+                    } else {
+                        f.name = a.name + "[" + a.fn + "]";
+                        f.type = a.type;
+                        n->schema.push_back(f);
+                    }
                     n->aggs.push_back(a);
-                    n->schema.push_back(f);
-                    ++ai;
                 }
             n->in.push_back(std::move(in));
         } else if (t == "hash_join_exec") {
@@ -358,10 +384,12 @@ struct Builder {
             auto r = node(j->get("right"), depth + 1);
             if (!r) return nullptr;
             const JValue *on = j->get("on");
-            if (!on || on->kind != JValue::Arr || on->arr.size() != 1 || on->arr[0]->kind != JValue::Arr || on->arr[0]->arr.size() != 2) {
-                fail("join on other than one key pair");
+            if (!on || on->kind != JValue::Arr || on->arr.empty() || on->arr.size() > 2) {
+                fail("join on other than one or two key pairs");
                 return nullptr;
             }
+            for (auto &pair : on->arr)
+                if (pair->kind != JValue::Arr || pair->arr.size() != 2) { fail("malformed join key pair"); return nullptr; }
             auto keycol = [&](const JValue *k, const std::vector<Field> &schema) {
                 if (k->kind == JValue::Str) {  // older fork revision: bare names
                     for (size_t i = 0; i < schema.size(); ++i)
@@ -373,6 +401,11 @@ struct Builder {
             n->on_l = keycol(on->arr[0]->arr[0].get(), l->schema);
             n->on_r = keycol(on->arr[0]->arr[1].get(), r->schema);
             if (n->on_l < 0 || n->on_r < 0) { fail("join key not in the input schemas"); return nullptr; }
+            if (on->arr.size() == 2) {
+                n->on_l2 = keycol(on->arr[1]->arr[0].get(), l->schema);
+                n->on_r2 = keycol(on->arr[1]->arr[1].get(), r->schema);
+                if (n->on_l2 < 0 || n->on_r2 < 0) { fail("join key not in the input schemas"); return nullptr; }
+            }
             n->schema = l->schema;
             n->schema.insert(n->schema.end(), r->schema.begin(), r->schema.end());
             n->in.push_back(std::move(l));
@@ -427,7 +460,7 @@ inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
         case NKind::Aggregate: {
             std::vector<char> r(n->in[0]->schema.size(), 0);
             for (int c : n->group) need(r, c);
-            for (auto &a : n->aggs) need(r, a.arg);
+            for (auto &a : n->aggs) { need(r, a.arg); need(r, a.arg2); }
             mark_required(p, n->in[0].get(), r);
             break;
         }
@@ -436,6 +469,8 @@ inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
             std::vector<char> l(req.begin(), req.begin() + nl), r(req.begin() + nl, req.end());
             need(l, n->on_l);
             need(r, n->on_r);
+            need(l, n->on_l2);
+            need(r, n->on_r2);
             mark_required(p, n->in[0].get(), l);
             mark_required(p, n->in[1].get(), r);
             break;
@@ -495,6 +530,7 @@ inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> 
             std::vector<char> l(droppable.begin(), droppable.begin() + nl), r(droppable.begin() + nl, droppable.end());
             l[(size_t)n->on_l] = 1;  // NULL keys never match in an inner join
             r[(size_t)n->on_r] = 1;
+            if (n->on_l2 >= 0) { l[(size_t)n->on_l2] = 1; r[(size_t)n->on_r2] = 1; }
             mark_null_droppable(p, n->in[0].get(), l);
             mark_null_droppable(p, n->in[1].get(), r);
             break;

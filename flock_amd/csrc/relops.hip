@@ -62,6 +62,22 @@ __global__ __launch_bounds__(kBlock) void mask_cmp_lit_kernel(const void *__rest
         mask[i] = cmp_i64(x, lit, op, uns && !modulus) ? 1 : 0;
     }
 }
+__global__ __launch_bounds__(kBlock) void mask_cmp_f64_kernel(const double *__restrict__ v, int64_t n, int32_t op, double lit,
+                                                              uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double x = v[i];
+        bool r;
+        switch (op) {
+            case 0: r = x == lit; break;
+            case 1: r = x != lit; break;
+            case 2: r = x < lit; break;
+            case 3: r = x <= lit; break;
+            case 4: r = x > lit; break;
+            default: r = x >= lit; break;
+        }
+        mask[i] = r ? 1 : 0;
+    }
+}
 __global__ __launch_bounds__(kBlock) void mask_cmp_col_kernel(const void *__restrict__ a, int32_t ta, const void *__restrict__ b, int32_t tb,
                                                               int64_t n, int32_t op, uint8_t *__restrict__ mask) {
     const bool uns = ta == (int32_t)ColType::U64 && tb == (int32_t)ColType::U64;
@@ -163,6 +179,100 @@ __global__ __launch_bounds__(kBlock) void live_slot_mask_kernel(const int32_t *_
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) mask[i] = tf[i] != 0x7fffffff;
 }
 
+struct AggSpecs {
+    const void *values[kMaxGroupAggs];
+    int32_t op[kMaxGroupAggs];
+    int32_t type[kMaxGroupAggs];
+    int32_t n;
+};
+// doubles <-> unsigned keys of the same order (negative values: all bits flipped; others: the sign bit set)
+__device__ __forceinline__ uint64_t f64_order_key(double d) {
+    const uint64_t b = (uint64_t)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint64_t f64_from_order_key(uint64_t k) { return (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; }
+__device__ __forceinline__ uint64_t agg_identity(int32_t op) {
+    switch (op) {
+        case (int32_t)AggOp::MAX_S: return (uint64_t)INT64_MIN;
+        case (int32_t)AggOp::MIN_S: return (uint64_t)INT64_MAX;
+        case (int32_t)AggOp::MIN_U: return ~0ull;
+        case (int32_t)AggOp::MIN_F64: return ~0ull;
+        default: return 0;  // COUNT, SUM_INT, MAX_U, SUM_F64 (+0.0)
+    }
+}
+__global__ __launch_bounds__(kBlock) void group_init_n_kernel(int64_t *__restrict__ tk, uint64_t *__restrict__ ta, int32_t *__restrict__ tf,
+                                                              int64_t slots, AggSpecs sp) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
+        tk[i] = kEmptyKey;
+        tf[i] = 0x7fffffff;
+        for (int a = 0; a < sp.n; ++a) ta[i * sp.n + a] = agg_identity(sp.op[a]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *__restrict__ keys, int64_t n, AggSpecs sp, int64_t *tk,
+                                                                uint64_t *ta, int32_t *tf, uint64_t cap, uint32_t *err) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t key = keys[i];
+        const int64_t s = claim_slot(tk, cap, key);
+        if (s < 0) {
+            atomicOr(err, 1u);
+            continue;
+        }
+        if (s == (int64_t)cap) tk[s] = key;  // the dedicated slot of the sentinel key
+        atomicMin(&tf[s], (int32_t)i);
+        for (int a = 0; a < sp.n; ++a) {
+            uint64_t *acc = &ta[s * sp.n + a];
+            const int32_t op = sp.op[a];
+            if (op == (int32_t)AggOp::COUNT) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(acc), 1ull);
+            } else if (op == (int32_t)AggOp::SUM_F64) {
+                atomicAdd(reinterpret_cast<double *>(acc), static_cast<const double *>(sp.values[a])[i]);
+            } else if (op == (int32_t)AggOp::MAX_F64) {
+                atomicMax(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)f64_order_key(static_cast<const double *>(sp.values[a])[i]));
+            } else if (op == (int32_t)AggOp::MIN_F64) {
+                atomicMin(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)f64_order_key(static_cast<const double *>(sp.values[a])[i]));
+            } else {
+                const int64_t v = load_as_i64(sp.values[a], sp.type[a], i);
+                if (op == (int32_t)AggOp::SUM_INT) atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)v);
+                else if (op == (int32_t)AggOp::MAX_S) atomicMax(reinterpret_cast<long long *>(acc), (long long)v);
+                else if (op == (int32_t)AggOp::MIN_S) atomicMin(reinterpret_cast<long long *>(acc), (long long)v);
+                else if (op == (int32_t)AggOp::MAX_U) atomicMax(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)v);
+                else atomicMin(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)v);
+            }
+        }
+    }
+}
+// out[a][g] = ta[slot_rows[g] * n + a]
+struct AggOuts {
+    uint64_t *out[kMaxGroupAggs];
+};
+__global__ __launch_bounds__(kBlock) void group_collect_n_kernel(const uint64_t *__restrict__ ta, const int32_t *__restrict__ slot_rows,
+                                                                 int64_t n_groups, AggSpecs sp, AggOuts o) {
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * kBlock)
+        for (int a = 0; a < sp.n; ++a) {
+            const uint64_t v = ta[(int64_t)slot_rows[g] * sp.n + a];
+            o.out[a][g] = (sp.op[a] == (int32_t)AggOp::MAX_F64 || sp.op[a] == (int32_t)AggOp::MIN_F64) ? f64_from_order_key(v) : v;
+        }
+}
+__global__ __launch_bounds__(kBlock) void pack_pair_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n,
+                                                           int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = (int64_t)(((uint64_t)(uint32_t)a[i] << 32) | (uint64_t)(uint32_t)b[i]);
+}
+__global__ __launch_bounds__(kBlock) void unpack_pair_kernel(const int64_t *__restrict__ k, int64_t n, int32_t *__restrict__ a,
+                                                             int32_t *__restrict__ b) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        a[i] = (int32_t)((uint64_t)k[i] >> 32);
+        b[i] = (int32_t)(uint32_t)k[i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void i64_to_f64_kernel(const int64_t *__restrict__ in, int64_t n, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (double)in[i];
+}
+__global__ __launch_bounds__(kBlock) void avg_finish_kernel(const double *__restrict__ sum, const uint64_t *__restrict__ count, int64_t n,
+                                                            double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = sum[i] / (double)count[i];
+}
+
 // ---- distinct (int32, Utf8)
 __device__ __forceinline__ bool same_pair(const int32_t *key, const int32_t *off, const uint8_t *bytes, int32_t a, int32_t b) {
     if (key[a] != key[b]) return false;
@@ -199,6 +309,69 @@ __global__ __launch_bounds__(kBlock) void distinct_insert_kernel(const int32_t *
             s = (s + 1) & (cap - 1);
         }
         is_rep[i] = rep;
+    }
+}
+
+// ---- Utf8 keys
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t *p, int32_t len) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (int32_t b = 0; b < len; ++b) h = (h ^ p[b]) * 0x100000001B3ull;
+    return mix64(h ^ (uint64_t)(uint32_t)len);
+}
+__device__ __forceinline__ bool same_bytes(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb) {
+    if (la != lb) return false;
+    for (int32_t k = 0; k < la; ++k)
+        if (a[k] != b[k]) return false;
+    return true;
+}
+__global__ __launch_bounds__(kBlock) void hash_utf8_kernel(const int32_t *__restrict__ off, const uint8_t *__restrict__ bytes, int64_t n,
+                                                           int64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = (int64_t)hash_bytes(bytes + off[i], off[i + 1] - off[i]);
+}
+__global__ __launch_bounds__(kBlock) void utf8_codes_build_kernel(const int32_t *__restrict__ off, const uint8_t *__restrict__ bytes, int64_t n,
+                                                                  int32_t *table, uint64_t cap, int64_t *__restrict__ codes) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint8_t *me = bytes + off[i];
+        const int32_t len = off[i + 1] - off[i];
+        uint64_t s = hash_bytes(me, len) & (cap - 1);
+        int64_t code = i;
+        for (uint64_t probe = 0; probe < cap; ++probe) {
+            int32_t cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                int32_t expected = -1;
+                if (__hip_atomic_compare_exchange_strong(&table[s], &expected, (int32_t)i, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break;
+                cur = expected;
+            }
+            if (same_bytes(me, len, bytes + off[cur], off[cur + 1] - off[cur])) {
+                code = cur;
+                break;
+            }
+            s = (s + 1) & (cap - 1);
+        }
+        if (codes) codes[i] = code;
+    }
+}
+__global__ __launch_bounds__(kBlock) void utf8_codes_probe_kernel(const int32_t *__restrict__ boff, const uint8_t *__restrict__ bbytes,
+                                                                  const int32_t *__restrict__ table, uint64_t cap,
+                                                                  const int32_t *__restrict__ off, const uint8_t *__restrict__ bytes, int64_t n,
+                                                                  int64_t *__restrict__ codes) {
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+        const uint8_t *me = bytes + off[j];
+        const int32_t len = off[j + 1] - off[j];
+        uint64_t s = hash_bytes(me, len) & (cap - 1);
+        int64_t code = -(j + 2);
+        for (uint64_t probe = 0; probe < cap; ++probe) {
+            const int32_t cur = table[s];
+            if (cur < 0) break;
+            if (same_bytes(me, len, bbytes + boff[cur], boff[cur + 1] - boff[cur])) {
+                code = cur;
+                break;
+            }
+            s = (s + 1) & (cap - 1);
+        }
+        codes[j] = code;
     }
 }
 
@@ -337,6 +510,13 @@ int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op
     return FLOCKGPU_OK;
 }
 
+int mask_cmp_f64_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, double lit, uint8_t *mask) {
+    if (col.type != ColType::F64) return fail(ctx, FLOCKGPU_ERR_INVALID, "Float64 comparison on a column of another type");
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "mask_cmp_f64_kernel", mask_cmp_f64_kernel, rows, static_cast<const double *>(col.values), rows, (int32_t)op, lit, mask);
+    return FLOCKGPU_OK;
+}
+
 int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask) {
     if (col.type == ColType::UTF8 || col.type == ColType::F64 || col.type == ColType::U64)
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "modulo needs a signed integer column");
@@ -471,6 +651,86 @@ int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, con
     return FLOCKGPU_OK;
 }
 
+int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
+                     GroupResultN *out) {
+    *out = GroupResultN{};
+    const std::string base = name;
+    if (n_specs < 0 || n_specs > kMaxGroupAggs) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than %d accumulators per group", name, kMaxGroupAggs);
+    if (rows >= (int64_t(1) << 30)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^30 rows in a generic GROUP BY", name);
+    AggSpecs sp{};
+    sp.n = n_specs;
+    for (int a = 0; a < n_specs; ++a) {
+        sp.values[a] = specs[a].values;
+        sp.op[a] = (int32_t)specs[a].op;
+        sp.type[a] = (int32_t)specs[a].type;
+        if (specs[a].op != AggOp::COUNT && !specs[a].values && rows > 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: accumulator without a value column", name);
+        const bool is_f64 = specs[a].type == ColType::F64, is_text = specs[a].type == ColType::UTF8;
+        const bool f64_op = specs[a].op == AggOp::SUM_F64 || specs[a].op == AggOp::MAX_F64 || specs[a].op == AggOp::MIN_F64;
+        const bool bad = specs[a].op == AggOp::COUNT ? false : (f64_op ? !is_f64 : (is_f64 || is_text));
+        if (bad) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: accumulator over a column of the wrong type", name);
+    }
+    const int width = std::max(n_specs, 1);
+    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
+    const int64_t slots = (int64_t)cap + 1;
+    int64_t *tk = nullptr;
+    uint64_t *ta = nullptr;
+    int32_t *tf = nullptr;
+    uint8_t *live = nullptr;
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
+    FG_TRY(arena_get_t(ctx, (base + ".tan").c_str(), (size_t)slots * (size_t)width, &ta));
+    FG_TRY(arena_get_t(ctx, (base + ".tf").c_str(), (size_t)slots, &tf));
+    FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
+    if (rows > 0) RELOPS_LAUNCH(ctx, "group_insert_n_kernel", group_insert_n_kernel, rows, keys, rows, sp, tk, ta, tf, cap, d_err);
+    RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
+    int32_t *slot_rows = nullptr;
+    int64_t n_groups = 0;
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
+    if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
+    int64_t *ok = nullptr;
+    int32_t *of = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".ok").c_str(), (size_t)n_groups + 2, &ok));
+    FG_TRY(arena_get_t(ctx, (base + ".of").c_str(), (size_t)n_groups + 4, &of));
+    FG_TRY(gather_i64(ctx, tk, slot_rows, n_groups, ok));
+    FG_TRY(gather_i32(ctx, tf, slot_rows, n_groups, of));
+    AggOuts o{};
+    for (int a = 0; a < n_specs; ++a) {
+        FG_TRY(arena_get_t(ctx, (base + ".oa" + std::to_string(a)).c_str(), (size_t)n_groups + 2, &o.out[a]));
+        out->agg[a] = o.out[a];
+    }
+    if (n_specs > 0 && n_groups > 0) RELOPS_LAUNCH(ctx, "group_collect_n_kernel", group_collect_n_kernel, n_groups, ta, slot_rows, n_groups, sp, o);
+    out->n_groups = n_groups;
+    out->keys = ok;
+    out->first_row = of;
+    return FLOCKGPU_OK;
+}
+
+int pack_i32_pair(flockgpu_ctx *ctx, const int32_t *a, const int32_t *b, int64_t n, int64_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "pack_pair_kernel", pack_pair_kernel, n, a, b, n, out);
+    return FLOCKGPU_OK;
+}
+int unpack_i32_pair(flockgpu_ctx *ctx, const int64_t *keys, int64_t n, int32_t *a, int32_t *b) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "unpack_pair_kernel", unpack_pair_kernel, n, keys, n, a, b);
+    return FLOCKGPU_OK;
+}
+int i64_to_f64(flockgpu_ctx *ctx, const int64_t *in, int64_t n, double *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "i64_to_f64_kernel", i64_to_f64_kernel, n, in, n, out);
+    return FLOCKGPU_OK;
+}
+int avg_finish(flockgpu_ctx *ctx, const double *sum, const uint64_t *count, int64_t n, double *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "avg_finish_kernel", avg_finish_kernel, n, sum, count, n, out);
+    return FLOCKGPU_OK;
+}
+
 int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, const flockgpu_utf8 &text, int64_t rows, int32_t **out_rows,
                       int64_t *n_out) {
     const std::string base = name;
@@ -484,6 +744,31 @@ int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, c
     if (rows > 0)
         RELOPS_LAUNCH(ctx, "distinct_insert_kernel", distinct_insert_kernel, rows, key, text.offsets, text.data, rows, table, cap, rep);
     return mask_to_rows(ctx, (base + ".sel").c_str(), rep, rows, out_rows, n_out);
+}
+
+int hash_utf8_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out) {
+    if (col.type != ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_INVALID, "hash_utf8: not a Utf8 column");
+    if (rows <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "hash_utf8_kernel", hash_utf8_kernel, rows, col.offsets, static_cast<const uint8_t *>(col.values), rows, out);
+    return FLOCKGPU_OK;
+}
+
+int utf8_codes(flockgpu_ctx *ctx, const char *name, const DevColumn &build, int64_t n_build, int64_t *build_codes, const DevColumn *probe,
+               int64_t n_probe, int64_t *probe_codes) {
+    const std::string base = name;
+    if (build.type != ColType::UTF8 || (probe && probe->type != ColType::UTF8)) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: not a Utf8 column", name);
+    if (n_build >= (int64_t(1) << 30)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^30 rows in a Utf8 dictionary", name);
+    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(n_build, 1) * 2);
+    int32_t *table = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".dict").c_str(), (size_t)cap, &table));
+    RELOPS_LAUNCH(ctx, "fill_i32_kernel", fill_i32_kernel, (int64_t)cap, table, (int64_t)cap, (int32_t)-1);
+    if (n_build > 0)
+        RELOPS_LAUNCH(ctx, "utf8_codes_build_kernel", utf8_codes_build_kernel, n_build, build.offsets, static_cast<const uint8_t *>(build.values), n_build,
+                      table, cap, build_codes);
+    if (probe && probe_codes && n_probe > 0)
+        RELOPS_LAUNCH(ctx, "utf8_codes_probe_kernel", utf8_codes_probe_kernel, n_probe, build.offsets, static_cast<const uint8_t *>(build.values), table,
+                      cap, probe->offsets, static_cast<const uint8_t *>(probe->values), n_probe, probe_codes);
+    return FLOCKGPU_OK;
 }
 
 int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out, int *any) {

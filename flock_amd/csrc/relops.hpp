@@ -37,6 +37,8 @@ int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t 
 // ---- predicates: one byte per row (1 = true)
 int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, int64_t lit, uint8_t *mask);
 int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask);
+// Float64 column against a literal (IEEE comparison; NaN compares false except for !=)
+int mask_cmp_f64_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, double lit, uint8_t *mask);
 int mask_cmp_col(flockgpu_ctx *ctx, const DevColumn &a, const DevColumn &b, int64_t rows, CmpOp op, uint8_t *mask);
 int mask_utf8_eq(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, const std::string &lit, bool negate, uint8_t *mask);
 int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t rows, bool is_and, uint8_t *out);
@@ -56,6 +58,42 @@ struct GroupResult {
 };
 int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const uint64_t *values, AggKind kind, int64_t rows,
                    GroupResult *out);
+// The same GROUP BY with up to kMaxGroupAggs accumulators per group, all in one table (one pass over the rows).
+// MAX_F64 / MIN_F64 order doubles through their order-preserving bit pattern (no NaN among the inputs: Arrow's min / max kernels
+// skip NaN only against non-NaN values, a case the engine does not claim).
+// Accumulators are 64-bit: COUNT (rows), SUM_INT (two's complement add of an integer column: Int32 sign-extended), MAX / MIN
+// signed or unsigned, SUM_F64 (double add: exact -- hence order-free -- while every partial sum is an integer below 2^53, which
+// is what AVG's partial sums of integer columns are).
+enum class AggOp : int32_t { COUNT = 0, SUM_INT = 1, MAX_S = 2, MAX_U = 3, MIN_S = 4, MIN_U = 5, SUM_F64 = 6, MAX_F64 = 7, MIN_F64 = 8 };
+constexpr int kMaxGroupAggs = 4;
+struct AggSpec {
+    AggOp op = AggOp::COUNT;
+    const void *values = nullptr;  // null for COUNT
+    ColType type = ColType::I64;   // storage type of `values`
+};
+struct GroupResultN {
+    int64_t n_groups = 0;
+    int64_t *keys = nullptr;
+    uint64_t *agg[kMaxGroupAggs] = {};  // 64-bit patterns: int64 / uint64 / double by AggOp
+    int32_t *first_row = nullptr;
+};
+int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
+                     GroupResultN *out);
+// ---- Utf8 keys (YSB joins and groups on UUID strings, flock/src/distributed_plan/planner.rs:298-346)
+// out[i] = 64-bit hash of row i's bytes: equal strings -> equal keys (enough for a hash repartition; NOT an equality test)
+int hash_utf8_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);
+// Exact dictionary codes: codes[i] = row number of the first-inserted row of `build` with the same bytes (a hash table of row
+// numbers with a full byte compare on every hit).  probe_codes[j] = the code of the equal `build` string, or -(j + 2) when
+// `build` does not contain it (negative codes are pairwise different and match nothing).  Either output may be null.
+int utf8_codes(flockgpu_ctx *ctx, const char *name, const DevColumn &build, int64_t n_build, int64_t *build_codes, const DevColumn *probe,
+               int64_t n_probe, int64_t *probe_codes);
+// (a, b) Int32 pairs <-> one 64-bit key: key = (int64(a) << 32) | uint32(b)
+int pack_i32_pair(flockgpu_ctx *ctx, const int32_t *a, const int32_t *b, int64_t n, int64_t *out);
+int unpack_i32_pair(flockgpu_ctx *ctx, const int64_t *keys, int64_t n, int32_t *a, int32_t *b);
+// out[i] = (double)in[i]
+int i64_to_f64(flockgpu_ctx *ctx, const int64_t *in, int64_t n, double *out);
+// out[i] = sum[i] / (double)count[i]   (AVG's finish: one IEEE division, as DataFusion's AvgAccumulator::evaluate)
+int avg_finish(flockgpu_ctx *ctx, const double *sum, const uint64_t *count, int64_t n, double *out);
 // GROUP BY (int32 key, Utf8 value) without aggregates = DISTINCT over both columns: the first row of every distinct pair,
 // ascending.
 int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, const flockgpu_utf8 &text, int64_t rows,

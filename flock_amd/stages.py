@@ -166,3 +166,13 @@ def split_at_repartitions(plan: dict) -> List[Stage]:
 
     emit(cut(copy.deepcopy(plan), True))
     return stages
+
+
+def stage_levels(stages):
+    """The reference numbers stages by depth ("=== Stage 0 ===" prints both base-fed plans of a join, planner.rs:148-171):
+    level 0 = plans fed by base relations only, level k = 1 + the deepest producer.  Returns one level per stage plan."""
+    levels = []
+    for st in stages:
+        feeders = [j for j in st.inputs if j is not None]
+        levels.append(1 + max(levels[j] for j in feeders) if feeders else 0)
+    return levels

@@ -81,8 +81,10 @@ typedef struct flockgpu_plan flockgpu_plan;
  * expression or type the engine does not execute (flockgpu_last_error names it). */
 int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out);
 void flockgpu_plan_destroy(flockgpu_plan *plan);
-/* Host-only: parses a plan without a device context.  *query receives the NEXMark query number (1, 2, 3, 5, 7, 8, 13)
- * when the whole plan is one fused pipeline, 0 for any other executable plan (stage plans, generic operator trees). */
+/* Host-only: parses a plan without a device context.  *query receives the NEXMark query number (1, 2, 3, 4, 5, 7, 8, 9, 13;
+ * 100 for the Yahoo Streaming Benchmark's query) when the whole plan is one fused pipeline, 0 for any other executable plan
+ * (stage plans, generic operator trees).  q4 / q9 run fused on batches whose auction ids are dense and increasing and on the
+ * generic operators otherwise (decided per execute). */
 int flockgpu_plan_recognise(const char *plan_json, size_t len, int *query);
 /* Host-only: the operator tree with derived schemas and, per node, what executes it (a fused pipeline or the generic
  * operators), as text.  Returns the status flockgpu_plan_create would; on UNSUPPORTED the text says why. */

@@ -55,18 +55,36 @@ def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
 
 def test_reference_plan_fixtures_parse():
     """The three serde_json fixtures the reference ships (flock/src/tests/data/plan/*.json; read where the reference tree is
-    present) go through the real parser: the pure projection is executable, the MIN / MAX aggregate and the sort + limit
-    plans come back UNSUPPORTED -- never a parse error."""
+    present) go through the real parser: the projection and the MAX / MIN GROUP BY plan are executable operator trees, the
+    sort + limit plan comes back UNSUPPORTED naming the node -- never a parse error."""
     ref = "/root/reference/flock/src/tests/data/plan"
     if not os.path.isdir(ref):
         pytest.skip("reference tree not present on this box")
     from flock_amd import _ffi, FlockGpuError
     from flock_amd.runtime import explain
     assert "Scan" in explain(open(os.path.join(ref, "simple_select.json")).read())
-    for name, why in (("aggregate.json", "min"), ("join.json", "global_limit_exec")):
-        with pytest.raises(FlockGpuError) as e:
-            explain(open(os.path.join(ref, name)).read())
-        assert e.value.code == _ffi.ERR_UNSUPPORTED and why in str(e.value)
+    agg = explain(open(os.path.join(ref, "aggregate.json")).read())
+    assert agg.splitlines()[0] == "Project [MAX(c1):Int64, MIN(c2):Float64, c3:Utf8]" and "Aggregate(Partial)" in agg
+    # the plan authored for the GPU box (tools/make_plan_fixtures.py: golden_aggregate) is the same operator tree
+    assert agg == explain(open(os.path.join(PLANS, "golden_aggregate.json")).read())
+    with pytest.raises(FlockGpuError) as e:
+        explain(open(os.path.join(ref, "join.json")).read())
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and "global_limit_exec" in str(e.value)
+    # ... and below its sort + limit, join.json is the tree of golden_join
+    import json as _json
+    below = _json.load(open(os.path.join(ref, "join.json")))["input"]["input"]["input"]
+    assert explain(below) == explain(open(os.path.join(PLANS, "golden_join.json")).read())
+
+
+def test_aggregate_fixture_splits_as_the_reference_asserts():
+    """flock/src/driver/funcgen/dag.rs:488-520 (partition_json): aggregate.json cuts into 2 sub-plans with 1 edge -- projection
+    + FinalPartitioned + memory_exec above, Partial + coalesce + filter + memory_exec below."""
+    from flock_amd.stages import build_query_dag
+    stages = build_query_dag(json.load(open(os.path.join(PLANS, "golden_aggregate.json"))))
+    assert len(stages) == 2 and stages[1].inputs == [0] and stages[0].inputs == [None]
+    top, low = json.dumps(stages[1].plan), json.dumps(stages[0].plan)
+    assert '"projection_exec"' in top and '"FinalPartitioned"' in top and '"memory_exec"' in top and '"Partial"' not in top
+    assert '"Partial"' in low and '"coalesce_batches_exec"' in low and '"filter_exec"' in low and '"memory_exec"' in low
 
 
 def test_root_projection_is_honoured():
@@ -340,3 +358,53 @@ def test_q13_side_input_join_through_collect(gpu):
         total += len(want)
     assert total > 100
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_reference_operator_goldens_through_the_hip_plan_path(gpu):
+    """The two operator-level goldens the reference holds at exactly this boundary -- a deserialised plan, feed_data_sources,
+    execute, an expected table (flock/src/runtime/context.rs:430-503 and :505-589) -- through the HIP plan path: the reference's
+    batches in, the reference's expected rows out.  The reference's final `ORDER BY` / `LIMIT` are applied here on the host
+    (the engine hands sort / limit plans back as UNSUPPORTED); the aggregate golden also runs as the two stage plans
+    dag.rs:488-520 cuts it into."""
+    import pyarrow as pa
+    from flock_amd.runtime import ExecutionContext, collect
+    from flock_amd.stages import build_query_dag
+    batch = pa.record_batch([pa.array([90, 90, 91, 101, 92, 102, 93, 103], pa.int64()),
+                             pa.array([92.1, 93.2, 95.3, 96.4, 98.5, 99.6, 100.7, 101.8], pa.float64()),
+                             pa.array(["a", "a", "d", "b", "b", "d", "c", "c"]),
+                             pa.array([33, 1, 54, 33, 12, 75, 2, 87], pa.uint64()),
+                             pa.array(["rapport", "pedantic", "mimesis", "haptic", "baksheesh", "amok", "devious", "c"]),
+                             pa.array([-90, -90, -91, -101, -92, -102, -93, -103], pa.int64())], names=["c1", "c2", "c3", "c4", "c5", "neg"])
+    want = [(90, 92.1, "a"), (101, 96.4, "b"), (91, 95.3, "d")]               # context.rs:493-501, ORDER BY c3
+    plan = json.load(open(os.path.join(PLANS, "golden_aggregate.json")))
+    ctx = ExecutionContext([plan], name="golden-agg", gpu=gpu)
+    rb = collect(ctx, [[[batch]]])[0][0]
+    ctx.close()
+    assert rb.schema.names == ["MAX(c1)", "MIN(c2)", "c3"]
+    rows = sorted(zip(rb["MAX(c1)"].to_pylist(), rb["MIN(c2)"].to_pylist(), rb["c3"].to_pylist()), key=lambda r: r[2])
+    assert rows == want
+    # the same through its two stage plans: Partial -> Hash([c3], 8) partitions -> FinalPartitioned per partition
+    low, top = build_query_dag(plan)
+    c0 = ExecutionContext([low.plan], name="golden-agg-0", gpu=gpu)
+    parts = collect(c0, [[[batch.slice(0, 5)]]]), collect(c0, [[[batch.slice(5)]]])      # two producers
+    c0.close()
+    assert all(len(p) == 8 for p in parts)
+    c1 = ExecutionContext([top.plan], name="golden-agg-1", gpu=gpu)
+    staged = []
+    for p in range(8):
+        src = [b for prod in parts for b in prod[p] if b.num_rows]
+        if src:
+            out = collect(c1, [[src]])[0][0]
+            staged += list(zip(out["MAX(c1)"].to_pylist(), out["MIN(c2)"].to_pylist(), out["c3"].to_pylist()))
+    c1.close()
+    assert sorted(staged, key=lambda r: r[2]) == want
+    # ---- context.rs:505-589: SELECT a, b, d FROM t1 JOIN t2 ON a = c ORDER BY a ASC LIMIT 3
+    t1 = pa.record_batch([pa.array(["a", "b", "c", "d"]), pa.array([1, 10, 10, 100], pa.int32())], names=["a", "b"])
+    t2 = pa.record_batch([pa.array(["a", "b", "c", "d"]), pa.array([1, 10, 10, 100], pa.int32())], names=["c", "d"])
+    ctx = ExecutionContext([open(os.path.join(PLANS, "golden_join.json")).read()], name="golden-join", gpu=gpu)
+    rb = collect(ctx, [[[t1]], [[t2]]])[0][0]
+    ctx.close()
+    assert rb.schema.names == ["a", "b", "d"]
+    rows = sorted(zip(rb["a"].to_pylist(), rb["b"].to_pylist(), rb["d"].to_pylist()))
+    assert rows[:3] == [("a", 1, 1), ("b", 10, 10), ("c", 10, 10)] and len(rows) == 4

@@ -193,9 +193,130 @@ def q13():
                               (col("b_date_time", 3), "b_date_time"), (col("value", 5), "value")], out)
 
 
+def winning_bids(with_category):
+    """Q of q4.sql / q9.sql: MAX(price) per auction over the bids placed while the auction was open.
+    flock/src/distributed_plan/planner.rs:218-256 (q4 stages 0-2; q9 is the same sub-plan without `category`):
+      HashAggregateExec FinalPartitioned gby=[a_id(, category)] aggr=[MAX(bid.price)] <- Hash([a_id(, category)]) <- Partial
+        <- FilterExec b_date_time@6 >= a_date_time@1 AND b_date_time@6 <= expires@2
+        <- HashJoinExec Partitioned on=[(a_id@0, auction@0)] <- Hash([a_id]) <- auction ; Hash([auction]) <- bid"""
+    if with_category:
+        af = [AUCTION[0], AUCTION[5], AUCTION[6], AUCTION[8]]
+        a_scan, b_scan, bf = memory(AUCTION, [0, 5, 6, 8], "auction"), memory(BID, [0, 2, 3], "bid"), [BID[0], BID[2], BID[3]]
+    else:
+        af = [AUCTION[0], AUCTION[5], AUCTION[6]]
+        a_scan, b_scan, bf = memory(AUCTION, [0, 5, 6], "auction"), memory(BID, [0, 1, 2, 3], "bid"), BID
+    jf = af + bf
+    ix = {f["name"]: i for i, f in enumerate(jf)}
+    j = join(coalesce(hashp(rr(a_scan), [col("a_id", 0)])), coalesce(hashp(rr(b_scan), [col("auction", 0)])),
+             [(("a_id", 0), ("auction", 0))], jf)
+    bdt = col("b_date_time", ix["b_date_time"])
+    between = binary(binary(bdt, "GtEq", col("a_date_time", 1)), "And", binary(bdt, "LtEq", col("expires", 2)))
+    grp = [(col("a_id", 0), "a_id")] + ([(col("category", 3), "category")] if with_category else [])
+    gf = [field("a_id", "Int32")] + ([field("category", "Int32")] if with_category else [])
+    mx = [{"aggregate_expr": "max", "name": "MAX(bid.price)", "data_type": "Int32", "nullable": True, "expr": col("price", ix["price"])}]
+    partial = agg(coalesce(filt(coalesce(j), between)), "Partial", grp, mx, jf, gf + [field("MAX(bid.price)[max]", "Int32", True)])
+    keys = [col("a_id", 0)] + ([col("category", 1)] if with_category else [])
+    fgrp = [(col("a_id", 0), "a_id")] + ([(col("category", 1), "category")] if with_category else [])
+    return agg(coalesce(hashp(partial, keys)), "FinalPartitioned", fgrp, mx, jf, gf + [field("MAX(bid.price)", "Int32", True)])
+
+
+def q4():
+    # benchmarks/src/nexmark/query/q4.sql; flock/src/distributed_plan/planner.rs:218-256 (stages re-joined into one plan)
+    fin = [field("final", "Int32", True), field("category", "Int32")]
+    q = proj(proj(winning_bids(True), [(col("MAX(bid.price)", 2), "final"), (col("category", 1), "category")], fin),
+             [(col("final", 0), "final"), (col("category", 1), "category")], fin)
+    avg = [{"aggregate_expr": "avg", "name": "AVG(Q.final)", "data_type": "Float64", "nullable": True, "expr": col("final", 0)}]
+    part = [field("category", "Int32"), field("AVG(Q.final)[count]", "UInt64", True), field("AVG(Q.final)[sum]", "Float64", True)]
+    out = [field("category", "Int32"), field("AVG(Q.final)", "Float64", True)]
+    partial = agg(q, "Partial", [(col("category", 1), "category")], avg, fin, part)
+    final = agg(coalesce(hashp(partial, [col("category", 0)])), "FinalPartitioned", [(col("category", 0), "category")], avg, fin, out)
+    return proj(final, [(col("category", 0), "category"), (col("AVG(Q.final)", 1), "AVG(Q.final)")], out)
+
+
+def q9():
+    # benchmarks/src/nexmark/query/q9.sql + q9_plan.fmt: bid JOIN Q ON auction = id AND price = final
+    idf = [field("id", "Int32"), field("final", "Int32", True)]
+    q = proj(proj(winning_bids(False), [(col("a_id", 0), "id"), (col("MAX(bid.price)", 1), "final")], idf),
+             [(col("id", 0), "id"), (col("final", 1), "final")], idf)
+    left = coalesce(hashp(rr(memory(BID, [0, 1, 2, 3], "bid")), [col("auction", 0), col("price", 2)]))
+    right = coalesce(hashp(q, [col("id", 0), col("final", 1)]))
+    j = join(left, right, [(("auction", 0), ("id", 0)), (("price", 2), ("final", 1))], BID + idf)
+    return proj(coalesce(j), [(col("auction", 0), "auction"), (col("bidder", 1), "bidder"), (col("price", 2), "price"),
+                              (col("b_date_time", 3), "b_date_time")], BID)
+
+
+AD_EVENT = [field("user_id", "Utf8"), field("page_id", "Utf8"), field("ad_id", "Utf8"), field("ad_type", "Utf8"),
+            field("event_type", "Utf8"), field("event_time", TS), field("ip_address", "Utf8")]
+CAMPAIGN = [field("c_ad_id", "Utf8"), field("campaign_id", "Utf8")]
+
+
+def ysb():
+    # benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346 (stages re-joined into one plan)
+    ev = [AD_EVENT[2], AD_EVENT[4]]
+    left = coalesce(hashp(coalesce(filt(rr(memory(AD_EVENT, [2, 4], "ysb_ad_events")), binary(col("event_type", 1), "Eq", lit("Utf8", "view")))),
+                          [col("ad_id", 0)]))
+    right = coalesce(hashp(rr(memory(CAMPAIGN, [0, 1], "ysb_campaigns")), [col("c_ad_id", 0)]))
+    jf = ev + CAMPAIGN
+    j = {"execution_plan": "hash_join_exec", "left": left, "right": right, "on": [[col("ad_id", 0), col("c_ad_id", 0)]],
+         "join_type": "Inner", "mode": "Partitioned", "random_state": {"k0": 0, "k1": 0, "k2": 0, "k3": 0}, "schema": schema(jf)}
+    cnt = [{"aggregate_expr": "count", "name": "COUNT(UInt8(1))", "data_type": "UInt64", "nullable": True, "expr": lit("UInt8", 1)}]
+    part = [field("campaign_id", "Utf8"), field("COUNT(UInt8(1))[count]", "UInt64", True)]
+    out = [field("campaign_id", "Utf8"), field("COUNT(UInt8(1))", "UInt64", True)]
+    partial = agg(coalesce(j), "Partial", [(col("campaign_id", 3), "campaign_id")], cnt, jf, part)
+    final = agg(coalesce(hashp(partial, [col("campaign_id", 0)])), "FinalPartitioned", [(col("campaign_id", 0), "campaign_id")], cnt, jf, out)
+    return proj(final, [(col("campaign_id", 0), "campaign_id"), (col("COUNT(UInt8(1))", 1), "COUNT(UInt8(1))")], out)
+
+
+def name_col(name):
+    # older fork revisions serialise a column by name only (the dialect of flock/src/tests/data/plan/*.json)
+    return {"physical_expr": "column", "name": name}
+
+
+def golden_aggregate():
+    """The plan of the reference's operator-level golden at this boundary (flock/src/runtime/context.rs:430-503:
+    `SELECT MAX(c1), MIN(c2), c3 FROM test WHERE c2 < 99 GROUP BY c3 [ORDER BY c3]`), without the final sort, in the shape and
+    dialect of the reference's aggregate.json fixture: Projection <- FinalPartitioned <- Hash([c3], 8) <- Partial <- Filter
+    (c2 < TRY_CAST(99 AS Float64)) <- RoundRobin <- MemoryExec [0, 1, 2]."""
+    f = [field("c1", "Int64"), field("c2", "Float64"), field("c3", "Utf8")]
+    aggs = [{"aggregate_expr": "max", "data_type": "Int64", "expr": name_col("c1"), "name": "MAX(c1)", "nullable": True},
+            {"aggregate_expr": "min", "data_type": "Float64", "expr": name_col("c2"), "name": "MIN(c2)", "nullable": True}]
+    pred = {"physical_expr": "binary_expr", "left": name_col("c2"), "op": "Lt",
+            "right": {"physical_expr": "try_cast_expr", "cast_type": "Float64", "expr": lit("Int64", 99)}}
+    part = [field("c3", "Utf8"), field("MAX(c1)[max]", "Int64", True), field("MIN(c2)[min]", "Float64", True)]
+    out = [field("c3", "Utf8"), field("MAX(c1)", "Int64", True), field("MIN(c2)", "Float64", True)]
+    scan = {"execution_plan": "memory_exec", "schema": schema(f), "projection": [0, 1, 2]}
+    grp = [[name_col("c3"), "c3"]]
+    partial = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": grp, "aggr_expr": aggs, "input": coalesce(filt(rr(scan), pred)),
+               "input_schema": schema(f), "schema": schema(part), "output_rows": {"metric_type": "Counter", "value": 0}}
+    final = {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": grp, "aggr_expr": aggs,
+             "input": coalesce({"execution_plan": "repartition_exec", "input": partial, "partitioning": {"Hash": [[name_col("c3")], P]}}),
+             "input_schema": schema(f), "schema": schema(out), "output_rows": {"metric_type": "Counter", "value": 0}}
+    pf = [field("MAX(c1)", "Int64", True), field("MIN(c2)", "Float64", True), field("c3", "Utf8")]
+    return {"execution_plan": "projection_exec", "expr": [[name_col("MAX(c1)"), "MAX(c1)"], [name_col("MIN(c2)"), "MIN(c2)"], [name_col("c3"), "c3"]],
+            "input": final, "schema": schema(pf)}
+
+
+def golden_join():
+    """The plan of flock/src/runtime/context.rs:505-589 (`SELECT a, b, d FROM t1 JOIN t2 ON a = c [ORDER BY a LIMIT 3]`) below
+    its sort + limit, in the shape and dialect of the reference's join.json: Projection <- HashJoin on [["a", "c"]] (Utf8 keys,
+    bare names) <- Hash([a], 8) <- t1 ; Hash([c], 8) <- t2."""
+    t1 = [field("a", "Utf8"), field("b", "Int32")]
+    t2 = [field("c", "Utf8"), field("d", "Int32")]
+    side = lambda f, k: coalesce({"execution_plan": "repartition_exec", "partitioning": {"Hash": [[name_col(k)], P]},
+                                  "input": rr({"execution_plan": "memory_exec", "schema": schema(f), "projection": [0, 1]})})
+    j = {"execution_plan": "hash_join_exec", "left": side(t1, "a"), "right": side(t2, "c"), "on": [["a", "c"]], "join_type": "Inner",
+         "mode": "Partitioned", "random_state": {"k0": 0, "k1": 0, "k2": 0, "k3": 0}, "schema": schema(t1 + t2)}
+    return {"execution_plan": "projection_exec", "expr": [[name_col("a"), "a"], [name_col("b"), "b"], [name_col("d"), "d"]], "input": coalesce(j),
+            "schema": schema([t1[0], t1[1], t2[1]])}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13)):
+    for name, fn in (("golden_aggregate", golden_aggregate), ("golden_join", golden_join)):
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(fn(), f, indent=1, sort_keys=True)
+            f.write("\n")
+    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13), ("q4", q4), ("q9", q9), ("ysb", ysb)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
