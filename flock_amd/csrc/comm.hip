@@ -96,12 +96,14 @@ int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, in
 
 // Variable-size all-to-all of one device buffer: bytes [send_off[p], send_off[p+1]) go to rank p, bytes from rank s land at
 // [recv_off[s], recv_off[s+1]).  Offsets are host arrays of n + 1 entries.  Stream-ordered (rccl) / synchronising (local).
-int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off) {
+// skip_self: the rank's own chunk stays where it is (the caller reads it from the send buffer).
+int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off,
+               bool skip_self = false) {
     const int n = c->n;
     const uint8_t *s8 = static_cast<const uint8_t *>(send);
     uint8_t *r8 = static_cast<uint8_t *>(recv);
     if (n == 1) {
-        if (send_off[1] > send_off[0]) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[0], s8 + send_off[0], (size_t)(send_off[1] - send_off[0]), hipMemcpyDeviceToDevice, ctx->stream));
+        if (send_off[1] > send_off[0] && !skip_self) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[0], s8 + send_off[0], (size_t)(send_off[1] - send_off[0]), hipMemcpyDeviceToDevice, ctx->stream));
         return FLOCKGPU_OK;
     }
     if (!c->is_rccl) {
@@ -115,7 +117,8 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
             const int64_t bytes = so[c->rank + 1] - so[c->rank];
             if (bytes != recv_off[s + 1] - recv_off[s]) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s,
                                                                     (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
-            if (bytes) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream));
+            if (bytes && !(skip_self && s == c->rank))
+                FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream));
         }
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         g.barrier();  // every rank has pulled its runs: send buffers may be reused
@@ -129,6 +132,7 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
     for (uint64_t k = 0; k < rounds; ++k) {
         FG_NCCL(ctx, ncclGroupStart());
         for (int p = 0; p < n; ++p) {
+            if (skip_self && p == c->rank) continue;
             const int64_t sb = send_off[p + 1] - send_off[p], rb = recv_off[p + 1] - recv_off[p];
             const int64_t s0 = std::min<int64_t>(sb, (int64_t)k * kMaxPeerBytes), s1 = std::min<int64_t>(sb, (int64_t)(k + 1) * kMaxPeerBytes);
             const int64_t r0 = std::min<int64_t>(rb, (int64_t)k * kMaxPeerBytes), r1 = std::min<int64_t>(rb, (int64_t)(k + 1) * kMaxPeerBytes);
@@ -226,6 +230,21 @@ __global__ __launch_bounds__(kBlock) void regroup_index_kernel(const int64_t *__
     }
 }
 
+// dst[out_start[run] ...] = src[src_start[run] ...] for every run, `width` bytes per row: grid (shares per run, runs).  Runs start at
+// arbitrary rows, so the body moves 4-byte words (rows are 4 or 8 bytes wide: always whole words).
+// src_start[run] >= 0: a row of the received buffer; < 0: row -1 - src_start[run] of this rank's own send buffer (its chunk is not copied
+// to itself first).
+__global__ __launch_bounds__(kBlock) void regroup_copy_kernel(const int64_t *__restrict__ out_start, const int64_t *__restrict__ src_start,
+                                                              const uint8_t *__restrict__ src, const uint8_t *__restrict__ self_src,
+                                                              uint8_t *__restrict__ dst, int32_t width) {
+    const int run = blockIdx.y;
+    const int64_t words = (out_start[run + 1] - out_start[run]) * (width / 4);
+    const int64_t s0 = src_start[run];
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(s0 >= 0 ? src + s0 * width : self_src + (-1 - s0) * width);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst + out_start[run] * width);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (int64_t)gridDim.x * kBlock) d[i] = s[i];
+}
+
 inline unsigned grid_for(flockgpu_ctx *ctx, int64_t n) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(n, kBlock), (int64_t)ctx->num_cus * 16));
 }
@@ -264,7 +283,23 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     const int32_t *part_rows = nullptr;
     const int64_t *d_group_off = nullptr, *pw = nullptr;  // pw: n * n_win + 1 group offsets, destination-major (pinned, valid after the wait)
     int64_t n_send = 0;
-    FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send));
+    // the 4-byte columns ride in the partition's emit pass (send order written directly); 8-byte and Utf8 columns are taken below
+    int64_t covered = 0;
+    for (int w = 0; w < n_win; ++w) covered += win->pane_row_offsets[win->win_pane_hi[w]] - win->pane_row_offsets[win->win_pane_lo[w]];
+    PartPayload payload;
+    std::vector<int> payload_of(cols.size(), -1);
+    for (size_t i = 0; i < cols.size(); ++i) {
+        if (cols[i].utf8() || cols[i].width != 4 || payload.n == 4) continue;
+        void *p = nullptr;
+        FG_TRY(arena_get(ctx, (name + ".send" + std::to_string(i)).c_str(), (size_t)covered * 4 + 16, &p));
+        payload.src[payload.n] = static_cast<const int32_t *>(cols[i].values);
+        payload.dst[payload.n] = static_cast<int32_t *>(p);
+        payload_of[i] = payload.n++;
+    }
+    payload.skip_rows = true;
+    for (size_t i = 0; i < cols.size(); ++i) payload.skip_rows = payload.skip_rows && payload_of[i] >= 0;
+    FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send, &payload,
+                                  (name + ".part").c_str()));
     int64_t *d_run_start = nullptr;
     FG_TRY(arena_get_t(ctx, (name + ".run_start").c_str(), (size_t)n + 2, &d_run_start));
     hipLaunchKernelGGL(pick_run_starts_kernel, dim3(1), dim3(64), 0, ctx->stream, d_group_off, n_win, n, d_run_start);
@@ -303,6 +338,8 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
             }
             FG_TRY(check_launch(ctx, "run_bytes_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (payload_of[i] >= 0) {
+            sent[i].values = payload.dst[payload_of[i]];
         } else {
             void *p = nullptr;
             FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
@@ -365,12 +402,16 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         out_start[(size_t)n_runs] = src_start[(size_t)n_runs] = pos;
         out->win_off[(size_t)n_win] = pos;
     }
-    int64_t *d_out_start = nullptr, *d_src_start = nullptr;
+    int64_t *d_out_start = nullptr, *d_src_start = nullptr, *d_src_self = nullptr;
     int32_t *d_index = nullptr;
     FG_TRY(upload(ctx, name + ".out_start", out_start.data(), out_start.size(), &d_out_start));
     FG_TRY(upload(ctx, name + ".src_start", src_start.data(), src_start.size(), &d_src_start));
+    // fixed-width columns: the rank's own chunk never leaves the send buffer -- its runs are regrouped from there (src = -1 - row)
+    std::vector<int64_t> src_self(src_start);
+    for (int w = 0; w < n_win; ++w) src_self[(size_t)w * n + c->rank] = -1 - pw[(size_t)c->rank * n_win + w];
+    FG_TRY(upload(ctx, name + ".src_self", src_self.data(), src_self.size(), &d_src_self));
     FG_TRY(arena_get_t(ctx, (name + ".index").c_str(), (size_t)n_recv + 4, &d_index));
-    if (n_recv > 0 && n_runs > 0) {
+    if (n_recv > 0 && n_runs > 0 && !ucols.empty()) {   // (only the Utf8 regroup reads the row-level index)
         LaunchScope ls(ctx, "regroup_index_kernel");
         hipLaunchKernelGGL(regroup_index_kernel, dim3((unsigned)std::min<int64_t>(n_runs, (int64_t)ctx->num_cus * 32)), dim3(kBlock), 0, ctx->stream, d_out_start,
                            d_src_start, n_runs, d_index);
@@ -396,9 +437,15 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
                 so[(size_t)p] = run_start[(size_t)p] * col.width;
                 ro[(size_t)p] = recv_rows_off[(size_t)p] * col.width;
             }
-            FG_TRY(all_to_all(ctx, c, sent[i].values, so.data(), raw, ro.data()));
-            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(raw), d_index, n_recv, static_cast<int32_t *>(fin)));
-            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(raw), d_index, n_recv, static_cast<int64_t *>(fin)));
+            FG_TRY(all_to_all(ctx, c, sent[i].values, so.data(), raw, ro.data(), true));
+            if (n_recv > 0 && n_runs > 0) {   // (source, window) runs -> window order: contiguous runs, copied as such
+                LaunchScope ls(ctx, "regroup_copy_kernel");
+                const unsigned per_run = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(div_up(n_recv, n_runs) * col.width, (int64_t)kBlock * 16 * 4),
+                                                                                           std::max<int64_t>(1, (int64_t)ctx->num_cus * 16 / n_runs)));
+                hipLaunchKernelGGL(regroup_copy_kernel, dim3(per_run, (unsigned)n_runs), dim3(kBlock), 0, ctx->stream, d_out_start, d_src_self,
+                                   static_cast<const uint8_t *>(raw), static_cast<const uint8_t *>(sent[i].values), static_cast<uint8_t *>(fin), col.width);
+            }
+            FG_TRY(check_launch(ctx, "regroup_copy_kernel"));
             out->cols[i].type = col.width == 4 ? ColType::I32 : ColType::I64;
             out->cols[i].values = fin;
             continue;
@@ -555,14 +602,19 @@ int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_panes = win->n_panes, n_win = win->n_windows;
     // stage 0 (q5.dag): HashAggregateExec mode=Partial on this rank's rows, pane by pane
-    flockgpu_q5_partial_result part{};
-    FG_TRY(flockgpu_q5_partial_counts(ctx, bid, win, &part));
-    // RepartitionExec Hash([auction], n): the groups of every pane, one "window" per pane
-    std::vector<int32_t> lo, hi;
-    std::vector<int64_t> pane_off(part.pane_out_offsets, part.pane_out_offsets + n_panes + 1);
-    const flockgpu_windows panes = single_pane_windows(pane_off, lo, hi);
+    // (per 8192-row tile: one pass over the bids, pairs written straight into the pane's region -- gather.hpp: Q5TilePartial)
+    Q5TilePartial part;
+    FG_TRY(q5_partial_by_tile(ctx, bid, win, &part));
+    // RepartitionExec Hash([auction], n): the groups of every pane, one "window" per pane.  The schedule names the used part of every
+    // region (pane 2p) and leaves the unused space behind it (pane 2p + 1) out of every window.
+    std::vector<int32_t> lo((size_t)std::max(n_panes, 1)), hi(lo.size());
+    for (int p = 0; p < n_panes; ++p) {
+        lo[(size_t)p] = 2 * p;
+        hi[(size_t)p] = 2 * p + 1;
+    }
+    const flockgpu_windows panes{part.offsets.data(), 2 * n_panes, lo.data(), hi.data(), n_panes};
     XRecv got;
-    FG_TRY(exchange_relation(ctx, comm, "xq5", {XCol{part.auction, nullptr, 4}, XCol{part.count, nullptr, 4}}, 0, part.rows, &panes, &got));
+    FG_TRY(exchange_relation(ctx, comm, "xq5", {XCol{part.auction, nullptr, 4}, XCol{part.count, nullptr, 4}}, 0, part.capacity, &panes, &got));
     // stage 1: FinalPartitioned COUNT + MAX + join over the groups this rank owns (windows over the received panes)
     const flockgpu_windows recv_win{got.win_off.data(), n_panes, win->win_pane_lo, win->win_pane_hi, n_win};
     flockgpu_q5_result local{};
@@ -645,7 +697,15 @@ int flockgpu_q8_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const floc
     FG_HIP(ctx, hipSetDevice(ctx->device));
     XRecv a, p;
     FG_TRY(exchange_relation(ctx, comm, "xq8p", {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}}, 0, person->rows, person_win, &p));
-    FG_TRY(exchange_relation(ctx, comm, "xq8a", {XCol{auction->seller, nullptr, 4}}, 0, auction->rows, auction_win, &a));
+    // q8.dag: HashAggregateExec(Partial) gby=[seller] before the repartition -- the sellers travel as their per-tile DISTINCT values
+    // (3/4 of a window's auctions name one of a few hot sellers), the FinalPartitioned DISTINCT is the join's own seller set
+    const int32_t *sellers = nullptr;
+    std::vector<int64_t> seller_off;
+    int64_t n_sellers = 0;
+    FG_TRY(tile_distinct_i32(ctx, "xq8a.distinct", auction->seller, auction->rows, auction_win, &sellers, &seller_off, &n_sellers));
+    std::vector<int32_t> slo, shi;
+    const flockgpu_windows seller_win = single_pane_windows(seller_off, slo, shi);
+    FG_TRY(exchange_relation(ctx, comm, "xq8a", {XCol{sellers, nullptr, 4}}, 0, n_sellers, &seller_win, &a));
     std::vector<int32_t> alo, ahi, plo, phi;
     const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
     const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values),

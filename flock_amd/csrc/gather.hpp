@@ -80,8 +80,38 @@ int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_byt
 
 // flockgpu_partition_by_key without its host wait (shuffle.hip): rows grouped by (destination, window) on the device, the
 // n_parts * n_win + 1 group offsets on the device and queued into pinned memory (valid after the next stream synchronisation).
+// `payload`: up to four 4-byte columns whose values the emit pass writes in send order next to the row numbers (it has the
+// tile's rows at hand: the separate `take` per column -- 12 B of traffic per row and column -- is not needed for them).
+struct PartPayload {
+    int32_t n = 0;
+    const int32_t *src[4] = {};
+    int32_t *dst[4] = {};  // rows of every window entries each, caller-owned
+    bool skip_rows = false;  // the caller needs no row numbers (every column it moves is a payload column)
+};
 int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win, int32_t n_parts,
-                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out);
+                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out,
+                           const PartPayload *payload = nullptr, const char *cache_name = nullptr);
+
+// q8.dag's Partial DISTINCT for the in-library exchange (shuffle.hip): the first occurrence of every key inside each 8192-row tile of a
+// window (a tile = one input partition of HashAggregateExec(Partial) with no aggregates), as a compact key column in input order with the
+// windows' new row offsets.  Keys may repeat across tiles (and INT32_MIN, the table's empty mark, is never deduplicated): the
+// FinalPartitioned DISTINCT on the receiving side removes what is left.  Synchronises once.
+int tile_distinct_i32(flockgpu_ctx *ctx, const char *name, const int32_t *keys, int64_t rows, const flockgpu_windows *win,
+                      const int32_t **out_keys, std::vector<int64_t> *out_win_off, int64_t *n_out);
+
+// q5.dag's Partial stage for the in-library exchange (q5.hip): COUNT GROUP BY auction per 8192-row TILE of a pane -- a tile plays
+// the part of one input partition of HashAggregateExec(Partial), whose RoundRobin-fed partitions each emit their own groups in the
+// reference, too -- written as (auction, count) pairs into the pane's region of ONE pass over the bids: no global counters, no
+// clear, no compaction passes.  Region p starts at offsets[2p] and holds offsets[2p + 1] - offsets[2p] pairs; [offsets[2p + 1],
+// offsets[2p + 2]) is unused space (a pane's region is as large as the pane: pairs <= rows).  Synchronises once.
+struct Q5TilePartial {
+    const int32_t *auction = nullptr;   // device, `capacity` slots
+    const uint32_t *count = nullptr;
+    int64_t capacity = 0;
+    std::vector<int64_t> offsets;       // host, 2 * n_panes + 1
+    int64_t pairs = 0;
+};
+int q5_partial_by_tile(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win, Q5TilePartial *out);
 
 // In-place inclusive scan of n int32 values; `name` keys the scan-state arena buffers.
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n);

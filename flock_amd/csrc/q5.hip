@@ -270,25 +270,6 @@ __global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__rest
     }
 }
 
-// Weighted input (the FinalPartitioned side): a window's counts must stay below 2^32 -- the direct-address counters are
-// uint32 and the packed table slots carry their count in the low half.  Per-pane weight totals, summed per window on the host.
-__global__ __launch_bounds__(kBlock) void q5_pane_weight_kernel(const uint32_t *__restrict__ weight, const int64_t *__restrict__ seg_off,
-                                                                unsigned long long *__restrict__ pane_sum) {
-    __shared__ unsigned long long s_part[kWavesPerBlock];
-    const int pane = blockIdx.y;
-    const int64_t lo = seg_off[2 * pane], hi = seg_off[2 * pane + 1];
-    unsigned long long acc = 0;
-    for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kBlock) acc += weight[i];
-    acc = wave_sum_u64(acc);
-    if (lane_id() == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < kWavesPerBlock; ++w) t += s_part[w];
-        if (t) atomicAdd(&pane_sum[pane], t);
-    }
-}
-
 // One launch instead of five memsets: the counters in use (their number from the device when the layout was made there),
 // the window tables, the scalars, the slow list head and the per-workgroup maxima.
 __global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, const uint64_t *__restrict__ info, uint64_t cnt_host,
@@ -317,23 +298,17 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ pane_win_ptr,
                                                           const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                           uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
-                                                          int32_t *slow_list, const uint64_t *__restrict__ spec_info) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
+                                                          int32_t *slow_list, const uint64_t *__restrict__ spec_info,
+                                                          unsigned long long *pane_wsum) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kWeighted ? 4 : kHist + kHistPad];
     __shared__ int32_t s_red[8];
+    __shared__ unsigned long long s_w[kWavesPerBlock];
     if (spec_info && !spec_info[2]) return;  // the device layout declined this call
-    {
-        uint4 *z = reinterpret_cast<uint4 *>(hist);
-        for (int s = threadIdx.x; s < (kHist + kHistPad) / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
-    }
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kQ5Tile);
     FlushArgs f;
     f.wp0 = pane_win_ptr[tr.seg];
     f.wp1 = pane_win_ptr[tr.seg + 1];
     if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
-    if (tr.lo != tr.tile_begin || tr.hi != tr.tile_begin + kQ5Tile) {  // ragged first / last tile of a pane
-        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
-        return;
-    }
     f.pane = panes[tr.seg];
     f.pane_win_idx = pane_win_idx;
     f.counters = counters;
@@ -341,6 +316,53 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     f.cap = cap;
     f.tab_used = tab_used;
     f.err = err;
+    const bool full_tile = tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile;
+    if (kWeighted) {
+        // Rows are the partial groups other partitions sent: per source they arrive as the source's counters in ascending key
+        // order, i.e. an 8192-row tile holds ~8192 DISTINCT keys over a range wider than the LDS histogram.  Nothing to
+        // aggregate in LDS: every row is one fire-and-forget atomic on the pane's counters, consecutive lanes on consecutive
+        // counters (0.34 ms of LDS hashing in q5_count_slow_kernel before).  Ragged tiles take the same path, row-guarded;
+        // the per-pane weight totals of the 2^32 guard ride along (a pass of their own before: 0.085 ms).
+        unsigned long long wsum = 0;
+        // lane l takes row  chunk * 256 + l : a wave's 64 atomics of one instruction land on 64 consecutive counters (two cache lines).
+        // With the 16-byte loads of the unweighted path (lane l = rows 4l .. 4l + 3) they would stride 16 bytes over eight lines: 0.6 ms
+        // instead of 0.1 ms for 6.5e7 groups.
+        constexpr int kChunks = kQ5Tile / kBlock, kBatch = 8;
+#pragma unroll 1
+        for (int c0 = 0; c0 < kChunks; c0 += kBatch) {
+            int32_t kk[kBatch];
+            uint32_t ww[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const int64_t r = tr.tile_begin + (int64_t)(c0 + b) * kBlock + threadIdx.x;
+                const bool in = full_tile || (r >= tr.lo && r < tr.hi);
+                kk[b] = in ? auction[r] : 0;
+                ww[b] = in ? weight[r] : 0u;
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+                if (ww[b]) {   // (a zero count changes nothing; rows outside the pane carry zero)
+                    emit_pair(kk[b], ww[b], f);
+                    wsum += ww[b];
+                }
+        }
+        wsum = wave_sum_u64(wsum);
+        if (lane_id() == 0) s_w[threadIdx.x >> 6] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0 && pane_wsum) {
+            const unsigned long long tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (tot) atomicAdd(&pane_wsum[tr.seg], tot);
+        }
+        return;
+    }
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(hist);
+        for (int s = threadIdx.x; s < (kHist + kHistPad) / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
+    }
+    if (!full_tile) {  // ragged first / last tile of a pane
+        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)blockIdx.x;
+        return;
+    }
 
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     int32_t k[kQ5Iters][4];
@@ -373,24 +395,6 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
         if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)(blockIdx.x | kWideTile);
         return;
     }
-    if (kWeighted) {
-#pragma unroll
-        for (int it = 0; it < kQ5Iters; ++it) {
-            const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-            const uint4 w4 = *reinterpret_cast<const uint4 *>(weight + r0);
-            atomicAdd(&hist[(uint32_t)k[it][0] - (uint32_t)mn], w4.x);
-            atomicAdd(&hist[(uint32_t)k[it][1] - (uint32_t)mn], w4.y);
-            atomicAdd(&hist[(uint32_t)k[it][2] - (uint32_t)mn], w4.z);
-            atomicAdd(&hist[(uint32_t)k[it][3] - (uint32_t)mn], w4.w);
-        }
-        __syncthreads();
-        for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
-            const uint32_t c = hist[s];
-            if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
-        }
-        return;
-    }
-
     // hot key of this wave, kept in scalar registers across iterations
     int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
     uint32_t hot_cnt = 0;
@@ -432,6 +436,120 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
         const uint32_t c = hist[s];
         if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
+    }
+}
+
+// ---- Partial COUNT per tile (the exchange's stage 0): the histogram phase of q5_count_kernel, then the tile's bins are written as
+// (key, count) pairs at a position claimed with ONE atomic per tile on the pane's cursor.  Ragged tiles and tiles whose keys spread wider than the histogram hand their rows out as
+// (key, 1) pairs: exact, merely uncompressed (the FinalPartitioned side adds pairs up whatever their number).
+__global__ __launch_bounds__(kBlock) void q5_partial_tile_kernel(const int32_t *__restrict__ auction, SegTiles st,
+                                                                 const int64_t *__restrict__ region_start, uint32_t *cursor,
+                                                                 int32_t *__restrict__ out_key, uint32_t *__restrict__ out_cnt) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
+    __shared__ int32_t s_red[8];
+    __shared__ uint32_t s_base;
+    // Workgroup b takes tile b / n_seg of pane b % n_seg: the ~2000 workgroups in flight then spread over all panes, and so do their
+    // claims on the panes' cursors.  In tile order they would all sit in one or two panes: a returning atomic on one word completes
+    // ~88 times per microsecond, i.e. 1.4 ms for the 122 K tiles of 1e9 bids (measured 1.28 ms; this order: see DESIGN.md section 8).
+    const int32_t pane = (int32_t)(blockIdx.x % (uint32_t)st.n_seg);
+    const int32_t tile = st.tile_first[pane] + (int32_t)(blockIdx.x / (uint32_t)st.n_seg);
+    if (tile >= st.tile_first[pane + 1]) return;
+    const TileRange tr = locate_tile(st, tile, kQ5Tile);
+    const int64_t reg = region_start[tr.seg];
+    if (reg < 0) return;  // pane of no window
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(hist);
+        for (int s = threadIdx.x; s < (kHist + kHistPad) / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
+    }
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const bool full_tile = tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile;
+    int32_t k[kQ5Iters][4];
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+    if (full_tile) {
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
+            const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+            k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
+        }
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            mn = min(mn, min(min(k[it][0], k[it][1]), min(k[it][2], k[it][3])));
+            mx = max(mx, max(max(k[it][0], k[it][1]), max(k[it][2], k[it][3])));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, __shfl_xor(mn, o, 64));
+            mx = max(mx, __shfl_xor(mx, o, 64));
+        }
+        if (lane == 0) {
+            s_red[wave] = mn;
+            s_red[4 + wave] = mx;
+        }
+    }
+    __syncthreads();  // also orders the zeroing of `hist`
+    if (full_tile) {
+        mn = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    }
+    const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+    if (!full_tile || span >= (uint32_t)kHist) {   // rows as they are
+        const uint32_t n = (uint32_t)(tr.hi - tr.lo);
+        if (threadIdx.x == 0) s_base = atomicAdd(&cursor[tr.seg], n);
+        __syncthreads();
+        const int64_t o = reg + s_base;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+            out_key[o + i] = auction[tr.lo + i];
+            out_cnt[o + i] = 1u;
+        }
+        return;
+    }
+    // The tile hands out bins [0, span] of its histogram -- zero counts included -- as pairs in key order: span + 1 slots are claimed
+    // NOW, before the histogram is built, so the claim's round trip (a returning atomic) is hidden behind the counting, and the write-out
+    // is a plain coalesced copy of the bins: no compaction, no scan.  NEXMark's ids are dense (616 of a tile's 635 ids occur), so the
+    // empty pairs are ~3 % of the output; for sparse keys they cost exchange bandwidth, never correctness (a zero count adds nothing),
+    // and a tile never hands out more pairs than half its rows (span < kHist = 4096).
+    if (threadIdx.x == 0) s_base = atomicAdd(&cursor[tr.seg], span + 1u);
+    // hot key of this wave, kept in scalar registers across iterations (as in q5_count_kernel)
+    int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
+    uint32_t hot_cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kQ5Iters; ++it) {
+        uint64_t b0 = __ballot(k[it][0] == hot);
+        if (__popcll((unsigned long long)b0) < kHotMin) {
+            if (hot_cnt) {
+                if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+                hot_cnt = 0;
+            }
+            const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
+            const uint64_t m1 = __ballot(k[it][0] == c1);
+            hot = c1;
+            b0 = m1;
+            if (__popcll((unsigned long long)m1) < kHotMin && ~m1) {
+                const int l2 = __ffsll((unsigned long long)~m1) - 1;
+                const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                const uint64_t m2 = __ballot(k[it][0] == c2);
+                if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                    hot = c2;
+                    b0 = m2;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool is_hot = k[it][j] == hot;
+            const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
+            hot_cnt += (uint32_t)__popcll((unsigned long long)b);
+            const uint32_t bin = is_hot ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+    __syncthreads();
+    const int64_t o = reg + s_base;
+    for (uint32_t b = threadIdx.x; b <= span; b += kBlock) {
+        out_key[o + b] = (int32_t)((uint32_t)mn + b);
+        out_cnt[o + b] = hist[b];
     }
 }
 
@@ -916,10 +1034,6 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     if (weight && n_panes > 0) {
         FG_TRY(arena_get_t(ctx, "q5.pane_weight", (size_t)n_panes + 1, &d_wsum));
         FG_TRY(pinned_get_t(ctx, "q5.pane_weight", (size_t)n_panes + 1, &h_wsum));
-        FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
-        hipLaunchKernelGGL(q5_pane_weight_kernel, dim3(16, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, weight, st.seg_off, d_wsum);
-        FG_TRY(check_launch(ctx, "q5_pane_weight_kernel"));
-        FG_HIP(ctx, hipMemcpyAsync(h_wsum, d_wsum, sizeof(unsigned long long) * (size_t)n_panes, hipMemcpyDeviceToHost, ctx->stream));
     }
     // hash tables: only stragglers in dense mode; every group otherwise (sized from the density seen last call)
     double rpg = ctx->q5_rows_per_group < 1.0 ? 1.0 : ctx->q5_rows_per_group;
@@ -952,14 +1066,16 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                                (uint64_t)n_meta, slow_list, block_max, (uint64_t)gx * n_win);
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
+        if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
         if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
                 hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list, spec_info);
+                                   slow_list, spec_info, d_wsum);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
+            if (d_wsum) FG_HIP(ctx, hipMemcpyAsync(h_wsum, d_wsum, sizeof(unsigned long long) * (size_t)n_panes, hipMemcpyDeviceToHost, ctx->stream));
             {
                 LaunchScope ls(ctx, "q5_count_slow_kernel");
                 const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
@@ -1064,7 +1180,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             cnt_total = h_info[0];
             scan_total = h_info[1];
         }
-        if (h_wsum) {   // (the copy was queued before the loop: valid after any synchronisation)
+        if (h_wsum) {   // per-pane weight totals, summed by the count kernel: a window's counts must stay below 2^32 (uint32 counters)
             for (int w = 0; w < n_win; ++w) {
                 unsigned long long tot = 0;
                 for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p) tot += h_wsum[p];
@@ -1184,6 +1300,69 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     out->rows = n_sel;
     return FLOCKGPU_OK;
 }
+
+namespace flockgpu {
+
+int q5_partial_by_tile(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win, Q5TilePartial *out) {
+    *out = Q5TilePartial{};
+    FG_TRY(check_windows(ctx, win, bid->rows, "q5 partial"));
+    if (bid->rows > 0 && !bid->auction) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 partial: null auction column");
+    if (reinterpret_cast<uintptr_t>(bid->auction) & 15) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: auction column must be 16-byte aligned");
+    if (bid->rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5 partial: more than 2^31 rows per call");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_panes = win->n_panes;
+    std::vector<char> used((size_t)std::max(n_panes, 1), 0);
+    for (int w = 0; w < win->n_windows; ++w)
+        for (int p = win->win_pane_lo[w]; p < win->win_pane_hi[w]; ++p) used[(size_t)p] = 1;
+    std::vector<int64_t> sb((size_t)n_panes), se((size_t)n_panes);
+    for (int p = 0; p < n_panes; ++p) {
+        sb[(size_t)p] = win->pane_row_offsets[p];
+        se[(size_t)p] = win->pane_row_offsets[p + 1];
+    }
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, "q5.tile_panes", sb.data(), se.data(), n_panes, kQ5Tile, &st));  // (own name: "q5" holds the FinalPartitioned side's schedule)
+    int64_t *d_reg = nullptr, *h_reg = nullptr;
+    uint32_t *d_cur = nullptr, *h_cur = nullptr;
+    int32_t *o_key = nullptr;
+    uint32_t *o_cnt = nullptr;
+    FG_TRY(arena_get_t(ctx, "q5.tile_region", (size_t)n_panes + 1, &d_reg));
+    FG_TRY(pinned_get_t(ctx, "q5.tile_region", (size_t)n_panes + 1, &h_reg));
+    FG_TRY(arena_get_t(ctx, "q5.tile_cursor", (size_t)n_panes + 1, &d_cur));
+    FG_TRY(pinned_get_t(ctx, "q5.tile_cursor", (size_t)n_panes + 1, &h_cur));
+    FG_TRY(arena_get_t(ctx, "q5.tile_key", (size_t)bid->rows + 4, &o_key));
+    FG_TRY(arena_get_t(ctx, "q5.tile_cnt", (size_t)bid->rows + 4, &o_cnt));
+    // (the pinned staging was last read under the synchronisation that ended the previous call)
+    for (int p = 0; p < n_panes; ++p) h_reg[p] = used[(size_t)p] ? sb[(size_t)p] : -1;
+    FG_HIP(ctx, hipMemcpyAsync(d_reg, h_reg, sizeof(int64_t) * (size_t)std::max(n_panes, 1), hipMemcpyHostToDevice, ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_cur, 0, sizeof(uint32_t) * ((size_t)n_panes + 1), ctx->stream));
+    int64_t max_tiles = 0;
+    for (int p = 0; p < n_panes; ++p)
+        if (se[(size_t)p] > sb[(size_t)p]) max_tiles = std::max(max_tiles, div_up(se[(size_t)p] - (sb[(size_t)p] & ~int64_t(3)), (int64_t)kQ5Tile));
+    if (max_tiles * n_panes >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5 partial: too many (pane, tile) pairs");
+    if (st.n_tiles > 0) {
+        LaunchScope ls(ctx, "q5_partial_tile_kernel");
+        hipLaunchKernelGGL(q5_partial_tile_kernel, dim3((unsigned)(max_tiles * n_panes)), dim3(kBlock), 0, ctx->stream, bid->auction, st, d_reg, d_cur, o_key,
+                           o_cnt);
+    }
+    FG_TRY(check_launch(ctx, "q5_partial_tile_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(h_cur, d_cur, sizeof(uint32_t) * (size_t)std::max(n_panes, 1), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->auction = o_key;
+    out->count = o_cnt;
+    out->capacity = bid->rows;
+    out->offsets.resize((size_t)2 * n_panes + 1);
+    for (int p = 0; p < n_panes; ++p) {
+        const int64_t n = used[(size_t)p] ? (int64_t)h_cur[p] : 0;
+        if (n > se[(size_t)p] - sb[(size_t)p]) return fail(ctx, FLOCKGPU_ERR_HIP, "q5 partial: pane %d claims %lld pairs for %lld rows", p, (long long)n, (long long)(se[(size_t)p] - sb[(size_t)p]));
+        out->offsets[(size_t)2 * p] = sb[(size_t)p];
+        out->offsets[(size_t)2 * p + 1] = sb[(size_t)p] + n;
+        out->pairs += n;
+    }
+    out->offsets[(size_t)2 * n_panes] = n_panes ? se[(size_t)n_panes - 1] : 0;
+    return FLOCKGPU_OK;
+}
+
+}  // namespace flockgpu
 
 extern "C" {
 

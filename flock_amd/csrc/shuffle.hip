@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void partition_count_kernel(const int32_t *
 __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
                                                                 uint32_t n_parts, const uint32_t *__restrict__ counts,
                                                                 const uint64_t *__restrict__ tile_base,
-                                                                int32_t *__restrict__ out_rows) {
+                                                                int32_t *__restrict__ out_rows, PartPayload pl) {
     __shared__ uint16_t s_list[kFlagTile];
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
@@ -92,9 +92,76 @@ __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *_
         const uint32_t total = build_flag_list(flags_of(d, part), wc, s_list);
         __syncthreads();
         const uint64_t base = tile_base[slot];
-        for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+            const int64_t r = tr.tile_begin + s_list[i];
+            if (!pl.skip_rows) out_rows[base + i] = (int32_t)r;
+            for (int c = 0; c < pl.n; ++c) pl.dst[c][base + i] = pl.src[c][r];  // the tile's rows: L2-resident since tile_parts
+        }
         __syncthreads();  // s_list is rewritten for the next destination
     }
+}
+
+// ---- Partial DISTINCT per tile.  What repeats inside a tile of sellers is the hot key (3/4 of a window's auctions name one of a few
+// sellers; the others are ~2000 different ids of millions): each wave follows the key most of its lanes hold -- kept while it covers
+// >= 16 lanes, re-elected from two lanes otherwise, as q8_sellers_bitmap_kernel does -- and hands it on ONCE; every other row is handed
+// on as it is.  No LDS, no atomics: a version with an 8192-slot LDS set (exact per tile) took 0.18 ms for 6e7 keys, i.e. more than the
+// shuffle of the rows it saved.  Duplicates that survive are the FinalPartitioned DISTINCT's job.
+__global__ __launch_bounds__(kBlock) void tile_distinct_flag_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
+                                                                    uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    int32_t a[kFlagIters][4];
+    load_flag_tile(keys, n_rows, tr, a);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t rel0 = flag_rel0();
+    const int lane = lane_id();
+    uint32_t flags = 0;
+    int32_t hot = 0;
+    bool have_hot = false, hot_sent = false;  // wave-uniform
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const int32_t key = a[it][j];
+            const bool live = rel >= rel_lo && rel < rel_hi;
+            uint64_t m = have_hot ? __ballot(live && key == hot) : 0;
+            if (__popcll((unsigned long long)m) < 16) {
+                const uint64_t lv = __ballot(live);
+                const bool prev_have = have_hot;
+                const int32_t prev_hot = hot;
+                have_hot = false;
+                m = 0;
+                if (lv) {
+                    const int32_t c1 = __builtin_amdgcn_readlane(key, __ffsll((unsigned long long)lv) - 1);
+                    uint64_t m1 = __ballot(live && key == c1);
+                    int32_t c = c1;
+                    const uint64_t rest = lv & ~m1;
+                    if (__popcll((unsigned long long)m1) < 16 && rest) {
+                        const int32_t c2 = __builtin_amdgcn_readlane(key, __ffsll((unsigned long long)rest) - 1);
+                        const uint64_t m2 = __ballot(live && key == c2);
+                        if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                            m1 = m2;
+                            c = c2;
+                        }
+                    }
+                    if (__popcll((unsigned long long)m1) >= 2) {   // worth following
+                        hot_sent = hot_sent && prev_have && c == prev_hot;   // the same key re-elected: it was handed on already
+                        hot = c;
+                        have_hot = true;
+                        m = m1;
+                    }
+                }
+            }
+            bool first = live;
+            if (m) {
+                const bool in_m = (m >> lane) & 1;
+                if (in_m) first = !hot_sent && lane == __ffsll((unsigned long long)m) - 1;
+                hot_sent = true;
+            }
+            flags |= (first ? 1u : 0u) << (it * 4 + j);
+        }
+    store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
 }  // namespace
@@ -105,8 +172,13 @@ namespace flockgpu {
 // group offsets -- on the device (*d_group_off) and queued for copy into pinned memory (*h_group_off, valid after the next
 // synchronisation of the ctx stream).  The number of rows written is known up front: every row of every window.
 int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows, const flockgpu_windows *win, int32_t n_parts,
-                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out) {
+                           const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out,
+                           const PartPayload *payload, const char *cache_name) {
+    // `cache_name` keys the schedule-dependent state (tile descriptors, first-tile table): a caller that partitions two relations
+    // per call (the q3 / q8 exchanges) gives each its own, so that neither evicts the other's cached upload (a re-upload waits for the stream)
+    const std::string nm = cache_name ? cache_name : "partition";
     if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (payload && (payload->n < 0 || payload->n > 4)) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: at most four payload columns");
     if (rows < 0 || (rows > 0 && !keys)) return fail(ctx, FLOCKGPU_ERR_INVALID, "partition: null argument");
     if (n_parts < 1 || n_parts > kMaxParts)
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: n_parts must be in [1, %d]", kMaxParts);
@@ -123,7 +195,7 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
         covered += se[w] - sb[w];
     }
     SegTiles st;
-    FG_TRY(build_seg_tiles(ctx, "partition", sb.data(), se.data(), n_win, kFlagTile, &st));
+    FG_TRY(build_seg_tiles(ctx, nm.c_str(), sb.data(), se.data(), n_win, kFlagTile, &st));
     const int64_t slots = (int64_t)st.n_tiles * n_parts;
     if (slots > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partition: too many (destination, tile) pairs");
     const size_t n_groups = (size_t)n_parts * n_win;
@@ -131,9 +203,9 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
     // first pseudo-tile of every (destination, window) group: destination-major.  Rebuilt only when the schedule changes
     // (the pinned staging of the previous upload may still be in flight otherwise).
     int32_t *d_first = nullptr, *h_first = nullptr;
-    FG_TRY(arena_get_t(ctx, "partition.first", n_groups + 1, &d_first));
-    FG_TRY(pinned_get_t(ctx, "partition.first", n_groups + 1, &h_first));
-    std::vector<int64_t> &first_key = ctx->host_i64["partition.first_key"];
+    FG_TRY(arena_get_t(ctx, (nm + ".first").c_str(), n_groups + 1, &d_first));
+    FG_TRY(pinned_get_t(ctx, (nm + ".first").c_str(), n_groups + 1, &h_first));
+    std::vector<int64_t> &first_key = ctx->host_i64[nm + ".first_key"];
     std::vector<int64_t> key_now;
     key_now.reserve((size_t)2 * n_win + 3);
     key_now.push_back(n_parts);
@@ -177,7 +249,7 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
     if (st.n_tiles > 0) {
         LaunchScope ls(ctx, "partition_emit_kernel");
         hipLaunchKernelGGL(partition_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st,
-                           (uint32_t)n_parts, counts, tile_base, o_rows);
+                           (uint32_t)n_parts, counts, tile_base, o_rows, payload ? *payload : PartPayload{});
     }
     FG_TRY(check_launch(ctx, "partition_emit_kernel"));
     FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * (n_groups + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -185,6 +257,54 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
     *d_group_off = d_off;
     *h_group_off = h_off;
     *n_out = covered;
+    return FLOCKGPU_OK;
+}
+
+int tile_distinct_i32(flockgpu_ctx *ctx, const char *name, const int32_t *keys, int64_t rows, const flockgpu_windows *win,
+                      const int32_t **out_keys, std::vector<int64_t> *out_win_off, int64_t *n_out) {
+    const std::string nm = name;
+    *out_keys = nullptr;
+    *n_out = 0;
+    FG_TRY(check_windows(ctx, win, rows, "partial distinct"));
+    if (rows > 0 && !keys) return fail(ctx, FLOCKGPU_ERR_INVALID, "partial distinct: null key column");
+    if (reinterpret_cast<uintptr_t>(keys) & 15) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partial distinct: key column must be 16-byte aligned");
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "partial distinct: relations are limited to 2^31 rows per call");
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_win = win->n_windows;
+    std::vector<int64_t> sb((size_t)std::max(n_win, 1)), se(sb.size());
+    int64_t covered = 0;
+    for (int w = 0; w < n_win; ++w) {
+        sb[(size_t)w] = win->pane_row_offsets[win->win_pane_lo[w]];
+        se[(size_t)w] = win->pane_row_offsets[win->win_pane_hi[w]];
+        covered += se[(size_t)w] - sb[(size_t)w];
+    }
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, nm.c_str(), sb.data(), se.data(), n_win, kFlagTile, &st));
+    uint32_t *flag_words = nullptr, *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    int64_t *d_off = nullptr, *h_off = nullptr;
+    int32_t *o_rows = nullptr, *o_keys = nullptr;
+    FG_TRY(arena_get_t(ctx, (nm + ".flags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flag_words));
+    FG_TRY(arena_get_t(ctx, (nm + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (nm + ".tile_base").c_str(), (size_t)st.n_tiles + 2, &tile_base));
+    FG_TRY(arena_get_t(ctx, (nm + ".off").c_str(), (size_t)n_win + 2, &d_off));
+    FG_TRY(pinned_get_t(ctx, (nm + ".off").c_str(), (size_t)n_win + 2, &h_off));
+    FG_TRY(arena_get_t(ctx, (nm + ".rows").c_str(), (size_t)covered + 4, &o_rows));
+    FG_TRY(arena_get_t(ctx, (nm + ".keys").c_str(), (size_t)covered + 4, &o_keys));
+    if (st.n_tiles > 0) {
+        LaunchScope ls(ctx, "tile_distinct_flag_kernel");
+        hipLaunchKernelGGL(tile_distinct_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st, flag_words, counts);
+    }
+    FG_TRY(check_launch(ctx, "tile_distinct_flag_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(emit_flagged_rows(ctx, st, flag_words, counts, tile_base, o_rows));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out_win_off->assign(h_off, h_off + n_win + 1);
+    if (n_win == 0) out_win_off->assign(1, 0);
+    *n_out = (*out_win_off)[(size_t)n_win];
+    FG_TRY(gather_i32(ctx, keys, o_rows, *n_out, o_keys));
+    *out_keys = o_keys;
     return FLOCKGPU_OK;
 }
 
