@@ -140,11 +140,25 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
             uint64_t v;
             if (staged) v = lds_head8(stage, in ? (uint32_t)(off[j] - b0) + phase : 0u, len > 8 ? 8u : len);
             else v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);  // len 0: nothing is read past the buffer
-            if (!(in && len <= 8 && lits_hit(v, len, lits))) continue;
+            const bool hit = in && len <= 8 && lits_hit(v, len, lits);
             if (kDense) {
-                const uint32_t idx = (uint32_t)key[it][j] - (uint32_t)wt.base;
-                if (idx < wt.range) direct[wt.off + idx] = (int32_t)r;  // (range 0: the layout pass declined the dense path)
-            } else if (!multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
+                // EVERY person of the window stores into its slot -- its row when the state filter keeps it, -1 otherwise -- so a window
+                // whose ids have no gaps (range = rows) needs no fill pass; the table layout came from the window's first and last id
+                // alone (q3_edge_layout_kernel), so "strictly increasing" is verified here: an id at or below its predecessor's, or
+                // outside [first, last], flags the call and the host takes the general path (one synchronisation, as before).
+                if (in) {
+                    const uint32_t idx = (uint32_t)key[it][j] - (uint32_t)wt.base;
+                    int32_t prev;
+                    if (j > 0) prev = key[it][j - 1];
+                    else {
+                        prev = __shfl_up(key[it][3], 1, 64);
+                        if (lane == 0 && r > tr.lo) prev = p_id[r - 1];   // (one lane per wave and iteration)
+                    }
+                    const bool ordered = r == tr.lo || key[it][j] > prev;
+                    if (idx < wt.range && ordered) direct[wt.off + idx] = hit ? (int32_t)r : -1;
+                    else if (wt.range) atomicOr(err, 1u);   // (range 0: the layout pass declined the dense path already)
+                }
+            } else if (hit && !multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
                 atomicOr(err, 1u);
             }
         }
@@ -280,23 +294,27 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
     if (!kEmit && lane == 0) counts[(size_t)tile * kWavesPerBlock + wave] = wave_total;
 }
 
-// Dense-path layout decided ON THE DEVICE from the exact per-window key statistics, so that the host does not wait for
-// them: window w gets a direct-address table over [min, max] when its p_id are strictly increasing and the range is at
-// most 8 x its rows + 1024 (the host sized the arena for exactly that bound).  One window that does not qualify
-// declines the whole call: every range becomes 0 (nothing is built, nothing joins) and info[1] = 0 tells the host,
-// at its single synchronisation, to run the general path instead.
-__global__ __launch_bounds__(kBlock) void q3_layout_kernel(const int32_t *__restrict__ stats, const int64_t *__restrict__ seg_off,
-                                                           int32_t n_win, WinTable *__restrict__ wins, uint64_t *__restrict__ info) {
+// Dense-path layout decided ON THE DEVICE, so that the host does not wait for it: window w gets a direct-address table over
+// [first p_id, last p_id] when that range is at least its rows and at most 8 x its rows + 1024 (the host sized the arena for exactly
+// that bound).  One window that does not qualify declines the whole call: every range becomes 0 (nothing is built, nothing joins) and
+// info[1] = 0 tells the host, at its single synchronisation, to run the general path instead.
+// First and last id: two loads per window instead of a pass over the column (segment_stats_kernel: 0.03 ms per 2e7 persons).  For strictly
+// increasing ids -- which q3_build_kernel verifies row by row while it builds -- they are the minimum and the maximum.  info[2] = 1
+// when some window's range exceeds its rows (gaps: slots no person writes, so the table is filled with -1 first).
+__global__ __launch_bounds__(kBlock) void q3_edge_layout_kernel(const int32_t *__restrict__ p_id, const int64_t *__restrict__ seg_off,
+                                                                int32_t n_win, WinTable *__restrict__ wins, uint64_t *__restrict__ info) {
     __shared__ uint64_t s_wave[kWavesPerBlock];
     __shared__ uint64_t s_carry;
-    int ok = 1;
+    int ok = 1, gaps = 0;
     for (int32_t w = threadIdx.x; w < n_win; w += kBlock) {
-        const int64_t rows = seg_off[2 * w + 1] - seg_off[2 * w];
-        if (rows <= 0) continue;
-        const int64_t range = (int64_t)stats[n_win + w] - (int64_t)stats[w] + 1;
-        if (!stats[2 * n_win + w] || range > 8 * rows + 1024) ok = 0;
+        const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
+        if (hi <= lo) continue;
+        const int64_t range = (int64_t)p_id[hi - 1] - (int64_t)p_id[lo] + 1;
+        if (range < hi - lo || range > 8 * (hi - lo) + 1024) ok = 0;
+        if (range != hi - lo) gaps = 1;
     }
     ok = __syncthreads_and(ok);
+    gaps = __syncthreads_or(gaps);
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -305,8 +323,8 @@ __global__ __launch_bounds__(kBlock) void q3_layout_kernel(const int32_t *__rest
         uint64_t range = 0;
         int32_t base = 0;
         if (ok && w < n_win && seg_off[2 * w + 1] > seg_off[2 * w]) {
-            base = stats[w];
-            range = (uint64_t)((int64_t)stats[n_win + w] - (int64_t)base + 1);
+            base = p_id[seg_off[2 * w]];
+            range = (uint64_t)((int64_t)p_id[seg_off[2 * w + 1] - 1] - (int64_t)base + 1);
         }
         const uint64_t incl = wave_incl_scan_u64(range);
         if (lane == 63) s_wave[wave] = incl;
@@ -321,16 +339,20 @@ __global__ __launch_bounds__(kBlock) void q3_layout_kernel(const int32_t *__rest
     if (threadIdx.x == 0) {
         info[0] = s_carry;  // entries in use
         info[1] = (uint64_t)ok;
+        info[2] = (uint64_t)(ok && gaps);
     }
 }
 
-// direct[0 .. info[0]) = -1; the grid covers the arena's bound, workgroups past the entries in use leave at once
+// direct[0 .. info[0]) = -1 when info[2] says some slot is written by no person; the grid covers the arena's bound, workgroups past
+// the entries in use (or all of them, without gaps) leave at once
 __global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restrict__ direct, const uint64_t *__restrict__ info) {
+    if (!info[2]) return;
     const uint64_t n = info[0] + 4;
-    const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
-    if (i + 4 <= n) *reinterpret_cast<int4 *>(direct + i) = make_int4(-1, -1, -1, -1);
-    else
-        for (uint64_t k = i; k < n; ++k) direct[k] = -1;
+    for (uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < n; i += (uint64_t)gridDim.x * kBlock * 4) {
+        if (i + 4 <= n) *reinterpret_cast<int4 *>(direct + i) = make_int4(-1, -1, -1, -1);
+        else
+            for (uint64_t k = i; k < n; ++k) direct[k] = -1;
+    }
 }
 
 }  // namespace
@@ -385,8 +407,6 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     int32_t *d_stats = nullptr, *h_stats = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
     FG_TRY(pinned_get_t(ctx, "q3.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
-    FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
-
     uint32_t *counts = nullptr;
     uint64_t *tile_base = nullptr;
     FG_TRY(arena_get_t(ctx, "q3.counts", (size_t)st_a.n_tiles * kWavesPerBlock + 4, &counts));
@@ -408,11 +428,13 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     // totals in ONE synchronisation (three before: statistics, pair counts, byte totals; ~60 us each at 1e8 events where
     // the kernels take 90 us).  After a call that did not qualify the statistics are read first, as before.
     // iterations of a person tile per build workgroup: all eight when the tiles alone fill the chip, else two
-    const int build_y_shift = st_p.n_tiles >= (int64_t)ctx->num_cus * 4 ? 3 : 1;
+    int build_y_shift = st_p.n_tiles >= (int64_t)ctx->num_cus * 4 ? 3 : 1;
+    if (const char *e = getenv("FLOCKGPU_Q3_YSHIFT")) build_y_shift = atoi(e);   // (experiment knob: iterations of a tile per workgroup = 1 << shift)
     std::vector<int64_t> &regime = ctx->host_i64["q3.dense_regime"];
     if (regime.empty()) regime.push_back(1);
     bool try_dense = n_win > 0;
-    if (try_dense && !regime[0]) {
+    if (try_dense && !regime[0]) {   // the previous call did not qualify: look before building (exact statistics, one more wait)
+        FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
         FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int w = 0; w < n_win && try_dense; ++w) {
@@ -431,14 +453,19 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)n_win, &d_wins));
         FG_TRY(arena_get_t(ctx, "q3.direct", bound_entries, &direct));
         FG_TRY(arena_get_t(ctx, "q3.flag_words", (size_t)st_a.n_tiles * kBlock, &flag_words));
-        FG_TRY(arena_get_t(ctx, "q3.layout_info", 2, &d_info));
-        FG_TRY(pinned_get_t(ctx, "q3.layout_info", 2, &h_info));
+        FG_TRY(arena_get_t(ctx, "q3.layout_info", 4, &d_info));
+        FG_TRY(pinned_get_t(ctx, "q3.layout_info", 4, &h_info));
+        uint32_t *h_err = nullptr;
+        FG_TRY(pinned_get_t(ctx, "q3.err", 4, &h_err));
+        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
         FG_TRY(arena_get_t(ctx, "q3.out_auction_row", bound_pairs + 1, &o_ar));
         FG_TRY(arena_get_t(ctx, "q3.out_person_row", bound_pairs + 1, &o_pr));
         FG_TRY(arena_get_t(ctx, "q3.out_a_id", bound_pairs + 1, &o_aid));
-        hipLaunchKernelGGL(q3_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_stats, st_p.seg_off, n_win, d_wins, d_info);
-        FG_TRY(check_launch(ctx, "q3_layout_kernel"));
-        hipLaunchKernelGGL(q3_fill_direct_kernel, dim3((unsigned)div_up((int64_t)bound_entries, kBlock * 4)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(q3_edge_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, person->p_id, st_p.seg_off, n_win, d_wins, d_info);
+        FG_TRY(check_launch(ctx, "q3_edge_layout_kernel"));
+        // (at most 4096 workgroups walk the entries: a grid over the arena's bound is 156 K workgroups at 2e7 persons, 35 us of
+        // dispatch even when every one of them leaves at once)
+        hipLaunchKernelGGL(q3_fill_direct_kernel, dim3((unsigned)std::min<int64_t>(div_up((int64_t)bound_entries, kBlock * 4), 4096)), dim3(kBlock), 0,
                            ctx->stream, direct, d_info);
         FG_TRY(check_launch(ctx, "q3_fill_direct_kernel"));
         if (st_p.n_tiles > 0) {
@@ -463,15 +490,28 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
         FG_TRY(check_launch(ctx, "q3_emit_dense_kernel"));
         const uint64_t *d_pairs = tile_base + st_a.n_tiles;
-        FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)bound_pairs, &g_text, d_pairs));
+        // The take of the three Utf8 columns is queued before the host knows the pair count: its grid and its scan cover the previous
+        // call's count + 1/8 rather than the bound (one pair per auction: 10x the pairs NEXMark's filters leave -- 27 us of scanning
+        // empty tiles at 1e8 events, where the whole call takes 150 us).  A call that turns out larger redoes the take (below).
+        std::vector<int64_t> &pairs_hint = ctx->host_i64["q3.pairs_hint"];
+        if (pairs_hint.empty()) pairs_hint.push_back(0);
+        const int64_t take_rows = pairs_hint[0] > 0 ? std::min<int64_t>((int64_t)bound_pairs, pairs_hint[0]) : (int64_t)bound_pairs;
+        FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, take_rows, &g_text, d_pairs));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*h_err) h_info[1] = 0;   // some window's ids are not strictly increasing: what was built is void
         regime[0] = h_info[1] ? 1 : 0;
         if (h_info[1]) {
             offs.assign(h_off, h_off + n_win + 1);
             n_pairs = (uint64_t)offs[n_win];
+            if ((int64_t)n_pairs > take_rows) {   // more pairs than the take was laid out for: once more, exactly
+                FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)n_pairs, &g_text, nullptr));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
             gather_utf8_multi_narrow(&g_text, (int64_t)n_pairs);
+            pairs_hint[0] = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 4096;
         } else {
             try_dense = false;  // some window's persons are unsorted, duplicated or too sparse: general path below
         }
