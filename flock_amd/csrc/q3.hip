@@ -39,7 +39,17 @@ struct Utf8Lits {  // literals of the `state = lit OR ...` chain, each <= 8 byte
 struct WinTable {
     int32_t base;     // min p_id of the window
     uint32_t range;   // max - min + 1 (0: the window has no persons)
-    uint64_t off;     // offset of the window's entries in the table arena
+    uint64_t off;     // offset of the window's entries in the table arena (windows with gaps in their ids)
+    // A window whose ids have NO gaps (range = rows: NEXMark's persons, any id-ordered dense source) needs no table at all: person
+    // p_id sits in row first_row + (p_id - base), and "the state filter keeps it" is one bit.  The bits are a plain bitmap over the
+    // rows of the window's person tiles (1 KiB per tile, bit = row - first tile's begin): the build kernel's lanes hold four
+    // consecutive rows each, eight lanes OR their nibbles into one word with three DPP steps and store it -- no atomics -- and the
+    // whole relation's bits (2.4 MB for 2e7 persons) stay in L2 under the probe, whose lookups no longer go to HBM (1.32x the
+    // algorithmic traffic with the 80 MB row table).
+    int32_t first_row;   // gapless: the window's first person row
+    int32_t first_tile;  // gapless: index of the window's first person tile (bit blocks are indexed by tile)
+    uint32_t lead;       // gapless: first_row - (first_row & ~3): where the window starts inside its first tile
+    uint32_t gapless;
 };
 
 // ---- build (both paths): flag-tile row layout, four consecutive persons per lane and iteration ---------------------
@@ -80,12 +90,13 @@ __device__ __forceinline__ uint64_t lds_head8(const uint32_t *w, uint32_t byte_p
     return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1));
 }
 
-template <bool kDense>
+template <bool kDense, bool kBits>
 __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restrict__ p_id,
                                                           const int32_t *__restrict__ state_off,
                                                           const uint8_t *__restrict__ state_data, int64_t n_rows, SegTiles st,
                                                           Utf8Lits lits, const WinTable *__restrict__ wins, int32_t *direct,
-                                                          uint64_t *tables, uint32_t cap, int32_t *next, uint32_t *err, int y_shift) {
+                                                          uint32_t *__restrict__ bits, uint64_t *tables, uint32_t cap, int32_t *next,
+                                                          uint32_t *err, int y_shift) {
     // A relation of a few hundred tiles (2e6 persons at 1e8 events: 245) leaves most CUs without a workgroup, and one
     // workgroup walks its tile's eight iterations alone: blockIdx.y splits the iterations of a tile over 8 >> y_shift
     // workgroups (rows are independent: nothing is produced per tile).
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
             for (uint32_t o = lane * 16; b1 > b0 && o < span; o += 64 * 16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(stage) + o) = src[o >> 4];
             __builtin_amdgcn_wave_barrier();
         }
+        uint32_t nib = 0;   // kBits: this lane's four filter bits at their place in the word of its 8-lane group
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r0 + j;
@@ -155,23 +167,37 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                         if (lane == 0 && r > tr.lo) prev = p_id[r - 1];   // (one lane per wave and iteration)
                     }
                     const bool ordered = r == tr.lo || key[it][j] > prev;
-                    if (idx < wt.range && ordered) direct[wt.off + idx] = hit ? (int32_t)r : -1;
-                    else if (wt.range) atomicOr(err, 1u);   // (range 0: the layout pass declined the dense path already)
+                    if (idx < wt.range && ordered) {
+                        if (!kBits) direct[wt.off + idx] = hit ? (int32_t)r : -1;
+                    } else if (wt.range) {
+                        atomicOr(err, 1u);   // (range 0: the layout pass declined the dense path already)
+                    }
                 }
+                if (kBits) nib |= (hit ? 1u : 0u) << (4 * (lane & 7) + j);
             } else if (hit && !multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
                 atomicOr(err, 1u);
             }
+        }
+        if (kDense && kBits) {   // 32 consecutive rows = 8 lanes = one word
+            nib |= (uint32_t)__shfl_xor((int)nib, 1, 64);
+            nib |= (uint32_t)__shfl_xor((int)nib, 2, 64);
+            nib |= (uint32_t)__shfl_xor((int)nib, 4, 64);
+            if ((lane & 7) == 0) bits[(size_t)blockIdx.x * (kFlagTile / 32) + wave * 64 + it * 8 + (lane >> 3)] = nib;
         }
         if (staged) __builtin_amdgcn_wave_barrier();  // the slot is rewritten by the next iteration
     }
 }
 
 // ---- dense probe: flags, then (auction_row, person_row, a_id) ----------------------------------------------------
+// kBits: every window is gapless (bit blocks, no row table); else: the row table for every window.  Two instances, not a branch per
+// window: both lookups unrolled over a lane's 32 rows in one kernel took 136 VGPRs (three waves per SIMD) and ran 20 % slower.
+template <bool kBits>
 __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__restrict__ seller,
                                                                const int32_t *__restrict__ category, int64_t n_rows,
                                                                int64_t category_lit, SegTiles st,
                                                                const WinTable *__restrict__ wins,
                                                                const int32_t *__restrict__ direct,
+                                                               const uint32_t *__restrict__ bits,
                                                                uint32_t *__restrict__ flag_words,
                                                                uint32_t *__restrict__ counts) {
     int32_t tile = (int32_t)blockIdx.x;
@@ -189,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
         if (next < st.n_tiles) trn = locate_tile(st, next, kFlagTile);
         const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
         const int32_t *tab = direct + wt.off;
+        const uint32_t *wbits = bits + (size_t)wt.first_tile * (kFlagTile / 32);
         uint32_t flags = 0;
 #pragma unroll
         for (int it = 0; it < kFlagIters; ++it)
@@ -199,7 +226,13 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
                 const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit && idx < wt.range;
                 // unconditional load from a clamped index: a load under a per-row branch is waited for before the
                 // next row is looked at, i.e. one memory round trip per surviving row instead of one per tile
-                const bool f = need & (tab[need ? idx : 0u] >= 0);
+                bool f;
+                if (kBits) {   // the person's bit: tile and position from its row offset inside the window
+                    const uint32_t rel_w = need ? wt.lead + idx : 0u;
+                    f = need & ((wbits[rel_w >> 5] >> (rel_w & 31u)) & 1u);
+                } else {
+                    f = need & (tab[need ? idx : 0u] >= 0);
+                }
                 flags |= (f ? 1u : 0u) << (it * 4 + j);
             }
         store_flags_and_counts(flags, tile, flag_words, counts);
@@ -209,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
     }
 }
 
+template <bool kBits>
 __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__restrict__ seller,
                                                                const int32_t *__restrict__ a_id, SegTiles st,
                                                                const uint32_t *__restrict__ flag_words,
@@ -231,7 +265,8 @@ __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__
     for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
         const int64_t r = tr.tile_begin + s_list[i];
         out_auction_row[base + i] = (int32_t)r;
-        out_person_row[base + i] = direct[wt.off + (uint32_t)(seller[r] - wt.base)];
+        const uint32_t idx = (uint32_t)(seller[r] - wt.base);
+        out_person_row[base + i] = kBits ? wt.first_row + (int32_t)idx : direct[wt.off + idx];
         out_a_id[base + i] = a_id[r];
     }
 }
@@ -302,7 +337,8 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
 // increasing ids -- which q3_build_kernel verifies row by row while it builds -- they are the minimum and the maximum.  info[2] = 1
 // when some window's range exceeds its rows (gaps: slots no person writes, so the table is filled with -1 first).
 __global__ __launch_bounds__(kBlock) void q3_edge_layout_kernel(const int32_t *__restrict__ p_id, const int64_t *__restrict__ seg_off,
-                                                                int32_t n_win, WinTable *__restrict__ wins, uint64_t *__restrict__ info) {
+                                                                const int32_t *__restrict__ tile_first, int32_t n_win, int32_t bits_mode,
+                                                                WinTable *__restrict__ wins, uint64_t *__restrict__ info) {
     __shared__ uint64_t s_wave[kWavesPerBlock];
     __shared__ uint64_t s_carry;
     int ok = 1, gaps = 0;
@@ -315,31 +351,39 @@ __global__ __launch_bounds__(kBlock) void q3_edge_layout_kernel(const int32_t *_
     }
     ok = __syncthreads_and(ok);
     gaps = __syncthreads_or(gaps);
+    const int qualifies = ok;
+    if (bits_mode && gaps) ok = 0;   // the bit-block kernels were launched, but some window needs the row table: declined, info[2] says why
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int32_t w0 = 0; w0 < n_win; w0 += kBlock) {
         const int32_t w = w0 + (int32_t)threadIdx.x;
-        uint64_t range = 0;
+        uint64_t range = 0, entries = 0;
         int32_t base = 0;
+        int64_t lo = 0;
+        bool gapless = false;
         if (ok && w < n_win && seg_off[2 * w + 1] > seg_off[2 * w]) {
-            base = p_id[seg_off[2 * w]];
+            lo = seg_off[2 * w];
+            base = p_id[lo];
             range = (uint64_t)((int64_t)p_id[seg_off[2 * w + 1] - 1] - (int64_t)base + 1);
+            gapless = range == (uint64_t)(seg_off[2 * w + 1] - lo);
+            entries = bits_mode ? 0 : range;
         }
-        const uint64_t incl = wave_incl_scan_u64(range);
+        const uint64_t incl = wave_incl_scan_u64(entries);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint64_t off = s_carry + incl - range;
+        uint64_t off = s_carry + incl - entries;
         for (int v = 0; v < wave; ++v) off += s_wave[v];
-        if (w < n_win) wins[w] = WinTable{base, (uint32_t)range, off};
+        if (w < n_win)
+            wins[w] = WinTable{base, (uint32_t)range, off, (int32_t)lo, gapless ? tile_first[w] : 0, (uint32_t)(lo - (lo & ~int64_t(3))), gapless ? 1u : 0u};
         __syncthreads();
-        if (threadIdx.x == kBlock - 1) s_carry = off + range;
+        if (threadIdx.x == kBlock - 1) s_carry = off + entries;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         info[0] = s_carry;  // entries in use
         info[1] = (uint64_t)ok;
-        info[2] = (uint64_t)(ok && gaps);
+        info[2] = (uint64_t)(qualifies && gaps);   // table mode: fill first; bits mode: declined only because of gaps
     }
 }
 
@@ -431,7 +475,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     int build_y_shift = st_p.n_tiles >= (int64_t)ctx->num_cus * 4 ? 3 : 1;
     if (const char *e = getenv("FLOCKGPU_Q3_YSHIFT")) build_y_shift = atoi(e);   // (experiment knob: iterations of a tile per workgroup = 1 << shift)
     std::vector<int64_t> &regime = ctx->host_i64["q3.dense_regime"];
-    if (regime.empty()) regime.push_back(1);
+    // 2: dense, every window gapless last time (bit blocks, no row table) -- also where a ctx starts; 1: dense with the row table;
+    // 0: the last call took the general path
+    if (regime.empty()) regime.push_back(2);
     bool try_dense = n_win > 0;
     if (try_dense && !regime[0]) {   // the previous call did not qualify: look before building (exact statistics, one more wait)
         FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
@@ -443,8 +489,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             if (!h_stats[2 * n_win + w] || range > 8 * (pe[w] - pb[w]) + 1024) try_dense = false;
         }
     }
-    if (try_dense) {
-        const size_t bound_entries = (size_t)8 * (size_t)person->rows + (size_t)1024 * n_win + 8;
+    bool bits_mode = regime[0] != 1;
+    for (bool done = false; try_dense && !done;) {
+        const size_t bound_entries = bits_mode ? 8 : (size_t)8 * (size_t)person->rows + (size_t)1024 * n_win + 8;
         const size_t bound_pairs = (size_t)auction->rows;  // one person per key: an auction joins at most one
         WinTable *d_wins = nullptr;
         int32_t *direct = nullptr;
@@ -452,6 +499,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         uint64_t *d_info = nullptr, *h_info = nullptr;
         FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)n_win, &d_wins));
         FG_TRY(arena_get_t(ctx, "q3.direct", bound_entries, &direct));
+        uint32_t *bits = nullptr;   // one 1 KiB block per person tile (windows without gaps)
+        FG_TRY(arena_get_t(ctx, "q3.state_bits", (size_t)std::max(st_p.n_tiles, 1) * (kFlagTile / 32) + 4, &bits));
         FG_TRY(arena_get_t(ctx, "q3.flag_words", (size_t)st_a.n_tiles * kBlock, &flag_words));
         FG_TRY(arena_get_t(ctx, "q3.layout_info", 4, &d_info));
         FG_TRY(pinned_get_t(ctx, "q3.layout_info", 4, &h_info));
@@ -461,31 +510,34 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(arena_get_t(ctx, "q3.out_auction_row", bound_pairs + 1, &o_ar));
         FG_TRY(arena_get_t(ctx, "q3.out_person_row", bound_pairs + 1, &o_pr));
         FG_TRY(arena_get_t(ctx, "q3.out_a_id", bound_pairs + 1, &o_aid));
-        hipLaunchKernelGGL(q3_edge_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, person->p_id, st_p.seg_off, n_win, d_wins, d_info);
+        hipLaunchKernelGGL(q3_edge_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, person->p_id, st_p.seg_off, st_p.tile_first, n_win,
+                           bits_mode ? 1 : 0, d_wins, d_info);
         FG_TRY(check_launch(ctx, "q3_edge_layout_kernel"));
         // (at most 4096 workgroups walk the entries: a grid over the arena's bound is 156 K workgroups at 2e7 persons, 35 us of
         // dispatch even when every one of them leaves at once)
-        hipLaunchKernelGGL(q3_fill_direct_kernel, dim3((unsigned)std::min<int64_t>(div_up((int64_t)bound_entries, kBlock * 4), 4096)), dim3(kBlock), 0,
-                           ctx->stream, direct, d_info);
-        FG_TRY(check_launch(ctx, "q3_fill_direct_kernel"));
+        if (!bits_mode) {
+            hipLaunchKernelGGL(q3_fill_direct_kernel, dim3((unsigned)std::min<int64_t>(div_up((int64_t)bound_entries, kBlock * 4), 4096)), dim3(kBlock), 0,
+                               ctx->stream, direct, d_info);
+            FG_TRY(check_launch(ctx, "q3_fill_direct_kernel"));
+        }
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
-            hipLaunchKernelGGL(q3_build_kernel<true>, dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
-                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct,
+            hipLaunchKernelGGL((bits_mode ? q3_build_kernel<true, true> : q3_build_kernel<true, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
+                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct, bits,
                                nullptr, 0u, nullptr, d_err, build_y_shift);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
-            hipLaunchKernelGGL(q3_probe_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
-                               auction->category, auction->rows, category_lit, st_a, d_wins, direct, flag_words, counts);
+            hipLaunchKernelGGL(bits_mode ? q3_probe_flag_kernel<true> : q3_probe_flag_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
+                               auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
         }
         FG_TRY(check_launch(ctx, "q3_probe_flag_kernel"));
         FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
         if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_emit_dense_kernel");
-            hipLaunchKernelGGL(q3_emit_dense_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
+            hipLaunchKernelGGL(bits_mode ? q3_emit_dense_kernel<true> : q3_emit_dense_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller,
                                auction->a_id, st_a, flag_words, counts, tile_base, d_wins, direct, o_ar, o_pr, o_aid);
         }
         FG_TRY(check_launch(ctx, "q3_emit_dense_kernel"));
@@ -498,12 +550,13 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         const int64_t take_rows = pairs_hint[0] > 0 ? std::min<int64_t>((int64_t)bound_pairs, pairs_hint[0]) : (int64_t)bound_pairs;
         FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, take_rows, &g_text, d_pairs));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (*h_err) h_info[1] = 0;   // some window's ids are not strictly increasing: what was built is void
-        regime[0] = h_info[1] ? 1 : 0;
         if (h_info[1]) {
+            done = true;
+            regime[0] = bits_mode ? 2 : 1;
             offs.assign(h_off, h_off + n_win + 1);
             n_pairs = (uint64_t)offs[n_win];
             if ((int64_t)n_pairs > take_rows) {   // more pairs than the take was laid out for: once more, exactly
@@ -512,6 +565,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             }
             gather_utf8_multi_narrow(&g_text, (int64_t)n_pairs);
             pairs_hint[0] = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 4096;
+        } else if (bits_mode && !*h_err && h_info[2]) {
+            bits_mode = false;  // the windows qualify but some have gaps in their ids: once more, with the row table
         } else {
             try_dense = false;  // some window's persons are unsorted, duplicated or too sparse: general path below
         }
@@ -529,8 +584,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_build_kernel");
-            hipLaunchKernelGGL(q3_build_kernel<false>, dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
-                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr,
+            hipLaunchKernelGGL((q3_build_kernel<false, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
+                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, nullptr,
                                tables, cap, next, d_err, build_y_shift);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
