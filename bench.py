@@ -65,6 +65,7 @@ def parse():
                     help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all "
                          "inside libflockgpu; auto = windows at N = 1, exchange at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
+    ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
     return ap.parse_args()
@@ -650,6 +651,24 @@ def plan_collect_pcie(gpu, eps, steps):
                     "synchronisation per collect"}
 
 
+def plan_collect_pcie_both(gpu, eps, steps):
+    """The same measurement twice: in this process (after every other entry: ~16 GB of host arrays, 64-thread CPU baselines, Arrow's
+    and torch's thread pools behind it) and in a fresh process -- what a function instance of the reference is.  The staging threads'
+    memcpy out of pageable memory is what differs (measured 4.8 vs 1.96 ms per window on one box; none of the other side entries alone
+    reproduces it: tools/gpu_pcie_check.sh)."""
+    import subprocess
+    e = plan_collect_pcie(gpu, eps, steps)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--only-plan-collect", "--eps", str(eps), "--steps", str(max(steps, 5))],
+                           capture_output=True, text=True, timeout=300)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        f = json.loads(line)
+        e["fresh_process"] = {k: f[k] for k in ("value", "ms_per_step", "roofline")}
+    except Exception as ex:   # a side measurement must never hide the headline
+        e["fresh_process"] = {"error": repr(ex)}
+    return e
+
+
 def main():
     args = parse()
     import torch
@@ -660,6 +679,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: flock_amd has no CPU path")
     torch.cuda.set_device(local)
+    if args.only_plan_collect:
+        from flock_amd import GpuContext
+        print(json.dumps(plan_collect_pcie(GpuContext(local), args.eps, max(args.steps, 5))))
+        return
     mode = args.mode if args.mode != "auto" else ("exchange" if world > 1 else "windows")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -772,7 +795,7 @@ def main():
                           ("payload_next", lambda: payload_side(ctx, steps2, args.no_cpu)),
                           ("ysb_next", lambda: ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)),
                           ("q5_pcie_inclusive", lambda: pcie_inclusive_q5(ctx, args.eps)),
-                          ("plan_collect_pcie", lambda: plan_collect_pcie(ctx, args.eps, steps2))):
+                          ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2))):
             try:
                 also[label] = fn()
             except Exception as e:
