@@ -142,11 +142,12 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
                                                                  SegTiles st, const WinBitmap *__restrict__ wins,
                                                                  const uint32_t *__restrict__ bitmaps,
                                                                  uint32_t *__restrict__ flag_words,
-                                                                 uint32_t *__restrict__ counts) {
+                                                                 uint32_t *__restrict__ counts, uint32_t *err) {
     int32_t tile = (int32_t)blockIdx.x;
     if (tile >= st.n_tiles) return;
     TileRange tr = locate_tile(st, tile, kFlagTile);
     const int32_t rel0 = flag_rel0();
+    const int lane = lane_id();
 #pragma unroll 1
     for (;;) {  // tiles b, b + G, ... with the next descriptor requested early (scan.hpp)
         int32_t a[kFlagIters][4];
@@ -164,7 +165,20 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
             for (int j = 0; j < 4; ++j) {
                 const int32_t rel = rel0 + it * 256 + j;
                 const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
-                const bool in = rel >= rel_lo && rel < rel_hi && idx < wb.n_bits;
+                const bool row_in = rel >= rel_lo && rel < rel_hi;
+                const bool in = row_in && idx < wb.n_bits;
+                // The layout came from the window's first and last id alone (q8_edge_layout_kernel): that they are the minimum and the
+                // maximum, and that every row is already DISTINCT, holds when the ids are strictly increasing -- verified here, row against
+                // predecessor; a violation voids the call (general path), reported with the results in the same synchronisation.
+                if (row_in && wb.n_bits) {
+                    int32_t prev;
+                    if (j > 0) prev = a[it][j - 1];
+                    else {
+                        prev = __shfl_up(a[it][3], 1, 64);
+                        if (lane == 0 && rel > rel_lo) prev = p_id[tr.tile_begin + rel - 1];   // (one lane per wave and iteration)
+                    }
+                    if (!(rel == rel_lo || a[it][j] > prev) || idx >= wb.n_bits) atomicOr(err, 1u);
+                }
                 // unconditional load from a clamped index: loads under per-row branches queue behind each other
                 const bool f = in & ((gbm[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);
                 flags |= (f ? 1u : 0u) << (it * 4 + j);
@@ -265,20 +279,21 @@ __global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
-// Dense-path layout decided on the device (as q3.hip's q3_layout_kernel): window w gets a bitmap over
-// [min p_id & ~31, max p_id] when its p_id are strictly increasing and the bitmap has at most 64 x rows + 4096 bits (the
-// bound the host sized the arena for).  A window that does not qualify declines the whole call: every n_bits becomes
-// 0 (no seller is recorded, no person flagged) and info[1] = 0 sends the host to the general path.
-__global__ __launch_bounds__(kBlock) void q8_layout_kernel(const int32_t *__restrict__ stats, const int64_t *__restrict__ seg_off,
-                                                           int32_t n_win, WinBitmap *__restrict__ wins, uint64_t *__restrict__ info) {
+// Dense-path layout decided on the device: window w gets a bitmap over [first p_id & ~31, last p_id] when it has at least as many
+// bits as rows and at most 64 x rows + 4096 (the bound the host sized the arena for).  A window that does not qualify declines the
+// whole call: every n_bits becomes 0 (no seller is recorded, no person flagged) and info[1] = 0 sends the host to the general path.
+// First and last id: two loads per window instead of segment_stats_kernel's pass over the column:
+// 0.033 ms per 2e7 persons); q8_persons_flag_kernel verifies that the ids are strictly increasing, which makes them minimum and maximum.
+__global__ __launch_bounds__(kBlock) void q8_edge_layout_kernel(const int32_t *__restrict__ p_id, const int64_t *__restrict__ seg_off,
+                                                                int32_t n_win, WinBitmap *__restrict__ wins, uint64_t *__restrict__ info) {
     __shared__ uint64_t s_wave[kWavesPerBlock];
     __shared__ uint64_t s_carry;
     int ok = 1;
     for (int32_t w = threadIdx.x; w < n_win; w += kBlock) {
-        const int64_t rows = seg_off[2 * w + 1] - seg_off[2 * w];
-        if (rows <= 0) continue;
-        const int64_t base = (int64_t)stats[w] & ~int64_t(31), bits = (int64_t)stats[n_win + w] - base + 1;
-        if (!stats[2 * n_win + w] || bits > 64 * rows + 4096 || bits >= (int64_t(1) << 31)) ok = 0;
+        const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
+        if (hi <= lo) continue;
+        const int64_t base = (int64_t)p_id[lo] & ~int64_t(31), bits = (int64_t)p_id[hi - 1] - base + 1;
+        if (bits < hi - lo || bits > 64 * (hi - lo) + 4096 || bits >= (int64_t(1) << 31)) ok = 0;
     }
     ok = __syncthreads_and(ok);
     if (threadIdx.x == 0) s_carry = 0;
@@ -288,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void q8_layout_kernel(const int32_t *__rest
         const int32_t w = w0 + (int32_t)threadIdx.x;
         int64_t base = 0, bits = 0;
         if (ok && w < n_win && seg_off[2 * w + 1] > seg_off[2 * w]) {
-            base = (int64_t)stats[w] & ~int64_t(31);
-            bits = (int64_t)stats[n_win + w] - base + 1;
+            base = (int64_t)p_id[seg_off[2 * w]] & ~int64_t(31);
+            bits = (int64_t)p_id[seg_off[2 * w + 1] - 1] - base + 1;
         }
         const uint64_t words = (uint64_t)((bits + 31) >> 5);
         const uint64_t incl = wave_incl_scan_u64(words);
@@ -308,13 +323,15 @@ __global__ __launch_bounds__(kBlock) void q8_layout_kernel(const int32_t *__rest
     }
 }
 
-// bitmaps[0 .. info[0] + 4) = 0; the grid covers the arena's bound
+// bitmaps[0 .. info[0] + 4) = 0 (a bounded grid walks the words in use: a grid over the arena's bound is tens of thousands of
+// workgroups that leave at once)
 __global__ __launch_bounds__(kBlock) void q8_zero_bitmaps_kernel(uint32_t *__restrict__ bitmaps, const uint64_t *__restrict__ info) {
     const uint64_t n = info[0] + 4;
-    const uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
-    if (i + 4 <= n) *reinterpret_cast<uint4 *>(bitmaps + i) = make_uint4(0, 0, 0, 0);
-    else
-        for (uint64_t k = i; k < n; ++k) bitmaps[k] = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < n; i += (uint64_t)gridDim.x * kBlock * 4) {
+        if (i + 4 <= n) *reinterpret_cast<uint4 *>(bitmaps + i) = make_uint4(0, 0, 0, 0);
+        else
+            for (uint64_t k = i; k < n; ++k) bitmaps[k] = 0;
+    }
 }
 
 }  // namespace
@@ -359,8 +376,6 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     int32_t *d_stats = nullptr, *h_stats = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &d_stats));
     FG_TRY(pinned_get_t(ctx, "q8.stats", (size_t)3 * std::max(n_win, 1), &h_stats));
-    FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
-
     uint32_t *flag_words = nullptr, *counts = nullptr;
     uint64_t *tile_base = nullptr;
     FG_TRY(arena_get_t(ctx, "q8.flag_words", (size_t)st_p.n_tiles * kBlock, &flag_words));
@@ -381,7 +396,8 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     std::vector<int64_t> &regime = ctx->host_i64["q8.dense_regime"];
     if (regime.empty()) regime.push_back(1);
     bool try_dense = n_win > 0;
-    if (try_dense && !regime[0]) {
+    if (try_dense && !regime[0]) {   // the previous call did not qualify: look before building (exact statistics, one more wait)
+        FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
         FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int w = 0; w < n_win && try_dense; ++w) {
@@ -399,9 +415,13 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         FG_TRY(arena_get_t(ctx, "q8.bitmaps", bound_words, &bitmaps));
         FG_TRY(arena_get_t(ctx, "q8.layout_info", 2, &d_info));
         FG_TRY(pinned_get_t(ctx, "q8.layout_info", 2, &h_info));
-        hipLaunchKernelGGL(q8_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_stats, st_p.seg_off, n_win, d_wins, d_info);
-        FG_TRY(check_launch(ctx, "q8_layout_kernel"));
-        hipLaunchKernelGGL(q8_zero_bitmaps_kernel, dim3((unsigned)div_up((int64_t)bound_words, kBlock * 4)), dim3(kBlock), 0,
+        uint32_t *d_verr = nullptr, *h_verr = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.order_err", 4, &d_verr));
+        FG_TRY(pinned_get_t(ctx, "q8.order_err", 4, &h_verr));
+        FG_HIP(ctx, hipMemsetAsync(d_verr, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(q8_edge_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, person->p_id, st_p.seg_off, n_win, d_wins, d_info);
+        FG_TRY(check_launch(ctx, "q8_edge_layout_kernel"));
+        hipLaunchKernelGGL(q8_zero_bitmaps_kernel, dim3((unsigned)std::min<int64_t>(div_up((int64_t)bound_words, kBlock * 4), 4096)), dim3(kBlock), 0,
                            ctx->stream, bitmaps, d_info);
         FG_TRY(check_launch(ctx, "q8_zero_bitmaps_kernel"));
         if (st_a.n_tiles > 0) {
@@ -414,20 +434,31 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
             LaunchScope ls(ctx, "q8_persons_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_p.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
             hipLaunchKernelGGL(q8_persons_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows,
-                               st_p, d_wins, bitmaps, flag_words, counts);
+                               st_p, d_wins, bitmaps, flag_words, counts, d_verr);
         }
         FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
         FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
         FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
-        FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, out_cap - 16, &g_name, tile_base + st_p.n_tiles));
+        // (the take of the names is laid out for the previous call's row count + 1/8, not for "every person": q3.hip does the same)
+        std::vector<int64_t> &rows_hint = ctx->host_i64["q8.rows_hint"];
+        if (rows_hint.empty()) rows_hint.push_back(0);
+        const int64_t take_rows = rows_hint[0] > 0 ? std::min<int64_t>(out_cap - 16, rows_hint[0]) : out_cap - 16;
+        FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, take_rows, &g_name, tile_base + st_p.n_tiles));
         FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_verr, d_verr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*h_verr) h_info[1] = 0;   // some window's ids are not strictly increasing: the bitmaps' bounds and the DISTINCT shortcut are void
         regime[0] = h_info[1] ? 1 : 0;
         if (h_info[1]) {
             offs.assign(h_off, h_off + n_win + 1);
             n_out = offs[n_win];
+            if (n_out > take_rows) {   // more rows than the take was laid out for: once more, exactly
+                FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, n_out, &g_name, nullptr));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
             gather_utf8_narrow(&g_name, n_out);
+            rows_hint[0] = n_out + n_out / 8 + 4096;
         } else {
             try_dense = false;
         }
