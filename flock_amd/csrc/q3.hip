@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
         if ((it >> y_shift) != (int)blockIdx.y) continue;  // (block-uniform)
         const int64_t r0 = wbase + it * 256;
         const int64_t chunk0 = r0 - lane * 4;               // the wave's first row of this iteration
+        const int32_t before = kDense ? p_id[chunk0 > 0 ? chunk0 - 1 : 0] : 0;   // the id in front of the chunk (one address per wave; order check)
         int32_t off[5];
         const bool inside = off_aligned && chunk0 >= 0 && chunk0 + 256 < n_rows;  // (wave-uniform) all 257 offsets exist
         if (inside) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                     if (j > 0) prev = key[it][j - 1];
                     else {
                         prev = __shfl_up(key[it][3], 1, 64);
-                        if (lane == 0 && r > tr.lo) prev = p_id[r - 1];   // (one lane per wave and iteration)
+                        if (lane == 0) prev = before;
                     }
                     const bool ordered = r == tr.lo || key[it][j] > prev;
                     if (idx < wt.range && ordered) {

@@ -152,6 +152,13 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
     for (;;) {  // tiles b, b + G, ... with the next descriptor requested early (scan.hpp)
         int32_t a[kFlagIters][4];
         load_flag_tile(p_id, n_rows, tr, a);
+        // the id in front of each of the wave's eight 256-row chunks (one address per wave; requested with the tile, not under a branch later)
+        int32_t before[kFlagIters];
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it) {
+            const int64_t r = tr.tile_begin + (rel0 - lane * 4) + it * 256 - 1;
+            before[it] = p_id[r < 0 ? 0 : r];
+        }
         const WinBitmap wb = wins[tr.seg];
         const int32_t next = tile + (int32_t)gridDim.x;
         TileRange trn = tr;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
                     if (j > 0) prev = a[it][j - 1];
                     else {
                         prev = __shfl_up(a[it][3], 1, 64);
-                        if (lane == 0 && rel > rel_lo) prev = p_id[tr.tile_begin + rel - 1];   // (one lane per wave and iteration)
+                        if (lane == 0) prev = before[it];
                     }
                     if (!(rel == rel_lo || a[it][j] > prev) || idx >= wb.n_bits) atomicOr(err, 1u);
                 }
