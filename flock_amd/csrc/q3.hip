@@ -243,6 +243,60 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
     }
 }
 
+// The same pass for a relation of a few hundred tiles (6e6 auctions at 1e8 events: 733 tiles, 2.9 per CU -- one thin wave of workgroups
+// whose eight serial iterations each wait for a seller load, then for the lookup behind it: 17.8 us for 48 MB, 34 % of the roofline).
+// Sixteen waves per tile instead of four: quarter q = threadIdx.x / 256 of the workgroup takes iterations 2q and 2q + 1 of the
+// flag-tile layout, i.e. byte q of every lane's flag word (a plain byte store), and the four quarters' wave counts meet in LDS.
+template <bool kBits>
+__global__ __launch_bounds__(4 * kBlock) void q3_probe_flag_small_kernel(const int32_t *__restrict__ seller,
+                                                                         const int32_t *__restrict__ category, int64_t n_rows,
+                                                                         int64_t category_lit, SegTiles st,
+                                                                         const WinTable *__restrict__ wins,
+                                                                         const int32_t *__restrict__ direct,
+                                                                         const uint32_t *__restrict__ bits,
+                                                                         uint32_t *__restrict__ flag_words,
+                                                                         uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_cnt[4][kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int quarter = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1), wave = t >> 6, lane = t & 63;
+    const int32_t rel0 = wave * kFlagWaveRows + lane * 4;
+    const WinTable wt = wins[tr.seg];
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const int32_t *tab = direct + wt.off;
+    const uint32_t *wbits = bits + (size_t)wt.first_tile * (kFlagTile / 32);
+    int32_t sv[2][4], cv[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t r0 = tr.tile_begin + rel0 + (quarter * 2 + k) * 256;
+        load4_i32(seller, r0, n_rows, sv[k]);
+        load4_i32(category, r0, n_rows, cv[k]);
+    }
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + (quarter * 2 + k) * 256 + j;
+            const uint32_t idx = (uint32_t)sv[k][j] - (uint32_t)wt.base;
+            const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)cv[k][j] == category_lit && idx < wt.range;
+            bool f;
+            if (kBits) {
+                const uint32_t rel_w = need ? wt.lead + idx : 0u;
+                f = need & ((wbits[rel_w >> 5] >> (rel_w & 31u)) & 1u);
+            } else {
+                f = need & (tab[need ? idx : 0u] >= 0);
+            }
+            flags |= (f ? 1u : 0u) << (k * 4 + j);
+        }
+    reinterpret_cast<uint8_t *>(flag_words)[((size_t)tile * kBlock + t) * 4 + quarter] = (uint8_t)flags;   // bits 8q .. 8q + 7 of the lane's word
+    const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
+    if (lane == 63) s_cnt[quarter][wave] = incl;
+    __syncthreads();
+    if (threadIdx.x < kWavesPerBlock)
+        counts[(size_t)tile * kWavesPerBlock + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+}
+
 template <bool kBits>
 __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__restrict__ seller,
                                                                const int32_t *__restrict__ a_id, SegTiles st,
@@ -528,7 +582,11 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
                                nullptr, 0u, nullptr, d_err, build_y_shift);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
-        if (st_a.n_tiles > 0) {
+        if (st_a.n_tiles > 0 && st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
+            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            hipLaunchKernelGGL(bits_mode ? q3_probe_flag_small_kernel<true> : q3_probe_flag_small_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(4 * kBlock), 0,
+                               ctx->stream, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
+        } else if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
             hipLaunchKernelGGL(bits_mode ? q3_probe_flag_kernel<true> : q3_probe_flag_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller,
