@@ -264,6 +264,7 @@ struct XCol {  // a column to shuffle: fixed width (4 or 8 bytes per row) or Utf
     const void *values = nullptr;
     const int32_t *offsets = nullptr;  // Utf8 only
     int width = 4;                     // 4 | 8; ignored for Utf8
+    bool indirect = false;             // the ORIGINAL column: row i of the relation being shuffled is its row base_rows[i]
     bool utf8() const { return offsets != nullptr; }
 };
 struct XRecv {
@@ -274,9 +275,14 @@ struct XRecv {
 
 // RepartitionExec Hash([key], n_ranks) for one relation: every row of every window goes to rank part(key).
 // `name` keys the arena buffers (they must outlive the operator that consumes the result).
+// `base_rows` (may be null): the relation is a row selection of a larger one (a filter ran first); columns marked `indirect` are taken
+// straight from the original columns through it -- their values are never compacted on their own, only taken in send order.
 int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &name, const std::vector<XCol> &cols, int key_col, int64_t rows,
-                      const flockgpu_windows *win, XRecv *out) {
+                      const flockgpu_windows *win, XRecv *out, const int32_t *base_rows = nullptr) {
     const int n = c->n, n_win = win->n_windows;
+    if (cols[(size_t)key_col].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: the key column must be given compacted");
+    for (auto &col : cols)
+        if (col.indirect && !base_rows) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: an indirect column without the row selection");
     // ---- partition, send-order gathers and the per-destination Utf8 byte counts are queued back to back; the host waits ONCE
     // for the group offsets, the Utf8 totals and the run bytes together.  (No wait for the pinned staging of `upload`: the previous
     // call that used these names ended with the operator's own synchronisation.)
@@ -289,7 +295,7 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     PartPayload payload;
     std::vector<int> payload_of(cols.size(), -1);
     for (size_t i = 0; i < cols.size(); ++i) {
-        if (cols[i].utf8() || cols[i].width != 4 || payload.n == 4) continue;
+        if (cols[i].utf8() || cols[i].width != 4 || payload.n == 4 || cols[i].indirect) continue;
         void *p = nullptr;
         FG_TRY(arena_get(ctx, (name + ".send" + std::to_string(i)).c_str(), (size_t)covered * 4 + 16, &p));
         payload.src[payload.n] = static_cast<const int32_t *>(cols[i].values);
@@ -300,6 +306,16 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     for (size_t i = 0; i < cols.size(); ++i) payload.skip_rows = payload.skip_rows && payload_of[i] >= 0;
     FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send, &payload,
                                   (name + ".part").c_str()));
+    const int32_t *src_rows = part_rows;   // rows of the columns' own row space, in send order
+    bool any_indirect = false;
+    for (auto &col : cols) any_indirect = any_indirect || col.indirect;
+    if (any_indirect) {
+        int32_t *comp = nullptr;
+        FG_TRY(arena_get_t(ctx, (name + ".comp_rows").c_str(), (size_t)n_send + 4, &comp));
+        FG_TRY(gather_i32(ctx, base_rows, part_rows, n_send, comp));
+        src_rows = comp;
+    }
+    auto rows_of = [&](const XCol &col) { return col.indirect ? src_rows : part_rows; };
     int64_t *d_run_start = nullptr;
     FG_TRY(arena_get_t(ctx, (name + ".run_start").c_str(), (size_t)n + 2, &d_run_start));
     hipLaunchKernelGGL(pick_run_starts_kernel, dim3(1), dim3(64), 0, ctx->stream, d_group_off, n_win, n, d_run_start);
@@ -320,8 +336,11 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     Utf8MultiGather g_send, g_recv;
     if (!ucols.empty()) {
         flockgpu_utf8 srcs[4];
-        for (size_t j = 0; j < ucols.size(); ++j) srcs[j] = flockgpu_utf8{cols[ucols[j]].offsets, static_cast<const uint8_t *>(cols[ucols[j]].values)};
-        FG_TRY(gather_utf8_multi_begin(ctx, (name + ".sendu").c_str(), srcs, (int)ucols.size(), part_rows, n_send, &g_send));
+        for (size_t j = 0; j < ucols.size(); ++j) {
+            srcs[j] = flockgpu_utf8{cols[ucols[j]].offsets, static_cast<const uint8_t *>(cols[ucols[j]].values)};
+            if (cols[ucols[j]].indirect != cols[ucols[0]].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: Utf8 columns of one relation must share their row space");
+        }
+        FG_TRY(gather_utf8_multi_begin(ctx, (name + ".sendu").c_str(), srcs, (int)ucols.size(), rows_of(cols[ucols[0]]), n_send, &g_send));
     }
     for (size_t i = 0; i < cols.size(); ++i) {
         const XCol &col = cols[i];
@@ -333,8 +352,8 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
             FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
             if (n_send > 0) {
                 LaunchScope ls(ctx, "run_bytes_kernel");
-                hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, part_rows, d_run_start,
-                                   sent[i].d_run_bytes);
+                hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, rows_of(col),
+                                   d_run_start, sent[i].d_run_bytes);
             }
             FG_TRY(check_launch(ctx, "run_bytes_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -343,8 +362,8 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         } else {
             void *p = nullptr;
             FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
-            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), part_rows, n_send, static_cast<int32_t *>(p)));
-            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), part_rows, n_send, static_cast<int64_t *>(p)));
+            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), rows_of(col), n_send, static_cast<int32_t *>(p)));
+            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), rows_of(col), n_send, static_cast<int64_t *>(p)));
             sent[i].values = p;
         }
     }
@@ -671,13 +690,24 @@ int flockgpu_q3_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const floc
     FG_TRY(check_single_panes(ctx, auction_win, "q3 exchange"));
     FG_TRY(check_single_panes(ctx, person_win, "q3 exchange"));
     FG_HIP(ctx, hipSetDevice(ctx->device));
+    // stage 0 of planner.rs:152-171 runs BEFORE the repartition: FilterExec category = lit on the auctions, state = a OR b OR ... on the
+    // persons; only the rows they keep are partitioned and travel (the join below filters again: a no-op on what arrives)
+    Q3Stage0 f;
+    FG_TRY(q3_stage0_filters(ctx, auction, auction_win, person, person_win, category_lit, state_lits, n_state_lits, &f));
+    std::vector<int32_t> falo, fahi, fplo, fphi;
+    const flockgpu_windows faw = single_pane_windows(f.auction_off, falo, fahi), fpw = single_pane_windows(f.person_off, fplo, fphi);
+    int32_t *a_key = nullptr, *p_key = nullptr;   // the partition keys of the kept rows (the other columns are taken through the row lists)
+    FG_TRY(arena_get_t(ctx, "xq3a.key", (size_t)f.n_auctions + 4, &a_key));
+    FG_TRY(arena_get_t(ctx, "xq3p.key", (size_t)f.n_persons + 4, &p_key));
+    FG_TRY(gather_i32(ctx, auction->seller, f.auction_rows, f.n_auctions, a_key));
+    FG_TRY(gather_i32(ctx, person->p_id, f.person_rows, f.n_persons, p_key));
     XRecv a, p;
-    FG_TRY(exchange_relation(ctx, comm, "xq3a", {XCol{auction->a_id, nullptr, 4}, XCol{auction->seller, nullptr, 4}, XCol{auction->category, nullptr, 4}}, 1,
-                             auction->rows, auction_win, &a));
+    FG_TRY(exchange_relation(ctx, comm, "xq3a", {XCol{auction->a_id, nullptr, 4, true}, XCol{a_key, nullptr, 4}, XCol{auction->category, nullptr, 4, true}}, 1,
+                             f.n_auctions, &faw, &a, f.auction_rows));
     FG_TRY(exchange_relation(ctx, comm, "xq3p",
-                             {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}, XCol{person->city.data, person->city.offsets, 0},
-                              XCol{person->state.data, person->state.offsets, 0}},
-                             0, person->rows, person_win, &p));
+                             {XCol{p_key, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0, true}, XCol{person->city.data, person->city.offsets, 0, true},
+                              XCol{person->state.data, person->state.offsets, 0, true}},
+                             0, f.n_persons, &fpw, &p, f.person_rows));
     std::vector<int32_t> alo, ahi, plo, phi;
     const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
     auto u = [](const DevColumn &c) { return flockgpu_utf8{c.offsets, static_cast<const uint8_t *>(c.values)}; };

@@ -92,6 +92,17 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
                            const int32_t **d_rows, const int64_t **d_group_off, const int64_t **h_group_off, int64_t *n_out,
                            const PartPayload *payload = nullptr, const char *cache_name = nullptr);
 
+// q3's stage 0 for the in-library exchange (q3.hip; planner.rs:152-171: FilterExec category = lit / state = a OR b OR ... BEFORE the
+// hash repartition): the rows each filter keeps, in input order, with the windows' new row offsets.  Synchronises once for both.
+struct Q3Stage0 {
+    const int32_t *auction_rows = nullptr, *person_rows = nullptr;   // device
+    std::vector<int64_t> auction_off, person_off;                    // host, n_windows + 1
+    int64_t n_auctions = 0, n_persons = 0;
+};
+int q3_stage0_filters(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                      const flockgpu_person_cols *person, const flockgpu_windows *person_win, int64_t category_lit,
+                      const char *const *state_lits, int n_state_lits, Q3Stage0 *out);
+
 // q8.dag's Partial DISTINCT for the in-library exchange (shuffle.hip): the first occurrence of every key inside each 8192-row tile of a
 // window (a tile = one input partition of HashAggregateExec(Partial) with no aggregates), as a compact key column in input order with the
 // windows' new row offsets.  Keys may repeat across tiles (and INT32_MIN, the table's empty mark, is never deduplicated): the

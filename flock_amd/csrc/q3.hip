@@ -454,7 +454,140 @@ __global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restr
     }
 }
 
+// ---- stage 0 on its own (the exchange filters before it shuffles): row flags of one filter each, flag-tile layout
+__global__ __launch_bounds__(kBlock) void q3_category_flag_kernel(const int32_t *__restrict__ category, int64_t n_rows, int64_t category_lit,
+                                                                  SegTiles st, uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    int32_t c[kFlagIters][4];
+    load_flag_tile(category, n_rows, tr, c);
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin), rel0 = flag_rel0();
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            flags |= ((rel >= rel_lo && rel < rel_hi && (int64_t)c[it][j] == category_lit) ? 1u : 0u) << (it * 4 + j);
+        }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+__global__ __launch_bounds__(kBlock) void q3_state_flag_kernel(const int32_t *__restrict__ state_off, const uint8_t *__restrict__ state_data,
+                                                               int64_t n_rows, SegTiles st, Utf8Lits lits, uint32_t *__restrict__ flag_words,
+                                                               uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+        int32_t off[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int64_t r = r0 + j;
+            off[j] = state_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j;
+            const bool in = r >= tr.lo && r < tr.hi;
+            const uint32_t len = in ? (uint32_t)(off[j + 1] - off[j]) : 0u;
+            const uint64_t v = utf8_head8(state_data, len ? off[j] : 0, len > 8 ? 8u : len);
+            flags |= ((in && len <= 8 && lits_hit(v, len, lits)) ? 1u : 0u) << (it * 4 + j);
+        }
+    }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+
+int make_lits(flockgpu_ctx *ctx, const char *const *state_lits, int n_state_lits, Utf8Lits *lits) {
+    if (n_state_lits < 0 || n_state_lits > kMaxLits) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: more than 8 literals");
+    *lits = Utf8Lits{};
+    lits->n = n_state_lits;
+    for (int l = 0; l < n_state_lits; ++l) {
+        const size_t len = std::strlen(state_lits[l]);
+        if (len > 8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: Utf8 literal longer than 8 bytes");
+        lits->len[l] = (uint32_t)len;
+        for (size_t k = 0; k < len; ++k) lits->bytes[l] |= (uint64_t)(uint8_t)state_lits[l][k] << (8 * k);
+    }
+    return FLOCKGPU_OK;
+}
+
 }  // namespace
+
+namespace flockgpu {
+
+int q3_stage0_filters(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                      const flockgpu_person_cols *person, const flockgpu_windows *person_win, int64_t category_lit,
+                      const char *const *state_lits, int n_state_lits, Q3Stage0 *out) {
+    *out = Q3Stage0{};
+    FG_TRY(check_windows(ctx, auction_win, auction->rows, "q3.auction"));
+    FG_TRY(check_windows(ctx, person_win, person->rows, "q3.person"));
+    if (auction->rows >= (int64_t(1) << 31) || person->rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: relations are limited to 2^31 rows per call");
+    if (auction->rows > 0 && !auction->category) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3: null category column");
+    if (person->rows > 0 && (!person->state.offsets || !person->state.data)) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3: null state column");
+    if (reinterpret_cast<uintptr_t>(auction->category) & 15) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: category column must be 16-byte aligned");
+    Utf8Lits lits;
+    FG_TRY(make_lits(ctx, state_lits, n_state_lits, &lits));
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    struct Side {
+        const char *name;
+        const flockgpu_windows *win;
+        int64_t rows;
+        SegTiles st;
+        uint32_t *flags = nullptr, *counts = nullptr;
+        uint64_t *base = nullptr;
+        int64_t *d_off = nullptr, *h_off = nullptr;
+        int32_t *o_rows = nullptr;
+    } sides[2] = {{"xq3.f_auction", auction_win, auction->rows, {}}, {"xq3.f_person", person_win, person->rows, {}}};
+    for (Side &sd : sides) {
+        const int n_win = sd.win->n_windows;
+        std::vector<int64_t> sb((size_t)std::max(n_win, 1)), se(sb.size());
+        int64_t covered = 0;
+        for (int w = 0; w < n_win; ++w) {
+            sb[(size_t)w] = sd.win->pane_row_offsets[sd.win->win_pane_lo[w]];
+            se[(size_t)w] = sd.win->pane_row_offsets[sd.win->win_pane_hi[w]];
+            covered += se[(size_t)w] - sb[(size_t)w];
+        }
+        const std::string nm = sd.name;
+        FG_TRY(build_seg_tiles(ctx, nm.c_str(), sb.data(), se.data(), n_win, kFlagTile, &sd.st));
+        FG_TRY(arena_get_t(ctx, (nm + ".flags").c_str(), (size_t)sd.st.n_tiles * kBlock + 4, &sd.flags));
+        FG_TRY(arena_get_t(ctx, (nm + ".counts").c_str(), (size_t)sd.st.n_tiles * kWavesPerBlock + 4, &sd.counts));
+        FG_TRY(arena_get_t(ctx, (nm + ".tile_base").c_str(), (size_t)sd.st.n_tiles + 2, &sd.base));
+        FG_TRY(arena_get_t(ctx, (nm + ".off").c_str(), (size_t)n_win + 2, &sd.d_off));
+        FG_TRY(pinned_get_t(ctx, (nm + ".off").c_str(), (size_t)n_win + 2, &sd.h_off));
+        FG_TRY(arena_get_t(ctx, (nm + ".rows").c_str(), (size_t)covered + 4, &sd.o_rows));
+    }
+    if (sides[0].st.n_tiles > 0) {
+        LaunchScope ls(ctx, "q3_category_flag_kernel");
+        hipLaunchKernelGGL(q3_category_flag_kernel, dim3((unsigned)sides[0].st.n_tiles), dim3(kBlock), 0, ctx->stream, auction->category, auction->rows,
+                           category_lit, sides[0].st, sides[0].flags, sides[0].counts);
+    }
+    FG_TRY(check_launch(ctx, "q3_category_flag_kernel"));
+    if (sides[1].st.n_tiles > 0) {
+        LaunchScope ls(ctx, "q3_state_flag_kernel");
+        hipLaunchKernelGGL(q3_state_flag_kernel, dim3((unsigned)sides[1].st.n_tiles), dim3(kBlock), 0, ctx->stream, person->state.offsets,
+                           person->state.data, person->rows, sides[1].st, lits, sides[1].flags, sides[1].counts);
+    }
+    FG_TRY(check_launch(ctx, "q3_state_flag_kernel"));
+    for (Side &sd : sides) {
+        FG_TRY(launch_tile_scan(ctx, sd.counts, sd.st.n_tiles, sd.base, sd.st.tile_first, sd.st.n_seg, sd.d_off));
+        FG_TRY(emit_flagged_rows(ctx, sd.st, sd.flags, sd.counts, sd.base, sd.o_rows));
+        FG_HIP(ctx, hipMemcpyAsync(sd.h_off, sd.d_off, sizeof(int64_t) * ((size_t)sd.win->n_windows + 1), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->auction_rows = sides[0].o_rows;
+    out->person_rows = sides[1].o_rows;
+    out->auction_off.assign(sides[0].h_off, sides[0].h_off + auction_win->n_windows + 1);
+    out->person_off.assign(sides[1].h_off, sides[1].h_off + person_win->n_windows + 1);
+    if (auction_win->n_windows == 0) out->auction_off.assign(1, 0);
+    if (person_win->n_windows == 0) out->person_off.assign(1, 0);
+    out->n_auctions = out->auction_off.back();
+    out->n_persons = out->person_off.back();
+    return FLOCKGPU_OK;
+}
+
+}  // namespace flockgpu
 
 extern "C" {
 
@@ -477,15 +610,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     if ((reinterpret_cast<uintptr_t>(auction->seller) & 15) || (reinterpret_cast<uintptr_t>(auction->category) & 15) ||
         (reinterpret_cast<uintptr_t>(person->p_id) & 15))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: seller, category and p_id columns must be 16-byte aligned");
-    if (n_state_lits < 0 || n_state_lits > kMaxLits) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: more than 8 literals");
-    Utf8Lits lits{};
-    lits.n = n_state_lits;
-    for (int l = 0; l < n_state_lits; ++l) {
-        const size_t len = std::strlen(state_lits[l]);
-        if (len > 8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: Utf8 literal longer than 8 bytes");
-        lits.len[l] = (uint32_t)len;
-        for (size_t k = 0; k < len; ++k) lits.bytes[l] |= (uint64_t)(uint8_t)state_lits[l][k] << (8 * k);
-    }
+    Utf8Lits lits;
+    FG_TRY(make_lits(ctx, state_lits, n_state_lits, &lits));
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = auction_win->n_windows;
 

@@ -52,9 +52,9 @@ const char *flockgpu_comm_transport(const flockgpu_comm *comm);
 int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_bid_cols *bid,
                                    const flockgpu_windows *win, flockgpu_q5_result *out);
 
-/* ---- q3 with the join shuffle of planner.rs:152-171: auctions repartitioned on seller, persons on p_id (rows are
- * filtered AFTER the shuffle by the fused join, so the shuffle also carries the rows the filters drop -- the same rows
- * the reference's stage 0 would have dropped before its repartition; see flockgpu_plan for the staged form). */
+/* ---- q3 as planner.rs:152-171 stages it: stage 0 = FilterExec category = lit on this rank's auctions and state = a OR b OR ... on its
+ * persons, then RepartitionExec Hash([seller]) / Hash([p_id]) of the rows the filters keep (only those travel); stage 1 = the join on the
+ * rank that owns the key. */
 int flockgpu_q3_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_auction_cols *auction,
                               const flockgpu_windows *auction_win, const flockgpu_person_cols *person,
                               const flockgpu_windows *person_win, int64_t category_lit, const char *const *state_lits,
