@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun helper: everything that touches q5 (parity, goldens, exchange, plans), then the q5 step with its kernels
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests -m gpu -q -x -k "q5 or golden or frozen or unfrozen or exchange or comm or stage or plan or baseline or full_size" 2>&1 | tail -5)
+(timeout 900 python -m pytest tests -m gpu -q -x -k "q5 or golden or frozen or unfrozen or exchange or comm or stage or plan or baseline or full_size" 2>&1 | grep -E "passed|failed" | tail -3)
 for i in 1 2; do
 FLOCK_BENCH_STEP_TIMES=1 timeout 300 python bench.py --query 5 --no-also --no-cpu --steps 10 --warmup 3 2> gpurun_out/q5.err | tail -1 > gpurun_out/q5.json
 grep 'step wall' gpurun_out/q5.err
