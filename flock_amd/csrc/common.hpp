@@ -213,4 +213,31 @@ inline int check_windows(flockgpu_ctx *ctx, const flockgpu_windows *w, int64_t r
     return FLOCKGPU_OK;
 }
 
+// 16-byte load of a column that is read once and never again (the streaming passes): non-temporal, so the stream does not push
+// the data the pass keeps coming back to (direct-address counters, tables, bitmaps) out of L2 / the Infinity Cache.
+typedef int flockgpu_v4i __attribute__((ext_vector_type(4)));
+// 16-byte / 4-byte stores of results the GPU does not read again (they go to the host or to a later call): non-temporal, so their
+// write-back does not land on whatever kernel runs next (the q5 counters' clear cost the count pass 0.04-0.15 ms that way).
+typedef unsigned int flockgpu_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store4(void *p, uint4 v) {
+#ifdef FLOCKGPU_AB_PLAIN_STORES   // (A/B builds only)
+    *reinterpret_cast<uint4 *>(p) = v;
+#else
+    flockgpu_v4u t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<flockgpu_v4u *>(p));
+#endif
+}
+__device__ __forceinline__ void stream_store(int32_t *p, int32_t v) {
+#ifdef FLOCKGPU_AB_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+__device__ __forceinline__ int4 stream_load4(const int32_t *p) {
+    const flockgpu_v4i v = __builtin_nontemporal_load(reinterpret_cast<const flockgpu_v4i *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
 }  // namespace flockgpu

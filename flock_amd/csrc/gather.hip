@@ -388,7 +388,7 @@ __device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_o
     if (blockIdx.x == 0 && threadIdx.x == 0) out_off[0] = 0;
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k)
-        if (i0 + k * kBlock < n) out_off[i0 + k * kBlock + 1] = (int32_t)(base + excl[k] + len[k]);
+        if (i0 + k * kBlock < n) stream_store(&out_off[i0 + k * kBlock + 1], (int32_t)(base + excl[k] + len[k]));
     if (tile_bytes == 0) return;
     const uint32_t phase = (uint32_t)(base & 15);  // LDS byte i holds output byte (base - phase) + i
     const bool staged = phase + tile_bytes <= (uint32_t)kStageBytes;  // block-uniform
@@ -439,7 +439,7 @@ __device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_o
     const uint32_t end = phase + tile_bytes;
     for (uint32_t o = threadIdx.x * 16; o < end; o += kBlock * 16) {
         if (o >= phase && o + 16 <= end) {
-            *reinterpret_cast<uint4 *>(gout + o) = *reinterpret_cast<const uint4 *>(s_stage + o);
+            stream_store4(gout + o, *reinterpret_cast<const uint4 *>(s_stage + o));
         } else {  // first / last chunk is shared with the neighbouring tile: only this tile's bytes
             for (uint32_t c = (o < phase ? phase : o); c < o + 16 && c < end; ++c) gout[c] = s_stage[c];
         }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void q2_load_tile(const int32_t *__restrict__ auction
     if (tr.tile_begin + kQ2Tile <= n_rows) {  // block-uniform: no row of the tile is past the column
 #pragma unroll
         for (int it = 0; it < kQ2Iters; ++it) {
-            const int4 t = *reinterpret_cast<const int4 *>(auction + wbase + it * 256);
+            const int4 t = stream_load4(auction + wbase + it * 256);
             a[it][0] = t.x; a[it][1] = t.y; a[it][2] = t.z; a[it][3] = t.w;
         }
     } else {

@@ -319,10 +319,10 @@ __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__
     const uint64_t base = tile_base[tile];
     for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
         const int64_t r = tr.tile_begin + s_list[i];
-        out_auction_row[base + i] = (int32_t)r;
+        stream_store(&out_auction_row[base + i], (int32_t)r);   // (results: not read again by this call except person_row, which the take reads once)
         const uint32_t idx = (uint32_t)(seller[r] - wt.base);
         out_person_row[base + i] = kBits ? wt.first_row + (int32_t)idx : direct[wt.off + idx];
-        out_a_id[base + i] = a_id[r];
+        stream_store(&out_a_id[base + i], a_id[r]);
     }
 }
 

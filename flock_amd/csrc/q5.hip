@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-        const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+        const int4 t = stream_load4(auction + r0);
         k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
     }
     int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void q5_partial_tile_kernel(const int32_t *
 #pragma unroll
         for (int it = 0; it < kQ5Iters; ++it) {
             const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
-            const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+            const int4 t = stream_load4(auction + r0);
             k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
         }
 #pragma unroll

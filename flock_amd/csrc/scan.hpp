@@ -205,6 +205,26 @@ __device__ __forceinline__ void load_flag_tile(const int32_t *__restrict__ col, 
     if (tr.tile_begin + kFlagTile <= n_rows) {  // block-uniform: no row of the tile is past the column
 #pragma unroll
         for (int it = 0; it < kFlagIters; ++it) {
+#ifdef FLOCKGPU_AB_PLAIN_TILE_LOADS   // (A/B builds only: tools/gpu_ab_stream_loads.sh)
+            const int4 t = *reinterpret_cast<const int4 *>(col + wbase + it * 256);
+#else
+            const int4 t = stream_load4(col + wbase + it * 256);   // (read once per pass: non-temporal, common.hpp)
+#endif
+            a[it][0] = t.x; a[it][1] = t.y; a[it][2] = t.z; a[it][3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it) load4_i32(col, wbase + it * 256, n_rows, a[it]);
+    }
+}
+
+// The same with ordinary (cached) loads, for a column a second pass reads again right away.
+__device__ __forceinline__ void load_flag_tile_cached(const int32_t *__restrict__ col, int64_t n_rows, const TileRange &tr,
+                                                      int32_t (&a)[kFlagIters][4]) {
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    if (tr.tile_begin + kFlagTile <= n_rows) {
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it) {
             const int4 t = *reinterpret_cast<const int4 *>(col + wbase + it * 256);
             a[it][0] = t.x; a[it][1] = t.y; a[it][2] = t.z; a[it][3] = t.w;
         }

@@ -1,7 +1,12 @@
 cd "$GRAFT_REPO_ROOT"
-for i in 1 2 3; do
-for v in "" "1"; do
-  if [ -n "$v" ]; then export FLOCKGPU_Q5_NO_PRECLEAN=1; else unset FLOCKGPU_Q5_NO_PRECLEAN; fi
-  python bench.py --query 5 --no-also --no-cpu --steps 30 --warmup 3 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('no_preclean=$v', d['ms_per_step'], 'count', r['avg_launch_ms'], 'range', r['kernels_ms'].get('q5_range_kernel'))"
-done; done
+python bench.py --no-cpu --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/bench_nocpu.json
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/bench_nocpu.json").read())
+print("q5", d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
+q3 = d["q3"]; print("q3", q3["ms_per_step"], q3["roofline"]["frac"])
+for k, v in d["also"].items():
+    if k == "exchange_1rank":
+        for kk, vv in v.items(): print("x1", kk, vv.get("ms_per_step"), vv.get("over_window_sharded_step"))
+    elif isinstance(v, dict): print(k, v.get("ms_per_step"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("avg_launch_ms"))
+PY
