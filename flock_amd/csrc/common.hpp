@@ -235,6 +235,17 @@ __device__ __forceinline__ void stream_store(int32_t *p, int32_t v) {
     __builtin_nontemporal_store(v, p);
 #endif
 }
+__device__ __forceinline__ void stream_store(int64_t *p, int64_t v) {
+#ifdef FLOCKGPU_AB_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+__device__ __forceinline__ uint4 stream_load4u(const uint32_t *p) {
+    const flockgpu_v4u v = __builtin_nontemporal_load(reinterpret_cast<const flockgpu_v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ int4 stream_load4(const int32_t *p) {
     const flockgpu_v4i v = __builtin_nontemporal_load(reinterpret_cast<const flockgpu_v4i *>(p));
     return make_int4(v.x, v.y, v.z, v.w);

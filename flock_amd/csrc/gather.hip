@@ -204,10 +204,10 @@ __global__ __launch_bounds__(kBlock) void emit_bids_kernel(const int32_t *__rest
     const uint64_t base = tile_base[tile];
     for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
         const int64_t r = tr.tile_begin + s_list[i];
-        o_auction[base + i] = auction[r];
-        o_price[base + i] = price[r];
-        o_bidder[base + i] = bidder[r];
-        o_time[base + i] = b_date_time[r];
+        stream_store(&o_auction[base + i], auction[r]);   // (result columns: not read again on the device)
+        stream_store(&o_price[base + i], price[r]);
+        stream_store(&o_bidder[base + i], bidder[r]);
+        stream_store(&o_time[base + i], b_date_time[r]);
     }
 }
 

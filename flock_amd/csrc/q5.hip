@@ -345,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
             for (int b = 0; b < kBatch; ++b) {
                 const int64_t r = tr.tile_begin + (int64_t)(c0 + b) * kBlock + threadIdx.x;
                 const bool in = full_tile || (r >= tr.lo && r < tr.hi);
-                kk[b] = in ? auction[r] : 0;
-                ww[b] = in ? weight[r] : 0u;
+                kk[b] = in ? __builtin_nontemporal_load(&auction[r]) : 0;   // (pairs are read once)
+                ww[b] = in ? __builtin_nontemporal_load(&weight[r]) : 0u;
             }
 #pragma unroll
             for (int b = 0; b < kBatch; ++b)
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
             for (int it = 0; it < kQ5Iters; ++it) {
                 const int64_t r0 = tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4;
                 if (r0 >= tr.lo && r0 + 4 <= tr.hi) {
-                    const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+                    const int4 t = stream_load4(auction + r0);
                     k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
                 } else {
 #pragma unroll

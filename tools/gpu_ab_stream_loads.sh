@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read()); o=['$v']
 def f(e): r=e.get('roofline') or {}; return '%s/%s' % (e.get('ms_per_step'), r.get('avg_launch_ms'))
 o.append('q5 '+f(d)); o.append('q3 '+f(d['q3']))
-for k in ('q2','q8','q3_1e9_events','q2_1e9_bids','q8_4e9_events','q7_next','q9_next','q4_next','q13_next'): o.append(k.replace('_next','')+' '+f(d['also'][k]))
+for k in ('q2','q8','q3_1e9_events','q2_1e9_bids','q8_4e9_events','q7_next','q9_next','q4_next','q13_next','ysb_next','json_ingest_next','q11_next'): o.append(k.replace('_next','')+' '+f(d['also'][k]))
 for k,v in d['also']['exchange_1rank'].items(): o.append('x'+k+' '+str(v.get('ms_per_step')))
 print(' | '.join(o))"
 done; done
