@@ -139,7 +139,7 @@ __device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, const FlushAr
 }
 
 // ---- pane key-range estimate: kRangeBlocks x 256 lanes x 4 strided 16-byte samples per pane (<1 % of a pane) ------
-constexpr int kRangeBlocks = 8;
+constexpr int kRangeBlocks = 2;   // (8: 0.043 ms per 1e9 bids -- every 16-byte sample costs a whole line; the 6 % margins of q5_pane_layout absorb the coarser estimate)
 // Every (pane, block) writes its own sampled extrema (no initialisation, no atomics): rng[(pane * kRangeBlocks + block) * 2 + {0, 1}].
 __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restrict__ auction, int64_t n_rows,
                                                           const int64_t *__restrict__ seg_off, int32_t *__restrict__ rng) {
