@@ -136,6 +136,10 @@ def test_q2_overlapping_windows_and_empty_input(ctx):
 # ------------------------------------------------------------------ q3
 @pytest.mark.parametrize("seed,eps,seconds", CASES)
 def test_q3_join_per_epoch(ctx, seed, eps, seconds):
+    _check_q3_nexmark(ctx, seed, eps, seconds)
+
+
+def _check_q3_nexmark(ctx, seed, eps, seconds):
     from flock_amd import Window, run_query
     g = _gpu_stream(ctx, seed, eps, seconds, Window.element_wise())
     out = run_query(ctx, 3, g).to_host()
@@ -389,6 +393,10 @@ def test_q13_side_input_join(ctx, n_side, dups):
 # ------------------------------------------------------------------ q8
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 10)])
 def test_q8_tumbling_windows(ctx, seed, eps, seconds):
+    _check_q8_nexmark(ctx, seed, eps, seconds)
+
+
+def _check_q8_nexmark(ctx, seed, eps, seconds):
     from flock_amd import query_window, run_query
     g = _gpu_stream(ctx, seed, eps, seconds, query_window(8))
     out = run_query(ctx, 8, g).to_host()
@@ -508,6 +516,15 @@ def test_q3_every_path_is_exact(ctx, case):
         assert sorted(zip(g_name[sl], g_state[sl], out["a_id"][sl].tolist())) == want, (case, w)
         total += len(ar)
     assert total == len(out["a_id"]) and total > 1000
+
+
+def test_q3_q8_follow_the_data_on_one_ctx(ctx):
+    """The dense paths are speculated from what the previous call on the ctx saw (bit blocks / row table / general path, sizes of
+    the Utf8 takes): after the hostile inputs above the same ctx must come back to exact answers on generator data, small then
+    ten times larger (the take laid out for the small call is too small and is redone), then small again."""
+    for eps, seconds in ((2_000, 4), (40_000, 5), (2_000, 3)):
+        _check_q3_nexmark(ctx, 31, eps, seconds)
+        _check_q8_nexmark(ctx, 31, eps, 20)
 
 
 # ------------------------------------------------------------------ full-size, size-independent properties
