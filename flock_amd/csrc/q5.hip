@@ -276,12 +276,15 @@ __global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__rest
 __global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, const uint64_t *__restrict__ info, uint64_t cnt_host,
                                                           uint64_t cnt_from, uint64_t *__restrict__ tables, uint64_t table_words,
                                                           uint64_t *__restrict__ meta, uint64_t meta_words, int32_t *__restrict__ slow_list,
-                                                          uint32_t *__restrict__ block_max, uint64_t block_max_words) {
+                                                          uint32_t *__restrict__ block_max, uint64_t block_max_words, int plain_stores) {
     const uint64_t cnt = info ? (info[2] ? info[0] : 0) : cnt_host;
     const uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
     const uint4 z = make_uint4(0, 0, 0, 0);
     // (non-temporal: the zeroes go to HBM as they are written instead of lingering as dirty lines whose write-back lands on the kernel that
     // runs next -- measured: +0.04 ms on whichever kernel followed the clear)
+    if (plain_stores) {   // (FLOCKGPU_Q5_PLAIN_CLEAR: the round-1 behaviour, kept for the counter-level A/B in profiles/r02/q5_clear_policy.txt)
+        for (uint64_t i = i0 + cnt_from / 4; i * 4 < cnt + 3; i += stride) reinterpret_cast<uint4 *>(counters)[i] = z;
+    } else
     for (uint64_t i = i0 + cnt_from / 4; i * 4 < cnt + 3; i += stride) {
         uint32_t *p = counters + i * 4;
         __builtin_nontemporal_store(0u, p);
@@ -882,6 +885,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: auction / count columns must be 16-byte aligned");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = win->n_windows, n_panes = win->n_panes;
+    static const bool plain_clear = getenv("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (experiment knob: cached stores in the clear, as in round 1)
 
     // pane -> windows CSR, window row counts
     std::vector<int32_t> ptr(n_panes + 1, 0), idx;
@@ -1083,7 +1087,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
             hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
                                (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
-                               slow_list, block_max, (uint64_t)gx * n_win);
+                               slow_list, block_max, (uint64_t)gx * n_win, plain_clear ? 1 : 0);
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
         if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
@@ -1318,13 +1322,13 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     out->win_max = wmax.data();
     out->win_groups = wgrp.data();
     out->rows = n_sel;
-    static const bool no_preclean = getenv("FLOCKGPU_Q5_NO_PRECLEAN") != nullptr;   // (A/B knob)
+    static const bool no_preclean = getenv("FLOCKGPU_Q5_NO_PRECLEAN") != nullptr || getenv("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (A/B knobs)
     if (speculate && dense && cnt_total > 0 && !no_preclean) {   // clean up after use (see `preclean` above); the results above are already on their way
         int32_t *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)cnt_total / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
         hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
-                           uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0));
+                           uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0);
         FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         preclean[0] = (int64_t)reinterpret_cast<uintptr_t>(counters);
         preclean[1] = (int64_t)std::max<uint64_t>(clean_upto, cnt_total);
