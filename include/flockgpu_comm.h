@@ -44,7 +44,8 @@ int flockgpu_comm_size(const flockgpu_comm *comm);
 /* "rccl" | "local" */
 const char *flockgpu_comm_transport(const flockgpu_comm *comm);
 
-/* ---- q5 as q5.dag runs it: HashAggregateExec(Partial) COUNT on this rank's rows, pane by pane -> the (auction, count)
+/* ---- q5 as q5.dag runs it: HashAggregateExec(Partial) COUNT on this rank's rows, per 8192-row tile of every pane (a tile stands for one
+ * input partition of the Partial stage: the same auction may leave a rank in several pairs, as it does in the reference) -> the (auction, count)
  * GROUPS are repartitioned on `auction` (a group moves once although its pane is in two hopping windows; the bids
  * themselves never cross the fabric) -> FinalPartitioned COUNT, MAX and the num = maxn join over the owned auctions ->
  * all-reduce(MAX) of the per-window maxima.  out: this rank's winners; win_max is the GLOBAL maximum per window, rows of
