@@ -56,8 +56,8 @@ DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300, 13
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)    # (a step is ~1 ms: twenty of them average the host's turnaround and the clock ramp out)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9, 13])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
