@@ -1,7 +1,8 @@
 """tests/golden/nexmark_hashes.json (minted by tools/make_nexmark_goldens.py from oracle == pyarrow agreement,
 SURVEY.md section 8c) against (CPU) the oracle re-run on the small configurations and (GPU, -m gpu) the HIP path on EVERY
 window of EVERY configuration, BASELINE.json's full sizes included: q2 1e8 bids (109 windows), q3 1e8 / 1e9 events
-(100 / 1000 windows), q5 1e9 bids (216 windows), q8 1e9 events (100 windows)."""
+(100 / 1000 windows), q5 1e9 bids (216 windows), q8 1e9 events (100 windows); the "next" queries q7 (1e9 bids, 108 windows) and
+q4 / q9 (300 s = 2.76e8 bids, 300 windows each) at the sizes bench.py runs them."""
 import json
 import os
 import sys
@@ -27,7 +28,8 @@ ALL = sorted(GOLDEN, key=lambda k: (_parse(k)[2] * _parse(k)[3], k))
 def test_golden_file_covers_the_baseline_configs():
     for k, windows in (("q2/seed=20260925/eps=1000000/seconds=109", 109), ("q3/seed=20260925/eps=1000000/seconds=100", 100),
                        ("q3/seed=20260925/eps=1000000/seconds=1000", 1000), ("q5/seed=20260925/eps=1000000/seconds=1087", 216),
-                       ("q8/seed=20260925/eps=1000000/seconds=1000", 100)):
+                       ("q8/seed=20260925/eps=1000000/seconds=1000", 100), ("q7/seed=20260925/eps=1000000/seconds=1087", 108),
+                       ("q9/seed=20260925/eps=1000000/seconds=300", 300), ("q4/seed=20260925/eps=1000000/seconds=300", 300)):
         assert GOLDEN[k]["windows"] == windows == len(GOLDEN[k]["fingerprints"]), k
         assert GOLDEN[k]["result_rows"] > 0
 
@@ -72,9 +74,10 @@ def hip_fingerprints(ctx, q, seed, eps, seconds):
     """Per-window fingerprints of the HIP path's OUTPUT COLUMNS (C ABI -> host copies), hashed with the checker's hash."""
     import torch
     from flock_amd import NEXMarkSource, query_window, run_query
-    rel = {1: ("bid",), 2: ("bid",), 5: ("bid",), 3: ("auction", "person"), 8: ("auction", "person")}[q]
-    cols = {1: ("auction", "bidder", "price", "b_date_time"), 2: ("auction", "price"), 5: ("auction",)}.get(q, ("auction",))
-    g = NEXMarkSource(seconds, eps, query_window(q), seed=seed).generate_data(ctx, relations=rel, bid_columns=cols)
+    all4 = ("auction", "bidder", "price", "b_date_time")
+    rel = {1: ("bid",), 2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person"), 9: ("bid", "auction"), 4: ("bid", "auction")}[q]
+    cols = {1: all4, 2: ("auction", "price"), 5: ("auction",), 7: all4, 9: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
+    g = NEXMarkSource(seconds, eps, query_window(q), seed=seed).generate_data(ctx, relations=rel, bid_columns=cols, auction_times=q in (4, 9))
     out = run_query(ctx, q, g)
     if q == 1:
         off = g.window_schedule("bid").pane_row_offsets
@@ -87,6 +90,18 @@ def hip_fingerprints(ctx, q, seed, eps, seconds):
         a, n, off = out.to_host()
         assert n.dtype == np.uint64                          # q5_plan.fmt:1 `num: UInt64`
         h = oracle.row_hashes([a, n.astype(np.int64)])
+    elif q == 7:
+        o = out.to_host()
+        off = o["offsets"]
+        h = oracle.row_hashes([o["auction"], o["price"], o["bidder"], o["b_date_time"]]) if len(o["price"]) else np.zeros(0, np.uint64)
+    elif q == 9:
+        o = out.to_host()
+        off = o["offsets"]
+        h = oracle.row_hashes([o["auction"], o["bidder"], o["price"], o["b_date_time"]]) if len(o["price"]) else np.zeros(0, np.uint64)
+    elif q == 4:
+        o = out.to_host()
+        off = o["offsets"]
+        h = oracle.row_hashes([o["category"], o["avg"]]) if len(o["avg"]) else np.zeros(0, np.uint64)
     elif q == 3:
         o = out.to_host()
         off, n = o["offsets"], len(o["a_id"])

@@ -40,8 +40,13 @@ CONFIGS = {
     3: SMALL + [(20260925, 1_000_000, 100), (20260925, 1_000_000, 1000)],
     5: [(1, 1000, 23), (7, 5000, 30), (42, 50_000, 20), (20260925, 1_000_000, 1087)],
     8: [(1, 1000, 23), (7, 5000, 30), (42, 50_000, 20), (20260925, 1_000_000, 1000)],
+    # SURVEY.md section 8(f) "next" queries at the sizes bench.py runs them (q7: 1e9 bids; q4 / q9: 300 s = 2.76e8 bids)
+    7: [(1, 1000, 23), (7, 5000, 30), (42, 50_000, 20), (20260925, 1_000_000, 1087)],
+    9: [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 6), (20260925, 1_000_000, 300)],
+    4: [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 6), (20260925, 1_000_000, 300)],
 }
-WINDOW = {1: ("elementwise",), 2: ("elementwise",), 3: ("elementwise",), 5: ("hopping", 10, 5), 8: ("tumbling", 10)}
+WINDOW = {1: ("elementwise",), 2: ("elementwise",), 3: ("elementwise",), 5: ("hopping", 10, 5), 8: ("tumbling", 10), 7: ("tumbling", 10),
+          9: ("elementwise",), 4: ("elementwise",)}
 
 
 def key(q, seed, eps, seconds):
@@ -175,19 +180,64 @@ def q8_window(c, alo, ahi, plo, phi):
     return fp
 
 
+def q7_window(c, lo, hi):
+    pa, pc = _pa()
+    b = {k: v[lo:hi] for k, v in c["bid"].items()}
+    rows = oracle.q7_highest_bid(b["price"])
+    if hi > lo:
+        mask = pc.equal(pa.array(b["price"]), pc.max(pa.array(b["price"])))
+        assert np.array_equal(np.flatnonzero(mask.to_numpy(zero_copy_only=False)), rows)
+    return oracle.multiset_fingerprint([(b["auction"], rows), (b["price"], rows), (b["bidder"], rows), (b["b_date_time"], rows)])   # q7.sql's column order
+
+
+def _winning_bids_pa(a, b):
+    """Q of q4.sql / q9.sql through pyarrow: join, BETWEEN, MAX GROUP BY (a_id, category)."""
+    pa, pc = _pa()
+    ta = pa.table({"a_id": a["a_id"], "category": a["category"], "a_date_time": a["a_date_time"], "expires": a["expires"]})
+    tb = pa.table({"auction": b["auction"], "price": b["price"], "b_date_time": b["b_date_time"], "row": np.arange(len(b["price"]))})
+    j = ta.join(tb, keys="a_id", right_keys="auction", join_type="inner")
+    j = j.filter(pc.and_(pc.greater_equal(j["b_date_time"], j["a_date_time"]), pc.less_equal(j["b_date_time"], j["expires"])))
+    return tb, j.group_by(["a_id", "category"], use_threads=False).aggregate([("price", "max")])
+
+
+def q9_window(c, alo, ahi, blo, bhi):
+    a = {k: v[alo:ahi] for k, v in c["auction"].items()}
+    b = {k: v[blo:bhi] for k, v in c["bid"].items()}
+    rows = oracle.q9_winning_bids(a["a_id"], a["a_date_time"], a["expires"], b["auction"], b["price"], b["b_date_time"])
+    tb, q = _winning_bids_pa(a, b)
+    back = tb.join(q.select(["a_id", "price_max"]), keys=["auction", "price"], right_keys=["a_id", "price_max"], join_type="inner")
+    assert sorted(back["row"].to_pylist()) == rows.tolist()
+    return oracle.multiset_fingerprint([(b["auction"], rows), (b["bidder"], rows), (b["price"], rows), (b["b_date_time"], rows)])
+
+
+def q4_window(c, alo, ahi, blo, bhi):
+    a = {k: v[alo:ahi] for k, v in c["auction"].items()}
+    b = {k: v[blo:bhi] for k, v in c["bid"].items()}
+    cats, avg = oracle.q4_avg_final_by_category(a["a_id"], a["category"], a["a_date_time"], a["expires"], b["auction"], b["price"], b["b_date_time"])
+    _, q = _winning_bids_pa(a, b)
+    q4 = q.group_by("category", use_threads=False).aggregate([("price_max", "mean")]).sort_by("category")
+    assert cats.tolist() == q4["category"].to_pylist() and avg.tobytes() == q4["price_max_mean"].to_numpy().astype(np.float64).tobytes()
+    return oracle.multiset_fingerprint([cats, avg])   # (the Float64 column by its bits)
+
+
 def mint(q, seed, eps, seconds, threads):
     rel = {1: {"bid": ("auction", "bidder", "price", "b_date_time")}, 2: {"bid": ("auction", "price")},
            3: {"auction": ("a_id", "seller", "category"), "person": ("p_id", "name", "city", "state")},
-           5: {"bid": ("auction",)}, 8: {"auction": ("seller",), "person": ("p_id", "name")}}[q]
+           5: {"bid": ("auction",)}, 8: {"auction": ("seller",), "person": ("p_id", "name")},
+           7: {"bid": ("auction", "bidder", "price", "b_date_time")},
+           9: {"auction": ("a_id", "category", "a_date_time", "expires"), "bid": ("auction", "bidder", "price", "b_date_time")},
+           4: {"auction": ("a_id", "category", "a_date_time", "expires"), "bid": ("auction", "bidder", "price", "b_date_time")}}[q]
     t0 = time.time()
     c, offs = generate(seed, eps, seconds, rel, threads)
     wins = windows_of(q, seconds)
 
     def one(w):
         e0, e1 = w
-        if q in (1, 2, 5):
+        if q in (1, 2, 5, 7):
             lo, hi = int(offs["bid"][e0]), int(offs["bid"][e1])
-            return {1: q1_window, 2: q2_window, 5: q5_window}[q](c, lo, hi)
+            return {1: q1_window, 2: q2_window, 5: q5_window, 7: q7_window}[q](c, lo, hi)
+        if q in (4, 9):
+            return (q4_window if q == 4 else q9_window)(c, int(offs["auction"][e0]), int(offs["auction"][e1]), int(offs["bid"][e0]), int(offs["bid"][e1]))
         span = (int(offs["auction"][e0]), int(offs["auction"][e1]), int(offs["person"][e0]), int(offs["person"][e1]))
         return (q3_window if q == 3 else q8_window)(c, *span)
 
