@@ -153,7 +153,9 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
 
 /* ---- q5: COUNT(*) GROUP BY auction; MAX(num); rows with num = maxn, ties kept
  * (q5.sql, q5_plan.fmt:1-13, q5.dag).  Hopping windows share panes: every bid is read once.
- * Output: per window, (auction Int32, num UInt64) rows sorted by auction. */
+ * Output: per window, (auction Int32, num UInt64) rows sorted by auction.
+ * The call returns with its results complete and may leave one clean-up kernel queued on the ctx stream (it zeroes the counters the
+ * call used, so that the next call does not have to): work the caller queues on the same stream simply runs behind it. */
 typedef struct {
     const int32_t *auction;           /* device */
     const uint64_t *num;              /* device */
