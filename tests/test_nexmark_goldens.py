@@ -29,7 +29,8 @@ def test_golden_file_covers_the_baseline_configs():
     for k, windows in (("q2/seed=20260925/eps=1000000/seconds=109", 109), ("q3/seed=20260925/eps=1000000/seconds=100", 100),
                        ("q3/seed=20260925/eps=1000000/seconds=1000", 1000), ("q5/seed=20260925/eps=1000000/seconds=1087", 216),
                        ("q8/seed=20260925/eps=1000000/seconds=1000", 100), ("q7/seed=20260925/eps=1000000/seconds=1087", 108),
-                       ("q9/seed=20260925/eps=1000000/seconds=300", 300), ("q4/seed=20260925/eps=1000000/seconds=300", 300)):
+                       ("q9/seed=20260925/eps=1000000/seconds=300", 300), ("q4/seed=20260925/eps=1000000/seconds=300", 300),
+                       ("q13/seed=20260925/eps=1000000/seconds=1087", 1087)):
         assert GOLDEN[k]["windows"] == windows == len(GOLDEN[k]["fingerprints"]), k
         assert GOLDEN[k]["result_rows"] > 0
 
@@ -75,8 +76,8 @@ def hip_fingerprints(ctx, q, seed, eps, seconds):
     import torch
     from flock_amd import NEXMarkSource, query_window, run_query
     all4 = ("auction", "bidder", "price", "b_date_time")
-    rel = {1: ("bid",), 2: ("bid",), 5: ("bid",), 7: ("bid",), 3: ("auction", "person"), 8: ("auction", "person"), 9: ("bid", "auction"), 4: ("bid", "auction")}[q]
-    cols = {1: all4, 2: ("auction", "price"), 5: ("auction",), 7: all4, 9: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
+    rel = {1: ("bid",), 2: ("bid",), 5: ("bid",), 7: ("bid",), 13: ("bid",), 3: ("auction", "person"), 8: ("auction", "person"), 9: ("bid", "auction"), 4: ("bid", "auction")}[q]
+    cols = {1: all4, 2: ("auction", "price"), 5: ("auction",), 7: all4, 13: all4, 9: all4, 4: ("auction", "price", "b_date_time")}.get(q, ("auction",))
     g = NEXMarkSource(seconds, eps, query_window(q), seed=seed).generate_data(ctx, relations=rel, bid_columns=cols, auction_times=q in (4, 9))
     out = run_query(ctx, q, g)
     if q == 1:
@@ -94,6 +95,10 @@ def hip_fingerprints(ctx, q, seed, eps, seconds):
         o = out.to_host()
         off = o["offsets"]
         h = oracle.row_hashes([o["auction"], o["price"], o["bidder"], o["b_date_time"]]) if len(o["price"]) else np.zeros(0, np.uint64)
+    elif q == 13:
+        o = out.to_host()
+        off = o["offsets"]
+        h = oracle.row_hashes([o["auction"], o["bidder"], o["price"], o["b_date_time"], o["value"]]) if len(o["price"]) else np.zeros(0, np.uint64)
     elif q == 9:
         o = out.to_host()
         off = o["offsets"]

@@ -44,9 +44,10 @@ CONFIGS = {
     7: [(1, 1000, 23), (7, 5000, 30), (42, 50_000, 20), (20260925, 1_000_000, 1087)],
     9: [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 6), (20260925, 1_000_000, 300)],
     4: [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 6), (20260925, 1_000_000, 300)],
+    13: [(1, 1000, 3), (7, 5000, 4), (42, 50_000, 12), (20260925, 1_000_000, 1087)],
 }
 WINDOW = {1: ("elementwise",), 2: ("elementwise",), 3: ("elementwise",), 5: ("hopping", 10, 5), 8: ("tumbling", 10), 7: ("tumbling", 10),
-          9: ("elementwise",), 4: ("elementwise",)}
+          9: ("elementwise",), 4: ("elementwise",), 13: ("elementwise",)}
 
 
 def key(q, seed, eps, seconds):
@@ -190,6 +191,29 @@ def q7_window(c, lo, hi):
     return oracle.multiset_fingerprint([(b["auction"], rows), (b["price"], rows), (b["bidder"], rows), (b["b_date_time"], rows)])   # q7.sql's column order
 
 
+def side_input_of(seed, eps, seconds, stride=6007):
+    """The bounded side input flock_amd.nexmark.synthetic_side_input builds for a generated stream (the reference reads q13's table from
+    a user-supplied CSV in S3, benchmarks/src/nexmark/main.rs:44,353-361): every `stride`-th auction id the bids can name, value = 7 key + 1."""
+    n_auctions = oracle.NexmarkStream(seed=seed, eps=eps).counts(0, seconds * eps)[1]
+    first = 1000
+    key = np.arange(first - first % stride + stride, first + n_auctions + stride, stride, dtype=np.int32)
+    return key, (key * 7 + 1).astype(np.int32)
+
+
+def q13_window(c, lo, hi):
+    pa, pc = _pa()
+    b = {k: v[lo:hi] for k, v in c["bid"].items()}
+    key, value = c["side"]
+    br, sr = oracle.q13_side_join(b["auction"], key)
+    fp = oracle.multiset_fingerprint([(b["auction"], br), (b["bidder"], br), (b["price"], br), (b["b_date_time"], br), (value, sr)])
+    tb = pa.table({"auction": b["auction"], "row": np.arange(hi - lo)})
+    j = tb.join(pa.table({"key": key, "value": value}), keys="auction", right_keys="key", join_type="inner")
+    rows = j["row"].to_numpy()
+    alt = oracle.multiset_fingerprint([(b["auction"], rows), (b["bidder"], rows), (b["price"], rows), (b["b_date_time"], rows), j["value"].to_numpy()])
+    assert fp == alt, (fp, alt)
+    return fp
+
+
 def _winning_bids_pa(a, b):
     """Q of q4.sql / q9.sql through pyarrow: join, BETWEEN, MAX GROUP BY (a_id, category)."""
     pa, pc = _pa()
@@ -224,18 +248,20 @@ def mint(q, seed, eps, seconds, threads):
     rel = {1: {"bid": ("auction", "bidder", "price", "b_date_time")}, 2: {"bid": ("auction", "price")},
            3: {"auction": ("a_id", "seller", "category"), "person": ("p_id", "name", "city", "state")},
            5: {"bid": ("auction",)}, 8: {"auction": ("seller",), "person": ("p_id", "name")},
-           7: {"bid": ("auction", "bidder", "price", "b_date_time")},
+           7: {"bid": ("auction", "bidder", "price", "b_date_time")}, 13: {"bid": ("auction", "bidder", "price", "b_date_time")},
            9: {"auction": ("a_id", "category", "a_date_time", "expires"), "bid": ("auction", "bidder", "price", "b_date_time")},
            4: {"auction": ("a_id", "category", "a_date_time", "expires"), "bid": ("auction", "bidder", "price", "b_date_time")}}[q]
     t0 = time.time()
     c, offs = generate(seed, eps, seconds, rel, threads)
+    if q == 13:
+        c["side"] = side_input_of(seed, eps, seconds)
     wins = windows_of(q, seconds)
 
     def one(w):
         e0, e1 = w
-        if q in (1, 2, 5, 7):
+        if q in (1, 2, 5, 7, 13):
             lo, hi = int(offs["bid"][e0]), int(offs["bid"][e1])
-            return {1: q1_window, 2: q2_window, 5: q5_window, 7: q7_window}[q](c, lo, hi)
+            return {1: q1_window, 2: q2_window, 5: q5_window, 7: q7_window, 13: q13_window}[q](c, lo, hi)
         if q in (4, 9):
             return (q4_window if q == 4 else q9_window)(c, int(offs["auction"][e0]), int(offs["auction"][e1]), int(offs["bid"][e0]), int(offs["bid"][e1]))
         span = (int(offs["auction"][e0]), int(offs["auction"][e1]), int(offs["person"][e0]), int(offs["person"][e1]))
