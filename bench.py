@@ -11,7 +11,7 @@ q5 hot-items over 1.0e9 synthetic bids (1087 s x 1e6 events/s, Hopping(10 s, 5 s
 CPU leg.  q2 / q8 (configs[1], [4]), q3 at 1e9 events, the "next" rows, a PCIe-inclusive q5 and a plan-level
 `collect` run are in "also"; "exchange_1rank" shows what the in-library exchange costs over the plain operators.
 
-N > 1 (`torchrun ... bench.py --gpus N`): north_star's configuration -- the SAME 1e9 bids in total, every window striped
+N > 1 (`torchrun ... bench.py --gpus N`, or plain `python bench.py --gpus N`, which starts the N ranks itself): north_star's configuration -- the SAME 1e9 bids in total, every window striped
 over the N ranks, q5.dag's Partial COUNT -> hash repartition of the groups (RCCL send / recv inside libflockgpu) ->
 FinalPartitioned COUNT / MAX / join -> all-reduce(MAX): "scaling": "strong", value = 1e9 bids / the slowest rank's
 time.  "also" then carries q8 / q3 key-partitioned the same way and the window-sharded q5 (every rank its own slice of
@@ -49,6 +49,15 @@ DOMINANT = {
     9: ("aq_final_kernel", 16.0, "bid"),               # auction + price + b_date_time per bid ("next" query)
     4: ("aq_final_kernel", 16.0, "bid"),
     13: ("q13_flag_kernel", 4.0, "bid"),               # auction per bid: bitmap test, the few candidates probe the table
+}
+# exchange mode (key-partitioned): the pass that reads the rank's RAW rows is the one the stage-0 kernels make --
+# q5.dag's Partial COUNT per tile, q3's stage-0 category filter, q8.dag's Partial DISTINCT of the sellers.  (`q5_count_kernel` there is
+# the weighted instance over the received (auction, count) pairs, `q3_probe_flag_kernel` runs on the filtered rows: billing them the
+# raw column gave fractions above 1 in round 2.)
+DOMINANT_EXCHANGE = {
+    5: ("q5_partial_tile_kernel", 4.0, "bid"),         # auction column of this rank's stripe, once
+    3: ("q3_category_flag_kernel", 4.0, "auction"),    # category column of this rank's stripe, once
+    8: ("tile_distinct_flag_kernel", 4.0, "auction"),  # seller column of this rank's stripe, once
 }
 DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300, 13: 1087}   # 1e9 bids / 1e8 bids / 1e8 events / 1e9 events
 
@@ -184,16 +193,15 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
     return dt, stats, res
 
 
-def roofline(q, stats, rel_rows, steps=None):
-    """steps: when the kernel runs more than once per step (the exchange's q5: Partial over the bids + FinalPartitioned over
-    the groups, both `q5_count_kernel`) the figure is per STEP -- the step's algorithmic bytes over the kernel's time per step."""
-    name, bpr, rel = DOMINANT[q]
+def roofline(q, stats, rel_rows, table=None):
+    """achieved = the dominant kernel's algorithmic bytes per launch / its average launch duration (HIP events on the launch
+    stream inside the timed region).  `table`: DOMINANT (plain operators) or DOMINANT_EXCHANGE (stage-0 kernels of the exchange)."""
+    name, bpr, rel = (table or DOMINANT)[q]
     st = stats.get(name)
     if not st or not st["launches"]:
         return None
     alg_bytes = bpr * rel_rows[rel]
-    per_step = bool(steps) and st["launches"] != steps
-    avg_ms = st["total_ms"] / (steps if per_step else st["launches"])
+    avg_ms = st["total_ms"] / st["launches"]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
     prof = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, measured separately
@@ -205,7 +213,7 @@ def roofline(q, stats, rel_rows, steps=None):
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, not this one)" if traffic else None,
-            "avg_launch_ms": round(avg_ms, 4), **({"avg_launch_ms_is": f"sum of the {st['launches'] // steps} launches of one step"} if per_step else {}),
+            "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes), "launches": st["launches"],
             "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
 
@@ -601,7 +609,7 @@ def exchange_entry(ctx, comm, q, seconds, eps, steps, warmup, rank, world, barri
     del full
     torch.cuda.empty_cache()
     rel = {"bid": st.bids.rows if st.bids else 0, "auction": st.auctions.rows if st.auctions else 0}
-    dt, stats, r = run_steps(ctx, lambda: st.run(ctx, comm), steps, warmup, barrier, DOMINANT[q][0])
+    dt, stats, r = run_steps(ctx, lambda: st.run(ctx, comm), steps, warmup, barrier, DOMINANT_EXCHANGE[q][0])
     dt_max, rows_all = reduce_max_sum(dt, float(st.rows()))
     w = query_window(q)
     e = {"value": round(rows_all * steps / dt_max, 1), "unit": "rows/s", "scaling": "strong", "ms_per_step": round(dt_max / steps * 1e3, 3),
@@ -609,7 +617,7 @@ def exchange_entry(ctx, comm, q, seconds, eps, steps, warmup, rank, world, barri
          "result_rows_rank0": int(r.rows), "seconds_of_events": seconds,
          "workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {eps} events/s striped over {world} GPU(s)",
          "parallelism": f"key-partitioned x{world}: hash repartition + {comm.transport} all-to-all inside libflockgpu",
-         "transport": comm.transport, "ranks": comm.size, "roofline": roofline(q, stats, rel, steps),
+         "transport": comm.transport, "ranks": comm.size, "roofline": roofline(q, stats, rel, DOMINANT_EXCHANGE),
          "kernels_ms_rank0": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
     del st, r
     torch.cuda.empty_cache()
@@ -669,8 +677,161 @@ def plan_collect_pcie_both(gpu, eps, steps):
     return e
 
 
+# ------------------------------------------------------------------ the driver's contract: N ranks, ONE short JSON line
+LAST_LINE_LIMIT = 4000          # bytes; round 2's 22 KB line was not parsed by the driver
+
+
+def visible_devices():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def spawn_ranks(args, argv, n_devices=None, popen=None):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here, one process per GPU, the way
+    `torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` would.  Rank 0's stdout is this process's
+    stdout (its last line is the JSON line); the other ranks' stdout goes to stderr.  Refuses -- non-zero exit, nothing
+    printed on stdout -- when fewer than N devices are visible: never silently a 1-GPU number under `n_gpus: N`."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = visible_devices() if n_devices is None else n_devices
+    if os.environ.get("FLOCK_BENCH_SHARED_GPU") == "1" and have >= 1:
+        have = n      # test hook: the ranks share the visible device(s); RCCL refuses that, which exercises the fall-back path
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible: refusing to run", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    popen = popen or subprocess.Popen
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                           stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("FLOCK_BENCH_SPAWN_TIMEOUT", "1500"))
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+        if pending and (rc != 0 or time.time() > deadline):
+            # a rank died (or the job hangs): stop exactly the processes started here, by PID
+            time.sleep(5.0 if rc != 0 else 0.0)
+            for p in pending:
+                if p.poll() is None:
+                    p.kill()
+            for p in pending:
+                p.wait()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def _sig(x, digits=4):
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _terse_roofline(r):
+    if not r:
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch", "launches")
+    return {k: r[k] for k in keep if k in r}
+
+
+def _terse_cpu(c):
+    if not c:
+        return None
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+    out["sample"] = str(c.get("sample", ""))[:160]
+    if isinstance(c.get("acero"), dict) and "value" in c["acero"]:
+        out["acero"] = {"value": c["acero"]["value"], "cores": c["acero"].get("cores")}
+    return out
+
+
+def final_line(out):
+    """The ONE line the driver parses: headline + config + roofline + cpu_baseline + a terse q3 + one triple per side entry
+    (rows/s, ms per step, roofline fraction).  Everything else -- per-kernel times, samples, notes -- goes to bench_also.json."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = dict(out.get("config") or {})
+    cfg.pop("collective", None)
+    line["config"] = cfg
+    line["roofline"] = _terse_roofline(out.get("roofline"))
+    line["cpu_baseline"] = _terse_cpu(out.get("cpu_baseline"))
+    for k in ("exchange_error", "exchange_phases_ms"):
+        if out.get(k):
+            line[k] = out[k] if not isinstance(out[k], str) else out[k][:300]
+    ws = out.get("window_sharded")
+    if isinstance(ws, dict):   # N > 1: the same ranks without the exchange (every rank its own slice of the stream, "weak")
+        line["window_sharded"] = {"value": ws.get("value"), "ms_per_step": ws.get("ms_per_step"), "scaling": ws.get("scaling"),
+                                  "roofline_frac": (ws.get("roofline") or {}).get("frac")}
+    q3 = out.get("q3")
+    if isinstance(q3, dict):
+        if "error" in q3:
+            line["q3"] = {"error": str(q3["error"])[:120]}
+        else:
+            line["q3"] = {"workload": "NEXMark q3 elementwise, 1e8 events (BASELINE.json configs[2])", "value": q3.get("value"), "unit": "rows/s",
+                          "ms_per_step": q3.get("ms_per_step"), "input_rows": q3.get("input_rows"),
+                          "roofline": {k: v for k, v in (_terse_roofline(q3.get("roofline")) or {}).items()
+                                       if k in ("kernel", "achieved", "frac", "traffic", "avg_launch_ms")},
+                          "cpu_baseline": {k: v for k, v in (_terse_cpu(q3.get("cpu_baseline")) or {}).items() if k != "sample"}}
+    also = out.get("also")
+    terse = {}
+    if isinstance(also, dict):
+        def triple(e):
+            if not isinstance(e, dict) or "value" not in e:
+                return "error" if isinstance(e, dict) and "error" in e else None
+            r = e.get("roofline") or {}
+            return [_sig(float(e["value"])), e.get("ms_per_step"), r.get("frac")]
+        for k, e in also.items():
+            if k == "exchange_1rank" and isinstance(e, dict) and "error" not in e:
+                for k2, e2 in e.items():
+                    t = triple(e2)
+                    if isinstance(t, list) and isinstance(e2, dict) and "over_window_sharded_step" in e2:
+                        t.append(e2["over_window_sharded_step"])
+                    terse[f"x1_{k2}"] = t
+            else:
+                terse[k] = triple(e)
+        line["also_fields"] = ["rows_per_s", "ms_per_step", "roofline_frac"]
+        line["also"] = terse
+        line["also_file"] = out.get("also_file")
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) > LAST_LINE_LIMIT and terse:      # never over the limit: side entries go first, the headline never
+        terse.pop(next(reversed(terse)))
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LAST_LINE_LIMIT:
+        for k in ("also", "also_fields", "q3"):
+            line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_full(out):
+    """The complete measurement record (every side entry with its kernels, samples and notes) next to the short line."""
+    path = os.environ.get("FLOCK_BENCH_ALSO") or os.path.join(ROOT, "gpurun_out", "bench_also.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -678,6 +839,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: flock_amd has no CPU path")
+    if world != args.gpus and "WORLD_SIZE" in os.environ and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} under WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
+    shared_gpu = os.environ.get("FLOCK_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local %= torch.cuda.device_count()
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local}, {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local)
     if args.only_plan_collect:
         from flock_amd import GpuContext
@@ -687,15 +855,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-        tok = torch.zeros(1, device=f"cuda:{local}")
+        if shared_gpu:   # (test hook) two ranks on one device: torch's RCCL group would refuse it as the library's does
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        host_dev = "cpu" if shared_gpu else f"cuda:{local}"
+        tok = torch.zeros(1, device=host_dev)
 
         def barrier():
             dist.all_reduce(tok)
             torch.cuda.synchronize()
 
         def reduce_max_sum(dt, rows):
-            t = torch.tensor([dt, rows], dtype=torch.float64, device=f"cuda:{local}")
+            t = torch.tensor([dt, rows], dtype=torch.float64, device=host_dev)
             tmax = t.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -731,7 +903,47 @@ def main():
         return Comm(h, lib)
 
     out, stream, res = None, None, None
+
+    def windows_headline(steps, warmup, with_cpu):
+        """Every rank runs its own slice of the stream, whole windows, no data-path collective ("weak")."""
+        stream = make_stream(ctx, q, seconds, args.eps, rank)
+        rel_rows, rows = rel_rows_of(stream), input_rows(q, stream)
+        dt, stats, res = run_steps(ctx, lambda: run_query(ctx, q, stream), steps, warmup, barrier, DOMINANT[q][0])
+        dt_max, rows_all = reduce_max_sum(dt, float(rows))
+        o = None
+        if rank == 0:
+            o = {"metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": round(rows_all * steps / dt_max, 1),
+                 "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                 "ms_per_step": round(dt_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                 "dtype": "int32", "data": "synthetic",
+                 "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s per GPU", "query": f"q{q}",
+                            "input_rows_per_gpu": int(rows), "windows_per_gpu": int(res.n_windows),
+                            "parallelism": f"window-sharded x{world} (no data-path collective)", "result_rows": int(res.rows)},
+                 "roofline": roofline(q, stats, rel_rows), "cpu_baseline": None}
+            if with_cpu:
+                o["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
+        del stream, res
+        torch.cuda.empty_cache()
+        return o
+
     if mode == "exchange":
+        # The exchange's ncclSend / ncclRecv pairs between DIFFERENT devices meet real hardware in the driver's multi-GPU run
+        # first.  So: the window-sharded job (no collective in the data path) is measured FIRST and kept as the line to fall back
+        # to; the exchange then runs under a watchdog.  An error falls back with `exchange_error`; a hang (a collective that
+        # never returns cannot be cancelled from inside) makes every rank print-and-leave after the deadline.
+        import threading
+        safe = windows_headline(args.steps, args.warmup, False) if world > 1 else None
+
+        def exchange_hung():
+            if rank == 0 and safe is not None:
+                safe["exchange_error"] = f"watchdog: the key-partitioned exchange did not finish within {hang_s:.0f} s; window-sharded line reported"
+                print(final_line(safe), flush=True)
+            os._exit(0 if safe is not None else 3)
+        hang_s = float(os.environ.get("FLOCK_BENCH_EXCHANGE_TIMEOUT", "300"))
+        dog = threading.Timer(hang_s, exchange_hung)
+        dog.daemon = True
+        if world > 1:
+            dog.start()
         try:
             comm = make_comm()
             head = exchange_entry(ctx, comm, q, seconds, args.eps, args.steps, args.warmup, rank, world, barrier, reduce_max_sum)
@@ -744,30 +956,21 @@ def main():
                                   "collective": {"library": "RCCL (ncclSend / ncclRecv groups inside libflockgpu)", "ranks": head["ranks"],
                                                  "transport": head["transport"]},
                                   "result_rows_rank0": head["result_rows_rank0"]},
-                       "roofline": head["roofline"], "cpu_baseline": None, "kernels_ms_rank0": head["kernels_ms_rank0"]}
+                       "roofline": head["roofline"], "cpu_baseline": None, "kernels_ms_rank0": head["kernels_ms_rank0"],
+                       "exchange_phases_ms": head.get("phases_ms")}
+                if safe is not None:
+                    out["window_sharded"] = {k: safe[k] for k in ("value", "ms_per_step", "scaling", "roofline")}
         except Exception as e:   # the exchange must never take the run with it: fall back to the window-sharded job
             comm_error = repr(e)
             mode = "windows"
-    if mode == "windows":
-        stream = make_stream(ctx, q, seconds, args.eps, rank)
-        rel_rows, rows = rel_rows_of(stream), input_rows(q, stream)
-        dt, stats, res = run_steps(ctx, lambda: run_query(ctx, q, stream), args.steps, args.warmup, barrier, DOMINANT[q][0])
-        dt_max, rows_all = reduce_max_sum(dt, float(rows))
-        if rank == 0:
-            out = {"metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": round(rows_all * args.steps / dt_max, 1),
-                   "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                   "dtype": "int32", "data": "synthetic",
-                   "config": {"workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {args.eps} events/s per GPU", "query": f"q{q}",
-                              "input_rows_per_gpu": int(rows), "windows_per_gpu": int(res.n_windows),
-                              "parallelism": f"window-sharded x{world} (no data-path collective)", "result_rows": int(res.rows)},
-                   "roofline": roofline(q, stats, rel_rows), "cpu_baseline": None}
-            if comm_error:
+            if safe is not None:
+                out = safe
                 out["exchange_error"] = comm_error
-            if world == 1 and not args.no_cpu:
-                out["cpu_baseline"] = cpu_baseline(q, stream, args.cpu_threads)
-        del stream, res
-        torch.cuda.empty_cache()
+        dog.cancel()
+    if mode == "windows" and out is None and not (comm_error and world > 1):
+        out = windows_headline(args.steps, args.warmup, world == 1 and not args.no_cpu)
+        if out is not None and comm_error:
+            out["exchange_error"] = comm_error
 
     steps2 = max(args.steps, 10)   # the side entries' steps are 0.1-5 ms: ten of them cost nothing and average the host's turnaround out
     # ---- N = 1: the other BASELINE configs; q3 (named by the metric) at top level
@@ -826,14 +1029,14 @@ def main():
         def bail():
             if rank == 0 and out is not None:
                 out["also"] = {"error": "watchdog: side measurements did not finish"}
-                print(json.dumps(out), flush=True)
+                print(final_line(out), flush=True)
             os._exit(0)
         dog = threading.Timer(300.0, bail)
         dog.daemon = True
         dog.start()
         also = {}
         try:
-            if comm is not None:
+            if comm is not None and not comm_error:
                 for label, q2 in (("q8_exchange", 8), ("q3_exchange", 3), ("q5_exchange", 5)):
                     if q2 == q and mode == "exchange":
                         continue
@@ -842,15 +1045,6 @@ def main():
                                                      reduce_max_sum)
                     except Exception as e:
                         also[label] = {"error": repr(e)}
-            if mode == "exchange":
-                s5 = make_stream(ctx, q, seconds, args.eps, rank)
-                d2, st2, r2 = run_steps(ctx, lambda: run_query(ctx, q, s5), steps2, 1, barrier, DOMINANT[q][0])
-                dmax, rall = reduce_max_sum(d2, float(input_rows(q, s5)))
-                also[f"q{q}_window_sharded"] = {"value": round(rall * steps2 / dmax, 1), "unit": "rows/s", "scaling": "weak",
-                                                "ms_per_step": round(dmax / steps2 * 1e3, 3), "input_rows_all_gpus": int(rall),
-                                                "parallelism": f"window-sharded x{world}: every rank its own {seconds} s slice of the stream, no data-path collective",
-                                                "roofline": roofline(q, st2, rel_rows_of(s5))}
-                del s5, r2
         except Exception as e:
             also["error"] = repr(e)
         dog.cancel()
@@ -869,7 +1063,14 @@ def main():
     except Exception:
         pass
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if out is None:
+            raise SystemExit("bench.py: no measurement was produced")
+        out["also_file"] = os.path.relpath(os.environ.get("FLOCK_BENCH_ALSO") or os.path.join(ROOT, "gpurun_out", "bench_also.json"), ROOT)
+        if write_full(out) is None:
+            out["also_file"] = None
+        if os.environ.get("FLOCK_BENCH_VERBOSE"):
+            print(json.dumps(out), file=sys.stderr, flush=True)
+        print(final_line(out), flush=True)
 
 
 if __name__ == "__main__":

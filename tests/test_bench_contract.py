@@ -40,3 +40,140 @@ def test_launch_scopes_name_real_kernels():
     for f in glob.glob(os.path.join(ROOT, "flock_amd", "csrc", "*.hip")):
         for label in re.findall(r'LaunchScope\s+ls\(ctx,\s*"(\w+)"\)', open(f).read()):
             assert label in kernels, (os.path.basename(f), label)
+
+
+def _fat_out():
+    """A measurement record shaped like a full default run, with the prose that made round 2's line 22 KB."""
+    roof = {"bound": "hbm", "kernel": "q5_count_kernel", "achieved": 5311.3, "peak": 8000.0, "unit": "GB/s", "frac": 0.6639, "traffic": 4353122634,
+            "traffic_source": "x" * 120, "avg_launch_ms": 0.7531, "algorithmic_bytes_per_launch": 4000160000, "launches": 20,
+            "kernels_ms": {f"kernel_number_{i}_kernel": 0.01 * i for i in range(30)}}
+    cpu = {"value": 105387299.4, "unit": "rows/s", "cores": 64, "kind": "port", "sample": "s" * 400, "seconds": 20.1,
+           "pass_seconds": {"mean": 2.9, "min": 2.8, "max": 3.0}, "acero": {"value": 1.4e8, "unit": "rows/s", "cores": 256, "kind": "port", "sample": "a" * 300}}
+    entry = {"value": 6.88e11, "unit": "rows/s", "ms_per_step": 0.146, "input_rows": 100280000, "windows": 109, "result_rows": 815280,
+             "roofline": dict(roof), "cpu_baseline": dict(cpu), "note": "n" * 300}
+    also = {f"entry_{i}_next": dict(entry) for i in range(24)}
+    also["broken"] = {"error": "RuntimeError('boom')"}
+    also["exchange_1rank"] = {"q5": dict(entry, over_window_sharded_step=1.6), "q3": dict(entry), "q8": {"error": "x"}}
+    return {"metric": "NEXMark rows/sec per node (q3 join, q5 agg)", "value": 9.8e11, "unit": "rows/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 1.017, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "NEXMark q5 hopping(10,5) over 1087 s x 1000000 events/s per GPU", "query": "q5", "input_rows_per_gpu": 1000040000,
+                       "windows_per_gpu": 216, "parallelism": "window-sharded x1 (no data-path collective)", "result_rows": 229},
+            "roofline": roof, "cpu_baseline": cpu, "q3": dict(entry), "also": also, "also_file": "gpurun_out/bench_also.json"}
+
+
+def test_last_line_is_short_and_carries_roofline_and_cpu_baseline():
+    import json
+    import bench
+    line = bench.final_line(_fat_out())
+    assert "\n" not in line and len(line) < 4096, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["config"]["workload"].startswith("NEXMark q5") and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["q3"]["roofline"]["frac"] <= 1 and d["also"]["entry_0_next"][0] > 0 and d["also"]["broken"] == "error"
+    # an absurdly large record still ends in a parseable line below the limit (side entries are dropped first)
+    fat = _fat_out()
+    fat["also"].update({f"more_{i}": dict(fat["q3"]) for i in range(400)})
+    line = bench.final_line(fat)
+    assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] > 0
+
+
+def test_exchange_mode_bills_the_kernels_that_read_the_raw_rows():
+    """Round 2 charged the raw column to kernels that run on filtered / pre-aggregated rows (fractions above 1)."""
+    import bench
+    kernels = _kernel_names()
+    assert bench.DOMINANT_EXCHANGE[5][0] == "q5_partial_tile_kernel" and bench.DOMINANT_EXCHANGE[3][0] == "q3_category_flag_kernel"
+    for q, (name, bpr, rel) in bench.DOMINANT_EXCHANGE.items():
+        assert name in kernels and name != bench.DOMINANT[q][0] and bpr == 4.0
+    stats = {"q5_partial_tile_kernel": {"launches": 10, "total_ms": 9.0}, "q5_count_kernel": {"launches": 10, "total_ms": 3.8}}
+    r = bench.roofline(5, stats, {"bid": 1_000_040_000, "auction": 0}, bench.DOMINANT_EXCHANGE)
+    assert r["kernel"] == "q5_partial_tile_kernel" and 0.5 < r["frac"] < 0.6
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks(monkeypatch):
+    import bench
+
+    class FakeProc:
+        started = []
+
+        def __init__(self, cmd, env=None, stdout=None):
+            self.cmd, self.env, self.stdout = cmd, env, stdout
+            FakeProc.started.append(self)
+
+        def poll(self):
+            return 0
+
+        def wait(self):
+            return 0
+
+        def kill(self):
+            pass
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse()
+    # fewer devices than ranks: refuse, start nothing
+    assert bench.spawn_ranks(args, sys.argv[1:], n_devices=1, popen=FakeProc) != 0 and not FakeProc.started
+    assert bench.spawn_ranks(args, sys.argv[1:], n_devices=2, popen=FakeProc) == 0
+    assert [p.env["RANK"] for p in FakeProc.started] == ["0", "1"] and all(p.env["WORLD_SIZE"] == "2" for p in FakeProc.started)
+    assert all(p.env["MASTER_ADDR"] == "127.0.0.1" and p.env["LOCAL_RANK"] == p.env["RANK"] for p in FakeProc.started)
+    assert len({p.env["MASTER_PORT"] for p in FakeProc.started}) == 1
+    assert FakeProc.started[0].stdout is None and FakeProc.started[1].stdout is sys.stderr      # only rank 0 owns stdout
+    assert FakeProc.started[0].cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    # main() takes that branch (and exits with the spawn's status) before touching torch / the GPU
+    called = {}
+    monkeypatch.setattr(bench, "spawn_ranks", lambda a, argv: called.setdefault("rc", 7))
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 7
+    assert called == {"rc": 7}
+
+
+def test_a_dead_rank_fails_the_job(monkeypatch):
+    import bench
+
+    class Proc:
+        def __init__(self, cmd, env=None, stdout=None):
+            self.rank, self.killed = int(env["RANK"]), False
+
+        def poll(self):
+            return 3 if self.rank == 1 else (-9 if self.killed else None)
+
+        def wait(self):
+            return 0
+
+        def kill(self):
+            self.killed = True
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setattr(bench.time, "sleep", lambda s: None)
+    assert bench.spawn_ranks(bench.parse(), ["--gpus", "2"], n_devices=2, popen=Proc) == 3
+
+
+@__import__("pytest").mark.gpu
+def test_bench_prints_one_short_line_on_the_gpu(tmp_path):
+    import json
+    import subprocess
+    env = dict(os.environ, FLOCK_BENCH_ALSO=str(tmp_path / "also.json"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--seconds", "60", "--steps", "3", "--warmup", "1", "--no-also"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    d = json.loads(last)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "q5_count_kernel"
+    assert d["cpu_baseline"] is None or d["cpu_baseline"]["value"] > 0
+    assert json.load(open(tmp_path / "also.json"))["value"] == d["value"]
+    # --gpus beyond the visible devices: refused, non-zero, no JSON on stdout
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-also", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in env.items() if k != "WORLD_SIZE"})
+    assert p.returncode != 0 and "{" not in p.stdout
