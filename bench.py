@@ -210,6 +210,8 @@ def roofline(q, stats, rel_rows, table=None):
             traffic = json.load(open(prof)).get(name)
         except Exception:
             traffic = None
+        if traffic and not (0.9 * alg_bytes <= traffic <= 3.0 * alg_bytes):
+            traffic = None      # the PMC passes were taken at the default workload size: not this run's bytes
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, not this one)" if traffic else None,
@@ -611,8 +613,20 @@ def exchange_entry(ctx, comm, q, seconds, eps, steps, warmup, rank, world, barri
     rel = {"bid": st.bids.rows if st.bids else 0, "auction": st.auctions.rows if st.auctions else 0}
     dt, stats, r = run_steps(ctx, lambda: st.run(ctx, comm), steps, warmup, barrier, DOMINANT_EXCHANGE[q][0])
     dt_max, rows_all = reduce_max_sum(dt, float(st.rows()))
+    # the call's stream timeline by phase (HIP events at the phase boundaries inside the library), three untimed calls
+    phases = None
+    try:
+        comm.phases(True)
+        for _ in range(3):
+            st.run(ctx, comm)
+        torch.cuda.synchronize()
+        phases = {k: round(v["total_ms"] / max(v["calls"], 1), 4) for k, v in comm.phase_times().items()}
+        comm.phases(False)
+        barrier()
+    except Exception as ex:
+        phases = {"error": repr(ex)}
     w = query_window(q)
-    e = {"value": round(rows_all * steps / dt_max, 1), "unit": "rows/s", "scaling": "strong", "ms_per_step": round(dt_max / steps * 1e3, 3),
+    e = {"value": round(rows_all * steps / dt_max, 1), "unit": "rows/s", "scaling": "strong", "phases_ms": phases, "ms_per_step": round(dt_max / steps * 1e3, 3),
          "input_rows_all_gpus": int(rows_all), "input_rows_this_rank": int(st.rows()), "windows": int(r.n_windows),
          "result_rows_rank0": int(r.rows), "seconds_of_events": seconds,
          "workload": f"NEXMark q{q} {w.kind}({w.size},{w.hop}) over {seconds} s x {eps} events/s striped over {world} GPU(s)",

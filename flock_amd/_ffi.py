@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflockgpu.so")
 
-OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_PLAN = range(7)
+OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_PLAN, ERR_PEER = range(8)
 H2D, D2H, D2D = 1, 2, 3
 ABI_VERSION = 1
 
@@ -218,6 +218,10 @@ SYMBOLS = {
     "flockgpu_comm_size": (_i, [_vp]),
     "flockgpu_comm_transport": (C.c_char_p, [_vp]),
     "flockgpu_comm_barrier": (_i, [_vp, _vp]),
+    "flockgpu_comm_inject_failure": (_i, [_vp, _i]),
+    "flockgpu_comm_phase_enable": (_i, [_vp, _i]),
+    "flockgpu_comm_phase_reset": (_i, [_vp]),
+    "flockgpu_comm_phase_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     "flockgpu_q5_hot_items_exchange": (_i, [_vp, _vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
     "flockgpu_q3_join_exchange": (_i, [_vp, _vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),
                                        C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),

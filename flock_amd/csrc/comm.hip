@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -29,16 +30,25 @@ struct LocalGroup {
     std::vector<const int64_t *> send_off;         // per rank: n + 1 byte offsets of its per-destination runs
     std::vector<const int64_t *> counts;           // per rank: host array of n * m values
     std::vector<uint64_t *> reduce;                // per rank: host array being max-reduced
-    void barrier() {
+    bool failed = false;                           // a rank left a collective with an error: the group is dead, nobody waits for it again
+    // false: some rank of the group failed (before or while this one waited) -- the caller returns an error instead of waiting forever
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
         const uint64_t gen = generation;
         if (++waiting == n) {
             waiting = 0;
             ++generation;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            return true;
         }
+        cv.wait(lk, [&] { return generation != gen || failed; });
+        return generation != gen;
+    }
+    void poison() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
     }
 };
 
@@ -46,14 +56,74 @@ constexpr int64_t kMaxPeerBytes = int64_t(1) << 30;  // RCCL transfers above 2 G
 
 }  // namespace
 
+struct PhaseMark {
+    const char *name;
+    hipEvent_t ev;
+};
+
 struct flockgpu_comm {
     int n = 1, rank = 0;
     bool is_rccl = false;
+    bool dead = false;   // a collective failed on this rank: every later call returns an error at once (the peers' state is unknown)
     ncclComm_t nccl = nullptr;
     std::shared_ptr<LocalGroup> local;
+    // per-phase stream timeline of the exchange calls (flockgpu_comm_phase_*): events on the ctx stream at the phase boundaries
+    bool phases_on = false;
+    std::vector<PhaseMark> marks;
+    std::vector<hipEvent_t> ev_pool;
+    std::map<std::string, flockgpu::KernelStat> phase_stats;
+    std::vector<std::string> phase_order;
+    int inject = 0;      // flockgpu_comm_inject_failure: 1 = the next exchange's preparation fails, 2 = its data movement fails
 };
 
 namespace {
+
+// A rank that fails inside the protocol takes its communicator down: the local group is poisoned (peers waiting at a barrier wake
+// up with an error), the RCCL communicator is aborted (this rank's queued sends / receives are cancelled; peers that already wait
+// on them are beyond help from here, which is why every data-dependent failure is AGREED on in the counts exchange before any
+// data moves -- see exchange_relation).
+void kill_comm(flockgpu_comm *c) {
+    if (c->dead) return;
+    c->dead = true;
+    if (c->local) c->local->poison();
+    if (c->nccl) {
+        (void)ncclCommAbort(c->nccl);
+        c->nccl = nullptr;
+    }
+}
+
+void phase_begin(flockgpu_comm *c) {   // marks a failed call left behind
+    for (auto &m : c->marks) c->ev_pool.push_back(m.ev);
+    c->marks.clear();
+}
+void phase_mark(flockgpu_ctx *ctx, flockgpu_comm *c, const char *name) {
+    if (!c->phases_on) return;
+    hipEvent_t e = nullptr;
+    if (!c->ev_pool.empty()) {
+        e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        return;
+    }
+    (void)hipEventRecord(e, ctx->stream);
+    c->marks.push_back({name, e});
+}
+// closes the call's timeline: phase i lasted from its mark to the next one (idle gaps while the host waited belong to the phase they follow)
+void phase_finish(flockgpu_ctx *ctx, flockgpu_comm *c) {
+    if (!c->phases_on || c->marks.empty()) return;
+    phase_mark(ctx, c, "end");
+    (void)hipEventSynchronize(c->marks.back().ev);
+    for (size_t i = 0; i + 1 < c->marks.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->marks[i].ev, c->marks[i + 1].ev) != hipSuccess) continue;
+        if (!c->phase_stats.count(c->marks[i].name)) c->phase_order.push_back(c->marks[i].name);
+        flockgpu::KernelStat &st = c->phase_stats[c->marks[i].name];
+        st.launches += 1;
+        st.total_ms += ms;
+    }
+    for (auto &m : c->marks) c->ev_pool.push_back(m.ev);
+    c->marks.clear();
+}
 
 #define FG_NCCL(ctx, expr)                                                                                               \
     do {                                                                                                                 \
@@ -72,9 +142,9 @@ int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, in
     if (!c->is_rccl) {
         LocalGroup &g = *c->local;
         g.counts[(size_t)c->rank] = send;
-        g.barrier();
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
         for (int s = 0; s < n; ++s) std::copy(g.counts[(size_t)s] + (size_t)c->rank * m, g.counts[(size_t)s] + (size_t)(c->rank + 1) * m, recv + (size_t)s * m);
-        g.barrier();  // nobody rewrites its send array before everyone has read it
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");  // nobody rewrites its send array before everyone has read it
         return FLOCKGPU_OK;
     }
     int64_t *d = nullptr, *h = nullptr;
@@ -108,21 +178,30 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
     }
     if (!c->is_rccl) {
         LocalGroup &g = *c->local;
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // this rank's send buffer is complete
+        // A failure of this rank between the two barriers must not leave the peers waiting at the second one: the work in between
+        // runs to its end (or to its first error), the rank still arrives at the barrier, and only then reports -- the caller
+        // (exchange_relation) takes the communicator down, which wakes every peer's NEXT wait with an error.
+        int rc = FLOCKGPU_OK;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: stream synchronisation before the all-to-all failed");  // this rank's send buffer is complete
         g.send_ptr[(size_t)c->rank] = send;
         g.send_off[(size_t)c->rank] = send_off;
-        g.barrier();
-        for (int s = 0; s < n; ++s) {
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
+        for (int s = 0; s < n && rc == FLOCKGPU_OK; ++s) {
             const int64_t *so = g.send_off[(size_t)s];
             const int64_t bytes = so[c->rank + 1] - so[c->rank];
-            if (bytes != recv_off[s + 1] - recv_off[s]) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s,
-                                                                    (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
-            if (bytes && !(skip_self && s == c->rank))
-                FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream));
+            if (bytes != recv_off[s + 1] - recv_off[s]) {
+                rc = fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s, (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
+                break;
+            }
+            if (bytes && !(skip_self && s == c->rank)) {
+                const hipError_t e = hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream);
+                if (e != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: copy from rank %d failed: %s", s, hipGetErrorString(e));
+            }
         }
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        g.barrier();  // every rank has pulled its runs: send buffers may be reused
-        return FLOCKGPU_OK;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == FLOCKGPU_OK) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: stream synchronisation after the all-to-all failed");
+        const bool met = g.barrier();  // every rank has pulled its runs: send buffers may be reused
+        if (rc != FLOCKGPU_OK) return rc;
+        return met ? FLOCKGPU_OK : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
     }
     // rounds of at most kMaxPeerBytes per (source, destination) pair: both ends of a pair know its size from the counts
     // exchange, so they post the same sequence of sends / receives for it -- no agreement on a global round count needed
@@ -144,31 +223,51 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
     return FLOCKGPU_OK;
 }
 
-// host array of m values, max over the ranks (synchronises)
-int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, uint64_t *vals, int m) {
+// host array of m values, max over the ranks (synchronises).  `entry_rc`: this rank's status so far -- it travels as one more value,
+// so a rank that failed earlier in the call still takes part (its peers do not wait for it forever) and EVERY rank returns an error.
+int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, uint64_t *vals, int m) {
     const int n = c->n;
-    if (n == 1 || m == 0) return FLOCKGPU_OK;
+    if (n == 1) return entry_rc;
+    if (c->dead) return entry_rc != FLOCKGPU_OK ? entry_rc : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: the communicator is dead (an earlier collective failed)");
+    const std::string first_error = ctx->last_error;
+    std::vector<uint64_t> &buf = ctx->host_u64["comm.reduce_buf"];
+    buf.assign(vals, vals + m);
+    buf.push_back((uint64_t)entry_rc);
+    const int mm = m + 1;
     if (!c->is_rccl) {
         LocalGroup &g = *c->local;
-        g.reduce[(size_t)c->rank] = vals;
-        g.barrier();
-        std::vector<uint64_t> mx(vals, vals + m);
-        for (int s = 0; s < n; ++s)
-            for (int j = 0; j < m; ++j) mx[(size_t)j] = std::max(mx[(size_t)j], g.reduce[(size_t)s][j]);
-        g.barrier();  // everyone has read the inputs
-        std::copy(mx.begin(), mx.end(), vals);
-        g.barrier();
-        return FLOCKGPU_OK;
+        g.reduce[(size_t)c->rank] = buf.data();
+        bool met = g.barrier();
+        std::vector<uint64_t> mx(buf);
+        for (int s = 0; s < n && met; ++s)
+            for (int j = 0; j < mm; ++j) mx[(size_t)j] = std::max(mx[(size_t)j], g.reduce[(size_t)s][j]);
+        met = met && g.barrier();  // everyone has read the inputs
+        if (!met) return entry_rc != FLOCKGPU_OK ? entry_rc : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
+        buf = mx;
+    } else {
+        uint64_t *d = nullptr, *h = nullptr;
+        int rc = arena_get_t(ctx, "comm.reduce", (size_t)mm + 2, &d);
+        if (rc == FLOCKGPU_OK) rc = pinned_get_t(ctx, "comm.reduce", (size_t)mm + 2, &h);
+        if (rc == FLOCKGPU_OK) rc = [&]() -> int {
+            std::copy(buf.begin(), buf.end(), h);
+            FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(uint64_t) * (size_t)mm, hipMemcpyHostToDevice, ctx->stream));
+            FG_NCCL(ctx, ncclAllReduce(d, d, (size_t)mm, ncclUint64, ncclMax, c->nccl, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(uint64_t) * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            std::copy(h, h + mm, buf.begin());
+            return FLOCKGPU_OK;
+        }();
+        if (rc != FLOCKGPU_OK) {   // the transport itself failed on this rank
+            kill_comm(c);
+            return entry_rc != FLOCKGPU_OK ? entry_rc : rc;
+        }
     }
-    uint64_t *d = nullptr, *h = nullptr;
-    FG_TRY(arena_get_t(ctx, "comm.reduce", (size_t)m + 2, &d));
-    FG_TRY(pinned_get_t(ctx, "comm.reduce", (size_t)m + 2, &h));
-    std::copy(vals, vals + m, h);
-    FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(uint64_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
-    FG_NCCL(ctx, ncclAllReduce(d, d, (size_t)m, ncclUint64, ncclMax, c->nccl, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(uint64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::copy(h, h + m, vals);
+    if (entry_rc != FLOCKGPU_OK) {
+        ctx->last_error = first_error;
+        return entry_rc;
+    }
+    if (buf[(size_t)m] != 0) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: another rank failed with status %llu", (unsigned long long)buf[(size_t)m]);
+    std::copy(buf.begin(), buf.begin() + m, vals);
     return FLOCKGPU_OK;
 }
 
@@ -230,19 +329,19 @@ __global__ __launch_bounds__(kBlock) void regroup_index_kernel(const int64_t *__
     }
 }
 
-// dst[out_start[run] ...] = src[src_start[run] ...] for every run, `width` bytes per row: grid (shares per run, runs).  Runs start at
+// dst[out_start[run] ...] = src[src_start[run] ...] for every run, `width` bytes per row: grid = per_run shares x runs.  Runs start at
 // arbitrary rows, so the body moves 4-byte words (rows are 4 or 8 bytes wide: always whole words).
 // src_start[run] >= 0: a row of the received buffer; < 0: row -1 - src_start[run] of this rank's own send buffer (its chunk is not copied
 // to itself first).
 __global__ __launch_bounds__(kBlock) void regroup_copy_kernel(const int64_t *__restrict__ out_start, const int64_t *__restrict__ src_start,
                                                               const uint8_t *__restrict__ src, const uint8_t *__restrict__ self_src,
-                                                              uint8_t *__restrict__ dst, int32_t width) {
-    const int run = blockIdx.y;
+                                                              uint8_t *__restrict__ dst, int32_t width, int32_t per_run) {
+    const int run = (int)(blockIdx.x / (unsigned)per_run);   // (runs in grid.x: grid.y stops at 65535, 64 ranks x 1087 panes do not)
     const int64_t words = (out_start[run + 1] - out_start[run]) * (width / 4);
     const int64_t s0 = src_start[run];
     const uint32_t *s = reinterpret_cast<const uint32_t *>(s0 >= 0 ? src + s0 * width : self_src + (-1 - s0) * width);
     uint32_t *d = reinterpret_cast<uint32_t *>(dst + out_start[run] * width);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (int64_t)gridDim.x * kBlock) d[i] = s[i];
+    for (int64_t i = (int64_t)(blockIdx.x % (unsigned)per_run) * kBlock + threadIdx.x; i < words; i += (int64_t)per_run * kBlock) d[i] = s[i];
 }
 
 inline unsigned grid_for(flockgpu_ctx *ctx, int64_t n) {
@@ -277,50 +376,25 @@ struct XRecv {
 // `name` keys the arena buffers (they must outlive the operator that consumes the result).
 // `base_rows` (may be null): the relation is a row selection of a larger one (a filter ran first); columns marked `indirect` are taken
 // straight from the original columns through it -- their values are never compacted on their own, only taken in send order.
-int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &name, const std::vector<XCol> &cols, int key_col, int64_t rows,
+//
+// Failure protocol (a per-rank error must become an error on EVERY rank, never a rank waiting for a peer that has left):
+//   * `entry_rc`: the rank's status when it arrives (a stage before the exchange may have failed); a failed rank skips its
+//     preparation but STILL takes part in the counts exchange, whose message carries the status -- every rank then returns;
+//   * data-dependent limits of the RECEIVING side (2^31 rows / Utf8 bytes per rank) are decided from totals every rank announces to
+//     every rank, so all ranks reach the same verdict before a single data byte moves;
+//   * what can fail after that is the transport or the device itself: that rank takes its communicator down (kill_comm).
+int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, const std::string &name, const std::vector<XCol> &cols, int key_col, int64_t rows,
                       const flockgpu_windows *win, XRecv *out, const int32_t *base_rows = nullptr) {
     const int n = c->n, n_win = win->n_windows;
-    if (cols[(size_t)key_col].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: the key column must be given compacted");
-    for (auto &col : cols)
-        if (col.indirect && !base_rows) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: an indirect column without the row selection");
-    // ---- partition, send-order gathers and the per-destination Utf8 byte counts are queued back to back; the host waits ONCE
-    // for the group offsets, the Utf8 totals and the run bytes together.  (No wait for the pinned staging of `upload`: the previous
-    // call that used these names ended with the operator's own synchronisation.)
-    const int32_t *part_rows = nullptr;
-    const int64_t *d_group_off = nullptr, *pw = nullptr;  // pw: n * n_win + 1 group offsets, destination-major (pinned, valid after the wait)
-    int64_t n_send = 0;
-    // the 4-byte columns ride in the partition's emit pass (send order written directly); 8-byte and Utf8 columns are taken below
-    int64_t covered = 0;
-    for (int w = 0; w < n_win; ++w) covered += win->pane_row_offsets[win->win_pane_hi[w]] - win->pane_row_offsets[win->win_pane_lo[w]];
-    PartPayload payload;
-    std::vector<int> payload_of(cols.size(), -1);
-    for (size_t i = 0; i < cols.size(); ++i) {
-        if (cols[i].utf8() || cols[i].width != 4 || payload.n == 4 || cols[i].indirect) continue;
-        void *p = nullptr;
-        FG_TRY(arena_get(ctx, (name + ".send" + std::to_string(i)).c_str(), (size_t)covered * 4 + 16, &p));
-        payload.src[payload.n] = static_cast<const int32_t *>(cols[i].values);
-        payload.dst[payload.n] = static_cast<int32_t *>(p);
-        payload_of[i] = payload.n++;
-    }
-    payload.skip_rows = true;
-    for (size_t i = 0; i < cols.size(); ++i) payload.skip_rows = payload.skip_rows && payload_of[i] >= 0;
-    FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send, &payload,
-                                  (name + ".part").c_str()));
-    const int32_t *src_rows = part_rows;   // rows of the columns' own row space, in send order
-    bool any_indirect = false;
-    for (auto &col : cols) any_indirect = any_indirect || col.indirect;
-    if (any_indirect) {
-        int32_t *comp = nullptr;
-        FG_TRY(arena_get_t(ctx, (name + ".comp_rows").c_str(), (size_t)n_send + 4, &comp));
-        FG_TRY(gather_i32(ctx, base_rows, part_rows, n_send, comp));
-        src_rows = comp;
-    }
-    auto rows_of = [&](const XCol &col) { return col.indirect ? src_rows : part_rows; };
-    int64_t *d_run_start = nullptr;
-    FG_TRY(arena_get_t(ctx, (name + ".run_start").c_str(), (size_t)n + 2, &d_run_start));
-    hipLaunchKernelGGL(pick_run_starts_kernel, dim3(1), dim3(64), 0, ctx->stream, d_group_off, n_win, n, d_run_start);
-    FG_TRY(check_launch(ctx, "pick_run_starts_kernel"));
-
+    if (c->dead) return entry_rc != FLOCKGPU_OK ? entry_rc : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: the communicator is dead (an earlier collective failed)");
+    phase_mark(ctx, c, "partition+take");
+    int n_utf8 = 0;
+    std::vector<size_t> ucols;  // the Utf8 columns: gathered together (one row list, one length pass, one scan, one emit)
+    for (size_t i = 0; i < cols.size(); ++i)
+        if (cols[i].utf8()) {
+            ucols.push_back(i);
+            ++n_utf8;
+        }
     struct Sent {
         const void *values = nullptr;
         flockgpu_utf8 u{};
@@ -328,79 +402,191 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         unsigned long long *d_run_bytes = nullptr, *h_run_bytes = nullptr;
     };
     std::vector<Sent> sent(cols.size());
-    int n_utf8 = 0;
-    std::vector<size_t> ucols;  // the Utf8 columns: gathered together (one row list, one length pass, one scan, one emit)
-    for (size_t i = 0; i < cols.size(); ++i)
-        if (cols[i].utf8()) ucols.push_back(i);
-    if (ucols.size() > 4) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: more than four Utf8 columns in one relation");
-    Utf8MultiGather g_send, g_recv;
-    if (!ucols.empty()) {
-        flockgpu_utf8 srcs[4];
-        for (size_t j = 0; j < ucols.size(); ++j) {
-            srcs[j] = flockgpu_utf8{cols[ucols[j]].offsets, static_cast<const uint8_t *>(cols[ucols[j]].values)};
-            if (cols[ucols[j]].indirect != cols[ucols[0]].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: Utf8 columns of one relation must share their row space");
-        }
-        FG_TRY(gather_utf8_multi_begin(ctx, (name + ".sendu").c_str(), srcs, (int)ucols.size(), rows_of(cols[ucols[0]]), n_send, &g_send));
-    }
-    for (size_t i = 0; i < cols.size(); ++i) {
-        const XCol &col = cols[i];
-        const std::string key = name + ".send" + std::to_string(i);
-        if (col.utf8()) {
-            ++n_utf8;
-            FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
-            FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
-            FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
-            if (n_send > 0) {
-                LaunchScope ls(ctx, "run_bytes_kernel");
-                hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, rows_of(col),
-                                   d_run_start, sent[i].d_run_bytes);
-            }
-            FG_TRY(check_launch(ctx, "run_bytes_kernel"));
-            FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        } else if (payload_of[i] >= 0) {
-            sent[i].values = payload.dst[payload_of[i]];
-        } else {
-            void *p = nullptr;
-            FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
-            if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), rows_of(col), n_send, static_cast<int32_t *>(p)));
-            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), rows_of(col), n_send, static_cast<int64_t *>(p)));
-            sent[i].values = p;
-        }
-    }
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ucols.empty()) {
-        flockgpu_utf8 outs[4];
-        int64_t nb[4];
-        FG_TRY(gather_utf8_multi_finish(ctx, g_send, outs, nb));
-        for (size_t j = 0; j < ucols.size(); ++j) {
-            sent[ucols[j]].u = outs[j];
-            sent[ucols[j]].bytes = nb[j];
-        }
-    }
-    std::vector<int64_t> run_start((size_t)n + 1);
-    for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
-    if (run_start[(size_t)n] != n_send) return fail(ctx, FLOCKGPU_ERR_HIP, "exchange: the partition pass covered %lld of %lld rows", (long long)run_start[(size_t)n], (long long)n_send);
+    const int64_t *pw = nullptr;  // n * n_win + 1 group offsets, destination-major (pinned, valid after the wait)
+    int64_t n_send = 0;
+    int64_t *d_run_start = nullptr;
+    std::vector<int64_t> run_start((size_t)n + 1, 0);
 
-    // ---- counts: rows per (destination, window) + bytes per Utf8 column per destination, one message per peer
-    const int m = n_win + n_utf8;
-    std::vector<int64_t> send_counts((size_t)n * m), recv_counts((size_t)n * m);
-    for (int d = 0; d < n; ++d) {
-        for (int w = 0; w < n_win; ++w) send_counts[(size_t)d * m + w] = pw[(size_t)d * n_win + w + 1] - pw[(size_t)d * n_win + w];
-        int u = 0;
-        for (size_t i = 0; i < cols.size(); ++i)
-            if (cols[i].utf8()) send_counts[(size_t)d * m + n_win + u++] = (int64_t)sent[i].h_run_bytes[d];
+    // ---- partition, send-order gathers and the per-destination Utf8 byte counts are queued back to back; the host waits ONCE
+    // for the group offsets, the Utf8 totals and the run bytes together.  (No wait for the pinned staging of `upload`: the previous
+    // call that used these names ended with the operator's own synchronisation.)
+    auto prepare = [&]() -> int {
+        if (c->inject == 1) {
+            c->inject = 0;
+            return fail(ctx, FLOCKGPU_ERR_CAPACITY, "exchange of '%s': injected failure on rank %d (test hook)", name.c_str(), c->rank);
+        }
+        if (cols[(size_t)key_col].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: the key column must be given compacted");
+        for (auto &col : cols)
+            if (col.indirect && !base_rows) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: an indirect column without the row selection");
+        if (ucols.size() > 4) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: more than four Utf8 columns in one relation");
+        const int32_t *part_rows = nullptr;
+        const int64_t *d_group_off = nullptr;
+        // the 4-byte columns ride in the partition's emit pass (send order written directly); 8-byte and Utf8 columns are taken below
+        int64_t covered = 0;
+        for (int w = 0; w < n_win; ++w) covered += win->pane_row_offsets[win->win_pane_hi[w]] - win->pane_row_offsets[win->win_pane_lo[w]];
+        PartPayload payload;
+        std::vector<int> payload_of(cols.size(), -1);
+        for (size_t i = 0; i < cols.size(); ++i) {
+            if (cols[i].utf8() || cols[i].width != 4 || payload.n == 4 || cols[i].indirect) continue;
+            void *p = nullptr;
+            FG_TRY(arena_get(ctx, (name + ".send" + std::to_string(i)).c_str(), (size_t)covered * 4 + 16, &p));
+            payload.src[payload.n] = static_cast<const int32_t *>(cols[i].values);
+            payload.dst[payload.n] = static_cast<int32_t *>(p);
+            payload_of[i] = payload.n++;
+        }
+        payload.skip_rows = true;
+        for (size_t i = 0; i < cols.size(); ++i) payload.skip_rows = payload.skip_rows && payload_of[i] >= 0;
+        FG_TRY(partition_by_key_async(ctx, static_cast<const int32_t *>(cols[(size_t)key_col].values), rows, win, n, &part_rows, &d_group_off, &pw, &n_send, &payload,
+                                      (name + ".part").c_str()));
+        const int32_t *src_rows = part_rows;   // rows of the columns' own row space, in send order
+        bool any_indirect = false;
+        for (auto &col : cols) any_indirect = any_indirect || col.indirect;
+        if (any_indirect) {
+            int32_t *comp = nullptr;
+            FG_TRY(arena_get_t(ctx, (name + ".comp_rows").c_str(), (size_t)n_send + 4, &comp));
+            FG_TRY(gather_i32(ctx, base_rows, part_rows, n_send, comp));
+            src_rows = comp;
+        }
+        auto rows_of = [&](const XCol &col) { return col.indirect ? src_rows : part_rows; };
+        FG_TRY(arena_get_t(ctx, (name + ".run_start").c_str(), (size_t)n + 2, &d_run_start));
+        hipLaunchKernelGGL(pick_run_starts_kernel, dim3(1), dim3(64), 0, ctx->stream, d_group_off, n_win, n, d_run_start);
+        FG_TRY(check_launch(ctx, "pick_run_starts_kernel"));
+        Utf8MultiGather g_send;
+        if (!ucols.empty()) {
+            flockgpu_utf8 srcs[4];
+            for (size_t j = 0; j < ucols.size(); ++j) {
+                srcs[j] = flockgpu_utf8{cols[ucols[j]].offsets, static_cast<const uint8_t *>(cols[ucols[j]].values)};
+                if (cols[ucols[j]].indirect != cols[ucols[0]].indirect) return fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: Utf8 columns of one relation must share their row space");
+            }
+            FG_TRY(gather_utf8_multi_begin(ctx, (name + ".sendu").c_str(), srcs, (int)ucols.size(), rows_of(cols[ucols[0]]), n_send, &g_send));
+        }
+        for (size_t i = 0; i < cols.size(); ++i) {
+            const XCol &col = cols[i];
+            const std::string key = name + ".send" + std::to_string(i);
+            if (col.utf8()) {
+                FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
+                FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
+                FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
+                if (n_send > 0) {
+                    LaunchScope ls(ctx, "run_bytes_kernel");
+                    hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, rows_of(col),
+                                       d_run_start, sent[i].d_run_bytes);
+                }
+                FG_TRY(check_launch(ctx, "run_bytes_kernel"));
+                FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+            } else if (payload_of[i] >= 0) {
+                sent[i].values = payload.dst[payload_of[i]];
+            } else {
+                void *p = nullptr;
+                FG_TRY(arena_get(ctx, key.c_str(), (size_t)n_send * col.width + 16, &p));
+                if (col.width == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(col.values), rows_of(col), n_send, static_cast<int32_t *>(p)));
+                else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(col.values), rows_of(col), n_send, static_cast<int64_t *>(p)));
+                sent[i].values = p;
+            }
+        }
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!ucols.empty()) {
+            flockgpu_utf8 outs[4];
+            int64_t nb[4];
+            FG_TRY(gather_utf8_multi_finish(ctx, g_send, outs, nb));
+            for (size_t j = 0; j < ucols.size(); ++j) {
+                sent[ucols[j]].u = outs[j];
+                sent[ucols[j]].bytes = nb[j];
+            }
+        }
+        for (int d = 0; d <= n; ++d) run_start[(size_t)d] = pw[(size_t)d * n_win];
+        if (run_start[(size_t)n] != n_send) return fail(ctx, FLOCKGPU_ERR_HIP, "exchange: the partition pass covered %lld of %lld rows", (long long)run_start[(size_t)n], (long long)n_send);
+        return FLOCKGPU_OK;
+    };
+    int rc = entry_rc;
+    if (rc == FLOCKGPU_OK) rc = prepare();
+    const std::string first_error = ctx->last_error;
+
+    // ---- counts: rows per (destination, window) + bytes per Utf8 column per destination, one message per peer.  The message also
+    // carries this rank's status and -- the same in every copy -- its row / byte totals for EVERY destination, from which every rank
+    // computes what every rank will receive.
+    phase_mark(ctx, c, "counts");
+    const int m = n_win + n_utf8;                 // per-destination part
+    const int tot = n * (1 + n_utf8);             // totals[d * (1 + n_utf8) + {0: rows, 1 + u: bytes of Utf8 column u}]
+    const int mm = m + 1 + tot;
+    std::vector<int64_t> send_counts((size_t)n * mm, 0), recv_counts((size_t)n * mm, 0);
+    if (rc == FLOCKGPU_OK) {
+        std::vector<int64_t> totals((size_t)tot, 0);
+        for (int d = 0; d < n; ++d) {
+            totals[(size_t)d * (1 + n_utf8)] = run_start[(size_t)d + 1] - run_start[(size_t)d];
+            for (int w = 0; w < n_win; ++w) send_counts[(size_t)d * mm + w] = pw[(size_t)d * n_win + w + 1] - pw[(size_t)d * n_win + w];
+            int u = 0;
+            for (size_t i = 0; i < cols.size(); ++i)
+                if (cols[i].utf8()) {
+                    send_counts[(size_t)d * mm + n_win + u] = (int64_t)sent[i].h_run_bytes[d];
+                    totals[(size_t)d * (1 + n_utf8) + 1 + u] = (int64_t)sent[i].h_run_bytes[d];
+                    ++u;
+                }
+        }
+        for (int d = 0; d < n; ++d) std::copy(totals.begin(), totals.end(), send_counts.begin() + (size_t)d * mm + m + 1);
     }
-    FG_TRY(exchange_counts(ctx, c, send_counts.data(), m, recv_counts.data()));
+    for (int d = 0; d < n; ++d) send_counts[(size_t)d * mm + m] = rc;
+    {
+        const int rc2 = exchange_counts(ctx, c, send_counts.data(), mm, recv_counts.data());
+        if (rc2 != FLOCKGPU_OK) {   // the transport failed under this rank
+            kill_comm(c);
+            if (rc != FLOCKGPU_OK) ctx->last_error = first_error;
+            return rc != FLOCKGPU_OK ? rc : rc2;
+        }
+    }
+    if (rc != FLOCKGPU_OK) {   // the peers have been told
+        ctx->last_error = first_error;
+        return rc;
+    }
+    for (int s = 0; s < n; ++s)
+        if (recv_counts[(size_t)s * mm + m] != 0)
+            return fail(ctx, FLOCKGPU_ERR_PEER, "exchange of '%s': rank %d failed with status %lld before the repartition", name.c_str(), s, (long long)recv_counts[(size_t)s * mm + m]);
+    for (int d = 0; d < n; ++d) {   // the same verdict on every rank: what rank d is going to receive
+        int64_t r = 0;
+        for (int s = 0; s < n; ++s) r += recv_counts[(size_t)s * mm + m + 1 + (size_t)d * (1 + n_utf8)];
+        if (r >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange of '%s': rank %d would receive %lld rows (limit 2^31 per rank and call)", name.c_str(), d, (long long)r);
+        for (int u = 0; u < n_utf8; ++u) {
+            int64_t by = 0;
+            for (int s = 0; s < n; ++s) by += recv_counts[(size_t)s * mm + m + 1 + (size_t)d * (1 + n_utf8) + 1 + u];
+            if (by >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange of '%s': a Utf8 column received by rank %d would hold %lld bytes (Arrow int32 offsets)", name.c_str(), d, (long long)by);
+        }
+    }
+    phase_mark(ctx, c, "all_to_all+regroup");
+
+    out->cols.assign(cols.size(), DevColumn{});
+    if (n == 1) {
+        // Hash([key], 1): one destination, so send order IS window order -- the send buffers are the result (the regrouping copies and
+        // the Utf8 regroup take were a pure copy of them: 0.32 ms per 8e7 q5 groups, the person strings of q3 / q8 moved a second time)
+        out->rows = n_send;
+        out->win_off.assign(pw, pw + n_win + 1);
+        for (size_t i = 0; i < cols.size(); ++i) {
+            DevColumn &o = out->cols[i];
+            if (cols[i].utf8()) {
+                o.type = ColType::UTF8;
+                o.values = sent[i].u.data;
+                o.offsets = sent[i].u.offsets;
+                o.bytes = sent[i].bytes;
+            } else {
+                o.type = cols[i].width == 4 ? ColType::I32 : ColType::I64;
+                o.values = sent[i].values;
+            }
+        }
+        return FLOCKGPU_OK;
+    }
 
     // ---- received layout: source-major runs; windows want (window, source) order
+    auto move = [&]() -> int {
+    if (c->inject == 2) {
+        c->inject = 0;
+        return fail(ctx, FLOCKGPU_ERR_HIP, "exchange of '%s': injected transport failure on rank %d (test hook)", name.c_str(), c->rank);
+    }
     std::vector<int64_t> recv_rows_off((size_t)n + 1, 0);
     for (int s = 0; s < n; ++s) {
         int64_t r = 0;
-        for (int w = 0; w < n_win; ++w) r += recv_counts[(size_t)s * m + w];
+        for (int w = 0; w < n_win; ++w) r += recv_counts[(size_t)s * mm + w];
         recv_rows_off[(size_t)s + 1] = recv_rows_off[(size_t)s] + r;
     }
     const int64_t n_recv = recv_rows_off[(size_t)n];
-    if (n_recv >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: a rank would receive more than 2^31 rows");
     const int n_runs = n * n_win;
     std::vector<int64_t> out_start((size_t)n_runs + 1), src_start((size_t)n_runs + 1);
     out->win_off.assign((size_t)n_win + 1, 0);
@@ -411,7 +597,7 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         for (int w = 0; w < n_win; ++w) {
             out->win_off[(size_t)w] = pos;
             for (int s = 0; s < n; ++s) {
-                const int64_t cnt = recv_counts[(size_t)s * m + w];
+                const int64_t cnt = recv_counts[(size_t)s * mm + w];
                 out_start[(size_t)w * n + s] = pos;
                 src_start[(size_t)w * n + s] = src_pos[(size_t)s];
                 src_pos[(size_t)s] += cnt;
@@ -438,7 +624,6 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
     FG_TRY(check_launch(ctx, "regroup_index_kernel"));
 
     // ---- one all-to-all per column buffer, then the regrouping take
-    out->cols.assign(cols.size(), DevColumn{});
     out->rows = n_recv;
     std::vector<int64_t> so((size_t)n + 1), ro((size_t)n + 1);
     int u = 0;
@@ -461,8 +646,8 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
                 LaunchScope ls(ctx, "regroup_copy_kernel");
                 const unsigned per_run = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(div_up(n_recv, n_runs) * col.width, (int64_t)kBlock * 16 * 4),
                                                                                            std::max<int64_t>(1, (int64_t)ctx->num_cus * 16 / n_runs)));
-                hipLaunchKernelGGL(regroup_copy_kernel, dim3(per_run, (unsigned)n_runs), dim3(kBlock), 0, ctx->stream, d_out_start, d_src_self,
-                                   static_cast<const uint8_t *>(raw), static_cast<const uint8_t *>(sent[i].values), static_cast<uint8_t *>(fin), col.width);
+                hipLaunchKernelGGL(regroup_copy_kernel, dim3(per_run * (unsigned)n_runs), dim3(kBlock), 0, ctx->stream, d_out_start, d_src_self,
+                                   static_cast<const uint8_t *>(raw), static_cast<const uint8_t *>(sent[i].values), static_cast<uint8_t *>(fin), col.width, (int32_t)per_run);
             }
             FG_TRY(check_launch(ctx, "regroup_copy_kernel"));
             out->cols[i].type = col.width == 4 ? ColType::I32 : ColType::I64;
@@ -473,12 +658,11 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         std::vector<int64_t> send_delta((size_t)n), recv_delta((size_t)n), sb((size_t)n + 1, 0), rb((size_t)n + 1, 0);
         for (int p = 0; p < n; ++p) {
             sb[(size_t)p + 1] = sb[(size_t)p] + (int64_t)sent[i].h_run_bytes[p];
-            rb[(size_t)p + 1] = rb[(size_t)p] + recv_counts[(size_t)p * m + n_win + u];
+            rb[(size_t)p + 1] = rb[(size_t)p] + recv_counts[(size_t)p * mm + n_win + u];
             send_delta[(size_t)p] = -sb[(size_t)p];
             recv_delta[(size_t)p] = rb[(size_t)p];
         }
         ++u;
-        if (rb[(size_t)n] >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: a received Utf8 column exceeds 2^31 bytes");
         int64_t *d_sd = nullptr, *d_rd = nullptr, *d_rro = nullptr;
         FG_TRY(upload(ctx, key + ".sdelta", send_delta.data(), (size_t)n, &d_sd));
         FG_TRY(upload(ctx, key + ".rdelta", recv_delta.data(), (size_t)n, &d_rd));
@@ -507,6 +691,7 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         recv_bytes_total[i] = rb[(size_t)n];
     }
     if (!ucols.empty()) {  // the regrouping take of the Utf8 columns: a permutation keeps the byte totals, so no host wait
+        Utf8MultiGather g_recv;
         flockgpu_utf8 srcs[4], outs[4];
         int64_t known[4], nb[4];
         for (size_t j = 0; j < ucols.size(); ++j) {
@@ -524,6 +709,10 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, const std::string &na
         }
     }
     return FLOCKGPU_OK;
+    };
+    rc = move();
+    if (rc != FLOCKGPU_OK) kill_comm(c);   // past the agreement: the peers are already moving data
+    return rc;
 }
 
 flockgpu_windows single_pane_windows(const std::vector<int64_t> &win_off, std::vector<int32_t> &lo, std::vector<int32_t> &hi) {
@@ -598,6 +787,8 @@ int flockgpu_comm_init_local(int n_ranks, flockgpu_comm **out) {
 void flockgpu_comm_destroy(flockgpu_comm *comm) {
     if (!comm) return;
     if (comm->nccl) (void)ncclCommDestroy(comm->nccl);
+    for (auto &m : comm->marks) (void)hipEventDestroy(m.ev);
+    for (hipEvent_t e : comm->ev_pool) (void)hipEventDestroy(e);
     delete comm;
 }
 int flockgpu_comm_rank(const flockgpu_comm *comm) { return comm ? comm->rank : -1; }
@@ -609,21 +800,62 @@ int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm) {
     FG_TRY(check_comm(ctx, comm, "barrier"));
     FG_HIP(ctx, hipSetDevice(ctx->device));
     uint64_t one = 1;
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return all_reduce_max(ctx, comm, &one, 1);
+    int rc = FLOCKGPU_OK;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "barrier: stream synchronisation failed");
+    return all_reduce_max(ctx, comm, rc, &one, 1);
 }
 
+int flockgpu_comm_inject_failure(flockgpu_comm *comm, int where) {
+    if (!comm || where < 0 || where > 2) return FLOCKGPU_ERR_INVALID;
+    comm->inject = where;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_comm_phase_enable(flockgpu_comm *comm, int on) {
+    if (!comm) return FLOCKGPU_ERR_INVALID;
+    comm->phases_on = on != 0;
+    return FLOCKGPU_OK;
+}
+int flockgpu_comm_phase_reset(flockgpu_comm *comm) {
+    if (!comm) return FLOCKGPU_ERR_INVALID;
+    comm->phase_stats.clear();
+    comm->phase_order.clear();
+    return FLOCKGPU_OK;
+}
+int flockgpu_comm_phase_read(flockgpu_comm *comm, flockgpu_kernel_stat *out, int cap, int *n) {
+    if (!comm || !n || (cap > 0 && !out)) return FLOCKGPU_ERR_INVALID;
+    int i = 0;
+    for (const std::string &name : comm->phase_order) {
+        if (i < cap) {
+            const flockgpu::KernelStat &st = comm->phase_stats[name];
+            std::snprintf(out[i].name, sizeof out[i].name, "%s", name.c_str());
+            out[i].launches = st.launches;
+            out[i].total_ms = st.total_ms;
+        }
+        ++i;
+    }
+    *n = i;
+    return FLOCKGPU_OK;
+}
+
+// Argument errors (null pointers, malformed schedules) are the HOST's bug and are reported at once, before any collective: a host
+// that passes them on one rank only breaks the "every rank calls the same entry points" contract.  Everything that can fail at
+// RUN time (device errors, capacity limits, data-dependent refusals) goes through the status-carrying collectives, so that it
+// becomes an error on every rank (exchange_relation, all_reduce_max).
 int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
                                    flockgpu_q5_result *out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_TRY(check_comm(ctx, comm, "q5 exchange"));
+    phase_begin(comm);
     if (!bid || !win || !out || bid->rows < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 exchange: null argument");
+    FG_TRY(check_windows(ctx, win, bid->rows, "q5 exchange"));
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_panes = win->n_panes, n_win = win->n_windows;
+    phase_mark(ctx, comm, "partial");
     // stage 0 (q5.dag): HashAggregateExec mode=Partial on this rank's rows, pane by pane
     // (per 8192-row tile: one pass over the bids, pairs written straight into the pane's region -- gather.hpp: Q5TilePartial)
     Q5TilePartial part;
-    FG_TRY(q5_partial_by_tile(ctx, bid, win, &part));
+    int rc = q5_partial_by_tile(ctx, bid, win, &part);
     // RepartitionExec Hash([auction], n): the groups of every pane, one "window" per pane.  The schedule names the used part of every
     // region (pane 2p) and leaves the unused space behind it (pane 2p + 1) out of every window.
     std::vector<int32_t> lo((size_t)std::max(n_panes, 1)), hi(lo.size());
@@ -631,27 +863,39 @@ int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const
         lo[(size_t)p] = 2 * p;
         hi[(size_t)p] = 2 * p + 1;
     }
+    if (rc != FLOCKGPU_OK) part.offsets.assign((size_t)2 * n_panes + 1, 0);
     const flockgpu_windows panes{part.offsets.data(), 2 * n_panes, lo.data(), hi.data(), n_panes};
     XRecv got;
-    FG_TRY(exchange_relation(ctx, comm, "xq5", {XCol{part.auction, nullptr, 4}, XCol{part.count, nullptr, 4}}, 0, part.capacity, &panes, &got));
+    rc = exchange_relation(ctx, comm, rc, "xq5", {XCol{part.auction, nullptr, 4}, XCol{part.count, nullptr, 4}}, 0, part.capacity, &panes, &got);
     // stage 1: FinalPartitioned COUNT + MAX + join over the groups this rank owns (windows over the received panes)
-    const flockgpu_windows recv_win{got.win_off.data(), n_panes, win->win_pane_lo, win->win_pane_hi, n_win};
+    phase_mark(ctx, comm, "final");
     flockgpu_q5_result local{};
-    FG_TRY(flockgpu_q5_hot_items_weighted(ctx, static_cast<const int32_t *>(got.cols[0].values), static_cast<const uint32_t *>(got.cols[1].values),
-                                          got.rows, &recv_win, &local));
+    if (rc == FLOCKGPU_OK) {
+        const flockgpu_windows recv_win{got.win_off.data(), n_panes, win->win_pane_lo, win->win_pane_hi, n_win};
+        rc = flockgpu_q5_hot_items_weighted(ctx, static_cast<const int32_t *>(got.cols[0].values), static_cast<const uint32_t *>(got.cols[1].values), got.rows,
+                                            &recv_win, &local);
+    }
     // MAX across the partitions (q5.dag: Partial MAX per partition -> CoalescePartitions -> Final MAX), 8 bytes per window
+    phase_mark(ctx, comm, "all_reduce_max");
     std::vector<uint64_t> &gmax = ctx->host_u64["xq5.win_max"];
-    gmax.assign(local.win_max, local.win_max + n_win);
-    FG_TRY(all_reduce_max(ctx, comm, gmax.data(), n_win));
+    if (rc == FLOCKGPU_OK) gmax.assign(local.win_max, local.win_max + n_win);
+    else gmax.assign((size_t)n_win, 0);
+    rc = all_reduce_max(ctx, comm, rc, gmax.data(), n_win);
+    if (rc != FLOCKGPU_OK) {
+        phase_finish(ctx, comm);
+        return rc;
+    }
     // the join num = maxn: windows whose local maximum is below the global one keep none of their rows.  Winners of a
     // window are contiguous; keep-runs are copied down on the device.
     std::vector<int64_t> &offs = ctx->host_i64["xq5.win_out_offsets"];
     offs.assign((size_t)n_win + 1, 0);
     std::vector<int64_t> runs((size_t)3 * std::max(n_win, 1), 0);  // src | dst | len per window
     int64_t pos = 0;
+    bool all_kept = true;
     for (int w = 0; w < n_win; ++w) {
         const int64_t a = local.win_out_offsets[w], b = local.win_out_offsets[w + 1];
         const bool keep = b > a && gmax[(size_t)w] > 0 && local.win_max[w] == gmax[(size_t)w];
+        all_kept = all_kept && (keep || b == a);
         offs[(size_t)w] = pos;
         runs[(size_t)w] = a;
         runs[(size_t)n_win + w] = pos;
@@ -659,6 +903,18 @@ int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const
         if (keep) pos += b - a;
     }
     offs[(size_t)n_win] = pos;
+    std::vector<uint64_t> &grp = ctx->host_u64["xq5.win_groups"];
+    grp.assign(local.win_groups, local.win_groups + n_win);
+    out->win_out_offsets = offs.data();
+    out->win_max = gmax.data();
+    out->win_groups = grp.data();
+    out->rows = pos;
+    if (all_kept) {   // every window's local maximum is the global one (always so on one rank): the local winners ARE the result
+        out->auction = local.auction;
+        out->num = local.num;
+        phase_finish(ctx, comm);
+        return FLOCKGPU_OK;
+    }
     int32_t *o_a = nullptr;
     uint64_t *o_n = nullptr;
     int64_t *d_runs = nullptr;
@@ -670,14 +926,9 @@ int flockgpu_q5_hot_items_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const
                            local.num, o_a, o_n);
         FG_TRY(check_launch(ctx, "copy_runs_kernel"));
     }
-    std::vector<uint64_t> &grp = ctx->host_u64["xq5.win_groups"];
-    grp.assign(local.win_groups, local.win_groups + n_win);
     out->auction = o_a;
     out->num = o_n;
-    out->win_out_offsets = offs.data();
-    out->win_max = gmax.data();
-    out->win_groups = grp.data();
-    out->rows = pos;
+    phase_finish(ctx, comm);
     return FLOCKGPU_OK;
 }
 
@@ -686,62 +937,91 @@ int flockgpu_q3_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const floc
                               const char *const *state_lits, int n_state_lits, flockgpu_q3_result *out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_TRY(check_comm(ctx, comm, "q3 exchange"));
+    phase_begin(comm);
     if (!auction || !person || !auction_win || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3 exchange: null argument");
+    FG_TRY(check_windows(ctx, auction_win, auction->rows, "q3 exchange"));
+    FG_TRY(check_windows(ctx, person_win, person->rows, "q3 exchange"));
     FG_TRY(check_single_panes(ctx, auction_win, "q3 exchange"));
     FG_TRY(check_single_panes(ctx, person_win, "q3 exchange"));
+    if (auction_win->n_windows != person_win->n_windows) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3 exchange: the two schedules differ in their window count");
     FG_HIP(ctx, hipSetDevice(ctx->device));
+    phase_mark(ctx, comm, "stage0 filters");
     // stage 0 of planner.rs:152-171 runs BEFORE the repartition: FilterExec category = lit on the auctions, state = a OR b OR ... on the
     // persons; only the rows they keep are partitioned and travel (the join below filters again: a no-op on what arrives)
     Q3Stage0 f;
-    FG_TRY(q3_stage0_filters(ctx, auction, auction_win, person, person_win, category_lit, state_lits, n_state_lits, &f));
+    int32_t *a_key = nullptr, *p_key = nullptr;   // the partition keys of the kept rows (the other columns are taken through the row lists)
+    int rc = [&]() -> int {
+        FG_TRY(q3_stage0_filters(ctx, auction, auction_win, person, person_win, category_lit, state_lits, n_state_lits, &f));
+        FG_TRY(arena_get_t(ctx, "xq3a.key", (size_t)f.n_auctions + 4, &a_key));
+        FG_TRY(arena_get_t(ctx, "xq3p.key", (size_t)f.n_persons + 4, &p_key));
+        FG_TRY(gather_i32(ctx, auction->seller, f.auction_rows, f.n_auctions, a_key));
+        FG_TRY(gather_i32(ctx, person->p_id, f.person_rows, f.n_persons, p_key));
+        return FLOCKGPU_OK;
+    }();
+    if (rc != FLOCKGPU_OK) {   // a failed rank still walks through both exchanges (with empty schedules of the right shape)
+        f.auction_off.assign((size_t)auction_win->n_windows + 1, 0);
+        f.person_off.assign((size_t)person_win->n_windows + 1, 0);
+    }
     std::vector<int32_t> falo, fahi, fplo, fphi;
     const flockgpu_windows faw = single_pane_windows(f.auction_off, falo, fahi), fpw = single_pane_windows(f.person_off, fplo, fphi);
-    int32_t *a_key = nullptr, *p_key = nullptr;   // the partition keys of the kept rows (the other columns are taken through the row lists)
-    FG_TRY(arena_get_t(ctx, "xq3a.key", (size_t)f.n_auctions + 4, &a_key));
-    FG_TRY(arena_get_t(ctx, "xq3p.key", (size_t)f.n_persons + 4, &p_key));
-    FG_TRY(gather_i32(ctx, auction->seller, f.auction_rows, f.n_auctions, a_key));
-    FG_TRY(gather_i32(ctx, person->p_id, f.person_rows, f.n_persons, p_key));
     XRecv a, p;
-    FG_TRY(exchange_relation(ctx, comm, "xq3a", {XCol{auction->a_id, nullptr, 4, true}, XCol{a_key, nullptr, 4}, XCol{auction->category, nullptr, 4, true}}, 1,
-                             f.n_auctions, &faw, &a, f.auction_rows));
-    FG_TRY(exchange_relation(ctx, comm, "xq3p",
-                             {XCol{p_key, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0, true}, XCol{person->city.data, person->city.offsets, 0, true},
-                              XCol{person->state.data, person->state.offsets, 0, true}},
-                             0, f.n_persons, &fpw, &p, f.person_rows));
-    std::vector<int32_t> alo, ahi, plo, phi;
-    const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
-    auto u = [](const DevColumn &c) { return flockgpu_utf8{c.offsets, static_cast<const uint8_t *>(c.values)}; };
-    const flockgpu_auction_cols ac{static_cast<const int32_t *>(a.cols[0].values), static_cast<const int32_t *>(a.cols[1].values),
-                                   static_cast<const int32_t *>(a.cols[2].values), a.rows};
-    const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values), u(p.cols[1]), u(p.cols[2]), u(p.cols[3]), p.rows};
-    return flockgpu_q3_join(ctx, &ac, &aw, &pc, &pw, category_lit, state_lits, n_state_lits, out);
+    rc = exchange_relation(ctx, comm, rc, "xq3a", {XCol{auction->a_id, nullptr, 4, true}, XCol{a_key, nullptr, 4}, XCol{auction->category, nullptr, 4, true}}, 1,
+                           f.n_auctions, &faw, &a, f.auction_rows);
+    rc = exchange_relation(ctx, comm, rc, "xq3p",
+                           {XCol{p_key, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0, true}, XCol{person->city.data, person->city.offsets, 0, true},
+                            XCol{person->state.data, person->state.offsets, 0, true}},
+                           0, f.n_persons, &fpw, &p, f.person_rows);
+    phase_mark(ctx, comm, "join");
+    if (rc == FLOCKGPU_OK) {
+        std::vector<int32_t> alo, ahi, plo, phi;
+        const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
+        auto u = [](const DevColumn &c) { return flockgpu_utf8{c.offsets, static_cast<const uint8_t *>(c.values)}; };
+        const flockgpu_auction_cols ac{static_cast<const int32_t *>(a.cols[0].values), static_cast<const int32_t *>(a.cols[1].values),
+                                       static_cast<const int32_t *>(a.cols[2].values), a.rows};
+        const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values), u(p.cols[1]), u(p.cols[2]), u(p.cols[3]), p.rows};
+        rc = flockgpu_q3_join(ctx, &ac, &aw, &pc, &pw, category_lit, state_lits, n_state_lits, out);
+    }
+    phase_finish(ctx, comm);
+    return rc;
 }
 
 int flockgpu_q8_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
                               const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win, flockgpu_q8_result *out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_TRY(check_comm(ctx, comm, "q8 exchange"));
+    phase_begin(comm);
     if (!auction || !person || !auction_win || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q8 exchange: null argument");
+    FG_TRY(check_windows(ctx, auction_win, auction->rows, "q8 exchange"));
+    FG_TRY(check_windows(ctx, person_win, person->rows, "q8 exchange"));
     FG_TRY(check_single_panes(ctx, auction_win, "q8 exchange"));
     FG_TRY(check_single_panes(ctx, person_win, "q8 exchange"));
+    if (auction_win->n_windows != person_win->n_windows) return fail(ctx, FLOCKGPU_ERR_INVALID, "q8 exchange: the two schedules differ in their window count");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     XRecv a, p;
-    FG_TRY(exchange_relation(ctx, comm, "xq8p", {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}}, 0, person->rows, person_win, &p));
+    int rc = exchange_relation(ctx, comm, FLOCKGPU_OK, "xq8p", {XCol{person->p_id, nullptr, 4}, XCol{person->name.data, person->name.offsets, 0}}, 0, person->rows,
+                               person_win, &p);
     // q8.dag: HashAggregateExec(Partial) gby=[seller] before the repartition -- the sellers travel as their per-tile DISTINCT values
     // (3/4 of a window's auctions name one of a few hot sellers), the FinalPartitioned DISTINCT is the join's own seller set
+    phase_mark(ctx, comm, "partial distinct");
     const int32_t *sellers = nullptr;
     std::vector<int64_t> seller_off;
     int64_t n_sellers = 0;
-    FG_TRY(tile_distinct_i32(ctx, "xq8a.distinct", auction->seller, auction->rows, auction_win, &sellers, &seller_off, &n_sellers));
+    if (rc == FLOCKGPU_OK) rc = tile_distinct_i32(ctx, "xq8a.distinct", auction->seller, auction->rows, auction_win, &sellers, &seller_off, &n_sellers);
+    if (rc != FLOCKGPU_OK) seller_off.assign((size_t)auction_win->n_windows + 1, 0);
     std::vector<int32_t> slo, shi;
     const flockgpu_windows seller_win = single_pane_windows(seller_off, slo, shi);
-    FG_TRY(exchange_relation(ctx, comm, "xq8a", {XCol{sellers, nullptr, 4}}, 0, n_sellers, &seller_win, &a));
-    std::vector<int32_t> alo, ahi, plo, phi;
-    const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
-    const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values),
-                                  flockgpu_utf8{p.cols[1].offsets, static_cast<const uint8_t *>(p.cols[1].values)}, {nullptr, nullptr}, {nullptr, nullptr}, p.rows};
-    const flockgpu_auction_cols ac{nullptr, static_cast<const int32_t *>(a.cols[0].values), nullptr, a.rows};
-    return flockgpu_q8_join(ctx, &pc, &pw, &ac, &aw, out);
+    rc = exchange_relation(ctx, comm, rc, "xq8a", {XCol{sellers, nullptr, 4}}, 0, n_sellers, &seller_win, &a);
+    phase_mark(ctx, comm, "join");
+    if (rc == FLOCKGPU_OK) {
+        std::vector<int32_t> alo, ahi, plo, phi;
+        const flockgpu_windows aw = single_pane_windows(a.win_off, alo, ahi), pw = single_pane_windows(p.win_off, plo, phi);
+        const flockgpu_person_cols pc{static_cast<const int32_t *>(p.cols[0].values),
+                                      flockgpu_utf8{p.cols[1].offsets, static_cast<const uint8_t *>(p.cols[1].values)}, {nullptr, nullptr}, {nullptr, nullptr}, p.rows};
+        const flockgpu_auction_cols ac{nullptr, static_cast<const int32_t *>(a.cols[0].values), nullptr, a.rows};
+        rc = flockgpu_q8_join(ctx, &pc, &pw, &ac, &aw, out);
+    }
+    phase_finish(ctx, comm);
+    return rc;
 }
 
 }  // extern "C"

@@ -330,6 +330,24 @@ class Comm:
             self._lib.flockgpu_comm_destroy(self.h)
             self.h = None
 
+    def inject_failure(self, where: int):
+        """Test hook (include/flockgpu_comm.h): 1 = the next exchange fails before the agreement, 2 = after it."""
+        if self._lib.flockgpu_comm_inject_failure(self.h, where) != _ffi.OK:
+            raise FlockGpuError(_ffi.ERR_INVALID, "flockgpu_comm_inject_failure: bad argument")
+
+    def phases(self, on: bool = True, reset: bool = True):
+        """Per-phase stream timeline of this rank's exchange calls on / off."""
+        self._lib.flockgpu_comm_phase_enable(self.h, 1 if on else 0)
+        if reset:
+            self._lib.flockgpu_comm_phase_reset(self.h)
+
+    def phase_times(self) -> dict:
+        """{phase: {"calls": n, "total_ms": t}} since the last reset, in the order the phases first ran."""
+        n = C.c_int(0)
+        buf = (_ffi.KernelStat * 32)()
+        self._lib.flockgpu_comm_phase_read(self.h, buf, 32, C.byref(n))
+        return {buf[i].name.decode(): {"calls": int(buf[i].launches), "total_ms": float(buf[i].total_ms)} for i in range(min(n.value, 32))}
+
     @staticmethod
     def local(n_ranks: int):
         """n_ranks handles for ranks that are threads of this process (flockgpu_comm_init_local)."""

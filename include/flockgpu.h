@@ -40,7 +40,8 @@ enum {
     FLOCKGPU_ERR_OOM = 3,         /* device arena allocation failed                           */
     FLOCKGPU_ERR_UNSUPPORTED = 4, /* plan shape / size outside what the kernels implement     */
     FLOCKGPU_ERR_CAPACITY = 5,    /* hash table overflow after the retry budget               */
-    FLOCKGPU_ERR_PLAN = 6         /* plan JSON could not be parsed / matched                  */
+    FLOCKGPU_ERR_PLAN = 6,        /* plan JSON could not be parsed / matched                  */
+    FLOCKGPU_ERR_PEER = 7         /* exchange: another rank of the communicator failed (flockgpu_comm.h); this rank's inputs are fine */
 };
 
 typedef struct flockgpu_ctx flockgpu_ctx;

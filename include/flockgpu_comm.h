@@ -70,6 +70,26 @@ int flockgpu_q8_join_exchange(flockgpu_ctx *ctx, flockgpu_comm *comm, const floc
 /* Host barrier + stream synchronisation across the ranks (benchmark bracketing). */
 int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm);
 
+/* Failure semantics.  Every rank calls the same entry points in the same order with valid arguments (argument errors are
+ * returned at once, before any collective).  A failure at RUN time on one rank -- a device error, a capacity limit, a
+ * data-dependent refusal such as "rank 3 would receive more than 2^31 rows" -- is carried in the exchange's own messages
+ * (the counts exchange before any data moves, the closing all-reduce), so EVERY rank returns: the failing rank its own status,
+ * the others FLOCKGPU_ERR_PEER.  Nobody is left waiting for a rank that has gone.  A failure of the transport itself (RCCL /
+ * device lost) marks the communicator dead on that rank: its later calls fail at once, a local group wakes its waiting peers
+ * (reference: a failed function fails the whole query, flock-function/src/aws/actor.rs:425-543). */
+
+/* Test hook for the failure semantics above: the next exchange call of this rank fails in its preparation (where = 1: a run-time
+ * failure BEFORE the agreement -- every rank returns, the communicator stays usable) or in its data movement (where = 2: a
+ * transport failure AFTER it -- this rank's communicator dies and wakes its local peers).  0 clears. */
+int flockgpu_comm_inject_failure(flockgpu_comm *comm, int where);
+
+/* Per-phase timeline of the exchange calls on this rank's stream (HIP events at the phase boundaries: partial / stage-0
+ * filters, partition + take, counts, all-to-all + regroup, final / join, all-reduce).  Off by default; totals accumulate over
+ * the calls since the last reset and are read back like the kernel statistics (name, calls, total ms). */
+int flockgpu_comm_phase_enable(flockgpu_comm *comm, int on);
+int flockgpu_comm_phase_reset(flockgpu_comm *comm);
+int flockgpu_comm_phase_read(flockgpu_comm *comm, flockgpu_kernel_stat *out, int cap, int *n);
+
 #ifdef __cplusplus
 }
 #endif

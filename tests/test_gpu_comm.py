@@ -176,3 +176,140 @@ def test_exchange_through_rccl_one_rank(host):
     ctx.comm_barrier(comm)
     comm.close()
     ctx.close()
+
+
+def _run_ranks_collect(world, body, comms=None, ctxs=None, timeout=60):
+    """Like _run_ranks, but every rank's outcome is returned (value or exception) -- for the failure-semantics tests."""
+    import torch
+    from flock_amd import Comm, GpuContext
+    own = comms is None
+    comms = comms or Comm.local(world)
+    ctxs = ctxs or [GpuContext(0, own_stream=True) for _ in range(world)]
+    out = [None] * world
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            out[r] = ("ok", body(r, ctxs[r], comms[r]))
+        except BaseException as e:      # noqa: BLE001
+            out[r] = ("error", e)
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=timeout)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck: a per-rank error became a deadlock"
+    if own:
+        for c in comms:
+            c.close()
+        for c in ctxs:
+            c.close()
+    return out
+
+
+def _q5_stripes(host, world):
+    from flock_amd import Bids, WindowSchedule
+    pane_off = host["epoch"]["bid"][::5]
+    n_panes = len(pane_off) - 1
+    lo, hi = np.arange(0, n_panes - 1, dtype=np.int32), np.arange(2, n_panes + 1, dtype=np.int32)
+    out = []
+    for r in range(world):
+        rows, off = _stripe_rows(pane_off, r, world)
+        out.append((Bids(auction=_dev(host["bid"][rows]), rows=len(rows)), WindowSchedule(off, lo, hi)))
+    return out, pane_off, lo, hi
+
+
+@pytest.mark.parametrize("query", ["q5", "q3", "q8"])
+def test_a_run_time_failure_on_one_rank_is_an_error_on_every_rank(host, query):
+    """a rank that fails between two collectives used to leave its peers waiting forever.  The failing
+    rank's status now travels in the counts exchange: it returns its own error, the others FLOCKGPU_ERR_PEER, nobody hangs,
+    and the communicator is still good for the next call (nothing was half-sent)."""
+    from flock_amd import Auctions, Comm, GpuContext, Persons, WindowSchedule, _ffi
+    from flock_amd import FlockGpuError
+    world, bad = 3, 1
+    comms = Comm.local(world)
+    ctxs = [GpuContext(0, own_stream=True) for _ in range(world)]
+    if query == "q5":
+        stripes, pane_off, lo, hi = _q5_stripes(host, world)
+        call = lambda r, ctx, comm: ctx.q5_hot_items_exchange(comm, *stripes[r]).to_host()
+    else:
+        au, pe, ep = host["au"], host["pe"], host["epoch"]
+        step = 1 if query == "q3" else 10
+        pane_a, pane_p = ep["auction"][::step], ep["person"][::step]
+        ids = np.arange(len(pane_a) - 1, dtype=np.int32)
+        stripes = []
+        for r in range(world):
+            ra, oa = _stripe_rows(pane_a, r, world)
+            rp, op = _stripe_rows(pane_p, r, world)
+            a = Auctions(_dev(au["a_id"][ra]), _dev(au["seller"][ra]), _dev(au["category"][ra]), len(ra))
+            p = Persons(_dev(pe["p_id"][rp]), _utf8_dev(_take_utf8(pe["name"], rp)), _utf8_dev(_take_utf8(pe["city"], rp)),
+                        _utf8_dev(_take_utf8(pe["state"], rp)), len(rp))
+            stripes.append((a, WindowSchedule(oa, ids, ids + 1), p, WindowSchedule(op, ids, ids + 1)))
+        if query == "q3":
+            call = lambda r, ctx, comm: ctx.q3_join_exchange(comm, *stripes[r]).to_host()
+        else:
+            call = lambda r, ctx, comm: ctx.q8_join_exchange(comm, stripes[r][2], stripes[r][3], stripes[r][0], stripes[r][1]).to_host()
+    good = _run_ranks_collect(world, call, comms, ctxs)
+    assert all(k == "ok" for k, _ in good)
+    comms[bad].inject_failure(1)
+    res = _run_ranks_collect(world, call, comms, ctxs)
+    for r, (kind, val) in enumerate(res):
+        assert kind == "error" and isinstance(val, FlockGpuError), (r, kind, val)
+        if r == bad:
+            assert val.code == _ffi.ERR_CAPACITY and "injected" in str(val)
+        else:
+            assert val.code == _ffi.ERR_PEER and f"rank {bad}" in str(val)
+    # nothing was half-sent: the same communicator runs the query again, same rows as before
+    again = _run_ranks_collect(world, call, comms, ctxs)
+    assert all(k == "ok" for k, _ in again)
+    for (_, a), (_, b) in zip(good, again):
+        if isinstance(a, tuple):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        else:
+            assert np.array_equal(a["offsets"], b["offsets"])
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_a_transport_failure_kills_the_communicator_without_a_deadlock(host):
+    """A failure AFTER the agreement (the transport itself): the failing rank takes its communicator down; peers waiting at a
+    barrier of the local group wake up with FLOCKGPU_ERR_PEER (or had already finished); every later call fails at once."""
+    from flock_amd import Comm, FlockGpuError, GpuContext, _ffi
+    world, bad = 3, 2
+    comms = Comm.local(world)
+    ctxs = [GpuContext(0, own_stream=True) for _ in range(world)]
+    stripes, *_ = _q5_stripes(host, world)
+    call = lambda r, ctx, comm: ctx.q5_hot_items_exchange(comm, *stripes[r]).to_host()
+    comms[bad].inject_failure(2)
+    res = _run_ranks_collect(world, call, comms, ctxs)
+    assert res[bad][0] == "error" and res[bad][1].code == _ffi.ERR_HIP and "injected" in str(res[bad][1])
+    for r in range(world):
+        if r != bad:
+            assert res[r][0] == "error" and res[r][1].code == _ffi.ERR_PEER, res[r]
+    res = _run_ranks_collect(world, call, comms, ctxs, timeout=30)
+    assert all(k == "error" and isinstance(v, FlockGpuError) and v.code == _ffi.ERR_PEER for k, v in res), res
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_exchange_phase_timeline(host):
+    """flockgpu_comm_phase_*: the stream timeline of the exchange calls by phase (what bench.py reports per rank)."""
+    from flock_amd import Comm, GpuContext
+    comm = Comm.local(1)[0]
+    ctx = GpuContext(0)
+    stripes, *_ = _q5_stripes(host, 1)
+    comm.phases(True)
+    for _ in range(3):
+        ctx.q5_hot_items_exchange(comm, *stripes[0])
+    t = comm.phase_times()
+    assert list(t) == ["partial", "partition+take", "counts", "all_to_all+regroup", "final", "all_reduce_max"], t
+    assert all(v["calls"] == 3 and v["total_ms"] >= 0 for v in t.values()) and t["partial"]["total_ms"] > 0
+    comm.phases(False)
+    ctx.q5_hot_items_exchange(comm, *stripes[0])
+    assert comm.phase_times() == {}
+    comm.close()
+    ctx.close()
