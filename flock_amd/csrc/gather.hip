@@ -350,15 +350,14 @@ __global__ void utf8_col_bases_kernel(const uint64_t *__restrict__ tile_base, in
 // Writes out_off and the bytes.  The tile's bytes form ONE contiguous range of the output, so they are assembled
 // in LDS (byte writes are cheap there) and streamed out with aligned 16-byte stores; byte-granular global stores
 // made this kernel 10x slower than everything else in q8.
-__device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src,
-                                               const int32_t *__restrict__ rows, int64_t n, const uint32_t *__restrict__ counts,
-                                               const uint64_t *__restrict__ tile_base, uint64_t col_base, int32_t *__restrict__ out_off,
-                                               uint8_t *__restrict__ out, uint8_t *s_stage, uint32_t *s_it) {
+__device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src,
+                                                  const int32_t *__restrict__ rows, int64_t n, const uint32_t *__restrict__ counts,
+                                                  const uint64_t base, int32_t *__restrict__ out_off,
+                                                  uint8_t *__restrict__ out, uint8_t *s_stage, uint32_t *s_it) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
     const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
     const uint32_t tile_bytes = wc.x + wc.y + wc.z + wc.w;
-    const uint64_t base = tile_base[blockIdx.x] - col_base;
     int32_t b[kLenItems];
     uint32_t len[kLenItems], excl[kLenItems];
 #pragma unroll
@@ -446,6 +445,13 @@ __device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_o
     }
 }
 
+__device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src,
+                                               const int32_t *__restrict__ rows, int64_t n, const uint32_t *__restrict__ counts,
+                                               const uint64_t *__restrict__ tile_base, uint64_t col_base, int32_t *__restrict__ out_off,
+                                               uint8_t *__restrict__ out, uint8_t *s_stage, uint32_t *s_it) {
+    utf8_emit_tile_at(src_off, src, rows, n, counts, tile_base[blockIdx.x] - col_base, out_off, out, s_stage, s_it);
+}
+
 __global__ __launch_bounds__(kBlock) void utf8_emit_kernel(const int32_t *__restrict__ src_off,
                                                            const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
                                                            int64_t n, const uint32_t *__restrict__ counts,
@@ -465,6 +471,36 @@ __global__ __launch_bounds__(kBlock) void utf8_emit_multi_kernel(Utf8Cols cols, 
     const size_t shift = (size_t)c * tiles_stride;
     utf8_emit_tile(cols.src_off[c], cols.src[c], rows, n, counts + shift * kWavesPerBlock, tile_base + shift, tile_base[shift], cols.out_off[c],
                    cols.out[c], s_stage, s_it);
+}
+
+// The multi-column emit WITHOUT a scan launch in front of it: workgroup (tile, column) sums the byte counts of the column's lower
+// tiles itself (block_base_of_tile).  The byte buffers were sized from the PREVIOUS call's totals (the host has not seen this call's
+// yet): a tile that would write past its column's capacity writes nothing and raises `h_over`; the last tile of a column reports the
+// column's total -- both straight into pinned host memory, read after the call's one synchronisation.
+struct Utf8Caps {
+    uint64_t cap[kMaxUtf8Multi];
+};
+__global__ __launch_bounds__(kBlock) void utf8_emit_multi_self_kernel(Utf8Cols cols, const int32_t *__restrict__ rows, int64_t n,
+                                                                      const uint64_t *__restrict__ d_n, int64_t tiles_stride,
+                                                                      const uint32_t *__restrict__ counts, Utf8Caps caps,
+                                                                      uint64_t *__restrict__ h_tot, uint32_t *__restrict__ h_over) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];
+    __shared__ uint64_t s_red[kWavesPerBlock];
+    if (d_n) n = min(n, (int64_t)*d_n);
+    const int c = blockIdx.y;
+    const uint32_t *col_counts = counts + (size_t)c * tiles_stride * kWavesPerBlock;
+    const uint64_t base = block_base_of_tile(col_counts, (int32_t)blockIdx.x, s_red);
+    const uint4 wc = *reinterpret_cast<const uint4 *>(col_counts + (size_t)blockIdx.x * kWavesPerBlock);
+    const uint64_t mine = (uint64_t)wc.x + wc.y + wc.z + wc.w;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) h_tot[c] = base + mine;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cols.out_off[c][0] = 0;
+    if (base + mine > caps.cap[c]) {   // (block-uniform) the hint was too small: the host redoes the take with exact sizes
+        if (threadIdx.x == 0) __hip_atomic_store(h_over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if ((int64_t)blockIdx.x * kLenTile >= n) return;   // tiles of the bound beyond the true row count
+    utf8_emit_tile_at(cols.src_off[c], cols.src[c], rows, n, col_counts, base, cols.out_off[c], cols.out[c], s_stage, s_it);
 }
 
 // ---- in-place inclusive scan: tile sums -> tile scan -> apply -----------------------------------------------------
@@ -750,6 +786,51 @@ int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockg
                            g.counts, g.tile_base);
     }
     return check_launch(ctx, "utf8_emit_multi_kernel");
+}
+
+int gather_utf8_multi_fast(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n_bound,
+                           const uint64_t *d_n, const int64_t *cap_bytes, Utf8FastGather *g) {
+    if (k < 1 || k > kMaxUtf8Multi) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: 1 to %d Utf8 columns per gather", name, kMaxUtf8Multi);
+    g->name = name;
+    g->k = k;
+    g->tiles = n_bound > 0 ? div_up(n_bound, kLenTile) : 0;
+    if (g->tiles > kSelfScanMaxTiles) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles for the self-scanning take", name);
+    uint64_t *h = nullptr;
+    FG_TRY(pinned_get_t(ctx, (g->name + ".fast").c_str(), (size_t)kMaxUtf8Multi + 2, &h));
+    g->h_tot = h;
+    g->h_over = reinterpret_cast<uint32_t *>(h + kMaxUtf8Multi);
+    for (int c = 0; c < kMaxUtf8Multi; ++c) h[c] = 0;      // (the previous call's values were read under its synchronisation)
+    *g->h_over = 0;
+    Utf8Cols cols{};
+    Utf8Caps caps{};
+    cols.k = k;
+    for (int c = 0; c < k; ++c) {
+        const std::string k_off = g->name + ".off" + std::to_string(c), k_bytes = g->name + ".bytes" + std::to_string(c);
+        int32_t *o_off = nullptr;
+        uint8_t *o_b = nullptr;
+        FG_TRY(arena_get_t(ctx, k_off.c_str(), (size_t)std::max<int64_t>(n_bound, 0) + 1, &o_off));
+        FG_TRY(arena_get_t(ctx, k_bytes.c_str(), (size_t)std::max<int64_t>(cap_bytes[c], 0) + 16, &o_b));
+        cols.src_off[c] = srcs[c].offsets;
+        cols.src[c] = srcs[c].data;
+        cols.out_off[c] = o_off;
+        cols.out[c] = o_b;
+        caps.cap[c] = (uint64_t)std::max<int64_t>(cap_bytes[c], 0);
+        g->out[c] = flockgpu_utf8{o_off, o_b};
+    }
+    if (g->tiles == 0) return FLOCKGPU_OK;
+    uint32_t *counts = nullptr;
+    FG_TRY(arena_get_t(ctx, (g->name + ".counts").c_str(), (size_t)g->tiles * k * kWavesPerBlock, &counts));
+    {
+        LaunchScope ls(ctx, "utf8_len_kernel");
+        hipLaunchKernelGGL(utf8_len_multi_kernel, dim3((unsigned)g->tiles), dim3(kBlock), 0, ctx->stream, cols, rows, n_bound, d_n, g->tiles, counts);
+    }
+    FG_TRY(check_launch(ctx, "utf8_len_multi_kernel"));
+    {
+        LaunchScope ls(ctx, "utf8_emit_kernel");
+        hipLaunchKernelGGL(utf8_emit_multi_self_kernel, dim3((unsigned)g->tiles, (unsigned)k), dim3(kBlock), 0, ctx->stream, cols, rows, n_bound, d_n, g->tiles, counts,
+                           caps, h, g->h_over);
+    }
+    return check_launch(ctx, "utf8_emit_multi_self_kernel");
 }
 
 int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

@@ -75,6 +75,22 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n);
 int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockgpu_utf8 *outs, int64_t *n_bytes, const int64_t *known_bytes = nullptr);
 
+// The same take with NO scan launch and NO host wait between lengths and bytes (a small-batch call is launch- and wait-bound:
+// q3 at 1e8 events): the emit workgroups sum the lower tiles' byte counts themselves, the byte buffers are sized by `cap_bytes`
+// (the caller's estimate: the previous call's totals plus slack), totals and an "estimate too small" flag land in pinned memory.
+// Queue it, synchronise ONCE with whatever else the call waits for, then read h_tot[c] / *h_over: on overflow (or more than n_bound
+// rows) redo the take with gather_utf8_multi_begin / finish.  out[c] are valid when *h_over == 0.
+struct Utf8FastGather {
+    std::string name;
+    int k = 0;
+    int64_t tiles = 0;
+    flockgpu_utf8 out[4]{};
+    const uint64_t *h_tot = nullptr;   // pinned, k byte totals
+    uint32_t *h_over = nullptr;        // pinned
+};
+int gather_utf8_multi_fast(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n_bound,
+                           const uint64_t *d_n, const int64_t *cap_bytes, Utf8FastGather *g);
+
 // Utf8 gather whose total byte count the caller already knows (a permutation of a column of known size): no host wait.
 int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out);
 

@@ -90,13 +90,21 @@ __device__ __forceinline__ uint64_t lds_head8(const uint32_t *w, uint32_t byte_p
     return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1));
 }
 
-template <bool kDense, bool kBits>
+// kInline (bits mode only): no layout kernel in front -- every workgroup derives its window's table from the window's first and last id
+// itself (two loads), the window's first workgroup leaves it in `wins_out` for the probe and emit kernels, and `err` is a word of PINNED
+// HOST memory the host zeroed before the launch (plain system-scope stores of 1: no memset node, no copy back).  A window whose ids
+// have gaps (or are not increasing: the row check below) voids the call; the host then runs the general sequence.
+__device__ __forceinline__ void raise_flag(uint32_t *flag, bool host_word) {
+    if (host_word) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else atomicOr(flag, 1u);
+}
+template <bool kDense, bool kBits, bool kInline = false>
 __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restrict__ p_id,
                                                           const int32_t *__restrict__ state_off,
                                                           const uint8_t *__restrict__ state_data, int64_t n_rows, SegTiles st,
                                                           Utf8Lits lits, const WinTable *__restrict__ wins, int32_t *direct,
                                                           uint32_t *__restrict__ bits, uint64_t *tables, uint32_t cap, int32_t *next,
-                                                          uint32_t *err, int y_shift) {
+                                                          uint32_t *err, int y_shift, WinTable *__restrict__ wins_out) {
     // A relation of a few hundred tiles (2e6 persons at 1e8 events: 245) leaves most CUs without a workgroup, and one
     // workgroup walks its tile's eight iterations alone: blockIdx.y splits the iterations of a tile over 8 >> y_shift
     // workgroups (rows are independent: nothing is produced per tile).
@@ -106,7 +114,17 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     uint32_t *stage = s_stage[wave];
     WinTable wt{};
-    if (kDense) wt = wins[tr.seg];
+    if (kDense && !kInline) wt = wins[tr.seg];
+    if (kInline) {
+        const int64_t lo = st.seg_off[2 * tr.seg], hi = st.seg_off[2 * tr.seg + 1];   // (hi > lo: the window has a tile)
+        const int32_t first = p_id[lo], last = p_id[hi - 1];
+        const bool gapless = (int64_t)last - (int64_t)first + 1 == hi - lo;
+        wt = WinTable{first, gapless ? (uint32_t)(hi - lo) : 0u, 0, (int32_t)lo, st.tile_first[tr.seg], (uint32_t)(lo - (lo & ~int64_t(3))), gapless ? 1u : 0u};
+        if (threadIdx.x == 0) {
+            if (!gapless) raise_flag(err, true);
+            if ((int32_t)blockIdx.x == st.tile_first[tr.seg] && blockIdx.y == 0) wins_out[tr.seg] = wt;
+        }
+    }
     uint64_t *tab = kDense ? nullptr : tables + (size_t)tr.seg * cap;
     int32_t key[kFlagIters][4];
     load_flag_tile(p_id, n_rows, tr, key);
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                     if (idx < wt.range && ordered) {
                         if (!kBits) direct[wt.off + idx] = hit ? (int32_t)r : -1;
                     } else if (wt.range) {
-                        atomicOr(err, 1u);   // (range 0: the layout pass declined the dense path already)
+                        raise_flag(err, kInline);   // (range 0: the layout pass declined the dense path already)
                     }
                 }
                 if (kBits) nib |= (hit ? 1u : 0u) << (4 * (lane & 7) + j);
@@ -322,6 +340,41 @@ __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__
         stream_store(&out_auction_row[base + i], (int32_t)r);   // (results: not read again by this call except person_row, which the take reads once)
         const uint32_t idx = (uint32_t)(seller[r] - wt.base);
         out_person_row[base + i] = kBits ? wt.first_row + (int32_t)idx : direct[wt.off + idx];
+        stream_store(&out_a_id[base + i], a_id[r]);
+    }
+}
+
+// The same emit WITHOUT a scan launch in front of it (bits mode): the workgroup sums the lower tiles' counts itself
+// (block_base_of_tile), the first tile of a window reports the window's output offset and the last tile the pair total -- straight into
+// pinned host memory (h_off, h_info[1]) and, for the Utf8 take queued behind, into d_pairs.
+__global__ __launch_bounds__(kBlock) void q3_emit_dense_self_kernel(const int32_t *__restrict__ seller, const int32_t *__restrict__ a_id, SegTiles st,
+                                                                    const uint32_t *__restrict__ flag_words, const uint32_t *__restrict__ counts,
+                                                                    const WinTable *__restrict__ wins, int32_t *__restrict__ out_auction_row,
+                                                                    int32_t *__restrict__ out_person_row, int32_t *__restrict__ out_a_id,
+                                                                    uint64_t *__restrict__ d_pairs, int64_t *__restrict__ h_off, uint64_t *__restrict__ h_info) {
+    __shared__ uint16_t s_list[kFlagTile];
+    __shared__ uint64_t s_red[kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint64_t base = block_base_of_tile(counts, tile, s_red);
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    if (threadIdx.x == 0) {
+        if (tile == st.tile_first[tr.seg]) h_off[tr.seg] = (int64_t)base;
+        if (tile == st.n_tiles - 1) {
+            const uint64_t total = base + wc.x + wc.y + wc.z + wc.w;
+            *d_pairs = total;
+            h_info[1] = total;
+        }
+    }
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const WinTable wt = wins[tr.seg];
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const int64_t r = tr.tile_begin + s_list[i];
+        stream_store(&out_auction_row[base + i], (int32_t)r);
+        const uint32_t idx = (uint32_t)(seller[r] - wt.base);
+        out_person_row[base + i] = wt.first_row + (int32_t)idx;
         stream_store(&out_a_id[base + i], a_id[r]);
     }
 }
@@ -671,6 +724,103 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
     }
     bool bits_mode = regime[0] != 1;
+    // ---- the steady-state sequence of the gapless dense path: build (layout inline) -> probe -> emit (self-scan) -> Utf8 lengths ->
+    // Utf8 bytes (self-scan), FIVE launches and ONE synchronisation, nothing else on the stream: no memset / copy nodes (flags, window
+    // offsets and totals are written by the kernels straight into one pinned block), no scan launches (the emitting workgroups sum the
+    // lower tiles' counts themselves), no host wait between the Utf8 lengths and bytes (buffers sized from the previous call's totals).
+    // At 1e8 events the call was ~12 kernels + 5 copy nodes of 4-17 us each (0.126 ms for 0.085 ms of kernels).  Anything unusual --
+    // first call of a ctx, ids with gaps or out of order, an empty person window, totals beyond the estimates, more tiles than a
+    // self-scan should read -- takes (or falls through to) the general sequence below, which also refreshes the estimates.
+    std::vector<int64_t> &fast = ctx->host_i64["q3.fast_hint"];   // {rows the take is laid out for, byte capacity x 3, valid}
+    if (fast.size() != 5) fast.assign(5, 0);
+    bool fast_done = false;
+    static const bool no_fast = getenv("FLOCKGPU_Q3_NO_FAST") != nullptr;   // (A/B knob)
+    bool fast_ok = try_dense && bits_mode && fast[4] && !no_fast && st_a.n_tiles > 0 && st_a.n_tiles <= kSelfScanMaxTiles && st_p.n_tiles > 0;
+    for (int w = 0; w < n_win && fast_ok; ++w)
+        if (pe[w] == pb[w] && ae[w] > ab[w]) fast_ok = false;   // (a window without persons leaves its table entry unwritten)
+    if (fast_ok) {
+        const size_t bound_pairs = (size_t)auction->rows;
+        WinTable *d_wins = nullptr;
+        uint32_t *bits = nullptr, *flag_words = nullptr;
+        uint64_t *d_pairs = nullptr, *h_blk = nullptr;
+        FG_TRY(arena_get_t(ctx, "q3.wins", (size_t)n_win, &d_wins));
+        FG_TRY(arena_get_t(ctx, "q3.state_bits", (size_t)std::max(st_p.n_tiles, 1) * (kFlagTile / 32) + 4, &bits));
+        FG_TRY(arena_get_t(ctx, "q3.flag_words", (size_t)st_a.n_tiles * kBlock, &flag_words));
+        FG_TRY(arena_get_t(ctx, "q3.fast_pairs", 2, &d_pairs));
+        FG_TRY(pinned_get_t(ctx, "q3.fast", (size_t)n_win + 8, &h_blk));   // [0] flags, [1] pairs, [4 ..] window offsets
+        FG_TRY(arena_get_t(ctx, "q3.out_auction_row", bound_pairs + 1, &o_ar));
+        FG_TRY(arena_get_t(ctx, "q3.out_person_row", bound_pairs + 1, &o_pr));
+        FG_TRY(arena_get_t(ctx, "q3.out_a_id", bound_pairs + 1, &o_aid));
+        uint32_t *h_flag = reinterpret_cast<uint32_t *>(h_blk);
+        int64_t *h_woff = reinterpret_cast<int64_t *>(h_blk + 4);
+        h_blk[0] = 0;   // (the previous call's values were read under its synchronisation)
+        h_blk[1] = 0;
+        {
+            LaunchScope ls(ctx, "q3_build_kernel");
+            hipLaunchKernelGGL((q3_build_kernel<true, true, true>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream, person->p_id,
+                               person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, bits, nullptr, 0u, nullptr, h_flag,
+                               build_y_shift, d_wins);
+        }
+        FG_TRY(check_launch(ctx, "q3_build_kernel"));
+        if (st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
+            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            hipLaunchKernelGGL(q3_probe_flag_small_kernel<true>, dim3((unsigned)st_a.n_tiles), dim3(4 * kBlock), 0, ctx->stream, auction->seller, auction->category,
+                               auction->rows, category_lit, st_a, d_wins, nullptr, bits, flag_words, counts);
+        } else {
+            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+            hipLaunchKernelGGL(q3_probe_flag_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, auction->seller, auction->category, auction->rows, category_lit,
+                               st_a, d_wins, nullptr, bits, flag_words, counts);
+        }
+        FG_TRY(check_launch(ctx, "q3_probe_flag_kernel"));
+        {
+            LaunchScope ls(ctx, "q3_emit_dense_kernel");
+            hipLaunchKernelGGL(q3_emit_dense_self_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller, auction->a_id, st_a, flag_words,
+                               counts, d_wins, o_ar, o_pr, o_aid, d_pairs, h_woff, h_blk);
+        }
+        FG_TRY(check_launch(ctx, "q3_emit_dense_self_kernel"));
+        const int64_t take_rows = std::min<int64_t>((int64_t)bound_pairs, std::max<int64_t>(fast[0], 1));
+        Utf8FastGather ft;
+        const int rc_take = gather_utf8_multi_fast(ctx, "q3.out_text", text_cols, 3, o_pr, take_rows, d_pairs, &fast[1], &ft);
+        if (rc_take != FLOCKGPU_OK && rc_take != FLOCKGPU_ERR_UNSUPPORTED) return rc_take;
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!*h_flag) {   // every window gapless and strictly increasing: what was built stands
+            n_pairs = h_blk[1];
+            offs.assign((size_t)n_win + 1, 0);
+            offs[(size_t)n_win] = (int64_t)n_pairs;
+            for (int w = n_win - 1; w >= 0; --w) offs[(size_t)w] = ae[w] > ab[w] ? h_woff[w] : offs[(size_t)w + 1];
+            regime[0] = 2;
+            flockgpu_utf8 text_out[3];
+            int64_t text_bytes[3];
+            if (rc_take != FLOCKGPU_OK || *ft.h_over || (int64_t)n_pairs > take_rows) {   // estimates too small: the take once more, exactly
+                FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)n_pairs, &g_text, nullptr));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                FG_TRY(gather_utf8_multi_finish(ctx, g_text, text_out, text_bytes));
+            } else {
+                for (int c = 0; c < 3; ++c) {
+                    text_out[c] = ft.out[c];
+                    text_bytes[c] = (int64_t)ft.h_tot[c];
+                }
+            }
+            fast[0] = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 4096;
+            for (int c = 0; c < 3; ++c) fast[1 + c] = text_bytes[c] + text_bytes[c] / 8 + 65536;
+            out->name = text_out[0];
+            out->city = text_out[1];
+            out->state = text_out[2];
+            out->name_bytes = text_bytes[0];
+            out->city_bytes = text_bytes[1];
+            out->state_bytes = text_bytes[2];
+            out->a_id = o_aid;
+            out->auction_row = o_ar;
+            out->person_row = o_pr;
+            out->win_out_offsets = offs.data();
+            out->rows = (int64_t)n_pairs;
+            fast_done = true;
+        } else {
+            fast[4] = 0;   // not this input: the general sequence decides between the row table and the hash join
+        }
+    }
+    if (fast_done) return FLOCKGPU_OK;
     for (bool done = false; try_dense && !done;) {
         const size_t bound_entries = bits_mode ? 8 : (size_t)8 * (size_t)person->rows + (size_t)1024 * n_win + 8;
         const size_t bound_pairs = (size_t)auction->rows;  // one person per key: an auction joins at most one
@@ -705,7 +855,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL((bits_mode ? q3_build_kernel<true, true> : q3_build_kernel<true, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
                                person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, direct, bits,
-                               nullptr, 0u, nullptr, d_err, build_y_shift);
+                               nullptr, 0u, nullptr, d_err, build_y_shift, (WinTable *)nullptr);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0 && st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
@@ -771,7 +921,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL((q3_build_kernel<false, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
                                person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, nullptr,
-                               tables, cap, next, d_err, build_y_shift);
+                               tables, cap, next, d_err, build_y_shift, (WinTable *)nullptr);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0) {
@@ -806,6 +956,13 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     flockgpu_utf8 text_out[3];
     int64_t text_bytes[3];
     FG_TRY(gather_utf8_multi_finish(ctx, g_text, text_out, text_bytes));
+    if (regime[0] == 2) {   // a gapless dense call: the next one of this ctx may take the five-launch sequence with these estimates
+        fast[0] = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 4096;
+        for (int c = 0; c < 3; ++c) fast[1 + c] = text_bytes[c] + text_bytes[c] / 8 + 65536;
+        fast[4] = 1;
+    } else {
+        fast[4] = 0;
+    }
     out->name = text_out[0];
     out->city = text_out[1];
     out->state = text_out[2];

@@ -172,6 +172,27 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
     return (uint64_t)s0 + ((uint64_t)s1 << 21) + ((uint64_t)s2 << 42);
 }
 
+// Self-scan: the exclusive base of tile `tile` = sum of counts[0 .. tile * kWavesPerBlock), summed by the emitting workgroup itself --
+// every count was written by the PREVIOUS launch, so no scan launch (and no boundary either side of it) sits between count and emit.
+// 16 B per lower tile from L2: 733 tiles (q3 at 1e8 events) read 6 KB each on average, 7324 tiles 58 KB; relations of more than
+// kSelfScanMaxTiles tiles keep the scan kernel.  All threads of the workgroup get the sum; s_red: kWavesPerBlock words of LDS.
+constexpr int32_t kSelfScanMaxTiles = 16384;
+__device__ __forceinline__ uint64_t block_base_of_tile(const uint32_t *__restrict__ counts, int32_t tile, uint64_t *s_red) {
+    uint64_t sum = 0;
+    for (int32_t t = (int32_t)threadIdx.x; t < tile; t += kBlock) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(counts + (size_t)t * kWavesPerBlock);
+        sum += (uint64_t)w.x + w.y + w.z + w.w;
+    }
+    sum = wave_sum_u64(sum);
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    uint64_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) tot += s_red[w];
+    __syncthreads();   // (s_red may be reused)
+    return tot;
+}
+
 // Host: launches the scan (defined in gather.hip).  counts: n_tiles * kWavesPerBlock uint32 (16-byte aligned);
 // tile_base: n_tiles + 1; seg_out_off (may be null): n_seg + 1.
 int launch_tile_scan(flockgpu_ctx *ctx, const uint32_t *counts, int32_t n_tiles, uint64_t *tile_base,

@@ -527,6 +527,57 @@ def test_q3_q8_follow_the_data_on_one_ctx(ctx):
         _check_q8_nexmark(ctx, 31, eps, 20)
 
 
+def test_q3_five_launch_sequence_equals_the_general_one():
+    """From its second gapless call on a ctx q3 runs build -> probe -> emit -> Utf8 lengths -> Utf8 bytes with self-scanning emits and
+    results written straight into pinned memory (q3.hip, "steady-state sequence").  Same bytes as the first (general) call; a call
+    with more pairs / bytes than the estimates redoes the take; an input whose ids have gaps or are out of order voids the sequence
+    and is answered exactly by the general one; and the ctx comes back to the fast sequence afterwards."""
+    from flock_amd import Auctions, GpuContext, Persons, Window, WindowSchedule, run_query
+    c = GpuContext(0)
+    g = _gpu_stream(c, 77, 30_000, 6, Window.element_wise())
+    first = run_query(c, 3, g).to_host()
+    for _ in range(3):
+        again = run_query(c, 3, g).to_host()
+        for k in ("a_id", "auction_row", "person_row", "offsets"):
+            assert np.array_equal(first[k], again[k]), k
+        for k in ("name", "city", "state"):
+            assert np.array_equal(first[k][0], again[k][0]) and np.array_equal(first[k][1], again[k][1]), k
+    assert len(first["a_id"]) > 0
+    _check_q3_nexmark(c, 78, 300_000, 4)          # ten times the pairs: the take laid out for the small call is redone
+    _check_q3_nexmark(c, 78, 300_000, 4)          # ... and now fits
+    _check_q3_nexmark(c, 79, 30_000, 3)
+    # hostile: gaps in the ids of one window, then a swapped pair -- same ctx, estimates still valid
+    rng = np.random.default_rng(5)
+    npn, na = 30_000, 90_000
+    for hostile in ("gap", "swap"):
+        p_id = np.arange(npn, dtype=np.int32) + 1000
+        if hostile == "gap":
+            p_id[20_000:] += 7
+        else:
+            p_id[[12_345, 12_346]] = p_id[[12_346, 12_345]]
+        st = rng.choice(np.array([b"or", b"id", b"ca", b"wa", b"tx"], dtype=object), npn)
+        state = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32), np.frombuffer(b"".join(st), np.uint8).copy())
+        nm = [b"n%d" % (i % 313) for i in range(npn)]
+        name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32), np.frombuffer(b"".join(nm), np.uint8).copy())
+        seller = rng.choice(p_id, na).astype(np.int32)
+        category = rng.integers(9, 12, na).astype(np.int32)
+        a_id = (np.arange(na) * 3 + 1).astype(np.int32)
+        pw = WindowSchedule(np.array([0, 10_000, npn]), np.arange(2), np.arange(1, 3))
+        aw = WindowSchedule(np.array([0, 40_001, na]), np.arange(2), np.arange(1, 3))
+        out = c.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw, Persons(_dev(p_id), _utf8(name), _utf8(name), _utf8(state), npn), pw).to_host()
+        off, total = out["offsets"], 0
+        for w in range(2):
+            (alo, ahi), (plo, phi) = aw.window_rows(w), pw.window_rows(w)
+            ar, pr = oracle.q3_join(seller[alo:ahi], category[alo:ahi], p_id[plo:phi], state.slice(plo, phi))
+            sl = slice(off[w], off[w + 1])
+            assert sorted(zip((out["auction_row"][sl] - alo).tolist(), (out["person_row"][sl] - plo).tolist())) == sorted(zip(ar.tolist(), pr.tolist())), (hostile, w)
+            total += len(ar)
+        assert total == len(out["a_id"]) > 1000
+        _check_q3_nexmark(c, 80, 30_000, 3)       # (general sequence again: it re-arms the estimates)
+        _check_q3_nexmark(c, 80, 30_000, 3)       # (fast sequence)
+    c.close()
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_full_size_properties(ctx):
     """1e8-event stream (configs q2/q3 of BASELINE.json): checks that need no CPU pass over all rows."""
