@@ -34,14 +34,23 @@ class Bitmap:
     """Bit per sequence number (flock/src/runtime/arena/bitmap.rs): `Bitmap::new(seq_len + 1)`, numbers start at 1."""
 
     def __init__(self, size: int):
+        # bitmap.rs:35-47: the byte count is rounded up to a multiple of 64, and BOTH accessors assert `i < capacity` in bits --
+        # one bound for `set` and `is_set`, so a sequence number in the slack is recognised when it is delivered again
         self.size = size
-        self._bits = bytearray((size + 7) // 8)
+        n_bytes = (size + 7) // 8
+        self._bits = bytearray((n_bytes + 63) // 64 * 64)
+
+    @property
+    def capacity(self) -> int:
+        return len(self._bits) << 3
 
     def set(self, i: int):
+        assert 0 <= i < self.capacity, f"bit {i} outside a bitmap of {self.capacity} bits"     # bitmap.rs:58
         self._bits[i >> 3] |= 1 << (i & 7)
 
     def is_set(self, i: int) -> bool:
-        return 0 <= i < self.size and bool(self._bits[i >> 3] >> (i & 7) & 1)
+        assert 0 <= i < self.capacity, f"bit {i} outside a bitmap of {self.capacity} bits"     # bitmap.rs:52
+        return bool(self._bits[i >> 3] >> (i & 7) & 1)
 
 
 @dataclass

@@ -127,7 +127,15 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
     }
     uint64_t *tab = kDense ? nullptr : tables + (size_t)tr.seg * cap;
     int32_t key[kFlagIters][4];
-    load_flag_tile(p_id, n_rows, tr, key);
+    if (y_shift >= 3) {
+        load_flag_tile(p_id, n_rows, tr, key);
+    } else {   // the iterations of the tile are split over blockIdx.y: load this workgroup's only (all eight were 4x the p_id traffic at y_shift 1)
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it) {
+            if ((it >> y_shift) == (int)blockIdx.y) load4_i32(p_id, wbase + it * 256, n_rows, key[it]);
+            else key[it][0] = key[it][1] = key[it][2] = key[it][3] = 0;
+        }
+    }
     const uintptr_t data_addr = reinterpret_cast<uintptr_t>(state_data);
     const bool off_aligned = (reinterpret_cast<uintptr_t>(state_off) & 15) == 0;
 #pragma unroll
@@ -135,7 +143,9 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
         if ((it >> y_shift) != (int)blockIdx.y) continue;  // (block-uniform)
         const int64_t r0 = wbase + it * 256;
         const int64_t chunk0 = r0 - lane * 4;               // the wave's first row of this iteration
-        const int32_t before = kDense ? p_id[chunk0 > 0 ? chunk0 - 1 : 0] : 0;   // the id in front of the chunk (one address per wave; order check)
+        // the id in front of the chunk (one address per wave; order check).  Clamped into the column: the chunks of a ragged last tile lie
+        // past its end (rocgdb caught the unclamped load faulting on a 3600-row column in a fresh process)
+        const int32_t before = kDense ? p_id[chunk0 > 0 ? (chunk0 - 1 < n_rows ? chunk0 - 1 : n_rows - 1) : 0] : 0;
         int32_t off[5];
         const bool inside = off_aligned && chunk0 >= 0 && chunk0 + 256 < n_rows;  // (wave-uniform) all 257 offsets exist
         if (inside) {
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__
 // whose eight serial iterations each wait for a seller load, then for the lookup behind it: 17.8 us for 48 MB, 34 % of the roofline).
 // Sixteen waves per tile instead of four: quarter q = threadIdx.x / 256 of the workgroup takes iterations 2q and 2q + 1 of the
 // flag-tile layout, i.e. byte q of every lane's flag word (a plain byte store), and the four quarters' wave counts meet in LDS.
-template <bool kBits>
-__global__ __launch_bounds__(4 * kBlock) void q3_probe_flag_small_kernel(const int32_t *__restrict__ seller,
+template <bool kBits, int kParts>
+__global__ __launch_bounds__(kParts * kBlock) void q3_probe_flag_small_kernel(const int32_t *__restrict__ seller,
                                                                          const int32_t *__restrict__ category, int64_t n_rows,
                                                                          int64_t category_lit, SegTiles st,
                                                                          const WinTable *__restrict__ wins,
@@ -274,7 +284,9 @@ __global__ __launch_bounds__(4 * kBlock) void q3_probe_flag_small_kernel(const i
                                                                          const uint32_t *__restrict__ bits,
                                                                          uint32_t *__restrict__ flag_words,
                                                                          uint32_t *__restrict__ counts) {
-    __shared__ uint32_t s_cnt[4][kWavesPerBlock];
+    constexpr int kPer = kFlagIters / kParts;   // iterations of the flag-tile layout per part: bits kPer * 4 * part .. of every lane's flag word
+    static_assert(kParts == 2 || kParts == 4, "two or four parts per tile");
+    __shared__ uint32_t s_cnt[kParts][kWavesPerBlock];
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
     const int quarter = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1), wave = t >> 6, lane = t & 63;
@@ -283,19 +295,19 @@ __global__ __launch_bounds__(4 * kBlock) void q3_probe_flag_small_kernel(const i
     const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
     const int32_t *tab = direct + wt.off;
     const uint32_t *wbits = bits + (size_t)wt.first_tile * (kFlagTile / 32);
-    int32_t sv[2][4], cv[2][4];
+    int32_t sv[kPer][4], cv[kPer][4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int64_t r0 = tr.tile_begin + rel0 + (quarter * 2 + k) * 256;
+    for (int k = 0; k < kPer; ++k) {
+        const int64_t r0 = tr.tile_begin + rel0 + (quarter * kPer + k) * 256;
         load4_i32(seller, r0, n_rows, sv[k]);
         load4_i32(category, r0, n_rows, cv[k]);
     }
     uint32_t flags = 0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < kPer; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int32_t rel = rel0 + (quarter * 2 + k) * 256 + j;
+            const int32_t rel = rel0 + (quarter * kPer + k) * 256 + j;
             const uint32_t idx = (uint32_t)sv[k][j] - (uint32_t)wt.base;
             const bool need = rel >= rel_lo && rel < rel_hi && (int64_t)cv[k][j] == category_lit && idx < wt.range;
             bool f;
@@ -307,12 +319,30 @@ __global__ __launch_bounds__(4 * kBlock) void q3_probe_flag_small_kernel(const i
             }
             flags |= (f ? 1u : 0u) << (k * 4 + j);
         }
-    reinterpret_cast<uint8_t *>(flag_words)[((size_t)tile * kBlock + t) * 4 + quarter] = (uint8_t)flags;   // bits 8q .. 8q + 7 of the lane's word
+    if (kParts == 4) reinterpret_cast<uint8_t *>(flag_words)[((size_t)tile * kBlock + t) * 4 + quarter] = (uint8_t)flags;   // bits 8q .. 8q + 7 of the lane's word
+    else reinterpret_cast<uint16_t *>(flag_words)[((size_t)tile * kBlock + t) * 2 + quarter] = (uint16_t)flags;           // bits 16q .. 16q + 15
     const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
     if (lane == 63) s_cnt[quarter][wave] = incl;
     __syncthreads();
-    if (threadIdx.x < kWavesPerBlock)
-        counts[(size_t)tile * kWavesPerBlock + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+    if (threadIdx.x < kWavesPerBlock) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < kParts; ++q) c += s_cnt[q][threadIdx.x];
+        counts[(size_t)tile * kWavesPerBlock + threadIdx.x] = c;
+    }
+}
+
+// Workgroup shape of the few-tiles probe: sixteen waves per tile while all tiles' workgroups are resident at once (2048 threads per CU), else
+// eight -- 733 tiles x 1024 threads (6e6 auctions) is 1.43 rounds of workgroups, i.e. a second, mostly empty round.
+template <bool kBits>
+static void launch_probe_small(flockgpu_ctx *ctx, int32_t n_tiles, const int32_t *seller, const int32_t *category, int64_t n_rows, int64_t category_lit,
+                               const SegTiles &st, const WinTable *wins, const int32_t *direct, const uint32_t *bits, uint32_t *flag_words, uint32_t *counts) {
+    if ((int64_t)n_tiles * 4 * kBlock <= (int64_t)ctx->num_cus * 2048)
+        hipLaunchKernelGGL((q3_probe_flag_small_kernel<kBits, 4>), dim3((unsigned)n_tiles), dim3(4 * kBlock), 0, ctx->stream, seller, category, n_rows, category_lit, st, wins,
+                           direct, bits, flag_words, counts);
+    else
+        hipLaunchKernelGGL((q3_probe_flag_small_kernel<kBits, 2>), dim3((unsigned)n_tiles), dim3(2 * kBlock), 0, ctx->stream, seller, category, n_rows, category_lit, st, wins,
+                           direct, bits, flag_words, counts);
 }
 
 template <bool kBits>
@@ -735,7 +765,10 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     if (fast.size() != 5) fast.assign(5, 0);
     bool fast_done = false;
     static const bool no_fast = getenv("FLOCKGPU_Q3_NO_FAST") != nullptr;   // (A/B knob)
-    bool fast_ok = try_dense && bits_mode && fast[4] && !no_fast && st_a.n_tiles > 0 && st_a.n_tiles <= kSelfScanMaxTiles && st_p.n_tiles > 0;
+    // (beyond a few thousand tiles the self-scans cost more than the scan launches they replace: 1e9 events, 7324 + 3 x 5860 tiles, ran
+    // 0.571 vs 0.530 ms -- and there the launches and waits are a small part of the call anyway)
+    static const int64_t fast_max_tiles = getenv("FLOCKGPU_Q3_FAST_MAX_TILES") ? atoll(getenv("FLOCKGPU_Q3_FAST_MAX_TILES")) : 2048;
+    bool fast_ok = try_dense && bits_mode && fast[4] && !no_fast && st_a.n_tiles > 0 && st_a.n_tiles <= fast_max_tiles && st_p.n_tiles > 0;
     for (int w = 0; w < n_win && fast_ok; ++w)
         if (pe[w] == pb[w] && ae[w] > ab[w]) fast_ok = false;   // (a window without persons leaves its table entry unwritten)
     if (fast_ok) {
@@ -764,8 +797,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
-            hipLaunchKernelGGL(q3_probe_flag_small_kernel<true>, dim3((unsigned)st_a.n_tiles), dim3(4 * kBlock), 0, ctx->stream, auction->seller, auction->category,
-                               auction->rows, category_lit, st_a, d_wins, nullptr, bits, flag_words, counts);
+            launch_probe_small<true>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, nullptr, bits, flag_words, counts);
         } else {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
@@ -860,8 +892,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0 && st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
-            hipLaunchKernelGGL(bits_mode ? q3_probe_flag_small_kernel<true> : q3_probe_flag_small_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(4 * kBlock), 0,
-                               ctx->stream, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
+            if (bits_mode) launch_probe_small<true>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
+            else launch_probe_small<false>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
         } else if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_a.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);

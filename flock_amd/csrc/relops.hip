@@ -422,7 +422,8 @@ template <bool kEmit>
 __global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__restrict__ keys, int64_t n, const int64_t *__restrict__ tk,
                                                             const int32_t *__restrict__ head, const int32_t *__restrict__ next, uint64_t cap,
                                                             int32_t *__restrict__ counts, int32_t *__restrict__ out_left,
-                                                            int32_t *__restrict__ out_right) {
+                                                            int32_t *__restrict__ out_right, unsigned long long *__restrict__ total64) {
+    unsigned long long mine = 0;   // count pass: the pair total in 64 bits (the 32-bit scan of `counts` wraps beyond 2^32 pairs)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t s = find_slot(tk, cap, keys[i]);
         int32_t c = 0;
@@ -442,7 +443,14 @@ __global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__res
                 ++c;
             }
         }
-        if (!kEmit) counts[i] = c;
+        if (!kEmit) {
+            counts[i] = c;
+            mine += (unsigned long long)c;
+        }
+    }
+    if (!kEmit) {
+        mine = wave_sum_u64(mine);
+        if (lane_id() == 0 && mine) atomicAdd(total64, mine);
     }
 }
 __global__ __launch_bounds__(kBlock) void fold_key_kernel(const int64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ out) {
@@ -805,7 +813,7 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(n_left, 1) * 2);
     const int64_t slots = (int64_t)cap + 1;
     int64_t *tk = nullptr;
-    int32_t *head = nullptr, *next = nullptr, *counts = nullptr, *h_tot = nullptr;
+    int32_t *head = nullptr, *next = nullptr, *counts = nullptr;
     uint32_t *d_err = nullptr, *h_err = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
     FG_TRY(arena_get_t(ctx, (base + ".head").c_str(), (size_t)slots, &head));
@@ -813,7 +821,6 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
     FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".tot").c_str(), 4, &h_tot));
     int32_t *ol = nullptr, *orr = nullptr;
     if (n_left <= 0 || n_right <= 0) {
         FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
@@ -822,22 +829,28 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         *right_rows = orr;
         return FLOCKGPU_OK;
     }
+    unsigned long long *d_tot64 = nullptr, *h_tot64 = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot64));
+    FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot64));
     FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_tot64, 0, sizeof(unsigned long long), ctx->stream));
     RELOPS_LAUNCH(ctx, "join_init_kernel", join_init_kernel, slots, tk, head, slots);
     RELOPS_LAUNCH(ctx, "join_build_kernel", join_build_kernel, n_left, left, n_left, tk, head, next, cap, d_err);
     RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
-                  (int32_t *)nullptr);
+                  (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
-    FG_HIP(ctx, hipMemcpyAsync(h_tot, counts + (n_right - 1), sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_tot64, d_tot64, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
-    const int64_t total = (int64_t)(uint32_t)h_tot[0];
-    if (total >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output exceeds 2^31 rows", name);
+    // the 64-bit total decides: the 32-bit inclusive scan of `counts` is only read when it cannot have wrapped
+    if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);
+    const int64_t total = (int64_t)h_tot64[0];
     FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)total + 4, &ol));
     FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)total + 4, &orr));
     if (total > 0)
-        RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<true>, n_right, right, n_right, tk, head, next, cap, counts, ol, orr);
+        RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<true>, n_right, right, n_right, tk, head, next, cap, counts, ol, orr,
+                      (unsigned long long *)nullptr);
     *left_rows = ol;
     *right_rows = orr;
     *n_pairs = total;

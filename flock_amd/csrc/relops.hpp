@@ -102,7 +102,9 @@ int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, c
 int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out, int *any);
 
 // ---- inner equi-join on one 64-bit key: every (left_row, right_row) pair with equal keys, ordered by right row
-// (the probe side), then by left row.  Builds on the left (DataFusion's build side).
+// (the probe side); the left rows of one right row come in the build chain's order, which is NOT defined (concurrent push-front
+// inserts) -- callers compare multisets, as the reference does (test_util.rs:61-90).  Builds on the left (DataFusion's build side).
+// More than 2^31 - 1 pairs: FLOCKGPU_ERR_UNSUPPORTED, decided from a 64-bit total before anything is emitted.
 int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
 

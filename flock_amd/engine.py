@@ -22,6 +22,24 @@ def _torch():
     return torch
 
 
+def _cached_ffi(obj, fields, make):
+    """The ctypes view of a column container, rebuilt only when one of its columns (or the row count) was replaced: building it costs a
+    `data_ptr()` per column and a ctypes cast per host array -- tens of microseconds per call, as much as the kernels of a small batch
+    (q3 at 1e8 events: ~60 us), and a host in the reference's own language has none of it."""
+    def ident(v):   # device columns by address (an id() can be reused by a new tensor), host arrays by identity
+        if v is None:
+            return 0
+        if isinstance(v, DeviceUtf8):
+            return (v.offsets.data_ptr(), v.data.data_ptr())
+        return v.data_ptr() if hasattr(v, "data_ptr") else id(v)
+    key = tuple(ident(getattr(obj, f)) for f in fields) + (getattr(obj, "rows", None),)
+    hit = obj.__dict__.get("_ffi_cache")
+    if hit is None or hit[0] != key:
+        hit = (key, make())
+        obj.__dict__["_ffi_cache"] = hit
+    return hit[1]
+
+
 # ------------------------------------------------------------------ device column containers
 @dataclass
 class DeviceUtf8:
@@ -43,7 +61,8 @@ class Bids:
 
     def ffi(self) -> _ffi.BidCols:
         p = lambda t: None if t is None else t.data_ptr()
-        return _ffi.BidCols(p(self.auction), p(self.bidder), p(self.price), p(self.b_date_time), self.rows)
+        return _cached_ffi(self, ("auction", "bidder", "price", "b_date_time"),
+                           lambda: _ffi.BidCols(p(self.auction), p(self.bidder), p(self.price), p(self.b_date_time), self.rows))
 
 
 @dataclass
@@ -61,7 +80,7 @@ class Auctions:
 
     def ffi(self) -> _ffi.AuctionCols:
         p = lambda t: None if t is None else t.data_ptr()
-        return _ffi.AuctionCols(p(self.a_id), p(self.seller), p(self.category), self.rows)
+        return _cached_ffi(self, ("a_id", "seller", "category"), lambda: _ffi.AuctionCols(p(self.a_id), p(self.seller), p(self.category), self.rows))
 
 
 @dataclass
@@ -75,8 +94,8 @@ class Persons:
     def ffi(self) -> _ffi.PersonCols:
         z = _ffi.Utf8(None, None)
         u = lambda c: z if c is None else c.ffi()
-        return _ffi.PersonCols(None if self.p_id is None else self.p_id.data_ptr(), u(self.name), u(self.city),
-                               u(self.state), self.rows)
+        return _cached_ffi(self, ("p_id", "name", "city", "state"),
+                           lambda: _ffi.PersonCols(None if self.p_id is None else self.p_id.data_ptr(), u(self.name), u(self.city), u(self.state), self.rows))
 
 
 @dataclass
@@ -96,9 +115,10 @@ class WindowSchedule:
         return len(self.win_pane_lo)
 
     def ffi(self) -> _ffi.Windows:
-        return _ffi.Windows(self.pane_row_offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(self.pane_row_offsets) - 1,
-                            self.win_pane_lo.ctypes.data_as(C.POINTER(C.c_int32)),
-                            self.win_pane_hi.ctypes.data_as(C.POINTER(C.c_int32)), len(self.win_pane_lo))
+        return _cached_ffi(self, ("pane_row_offsets", "win_pane_lo", "win_pane_hi"),
+                           lambda: _ffi.Windows(self.pane_row_offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(self.pane_row_offsets) - 1,
+                                                self.win_pane_lo.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                self.win_pane_hi.ctypes.data_as(C.POINTER(C.c_int32)), len(self.win_pane_lo)))
 
     def window_rows(self, w: int):
         return int(self.pane_row_offsets[self.win_pane_lo[w]]), int(self.pane_row_offsets[self.win_pane_hi[w]])
