@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
         _lib.oracle_take_utf8.restype = u64
         _lib.oracle_hash_utf8_rows.argtypes = [vp, vp, vp, u64, vp]
         _lib.oracle_hash_utf8_rows.restype = None
+        _lib.oracle_ysb_campaign_counts.argtypes = [vp, vp, vp, vp, u64, C.c_char_p, u64, vp, vp, vp, u64, vp]
+        _lib.oracle_ysb_campaign_counts.restype = C.c_int
     return _lib
 
 
@@ -466,6 +468,62 @@ def ysb_campaign_counts(ad_id: Utf8, event_type: Utf8, c_ad_id: Utf8, campaign_i
     return out
 
 
+def _utf8_rows(u: "Utf8"):
+    b = u.data.tobytes()
+    return [b[u.offsets[i]:u.offsets[i + 1]] for i in range(len(u))]
+
+
+def ysb_campaign_groups(campaign_id: "Utf8"):
+    """(group number per campaign row, the groups' campaign_id bytes): rows with equal campaign_id share a number."""
+    names, group = {}, np.empty(len(campaign_id), np.int32)
+    for r, c in enumerate(_utf8_rows(campaign_id)):
+        group[r] = names.setdefault(c, len(names))
+    return group, list(names)
+
+
+def ysb_campaign_counts_c(ad_id: "Utf8", event_type: "Utf8", c_ad_id: "Utf8", campaign_id: "Utf8", lit: bytes = b"view", groups=None):
+    """ysb.sql for one window through the scalar C twin (oracle_ysb_campaign_counts): same {campaign_id bytes: COUNT(*)} as the
+    dict walk above, at C speed (ctypes releases the GIL: bench.py runs one window per thread).  `groups`: ysb_campaign_groups(campaign_id)
+    when the caller runs many windows against one campaign table."""
+    group, names = groups if groups is not None else ysb_campaign_groups(campaign_id)
+    counts = np.zeros(max(len(names), 1), np.uint64)
+    ad_off, et_off = np.ascontiguousarray(ad_id.offsets, np.int32), np.ascontiguousarray(event_type.offsets, np.int32)
+    ad_data, et_data = np.ascontiguousarray(ad_id.data), np.ascontiguousarray(event_type.data)
+    c_off, c_data = np.ascontiguousarray(c_ad_id.offsets, np.int32), np.ascontiguousarray(c_ad_id.data)
+    rc = lib().oracle_ysb_campaign_counts(_p(ad_off), _p(ad_data), _p(et_off), _p(et_data), len(ad_id), lit, len(lit), _p(c_off), _p(c_data),
+                                          _p(np.ascontiguousarray(group)), len(c_ad_id), _p(counts))
+    if rc != 0:
+        raise MemoryError("oracle_ysb_campaign_counts")
+    return {names[g]: int(counts[g]) for g in range(len(names)) if counts[g]}
+
+
+def ysb_campaign_counts_arrow(ad_id: "Utf8", event_type: "Utf8", c_ad_id: "Utf8", campaign_id: "Utf8", lit: bytes = b"view"):
+    """The same window through Arrow C++ (pyarrow compute / Acero: filter, hash join, group_by count_all) -- the independent second
+    engine the YSB goldens are minted against (the reference's own differential YSB test compares its distributed run with a local
+    DataFusion run, flock/src/launcher/aws/mod.rs:681-844; DataFusion is not buildable here)."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+
+    def arr(u, binary=True):
+        return pa.Array.from_buffers(pa.binary(), len(u), [None, pa.py_buffer(np.ascontiguousarray(u.offsets, np.int32)), pa.py_buffer(np.ascontiguousarray(u.data))])
+    ev = pa.table({"ad_id": arr(ad_id), "event_type": arr(event_type)})
+    ev = ev.filter(pc.equal(ev["event_type"], pa.scalar(lit, pa.binary())))
+    ca = pa.table({"c_ad_id": arr(c_ad_id), "campaign_id": arr(campaign_id)})
+    j = ev.join(ca, keys="ad_id", right_keys="c_ad_id", join_type="inner")
+    g = j.group_by("campaign_id", use_threads=False).aggregate([([], "count_all")])
+    return dict(zip(g["campaign_id"].to_pylist(), g["count_all"].to_pylist()))
+
+
+def ysb_fingerprint(counts: dict) -> str:
+    """Order-free fingerprint of one window's {campaign_id: count} (rows:sum of fmix64 row hashes, as multiset_fingerprint)."""
+    names = sorted(counts)
+    if not names:
+        return "0:0000000000000000"
+    off = np.concatenate(([0], np.cumsum([len(c) for c in names]))).astype(np.int32)
+    col = Utf8(off, np.frombuffer(b"".join(names), np.uint8).copy() if off[-1] else np.zeros(0, np.uint8))
+    return multiset_fingerprint([col, np.array([counts[c] for c in names], np.int64)])
+
+
 # ---- q11: user sessions ---------------------------------------------------------------------------------------------
 def q11_user_sessions(bidder, b_date_time, epoch_row_offsets, timeout_s, base_time_ms):
     """The session launcher's walk, literally (flock-function/src/aws/window/session.rs), then q11.sql over what every
@@ -550,6 +608,68 @@ def q11_user_sessions_columnar(bidder, b_date_time, epoch_row_offsets, timeout_s
     o = np.argsort(close[keep], kind="stable")
     out_off = np.searchsorted(close[keep][o], np.arange(n_epochs + 1), side="left").astype(np.int64)
     return out_off, who[keep][o].astype(np.int32), cnt[keep][o], mn[keep][o], mx[keep][o]
+
+
+def q11_user_sessions_arrow(bidder, b_date_time, epoch_row_offsets, timeout_s, base_time_ms):
+    """q11 a third way, with Arrow C++ doing the relational work (pyarrow compute / Acero): rows sorted by (bidder, arrival), a session
+    id per row from a running sum of "a new session starts here", `group_by(session) -> COUNT / MIN / MAX` and a second
+    `group_by(close epoch, bidder)` for q11.sql's own GROUP BY over what one epoch hands out.  The break and close rules are
+    session.rs:64-178 as stated at q11_user_sessions; this is the engine the q11 goldens are minted against (with the literal walk).
+    Returns the same tuple as q11_user_sessions_columnar."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    off = np.asarray(epoch_row_offsets, dtype=np.int64)
+    n_epochs, lo, hi = len(off) - 1, int(off[0]), int(off[-1])
+    n = hi - lo
+    if n == 0:
+        return (np.zeros(n_epochs + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.int64))
+    row = np.arange(n, dtype=np.int64)
+    ep = (np.searchsorted(off - lo, row, side="right") - 1).astype(np.int64)
+    t = pa.table({"bidder": np.asarray(bidder)[lo:hi], "ts": np.asarray(b_date_time, np.int64)[lo:hi], "ep": ep, "row": row})
+    t = t.take(pc.sort_indices(t, sort_keys=[("bidder", "ascending"), ("row", "ascending")]))
+    sec = pc.divide(t["ts"], 1000)                                       # (timestamps >= 0: truncation = floor)
+    clock = pc.max_element_wise(t["ep"], pc.add(pc.subtract(sec, base_time_ms // 1000), timeout_s + 1))   # first epoch whose time-out check fires
+    k, e = t["bidder"].combine_chunks(), t["ep"].combine_chunks()
+    sec, clock = sec.combine_chunks(), clock.combine_chunks()
+    prev = lambda a: a.slice(0, n - 1)
+    nxt = lambda a: a.slice(1, n - 1)
+    joins = pc.and_(pc.equal(prev(k), nxt(k)),
+                    pc.or_(pc.equal(prev(e), nxt(e)),
+                           pc.and_(pc.greater_equal(prev(clock), nxt(e)), pc.less_equal(pc.subtract(nxt(sec), prev(sec)), timeout_s))))
+    starts = pa.concat_arrays([pa.array([1], pa.int64()), pc.cast(pc.invert(joins), pa.int64())])
+    sid = pc.cumulative_sum(starts)
+    t = t.append_column("sid", sid).append_column("clock", clock)
+    g = t.group_by("sid", use_threads=False).aggregate([("bidder", "min"), ("ts", "min"), ("ts", "max"), ([], "count_all"), ("clock", "max"), ("ep", "max"),
+                                                         ("row", "max")]).sort_by("sid")
+    who = g["bidder_min"].to_numpy()
+    m = len(who)
+    # a session closes when its bidder's NEXT session starts (that epoch) or when the time-out check fires, whichever is first;
+    # the clock of a session = the clock of its LAST row (rows of a session are time-ordered within the walk: take the last by arrival)
+    last_row = g["row_max"].to_numpy()
+    order_rows = t["row"].to_numpy()
+    pos_of = np.empty(n, np.int64)
+    pos_of[order_rows] = np.arange(n)
+    last_clock = clock.to_numpy()[pos_of[last_row]]
+    first_ep_next = np.r_[t["ep"].to_numpy()[np.flatnonzero(starts.to_numpy())][1:], -1]
+    follows = np.r_[who[1:] == who[:-1], False]
+    close = np.where(follows, np.minimum(last_clock, first_ep_next), np.where(last_clock <= n_epochs - 1, last_clock, -1))
+    s = pa.table({"close": close, "bidder": who, "cnt": g["count_all"].to_numpy(), "mn": g["ts_min"].to_numpy(), "mx": g["ts_max"].to_numpy()})
+    s = s.filter(pc.greater_equal(s["close"], 0))
+    r = s.group_by(["close", "bidder"], use_threads=False).aggregate([("cnt", "sum"), ("mn", "min"), ("mx", "max")]).sort_by([("close", "ascending"), ("bidder", "ascending")])
+    c = r["close"].to_numpy()
+    out_off = np.searchsorted(c, np.arange(n_epochs + 1), side="left").astype(np.int64)
+    return (out_off, r["bidder"].to_numpy().astype(np.int32), r["cnt_sum"].to_numpy().astype(np.uint64), r["mn_min"].to_numpy().astype(np.int64),
+            r["mx_max"].to_numpy().astype(np.int64))
+
+
+def q11_fingerprints(result) -> list:
+    """One fingerprint per epoch of a (epoch_out_offsets, bidder, bid_count, start_time, end_time) result."""
+    out_off, who, cnt, mn, mx = result
+    fps = []
+    for t in range(len(out_off) - 1):
+        sl = slice(int(out_off[t]), int(out_off[t + 1]))
+        fps.append(multiset_fingerprint([np.asarray(who[sl], np.int32), np.asarray(cnt[sl]).astype(np.int64), np.asarray(mn[sl], np.int64), np.asarray(mx[sl], np.int64)]))
+    return fps
 
 
 # ---- JSON lines <-> columns (the reference's event buffers and `event_bytes_to_batch`) ------------------------------------

@@ -245,3 +245,58 @@ void oracle_hash_utf8_rows(const int32_t *off, const unsigned char *bytes, const
         out[i] = fmix64(h + (uint64_t)(off[r + 1] - off[r]) * 0x9E3779B97F4A7C15ull);
     }
 }
+
+/* ---- Yahoo Streaming Benchmark (benchmarks/src/ysb/ysb.sql; flock/src/distributed_plan/planner.rs:298-346):
+ *   SELECT campaign_id, COUNT(*) FROM ad_event INNER JOIN campaign ON ad_id = c_ad_id WHERE event_type = lit GROUP BY campaign_id
+ * One call = one window.  The campaign table's rows are given with a group number per row (rows with equal campaign_id bytes share
+ * a number; the Python side assigns them); counts[g] += 1 for every (event, campaign row) pair that joins -- duplicate c_ad_id rows
+ * all count (A4), keys compare bytewise (A7).  The scalar C twin of oracle.ysb_campaign_counts (a Python dict walk, kept as the
+ * literal restatement), cross-checked against it and against Arrow C++ (tests/test_oracle_ysb.py). */
+static uint64_t fnv1a(const uint8_t *p, uint64_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint64_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+int oracle_ysb_campaign_counts(const int32_t *ad_off, const uint8_t *ad_data, const int32_t *et_off, const uint8_t *et_data, uint64_t n_events,
+                               const uint8_t *lit, uint64_t lit_len, const int32_t *c_off, const uint8_t *c_data, const int32_t *c_group,
+                               uint64_t n_campaign_rows, uint64_t *counts /* n_groups, zeroed by the caller */) {
+    uint64_t cap = 16;
+    while (cap < n_campaign_rows * 2 + 1) cap <<= 1;
+    int64_t *head = (int64_t *)malloc(cap * sizeof(int64_t));      /* slot -> first campaign row with that key, -1 = empty */
+    int64_t *next = (int64_t *)malloc((n_campaign_rows + 1) * sizeof(int64_t));
+    if (!head || !next) { free(head); free(next); return -1; }
+    for (uint64_t i = 0; i < cap; ++i) head[i] = -1;
+    for (uint64_t r = 0; r < n_campaign_rows; ++r) {
+        const uint8_t *k = c_data + c_off[r];
+        const uint64_t len = (uint64_t)(c_off[r + 1] - c_off[r]);
+        uint64_t s = fnv1a(k, len) & (cap - 1);
+        for (;;) {
+            if (head[s] < 0) { head[s] = (int64_t)r; next[r] = -1; break; }
+            const int64_t h = head[s];
+            const uint64_t hl = (uint64_t)(c_off[h + 1] - c_off[h]);
+            if (hl == len && memcmp(c_data + c_off[h], k, len) == 0) {   /* same key: chain (order is irrelevant for counting) */
+                next[r] = next[h]; next[h] = (int64_t)r; break;
+            }
+            s = (s + 1) & (cap - 1);
+        }
+    }
+    for (uint64_t i = 0; i < n_events; ++i) {
+        const uint64_t tl = (uint64_t)(et_off[i + 1] - et_off[i]);
+        if (tl != lit_len || memcmp(et_data + et_off[i], lit, lit_len) != 0) continue;
+        const uint8_t *k = ad_data + ad_off[i];
+        const uint64_t len = (uint64_t)(ad_off[i + 1] - ad_off[i]);
+        uint64_t s = fnv1a(k, len) & (cap - 1);
+        for (;;) {
+            const int64_t h = head[s];
+            if (h < 0) break;
+            const uint64_t hl = (uint64_t)(c_off[h + 1] - c_off[h]);
+            if (hl == len && memcmp(c_data + c_off[h], k, len) == 0) {
+                for (int64_t r = h; r >= 0; r = next[r]) counts[c_group[r]] += 1;
+                break;
+            }
+            s = (s + 1) & (cap - 1);
+        }
+    }
+    free(head); free(next);
+    return 0;
+}
