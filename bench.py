@@ -74,6 +74,8 @@ def parse():
                     help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all "
                          "inside libflockgpu; auto = windows at N = 1, exchange at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
+    ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -218,6 +220,16 @@ def roofline(q, stats, rel_rows, table=None):
             "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes), "launches": st["launches"],
             "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
+
+
+def traffic_of(kernel, alg_bytes):
+    """PMC-derived HBM bytes per launch of `kernel` from profiles/traffic.json when they were taken at this workload size."""
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(prof)).get(kernel)
+    except Exception:
+        return None
+    return t if t and 0.9 * alg_bytes <= t <= 3.0 * alg_bytes else None
 
 
 def rel_rows_of(stream):
@@ -410,7 +422,7 @@ def ysb_side(ctx, eps, steps, no_cpu, threads, seconds=50):
     out = {"value": round(g.rows * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(g.rows),
            "windows": res.n_windows, "result_rows": int(res.rows), "seconds_of_events": seconds,
            "roofline": {"bound": "hbm", "kernel": "ysb_count_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_of("ysb_count_kernel", alg),
                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg), "launches": st["launches"],
                         "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}}
     if not no_cpu:
@@ -474,7 +486,7 @@ def q11_side(ctx, eps, steps, no_cpu, seconds=109):
         alg_per_launch = alg / per_step
         out["roofline"] = {"bound": "hbm", "kernel": "sort_emit_kernel", "achieved": round(alg_per_launch / (avg_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_per_launch),
+                           "traffic": traffic_of("sort_emit_kernel", alg_per_launch), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_per_launch),
                            "launches": st["launches"],
                            "kernels_ms_per_step": {k: round(v["total_ms"] / max(steps, 1), 4) for k, v in stats.items()}}
     if not no_cpu:
@@ -529,7 +541,7 @@ def json_side(ctx, steps, no_cpu, block_events=200_000, copies=100):
         alg = n_bytes + 20.0 * n                       # the text once + the four output columns
         out["roofline"] = {"bound": "hbm", "kernel": "json_parse_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                           "traffic": traffic_of("json_parse_kernel", alg), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                            "launches": st["launches"],
                            "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
     if not no_cpu:
@@ -634,6 +646,51 @@ def entry_for(ctx, q, seconds, eps, steps, warmup, no_cpu, threads, barrier=lamb
          "roofline": roofline(q, st, rel_rows_of(s))}
     if not no_cpu and seconds == DEFAULT_SECONDS[q]:
         e["cpu_baseline"] = cpu_baseline(q, s, threads)
+    del s, r
+    torch.cuda.empty_cache()
+    return e
+
+
+# ------------------------------------------------------------------ outside the generator's envelope: the GENERAL hash paths
+# NEXMark ids are dense and time-ordered, and the dense paths (bit blocks, direct-address counters) are what the headline runs on.
+# The same queries on keys in no particular order take the general hash join / hash aggregate kernels -- exact, and measured here so
+# that the fall-back is a number, not a cliff: the stream's keys are shuffled inside every window (q3 / q8: which person holds which
+# p_id; q5: which bid names which auction inside a 5-s pane), sizes as in the dense rows.
+GENERAL = {"q3_general": (3, 1000, "q3_probe_count_kernel", 8.0, "auction"), "q8_general": (8, 1000, "q8_sellers_set_kernel", 4.0, "auction"),
+           "q5_uniform": (5, 1087, "q5_count_slow_kernel", 4.0, "bid")}
+
+
+def shuffle_within_segments(col, seg_off, seed):
+    """A permutation of `col` that moves values only inside their segment [seg_off[i], seg_off[i + 1]) (device tensor in, copy out)."""
+    import numpy as np
+    import torch
+    g = torch.Generator(device=col.device)
+    g.manual_seed(seed)
+    n = int(col.numel())
+    seg = torch.repeat_interleave(torch.arange(len(seg_off) - 1, device=col.device), torch.from_numpy(np.diff(seg_off)).to(col.device))
+    key = seg.to(torch.float64) + torch.rand(n, generator=g, device=col.device, dtype=torch.float64) * 0.999
+    perm = torch.argsort(key)
+    out = col[perm].contiguous()
+    del seg, key, perm
+    return out
+
+
+def general_entry(ctx, label, eps, steps):
+    import torch
+    from flock_amd import query_window, run_query
+    q, seconds, kernel, bpr, rel = GENERAL[label]
+    s = make_stream(ctx, q, seconds, eps, 0)
+    w = query_window(q)
+    if q == 5:
+        s.bids.auction = shuffle_within_segments(s.bids.auction, s.window_schedule("bid", w).pane_row_offsets, 5)
+    else:
+        s.persons.p_id = shuffle_within_segments(s.persons.p_id, s.window_schedule("person", w).pane_row_offsets, 5)
+    torch.cuda.synchronize()
+    dt, st, r = run_steps(ctx, lambda: run_query(ctx, q, s), steps, 2, lambda: None, kernel)
+    table = {q: (kernel, bpr, rel)}
+    e = {"value": round(input_rows(q, s) * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(input_rows(q, s)),
+         "windows": r.n_windows, "result_rows": int(r.rows), "seconds_of_events": seconds, "keys": "shuffled inside every window (general hash path)",
+         "roofline": roofline(q, st, rel_rows_of(s), table)}
     del s, r
     torch.cuda.empty_cache()
     return e
@@ -902,6 +959,17 @@ def main():
         from flock_amd import GpuContext
         print(json.dumps(plan_collect_pcie(GpuContext(local), args.eps, max(args.steps, 5))))
         return
+    if args.only_side:
+        from flock_amd import GpuContext
+        g = GpuContext(local)
+        n = max(args.steps, 3)
+        e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True)}[args.only_side]()
+        print(json.dumps(e))
+        return
+    if args.only_general:
+        from flock_amd import GpuContext
+        print(json.dumps(general_entry(GpuContext(local), args.only_general, args.eps, max(args.steps, 3))))
+        return
     mode = args.mode if args.mode != "auto" else ("exchange" if world > 1 else "windows")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1043,6 +1111,11 @@ def main():
             try:
                 also[label] = entry_for(ctx, q2, secs, args.eps, steps2, 2, args.no_cpu, args.cpu_threads)
             except Exception as e:  # a side measurement must never hide the headline
+                also[label] = {"error": repr(e)}
+        for label in GENERAL:
+            try:
+                also[label] = general_entry(ctx, label, args.eps, 5)
+            except Exception as e:
                 also[label] = {"error": repr(e)}
         for label, fn in (("q11_next", lambda: q11_side(ctx, args.eps, steps2, args.no_cpu)),
                           ("json_ingest_next", lambda: json_side(ctx, steps2, args.no_cpu)),

@@ -19,17 +19,22 @@ DOMINANT = {5: "q5_count_kernel", 2: "q2_flag_kernel", 3: "q3_probe_flag_kernel"
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, "
                        "tools/gpu_profile.sh): bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 reports half of a 16 B/lane coalesced stream, "
                        "MI355X_MICROARCH.md HBM section) + WRITE_SIZE_KB * 1024.  Source CSVs: profiles/%s/q*_pmc_*.csv" % tag}
-for q, kern in DOMINANT.items():
+# (file prefix, kernel): the query rows, the "next" side entries and the general-path rows
+ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
+                                                            ("q3_general", "q3_probe_general_kernel"), ("q8_general", "q8_sellers_set_kernel"),
+                                                            ("q5_uniform", "q5_count_slow_kernel"), ("q4", "aq_final_kernel")]
+for q, kern in ROWS:
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        p = os.path.join(dst, f"q{q}_pmc_{c}.csv")
+        p = os.path.join(dst, f"{q}_pmc_{c}.csv")
         if not os.path.exists(p):
             continue
         for r in csv.DictReader(open(p)):
             if kern + "(" in r["kernel"] or kern + "<" in r["kernel"]:
                 vals[c] = float(r[f"avg_{c}_KB"])
-    if len(vals) == 2:
-        traffic[kern] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
-        traffic[kern + "_detail"] = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
+    name = kern if not q.endswith(("_general", "_uniform")) and q != "q4" else f"{kern}@{q}"
+    if len(vals) == 2 and name not in traffic:
+        traffic[name] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+        traffic[name + "_detail"] = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

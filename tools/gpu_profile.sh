@@ -34,6 +34,29 @@ for q in ${QUERIES:-5 2 8 3 7 9 13}; do
   done
   rm -f "$OUT"/q${q}_*_run.log
 done
+# the side entries bench.py reports under `also` (q11, YSB, JSON ingest) and the general-path rows: kernel stats + PMC passes each
+for side in ${SIDES:-q11 ysb json}; do
+  cmd="python bench.py --only-side $side --steps 3"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$side -- $cmd > "$OUT/${side}_stats_run.log" 2>&1
+  f=$(find /tmp/prof_$side -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${side}_kernel_stats.csv"
+  grep '^{' "$OUT/${side}_stats_run.log" | tail -1 > "$OUT/${side}_bench_under_rocprof.json"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${c}_$side -- $cmd > "$OUT/${side}_${c}_run.log" 2>&1
+    summarise /tmp/pmc_${c}_$side $c "$OUT/${side}_pmc_${c}.csv"
+  done
+  rm -f "$OUT"/${side}_*_run.log
+done
+for gen in ${GENERALS:-q3_general q8_general q5_uniform}; do
+  cmd="python bench.py --only-general $gen --steps 3"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$gen -- $cmd > "$OUT/${gen}_stats_run.log" 2>&1
+  f=$(find /tmp/prof_$gen -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${gen}_kernel_stats.csv"
+  grep '^{' "$OUT/${gen}_stats_run.log" | tail -1 > "$OUT/${gen}_bench_under_rocprof.json"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${c}_$gen -- $cmd > "$OUT/${gen}_${c}_run.log" 2>&1
+    summarise /tmp/pmc_${c}_$gen $c "$OUT/${gen}_pmc_${c}.csv"
+  done
+  rm -f "$OUT"/${gen}_*_run.log
+done
 ls -la "$OUT"
 # the "next" rows that bench.py only reports under `also` (q11, YSB, JSON ingest, q4, the 1e9 variants): one kernel-stats run
 # of the whole default bench
