@@ -827,172 +827,6 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
     }
 }
 
-// ---- the same two passes walking PANES instead of windows ----------------------------------------------------------------------
-// q5_scan_kernel reads, per window, the counters of every pane of the window: under Hopping(10 s, 5 s) every pane is in two windows
-// and its counters are read twice per pass (0.57 GB for 1e9 bids, 0.105 ms).  Here workgroup (x, p) sweeps its share of pane p's
-// counters ONCE and serves every window w that contains p: the count of key k in w is the sum over w's panes whose range holds k
-// (+ w's straggler table), and k is accounted to w by the LOWEST such pane -- the sweep of a higher pane skips the keys a lower pane
-// of the same window also covers, the lower pane's sweep fetches the higher panes' counters for them.  NEXMark's panes cover
-// consecutive id ranges that overlap by the few auctions in flight at the pane boundary, so the second fetch is a few per cent.
-// Straggler-table entries whose key lies in NO pane range of the window are handled by the window's first pane's workgroups.
-// Needs at most kMaxWinPanes windows per pane (the host falls back to q5_scan_kernel otherwise).
-template <bool SELECT>
-__global__ __launch_bounds__(kBlock) void q5_pane_scan_kernel(const WinDesc *__restrict__ wins, const PaneDesc *__restrict__ panes,
-                                                              const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx,
-                                                              const uint32_t *__restrict__ counters, const uint64_t *__restrict__ tables, uint32_t cap,
-                                                              const uint32_t *__restrict__ tab_used, uint64_t *win_max, uint64_t *win_groups,
-                                                              uint32_t *block_max, uint32_t *cursor, uint32_t out_cap, int32_t *out_win, int32_t *out_key,
-                                                              const uint64_t *__restrict__ spec_info) {
-    __shared__ WinDesc s_win[kMaxWinPanes];
-    __shared__ PaneDesc s_wp[kMaxWinPanes][kMaxWinPanes];
-    __shared__ int32_t s_w[kMaxWinPanes];
-    __shared__ uint32_t s_tab[kMaxWinPanes], s_mx[kMaxWinPanes], s_active[kMaxWinPanes];
-    __shared__ uint32_t s_best[kMaxWinPanes][kWavesPerBlock];
-    __shared__ uint64_t s_groups[kMaxWinPanes][kWavesPerBlock];
-    if (spec_info && !spec_info[2]) return;
-    const int32_t p = blockIdx.y;
-    const int wp0 = pane_win_ptr[p], nw = pane_win_ptr[p + 1] - wp0;
-    if (nw == 0) return;
-    if ((int)threadIdx.x < nw) {
-        const int32_t w = pane_win_idx[wp0 + threadIdx.x];
-        const WinDesc d = wins[w];
-        s_w[threadIdx.x] = w;
-        s_win[threadIdx.x] = d;
-        s_tab[threadIdx.x] = tab_used[w];
-        const uint32_t mx = SELECT ? (uint32_t)win_max[w] : 0u;
-        s_mx[threadIdx.x] = mx;
-        // select visits the same keys as the same block of the max pass did: a block whose maximum for a window is not the window's
-        // holds no winner of it (an empty window -- MAX is NULL -- has no winners at all)
-        const int slot = p - d.pane_lo;   // (a window of more than kMaxWinPanes panes has no counters: only its first pane's workgroups do anything for it)
-        s_active[threadIdx.x] = !SELECT || (mx != 0 && slot < kMaxWinPanes && block_max[((size_t)w * kMaxWinPanes + slot) * gridDim.x + blockIdx.x] == mx);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nw * kMaxWinPanes; t += kBlock) {
-        const int wi = t / kMaxWinPanes, q = t % kMaxWinPanes;
-        const WinDesc d = s_win[wi];
-        PaneDesc pq{0, 0, 0, 0};
-        if (d.range && d.pane_lo + q < d.pane_hi && d.pane_hi - d.pane_lo <= kMaxWinPanes) pq = panes[d.pane_lo + q];
-        s_wp[wi][q] = pq;
-    }
-    __syncthreads();
-    bool any = false;
-    for (int wi = 0; wi < nw; ++wi) any = any || s_active[wi];
-    if (SELECT && !any) return;
-    const PaneDesc pd = panes[p];
-    uint32_t best[kMaxWinPanes], groups[kMaxWinPanes];
-#pragma unroll
-    for (int wi = 0; wi < kMaxWinPanes; ++wi) best[wi] = groups[wi] = 0;
-    const uint32_t n4 = pd.range / 4;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
-        const int64_t k0 = pd.base + (int64_t)i * 4;
-        const uint4 me = *reinterpret_cast<const uint4 *>(counters + pd.cnt_off + (uint64_t)i * 4);
-#pragma unroll
-        for (int wi = 0; wi < kMaxWinPanes; ++wi) {
-            if (wi >= nw) break;
-            if (!s_active[wi] || !s_win[wi].range) continue;
-            const int self = p - s_win[wi].pane_lo, n_q = s_win[wi].pane_hi - s_win[wi].pane_lo;
-            uint32_t c[4] = {me.x, me.y, me.z, me.w};
-            bool owned = true;
-            for (int q = 0; q < n_q; ++q) {
-                if (q == self) continue;
-                const PaneDesc pq = s_wp[wi][q];
-                const uint64_t idx = (uint64_t)(k0 - pq.base);
-                if (idx < (uint64_t)pq.range) {   // (bases and ranges are multiples of 4: the aligned group is inside or outside as a whole)
-                    if (q < self) {
-                        owned = false;   // a lower pane of this window covers these keys: its sweep accounts for them
-                        break;
-                    }
-                    const uint4 o = *reinterpret_cast<const uint4 *>(counters + pq.cnt_off + idx);
-                    c[0] += o.x; c[1] += o.y; c[2] += o.z; c[3] += o.w;
-                }
-            }
-            if (!owned) continue;
-            if (s_tab[wi]) {
-                const uint64_t *tab = tables + (size_t)s_w[wi] * cap;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] += table_find(tab, cap, (uint32_t)(int32_t)(k0 + j));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (SELECT) {
-                    const bool hit = c[j] == s_mx[wi];
-                    const uint64_t b = __ballot(hit);
-                    if (b) {   // one cursor bump per wave: when every group ties for the MAX each lane is a winner
-                        const int leader = __ffsll((unsigned long long)b) - 1;
-                        uint32_t base = 0;
-                        if (lane_id() == leader) base = atomicAdd(cursor, (uint32_t)__popcll((unsigned long long)b));
-                        base = __builtin_amdgcn_readlane(base, leader);
-                        const uint32_t pos = base + mbcnt(b);
-                        if (hit && pos < out_cap) {
-                            out_win[pos] = s_w[wi];
-                            out_key[pos] = (int32_t)(k0 + j);
-                        }
-                    }
-                } else {
-                    best[wi] = max(best[wi], c[j]);
-                    groups[wi] += c[j] != 0;
-                }
-            }
-        }
-    }
-    // straggler-table entries outside every pane range of their window: complete on their own; served by the window's first pane
-#pragma unroll
-    for (int wi = 0; wi < kMaxWinPanes; ++wi) {
-        if (wi >= nw) break;
-        if (!s_tab[wi] || s_win[wi].pane_lo != p || !s_active[wi]) continue;
-        const uint64_t *tab = tables + (size_t)s_w[wi] * cap;
-        const int n_q = s_win[wi].range ? min(s_win[wi].pane_hi - s_win[wi].pane_lo, kMaxWinPanes) : 0;
-        for (uint32_t sl = blockIdx.x * kBlock + threadIdx.x; sl < cap; sl += gridDim.x * kBlock) {
-            const uint64_t e = tab[sl];
-            if (!e) continue;
-            const int64_t key = (int32_t)(uint32_t)(e >> 32);
-            bool covered = false;
-            for (int q = 0; q < n_q; ++q) covered = covered || (uint64_t)(key - s_wp[wi][q].base) < (uint64_t)s_wp[wi][q].range;
-            if (covered) continue;   // counted by the sweep above
-            if (SELECT) {
-                if ((uint32_t)e == s_mx[wi]) {
-                    const uint32_t pos = atomicAdd(cursor, 1u);
-                    if (pos < out_cap) {
-                        out_win[pos] = s_w[wi];
-                        out_key[pos] = (int32_t)key;
-                    }
-                }
-            } else {
-                best[wi] = max(best[wi], (uint32_t)e);
-                groups[wi] += 1;
-            }
-        }
-    }
-    if (!SELECT) {   // one update per WORKGROUP and window (same-address atomics from every wave were the pass's pace once)
-#pragma unroll
-        for (int wi = 0; wi < kMaxWinPanes; ++wi) {
-            if (wi >= nw) break;
-            const uint32_t b = wave_max_u32(best[wi]);
-            const uint64_t g = wave_sum_u64(groups[wi]);
-            if (lane_id() == 0) {
-                s_best[wi][threadIdx.x >> 6] = b;
-                s_groups[wi][threadIdx.x >> 6] = g;
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < nw) {
-            const int wi = threadIdx.x;
-            uint32_t b = 0;
-            uint64_t gs = 0;
-#pragma unroll
-            for (int v = 0; v < kWavesPerBlock; ++v) {
-                b = max(b, s_best[wi][v]);
-                gs += s_groups[wi][v];
-            }
-            const int32_t w = s_w[wi];
-            const int slot = p - s_win[wi].pane_lo;
-            if (b && slot < kMaxWinPanes) block_max[((size_t)w * kMaxWinPanes + slot) * gridDim.x + blockIdx.x] = b;
-            if (b) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)b);
-            if (gs) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)gs);
-        }
-    }
-}
-
 // ---- partial aggregation (q5.dag: HashAggregateExec mode=Partial, the stage BEFORE the hash repartition) ---------------
 // After the count pass with "window = pane", the groups of pane p are its non-zero direct-address counters plus the
 // live slots of its straggler table.  Both are compacted with the flag-tile machinery over ONE flat index space:
@@ -1078,10 +912,8 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     }
     if (max_win_rows >= (int64_t(1) << 32))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: a window holds >= 2^32 rows (32-bit counters)");
-    int max_pane_wins = 0;
     for (int p = 0; p < n_panes; ++p) {
         if (ptr[p + 1]) covered_rows += win->pane_row_offsets[p + 1] - win->pane_row_offsets[p];
-        max_pane_wins = std::max(max_pane_wins, ptr[p + 1]);
         ptr[p + 1] += ptr[p];
     }
     idx.resize(ptr[n_panes]);
@@ -1260,20 +1092,15 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
         // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
         const uint64_t per_win = n_win > 0 ? std::max<uint64_t>(cap, scan_total / n_win / 4) : cap;
-        // the pane-walking passes (every pane's counters read once per pass) need the windows of a pane to fit their LDS tables
-        static const bool no_pane_scan = getenv("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob)
-        const bool pane_scan = !no_pane_scan && max_pane_wins <= kMaxWinPanes && n_panes > 0;
-        const uint64_t per_pane = n_panes > 0 ? std::max<uint64_t>(cap, cnt_total / (uint64_t)n_panes / 4) : cap;
-        const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)(pane_scan ? per_pane : per_win), kBlock * 2), 1), 64);
+        const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
         uint32_t *block_max = nullptr;
-        const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_scan ? kMaxWinPanes : 1);
-        FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)n_block_max, &block_max));
+        FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * std::max(n_win, 1), &block_max));
         {   // one clear for everything this attempt writes into
-            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, n_block_max});
+            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, (uint64_t)gx * n_win});
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
             hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
                                (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
-                               slow_list, block_max, n_block_max, plain_clear ? 1 : 0);
+                               slow_list, block_max, (uint64_t)gx * n_win, plain_clear ? 1 : 0);
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
         if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
@@ -1349,20 +1176,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             part->rows = n_out;
             return FLOCKGPU_OK;
         }
-        if (n_win > 0 && pane_scan) {
-            {
-                LaunchScope ls(ctx, "q5_max_kernel");
-                hipLaunchKernelGGL(q5_pane_scan_kernel<false>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_wins, d_panes, d_ptr, d_idx, counters, tables,
-                                   cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
-            }
-            FG_TRY(check_launch(ctx, "q5_max_kernel"));
-            {
-                LaunchScope ls(ctx, "q5_select_kernel");
-                hipLaunchKernelGGL(q5_pane_scan_kernel<true>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_wins, d_panes, d_ptr, d_idx, counters, tables,
-                                   cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
-            }
-            FG_TRY(check_launch(ctx, "q5_select_kernel"));
-        } else if (n_win > 0) {
+        if (n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<false>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
