@@ -667,6 +667,9 @@ def shuffle_within_segments(col, seg_off, seed):
     g = torch.Generator(device=col.device)
     g.manual_seed(seed)
     n = int(col.numel())
+    seg_off = np.asarray(seg_off, np.int64)
+    if seg_off[-1] < n:      # rows behind the last segment (the partial trailing window of a hopping schedule) stay among themselves
+        seg_off = np.append(seg_off, n)
     seg = torch.repeat_interleave(torch.arange(len(seg_off) - 1, device=col.device), torch.from_numpy(np.diff(seg_off)).to(col.device))
     key = seg.to(torch.float64) + torch.rand(n, generator=g, device=col.device, dtype=torch.float64) * 0.999
     perm = torch.argsort(key)
