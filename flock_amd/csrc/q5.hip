@@ -827,6 +827,246 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
     }
 }
 
+// ---- keys in no particular order: partition by key range, then count in LDS ("wide" mode) -----------------------------------------
+// The kernels above are built for keys that sweep their range with time (a tile of 8192 bids names ~600 consecutive auctions).  Bids
+// whose keys are spread over the whole pane range (3e5 ids per 5-s pane; `also.q5_uniform`: the generator's bids shuffled inside
+// their panes) make every tile "wide": the LDS histogram declines it and q5_count_slow_kernel ends up issuing one global atomic per
+// ROW on a random counter -- 2.5e10 atomics / s is what the memory side gives (39 ms per 1e9 bids).  General hash aggregation the
+// LDS-staged way instead:
+//   partition : one radix pass over the pane's rows on the HIGH bits of (key - pane base): digit = (key - base) >> kPartShift, one more
+//               digit for the keys outside the pane's estimated range; count -> scan -> emit as in sort.hip (lanes holding one digit
+//               find each other by ballots, rows leave the tile regrouped by digit as runs of consecutive addresses).  The histogram
+//               matrix is laid out (pane, digit, tile), so ONE scan yields every (pane, digit) bucket as a contiguous run of keys.
+//   count     : one workgroup per (pane, digit) bucket streams its keys into an LDS histogram over the bucket's 2^kPartShift counters
+//               (the first lane's key counted once per instruction: hot keys) and STORES the bins -- it owns them: no global atomics.
+//               The out-of-range bucket goes row by row through emit_pair (the windows' straggler tables), as before.
+// 16 B of traffic per row instead of 4, and ~10x faster than a random global atomic per row.  Chosen from what the previous call of the
+// ctx saw (most tiles wide) and left again when a sample of the partition's tiles turns out narrow.
+constexpr int kPartItems = 16;
+constexpr int kPartTile = kBlock * kPartItems;           // 4096 rows
+constexpr int kPartWaveRows = kPartTile / kWavesPerBlock;
+constexpr int kPartShift = 14;                           // 16384 counters = 64 KB of LDS per bucket
+constexpr int kPartMaxDigits = 256;
+
+__device__ __forceinline__ uint32_t part_digit(int32_t key, const PaneDesc &pd, uint32_t straggler) {
+    const uint64_t idx = (uint64_t)((int64_t)key - pd.base);
+    return idx < (uint64_t)pd.range ? (uint32_t)(idx >> kPartShift) : straggler;
+}
+
+// hist[(tile_first[pane] * nd) + digit * tiles_of_pane + tile_in_pane]
+__global__ __launch_bounds__(kBlock) void q5_part_count_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
+                                                               const int32_t *__restrict__ pane_win_ptr, uint32_t nd, int32_t *__restrict__ hist,
+                                                               uint32_t *__restrict__ sample) {
+    __shared__ uint32_t s_h[kPartMaxDigits];
+    __shared__ int32_t s_red[2 * kWavesPerBlock];
+    s_h[threadIdx.x] = 0;
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kPartTile);
+    const int32_t t0 = st.tile_first[tr.seg], tiles_p = st.tile_first[tr.seg + 1] - t0;
+    int32_t *out = hist + (size_t)t0 * nd + ((int32_t)blockIdx.x - t0);
+    const bool used = pane_win_ptr[tr.seg] != pane_win_ptr[tr.seg + 1];
+    const PaneDesc pd = panes[tr.seg];
+    __syncthreads();
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+    if (used) {
+#pragma unroll
+        for (int it = 0; it < kPartItems / 4; ++it) {
+            const int64_t r0 = tr.tile_begin + (int64_t)(it * kBlock + threadIdx.x) * 4;
+            int32_t k[4];
+            if (r0 >= tr.lo && r0 + 4 <= tr.hi) {
+                const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
+                k[0] = t.x; k[1] = t.y; k[2] = t.z; k[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k[j] = (r0 + j >= tr.lo && r0 + j < tr.hi) ? auction[r0 + j] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = r0 + j >= tr.lo && r0 + j < tr.hi;
+                const uint32_t d = part_digit(k[j], pd, nd - 1);
+                if (valid) {
+                    mn = min(mn, k[j]);
+                    mx = max(mx, k[j]);
+                }
+                const uint32_t hot = __builtin_amdgcn_readfirstlane(d);
+                const uint64_t b = __ballot(valid && d == hot);
+                if (valid && d == hot) {
+                    if (mbcnt(b) == 0) atomicAdd(&s_h[hot], (uint32_t)__popcll((unsigned long long)b));
+                } else if (valid) {
+                    atomicAdd(&s_h[d], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nd) out[(size_t)threadIdx.x * tiles_p] = (int32_t)s_h[threadIdx.x];
+    if ((blockIdx.x & 63u) == 0) {   // a sample of the tiles reports whether the fast kernel would have taken it (span below its histogram)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, __shfl_xor(mn, o, 64));
+            mx = max(mx, __shfl_xor(mx, o, 64));
+        }
+        if (lane_id() == 0) {
+            s_red[threadIdx.x >> 6] = mn;
+            s_red[kWavesPerBlock + (threadIdx.x >> 6)] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kWavesPerBlock; ++w) {
+                mn = min(mn, s_red[w]);
+                mx = max(mx, s_red[kWavesPerBlock + w]);
+            }
+            atomicAdd(&sample[0], 1u);
+            if (mx >= mn && (uint32_t)mx - (uint32_t)mn < (uint32_t)kHist / 2) atomicAdd(&sample[1], 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void q5_part_emit_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
+                                                              const int32_t *__restrict__ pane_win_ptr, uint32_t nd, const int32_t *__restrict__ hist_incl,
+                                                              int32_t *__restrict__ keys_out) {
+    __shared__ uint32_t s_wh[kWavesPerBlock][kPartMaxDigits];  // running digit counts of a wave, then its base inside the digit
+    __shared__ uint32_t s_dig_off[kPartMaxDigits];             // tile-local position of the digit's first row
+    __shared__ uint32_t s_glob[kPartMaxDigits];                // output position of the digit's first row of this tile
+    __shared__ uint32_t s_wave_total[kWavesPerBlock];
+    __shared__ int32_t s_keys[kPartTile];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) s_wh[w][threadIdx.x] = 0;
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kPartTile);
+    if (pane_win_ptr[tr.seg] == pane_win_ptr[tr.seg + 1]) return;   // (block-uniform) the pane is in no window: nothing was counted
+    const int32_t t0 = st.tile_first[tr.seg], tiles_p = st.tile_first[tr.seg + 1] - t0;
+    const int32_t *incl = hist_incl + (size_t)t0 * nd + ((int32_t)blockIdx.x - t0);
+    const PaneDesc pd = panes[tr.seg];
+    const int64_t wave_begin = tr.tile_begin + (int64_t)wave * kPartWaveRows;
+    int32_t k[kPartItems];
+    uint32_t rank[kPartItems];
+#pragma unroll
+    for (int it = 0; it < kPartItems; ++it) {
+        const int64_t r = wave_begin + it * 64 + lane;
+        k[it] = auction[r < tr.lo ? tr.lo : (r >= tr.hi ? tr.hi - 1 : r)];   // clamped: no load under a per-row branch
+    }
+    __syncthreads();
+    volatile uint32_t *wh = s_wh[wave];
+#pragma unroll
+    for (int it = 0; it < kPartItems; ++it) {
+        const int64_t r = wave_begin + it * 64 + lane;
+        const bool valid = r >= tr.lo && r < tr.hi;
+        const uint32_t d = part_digit(k[it], pd, nd - 1);
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t below = mbcnt(m);
+        const uint32_t before = wh[d];
+        rank[it] = before + below;
+        if (valid && below == 0) wh[d] = before + (uint32_t)__popcll((unsigned long long)m);
+    }
+    __syncthreads();
+    {   // thread d: wave bases of digit d, tile-local and global start of the digit
+        const uint32_t d = threadIdx.x;
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            const uint32_t c = s_wh[w][d];
+            s_wh[w][d] = total;
+            total += c;
+        }
+        const uint32_t in = wave_incl_scan_u32(total);
+        if (lane == 63) s_wave_total[wave] = in;
+        __syncthreads();
+        uint32_t off = in - total;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) off += w < wave ? s_wave_total[w] : 0u;
+        s_dig_off[d] = off;
+        s_glob[d] = d < nd ? (uint32_t)incl[(size_t)d * tiles_p] - total : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kPartItems; ++it) {
+        const int64_t r = wave_begin + it * 64 + lane;
+        if (r >= tr.lo && r < tr.hi) {
+            const uint32_t d = part_digit(k[it], pd, nd - 1);
+            s_keys[s_dig_off[d] + s_wh[wave][d] + rank[it]] = k[it];
+        }
+    }
+    __syncthreads();
+    const int32_t first_valid = (int32_t)(tr.lo - tr.tile_begin);
+    const int32_t tile_n = (int32_t)(tr.hi - tr.lo);
+    (void)first_valid;
+    for (int32_t j = threadIdx.x; j < tile_n; j += kBlock) {
+        const int32_t key = s_keys[j];
+        const uint32_t d = part_digit(key, pd, nd - 1);
+        keys_out[s_glob[d] + ((uint32_t)j - s_dig_off[d])] = key;
+    }
+}
+
+// One workgroup per (digit, pane) bucket: rows [start, end) of the partitioned keys, all inside [base + digit << shift, + 2^shift).
+__global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *__restrict__ keys, SegTiles st, const PaneDesc *__restrict__ panes,
+                                                                 const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx,
+                                                                 uint32_t nd, const int32_t *__restrict__ hist_incl, uint32_t *counters, uint64_t *tables,
+                                                                 uint32_t cap, uint32_t *tab_used, uint32_t *err) {
+    __shared__ uint32_t s_hist[1 << kPartShift];
+    const uint32_t d = blockIdx.x;
+    const int32_t p = blockIdx.y;
+    const int32_t t0 = st.tile_first[p], tiles_p = st.tile_first[p + 1] - t0;
+    if (tiles_p == 0 || pane_win_ptr[p] == pane_win_ptr[p + 1]) return;
+    const size_t slot0 = (size_t)t0 * nd + (size_t)d * tiles_p;
+    const int64_t begin = slot0 == 0 ? 0 : (int64_t)hist_incl[slot0 - 1], end = (int64_t)hist_incl[slot0 + tiles_p - 1];
+    if (end <= begin) return;
+    const PaneDesc pd = panes[p];
+    if (d == nd - 1) {   // keys outside the pane's estimated range: the windows' straggler tables, row by row
+        FlushArgs f;
+        f.wp0 = pane_win_ptr[p];
+        f.wp1 = pane_win_ptr[p + 1];
+        f.pane = pd;
+        f.pane_win_idx = pane_win_idx;
+        f.counters = counters;
+        f.tables = tables;
+        f.cap = cap;
+        f.tab_used = tab_used;
+        f.err = err;
+        for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) emit_pair(keys[i], 1u, f);
+        return;
+    }
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_hist);
+        for (int i = threadIdx.x; i < (1 << kPartShift) / 4; i += kBlock) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const uint32_t key0 = (uint32_t)(int32_t)(pd.base + ((int64_t)d << kPartShift));
+    constexpr int kUnroll = 8;
+    for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += (int64_t)kBlock * kUnroll) {
+        int32_t k[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBlock;
+            k[u] = keys[i < end ? i : end - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const bool valid = i0 + (int64_t)u * kBlock < end;
+            const uint32_t bin = ((uint32_t)k[u] - key0) & ((1u << kPartShift) - 1);
+            // the first lane's key once per instruction: half of NEXMark's bids name one auction, wherever they sit
+            const uint32_t hot = __builtin_amdgcn_readfirstlane(bin);
+            const uint64_t b = __ballot(valid && bin == hot);
+            if (valid && bin == hot) {
+                if (mbcnt(b) == 0) atomicAdd(&s_hist[hot], (uint32_t)__popcll((unsigned long long)b));
+            } else if (valid) {
+                atomicAdd(&s_hist[bin], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t idx0 = (uint64_t)d << kPartShift;
+    for (uint32_t i = threadIdx.x; i < (1u << kPartShift); i += kBlock) {
+        const uint32_t c = s_hist[i];
+        if (c && idx0 + i < (uint64_t)pd.range) counters[pd.cnt_off + idx0 + i] = c;   // this workgroup owns the bucket's counters (cleared before)
+    }
+}
+
 // ---- partial aggregation (q5.dag: HashAggregateExec mode=Partial, the stage BEFORE the hash repartition) ---------------
 // After the count pass with "window = pane", the groups of pane p are its non-zero direct-address counters plus the
 // live slots of its straggler table.  Both are compacted with the flag-tile machinery over ONE flat index space:
@@ -975,7 +1215,13 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         hipLaunchKernelGGL(q5_range_kernel, dim3(kRangeBlocks, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, auction, rows, st.seg_off, d_rng);
     }
     FG_TRY(check_launch(ctx, "q5_range_kernel"));
-    bool speculate = dense && !part && hint[2] && hint[0] > 0;
+    // "wide" mode (partition by key range, then count in LDS -- see q5_part_count_kernel): entered when the previous call of this ctx
+    // found most tiles wider than the fast kernel's histogram, left when a sample of the partition's tiles is narrow again
+    std::vector<int64_t> &wide_hint = ctx->host_i64["q5.wide_hint"];
+    if (wide_hint.size() != 1) wide_hint.assign(1, 0);
+    static const bool no_wide = getenv("FLOCKGPU_Q5_NO_WIDE") != nullptr;   // (A/B knob)
+    bool wide_mode = wide_hint[0] != 0 && !weight && !part && !no_wide && dense;
+    bool speculate = dense && !part && hint[2] && hint[0] > 0 && !wide_mode;   // (wide mode sizes its digit count from the host-side layout)
     auto host_layout = [&]() -> int {   // the same rules on the host: first call of a ctx, the Partial stage, a declined speculation
         FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * n_rng, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1104,7 +1350,45 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
         if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
-        if (st.n_tiles > 0 && n_win > 0) {
+        uint32_t nd = 0;
+        if (wide_mode && dense) {
+            uint32_t max_range = 0;
+            for (int p = 0; p < n_panes; ++p) max_range = std::max(max_range, panes[(size_t)p].range);
+            nd = (uint32_t)div_up((int64_t)max_range, int64_t(1) << kPartShift) + 1;
+        }
+        const bool wide = wide_mode && dense && nd >= 2 && nd <= (uint32_t)kPartMaxDigits && st.n_tiles > 0 && n_win > 0;
+        uint32_t *d_sample = nullptr, *h_sample = nullptr;
+        FG_TRY(arena_get_t(ctx, "q5.part_sample", 4, &d_sample));
+        FG_TRY(pinned_get_t(ctx, "q5.part_sample", 4, &h_sample));
+        h_sample[0] = h_sample[1] = 0;
+        if (wide) {
+            SegTiles st4;
+            FG_TRY(build_seg_tiles(ctx, "q5.part", sb.data(), se.data(), n_panes, kPartTile, &st4));
+            const int64_t slots = (int64_t)st4.n_tiles * nd;
+            if (slots >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: too many (pane, digit, tile) slots for the partition pass");
+            int32_t *hist = nullptr, *part_keys = nullptr;
+            FG_TRY(arena_get_t(ctx, "q5.part_hist", (size_t)slots + 4, &hist));
+            FG_TRY(arena_get_t(ctx, "q5.part_keys", (size_t)rows + 4, &part_keys));
+            FG_HIP(ctx, hipMemsetAsync(d_sample, 0, 2 * sizeof(uint32_t), ctx->stream));
+            {
+                LaunchScope ls(ctx, "q5_part_count_kernel");
+                hipLaunchKernelGGL(q5_part_count_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, d_sample);
+            }
+            FG_TRY(check_launch(ctx, "q5_part_count_kernel"));
+            FG_TRY(inclusive_scan_i32(ctx, "q5.part_scan", hist, slots));
+            {
+                LaunchScope ls(ctx, "q5_part_emit_kernel");
+                hipLaunchKernelGGL(q5_part_emit_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, part_keys);
+            }
+            FG_TRY(check_launch(ctx, "q5_part_emit_kernel"));
+            {
+                LaunchScope ls(ctx, "q5_bucket_count_kernel");
+                hipLaunchKernelGGL(q5_bucket_count_kernel, dim3(nd, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, part_keys, st4, d_panes, d_ptr, d_idx, nd, hist,
+                                   counters, tables, cap, d_used, d_err);
+            }
+            FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));
+            FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        } else if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
                 hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0,
@@ -1121,6 +1405,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                                    slow_list, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
+            if (!weight && !part) FG_HIP(ctx, hipMemcpyAsync(h_sample + 2, slow_list, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));   // tiles the fast kernel declined
         }
         if (part) {  // Partial stage: hand out the groups of every pane (window w == pane w)
             const int64_t tab0 = ((int64_t)cnt_total + 3) & ~int64_t(3);
@@ -1249,6 +1534,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     hint[0] = (int64_t)cnt_total;   // the next call of this kind sizes its counters from this one and lays them out on the device
     hint[1] = (int64_t)scan_total;
     hint[2] = dense ? 1 : 0;
+    if (!weight && !part) {
+        uint32_t *h_sample = nullptr;
+        FG_TRY(pinned_get_t(ctx, "q5.part_sample", 4, &h_sample));
+        if (wide_mode && h_sample[0]) wide_hint[0] = (uint64_t)h_sample[1] * 4 >= (uint64_t)h_sample[0] * 3 ? 0 : 1;   // three quarters of the sample narrow: back to the fast kernel
+        else if (!wide_mode && dense && st.n_tiles > 64) wide_hint[0] = (int64_t)h_sample[2] * 4 > (int64_t)st.n_tiles ? 1 : 0;
+    }
     // remember how dense the groups were so the next sparse call sizes its tables right away
     {
         double best = 1e30;

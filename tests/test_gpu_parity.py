@@ -439,6 +439,51 @@ def test_q8_duplicates_collapse(ctx):
         assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, w
 
 
+def test_q5_keys_in_no_order_take_the_partitioned_count():
+    """Keys spread over the whole pane range make every tile wider than the fast kernel's LDS histogram.  The first such call on a ctx
+    goes through the general per-tile kernel and notes it; from the second call on the pane's rows are partitioned by key range and
+    counted in LDS (q5_part_count / q5_part_emit / q5_bucket_count).  Exact either way -- hot keys, keys outside the sampled range and
+    ragged panes included -- and a ctx that sees time-ordered keys again goes back to the fast kernel."""
+    from flock_amd import Bids, GpuContext, WindowSchedule
+    c = GpuContext(0)
+    rng = np.random.default_rng(17)
+    pane_rows = [600_001, 450_000, 0, 700_003, 512_000]
+    offs = np.concatenate(([0], np.cumsum(pane_rows)))
+    n = int(offs[-1])
+    auction = np.empty(n, np.int32)
+    for p in range(len(pane_rows)):
+        lo, hi = offs[p], offs[p + 1]
+        base = 1000 + 250_000 * p
+        a = rng.integers(base, base + 300_000, hi - lo)
+        a[rng.random(hi - lo) < 0.4] = base + 77                      # a hot auction
+        if hi > lo:
+            a[rng.integers(0, hi - lo, 50)] = rng.integers(-2**31, 2**31 - 1, 50)   # strangers far outside any estimate
+        auction[lo:hi] = a
+    sched = WindowSchedule(offs, np.arange(0, 4, dtype=np.int32), np.arange(2, 6, dtype=np.int32))   # Hopping over 2 panes, stride 1
+    bids = Bids(auction=_dev(auction), rows=n)
+    for call in range(3):                                                # general kernel, then the partitioned count twice
+        _q5_check(c, bids, sched, auction)
+    stats_before = None
+    c.profile_reset()
+    c.profile(True)
+    _q5_check(c, bids, sched, auction)
+    stats_before = c.profile_read()
+    c.profile(False)
+    assert "q5_bucket_count_kernel" in stats_before and "q5_count_kernel" not in stats_before, sorted(stats_before)
+    # time-ordered keys again (the generator's shape): the sample of the partition's tiles is narrow, the next call is the fast kernel's
+    ordered = np.sort(auction[: offs[2]]).astype(np.int32)
+    sched2 = WindowSchedule(offs[:3], np.array([0], np.int32), np.array([2], np.int32))
+    b2 = Bids(auction=_dev(ordered), rows=len(ordered))
+    _q5_check(c, b2, sched2, ordered)
+    c.profile_reset()
+    c.profile(True)
+    _q5_check(c, b2, sched2, ordered)
+    st = c.profile_read()
+    c.profile(False)
+    assert "q5_count_kernel" in st and "q5_bucket_count_kernel" not in st, sorted(st)
+    c.close()
+
+
 # ------------------------------------------------------------------ dense / general path selection (q3, q8)
 def _sorted_keys(rng, n, spread, lo=-50_000):
     """n strictly increasing int32 keys with an average gap of `spread`."""
