@@ -431,22 +431,45 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
         if (wc.x + wc.y + wc.z + wc.w == 0) return;
         pos = tile_base[tile] + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u);
     }
+    // the tile's two columns are requested as a whole before the first row is looked at (sixteen 16-byte loads in flight per lane:
+    // walking the iterations one by one waited for a pair of loads eight times), and the FIRST probe of a lane's four rows of an
+    // iteration goes out together from clamped slots -- at the load factor the host sizes for (<= 0.67 of the window's persons, half
+    // of whom the state filter drops) it settles most rows; what is left walks on row by row
+    int32_t sv[kFlagIters][4], cv[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, sv);
+    load_flag_tile(category, n_rows, tr, cv);
     uint32_t wave_total = 0;
-#pragma unroll 1
+#pragma unroll 2
     for (int it = 0; it < kFlagIters; ++it) {
         const int64_t r0 = wbase + it * 256;
-        int32_t s4[4], c4[4], head[4];
-        load4_i32(seller, r0, n_rows, s4);
-        load4_i32(category, r0, n_rows, c4);
-        uint32_t mine = 0;
+        int32_t head[4];
+        uint32_t slot[4];
+        uint64_t first[4];
+        bool need[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r0 + j;
+            need[j] = r >= tr.lo && r < tr.hi && (int64_t)cv[it][j] == category_lit;
+            slot[j] = slot_of((uint32_t)sv[it][j], cap);
+            first[j] = tab[need[j] ? slot[j] : 0u];
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             head[j] = -1;
-            if (r >= tr.lo && r < tr.hi && (int64_t)c4[j] == category_lit) {
-                head[j] = multimap_find(tab, cap, s4[j]);
-                for (int32_t p = head[j]; p >= 0; p = next[p]) ++mine;
+            if (!need[j]) continue;
+            uint64_t cur = first[j];
+            uint32_t sl = slot[j];
+            for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
+                if (cur == kEmpty64) break;
+                if ((int32_t)(cur >> 32) == sv[it][j]) {
+                    head[j] = (int32_t)(uint32_t)cur;
+                    break;
+                }
+                sl = (sl + 1 == cap) ? 0 : sl + 1;
+                cur = tab[sl];
             }
+            for (int32_t p = head[j]; p >= 0; p = next[p]) ++mine;
         }
         const uint32_t incl = wave_incl_scan_u32(mine);
         const uint32_t it_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
