@@ -607,32 +607,60 @@ def payload_side(ctx, steps, no_cpu, rows=10_000_000):
 
 # ------------------------------------------------------------------ PCIe-inclusive side measurement
 def pcie_inclusive_q5(ctx, eps, seconds=100):
-    """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query.  PCIe-bound;
-    reported beside `value`, never as `value`."""
+    """q5 when the host hands over pinned Arrow buffers: H2D copy of the `auction` column + the query, reported beside `value`, never as
+    `value`.  Batch k + 1's copy runs on a second stream into a second device buffer while batch k's query runs (the reference feeds
+    per batch, context.rs:257-325): the step is max(copy, query), not their sum; the serial figure rides along."""
     import torch
     from flock_amd import Bids, NEXMarkSource, Window
     w = Window.hopping(10, 5)
     g = NEXMarkSource(seconds, eps, w, seed=7).generate_data(ctx, relations=("bid",), bid_columns=("auction",))
     sched = g.window_schedule("bid", w)
     host = g.bids.auction.cpu().pin_memory()
-    dev = torch.empty_like(g.bids.auction)
+    dev = [torch.empty_like(g.bids.auction), torch.empty_like(g.bids.auction)]
+    rows = g.bids.rows
 
-    def step():
-        dev.copy_(host, non_blocking=True)
+    def serial_step():
+        dev[0].copy_(host, non_blocking=True)
         torch.cuda.current_stream().synchronize()   # the ctx stream is ordered against the default stream anyway
-        return ctx.q5_hot_items(Bids(auction=dev, rows=g.bids.rows), sched)
+        return ctx.q5_hot_items(Bids(auction=dev[0], rows=rows), sched)
     for _ in range(2):
-        step()
+        serial_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 3
     for _ in range(n):
-        step()
+        serial_step()
+    torch.cuda.synchronize()
+    dt_serial = (time.perf_counter() - t0) / n
+    # overlapped: copy stream + the ctx's stream, two buffers, events both ways
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    used = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def prefetch(k):
+        with torch.cuda.stream(side):
+            side.wait_event(used[k & 1])            # the query that read this buffer two batches ago is done
+            dev[k & 1].copy_(host, non_blocking=True)
+            copied[k & 1].record(side)
+    for e in used:
+        e.record(main)
+    n = 8
+    prefetch(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        prefetch(k + 1)                             # batch k + 1 starts to cross the bus ...
+        main.wait_event(copied[k & 1])
+        r = ctx.q5_hot_items(Bids(auction=dev[k & 1], rows=rows), sched)   # ... while batch k's query runs (and returns its rows)
+        used[k & 1].record(main)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(g.bids.rows / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "input_rows": int(g.bids.rows),
-            "h2d_GBps_floor": round(g.bids.rows * 4 / dt / 1e9, 1),
-            "note": "pinned host auction column copied H2D every step, then q5 (copy and query not overlapped)"}
+    del r
+    return {"value": round(rows / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "input_rows": int(rows),
+            "roofline": {"bound": "pcie", "achieved": round(rows * 4 / dt / 1e9, 2), "peak": 63.0, "unit": "GB/s", "frac": round(rows * 4 / dt / 1e9 / 63.0, 4),
+                         "algorithmic_bytes_per_step": int(rows * 4)},
+            "serial_ms_per_step": round(dt_serial * 1e3, 3),
+            "note": "pinned host auction column: batch k + 1 copied H2D on a second stream while batch k's q5 runs (two device buffers)"}
 
 
 def entry_for(ctx, q, seconds, eps, steps, warmup, no_cpu, threads, barrier=lambda: None):

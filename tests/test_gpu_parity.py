@@ -478,8 +478,7 @@ def test_q5_keys_in_no_order_take_the_partitioned_count():
     c.profile(False)
     assert "q5_bucket_count_kernel" in stats_before and "q5_count_kernel" not in stats_before, sorted(stats_before)
     # time-ordered keys again (the generator's shape): the sample of the partition's tiles is narrow, the next call is the fast kernel's
-    head = auction[: offs[2]]
-    ordered = np.sort(head[(head >= 1000) & (head < 700_000)]).astype(np.int32)      # (without the strangers: they would sit in the sampled first / last tile)
+    ordered = np.sort(rng.integers(1000, 61_000, 1_000_000)).astype(np.int32)        # ~16 bids per auction, in auction order: an 8192-row tile spans ~500 ids
     half = len(ordered) // 2
     sched2 = WindowSchedule(np.array([0, half, len(ordered)]), np.array([0], np.int32), np.array([2], np.int32))
     b2 = Bids(auction=_dev(ordered), rows=len(ordered))
