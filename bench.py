@@ -766,10 +766,16 @@ def exchange_entry(ctx, comm, q, seconds, eps, steps, warmup, rank, world, barri
 def plan_collect_pcie(gpu, eps, steps):
     """`runtime.collect` over the q5 plan at the reference's granule (178 329-row bid batches, nexmark.rs:183-187): Arrow host
     batches in -> staged / pinned H2D -> fused q5 -> pinned D2H out, one Hopping(10, 5) window per collect.  PCIe roofline: the
-    bytes that cross the bus (the scanned `auction` column in, the winners out) / 63 GB/s."""
+    bytes that cross the bus (the scanned `auction` column in, the winners out) / 63 GB/s.
+    Four ways: one function instance feeding pageable buffers (what the reference's host hands over); two instances side by side
+    (two plans, two streams, two host threads: window k + 1 is fed while window k executes -- the reference runs one instance per
+    partition, context.rs:172-216); and both again with the batches' memory registered (`flockgpu_host_register`), where feed hands
+    the Arrow buffers to the DMA engine as they are."""
+    import ctypes as C
+    import threading
     import numpy as np
     import pyarrow as pa
-    from flock_amd import NEXMarkSource, Window
+    from flock_amd import GpuContext, NEXMarkSource, Window, _ffi
     from flock_amd.runtime import ExecutionContext, collect
     plan = open(os.path.join(ROOT, "tests", "golden", "plans", "q5.json")).read()
     g = NEXMarkSource(10, eps, Window.hopping(10, 5), seed=7).generate_data(gpu, relations=("bid",))
@@ -779,23 +785,56 @@ def plan_collect_pcie(gpu, eps, steps):
     batches = [pa.record_batch([pa.array(cols["auction"][i:i + gran]), pa.array(cols["bidder"][i:i + gran]), pa.array(cols["price"][i:i + gran]),
                                 pa.array(cols["b_date_time"][i:i + gran]).cast(pa.timestamp("ms"))], names=["auction", "bidder", "price", "b_date_time"])
                for i in range(0, n, gran)]
-    ctx = ExecutionContext([plan], gpu=gpu)
-    out = None
-    for _ in range(2):
-        out = collect(ctx, [[batches]])
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = collect(ctx, [[batches]])
-    dt = (time.perf_counter() - t0) / steps
-    ctx.close()
-    moved = 4.0 * n + 12.0 * out[0][0].num_rows
-    return {"value": round(n / dt, 1), "unit": "rows/s", "ms_per_step": round(dt * 1e3, 3), "input_rows": int(n), "batches": len(batches),
-            "granule_rows": gran, "result_rows": int(out[0][0].num_rows),
-            "roofline": {"bound": "pcie", "achieved": round(moved / dt / 1e9, 2), "peak": 63.0, "unit": "GB/s", "frac": round(moved / dt / 1e9 / 63.0, 4),
-                         "algorithmic_bytes_per_step": int(moved)},
-            "note": "pageable pyarrow buffers: staged through the plan's pinned lanes (four host threads, each memcpy -> async H2D over two "
-                    "4 MiB chunks); only the column the plan reads crosses the bus; feed -> execute -> clean per window, one device "
-                    "synchronisation per collect"}
+    result_rows = [0]
+
+    def run(n_inst):
+        ctxs = [ExecutionContext([plan], gpu=GpuContext(gpu.device, own_stream=True)) for _ in range(n_inst)]
+        for c in ctxs:
+            for _ in range(2):
+                result_rows[0] = collect(c, [[batches]])[0][0].num_rows
+        gate = threading.Barrier(n_inst + 1)
+
+        def work(c):
+            gate.wait()
+            for _ in range(steps):
+                collect(c, [[batches]])
+        th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = (time.perf_counter() - t0) / (steps * n_inst)     # wall time per window, all instances together
+        for c in ctxs:
+            c.close()
+        return dt
+    moved = lambda: 4.0 * n + 12.0 * result_rows[0]
+    dt1 = run(1)
+    out = {"value": round(n / dt1, 1), "unit": "rows/s", "ms_per_step": round(dt1 * 1e3, 3), "input_rows": int(n), "batches": len(batches),
+           "granule_rows": gran, "result_rows": int(result_rows[0]),
+           "roofline": {"bound": "pcie", "achieved": round(moved() / dt1 / 1e9, 2), "peak": 63.0, "unit": "GB/s", "frac": round(moved() / dt1 / 1e9 / 63.0, 4),
+                        "algorithmic_bytes_per_step": int(moved())},
+           "note": "pageable pyarrow buffers, ONE function instance: staged through the plan's pinned lanes (four host threads, each memcpy -> "
+                   "async H2D over two 4 MiB chunks); only the column the plan reads crosses the bus; feed -> execute -> clean per window"}
+
+    def variant(dt):
+        return {"ms_per_window": round(dt * 1e3, 3), "value": round(n / dt, 1), "pcie_GBps": round(moved() / dt / 1e9, 2), "pcie_frac": round(moved() / dt / 1e9 / 63.0, 4)}
+    try:
+        out["two_instances_pageable"] = variant(run(2))
+        lib = _ffi.load()
+        regs = []
+        for k in ("auction", "bidder", "price", "b_date_time"):
+            ptr, nb = cols[k].ctypes.data, cols[k].nbytes
+            if lib.flockgpu_host_register(C.c_void_p(ptr), nb) == 0:
+                regs.append(ptr)
+        out["one_instance_registered"] = variant(run(1))
+        out["two_instances_registered"] = variant(run(2))
+        for ptr in regs:
+            lib.flockgpu_host_unregister(C.c_void_p(ptr))
+    except Exception as ex:   # a side measurement must never hide the rest
+        out["variants_error"] = repr(ex)
+    return out
 
 
 def plan_collect_pcie_both(gpu, eps, steps):

@@ -198,11 +198,12 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *
 }
 
 // ---- general path -----------------------------------------------------------------------------------------------
-// DISTINCT seller, general keys, staged in LDS: the tile's keys are made distinct in an LDS set first (16384 slots for at most 8192
-// keys: load factor <= 0.5; inserts are LDS compare-and-swaps), and only the distinct ones -- ~700 of 8192 for NEXMark's sellers -- go
+// DISTINCT seller, general keys, staged in LDS: the tile's keys are made distinct in an LDS set first (8192 slots; inserts are LDS
+// compare-and-swaps; a key that finds no room within 32 slots goes to the global set directly), and only the distinct ones -- ~700 of 8192 for NEXMark's sellers -- go
 // on to the window's set in global memory, where most of them are found present with one load.  (Straight to the global set, row
 // by row: 1.09 ms per 6e7 auctions, 18x the bitmap kernel of the dense path; with the loads of a lane's four rows grouped: 1.34 ms.)
-constexpr int kLdsSetSlots = 16384;
+constexpr int kLdsSetSlots = 8192;     // 32 KB: four workgroups per CU (16384 slots = two per CU: 0.79 ms instead of 0.64 per 6e7 auctions)
+constexpr int kLdsSetMaxProbe = 32;    // a longer run means the tile is full of distinct keys: that key goes straight to the global set
 __global__ __launch_bounds__(kBlock) void q8_sellers_set_kernel(const int32_t *__restrict__ seller, int64_t n_rows,
                                                                 SegTiles st, uint64_t *sets, uint32_t cap, uint32_t *err) {
     __shared__ uint32_t s_set[kLdsSetSlots];
@@ -235,27 +236,47 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_set_kernel(const int32_t *_
                 s_has_m1 = 1;
                 continue;
             }
-            uint32_t sl = (k * kFibHash) >> (32 - 14);
-            for (;;) {   // (terminates: at most 8192 keys in 16384 slots)
+            uint32_t sl = (k * kFibHash) >> (32 - 13);
+            bool placed = false;
+            for (int probe = 0; probe < kLdsSetMaxProbe; ++probe) {
                 const uint32_t cur = s_set[sl];
-                if (cur == k) break;
+                if (cur == k) { placed = true; break; }
                 if (cur == kEmpty32) {
                     const uint32_t old = atomicCAS(&s_set[sl], kEmpty32, k);
-                    if (old == kEmpty32 || old == k) break;
+                    if (old == kEmpty32 || old == k) { placed = true; break; }
                 }
                 sl = (sl + 1) & (kLdsSetSlots - 1);
             }
+            if (!placed && set_insert(set, cap, (int32_t)k, 0) < 0) atomicOr(err, 1u);
         }
     }
-    (void)lane;
     __syncthreads();
+    // The distinct keys sit in ~5 % of the LDS slots.  Walking the slots and inserting where one is occupied leaves ~3 lanes of a wave
+    // busy per step, each step as long as one insert's chain of dependent global operations (64 steps per lane: 1.8 ms per 6e7
+    // auctions).  So every wave gathers the occupied slots of its share into a queue and inserts 64 keys at a time, all lanes busy.
+    __shared__ uint32_t s_q[kWavesPerBlock][128];
+    volatile uint32_t *q = s_q[threadIdx.x >> 6];
+    uint32_t qn = 0;   // wave-uniform
+    auto insert = [&](uint32_t k) {
+        const uint64_t first = ld64(&set[slot_of(k, cap)]);
+        if (first != kEmpty64 && (uint32_t)(first >> 32) == k) return;   // already in the window's set
+        if (set_insert(set, cap, (int32_t)k, 0) < 0) atomicOr(err, 1u);
+    };
     for (int i = threadIdx.x; i < kLdsSetSlots; i += kBlock) {
         const uint32_t k = s_set[i];
-        if (k == kEmpty32) continue;
-        const uint64_t first = ld64(&set[slot_of(k, cap)]);
-        if (first != kEmpty64 && (uint32_t)(first >> 32) == k) continue;   // already in the window's set
-        if (set_insert(set, cap, (int32_t)k, 0) < 0) atomicOr(err, 1u);
+        const bool occ = k != kEmpty32;
+        const uint64_t b = __ballot(occ);
+        if (occ) q[qn + mbcnt(b)] = k;
+        qn += (uint32_t)__popcll((unsigned long long)b);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            qn -= 64;
+            const uint32_t mine = q[qn + lane];
+            __builtin_amdgcn_wave_barrier();
+            insert(mine);
+        }
     }
+    if ((uint32_t)lane < qn) insert(q[lane]);
     if (threadIdx.x == 0 && s_has_m1 && set_insert(set, cap, -1, 0) < 0) atomicOr(err, 1u);
 }
 
