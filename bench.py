@@ -75,7 +75,7 @@ def parse():
                          "inside libflockgpu; auto = windows at N = 1, exchange at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
-    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -837,6 +837,71 @@ def plan_collect_pcie(gpu, eps, steps):
     return out
 
 
+def plan_stages(gpu, eps, steps):
+    """The reference's distributed mode through the plan ABI: q3 / q5 / q8 cut into their stage plans (flock_amd.stages.build_query_dag =
+    flock/src/distributed_plan/stage.rs:269-367), every stage a function group with 8 hash partitions, run in one process
+    (StagedRun) -- against the same window through the whole-query plan (one fused pipeline) on the same ABI.  One window per run:
+    q3 one epoch, q5 Hopping(10 s), q8 Tumbling(10 s), at `eps` events/s; host Arrow batches in, host Arrow batches out."""
+    import numpy as np
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext, collect
+    from flock_amd.stages import StagedRun, build_query_dag
+    out = {}
+    for q, seconds in ((3, 1), (5, 10), (8, 10)):
+        plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", f"q{q}.json")))
+        g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=11).generate_data(gpu)
+
+        def utf8(u, n):
+            off = u.offsets.cpu().numpy()[: n + 1]
+            return pa.StringArray.from_buffers(n, pa.py_buffer(off.tobytes()), pa.py_buffer(u.data.cpu().numpy()[: int(off[-1])].tobytes()))
+        if q == 5:
+            b = g.bids
+            rel = {"bid": pa.record_batch([pa.array(b.auction.cpu().numpy()), pa.array(b.bidder.cpu().numpy()), pa.array(b.price.cpu().numpy()),
+                                           pa.array(b.b_date_time.cpu().numpy()).cast(pa.timestamp("ms"))], names=["auction", "bidder", "price", "b_date_time"])}
+        else:
+            a, p = g.auctions, g.persons
+            rel = {"auction": pa.record_batch([pa.array(a.a_id.cpu().numpy()), pa.array(a.seller.cpu().numpy()), pa.array(a.category.cpu().numpy())],
+                                              names=["a_id", "seller", "category"]),
+                   "person": pa.record_batch([pa.array(p.p_id.cpu().numpy()), utf8(p.name, p.rows), utf8(p.city, p.rows), utf8(p.state, p.rows)],
+                                             names=["p_id", "name", "city", "state"])}
+            if q == 8:
+                rel = {"person": rel["person"], "auction": rel["auction"]}
+        rows = sum(rb.num_rows for rb in rel.values())
+        whole = ExecutionContext([plan], gpu=gpu)
+        staged = StagedRun(gpu, build_query_dag(plan))
+        src = [[[rb]] for rb in rel.values()]
+        n_whole = sum(b.num_rows for b in collect(whole, src)[0])
+        n_staged = sum(b.num_rows for b in staged.run(rel))
+        if n_whole != n_staged:
+            raise RuntimeError(f"q{q}: the staged run returns {n_staged} rows, the whole plan {n_whole}")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            collect(whole, src)
+        t_whole = (time.perf_counter() - t0) / steps
+        gpu.profile_reset()
+        gpu.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            staged.run(rel)
+        t_staged = (time.perf_counter() - t0) / steps
+        stats = gpu.profile_read()
+        gpu.profile(False)
+        top = sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:6]
+        out[f"q{q}"] = {"input_rows": int(rows), "result_rows": int(n_whole), "whole_plan_ms": round(t_whole * 1e3, 3), "staged_ms": round(t_staged * 1e3, 3),
+                        "staged_over_whole": round(t_staged / t_whole, 2), "stages": len(staged.stages), "collects_per_run": 2 + 8,
+                        "staged_kernel_ms_per_run": round(sum(v["total_ms"] for v in stats.values()) / steps, 3),
+                        "top_kernels_ms_per_run": {k: round(v["total_ms"] / steps, 3) for k, v in top}}
+        whole.close()
+        staged.close()
+        del g
+    worst = max(v["staged_over_whole"] for v in out.values())
+    rows_all = sum(v["input_rows"] for v in out.values())
+    ms_all = sum(v["staged_ms"] for v in out.values())
+    return {"value": round(rows_all / (ms_all * 1e-3), 1), "unit": "rows/s", "ms_per_step": round(ms_all, 3), "worst_staged_over_whole": worst, **out,
+            "note": "value = input rows of the three windows / the time of their three staged runs (host Arrow in and out of every stage)"}
+
+
 def plan_collect_pcie_both(gpu, eps, steps):
     """The same measurement twice: in this process (after every other entry: ~16 GB of host arrays, 64-thread CPU baselines, Arrow's
     and torch's thread pools behind it) and in a fresh process -- what a function instance of the reference is.  The staging threads'
@@ -1033,7 +1098,9 @@ def main():
         from flock_amd import GpuContext
         g = GpuContext(local)
         n = max(args.steps, 3)
-        e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True)}[args.only_side]()
+        e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True),
+             "plan_stages": lambda: plan_stages(g, args.eps, n), "plan_collect": lambda: plan_collect_pcie(g, args.eps, max(n, 5)),
+             "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps)}[args.only_side]()
         print(json.dumps(e))
         return
     if args.only_general:
@@ -1192,7 +1259,8 @@ def main():
                           ("payload_next", lambda: payload_side(ctx, steps2, args.no_cpu)),
                           ("ysb_next", lambda: ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)),
                           ("q5_pcie_inclusive", lambda: pcie_inclusive_q5(ctx, args.eps)),
-                          ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2))):
+                          ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2)),
+                          ("plan_stages", lambda: plan_stages(ctx, args.eps, 5))):
             try:
                 also[label] = fn()
             except Exception as e:

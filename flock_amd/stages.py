@@ -176,3 +176,51 @@ def stage_levels(stages):
         feeders = [j for j in st.inputs if j is not None]
         levels.append(1 + max(levels[j] for j in feeders) if feeders else 0)
     return levels
+
+
+class StagedRun:
+    """The distributed run of a stage DAG in ONE process: every stage is a function group with its plan instantiated once
+    (`ExecutionContext`), a shuffling stage is executed with `execute_partitioned` (through `collect`) by `chunks` producers over
+    slices of its base relation, and partition j of every producer goes to invocation j of the consuming stage -- the routing of
+    flock-function/src/aws/actor.rs:425-543 without the Lambda invocations in between.  What the reference's
+    `launcher/aws` differential tests do with real functions (flock/src/launcher/aws/mod.rs:423-468)."""
+
+    def __init__(self, gpu, stages: List[Stage], chunks: int = 1):
+        from .runtime import ExecutionContext
+        self.stages, self.chunks = stages, chunks
+        self.ctxs = [ExecutionContext([st.plan], name=f"stage-{i}", gpu=gpu) for i, st in enumerate(stages)]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+    def run(self, relations):
+        """relations: {name: RecordBatch} of the base relations (one window).  Returns the root stage's batches."""
+        from .runtime import collect
+        outputs = {}
+        for i, (st, ctx) in enumerate(zip(self.stages, self.ctxs)):
+            feeders = [j for j in st.inputs if j is not None]
+            invocations = []
+            if any(j is None for j in st.inputs):
+                for c in range(self.chunks):
+                    src = []
+                    for rb in relations.values():
+                        lo, hi = rb.num_rows * c // self.chunks, rb.num_rows * (c + 1) // self.chunks
+                        src.append([[rb.slice(lo, hi - lo)]])
+                    invocations.append(src)
+            else:
+                parts = max(len(outputs[j]) for j in feeders)
+                for p in range(parts):
+                    invocations.append([[outputs[j][p] if len(outputs[j]) == parts else [b for part in outputs[j] for b in part]] for j in feeders])
+            result = None
+            for src in invocations:
+                out = collect(ctx, src)
+                if st.is_shuffling:
+                    result = result or [[] for _ in out]
+                    for p, batches in enumerate(out):
+                        result[p].extend(batches)
+                else:
+                    result = result or [[]]
+                    result[0].extend(out[0])
+            outputs[i] = result
+        return [b for part in outputs[len(self.stages) - 1] for b in part]
