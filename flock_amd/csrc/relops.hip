@@ -808,6 +808,13 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     const std::string base = name;
     *n_pairs = 0;
     *left_rows = *right_rows = nullptr;
+    // The hash table is built on the SMALLER side (DataFusion builds on the left; which side is hashed is unobservable in the pair
+    // multiset): q5's final stage joins 6e5 (auction, num) groups with ONE row of MAX(num) on num = maxn -- built on the left, every
+    // group with the same count chained onto one slot by compare-and-swap (1.39 ms of the staged q5's 2.1 ms of kernels).
+    if (n_left > 4 * n_right && n_left > 4096) {
+        const int rc = join_key64(ctx, (base + ".swapped").c_str(), right, n_right, left, n_left, right_rows, left_rows, n_pairs);
+        return rc;
+    }
     if (n_left >= (int64_t(1) << 30) || n_right >= (int64_t(1) << 31))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relation too large for the generic join", name);
     const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(n_left, 1) * 2);

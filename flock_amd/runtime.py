@@ -46,6 +46,7 @@ class _Plan:
         self.is_shuffling = bool(self._lib.flockgpu_plan_is_shuffling(h))
         self.partitions = self._lib.flockgpu_plan_output_partitions(h)
         self._fed = []   # the library borrows fed buffers until execute / reset returns (flockgpu_plan.h)
+        self._match_cache = {}
 
     def close(self):
         if self.h:
@@ -53,6 +54,20 @@ class _Plan:
             self.h = None
 
     def matches(self, i: int, schema) -> bool:
+        try:   # a function instance sees the same few schemas on every invocation: ask the library once per (leaf, schema)
+            hit = self._match_cache.get((i, schema))
+        except TypeError:
+            hit = None
+        if hit is not None:
+            return hit
+        ok = self._matches_uncached(i, schema)
+        try:
+            self._match_cache[(i, schema)] = ok
+        except TypeError:
+            pass
+        return ok
+
+    def _matches_uncached(self, i: int, schema) -> bool:
         buf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
         schema._export_to_c(C.addressof(buf))
         ok = self._lib.flockgpu_plan_input_matches(self.h, i, C.cast(buf, C.c_void_p)) == 1
