@@ -1116,15 +1116,47 @@ struct Exec {
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate shape is not supported");
     }
 
+    // The Utf8 columns of one take share their row list: up to four of them go through ONE length pass, ONE scan, ONE host wait and
+    // ONE emit launch (gather_utf8_multi_*) instead of a take -- and a wait -- per column.  A stage plan's operators materialise small
+    // tables many times over (filter, join output, one take per repartition), and at that size the waits ARE the cost.
     int take_table(const Node *n, const Table &in, const std::vector<char> &required, const int32_t *rows, int64_t n_rows, int first_out, Table *out) {
+        std::vector<size_t> utf8;
         for (size_t i = 0; i < in.cols.size(); ++i) {
             TCol &o = out->cols[(size_t)first_out + i];
             o.c.type = in.cols[i].c.type;
             o.c.is_ts = in.cols[i].c.is_ts;
             o.c.nullable = in.cols[i].c.nullable;
             if (!required[(size_t)first_out + i] || !in.cols[i].present) continue;
+            if (in.cols[i].c.type == ColType::UTF8) {
+                utf8.push_back(i);
+                continue;
+            }
             FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
             o.present = true;
+        }
+        for (size_t g0 = 0; g0 < utf8.size(); g0 += 4) {
+            const int k = (int)std::min<size_t>(4, utf8.size() - g0);
+            if (k == 1) {
+                const size_t i = utf8[g0];
+                TCol &o = out->cols[(size_t)first_out + i];
+                FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
+                o.present = true;
+                continue;
+            }
+            flockgpu_utf8 srcs[4], outs[4];
+            int64_t nb[4];
+            for (int j = 0; j < k; ++j) srcs[j] = flockgpu_utf8{in.cols[utf8[g0 + (size_t)j]].c.offsets, static_cast<const uint8_t *>(in.cols[utf8[g0 + (size_t)j]].c.values)};
+            Utf8MultiGather g;
+            FG_TRY(gather_utf8_multi_begin(ctx, node_key(pl, n, "mtake", first_out + (int)utf8[g0]).c_str(), srcs, k, rows, n_rows, &g));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FG_TRY(gather_utf8_multi_finish(ctx, g, outs, nb));
+            for (int j = 0; j < k; ++j) {
+                TCol &o = out->cols[(size_t)first_out + utf8[g0 + (size_t)j]];
+                o.c.values = outs[j].data;
+                o.c.offsets = outs[j].offsets;
+                o.c.bytes = nb[j];
+                o.present = true;
+            }
         }
         return FLOCKGPU_OK;
     }
@@ -1133,6 +1165,15 @@ struct Exec {
         if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
         FG_TRY(arena_get_t(ctx, node_key(pl, n, what).c_str(), (size_t)rows + 2, out));
         return widen_to_i64(ctx, c.c, rows, *out);
+    }
+
+    // FilterExec as a row selection: the input table and the rows of it the predicate keeps (input order)
+    int filter_rows(const Node *n, Table *in, int32_t **rows, int64_t *n_out) {
+        FG_TRY(exec(n->in[0].get(), in));
+        uint8_t *mask = nullptr;
+        int next = 0;
+        FG_TRY(eval_pred(n, n->pred.get(), *in, &next, &mask));
+        return mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in->rows, rows, n_out);
     }
 
     int exec(const Node *n, Table *t) {
@@ -1151,13 +1192,9 @@ struct Exec {
                 return exec(n->in[0].get(), t);  // placement is unobservable in one process; the root case is handled by the caller
             case NKind::Filter: {
                 Table in;
-                FG_TRY(exec(n->in[0].get(), &in));
-                uint8_t *mask = nullptr;
-                int next = 0;
-                FG_TRY(eval_pred(n, n->pred.get(), in, &next, &mask));
                 int32_t *rows = nullptr;
                 int64_t n_out = 0;
-                FG_TRY(mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in.rows, &rows, &n_out));
+                FG_TRY(filter_rows(n, &in, &rows, &n_out));
                 t->rows = n_out;
                 t->cols.assign(n->schema.size(), TCol{});
                 return take_table(n, in, n->required, rows, n_out, 0, t);
@@ -1570,24 +1607,42 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
     std::vector<int64_t> part_off;
     if (partitioned && root->kind == NKind::Repartition) {
         if (root->n_parts > capacity) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: %d output partitions, room for %d", root->n_parts, capacity);
+        // Filter -> Repartition (stage 0 of planner.rs:152-171: the rows a filter keeps are what travels): the filter's row selection
+        // and the partition's send order are COMPOSED and the columns taken once, from the filter's input -- materialising the
+        // filtered table first moved every column twice (the three Utf8 columns of q3's persons among them)
+        const Node *below = root->in[0].get();
+        while (below->kind == NKind::Repartition) below = below->in[0].get();
+        const bool compose = below->kind == NKind::Filter && plan->fused[(size_t)below->id].kind == kNone && below->schema.size() == root->schema.size() &&
+                             root->in[0]->schema.size() == root->schema.size();
         Table in;
-        FG_TRY(ex.exec(root->in[0].get(), &in));
+        int32_t *sel = nullptr;      // compose: rows of `in` the filter keeps
+        int64_t n_sel = 0;
+        if (compose) FG_TRY(ex.filter_rows(below, &in, &sel, &n_sel));
+        else FG_TRY(ex.exec(root->in[0].get(), &in));
+        const int64_t n_rows = compose ? n_sel : in.rows;
         // RepartitionExec Hash(exprs, n): equal keys must meet in one partition; hashing the first key column already
         // guarantees that, and which partition a key lands on is unobservable
-        const TCol &k = in.cols[(size_t)root->hash_cols[0]];
+        TCol k = in.cols[(size_t)root->hash_cols[0]];
+        if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+        if (compose) FG_TRY(take_column(ctx, node_key(plan, root, "pkcol").c_str(), in.cols[(size_t)root->hash_cols[0]].c, sel, n_sel, &k.c));
         int64_t *keys = nullptr;
         if (k.c.type == ColType::UTF8) {
-            if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
-            FG_TRY(arena_get_t(ctx, node_key(plan, root, "pk").c_str(), (size_t)in.rows + 2, &keys));
-            FG_TRY(hash_utf8_i64(ctx, k.c, in.rows, keys));
+            FG_TRY(arena_get_t(ctx, node_key(plan, root, "pk").c_str(), (size_t)n_rows + 2, &keys));
+            FG_TRY(hash_utf8_i64(ctx, k.c, n_rows, keys));
         } else {
-            FG_TRY(ex.key_i64(root, k, in.rows, "pk", &keys));
+            FG_TRY(ex.key_i64(root, k, n_rows, "pk", &keys));
         }
         int32_t *rows = nullptr;
-        FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, in.rows, root->n_parts, &rows, &part_off));
-        t.rows = in.rows;
+        FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, n_rows, root->n_parts, &rows, &part_off));
+        if (compose) {   // send order over the filter's input: sel[rows[i]]
+            int32_t *composed = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(plan, root, "rows").c_str(), (size_t)n_rows + 4, &composed));
+            FG_TRY(gather_i32(ctx, sel, rows, n_rows, composed));
+            rows = composed;
+        }
+        t.rows = n_rows;
         t.cols.assign(root->schema.size(), TCol{});
-        FG_TRY(ex.take_table(root, in, std::vector<char>(root->schema.size(), 1), rows, in.rows, 0, &t));
+        FG_TRY(ex.take_table(root, in, std::vector<char>(root->schema.size(), 1), rows, n_rows, 0, &t));
     } else {
         FG_TRY(ex.exec(root, &t));
         part_off = {0, t.rows};
