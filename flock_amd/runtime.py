@@ -32,6 +32,18 @@ def _pa():
     return pa
 
 
+# An exported ArrowArray / ArrowSchema is released by calling the `release` callback stored inside it (Arrow C Data Interface:
+# offset 64 of the 80-byte ArrowArray, offset 56 of the 72-byte ArrowSchema).  Re-importing the struct into pyarrow releases it,
+# too, but builds a Python object per column on the way -- per fed batch, 52 batches per window at the reference's granule.
+_RELEASE = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def _release(addr: int, offset: int):
+    fn = C.c_void_p.from_address(addr + offset).value
+    if fn:
+        _RELEASE(fn)(addr)
+
+
 class _Plan:
     def __init__(self, gpu: GpuContext, text: str):
         self.gpu, self.text = gpu, text
@@ -89,10 +101,10 @@ class _Plan:
         try:
             rc = self._lib.flockgpu_plan_feed(self.h, i, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
         finally:
-            # the library only borrowed the batches: re-import to release the exported structs
-            schema = pa.Schema._import_from_c(C.addressof(sbuf))
+            # the library only borrowed the batches (self._fed keeps them alive): hand the exported structs back
             for ab in abufs:
-                pa.RecordBatch._import_from_c(C.addressof(ab), schema)
+                _release(C.addressof(ab), 64)
+            _release(C.addressof(sbuf), 56)
         self.gpu._check(rc)
 
     def execute(self):
