@@ -32,6 +32,19 @@ from typing import List, Optional
 class Stage:
     plan: dict
     inputs: List[Optional[int]] = field(default_factory=list)   # per memory_exec leaf (BFS order): producing stage or None
+    # node of the reference's QueryDag this plan belongs to: a join's left and right sub-plans are ONE node holding two plans
+    # (`dag.insert(leaf, vec![left, right], ..)`, stage.rs:330-334 -- one function whose CloudExecutionPlan carries both), every other
+    # stage plan is a node of its own.  `dag_nodes(stages)` groups the stages that way; node and edge counts then equal the ones
+    # stage.rs's own tests assert (3 nodes / 2 edges for sort + limit over a join, stage.rs:776-901).
+    node: int = -1
+
+    def plan_has_join(self) -> bool:
+        n = self.plan
+        while isinstance(n, dict):
+            if n.get("execution_plan") == "hash_join_exec":
+                return True
+            n = n.get("input")
+        return False
 
     @property
     def is_shuffling(self) -> bool:
@@ -115,7 +128,40 @@ def build_query_dag(plan: dict) -> List[Stage]:
             hit = [feeders[k] for k, m in enumerate(markers) if m is lf]
             ins.append(hit[0] if hit else None)
         stages.append(Stage(plan_t, ins))
+    # reference DAG nodes: the two inputs of a join (consecutive, fed by base relations, consumed by the same stage) share one
+    node = 0
+    consumer = {}
+    for i, st in enumerate(stages):
+        for j in st.inputs:
+            if j is not None:
+                consumer[j] = i
+    for i, st in enumerate(stages):
+        sibling = i - 1
+        if (i > 0 and i in consumer and consumer.get(sibling) == consumer[i] and stages[consumer[i]].plan_has_join()
+                and not any(j is not None for j in st.inputs) and not any(j is not None for j in stages[sibling].inputs)):
+            st.node = stages[sibling].node
+        else:
+            st.node = node
+            node += 1
     return stages
+
+
+def dag_nodes(stages: List[Stage]) -> List[List[int]]:
+    """Stage indices grouped by reference QueryDag node (leaves first)."""
+    out = {}
+    for i, st in enumerate(stages):
+        out.setdefault(st.node if st.node >= 0 else 10_000 + i, []).append(i)
+    return [out[k] for k in sorted(out)]
+
+
+def dag_edge_count(stages: List[Stage]) -> int:
+    """Edges between reference DAG nodes (a join's two inputs reach their consumer through one edge)."""
+    edges = set()
+    for i, st in enumerate(stages):
+        for j in st.inputs:
+            if j is not None:
+                edges.add((stages[j].node, st.node))
+    return len(edges)
 
 
 def split_at_repartitions(plan: dict) -> List[Stage]:

@@ -68,6 +68,25 @@ def test_every_stage_plan_is_executable(q, n_dag, n_fine):
         assert fed == list(range(len(stages) - 1))           # every stage but the root feeds exactly one leaf
 
 
+def test_dag_nodes_and_edges_equal_the_counts_stage_rs_asserts():
+    """a join's left and right sub-plans are ONE node of the reference's QueryDag (stage.rs:330-334).  Node / edge counts
+    of stage.rs's own tests: aggregate 2 / 1 (stage.rs:605-606), join 2 nodes (stage.rs:682, :726), sort + limit over a join 3 / 2
+    (stage.rs:776-901)."""
+    from flock_amd.stages import build_query_dag, dag_edge_count, dag_nodes
+    agg = build_query_dag(json.load(open(os.path.join(PLANS, "golden_aggregate.json"))))
+    assert len(dag_nodes(agg)) == 2 and dag_edge_count(agg) == 1
+    join_plan = json.load(open(os.path.join(PLANS, "golden_join.json")))
+    join = build_query_dag(join_plan)
+    assert len(join) == 3 and dag_nodes(join) == [[0, 1], [2]] and dag_edge_count(join) == 1
+    sorted_join = {"execution_plan": "global_limit_exec", "limit": 3,
+                   "input": {"execution_plan": "sort_exec", "expr": [], "input": join_plan}}
+    st = build_query_dag(sorted_join)
+    assert len(st) == 4 and len(dag_nodes(st)) == 3 and dag_edge_count(st) == 2
+    assert dag_nodes(st)[0] == [0, 1] and all(j is None for i in (0, 1) for j in st[i].inputs)     # the two base-fed plans share node 0
+    for q in (3, 5, 8):
+        assert [len(g) for g in dag_nodes(build_query_dag(_plan(q)))] == [2, 1]
+
+
 def test_partial_count_stage_uses_the_fused_kernel():
     from flock_amd.runtime import explain
     from flock_amd.stages import split_at_repartitions
