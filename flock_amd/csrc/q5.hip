@@ -827,6 +827,139 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
     }
 }
 
+// ---- max + select for windows of one or two consecutive panes (ElementWise / Tumbling / Hopping(2h, h)), walking PANES --------------
+// q5_scan_kernel walks windows: under Hopping(10 s, 5 s) every pane is in two windows and its counters are read twice per pass
+// (0.57 GB per 1e9 bids at 5.4 TB/s = 0.105 ms: bandwidth, not instructions).  Here workgroup (x, p) reads its share of pane p's
+// counters ONCE and serves both windows of the pane:
+//   as the FIRST pane of window wb = (p, p + 1): count(k) = c_p[k] + c_{p+1}[k] where pane p + 1 covers k (the few auctions in flight
+//     at the pane boundary), and every key of pane p is accounted to wb here;
+//   as the SECOND pane of window wa = (p - 1, p): only the keys pane p - 1 does NOT cover (the others were accounted by its sweep).
+// A generic version of this (any number of panes per window and windows per pane, descriptors in LDS) measured 0.134 + 0.048 ms
+// against 0.105 + 0.015 ms of the window walk: instruction overhead ate the saved traffic.  This one is specialised to the two roles.
+template <bool SELECT>
+__global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_wa,
+                                                              const int32_t *__restrict__ pane_wb, const uint32_t *__restrict__ counters,
+                                                              const uint64_t *__restrict__ tables, uint32_t cap, const uint32_t *__restrict__ tab_used,
+                                                              uint64_t *win_max, uint64_t *win_groups, uint32_t *block_max, uint32_t *cursor,
+                                                              uint32_t out_cap, int32_t *out_win, int32_t *out_key, const uint64_t *__restrict__ spec_info) {
+    __shared__ uint32_t s_best[2][kWavesPerBlock];
+    __shared__ uint64_t s_groups[2][kWavesPerBlock];
+    if (spec_info && !spec_info[2]) return;
+    const int32_t p = blockIdx.y;
+    const int32_t wa = pane_wa[p], wb = pane_wb[p];
+    if (wa < 0 && wb < 0) return;
+    const PaneDesc pd = panes[p];
+    const PaneDesc prev = wa >= 0 ? panes[p - 1] : PaneDesc{0, 0, 0, 0};
+    const bool two_b = wb >= 0 && pane_wa[p + 1] == wb;   // wb has a second pane (p + 1) -- pane_wa has n_panes + 1 entries, the last one -1
+    const PaneDesc next = two_b ? panes[p + 1] : PaneDesc{0, 0, 0, 0};
+    const uint32_t mx_a = SELECT && wa >= 0 ? (uint32_t)win_max[wa] : 0u, mx_b = SELECT && wb >= 0 ? (uint32_t)win_max[wb] : 0u;
+    // select revisits the keys the same workgroup saw in the max pass: no winner of a window where its maximum was lower
+    bool act_a = wa >= 0, act_b = wb >= 0;
+    if (SELECT) {
+        act_a = act_a && mx_a != 0 && block_max[((size_t)wa * 2 + 1) * gridDim.x + blockIdx.x] == mx_a;
+        act_b = act_b && mx_b != 0 && block_max[((size_t)wb * 2 + 0) * gridDim.x + blockIdx.x] == mx_b;
+        if (!act_a && !act_b) return;
+    }
+    const bool tab_a = wa >= 0 && tab_used[wa] != 0, tab_b = wb >= 0 && tab_used[wb] != 0;
+    const uint64_t *ta = tables + (size_t)(wa >= 0 ? wa : 0) * cap, *tb = tables + (size_t)(wb >= 0 ? wb : 0) * cap;
+    uint32_t best_a = 0, best_b = 0, groups_a = 0, groups_b = 0;
+    auto take = [&](uint32_t c, int32_t key, int32_t w, uint32_t mx, uint32_t &best, uint32_t &groups) {
+        if (SELECT) {
+            const bool hit = c == mx;
+            const uint64_t b = __ballot(hit);
+            if (b) {   // one cursor bump per wave
+                const int leader = __ffsll((unsigned long long)b) - 1;
+                uint32_t base = 0;
+                if (lane_id() == leader) base = atomicAdd(cursor, (uint32_t)__popcll((unsigned long long)b));
+                base = __builtin_amdgcn_readlane(base, leader);
+                const uint32_t pos = base + mbcnt(b);
+                if (hit && pos < out_cap) {
+                    out_win[pos] = w;
+                    out_key[pos] = key;
+                }
+            }
+        } else {
+            best = max(best, c);
+            groups += c != 0;
+        }
+    };
+    const uint32_t n4 = pd.range / 4;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
+        const int64_t k0 = pd.base + (int64_t)i * 4;
+        const uint4 me = *reinterpret_cast<const uint4 *>(counters + pd.cnt_off + (uint64_t)i * 4);
+        if (act_b) {   // (block-uniform)
+            uint32_t c[4] = {me.x, me.y, me.z, me.w};
+            const uint64_t idx = (uint64_t)(k0 - next.base);
+            if (idx < (uint64_t)next.range) {   // (bases and ranges are multiples of 4: the aligned group is covered as a whole or not at all)
+                const uint4 o = *reinterpret_cast<const uint4 *>(counters + next.cnt_off + idx);
+                c[0] += o.x; c[1] += o.y; c[2] += o.z; c[3] += o.w;
+            }
+            if (tab_b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] += table_find(tb, cap, (uint32_t)(int32_t)(k0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) take(c[j], (int32_t)(k0 + j), wb, mx_b, best_b, groups_b);
+        }
+        if (act_a && !((uint64_t)(k0 - prev.base) < (uint64_t)prev.range)) {
+            uint32_t c[4] = {me.x, me.y, me.z, me.w};
+            if (tab_a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] += table_find(ta, cap, (uint32_t)(int32_t)(k0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) take(c[j], (int32_t)(k0 + j), wa, mx_a, best_a, groups_a);
+        }
+    }
+    if (tab_b && act_b) {   // straggler-table entries of wb that neither of its panes covers: complete on their own
+        for (uint32_t sl = blockIdx.x * kBlock + threadIdx.x; sl < cap; sl += gridDim.x * kBlock) {
+            const uint64_t e = tb[sl];
+            if (!e) continue;
+            const int64_t key = (int32_t)(uint32_t)(e >> 32);
+            if ((uint64_t)(key - pd.base) < (uint64_t)pd.range || (uint64_t)(key - next.base) < (uint64_t)next.range) continue;
+            if (SELECT) {
+                if ((uint32_t)e == mx_b) {
+                    const uint32_t pos = atomicAdd(cursor, 1u);
+                    if (pos < out_cap) {
+                        out_win[pos] = wb;
+                        out_key[pos] = (int32_t)key;
+                    }
+                }
+            } else {
+                best_b = max(best_b, (uint32_t)e);
+                groups_b += 1;
+            }
+        }
+    }
+    if (!SELECT) {   // one update per workgroup and window
+        const uint32_t ba = wave_max_u32(best_a), bb = wave_max_u32(best_b);
+        const uint64_t ga = wave_sum_u64(groups_a), gb = wave_sum_u64(groups_b);
+        if (lane_id() == 0) {
+            s_best[0][threadIdx.x >> 6] = ba;
+            s_best[1][threadIdx.x >> 6] = bb;
+            s_groups[0][threadIdx.x >> 6] = ga;
+            s_groups[1][threadIdx.x >> 6] = gb;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int r = threadIdx.x;   // 0: role a (second pane of wa), 1: role b (first pane of wb)
+            const int32_t w = r == 0 ? wa : wb;
+            uint32_t b = 0;
+            uint64_t g = 0;
+#pragma unroll
+            for (int v = 0; v < kWavesPerBlock; ++v) {
+                b = max(b, s_best[r][v]);
+                g += s_groups[r][v];
+            }
+            if (w >= 0) {
+                if (b) block_max[((size_t)w * 2 + (r == 0 ? 1 : 0)) * gridDim.x + blockIdx.x] = b;
+                if (b) atomicMax(reinterpret_cast<unsigned long long *>(&win_max[w]), (unsigned long long)b);
+                if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
+            }
+        }
+    }
+}
+
 // ---- keys in no particular order: partition by key range, then count in LDS ("wide" mode) -----------------------------------------
 // The kernels above are built for keys that sweep their range with time (a tile of 8192 bids names ~600 consecutive auctions).  Bids
 // whose keys are spread over the whole pane range (3e5 ids per 5-s pane; `also.q5_uniform`: the generator's bids shuffled inside
@@ -1156,6 +1289,18 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         if (ptr[p + 1]) covered_rows += win->pane_row_offsets[p + 1] - win->pane_row_offsets[p];
         ptr[p + 1] += ptr[p];
     }
+    // roles of a pane under windows of one or two consecutive panes: wa = the window it is the SECOND pane of, wb = the window it is the
+    // FIRST pane of (-1: none).  Any other schedule (longer windows, two windows in one role) keeps the window-walking passes.
+    std::vector<int32_t> role_a((size_t)n_panes + 1, -1), role_b((size_t)n_panes + 1, -1);
+    bool hop2 = n_win > 0 && n_panes > 0;
+    for (int w = 0; w < n_win && hop2; ++w) {
+        const int lo = win->win_pane_lo[w], np = win->win_pane_hi[w] - lo;
+        if (np < 1 || np > 2 || role_b[(size_t)lo] >= 0 || (np == 2 && role_a[(size_t)lo + 1] >= 0)) hop2 = false;
+        else {
+            role_b[(size_t)lo] = w;
+            if (np == 2) role_a[(size_t)lo + 1] = w;
+        }
+    }
     idx.resize(ptr[n_panes]);
     {
         std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
@@ -1175,20 +1320,27 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     FG_TRY(arena_get_t(ctx, "q5.pane_win_idx", idx.size() + 1, &d_idx));
     FG_TRY(pinned_get_t(ctx, "q5.pane_win_ptr", ptr.size(), &h_ptr));
     FG_TRY(pinned_get_t(ctx, "q5.pane_win_idx", idx.size() + 1, &h_idx));
+    int32_t *d_roles = nullptr, *h_roles = nullptr;   // role_a (n_panes + 1) | role_b (n_panes + 1)
+    FG_TRY(arena_get_t(ctx, "q5.pane_roles", 2 * role_a.size(), &d_roles));
+    FG_TRY(pinned_get_t(ctx, "q5.pane_roles", 2 * role_a.size(), &h_roles));
     {   // the pane -> windows CSR is uploaded only when it (or its buffers) changed: a stream of equal batches re-submits the same schedule
         std::vector<int64_t> &sig = ctx->host_i64["q5.csr_sig"];
         std::vector<int64_t> now;
-        now.reserve(ptr.size() + idx.size() + 2);
+        now.reserve(ptr.size() + idx.size() + 3);
         now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_ptr));
         now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_idx));
+        now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_roles));
         now.insert(now.end(), ptr.begin(), ptr.end());
         now.insert(now.end(), idx.begin(), idx.end());
         if (sig != now) {
             std::copy(ptr.begin(), ptr.end(), h_ptr);
             std::copy(idx.begin(), idx.end(), h_idx);
+            std::copy(role_a.begin(), role_a.end(), h_roles);
+            std::copy(role_b.begin(), role_b.end(), h_roles + role_a.size());
             FG_HIP(ctx, hipMemcpyAsync(d_ptr, h_ptr, ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             if (!idx.empty())
                 FG_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(d_roles, h_roles, 2 * role_a.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             sig = now;
         }
     }
@@ -1338,15 +1490,20 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
         // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
         const uint64_t per_win = n_win > 0 ? std::max<uint64_t>(cap, scan_total / n_win / 4) : cap;
-        const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)per_win, kBlock * 2), 1), 64);
+        static const bool no_hop2 = getenv("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
+        const bool pane_walk = hop2 && !no_hop2;
+        const uint64_t per_pane = n_panes > 0 ? std::max<uint64_t>(cap, cnt_total / (uint64_t)n_panes / 4) : cap;
+        static const int hop2_blocks = getenv("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(getenv("FLOCKGPU_Q5_HOP2_BLOCKS")) : 64;
+        const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)(pane_walk ? per_pane : per_win), kBlock * 2), 1), pane_walk ? hop2_blocks : 64);
         uint32_t *block_max = nullptr;
-        FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)gx * std::max(n_win, 1), &block_max));
+        const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_walk ? 2 : 1);
+        FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)n_block_max, &block_max));
         {   // one clear for everything this attempt writes into
-            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, (uint64_t)gx * n_win});
+            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, n_block_max});
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
             hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
                                (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
-                               slow_list, block_max, (uint64_t)gx * n_win, plain_clear ? 1 : 0);
+                               slow_list, block_max, n_block_max, plain_clear ? 1 : 0);
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
         if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
@@ -1461,7 +1618,20 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             part->rows = n_out;
             return FLOCKGPU_OK;
         }
-        if (n_win > 0) {
+        if (n_win > 0 && pane_walk) {
+            {
+                LaunchScope ls(ctx, "q5_max_kernel");
+                hipLaunchKernelGGL(q5_hop2_scan_kernel<false>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles, d_roles + role_a.size(), counters,
+                                   tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
+            }
+            FG_TRY(check_launch(ctx, "q5_max_kernel"));
+            {
+                LaunchScope ls(ctx, "q5_select_kernel");
+                hipLaunchKernelGGL(q5_hop2_scan_kernel<true>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles, d_roles + role_a.size(), counters,
+                                   tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
+            }
+            FG_TRY(check_launch(ctx, "q5_select_kernel"));
+        } else if (n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
                 hipLaunchKernelGGL(q5_scan_kernel<false>, dim3(gx, (unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins,
