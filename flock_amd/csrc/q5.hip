@@ -1493,7 +1493,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         static const bool no_hop2 = getenv("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
         const bool pane_walk = hop2 && !no_hop2;
         const uint64_t per_pane = n_panes > 0 ? std::max<uint64_t>(cap, cnt_total / (uint64_t)n_panes / 4) : cap;
-        static const int hop2_blocks = getenv("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(getenv("FLOCKGPU_Q5_HOP2_BLOCKS")) : 64;
+        static const int hop2_blocks = getenv("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(getenv("FLOCKGPU_Q5_HOP2_BLOCKS")) : 32;   // (max pass 0.062 / 0.073 / 0.108 ms with 32 / 64 / 128 per pane)
         const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)(pane_walk ? per_pane : per_win), kBlock * 2), 1), pane_walk ? hop2_blocks : 64);
         uint32_t *block_max = nullptr;
         const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_walk ? 2 : 1);
