@@ -960,6 +960,63 @@ __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__
     }
 }
 
+// ---- the call's read-back in ONE kernel -----------------------------------------------------------------------------------------
+// A call used to end with four device-to-host copy nodes (scalars, the first winners' windows and keys, the device layout's verdict)
+// and, after the host had ordered the winners, two host-to-device copies of the result columns: nine copy nodes of ~4 us each per
+// call with the schedule upload and the sample, 4 % of the 1e9-bid step (rocprofv3: 54 `copyBuffer` for 6 calls).  One workgroup does
+// it all: it copies the scalars into ONE pinned block with plain stores, orders up to kFinishMax winners by (window, auction) with a
+// bitonic sort in LDS, writes the result columns where they stay (device) and the windows' output offsets into the pinned block.
+// More winners than that (mass ties) or a failed attempt: sorted = 0 and the host takes the old road.
+constexpr int kFinishThreads = 1024;
+constexpr uint32_t kFinishMax = 1024;
+__global__ __launch_bounds__(kFinishThreads) void q5_finish_kernel(const uint64_t *__restrict__ meta, uint32_t n_meta, int32_t n_win, const uint64_t *__restrict__ info,
+                                                                   const int32_t *__restrict__ slow_list, const int32_t *__restrict__ sel_win,
+                                                                   const int32_t *__restrict__ sel_key, uint32_t out_cap, int32_t *__restrict__ out_auction,
+                                                                   uint64_t *__restrict__ out_num, uint64_t *__restrict__ h_fin) {
+    __shared__ uint64_t s_k[kFinishMax];
+    const uint32_t *tail = reinterpret_cast<const uint32_t *>(meta + 2 * (size_t)n_win);
+    const uint32_t n_sel = tail[0], err = tail[1];
+    for (uint32_t i = threadIdx.x; i < n_meta; i += kFinishThreads) h_fin[i] = meta[i];
+    if (threadIdx.x < 3) h_fin[n_meta + threadIdx.x] = info ? info[threadIdx.x] : 0;
+    if (threadIdx.x == 3) h_fin[n_meta + 3] = (uint64_t)(uint32_t)slow_list[0];
+    const bool sortable = !err && n_sel <= kFinishMax && n_sel <= out_cap && (!info || info[2]);
+    if (threadIdx.x == 4) h_fin[n_meta + 4] = sortable ? 1 : 0;
+    int64_t *h_off = reinterpret_cast<int64_t *>(h_fin + n_meta + 5);
+    if (!sortable) return;   // (block-uniform)
+    uint32_t p2 = 1;
+    while (p2 < n_sel) p2 <<= 1;
+    if (threadIdx.x < p2)
+        s_k[threadIdx.x] = threadIdx.x < n_sel ? ((uint64_t)(uint32_t)sel_win[threadIdx.x] << 32) | ((uint32_t)sel_key[threadIdx.x] ^ 0x80000000u) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= p2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t i = threadIdx.x, l = i ^ j;
+            if (i < p2 && l > i) {
+                const uint64_t a = s_k[i], b = s_k[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s_k[i] = b;
+                    s_k[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < n_sel) {
+        const uint64_t e = s_k[threadIdx.x];
+        out_auction[threadIdx.x] = (int32_t)((uint32_t)e ^ 0x80000000u);
+        out_num[threadIdx.x] = meta[(uint32_t)(e >> 32)];   // the window's MAX
+    }
+    for (int32_t w = threadIdx.x; w <= n_win; w += kFinishThreads) {   // offsets[w] = first winner of a window >= w
+        uint32_t lo = 0, hi = n_sel;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((int32_t)(s_k[mid] >> 32) < w) lo = mid + 1;
+            else hi = mid;
+        }
+        h_off[w] = (int64_t)lo;
+    }
+}
+
 // ---- keys in no particular order: partition by key range, then count in LDS ("wide" mode) -----------------------------------------
 // The kernels above are built for keys that sweep their range with time (a tile of 8192 bids names ~600 consecutive auctions).  Bids
 // whose keys are spread over the whole pane range (3e5 ids per 5-s pane; `also.q5_uniform`: the generator's bids shuffled inside
@@ -1425,6 +1482,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         std::copy(panes.begin(), panes.end(), h_panes);
         std::copy(wins.begin(), wins.end(), h_wins);
+        ctx->host_i64["q5.wins_sig"].clear();   // the windows' buffer is rewritten here: the speculating path uploads its ranges again
         FG_HIP(ctx, hipMemcpyAsync(d_panes, h_panes, panes.size() * sizeof(PaneDesc), hipMemcpyHostToDevice, ctx->stream));
         FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
         return FLOCKGPU_OK;
@@ -1444,8 +1502,21 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)hint[0] + (size_t)hint[0] / 8 + 4, &counters));
         capacity = ctx->arena["q5.counters"].cap / sizeof(uint32_t) - 4;
         if (preclean[0] == (int64_t)reinterpret_cast<uintptr_t>(counters)) clean_upto = (uint64_t)preclean[1];
-        std::copy(wins.begin(), wins.end(), h_wins);
-        FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+        {   // the windows' pane ranges: uploaded when the schedule or the buffer changed (the layout kernel rewrites base / range, never lo / hi)
+            std::vector<int64_t> &wsig = ctx->host_i64["q5.wins_sig"];   // (one buffer, one record of what it holds)
+            std::vector<int64_t> wnow;
+            wnow.reserve((size_t)2 * n_win + 2);
+            wnow.push_back((int64_t)reinterpret_cast<uintptr_t>(d_wins));
+            for (int w = 0; w < n_win; ++w) {
+                wnow.push_back(win->win_pane_lo[w]);
+                wnow.push_back(win->win_pane_hi[w]);
+            }
+            if (wsig != wnow) {
+                std::copy(wins.begin(), wins.end(), h_wins);
+                FG_HIP(ctx, hipMemcpyAsync(d_wins, h_wins, wins.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+                wsig = wnow;
+            }
+        }
         hipLaunchKernelGGL(q5_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes,
                            d_wins, d_info);
         FG_TRY(check_launch(ctx, "q5_layout_kernel"));
@@ -1476,6 +1547,11 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     std::vector<int32_t> h_win, h_key;
     uint32_t n_sel = 0;
     const int32_t *sel_win = nullptr, *sel_key = nullptr;  // set when the winners stay on the device
+    bool fin_sorted = false;                               // q5_finish_kernel ordered the winners: result columns and offsets are in place
+    const int64_t *fin_off = nullptr;
+    const int32_t *fin_auction = nullptr;
+    const uint64_t *fin_num = nullptr;
+    uint32_t h_slow_count = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 8 || cap64 >= (uint64_t(1) << 31))
             return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q5: hash table capacity %llu still overflows", (unsigned long long)cap64);
@@ -1562,7 +1638,6 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                                    slow_list, spec_info);
             }
             FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
-            if (!weight && !part) FG_HIP(ctx, hipMemcpyAsync(h_sample + 2, slow_list, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));   // tiles the fast kernel declined
         }
         if (part) {  // Partial stage: hand out the groups of every pane (window w == pane w)
             const int64_t tab0 = ((int64_t)cnt_total + 3) & ~int64_t(3);
@@ -1647,17 +1722,24 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         }
-        // one synchronisation for the scalars AND the winners: a window has one winner unless counts tie, so the first
-        // kSpecWinners entries are copied back speculatively together with the scalars
+        // one synchronisation for the scalars AND the winners, and one kernel instead of copy nodes: q5_finish_kernel leaves the
+        // scalars, the layout's verdict, the ordered winners' offsets in ONE pinned block and the result columns on the device
         constexpr uint32_t kSpecWinners = 4096;
-        int32_t *h_swin = nullptr, *h_skey = nullptr;
-        FG_TRY(pinned_get_t(ctx, "q5.spec_win", kSpecWinners, &h_swin));
-        FG_TRY(pinned_get_t(ctx, "q5.spec_key", kSpecWinners, &h_skey));
-        FG_HIP(ctx, hipMemcpyAsync(h_meta, d_meta, sizeof(uint64_t) * n_meta, hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipMemcpyAsync(h_swin, o_win, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipMemcpyAsync(h_skey, o_key, sizeof(int32_t) * kSpecWinners, hipMemcpyDeviceToHost, ctx->stream));
-        if (speculate) FG_HIP(ctx, hipMemcpyAsync(h_info, d_info, sizeof(uint64_t) * 3, hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t *h_fin = nullptr;
+        int32_t *fin_a = nullptr;
+        uint64_t *fin_n = nullptr;
+        FG_TRY(pinned_get_t(ctx, "q5.finish", n_meta + 8 + (size_t)n_win + 2, &h_fin));
+        FG_TRY(arena_get_t(ctx, "q5.out_auction", (size_t)kFinishMax + 1, &fin_a));
+        FG_TRY(arena_get_t(ctx, "q5.out_num", (size_t)kFinishMax + 1, &fin_n));
+        hipLaunchKernelGGL(q5_finish_kernel, dim3(1), dim3(kFinishThreads), 0, ctx->stream, d_meta, (uint32_t)n_meta, n_win, spec_info, slow_list, o_win, o_key, out_cap,
+                           fin_a, fin_n, h_fin);
+        FG_TRY(check_launch(ctx, "q5_finish_kernel"));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::copy(h_fin, h_fin + n_meta, h_meta);
+        if (speculate) std::copy(h_fin + n_meta, h_fin + n_meta + 3, h_info);
+        h_slow_count = (uint32_t)h_fin[n_meta + 3];
+        fin_sorted = h_fin[n_meta + 4] != 0;
+        fin_off = reinterpret_cast<const int64_t *>(h_fin + n_meta + 5);
         if (speculate) {
             if (!h_info[2]) {   // declined (ranges moved beyond the counters the previous call sized, or not dense any more): the slow way
                 speculate = false;
@@ -1692,9 +1774,13 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         h_win.resize(n_sel);
         h_key.resize(n_sel);
-        if (n_sel <= kSpecWinners) {
-            std::copy(h_swin, h_swin + n_sel, h_win.begin());
-            std::copy(h_skey, h_skey + n_sel, h_key.begin());
+        if (fin_sorted) {
+            fin_auction = fin_a;
+            fin_num = fin_n;
+        } else if (n_sel <= kSpecWinners) {   // more winners than the finish kernel orders: copy them back, order them here (below)
+            FG_HIP(ctx, hipMemcpyAsync(h_win.data(), o_win, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(h_key.data(), o_key, sizeof(int32_t) * n_sel, hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         } else {  // many ties: ordered on the device below
             sel_win = o_win;
             sel_key = o_key;
@@ -1708,7 +1794,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         uint32_t *h_sample = nullptr;
         FG_TRY(pinned_get_t(ctx, "q5.part_sample", 4, &h_sample));
         if (wide_mode && h_sample[0]) wide_hint[0] = (uint64_t)h_sample[1] * 4 >= (uint64_t)h_sample[0] * 3 ? 0 : 1;   // three quarters of the sample narrow: back to the fast kernel
-        else if (!wide_mode && dense && st.n_tiles > 64) wide_hint[0] = (int64_t)h_sample[2] * 4 > (int64_t)st.n_tiles ? 1 : 0;
+        else if (!wide_mode && dense && st.n_tiles > 64) wide_hint[0] = (int64_t)h_slow_count * 4 > (int64_t)st.n_tiles ? 1 : 0;   // tiles the fast kernel declined
     }
     // remember how dense the groups were so the next sparse call sizes its tables right away
     {
@@ -1725,6 +1811,15 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     offs.assign((size_t)n_win + 1, 0);
     wmax.assign(h_meta, h_meta + n_win);
     wgrp.assign(h_meta + n_win, h_meta + 2 * n_win);
+    if (fin_sorted) {   // the usual case: the finish kernel left the ordered result columns on the device and the offsets in pinned memory
+        offs.assign(fin_off, fin_off + n_win + 1);
+        out->auction = fin_auction;
+        out->num = fin_num;
+        out->win_out_offsets = offs.data();
+        out->win_max = wmax.data();
+        out->win_groups = wgrp.data();
+        out->rows = n_sel;
+    } else
     if (sel_key) {
         // Every group of a window can tie for its MAX (equal counts): then the result is as large as the group set, and
         // (window, auction) order comes from two stable radix sorts on the device -- by auction, then by window --
@@ -1765,7 +1860,8 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         out->rows = n_sel;
         return FLOCKGPU_OK;   // (the rare many-ties path leaves the clean-up to the next call)
     }
-    // few winners (the usual case): order them by (window, auction) on the host and hand them back on the device
+    if (!fin_sorted) {
+    // more winners than the finish kernel orders, fewer than the device sorts pay for: ordered by (window, auction) on the host
     std::vector<uint32_t> order(n_sel);
     for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -1796,6 +1892,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     out->win_max = wmax.data();
     out->win_groups = wgrp.data();
     out->rows = n_sel;
+    }
     static const bool no_preclean = getenv("FLOCKGPU_Q5_NO_PRECLEAN") != nullptr || getenv("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (A/B knobs)
     if (speculate && dense && cnt_total > 0 && !no_preclean) {   // clean up after use (see `preclean` above); the results above are already on their way
         int32_t *slow_list = nullptr;
