@@ -47,11 +47,6 @@ struct flockgpu_ctx {
     // adaptive hash-table sizing hints (rows per distinct key observed last call)
     double q5_rows_per_group = 8.0;
     double q8_rows_per_seller = 4.0;
-    // a second stream for clean-up work that may run beside the caller's turnaround and the next call's first kernels (q5's
-    // counter clear): created on first use; `side_pending` = a clean-up is in flight whose completion `side_done` marks
-    hipStream_t side = nullptr;
-    hipEvent_t side_begin = nullptr, side_done = nullptr;
-    bool side_pending = false;
     // profiling
     hipEvent_t sync_event = nullptr;  // for waits that must not include work queued after a copy (created on first use)
     bool profiling = false;
@@ -94,7 +89,6 @@ inline int arena_get(flockgpu_ctx *ctx, const char *name, size_t bytes, void **o
     if (b.cap < bytes) {
         if (b.ptr) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
-            if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);   // (a clean-up kernel may still write the buffer)
             if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_HIP, "sync before arena grow: %s", hipGetErrorString(e));
             (void)hipFree(b.ptr);
             b.ptr = nullptr;
@@ -201,22 +195,6 @@ inline void profile_drain(flockgpu_ctx *ctx) {
 }
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// The side stream (created on first use) and its two events.
-inline int side_stream(flockgpu_ctx *ctx) {
-    if (ctx->side) return FLOCKGPU_OK;
-    FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    FG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_begin, hipEventDisableTiming));
-    FG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
-    return FLOCKGPU_OK;
-}
-// Work queued on the main stream from here on runs behind the clean-up in flight on the side stream (no host wait).
-inline int side_join(flockgpu_ctx *ctx) {
-    if (!ctx->side_pending) return FLOCKGPU_OK;
-    FG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    ctx->side_pending = false;
-    return FLOCKGPU_OK;
-}
 
 // Validates a window schedule against a relation of `rows` rows.
 inline int check_windows(flockgpu_ctx *ctx, const flockgpu_windows *w, int64_t rows, const char *what) {

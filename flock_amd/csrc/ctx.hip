@@ -42,12 +42,6 @@ void flockgpu_ctx_destroy(flockgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->side) {
-        (void)hipStreamSynchronize(ctx->side);
-        (void)hipEventDestroy(ctx->side_begin);
-        (void)hipEventDestroy(ctx->side_done);
-        (void)hipStreamDestroy(ctx->side);
-    }
     profile_drain(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->sync_event) (void)hipEventDestroy(ctx->sync_event);
@@ -64,8 +58,6 @@ const char *flockgpu_last_error(const flockgpu_ctx *ctx) { return ctx ? ctx->las
 int flockgpu_ctx_synchronize(flockgpu_ctx *ctx) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->side) FG_HIP(ctx, hipStreamSynchronize(ctx->side));   // (clean-up work of the last call)
-    ctx->side_pending = false;
     return FLOCKGPU_OK;
 }
 

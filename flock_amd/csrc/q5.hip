@@ -1574,7 +1574,6 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         uint32_t *block_max = nullptr;
         const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_walk ? 2 : 1);
         FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)n_block_max, &block_max));
-        FG_TRY(side_join(ctx));   // the previous call's counter clean-up (side stream) is ordered before everything that touches the counters
         {   // one clear for everything this attempt writes into
             const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, n_block_max});
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
@@ -1899,16 +1898,9 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         int32_t *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)cnt_total / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
-        // ... on the ctx's SIDE stream, behind everything this call queued: the clear (0.047 ms per 1e9 bids) then runs beside the
-        // host's turnaround AND the next call's range / layout kernels (which do not touch the counters) instead of in front of them
-        FG_TRY(side_stream(ctx));
-        FG_HIP(ctx, hipEventRecord(ctx->side_begin, ctx->stream));
-        FG_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->side_begin, 0));
-        hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->side, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
+        hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
                            uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0);
         FG_TRY(check_launch(ctx, "q5_clear_kernel"));
-        FG_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side));
-        ctx->side_pending = true;
         preclean[0] = (int64_t)reinterpret_cast<uintptr_t>(counters);
         preclean[1] = (int64_t)std::max<uint64_t>(clean_upto, cnt_total);
     }
