@@ -22,7 +22,8 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate
 # (file prefix, kernel): the query rows, the "next" side entries and the general-path rows
 ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
                                                             ("q3_general", "q3_probe_general_kernel"), ("q8_general", "q8_sellers_set_kernel"),
-                                                            ("q5_uniform", "q5_count_slow_kernel"), ("q4", "aq_final_kernel")]
+                                                            ("q5_uniform", "q5_part_emit_kernel"), ("q4", "aq_final_kernel"),
+                                                            ("q3_1e8", "q3_probe_flag_small_kernel")]
 for q, kern in ROWS:
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -32,7 +33,9 @@ for q, kern in ROWS:
         for r in csv.DictReader(open(p)):
             if kern + "(" in r["kernel"] or kern + "<" in r["kernel"]:
                 vals[c] = float(r[f"avg_{c}_KB"])
-    name = kern if not q.endswith(("_general", "_uniform")) and q != "q4" else f"{kern}@{q}"
+    name = kern if not q.endswith(("_general", "_uniform")) and q not in ("q4", "q3_1e8") else f"{kern}@{q}"
+    if q == "q3_1e8":
+        name = "q3_probe_flag_kernel@1e8_events"   # (bench.py's label of both probe kernels)
     if len(vals) == 2 and name not in traffic:
         traffic[name] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
         traffic[name + "_detail"] = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
