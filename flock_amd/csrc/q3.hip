@@ -345,84 +345,6 @@ static void launch_probe_small(flockgpu_ctx *ctx, int32_t n_tiles, const int32_t
                            direct, bits, flag_words, counts);
 }
 
-// ---- the few-tiles regime without a build pass: the auction side looks the person up itself ------------------------------------------
-// With every window's ids gapless, person p_id sits in row first_row + (p_id - base), so an auction can test `state IN (...)` of its
-// seller directly: two offsets and the first bytes of the value (L2 / Infinity-Cache hits at this size: 2e6 persons = 12 MB of offsets
-// and bytes) instead of one bit -- and the build kernel, its bit blocks and the boundary behind it (13 us + 2 us of the 1e8-event
-// call's ~60 us of kernels) are gone.  What the build verified row by row -- every window's ids ARE first + 0, 1, 2, ... -- the auction
-// tiles verify here, a slice of their window's persons each (coalesced, ~5 ids per lane).  Five loads per row instead of one, all
-// unconditional from clamped rows; only sensible while the tables are cache-resident, so the host takes it below kDirectMaxPersons.
-template <int kParts>
-__global__ __launch_bounds__(kParts * kBlock) void q3_probe_direct_kernel(const int32_t *__restrict__ seller, const int32_t *__restrict__ category, int64_t n_rows,
-                                                                          int64_t category_lit, SegTiles st, SegTiles st_p, const int32_t *__restrict__ p_id,
-                                                                          const int32_t *__restrict__ state_off, const uint8_t *__restrict__ state_data,
-                                                                          int64_t n_persons, Utf8Lits lits, WinTable *__restrict__ wins_out,
-                                                                          uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts, uint32_t *err) {
-    constexpr int kPer = kFlagIters / kParts;
-    static_assert(kParts == 2 || kParts == 4, "two or four parts per tile");
-    __shared__ uint32_t s_cnt[kParts][kWavesPerBlock];
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const int part = threadIdx.x >> 8, t = threadIdx.x & (kBlock - 1), wave = t >> 6, lane = t & 63;
-    const int32_t rel0 = wave * kFlagWaveRows + lane * 4;
-    // the window's person rows and its table (base id, first row); a window without persons joins nothing
-    const int64_t plo = st_p.seg_off[2 * tr.seg], phi = st_p.seg_off[2 * tr.seg + 1];
-    const int32_t base = phi > plo ? p_id[plo] : 0;
-    const uint32_t n_p = (uint32_t)(phi - plo);
-    const int32_t t0 = st.tile_first[tr.seg], nt = st.tile_first[tr.seg + 1] - t0;
-    if (threadIdx.x == 0 && tile == t0)
-        wins_out[tr.seg] = WinTable{base, n_p, 0, (int32_t)plo, 0, 0, 1u};
-    int32_t sv[kPer][4], cv[kPer][4];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int64_t r0 = tr.tile_begin + rel0 + (part * kPer + k) * 256;
-        load4_i32(seller, r0, n_rows, sv[k]);
-        load4_i32(category, r0, n_rows, cv[k]);
-    }
-    {   // this tile's slice of the window's persons: id = base + (row - first row), for every row
-        const int64_t slice = ((int64_t)n_p + nt - 1) / nt, s0 = plo + (int64_t)(tile - t0) * slice, s1 = s0 + slice < phi ? s0 + slice : phi;
-        bool bad = false;
-        for (int64_t r = s0 + threadIdx.x; r < s1; r += kParts * kBlock) bad = bad || p_id[r] != base + (int32_t)(r - plo);
-        if (bad) raise_flag(err, true);
-    }
-    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
-    bool need[kPer][4];
-    int32_t o0[kPer][4], o1[kPer][4];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t rel = rel0 + (part * kPer + k) * 256 + j;
-            const uint32_t idx = (uint32_t)sv[k][j] - (uint32_t)base;
-            need[k][j] = rel >= rel_lo && rel < rel_hi && (int64_t)cv[k][j] == category_lit && idx < n_p;
-            const int64_t pr = need[k][j] ? plo + idx : 0;
-            o0[k][j] = state_off[pr];
-            o1[k][j] = state_off[pr + 1];
-        }
-    uint32_t flags = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t len = need[k][j] ? (uint32_t)(o1[k][j] - o0[k][j]) : 0u;
-            const uint64_t v = utf8_head8(state_data, len ? o0[k][j] : 0, len > 8 ? 8u : len);
-            const bool f = need[k][j] && len <= 8 && lits_hit(v, len, lits);
-            flags |= (f ? 1u : 0u) << (k * 4 + j);
-        }
-    if (kParts == 4) reinterpret_cast<uint8_t *>(flag_words)[((size_t)tile * kBlock + t) * 4 + part] = (uint8_t)flags;
-    else reinterpret_cast<uint16_t *>(flag_words)[((size_t)tile * kBlock + t) * 2 + part] = (uint16_t)flags;
-    const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags));
-    if (lane == 63) s_cnt[part][wave] = incl;
-    __syncthreads();
-    if (threadIdx.x < kWavesPerBlock) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int q = 0; q < kParts; ++q) c += s_cnt[q][threadIdx.x];
-        counts[(size_t)tile * kWavesPerBlock + threadIdx.x] = c;
-    }
-    (void)n_persons;
-}
-
 template <bool kBits>
 __global__ __launch_bounds__(kBlock) void q3_emit_dense_kernel(const int32_t *__restrict__ seller,
                                                                const int32_t *__restrict__ a_id, SegTiles st,
@@ -887,26 +809,14 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         int64_t *h_woff = reinterpret_cast<int64_t *>(h_blk + 4);
         h_blk[0] = 0;   // (the previous call's values were read under its synchronisation)
         h_blk[1] = 0;
-        // few persons (their offsets and bytes stay cache-resident): no build pass, the auction side looks its seller's state up itself
-        static const int64_t direct_max_persons = getenv("FLOCKGPU_Q3_DIRECT_MAX_PERSONS") ? atoll(getenv("FLOCKGPU_Q3_DIRECT_MAX_PERSONS")) : (int64_t(4) << 20);
-        const bool direct = person->rows <= direct_max_persons && st_a.n_tiles < (int64_t)ctx->num_cus * 6;
-        if (direct) {
-            LaunchScope ls(ctx, "q3_probe_flag_kernel");
-            if ((int64_t)st_a.n_tiles * 4 * kBlock <= (int64_t)ctx->num_cus * 2048)
-                hipLaunchKernelGGL((q3_probe_direct_kernel<4>), dim3((unsigned)st_a.n_tiles), dim3(4 * kBlock), 0, ctx->stream, auction->seller, auction->category, auction->rows,
-                                   category_lit, st_a, st_p, person->p_id, person->state.offsets, person->state.data, person->rows, lits, d_wins, flag_words, counts, h_flag);
-            else
-                hipLaunchKernelGGL((q3_probe_direct_kernel<2>), dim3((unsigned)st_a.n_tiles), dim3(2 * kBlock), 0, ctx->stream, auction->seller, auction->category, auction->rows,
-                                   category_lit, st_a, st_p, person->p_id, person->state.offsets, person->state.data, person->rows, lits, d_wins, flag_words, counts, h_flag);
-        } else {
+        {
             LaunchScope ls(ctx, "q3_build_kernel");
             hipLaunchKernelGGL((q3_build_kernel<true, true, true>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream, person->p_id,
                                person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, bits, nullptr, 0u, nullptr, h_flag,
                                build_y_shift, d_wins);
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
-        if (direct) {
-        } else if (st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
+        if (st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
             launch_probe_small<true>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, nullptr, bits, flag_words, counts);
         } else {
