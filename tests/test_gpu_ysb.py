@@ -112,3 +112,51 @@ def test_ysb_long_literals_and_wide_campaign_tables(ctx, n_camp_rows):
         for w in range(2):
             want = oracle.ysb_campaign_counts(ad.slice(offs[w], offs[w + 1]), et.slice(offs[w], offs[w + 1]), c_ad, camp, lit)
             assert got[w] == want and sum(want.values()) > 1000, (lit, w)
+
+
+def _hash_words(keys):
+    """ysb.hip's `hash_words` over equal-length byte keys (<= 40 bytes), vectorised: the test needs two DIFFERENT keys that
+    the device table cannot tell apart by hash."""
+    n, ln = len(keys), len(keys[0])
+    buf = np.zeros((n, 40), np.uint8)
+    buf[:, :ln] = np.frombuffer(b"".join(keys), np.uint8).reshape(n, ln)
+    w = buf.view("<u4").astype(np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    h = np.full(n, 0x811C9DC5 ^ ln, np.uint64)
+    for i in range(10):
+        h = ((h ^ w[:, i]) * np.uint64(0x9E3779B1)) & m
+        h = ((h << np.uint64(13)) | (h >> np.uint64(19))) & m
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & m
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & m
+    h ^= h >> np.uint64(16)
+    return h.astype(np.uint32)
+
+
+def test_ysb_two_ads_with_one_hash(ctx):
+    """Two ad ids whose 32-bit hashes are EQUAL: same home slot, same tag in the workgroup's LDS copy of the table, so the
+    walk stops at whichever of them sits first and only the comparison of the whole key tells them apart (the probe then
+    carries on in the global table).  Counts of both, and of a third ad that is in no campaign, must still be exact."""
+    from flock_amd import WindowSchedule
+    from flock_amd.ysb import campaign_counts
+    keys = [b"ad-%033d" % i for i in range(400_000)]
+    h = _hash_words(keys)
+    order = np.argsort(h, kind="stable")
+    same = np.nonzero(h[order][1:] == h[order][:-1])[0]
+    assert len(same) > 0, "no 32-bit collision among 4e5 keys (expected ~18)"
+    twins = [(keys[order[i]], keys[order[i + 1]]) for i in same[:3]]
+    rng = np.random.default_rng(5)
+    for a, b in twins:
+        others = [b"ad-%033d" % i for i in range(500_000, 500_040)]
+        c_keys = [a, b] + others
+        camps = [b"campaign-a", b"campaign-b"] + [b"campaign-%02d" % (i % 7) for i in range(len(others))]
+        pool = c_keys + [b"ad-%033d" % 999_999_999]
+        n = 30_000
+        ad = _col([pool[i] for i in rng.integers(0, len(pool), n)])
+        et = _col([[b"view", b"click"][i] for i in rng.integers(0, 2, n)])
+        offs = np.array([0, 11_111, n])
+        sched = WindowSchedule(offs, np.arange(2), np.arange(1, 3))
+        c_ad, camp = _col(c_keys), _col(camps)
+        got = _result_dicts(campaign_counts(ctx, _utf8(ad), _utf8(et), n, sched, _utf8(c_ad), _utf8(camp), len(c_keys)).to_host())
+        for w in range(2):
+            want = oracle.ysb_campaign_counts(ad.slice(offs[w], offs[w + 1]), et.slice(offs[w], offs[w + 1]), c_ad, camp)
+            assert got[w] == want and want[b"campaign-a"] > 50 and want[b"campaign-b"] > 50, (a, b, w)
