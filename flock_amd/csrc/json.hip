@@ -41,6 +41,10 @@ struct JsonSpec {
     int32_t type[kMaxFields];
     int32_t name_len[kMaxFields];
     char name[kMaxFields][kMaxName];
+    // the bytes that precede field f's value in a line as serde_json writes it: `{"name":` for the first field, `,"name":`
+    // after it, as little-endian words (parse_line_words compares four bytes at a time)
+    int32_t pre_len[kMaxFields];
+    uint32_t pre[kMaxFields][(kMaxName + 3 + 7) / 8 * 2];
 };
 
 struct JsonOut {
@@ -267,6 +271,7 @@ __device__ uint32_t parse_line(const Text<kLds> &t, int32_t p, int32_t end, cons
                 ++p;
             }
             if (p >= end || t.at(p) < '0' || t.at(p) > '9') return kErrSyntax;  // not a number at all (a string, true, null ...)
+            if (t.at(p) == '0' && p + 1 < end && t.at(p + 1) >= '0' && t.at(p + 1) <= '9') return kErrSyntax;  // JSON has no leading zeros
             uint64_t v = 0;
             int digits = 0;
             while (p < end) {
@@ -344,7 +349,7 @@ __device__ bool parse_line_fast(const Text<kLds> &t, int32_t p, int32_t end, con
                 ++digits;
                 ++p;
             }
-            if (digits == 0 || digits > 18) return false;
+            if (digits == 0 || digits > 18 || (digits > 1 && t.at(p - digits) == '0')) return false;
             const int64_t sv = neg ? -(int64_t)v : (int64_t)v;
             if (spec.type[f] == kInt32) {
                 if (sv < -2147483648ll || sv > 2147483647ll) return false;
@@ -359,7 +364,131 @@ __device__ bool parse_line_fast(const Text<kLds> &t, int32_t p, int32_t end, con
     return p == end;
 }
 
+// ---- the same shape, four and eight bytes at a time (text staged in LDS) ------------------------------------------------
+// One lane still walks one line, but through unaligned 4- and 8-byte LDS reads and SWAR arithmetic instead of a byte per
+// trip: ~16 instructions per byte of text made the byte-wise walk instruction-bound at a third of the HBM rate.
+// The staged range carries 16 bytes of slack, so a read that starts inside a line may run past its end; whatever lies
+// there is cut off by `end` before it is used.
+// Four / eight bytes of the staged text from ANY byte offset, out of dword-aligned reads and a funnel shift: an LDS read
+// that is not dword-aligned is ~6x as expensive on gfx950 (64 lanes at a 74-byte stride: ~68 cycles of the CU's LDS pipe per
+// wave read at a byte offset whatever the width, 10-12 for an aligned b32 / a 4-byte-aligned b64, ~17 for the three dwords
+// read here -- tools/micro/lds_unaligned.hip).  `s` is 16-byte aligned.
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t *s, int32_t o) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(s + (o & ~3));
+    return __funnelshift_r(w[0], w[1], (uint32_t)(o & 3) * 8);
+}
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t *s, int32_t o) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(s + (o & ~3));
+    const uint32_t sh = (uint32_t)(o & 3) * 8, w0 = w[0], w1 = w[1], w2 = w[2];
+    return (uint64_t)__funnelshift_r(w0, w1, sh) | ((uint64_t)__funnelshift_r(w1, w2, sh) << 32);
+}
+// Bytes of x that are NOT an ASCII digit, as 0x80 flags (exact for every byte: no carry crosses a byte).
+__device__ __forceinline__ uint64_t non_digit_flags(uint64_t x) {
+    const uint64_t t = x ^ 0x3030303030303030ull;
+    return (((t & 0x7F7F7F7F7F7F7F7Full) + 0x7676767676767676ull) | t) & 0x8080808080808080ull;
+}
+// Value of four digits, most significant in the lowest byte (w = text ^ '0000').
+__device__ __forceinline__ uint32_t four_digits(uint32_t w) { return ((((w * 2561u) >> 8) & 0x00FF00FFu) * 6553601u) >> 16; }
+// Value of the first nd (1..8) digits of the eight text bytes x.
+__device__ __forceinline__ uint32_t leading_digits(uint64_t x, int nd) {
+    const uint64_t t = (x ^ 0x3030303030303030ull) << (8 * (8 - nd));  // right-aligned: the vacated low bytes read as 0 digits
+    return four_digits((uint32_t)t) * 10000u + four_digits((uint32_t)(t >> 32));
+}
+
+// (The LDS pipe is what this walk is bound by -- SQ_LDS_IDX_ACTIVE at 82 % of the kernel's cycles with the first version's
+// ~25 byte-offset reads per bid line: hence few reads, ~14 per line, and every one of them dword-aligned.)
+// kUnroll >= spec.n: the trip over the fields is unrolled at compile time, so that everything read from `spec` (the kernel's
+// argument block) sits at a constant offset and arrives in a few wide scalar loads up front -- indexed by a loop counter it
+// was ~8 dependent scalar loads per field, each waited for with the LDS counter.
+template <int kUnroll>
+__device__ __forceinline__ bool parse_line_words(const uint8_t *s, int32_t s_base, int32_t p, int32_t end, const JsonSpec &spec,
+                                                 int64_t row, const JsonOut &out) {
+    p -= s_base;
+    end -= s_base;
+#pragma unroll
+    for (int f = 0; f < kUnroll; ++f) {
+        if (f >= spec.n) break;
+        const int32_t pl = spec.pre_len[f];
+        if (p + pl + 1 > end) return false;  // the prefix and at least one byte of value
+        uint64_t diff = 0;
+#pragma unroll
+        for (int j = 0; j < (kMaxName + 3 + 7) / 8; ++j) {
+            if (8 * j >= pl) break;
+            const int32_t left = pl - 8 * j;
+            const uint64_t want = (uint64_t)spec.pre[f][2 * j] | ((uint64_t)spec.pre[f][2 * j + 1] << 32);
+            if (left > 4) diff |= (lds_u64(s, p + 8 * j) ^ want) & (left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull);
+            else diff |= ((uint64_t)lds_u32(s, p + 8 * j) ^ want) & ((1ull << (8 * left)) - 1ull);
+        }
+        if (diff) return false;
+        p += pl;
+        if (spec.type[f] == kUtf8) {
+            const int32_t b = p + 1;
+            uint64_t x = lds_u64(s, p);
+            if ((x & 0xFFu) != '"') return false;
+            x |= 0xFFu;  // the opening quote is not the closing one
+            uint32_t c = 0;
+            for (;;) {  // the first quote, backslash or control character (the lowest flag of each test is exact)
+                const uint64_t q = x ^ 0x2222222222222222ull, bs = x ^ 0x5C5C5C5C5C5C5C5Cull;
+                const uint64_t m = (((q - 0x0101010101010101ull) & ~q) | ((bs - 0x0101010101010101ull) & ~bs) |
+                                    ((x - 0x2020202020202020ull) & ~x)) & 0x8080808080808080ull;
+                if (m) {
+                    const int at = (__ffsll((unsigned long long)m) - 1) >> 3;
+                    p += at;
+                    c = (uint32_t)(x >> (8 * at)) & 0xFFu;
+                    break;
+                }
+                p += 8;
+                if (p >= end) return false;
+                x = lds_u64(s, p);
+            }
+            if (p >= end || c != '"') return false;
+            out.pairs[f][2 * row] = b + s_base;
+            out.pairs[f][2 * row + 1] = p + s_base;
+            out.ulen[f][row] = p - b;
+            ++p;
+        } else {
+            uint64_t x0 = lds_u64(s, p);
+            const bool neg = (x0 & 0xFFu) == '-';
+            if (neg) x0 = lds_u64(s, ++p);
+            // how many digits (up to 18), eight at a time; then the leading 1..8 digits and whole groups of eight, the
+            // groups cut out of the words already read
+            uint64_t x1 = 0, x2 = 0;
+            const uint64_t m0 = non_digit_flags(x0);
+            int total = m0 ? (__ffsll((unsigned long long)m0) - 1) >> 3 : 8;
+            if (total == 8 && p + 8 < end) {  // (never a read beyond the slack)
+                x1 = lds_u64(s, p + 8);
+                const uint64_t m1 = non_digit_flags(x1);
+                total += m1 ? (__ffsll((unsigned long long)m1) - 1) >> 3 : 8;
+                if (total == 16 && p + 16 < end) {
+                    x2 = lds_u64(s, p + 16);
+                    const uint64_t m2 = non_digit_flags(x2);
+                    total += m2 ? (__ffsll((unsigned long long)m2) - 1) >> 3 : 8;
+                }
+            }
+            total = min(total, end - p);
+            if (total <= 0 || total > 18 || (total > 1 && (x0 & 0xFFu) == '0')) return false;  // (leading zero: the general parser's error)
+            const int lead = total - ((total - 1) & ~7);
+            uint64_t v = leading_digits(x0, lead);
+            if (total > 8) {
+                const int sh = 8 * lead;  // 8 .. 64
+                v = v * 100000000ull + leading_digits(lead == 8 ? x1 : (x0 >> sh) | (x1 << (64 - sh)), 8);
+                if (total > 16) v = v * 100000000ull + leading_digits(lead == 8 ? x2 : (x1 >> sh) | (x2 << (64 - sh)), 8);
+            }
+            p += total;
+            const int64_t sv = neg ? -(int64_t)v : (int64_t)v;
+            if (spec.type[f] == kInt32) {
+                if (sv < -2147483648ll || sv > 2147483647ll) return false;
+                reinterpret_cast<int32_t *>(out.values[f])[row] = (int32_t)sv;
+            } else {
+                reinterpret_cast<int64_t *>(out.values[f])[row] = sv;
+            }
+        }
+    }
+    return p + 1 == end && s[p] == '}';
+}
+
 // err[0] = first bad line + 1 (0: none) as atomicMin over (line + 1) stored inverted, err[1] = its code
+template <int kUnroll>
 __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__restrict__ bytes, int64_t n_bytes,
                                                             const int32_t *__restrict__ line_start, int64_t n_lines, JsonSpec spec,
                                                             JsonOut out, int32_t stage_bytes, unsigned long long *err) {
@@ -371,7 +500,12 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
     const int64_t l1 = min(l0 + kParseLines, n_lines);
     const int32_t b0 = line_start[l0], b1 = min((int64_t)line_start[l1], n_bytes);
     const int32_t a0 = b0 & ~15;
-    const bool staged = b1 - a0 <= stage_bytes;  // block-uniform
+    const bool staged = b1 - a0 + 16 <= stage_bytes;  // block-uniform; 16 bytes of slack for reads that overrun a line
+    // this lane's line: asked for before the staging so that the loads overlap it
+    const int64_t line = l0 + threadIdx.x;
+    const int64_t line_c = min(line, n_lines - 1);
+    const int32_t p = line_start[line_c];
+    const int32_t e = min((int64_t)line_start[line_c + 1] - 1, n_bytes);  // without the newline
     if (staged) {
         for (int32_t o = a0 + (int32_t)threadIdx.x * 16; o < b1; o += kBlock * 16) {
             if ((int64_t)o + 16 <= n_bytes) {
@@ -382,14 +516,11 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
         }
     }
     __syncthreads();
-    const int64_t line = l0 + threadIdx.x;
     if (line >= n_lines) return;
-    const int32_t p = line_start[line];
-    const int32_t e = min((int64_t)line_start[line + 1] - 1, n_bytes);  // without the newline
     uint32_t rc;
     if (staged) {
         const Text<true> t{bytes, s_stage, a0};
-        rc = parse_line_fast(t, p, e, s_spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
+        rc = parse_line_words<kUnroll>(s_stage, a0, p, e, spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
     } else {
         const Text<false> t{bytes, nullptr, 0};
         rc = parse_line_fast(t, p, e, s_spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
@@ -515,6 +646,14 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
         spec.type[f] = fields[f].type;
         spec.name_len[f] = (int32_t)len;
         std::memcpy(spec.name[f], fields[f].name, len);
+        char pre[sizeof spec.pre[0]] = {};
+        pre[0] = f == 0 ? '{' : ',';
+        pre[1] = '"';
+        std::memcpy(pre + 2, fields[f].name, len);
+        pre[len + 2] = '"';
+        pre[len + 3] = ':';
+        spec.pre_len[f] = (int32_t)len + 4;
+        std::memcpy(spec.pre[f], pre, sizeof spec.pre[f]);
     }
     FG_HIP(ctx, hipSetDevice(ctx->device));
     for (int f = 0; f < n_fields; ++f) out[f] = flockgpu_json_column{};
@@ -591,7 +730,8 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
         // not fit reads them from global memory instead.
         int64_t want = (n_bytes / n_lines + 1) * kParseLines * 5 / 4 + 64;
         const int32_t stage_bytes = (int32_t)std::min<int64_t>(kStageBytes, (want + 1023) & ~int64_t(1023));
-        hipLaunchKernelGGL(json_parse_kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), (size_t)stage_bytes, ctx->stream,
+        auto kernel = n_fields <= 4 ? json_parse_kernel<4> : n_fields <= 8 ? json_parse_kernel<8> : json_parse_kernel<kMaxFields>;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), (size_t)stage_bytes, ctx->stream,
                            json, n_bytes, line_start, n_lines, spec, jo, stage_bytes, d_err);
     }
     FG_TRY(check_launch(ctx, "json_parse_kernel"));

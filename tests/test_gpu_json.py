@@ -108,6 +108,8 @@ def test_lines_longer_than_the_staging_buffer(ctx):
     (b'{"a":1,"b":"x"} trailing\n', "INVALID"),
     (b'{"a":"1","b":"x"}\n', "INVALID"),                               # string where an integer is expected
     (b'{"\\u0061":1,"b":"x"}\n', "UNSUPPORTED"),                       # escape in a key
+    (b'{"a":007,"b":"x"}\n', "INVALID"),                               # leading zeros (serde_json: "invalid number")
+    (b'{"b":"x", "a": -01}\n', "INVALID"),
 ])
 def test_errors_name_the_line(ctx, bad, code):
     from flock_amd import FlockGpuError, _ffi
@@ -120,3 +122,36 @@ def test_errors_name_the_line(ctx, bad, code):
 def test_empty_text(ctx):
     got, n = ctx.json_lines_decode(_dev_bytes(b""), [("a", "int32"), ("b", "utf8")])
     assert n == 0 and got["a"].numel() == 0 and got["b"].offsets.cpu().tolist() == [0]
+
+
+def test_compact_lines_every_digit_count_and_string_length(ctx):
+    """The shape serde_json writes is walked eight bytes at a time (`parse_line_words`): integers of 1 .. 19 digits of
+    either sign, INT64's ends, strings of 0 .. 40 bytes (every position of the closing quote inside an
+    8-byte read), multi-byte UTF-8, and a text that ends in a digit / in the closing brace without a newline."""
+    fields = [("a", "int64"), ("s", "utf8"), ("b", "int32"), ("c", "int64")]
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(6000):
+        nd = i % 19 + 1
+        a = int(rng.integers(10 ** (nd - 1), min(10 ** nd, 2 ** 63))) if nd > 1 else int(rng.integers(0, 10))
+        a = min(a, 2 ** 63 - 1) * (-1 if i % 3 == 0 else 1)
+        if i % 500 == 1: a = 2 ** 63 - 1
+        if i % 500 == 2: a = -2 ** 63
+        s = ("é" if i % 7 == 0 else "") + "abcdefghijklmnopqrstuvwxyz0123456789{}:,'"[: i % 41]
+        b = int(rng.integers(-2 ** 31, 2 ** 31)) if i % 11 else [2 ** 31 - 1, -2 ** 31, 0][i % 3]
+        c = int(rng.integers(0, 10 ** (i % 18 + 1)))
+        lines.append(b'{"a":%d,"s":"%s","b":%d,"c":%d}' % (a, s.encode(), b, c))
+    want = None
+    for tail in (b"\n", b""):
+        text = b"\n".join(lines) + tail
+        want = want or oracle.json_lines_decode(text + b"\n" if not tail else text, fields)
+        got, n = ctx.json_lines_decode(_dev_bytes(text), fields)
+        assert n == len(lines)
+        _check(got, want, fields, n)
+    # a text that ends in a digit of a number that the line does not close: an error, not a read past the text
+    from flock_amd import FlockGpuError
+    with pytest.raises(FlockGpuError):
+        ctx.json_lines_decode(_dev_bytes(b'{"a":1,"s":"x","b":2,"c":12345678'), fields)
+    # 20 digits: out of range whichever path meets it
+    with pytest.raises(FlockGpuError):
+        ctx.json_lines_decode(_dev_bytes(b'{"a":12345678901234567890,"s":"x","b":2,"c":3}\n'), fields)
