@@ -7,7 +7,7 @@
 //           (digit, tile) run
 //   emit  : wave w of a tile owns rows [1024 w, 1024 (w+1)), lane = row % 64, so (wave, iteration, lane) IS arrival
 //           order.  Per iteration the lanes holding the same digit find each other with one ballot per digit bit
-//           (`m &= bit ? ballot : ~ballot`), the lowest lane of a group advances the wave's digit counter in LDS, and
+//           (`m &= ~(ballot ^ my bit)`), the lowest lane of a group advances the wave's digit counter in LDS, and
 //           rank = counter before + lanes of the group below me.  Keys and values are then regrouped by digit in LDS
 //           and leave the tile as runs of consecutive addresses: reads 8 B / row, writes 8 B / row.
 // The pass count adapts to the key range: ceil(bits / 8) passes of equal width.
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void sort_count_kernel(const int32_t *__res
     if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = (int32_t)s_h[threadIdx.x];
 }
 
+template <int kBits>  // width of this pass's digit
 __global__ __launch_bounds__(kBlock) void sort_emit_kernel(const int32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                            int64_t n, int32_t bias, int shift, uint32_t mask, int32_t n_tiles,
                                                            const int32_t *__restrict__ hist_incl, int32_t *__restrict__ keys_out,
@@ -78,34 +79,50 @@ __global__ __launch_bounds__(kBlock) void sort_emit_kernel(const int32_t *__rest
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < kWavesPerBlock; ++w) s_wh[w][threadIdx.x] = 0;
-    const int64_t tile_begin = (int64_t)blockIdx.x * kSortTile;
-    const int64_t wave_begin = tile_begin + (int64_t)wave * kWaveRows;
+    // (n < 2^31: row numbers in 32 bits -- a 64-bit clamp and address per load was a tenth of this kernel's VALU work)
+    const uint32_t n32 = (uint32_t)n;
+    const uint32_t tile_begin = blockIdx.x * (uint32_t)kSortTile;
+    const uint32_t wave_begin = tile_begin + (uint32_t)wave * kWaveRows;
     int32_t k[kSortItems];
     uint32_t v[kSortItems], rank[kSortItems];
+    if (vals_in) {
 #pragma unroll
-    for (int it = 0; it < kSortItems; ++it) {
-        const int64_t r = wave_begin + it * 64 + lane;
-        const int64_t rc = r < n ? r : n - 1;  // clamped: no load under a per-row branch
-        k[it] = keys_in[rc];
-        v[it] = vals_in ? vals_in[rc] : (uint32_t)rc;
+        for (int it = 0; it < kSortItems; ++it) {
+            const uint32_t rc = min(wave_begin + it * 64 + lane, n32 - 1);  // clamped: no load under a per-row branch
+            k[it] = keys_in[rc];
+            v[it] = vals_in[rc];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kSortItems; ++it) {
+            const uint32_t rc = min(wave_begin + it * 64 + lane, n32 - 1);
+            k[it] = keys_in[rc];
+            v[it] = rc;
+        }
     }
     __syncthreads();
-    volatile uint32_t *wh = s_wh[wave];
+    uint32_t *wh = s_wh[wave];  // this wave's running digit counts: written and read by this wave only, in program order
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
-        const bool valid = wave_begin + it * 64 + lane < n;
+        const bool valid = wave_begin + it * 64 + lane < n32;
         const uint32_t d = digit_of(k[it], bias, shift, mask);
-        uint64_t m = __ballot(valid);
+        // the lanes that hold my digit: per digit bit, keep the lanes whose bit equals mine.  With t = 0 / ~0 for my bit the
+        // lanes to keep are ~(ballot ^ t): one three-input boolean op per half of the mask (four VALU instructions a round,
+        // where `m &= bit ? ballot : ~ballot` on a 64-bit mask compiled to nine -- this kernel is VALU-bound, not HBM-bound)
+        const uint64_t live = __ballot(valid);
+        uint32_t m_lo = (uint32_t)live, m_hi = (uint32_t)(live >> 32);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {  // digit bits above the pass width are 0 in every lane: those rounds keep m
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+        for (int b = 0; b < kBits; ++b) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);  // 0 or ~0: my bit b, sign-extended
+            const uint64_t bal = __ballot(t != 0u);
+            m_lo &= ~((uint32_t)bal ^ t);
+            m_hi &= ~((uint32_t)(bal >> 32) ^ t);
         }
-        const uint32_t below = mbcnt(m);
-        const uint32_t before = wh[d];
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t before = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         rank[it] = before + below;
-        if (valid && below == 0) wh[d] = before + (uint32_t)__popcll((unsigned long long)m);
+        if (valid && below == 0)
+            __hip_atomic_store(&wh[d], before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __syncthreads();
     {   // thread d: wave bases of digit d, tile-local and global start of the digit
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void sort_emit_kernel(const int32_t *__rest
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
-        if (wave_begin + it * 64 + lane < n) {
+        if (wave_begin + it * 64 + lane < n32) {
             const uint32_t d = digit_of(k[it], bias, shift, mask);
             const uint32_t lp = s_dig_off[d] + s_wh[wave][d] + rank[it];
             s_keys[lp] = k[it];
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void sort_emit_kernel(const int32_t *__rest
         }
     }
     __syncthreads();
-    const int32_t tile_n = (int32_t)(n - tile_begin < kSortTile ? n - tile_begin : kSortTile);
+    const int32_t tile_n = (int32_t)min(n32 - tile_begin, (uint32_t)kSortTile);
     for (int32_t j = threadIdx.x; j < tile_n; j += kBlock) {
         const int32_t key = s_keys[j];
         const uint32_t d = digit_of(key, bias, shift, mask);
@@ -262,7 +279,9 @@ int radix_sort_pairs(flockgpu_ctx *ctx, const char *name, const int32_t *keys, c
         FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), hist, tiles << nb));
         {
             LaunchScope ls(ctx, "sort_emit_kernel");
-            hipLaunchKernelGGL(sort_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, k_in, v_in, n, bias, shift, mask,
+            static constexpr decltype(&sort_emit_kernel<8>) kEmit[8] = {sort_emit_kernel<1>, sort_emit_kernel<2>, sort_emit_kernel<3>, sort_emit_kernel<4>,
+                                                                        sort_emit_kernel<5>, sort_emit_kernel<6>, sort_emit_kernel<7>, sort_emit_kernel<8>};
+            hipLaunchKernelGGL(kEmit[nb - 1], dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, k_in, v_in, n, bias, shift, mask,
                                (int32_t)tiles, hist, kb[dst], vb[dst]);
         }
         FG_TRY(check_launch(ctx, "sort_emit_kernel"));

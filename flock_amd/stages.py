@@ -231,9 +231,15 @@ class StagedRun:
     flock-function/src/aws/actor.rs:425-543 without the Lambda invocations in between.  What the reference's
     `launcher/aws` differential tests do with real functions (flock/src/launcher/aws/mod.rs:423-468)."""
 
-    def __init__(self, gpu, stages: List[Stage], chunks: int = 1):
+    def __init__(self, gpu, stages: List[Stage], chunks: int = 1, instances: int = 0):
+        """instances: function instances of a consuming stage.  0 = one per hash partition (the reference's default: the stage's
+        concurrency equals its input partitioning); k > 0 = partition p goes to instance p % k, which feeds everything it is sent
+        into ONE execute -- a GPU function hosting several partitions.  The union over the instances is the same multiset either
+        way: the partitions are disjoint in the key the stage joins / groups on (what `HashJoinExec mode=Partitioned` and
+        `FinalPartitioned` rest on), so a join or an aggregate over several partitions at once is the union of the per-partition
+        results."""
         from .runtime import ExecutionContext
-        self.stages, self.chunks = stages, chunks
+        self.stages, self.chunks, self.instances = stages, chunks, instances
         self.ctxs = [ExecutionContext([st.plan], name=f"stage-{i}", gpu=gpu) for i, st in enumerate(stages)]
 
     def close(self):
@@ -256,8 +262,11 @@ class StagedRun:
                     invocations.append(src)
             else:
                 parts = max(len(outputs[j]) for j in feeders)
-                for p in range(parts):
-                    invocations.append([[outputs[j][p] if len(outputs[j]) == parts else [b for part in outputs[j] for b in part]] for j in feeders])
+                k = min(self.instances, parts) if self.instances > 0 else parts
+                for inst in range(k):
+                    mine = range(inst, parts, k)
+                    invocations.append([[[b for p in mine for b in outputs[j][p]] if len(outputs[j]) == parts
+                                         else [b for part in outputs[j] for b in part]] for j in feeders])
             result = None
             for src in invocations:
                 out = collect(ctx, src)

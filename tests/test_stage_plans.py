@@ -226,6 +226,25 @@ def test_staged_execution_equals_whole_plan_equals_oracle(gpu, rule, q, seed, ep
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q,seed,eps,n", [(3, 3, 50_000, 150_000), (5, 5, 20_000, 100_000), (8, 8, 50_000, 200_000)])
+def test_one_function_instance_may_host_several_partitions(gpu, q, seed, eps, n):
+    """`StagedRun(instances=k)`: partition p of a shuffle goes to instance p % k of the consuming stage, which feeds all it gets
+    into one execute.  Same rows as one instance per partition (and as the oracle) for k = 1 and for a k that does not divide 8."""
+    from flock_amd import stages as S
+    relations, host = _relations(seed, eps, n)
+    want = _oracle_rows(q, host)
+    assert len(want) > 0
+    for k in (0, 1, 3):
+        run = S.StagedRun(gpu, S.build_query_dag(_plan(q)), instances=k)
+        try:
+            src = {name: relations[name] for name in (["bid"] if q == 5 else (["person", "auction"] if q == 8 else ["auction", "person"]))}
+            assert _rows(run.run(src)) == want, k
+            assert _rows(run.run(src)) == want, k     # the plans are reusable: a second window through the same instances
+        finally:
+            run.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("q", [1, 2, 3, 5, 7, 8, 13])
 def test_generic_operators_equal_the_fused_pipelines(gpu, q, monkeypatch):
     """Every whole-query plan once through its fused pipeline and once with FLOCKGPU_PLAN_GENERIC=1 (relops.hip only)."""

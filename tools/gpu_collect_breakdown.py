@@ -33,17 +33,18 @@ for q, seconds in ((3, 1), (8, 10)):
            "person": pa.record_batch([pa.array(p.p_id.cpu().numpy()), utf8(p.name, p.rows), utf8(p.city, p.rows), utf8(p.state, p.rows)], names=["p_id", "name", "city", "state"])}
     if q == 8:
         rel = {"person": rel["person"], "auction": rel["auction"]}
-    st = StagedRun(gpu, build_query_dag(plan))
-    for _ in range(3):
-        st.run(rel)
-    T.clear()
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        st.run(rel)
-    total = time.perf_counter() - t0
-    c = sum(v for k, v in T.items() if k.startswith("C:"))
-    print(f"q{q}: {total / n * 1e3:.3f} ms per staged run; inside the library {c / n * 1e3:.3f} ms, Python / Arrow glue {(total - c) / n * 1e3:.3f} ms")
-    for k, v in sorted(T.items()):
-        print(f"   {k}: {v / n * 1e3:.3f} ms per run")
-    st.close()
+    for inst in (0, 1):
+      st = StagedRun(gpu, build_query_dag(plan), instances=inst)
+      for _ in range(3):
+          st.run(rel)
+      T.clear()
+      n = 10
+      t0 = time.perf_counter()
+      for _ in range(n):
+          st.run(rel)
+      total = time.perf_counter() - t0
+      c = sum(v for k, v in T.items() if k.startswith("C:"))
+      print(f"q{q} instances={inst}: {total / n * 1e3:.3f} ms per staged run; inside the library {c / n * 1e3:.3f} ms, Python / Arrow glue {(total - c) / n * 1e3:.3f} ms")
+      for k, v in sorted(T.items()):
+          print(f"   {k}: {v / n * 1e3:.3f} ms per run")
+      st.close()
