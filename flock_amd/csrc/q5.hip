@@ -1136,23 +1136,28 @@ __global__ __launch_bounds__(kBlock) void q5_part_emit_kernel(const int32_t *__r
         k[it] = auction[r < tr.lo ? tr.lo : (r >= tr.hi ? tr.hi - 1 : r)];   // clamped: no load under a per-row branch
     }
     __syncthreads();
-    volatile uint32_t *wh = s_wh[wave];
+    uint32_t *wh = s_wh[wave];  // written and read by this wave only, in program order (LDS instructions: a volatile pointer here
+                                // compiled to system-scope FLAT loads and stores, each waited for)
 #pragma unroll
     for (int it = 0; it < kPartItems; ++it) {
         const int64_t r = wave_begin + it * 64 + lane;
         const bool valid = r >= tr.lo && r < tr.hi;
         const uint32_t d = part_digit(k[it], pd, nd - 1);
-        uint64_t m = __ballot(valid);
+        // lanes that hold my digit: keep, per digit bit, the lanes whose bit equals mine = ~(ballot ^ t), t = 0 / ~0 for my bit
+        const uint64_t live = __ballot(valid);
+        uint32_t m_lo = (uint32_t)live, m_hi = (uint32_t)(live >> 32);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);
+            const uint64_t bal = __ballot(t != 0u);
+            m_lo &= ~((uint32_t)bal ^ t);
+            m_hi &= ~((uint32_t)(bal >> 32) ^ t);
         }
-        const uint32_t below = mbcnt(m);
-        const uint32_t before = wh[d];
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t before = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         rank[it] = before + below;
-        if (valid && below == 0) wh[d] = before + (uint32_t)__popcll((unsigned long long)m);
+        if (valid && below == 0)
+            __hip_atomic_store(&wh[d], before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     __syncthreads();
     {   // thread d: wave bases of digit d, tile-local and global start of the digit

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_set_kernel(const int32_t *_
     // busy per step, each step as long as one insert's chain of dependent global operations (64 steps per lane: 1.8 ms per 6e7
     // auctions).  So every wave gathers the occupied slots of its share into a queue and inserts 64 keys at a time, all lanes busy.
     __shared__ uint32_t s_q[kWavesPerBlock][128];
-    volatile uint32_t *q = s_q[threadIdx.x >> 6];
+    uint32_t *q = s_q[threadIdx.x >> 6];   // this wave's queue (LDS instructions; a volatile pointer compiled to system-scope FLAT accesses)
     uint32_t qn = 0;   // wave-uniform
     auto insert = [&](uint32_t k) {
         const uint64_t first = ld64(&set[slot_of(k, cap)]);
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_set_kernel(const int32_t *_
         const uint32_t k = s_set[i];
         const bool occ = k != kEmpty32;
         const uint64_t b = __ballot(occ);
-        if (occ) q[qn + mbcnt(b)] = k;
+        if (occ) __hip_atomic_store(&q[qn + mbcnt(b)], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         qn += (uint32_t)__popcll((unsigned long long)b);
         __builtin_amdgcn_wave_barrier();
         if (qn >= 64) {
             qn -= 64;
-            const uint32_t mine = q[qn + lane];
+            const uint32_t mine = __hip_atomic_load(&q[qn + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __builtin_amdgcn_wave_barrier();
             insert(mine);
         }
     }
-    if ((uint32_t)lane < qn) insert(q[lane]);
+    if ((uint32_t)lane < qn) insert(__hip_atomic_load(&q[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
     if (threadIdx.x == 0 && s_has_m1 && set_insert(set, cap, -1, 0) < 0) atomicOr(err, 1u);
 }
 
