@@ -879,7 +879,7 @@ def plan_stages(gpu, eps, steps):
         for _ in range(steps):
             staged.run(rel)
         t_staged = (time.perf_counter() - t0) / steps
-        one = StagedRun(gpu, build_query_dag(plan), instances=1)   # ONE function instance per consuming stage hosts all 8 partitions
+        one = StagedRun(gpu, build_query_dag(plan), instances=1, share_sources=True)   # ONE function instance per consuming stage hosts all 8 partitions; one upload per relation
         if sum(b.num_rows for b in one.run(rel)) != n_whole:
             raise RuntimeError(f"q{q}: the one-instance staged run differs from the whole plan")
         one.run(rel)

@@ -95,6 +95,8 @@ struct DevBuf {  // a leaf column on the device, grown by feeds
 struct LeafData {
     std::vector<DevBuf> cols;
     int64_t rows = 0;
+    int64_t dropped = 0;     // rows a feed left out because of NULLs
+    bool borrowed = false;   // cols alias another plan's leaf (flockgpu_plan_feed_shared): nothing here is this leaf's to grow
 };
 
 enum Fused { kNone = 0, kQ2, kQ3, kQ5, kQ7, kQ8, kQ13, kPartialCount, kQ9, kQ4, kYsb };
@@ -1749,6 +1751,7 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const Leaf &lf = plan->ir.leaves[(size_t)input];
     LeafData &ld = plan->leaves[(size_t)input];
+    if (ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: input %d shares another plan's relation; reset the plan first", input);
     std::vector<int> child(lf.schema.size(), -1);
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (!lf.needed[c]) continue;
@@ -1876,6 +1879,7 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
             }
         }
         ld.rows += filt ? (int64_t)k.size() : n;
+        if (filt) ld.dropped += n - (int64_t)k.size();
     }
     FG_TRY(flush_jobs(plan));  // every pageable buffer of this feed, several staging lanes side by side
     for (auto &r : rebases) FG_TRY(add_i32(ctx, r.data, r.n, r.delta));  // (stream-ordered behind the copies above)
@@ -1889,9 +1893,43 @@ int flockgpu_plan_reset(flockgpu_plan *plan) {
     plan->fed_bytes = 0;
     for (auto &ld : plan->leaves) {
         ld.rows = 0;
-        for (auto &c : ld.cols) c.bytes = 0;
+        ld.dropped = 0;
+        for (auto &c : ld.cols) {
+            c.bytes = 0;
+            if (ld.borrowed) c.values = nullptr, c.offsets = nullptr;   // the donor's memory: never grown or appended to from here
+        }
+        ld.borrowed = false;
     }
     return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_feed_shared(flockgpu_plan *plan, int input, const flockgpu_plan *donor, int donor_input) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (!donor || donor == plan || input < 0 || input >= (int)plan->ir.leaves.size() || donor_input < 0 || donor_input >= (int)donor->ir.leaves.size())
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: bad argument");
+    if (donor->ctx != ctx) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: the two plans live on different contexts (streams)");
+    const Leaf &lf = plan->ir.leaves[(size_t)input], &df = donor->ir.leaves[(size_t)donor_input];
+    LeafData &ld = plan->leaves[(size_t)input];
+    const LeafData &dd = donor->leaves[(size_t)donor_input];
+    if (ld.rows != 0 || ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: input %d already holds rows", input);
+    if (dd.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: the donor's relation is itself shared");
+    // what the donor left out because of NULLs it was allowed to drop need not be droppable here
+    if (dd.dropped) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed_shared: the donor dropped %lld rows with NULLs", (long long)dd.dropped);
+    std::vector<int> from(lf.schema.size(), -1);
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (!lf.needed[c]) continue;
+        for (size_t d = 0; d < df.schema.size(); ++d)
+            if (df.needed[d] && df.schema[d].name == lf.schema[c].name && df.schema[d].type == lf.schema[c].type) from[c] = (int)d;
+        if (from[c] < 0)
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed_shared: the donor does not hold column '%s' as %s", lf.schema[c].name.c_str(), type_name(lf.schema[c]));
+        if (dd.rows > 0 && !dd.cols[(size_t)from[c]].values) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: the donor has not been fed");
+    }
+    for (size_t c = 0; c < lf.schema.size(); ++c)
+        if (from[c] >= 0) ld.cols[c] = dd.cols[(size_t)from[c]];
+    ld.rows = dd.rows;
+    ld.borrowed = true;
+    return FLOCKGPU_OK;   // same stream as the donor's copies: ordered behind them without a wait
 }
 
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch) {

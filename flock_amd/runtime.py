@@ -107,6 +107,15 @@ class _Plan:
             _release(C.addressof(sbuf), 56)
         self.gpu._check(rc)
 
+    def feed_shared(self, i: int, donor: "_Plan", donor_input: int) -> bool:
+        """Leaf i reads the relation `donor`'s leaf was fed, in place (flockgpu_plan_feed_shared).  False -- and nothing changed --
+        when the donor does not hold what this plan reads."""
+        rc = self._lib.flockgpu_plan_feed_shared(self.h, i, donor.h, donor_input)
+        if rc == _ffi.ERR_UNSUPPORTED:
+            return False
+        self.gpu._check(rc)
+        return True
+
     def execute(self):
         pa = _pa()
         sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
@@ -159,6 +168,26 @@ class ExecutionContext:
                 if found is not None:
                     partitions = sources.pop(found)
                     plan.feed(i, [b for part in partitions for b in part])
+
+    def share_data_sources(self, donor: "ExecutionContext") -> bool:
+        """Instead of feed_data_sources: every leaf reads, in place, the relation of the same name that `donor` (another function
+        hosted on the same GPU context, already fed and not yet cleaned) holds on the device.  All leaves or none: False when a
+        leaf finds no such relation or the donor does not keep a column it reads -- feed this context its own copy then."""
+        pairs = []
+        for plan in self.plans:
+            for i, name in enumerate(plan.inputs):
+                hit = next(((dp, di) for dp in donor.plans for di, dn in enumerate(dp.inputs) if dn == name and dn), None)
+                if hit is None:
+                    return False
+                pairs.append((plan, i, hit[0], hit[1]))
+        done = []
+        for plan, i, dp, di in pairs:
+            if not plan.feed_shared(i, dp, di):
+                for q in done:
+                    q.reset()
+                return False
+            done.append(plan)
+        return True
 
     # -- context.rs:172-191
     def execute(self):

@@ -231,15 +231,17 @@ class StagedRun:
     flock-function/src/aws/actor.rs:425-543 without the Lambda invocations in between.  What the reference's
     `launcher/aws` differential tests do with real functions (flock/src/launcher/aws/mod.rs:423-468)."""
 
-    def __init__(self, gpu, stages: List[Stage], chunks: int = 1, instances: int = 0):
+    def __init__(self, gpu, stages: List[Stage], chunks: int = 1, instances: int = 0, share_sources: bool = False):
         """instances: function instances of a consuming stage.  0 = one per hash partition (the reference's default: the stage's
         concurrency equals its input partitioning); k > 0 = partition p goes to instance p % k, which feeds everything it is sent
         into ONE execute -- a GPU function hosting several partitions.  The union over the instances is the same multiset either
         way: the partitions are disjoint in the key the stage joins / groups on (what `HashJoinExec mode=Partitioned` and
         `FinalPartitioned` rest on), so a join or an aggregate over several partitions at once is the union of the per-partition
-        results."""
+        results.
+        share_sources: the stages that read base relations are fed ONE device copy of a relation between them (chunks = 1;
+        `ExecutionContext.share_data_sources`): q5's two subplans both scan `bid`."""
         from .runtime import ExecutionContext
-        self.stages, self.chunks, self.instances = stages, chunks, instances
+        self.stages, self.chunks, self.instances, self.share_sources = stages, chunks, instances, share_sources
         self.ctxs = [ExecutionContext([st.plan], name=f"stage-{i}", gpu=gpu) for i, st in enumerate(stages)]
 
     def close(self):
@@ -250,7 +252,23 @@ class StagedRun:
         """relations: {name: RecordBatch} of the base relations (one window).  Returns the root stage's batches."""
         from .runtime import collect
         outputs = {}
+        base = [i for i, st in enumerate(self.stages) if any(j is None for j in st.inputs)]
+        if self.share_sources and self.chunks == 1 and len(base) > 1:
+            # one upload per relation: the first source stage is fed, the others read its device copy; all execute before any cleans
+            src = [[[rb]] for rb in relations.values()]
+            donor = self.ctxs[base[0]]
+            donor.feed_data_sources(src)
+            for i in base[1:]:
+                if not self.ctxs[i].share_data_sources(donor):
+                    self.ctxs[i].feed_data_sources(src)
+            for i in base:
+                ctx = self.ctxs[i]
+                outputs[i] = [p for p in ctx.execute_partitioned()[0]] if self.stages[i].is_shuffling else [ctx.execute()[0]]
+            for i in reversed(base):
+                self.ctxs[i].clean_data_sources()
         for i, (st, ctx) in enumerate(zip(self.stages, self.ctxs)):
+            if i in outputs:
+                continue
             feeders = [j for j in st.inputs if j is not None]
             invocations = []
             if any(j is None for j in st.inputs):

@@ -109,6 +109,15 @@ int flockgpu_plan_output_partitions(const flockgpu_plan *plan);
 int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema,
                        const struct ArrowArray *const *batches, int n_batches);
 
+/* One upload for several plans hosted by one process: leaf `input` of `plan` reads the relation that `donor`'s leaf
+ * `donor_input` was fed, in place (no copy; both plans must have been created on the same flockgpu_ctx, whose stream orders
+ * the donor's transfers before this plan's kernels).  The reference feeds every function its own copy of the source
+ * payload (flock-function/src/aws/actor.rs:54-79); two stage plans that scan the same relation -- q5's two subplans both
+ * start at `bid` (playground/src/distributed_plan/nexmark/q5.dag) -- hosted by one GPU need the 4 B x bids on the device
+ * once.  Valid until `donor` is fed again or reset: execute this plan first.  FLOCKGPU_ERR_UNSUPPORTED (nothing changed,
+ * feed the plan its own copy) when the donor does not hold a column this plan reads, or dropped rows with NULLs. */
+int flockgpu_plan_feed_shared(flockgpu_plan *plan, int input, const flockgpu_plan *donor, int donor_input);
+
 /* execute(): runs the plan on everything fed so far as ONE window and exports one RecordBatch. */
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch);
 /* execute_partitioned(): `out_batches` has room for `capacity` record batches; *n_partitions of them are filled: the

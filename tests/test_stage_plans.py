@@ -229,19 +229,59 @@ def test_staged_execution_equals_whole_plan_equals_oracle(gpu, rule, q, seed, ep
 @pytest.mark.parametrize("q,seed,eps,n", [(3, 3, 50_000, 150_000), (5, 5, 20_000, 100_000), (8, 8, 50_000, 200_000)])
 def test_one_function_instance_may_host_several_partitions(gpu, q, seed, eps, n):
     """`StagedRun(instances=k)`: partition p of a shuffle goes to instance p % k of the consuming stage, which feeds all it gets
-    into one execute.  Same rows as one instance per partition (and as the oracle) for k = 1 and for a k that does not divide 8."""
+    into one execute.  Same rows as one instance per partition (and as the oracle) for k = 1 and for a k that does not divide 8;
+    and with the source stages sharing one device copy of a relation (`share_sources`: q5's two subplans both scan `bid`)."""
     from flock_amd import stages as S
     relations, host = _relations(seed, eps, n)
     want = _oracle_rows(q, host)
     assert len(want) > 0
-    for k in (0, 1, 3):
-        run = S.StagedRun(gpu, S.build_query_dag(_plan(q)), instances=k)
+    for k, share in ((0, False), (1, False), (3, False), (1, True)):
+        run = S.StagedRun(gpu, S.build_query_dag(_plan(q)), instances=k, share_sources=share)
         try:
             src = {name: relations[name] for name in (["bid"] if q == 5 else (["person", "auction"] if q == 8 else ["auction", "person"]))}
-            assert _rows(run.run(src)) == want, k
-            assert _rows(run.run(src)) == want, k     # the plans are reusable: a second window through the same instances
+            assert _rows(run.run(src)) == want, (k, share)
+            assert _rows(run.run(src)) == want, (k, share)     # the plans are reusable: a second window through the same instances
         finally:
             run.close()
+
+
+@pytest.mark.gpu
+def test_two_plans_read_one_upload(gpu):
+    """flockgpu_plan_feed_shared: q5's stage plans both scan `bid.auction`; the second reads the first one's device copy.  A plan
+    that reads a column the donor never uploaded is refused (nothing changes, it is fed its own copy), a shared leaf cannot be
+    appended to, and after the donor's next window the borrower sees the new rows only through a new share."""
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd import stages as S
+    from flock_amd.runtime import ExecutionContext
+    relations, host = _relations(5, 20_000, 100_000)
+    st = S.build_query_dag(_plan(5))
+    a, b = ExecutionContext([st[0].plan], gpu=gpu), ExecutionContext([st[1].plan], gpu=gpu)
+    wants_price = ExecutionContext([_plan(2)], gpu=gpu)          # q2 reads bid.auction AND bid.price
+    try:
+        src = [[[relations["bid"]]]]
+        b.feed_data_sources(src)
+        own = _rows(x for part in b.execute_partitioned()[0] for x in part)
+        b.clean_data_sources()
+        a.feed_data_sources(src)
+        assert b.share_data_sources(a)
+        with pytest.raises(FlockGpuError) as e:                  # no appending to a relation that is not this plan's
+            b.plans[0].feed(0, [relations["bid"]])
+        assert e.value.code == _ffi.ERR_INVALID
+        assert not wants_price.share_data_sources(a)             # the donor uploaded `auction` only
+        shared = _rows(x for part in b.execute_partitioned()[0] for x in part)
+        assert shared == own and len(own) > 0
+        a.clean_data_sources()
+        b.clean_data_sources()
+        half = relations["bid"].slice(0, 50_000)                 # the next window: fewer rows
+        a.feed_data_sources([[[half]]])
+        assert b.share_data_sources(a)
+        small = sum(x.num_rows for part in b.execute_partitioned()[0] for x in part)
+        b.clean_data_sources()
+        b.feed_data_sources([[[half]]])
+        assert small == sum(x.num_rows for part in b.execute_partitioned()[0] for x in part) and 0 < small < len(own)
+    finally:
+        for c in (a, b, wants_price):
+            c.close()
 
 
 @pytest.mark.gpu
