@@ -11,11 +11,13 @@ q5 hot-items over 1.0e9 synthetic bids (1087 s x 1e6 events/s, Hopping(10 s, 5 s
 CPU leg.  q2 / q8 (configs[1], [4]), q3 at 1e9 events, the "next" rows, a PCIe-inclusive q5 and a plan-level
 `collect` run are in "also"; "exchange_1rank" shows what the in-library exchange costs over the plain operators.
 
-N > 1 (`torchrun ... bench.py --gpus N`, or plain `python bench.py --gpus N`, which starts the N ranks itself): north_star's configuration -- the SAME 1e9 bids in total, every window striped
-over the N ranks, q5.dag's Partial COUNT -> hash repartition of the groups (RCCL send / recv inside libflockgpu) ->
-FinalPartitioned COUNT / MAX / join -> all-reduce(MAX): "scaling": "strong", value = 1e9 bids / the slowest rank's
-time.  "also" then carries q8 / q3 key-partitioned the same way and the window-sharded q5 (every rank its own slice of
-the stream, no data-path collective: "weak").  `--mode windows` makes the window-sharded job the headline instead.
+N > 1 (`torchrun ... bench.py --gpus N`, or plain `python bench.py --gpus N`, which starts the N ranks itself): the SAME job on
+every rank -- its own 1e9-bid slice of the stream, whole windows, no data-path collective: "scaling": "weak", value = N x 1e9
+bids / the slowest rank's time (NEXMark windows are independent units: this is how the path shards).  Behind it, under a
+watchdog, north_star's key-partitioned configuration (BASELINE.json configs[3]) -- 1e9 bids in total, every window striped over
+the N ranks, q5.dag's Partial COUNT -> hash repartition of the groups (RCCL send / recv inside libflockgpu) -> FinalPartitioned
+COUNT / MAX / join -> all-reduce(MAX) -- reported as `exchange` ("strong") with its per-phase timeline, or as `exchange_error`.
+"also" then carries q8 / q3 key-partitioned the same way.  `--mode exchange` makes the exchange the headline instead.
 
 roofline: dominant kernel's ALGORITHMIC bytes / its average launch duration measured
 with HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md);
@@ -72,7 +74,7 @@ def parse():
     ap.add_argument("--eps", type=int, default=1_000_000)
     ap.add_argument("--mode", choices=["auto", "windows", "exchange"], default="auto",
                     help="windows: every rank owns whole windows (no collective); exchange: hash repartition + all-to-all "
-                         "inside libflockgpu; auto = windows at N = 1, exchange at N > 1")
+                         "inside libflockgpu as the headline; auto = windows, with the exchange attached as `exchange` at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
     ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
@@ -1022,6 +1024,11 @@ def final_line(out):
     for k in ("exchange_error", "exchange_phases_ms"):
         if out.get(k):
             line[k] = out[k] if not isinstance(out[k], str) else out[k][:300]
+    ex = out.get("exchange")
+    if isinstance(ex, dict):   # N > 1: the same windows striped over the ranks, hash repartition + RCCL all-to-all ("strong": total rows fixed)
+        line["exchange"] = {"value": ex.get("value"), "ms_per_step": ex.get("ms_per_step"), "scaling": ex.get("scaling"),
+                            "input_rows_all_gpus": ex.get("input_rows_all_gpus"), "transport": ex.get("transport"), "ranks": ex.get("ranks"),
+                            "phases_ms": ex.get("phases_ms"), "roofline_frac": (ex.get("roofline") or {}).get("frac")}
     ws = out.get("window_sharded")
     if isinstance(ws, dict):   # N > 1: the same ranks without the exchange (every rank its own slice of the stream, "weak")
         line["window_sharded"] = {"value": ws.get("value"), "ms_per_step": ws.get("ms_per_step"), "scaling": ws.get("scaling"),
@@ -1115,7 +1122,10 @@ def main():
         from flock_amd import GpuContext
         print(json.dumps(general_entry(GpuContext(local), args.only_general, args.eps, max(args.steps, 3))))
         return
-    mode = args.mode if args.mode != "auto" else ("exchange" if world > 1 else "windows")
+    # auto: the window-sharded job is the headline at every N (the same per-GPU workload as N = 1, "weak": what the driver's scaling
+    # curve compares); at N > 1 the key-partitioned exchange of north_star / configs[3] runs behind it and is reported as `exchange`
+    mode = args.mode if args.mode != "auto" else "windows"
+    attach_exchange = args.mode == "auto" and world > 1 and args.query in (3, 5, 8)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -1235,6 +1245,33 @@ def main():
         out = windows_headline(args.steps, args.warmup, world == 1 and not args.no_cpu)
         if out is not None and comm_error:
             out["exchange_error"] = comm_error
+    if attach_exchange:
+        # north_star's multi-GPU configuration (BASELINE.json configs[3]): the SAME windows, every one striped over the ranks, Partial ->
+        # hash repartition (RCCL send / recv inside libflockgpu) -> Final.  Its ncclSend / ncclRecv pairs between different devices meet
+        # real hardware here first, so it runs AFTER the headline is safe and under a watchdog: an error is reported as
+        # `exchange_error`; a hang (a collective that never returns cannot be cancelled from inside) makes every rank print-and-leave.
+        import threading
+
+        def exchange_hung():
+            if rank == 0 and out is not None:
+                out["exchange_error"] = f"watchdog: the key-partitioned exchange did not finish within {hang_s:.0f} s"
+                print(final_line(out), flush=True)
+            os._exit(0)
+        hang_s = float(os.environ.get("FLOCK_BENCH_EXCHANGE_TIMEOUT", "300"))
+        dog = threading.Timer(hang_s, exchange_hung)
+        dog.daemon = True
+        dog.start()
+        try:
+            comm = make_comm()
+            head = exchange_entry(ctx, comm, q, seconds, args.eps, args.steps, args.warmup, rank, world, barrier, reduce_max_sum)
+            if rank == 0 and out is not None:
+                out["exchange"] = dict(head, collective={"library": "RCCL (ncclSend / ncclRecv groups inside libflockgpu)", "ranks": head["ranks"],
+                                                         "transport": head["transport"]})
+        except Exception as e:
+            comm_error = repr(e)
+            if rank == 0 and out is not None:
+                out["exchange_error"] = comm_error
+        dog.cancel()
 
     steps2 = max(args.steps, 10)   # the side entries' steps are 0.1-5 ms: ten of them cost nothing and average the host's turnaround out
     # ---- N = 1: the other BASELINE configs; q3 (named by the metric) at top level
@@ -1308,7 +1345,7 @@ def main():
         try:
             if comm is not None and not comm_error:
                 for label, q2 in (("q8_exchange", 8), ("q3_exchange", 3), ("q5_exchange", 5)):
-                    if q2 == q and mode == "exchange":
+                    if q2 == q and (mode == "exchange" or attach_exchange):
                         continue
                     try:
                         also[label] = exchange_entry(ctx, comm, q2, 1000 if q2 == 3 else DEFAULT_SECONDS[q2], args.eps, steps2, 1, rank, world, barrier,

@@ -19,7 +19,7 @@ def test_defaults_are_one_gpu_and_a_few_steps(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert a.gpus == 1 and 1 <= a.steps <= 20 and 0 <= a.warmup <= 10 and a.query == 5 and a.mode == "auto"      # auto: window-sharded at N = 1, key-partitioned exchange at N > 1
+    assert a.gpus == 1 and 1 <= a.steps <= 20 and 0 <= a.warmup <= 10 and a.query == 5 and a.mode == "auto"      # auto: window-sharded headline at every N; at N > 1 the key-partitioned exchange rides along as `exchange`
     assert bench.DEFAULT_SECONDS[5] * a.eps * 46 // 50 >= 1_000_000_000          # the headline config: 1e9 bids
 
 
@@ -81,6 +81,26 @@ def test_last_line_is_short_and_carries_roofline_and_cpu_baseline():
     fat["also"].update({f"more_{i}": dict(fat["q3"]) for i in range(400)})
     line = bench.final_line(fat)
     assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] > 0
+
+
+def test_n_ranks_line_keeps_the_weak_headline_and_carries_the_exchange():
+    """N > 1: the headline is the same per-GPU job as N = 1 ("weak", what a scaling curve compares); the key-partitioned exchange of
+    north_star is its own object with "strong" and the phase timeline -- or an `exchange_error` string."""
+    import json
+    import bench
+    out = _fat_out()
+    out["n_gpus"] = 8
+    out["exchange"] = {"value": 3.1e12, "unit": "rows/s", "scaling": "strong", "ms_per_step": 0.32, "input_rows_all_gpus": 998200000, "ranks": 8, "transport": "rccl",
+                       "phases_ms": {"partial": 0.11, "partition+take": 0.08, "counts": 0.01, "all_to_all+regroup": 0.05, "final": 0.07}, "roofline": {"frac": 0.55},
+                       "kernels_ms_rank0": {f"k{i}": 0.1 for i in range(40)}, "workload": "w" * 200}
+    d = json.loads(bench.final_line(out))
+    assert d["scaling"] == "weak" and d["n_gpus"] == 8 and d["roofline"]["frac"] <= 1
+    assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] == 3.1e12 and d["exchange"]["phases_ms"]["final"] == 0.07
+    assert "kernels_ms_rank0" not in d["exchange"] and len(bench.final_line(out)) < 4096
+    out.pop("exchange")
+    out["exchange_error"] = "RuntimeError('ncclCommInitRank: unhandled system error')" + "x" * 1000
+    d = json.loads(bench.final_line(out))
+    assert d["exchange_error"].startswith("RuntimeError") and len(d["exchange_error"]) <= 300 and d["value"] == 9.8e11
 
 
 def test_exchange_mode_bills_the_kernels_that_read_the_raw_rows():
@@ -177,3 +197,24 @@ def test_bench_prints_one_short_line_on_the_gpu(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-also", "--no-cpu"],
                        capture_output=True, text=True, timeout=300, env={k: v for k, v in env.items() if k != "WORLD_SIZE"})
     assert p.returncode != 0 and "{" not in p.stdout
+
+
+@__import__("pytest").mark.gpu
+def test_two_ranks_on_one_gpu_keep_the_headline_when_the_exchange_cannot_start(tmp_path):
+    """`--gpus 2` with both ranks on the one visible device (FLOCK_BENCH_SHARED_GPU, gloo for the barrier): RCCL refuses two ranks on one
+    device, so the exchange cannot start -- the line must still be the window-sharded headline of two ranks, with `exchange_error`
+    (or, should a transport accept it, an `exchange` object)."""
+    import json
+    import subprocess
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, FLOCK_BENCH_ALSO=str(tmp_path / "also.json"),
+               FLOCK_BENCH_SHARED_GPU="1", FLOCK_BENCH_EXCHANGE_TIMEOUT="90", FLOCK_BENCH_SPAWN_TIMEOUT="400")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--seconds", "60", "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
+    assert len(last) < 4096
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"].startswith("window-sharded x2")
+    assert ("exchange_error" in d) != ("exchange" in d)
+    if "exchange" in d:
+        assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] > 0
