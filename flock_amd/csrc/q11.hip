@@ -77,6 +77,16 @@ struct CutRows {  // the nine sorted rows around a thread's eight boundaries
 // (j0 is a multiple of 8), row j0-1 from the lane below (lane 0 reads it)
 __device__ __forceinline__ void load_cut_rows(const int32_t *__restrict__ keys, const int64_t *__restrict__ ts_s,
                                               const int32_t *__restrict__ ep_s, int64_t n, int64_t j0, CutRows &c) {
+    // lane 0's row j0 - 1 is asked for FIRST, so that it is in flight together with the rows below instead of after the shuffles
+    // (a second memory round trip per workgroup of a kernel that makes one pass over 2048 boundaries and leaves)
+    int32_t k_prev = 0, e_prev = 0;
+    int64_t t_prev = 0;
+    if (lane_id() == 0) {
+        const int64_t r = j0 > 0 ? (j0 - 1 < n ? j0 - 1 : n - 1) : 0;
+        k_prev = keys[r];
+        e_prev = ep_s[r];
+        t_prev = ts_s[r];
+    }
     if (j0 + kCutItems <= n) {
         const int4 k0 = *reinterpret_cast<const int4 *>(keys + j0), k1 = *reinterpret_cast<const int4 *>(keys + j0 + 4);
         const int4 e0 = *reinterpret_cast<const int4 *>(ep_s + j0), e1 = *reinterpret_cast<const int4 *>(ep_s + j0 + 4);
@@ -103,16 +113,10 @@ __device__ __forceinline__ void load_cut_rows(const int32_t *__restrict__ keys, 
     // every lane of the wave executes the shuffles (j0 <= n for the whole wave or clamped rows above)
     const int32_t pk = __shfl_up(c.key[kCutItems], 1, 64), pe = __shfl_up(c.ep[kCutItems], 1, 64);
     const int64_t pt = __shfl_up(c.ts[kCutItems], 1, 64);
-    if (lane_id() == 0) {
-        const int64_t r = j0 > 0 ? j0 - 1 : 0;
-        c.key[0] = keys[r];
-        c.ep[0] = ep_s[r];
-        c.ts[0] = ts_s[r];
-    } else {
-        c.key[0] = pk;
-        c.ep[0] = pe;
-        c.ts[0] = pt;
-    }
+    const bool first = lane_id() == 0;
+    c.key[0] = first ? k_prev : pk;
+    c.ep[0] = first ? e_prev : pe;
+    c.ts[0] = first ? t_prev : pt;
 }
 
 __device__ __forceinline__ uint32_t cut_mask(const CutRows &c, int64_t n, int64_t j0, const SessionParams &p) {
