@@ -296,6 +296,15 @@ constexpr int kMaxUtf8Multi = 4;
 constexpr int kStageBytes = 18 * 1024;  // LDS staging buffer of the emit kernel: 18 B per value on average, 8 workgroups
                                         // per CU (tiles beyond it copy directly, byte by byte)
 
+// src_off[r] and src_off[r + 1] through ONE 8-byte load (dword-aligned, which is all the hardware asks of a global load): with one row per
+// lane every load instruction of a wave touches up to 64 cache lines, and the texture path takes them one line per cycle -- the Utf8 take is
+// bound by its count of divergent load instructions (six per value before: two offsets, four dwords of bytes), not by bytes.
+__device__ __forceinline__ int2 load_off_pair(const int32_t *__restrict__ src_off, int32_t r) {
+    int2 v;
+    __builtin_memcpy(&v, src_off + r, 8);
+    return v;
+}
+
 // d_n (may be null): the row list's length when only the device knows it yet; n is then an upper bound.
 __global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restrict__ src_off,
                                                           const int32_t *__restrict__ rows, int64_t n,
@@ -306,8 +315,8 @@ __global__ __launch_bounds__(kBlock) void utf8_len_kernel(const int32_t *__restr
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k)
         if (i0 + k * kBlock < n) {
-            const int32_t r = rows[i0 + k * kBlock];
-            mine += (uint32_t)(src_off[r + 1] - src_off[r]);
+            const int2 o = load_off_pair(src_off, rows[i0 + k * kBlock]);
+            mine += (uint32_t)(o.y - o.x);
         }
     const uint32_t incl = wave_incl_scan_u32(mine);
     if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
@@ -337,7 +346,10 @@ __global__ __launch_bounds__(kBlock) void utf8_len_multi_kernel(Utf8Cols cols, c
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < kLenItems; ++k)
-            if (r[k] >= 0) mine += (uint32_t)(cols.src_off[c][r[k] + 1] - cols.src_off[c][r[k]]);
+            if (r[k] >= 0) {
+                const int2 o = load_off_pair(cols.src_off[c], r[k]);
+                mine += (uint32_t)(o.y - o.x);
+            }
         const uint32_t incl = wave_incl_scan_u32(mine);
         if (lane_id() == 63) counts[((size_t)c * tiles_stride + blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
     }
@@ -365,9 +377,9 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
         b[k] = 0;
         len[k] = 0;
         if (i0 + k * kBlock < n) {
-            const int32_t r = rows[i0 + k * kBlock];
-            b[k] = src_off[r];
-            len[k] = (uint32_t)(src_off[r + 1] - b[k]);
+            const int2 o = load_off_pair(src_off, rows[i0 + k * kBlock]);
+            b[k] = o.x;
+            len[k] = (uint32_t)(o.y - o.x);
         }
         const uint32_t incl = wave_incl_scan_u32(len[k]);
         excl[k] = incl - len[k];
@@ -391,36 +403,43 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
     if (tile_bytes == 0) return;
     const uint32_t phase = (uint32_t)(base & 15);  // LDS byte i holds output byte (base - phase) + i
     const bool staged = phase + tile_bytes <= (uint32_t)kStageBytes;  // block-uniform
-    // The source is read through aligned 4-byte words (a string starts at any byte): the first four words of
-    // every value are requested together, before any of them is used -- one memory round trip for the whole
-    // tile instead of one per word.  (A word index is clamped to the string's last word: no read past its end.)
-    uint32_t w4[kLenItems][4];
+    // The first 16 bytes of every value through ONE or TWO 16-byte ALIGNED loads (a string starts at any byte), all of them requested
+    // together, before any is used: one memory round trip for the whole tile.  An aligned 16-byte chunk that holds at least one byte
+    // of the value never crosses a page, so nothing is read that could fault; the second chunk is asked for only by the lanes whose
+    // head runs into it.  (Four dword loads per value before: twice to four times the divergent load instructions.)
+    uint4 c0[kLenItems], c1[kLenItems];
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
         const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + (uint32_t)b[k];
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3));
-        const uint32_t last = len[k] ? (uint32_t)(((addr & 3) + len[k] - 1) >> 2) : 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w4[k][i] = len[k] ? w[min((uint32_t)i, last)] : 0u;
+        const uint4 *q = reinterpret_cast<const uint4 *>(addr & ~uintptr_t(15));
+        const uint32_t o = (uint32_t)(addr & 15), head_len = len[k] < 16u ? len[k] : 16u;
+        c0[k] = make_uint4(0, 0, 0, 0);
+        c1[k] = make_uint4(0, 0, 0, 0);
+        if (len[k]) c0[k] = q[0];
+        if (o + head_len > 16u) c1[k] = q[1];
     }
 #pragma unroll
     for (int k = 0; k < kLenItems; ++k) {
         if (len[k] == 0) continue;
         const uintptr_t addr = reinterpret_cast<uintptr_t>(src) + (uint32_t)b[k];
-        const uint32_t sh = (uint32_t)(addr & 3) * 8;
-        // bytes 0..12 of the string, realigned: d[i] = bytes 4i .. 4i+3
+        const uint32_t o = (uint32_t)(addr & 15), qd = o >> 2, sh = (o & 3) * 8;
+        // bytes 0..15 of the string, realigned: d[i] = bytes 4i .. 4i+3 = dwords qd + i, qd + i + 1 of the 32 loaded bytes, shifted
+        const uint32_t W[9] = {c0[k].x, c0[k].y, c0[k].z, c0[k].w, c1[k].x, c1[k].y, c1[k].z, c1[k].w, 0u};
+        uint32_t V[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) V[j] = qd == 0 ? W[j] : qd == 1 ? W[j + 1] : qd == 2 ? W[j + 2] : W[j + 3];
         uint32_t d[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) d[i] = __funnelshift_r(w4[k][i], w4[k][i + 1], sh);
-        d[3] = w4[k][3] >> sh;
+        for (int i = 0; i < 4; ++i) d[i] = __funnelshift_r(V[i], V[i + 1], sh);
         uint8_t *dst = staged ? s_stage + phase + excl[k] : out + base + excl[k];
-        const uint32_t head = 16 - (sh >> 3);  // bytes available from the four words
+        const uint32_t head = 16;  // bytes in d[]
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if ((uint32_t)c < len[k] && (uint32_t)c < head) dst[c] = (uint8_t)(d[c >> 2] >> (8 * (c & 3)));
-        if (len[k] > head) {  // long string: the rest word by word
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(addr & ~uintptr_t(3)) + 4;
-            uint32_t done = head, cur = 0, have = 0;
+            if ((uint32_t)c < len[k]) dst[c] = (uint8_t)(d[c >> 2] >> (8 * (c & 3)));
+        if (len[k] > head) {  // long string: the rest word by word, from the first word that holds byte 16 on
+            const uintptr_t a16 = addr + 16;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(a16 & ~uintptr_t(3));
+            uint32_t done = head, cur = *w++ >> (8 * (uint32_t)(a16 & 3)), have = 4 - (uint32_t)(a16 & 3);
             while (done < len[k]) {
                 if (have == 0) {
                     cur = *w++;
