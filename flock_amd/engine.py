@@ -490,10 +490,22 @@ class GpuContext:
         self._check(self._lib.flockgpu_q5_hot_items(self._h, C.byref(b), C.byref(w), C.byref(r)))
         return Q5Out(self, r, windows.n_windows)
 
-    def json_lines_decode(self, text, fields):
+    def _device_view(self, ptr, n, dtype):
+        """A torch tensor over `n` elements of library-owned device memory at `ptr` (no copy; __cuda_array_interface__)."""
+        torch = _torch()
+        if not n or not ptr:
+            return torch.empty(0, dtype=dtype, device=f"cuda:{self.device}")
+        typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+
+        class _Span:
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_Span(), device=f"cuda:{self.device}")
+
+    def json_lines_decode(self, text, fields, borrow=False):
         """Newline-delimited JSON (uint8 device tensor) -> columns: `fields` = [(name, "int32" | "int64" | "utf8")].
         Returns {name: int32 / int64 device tensor | DeviceUtf8} and the row count (`event_bytes_to_batch`,
-        flock/src/transmute.rs:255-266, on the device)."""
+        flock/src/transmute.rs:255-266, on the device).  borrow: the tensors are views of the library's own result columns
+        (what the C ABI hands out: valid until the next call on this context) instead of copies of them."""
         torch = _torch()
         kinds = {"int32": _ffi.JSON_INT32, "int64": _ffi.JSON_INT64, "utf8": _ffi.JSON_UTF8}
         spec = (_ffi.JsonField * len(fields))(*[_ffi.JsonField(n.encode(), kinds[t]) for n, t in fields])
@@ -501,6 +513,13 @@ class GpuContext:
         rows = C.c_int64(0)
         self._check(self._lib.flockgpu_json_lines_decode(self._h, text.data_ptr(), text.numel(), spec, len(fields), cols, C.byref(rows)))
         n, dev, out = rows.value, f"cuda:{self.device}", {}
+        if borrow:
+            for (name, t), c in zip(fields, cols):
+                if t == "utf8":
+                    out[name] = DeviceUtf8(self._device_view(c.utf8.offsets, n + 1, torch.int32), self._device_view(c.utf8.data, int(c.utf8_bytes), torch.uint8))
+                else:
+                    out[name] = self._device_view(c.values, n, torch.int32 if t == "int32" else torch.int64)
+            return out, n
         for (name, t), c in zip(fields, cols):
             if t == "utf8":
                 off = torch.empty(n + 1, dtype=torch.int32, device=dev)

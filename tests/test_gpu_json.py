@@ -53,6 +53,10 @@ def test_generated_relations(ctx, relation, n_events):
     got2, n2 = event_bytes_to_columns(ctx, _dev_bytes(text[:-1]), relation)
     assert n2 == n
     _check(got2, cols, SCHEMAS[relation], n)
+    # the library's own result columns, viewed in place (valid until the next call on the context): the same values
+    got3, n3 = ctx.json_lines_decode(_dev_bytes(text), [(name, t) for name, t in SCHEMAS[relation]], borrow=True)
+    assert n3 == n
+    _check(got3, cols, SCHEMAS[relation], n)
 
 
 def test_free_form_objects_and_escapes(ctx):

@@ -30,9 +30,13 @@ for q, kern in ROWS:
         p = os.path.join(dst, f"{q}_pmc_{c}.csv")
         if not os.path.exists(p):
             continue
+        tot, launches = 0.0, 0   # every instantiation of a template kernel, weighted by its launches (what bench.py's average is)
         for r in csv.DictReader(open(p)):
             if kern + "(" in r["kernel"] or kern + "<" in r["kernel"]:
-                vals[c] = float(r[f"avg_{c}_KB"])
+                tot += float(r[f"avg_{c}_KB"]) * int(r["launches"])
+                launches += int(r["launches"])
+        if launches:
+            vals[c] = tot / launches
     name = kern if not q.endswith(("_general", "_uniform")) and q not in ("q4", "q3_1e8") else f"{kern}@{q}"
     if q == "q3_1e8":
         name = "q3_probe_flag_kernel@1e8_events"   # (bench.py's label of both probe kernels)
