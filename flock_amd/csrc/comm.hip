@@ -53,6 +53,22 @@ struct LocalGroup {
 };
 
 constexpr int64_t kMaxPeerBytes = int64_t(1) << 30;  // RCCL transfers above 2 GiB per peer arrived corrupted (round 1): stay well below
+// (FLOCKGPU_COMM_MAX_PEER_BYTES lowers it: how the tests drive a relation through several rounds with ragged last pieces)
+static int64_t max_peer_bytes() {
+    static const int64_t v = [] {
+        const char *e = getenv("FLOCKGPU_COMM_MAX_PEER_BYTES");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 && x < kMaxPeerBytes ? (int64_t)x : kMaxPeerBytes;
+    }();
+    return v;
+}
+// Piece k of a (source, destination) pair of `bytes` bytes: [lo, hi).  Both ends of a pair know its size from the counts exchange, so
+// they walk the same pieces -- no agreement on a global round count is needed.
+static void peer_piece(int64_t bytes, uint64_t k, int64_t *lo, int64_t *hi) {
+    const int64_t cap = max_peer_bytes();
+    *lo = std::min<int64_t>(bytes, (int64_t)k * cap);
+    *hi = std::min<int64_t>(bytes, (int64_t)(k + 1) * cap);
+}
 
 }  // namespace
 
@@ -193,9 +209,15 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
                 rc = fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s, (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
                 break;
             }
-            if (bytes && !(skip_self && s == c->rank)) {
-                const hipError_t e = hipMemcpyAsync(r8 + recv_off[s], static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank], (size_t)bytes, hipMemcpyDefault, ctx->stream);
-                if (e != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: copy from rank %d failed: %s", s, hipGetErrorString(e));
+            if (bytes && !(skip_self && s == c->rank)) {   // in the pieces the RCCL transport would post (same arithmetic, tested here)
+                for (uint64_t k = 0;; ++k) {
+                    int64_t lo, hi;
+                    peer_piece(bytes, k, &lo, &hi);
+                    if (hi <= lo) break;
+                    const hipError_t e = hipMemcpyAsync(r8 + recv_off[s] + lo, static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank] + lo, (size_t)(hi - lo),
+                                                        hipMemcpyDefault, ctx->stream);
+                    if (e != hipSuccess) { rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: copy from rank %d failed: %s", s, hipGetErrorString(e)); break; }
+                }
             }
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == FLOCKGPU_OK) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: stream synchronisation after the all-to-all failed");
@@ -203,18 +225,17 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
         if (rc != FLOCKGPU_OK) return rc;
         return met ? FLOCKGPU_OK : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
     }
-    // rounds of at most kMaxPeerBytes per (source, destination) pair: both ends of a pair know its size from the counts
-    // exchange, so they post the same sequence of sends / receives for it -- no agreement on a global round count needed
+    // rounds of at most max_peer_bytes() per (source, destination) pair
     int64_t biggest = 0;
     for (int p = 0; p < n; ++p) biggest = std::max({biggest, send_off[p + 1] - send_off[p], recv_off[p + 1] - recv_off[p]});
-    const uint64_t rounds = (uint64_t)std::max<int64_t>(1, div_up(biggest, kMaxPeerBytes));
+    const uint64_t rounds = (uint64_t)std::max<int64_t>(1, div_up(biggest, max_peer_bytes()));
     for (uint64_t k = 0; k < rounds; ++k) {
         FG_NCCL(ctx, ncclGroupStart());
         for (int p = 0; p < n; ++p) {
             if (skip_self && p == c->rank) continue;
-            const int64_t sb = send_off[p + 1] - send_off[p], rb = recv_off[p + 1] - recv_off[p];
-            const int64_t s0 = std::min<int64_t>(sb, (int64_t)k * kMaxPeerBytes), s1 = std::min<int64_t>(sb, (int64_t)(k + 1) * kMaxPeerBytes);
-            const int64_t r0 = std::min<int64_t>(rb, (int64_t)k * kMaxPeerBytes), r1 = std::min<int64_t>(rb, (int64_t)(k + 1) * kMaxPeerBytes);
+            int64_t s0, s1, r0, r1;
+            peer_piece(send_off[p + 1] - send_off[p], k, &s0, &s1);
+            peer_piece(recv_off[p + 1] - recv_off[p], k, &r0, &r1);
             if (s1 > s0) FG_NCCL(ctx, ncclSend(s8 + send_off[p] + s0, (size_t)(s1 - s0), ncclUint8, p, c->nccl, ctx->stream));
             if (r1 > r0) FG_NCCL(ctx, ncclRecv(r8 + recv_off[p] + r0, (size_t)(r1 - r0), ncclUint8, p, c->nccl, ctx->stream));
         }
