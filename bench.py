@@ -891,6 +891,15 @@ def plan_stages(gpu, eps, steps):
             one.run(rel)
         t_one = (time.perf_counter() - t0) / steps
         one.close()
+        dev = StagedRun(gpu, build_query_dag(plan), share_sources=True, on_device=True)   # ... and the stages' results handed over in HBM
+        if sum(b.num_rows for b in dev.run(rel)) != n_whole:
+            raise RuntimeError(f"q{q}: the on-device staged run differs from the whole plan")
+        dev.run(rel)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dev.run(rel)
+        t_dev = (time.perf_counter() - t0) / steps
+        dev.close()
         gpu.profile_reset()      # the kernels' share: a second, bracketed pass (two event records per launch cost as much as these kernels)
         gpu.profile(True)
         for _ in range(steps):
@@ -901,6 +910,7 @@ def plan_stages(gpu, eps, steps):
         out[f"q{q}"] = {"input_rows": int(rows), "result_rows": int(n_whole), "whole_plan_ms": round(t_whole * 1e3, 3), "staged_ms": round(t_staged * 1e3, 3),
                         "staged_over_whole": round(t_staged / t_whole, 2), "stages": len(staged.stages), "collects_per_run": 2 + 8, "note": "the 8 invocations of the last stage run one after the other here; the reference runs them on 8 functions side by side",
                         "one_instance_ms": round(t_one * 1e3, 3), "one_instance_over_whole": round(t_one / t_whole, 2), "one_instance_collects_per_run": 3,
+                        "on_device_ms": round(t_dev * 1e3, 3), "on_device_over_whole": round(t_dev / t_whole, 2),
                         "staged_kernel_ms_per_run": round(sum(v["total_ms"] for v in stats.values()) / steps, 3),
                         "top_kernels_ms_per_run": {k: round(v["total_ms"] / steps, 3) for k, v in top}}
         whole.close()

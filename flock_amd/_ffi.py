@@ -204,6 +204,8 @@ SYMBOLS = {
     "flockgpu_plan_input_matches": (_i, [_vp, _i, _vp]),
     "flockgpu_plan_feed": (_i, [_vp, _i, _vp, C.POINTER(_vp), _i]),
     "flockgpu_plan_feed_shared": (_i, [_vp, _i, _vp, _i]),
+    "flockgpu_plan_execute_retain": (_i, [_vp, C.POINTER(C.c_int64)]),
+    "flockgpu_plan_feed_from": (_i, [_vp, _i, _vp]),
     "flockgpu_plan_execute": (_i, [_vp, _vp, _vp]),
     "flockgpu_plan_execute_partitioned": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i)]),
     "flockgpu_plan_explain": (_i, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

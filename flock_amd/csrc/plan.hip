@@ -131,6 +131,8 @@ struct flockgpu_plan {
     std::vector<CopyJob> jobs;   // the pageable copies of the feed in progress
     std::vector<CopyJob> runs;   // transfers of the feed in progress, merged while they stay contiguous (h2d)
     int64_t fed_bytes = 0;
+    Table retained;              // flockgpu_plan_execute_retain: the result, left on the device for the plans that consume it
+    bool has_retained = false;
 };
 
 namespace {
@@ -1752,6 +1754,7 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
     const Leaf &lf = plan->ir.leaves[(size_t)input];
     LeafData &ld = plan->leaves[(size_t)input];
     if (ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: input %d shares another plan's relation; reset the plan first", input);
+    plan->has_retained = false;
     std::vector<int> child(lf.schema.size(), -1);
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (!lf.needed[c]) continue;
@@ -1891,6 +1894,7 @@ int flockgpu_plan_reset(flockgpu_plan *plan) {
     // borrowed pinned buffers may still be read by the DMA engine: the caller is about to drop them
     if (plan->fed_bytes) (void)hipStreamSynchronize(plan->ctx->stream);
     plan->fed_bytes = 0;
+    plan->has_retained = false;   // (its columns may alias the leaves, and the arena buffers behind it are reused by the next execute)
     for (auto &ld : plan->leaves) {
         ld.rows = 0;
         ld.dropped = 0;
@@ -1930,6 +1934,60 @@ int flockgpu_plan_feed_shared(flockgpu_plan *plan, int input, const flockgpu_pla
     ld.rows = dd.rows;
     ld.borrowed = true;
     return FLOCKGPU_OK;   // same stream as the donor's copies: ordered behind them without a wait
+}
+
+int flockgpu_plan_execute_retain(flockgpu_plan *plan, int64_t *rows) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    plan->has_retained = false;
+    Exec ex{plan, ctx};
+    Table t;
+    // a root hash repartition is not computed: which partition a key lands in is unobservable once every partition is handed to
+    // the same consumer, and that is the only hand-over this call serves
+    FG_TRY(ex.exec(plan->ir.root.get(), &t));
+    const Node *root = plan->ir.root.get();
+    if (t.cols.size() != root->schema.size()) return fail(ctx, FLOCKGPU_ERR_HIP, "plan execute: %zu result columns for a schema of %zu", t.cols.size(), root->schema.size());
+    for (size_t c = 0; c < t.cols.size(); ++c)
+        if (!t.cols[c].present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: output column '%s' was not materialised", root->schema[c].name.c_str());
+    plan->retained = t;
+    plan->has_retained = true;
+    if (rows) *rows = t.rows;
+    return FLOCKGPU_OK;   // no host wait: the consumer's kernels follow on the same stream
+}
+
+int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan *producer) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (!producer || producer == plan || input < 0 || input >= (int)plan->ir.leaves.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: bad argument");
+    if (producer->ctx != ctx) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: the two plans live on different contexts (streams)");
+    if (!producer->has_retained) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: the producer holds no retained result (flockgpu_plan_execute_retain)");
+    const Leaf &lf = plan->ir.leaves[(size_t)input];
+    LeafData &ld = plan->leaves[(size_t)input];
+    if (ld.rows != 0 || ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: input %d already holds rows", input);
+    const std::vector<Field> &ps = producer->ir.root->schema;
+    const Table &t = producer->retained;
+    std::vector<int> from(lf.schema.size(), -1);
+    bool empty = false;   // a NULL the plan may drop (MAX over no rows): the relation is empty
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (!lf.needed[c]) continue;
+        for (size_t d = 0; d < ps.size(); ++d)
+            if (ps[d].name == lf.schema[c].name && ps[d].type == lf.schema[c].type) from[c] = (int)d;
+        if (from[c] < 0) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed_from: the producer's result has no column '%s' of type %s", lf.schema[c].name.c_str(), type_name(lf.schema[c]));
+        if (t.cols[(size_t)from[c]].c.all_null) {
+            if (!lf.null_droppable[c]) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed_from: column '%s' is NULL and would reach the output", lf.schema[c].name.c_str());
+            empty = true;
+        }
+    }
+    if (empty || t.rows == 0) return FLOCKGPU_OK;   // an unfed leaf is an empty relation
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (from[c] < 0) continue;
+        const DevColumn &col = t.cols[(size_t)from[c]].c;
+        ld.cols[c] = DevBuf{const_cast<void *>(col.values), const_cast<int32_t *>(col.offsets), col.bytes};
+    }
+    ld.rows = t.rows;
+    ld.borrowed = true;
+    return FLOCKGPU_OK;
 }
 
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch) {

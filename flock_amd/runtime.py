@@ -116,6 +116,20 @@ class _Plan:
         self.gpu._check(rc)
         return True
 
+    def execute_retain(self) -> int:
+        """Runs the plan and leaves the result on the device for `feed_from` of the plans that consume it; returns its row count."""
+        rows = C.c_int64(0)
+        self.gpu._check(self._lib.flockgpu_plan_execute_retain(self.h, C.byref(rows)))
+        return rows.value
+
+    def feed_from(self, i: int, producer: "_Plan") -> bool:
+        """Leaf i reads `producer`'s retained result in place.  False -- nothing changed -- when that result lacks a column the leaf reads."""
+        rc = self._lib.flockgpu_plan_feed_from(self.h, i, producer.h)
+        if rc == _ffi.ERR_UNSUPPORTED:
+            return False
+        self.gpu._check(rc)
+        return True
+
     def execute(self):
         pa = _pa()
         sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
@@ -188,6 +202,20 @@ class ExecutionContext:
                 return False
             done.append(plan)
         return True
+
+    def execute_retain(self):
+        """execute, with every plan's result left on the device (`_Plan.execute_retain`): [rows per plan]."""
+        return [plan.execute_retain() for plan in self.plans]
+
+    def feed_from(self, producers: Sequence["ExecutionContext"]):
+        """feed_data_sources from stages hosted on the same GPU context: every leaf takes the first remaining producer plan whose
+        retained result holds the columns it reads (matched by name and type, as compare_schema matches batches)."""
+        left = [p for ctx in producers for p in ctx.plans]
+        for plan in self.plans:
+            for i in range(len(plan.inputs)):
+                hit = next((p for p in left if plan.feed_from(i, p)), None)
+                if hit is not None:
+                    left.remove(hit)
 
     # -- context.rs:172-191
     def execute(self):

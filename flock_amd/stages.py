@@ -231,7 +231,7 @@ class StagedRun:
     flock-function/src/aws/actor.rs:425-543 without the Lambda invocations in between.  What the reference's
     `launcher/aws` differential tests do with real functions (flock/src/launcher/aws/mod.rs:423-468)."""
 
-    def __init__(self, gpu, stages: List[Stage], chunks: int = 1, instances: int = 0, share_sources: bool = False):
+    def __init__(self, gpu, stages: List[Stage], chunks: int = 1, instances: int = 0, share_sources: bool = False, on_device: bool = False):
         """instances: function instances of a consuming stage.  0 = one per hash partition (the reference's default: the stage's
         concurrency equals its input partitioning); k > 0 = partition p goes to instance p % k, which feeds everything it is sent
         into ONE execute -- a GPU function hosting several partitions.  The union over the instances is the same multiset either
@@ -239,9 +239,12 @@ class StagedRun:
         `FinalPartitioned` rest on), so a join or an aggregate over several partitions at once is the union of the per-partition
         results.
         share_sources: the stages that read base relations are fed ONE device copy of a relation between them (chunks = 1;
-        `ExecutionContext.share_data_sources`): q5's two subplans both scan `bid`."""
+        `ExecutionContext.share_data_sources`): q5's two subplans both scan `bid`.
+        on_device: one instance per stage, and a stage's result stays in HBM for the stages that consume it
+        (`flockgpu_plan_execute_retain` / `flockgpu_plan_feed_from`): only the base relations come from the host and only the last
+        stage's result goes back to it."""
         from .runtime import ExecutionContext
-        self.stages, self.chunks, self.instances, self.share_sources = stages, chunks, instances, share_sources
+        self.stages, self.chunks, self.instances, self.share_sources, self.on_device = stages, chunks, instances, share_sources, on_device
         self.ctxs = [ExecutionContext([st.plan], name=f"stage-{i}", gpu=gpu) for i, st in enumerate(stages)]
 
     def close(self):
@@ -251,6 +254,8 @@ class StagedRun:
     def run(self, relations):
         """relations: {name: RecordBatch} of the base relations (one window).  Returns the root stage's batches."""
         from .runtime import collect
+        if self.on_device:
+            return self._run_on_device(relations)
         outputs = {}
         base = [i for i, st in enumerate(self.stages) if any(j is None for j in st.inputs)]
         if self.share_sources and self.chunks == 1 and len(base) > 1:
@@ -297,3 +302,24 @@ class StagedRun:
                     result[0].extend(out[0])
             outputs[i] = result
         return [b for part in outputs[len(self.stages) - 1] for b in part]
+
+    def _run_on_device(self, relations):
+        src = [[[rb]] for rb in relations.values()]
+        last = len(self.stages) - 1
+        donor, out = None, None
+        try:
+            for i, (st, ctx) in enumerate(zip(self.stages, self.ctxs)):
+                if any(j is None for j in st.inputs):
+                    if donor is None or not (self.share_sources and ctx.share_data_sources(donor)):
+                        ctx.feed_data_sources(src)
+                        donor = donor or ctx
+                else:
+                    ctx.feed_from([self.ctxs[j] for j in st.inputs if j is not None])
+                if i == last:
+                    out = ctx.execute()[0]
+                else:
+                    ctx.execute_retain()
+        finally:
+            for ctx in reversed(self.ctxs):   # consumers first: a producer's buffers are only released once nothing reads them
+                ctx.clean_data_sources()
+        return out

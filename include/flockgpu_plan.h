@@ -126,6 +126,17 @@ int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, s
 int flockgpu_plan_execute_partitioned(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batches,
                                       int capacity, int *n_partitions);
 
+/* Stage-to-stage hand-over in HBM, for stage plans hosted by ONE process on one flockgpu_ctx (the reference's boundary between two
+ * stages is a network hop carrying Arrow Flight data, flock-function/src/aws/actor.rs:425-543; between two stages on one GPU it is a
+ * pointer).  execute_retain runs the plan like execute but leaves the result on the device instead of exporting it (*rows = its row
+ * count; a root hash repartition is skipped: which partition a key lands in is unobservable when every partition goes to the same
+ * consumer).  feed_from makes leaf `input` of `plan` read that result in place -- columns matched by name and type like
+ * flockgpu_plan_feed does; FLOCKGPU_ERR_UNSUPPORTED, nothing changed, when the result lacks a column the plan reads, so a host can
+ * try its producers in turn.  The result stays valid until the producer is fed, executed or reset again: execute the consumer first.
+ * No host wait in either call. */
+int flockgpu_plan_execute_retain(flockgpu_plan *plan, int64_t *rows);
+int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan *producer);
+
 /* clean_data_sources(): drops the inputs, keeps device arenas and hash-table sizing for the next invocation. */
 int flockgpu_plan_reset(flockgpu_plan *plan);
 

@@ -230,19 +230,53 @@ def test_staged_execution_equals_whole_plan_equals_oracle(gpu, rule, q, seed, ep
 def test_one_function_instance_may_host_several_partitions(gpu, q, seed, eps, n):
     """`StagedRun(instances=k)`: partition p of a shuffle goes to instance p % k of the consuming stage, which feeds all it gets
     into one execute.  Same rows as one instance per partition (and as the oracle) for k = 1 and for a k that does not divide 8;
-    and with the source stages sharing one device copy of a relation (`share_sources`: q5's two subplans both scan `bid`)."""
+    and with the source stages sharing one device copy of a relation (`share_sources`: q5's two subplans both scan `bid`); and with
+    the stages' results handed over in HBM (`on_device`: flockgpu_plan_execute_retain / flockgpu_plan_feed_from)."""
     from flock_amd import stages as S
     relations, host = _relations(seed, eps, n)
     want = _oracle_rows(q, host)
     assert len(want) > 0
-    for k, share in ((0, False), (1, False), (3, False), (1, True)):
-        run = S.StagedRun(gpu, S.build_query_dag(_plan(q)), instances=k, share_sources=share)
+    for k, share, dev in ((0, False, False), (1, False, False), (3, False, False), (1, True, False), (1, False, True), (1, True, True)):
+        run = S.StagedRun(gpu, S.build_query_dag(_plan(q)), instances=k, share_sources=share, on_device=dev)
         try:
             src = {name: relations[name] for name in (["bid"] if q == 5 else (["person", "auction"] if q == 8 else ["auction", "person"]))}
-            assert _rows(run.run(src)) == want, (k, share)
-            assert _rows(run.run(src)) == want, (k, share)     # the plans are reusable: a second window through the same instances
+            assert _rows(run.run(src)) == want, (k, share, dev)
+            assert _rows(run.run(src)) == want, (k, share, dev)     # the plans are reusable: a second window through the same instances
         finally:
             run.close()
+
+
+@pytest.mark.gpu
+def test_a_stage_reads_its_producers_results_on_the_device(gpu):
+    """flockgpu_plan_execute_retain / flockgpu_plan_feed_from on q3's three stage plans: the join stage finds each of its two inputs
+    among the producers by column names, a producer without a retained result or with the wrong columns is refused without a trace,
+    and a second window through the same plans gives the second window's rows."""
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd import stages as S
+    from flock_amd.runtime import ExecutionContext
+    st = S.build_query_dag(_plan(3))
+    persons, auctions, join = (ExecutionContext([x.plan], gpu=gpu) for x in st)
+    try:
+        for seed, n in ((3, 150_000), (4, 90_000)):
+            relations, host = _relations(seed, 50_000, n)
+            persons.feed_data_sources([[[relations["person"]]]])
+            auctions.feed_data_sources([[[relations["auction"]]]])
+            with pytest.raises(FlockGpuError) as e:                     # nothing retained yet
+                join.plans[0].feed_from(0, persons.plans[0])
+            assert e.value.code == _ffi.ERR_INVALID
+            assert persons.execute_retain()[0] > 0 and auctions.execute_retain()[0] > 0
+            assert not join.plans[0].feed_from(0, persons.plans[0]) or not join.plans[0].feed_from(1, persons.plans[0])   # one of the two leaves wants the auctions
+            join.clean_data_sources()
+            join.feed_from([persons, auctions])
+            got = _rows(join.execute()[0])
+            assert got == _oracle_rows(3, host) and len(got) > 0
+            for c in (join, auctions, persons):
+                c.clean_data_sources()
+            with pytest.raises(FlockGpuError):                          # a reset drops the retained result
+                join.plans[0].feed_from(0, persons.plans[0])
+    finally:
+        for c in (persons, auctions, join):
+            c.close()
 
 
 @pytest.mark.gpu
