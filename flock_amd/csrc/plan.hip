@@ -1281,7 +1281,37 @@ struct Exec {
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown node");
     }
 
+    // Final / FinalPartitioned directly over the Partial of the SAME plan (only a repartition in between): the Partial saw the
+    // whole input of this execute, so its output already holds every group exactly once and its state columns ARE the results
+    // (COUNT / SUM / MAX / MIN states have the result's type; AVG's (count, sum) state does not).  The stage plans stage.rs cuts keep
+    // Partial -> Hash repartition -> FinalPartitioned in one plan (q5.dag, q8.dag): a second hash pass over the groups for nothing.
+    bool final_is_identity(const Node *n, const Node **partial) const {
+        if (n->mode == "Partial" || n->group.empty()) return false;
+        const Node *c = n->in[0].get();
+        while (c->kind == NKind::Repartition) c = c->in[0].get();
+        if (c->kind != NKind::Aggregate || c->mode != "Partial" || c->group.size() != n->group.size() || c->aggs.size() != n->aggs.size() ||
+            c->schema.size() != n->schema.size())
+            return false;
+        for (size_t i = 0; i < n->group.size(); ++i)
+            if (n->group[i] != (int)i) return false;
+        for (size_t a = 0; a < n->aggs.size(); ++a)
+            if (n->aggs[a].fn != c->aggs[a].fn || n->aggs[a].fn == "avg" || n->aggs[a].arg != (int)(n->group.size() + a)) return false;
+        for (size_t i = 0; i < n->schema.size(); ++i)
+            if (c->schema[i].type != n->schema[i].type) return false;
+        *partial = c;
+        return true;
+    }
+
     int exec_aggregate(const Node *n, Table *t) {
+        const Node *partial = nullptr;
+        if (final_is_identity(n, &partial)) {
+            FG_TRY(exec(partial, t));
+            for (size_t i = 0; i < n->schema.size() && i < t->cols.size(); ++i) {
+                t->cols[i].c.is_ts = n->schema[i].is_ts;
+                t->cols[i].c.nullable = n->schema[i].nullable;
+            }
+            return FLOCKGPU_OK;
+        }
         Table in;
         FG_TRY(exec(n->in[0].get(), &in));
         const bool is_final = n->mode != "Partial";
