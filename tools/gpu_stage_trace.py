@@ -9,6 +9,7 @@ from flock_amd import runtime as R
 from flock_amd.stages import StagedRun, build_query_dag
 
 gpu = GpuContext(0)
+ON_DEVICE = os.environ.get("TRACE_ON_DEVICE", "1") == "1"
 orig_collect = R.collect
 log = []
 def traced(ctx, src):
@@ -35,12 +36,25 @@ for q, seconds in ((3, 1), (8, 10), (5, 10)):
                "person": pa.record_batch([pa.array(p.p_id.cpu().numpy()), utf8(p.name, p.rows), utf8(p.city, p.rows), utf8(p.state, p.rows)], names=["p_id", "name", "city", "state"])}
         if q == 8:
             rel = {"person": rel["person"], "auction": rel["auction"]}
-    st = StagedRun(gpu, build_query_dag(plan), instances=1)
+    st = StagedRun(gpu, build_query_dag(plan), instances=1, share_sources=True, on_device=ON_DEVICE)
     for _ in range(3):
         st.run(rel)
     import flock_amd.stages as S
     R.collect = traced
     log.clear()
+    if ON_DEVICE:   # one bracket per stage: execute_retain / execute of every stage context
+        for ctx in st.ctxs:
+            for name in ("execute_retain", "execute"):
+                f = getattr(ctx, name)
+                def g(f=f, ctx=ctx, name=name):
+                    gpu.profile_reset(); gpu.profile(True)
+                    t0 = time.perf_counter()
+                    out = f()
+                    dt = time.perf_counter() - t0
+                    stt = gpu.profile_read(); gpu.profile(False)
+                    log.append((ctx.name + "." + name, dt, stt))
+                    return out
+                setattr(ctx, name, g)
     st.run(rel)
     R.collect = orig_collect
     print(f"== q{q}")
