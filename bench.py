@@ -919,7 +919,9 @@ def plan_stages(gpu, eps, steps):
     worst = max(v["staged_over_whole"] for v in out.values())
     rows_all = sum(v["input_rows"] for v in out.values())
     ms_all = sum(v["staged_ms"] for v in out.values())
-    return {"value": round(rows_all / (ms_all * 1e-3), 1), "unit": "rows/s", "ms_per_step": round(ms_all, 3), "worst_staged_over_whole": worst, **out,
+    return {"value": round(rows_all / (ms_all * 1e-3), 1), "unit": "rows/s", "ms_per_step": round(ms_all, 3), "worst_staged_over_whole": worst,
+            "worst_one_instance_over_whole": max(v["one_instance_over_whole"] for v in out.values()),
+            "worst_on_device_over_whole": max(v["on_device_over_whole"] for v in out.values()), **out,
             "note": "value = input rows of the three windows / the time of their three staged runs (host Arrow in and out of every stage)"}
 
 
