@@ -357,6 +357,7 @@ struct Builder {
                     if (a.fn == "avg") a.type = ColType::F64;
                     Field f;
                     f.nullable = true;
+                    f.is_ts = ts && (a.fn == "max" || a.fn == "min");   // MIN / MAX of a Timestamp column is a Timestamp (q11's start_time / end_time)
                     if (is_final) {
                         f.name = a.name;
                         f.type = a.type;

@@ -180,6 +180,24 @@ def q7():
                               (col("b_date_time", 3), "b_date_time")], out)
 
 
+def q11():
+    # benchmarks/src/nexmark/query/q11.sql over the bids of the session windows closed in an epoch (flock-function/src/aws/window/session.rs:
+    # 187-321 sends them; the plan below is what `physical_plan(q11.sql)` is for a DataFusion of this fork's vintage, in the dialect and
+    # two-phase aggregate shape of q5.dag): Projection <- FinalPartitioned <- Hash([bidder], 8) <- Partial <- RoundRobin <- MemoryExec
+    inp = [field("bidder", "Int32"), field("b_date_time", TS)]
+    names = ("COUNT(UInt8(1))", "MIN(bid.b_date_time)", "MAX(bid.b_date_time)")
+    aggs = [{"aggregate_expr": "count", "name": names[0], "data_type": "UInt64", "nullable": True, "expr": lit("UInt8", 1)},
+            {"aggregate_expr": "min", "name": names[1], "data_type": TS, "nullable": True, "expr": col("b_date_time", 1)},
+            {"aggregate_expr": "max", "name": names[2], "data_type": TS, "nullable": True, "expr": col("b_date_time", 1)}]
+    part = [field("bidder", "Int32"), field(names[0] + "[count]", "UInt64", True), field(names[1] + "[min]", TS, True), field(names[2] + "[max]", TS, True)]
+    fin = [field("bidder", "Int32"), field(names[0], "UInt64", True), field(names[1], TS, True), field(names[2], TS, True)]
+    grp = [(col("bidder", 0), "bidder")]
+    partial = agg(rr(memory(BID, [1, 3], "bid")), "Partial", grp, aggs, inp, part)
+    final = agg(coalesce(hashp(partial, [col("bidder", 0)])), "FinalPartitioned", grp, aggs, inp, fin)
+    out = [field("bidder", "Int32"), field("bid_count", "UInt64", True), field("start_time", TS, True), field("end_time", TS, True)]
+    return proj(final, [(col("bidder", 0), "bidder"), (col(names[0], 1), "bid_count"), (col(names[1], 2), "start_time"), (col(names[2], 3), "end_time")], out)
+
+
 def q13():
     # benchmarks/src/nexmark/query/q13.sql + q13_plan.fmt (SURVEY.md section 8(f) "next" query):
     # Projection [auction, bidder, price, b_date_time, value] <- HashJoin(auction = key)
@@ -316,7 +334,7 @@ def main():
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
-    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13), ("q4", q4), ("q9", q9), ("ysb", ysb)):
+    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13), ("q4", q4), ("q9", q9), ("q11", q11), ("ysb", ysb)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
