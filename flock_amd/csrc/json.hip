@@ -487,15 +487,183 @@ __device__ __forceinline__ bool parse_line_words(const uint8_t *s, int32_t s_bas
     return p + 1 == end && s[p] == '}';
 }
 
+// ---- any flat object, four and eight bytes at a time -------------------------------------------------------------------
+// What other writers produce (Python's json.dumps puts a space after ':' and ','; members come in any order): white space where JSON
+// allows it, the schema's members in ANY order, nothing else -- no unknown members, no escapes, no repeated keys (those lines go on to
+// parse_line, which also words the errors).  Same machinery as parse_line_words: dword-aligned LDS reads, SWAR searches, integers eight
+// digits per step; the key of a member is compared against every schema name as 64-bit words (the names come out of the kernel
+// arguments, wave-uniform).  The byte-wise general parser spends ~60 instructions per character on such lines.
+__device__ __forceinline__ uint64_t bytes_equal_flags(uint64_t x, uint32_t c) {   // 0x80 in every byte of x that equals c (exact)
+    const uint64_t v = x ^ (0x0101010101010101ull * c);
+    return ~(((v & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | v) & 0x8080808080808080ull;
+}
+// position of the first byte at or after p that is not JSON white space (end if there is none)
+__device__ __forceinline__ int32_t skip_ws_words(const uint8_t *s, int32_t p, int32_t end) {
+    while (p < end) {
+        const uint64_t x = lds_u64(s, p);
+        const uint64_t ws = bytes_equal_flags(x, ' ') | bytes_equal_flags(x, '\t') | bytes_equal_flags(x, '\r') | bytes_equal_flags(x, '\n');
+        const uint64_t other = ~ws & 0x8080808080808080ull;
+        if (other) return min(end, p + ((__ffsll((unsigned long long)other) - 1) >> 3));
+        p += 8;
+    }
+    return end;
+}
+
+__device__ bool parse_line_flex(const uint8_t *s, int32_t s_base, int32_t p, int32_t end, const JsonSpec &spec, const JsonOut &out, int64_t row) {
+    p -= s_base;
+    end -= s_base;
+    while (end > p && is_ws(s[end - 1])) --end;
+    p = skip_ws_words(s, p, end);
+    if (p >= end || s[p] != '{') return false;
+    p = skip_ws_words(s, p + 1, end);
+    uint32_t seen = 0;
+    for (int member = 0; member < spec.n; ++member) {   // one schema field per member, each once
+        // ---- "key"
+        if (p >= end || s[p] != '"') return false;
+        const int32_t kb = p + 1;
+        int32_t ke = kb;
+        for (;;) {
+            if (ke >= end) return false;
+            const uint64_t x = lds_u64(s, ke);
+            const uint64_t stop = bytes_equal_flags(x, '"') | bytes_equal_flags(x, '\\') | (((x - 0x2020202020202020ull) & ~x) & 0x8080808080808080ull);
+            if (stop) {
+                const int at = (__ffsll((unsigned long long)stop) - 1) >> 3;
+                ke += at;
+                if (((x >> (8 * at)) & 0xFFu) != '"') return false;   // an escape or a control character in a key
+                break;
+            }
+            ke += 8;
+        }
+        if (ke >= end) return false;
+        const int32_t klen = ke - kb;
+        if (klen <= 0 || klen >= kMaxName) return false;
+        uint64_t kw[kMaxName / 8];
+#pragma unroll
+        for (int j = 0; j < kMaxName / 8; ++j) {
+            const int32_t left = klen - 8 * j;
+            kw[j] = left <= 0 ? 0ull : lds_u64(s, kb + 8 * j) & (left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull);
+        }
+        int f = -1;
+        for (int i = 0; i < spec.n; ++i) {   // (wave-uniform trip: the names come out of the kernel arguments through scalar loads)
+            const uint32_t *nm = reinterpret_cast<const uint32_t *>(spec.name[i]);
+            bool same = spec.name_len[i] == klen;
+#pragma unroll
+            for (int j = 0; j < kMaxName / 8; ++j) same = same && kw[j] == ((uint64_t)nm[2 * j] | ((uint64_t)nm[2 * j + 1] << 32));
+            if (same) f = i;
+        }
+        if (f < 0 || ((seen >> f) & 1u)) return false;   // unknown member / repeated key: the general parser's business
+        seen |= 1u << f;
+        // ---- : value
+        p = skip_ws_words(s, ke + 1, end);
+        if (p >= end || s[p] != ':') return false;
+        p = skip_ws_words(s, p + 1, end);
+        if (p >= end) return false;
+        int32_t type = 0;
+        for (int i = 0; i < spec.n; ++i)
+            if (i == f) type = spec.type[i];
+        if (type == kUtf8) {
+            const int32_t b = p + 1;
+            uint64_t x = lds_u64(s, p);
+            if ((x & 0xFFu) != '"') return false;
+            x |= 0xFFu;
+            uint32_t c = 0;
+            for (;;) {
+                const uint64_t stop = bytes_equal_flags(x, '"') | bytes_equal_flags(x, '\\') | (((x - 0x2020202020202020ull) & ~x) & 0x8080808080808080ull);
+                if (stop) {
+                    const int at = (__ffsll((unsigned long long)stop) - 1) >> 3;
+                    p += at;
+                    c = (uint32_t)(x >> (8 * at)) & 0xFFu;
+                    break;
+                }
+                p += 8;
+                if (p >= end) return false;
+                x = lds_u64(s, p);
+            }
+            if (p >= end || c != '"') return false;
+            int32_t *pairs = nullptr, *ulen = nullptr;
+            for (int i = 0; i < spec.n; ++i)
+                if (i == f) pairs = out.pairs[i], ulen = out.ulen[i];
+            pairs[2 * row] = b + s_base;
+            pairs[2 * row + 1] = p + s_base;
+            ulen[row] = p - b;
+            ++p;
+        } else {
+            uint64_t x0 = lds_u64(s, p);
+            const bool neg = (x0 & 0xFFu) == '-';
+            if (neg) x0 = lds_u64(s, ++p);
+            uint64_t x1 = 0, x2 = 0;
+            const uint64_t m0 = non_digit_flags(x0);
+            int total = m0 ? (__ffsll((unsigned long long)m0) - 1) >> 3 : 8;
+            if (total == 8 && p + 8 < end) {
+                x1 = lds_u64(s, p + 8);
+                const uint64_t m1 = non_digit_flags(x1);
+                total += m1 ? (__ffsll((unsigned long long)m1) - 1) >> 3 : 8;
+                if (total == 16 && p + 16 < end) {
+                    x2 = lds_u64(s, p + 16);
+                    const uint64_t m2 = non_digit_flags(x2);
+                    total += m2 ? (__ffsll((unsigned long long)m2) - 1) >> 3 : 8;
+                }
+            }
+            total = min(total, end - p);
+            if (total <= 0 || total > 18 || (total > 1 && (x0 & 0xFFu) == '0')) return false;
+            const int lead = total - ((total - 1) & ~7);
+            uint64_t v = leading_digits(x0, lead);
+            if (total > 8) {
+                const int sh = 8 * lead;
+                v = v * 100000000ull + leading_digits(lead == 8 ? x1 : (x0 >> sh) | (x1 << (64 - sh)), 8);
+                if (total > 16) v = v * 100000000ull + leading_digits(lead == 8 ? x2 : (x1 >> sh) | (x2 << (64 - sh)), 8);
+            }
+            p += total;
+            if (p < end) {   // what follows an integer literal: a delimiter (a fraction or an exponent is the general parser's error)
+                const uint32_t c = s[p];
+                if (!(c == ',' || c == '}' || is_ws(c))) return false;
+            }
+            const int64_t sv = neg ? -(int64_t)v : (int64_t)v;
+            void *col = nullptr;
+            for (int i = 0; i < spec.n; ++i)
+                if (i == f) col = out.values[i];
+            if (type == kInt32) {
+                if (sv < -2147483648ll || sv > 2147483647ll) return false;
+                reinterpret_cast<int32_t *>(col)[row] = (int32_t)sv;
+            } else {
+                reinterpret_cast<int64_t *>(col)[row] = sv;
+            }
+        }
+        // ---- , or }
+        p = skip_ws_words(s, p, end);
+        if (p >= end) return false;
+        const uint32_t c = s[p];
+        if (c == '}') {
+            ++p;
+            break;
+        }
+        if (c != ',') return false;
+        p = skip_ws_words(s, p + 1, end);
+    }
+    return p == end && seen == (spec.n >= 32 ? ~0u : (1u << spec.n) - 1u);
+}
+
 // err[0] = first bad line + 1 (0: none) as atomicMin over (line + 1) stored inverted, err[1] = its code
-template <int kUnroll>
+//
+// Two kernels share one frame (256 lines per workgroup, their bytes staged in LDS):
+//   kRetry = false : the compact walk only (parse_line_words).  A workgroup that meets a line it cannot take -- or whose lines do not
+//                    fit the stage -- raises its flag in block_retry[] and *any_retry; nothing else.  This is the kernel every call runs,
+//                    and it carries neither the flat-object walker nor the general parser (with them inlined it needed 412 bytes of
+//                    scratch per lane for spilled scalar registers and ran 3x slower on lines it takes itself).
+//   kRetry = true  : only the flagged workgroups (all of them when block_retry is null): the flat-object walker, else the general
+//                    parser, which also words the errors.  Launched when *any_retry came back non-zero.
+template <int kUnroll, bool kRetry>
 __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__restrict__ bytes, int64_t n_bytes,
                                                             const int32_t *__restrict__ line_start, int64_t n_lines, JsonSpec spec,
-                                                            JsonOut out, int32_t stage_bytes, unsigned long long *err) {
+                                                            JsonOut out, int32_t stage_bytes, uint32_t *block_retry, uint32_t *any_retry,
+                                                            unsigned long long *err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];  // stage_bytes of dynamic LDS
-    __shared__ JsonSpec s_spec;  // lanes index the field names with their own (i, j): from LDS, not from the kernel arguments
-    for (int i = threadIdx.x; i < (int)(sizeof(JsonSpec) / 4); i += kBlock)
-        reinterpret_cast<uint32_t *>(&s_spec)[i] = reinterpret_cast<const uint32_t *>(&spec)[i];
+    __shared__ JsonSpec s_spec;  // (kRetry) lanes index the field names with their own (i, j): from LDS, not from the kernel arguments
+    if (kRetry) {
+        if (block_retry && !block_retry[blockIdx.x]) return;
+        for (int i = threadIdx.x; i < (int)(sizeof(JsonSpec) / 4); i += kBlock)
+            reinterpret_cast<uint32_t *>(&s_spec)[i] = reinterpret_cast<const uint32_t *>(&spec)[i];
+    }
     const int64_t l0 = (int64_t)blockIdx.x * kParseLines;
     const int64_t l1 = min(l0 + kParseLines, n_lines);
     const int32_t b0 = line_start[l0], b1 = min((int64_t)line_start[l1], n_bytes);
@@ -516,11 +684,20 @@ __global__ __launch_bounds__(kBlock) void json_parse_kernel(const uint8_t *__res
         }
     }
     __syncthreads();
+    if (!kRetry) {
+        const bool bad = line < n_lines && !(staged && parse_line_words<kUnroll>(s_stage, a0, p, e, spec, line, out));
+        const bool any = __syncthreads_or(bad);
+        if (threadIdx.x == 0) {
+            block_retry[blockIdx.x] = any ? 1u : 0u;
+            if (any) atomicOr(any_retry, 1u);
+        }
+        return;
+    }
     if (line >= n_lines) return;
     uint32_t rc;
     if (staged) {
         const Text<true> t{bytes, s_stage, a0};
-        rc = parse_line_words<kUnroll>(s_stage, a0, p, e, spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
+        rc = parse_line_flex(s_stage, a0, p, e, spec, out, line) ? 0u : parse_line(t, p, e, s_spec, line, out);   // (compact lines are flat objects, too)
     } else {
         const Text<false> t{bytes, nullptr, 0};
         rc = parse_line_fast(t, p, e, s_spec, line, out) ? 0u : parse_line(t, p, e, s_spec, line, out);
@@ -722,36 +899,70 @@ int flockgpu_json_lines_decode(flockgpu_ctx *ctx, const uint8_t *json, int64_t n
     FG_TRY(arena_get_t(ctx, "json.any_escape", kMaxFields, &d_any));
     FG_TRY(pinned_get_t(ctx, "json.any_escape", kMaxFields, &h_any));
     FG_HIP(ctx, hipMemsetAsync(d_err, 0xFF, sizeof(unsigned long long), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(d_any, 0, sizeof(uint32_t) * kMaxFields, ctx->stream));
-    if (n_lines > 0) {
-        LaunchScope ls(ctx, "json_parse_kernel");
-        // LDS per workgroup follows the text: 1.25 x the average bytes of 256 lines (+ alignment slack), so short lines
-        // (bids: 74 B -> 24 KB, six workgroups per CU) do not pay for the longest relation; a workgroup whose lines do
-        // not fit reads them from global memory instead.
-        int64_t want = (n_bytes / n_lines + 1) * kParseLines * 5 / 4 + 64;
-        const int32_t stage_bytes = (int32_t)std::min<int64_t>(kStageBytes, (want + 1023) & ~int64_t(1023));
-        auto kernel = n_fields <= 4 ? json_parse_kernel<4> : n_fields <= 8 ? json_parse_kernel<8> : json_parse_kernel<kMaxFields>;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)div_up(n_lines, kParseLines)), dim3(kBlock), (size_t)stage_bytes, ctx->stream,
-                           json, n_bytes, line_start, n_lines, spec, jo, stage_bytes, d_err);
-    }
-    FG_TRY(check_launch(ctx, "json_parse_kernel"));
-
-    // ---- strings: lengths -> offsets
+    uint32_t *d_retry = nullptr, *d_any_retry = nullptr, *h_any_retry = nullptr;
+    const int64_t n_blocks = div_up(std::max<int64_t>(n_lines, 1), kParseLines);
+    FG_TRY(arena_get_t(ctx, "json.block_retry", (size_t)n_blocks + 4, &d_retry));
+    FG_TRY(arena_get_t(ctx, "json.any_retry", 4, &d_any_retry));
+    FG_TRY(pinned_get_t(ctx, "json.any_retry", 4, &h_any_retry));
     int32_t *soff[kMaxFields] = {};
     for (int f = 0; f < n_fields; ++f) {
         if (spec.type[f] != kUtf8) continue;
         char name[48];
         snprintf(name, sizeof name, "json.str_off.%d", f);
         FG_TRY(arena_get_t(ctx, name, (size_t)n_lines + 4, &soff[f]));
+    }
+    // LDS per workgroup follows the text: 1.25 x the average bytes of 256 lines (+ alignment slack), so short lines
+    // (bids: 74 B -> 24 KB, six workgroups per CU) do not pay for the longest relation; a workgroup whose lines do
+    // not fit reads them from global memory instead.
+    const int64_t want = (n_bytes / std::max<int64_t>(n_lines, 1) + 1) * kParseLines * 5 / 4 + 64;
+    const int32_t stage_bytes = (int32_t)std::min<int64_t>(kStageBytes, (want + 1023) & ~int64_t(1023));
+    // hint = {route, calls on that route}: when most workgroups of a call ended in the second kernel (a writer other than serde_json)
+    // the next calls go there directly; every sixteenth of them tries the compact walk first again
+    std::vector<int64_t> &hint = ctx->host_i64["json.retry_hint"];
+    if (hint.size() < 2) hint.assign(2, 0);
+    const bool straight = hint[0] == 1 && (++hint[1] % 16) != 0;
+    *h_any_retry = 0;
+    // one round = a parse kernel, the string lengths behind it, ONE host wait for the errors, the escape flags and the retry flag
+    auto round = [&](bool second) -> int {
         if (n_lines > 0) {
-            hipLaunchKernelGGL(json_string_lengths_kernel, dim3((unsigned)div_up(n_lines, kBlock)), dim3(kBlock), 0, ctx->stream, jo.ulen[f],
-                               n_lines, soff[f], d_any + f);
-            FG_TRY(check_launch(ctx, "json_string_lengths_kernel"));
+            if (!second) FG_HIP(ctx, hipMemsetAsync(d_any_retry, 0, sizeof(uint32_t), ctx->stream));
+            FG_HIP(ctx, hipMemsetAsync(d_any, 0, sizeof(uint32_t) * kMaxFields, ctx->stream));
+            auto kernel = second ? (n_fields <= 4 ? json_parse_kernel<4, true> : n_fields <= 8 ? json_parse_kernel<8, true> : json_parse_kernel<kMaxFields, true>)
+                                 : (n_fields <= 4 ? json_parse_kernel<4, false> : n_fields <= 8 ? json_parse_kernel<8, false> : json_parse_kernel<kMaxFields, false>);
+            {
+                LaunchScope ls(ctx, second ? "json_parse_retry_kernel" : "json_parse_kernel");
+                hipLaunchKernelGGL(kernel, dim3((unsigned)n_blocks), dim3(kBlock), (size_t)stage_bytes, ctx->stream, json, n_bytes, line_start, n_lines, spec, jo,
+                                   stage_bytes, second && straight ? (uint32_t *)nullptr : d_retry, d_any_retry, d_err);
+            }
+            FG_TRY(check_launch(ctx, second ? "json_parse_retry_kernel" : "json_parse_kernel"));
+            for (int f = 0; f < n_fields; ++f) {
+                if (spec.type[f] != kUtf8) continue;
+                hipLaunchKernelGGL(json_string_lengths_kernel, dim3((unsigned)div_up(n_lines, kBlock)), dim3(kBlock), 0, ctx->stream, jo.ulen[f], n_lines, soff[f],
+                                   d_any + f);
+                FG_TRY(check_launch(ctx, "json_string_lengths_kernel"));
+            }
+            if (!second) FG_HIP(ctx, hipMemcpyAsync(h_any_retry, d_any_retry, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_any, d_any, sizeof(uint32_t) * kMaxFields, hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FLOCKGPU_OK;
+    };
+    if (straight) {
+        FG_TRY(round(true));
+    } else {
+        FG_TRY(round(false));
+        if (*h_any_retry) {   // some workgroup met a line the compact walk does not take
+            FG_TRY(round(true));
+            std::vector<uint32_t> flags((size_t)n_blocks);   // how many needed it: the next calls' route
+            FG_HIP(ctx, hipMemcpy(flags.data(), d_retry, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost));
+            int64_t flagged = 0;
+            for (uint32_t f : flags) flagged += f != 0;
+            hint[0] = flagged * 2 > n_blocks ? 1 : 0;
+        } else {
+            hint[0] = 0;
         }
     }
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(h_any, d_any, sizeof(uint32_t) * kMaxFields, hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err != ~0ull) {
         const long long line = (long long)(*h_err >> 8);
         const uint32_t code = (uint32_t)(*h_err & 0xFF);

@@ -159,3 +159,49 @@ def test_compact_lines_every_digit_count_and_string_length(ctx):
     # 20 digits: out of range whichever path meets it
     with pytest.raises(FlockGpuError):
         ctx.json_lines_decode(_dev_bytes(b'{"a":12345678901234567890,"s":"x","b":2,"c":3}\n'), fields)
+
+
+def test_flat_objects_in_any_order_with_white_space(ctx):
+    """What `parse_line_flex` takes before the byte-wise general parser does: flat objects holding exactly the schema's members, in any
+    order, with white space wherever JSON allows it (Python's default `json.dumps` separators among them).  Mixed into the same text:
+    compact serde_json lines (the first walker's), and lines only the general parser accepts (an unknown member, an escape) -- every
+    line must come out the same whoever parsed it."""
+    fields = [("id", "int64"), ("name", "utf8"), ("n", "int32"), ("city", "utf8")]
+    rng = np.random.default_rng(21)
+    lines = []
+    for i in range(8000):
+        o = {"id": int(rng.integers(-2 ** 62, 2 ** 62)) if i % 5 else int(rng.integers(0, 10 ** (i % 19))), "name": "name-%d" % i + "x" * (i % 23),
+             "n": int(rng.integers(-2 ** 31, 2 ** 31)), "city": ["", "Paris", "São Paulo", "a" * 40][i % 4]}
+        items = list(o.items())
+        order = rng.permutation(4) if i % 7 else np.arange(4)
+        kind = i % 6
+        if kind == 0:      # compact, schema order or not
+            line = "{" + ",".join('%s:%s' % (json.dumps(items[j][0]), json.dumps(items[j][1], ensure_ascii=False)) for j in order) + "}"
+        elif kind in (1, 2, 3):   # Python's default separators; more white space; tabs and a trailing \r
+            sep, col = [(", ", ": "), (" ,  ", "  :\t"), (",\t", ":  ")][kind - 1]
+            line = " " * (i % 3) + "{" + " " * (i % 2) + sep.join('%s%s%s' % (json.dumps(items[j][0]), col, json.dumps(items[j][1], ensure_ascii=False))
+                                                                  for j in order) + " " * (i % 4 == 1) + "}" + ("\r" if i % 9 == 0 else "")
+        elif kind == 4:    # an unknown member: the general parser's
+            line = json.dumps(dict([items[j] for j in order] + [("extra", [1, {"a": "}"}])]), ensure_ascii=False)
+        else:              # an escape in a value
+            o2 = dict(o, name=o["name"] + ' "q" \\ \n')
+            line = json.dumps({k: o2[k] for k in [items[j][0] for j in order]})
+        lines.append(line.encode())
+    text = b"\n".join(lines) + b"\n"
+    want = oracle.json_lines_decode(text, fields)
+    got, n = ctx.json_lines_decode(_dev_bytes(text), fields)
+    assert n == len(lines)
+    _check(got, want, fields, n)
+    # errors a flat line can hold are still the general parser's errors
+    from flock_amd import FlockGpuError, _ffi
+    for bad, code in ((b'{"id": 1, "name": "a", "n": 2}\n', "INVALID"),                       # a member is missing
+                      (b'{"id": 1, "name": "a", "n": 2, "city": "x", "id": 3}\n', None),      # a repeated key: last one wins (a map-building decoder)
+                      (b'{"id": 1.5, "name": "a", "n": 2, "city": "x"}\n', "UNSUPPORTED"),
+                      (b'{"id": 01, "name": "a", "n": 2, "city": "x"}\n', "INVALID"),
+                      (b'{"id": 1, "name": "a", "n": 2, "city": "x"} x\n', "INVALID")):
+        if code is None:
+            assert ctx.json_lines_decode(_dev_bytes(bad), fields)[0]["id"].cpu().tolist() == [3]
+            continue
+        with pytest.raises(FlockGpuError) as e:
+            ctx.json_lines_decode(_dev_bytes(bad), fields)
+        assert e.value.code == getattr(_ffi, "ERR_" + code), (bad, str(e.value))
