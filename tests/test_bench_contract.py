@@ -25,7 +25,8 @@ def test_defaults_are_one_gpu_and_a_few_steps(monkeypatch):
 
 def test_every_kernel_the_bench_names_exists():
     import bench
-    kernels = _kernel_names() | {"q3_probe_count_kernel"}   # (LaunchScope label of q3_probe_general_kernel<false>)
+    # (LaunchScope labels of q3_probe_general_kernel<false> and json_parse_kernel<n, retry = true>)
+    kernels = _kernel_names() | {"q3_probe_count_kernel", "json_parse_retry_kernel"}
     for q, (name, bytes_per_row, relation) in bench.DOMINANT.items():
         assert name in kernels, (q, name)
         assert bytes_per_row > 0 and relation in ("bid", "auction")
