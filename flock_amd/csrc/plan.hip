@@ -1980,6 +1980,43 @@ int flockgpu_plan_execute_retain(flockgpu_plan *plan, int64_t *rows) {
     if (t.cols.size() != root->schema.size()) return fail(ctx, FLOCKGPU_ERR_HIP, "plan execute: %zu result columns for a schema of %zu", t.cols.size(), root->schema.size());
     for (size_t c = 0; c < t.cols.size(); ++c)
         if (!t.cols[c].present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: output column '%s' was not materialised", root->schema[c].name.c_str());
+    // A result column must outlive the executes of OTHER plans on this context.  Buffers named after this plan (its leaves, its
+    // generic operators' outputs) do; a fused pipeline that hands out context-wide buffers ("q5.out_auction", ...) would have them
+    // overwritten by the same pipeline inside another plan -- q5's two stage plans both run the fused Partial COUNT (today its
+    // columns reach the plan's result through plan-named buffers; this keeps it that way for whatever is fused next).  Such a column
+    // is copied into a buffer of this plan (device to device, stream-ordered).
+    char prefix[40];
+    snprintf(prefix, sizeof prefix, "plan%p.", (const void *)plan);
+    auto mine = [&](const void *ptr) {
+        if (!ptr) return true;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+        for (auto it = ctx->arena.lower_bound(prefix); it != ctx->arena.end() && it->first.compare(0, strlen(prefix), prefix) == 0; ++it) {
+            const uintptr_t b = reinterpret_cast<uintptr_t>(it->second.ptr);
+            if (it->second.ptr && a >= b && a < b + it->second.cap) return true;
+        }
+        return false;
+    };
+    for (size_t c = 0; c < t.cols.size(); ++c) {
+        DevColumn &col = t.cols[c].c;
+        if (t.rows == 0 || col.all_null) continue;
+        if (col.type == ColType::UTF8) {
+            if (mine(col.values) && mine(col.offsets)) continue;
+            void *bytes = nullptr;
+            int32_t *offs = nullptr;
+            FG_TRY(arena_get(ctx, node_key(plan, root, "keepb", (int)c).c_str(), (size_t)col.bytes + 16, &bytes));
+            FG_TRY(arena_get_t(ctx, node_key(plan, root, "keepo", (int)c).c_str(), (size_t)t.rows + 4, &offs));
+            if (col.bytes) FG_HIP(ctx, hipMemcpyAsync(bytes, col.values, (size_t)col.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(offs, col.offsets, sizeof(int32_t) * ((size_t)t.rows + 1), hipMemcpyDeviceToDevice, ctx->stream));
+            col.values = bytes;
+            col.offsets = offs;
+        } else {
+            if (mine(col.values)) continue;
+            void *vals = nullptr;
+            FG_TRY(arena_get(ctx, node_key(plan, root, "keepv", (int)c).c_str(), (size_t)t.rows * col_width(col.type) + 16, &vals));
+            FG_HIP(ctx, hipMemcpyAsync(vals, col.values, (size_t)t.rows * col_width(col.type), hipMemcpyDeviceToDevice, ctx->stream));
+            col.values = vals;
+        }
+    }
     plan->retained = t;
     plan->has_retained = true;
     if (rows) *rows = t.rows;

@@ -280,6 +280,39 @@ def test_a_stage_reads_its_producers_results_on_the_device(gpu):
 
 
 @pytest.mark.gpu
+def test_a_retained_result_survives_another_plans_execute(gpu):
+    """q5's two source stage plans both run the fused Partial COUNT, whose output buffers belong to the context, not to a plan: the
+    counts stage keeps ITS result while the MAX stage executes the same pipeline over OTHER bids afterwards.  The join stage must see
+    the first window's counts against the second window's maximum."""
+    from flock_amd import stages as S
+    from flock_amd.runtime import ExecutionContext
+    st = S.build_query_dag(_plan(5))
+    mx, counts, join = (ExecutionContext([x.plan], gpu=gpu) for x in st)     # stage 0: MAX(num); stage 1: (auction, num); stage 2: join
+    try:
+        rel_a, _ = _relations(5, 20_000, 100_000)
+        rng = np.random.default_rng(3)
+        top = int(np.unique(rel_a["bid"]["auction"].to_numpy(), return_counts=True)[1].max())
+        # window B: a handful of auctions, its maximum count chosen to be a count that occurs in window A
+        a_vals, a_cnt = np.unique(rel_a["bid"]["auction"].to_numpy(), return_counts=True)
+        target = int(np.sort(a_cnt)[len(a_cnt) // 2])
+        b_auction = np.concatenate([np.full(target, 7, np.int32), np.full(max(target - 1, 1), 8, np.int32)])
+        rel_b = pa.record_batch([pa.array(b_auction), pa.array(b_auction), pa.array(b_auction), pa.array(np.zeros(len(b_auction), np.int64)).cast(TS)],
+                                names=["auction", "bidder", "price", "b_date_time"])
+        counts.feed_data_sources([[[rel_a["bid"]]]])
+        counts.execute_retain()
+        mx.feed_data_sources([[[rel_b]]])
+        mx.execute_retain()
+        join.feed_from([counts, mx])
+        got = _rows(join.execute()[0])
+        want = sorted((int(a), int(c)) for a, c in zip(a_vals, a_cnt) if c == target)
+        assert got == want and len(want) > 0 and target < top
+    finally:
+        for c in (join, mx, counts):
+            c.clean_data_sources()
+            c.close()
+
+
+@pytest.mark.gpu
 def test_two_plans_read_one_upload(gpu):
     """flockgpu_plan_feed_shared: q5's stage plans both scan `bid.auction`; the second reads the first one's device copy.  A plan
     that reads a column the donor never uploaded is refused (nothing changes, it is fed its own copy), a shared leaf cannot be
