@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kProbeBlock) void q13_probe_emit_kernel(const int32
 // tile only and needs no LDS copy: the count pass becomes a plain streaming kernel in the flag-tile geometry (256 lanes,
 // 32 rows per lane, tiles walked with the next descriptor requested early, as q2 / q7), the per-tile fixed costs (range
 // reduction for the shared bitmap words, scan, stores) are paid per 32 rows of a lane instead of per 8.
-__global__ __launch_bounds__(kBlock) void q13_flag_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void q13_flag_kernel(const int32_t *__restrict__ auction, int64_t n_rows, SegTiles st,
                                                           const uint64_t *__restrict__ table, uint32_t cap,
                                                           const int32_t *__restrict__ next, KeyBitmap bm,
                                                           uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {

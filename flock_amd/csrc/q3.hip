@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
 // kBits: every window is gapless (bit blocks, no row table); else: the row table for every window.  Two instances, not a branch per
 // window: both lookups unrolled over a lane's 32 rows in one kernel took 136 VGPRs (three waves per SIMD) and ran 20 % slower.
 template <bool kBits>
-__global__ __launch_bounds__(kBlock) void q3_probe_flag_kernel(const int32_t *__restrict__ seller,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void q3_probe_flag_kernel(const int32_t *__restrict__ seller,
                                                                const int32_t *__restrict__ category, int64_t n_rows,
                                                                int64_t category_lit, SegTiles st,
                                                                const WinTable *__restrict__ wins,

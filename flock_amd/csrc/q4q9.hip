@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void aq_final_kernel(const int32_t *__restr
 
 // q9 outer join: bids whose price equals their auction's final (no BETWEEN here: q9.sql joins bid with Q on
 // auction = id AND price = final only).
-__global__ __launch_bounds__(kBlock) void q9_flag_kernel(const int32_t *__restrict__ b_auction,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void q9_flag_kernel(const int32_t *__restrict__ b_auction,
                                                          const int32_t *__restrict__ b_price, int64_t n_bids, SegTiles st,
                                                          const WinTable *__restrict__ wins, const int32_t *__restrict__ direct,
                                                          const int32_t *__restrict__ final_price,

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t
     }
 }
 
-__global__ __launch_bounds__(kBlock) void q8_persons_flag_kernel(const int32_t *__restrict__ p_id, int64_t n_rows,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void q8_persons_flag_kernel(const int32_t *__restrict__ p_id, int64_t n_rows,
                                                                  SegTiles st, const WinBitmap *__restrict__ wins,
                                                                  const uint32_t *__restrict__ bitmaps,
                                                                  uint32_t *__restrict__ flag_words,
