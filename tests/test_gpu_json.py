@@ -205,3 +205,53 @@ def test_flat_objects_in_any_order_with_white_space(ctx):
         with pytest.raises(FlockGpuError) as e:
             ctx.json_lines_decode(_dev_bytes(bad), fields)
         assert e.value.code == getattr(_ffi, "ERR_" + code), (bad, str(e.value))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_schemas_and_writers(ctx, seed):
+    """Randomised: 1 .. 9 fields of random types and names (1 .. 31 bytes: every key-word count), integers of every digit count, strings
+    with and without escapes, and per text one of four writers -- serde_json's compact shape, Python's separators, members shuffled per
+    line, and a mix with unknown members -- so that all three parsers (compact walk, flat-object walker, general) and the routing
+    between their two kernels (first call, steady state, a change of writer on the same context) meet the same oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_fields = int(rng.integers(1, 10))
+    names = []
+    while len(names) < n_fields:
+        ln = int(rng.integers(1, 32))
+        nm = "".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz_0123456789"), ln))
+        if nm not in names:
+            names.append(nm)
+    types = [["int32", "int64", "utf8"][int(rng.integers(0, 3))] for _ in names]
+    fields = list(zip(names, types))
+
+    def value(t, i):
+        if t == "int32":
+            return int(rng.integers(-2 ** 31, 2 ** 31)) if i % 3 else int(rng.integers(0, 10 ** int(rng.integers(1, 10))))
+        if t == "int64":
+            d = int(rng.integers(1, 19))
+            return int(rng.integers(0, 10 ** d)) * (-1 if i % 4 == 0 else 1)
+        k = int(rng.integers(0, 6))
+        return ["", "x" * int(rng.integers(0, 40)), "é漢" * int(rng.integers(0, 5)), 'q"uote', "back\\slash\n", "plain %d" % i][k]
+
+    def lines(writer, n):
+        out = []
+        for i in range(n):
+            items = [(nm, value(t, i)) for nm, t in fields]
+            if writer in (2, 3):
+                items = [items[j] for j in rng.permutation(len(items))]
+            if writer == 3 and i % 5 == 0:
+                items.insert(int(rng.integers(0, len(items) + 1)), ("unknown member", [1, {"k": "}"}, None]))
+            if writer == 0:
+                out.append(json.dumps(dict(items), separators=(",", ":"), ensure_ascii=bool(i % 2)).encode())
+            elif writer == 1:
+                out.append(json.dumps(dict(items), ensure_ascii=bool(i % 2)).encode())
+            else:
+                sep = [",", ", ", " ,\t"][i % 3]
+                out.append(("{" + sep.join("%s%s%s" % (json.dumps(k), [":", ": ", " : "][i % 3], json.dumps(v, ensure_ascii=bool(i % 2))) for k, v in items) + "}").encode())
+        return b"\n".join(out) + (b"\n" if n % 2 else b"")
+    for writer in rng.permutation(4).tolist() + [0, 1, 1, 0]:     # (the same context throughout: the route hint carries over)
+        text = lines(writer, int(rng.integers(1, 3000)))
+        want = oracle.json_lines_decode(text, fields)
+        got, n = ctx.json_lines_decode(_dev_bytes(text), fields)
+        assert n == len(want[names[0]].offsets) - 1 if types[0] == "utf8" else n == len(want[names[0]])
+        _check(got, want, fields, n)
