@@ -46,6 +46,30 @@ int main() {
             t_poll_then_sync += std::chrono::duration<double, std::micro>(clk::now() - b).count();
             (void)a;
         }
+        double t_evs = 0, t_evq = 0, t_sq = 0;
+        hipEvent_t ev;
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        for (int i = 0; i < n; ++i) {   // (d) event record + hipEventSynchronize
+            auto a = clk::now();
+            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, flag, (uint32_t)(i + 1), spin);
+            hipEventRecord(ev, s);
+            hipEventSynchronize(ev);
+            t_evs += std::chrono::duration<double, std::micro>(clk::now() - a).count();
+        }
+        for (int i = 0; i < n; ++i) {   // (e) event record + spinning on hipEventQuery
+            auto a = clk::now();
+            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, flag, (uint32_t)(i + 1), spin);
+            hipEventRecord(ev, s);
+            while (hipEventQuery(ev) == hipErrorNotReady) {}
+            t_evq += std::chrono::duration<double, std::micro>(clk::now() - a).count();
+        }
+        for (int i = 0; i < n; ++i) {   // (f) spinning on hipStreamQuery
+            auto a = clk::now();
+            hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, flag, (uint32_t)(i + 1), spin);
+            while (hipStreamQuery(s) == hipErrorNotReady) {}
+            t_sq += std::chrono::duration<double, std::micro>(clk::now() - a).count();
+        }
+        printf("   event record + hipEventSynchronize %.2f us, + hipEventQuery spin %.2f us, hipStreamQuery spin %.2f us\n", t_evs / n, t_evq / n, t_sq / n);
         printf("kernel body ~%d cycles: launch+synchronize %.2f us, launch+poll %.2f us, synchronize after the poll %.2f us\n", spin, t_sync / n, t_poll / n,
                t_poll_then_sync / n);
     }
