@@ -235,7 +235,24 @@ SYMBOLS = {
     "flockgpu_host_register": (_i, [_vp, C.c_size_t]),
     "flockgpu_host_unregister": (_i, [_vp]),
     "flockgpu_plan_reset": (_i, [_vp]),
+    "flockgpu_plan_create_ex": (_i, [_vp, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(_vp)]),
+    "flockgpu_plan_execute_async": (_i, [_vp, _i]),
+    "flockgpu_plan_wait": (_i, [_vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "flockgpu_plan_ring_open": (_i, [_vp, _i]),
+    "flockgpu_plan_ring_close": (_i, [_vp]),
+    "flockgpu_plan_ring_state": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    "flockgpu_plan_feed_pane": (_i, [_vp, _i, _i64, _vp, C.POINTER(_vp), _i]),
+    "flockgpu_plan_partition_scheme": (C.c_char_p, []),
+    "flockgpu_plan_check_partition_scheme": (_i, [C.c_char_p]),
+    # asynchronous twins of the batched-window calls (one call in flight per ctx)
+    "flockgpu_q3_join_async": (_i, [_vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),
+                                    C.POINTER(Windows), _i64, C.POINTER(C.c_char_p), _i, C.POINTER(Q3Result)]),
+    "flockgpu_q5_hot_items_async": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), C.POINTER(Q5Result)]),
+    "flockgpu_q8_join_async": (_i, [_vp, C.POINTER(PersonCols), C.POINTER(Windows), C.POINTER(AuctionCols),
+                                    C.POINTER(Windows), C.POINTER(Q8Result)]),
+    "flockgpu_ctx_wait": (_i, [_vp]),
 }
+PLAN_GENERIC_ONLY = 1
 
 _lib = None
 

@@ -18,14 +18,20 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "build")
-LIB = os.path.join(HERE, "libflockgpu.so")
-STAMP = os.path.join(HERE, "csrc", ".build_stamp")
+# FLOCKGPU_BUILD_EXPERIMENTAL=1: a SECOND library, libflockgpu_experimental.so, compiled with -DFLOCKGPU_EXPERIMENTAL (plus whatever
+# FLOCKGPU_BUILD_DEFINES lists, e.g. "-DFLOCKGPU_AB_PLAIN_TILE_LOADS"): the only build in which the A/B knobs of common.hpp's exp_env()
+# read the environment.  The shipped libflockgpu.so is always built without it.
+EXPERIMENTAL = os.environ.get("FLOCKGPU_BUILD_EXPERIMENTAL", "") not in ("", "0")
+OBJ = os.path.join(HERE, "csrc", "build_experimental" if EXPERIMENTAL else "build")
+LIB = os.path.join(HERE, "libflockgpu_experimental.so" if EXPERIMENTAL else "libflockgpu.so")
+STAMP = os.path.join(HERE, "csrc", ".build_stamp_experimental" if EXPERIMENTAL else ".build_stamp")
 CFLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",            # q1's f64 multiply must stay a plain IEEE multiply
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
 ]
+if EXPERIMENTAL:
+    CFLAGS += ["-DFLOCKGPU_EXPERIMENTAL"] + os.environ.get("FLOCKGPU_BUILD_DEFINES", "").split()
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 LIBS = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 

@@ -5,7 +5,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -28,6 +30,8 @@ struct PendingEvent {
     const char *name;
     hipEvent_t start, stop;
 };
+
+struct AsyncWorker;  // ctx.hip: the ctx's worker thread (flockgpu_*_async / flockgpu_ctx_wait)
 
 }  // namespace flockgpu
 
@@ -54,6 +58,7 @@ struct flockgpu_ctx {
     std::vector<flockgpu::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, flockgpu::KernelStat> stats;
+    flockgpu::AsyncWorker *worker = nullptr;  // created by the first asynchronous call
 };
 
 namespace flockgpu {
@@ -196,6 +201,20 @@ inline void profile_drain(flockgpu_ctx *ctx) {
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Asynchronous calls (flockgpu.h): `fn` runs on the ctx's worker thread, one call in flight per ctx.  ctx_submit returns
+// FLOCKGPU_ERR_INVALID when a call is already in flight; ctx_wait returns the call's status (FLOCKGPU_ERR_INVALID: none submitted).
+int ctx_submit(flockgpu_ctx *ctx, std::function<int()> fn);
+int ctx_wait(flockgpu_ctx *ctx);
+
+// Experiment knobs (A/B switches the tools/gpu_*.sh scripts flip through the environment) exist only in builds made with
+// -DFLOCKGPU_EXPERIMENTAL (`FLOCKGPU_BUILD_EXPERIMENTAL=1 python -m flock_amd.build`, which writes libflockgpu_experimental.so): the
+// shipped library never reads them, so no untested configuration is reachable from a production host's environment.
+#ifdef FLOCKGPU_EXPERIMENTAL
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
 // Validates a window schedule against a relation of `rows` rows.
 inline int check_windows(flockgpu_ctx *ctx, const flockgpu_windows *w, int64_t rows, const char *what) {
     if (!w || w->n_panes < 0 || w->n_windows < 0 || !w->pane_row_offsets)
@@ -220,7 +239,7 @@ typedef int flockgpu_v4i __attribute__((ext_vector_type(4)));
 // write-back does not land on whatever kernel runs next (the q5 counters' clear cost the count pass 0.04-0.15 ms that way).
 typedef unsigned int flockgpu_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_store4(void *p, uint4 v) {
-#ifdef FLOCKGPU_AB_PLAIN_STORES   // (A/B builds only)
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_PLAIN_STORES)   // (A/B builds only)
     *reinterpret_cast<uint4 *>(p) = v;
 #else
     flockgpu_v4u t;
@@ -229,14 +248,14 @@ __device__ __forceinline__ void stream_store4(void *p, uint4 v) {
 #endif
 }
 __device__ __forceinline__ void stream_store(int32_t *p, int32_t v) {
-#ifdef FLOCKGPU_AB_PLAIN_STORES
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_PLAIN_STORES)
     *p = v;
 #else
     __builtin_nontemporal_store(v, p);
 #endif
 }
 __device__ __forceinline__ void stream_store(int64_t *p, int64_t v) {
-#ifdef FLOCKGPU_AB_PLAIN_STORES
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_PLAIN_STORES)
     *p = v;
 #else
     __builtin_nontemporal_store(v, p);

@@ -1,7 +1,79 @@
 // libflockgpu: context, error reporting, per-kernel HIP-event profiling.
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "common.hpp"
 
 using namespace flockgpu;
+
+// ---- the ctx's worker thread: runs the asynchronous calls (the reference's `tokio::spawn(collect(plan))`, context.rs:172-191)
+namespace flockgpu {
+
+struct AsyncWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    enum { Idle, Queued, Running, Done } state = Idle;
+    int rc = FLOCKGPU_OK;
+    bool quit = false;
+    std::thread th;
+    explicit AsyncWorker(int device) {
+        th = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return quit || state == Queued; });
+                if (quit) return;
+                state = Running;
+                std::function<int()> fn = std::move(task);
+                lk.unlock();
+                const int r = fn();
+                lk.lock();
+                rc = r;
+                state = Done;
+                cv.notify_all();
+            }
+        });
+    }
+    ~AsyncWorker() {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return state == Idle || state == Done; });   // (a call in flight finishes first)
+            quit = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
+
+int ctx_submit(flockgpu_ctx *ctx, std::function<int()> fn) {
+    if (!ctx->worker) ctx->worker = new AsyncWorker(ctx->device);
+    AsyncWorker *w = ctx->worker;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (w->state != AsyncWorker::Idle) return fail(ctx, FLOCKGPU_ERR_INVALID, "async: a call is already in flight on this ctx (flockgpu_ctx_wait first)");
+        w->task = std::move(fn);
+        w->state = AsyncWorker::Queued;
+    }
+    w->cv.notify_all();
+    return FLOCKGPU_OK;
+}
+
+int ctx_wait(flockgpu_ctx *ctx) {
+    AsyncWorker *w = ctx->worker;
+    if (!w) return fail(ctx, FLOCKGPU_ERR_INVALID, "wait: no asynchronous call was submitted on this ctx");
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (w->state == AsyncWorker::Idle) {
+        lk.unlock();
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "wait: no asynchronous call was submitted on this ctx");
+    }
+    w->cv.wait(lk, [w] { return w->state == AsyncWorker::Done; });
+    w->state = AsyncWorker::Idle;
+    return w->rc;
+}
+
+}  // namespace flockgpu
 
 extern "C" {
 
@@ -40,6 +112,8 @@ int flockgpu_ctx_create(int device, void *hip_stream, flockgpu_ctx **out) {
 
 void flockgpu_ctx_destroy(flockgpu_ctx *ctx) {
     if (!ctx) return;
+    delete ctx->worker;   // (joins: a call still in flight finishes first)
+    ctx->worker = nullptr;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     profile_drain(ctx);
@@ -59,6 +133,42 @@ int flockgpu_ctx_synchronize(flockgpu_ctx *ctx) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FLOCKGPU_OK;
+}
+
+int flockgpu_ctx_wait(flockgpu_ctx *ctx) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    return ctx_wait(ctx);
+}
+
+// The asynchronous twins of the batched-window entry points: the argument structs are copied (the host may build them on its
+// stack), the arrays they point to are borrowed until flockgpu_ctx_wait returns.
+int flockgpu_q3_join_async(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                           const flockgpu_person_cols *person, const flockgpu_windows *person_win, int64_t category_lit,
+                           const char *const *state_lits, int n_state_lits, flockgpu_q3_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!auction || !auction_win || !person || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q3 async: null argument");
+    const flockgpu_auction_cols a = *auction;
+    const flockgpu_person_cols p = *person;
+    const flockgpu_windows aw = *auction_win, pw = *person_win;
+    return ctx_submit(ctx, [=] { return flockgpu_q3_join(ctx, &a, &aw, &p, &pw, category_lit, state_lits, n_state_lits, out); });
+}
+
+int flockgpu_q5_hot_items_async(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win, flockgpu_q5_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!bid || !win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q5 async: null argument");
+    const flockgpu_bid_cols b = *bid;
+    const flockgpu_windows w = *win;
+    return ctx_submit(ctx, [=] { return flockgpu_q5_hot_items(ctx, &b, &w, out); });
+}
+
+int flockgpu_q8_join_async(flockgpu_ctx *ctx, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                           const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win, flockgpu_q8_result *out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!auction || !auction_win || !person || !person_win || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "q8 async: null argument");
+    const flockgpu_auction_cols a = *auction;
+    const flockgpu_person_cols p = *person;
+    const flockgpu_windows aw = *auction_win, pw = *person_win;
+    return ctx_submit(ctx, [=] { return flockgpu_q8_join(ctx, &p, &pw, &a, &aw, out); });
 }
 
 int flockgpu_malloc(flockgpu_ctx *ctx, size_t bytes, void **out_device_ptr) {

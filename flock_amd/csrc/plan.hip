@@ -97,6 +97,9 @@ struct LeafData {
     int64_t rows = 0;
     int64_t dropped = 0;     // rows a feed left out because of NULLs
     bool borrowed = false;   // cols alias another plan's leaf (flockgpu_plan_feed_shared): nothing here is this leaf's to grow
+    // pane ring (flockgpu_plan_ring_open): rows -- and per Utf8 column, bytes -- of every pane whose rows this leaf still holds, oldest first
+    std::vector<int64_t> pane_rows;
+    std::vector<std::vector<int64_t>> pane_bytes;   // [pane][column]
 };
 
 enum Fused { kNone = 0, kQ2, kQ3, kQ5, kQ7, kQ8, kQ13, kPartialCount, kQ9, kQ4, kYsb };
@@ -133,6 +136,25 @@ struct flockgpu_plan {
     int64_t fed_bytes = 0;
     Table retained;              // flockgpu_plan_execute_retain: the result, left on the device for the plans that consume it
     bool has_retained = false;
+    // ---- device-side pane ring (flockgpu_plan.h): the last ring_ppw panes stay in HBM across executes
+    int ring_ppw = 0;            // panes per window; 0: no ring, whole-window feeding
+    int64_t ring_first = 0;      // id of the oldest pane held
+    int ring_n = 0;              // panes held
+    // q5 (COUNT GROUP BY auction -> MAX -> join): a pane is retained as its Partial aggregate state, the (auction, count) groups, in
+    // `ring.q5a` / `ring.q5c` (pane after pane); the leaf holds only the newest pane's rows, until the next pane begins
+    bool ring_q5 = false;
+    std::vector<int64_t> ring_groups;   // groups per held pane (the newest pane's entry is valid when ring_newest_done)
+    bool ring_newest_done = false;
+    int32_t *ring_auction = nullptr;
+    uint32_t *ring_count = nullptr;
+    // ---- flockgpu_plan_execute_async: the finished call's outputs, handed over by flockgpu_plan_wait
+    bool async_pending = false;
+    ArrowSchema async_schema{};
+    std::vector<ArrowArray> async_batches;
+    int async_n = 0;
+    // ---- hash-placement guard: the scheme tag of the co-partitioned inputs fed since the last reset (-1: none fed yet)
+    int scheme_state = -1;       // 0: untagged batches, 1: tagged with scheme_tag
+    std::string scheme_tag;
 };
 
 namespace {
@@ -599,11 +621,18 @@ const char *fused_name(Fused f) {
     }
 }
 void describe(const flockgpu_plan *pl, const Node *n, int depth, std::ostringstream &os) {
-    static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition"};
+    static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition", "Sort", "Limit"};
     os << std::string((size_t)depth * 2, ' ') << kinds[(int)n->kind];
     if (n->kind == NKind::Aggregate) os << "(" << n->mode << ")";
     if (n->kind == NKind::Repartition) os << "(Hash, " << n->n_parts << ")";
     if (n->kind == NKind::Scan) os << "(" << pl->ir.leaves[(size_t)n->leaf].relation << ")";
+    if (n->kind == NKind::Limit) os << "(" << n->limit << ")";
+    if (n->kind == NKind::Sort) {
+        os << "(";
+        for (size_t i = 0; i < n->sort_cols.size(); ++i)
+            os << (i ? ", " : "") << n->schema[(size_t)n->sort_cols[i].col].name << (n->sort_cols[i].descending ? " DESC" : " ASC");
+        os << ")";
+    }
     os << " [";
     for (size_t i = 0; i < n->schema.size(); ++i) os << (i ? ", " : "") << n->schema[i].name << ":" << type_name(n->schema[i]);
     os << "]";
@@ -637,14 +666,13 @@ int classify(const flockgpu_plan *pl) {
     }
 }
 
-int parse_and_build(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan *pl) {
+int parse_and_build(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan *pl, uint32_t flags = 0) {
     JParser jp{plan_json, plan_json + len, {}};
     JPtr root;
     if (!jp.parse(root) || root->kind != JValue::Obj)
         return fail(ctx, FLOCKGPU_ERR_PLAN, "plan: JSON error: %s", jp.err.empty() ? "not an object" : jp.err.c_str());
     if (!build_plan(root.get(), &pl->ir)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan: %s", pl->ir.why.c_str());
-    const char *g = getenv("FLOCKGPU_PLAN_GENERIC");
-    pl->generic_only = g && atoi(g) != 0;
+    pl->generic_only = (flags & FLOCKGPU_PLAN_GENERIC_ONLY) != 0;
     pl->fused.assign((size_t)pl->ir.n_nodes, FusedInfo{});
     recognise_fused(pl, pl->ir.root.get());
     pl->query = classify(pl);
@@ -818,6 +846,12 @@ bool validity_has_nulls(const ArrowArray *a, int64_t offset, int64_t n) {
     return false;
 }
 
+}  // namespace
+extern "C" {
+static int ring_q5_partial(flockgpu_plan *plan);   // (pane ring, below)
+}
+namespace {
+
 // ------------------------------------------------------------------ execution
 struct Exec {
     flockgpu_plan *pl;
@@ -980,6 +1014,18 @@ struct Exec {
                 return FLOCKGPU_OK;
             }
             case kQ5: {
+                if (pl->ring_ppw && pl->ring_q5) {
+                    // pane ring: every pane was counted once, when it was the newest (its Partial groups stay on the device); the window is
+                    // the FinalPartitioned merge of the held panes' groups -> MAX -> join, i.e. q5.dag's second half over (auction, count) rows
+                    FG_TRY(ring_q5_partial(pl));
+                    int64_t total = 0;
+                    for (int64_t g : pl->ring_groups) total += g;
+                    flockgpu_windows w = whole(total, off_a, lo_a, hi_a);
+                    flockgpu_q5_result r{};
+                    FG_TRY(flockgpu_q5_hot_items_weighted(ctx, pl->ring_auction, pl->ring_count, total, &w, &r));
+                    place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::U64, r.num)}, r.rows, t);
+                    return FLOCKGPU_OK;
+                }
                 // both leaves scan the same relation; whichever was fed holds it (feed_data_sources gives it to the first match)
                 const bool first = A.rows > 0 || pl->leaves[(size_t)fi.leaf_b].rows == 0;
                 const int leaf = first ? fi.leaf_a : fi.leaf_b, col = first ? fi.a_cols[0] : fi.b_cols[0];
@@ -1235,6 +1281,16 @@ struct Exec {
             }
             case NKind::Aggregate:
                 return exec_aggregate(n, t);
+            case NKind::Sort:
+                return exec_sort(n, -1, t);
+            case NKind::Limit: {
+                // ORDER BY ... LIMIT n (context.rs:549-550): the order is computed for every row, only the first n are taken
+                const Node *c = n->in[0].get();
+                if (c->kind == NKind::Sort && pl->fused[(size_t)c->id].kind == kNone) return exec_sort(c, n->limit, t);
+                FG_TRY(exec(c, t));
+                t->rows = std::min<int64_t>(t->rows, n->limit);   // (Utf8 columns keep their byte buffers: the first rows' offsets still hold)
+                return FLOCKGPU_OK;
+            }
             case NKind::Join: {
                 Table L, R;
                 FG_TRY(exec(n->in[0].get(), &L));
@@ -1279,6 +1335,25 @@ struct Exec {
             }
         }
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown node");
+    }
+
+    // SortExec [+ GlobalLimitExec]: the stable order of relops.hpp's sort_rows, then one take of the columns somebody reads
+    int exec_sort(const Node *n, int64_t limit, Table *t) {
+        Table in;
+        FG_TRY(exec(n->in[0].get(), &in));
+        std::vector<SortKey> keys;
+        for (auto &sc : n->sort_cols) {
+            const TCol &c = in.cols[(size_t)sc.col];
+            if (!c.present && !c.c.all_null) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: ORDER BY column was not materialised");
+            keys.push_back(SortKey{c.c, sc.descending});
+        }
+        int32_t *rows = nullptr;
+        FG_TRY(sort_rows(ctx, node_key(pl, n, "sort").c_str(), keys.data(), (int)keys.size(), in.rows, &rows));
+        t->rows = limit >= 0 ? std::min<int64_t>(in.rows, limit) : in.rows;
+        t->cols.assign(n->schema.size(), TCol{});
+        FG_TRY(take_table(n, in, n->required, rows, t->rows, 0, t));
+        for (size_t i = 0; i < t->cols.size(); ++i) t->cols[i].c.all_null = in.cols[i].c.all_null;
+        return FLOCKGPU_OK;
     }
 
     // Final / FinalPartitioned directly over the Partial of the SAME plan (only a repartition in between): the Partial saw the
@@ -1518,8 +1593,44 @@ void release_batch(ArrowArray *a) {
     }
     a->release = nullptr;
 }
+constexpr const char *kPartitionScheme = "flockgpu/fmix32-mulhi/v1";
+constexpr const char *kPartitionSchemeKey = "flockgpu.partition_scheme";
+// Arrow C Data Interface metadata: int32 pair count, then per pair int32 key length, key, int32 value length, value (native endian)
+std::string encode_metadata(const char *key, const char *value) {
+    std::string m;
+    auto put = [&](int32_t v) { m.append(reinterpret_cast<const char *>(&v), 4); };
+    put(1);
+    put((int32_t)strlen(key));
+    m += key;
+    put((int32_t)strlen(value));
+    m += value;
+    return m;
+}
+// value of `key` in an Arrow metadata blob; false when absent (or the blob is malformed)
+bool find_metadata(const char *meta, const char *key, std::string *value) {
+    if (!meta) return false;
+    int32_t n = 0;
+    std::memcpy(&n, meta, 4);
+    const char *p = meta + 4;
+    for (int32_t i = 0; i < n && n < 4096; ++i) {
+        int32_t kl = 0, vl = 0;
+        std::memcpy(&kl, p, 4);
+        if (kl < 0 || kl > (1 << 20)) return false;
+        const char *k = p + 4;
+        std::memcpy(&vl, k + kl, 4);
+        if (vl < 0 || vl > (1 << 20)) return false;
+        const char *v = k + kl + 4;
+        if ((size_t)kl == strlen(key) && !std::memcmp(k, key, (size_t)kl)) {
+            value->assign(v, (size_t)vl);
+            return true;
+        }
+        p = v + vl;
+    }
+    return false;
+}
+
 struct SchemaPriv {
-    std::string format, name;
+    std::string format, name, metadata;
     std::vector<ArrowSchema *> child_ptrs;
     std::vector<std::unique_ptr<ArrowSchema>> children;
 };
@@ -1552,8 +1663,13 @@ void add_schema_child(ArrowSchema *parent, const char *format, const char *name,
     parent->children = p->child_ptrs.data();
     parent->n_children = (int64_t)p->child_ptrs.size();
 }
-void export_schema(const Node *root, ArrowSchema *out) {
+void export_schema(const Node *root, ArrowSchema *out, bool shuffled = false) {
     make_schema(out, "+s", "", false);
+    if (shuffled) {   // the partitions of a shuffling stage say how their rows were placed (flockgpu_plan.h "hash placement")
+        SchemaPriv *p = static_cast<SchemaPriv *>(out->private_data);
+        p->metadata = encode_metadata(kPartitionSchemeKey, kPartitionScheme);
+        out->metadata = p->metadata.data();
+    }
     for (auto &f : root->schema) {
         DevColumn c;
         c.type = f.type;
@@ -1684,7 +1800,7 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
     if ((int)part_off.size() - 1 > capacity) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: no room for the output batch");
     FG_TRY(export_batches(ctx, t, part_off, out_batches));
     plan->fed_bytes = 0;  // export synchronised the stream: every borrowed buffer has been read
-    export_schema(root, out_schema);
+    export_schema(root, out_schema, partitioned && root->kind == NKind::Repartition);
     *n_out = (int)part_off.size() - 1;
     return FLOCKGPU_OK;
 }
@@ -1693,15 +1809,20 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
 
 extern "C" {
 
-int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out) {
+int flockgpu_plan_create_ex(flockgpu_ctx *ctx, const char *plan_json, size_t len, uint32_t flags, flockgpu_plan **out) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
     if (!plan_json || !out) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_create: null argument");
+    if (flags & ~FLOCKGPU_PLAN_GENERIC_ONLY) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_create: unknown flag bits 0x%x", flags & ~FLOCKGPU_PLAN_GENERIC_ONLY);
     *out = nullptr;
     std::unique_ptr<flockgpu_plan> pl(new flockgpu_plan());
     pl->ctx = ctx;
-    FG_TRY(parse_and_build(ctx, plan_json, len, pl.get()));
+    FG_TRY(parse_and_build(ctx, plan_json, len, pl.get(), flags));
     *out = pl.release();
     return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out) {
+    return flockgpu_plan_create_ex(ctx, plan_json, len, 0, out);
 }
 
 int flockgpu_plan_recognise(const char *plan_json, size_t len, int *query) {
@@ -1725,6 +1846,14 @@ int flockgpu_plan_explain(const char *plan_json, size_t len, char *out, size_t c
 void flockgpu_plan_destroy(flockgpu_plan *plan) {
     if (!plan) return;
     flockgpu_ctx *ctx = plan->ctx;
+    if (plan->async_pending) {   // an execute nobody waited for: let it finish, drop what it produced
+        if (ctx_wait(ctx) == FLOCKGPU_OK) {
+            for (int i = 0; i < plan->async_n; ++i)
+                if (plan->async_batches[(size_t)i].release) plan->async_batches[(size_t)i].release(&plan->async_batches[(size_t)i]);
+            if (plan->async_schema.release) plan->async_schema.release(&plan->async_schema);
+        }
+        plan->async_pending = false;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     char prefix[64];
     snprintf(prefix, sizeof prefix, "plan%p.", (const void *)plan);
@@ -1774,17 +1903,38 @@ int flockgpu_plan_output_partitions(const flockgpu_plan *plan) {
 }
 int flockgpu_plan_is_shuffling(const flockgpu_plan *plan) { return plan && plan->ir.root->kind == NKind::Repartition ? 1 : 0; }
 
-int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema, const struct ArrowArray *const *batches,
-                       int n_batches) {
-    if (!plan) return FLOCKGPU_ERR_INVALID;
+// feed_data_sources for one leaf.  validate_only: every check of the feed, nothing moved (flockgpu_plan_feed_pane asks before it
+// opens a new pane, so that a refused feed leaves the ring as it was).
+static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *schema, const struct ArrowArray *const *batches, int n_batches,
+                     bool validate_only) {
     flockgpu_ctx *ctx = plan->ctx;
     if (!schema || input < 0 || input >= (int)plan->ir.leaves.size() || n_batches < 0 || (n_batches && !batches))
         return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: bad argument");
+    if (plan->async_pending) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: an asynchronous execute is in flight (flockgpu_plan_wait first)");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const Leaf &lf = plan->ir.leaves[(size_t)input];
     LeafData &ld = plan->leaves[(size_t)input];
     if (ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: input %d shares another plan's relation; reset the plan first", input);
-    plan->has_retained = false;
+    // hash placement (flockgpu_plan.h): the co-partitioned inputs of one invocation must all have been placed by the same scheme
+    int scheme_state = plan->scheme_state;
+    std::string scheme_tag = plan->scheme_tag;
+    if (lf.co_partitioned) {
+        bool any_rows = false;
+        for (int b = 0; b < n_batches; ++b) any_rows = any_rows || (batches[b] && batches[b]->length > 0);
+        if (any_rows) {
+            std::string tag;
+            const int tagged = find_metadata(schema->metadata, kPartitionSchemeKey, &tag) ? 1 : 0;
+            if (tagged && tag != kPartitionScheme)
+                return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: partitions placed by scheme '%s', this library places by '%s': one key would meet two consumers",
+                            tag.c_str(), kPartitionScheme);
+            if (scheme_state >= 0 && scheme_state != tagged)
+                return fail(ctx, FLOCKGPU_ERR_INVALID,
+                            "plan_feed: mixed hash placement -- this stage was fed partitions tagged '%s' and untagged ones (another engine's hash): "
+                            "every producer of a stage must place rows the same way", kPartitionScheme);
+            scheme_state = tagged;
+            scheme_tag = tag;
+        }
+    }
     std::vector<int> child(lf.schema.size(), -1);
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (!lf.needed[c]) continue;
@@ -1842,12 +1992,18 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
         add_rows += n_keep;
     }
     if (ld.rows + add_rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: more than 2^31 rows per relation");
+    for (size_t c = 0; c < lf.schema.size(); ++c)
+        if (child[c] >= 0 && lf.schema[c].type == ColType::UTF8 && ld.cols[c].bytes + add_bytes[c] >= (int64_t(1) << 31))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: Utf8 column exceeds 2^31 bytes");
+    if (validate_only) return FLOCKGPU_OK;
+    plan->has_retained = false;
+    plan->scheme_state = scheme_state;
+    plan->scheme_tag = scheme_tag;
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (child[c] < 0) continue;
         DevBuf &dc = ld.cols[c];
         void *p = nullptr;
         if (lf.schema[c].type == ColType::UTF8) {
-            if (dc.bytes + add_bytes[c] >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: Utf8 column exceeds 2^31 bytes");
             FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "off"), (size_t)(ld.rows + 1) * 4, (size_t)(ld.rows + add_rows + 1) * 4 + 16, &p));
             if (!dc.offsets) FG_HIP(ctx, hipMemsetAsync(p, 0, 4, ctx->stream));
             dc.offsets = static_cast<int32_t *>(p);
@@ -1919,15 +2075,225 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
     return FLOCKGPU_OK;  // no host wait: the copies are ordered before the plan's kernels on the ctx stream
 }
 
+int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema, const struct ArrowArray *const *batches,
+                       int n_batches) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    if (plan->ring_ppw) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_feed: the plan has an open pane ring (flockgpu_plan_feed_pane, or flockgpu_plan_ring_close first)");
+    return feed_impl(plan, input, schema, batches, n_batches, false);
+}
+
+// ------------------------------------------------------------------ pane ring
+// Drops the oldest pane: the rows (bytes) of the panes that stay move to the front of a second buffer, which then trades places
+// with the first (source and destination of one hipMemcpyAsync must not overlap); q5's group arrays likewise.
+static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *src, size_t keep_bytes, size_t cap_bytes, void **out) {
+    const std::string alt = key + ".alt";
+    void *p = nullptr;
+    FG_TRY(arena_get(ctx, alt.c_str(), std::max<size_t>(cap_bytes, 64), &p));
+    if (keep_bytes) FG_HIP(ctx, hipMemcpyAsync(p, src, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    std::swap(ctx->arena[key], ctx->arena[alt]);
+    *out = p;
+    return FLOCKGPU_OK;
+}
+static int ring_drop_oldest(flockgpu_plan *plan) {
+    flockgpu_ctx *ctx = plan->ctx;
+    if (plan->ring_n == 0) return FLOCKGPU_OK;
+    if (plan->ring_q5) {
+        const int64_t d = plan->ring_groups.empty() ? 0 : plan->ring_groups[0];
+        int64_t total = 0;
+        for (int64_t g : plan->ring_groups) total += g;
+        if (d && total > d) {
+            void *a = nullptr, *c = nullptr;
+            const size_t cap = ctx->arena[leaf_key(plan, 0, 0, "ring.q5a")].cap;
+            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5a"), plan->ring_auction + d, (size_t)(total - d) * 4, cap, &a));
+            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5c"), plan->ring_count + d, (size_t)(total - d) * 4, cap, &c));
+            plan->ring_auction = static_cast<int32_t *>(a);
+            plan->ring_count = static_cast<uint32_t *>(c);
+        }
+        if (!plan->ring_groups.empty()) plan->ring_groups.erase(plan->ring_groups.begin());
+    }
+    for (size_t l = 0; l < plan->leaves.size(); ++l) {
+        LeafData &ld = plan->leaves[l];
+        const Leaf &lf = plan->ir.leaves[l];
+        // (q5's state ring: the leaf holds the newest pane's rows only -- one entry, dropped only when that pane is the oldest, too)
+        if (ld.pane_rows.empty() || (plan->ring_q5 && plan->ring_n > 1)) continue;
+        const int64_t d = ld.pane_rows[0], keep = ld.rows - d;
+        for (size_t c = 0; c < ld.cols.size(); ++c) {
+            DevBuf &dc = ld.cols[c];
+            if (!dc.values) continue;
+            if (lf.schema[c].type == ColType::UTF8) {
+                const int64_t db = ld.pane_bytes[0][c];
+                if (keep > 0 && d > 0) {
+                    void *no = nullptr, *nb = nullptr;
+                    const size_t ocap = ctx->arena[leaf_key(plan, (int)l, (int)c, "off")].cap, bcap = ctx->arena[leaf_key(plan, (int)l, (int)c, "bytes")].cap;
+                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "off"), dc.offsets + d, (size_t)(keep + 1) * 4, ocap, &no));
+                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "bytes"), static_cast<uint8_t *>(dc.values) + db, (size_t)(dc.bytes - db), bcap, &nb));
+                    dc.offsets = static_cast<int32_t *>(no);
+                    dc.values = nb;
+                    if (db) FG_TRY(add_i32(ctx, dc.offsets, keep + 1, (int32_t)-db));
+                } else if (keep == 0 && dc.offsets) {
+                    FG_HIP(ctx, hipMemsetAsync(dc.offsets, 0, 4, ctx->stream));
+                }
+                dc.bytes -= db;
+            } else if (keep > 0 && d > 0) {
+                const size_t w = col_width(lf.schema[c].type);
+                void *nv = nullptr;
+                const size_t cap = ctx->arena[leaf_key(plan, (int)l, (int)c, "val")].cap;
+                FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "val"), static_cast<uint8_t *>(dc.values) + (size_t)d * w, (size_t)keep * w, cap, &nv));
+                dc.values = nv;
+            }
+        }
+        ld.rows = keep;
+        ld.pane_rows.erase(ld.pane_rows.begin());
+        ld.pane_bytes.erase(ld.pane_bytes.begin());
+    }
+    plan->ring_first += 1;
+    plan->ring_n -= 1;
+    if (plan->ring_n == 0) plan->ring_newest_done = false;
+    return FLOCKGPU_OK;
+}
+
+// q5's state ring: the newest pane's Partial aggregate -- HashAggregateExec(Partial) COUNT GROUP BY auction over the pane's rows,
+// counted ONCE -- appended to the retained groups.
+static int ring_q5_partial(flockgpu_plan *plan) {
+    flockgpu_ctx *ctx = plan->ctx;
+    if (plan->ring_newest_done || plan->ring_n == 0) return FLOCKGPU_OK;
+    // the bids sit in whichever of the plan's two `bid` leaves was fed (both scan the same relation)
+    const LeafData *ld = nullptr;
+    int col = -1;
+    for (size_t l = 0; l < plan->leaves.size() && !ld; ++l)
+        for (size_t c = 0; c < plan->ir.leaves[l].schema.size(); ++c)
+            if (plan->ir.leaves[l].needed[c] && plan->ir.leaves[l].schema[c].type == ColType::I32 && plan->leaves[l].rows > 0 && plan->leaves[l].cols[c].values) {
+                ld = &plan->leaves[l];
+                col = (int)c;
+                break;
+            }
+    int64_t before = 0;
+    for (size_t i = 0; i + 1 < plan->ring_groups.size(); ++i) before += plan->ring_groups[i];
+    int64_t groups = 0;
+    if (ld) {
+        int64_t off[2] = {0, ld->rows};
+        int32_t lo[1] = {0}, hi[1] = {1};
+        flockgpu_bid_cols bc{static_cast<const int32_t *>(ld->cols[(size_t)col].values), nullptr, nullptr, nullptr, ld->rows};
+        flockgpu_windows w{off, 1, lo, hi, 1};
+        flockgpu_q5_partial_result r{};
+        FG_TRY(flockgpu_q5_partial_counts(ctx, &bc, &w, &r));
+        groups = r.rows;
+        void *a = nullptr, *c = nullptr;
+        FG_TRY(grow(ctx, leaf_key(plan, 0, 0, "ring.q5a"), (size_t)before * 4, (size_t)(before + groups) * 4 + 64, &a));
+        FG_TRY(grow(ctx, leaf_key(plan, 0, 0, "ring.q5c"), (size_t)before * 4, (size_t)(before + groups) * 4 + 64, &c));
+        plan->ring_auction = static_cast<int32_t *>(a);
+        plan->ring_count = static_cast<uint32_t *>(c);
+        if (groups) {
+            FG_HIP(ctx, hipMemcpyAsync(plan->ring_auction + before, r.auction, (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(plan->ring_count + before, r.count, (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    plan->ring_groups.back() = groups;
+    plan->ring_newest_done = true;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_ring_open(flockgpu_plan *plan, int panes_per_window) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (panes_per_window < 1 || panes_per_window > 4096) return fail(ctx, FLOCKGPU_ERR_INVALID, "ring_open: %d panes per window", panes_per_window);
+    if (plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "ring_open: the plan already has an open ring");
+    for (auto &ld : plan->leaves)
+        if (ld.rows || ld.borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "ring_open: the plan holds inputs (flockgpu_plan_reset first)");
+    plan->ring_ppw = panes_per_window;
+    plan->ring_first = 0;
+    plan->ring_n = 0;
+    plan->ring_q5 = plan->query == 5 && !plan->generic_only;
+    plan->ring_groups.clear();
+    plan->ring_newest_done = false;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_ring_state(const flockgpu_plan *plan, int64_t *first_pane, int *n_panes, int *panes_per_window) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    if (first_pane) *first_pane = plan->ring_first;
+    if (n_panes) *n_panes = plan->ring_n;
+    if (panes_per_window) *panes_per_window = plan->ring_ppw;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, const struct ArrowSchema *schema,
+                            const struct ArrowArray *const *batches, int n_batches) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (!plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the plan has no open ring (flockgpu_plan_ring_open)");
+    if (input < 0 || input >= (int)plan->leaves.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: bad argument");
+    const int64_t newest = plan->ring_first + plan->ring_n - 1;
+    const bool begin = plan->ring_n == 0 || pane_id == newest + 1;
+    if (!begin && pane_id != newest)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: pane %lld out of order -- the ring holds panes [%lld, %lld], only pane %lld or %lld can be fed",
+                    (long long)pane_id, (long long)plan->ring_first, (long long)newest, (long long)newest, (long long)(newest + 1));
+    if (begin && plan->ring_n == plan->ring_ppw)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the ring is full (%d panes): flockgpu_plan_reset retires the oldest before pane %lld begins",
+                    plan->ring_ppw, (long long)pane_id);
+    // every check of the feed first: a refused feed must leave the ring as it was
+    if (n_batches > 0 || schema) FG_TRY(feed_impl(plan, input, schema, batches, n_batches, true));
+    if (begin) {
+        if (plan->ring_q5 && plan->ring_n > 0) {   // the pane that closes leaves its groups behind, its rows go
+            FG_TRY(ring_q5_partial(plan));
+            for (auto &ld : plan->leaves) {
+                ld.rows = 0;
+                for (auto &c : ld.cols) c.bytes = 0;
+                ld.pane_rows.clear();
+                ld.pane_bytes.clear();
+            }
+        }
+        if (plan->ring_n == 0) plan->ring_first = pane_id;
+        plan->ring_n += 1;
+        for (size_t l = 0; l < plan->leaves.size(); ++l) {
+            plan->leaves[l].pane_rows.push_back(0);
+            plan->leaves[l].pane_bytes.emplace_back(plan->leaves[l].cols.size(), 0);
+        }
+        if (plan->ring_q5) plan->ring_groups.push_back(0);
+        plan->ring_newest_done = false;
+    }
+    if (n_batches == 0) return FLOCKGPU_OK;   // an empty pane still advances the ring
+    LeafData &ld = plan->leaves[(size_t)input];
+    const int64_t rows_before = ld.rows;
+    std::vector<int64_t> bytes_before(ld.cols.size());
+    for (size_t c = 0; c < ld.cols.size(); ++c) bytes_before[c] = ld.cols[c].bytes;
+    FG_TRY(feed_impl(plan, input, schema, batches, n_batches, false));
+    ld.pane_rows.back() += ld.rows - rows_before;
+    for (size_t c = 0; c < ld.cols.size(); ++c) ld.pane_bytes.back()[c] += ld.cols[c].bytes - bytes_before[c];
+    plan->ring_newest_done = false;   // (more rows of the newest pane: its groups are counted again from its rows)
+    if (plan->ring_q5) plan->ring_groups.back() = 0;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_ring_close(flockgpu_plan *plan) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "ring_close: an asynchronous execute is in flight");
+    plan->ring_ppw = 0;
+    plan->ring_n = 0;
+    plan->ring_q5 = false;
+    plan->ring_groups.clear();
+    plan->ring_newest_done = false;
+    return flockgpu_plan_reset(plan);
+}
+
 int flockgpu_plan_reset(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
+    if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_reset: an asynchronous execute is in flight (flockgpu_plan_wait first)");
     // borrowed pinned buffers may still be read by the DMA engine: the caller is about to drop them
     if (plan->fed_bytes) (void)hipStreamSynchronize(plan->ctx->stream);
     plan->fed_bytes = 0;
     plan->has_retained = false;   // (its columns may alias the leaves, and the arena buffers behind it are reused by the next execute)
+    plan->scheme_state = -1;
+    plan->scheme_tag.clear();
+    if (plan->ring_ppw) {   // the window ends: the oldest pane of a full ring goes, the others stay on the device
+        if (plan->ring_n == plan->ring_ppw) FG_TRY(ring_drop_oldest(plan));
+        return FLOCKGPU_OK;
+    }
     for (auto &ld : plan->leaves) {
         ld.rows = 0;
         ld.dropped = 0;
+        ld.pane_rows.clear();
+        ld.pane_bytes.clear();
         for (auto &c : ld.cols) {
             c.bytes = 0;
             if (ld.borrowed) c.values = nullptr, c.offsets = nullptr;   // the donor's memory: never grown or appended to from here
@@ -1943,6 +2309,7 @@ int flockgpu_plan_feed_shared(flockgpu_plan *plan, int input, const flockgpu_pla
     if (!donor || donor == plan || input < 0 || input >= (int)plan->ir.leaves.size() || donor_input < 0 || donor_input >= (int)donor->ir.leaves.size())
         return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: bad argument");
     if (donor->ctx != ctx) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: the two plans live on different contexts (streams)");
+    if (plan->ring_ppw || donor->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_shared: a plan with an open pane ring feeds panes (flockgpu_plan_feed_pane)");
     const Leaf &lf = plan->ir.leaves[(size_t)input], &df = donor->ir.leaves[(size_t)donor_input];
     LeafData &ld = plan->leaves[(size_t)input];
     const LeafData &dd = donor->leaves[(size_t)donor_input];
@@ -2028,6 +2395,7 @@ int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan 
     flockgpu_ctx *ctx = plan->ctx;
     if (!producer || producer == plan || input < 0 || input >= (int)plan->ir.leaves.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: bad argument");
     if (producer->ctx != ctx) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: the two plans live on different contexts (streams)");
+    if (plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: a plan with an open pane ring feeds panes (flockgpu_plan_feed_pane)");
     if (!producer->has_retained) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed_from: the producer holds no retained result (flockgpu_plan_execute_retain)");
     const Leaf &lf = plan->ir.leaves[(size_t)input];
     LeafData &ld = plan->leaves[(size_t)input];
@@ -2060,6 +2428,7 @@ int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan 
 int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batch) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (!out_schema || !out_batch) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute: null output");
+    if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute: an asynchronous execute is in flight (flockgpu_plan_wait first)");
     int n = 0;
     return run_plan(plan, false, out_schema, out_batch, 1, &n);
 }
@@ -2068,7 +2437,56 @@ int flockgpu_plan_execute_partitioned(flockgpu_plan *plan, struct ArrowSchema *o
                                       int *n_partitions) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (!out_schema || !out_batches || !n_partitions || capacity < 1) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute_partitioned: bad argument");
+    if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute_partitioned: an asynchronous execute is in flight (flockgpu_plan_wait first)");
     return run_plan(plan, true, out_schema, out_batches, capacity, n_partitions);
+}
+
+// execute on the ctx's worker thread (the reference: one tokio task per plan, context.rs:172-191); the outputs wait in the plan
+int flockgpu_plan_execute_async(flockgpu_plan *plan, int partitioned) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (plan->async_pending) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_execute_async: a call is already in flight on this plan");
+    const int cap = partitioned && plan->ir.root->kind == NKind::Repartition ? plan->ir.root->n_parts : 1;
+    plan->async_batches.assign((size_t)cap, ArrowArray{});
+    plan->async_schema = ArrowSchema{};
+    plan->async_n = 0;
+    FG_TRY(ctx_submit(ctx, [plan, partitioned, cap] {
+        return run_plan(plan, partitioned != 0, &plan->async_schema, plan->async_batches.data(), cap, &plan->async_n);
+    }));
+    plan->async_pending = true;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_plan_wait(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batches, int capacity, int *n_partitions) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (!plan->async_pending) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_wait: no asynchronous execute was started on this plan");
+    const int rc = ctx_wait(ctx);
+    plan->async_pending = false;
+    if (rc != FLOCKGPU_OK) return rc;
+    auto drop = [&] {
+        for (int i = 0; i < plan->async_n; ++i)
+            if (plan->async_batches[(size_t)i].release) plan->async_batches[(size_t)i].release(&plan->async_batches[(size_t)i]);
+        if (plan->async_schema.release) plan->async_schema.release(&plan->async_schema);
+    };
+    if (!out_schema || !out_batches || capacity < plan->async_n) {
+        drop();
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_wait: %d output batches, room for %d", plan->async_n, capacity);
+    }
+    // (Arrow C Data Interface: a struct is moved by copying it bitwise and marking the source released)
+    *out_schema = plan->async_schema;
+    plan->async_schema.release = nullptr;
+    for (int i = 0; i < plan->async_n; ++i) {
+        out_batches[i] = plan->async_batches[(size_t)i];
+        plan->async_batches[(size_t)i].release = nullptr;
+    }
+    if (n_partitions) *n_partitions = plan->async_n;
+    return FLOCKGPU_OK;
+}
+
+const char *flockgpu_plan_partition_scheme(void) { return kPartitionScheme; }
+int flockgpu_plan_check_partition_scheme(const char *scheme) {
+    return scheme && !strcmp(scheme, kPartitionScheme) ? FLOCKGPU_OK : FLOCKGPU_ERR_UNSUPPORTED;
 }
 
 int flockgpu_host_alloc(size_t bytes, void **out) {

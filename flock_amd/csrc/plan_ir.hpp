@@ -2,11 +2,12 @@
 // `Arc<dyn ExecutionPlan>` (flock/src/runtime/context.rs:477-480; dialect: SURVEY.md appendix C, fixtures
 // flock/src/tests/data/plan/*.json) parsed into a small operator tree with derived schemas.  Host-side only.
 //
-// Kept nodes: memory_exec (Scan), filter_exec, projection_exec, hash_aggregate_exec, hash_join_exec and
-// repartition_exec with Hash partitioning.  coalesce_batches_exec, repartition_exec RoundRobinBatch, merge_exec /
-// coalesce_partitions_exec change neither the row multiset nor the schema and are dropped.
-// Anything else (sort_exec, global_limit_exec, unknown expressions / types) makes the plan UNSUPPORTED: the host keeps
-// its own engine for it.
+// Kept nodes: memory_exec (Scan), filter_exec, projection_exec, hash_aggregate_exec, hash_join_exec,
+// repartition_exec with Hash partitioning, sort_exec (ORDER BY over columns: the reference's own boundary goldens end in it,
+// flock/src/runtime/context.rs:471,549; the splitter cuts stages at it, distributed_plan/stage.rs:337) and global_limit_exec /
+// local_limit_exec.  coalesce_batches_exec, repartition_exec RoundRobinBatch, merge_exec / coalesce_partitions_exec change
+// neither the row multiset nor the schema and are dropped.  Anything else (window functions, outer
+// joins, unknown expressions / types) makes the plan UNSUPPORTED: the host keeps its own engine for it.
 #pragma once
 #include <set>
 #include <sstream>
@@ -35,7 +36,12 @@ struct Expr {
     std::unique_ptr<Expr> l, r;  // Bin operands; Cast operand in l
 };
 
-enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition };
+enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit };
+struct SortCol {
+    int col = -1;            // input column
+    bool descending = false;
+    bool nulls_first = false;  // parsed and carried; device columns hold no NULLs (a NULL that could reach a sort is refused at feed)
+};
 struct Agg {
     std::string fn;  // "count" | "max" | "min" | "sum" | "avg"
     int arg = -1;    // Partial: input column of the argument (-1: a literal, COUNT(UInt8(1))); Final: the first state column
@@ -59,8 +65,11 @@ struct Node {
     std::vector<Agg> aggs;
     int on_l = -1, on_r = -1;       // Join: key columns (left input, right input)
     int on_l2 = -1, on_r2 = -1;     // Join: second key pair (q9: auction = id AND price = final), -1 when there is one
+    bool join_partitioned = false;  // Join: mode=Partitioned (both inputs arrive hash-partitioned on the keys)
     std::vector<int> hash_cols;     // Repartition
     int n_parts = 0;
+    std::vector<SortCol> sort_cols; // Sort: ORDER BY keys, most significant first
+    int64_t limit = -1;             // Limit: rows kept
     std::vector<char> required;     // per output column: needed by an ancestor (or by the plan output)
 };
 
@@ -71,6 +80,10 @@ struct Leaf {
     // per column: a row whose value here is NULL can be dropped at the scan without changing the plan's result (the column
     // only feeds inner-join keys, MAX arguments or comparisons) -- how the NULL `maxn` of an empty partition is ingested
     std::vector<char> null_droppable;
+    // the leaf feeds a HashJoinExec mode=Partitioned / a FinalPartitioned aggregate without a hash repartition of this plan in
+    // between: its batches were placed by the PRODUCING stage's hash, and every such leaf of the plan must have been placed by
+    // the same one (flockgpu_plan.h "hash placement")
+    bool co_partitioned = false;
 };
 
 struct Plan {
@@ -380,6 +393,7 @@ struct Builder {
         } else if (t == "hash_join_exec") {
             n->kind = NKind::Join;
             if (j->s("join_type") != "Inner") { fail("only Inner joins"); return nullptr; }
+            n->join_partitioned = j->s("mode") == "Partitioned";
             auto l = node(j->get("left"), depth + 1);
             if (!l) return nullptr;
             auto r = node(j->get("right"), depth + 1);
@@ -411,6 +425,35 @@ struct Builder {
             n->schema.insert(n->schema.end(), r->schema.begin(), r->schema.end());
             n->in.push_back(std::move(l));
             n->in.push_back(std::move(r));
+        } else if (t == "sort_exec") {
+            n->kind = NKind::Sort;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            n->schema = in->schema;
+            const JValue *ex = j->get("expr");
+            if (!ex || ex->kind != JValue::Arr || ex->arr.empty()) { fail("sort_exec without expr"); return nullptr; }
+            for (auto &k : ex->arr) {
+                const JValue *e = k->get("expr");
+                if (!e || etag(e) != "column") { fail("ORDER BY on something other than a column"); return nullptr; }
+                SortCol sc;
+                sc.col = resolve(e, n->schema);
+                if (sc.col < 0) { fail("ORDER BY column '" + e->s("name") + "' not in the input schema"); return nullptr; }
+                const JValue *opt = k->get("options");
+                const JValue *d = opt ? opt->get("descending") : nullptr, *nf = opt ? opt->get("nulls_first") : nullptr;
+                sc.descending = d && d->kind == JValue::Bool && d->b;
+                sc.nulls_first = nf && nf->kind == JValue::Bool && nf->b;
+                n->sort_cols.push_back(sc);
+            }
+            n->in.push_back(std::move(in));
+        } else if (t == "global_limit_exec" || t == "local_limit_exec") {
+            n->kind = NKind::Limit;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            n->schema = in->schema;
+            const JValue *l = j->get("limit");
+            if (!l || l->kind != JValue::Num || !l->is_int || l->inum < 0) { fail("limit without a row count"); return nullptr; }
+            n->limit = l->inum;
+            n->in.push_back(std::move(in));
         } else {
             fail("execution_plan '" + t + "' is not supported");
             return nullptr;
@@ -482,6 +525,15 @@ inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
             mark_required(p, n->in[0].get(), r);
             break;
         }
+        case NKind::Sort: {
+            std::vector<char> r = req;
+            for (auto &k : n->sort_cols) need(r, k.col);
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
+        case NKind::Limit:
+            mark_required(p, n->in[0].get(), req);
+            break;
     }
 }
 
@@ -537,9 +589,33 @@ inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> 
             break;
         }
         case NKind::Repartition:
+        case NKind::Sort:   // (the order of the rows that remain does not depend on the rows that were dropped)
             mark_null_droppable(p, n->in[0].get(), droppable);
             break;
+        case NKind::Limit:  // WHICH rows make the first n depends on every row below: nothing may be dropped early
+            mark_null_droppable(p, n->in[0].get(), std::vector<char>(n->in[0]->schema.size(), 0));
+            break;
     }
+}
+
+inline void mark_co_partitioned(Plan *p, const Node *n, bool under) {
+    switch (n->kind) {
+        case NKind::Scan:
+            if (under) p->leaves[(size_t)n->leaf].co_partitioned = true;
+            return;
+        case NKind::Repartition:   // this plan places the rows itself from here on
+            under = false;
+            break;
+        case NKind::Join:
+            if (n->join_partitioned) under = true;
+            break;
+        case NKind::Aggregate:
+            if (n->mode == "FinalPartitioned") under = true;
+            break;
+        default:
+            break;
+    }
+    for (auto &c : n->in) mark_co_partitioned(p, c.get(), under);
 }
 
 inline bool build_plan(const JValue *root, Plan *plan) {
@@ -551,6 +627,7 @@ inline bool build_plan(const JValue *root, Plan *plan) {
     }
     mark_required(plan, plan->root.get(), std::vector<char>(plan->root->schema.size(), 1));
     mark_null_droppable(plan, plan->root.get(), std::vector<char>(plan->root->schema.size(), 0));
+    mark_co_partitioned(plan, plan->root.get(), false);
     return true;
 }
 

@@ -758,7 +758,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     // the kernels take 90 us).  After a call that did not qualify the statistics are read first, as before.
     // iterations of a person tile per build workgroup: all eight when the tiles alone fill the chip, else two
     int build_y_shift = st_p.n_tiles >= (int64_t)ctx->num_cus * 4 ? 3 : 1;
-    if (const char *e = getenv("FLOCKGPU_Q3_YSHIFT")) build_y_shift = atoi(e);   // (experiment knob: iterations of a tile per workgroup = 1 << shift)
+    if (const char *e = exp_env("FLOCKGPU_Q3_YSHIFT")) build_y_shift = atoi(e);   // (experiment knob: iterations of a tile per workgroup = 1 << shift)
     std::vector<int64_t> &regime = ctx->host_i64["q3.dense_regime"];
     // 2: dense, every window gapless last time (bit blocks, no row table) -- also where a ctx starts; 1: dense with the row table;
     // 0: the last call took the general path
@@ -785,10 +785,10 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
     std::vector<int64_t> &fast = ctx->host_i64["q3.fast_hint"];   // {rows the take is laid out for, byte capacity x 3, valid}
     if (fast.size() != 5) fast.assign(5, 0);
     bool fast_done = false;
-    static const bool no_fast = getenv("FLOCKGPU_Q3_NO_FAST") != nullptr;   // (A/B knob)
+    static const bool no_fast = exp_env("FLOCKGPU_Q3_NO_FAST") != nullptr;   // (A/B knob)
     // (beyond a few thousand tiles the self-scans cost more than the scan launches they replace: 1e9 events, 7324 + 3 x 5860 tiles, ran
     // 0.571 vs 0.530 ms -- and there the launches and waits are a small part of the call anyway)
-    static const int64_t fast_max_tiles = getenv("FLOCKGPU_Q3_FAST_MAX_TILES") ? atoll(getenv("FLOCKGPU_Q3_FAST_MAX_TILES")) : 2048;
+    static const int64_t fast_max_tiles = exp_env("FLOCKGPU_Q3_FAST_MAX_TILES") ? atoll(exp_env("FLOCKGPU_Q3_FAST_MAX_TILES")) : 2048;
     bool fast_ok = try_dense && bits_mode && fast[4] && !no_fast && st_a.n_tiles > 0 && st_a.n_tiles <= fast_max_tiles && st_p.n_tiles > 0;
     for (int w = 0; w < n_win && fast_ok; ++w)
         if (pe[w] == pb[w] && ae[w] > ab[w]) fast_ok = false;   // (a window without persons leaves its table entry unwritten)

@@ -1333,7 +1333,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: auction / count columns must be 16-byte aligned");
     FG_HIP(ctx, hipSetDevice(ctx->device));
     const int n_win = win->n_windows, n_panes = win->n_panes;
-    static const bool plain_clear = getenv("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (experiment knob: cached stores in the clear, as in round 1)
+    static const bool plain_clear = exp_env("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (experiment knob: cached stores in the clear, as in round 1)
 
     // pane -> windows CSR, window row counts
     std::vector<int32_t> ptr(n_panes + 1, 0), idx;
@@ -1433,7 +1433,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     // found most tiles wider than the fast kernel's histogram, left when a sample of the partition's tiles is narrow again
     std::vector<int64_t> &wide_hint = ctx->host_i64["q5.wide_hint"];
     if (wide_hint.size() != 1) wide_hint.assign(1, 0);
-    static const bool no_wide = getenv("FLOCKGPU_Q5_NO_WIDE") != nullptr;   // (A/B knob)
+    static const bool no_wide = exp_env("FLOCKGPU_Q5_NO_WIDE") != nullptr;   // (A/B knob)
     bool wide_mode = wide_hint[0] != 0 && !weight && !part && !no_wide && dense;
     bool speculate = dense && !part && hint[2] && hint[0] > 0 && !wide_mode;   // (wide mode sizes its digit count from the host-side layout)
     auto host_layout = [&]() -> int {   // the same rules on the host: first call of a ctx, the Partial stage, a declined speculation
@@ -1571,10 +1571,10 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
         // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
         const uint64_t per_win = n_win > 0 ? std::max<uint64_t>(cap, scan_total / n_win / 4) : cap;
-        static const bool no_hop2 = getenv("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
+        static const bool no_hop2 = exp_env("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
         const bool pane_walk = hop2 && !no_hop2;
         const uint64_t per_pane = n_panes > 0 ? std::max<uint64_t>(cap, cnt_total / (uint64_t)n_panes / 4) : cap;
-        static const int hop2_blocks = getenv("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(getenv("FLOCKGPU_Q5_HOP2_BLOCKS")) : 32;   // (max pass 0.062 / 0.073 / 0.108 ms with 32 / 64 / 128 per pane)
+        static const int hop2_blocks = exp_env("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(exp_env("FLOCKGPU_Q5_HOP2_BLOCKS")) : 32;   // (max pass 0.062 / 0.073 / 0.108 ms with 32 / 64 / 128 per pane)
         const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)(pane_walk ? per_pane : per_win), kBlock * 2), 1), pane_walk ? hop2_blocks : 64);
         uint32_t *block_max = nullptr;
         const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_walk ? 2 : 1);
@@ -1898,7 +1898,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     out->win_groups = wgrp.data();
     out->rows = n_sel;
     }
-    static const bool no_preclean = getenv("FLOCKGPU_Q5_NO_PRECLEAN") != nullptr || getenv("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (A/B knobs)
+    static const bool no_preclean = exp_env("FLOCKGPU_Q5_NO_PRECLEAN") != nullptr || exp_env("FLOCKGPU_Q5_PLAIN_CLEAR") != nullptr;   // (A/B knobs)
     if (speculate && dense && cnt_total > 0 && !no_preclean) {   // clean up after use (see `preclean` above); the results above are already on their way
         int32_t *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));

@@ -482,6 +482,82 @@ uint64_t pow2_at_least(uint64_t v) {
         FG_TRY(check_launch((ctx), name));                                                                            \
     } while (0)
 
+// ---- ORDER BY: order-preserving 64-bit sub-keys in the current row order, their range, the 32-bit digits a radix sort takes
+// chunk: Utf8 only -- -1 = the value's length, c >= 0 = bytes [8c, 8c + 8) big-endian, zero padded
+__device__ __forceinline__ uint64_t sort_norm(const void *__restrict__ v, const int32_t *__restrict__ off, int32_t type, int64_t r, int32_t chunk) {
+    switch (type) {
+        case (int32_t)ColType::I32: return (uint64_t)((int64_t) static_cast<const int32_t *>(v)[r]) ^ (uint64_t(1) << 63);
+        case (int32_t)ColType::I64: return (uint64_t) static_cast<const int64_t *>(v)[r] ^ (uint64_t(1) << 63);
+        case (int32_t)ColType::U64: return static_cast<const uint64_t *>(v)[r];
+        case (int32_t)ColType::F64: {
+            const uint64_t b = static_cast<const uint64_t *>(v)[r];
+            return (b >> 63) ? ~b : (b | (uint64_t(1) << 63));
+        }
+        default: {
+            const int32_t b = off[r], len = off[r + 1] - b;
+            if (chunk < 0) return (uint64_t)(uint32_t)len;
+            const uint8_t *p = static_cast<const uint8_t *>(v) + b;
+            uint64_t k = 0;
+            for (int i = 0; i < 8; ++i) {
+                const int32_t at = chunk * 8 + i;
+                k = (k << 8) | (at < len ? (uint64_t)p[at] : 0u);
+            }
+            return k;
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void sort_norm_kernel(const void *__restrict__ v, const int32_t *__restrict__ off, int32_t type,
+                                                           const int32_t *__restrict__ perm, int64_t n, int32_t chunk, int32_t descending,
+                                                           uint64_t *__restrict__ out, uint64_t *__restrict__ minmax) {
+    uint64_t mn = ~uint64_t(0), mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t k = sort_norm(v, off, type, perm ? perm[i] : i, chunk);
+        if (descending) k = ~k;
+        out[i] = k;
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0 && mn <= mx) {
+        atomicMin(reinterpret_cast<unsigned long long *>(&minmax[0]), (unsigned long long)mn);
+        atomicMax(reinterpret_cast<unsigned long long *>(&minmax[1]), (unsigned long long)mx);
+    }
+}
+__global__ __launch_bounds__(kBlock) void sort_minmax_init_kernel(uint64_t *__restrict__ minmax) {
+    if (threadIdx.x == 0) { minmax[0] = ~uint64_t(0); minmax[1] = 0; }
+}
+// digits[i] = bits [shift, shift + 32) of (key[i] - base); `perm` re-orders the keys that were computed for an earlier order
+__global__ __launch_bounds__(kBlock) void sort_digit_kernel(const uint64_t *__restrict__ key, const uint32_t *__restrict__ order, int64_t n,
+                                                            uint64_t base, int32_t shift, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = (int32_t)(uint32_t)((key[order ? order[i] : i] - base) >> shift);
+}
+__global__ __launch_bounds__(kBlock) void iota_i32_kernel(int32_t *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(kBlock) void compose_perm_kernel(const int32_t *__restrict__ perm, const uint32_t *__restrict__ order, int64_t n,
+                                                              int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = perm ? perm[order[i]] : (int32_t)order[i];
+}
+__global__ __launch_bounds__(kBlock) void utf8_max_len_kernel(const int32_t *__restrict__ off, int64_t n, uint64_t *__restrict__ minmax) {
+    uint64_t mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t l = (uint64_t)(uint32_t)(off[i + 1] - off[i]);
+        mx = l > mx ? l : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t b = __shfl_xor(mx, o, 64);
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) atomicMax(reinterpret_cast<unsigned long long *>(&minmax[1]), (unsigned long long)mx);
+}
+
 }  // namespace
 
 namespace flockgpu {
@@ -490,6 +566,79 @@ int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t 
     if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "key column must be an integer column");
     if (rows <= 0) return FLOCKGPU_OK;
     RELOPS_LAUNCH(ctx, "widen_kernel", widen_kernel, rows, col.values, (int32_t)col.type, rows, out);
+    return FLOCKGPU_OK;
+}
+
+int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows) {
+    const std::string base(name);
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relations are limited to 2^31 rows", name);
+    int32_t *perm[2] = {nullptr, nullptr};   // the order so far, ping-pong
+    FG_TRY(arena_get_t(ctx, (base + ".perm0").c_str(), (size_t)rows + 4, &perm[0]));
+    FG_TRY(arena_get_t(ctx, (base + ".perm1").c_str(), (size_t)rows + 4, &perm[1]));
+    *out_rows = perm[0];
+    if (rows == 0) return FLOCKGPU_OK;
+    uint64_t *nk = nullptr, *d_mm = nullptr, *h_mm = nullptr;
+    int32_t *digits = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".key").c_str(), (size_t)rows + 2, &nk));
+    FG_TRY(arena_get_t(ctx, (base + ".digit").c_str(), (size_t)rows + 4, &digits));
+    FG_TRY(arena_get_t(ctx, (base + ".minmax").c_str(), 2, &d_mm));
+    FG_TRY(pinned_get_t(ctx, (base + ".minmax").c_str(), 2, &h_mm));
+    const unsigned grid = grid_for(ctx, rows);
+    const int32_t *cur = nullptr;   // null: the identity
+    int at = 0;                     // perm[at] receives the next order
+    auto read_range = [&]() -> int {
+        FG_HIP(ctx, hipMemcpyAsync(h_mm, d_mm, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FLOCKGPU_OK;
+    };
+    // one stable pass over a 64-bit sub-key of column `k` (chunk: Utf8 only)
+    auto pass = [&](const SortKey &k, int32_t chunk) -> int {
+        hipLaunchKernelGGL(sort_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_mm);
+        hipLaunchKernelGGL(sort_norm_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, k.col.values, k.col.offsets, (int32_t)k.col.type, cur, rows, chunk,
+                           k.descending ? 1 : 0, nk, d_mm);
+        FG_TRY(check_launch(ctx, "sort_norm_kernel"));
+        FG_TRY(read_range());
+        const uint64_t lo = h_mm[0], span = h_mm[1] - h_mm[0];
+        if (span == 0) return FLOCKGPU_OK;   // every row ties on this sub-key
+        int bits = 1;
+        while (bits < 64 && (span >> bits)) ++bits;
+        const uint32_t *order = nullptr;     // the order of this sub-key's rows after its lower 32 bits were sorted
+        for (int shift = 0; shift < bits; shift += 32) {
+            const int nb = std::min(32, bits - shift);
+            hipLaunchKernelGGL(sort_digit_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, nk, order, rows, lo, shift, digits);
+            FG_TRY(check_launch(ctx, "sort_digit_kernel"));
+            int32_t *sk = nullptr;
+            uint32_t *sv = nullptr;
+            FG_TRY(radix_sort_pairs(ctx, (base + (shift ? ".hi" : ".lo")).c_str(), digits, order, rows, 0, nb, &sk, &sv));
+            order = sv;
+        }
+        hipLaunchKernelGGL(compose_perm_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, cur, order, rows, perm[at]);
+        FG_TRY(check_launch(ctx, "compose_perm_kernel"));
+        cur = perm[at];
+        at ^= 1;
+        return FLOCKGPU_OK;
+    };
+    for (int ki = n_keys - 1; ki >= 0; --ki) {
+        const SortKey &k = keys[ki];
+        if (k.col.all_null) continue;
+        if (k.col.type != ColType::UTF8) {
+            FG_TRY(pass(k, 0));
+            continue;
+        }
+        hipLaunchKernelGGL(sort_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_mm);
+        hipLaunchKernelGGL(utf8_max_len_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, k.col.offsets, rows, d_mm);
+        FG_TRY(check_launch(ctx, "utf8_max_len_kernel"));
+        FG_TRY(read_range());
+        const int64_t max_len = (int64_t)h_mm[1];
+        FG_TRY(pass(k, -1));                                            // length: decides between a string and its zero-padded twin
+        for (int32_t c = (int32_t)((max_len + 7) / 8) - 1; c >= 0; --c) FG_TRY(pass(k, c));
+    }
+    if (!cur) {   // no key moved anything: the identity
+        hipLaunchKernelGGL(iota_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, perm[0], rows);
+        FG_TRY(check_launch(ctx, "iota_i32_kernel"));
+        cur = perm[0];
+    }
+    *out_rows = const_cast<int32_t *>(cur);
     return FLOCKGPU_OK;
 }
 

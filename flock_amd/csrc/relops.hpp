@@ -12,6 +12,7 @@
 #include <string>
 
 #include "gather.hpp"
+#include "sort.hpp"
 
 namespace flockgpu {
 
@@ -112,6 +113,20 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
 // mix of flockgpu_partition_by_key.  part_offsets: host, n_parts + 1.
 int partition_rows_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, int32_t n_parts, int32_t **out_rows,
                          std::vector<int64_t> *part_offsets);
+
+// ---- ORDER BY (SortExec; the reference's boundary goldens end in it, flock/src/runtime/context.rs:471,549, and the stage splitter
+// cuts at it, flock/src/distributed_plan/stage.rs:337): the permutation of [0, rows) that orders the rows by `keys`, first key most
+// significant, ties in input order (stable).  LSD over the keys: every key becomes an order-preserving unsigned 64-bit value in the
+// current order (Int32 / Int64 / Timestamp: sign bit flipped; UInt64: as is; Float64: IEEE total order, NaN last; Utf8: bytewise
+// lexicographic -- the length as the least significant sub-key, then 8-byte big-endian chunks from the last to the first;
+// descending: complemented), its range is read back (one wait per sub-key; a constant sub-key costs no pass) and the stable radix
+// passes of sort.hpp run over the bits the range needs.  *out_rows: ctx-owned, `rows` entries.  Columns hold no NULLs
+// (`nulls_first` has nothing to place); an all-NULL column ties every row.
+struct SortKey {
+    DevColumn col;
+    bool descending = false;
+};
+int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows);
 
 // u32 -> u64 (COUNT partial states are UInt64 in the reference's schemas)
 int widen_u32_to_u64(flockgpu_ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out);

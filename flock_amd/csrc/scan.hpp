@@ -226,7 +226,7 @@ __device__ __forceinline__ void load_flag_tile(const int32_t *__restrict__ col, 
     if (tr.tile_begin + kFlagTile <= n_rows) {  // block-uniform: no row of the tile is past the column
 #pragma unroll
         for (int it = 0; it < kFlagIters; ++it) {
-#ifdef FLOCKGPU_AB_PLAIN_TILE_LOADS   // (A/B builds only: tools/gpu_ab_stream_loads.sh)
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_PLAIN_TILE_LOADS)   // (A/B builds only: tools/gpu_ab_stream_loads.sh)
             const int4 t = *reinterpret_cast<const int4 *>(col + wbase + it * 256);
 #else
             const int4 t = stream_load4(col + wbase + it * 256);   // (read once per pass: non-temporal, common.hpp)

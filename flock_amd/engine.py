@@ -611,6 +611,39 @@ class GpuContext:
         self._check(self._lib.flockgpu_q8_join(self._h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
         return Q8Out(self, r, person_windows.n_windows)
 
+    # -- asynchronous twins (flockgpu.h "asynchronous calls"): the call runs on the ctx's worker thread -- the reference's
+    # `tokio::spawn(collect(plan))`, context.rs:172-191 --, `.wait()` joins it.  One call in flight per context; calls on
+    # different contexts overlap on the GPU.
+    class _Pending:
+        def __init__(self, gpu, keep, make):
+            self._gpu, self._keep, self._make = gpu, keep, make
+
+        def wait(self):
+            self._gpu._check(self._gpu._lib.flockgpu_ctx_wait(self._gpu._h))
+            out = self._make()
+            self._keep = None
+            return out
+
+    def q5_hot_items_async(self, bids: Bids, windows: WindowSchedule) -> "GpuContext._Pending":
+        b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5Result()
+        self._check(self._lib.flockgpu_q5_hot_items_async(self._h, C.byref(b), C.byref(w), C.byref(r)))
+        return GpuContext._Pending(self, (bids, windows, b, w, r), lambda: Q5Out(self, r, windows.n_windows))
+
+    def q3_join_async(self, auctions: Auctions, auction_windows: WindowSchedule, persons: Persons, person_windows: WindowSchedule,
+                      category: int = 10, states: Sequence[str] = ("or", "id", "ca")) -> "GpuContext._Pending":
+        a, aw, p, pw, r = auctions.ffi(), auction_windows.ffi(), persons.ffi(), person_windows.ffi(), _ffi.Q3Result()
+        lits = (C.c_char_p * len(states))(*[s.encode() for s in states])
+        self._check(self._lib.flockgpu_q3_join_async(self._h, C.byref(a), C.byref(aw), C.byref(p), C.byref(pw), category, lits, len(states), C.byref(r)))
+        return GpuContext._Pending(self, (auctions, auction_windows, persons, person_windows, a, aw, p, pw, lits, r),
+                                   lambda: Q3Out(self, r, auction_windows.n_windows))
+
+    def q8_join_async(self, persons: Persons, person_windows: WindowSchedule, auctions: Auctions,
+                      auction_windows: WindowSchedule) -> "GpuContext._Pending":
+        p, pw, a, aw, r = persons.ffi(), person_windows.ffi(), auctions.ffi(), auction_windows.ffi(), _ffi.Q8Result()
+        self._check(self._lib.flockgpu_q8_join_async(self._h, C.byref(p), C.byref(pw), C.byref(a), C.byref(aw), C.byref(r)))
+        return GpuContext._Pending(self, (persons, person_windows, auctions, auction_windows, p, pw, a, aw, r),
+                                   lambda: Q8Out(self, r, person_windows.n_windows))
+
     # -- in-library exchange (include/flockgpu_comm.h): every window striped over the ranks of `comm`
     def q5_hot_items_exchange(self, comm: "Comm", bids: Bids, windows: WindowSchedule) -> Q5Out:
         b, w, r = bids.ffi(), windows.ffi(), _ffi.Q5Result()

@@ -45,12 +45,12 @@ def _release(addr: int, offset: int):
 
 
 class _Plan:
-    def __init__(self, gpu: GpuContext, text: str):
+    def __init__(self, gpu: GpuContext, text: str, generic_only: bool = False):
         self.gpu, self.text = gpu, text
         self._lib = _ffi.load()
         raw = text.encode()
         h = C.c_void_p()
-        gpu._check(self._lib.flockgpu_plan_create(gpu._h, raw, len(raw), C.byref(h)))
+        gpu._check(self._lib.flockgpu_plan_create_ex(gpu._h, raw, len(raw), _ffi.PLAN_GENERIC_ONLY if generic_only else 0, C.byref(h)))
         self.h = h
         self.query = self._lib.flockgpu_plan_query(h)
         self.inputs = [self._lib.flockgpu_plan_input_name(h, i).decode() for i in range(self._lib.flockgpu_plan_num_inputs(h))]
@@ -86,10 +86,14 @@ class _Plan:
         _pa().Schema._import_from_c(C.addressof(buf))  # takes ownership back and releases
         return ok
 
-    def feed(self, i: int, batches: Sequence):
+    def feed(self, i: int, batches: Sequence, pane: Optional[int] = None):
+        """feed_data_sources for leaf i; with `pane` the batches are pane `pane` of the plan's device-side window ring
+        (flockgpu_plan_feed_pane: only the new pane crosses PCIe, the ring keeps the others)."""
         pa = _pa()
         batches = [b for b in batches if b is not None]
         if not batches:
+            if pane is not None:   # an empty pane still advances the ring
+                self.gpu._check(self._lib.flockgpu_plan_feed_pane(self.h, i, pane, None, None, 0))
             return
         sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
         batches[0].schema._export_to_c(C.addressof(sbuf))
@@ -99,7 +103,10 @@ class _Plan:
         ptrs = (C.c_void_p * len(batches))(*[C.addressof(ab) for ab in abufs])
         self._fed.append(batches)
         try:
-            rc = self._lib.flockgpu_plan_feed(self.h, i, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
+            if pane is None:
+                rc = self._lib.flockgpu_plan_feed(self.h, i, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
+            else:
+                rc = self._lib.flockgpu_plan_feed_pane(self.h, i, pane, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
         finally:
             # the library only borrowed the batches (self._fed keeps them alive): hand the exported structs back
             for ab in abufs:
@@ -152,24 +159,76 @@ class _Plan:
         self.gpu._check(self._lib.flockgpu_plan_reset(self.h))
         self._fed = []
 
+    # -- asynchronous execute (flockgpu_plan_execute_async / flockgpu_plan_wait)
+    def execute_async(self, partitioned: bool = False):
+        self.gpu._check(self._lib.flockgpu_plan_execute_async(self.h, 1 if partitioned else 0))
+        self._async_partitioned = partitioned
+
+    def wait(self):
+        """The batches of the execute started by `execute_async`: one RecordBatch, or [partition] -> RecordBatch."""
+        pa = _pa()
+        cap = max(self.partitions, 1)
+        sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        abufs = C.create_string_buffer(_ARROW_ARRAY_BYTES * cap)
+        n = C.c_int(0)
+        self.gpu._check(self._lib.flockgpu_plan_wait(self.h, C.cast(sbuf, C.c_void_p), C.cast(abufs, C.c_void_p), cap, C.byref(n)))
+        schema = pa.Schema._import_from_c(C.addressof(sbuf))
+        out = [pa.RecordBatch._import_from_c(C.addressof(abufs) + p * _ARROW_ARRAY_BYTES, schema) for p in range(n.value)]
+        return out if self._async_partitioned else out[0]
+
+    # -- device-side pane ring (flockgpu_plan_ring_*)
+    def ring_open(self, panes_per_window: int):
+        self.gpu._check(self._lib.flockgpu_plan_ring_open(self.h, panes_per_window))
+
+    def ring_close(self):
+        self.gpu._check(self._lib.flockgpu_plan_ring_close(self.h))
+        self._fed = []
+
+    def ring_state(self):
+        first, n, ppw = C.c_int64(0), C.c_int(0), C.c_int(0)
+        self.gpu._check(self._lib.flockgpu_plan_ring_state(self.h, C.byref(first), C.byref(n), C.byref(ppw)))
+        return first.value, n.value, ppw.value
+
 
 class ExecutionContext:
     """Cloud execution context of one function: plans + name (context.rs:103-131)."""
 
     def __init__(self, plans: Sequence[Union[str, dict]], name: str = "flockgpu-00", gpu: Optional[GpuContext] = None,
-                 device: int = 0):
+                 device: int = 0, generic_only: bool = False, gpus: Optional[Sequence[GpuContext]] = None):
+        """`gpus`: one GpuContext (stream) per plan -- what `execute` needs to run the plans side by side like the reference's tokio
+        tasks; with a single `gpu` the plans share its stream and run one after the other.  `generic_only`: no fused pipeline."""
         self.name = name
-        self._gpu = gpu or GpuContext(device)
-        self._owns_gpu = gpu is None
-        self.plans: List[_Plan] = [_Plan(self._gpu, p if isinstance(p, str) else json.dumps(p)) for p in plans]
+        self._gpu = gpu or (gpus[0] if gpus else GpuContext(device))
+        self._owns_gpu = gpu is None and not gpus
+        ctxs = list(gpus) if gpus else [self._gpu] * len(plans)
+        if len(ctxs) != len(plans):
+            raise ValueError("ExecutionContext: one GpuContext per plan")
+        self.plans: List[_Plan] = [_Plan(g, p if isinstance(p, str) else json.dumps(p), generic_only) for g, p in zip(ctxs, plans)]
+        self._ring = 0
+
+    # -- hopping windows: the device-side pane ring (flockgpu_plan.h; reference: window/hopping.rs:52-74 re-sends every window whole)
+    def open_window_ring(self, panes_per_window: int):
+        """From now on `feed_data_sources(sources, pane=p)` feeds ONE pane (hop seconds of events); execute() runs the window of the
+        last `panes_per_window` panes, clean_data_sources() retires the oldest."""
+        for plan in self.plans:
+            plan.ring_open(panes_per_window)
+        self._ring = panes_per_window
+
+    def close_window_ring(self):
+        for plan in self.plans:
+            plan.ring_close()
+        self._ring = 0
 
     # -- context.rs:257-325
-    def feed_data_sources(self, sources):
+    def feed_data_sources(self, sources, pane: Optional[int] = None):
         """`sources[relation][partition][batch]`.  Every plan leaf takes the first remaining source whose first
         non-empty batch matches the leaf's columns by name (compare_schema, context.rs:402-416); a leaf without
-        a match stays an empty relation (context.rs:305-314)."""
+        a match stays an empty relation (context.rs:305-314).  `pane`: see open_window_ring."""
+        if (pane is None) != (not self._ring):
+            raise ValueError("feed_data_sources: `pane` goes with an open window ring")
         sources = [list(s) for s in sources]
         for plan in self.plans:
+            fed_a_pane = False
             for i in range(len(plan.inputs)):
                 found = None
                 for si, partitions in enumerate(sources):
@@ -181,7 +240,10 @@ class ExecutionContext:
                         break
                 if found is not None:
                     partitions = sources.pop(found)
-                    plan.feed(i, [b for part in partitions for b in part])
+                    plan.feed(i, [b for part in partitions for b in part], pane)
+                    fed_a_pane = True
+            if pane is not None and not fed_a_pane and plan.inputs:   # nothing arrived in this pane: the ring still advances
+                plan.feed(0, [], pane)
 
     def share_data_sources(self, donor: "ExecutionContext") -> bool:
         """Instead of feed_data_sources: every leaf reads, in place, the relation of the same name that `donor` (another function
@@ -217,12 +279,23 @@ class ExecutionContext:
                 if hit is not None:
                     left.remove(hit)
 
-    # -- context.rs:172-191
+    def _concurrent(self) -> bool:   # every plan on its own GpuContext: their executes can be in flight together
+        return len(self.plans) > 1 and len({id(p.gpu) for p in self.plans}) == len(self.plans)
+
+    # -- context.rs:172-191: one task per plan, then join them all
     def execute(self):
+        if self._concurrent():
+            for plan in self.plans:
+                plan.execute_async(False)
+            return [[plan.wait()] for plan in self.plans]
         return [[plan.execute()] for plan in self.plans]
 
     # -- context.rs:197-216: [plan][partition][batch]; a shuffling stage returns its P hash partitions
     def execute_partitioned(self):
+        if self._concurrent():
+            for plan in self.plans:
+                plan.execute_async(True)
+            return [[[b] for b in plan.wait()] for plan in self.plans]
         return [[[b] for b in plan.execute_partitioned()] for plan in self.plans]
 
     # -- context.rs:227-254
@@ -257,9 +330,16 @@ def explain(plan: Union[str, dict]) -> str:
     return text
 
 
-def collect(ctx: ExecutionContext, streams):
-    """`actor::collect` (flock-function/src/aws/actor.rs:54-79): feed -> execute -> clean."""
-    ctx.feed_data_sources(streams)
+def partition_scheme() -> str:
+    """How this library's shuffling stages place rows (flockgpu_plan_partition_scheme): a scheduler compares it across the
+    producers of a stage before it starts them -- mixed placements split one key over two consumers."""
+    return _ffi.load().flockgpu_plan_partition_scheme().decode()
+
+
+def collect(ctx: ExecutionContext, streams, pane: Optional[int] = None):
+    """`actor::collect` (flock-function/src/aws/actor.rs:54-79): feed -> execute -> clean.  With an open window ring `streams`
+    is ONE pane and the result is the window that pane completes (hopping.rs:52-74 without the re-send)."""
+    ctx.feed_data_sources(streams, pane)
     if ctx.is_shuffling():
         out = ctx.execute_partitioned()
         assert len(out) == 1

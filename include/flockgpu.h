@@ -261,6 +261,25 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
                      const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
                      flockgpu_q8_result *out);
 
+/* ---- asynchronous calls.  The reference runs every plan of a function on its own tokio task and joins them
+ * (flock/src/runtime/context.rs:172-191); a synchronous call here leaves the GPU idle while the host prepares the next one and
+ * wakes up from its wait (~0.09 ms of q5's 0.94 ms step, a third of q3's 0.10 ms at 1e8 events).  Every ctx owns one worker thread
+ * (started on first use).  A `*_async` entry point copies its argument structs, hands the call to the worker and returns;
+ * flockgpu_ctx_wait blocks until the call has finished and returns ITS status, with `out` filled exactly as by the synchronous
+ * call.  One call in flight per ctx -- a second submit before the wait is FLOCKGPU_ERR_INVALID; the arrays the arguments point to
+ * (device columns, window schedules, literals, `out`) are borrowed until the wait returns, and the ctx must not be used in
+ * between.  Calls on DIFFERENT ctxs (different streams) are in flight together. */
+int flockgpu_q3_join_async(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                           const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                           int64_t category_lit, const char *const *state_lits, int n_state_lits,
+                           flockgpu_q3_result *out);
+int flockgpu_q5_hot_items_async(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, const flockgpu_windows *win,
+                                flockgpu_q5_result *out);
+int flockgpu_q8_join_async(flockgpu_ctx *ctx, const flockgpu_person_cols *person, const flockgpu_windows *person_win,
+                           const flockgpu_auction_cols *auction, const flockgpu_windows *auction_win,
+                           flockgpu_q8_result *out);
+int flockgpu_ctx_wait(flockgpu_ctx *ctx);
+
 /* ---- key-partitioned exchange (the RepartitionExec Hash([key], n) step of the distributed plans,
  * flock/src/distributed_plan/planner.rs:152-171; row routing restated from
  * playground/src/distributed_plan/shuffle_writer.rs:106-148).  The reference hashes with ahash seeds (0,0,0,0);

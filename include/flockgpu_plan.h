@@ -25,7 +25,11 @@
  * flockgpu_plan_execute_partitioned returns its P hash partitions, partition j going to ring member j
  * (flock-function/src/aws/actor.rs:425-543).  Transparent nodes (RepartitionExec RoundRobinBatch, CoalesceBatchesExec,
  * CoalescePartitions / MergeExec) change neither the row multiset nor the schema and are folded away.
- * Anything else -- sort / limit, other aggregates, other types, outer joins -- returns FLOCKGPU_ERR_UNSUPPORTED so the
+ * SortExec (ORDER BY over Int32 / Int64 / UInt64 / Float64 / Utf8 / Timestamp columns, ASC / DESC, stable) and
+ * GlobalLimitExec / LocalLimitExec run on the device too: the reference's own goldens at this boundary end in them
+ * (flock/src/runtime/context.rs:471 `ORDER BY c3`, :549-550 `ORDER BY a ASC LIMIT 3`, flock/src/tests/data/plan/join.json) and its
+ * stage splitter cuts at sort_exec (flock/src/distributed_plan/stage.rs:337).
+ * Anything else -- window functions, other aggregates, other types, outer joins -- returns FLOCKGPU_ERR_UNSUPPORTED so the
  * host keeps its DataFusion path for that plan.  The root projection is honoured: output columns come back in the
  * plan's order under the plan's names.
  *
@@ -80,6 +84,10 @@ typedef struct flockgpu_plan flockgpu_plan;
 /* Parses the plan JSON and builds the operator tree.  FLOCKGPU_ERR_PLAN: not JSON; FLOCKGPU_ERR_UNSUPPORTED: a node,
  * expression or type the engine does not execute (flockgpu_last_error names it). */
 int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out);
+/* The same with options.  FLOCKGPU_PLAN_GENERIC_ONLY: no sub-tree is handed to a fused NEXMark pipeline, every node runs on the
+ * generic device operators -- how the tests run every reference plan both ways and require identical rows. */
+#define FLOCKGPU_PLAN_GENERIC_ONLY 1u
+int flockgpu_plan_create_ex(flockgpu_ctx *ctx, const char *plan_json, size_t len, uint32_t flags, flockgpu_plan **out);
 void flockgpu_plan_destroy(flockgpu_plan *plan);
 /* Host-only: parses a plan without a device context.  *query receives the NEXMark query number (1, 2, 3, 4, 5, 7, 8, 9, 13;
  * 100 for the Yahoo Streaming Benchmark's query) when the whole plan is one fused pipeline, 0 for any other executable plan
@@ -137,8 +145,60 @@ int flockgpu_plan_execute_partitioned(flockgpu_plan *plan, struct ArrowSchema *o
 int flockgpu_plan_execute_retain(flockgpu_plan *plan, int64_t *rows);
 int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan *producer);
 
-/* clean_data_sources(): drops the inputs, keeps device arenas and hash-table sizing for the next invocation. */
+/* clean_data_sources(): drops the inputs, keeps device arenas and hash-table sizing for the next invocation.  On a plan with
+ * an open pane ring (below) it ends the window instead: the oldest pane of a full ring is retired, the others stay. */
 int flockgpu_plan_reset(flockgpu_plan *plan);
+
+/* ---- asynchronous execute: the reference runs every plan of a function on its own tokio task and joins them
+ * (`tokio::spawn(collect(plan))`, flock/src/runtime/context.rs:172-191).  execute_async hands the whole execute (kernels, its host
+ * waits, the export into pinned memory) to the worker thread of the plan's flockgpu_ctx and returns at once; flockgpu_plan_wait blocks
+ * until it has finished, returns ITS status and fills the outputs exactly as flockgpu_plan_execute[_partitioned] would.  One call in
+ * flight per ctx; plans on different ctxs (different streams) overlap -- the host gap of one call is covered by the other's kernels.
+ * Between the two calls the plan and its ctx must not be touched. */
+int flockgpu_plan_execute_async(flockgpu_plan *plan, int partitioned);
+int flockgpu_plan_wait(flockgpu_plan *plan, struct ArrowSchema *out_schema, struct ArrowArray *out_batches, int capacity, int *n_partitions);
+
+/* ---- hopping windows on the streaming path: a device-side pane ring.
+ * The reference's hopping launcher re-sends every window whole (flock-function/src/aws/window/hopping.rs:52-74; the local twin
+ * flock/src/datasource/nexmark/queries/q5.rs:78-132): with Hopping(size, hop) every event crosses the wire -- here: PCIe -- size / hop
+ * times and is aggregated as often.  A plan with an open ring keeps the last `panes_per_window` panes (pane = hop seconds of events)
+ * ON THE DEVICE across executes; the host feeds only the NEW pane:
+ *     flockgpu_plan_ring_open(plan, size / hop);
+ *     per pane p:  flockgpu_plan_feed_pane(plan, input, p, schema, batches, n)   (once per input and as often as there are batches;
+ *                                                                                 an empty pane is fed with n_batches = 0)
+ *                  flockgpu_plan_execute*(...)     -> the window of the panes the ring holds, [p - panes_per_window + 1, p]
+ *                  flockgpu_plan_reset(plan)       -> retires pane p - panes_per_window + 1
+ * Every event is uploaded once.  What is retained per pane depends on the plan: for q5 (COUNT(*) GROUP BY auction -> MAX -> join)
+ * it is the pane's Partial aggregate state -- its (auction, count) groups, the state HashAggregateExec(Partial) emits -- so every bid
+ * is also COUNTED once and a window is the FinalPartitioned merge of its panes' groups; for every other plan it is the pane's rows
+ * (the columns the plan reads), and the window is executed over the retained rows.
+ * Pane ids are consecutive: the first feed_pane names the first pane, after that only the newest pane (more batches) or its
+ * successor (after a reset if the ring is full) may be fed; anything else -- an older pane, a skipped pane -- is
+ * FLOCKGPU_ERR_INVALID and leaves the ring as it was.  flockgpu_plan_feed on a plan with an open ring is FLOCKGPU_ERR_INVALID.
+ * ring_close drops every pane and returns the plan to whole-window feeding. */
+int flockgpu_plan_ring_open(flockgpu_plan *plan, int panes_per_window);
+int flockgpu_plan_ring_close(flockgpu_plan *plan);
+/* panes currently held: ids [*first_pane, *first_pane + *n_panes); n_panes = 0 before the first feed_pane */
+int flockgpu_plan_ring_state(const flockgpu_plan *plan, int64_t *first_pane, int *n_panes, int *panes_per_window);
+int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, const struct ArrowSchema *schema,
+                            const struct ArrowArray *const *batches, int n_batches);
+
+/* ---- hash placement of a shuffling stage.  flockgpu_plan_execute_partitioned places a row in partition
+ *     (murmur3_fmix32(fold32(key)) * n) >> 32
+ * (flockgpu.h: flockgpu_partition_by_key), NOT where the reference's DataFusion fork would put it
+ * (`create_hashes(.., ahash::RandomState::with_seeds(0, 0, 0, 0)) % n`, restated at playground/src/distributed_plan/shuffle_writer.rs:106-128;
+ * the ahash version is unpinned).  Which partition a key lands in is unobservable as long as EVERY producer
+ * of a stage places rows the same way; a stage with mixed producers -- some function instances on libflockgpu, some on DataFusion
+ * during a roll-out, a GPU-less fallback instance -- would split one key over two consumers (partition j -> ring member j,
+ * flock-function/src/aws/actor.rs:425-543) and silently lose join / aggregate rows.  Two guards:
+ *   * every batch of a shuffling stage's output carries the Arrow schema metadata  "flockgpu.partition_scheme" = this string
+ *     (Arrow Flight keeps schema metadata, so it travels with the payload);
+ *   * flockgpu_plan_feed refuses (FLOCKGPU_ERR_INVALID, nothing changed) a batch whose tag differs from what the plan's other
+ *     co-partitioned inputs -- the leaves below a HashJoinExec mode=Partitioned or a FinalPartitioned aggregate -- were fed since
+ *     the last reset: tagged with another scheme, or untagged next to tagged ones.
+ * A host that schedules stages should also compare flockgpu_plan_partition_scheme() across the producers it is about to start. */
+const char *flockgpu_plan_partition_scheme(void);
+int flockgpu_plan_check_partition_scheme(const char *scheme);   /* FLOCKGPU_OK | FLOCKGPU_ERR_UNSUPPORTED */
 
 /* Pinned host memory for the host's Arrow buffers ("Arrow buffers pinned and hipMemcpyAsync'd"): allocate buffers
  * with flockgpu_host_alloc, or register existing ones for as long as they are fed. */

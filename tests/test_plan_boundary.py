@@ -34,7 +34,10 @@ def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
     t = open(os.path.join(PLANS, "simple_select.json")).read().encode()
     got = C.c_int(-1)
     assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK and got.value == 0
-    t = open(os.path.join(PLANS, "unsupported_sort_limit.json")).read().encode()
+    # sort + limit are device operators (round 4): executable, no NEXMark query; an outer join is handed back
+    t = open(os.path.join(PLANS, "sort_limit.json")).read().encode()
+    assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.OK and got.value == 0
+    t = open(os.path.join(PLANS, "unsupported_left_join.json")).read().encode()
     assert lib.flockgpu_plan_recognise(t, len(t), C.byref(got)) == _ffi.ERR_UNSUPPORTED
     assert lib.flockgpu_plan_recognise(b"{not json", 9, C.byref(got)) == _ffi.ERR_PLAN
     # a q2-shaped plan with a different predicate operator is not the fused q2 pipeline (the generic filter runs it)
@@ -55,8 +58,8 @@ def test_plan_fixtures_are_recognised_and_foreign_shapes_rejected():
 
 def test_reference_plan_fixtures_parse():
     """The three serde_json fixtures the reference ships (flock/src/tests/data/plan/*.json; read where the reference tree is
-    present) go through the real parser: the projection and the MAX / MIN GROUP BY plan are executable operator trees, the
-    sort + limit plan comes back UNSUPPORTED naming the node -- never a parse error."""
+    present) go through the real parser: all three are executable operator trees -- join.json WHOLE, with its
+    GlobalLimitExec <- SortExec <- MergeExec on top (device operators since round 4)."""
     ref = "/root/reference/flock/src/tests/data/plan"
     if not os.path.isdir(ref):
         pytest.skip("reference tree not present on this box")
@@ -67,13 +70,30 @@ def test_reference_plan_fixtures_parse():
     assert agg.splitlines()[0] == "Project [MAX(c1):Int64, MIN(c2):Float64, c3:Utf8]" and "Aggregate(Partial)" in agg
     # the plan authored for the GPU box (tools/make_plan_fixtures.py: golden_aggregate) is the same operator tree
     assert agg == explain(open(os.path.join(PLANS, "golden_aggregate.json")).read())
-    with pytest.raises(FlockGpuError) as e:
-        explain(open(os.path.join(ref, "join.json")).read())
-    assert e.value.code == _ffi.ERR_UNSUPPORTED and "global_limit_exec" in str(e.value)
+    whole = explain(open(os.path.join(ref, "join.json")).read())
+    assert whole.splitlines()[0].startswith("Limit(3)") and whole.splitlines()[1].strip().startswith("Sort(b ASC)")
     # ... and below its sort + limit, join.json is the tree of golden_join
     import json as _json
     below = _json.load(open(os.path.join(ref, "join.json")))["input"]["input"]["input"]
     assert explain(below) == explain(open(os.path.join(PLANS, "golden_join.json")).read())
+    # the plans authored for the GPU box carry the reference's ORDER BY / LIMIT on top of the same trees
+    js = explain(open(os.path.join(PLANS, "golden_join_sorted.json")).read()).splitlines()
+    assert js[0].startswith("Limit(3)") and js[1].strip().startswith("Sort(a ASC)")
+    assert explain(open(os.path.join(PLANS, "golden_aggregate_sorted.json")).read()).splitlines()[0].startswith("Sort(c3 ASC)")
+    with pytest.raises(FlockGpuError) as e:
+        explain(open(os.path.join(PLANS, "unsupported_left_join.json")).read())
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and "Inner" in str(e.value)
+
+
+def test_sort_plans_split_at_sort_exec_and_every_stage_is_executable():
+    """stage.rs:337 cuts a plan at sort_exec like at a final aggregate; the stages it emits -- the sort stage among them -- are
+    plans the engine executes (round 3 returned UNSUPPORTED for exactly the stage the splitter had just cut)."""
+    from flock_amd.runtime import explain
+    from flock_amd.stages import build_query_dag
+    for name in ("golden_join_sorted", "golden_aggregate_sorted", "q3_sorted"):
+        stages = build_query_dag(json.load(open(os.path.join(PLANS, name + ".json"))))
+        texts = [explain(st.plan) for st in stages]
+        assert any(t.lstrip().startswith(("Sort(", "Limit(")) for t in texts), name
 
 
 def test_aggregate_fixture_splits_as_the_reference_asserts():
@@ -259,7 +279,7 @@ def test_unsupported_plan_and_bad_input_raise(gpu):
     from flock_amd import FlockGpuError, _ffi
     from flock_amd.runtime import ExecutionContext
     with pytest.raises(FlockGpuError) as e:
-        ExecutionContext([open(os.path.join(PLANS, "unsupported_sort_limit.json")).read()], gpu=gpu)
+        ExecutionContext([open(os.path.join(PLANS, "unsupported_left_join.json")).read()], gpu=gpu)
     assert e.value.code == _ffi.ERR_UNSUPPORTED
     ctx = ExecutionContext([_plan(2)], gpu=gpu)
     wrong_type = pa.record_batch([pa.array([1, 2], pa.int64()), pa.array([3, 4], pa.int32())], names=["auction", "price"])
@@ -364,8 +384,8 @@ def test_q13_side_input_join_through_collect(gpu):
 def test_reference_operator_goldens_through_the_hip_plan_path(gpu):
     """The two operator-level goldens the reference holds at exactly this boundary -- a deserialised plan, feed_data_sources,
     execute, an expected table (flock/src/runtime/context.rs:430-503 and :505-589) -- through the HIP plan path: the reference's
-    batches in, the reference's expected rows out.  The reference's final `ORDER BY` / `LIMIT` are applied here on the host
-    (the engine hands sort / limit plans back as UNSUPPORTED); the aggregate golden also runs as the two stage plans
+    batches in, the reference's expected rows out, ROW FOR ROW IN ORDER: the plans end in the reference's own `ORDER BY` /
+    `LIMIT` (SortExec / GlobalLimitExec run on the device since round 4); the aggregate golden also runs as the two stage plans
     dag.rs:488-520 cuts it into."""
     import pyarrow as pa
     from flock_amd.runtime import ExecutionContext, collect
@@ -384,6 +404,11 @@ def test_reference_operator_goldens_through_the_hip_plan_path(gpu):
     assert rb.schema.names == ["MAX(c1)", "MIN(c2)", "c3"]
     rows = sorted(zip(rb["MAX(c1)"].to_pylist(), rb["MIN(c2)"].to_pylist(), rb["c3"].to_pylist()), key=lambda r: r[2])
     assert rows == want
+    # ... and with the reference's ORDER BY c3 in the plan (context.rs:471): the rows arrive in its order
+    ctx = ExecutionContext([json.load(open(os.path.join(PLANS, "golden_aggregate_sorted.json")))], name="golden-agg-sorted", gpu=gpu)
+    rb = collect(ctx, [[[batch]]])[0][0]
+    ctx.close()
+    assert list(zip(rb["MAX(c1)"].to_pylist(), rb["MIN(c2)"].to_pylist(), rb["c3"].to_pylist())) == want
     # the same through its two stage plans: Partial -> Hash([c3], 8) partitions -> FinalPartitioned per partition
     low, top = build_query_dag(plan)
     c0 = ExecutionContext([low.plan], name="golden-agg-0", gpu=gpu)
@@ -408,3 +433,9 @@ def test_reference_operator_goldens_through_the_hip_plan_path(gpu):
     assert rb.schema.names == ["a", "b", "d"]
     rows = sorted(zip(rb["a"].to_pylist(), rb["b"].to_pylist(), rb["d"].to_pylist()))
     assert rows[:3] == [("a", 1, 1), ("b", 10, 10), ("c", 10, 10)] and len(rows) == 4
+    # the whole plan of context.rs:544-551 (= the shape of the reference's join.json): ORDER BY a ASC LIMIT 3 on the device,
+    # compared with context.rs:579-587 row for row
+    ctx = ExecutionContext([open(os.path.join(PLANS, "golden_join_sorted.json")).read()], name="golden-join-sorted", gpu=gpu)
+    rb = collect(ctx, [[[t1]], [[t2]]])[0][0]
+    ctx.close()
+    assert list(zip(rb["a"].to_pylist(), rb["b"].to_pylist(), rb["d"].to_pylist())) == [("a", 1, 1), ("b", 10, 10), ("c", 10, 10)]

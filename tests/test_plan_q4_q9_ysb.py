@@ -103,9 +103,9 @@ def _got(batches):
     return sorted(out)
 
 
-def _collect_whole(gpu, plan, sources):
+def _collect_whole(gpu, plan, sources, generic_only=False):
     from flock_amd.runtime import ExecutionContext, collect
-    ctx = ExecutionContext([plan], gpu=gpu)
+    ctx = ExecutionContext([plan], gpu=gpu, generic_only=generic_only)
     text = ctx.plans[0].description
     out = collect(ctx, [[[rb]] for rb in sources.values()])[0]
     ctx.close()
@@ -123,8 +123,7 @@ def test_whole_plan_fused_and_generic_equal_the_oracle(gpu, q, seed, eps, n, mon
     assert _got(out) == want                                      # AVG: Float64 equality, bit for bit
     if n > 1000:
         assert len(want) > 0
-    monkeypatch.setenv("FLOCKGPU_PLAN_GENERIC", "1")
-    text, out = _collect_whole(gpu, _plan(q), relations)
+    text, out = _collect_whole(gpu, _plan(q), relations, generic_only=True)   # FLOCKGPU_PLAN_GENERIC_ONLY
     assert "fused" not in text and _got(out) == want
 
 
@@ -169,6 +168,5 @@ def test_ysb_whole_plan_fused_generic_and_staged(gpu, seed, n_events, campaigns,
     for rule in ("build_query_dag", "split_at_repartitions"):
         got, sizes, _ = run_staged(gpu, getattr(S, rule)(_plan("ysb")), relations, chunks=2 if rule == "split_at_repartitions" else 1)
         assert _rows(got) == want, rule
-    monkeypatch.setenv("FLOCKGPU_PLAN_GENERIC", "1")
-    text, out = _collect_whole(gpu, _plan("ysb"), relations)
+    text, out = _collect_whole(gpu, _plan("ysb"), relations, generic_only=True)
     assert "fused" not in text and _rows(out) == want

@@ -1,0 +1,394 @@
+"""Round-4 additions to the plan-level ABI (include/flockgpu_plan.h), each against the oracle:
+  * SortExec / GlobalLimitExec on the device (reference goldens end in them: context.rs:471,549; stage.rs:337 cuts at sort_exec;
+    launcher/aws/mod.rs:350 `ORDER BY a_id`)
+  * the device-side pane ring for hopping windows (window/hopping.rs:52-74 re-sends every window whole)
+  * asynchronous execute (one tokio task per plan, context.rs:172-191)
+  * the hash-placement guard for shuffling stages (shuffle_writer.rs:106-128; actor.rs:425-543)."""
+import json
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import oracle
+from oracle import generic_ops as g
+from test_plan_boundary import PLANS, TS, _auction_batches, _bid_batches, _person_batches, _plan, _utf8
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _field(name, dt, nullable=False):
+    return {"data_type": dt, "dict_id": 0, "dict_is_ordered": False, "name": name, "nullable": nullable}
+
+
+_TS = {"Timestamp": ["Millisecond", None]}
+_SORT_FIELDS = [_field("i", "Int32"), _field("l", "Int64"), _field("u", "UInt64"), _field("f", "Float64"), _field("s", "Utf8"), _field("t", _TS)]
+
+
+def _sort_plan(keys, limit=None):
+    scan = {"execution_plan": "memory_exec", "schema": {"fields": _SORT_FIELDS, "metadata": {}}, "projection": list(range(len(_SORT_FIELDS)))}
+    names = [f["name"] for f in _SORT_FIELDS]
+    plan = {"execution_plan": "sort_exec", "input": scan,
+            "expr": [{"expr": {"physical_expr": "column", "name": k, "index": names.index(k)}, "options": {"descending": d, "nulls_first": d}}
+                     for k, d in keys]}
+    return plan if limit is None else {"execution_plan": "global_limit_exec", "limit": limit, "input": plan}
+
+
+def _sort_table(n, seed):
+    r = np.random.default_rng(seed)
+    words = [b"", b"a", b"a\x00", b"ab", b"abcdefgh", b"abcdefgh\x00", b"abcdefghi", b"abcdefghijklmnopq", b"abcdefghijklmnopr", b"zz", b"\xc3\xa9t\xc3\xa9",
+             b"Walton Abrams", b"Walton Abramson", b"b" * 40, b"b" * 39 + b"a"]
+    return {
+        "i": r.integers(-5, 5, n).astype(np.int32) * np.int32(400_000_000),          # both signs, the full 32-bit span, many ties
+        "l": r.integers(-2**62, 2**62, n, dtype=np.int64) // np.int64(r.integers(1, 1 << 40)),
+        "u": r.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + r.integers(0, 2, n).astype(np.uint64),
+        "f": np.where(r.random(n) < 0.3, np.round(r.normal(0, 3, n)), r.normal(0, 1e6, n)) + 0.0,   # ties, both signs (no -0.0 / NaN)
+        "s": [words[k] for k in r.integers(0, len(words), n)],
+        "t": r.integers(1_436_918_400_000, 1_436_918_400_000 + 50, n).astype(np.int64),
+    }
+
+
+def _sort_batch(t):
+    f = t["f"].copy()
+    f[f == 0] = 0.0
+    return pa.record_batch([pa.array(t["i"]), pa.array(t["l"]), pa.array(t["u"]), pa.array(f), pa.array(t["s"], pa.binary()).cast(pa.string()),
+                            pa.array(t["t"]).cast(TS)], names=["i", "l", "u", "f", "s", "t"])
+
+
+def _rows_in_order(rb):
+    cols = []
+    for c in rb.schema.names:
+        col = rb[c]
+        if pa.types.is_timestamp(col.type):
+            col = col.cast(pa.int64())
+        if pa.types.is_string(col.type):
+            col = col.cast(pa.binary())
+        cols.append(col.to_pylist())
+    return list(zip(*cols))
+
+
+# ------------------------------------------------------------------ CPU
+def test_sort_and_limit_parse_into_the_operator_tree():
+    from flock_amd.runtime import explain
+    text = explain(_sort_plan([("s", False), ("i", True)], limit=7))
+    assert text.splitlines()[0].startswith("Limit(7)") and "Sort(s ASC, i DESC)" in text.splitlines()[1]
+    # ORDER BY a computed expression is handed back, never mis-executed
+    from flock_amd import FlockGpuError, _ffi
+    bad = _sort_plan([("i", False)])
+    bad["expr"][0]["expr"] = {"physical_expr": "binary_expr", "op": "Plus", "left": bad["expr"][0]["expr"], "right": bad["expr"][0]["expr"]}
+    with pytest.raises(FlockGpuError) as e:
+        explain(bad)
+    assert e.value.code == _ffi.ERR_UNSUPPORTED
+
+
+def test_partition_scheme_is_named_and_checked():
+    import ctypes as C
+    from flock_amd import _ffi
+    from flock_amd.runtime import partition_scheme
+    lib = _ffi.load()
+    name = partition_scheme()
+    assert name.startswith("flockgpu/") and lib.flockgpu_plan_check_partition_scheme(name.encode()) == _ffi.OK
+    assert lib.flockgpu_plan_check_partition_scheme(b"datafusion/ahash-0000") == _ffi.ERR_UNSUPPORTED
+    assert lib.flockgpu_plan_check_partition_scheme(None) == _ffi.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------ GPU: ORDER BY / LIMIT
+@pytest.mark.gpu
+@pytest.mark.parametrize("keys,limit", [([("i", False)], None), ([("i", True)], 10), ([("l", False)], None), ([("u", True)], None),
+                                        ([("f", False)], None), ([("f", True), ("i", False)], 33), ([("s", False)], None), ([("s", True)], 5),
+                                        ([("t", False), ("s", False), ("u", False)], None), ([("i", False), ("s", True), ("l", False)], 1000),
+                                        ([("s", False)], 0)])
+@pytest.mark.parametrize("n,seed", [(1, 1), (700, 2), (20_000, 3)])
+def test_order_by_and_limit_equal_the_oracle_row_for_row(gpu, keys, limit, n, seed):
+    """Stable ORDER BY over every column type, ASC / DESC, multi-key, with and without LIMIT: the rows come back in exactly the
+    order the oracle's stable lexicographic sort gives (ties in input order)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = _sort_table(n, seed)
+    ctx = ExecutionContext([_sort_plan(keys, limit)], gpu=gpu)
+    rb = collect(ctx, [[[_sort_batch(t)]]])[0][0]
+    ctx.close()
+    table = {k: (v.tolist() if hasattr(v, "tolist") else list(v)) for k, v in t.items()}
+    want = g.sort_exec(table, keys)
+    if limit is not None:
+        want = g.limit_exec(want, limit)
+    assert rb.schema.names == ["i", "l", "u", "f", "s", "t"]
+    assert _rows_in_order(rb) == g.rows(want)
+
+
+@pytest.mark.gpu
+def test_empty_input_sorts_to_nothing(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    ctx = ExecutionContext([_sort_plan([("s", False), ("i", True)], limit=3)], gpu=gpu)
+    assert collect(ctx, [[[]]])[0][0].num_rows == 0
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_q3_order_by_a_id_through_the_plan_path(gpu):
+    """launcher/aws/mod.rs:340-351: the reference's distributed == local differential runs q3 with `ORDER BY a_id ASC`; a_id is unique
+    per result row, so the order is fully determined: row for row against the oracle."""
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=17, eps=40_000)
+    n = 160_000
+    ctx = ExecutionContext([open(os.path.join(PLANS, "q3_sorted.json")).read()], name="q3-sorted", gpu=gpu)
+    assert "fused q3" in ctx.plans[0].description and ctx.plans[0].description.startswith("Sort(a_id ASC)")
+    rb = collect(ctx, [[_person_batches(s, 0, n, n)], [_auction_batches(s, 0, n, n)]])[0][0]
+    ctx.close()
+    a, p = s.auctions(0, n), s.persons(0, n)
+    ar, pr = oracle.q3_join(a["seller"], a["category"], p["p_id"], p["state"])
+    names, cities, states = _utf8(p["name"]).to_pylist(), _utf8(p["city"]).to_pylist(), _utf8(p["state"]).to_pylist()
+    want = sorted(((names[j], cities[j], states[j], int(a["a_id"][i])) for i, j in zip(ar.tolist(), pr.tolist())), key=lambda r: r[3])
+    got = list(zip(rb["name"].to_pylist(), rb["city"].to_pylist(), rb["state"].to_pylist(), rb["a_id"].to_pylist()))
+    assert got == want and len(got) > 100
+
+
+@pytest.mark.gpu
+def test_sorted_stage_plans_run_stage_by_stage(gpu):
+    """The stages build_query_dag cuts out of `... ORDER BY a LIMIT 3` (stage.rs:337: a cut at sort_exec) all execute: the join
+    stage's partitions feed the sort stage, whose rows are context.rs:579-587 in order."""
+    from flock_amd.runtime import ExecutionContext, collect
+    from flock_amd.stages import build_query_dag
+    t1 = pa.record_batch([pa.array(["a", "b", "c", "d"]), pa.array([1, 10, 10, 100], pa.int32())], names=["a", "b"])
+    t2 = pa.record_batch([pa.array(["a", "b", "c", "d"]), pa.array([1, 10, 10, 100], pa.int32())], names=["c", "d"])
+    from test_stage_plans import run_staged
+    stages = build_query_dag(json.load(open(os.path.join(PLANS, "golden_join_sorted.json"))))
+    assert len(stages) == 4                                               # two repartition plans, the join, sort + limit (stage.rs:776-901)
+    got, _, _ = run_staged(gpu, stages, {"t1": t1, "t2": t2}, chunks=1)
+    assert len(got) == 1
+    assert list(zip(got[0]["a"].to_pylist(), got[0]["b"].to_pylist(), got[0]["d"].to_pylist())) == [("a", 1, 1), ("b", 10, 10), ("c", 10, 10)]
+
+
+# ------------------------------------------------------------------ GPU: the pane ring
+def _q5_rows(rb):
+    return sorted(zip(rb["auction"].to_pylist(), rb["num"].to_pylist()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic_only", [False, True])
+@pytest.mark.parametrize("size,hop", [(4, 2), (6, 2), (3, 3)])
+def test_q5_pane_ring_equals_whole_window_feeds_equals_oracle(gpu, generic_only, size, hop):
+    """hopping(size, hop) q5 through `collect`: with the ring every pane is fed ONCE and the window results equal those of the
+    reference's protocol (every window re-sent whole, hopping.rs:52-74) and the oracle -- on every window, incl. the ramp-up windows
+    of fewer panes and an empty pane.  generic_only: the rows ring (any plan); else q5's state ring (a pane is counted once)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    eps, seconds = 8_000, 16
+    s = oracle.NexmarkStream(seed=31, eps=eps)
+    ppw, n_panes = size // hop, seconds // hop
+    pane_batches = [_bid_batches(s, p * hop * eps, (p + 1) * hop * eps, 5_000) for p in range(n_panes)]
+    pane_host = [s.bids(p * hop * eps, (p + 1) * hop * eps)["auction"] for p in range(n_panes)]
+    pane_batches[5], pane_host[5] = [], np.zeros(0, np.int32)            # a pane in which nothing arrived
+    ring = ExecutionContext([_plan(5)], name="q5-ring", gpu=gpu, generic_only=generic_only)
+    whole = ExecutionContext([_plan(5)], name="q5-whole", gpu=gpu, generic_only=generic_only)
+    ring.open_window_ring(ppw)
+    for p in range(n_panes):
+        rb = collect(ring, [[pane_batches[p]]], pane=p)[0][0]
+        lo = max(0, p - ppw + 1)
+        first, held, _ = ring.plans[0].ring_state()                     # (after clean_data_sources: the oldest pane of a full ring is gone)
+        assert first + held == p + 1 and held == (ppw - 1 if p + 1 >= ppw else p + 1)
+        window = [b for q in range(lo, p + 1) for b in pane_batches[q]]
+        ref = collect(whole, [[window]])[0][0]
+        host = np.concatenate(pane_host[lo:p + 1]) if p + 1 > lo else np.zeros(0, np.int32)
+        oa, on = oracle.q5_hot_items(host) if len(host) else (np.zeros(0, np.int32), np.zeros(0, np.uint64))
+        assert _q5_rows(rb) == _q5_rows(ref) == sorted(zip(oa.tolist(), on.tolist())), (p, lo)
+        assert rb.schema == ref.schema
+    ring.close_window_ring()
+    # after ring_close the plan feeds whole windows again
+    rb = collect(ring, [[pane_batches[0]]])[0][0]
+    oa, on = oracle.q5_hot_items(pane_host[0])
+    assert _q5_rows(rb) == sorted(zip(oa.tolist(), on.tolist()))
+    ring.close()
+    whole.close()
+
+
+@pytest.mark.gpu
+def test_ring_retires_the_oldest_pane_and_counts_panes(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=2, eps=2_000)
+    ctx = ExecutionContext([_plan(5)], gpu=gpu)
+    ctx.open_window_ring(3)
+    assert ctx.plans[0].ring_state() == (0, 0, 3)
+    for p in range(10, 16):                                                # pane ids need not start at 0
+        collect(ctx, [[_bid_batches(s, (p - 10) * 2_000, (p - 9) * 2_000, 2_000)]], pane=p)
+        first, held, ppw = ctx.plans[0].ring_state()
+        assert ppw == 3 and first + held == p + 1 and held == min(2, p - 9)   # (after clean_data_sources: the oldest of a full ring is gone)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_ring_refuses_out_of_order_and_skipped_panes(gpu):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext
+    s = oracle.NexmarkStream(seed=3, eps=2_000)
+    b = lambda p: [[_bid_batches(s, p * 2_000, (p + 1) * 2_000, 2_000)]]
+    ctx = ExecutionContext([_plan(5)], gpu=gpu)
+    with pytest.raises(ValueError):
+        ctx.feed_data_sources(b(0), pane=0)                                 # no ring open
+    ctx.open_window_ring(2)
+    with pytest.raises(ValueError):
+        ctx.feed_data_sources(b(0))                                         # a ring is open: panes only
+    ctx.feed_data_sources(b(4), pane=4)
+    ctx.feed_data_sources(b(5), pane=5)
+    want = _q5_rows(ctx.execute()[0][0])
+    for bad in (3, 4, 7):                                                   # older than the ring, closed pane, skipped pane
+        with pytest.raises(FlockGpuError) as e:
+            ctx.feed_data_sources(b(bad), pane=bad)
+        assert e.value.code == _ffi.ERR_INVALID and "pane" in str(e.value)
+    with pytest.raises(FlockGpuError) as e:                                 # the successor needs room: the window must end first
+        ctx.feed_data_sources(b(6), pane=6)
+    assert e.value.code == _ffi.ERR_INVALID and "full" in str(e.value)
+    assert _q5_rows(ctx.execute()[0][0]) == want                            # a refused feed left the ring as it was
+    # a feed the plan refuses (wrong column type) also leaves the ring as it was -- even when it would have opened a new pane
+    ctx.clean_data_sources()
+    wrong = pa.record_batch([pa.array([1, 2], pa.int64())], names=["auction"])
+    with pytest.raises(FlockGpuError):
+        ctx.feed_data_sources([[[wrong]]], pane=6)
+    assert ctx.plans[0].ring_state() == (5, 1, 2)
+    ctx.feed_data_sources(b(6), pane=6)
+    host = s.bids(5 * 2_000, 7 * 2_000)["auction"]
+    oa, on = oracle.q5_hot_items(host)
+    assert _q5_rows(ctx.execute()[0][0]) == sorted(zip(oa.tolist(), on.tolist()))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_two_relation_utf8_plan_through_the_rows_ring(gpu):
+    """q8 (persons with a Utf8 column + auctions) over Hopping(3 panes): the generic rows ring keeps both relations' panes on the
+    device (Utf8 offsets rebased when the oldest pane goes) and every window equals the whole-window feed and the oracle."""
+    from flock_amd.runtime import ExecutionContext, collect
+    eps, n_panes, ppw = 30_000, 7, 3
+    s = oracle.NexmarkStream(seed=8, eps=eps)
+    pers = [_person_batches(s, p * eps, (p + 1) * eps, eps) for p in range(n_panes)]
+    aucs = [_auction_batches(s, p * eps, (p + 1) * eps, 11_000) for p in range(n_panes)]
+    ring = ExecutionContext([_plan(8)], name="q8-ring", gpu=gpu)
+    whole = ExecutionContext([_plan(8)], name="q8-whole", gpu=gpu)
+    ring.open_window_ring(ppw)
+    total = 0
+    for p in range(n_panes):
+        rb = collect(ring, [[pers[p]], [aucs[p]]], pane=p)[0][0]
+        lo = max(0, p - ppw + 1)
+        ref = collect(whole, [[[b for q in range(lo, p + 1) for b in pers[q]]], [[b for q in range(lo, p + 1) for b in aucs[q]]]])[0][0]
+        hp, ha = s.persons(lo * eps, (p + 1) * eps), s.auctions(lo * eps, (p + 1) * eps)
+        rows = oracle.q8_join(hp["p_id"], hp["name"], ha["seller"])
+        names = _utf8(hp["name"]).to_pylist()
+        want = sorted((int(hp["p_id"][r]), names[r]) for r in rows)
+        got = sorted(zip(rb["p_id"].to_pylist(), rb["name"].to_pylist()))
+        assert got == sorted(zip(ref["p_id"].to_pylist(), ref["name"].to_pylist())) == want, p
+        total += len(want)
+    assert total > 50
+    ring.close()
+    whole.close()
+
+
+# ------------------------------------------------------------------ GPU: asynchronous execute
+@pytest.mark.gpu
+def test_plans_on_their_own_contexts_execute_side_by_side(gpu):
+    """context.rs:172-191: every plan of a function runs on its own task.  Two plans (q5's two halves would be; here q5 and q2 over the
+    same bids) on two GpuContexts: execute() starts both, then joins them -- same batches as one after the other."""
+    from flock_amd import GpuContext
+    from flock_amd.runtime import ExecutionContext
+    s = oracle.NexmarkStream(seed=5, eps=50_000)
+    bids = _bid_batches(s, 0, 200_000, 40_000)
+    g2 = GpuContext(0, own_stream=True)
+    both = ExecutionContext([_plan(5), _plan(2)], name="two", gpus=[gpu, g2])
+    serial = ExecutionContext([_plan(5), _plan(2)], name="two-serial", gpu=gpu)
+    for ctx in (both, serial):
+        ctx.feed_data_sources([[bids], [bids]])
+    a, b = both.execute(), serial.execute()
+    assert both._concurrent() and not serial._concurrent()
+    assert _q5_rows(a[0][0]) == _q5_rows(b[0][0]) and a[1][0].equals(b[1][0]) and a[1][0].num_rows > 0
+    # wait without a started call, and a second start while one is in flight, are argument errors
+    from flock_amd import FlockGpuError, _ffi
+    with pytest.raises(FlockGpuError) as e:
+        both.plans[0].wait()
+    assert e.value.code == _ffi.ERR_INVALID
+    both.plans[0].execute_async()
+    with pytest.raises(FlockGpuError):
+        both.plans[0].execute_async()
+    with pytest.raises(FlockGpuError):
+        both.plans[0].execute()
+    assert _q5_rows(both.plans[0].wait()) == _q5_rows(b[0][0])
+    both.close()
+    serial.close()
+    g2.close()
+
+
+@pytest.mark.gpu
+def test_batched_calls_async_equal_sync(gpu):
+    """flockgpu_q{3,5,8}_*_async + flockgpu_ctx_wait: two contexts with one call each in flight give what the synchronous calls give."""
+    from flock_amd import GpuContext, NEXMarkSource, Window, run_query
+    g2 = GpuContext(0, own_stream=True)
+    src = NEXMarkSource(20, 30_000, Window.hopping(10, 5), seed=12)
+    data = src.generate_data(gpu)
+    sched = data.window_schedule("bid")
+    want = gpu.q5_hot_items(data.bids, sched).to_host()
+    p1 = gpu.q5_hot_items_async(data.bids, sched)
+    p2 = g2.q5_hot_items_async(data.bids, sched)
+    for got in (p1.wait().to_host(), p2.wait().to_host()):
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    sa, sp = data.window_schedule("auction", Window.element_wise()), data.window_schedule("person", Window.element_wise())
+    w3 = gpu.q3_join(data.auctions, sa, data.persons, sp).to_host()
+    p1 = gpu.q3_join_async(data.auctions, sa, data.persons, sp)
+    p2 = g2.q3_join_async(data.auctions, sa, data.persons, sp)
+    for got in (p1.wait().to_host(), p2.wait().to_host()):
+        assert all(np.array_equal(got[k], w3[k]) for k in ("a_id", "auction_row", "person_row", "offsets")) and len(w3["a_id"]) > 0
+    ta, tp = data.window_schedule("auction", Window.tumbling(10)), data.window_schedule("person", Window.tumbling(10))
+    w8 = gpu.q8_join(data.persons, tp, data.auctions, ta).to_host()
+    p2 = g2.q8_join_async(data.persons, tp, data.auctions, ta)
+    got = p2.wait().to_host()
+    assert all(np.array_equal(got[k], w8[k]) for k in ("p_id", "offsets")) and len(w8["p_id"]) > 0
+    g2.close()
+
+
+# ------------------------------------------------------------------ GPU: hash placement of shuffling stages
+@pytest.mark.gpu
+def test_mixed_hash_placement_is_rejected_not_silently_wrong(gpu):
+    """A join stage whose two inputs were placed by DIFFERENT hashes -- the auctions by libflockgpu's stage 0, the persons by another
+    engine (the oracle's repartition_hash, standing in for DataFusion's ahash) -- would meet only part of its pairs in each partition.
+    The library's partitions carry their scheme as Arrow schema metadata and the consuming stage refuses the mix at feed time."""
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext, collect, partition_scheme
+    from flock_amd.stages import build_query_dag
+    s = oracle.NexmarkStream(seed=19, eps=60_000)
+    n = 120_000
+    stages = build_query_dag(json.loads(_plan(3)))
+    shuffling = [st for st in stages if st.is_shuffling]
+    join = stages[-1]
+    outs = []
+    for st in shuffling:
+        ctx = ExecutionContext([st.plan], gpu=gpu)
+        rel = _person_batches(s, 0, n, n) if "person" in ctx.plans[0].inputs else _auction_batches(s, 0, n, n)
+        outs.append(collect(ctx, [[rel]]))                                   # [partition][batch]
+        ctx.close()
+    tag = outs[0][0][0].schema.metadata
+    assert tag and tag[b"flockgpu.partition_scheme"].decode() == partition_scheme()
+    P = len(outs[0])
+    jc = ExecutionContext([join.plan], gpu=gpu)
+    # all GPU-placed: partition p of both relations joins; the union over p is the whole join
+    total = 0
+    for p in range(P):
+        total += collect(jc, [[outs[0][p]], [outs[1][p]]])[0][0].num_rows
+    a, pe = s.auctions(0, n), s.persons(0, n)
+    ar, _ = oracle.q3_join(a["seller"], a["category"], pe["p_id"], pe["state"])
+    assert total == len(ar) > 0
+    # one side re-placed by another engine's hash (untagged batches): refused, nothing joined
+    other = outs[1][0][0].replace_schema_metadata(None)
+    with pytest.raises(FlockGpuError) as e:
+        jc.feed_data_sources([[outs[0][0]], [[other]]])
+    assert e.value.code == _ffi.ERR_INVALID and "placement" in str(e.value)
+    jc.clean_data_sources()
+    # every producer on the other engine (all untagged) is consistent again -- and a foreign tag is named
+    untagged = [[b.replace_schema_metadata(None) for b in part] for part in (outs[0][0], outs[1][0])]
+    jc.feed_data_sources([[untagged[0]], [untagged[1]]])
+    jc.clean_data_sources()
+    foreign = outs[0][0][0].replace_schema_metadata({"flockgpu.partition_scheme": "datafusion/ahash-0000"})
+    with pytest.raises(FlockGpuError) as e:
+        jc.feed_data_sources([[[foreign]]])
+    assert "datafusion/ahash-0000" in str(e.value)
+    jc.close()

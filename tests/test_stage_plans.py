@@ -354,22 +354,21 @@ def test_two_plans_read_one_upload(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("q", [1, 2, 3, 5, 7, 8, 13])
 def test_generic_operators_equal_the_fused_pipelines(gpu, q, monkeypatch):
-    """Every whole-query plan once through its fused pipeline and once with FLOCKGPU_PLAN_GENERIC=1 (relops.hip only)."""
+    """Every whole-query plan once through its fused pipeline and once with FLOCKGPU_PLAN_GENERIC_ONLY (relops.hip only)."""
     from flock_amd.runtime import ExecutionContext, collect
     relations, _ = _relations(11, 30_000, 120_000)
     key = np.arange(1000, 3000, 7, dtype=np.int32)
     side = pa.record_batch([pa.array(key), pa.array((key * 5).astype(np.int32))], names=["key", "value"])
     src = [[[rb]] for rb in relations.values()] + [[[side]]]
 
-    def run():
-        ctx = ExecutionContext([_plan(q)], gpu=gpu)
+    def run(generic_only=False):
+        ctx = ExecutionContext([_plan(q)], gpu=gpu, generic_only=generic_only)
         text = ctx.plans[0].description
         out = collect(ctx, src)[0]
         ctx.close()
         return text, out
     fused_text, fused = run()
-    monkeypatch.setenv("FLOCKGPU_PLAN_GENERIC", "1")
-    generic_text, generic = run()
+    generic_text, generic = run(generic_only=True)
     assert "fused" not in generic_text and (q == 1 or "fused" in fused_text)
     assert fused[0].schema == generic[0].schema
     assert _rows(fused) == _rows(generic) and fused[0].num_rows > 0

@@ -2,7 +2,8 @@
 # gpurun helper: A/B of non-temporal vs plain 16-byte loads in the shared flag-tile loader (scan.hpp: load_flag_tile), same box, alternating.
 # B = a second library built with -DFLOCKGPU_AB_PLAIN_TILE_LOADS (flock_amd/libflockgpu_plain_tile_loads.so), swapped in for its runs.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
-cp flock_amd/libflockgpu.so /tmp/A.so; cp flock_amd/libflockgpu_plain_tile_loads.so /tmp/B.so
+# build B first: FLOCKGPU_BUILD_EXPERIMENTAL=1 FLOCKGPU_BUILD_DEFINES=-DFLOCKGPU_AB_PLAIN_TILE_LOADS python -m flock_amd.build
+cp flock_amd/libflockgpu.so /tmp/A.so; cp flock_amd/libflockgpu_experimental.so /tmp/B.so
 for round in 1 2; do for v in A B; do
   cp /tmp/$v.so flock_amd/libflockgpu.so
   python bench.py --no-cpu --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "

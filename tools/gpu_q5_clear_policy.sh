@@ -6,6 +6,8 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/q5_clear_policy; rm -rf "$OUT"; mkdir -p "$OUT"
+# needs the experimental library (FLOCKGPU_BUILD_EXPERIMENTAL=1 python -m flock_amd.build): the shipped one ignores FLOCKGPU_Q5_PLAIN_CLEAR
+cp flock_amd/libflockgpu_experimental.so flock_amd/libflockgpu.so
 cmd="python bench.py --query 5 --steps 8 --warmup 2 --no-also --no-cpu"
 for mode in plain nontemporal; do
   if [ "$mode" = "plain" ]; then export FLOCKGPU_Q5_PLAIN_CLEAR=1; else unset FLOCKGPU_Q5_PLAIN_CLEAR; fi

@@ -328,9 +328,33 @@ def golden_join():
             "schema": schema([t1[0], t1[1], t2[1]])}
 
 
+def sort_by(inp, keys):
+    """sort_exec in the dialect of the reference's join.json: [{"expr": column, "options": {"descending", "nulls_first"}}]."""
+    return {"execution_plan": "sort_exec", "input": inp,
+            "expr": [{"expr": k, "options": {"descending": bool(desc), "nulls_first": bool(desc)}} for k, desc in keys],
+            "output_rows": {"metric_type": "Counter", "value": 0}, "sort_time_nanos": {"metric_type": "TimeNanos", "value": 0}}
+
+
+def golden_aggregate_sorted():
+    """context.rs:471 whole: `... GROUP BY c3 ORDER BY c3` = SortExec over the merged partitions of golden_aggregate()."""
+    return sort_by({"execution_plan": "merge_exec", "input": golden_aggregate()}, [(name_col("c3"), False)])
+
+
+def golden_join_sorted():
+    """context.rs:544-551 whole (the shape of the reference's join.json): GlobalLimit 3 <- Sort [a ASC] <- Merge <- golden_join()."""
+    return {"execution_plan": "global_limit_exec", "limit": 3,
+            "input": sort_by({"execution_plan": "merge_exec", "input": golden_join()}, [(name_col("a"), False)])}
+
+
+def q3_sorted():
+    """launcher/aws/mod.rs:340-351: q3 with `ORDER BY a_id ASC` (the reference's distributed == local differential recipe)."""
+    return sort_by({"execution_plan": "coalesce_partitions_exec", "input": q3()}, [(col("a_id", 3), False)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, fn in (("golden_aggregate", golden_aggregate), ("golden_join", golden_join)):
+    for name, fn in (("golden_aggregate", golden_aggregate), ("golden_join", golden_join), ("golden_aggregate_sorted", golden_aggregate_sorted),
+                     ("golden_join_sorted", golden_join_sorted), ("q3_sorted", q3_sorted)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
@@ -340,7 +364,8 @@ def main():
             f.write("\n")
     # shapes of the reference's own fixtures (flock/src/tests/data/plan/simple_select.json, join.json), authored here in the
     # same dialect (not copies of the reference files): a pure projection of an Int64 column -- executable by the generic
-    # operators -- and a plan that ends in sort + limit, which the engine must hand back as UNSUPPORTED
+    # operators --, the same under sort + limit (device operators since round 4), and a plan the engine must hand back as
+    # UNSUPPORTED (a LEFT join)
     simple = proj(rr(memory([field("c1", "Int64")], [0], None)), [(col("c1", 0), "c1")], [field("c1", "Int64")])
     with open(os.path.join(OUT, "simple_select.json"), "w") as f:
         json.dump(simple, f, indent=1, sort_keys=True)
@@ -348,8 +373,13 @@ def main():
     sort_limit = {"execution_plan": "global_limit_exec", "limit": 3,
                   "input": {"execution_plan": "sort_exec", "input": simple,
                             "expr": [{"expr": col("c1", 0), "options": {"descending": False, "nulls_first": False}}]}}
-    with open(os.path.join(OUT, "unsupported_sort_limit.json"), "w") as f:
+    with open(os.path.join(OUT, "sort_limit.json"), "w") as f:
         json.dump(sort_limit, f, indent=1, sort_keys=True)
+        f.write("\n")
+    left_join = golden_join()
+    left_join["input"]["input"]["join_type"] = "Left"
+    with open(os.path.join(OUT, "unsupported_left_join.json"), "w") as f:
+        json.dump(left_join, f, indent=1, sort_keys=True)
         f.write("\n")
     print("wrote", sorted(os.listdir(OUT)))
 
