@@ -222,6 +222,8 @@ SYMBOLS = {
     "flockgpu_comm_transport": (C.c_char_p, [_vp]),
     "flockgpu_comm_barrier": (_i, [_vp, _vp]),
     "flockgpu_comm_inject_failure": (_i, [_vp, _i]),
+    "flockgpu_comm_set_timeout": (_i, [_vp, C.c_double]),
+    "flockgpu_comm_set_max_piece_bytes": (_i, [_vp, _i64]),
     "flockgpu_comm_phase_enable": (_i, [_vp, _i]),
     "flockgpu_comm_phase_reset": (_i, [_vp]),
     "flockgpu_comm_phase_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),

@@ -8,10 +8,12 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "../../include/flockgpu_comm.h"
 #include "relops.hpp"
@@ -53,19 +55,11 @@ struct LocalGroup {
 };
 
 constexpr int64_t kMaxPeerBytes = int64_t(1) << 30;  // RCCL transfers above 2 GiB per peer arrived corrupted (round 1): stay well below
-// (FLOCKGPU_COMM_MAX_PEER_BYTES lowers it: how the tests drive a relation through several rounds with ragged last pieces)
-static int64_t max_peer_bytes() {
-    static const int64_t v = [] {
-        const char *e = getenv("FLOCKGPU_COMM_MAX_PEER_BYTES");
-        const long long x = e ? atoll(e) : 0;
-        return x > 0 && x < kMaxPeerBytes ? (int64_t)x : kMaxPeerBytes;
-    }();
-    return v;
-}
 // Piece k of a (source, destination) pair of `bytes` bytes: [lo, hi).  Both ends of a pair know its size from the counts exchange, so
-// they walk the same pieces -- no agreement on a global round count is needed.
-static void peer_piece(int64_t bytes, uint64_t k, int64_t *lo, int64_t *hi) {
-    const int64_t cap = max_peer_bytes();
+// they walk the same pieces -- no agreement on a global round count is needed.  `cap`: the communicator's piece limit (kMaxPeerBytes;
+// flockgpu_comm_set_max_piece_bytes lowers it -- on EVERY rank alike -- which is how the tests drive a relation through several
+// rounds with ragged last pieces).
+static void peer_piece(int64_t bytes, uint64_t k, int64_t cap, int64_t *lo, int64_t *hi) {
     *lo = std::min<int64_t>(bytes, (int64_t)k * cap);
     *hi = std::min<int64_t>(bytes, (int64_t)(k + 1) * cap);
 }
@@ -90,6 +84,8 @@ struct flockgpu_comm {
     std::map<std::string, flockgpu::KernelStat> phase_stats;
     std::vector<std::string> phase_order;
     int inject = 0;      // flockgpu_comm_inject_failure: 1 = the next exchange's preparation fails, 2 = its data movement fails
+    int64_t max_piece = kMaxPeerBytes;   // flockgpu_comm_set_max_piece_bytes
+    double timeout_s = 120.0;   // flockgpu_comm_set_timeout: how long a wait behind RCCL work may last before the peers are given up
 };
 
 namespace {
@@ -141,6 +137,41 @@ void phase_finish(flockgpu_ctx *ctx, flockgpu_comm *c) {
     c->marks.clear();
 }
 
+// The host wait behind RCCL work.  A blind hipStreamSynchronize sits there forever when a peer died after the counts agreement (its
+// sends never arrive): instead the stream is polled together with the communicator's asynchronous error state, under a deadline.
+// On an error or a time-out this rank aborts its communicator -- which also cancels its own queued sends / receives, so the
+// stream drains -- and returns FLOCKGPU_ERR_PEER: every rank comes back, none waits for a rank that has gone.
+int comm_stream_wait(flockgpu_ctx *ctx, flockgpu_comm *c, const char *what) {
+    if (!c->is_rccl || c->n == 1 || !c->nccl) {
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FLOCKGPU_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return FLOCKGPU_OK;
+        if (q != hipErrorNotReady) {
+            kill_comm(c);
+            return fail(ctx, FLOCKGPU_ERR_HIP, "%s: stream error behind a collective: %s", what, hipGetErrorString(q));
+        }
+        ncclResult_t async = ncclSuccess;
+        const ncclResult_t r = ncclCommGetAsyncError(c->nccl, &async);
+        if (r != ncclSuccess || (async != ncclSuccess && async != ncclInProgress)) {
+            const char *msg = ncclGetErrorString(r != ncclSuccess ? r : async);
+            kill_comm(c);
+            (void)hipStreamSynchronize(ctx->stream);   // (the abort cancelled what was queued)
+            return fail(ctx, FLOCKGPU_ERR_PEER, "%s: the communicator reported '%s' while this rank waited: a peer is gone", what, msg);
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > c->timeout_s) {
+            kill_comm(c);
+            (void)hipStreamSynchronize(ctx->stream);
+            return fail(ctx, FLOCKGPU_ERR_PEER, "%s: no progress behind a collective for %.0f s: a peer is gone (flockgpu_comm_set_timeout)", what, waited);
+        }
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(spin > 20000 ? 1000 : 50));   // the first ~ms is a busy poll: the common case ends there
+    }
+}
+
 #define FG_NCCL(ctx, expr)                                                                                               \
     do {                                                                                                                 \
         ncclResult_t r_ = (expr);                                                                                        \
@@ -175,7 +206,7 @@ int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, in
     }
     FG_NCCL(ctx, ncclGroupEnd());
     FG_HIP(ctx, hipMemcpyAsync(h + (size_t)n * m, d + (size_t)n * m, sizeof(int64_t) * (size_t)n * m, hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(comm_stream_wait(ctx, c, "counts exchange"));
     std::copy(h + (size_t)n * m, h + (size_t)2 * n * m, recv);
     return FLOCKGPU_OK;
 }
@@ -212,7 +243,7 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
             if (bytes && !(skip_self && s == c->rank)) {   // in the pieces the RCCL transport would post (same arithmetic, tested here)
                 for (uint64_t k = 0;; ++k) {
                     int64_t lo, hi;
-                    peer_piece(bytes, k, &lo, &hi);
+                    peer_piece(bytes, k, c->max_piece, &lo, &hi);
                     if (hi <= lo) break;
                     const hipError_t e = hipMemcpyAsync(r8 + recv_off[s] + lo, static_cast<const uint8_t *>(g.send_ptr[(size_t)s]) + so[c->rank] + lo, (size_t)(hi - lo),
                                                         hipMemcpyDefault, ctx->stream);
@@ -225,17 +256,17 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
         if (rc != FLOCKGPU_OK) return rc;
         return met ? FLOCKGPU_OK : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the local group failed");
     }
-    // rounds of at most max_peer_bytes() per (source, destination) pair
+    // rounds of at most c->max_piece bytes per (source, destination) pair
     int64_t biggest = 0;
     for (int p = 0; p < n; ++p) biggest = std::max({biggest, send_off[p + 1] - send_off[p], recv_off[p + 1] - recv_off[p]});
-    const uint64_t rounds = (uint64_t)std::max<int64_t>(1, div_up(biggest, max_peer_bytes()));
+    const uint64_t rounds = (uint64_t)std::max<int64_t>(1, div_up(biggest, c->max_piece));
     for (uint64_t k = 0; k < rounds; ++k) {
         FG_NCCL(ctx, ncclGroupStart());
         for (int p = 0; p < n; ++p) {
             if (skip_self && p == c->rank) continue;
             int64_t s0, s1, r0, r1;
-            peer_piece(send_off[p + 1] - send_off[p], k, &s0, &s1);
-            peer_piece(recv_off[p + 1] - recv_off[p], k, &r0, &r1);
+            peer_piece(send_off[p + 1] - send_off[p], k, c->max_piece, &s0, &s1);
+            peer_piece(recv_off[p + 1] - recv_off[p], k, c->max_piece, &r0, &r1);
             if (s1 > s0) FG_NCCL(ctx, ncclSend(s8 + send_off[p] + s0, (size_t)(s1 - s0), ncclUint8, p, c->nccl, ctx->stream));
             if (r1 > r0) FG_NCCL(ctx, ncclRecv(r8 + recv_off[p] + r0, (size_t)(r1 - r0), ncclUint8, p, c->nccl, ctx->stream));
         }
@@ -274,7 +305,7 @@ int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, uint64_t *
             FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(uint64_t) * (size_t)mm, hipMemcpyHostToDevice, ctx->stream));
             FG_NCCL(ctx, ncclAllReduce(d, d, (size_t)mm, ncclUint64, ncclMax, c->nccl, ctx->stream));
             FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(uint64_t) * (size_t)mm, hipMemcpyDeviceToHost, ctx->stream));
-            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FG_TRY(comm_stream_wait(ctx, c, "all-reduce"));
             std::copy(h, h + mm, buf.begin());
             return FLOCKGPU_OK;
         }();
@@ -732,6 +763,9 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, const s
     return FLOCKGPU_OK;
     };
     rc = move();
+    // The single-GPU operator that follows waits on this stream with a plain synchronisation: the received bytes must have ARRIVED --
+    // or the peers must be known gone -- before it starts (one more host wait per exchanged relation, on the RCCL transport only).
+    if (rc == FLOCKGPU_OK && c->is_rccl && c->n > 1) rc = comm_stream_wait(ctx, c, "all-to-all");
     if (rc != FLOCKGPU_OK) kill_comm(c);   // past the agreement: the peers are already moving data
     return rc;
 }
@@ -824,6 +858,18 @@ int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm) {
     int rc = FLOCKGPU_OK;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "barrier: stream synchronisation failed");
     return all_reduce_max(ctx, comm, rc, &one, 1);
+}
+
+int flockgpu_comm_set_timeout(flockgpu_comm *comm, double seconds) {
+    if (!comm || !(seconds > 0)) return FLOCKGPU_ERR_INVALID;
+    comm->timeout_s = seconds;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_comm_set_max_piece_bytes(flockgpu_comm *comm, int64_t bytes) {
+    if (!comm || bytes < 1) return FLOCKGPU_ERR_INVALID;
+    comm->max_piece = std::min<int64_t>(bytes, kMaxPeerBytes);
+    return FLOCKGPU_OK;
 }
 
 int flockgpu_comm_inject_failure(flockgpu_comm *comm, int where) {

@@ -793,7 +793,12 @@ int stage_lane(flockgpu_plan *pl, int lane, const std::vector<flockgpu_plan::Cop
     for (size_t i = (size_t)lane; i < pieces.size(); i += (size_t)n_lanes) {
         const int k = lane * 2 + pl->stage_next[lane];
         pl->stage_next[lane] ^= 1;
-        if (hipEventSynchronize(pl->stage_done[k]) != hipSuccess) return FLOCKGPU_ERR_HIP;
+        if (!pl->stage[k]) {   // a lane's two chunks exist from the lane's first use on (all 16 up front pinned 64 MiB per plan)
+            if (hipHostMalloc(&pl->stage[k], kStageChunk, hipHostMallocDefault) != hipSuccess) return FLOCKGPU_ERR_OOM;
+            if (hipEventCreateWithFlags(&pl->stage_done[k], hipEventDisableTiming) != hipSuccess) return FLOCKGPU_ERR_HIP;
+        } else if (hipEventSynchronize(pl->stage_done[k]) != hipSuccess) {
+            return FLOCKGPU_ERR_HIP;
+        }
         std::memcpy(pl->stage[k], pieces[i].src, pieces[i].bytes);
         if (hipMemcpyAsync(pieces[i].dst, pl->stage[k], pieces[i].bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FLOCKGPU_ERR_HIP;
         if (hipEventRecord(pl->stage_done[k], ctx->stream) != hipSuccess) return FLOCKGPU_ERR_HIP;
@@ -814,12 +819,6 @@ int flush_jobs(flockgpu_plan *pl) {
             total += n;
         }
     pl->jobs.clear();
-    for (int k = 0; k < kStageChunks; ++k)
-        if (!pl->stage[k]) {
-            FG_HIP(ctx, hipHostMalloc(&pl->stage[k], kStageChunk, hipHostMallocDefault));
-            FG_HIP(ctx, hipEventCreateWithFlags(&pl->stage_done[k], hipEventDisableTiming));
-            FG_HIP(ctx, hipEventRecord(pl->stage_done[k], ctx->stream));
-        }
     // small feeds stay on the calling thread; from a few MB on the lanes pay for their start-up
     static const int want_lanes = getenv("FLOCKGPU_STAGE_LANES") ? std::max(1, std::min(kStageLanes, atoi(getenv("FLOCKGPU_STAGE_LANES")))) : 4;
     const int n_lanes = total < (size_t(2) << 20) ? 1 : (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(1, std::thread::hardware_concurrency()));

@@ -1435,6 +1435,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     if (wide_hint.size() != 1) wide_hint.assign(1, 0);
     static const bool no_wide = exp_env("FLOCKGPU_Q5_NO_WIDE") != nullptr;   // (A/B knob)
     bool wide_mode = wide_hint[0] != 0 && !weight && !part && !no_wide && dense;
+    bool wide_ran = false;   // wide mode was asked for AND feasible for this input (digit count within limits)
     bool speculate = dense && !part && hint[2] && hint[0] > 0 && !wide_mode;   // (wide mode sizes its digit count from the host-side layout)
     auto host_layout = [&]() -> int {   // the same rules on the host: first call of a ctx, the Partial stage, a declined speculation
         FG_HIP(ctx, hipMemcpyAsync(h_rng, d_rng, sizeof(int32_t) * n_rng, hipMemcpyDeviceToHost, ctx->stream));
@@ -1595,6 +1596,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             nd = (uint32_t)div_up((int64_t)max_range, int64_t(1) << kPartShift) + 1;
         }
         const bool wide = wide_mode && dense && nd >= 2 && nd <= (uint32_t)kPartMaxDigits && st.n_tiles > 0 && n_win > 0;
+        wide_ran = wide;
         uint32_t *d_sample = nullptr, *h_sample = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.part_sample", 4, &d_sample));
         FG_TRY(pinned_get_t(ctx, "q5.part_sample", 4, &h_sample));
@@ -1798,7 +1800,11 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     if (!weight && !part) {
         uint32_t *h_sample = nullptr;
         FG_TRY(pinned_get_t(ctx, "q5.part_sample", 4, &h_sample));
-        if (wide_mode && h_sample[0]) wide_hint[0] = (uint64_t)h_sample[1] * 4 >= (uint64_t)h_sample[0] * 3 ? 0 : 1;   // three quarters of the sample narrow: back to the fast kernel
+        // wide mode asked for but not feasible for this input (a pane range beyond the digit limit, or under two digits): nothing was
+        // sampled, so the leave condition below could never fire and the ctx would stay without its device-side layout speculation
+        // for good -- back to the speculating path
+        if (wide_mode && !wide_ran) wide_hint[0] = 0;
+        else if (wide_mode && h_sample[0]) wide_hint[0] = (uint64_t)h_sample[1] * 4 >= (uint64_t)h_sample[0] * 3 ? 0 : 1;   // three quarters of the sample narrow: back to the fast kernel
         else if (!wide_mode && dense && st.n_tiles > 64) wide_hint[0] = (int64_t)h_slow_count * 4 > (int64_t)st.n_tiles ? 1 : 0;   // tiles the fast kernel declined
     }
     // remember how dense the groups were so the next sparse call sizes its tables right away

@@ -355,6 +355,16 @@ class Comm:
         if self._lib.flockgpu_comm_inject_failure(self.h, where) != _ffi.OK:
             raise FlockGpuError(_ffi.ERR_INVALID, "flockgpu_comm_inject_failure: bad argument")
 
+    def set_timeout(self, seconds: float):
+        """Deadline of the waits behind RCCL work (flockgpu_comm_set_timeout): a peer gone after the agreement costs at most this."""
+        if self._lib.flockgpu_comm_set_timeout(self.h, float(seconds)) != _ffi.OK:
+            raise FlockGpuError(_ffi.ERR_INVALID, "flockgpu_comm_set_timeout: bad argument")
+
+    def set_max_piece_bytes(self, n: int):
+        """Largest single transfer per peer (flockgpu_comm_set_max_piece_bytes); every rank must set the same value."""
+        if self._lib.flockgpu_comm_set_max_piece_bytes(self.h, int(n)) != _ffi.OK:
+            raise FlockGpuError(_ffi.ERR_INVALID, "flockgpu_comm_set_max_piece_bytes: bad argument")
+
     def phases(self, on: bool = True, reset: bool = True):
         """Per-phase stream timeline of this rank's exchange calls on / off."""
         self._lib.flockgpu_comm_phase_enable(self.h, 1 if on else 0)

@@ -23,12 +23,48 @@ class SessionWindows:
 
     def __init__(self, timeout_seconds: int, key: str = "bidder", time: str = "b_date_time", base_time_ms: int = BASE_TIME):
         self.timeout, self.key, self.time, self.base_s = int(timeout_seconds), key, time, base_time_ms // 1000
-        # key -> [pieces, last event's whole second]; a piece = (batch index, row numbers) into self._batches
+        # key -> [pieces, last event's whole second]; a piece = (batch id, row numbers) into self._batches
         self._open: Dict[int, list] = {}
-        self._batches: list = []
+        # epoch batches that some open session still points into: id -> [batch, pieces pointing into it].  A batch leaves the dict
+        # with its last piece, so a long-running stream holds what its OPEN sessions need and nothing else (a list with
+        # one slot per epoch forever, rescanned every epoch)
+        # (entry = [batch, pieces, live rows, keys with a piece in it]; a batch of which under a quarter is still live -- a hot key that
+        # never times out keeps touching every epoch -- is compacted: its live rows move into a small batch of their own)
+        self._batches: Dict[int, list] = {}
+        self._next_batch = 0
 
     def _rows_of(self, pieces) -> list:
-        return [self._batches[b].take(rows) for b, rows in pieces]
+        out = []
+        for b, rows in pieces:
+            entry = self._batches[b]
+            out.append(entry[0].take(rows))
+            entry[1] -= 1
+            entry[2] -= len(rows)
+            if entry[1] == 0:
+                del self._batches[b]
+        return out
+
+    def _compact(self):
+        import pyarrow as pa
+        for b in [b for b, e in self._batches.items() if e[0].num_rows > 256 and e[2] * 4 < e[0].num_rows]:
+            batch, _, _, keys = self._batches.pop(b)
+            takes, at, moved = [], 0, []
+            for k in keys:
+                cur = self._open.get(k)
+                if cur is None:
+                    continue
+                for i, (pb, rows) in enumerate(cur[0]):
+                    if pb == b:
+                        takes.append(rows)
+                        moved.append((cur[0], i, at, len(rows)))
+                        at += len(rows)
+            if not takes:
+                continue
+            nb = self._next_batch
+            self._next_batch += 1
+            self._batches[nb] = [batch.take(pa.array(np.concatenate(takes))), len(moved), at, set(keys)]
+            for pieces, i, lo, n in moved:
+                pieces[i] = (nb, np.arange(lo, lo + n))
 
     def add_epoch(self, epoch: int, batch) -> list:
         """`batch`: the epoch's events (a pyarrow RecordBatch, or None for an epoch without events).  Returns the closed sessions'
@@ -36,8 +72,9 @@ class SessionWindows:
         import pyarrow as pa
         closed: list = []
         if batch is not None and batch.num_rows:
-            bi = len(self._batches)
-            self._batches.append(batch)
+            bi = self._next_batch
+            self._next_batch += 1
+            entry = self._batches[bi] = [batch, 0, 0, set()]
             keys = batch.column(self.key).to_numpy(zero_copy_only=False)
             secs = batch.column(self.time).cast(pa.int64()).to_numpy(zero_copy_only=False) // 1000
             order = np.argsort(keys, kind="stable")           # one partition per key, arrival order inside it
@@ -52,20 +89,26 @@ class SessionWindows:
                 if cur is None:
                     cur = self._open.setdefault(k, [[], 0])
                 cur[0].append((bi, rows))
+                entry[1] += 1
+                entry[2] += len(rows)
+                entry[3].add(k)
                 cur[1] = int(secs[rows[-1]])
         now = self.base_s + epoch                                                       # session.rs:163-170
         for k in [k for k, (_, last) in self._open.items() if now - last > self.timeout]:
             closed.append(self._open.pop(k)[0])
         out = [b for pieces in closed for b in self._rows_of(pieces)]
-        self._gc()
+        self._compact()
         return out
 
-    def _gc(self):
-        """Epoch batches no open session points into any more are dropped."""
-        live = {b for pieces, _ in self._open.values() for b, _ in pieces}
-        for i in range(len(self._batches)):
-            if i not in live:
-                self._batches[i] = None
+    @property
+    def held_rows(self) -> int:
+        """Rows of the epoch batches (and compacted remainders) still held."""
+        return sum(e[0].num_rows for e in self._batches.values())
+
+    @property
+    def held_batches(self) -> int:
+        """Epoch batches still referenced by an open session."""
+        return len(self._batches)
 
     @property
     def open_sessions(self) -> int:

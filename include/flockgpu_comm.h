@@ -75,13 +75,25 @@ int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm);
  * data-dependent refusal such as "rank 3 would receive more than 2^31 rows" -- is carried in the exchange's own messages
  * (the counts exchange before any data moves, the closing all-reduce), so EVERY rank returns: the failing rank its own status,
  * the others FLOCKGPU_ERR_PEER.  Nobody is left waiting for a rank that has gone.  A failure of the transport itself (RCCL /
- * device lost) marks the communicator dead on that rank: its later calls fail at once, a local group wakes its waiting peers
- * (reference: a failed function fails the whole query, flock-function/src/aws/actor.rs:425-543). */
+ * device lost) marks the communicator dead on that rank: its later calls fail at once, a local group wakes its waiting peers at
+ * once, RCCL peers come back with FLOCKGPU_ERR_PEER from their next wait -- as soon as RCCL reports the error, at the latest after
+ * flockgpu_comm_set_timeout's deadline (reference: a failed function fails the whole query, flock-function/src/aws/actor.rs:425-543). */
 
 /* Test hook for the failure semantics above: the next exchange call of this rank fails in its preparation (where = 1: a run-time
  * failure BEFORE the agreement -- every rank returns, the communicator stays usable) or in its data movement (where = 2: a
  * transport failure AFTER it -- this rank's communicator dies and wakes its local peers).  0 clears. */
 int flockgpu_comm_inject_failure(flockgpu_comm *comm, int where);
+
+/* Every host wait behind RCCL work (counts exchange, all-to-all, all-reduce) polls the stream together with the communicator's
+ * asynchronous error state instead of blocking blindly: when RCCL reports an error, or nothing completes for `seconds` (default
+ * 120), this rank aborts its communicator -- its own queued sends / receives are cancelled, the stream drains -- and the call
+ * returns FLOCKGPU_ERR_PEER.  So a rank that died AFTER the counts agreement (process killed, device lost) costs its peers at most
+ * the time-out, never a hang. */
+int flockgpu_comm_set_timeout(flockgpu_comm *comm, double seconds);
+/* The largest single transfer per (source, destination) pair; a longer run crosses in several rounds, each side walking the same
+ * pieces.  Default (and maximum) 1 GiB.  Every rank of a communicator must set the same value; lowering it to a few KiB is how the
+ * tests drive the multi-round path on small inputs. */
+int flockgpu_comm_set_max_piece_bytes(flockgpu_comm *comm, int64_t bytes);
 
 /* Per-phase timeline of the exchange calls on this rank's stream (HIP events at the phase boundaries: partial / stage-0
  * filters, partition + take, counts, all-to-all + regroup, final / join, all-reduce).  Off by default; totals accumulate over

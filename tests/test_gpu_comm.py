@@ -37,11 +37,17 @@ def _take_utf8(u, rows):
     return oracle.take_utf8(u, rows)
 
 
+PIECE_BYTES = None   # test_exchange_in_many_small_pieces lowers every communicator's piece limit
+
+
 def _run_ranks(world, body):
     """body(rank, ctx, comm) on `world` threads, each with its own ctx (own stream) on device 0; returns the results."""
     import torch
     from flock_amd import Comm, GpuContext
     comms = Comm.local(world)
+    if PIECE_BYTES:
+        for c in comms:
+            c.set_max_piece_bytes(PIECE_BYTES)
     ctxs = [GpuContext(0, own_stream=True) for _ in range(world)]
     out, err = [None] * world, [None] * world
     torch.cuda.synchronize()
@@ -315,15 +321,14 @@ def test_exchange_phase_timeline(host):
     ctx.close()
 
 
-def test_exchange_in_many_small_pieces():
-    """The transports move a (source, destination) run in pieces of at most `max_peer_bytes()` (1 GiB; RCCL transfers above 2 GiB
-    arrived corrupted in round 1).  With the limit lowered to an odd 4099 bytes every run of the local-rank tests above crosses in
-    dozens of pieces with ragged tails -- the same piece arithmetic the RCCL rounds post their sends and receives with."""
-    import os
-    import subprocess
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_in_many_small_pieces(host, world, monkeypatch):
+    """The transports move a (source, destination) run in pieces of at most the communicator's piece limit (1 GiB; RCCL transfers
+    above 2 GiB arrived corrupted in round 1).  With the limit lowered to an odd 4099 bytes through flockgpu_comm_set_max_piece_bytes
+    every run of the local-rank tests above crosses in dozens of pieces with ragged tails -- the same piece arithmetic the RCCL rounds
+    post their sends and receives with (round 3 flipped this through an environment variable in a subprocess)."""
     import sys
-    env = dict(os.environ, FLOCKGPU_COMM_MAX_PEER_BYTES="4099")
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "local_ranks", "-p", "no:cacheprovider"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert " passed" in p.stdout and "deselected" in p.stdout
+    monkeypatch.setattr(sys.modules[__name__], "PIECE_BYTES", 4099)
+    test_q5_exchange_local_ranks(host, world)
+    if world == 2:
+        test_q3_q8_exchange_local_ranks(host, world)

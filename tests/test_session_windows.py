@@ -51,6 +51,10 @@ def test_closed_sessions_per_epoch_are_the_walks(seed, n_epochs, per_epoch, n_bi
                 c, mn, mx = got.get(int(kk), (0, 2 ** 62, 0))
                 got[int(kk)] = (c + int(m.sum()), min(mn, int(tt[m].min())), max(mx, int(tt[m].max())))
         assert got == want[t], t
+        # only what OPEN sessions still point into is held (never one slot per epoch forever), and a batch that is mostly
+        # dead is compacted: at most 4x the live rows (+ small batches) stay pinned
+        live = sum(len(rows) for pieces, _ in w._open.values() for _, rows in pieces)
+        assert (w.open_sessions > 0 or w.held_batches == 0) and w.held_rows <= 4 * live + 256 * w.held_batches
     assert sum(len(d) for d in want) > 0
 
 
