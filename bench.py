@@ -197,7 +197,7 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
     return dt, stats, res
 
 
-def roofline(q, stats, rel_rows, table=None):
+def roofline(q, stats, rel_rows, table=None, workload=None):
     """achieved = the dominant kernel's algorithmic bytes per launch / its average launch duration (HIP events on the launch
     stream inside the timed region).  `table`: DOMINANT (plain operators) or DOMINANT_EXCHANGE (stage-0 kernels of the exchange)."""
     name, bpr, rel = (table or DOMINANT)[q]
@@ -207,7 +207,7 @@ def roofline(q, stats, rel_rows, table=None):
     alg_bytes = bpr * rel_rows[rel]
     avg_ms = st["total_ms"] / st["launches"]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = traffic_of(name, alg_bytes)   # PMC-derived HBM bytes per launch, measured separately at the default workload sizes
+    traffic = traffic_of(name, alg_bytes, workload)   # PMC-derived HBM bytes per launch, measured in separate profiled runs of the same workload
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, not this one)" if traffic else None,
@@ -216,16 +216,29 @@ def roofline(q, stats, rel_rows, table=None):
             "kernels_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items()}}
 
 
-def traffic_of(kernel, alg_bytes):
-    """PMC-derived HBM bytes per launch of `kernel` from profiles/traffic.json when they were taken at this workload size (the file
-    holds one entry per kernel and workload: `kernel` or `kernel@workload`)."""
+def traffic_of(kernel, alg_bytes, workload=None):
+    """PMC-derived HBM bytes per launch of `kernel` from profiles/traffic.json.  An entry is `kernel@workload` (or plain `kernel` for
+    the default-size rows) and records the algorithmic bytes of the run it was measured in (`alg_bytes`): it is attached when it was
+    taken at THIS workload size (within 2 %) -- whatever its ratio to the algorithmic bytes; a kernel that moves ten times what it
+    needs is exactly the row the number is for (the 0.9-3x plausibility window dropped q8_general's 10.8x)."""
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         table = json.load(open(prof))
     except Exception:
         return None
-    for k, t in table.items():
-        if (k == kernel or k.startswith(kernel + "@")) and isinstance(t, (int, float)) and 0.9 * alg_bytes <= t <= 3.0 * alg_bytes:
+    keys = ([f"{kernel}@{workload}"] if workload else []) + [kernel] + [k for k in table if k.startswith(kernel + "@")]
+    for k in keys:
+        t = table.get(k)
+        d = table.get(k + "_detail") or {}
+        if not isinstance(t, (int, float)):
+            continue
+        at = d.get("alg_bytes")
+        if at is not None:
+            if abs(at - alg_bytes) <= 0.02 * alg_bytes:
+                return t
+        elif workload and k == f"{kernel}@{workload}":
+            return t
+        elif 0.9 * alg_bytes <= t <= 3.0 * alg_bytes:   # entries of earlier rounds carry no size: keep their plausibility window
             return t
     return None
 
@@ -699,13 +712,93 @@ def entry_for(ctx, q, seconds, eps, steps, warmup, no_cpu, threads, barrier=lamb
     return e
 
 
+# ------------------------------------------------------------------ calls in flight together; a ctx that alternates two streams
+def async_entry(gpu, q, seconds, eps, steps):
+    """Two contexts (two streams, two worker threads), one asynchronous call each in flight (flockgpu_q*_async / flockgpu_ctx_wait): call
+    k + 1 is submitted before call k is waited for, so the host gap of one call -- launch preparation, the wake-up after its wait --
+    is covered by the other's kernels.  The reference runs every plan of a function on its own tokio task (context.rs:172-191).
+    Same input columns for both contexts (read-only); ms_per_step = wall time / calls."""
+    import torch
+    from flock_amd import GpuContext, run_query, run_query_async
+    s = make_stream(gpu, q, seconds, eps, 0)
+    ctxs = [GpuContext(gpu.device, own_stream=True) for _ in range(2)]
+    want = None
+    for c in ctxs:
+        for _ in range(3):
+            want = run_query(c, q, s)
+    rows = int(want.rows)
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    pending, last = None, None
+    for k in range(steps):
+        p = run_query_async(ctxs[k & 1], q, s)
+        if pending is not None:
+            last = pending.wait()
+        pending = p
+    last = pending.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    ok = int(last.rows) == rows
+    t1 = time.perf_counter()
+    for k in range(steps):
+        run_query(ctxs[0], q, s)
+    torch.cuda.synchronize()
+    dt_sync = time.perf_counter() - t1
+    e = {"value": round(input_rows(q, s) * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 4), "sync_ms_per_step": round(dt_sync / steps * 1e3, 4),
+         "calls_in_flight": 2, "result_rows_equal": ok, "input_rows": int(input_rows(q, s))}
+    del s, want, last
+    for c in ctxs:
+        c.close()
+    torch.cuda.empty_cache()
+    return e
+
+
+def alternating_entry(gpu, q, eps, steps):
+    """ONE ctx answering two different streams in turn: the speculation state a call leaves in the ctx -- layout
+    hints, output-size estimates, which sequence to take -- describes the OTHER stream every time.  ms per call against the same two
+    streams on a ctx of their own each."""
+    import torch
+    from flock_amd import GpuContext, run_query
+    secs = {5: (200, 60), 3: (100, 30), 8: (200, 50)}[q]
+    a, b = make_stream(gpu, q, secs[0], eps, 0), make_stream(gpu, q, secs[1], eps // 3, 1)
+    one, own = GpuContext(gpu.device, own_stream=True), [GpuContext(gpu.device, own_stream=True) for _ in range(2)]
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (2 * steps)
+    alt = timed(lambda: (run_query(one, q, a), run_query(one, q, b)))
+    sep = timed(lambda: (run_query(own[0], q, a), run_query(own[1], q, b)))
+    for c in [one] + own:
+        c.close()
+    del a, b
+    torch.cuda.empty_cache()
+    return {"ms_per_call_alternating_on_one_ctx": round(alt * 1e3, 4), "ms_per_call_on_own_ctxs": round(sep * 1e3, 4), "penalty": round(alt / sep, 3),
+            "streams": f"{secs[0]} s x {eps} events/s and {secs[1]} s x {eps // 3} events/s"}
+
+
 # ------------------------------------------------------------------ outside the generator's envelope: the GENERAL hash paths
 # NEXMark ids are dense and time-ordered, and the dense paths (bit blocks, direct-address counters) are what the headline runs on.
 # The same queries on keys in no particular order take the general hash join / hash aggregate kernels -- exact, and measured here so
 # that the fall-back is a number, not a cliff: the stream's keys are shuffled inside every window (q3 / q8: which person holds which
 # p_id; q5: which bid names which auction inside a 5-s pane), sizes as in the dense rows.
-GENERAL = {"q3_general": (3, 1000, "q3_probe_count_kernel", 8.0, "auction"), "q8_general": (8, 1000, "q8_sellers_set_kernel", 4.0, "auction"),
-           "q5_uniform": (5, 1087, "q5_part_emit_kernel", 8.0, "bid")}     # the partition's emit pass: every key read and written once
+# label -> (query, seconds, bracketed kernel, algorithmic bytes per row, relation, what is done to the keys)
+#   *_general / q5_uniform: keys SHUFFLED inside every window / pane -- dense in range, no order.  Since round 4 q3 / q8 answer these
+#     on their RANGE paths (bitmaps / row table laid out from exact statistics + a uniqueness check; no hash table), q5 in wide mode.
+#   *_hash: keys SPREAD (id -> id * 1009 inside int32: a range no bitmap or row table can afford) and shuffled: the hash join / hash
+#     set kernels themselves -- exact for any input, and measured so that this fall-back stays a number.
+GENERAL = {"q3_general": (3, 1000, "q3_probe_flag_kernel", 8.0, "auction", "shuffle"), "q8_general": (8, 1000, "q8_sellers_bitmap_kernel", 4.0, "auction", "shuffle"),
+           "q5_uniform": (5, 1087, "q5_part_emit_kernel", 8.0, "bid", "shuffle"),     # the partition's emit pass: every key read and written once
+           "q3_hash": (3, 1000, "q3_probe_count_kernel", 8.0, "auction", "spread"), "q8_hash": (8, 1000, "q8_sellers_set_kernel", 4.0, "auction", "spread")}
 
 
 def shuffle_within_segments(col, seg_off, seed):
@@ -729,19 +822,24 @@ def shuffle_within_segments(col, seg_off, seed):
 def general_entry(ctx, label, eps, steps):
     import torch
     from flock_amd import query_window, run_query
-    q, seconds, kernel, bpr, rel = GENERAL[label]
+    q, seconds, kernel, bpr, rel, how = GENERAL[label]
     s = make_stream(ctx, q, seconds, eps, 0)
     w = query_window(q)
     if q == 5:
         s.bids.auction = shuffle_within_segments(s.bids.auction, s.window_schedule("bid", w).pane_row_offsets, 5)
     else:
+        if how == "spread":    # ids 1000 .. 2e7 -> up to 2e10 folded into int32 by the multiply: sparse AND unordered, the same map on both sides of the join
+            s.persons.p_id = (s.persons.p_id * 1009).contiguous()
+            s.auctions.seller = (s.auctions.seller * 1009).contiguous()
         s.persons.p_id = shuffle_within_segments(s.persons.p_id, s.window_schedule("person", w).pane_row_offsets, 5)
     torch.cuda.synchronize()
     dt, st, r = run_steps(ctx, lambda: run_query(ctx, q, s), steps, 2, lambda: None, kernel)
     table = {q: (kernel, bpr, rel)}
+    keys = {"shuffle": "shuffled inside every window: dense range, no order (q3 / q8: range path, q5: wide mode)",
+            "spread": "spread over the int32 range and shuffled (hash join / hash set kernels)"}[how]
     e = {"value": round(input_rows(q, s) * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(input_rows(q, s)),
-         "windows": r.n_windows, "result_rows": int(r.rows), "seconds_of_events": seconds, "keys": "shuffled inside every window (general hash path)",
-         "roofline": roofline(q, st, rel_rows_of(s), table)}
+         "windows": r.n_windows, "result_rows": int(r.rows), "seconds_of_events": seconds, "keys": keys,
+         "roofline": roofline(q, st, rel_rows_of(s), table, workload=label)}
     del s, r
     torch.cuda.empty_cache()
     return e
@@ -840,6 +938,36 @@ def plan_collect_pcie(gpu, eps, steps):
 
     def variant(dt):
         return {"ms_per_window": round(dt * 1e3, 3), "value": round(n / dt, 1), "pcie_GBps": round(moved() / dt / 1e9, 2), "pcie_frac": round(moved() / dt / 1e9 / 63.0, 4)}
+
+    # The same windows with the device-side PANE RING (flockgpu_plan_ring_*, round 4): a Hopping(10, 5) window is two 5-s panes; the
+    # reference re-sends both for every window (hopping.rs:52-74), the ring keeps the older one's Partial COUNT groups in HBM, so a
+    # collect uploads -- and counts -- only the new pane: half the bytes per window.
+    half = (len(batches) + 1) // 2
+    panes = [batches[:half], batches[half:]]
+    pane_rows = [sum(b.num_rows for b in p) for p in panes]
+
+    def run_ring():
+        c = ExecutionContext([plan], gpu=GpuContext(gpu.device, own_stream=True))
+        c.open_window_ring(2)
+        rows = 0
+        for k in range(3):
+            rows = collect(c, [[panes[k & 1]]], pane=k)[0][0].num_rows
+        t0 = time.perf_counter()
+        for k in range(3, 3 + steps):
+            collect(c, [[panes[k & 1]]], pane=k)
+        dt = (time.perf_counter() - t0) / steps
+        c.close()
+        return dt, rows
+
+    def ring_variant(dt, rows):
+        b = 4.0 * (pane_rows[0] + pane_rows[1]) / 2 + 12.0 * rows     # one pane in, the winners out
+        return {"ms_per_window": round(dt * 1e3, 3), "value": round(n / dt, 1), "bytes_over_pcie_per_window": int(b), "pcie_GBps": round(b / dt / 1e9, 2),
+                "pcie_frac": round(b / dt / 1e9 / 63.0, 4), "vs_whole_window_feed": round(dt1 / dt, 2),
+                "note": "value counts the WINDOW's bids (both panes) per second, like the whole-window rows: the same windows, half the upload"}
+    try:
+        out["ring_one_instance_pageable"] = ring_variant(*run_ring())
+    except Exception as ex:
+        out["ring_error"] = repr(ex)
     try:
         out["two_instances_pageable"] = variant(run(2))
         lib = _ffi.load()
@@ -850,6 +978,7 @@ def plan_collect_pcie(gpu, eps, steps):
                 regs.append(ptr)
         out["one_instance_registered"] = variant(run(1))
         out["two_instances_registered"] = variant(run(2))
+        out["ring_one_instance_registered"] = ring_variant(*run_ring())
         for ptr in regs:
             lib.flockgpu_host_unregister(C.c_void_p(ptr))
     except Exception as ex:   # a side measurement must never hide the rest
@@ -1063,6 +1192,14 @@ def final_line(out):
         line["exchange"] = {"value": ex.get("value"), "ms_per_step": ex.get("ms_per_step"), "scaling": ex.get("scaling"),
                             "input_rows_all_gpus": ex.get("input_rows_all_gpus"), "transport": ex.get("transport"), "ranks": ex.get("ranks"),
                             "phases_ms": ex.get("phases_ms"), "roofline_frac": (ex.get("roofline") or {}).get("frac")}
+    for k in ("exchange_q3", "exchange_q8"):
+        e2 = out.get(k)
+        if isinstance(e2, dict):
+            line[k] = ({"error": str(e2["error"])[:160]} if "error" in e2 else
+                       {"value": e2.get("value"), "ms_per_step": e2.get("ms_per_step"), "scaling": e2.get("scaling"), "ranks": e2.get("ranks"),
+                        "transport": e2.get("transport"), "roofline_frac": (e2.get("roofline") or {}).get("frac")})
+    if "exchange_ok" in out:
+        line["exchange_ok"] = out["exchange_ok"]
     ws = out.get("window_sharded")
     if isinstance(ws, dict):   # N > 1: the same ranks without the exchange (every rank its own slice of the stream, "weak")
         line["window_sharded"] = {"value": ws.get("value"), "ms_per_step": ws.get("ms_per_step"), "scaling": ws.get("scaling"),
@@ -1081,8 +1218,12 @@ def final_line(out):
     terse = {}
     if isinstance(also, dict):
         def triple(e):
+            if isinstance(e, dict) and "penalty" in e:   # a ctx alternating two streams: [-, ms per call, -, x the same calls on ctxs of their own]
+                return [None, e.get("ms_per_call_alternating_on_one_ctx"), None, e["penalty"]]
             if not isinstance(e, dict) or "value" not in e:
                 return "error" if isinstance(e, dict) and "error" in e else None
+            if "sync_ms_per_step" in e:                  # two calls in flight: [rows/s, ms per call, -, ms per call one at a time]
+                return [_sig(float(e["value"])), e.get("ms_per_step"), None, e["sync_ms_per_step"]]
             r = e.get("roofline") or {}
             return [_sig(float(e["value"])), e.get("ms_per_step"), r.get("frac")]
         for k, e in also.items():
@@ -1094,6 +1235,9 @@ def final_line(out):
                     terse[f"x1_{k2}"] = t
             else:
                 terse[k] = triple(e)
+                ring = e.get("ring_one_instance_pageable") if isinstance(e, dict) else None
+                if isinstance(ring, dict):   # the pane ring: [window rows/s, ms per window, PCIe fraction, x the whole-window feed]
+                    terse[k + "_ring"] = [_sig(float(ring["value"])), ring.get("ms_per_window"), ring.get("pcie_frac"), ring.get("vs_whole_window_feed")]
         line["also_fields"] = ["rows_per_s", "ms_per_step", "roofline_frac"]
         line["also"] = terse
         line["also_file"] = out.get("also_file")
@@ -1301,11 +1445,26 @@ def main():
             if rank == 0 and out is not None:
                 out["exchange"] = dict(head, collective={"library": "RCCL (ncclSend / ncclRecv groups inside libflockgpu)", "ranks": head["ranks"],
                                                          "transport": head["transport"]})
+            # the join shuffles north_star names next to q5's (BASELINE.json configs[2] / [4]): q3 and q8 through the same communicator,
+            # first-class on the last line with their own rows/s, ranks and transport -- every rank takes part, rank 0 reports
+            for q2 in (3, 8):
+                if q2 == q:
+                    continue
+                try:
+                    h2 = exchange_entry(ctx, comm, q2, DEFAULT_SECONDS[q2] if q2 == 3 else 1000, args.eps, max(args.steps // 2, 5), 2, rank, world, barrier, reduce_max_sum)
+                    if rank == 0 and out is not None:
+                        out[f"exchange_q{q2}"] = h2
+                except Exception as e2:
+                    if rank == 0 and out is not None:
+                        out[f"exchange_q{q2}"] = {"error": repr(e2)}
+                    break   # (a failed collective leaves the communicator dead: nothing further on it)
         except Exception as e:
             comm_error = repr(e)
             if rank == 0 and out is not None:
                 out["exchange_error"] = comm_error
         dog.cancel()
+        if rank == 0 and out is not None:
+            out["exchange_ok"] = "exchange" in out and "exchange_error" not in out
 
     steps2 = max(args.steps, 10)   # the side entries' steps are 0.1-5 ms: ten of them cost nothing and average the host's turnaround out
     # ---- N = 1: the other BASELINE configs; q3 (named by the metric) at top level
@@ -1331,6 +1490,16 @@ def main():
         for label in GENERAL:
             try:
                 also[label] = general_entry(ctx, label, args.eps, 5)
+            except Exception as e:
+                also[label] = {"error": repr(e)}
+        for label, fn in (("q5_async2", lambda: async_entry(ctx, 5, DEFAULT_SECONDS[5], args.eps, 20)),
+                          ("q3_async2", lambda: async_entry(ctx, 3, DEFAULT_SECONDS[3], args.eps, 40)),
+                          ("q8_async2", lambda: async_entry(ctx, 8, DEFAULT_SECONDS[8], args.eps, 20)),
+                          ("q5_alternating", lambda: alternating_entry(ctx, 5, args.eps, 10)),
+                          ("q3_alternating", lambda: alternating_entry(ctx, 3, args.eps, 10)),
+                          ("q8_alternating", lambda: alternating_entry(ctx, 8, args.eps, 10))):
+            try:
+                also[label] = fn()
             except Exception as e:
                 also[label] = {"error": repr(e)}
         for label, fn in (("q11_next", lambda: q11_side(ctx, args.eps, steps2, args.no_cpu)),

@@ -7,10 +7,10 @@ operator call raises.
 """
 from ._ffi import FlockGpuError, LIB_PATH, load  # noqa: F401
 from .engine import (Auctions, Bids, Comm, DeviceUtf8, GpuContext, Persons, WindowSchedule)  # noqa: F401
-from .nexmark import (NEXMarkSource, NEXMarkStream, Window, query_window, run_query, synthetic_side_input,  # noqa: F401
+from .nexmark import (NEXMarkSource, NEXMarkStream, Window, query_window, run_query, run_query_async, synthetic_side_input,  # noqa: F401
                       window_epochs)
 from .session import SessionWindows, launch_session_query  # noqa: F401
 
 __all__ = ["FlockGpuError", "GpuContext", "Bids", "Auctions", "Persons", "DeviceUtf8", "WindowSchedule", "Comm",
-           "NEXMarkSource", "NEXMarkStream", "Window", "query_window", "run_query", "window_epochs", "SessionWindows", "launch_session_query",
+           "NEXMarkSource", "NEXMarkStream", "Window", "query_window", "run_query", "run_query_async", "window_epochs", "SessionWindows", "launch_session_query",
            "load", "LIB_PATH"]

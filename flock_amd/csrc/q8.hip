@@ -39,15 +39,45 @@ __device__ __forceinline__ void bitmap_or_global(uint32_t *gw, uint32_t bits) {
     if ((*gw & bits) != bits) __hip_atomic_fetch_or(gw, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t *__restrict__ seller, int64_t n_rows,
-                                                                   SegTiles st, const WinBitmap *__restrict__ wins,
-                                                                   uint32_t *bitmaps) {
-    __shared__ uint32_t s_bm[kBmLdsWords];
-    __shared__ uint32_t s_red[2 * kWavesPerBlock];
-    for (int s = threadIdx.x; s < kBmLdsWords; s += kBlock) s_bm[s] = 0;
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const WinBitmap wb = wins[tr.seg];
+// ---- the gapless layout, derived by every workgroup itself (round 4: no layout launch, no zeroing launch) ---------------------------
+// A window whose person ids have NO gaps (last - first + 1 = rows: NEXMark's persons, any id-ordered dense source) gets its bitmap at a
+// place the HOST knows without looking at the data: words [(lo >> 5) + 2 w, ...) of one arena, lo = the window's first person row -- a
+// window of r rows needs at most r / 32 + 2 words whatever its first id is, and the regions of consecutive windows cannot overlap.  So
+// the kernels need no layout table: two loads (the window's first and last id) give base and size.  A window with gaps raises a flag in
+// pinned host memory (the call is void: the host runs the sequence with the device-side layout pass); that the ids are strictly
+// increasing -- which makes first and last the minimum and the maximum and every row DISTINCT -- is verified row by row by the person pass.
+struct GaplessWin {
+    WinBitmap wb;
+    int64_t lo;        // the window's first person row
+    int32_t first_id;  // p_id of that row: person p_id sits in row lo + (p_id - first_id)
+};
+__device__ __forceinline__ GaplessWin gapless_window(const int32_t *__restrict__ p_id, const int64_t *__restrict__ person_seg_off, int32_t w,
+                                                     uint32_t *h_flags) {
+    GaplessWin g{WinBitmap{0, 0u, 0}, 0, 0};
+    const int64_t lo = person_seg_off[2 * w], hi = person_seg_off[2 * w + 1];
+    if (hi <= lo) return g;
+    const int32_t first = p_id[lo], last = p_id[hi - 1];
+    g.lo = lo;
+    g.first_id = first;
+    if ((int64_t)last - (int64_t)first + 1 != hi - lo) {
+        if (threadIdx.x == 0) __hip_atomic_store(h_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return g;
+    }
+    const int32_t base = first & ~31;
+    g.wb = WinBitmap{base, (uint32_t)(last - base + 1), (uint64_t)(lo >> 5) + 2u * (uint64_t)w};
+    return g;
+}
+
+// kWords: the span of ids (in 32-id words) a tile may stage in LDS.  Ordered sources: a tile's keys span a few thousand ids (1024 words);
+// keys in any order (the range path): a tile spans its whole window -- 8192 words = 262144 ids = 32 KB, four workgroups per CU -- so that
+// what reaches memory is still one fire-and-forget OR per touched WORD, consecutive words per wave instruction, not one per row.
+template <int kWords>
+__device__ __forceinline__ void sellers_bitmap_tile(const int32_t *__restrict__ seller, int64_t n_rows, const TileRange &tr, const WinBitmap wb,
+                                                    uint32_t *bitmaps, uint32_t *s_bm, uint32_t *s_red) {
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_bm);
+        for (int s = threadIdx.x; s < kWords / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
+    }
     if (wb.n_bits == 0) return;
     int32_t a[kFlagIters][4];
     load_flag_tile(seller, n_rows, tr, a);
@@ -84,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t
     if (mn == 0xFFFFFFFFu) return;  // no key of the tile can join
     const uint32_t w0 = mn >> 5, n_words = (mx >> 5) - w0 + 1;
     uint32_t *gbm = bitmaps + wb.word_off;
-    const bool staged = n_words <= (uint32_t)kBmLdsWords;  // block-uniform
+    const bool staged = n_words <= (uint32_t)kWords;  // block-uniform
     int32_t hot = -2;  // wave-uniform: the key most lanes hold right now (3/4 of the auctions name ONE seller)
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it) {
@@ -138,6 +168,37 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t
     }
 }
 
+__global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t *__restrict__ seller, int64_t n_rows,
+                                                                   SegTiles st, const WinBitmap *__restrict__ wins,
+                                                                   uint32_t *bitmaps) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWords];
+    __shared__ uint32_t s_red[2 * kWavesPerBlock];
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, wins[tr.seg], bitmaps, s_bm, s_red);
+}
+// keys in any order: the wide LDS stage (range path; also builds the persons' presence bitmap)
+constexpr int kBmLdsWordsWide = 8192;
+__global__ __launch_bounds__(kBlock) void q8_key_bitmap_wide_kernel(const int32_t *__restrict__ key, int64_t n_rows, SegTiles st,
+                                                                    const WinBitmap *__restrict__ wins, uint32_t *bitmaps) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWordsWide];
+    __shared__ uint32_t s_red[2 * kWavesPerBlock];
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    sellers_bitmap_tile<kBmLdsWordsWide>(key, n_rows, tr, wins[tr.seg], bitmaps, s_bm, s_red);
+}
+// the same with the gapless layout derived in place (the auction tile's window index names the person window)
+__global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_inline_kernel(const int32_t *__restrict__ seller, int64_t n_rows, SegTiles st,
+                                                                          const int32_t *__restrict__ p_id, const int64_t *__restrict__ person_seg_off,
+                                                                          uint32_t *bitmaps, uint32_t *h_flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWords];
+    __shared__ uint32_t s_red[2 * kWavesPerBlock];
+    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    const GaplessWin g = gapless_window(p_id, person_seg_off, tr.seg, h_flags);
+    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, g.wb, bitmaps, s_bm, s_red);
+}
+
+// kOrdered: the layout came from the windows' first and last ids and every row is taken for DISTINCT -- both hold for strictly increasing
+// ids, verified here; else (the range path): layout from exact statistics, uniqueness checked by q8_unique_check_kernel, any order.
+template <bool kOrdered>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void q8_persons_flag_kernel(const int32_t *__restrict__ p_id, int64_t n_rows,
                                                                  SegTiles st, const WinBitmap *__restrict__ wins,
                                                                  const uint32_t *__restrict__ bitmaps,
@@ -177,7 +238,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 // The layout came from the window's first and last id alone (q8_edge_layout_kernel): that they are the minimum and the
                 // maximum, and that every row is already DISTINCT, holds when the ids are strictly increasing -- verified here, row against
                 // predecessor; a violation voids the call (general path), reported with the results in the same synchronisation.
-                if (row_in && wb.n_bits) {
+                if (kOrdered && row_in && wb.n_bits) {
                     int32_t prev;
                     if (j > 0) prev = a[it][j - 1];
                     else {
@@ -371,6 +432,23 @@ __global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
+// Range path: the persons arrive in any order, so "every flagged row is a DISTINCT (p_id, name)" is not given -- it holds when no
+// two flagged persons of a window share an id, i.e. when the window's flagged ROWS are as many as the ids present in BOTH bitmaps
+// (sellers S, persons P; both built with fire-and-forget ORs).  One workgroup per window counts popc(S & P) and compares; a window
+// where they differ (duplicate ids -- equal or different names -- among the persons that sell) voids the call: the hash path decides.
+__global__ __launch_bounds__(kBlock) void q8_unique_check_kernel(const WinBitmap *__restrict__ wins, const uint32_t *__restrict__ sellers,
+                                                                 const uint32_t *__restrict__ persons, const int64_t *__restrict__ seg_out_off, uint32_t *err) {
+    __shared__ uint64_t s_red[kWavesPerBlock];
+    const WinBitmap wb = wins[blockIdx.x];
+    const uint32_t n_words = (wb.n_bits + 31) >> 5;
+    uint64_t n = 0;
+    for (uint32_t i = threadIdx.x; i < n_words; i += kBlock) n += (uint64_t)__popc(sellers[wb.word_off + i] & persons[wb.word_off + i]);
+    n = wave_sum_u64(n);
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_red[0] + s_red[1] + s_red[2] + s_red[3] != (uint64_t)(seg_out_off[blockIdx.x + 1] - seg_out_off[blockIdx.x])) atomicOr(err, 1u);
+}
+
 // Dense-path layout decided on the device: window w gets a bitmap over [first p_id & ~31, last p_id] when it has at least as many
 // bits as rows and at most 64 x rows + 4096 (the bound the host sized the arena for).  A window that does not qualify declines the
 // whole call: every n_bits becomes 0 (no seller is recorded, no person flagged) and info[1] = 0 sends the host to the general path.
@@ -423,6 +501,312 @@ __global__ __launch_bounds__(kBlock) void q8_zero_bitmaps_kernel(uint32_t *__res
         if (i + 4 <= n) *reinterpret_cast<uint4 *>(bitmaps + i) = make_uint4(0, 0, 0, 0);
         else
             for (uint64_t k = i; k < n; ++k) bitmaps[k] = 0;
+    }
+}
+
+// ---- steady-state kernels of the gapless dense path (round 4) ------------------------------------------------------------------------
+// persons: the bit test of q8_persons_flag_kernel with the layout derived in place, PLUS -- for the rows that join -- the bytes of their
+// names: the tile's name offsets are read here (one 16-byte load per lane and iteration next to the p_id load: 4 B / row more of a
+// pure stream) so that no separate length pass over the result rows is needed.  Per tile: counts[4] (rows per wave), bytes4[4]
+// (name bytes per wave) and tile_tot {rows, bytes} for the emit pass's self-scan.
+__global__ __launch_bounds__(kBlock) void q8_persons_flag_fast_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ name_off, int64_t n_rows,
+                                                                      SegTiles st, const uint32_t *__restrict__ bitmaps, uint32_t *__restrict__ flag_words,
+                                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ bytes4, uint2 *__restrict__ tile_tot,
+                                                                      uint32_t *h_flags) {
+    __shared__ uint32_t s_tot[2][kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const GaplessWin g = gapless_window(p_id, st.seg_off, tr.seg, h_flags);
+    const WinBitmap wb = g.wb;
+    const int32_t rel0 = flag_rel0();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int32_t a[kFlagIters][4];
+    load_flag_tile(p_id, n_rows, tr, a);
+    const bool whole = tr.tile_begin >= 0 && tr.tile_begin + kFlagTile < n_rows;   // (block-uniform) every offset of the tile's rows + 1 exists
+    int32_t off[kFlagIters][5], before[kFlagIters];
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = tr.tile_begin + rel0 + it * 256, chunk0 = r0 - lane * 4;
+        const int64_t rb = chunk0 - 1;
+        before[it] = p_id[rb < 0 ? 0 : (rb < n_rows ? rb : n_rows - 1)];
+        if (whole) {
+            const int4 o = *reinterpret_cast<const int4 *>(name_off + r0);   // (r0 is a multiple of 4; the host checked the column's alignment)
+            off[it][0] = o.x; off[it][1] = o.y; off[it][2] = o.z; off[it][3] = o.w;
+            const int32_t last = name_off[chunk0 + 256];
+            const int32_t nxt = __shfl_down(off[it][0], 1, 64);
+            off[it][4] = lane == 63 ? last : nxt;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int64_t r = r0 + j;
+                off[it][j] = name_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+            }
+        }
+    }
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+    const uint32_t *gbm = bitmaps + wb.word_off;
+    uint32_t flags = 0, my_bytes = 0;
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
+            const bool row_in = rel >= rel_lo && rel < rel_hi;
+            const bool in = row_in && idx < wb.n_bits;
+            if (row_in && wb.n_bits) {   // strictly increasing, inside [first, last]: with "no gaps" the ids are exactly first .. last
+                int32_t prev;
+                if (j > 0) prev = a[it][j - 1];
+                else {
+                    prev = __shfl_up(a[it][3], 1, 64);
+                    if (lane == 0) prev = before[it];
+                }
+                bad = bad || !(rel == rel_lo || a[it][j] > prev) || idx >= wb.n_bits;
+            }
+            const bool f = in & ((gbm[in ? idx >> 5 : 0u] >> (idx & 31)) & 1u);
+            flags |= (f ? 1u : 0u) << (it * 4 + j);
+            my_bytes += f ? (uint32_t)(off[it][j + 1] - off[it][j]) : 0u;
+        }
+    if (bad) __hip_atomic_store(h_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    flag_words[(size_t)tile * kBlock + threadIdx.x] = flags;
+    const uint32_t incl_r = wave_incl_scan_u32((uint32_t)__popc(flags)), incl_b = wave_incl_scan_u32(my_bytes);
+    if (lane == 63) {
+        counts[(size_t)tile * kWavesPerBlock + wave] = incl_r;
+        bytes4[(size_t)tile * kWavesPerBlock + wave] = incl_b;
+        s_tot[0][wave] = incl_r;
+        s_tot[1][wave] = incl_b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tile_tot[tile] = make_uint2(s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3], s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3]);
+}
+
+// emit: EVERYTHING the query returns, in one pass over the person tiles -- person_row, p_id, name offsets and name bytes.  Every
+// other person of a window sells (the join keeps half the rows), so the names are read the way they lie: a wave's 256 consecutive
+// rows name one contiguous byte range (~3 KB), fetched with coalesced 16-byte loads into LDS; the names that join are packed in LDS
+// and leave as 16-byte stores (the row-driven take read 32-byte sectors at random and needed a length pass, a scan and a row list
+// first: 0.10 + 0.026 + 0.013 + 0.027 ms of q8's 0.30 ms at 1e9 events).  The workgroup finds its output position itself (sum of
+// the lower tiles' totals), reports the windows' offsets and the totals straight into pinned host memory, and zeroes its rows'
+// share of the seller bitmap for the next call (clean-up after use: no zeroing launch).
+constexpr int kNameStage = 4096;   // bytes of names per 256 rows that fit the wave's LDS slots (16 B per row on average; beyond: the call is declined)
+constexpr int kNameSlot = kNameStage + 48;   // (+ the in / out phase, and the dwords lds_copy_value reads past a value)
+// One value from the staged source bytes to its place in the packed output, both in LDS, at any two byte alignments: the value's
+// next 16 bytes come in as five ALIGNED dwords (an unaligned LDS read costs 6x) and are realigned in registers; they go out as the
+// few bytes up to the destination's next dword boundary, whole aligned dwords, and the bytes behind the last whole dword -- ~10 LDS
+// instructions for an 11-byte name where a byte-wise copy issued 18.
+__device__ __forceinline__ void lds_copy_value(uint8_t *out_base, uint32_t dst, const uint32_t *src_words, uint32_t src, uint32_t len) {
+    for (uint32_t done = 0; done < len; done += 16, src += 16, dst += 16) {
+        const uint32_t n = min(16u, len - done), wi = src >> 2, sh = (src & 3) * 8;
+        const uint32_t w0 = src_words[wi], w1 = src_words[wi + 1], w2 = src_words[wi + 2], w3 = src_words[wi + 3], w4 = src_words[wi + 4];
+        uint32_t v[5] = {__funnelshift_r(w0, w1, sh), __funnelshift_r(w1, w2, sh), __funnelshift_r(w2, w3, sh), __funnelshift_r(w3, w4, sh), 0u};
+        const uint32_t head = min(n, (4u - (dst & 3u)) & 3u);   // bytes up to the destination's dword boundary
+        for (uint32_t c = 0; c < head; ++c) out_base[dst + c] = (uint8_t)(v[0] >> (8 * c));
+        const uint32_t hs = head * 8, body = (n - head) >> 2;
+        uint32_t *ow = reinterpret_cast<uint32_t *>(out_base + dst + head);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < body) ow[k] = __funnelshift_r(v[k], v[k + 1], hs);
+        const uint32_t at = head + body * 4;   // bytes written so far; at most three more
+        for (uint32_t c = at; c < n; ++c) out_base[dst + c] = (uint8_t)(v[c >> 2] >> (8 * (c & 3)));
+    }
+}
+__global__ __launch_bounds__(kBlock) void q8_emit_fused_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ name_off,
+                                                               const uint8_t *__restrict__ name, int64_t n_rows, SegTiles st,
+                                                               const uint32_t *__restrict__ flag_words, const uint32_t *__restrict__ counts,
+                                                               const uint32_t *__restrict__ bytes4, const uint2 *__restrict__ tile_tot, uint32_t *bitmaps,
+                                                               int32_t *__restrict__ out_person_row, int32_t *__restrict__ out_p_id,
+                                                               int32_t *__restrict__ out_off, uint8_t *__restrict__ out_bytes, uint64_t cap_rows,
+                                                               uint64_t cap_bytes, int64_t *__restrict__ h_off, uint64_t *__restrict__ h_tot,
+                                                               uint32_t *h_flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kNameSlot];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kWavesPerBlock][kNameSlot];
+    __shared__ uint16_t s_row[kWavesPerBlock][256], s_end[kWavesPerBlock][256], s_src[kWavesPerBlock][256];
+    __shared__ uint64_t s_red[2 * kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    // ---- where this tile's rows and bytes start: the lower tiles' totals, summed here (no scan launch)
+    uint64_t sr = 0, sb = 0;
+    for (int32_t t0 = (int32_t)threadIdx.x; t0 < tile; t0 += 4 * kBlock) {   // (four loads in flight per lane: the sum of 2442 tiles' totals was a chain of ten)
+        uint2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t0 + k * kBlock < tile ? tile_tot[t0 + k * kBlock] : make_uint2(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sr += v[k].x;
+            sb += v[k].y;
+        }
+    }
+    sr = wave_sum_u64(sr);
+    sb = wave_sum_u64(sb);
+    if (lane == 0) {
+        s_red[wave] = sr;
+        s_red[kWavesPerBlock + wave] = sb;
+    }
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const GaplessWin g = gapless_window(p_id, st.seg_off, tr.seg, h_flags);
+    __syncthreads();
+    uint64_t base_rows = 0, base_bytes = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        base_rows += s_red[w];
+        base_bytes += s_red[kWavesPerBlock + w];
+    }
+    // ---- this tile's share of the bitmap goes back to zero (every tile of a window together covers the window's words)
+    if (g.wb.n_bits) {
+        const uint32_t idx_lo = (uint32_t)(g.first_id - g.wb.base) + (uint32_t)(tr.lo - g.lo), idx_hi = (uint32_t)(g.first_id - g.wb.base) + (uint32_t)(tr.hi - g.lo);
+        uint32_t *gbm = bitmaps + g.wb.word_off;
+        // (the window's first tile also clears the bits below the first id in the first word)
+        const uint32_t w_lo = tr.lo == g.lo ? 0u : idx_lo >> 5;
+        for (uint32_t wd = w_lo + threadIdx.x; wd <= ((idx_hi - 1) >> 5); wd += kBlock) gbm[wd] = 0;
+    }
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    const uint4 wbv = *reinterpret_cast<const uint4 *>(bytes4 + (size_t)tile * kWavesPerBlock);
+    const uint64_t tile_rows = (uint64_t)wc.x + wc.y + wc.z + wc.w, tile_bytes = (uint64_t)wbv.x + wbv.y + wbv.z + wbv.w;
+    if (threadIdx.x == 0) {
+        if (tile == st.tile_first[tr.seg]) h_off[tr.seg] = (int64_t)base_rows;
+        if (tile == st.n_tiles - 1) {
+            h_tot[0] = base_rows + tile_rows;
+            h_tot[1] = base_bytes + tile_bytes;
+        }
+        if (tile == 0 && cap_rows) out_off[0] = 0;
+    }
+    if (base_rows + tile_rows > cap_rows || base_bytes + tile_bytes > cap_bytes) {   // (block-uniform) the hints were too small: the host redoes this pass
+        if (threadIdx.x == 0) __hip_atomic_store(h_flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (tile_rows == 0) return;
+    uint64_t cur_rows = base_rows + (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u);
+    uint64_t cur_bytes = base_bytes + (wave > 0 ? wbv.x : 0u) + (wave > 1 ? wbv.y : 0u) + (wave > 2 ? wbv.z : 0u);
+    const uint32_t flags = flag_words[(size_t)tile * kBlock + threadIdx.x];
+    const int32_t rel0 = flag_rel0();
+    const bool whole = tr.tile_begin >= 0 && tr.tile_begin + kFlagTile < n_rows;
+    const uintptr_t name_addr = reinterpret_cast<uintptr_t>(name);
+    uint8_t *in = s_in[wave], *outb = s_out[wave];
+    uint16_t *lrow = s_row[wave], *lend = s_end[wave], *lsrc = s_src[wave];
+    // the name offsets of all eight iterations are asked for up front: the iterations themselves then wait for one memory round trip
+    // (their bytes), not for two in a row
+    int4 o4[kFlagIters];
+    int32_t olast[kFlagIters];
+    if (whole) {
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it) {
+            const int64_t r0 = tr.tile_begin + rel0 + it * 256;
+            o4[it] = *reinterpret_cast<const int4 *>(name_off + r0);
+            olast[it] = name_off[r0 - lane * 4 + 256];
+        }
+    }
+    // The bytes of iteration it + 1 are asked for (into registers) BEFORE iteration it is packed and written out: with four waves per
+    // SIMD and every iteration a chain "names -> LDS -> pack -> store", a wave that waits for its names with nothing else in flight
+    // left the memory system idle (0.19 ms for 0.55 GB; rocprofv3, round 4).
+    constexpr int kStageLoads = (kNameStage + 16 + 1023) / 1024;   // 16-byte loads per lane that cover a full slot
+    uint4 stg[kStageLoads];
+    auto range_of = [&](int it, int32_t *b0, int32_t *b1) {   // (whole tiles) the byte range the wave's 256 rows of iteration `it` name
+        *b0 = __builtin_amdgcn_readfirstlane(o4[it].x);
+        *b1 = __builtin_amdgcn_readlane(olast[it], 63);
+    };
+    auto fetch = [&](int32_t b0, int32_t b1) {
+        const uint32_t in_phase = (uint32_t)((name_addr + (uint32_t)b0) & 15), span = (uint32_t)(b1 - b0) + in_phase;
+        // a 16-byte aligned chunk that holds at least one byte of the range never crosses a page: reading its tail is safe
+        const uint4 *src = reinterpret_cast<const uint4 *>((name_addr + (uint32_t)b0) & ~uintptr_t(15));
+#pragma unroll
+        for (int k = 0; k < kStageLoads; ++k) {
+            const uint32_t o = lane * 16 + k * 1024;
+            stg[k] = (b1 > b0 && span <= (uint32_t)kNameStage + 16u && o < span) ? src[o >> 4] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (whole) {
+        int32_t b0, b1;
+        range_of(0, &b0, &b1);
+        fetch(b0, b1);
+    }
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const uint32_t f4 = (flags >> (it * 4)) & 15u;
+        const int64_t r0 = tr.tile_begin + rel0 + it * 256;
+        int32_t off[5];
+        if (whole) {
+            off[0] = o4[it].x; off[1] = o4[it].y; off[2] = o4[it].z; off[3] = o4[it].w;
+            const int32_t nxt = __shfl_down(off[0], 1, 64);
+            off[4] = lane == 63 ? olast[it] : nxt;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int64_t r = r0 + j;
+                off[j] = name_off[r < 0 ? 0 : (r > n_rows ? n_rows : r)];
+            }
+        }
+        const int32_t b0 = __builtin_amdgcn_readfirstlane(off[0]);
+        const int32_t b1 = __builtin_amdgcn_readlane(off[4], 63);
+        const uint32_t in_phase = (uint32_t)((name_addr + (uint32_t)b0) & 15);
+        const uint32_t span = (uint32_t)(b1 - b0) + in_phase;
+        const bool fits = b1 >= b0 && span <= (uint32_t)kNameStage + 16u;   // (wave-uniform)
+        if (!whole && fits) fetch(b0, b1);   // (a ragged last tile: no pipelining)
+        if (fits) {
+#pragma unroll
+            for (int k = 0; k < kStageLoads; ++k) {
+                const uint32_t o = lane * 16 + k * 1024;
+                if (b1 > b0 && o < span) *reinterpret_cast<uint4 *>(in + o) = stg[k];
+            }
+        }
+        if (whole && it + 1 < kFlagIters) {   // the next iteration's names, on their way while this one is packed
+            int32_t n0, n1;
+            range_of(it + 1, &n0, &n1);
+            fetch(n0, n1);
+        }
+        if (!__ballot(f4 != 0)) continue;   // (wave-uniform) none of these 256 persons sells
+        if (!fits) {   // names too long for the slots: not this kernel's input
+            if (lane == 0) __hip_atomic_store(h_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            continue;
+        }
+        uint32_t len[4], mine_b = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            len[j] = (f4 >> j) & 1u ? (uint32_t)(off[j + 1] - off[j]) : 0u;
+            mine_b += len[j];
+        }
+        const uint32_t mine_r = (uint32_t)__popc(f4);
+        const uint32_t incl_b = wave_incl_scan_u32(mine_b), incl_r = wave_incl_scan_u32(mine_r);
+        const uint32_t it_b = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63), it_r = (uint32_t)__builtin_amdgcn_readlane((int)incl_r, 63);
+        const uint32_t out_phase = (uint32_t)(cur_bytes & 15);
+        __builtin_amdgcn_wave_barrier();   // the staged bytes are in place
+        // the flagged rows line up in LDS lists (row, source position, end in the packed output) ...
+        uint32_t pos = incl_b - mine_b, rk = incl_r - mine_r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((f4 >> j) & 1u) {
+                pos += len[j];
+                lrow[rk] = (uint16_t)(rel0 + it * 256 + j);
+                lsrc[rk] = (uint16_t)(in_phase + (uint32_t)(off[j] - b0));
+                lend[rk] = (uint16_t)pos;
+                ++rk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        // ... and are copied one value per lane, every lane busy (walking a lane's own four rows left half the lanes idle at every step)
+        for (uint32_t i = lane; i < it_r; i += 64) {
+            const uint32_t end_i = lend[i], start_i = i ? lend[i - 1] : 0u;
+            lds_copy_value(outb, out_phase + start_i, reinterpret_cast<const uint32_t *>(in), lsrc[i], end_i - start_i);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the packed names: LDS byte i is output byte (cur_bytes - out_phase) + i
+        uint8_t *gout = out_bytes + (cur_bytes - out_phase);
+        const uint32_t end = out_phase + it_b;
+        for (uint32_t o = lane * 16; o < end; o += 64 * 16) {
+            if (o >= out_phase && o + 16 <= end) {
+                stream_store4(gout + o, *reinterpret_cast<const uint4 *>(outb + o));
+            } else {   // the first / last chunk is shared with the neighbouring iteration, wave or tile: only this iteration's bytes
+                for (uint32_t c = (o < out_phase ? out_phase : o); c < o + 16 && c < end; ++c) gout[c] = outb[c];
+            }
+        }
+        for (uint32_t i = lane; i < it_r; i += 64) {
+            const int64_t r = tr.tile_begin + lrow[i];
+            stream_store(&out_person_row[cur_rows + i], (int32_t)r);
+            stream_store(&out_p_id[cur_rows + i], g.first_id + (int32_t)(r - g.lo));   // no gaps: the id is arithmetic
+            stream_store(&out_off[cur_rows + i + 1], (int32_t)(cur_bytes + lend[i]));   // (lend: the value's end inside this iteration's bytes)
+        }
+        __builtin_amdgcn_wave_barrier();   // the slots are rewritten by the next iteration
+        cur_rows += it_r;
+        cur_bytes += it_b;
     }
 }
 
@@ -485,18 +869,111 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     // As in q3: the dense path is speculated -- a device pass lays the bitmaps out, everything up to the name lengths is
     // queued behind it, and the verdict, the row counts and the byte total reach the host in ONE synchronisation
     // (four before).  After a call that did not qualify the statistics are read first.
+    // regime of the ctx's last call: 1 = dense, ordered ids (speculated: where a ctx starts); 2 = dense RANGE, ids in any order (exact
+    // statistics first); 0 = hash tables
     std::vector<int64_t> &regime = ctx->host_i64["q8.dense_regime"];
     if (regime.empty()) regime.push_back(1);
-    bool try_dense = n_win > 0;
-    if (try_dense && !regime[0]) {   // the previous call did not qualify: look before building (exact statistics, one more wait)
+    // exact statistics of the persons' ids, one more wait: every window strictly increasing over an affordable range -> 1; an affordable
+    // range in any order -> 2 (bitmaps over [min, max] need no order: interleaved generators, Kafka partitions, a shuffled replay --
+    // ids that are dense but not time-ordered); else 0
+    auto look = [&](int *mode_out) -> int {
         FG_TRY(segment_key_stats(ctx, person->p_id, person->rows, st_p, d_stats, d_stats + n_win, d_stats + 2 * n_win));
         FG_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int32_t) * 3 * n_win, hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int w = 0; w < n_win && try_dense; ++w) {
+        bool ordered = true, affordable = true;
+        for (int w = 0; w < n_win; ++w) {
             if (pe[w] == pb[w]) continue;
             const int64_t base = (int64_t)h_stats[w] & ~int64_t(31), bits = (int64_t)h_stats[n_win + w] - base + 1;
-            if (!h_stats[2 * n_win + w] || bits > 64 * (pe[w] - pb[w]) + 4096 || bits >= (int64_t(1) << 31)) try_dense = false;
+            ordered = ordered && h_stats[2 * n_win + w];
+            affordable = affordable && bits <= 64 * (pe[w] - pb[w]) + 4096 && bits < (int64_t(1) << 31);
         }
+        *mode_out = affordable ? (ordered ? 1 : 2) : 0;
+        return FLOCKGPU_OK;
+    };
+    int mode = n_win > 0 ? (int)regime[0] : 0;
+    if (n_win > 0 && mode != 1) FG_TRY(look(&mode));   // the previous call did not qualify for the speculated path: look before building
+    bool try_dense = mode == 1;
+    // ---- the steady-state sequence of the gapless dense path: sellers (layout inline) -> persons (+ name lengths) -> emit (rows, ids,
+    // name offsets AND bytes; self-scan; zeroes the bitmap behind itself): THREE launches and ONE synchronisation, nothing else on the
+    // stream -- no memset / copy nodes (flags, window offsets and totals land in one pinned block), no scan launches, no separate Utf8
+    // length / take passes, no id gather.  Taken once a call of this ctx has gone through the general sequence below (which leaves the
+    // output-size estimates); anything unusual -- ids with gaps or out of order, long names, estimates too small beyond one retry --
+    // falls through to it again.
+    std::vector<int64_t> &fast = ctx->host_i64["q8.fast_hint"];   // {row capacity, byte capacity, valid, calls to skip after a decline, bitmap words known zero}
+    if (fast.size() != 5) fast.assign(5, 0);
+    if (fast[3] > 0) --fast[3];
+    const bool fast_ok = try_dense && regime[0] == 1 && fast[2] && fast[3] == 0 && st_a.n_tiles > 0 && st_p.n_tiles > 0 && st_p.n_tiles <= kSelfScanMaxTiles &&
+                         (reinterpret_cast<uintptr_t>(person->name.offsets) & 15) == 0;
+    if (fast_ok) {
+        const size_t words = (size_t)(person->rows >> 5) + (size_t)2 * n_win + 8;
+        uint32_t *bits = nullptr, *bytes4 = nullptr;
+        uint2 *tile_tot = nullptr;
+        uint64_t *h_blk = nullptr;
+        const void *bits_before = ctx->arena["q8.fast_bits"].ptr;
+        FG_TRY(arena_get_t(ctx, "q8.fast_bits", words, &bits));
+        if (bits != bits_before || fast[4] < (int64_t)words) {   // a new (or grown) arena, or a call that may have left bits behind
+            FG_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(uint32_t) * words, ctx->stream));
+        }
+        fast[4] = 0;   // (set again when this call's emit pass has cleaned up behind itself)
+        FG_TRY(arena_get_t(ctx, "q8.bytes4", (size_t)st_p.n_tiles * kWavesPerBlock + 4, &bytes4));
+        FG_TRY(arena_get_t(ctx, "q8.tile_tot", (size_t)st_p.n_tiles + 1, &tile_tot));
+        FG_TRY(pinned_get_t(ctx, "q8.fast", (size_t)n_win + 8, &h_blk));   // [0]: two flag words, [1] rows, [2] bytes, [4 ..] window offsets
+        uint32_t *h_flags = reinterpret_cast<uint32_t *>(h_blk);
+        int64_t *h_woff = reinterpret_cast<int64_t *>(h_blk + 4);
+        h_blk[0] = h_blk[1] = h_blk[2] = 0;   // (the previous call's values were read under its synchronisation)
+        {
+            LaunchScope ls(ctx, "q8_sellers_bitmap_kernel");
+            hipLaunchKernelGGL(q8_sellers_bitmap_inline_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller, auction->rows, st_a,
+                               person->p_id, st_p.seg_off, bits, h_flags);
+        }
+        FG_TRY(check_launch(ctx, "q8_sellers_bitmap_inline_kernel"));
+        {
+            LaunchScope ls(ctx, "q8_persons_flag_kernel");
+            hipLaunchKernelGGL(q8_persons_flag_fast_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id, person->name.offsets,
+                               person->rows, st_p, bits, flag_words, counts, bytes4, tile_tot, h_flags);
+        }
+        FG_TRY(check_launch(ctx, "q8_persons_flag_fast_kernel"));
+        int64_t cap_rows = std::min<int64_t>(out_cap - 16, std::max<int64_t>(fast[0], 1)), cap_bytes = std::max<int64_t>(fast[1], 16);
+        bool done = false;
+        for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+            int32_t *o_pid = nullptr, *o_off = nullptr;
+            uint8_t *o_bytes = nullptr;
+            FG_TRY(arena_get_t(ctx, "q8.out_p_id", (size_t)cap_rows + 1, &o_pid));
+            FG_TRY(arena_get_t(ctx, "q8.fast_name_off", (size_t)cap_rows + 2, &o_off));
+            FG_TRY(arena_get_t(ctx, "q8.fast_name_bytes", (size_t)cap_bytes + 32, &o_bytes));
+            h_flags[1] = 0;
+            {
+                LaunchScope ls(ctx, "q8_emit_fused_kernel");
+                hipLaunchKernelGGL(q8_emit_fused_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id, person->name.offsets,
+                                   person->name.data, person->rows, st_p, flag_words, counts, bytes4, tile_tot, bits, o_pr, o_pid, o_off, o_bytes,
+                                   (uint64_t)cap_rows, (uint64_t)cap_bytes, h_woff, h_blk + 1, h_flags);
+            }
+            FG_TRY(check_launch(ctx, "q8_emit_fused_kernel"));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (h_flags[0]) break;   // not this kernel's input: the general sequence decides
+            fast[4] = (int64_t)words;   // every tile's emit workgroup zeroed its share before anything else
+            if (h_flags[1]) {   // more rows / bytes than the estimates: the exact totals are known now, once more
+                cap_rows = (int64_t)h_blk[1] + 16;
+                cap_bytes = (int64_t)h_blk[2] + 16;
+                continue;
+            }
+            n_out = (int64_t)h_blk[1];
+            offs.assign((size_t)n_win + 1, 0);
+            offs[(size_t)n_win] = n_out;
+            for (int w = n_win - 1; w >= 0; --w) offs[(size_t)w] = pe[w] > pb[w] ? h_woff[w] : offs[(size_t)w + 1];
+            fast[0] = n_out + n_out / 8 + 4096;
+            fast[1] = (int64_t)h_blk[2] + (int64_t)h_blk[2] / 8 + 65536;
+            out->p_id = o_pid;
+            out->name = flockgpu_utf8{o_off, o_bytes};
+            out->name_bytes = (int64_t)h_blk[2];
+            out->person_row = o_pr;
+            out->win_out_offsets = offs.data();
+            out->rows = n_out;
+            done = true;
+        }
+        if (done) return FLOCKGPU_OK;
+        fast[2] = 0;
+        fast[3] = 16;   // a declined call costs three launches and a wait for nothing: not again right away
     }
     if (try_dense) {
         const size_t bound_words = (size_t)2 * (size_t)person->rows + (size_t)130 * n_win + 8;
@@ -525,7 +1002,7 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         if (st_p.n_tiles > 0) {
             LaunchScope ls(ctx, "q8_persons_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_p.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
-            hipLaunchKernelGGL(q8_persons_flag_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows,
+            hipLaunchKernelGGL(q8_persons_flag_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows,
                                st_p, d_wins, bitmaps, flag_words, counts, d_verr);
         }
         FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
@@ -541,7 +1018,6 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         FG_HIP(ctx, hipMemcpyAsync(h_verr, d_verr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (*h_verr) h_info[1] = 0;   // some window's ids are not strictly increasing: the bitmaps' bounds and the DISTINCT shortcut are void
-        regime[0] = h_info[1] ? 1 : 0;
         if (h_info[1]) {
             offs.assign(h_off, h_off + n_win + 1);
             n_out = offs[n_win];
@@ -555,8 +1031,81 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
             try_dense = false;
         }
     }
-    if (!try_dense) {
-        regime[0] = 0;
+    if (!try_dense && mode == 1) FG_TRY(look(&mode));   // the speculation was declined: the statistics say what the ids are like
+    if (!try_dense && mode == 1) mode = 0;               // (ordered and affordable by the statistics, yet declined: not an input for the bitmaps)
+    if (mode == 2) {
+        // ---- the RANGE path: bitmaps over every window's exact [min, max], persons in any order.  Sellers S and persons P are both
+        // built with the LDS-staged fire-and-forget ORs of the dense path; a person is flagged when its id is in S; the flagged rows are
+        // DISTINCT when rows = popc(S & P) per window (q8_unique_check_kernel) -- duplicates among the persons that sell send the call
+        // to the hash tables.  No hashing, no compare-and-swap: the persons shuffled inside every window ran 2.0 ms per 1e9 events
+        // through the hash path (the seller set alone 0.64 ms: 6.6e6 returning CAS on a 240 MB set, 4.7 % of the HBM rate).
+        std::vector<WinBitmap> h_wins((size_t)n_win);
+        uint64_t words = 0;
+        for (int w = 0; w < n_win; ++w) {
+            if (pe[w] == pb[w]) {
+                h_wins[(size_t)w] = WinBitmap{0, 0u, words};
+                continue;
+            }
+            const int32_t base = h_stats[w] & ~31;
+            const uint32_t bits = (uint32_t)((int64_t)h_stats[n_win + w] - base + 1);
+            h_wins[(size_t)w] = WinBitmap{base, bits, words};
+            words += (bits + 31) >> 5;
+        }
+        WinBitmap *d_wins = nullptr, *p_wins = nullptr;
+        uint32_t *sellers = nullptr, *present = nullptr, *d_err = nullptr, *h_err = nullptr;
+        FG_TRY(arena_get_t(ctx, "q8.wins", (size_t)n_win, &d_wins));
+        FG_TRY(pinned_get_t(ctx, "q8.wins", (size_t)n_win, &p_wins));
+        FG_TRY(arena_get_t(ctx, "q8.bitmaps", (size_t)words + 8, &sellers));
+        FG_TRY(arena_get_t(ctx, "q8.person_bits", (size_t)words + 8, &present));
+        FG_TRY(arena_get_t(ctx, "q8.order_err", 4, &d_err));
+        FG_TRY(pinned_get_t(ctx, "q8.order_err", 4, &h_err));
+        std::copy(h_wins.begin(), h_wins.end(), p_wins);   // (the staging was last read under the statistics' synchronisation)
+        FG_HIP(ctx, hipMemcpyAsync(d_wins, p_wins, sizeof(WinBitmap) * (size_t)n_win, hipMemcpyHostToDevice, ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(sellers, 0, sizeof(uint32_t) * ((size_t)words + 4), ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(present, 0, sizeof(uint32_t) * ((size_t)words + 4), ctx->stream));
+        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+        if (st_a.n_tiles > 0) {
+            LaunchScope ls(ctx, "q8_sellers_bitmap_kernel");
+            hipLaunchKernelGGL(q8_key_bitmap_wide_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller, auction->rows, st_a, d_wins, sellers);
+        }
+        FG_TRY(check_launch(ctx, "q8_sellers_bitmap_kernel"));
+        if (st_p.n_tiles > 0) {
+            {
+                LaunchScope ls(ctx, "q8_key_bitmap_wide_kernel");
+                hipLaunchKernelGGL(q8_key_bitmap_wide_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p, d_wins, present);
+            }
+            FG_TRY(check_launch(ctx, "q8_key_bitmap_wide_kernel"));
+            LaunchScope ls(ctx, "q8_persons_flag_kernel");
+            const unsigned grid = (unsigned)std::min<int64_t>(st_p.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
+            hipLaunchKernelGGL(q8_persons_flag_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p, d_wins, sellers, flag_words,
+                               counts, d_err);
+        }
+        FG_TRY(check_launch(ctx, "q8_persons_flag_kernel"));
+        FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
+        hipLaunchKernelGGL(q8_unique_check_kernel, dim3((unsigned)n_win), dim3(kBlock), 0, ctx->stream, d_wins, sellers, present, d_off, d_err);
+        FG_TRY(check_launch(ctx, "q8_unique_check_kernel"));
+        FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
+        std::vector<int64_t> &rows_hint = ctx->host_i64["q8.rows_hint"];
+        if (rows_hint.empty()) rows_hint.push_back(0);
+        const int64_t take_rows = rows_hint[0] > 0 ? std::min<int64_t>(out_cap - 16, rows_hint[0]) : out_cap - 16;
+        FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, take_rows, &g_name, tile_base + st_p.n_tiles));
+        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*h_err) {
+            mode = 0;   // duplicate ids among the persons that sell: DISTINCT (p_id, name) needs the names compared
+        } else {
+            offs.assign(h_off, h_off + n_win + 1);
+            n_out = offs[n_win];
+            if (n_out > take_rows) {
+                FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, n_out, &g_name, nullptr));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            gather_utf8_narrow(&g_name, n_out);
+            rows_hint[0] = n_out + n_out / 8 + 4096;
+        }
+    }
+    if (mode == 0) {
         const uint64_t pcap64 = std::max<uint64_t>(64, (uint64_t)max_p * 3 / 2 + 8);
         if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
         const uint32_t pcap = (uint32_t)pcap64;
@@ -609,6 +1158,14 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
     FG_TRY(arena_get_t(ctx, "q8.out_p_id", (size_t)n_out + 1, &o_pid));
     FG_TRY(gather_i32(ctx, person->p_id, o_pr, n_out, o_pid));
     FG_TRY(gather_utf8_finish(ctx, g_name, &out->name, &out->name_bytes));
+    regime[0] = mode;
+    if (mode == 1) {   // a dense call: the next one of this ctx may take the three-launch sequence with these estimates
+        fast[0] = n_out + n_out / 8 + 4096;
+        fast[1] = out->name_bytes + out->name_bytes / 8 + 65536;
+        fast[2] = 1;
+    } else {
+        fast[2] = 0;
+    }
     out->p_id = o_pid;
     out->person_row = o_pr;
     out->win_out_offsets = offs.data();

@@ -242,3 +242,17 @@ def run_query(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window:
         return ctx.q8_join(stream.persons, stream.window_schedule("person", window), stream.auctions,
                            stream.window_schedule("auction", window))
     raise NotImplementedError(f"q{query_number} is outside the hot-path scope (SURVEY.md section 8)")
+
+
+def run_query_async(ctx: GpuContext, query_number: int, stream: NEXMarkStream, window: Optional[Window] = None):
+    """`run_query` handed to the context's worker thread (flockgpu_q{3,5,8}_*_async): returns at once with a pending call whose
+    `.wait()` gives the result object.  One call in flight per context; calls on different contexts overlap on the GPU -- the
+    reference's one tokio task per plan (flock/src/runtime/context.rs:172-191)."""
+    window = window or query_window(query_number)
+    if query_number == 3:
+        return ctx.q3_join_async(stream.auctions, stream.window_schedule("auction", window), stream.persons, stream.window_schedule("person", window))
+    if query_number == 5:
+        return ctx.q5_hot_items_async(stream.bids, stream.window_schedule("bid", window))
+    if query_number == 8:
+        return ctx.q8_join_async(stream.persons, stream.window_schedule("person", window), stream.auctions, stream.window_schedule("auction", window))
+    raise NotImplementedError(f"q{query_number} has no asynchronous entry point")

@@ -631,6 +631,117 @@ def test_q3_five_launch_sequence_equals_the_general_one():
     c.close()
 
 
+def _q8_check(out, pw, aw, p_id, name, nm, seller, tag):
+    g_names, off = _str_rows(*out["name"]), out["offsets"]
+    total = 0
+    for w in range(pw.n_windows):
+        (plo, phi), (alo, ahi) = pw.window_rows(w), aw.window_rows(w)
+        rows = oracle.q8_join(p_id[plo:phi], name.slice(plo, phi), seller[alo:ahi])
+        want = sorted((int(p_id[plo + r]), nm[plo + r]) for r in rows)
+        sl = slice(off[w], off[w + 1])
+        assert sorted(zip(out["p_id"][sl].tolist(), g_names[sl])) == want, (tag, w)
+        assert np.array_equal(out["p_id"][sl], p_id[out["person_row"][sl]]), (tag, w)      # person_row names the joined input rows
+        total += len(want)
+    assert total == len(out["p_id"]) == off[-1]
+    return total
+
+
+def test_q8_three_launch_sequence_and_the_range_path():
+    """From its second dense call on a ctx q8 runs sellers -> persons (+ name lengths) -> fused emit (rows, ids, name offsets and bytes;
+    bitmap cleaned behind itself) on windows whose ids have no gaps (q8.hip "steady-state sequence").  Same rows as the general
+    sequence; estimates too small -> the emit pass once more; gaps, a swapped pair or long names void it and the general sequence
+    answers; and ids in ANY order over a dense range take the range path (bitmaps + uniqueness check), duplicates the hash path --
+    all on ONE ctx, so every switch of regime is exercised with the state the previous call left."""
+    from flock_amd import Auctions, GpuContext, Persons, Window, WindowSchedule, run_query
+    c = GpuContext(0)
+    g = _gpu_stream(c, 91, 40_000, 30, Window.tumbling(10))
+    first = run_query(c, 8, g).to_host()                     # general sequence (first call of the ctx)
+    for _ in range(3):                                       # three-launch sequence
+        again = run_query(c, 8, g).to_host()
+        for k in ("p_id", "person_row", "offsets"):
+            assert np.array_equal(first[k], again[k]), k
+        assert np.array_equal(first["name"][0], again["name"][0]) and np.array_equal(first["name"][1], again["name"][1])
+    assert len(first["p_id"]) > 1000
+    _check_q8_nexmark(c, 92, 400_000, 20)                    # ten times the rows: the emit pass is redone with the exact sizes
+    _check_q8_nexmark(c, 92, 400_000, 20)
+    _check_q8_nexmark(c, 93, 40_000, 20)
+    rng = np.random.default_rng(9)
+    npn, na = 70_000, 200_000
+    pw = WindowSchedule(np.array([0, 25_000, 25_000, 50_000, npn]), np.arange(4), np.arange(1, 5))      # window 1: no persons
+    aw = WindowSchedule(np.array([0, 80_001, 120_000, 120_000, na]), np.arange(4), np.arange(1, 5))     # window 2: no auctions
+    for case in ("gapless", "gap", "swap", "long_names", "shuffled", "shuffled_wide", "shuffled_dups", "gapless"):
+        p_id = np.arange(npn, dtype=np.int32) + 5000
+        if case == "gap":
+            p_id[60_000:] += 3
+        if case == "swap":
+            p_id[[31_000, 31_001]] = p_id[[31_001, 31_000]]
+        if case.startswith("shuffled"):                      # which person holds which id, shuffled inside every window
+            if case == "shuffled_wide":
+                p_id[50_000:] = 5000 + 50_000 + np.arange(npn - 50_000, dtype=np.int32) * 20      # last window spans 400 000 ids: beyond the LDS stage
+            for w in range(4):
+                lo, hi = pw.window_rows(w)
+                p_id[lo:hi] = rng.permutation(p_id[lo:hi])
+            if case == "shuffled_dups":
+                p_id[40_000] = p_id[40_001]                  # two persons of window 2 share an id ...
+        width = 40 if case == "long_names" else 9
+        nm = [(b"person-%d" % (i % 4999)).ljust(int(rng.integers(0, width)), b"x") if i % 11 else b"" for i in range(npn)]
+        if case == "shuffled_dups":
+            nm[40_000], nm[40_001] = b"twin-a", b"twin-b"    # ... under different names: both are DISTINCT rows
+        name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32), np.frombuffer(b"".join(nm), np.uint8).copy())
+        seller = rng.choice(p_id, na).astype(np.int32)
+        seller[::9] = rng.integers(-2**31, 2**31 - 1, len(seller[::9])).astype(np.int32)
+        seller[500:60_000:2] = p_id[4321]
+        if case == "shuffled_dups":
+            seller[100_000] = p_id[40_000]                   # the shared id sells: the duplicate matters
+        per = Persons(_dev(p_id), _utf8(name), None, None, npn)
+        auc = Auctions(None, _dev(seller), None, na)
+        for rep in range(2):                                 # second call: whatever sequence the first one armed
+            total = _q8_check(c.q8_join(per, pw, auc, aw).to_host(), pw, aw, p_id, name, nm, seller, (case, rep))
+            assert total > 1000
+    c.close()
+
+
+def test_q3_range_path_ids_in_any_order():
+    """q3 with the persons' ids shuffled inside every window (dense range, no order): the row table laid out from exact statistics
+    (q3.hip "RANGE path"); duplicates in a window void it for the hash join; gapless data afterwards returns to the bit blocks."""
+    from flock_amd import Auctions, GpuContext, Persons, WindowSchedule
+    c = GpuContext(0)
+    rng = np.random.default_rng(21)
+    npn, na = 50_000, 160_000
+    pw = WindowSchedule(np.array([0, 15_000, 15_000, 35_000, npn]), np.arange(4), np.arange(1, 5))
+    aw = WindowSchedule(np.array([0, 60_001, 90_000, 90_000, na]), np.arange(4), np.arange(1, 5))
+    for case in ("ordered", "shuffled", "shuffled", "shuffled_gaps", "shuffled_dups", "ordered", "ordered"):
+        p_id = np.arange(npn, dtype=np.int32) + 777
+        if case == "shuffled_gaps":
+            p_id = (777 + np.cumsum(rng.integers(1, 4, npn))).astype(np.int32)
+        if case.startswith("shuffled"):
+            for w in range(4):
+                lo, hi = pw.window_rows(w)
+                p_id[lo:hi] = rng.permutation(p_id[lo:hi])
+        if case == "shuffled_dups":
+            p_id[20_000:20_050] = p_id[20_050:20_100]
+        st = rng.choice(np.array([b"or", b"id", b"ca", b"wa", b"tx", b""], dtype=object), npn)
+        state = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32), np.frombuffer(b"".join(st), np.uint8).copy())
+        nm = [b"n%d" % (i % 313) for i in range(npn)]
+        name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32), np.frombuffer(b"".join(nm), np.uint8).copy())
+        seller = rng.choice(p_id, na).astype(np.int32)
+        seller[::6] = rng.integers(-2**31, 2**31 - 1, len(seller[::6])).astype(np.int32)
+        category = rng.integers(9, 12, na).astype(np.int32)
+        a_id = (np.arange(na) * 5 + 2).astype(np.int32)
+        out = c.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw, Persons(_dev(p_id), _utf8(name), _utf8(name), _utf8(state), npn), pw).to_host()
+        off, total = out["offsets"], 0
+        g_state, g_name = _str_rows(*out["state"]), _str_rows(*out["name"])
+        for w in range(4):
+            (alo, ahi), (plo, phi) = aw.window_rows(w), pw.window_rows(w)
+            ar, pr = oracle.q3_join(seller[alo:ahi], category[alo:ahi], p_id[plo:phi], state.slice(plo, phi))
+            sl = slice(off[w], off[w + 1])
+            assert sorted(zip((out["auction_row"][sl] - alo).tolist(), (out["person_row"][sl] - plo).tolist())) == sorted(zip(ar.tolist(), pr.tolist())), (case, w)
+            assert sorted(zip(g_name[sl], g_state[sl], out["a_id"][sl].tolist())) == sorted((nm[plo + j], st[plo + j], int(a_id[alo + i])) for i, j in zip(ar, pr)), (case, w)
+            total += len(ar)
+        assert total == len(out["a_id"]) > 1000, case
+    c.close()
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_full_size_properties(ctx):
     """1e8-event stream (configs q2/q3 of BASELINE.json): checks that need no CPU pass over all rows."""

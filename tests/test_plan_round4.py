@@ -183,7 +183,7 @@ def test_q5_pane_ring_equals_whole_window_feeds_equals_oracle(gpu, generic_only,
     ppw, n_panes = size // hop, seconds // hop
     pane_batches = [_bid_batches(s, p * hop * eps, (p + 1) * hop * eps, 5_000) for p in range(n_panes)]
     pane_host = [s.bids(p * hop * eps, (p + 1) * hop * eps)["auction"] for p in range(n_panes)]
-    pane_batches[5], pane_host[5] = [], np.zeros(0, np.int32)            # a pane in which nothing arrived
+    pane_batches[3], pane_host[3] = [], np.zeros(0, np.int32)            # a pane in which nothing arrived
     ring = ExecutionContext([_plan(5)], name="q5-ring", gpu=gpu, generic_only=generic_only)
     whole = ExecutionContext([_plan(5)], name="q5-whole", gpu=gpu, generic_only=generic_only)
     ring.open_window_ring(ppw)
@@ -296,24 +296,26 @@ def test_plans_on_their_own_contexts_execute_side_by_side(gpu):
     s = oracle.NexmarkStream(seed=5, eps=50_000)
     bids = _bid_batches(s, 0, 200_000, 40_000)
     g2 = GpuContext(0, own_stream=True)
-    both = ExecutionContext([_plan(5), _plan(2)], name="two", gpus=[gpu, g2])
-    serial = ExecutionContext([_plan(5), _plan(2)], name="two-serial", gpu=gpu)
+    p2 = json.loads(_plan(2))
+    p2["input"]["input"]["predicate"]["left"]["right"]["value"] = {"Int64": 7}      # auction % 7 = 0: rows at any stream size
+    both = ExecutionContext([p2, _plan(5)], name="two", gpus=[g2, gpu])
+    serial = ExecutionContext([p2, _plan(5)], name="two-serial", gpu=gpu)
     for ctx in (both, serial):
-        ctx.feed_data_sources([[bids], [bids]])
+        ctx.feed_data_sources([[bids], [bids]])      # (q2's leaf takes the first source, q5's first `bid` leaf the second)
     a, b = both.execute(), serial.execute()
     assert both._concurrent() and not serial._concurrent()
-    assert _q5_rows(a[0][0]) == _q5_rows(b[0][0]) and a[1][0].equals(b[1][0]) and a[1][0].num_rows > 0
+    assert _q5_rows(a[1][0]) == _q5_rows(b[1][0]) and a[0][0].equals(b[0][0]) and a[0][0].num_rows > 0
     # wait without a started call, and a second start while one is in flight, are argument errors
     from flock_amd import FlockGpuError, _ffi
     with pytest.raises(FlockGpuError) as e:
         both.plans[0].wait()
     assert e.value.code == _ffi.ERR_INVALID
-    both.plans[0].execute_async()
+    both.plans[1].execute_async()
     with pytest.raises(FlockGpuError):
-        both.plans[0].execute_async()
+        both.plans[1].execute_async()
     with pytest.raises(FlockGpuError):
-        both.plans[0].execute()
-    assert _q5_rows(both.plans[0].wait()) == _q5_rows(b[0][0])
+        both.plans[1].execute()
+    assert _q5_rows(both.plans[1].wait()) == _q5_rows(b[1][0])
     both.close()
     serial.close()
     g2.close()
