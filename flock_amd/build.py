@@ -22,9 +22,10 @@ CSRC = os.path.join(HERE, "csrc")
 # FLOCKGPU_BUILD_DEFINES lists, e.g. "-DFLOCKGPU_AB_PLAIN_TILE_LOADS"): the only build in which the A/B knobs of common.hpp's exp_env()
 # read the environment.  The shipped libflockgpu.so is always built without it.
 EXPERIMENTAL = os.environ.get("FLOCKGPU_BUILD_EXPERIMENTAL", "") not in ("", "0")
-OBJ = os.path.join(HERE, "csrc", "build_experimental" if EXPERIMENTAL else "build")
-LIB = os.path.join(HERE, "libflockgpu_experimental.so" if EXPERIMENTAL else "libflockgpu.so")
-STAMP = os.path.join(HERE, "csrc", ".build_stamp_experimental" if EXPERIMENTAL else ".build_stamp")
+_TAG = ("_" + os.environ["FLOCKGPU_BUILD_TAG"]) if EXPERIMENTAL and os.environ.get("FLOCKGPU_BUILD_TAG") else ""   # several A/B variants side by side
+OBJ = os.path.join(HERE, "csrc", "build_experimental" + _TAG if EXPERIMENTAL else "build")
+LIB = os.path.join(HERE, "libflockgpu_experimental" + _TAG + ".so" if EXPERIMENTAL else "libflockgpu.so")
+STAMP = os.path.join(HERE, "csrc", ".build_stamp_experimental" + _TAG if EXPERIMENTAL else ".build_stamp")
 CFLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",            # q1's f64 multiply must stay a plain IEEE multiply

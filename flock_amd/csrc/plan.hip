@@ -91,6 +91,10 @@ struct DevBuf {  // a leaf column on the device, grown by feeds
     void *values = nullptr;  // fixed-width values or Utf8 bytes
     int32_t *offsets = nullptr;
     int64_t bytes = 0;
+    // NULLs that may reach an output or an aggregate (round 4): one validity byte per row, materialised from the first batch that
+    // holds such a NULL on; rows [0, valid_rows) are covered (the rest -- batches without NULLs -- is filled with 1 when the leaf is scanned)
+    uint8_t *valid = nullptr;
+    int64_t valid_rows = 0;
 };
 struct LeafData {
     std::vector<DevBuf> cols;
@@ -912,9 +916,24 @@ struct Exec {
                 tc.c.values = b.values;
                 tc.c.offsets = b.offsets;
                 tc.c.bytes = b.bytes;
+                if (b.valid && b.valid_rows > 0) {   // batches fed after the last one with NULLs: all valid
+                    DevBuf &wb = pl->leaves[(size_t)src].cols[(size_t)leaf_column(n->leaf, src, (int)i)];
+                    if (wb.valid_rows < ld.rows) {
+                        FG_HIP(ctx, hipMemsetAsync(wb.valid + wb.valid_rows, 1, (size_t)(ld.rows - wb.valid_rows), ctx->stream));
+                        wb.valid_rows = ld.rows;
+                    }
+                    tc.c.valid = b.valid;
+                }
             }
         }
         return FLOCKGPU_OK;
+    }
+    // a fused pipeline reads plain NEXMark columns: a leaf column that carries validity sends its sub-tree to the generic operators
+    bool leaf_has_validity(int leaf) const {
+        if (leaf < 0) return false;
+        for (auto &c : pl->leaves[(size_t)resolve_leaf(leaf)].cols)
+            if (c.valid && c.valid_rows > 0) return true;
+        return false;
     }
 
     // leaf column as a typed device pointer (fused entry points)
@@ -1152,15 +1171,24 @@ struct Exec {
         CmpOp op;
         if (!cmp_of(e->s, &op, flip)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: operator '%s' in a predicate", e->s.c_str());
         auto column = [&](const Expr *x) -> const TCol * { return x->kind == EKind::Col && in.cols[(size_t)x->col].present ? &in.cols[(size_t)x->col] : nullptr; };
+        // a comparison with NULL is NULL, and a NULL predicate keeps no row: the comparison's mask is cleared where an operand is NULL
+        // (exact through AND and OR: NULL OR TRUE is TRUE, NULL OR FALSE is NULL -- dropped -- just as FALSE OR x evaluates)
+        auto nulls_out = [&](int rc, const TCol *a, const TCol *b = nullptr) -> int {
+            if (rc != FLOCKGPU_OK) return rc;
+            if (a && a->c.valid) FG_TRY(mask_and_valid(ctx, mask, a->c.valid, in.rows));
+            if (b && b->c.valid) FG_TRY(mask_and_valid(ctx, mask, b->c.valid, in.rows));
+            return FLOCKGPU_OK;
+        };
         if (l->kind == EKind::Col && (r->kind == EKind::LitI || r->kind == EKind::LitF) && column(l) && column(l)->c.type == ColType::F64)
-            return mask_cmp_f64_lit(ctx, column(l)->c, in.rows, op, r->kind == EKind::LitF ? r->f : (double)r->i, mask);
-        if (l->kind == EKind::Col && r->kind == EKind::LitI && column(l)) return mask_cmp_lit(ctx, column(l)->c, in.rows, op, r->i, mask);
+            return nulls_out(mask_cmp_f64_lit(ctx, column(l)->c, in.rows, op, r->kind == EKind::LitF ? r->f : (double)r->i, mask), column(l));
+        if (l->kind == EKind::Col && r->kind == EKind::LitI && column(l)) return nulls_out(mask_cmp_lit(ctx, column(l)->c, in.rows, op, r->i, mask), column(l));
         if (l->kind == EKind::Col && r->kind == EKind::LitS && column(l) && (op == CmpOp::EQ || op == CmpOp::NE))
-            return mask_utf8_eq(ctx, column(l)->c, in.rows, r->s, op == CmpOp::NE, mask);
-        if (l->kind == EKind::Col && r->kind == EKind::Col && column(l) && column(r)) return mask_cmp_col(ctx, column(l)->c, column(r)->c, in.rows, op, mask);
+            return nulls_out(mask_utf8_eq(ctx, column(l)->c, in.rows, r->s, op == CmpOp::NE, mask), column(l));
+        if (l->kind == EKind::Col && r->kind == EKind::Col && column(l) && column(r))
+            return nulls_out(mask_cmp_col(ctx, column(l)->c, column(r)->c, in.rows, op, mask), column(l), column(r));
         if (is_bin(l, "Modulo") && r->kind == EKind::LitI) {
             const Expr *c = uncast(l->l.get()), *m = uncast(l->r.get());
-            if (c->kind == EKind::Col && m->kind == EKind::LitI && column(c)) return mask_mod_cmp(ctx, column(c)->c, in.rows, m->i, op, r->i, mask);
+            if (c->kind == EKind::Col && m->kind == EKind::LitI && column(c)) return nulls_out(mask_mod_cmp(ctx, column(c)->c, in.rows, m->i, op, r->i, mask), column(c));
         }
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate shape is not supported");
     }
@@ -1200,11 +1228,18 @@ struct Exec {
             FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             FG_TRY(gather_utf8_multi_finish(ctx, g, outs, nb));
             for (int j = 0; j < k; ++j) {
-                TCol &o = out->cols[(size_t)first_out + utf8[g0 + (size_t)j]];
+                const size_t i = utf8[g0 + (size_t)j];
+                TCol &o = out->cols[(size_t)first_out + i];
                 o.c.values = outs[j].data;
                 o.c.offsets = outs[j].offsets;
                 o.c.bytes = nb[j];
                 o.present = true;
+                if (in.cols[i].c.valid) {
+                    uint8_t *v = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "mtakev", first_out + (int)i).c_str(), (size_t)std::max<int64_t>(n_rows, 0) + 16, &v));
+                    FG_TRY(gather_u8(ctx, in.cols[i].c.valid, rows, n_rows, v));
+                    o.c.valid = v;
+                }
             }
         }
         return FLOCKGPU_OK;
@@ -1227,7 +1262,7 @@ struct Exec {
 
     int exec(const Node *n, Table *t) {
         const FusedInfo &fi = pl->fused[(size_t)n->id];
-        if (fi.kind != kNone) {
+        if (fi.kind != kNone && !leaf_has_validity(fi.leaf_a) && !leaf_has_validity(fi.leaf_b)) {
             const int rc = run_fused(n, fi, t);
             // q4 / q9's fused kernels need dense, increasing auction ids inside a batch (include/flockgpu.h); any other batch runs
             // on the generic operators below
@@ -1275,6 +1310,7 @@ struct Exec {
                     flockgpu_bid_cols bc{nullptr, nullptr, static_cast<const int32_t *>(in.cols[(size_t)c->col].c.values), nullptr, in.rows};
                     FG_TRY(flockgpu_q1_project(ctx, &bc, l->kind == EKind::LitF ? l->f : (double)l->i, d));
                     o = dev_col(ColType::F64, d);
+                    o.c.valid = in.cols[(size_t)c->col].c.valid;   // literal * NULL is NULL
                 }
                 return FLOCKGPU_OK;
             }
@@ -1303,6 +1339,10 @@ struct Exec {
                 int64_t nl = L.rows, nr = R.rows;
                 if (lk.c.all_null) nl = 0;  // NULL keys never match
                 if (rk.c.all_null) nr = 0;
+                // (NULLs in a LEAF's key column were left out at feed: inner-join keys are null-droppable.  A computed key column that carries
+                // validity bytes -- a grouped MIN / MAX over nothing but NULLs joined on -- is not taken)
+                if (lk.c.valid || rk.c.valid || (n->on_l2 >= 0 && (L.cols[(size_t)n->on_l2].c.valid || R.cols[(size_t)n->on_r2].c.valid)))
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join on a computed column that holds NULLs");
                 int64_t *kl = nullptr, *kr = nullptr;
                 if (text_keys) {  // equal strings <-> equal dictionary codes (exact: full byte compare inside utf8_codes)
                     if (!lk.present || !rk.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
@@ -1344,7 +1384,7 @@ struct Exec {
         for (auto &sc : n->sort_cols) {
             const TCol &c = in.cols[(size_t)sc.col];
             if (!c.present && !c.c.all_null) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: ORDER BY column was not materialised");
-            keys.push_back(SortKey{c.c, sc.descending});
+            keys.push_back(SortKey{c.c, sc.descending, sc.nulls_first});
         }
         int32_t *rows = nullptr;
         FG_TRY(sort_rows(ctx, node_key(pl, n, "sort").c_str(), keys.data(), (int)keys.size(), in.rows, &rows));
@@ -1421,6 +1461,7 @@ struct Exec {
             const TCol &k = in.cols[(size_t)n->group[0]], &s = in.cols[(size_t)n->group[1]];
             if (k.c.type != ColType::I32 || s.c.type != ColType::UTF8 || !k.present || !s.present)
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Utf8)");
+            if (k.c.valid || s.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: DISTINCT over columns that hold NULLs");
             int32_t *rows = nullptr;
             int64_t n_out = 0;
             FG_TRY(distinct_i32_utf8(ctx, node_key(pl, n, "dist").c_str(), static_cast<const int32_t *>(k.c.values),
@@ -1437,10 +1478,17 @@ struct Exec {
         if (n->group.empty() || n->group.size() > 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY more than two columns");
         const TCol &k = in.cols[(size_t)n->group[0]];
         int64_t *keys = nullptr;
+        // NULL group keys form ONE group (DataFusion groups NULLs together): an Int32 key column widened to 64 bits has room for a value
+        // no Int32 takes; other key types with NULLs are handed back
+        constexpr int64_t kNullKey = int64_t(1) << 40;
+        const bool null_keys = k.c.valid != nullptr;
+        if (null_keys && (pair || k.c.type != ColType::I32))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 column");
         if (pair) {
             const TCol &k2 = in.cols[(size_t)n->group[1]];
             if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
+            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 column");
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
             FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
         } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
@@ -1450,6 +1498,7 @@ struct Exec {
         } else {
             if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
             FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
+            if (null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
         }
         AggSpec specs[kMaxGroupAggs];
         int n_specs = 0;
@@ -1467,35 +1516,36 @@ struct Exec {
             o.first = n_specs;
             o.count = a.fn == "avg" ? 2 : 1;
             if (n_specs + o.count > kMaxGroupAggs) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: more than %d accumulators in one GROUP BY", kMaxGroupAggs);
+            // (every accumulator carries its argument's validity: NULLs are skipped, a group without a valid value comes out NULL)
             if (a.fn == "count") {
                 if (is_final) {
                     const TCol *st = int_col(a.arg, "the COUNT state");
                     if (!st) return FLOCKGPU_ERR_UNSUPPORTED;
-                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, st->c.values, st->c.type};
-                } else {
-                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, st->c.values, st->c.type, nullptr};
+                } else {   // COUNT(*) / COUNT(UInt8(1)) counts rows, COUNT(col) the rows whose col is not NULL
+                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64, a.arg >= 0 ? in.cols[(size_t)a.arg].c.valid : nullptr};
                 }
             } else if ((a.fn == "max" || a.fn == "min") && a.arg >= 0 && in.cols[(size_t)a.arg].present && in.cols[(size_t)a.arg].c.type == ColType::F64) {
-                specs[n_specs++] = AggSpec{a.fn == "max" ? AggOp::MAX_F64 : AggOp::MIN_F64, in.cols[(size_t)a.arg].c.values, ColType::F64};
+                specs[n_specs++] = AggSpec{a.fn == "max" ? AggOp::MAX_F64 : AggOp::MIN_F64, in.cols[(size_t)a.arg].c.values, ColType::F64, in.cols[(size_t)a.arg].c.valid};
             } else if (a.fn == "max" || a.fn == "min" || a.fn == "sum") {
                 const TCol *v = int_col(a.arg, a.fn.c_str());
                 if (!v) return FLOCKGPU_ERR_UNSUPPORTED;
                 const bool uns = v->c.type == ColType::U64;
                 const AggOp op = a.fn == "sum" ? AggOp::SUM_INT : (a.fn == "max" ? (uns ? AggOp::MAX_U : AggOp::MAX_S) : (uns ? AggOp::MIN_U : AggOp::MIN_S));
-                specs[n_specs++] = AggSpec{op, v->c.values, v->c.type};
+                specs[n_specs++] = AggSpec{op, v->c.values, v->c.type, v->c.valid};
             } else {  // avg: (count, sum)
                 if (is_final) {
                     const TCol *cnt = int_col(a.arg, "the AVG count state");
                     if (!cnt) return FLOCKGPU_ERR_UNSUPPORTED;
                     const TCol &sm = in.cols[(size_t)a.arg2];
                     if (!sm.present || sm.c.type != ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: the AVG sum state must be Float64");
-                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, cnt->c.values, cnt->c.type};
-                    specs[n_specs++] = AggSpec{AggOp::SUM_F64, sm.c.values, ColType::F64};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, cnt->c.values, cnt->c.type, nullptr};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_F64, sm.c.values, ColType::F64, nullptr};
                 } else {
                     const TCol *v = int_col(a.arg, "AVG");
                     if (!v) return FLOCKGPU_ERR_UNSUPPORTED;
-                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64};
-                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, v->c.values, v->c.type};
+                    specs[n_specs++] = AggSpec{AggOp::COUNT, nullptr, ColType::I64, v->c.valid};
+                    specs[n_specs++] = AggSpec{AggOp::SUM_INT, v->c.values, v->c.type, v->c.valid};
                 }
             }
             outs.push_back(o);
@@ -1520,6 +1570,12 @@ struct Exec {
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk").c_str(), (size_t)g.n_groups + 4, &nk));
             FG_TRY(narrow_i64_to_i32(ctx, g.keys, g.n_groups, nk));
             t->cols[0] = dev_col(ColType::I32, nk);
+            if (null_keys) {   // the NULL group's key is NULL again
+                uint8_t *kv = nullptr;
+                FG_TRY(arena_get_t(ctx, node_key(pl, n, "nkv").c_str(), (size_t)g.n_groups + 16, &kv));
+                FG_TRY(valid_from_i64(ctx, g.keys, g.n_groups, kNullKey, kv));
+                t->cols[0].c.valid = kv;
+            }
         } else {
             t->cols[0] = dev_col(k.c.type, g.keys, nullptr, 0, k.c.is_ts);
         }
@@ -1544,10 +1600,14 @@ struct Exec {
             if (a.fn == "avg") {
                 if (is_final) {
                     double *avg = nullptr;
+                    uint8_t *av = nullptr;
                     FG_TRY(arena_get_t(ctx, node_key(pl, n, "av", (int)oc).c_str(), (size_t)g.n_groups + 2, &avg));
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "avv", (int)oc).c_str(), (size_t)g.n_groups + 16, &av));
                     FG_TRY(avg_finish(ctx, reinterpret_cast<const double *>(g.agg[o.first + 1]), g.agg[o.first], g.n_groups, avg));
+                    FG_TRY(valid_from_i64(ctx, reinterpret_cast<const int64_t *>(g.agg[o.first]), g.n_groups, 0, av));   // AVG over no valid value is NULL
                     t->cols[oc] = dev_col(ColType::F64, avg);
                     t->cols[oc].c.nullable = true;
+                    t->cols[oc].c.valid = av;
                     oc += 1;
                 } else {
                     double *sum = nullptr;
@@ -1564,6 +1624,7 @@ struct Exec {
                 if (want == ColType::UTF8 || (want == ColType::F64) != f64_acc)
                     return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: %s of a column into a column of another kind", a.fn.c_str());
                 FG_TRY(narrow_if_i32(g.agg[o.first], want, n->schema[oc].is_ts, oc));
+                if (a.fn != "count") t->cols[oc].c.valid = g.agg_valid[o.first];   // MIN / MAX / SUM over nothing but NULLs is NULL; COUNT(col) is 0
                 oc += 1;
             }
         }
@@ -1682,7 +1743,7 @@ void export_schema(const Node *root, ArrowSchema *out, bool shuffled = false) {
 int export_batches(flockgpu_ctx *ctx, const Table &t, const std::vector<int64_t> &part_off, ArrowArray *out_batches) {
     const int n_parts = (int)part_off.size() - 1;
     struct Slot { size_t at = 0, bytes = 0; const void *dev = nullptr; };
-    std::vector<Slot> values(t.cols.size()), offsets(t.cols.size()), validity(t.cols.size());
+    std::vector<Slot> values(t.cols.size()), offsets(t.cols.size()), validity(t.cols.size()), valid_bytes(t.cols.size());
     size_t total = 0;
     auto reserve = [&](Slot &s, const void *dev, size_t bytes) {
         s.at = total;
@@ -1699,18 +1760,26 @@ int export_batches(flockgpu_ctx *ctx, const Table &t, const std::vector<int64_t>
         } else {
             reserve(values[i], c.c.values, (size_t)t.rows * col_width(c.c.type));
         }
-        if (c.c.all_null) reserve(validity[i], nullptr, (size_t)(t.rows + 7) / 8);
+        if (c.c.all_null || c.c.valid) reserve(validity[i], nullptr, (size_t)(t.rows + 7) / 8 + 8);
+        if (c.c.valid && !c.c.all_null) reserve(valid_bytes[i], c.c.valid, (size_t)t.rows);   // one byte per row on the device: packed into bits below
     }
     auto block = std::make_shared<HostBlock>();
     block->ptr = pool().get(std::max<size_t>(total, 64), &block->cap);
     if (!block->ptr) return fail(ctx, FLOCKGPU_ERR_OOM, "plan execute: pinned host allocation of %zu bytes failed", total);
     uint8_t *base = static_cast<uint8_t *>(block->ptr);
-    for (auto *group : {&values, &offsets})
+    for (auto *group : {&values, &offsets, &valid_bytes})
         for (auto &s : *group)
             if (s.bytes && s.dev) FG_HIP(ctx, hipMemcpyAsync(base + s.at, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
     for (auto &s : validity)
         if (s.bytes) std::memset(base + s.at, 0, s.bytes);
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < t.cols.size(); ++i)   // validity bytes -> the Arrow bitmap (bit r of the column = row r; batches address it through `offset`)
+        if (valid_bytes[i].bytes) {
+            const uint8_t *vb = base + valid_bytes[i].at;
+            uint8_t *bits = base + validity[i].at;
+            for (int64_t r = 0; r < t.rows; ++r)
+                if (vb[r]) bits[r >> 3] |= (uint8_t)(1u << (r & 7));
+        }
     for (int p = 0; p < n_parts; ++p) {
         ArrowArray *a = &out_batches[p];
         BatchPriv *bp = new BatchPriv();
@@ -1730,8 +1799,15 @@ int export_batches(flockgpu_ctx *ctx, const Table &t, const std::vector<int64_t>
             std::memset(ch, 0, sizeof *ch);
             ch->length = len;
             ch->offset = lo;
-            const void *valid = c.c.all_null ? base + validity[i].at : nullptr;
+            const bool has_bitmap = c.c.all_null || (c.c.valid && t.rows > 0);
+            const void *valid = has_bitmap ? base + validity[i].at : nullptr;
             ch->null_count = c.c.all_null ? len : 0;
+            if (!c.c.all_null && valid_bytes[i].bytes) {
+                const uint8_t *vb = base + valid_bytes[i].at;
+                int64_t nulls = 0;
+                for (int64_t r = lo; r < lo + len; ++r) nulls += vb[r] ? 0 : 1;
+                ch->null_count = nulls;
+            }
             if (c.c.type == ColType::UTF8) cp->buffers = {valid, base + offsets[i].at, base + values[i].at};
             else cp->buffers = {valid, base + values[i].at};
             ch->n_buffers = (int64_t)cp->buffers.size();
@@ -1781,6 +1857,7 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
         } else {
             FG_TRY(ex.key_i64(root, k, n_rows, "pk", &keys));
         }
+        if (k.c.valid) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, n_rows, 0));   // (NULL keys: one key as far as placement goes; the slot's bytes are unspecified)
         int32_t *rows = nullptr;
         FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, n_rows, root->n_parts, &rows, &part_off));
         if (compose) {   // send order over the filter's input: sel[rows[i]]
@@ -1948,6 +2025,7 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
     std::vector<int64_t> add_bytes(lf.schema.size(), 0);
     std::vector<std::vector<int64_t>> keep((size_t)n_batches);  // per batch: the rows that survive NULL dropping (empty: all)
     std::vector<char> filtered((size_t)n_batches, 0);
+    std::vector<char> with_valid((size_t)n_batches * lf.schema.size(), 0);   // (batch, column): NULLs that stay -> validity bytes go along
     for (int b = 0; b < n_batches; ++b) {
         const ArrowArray *rb = batches[b];
         if (!rb || rb->n_children < schema->n_children) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_feed: batch %d does not match the schema", b);
@@ -1964,10 +2042,15 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
             }
             const int64_t off = a->offset + rb->offset;
             if (!validity_has_nulls(a, off, n)) continue;
-            // NULLs: acceptable only where dropping the row cannot change the result (join keys, MAX arguments, compared columns)
-            if (!lf.null_droppable[c])
-                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs that would reach the output (NEXMark fields are non-nullable)",
-                            lf.schema[c].name.c_str());
+            // NULLs.  Where dropping the row cannot change the result (inner-join keys, columns only compared under AND, MAX arguments of a
+            // global aggregate) the row is left out here; everywhere else the column travels with a validity byte per row and the
+            // operators honour it (NULLs skipped by COUNT(col) / MIN / MAX / SUM / AVG, one group for NULL keys, NULLs in the output)
+            if (!lf.null_droppable[c]) {
+                if (plan->ring_ppw)
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs that reach the output; the pane ring retains no validity", lf.schema[c].name.c_str());
+                with_valid[(size_t)b * lf.schema.size() + c] = 1;
+                continue;
+            }
             const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);
             std::vector<int64_t> &k = keep[(size_t)b];
             if (!filtered[(size_t)b]) {
@@ -2029,6 +2112,19 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
             DevBuf &dc = ld.cols[c];
             const ArrowArray *a = rb->children[child[c]];
             const int64_t off = a->offset + rb->offset;
+            if (with_valid[(size_t)b * lf.schema.size() + c]) {   // this batch's validity bytes (of the rows that stay), behind what the column holds
+                const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);
+                std::vector<uint8_t> vb;
+                if (filt) for (int64_t i : k) vb.push_back((bits[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+                else for (int64_t i = 0; i < n; ++i) vb.push_back((bits[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+                void *vp = nullptr;
+                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)(ld.rows + (int64_t)vb.size()) + 64, &vp));
+                dc.valid = static_cast<uint8_t *>(vp);
+                if (dc.valid_rows < ld.rows) FG_HIP(ctx, hipMemsetAsync(dc.valid + dc.valid_rows, 1, (size_t)(ld.rows - dc.valid_rows), ctx->stream));
+                FG_TRY(h2d(plan, dc.valid + ld.rows, vb.data(), vb.size()));
+                FG_TRY(flush_jobs(plan));   // (the bytes live in a temporary)
+                dc.valid_rows = ld.rows + (int64_t)vb.size();
+            }
             if (lf.schema[c].type == ColType::UTF8) {
                 const int32_t *so = static_cast<const int32_t *>(a->buffers[1]) + off;
                 const uint8_t *src = static_cast<const uint8_t *>(a->buffers[2]);
@@ -2295,7 +2391,8 @@ int flockgpu_plan_reset(flockgpu_plan *plan) {
         ld.pane_bytes.clear();
         for (auto &c : ld.cols) {
             c.bytes = 0;
-            if (ld.borrowed) c.values = nullptr, c.offsets = nullptr;   // the donor's memory: never grown or appended to from here
+            c.valid_rows = 0;
+            if (ld.borrowed) c.values = nullptr, c.offsets = nullptr, c.valid = nullptr;   // the donor's memory: never grown or appended to from here
         }
         ld.borrowed = false;
     }
@@ -2365,6 +2462,12 @@ int flockgpu_plan_execute_retain(flockgpu_plan *plan, int64_t *rows) {
     for (size_t c = 0; c < t.cols.size(); ++c) {
         DevColumn &col = t.cols[c].c;
         if (t.rows == 0 || col.all_null) continue;
+        if (col.valid && !mine(col.valid)) {
+            uint8_t *v = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(plan, root, "keepn", (int)c).c_str(), (size_t)t.rows + 16, &v));
+            FG_HIP(ctx, hipMemcpyAsync(v, col.valid, (size_t)t.rows, hipMemcpyDeviceToDevice, ctx->stream));
+            col.valid = v;
+        }
         if (col.type == ColType::UTF8) {
             if (mine(col.values) && mine(col.offsets)) continue;
             void *bytes = nullptr;
@@ -2417,7 +2520,7 @@ int flockgpu_plan_feed_from(flockgpu_plan *plan, int input, const flockgpu_plan 
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (from[c] < 0) continue;
         const DevColumn &col = t.cols[(size_t)from[c]].c;
-        ld.cols[c] = DevBuf{const_cast<void *>(col.values), const_cast<int32_t *>(col.offsets), col.bytes};
+        ld.cols[c] = DevBuf{const_cast<void *>(col.values), const_cast<int32_t *>(col.offsets), col.bytes, const_cast<uint8_t *>(col.valid), col.valid ? t.rows : 0};
     }
     ld.rows = t.rows;
     ld.borrowed = true;

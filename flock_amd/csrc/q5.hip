@@ -36,6 +36,17 @@ constexpr int kSlotBits = 11;
 static_assert(kSlots == (1 << kSlotBits), "slot bits");
 constexpr int kLdsMaxProbe = 24;
 constexpr uint32_t kFib = 0x9E3779B1u;
+// The count kernel's LDS phase: 1 (shipped) = lanes holding the wave's hot key issue no LDS atomic at all (exec-masked); 0 = they add to
+// a private scratch bin instead (branch-free, rounds 1-3); 2 = 1 + four lane-indexed replicas of every bin while the tile's span leaves
+// room.  A/B on one box, alternating (tools/gpu_ab_libs.sh, round 4): 0.741 / 0.728 / 0.730 and 0.753 / 0.732 / 0.728 ms per 1e9 bids --
+// the scratch-bin adds cost 2 %, and replicas buy nothing on top: with half the lanes masked off, the ~32 that remain spread over the
+// ~110 auctions in flight collide rarely enough (the counters' "two thirds of the LDS cycles are bank conflicts" was mostly the hot
+// lanes' 64 scratch adds folding twice over the 32 banks).  Variants 0 / 2 exist in experimental builds only.
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_VARIANT)
+constexpr int kQ5Variant = FLOCKGPU_AB_Q5_VARIANT;
+#else
+constexpr int kQ5Variant = 1;
+#endif
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
 constexpr uint32_t kWideTile = 0x40000000u;     // slow-list tag: declined for its key spread (not for being ragged)
@@ -419,13 +430,15 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     // hot key of this wave, kept in scalar registers across iterations
     int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
     uint32_t hot_cnt = 0;
+    const bool rep = kQ5Variant == 2 && span * 4 + 3 < (uint32_t)kHist;   // (block-uniform) room for four replicas of every bin
+    const uint32_t rmul = rep ? 4u : 1u, radd = rep ? (uint32_t)(lane & 3) : 0u;
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         uint64_t b0 = __ballot(k[it][0] == hot);
         if (__popcll((unsigned long long)b0) < kHotMin) {
             // the candidate went cold: park its count, then try this iteration's first two distinct keys
             if (hot_cnt) {
-                if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+                if (lane == 0) atomicAdd(&hist[((uint32_t)hot - (uint32_t)mn) * rmul], hot_cnt);
                 hot_cnt = 0;
             }
             const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
@@ -447,19 +460,29 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
             const bool is_hot = k[it][j] == hot;
             const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
             hot_cnt += (uint32_t)__popcll((unsigned long long)b);
-            // branch-free: lanes holding the hot key hit their private scratch bin instead
-            const uint32_t bin = is_hot ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
-            atomicAdd(&hist[bin], 1u);
+            if (kQ5Variant == 0) {
+                // branch-free: lanes holding the hot key hit their private scratch bin instead
+                const uint32_t bin = is_hot ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
+                atomicAdd(&hist[bin], 1u);
+            } else if (!is_hot) {
+                atomicAdd(&hist[((uint32_t)k[it][j] - (uint32_t)mn) * rmul + radd], 1u);
+            }
         }
     }
-    if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+    if (hot_cnt && lane == 0) atomicAdd(&hist[((uint32_t)hot - (uint32_t)mn) * rmul], hot_cnt);
     __syncthreads();
-    if (!full_tile) {   // hand the copies of key0 back (block-uniform branch)
-        if (threadIdx.x == 0) hist[(uint32_t)key0 - (uint32_t)mn] -= (uint32_t)(kQ5Tile - (tr.hi - tr.lo));
+    if (!full_tile) {   // hand the copies of key0 back (block-uniform branch; with replicas the SUM over a bin's four comes out right)
+        if (threadIdx.x == 0) hist[((uint32_t)key0 - (uint32_t)mn) * rmul] -= (uint32_t)(kQ5Tile - (tr.hi - tr.lo));
         __syncthreads();
     }
     for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
-        const uint32_t c = hist[s];
+        uint32_t c;
+        if (rep) {
+            const uint4 r4 = *reinterpret_cast<const uint4 *>(&hist[s * 4]);
+            c = r4.x + r4.y + r4.z + r4.w;
+        } else {
+            c = hist[s];
+        }
         if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
     }
 }

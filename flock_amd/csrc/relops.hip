@@ -181,9 +181,11 @@ __global__ __launch_bounds__(kBlock) void live_slot_mask_kernel(const int32_t *_
 
 struct AggSpecs {
     const void *values[kMaxGroupAggs];
+    const uint8_t *valid[kMaxGroupAggs];   // null: every row valid
     int32_t op[kMaxGroupAggs];
     int32_t type[kMaxGroupAggs];
     int32_t n;
+    uint32_t *seen;   // slots x n counters of valid contributions (null when no spec carries validity)
 };
 // doubles <-> unsigned keys of the same order (negative values: all bits flipped; others: the sign bit set)
 __device__ __forceinline__ uint64_t f64_order_key(double d) {
@@ -222,6 +224,10 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
         for (int a = 0; a < sp.n; ++a) {
             uint64_t *acc = &ta[s * sp.n + a];
             const int32_t op = sp.op[a];
+            if (sp.valid[a]) {   // a NULL reaches no accumulator
+                if (!sp.valid[a][i]) continue;
+                atomicAdd(&sp.seen[s * sp.n + a], 1u);
+            }
             if (op == (int32_t)AggOp::COUNT) {
                 atomicAdd(reinterpret_cast<unsigned long long *>(acc), 1ull);
             } else if (op == (int32_t)AggOp::SUM_F64) {
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
 // out[a][g] = ta[slot_rows[g] * n + a]
 struct AggOuts {
     uint64_t *out[kMaxGroupAggs];
+    uint8_t *valid[kMaxGroupAggs];
 };
 __global__ __launch_bounds__(kBlock) void group_collect_n_kernel(const uint64_t *__restrict__ ta, const int32_t *__restrict__ slot_rows,
                                                                  int64_t n_groups, AggSpecs sp, AggOuts o) {
@@ -251,7 +258,24 @@ __global__ __launch_bounds__(kBlock) void group_collect_n_kernel(const uint64_t 
         for (int a = 0; a < sp.n; ++a) {
             const uint64_t v = ta[(int64_t)slot_rows[g] * sp.n + a];
             o.out[a][g] = (sp.op[a] == (int32_t)AggOp::MAX_F64 || sp.op[a] == (int32_t)AggOp::MIN_F64) ? f64_from_order_key(v) : v;
+            if (o.valid[a]) o.valid[a][g] = sp.seen[(int64_t)slot_rows[g] * sp.n + a] ? 1 : 0;
         }
+}
+__global__ __launch_bounds__(kBlock) void gather_u8_kernel(const uint8_t *__restrict__ src, const int32_t *__restrict__ rows, int64_t n, uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = src[rows[i]];
+}
+__global__ __launch_bounds__(kBlock) void mask_and_valid_kernel(uint8_t *__restrict__ mask, const uint8_t *__restrict__ valid, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) mask[i] = mask[i] && valid[i] ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void replace_invalid_kernel(int64_t *__restrict__ keys, const uint8_t *__restrict__ valid, int64_t n, int64_t sentinel) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (!valid[i]) keys[i] = sentinel;
+}
+__global__ __launch_bounds__(kBlock) void valid_from_i64_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t sentinel, uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = keys[i] != sentinel ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void zero_u32_kernel(uint32_t *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = 0;
 }
 __global__ __launch_bounds__(kBlock) void pack_pair_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n,
                                                            int64_t *__restrict__ out) {
@@ -376,14 +400,21 @@ __global__ __launch_bounds__(kBlock) void utf8_codes_probe_kernel(const int32_t 
 }
 
 // ---- max: per-workgroup maxima (signed or unsigned order), folded on the host
-__global__ __launch_bounds__(kBlock) void max_kernel(const void *__restrict__ v, int32_t type, int64_t n, int64_t *__restrict__ block_out) {
+// block_out[b] = the block's maximum over its VALID rows, block_out[gridDim.x + b] = how many of them it saw
+__global__ __launch_bounds__(kBlock) void max_kernel(const void *__restrict__ v, const uint8_t *__restrict__ valid, int32_t type, int64_t n,
+                                                     int64_t *__restrict__ block_out) {
     __shared__ int64_t s_m[kWavesPerBlock];
+    __shared__ int64_t s_c[kWavesPerBlock];
     const bool uns = type == (int32_t)ColType::U64;
-    int64_t m = uns ? 0 : INT64_MIN;
+    int64_t m = uns ? 0 : INT64_MIN, cnt = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        if (valid && !valid[i]) continue;   // MAX ignores NULLs
+        ++cnt;
         const int64_t x = load_as_i64(v, type, i);
         if (cmp_i64(x, m, 4, uns)) m = x;
     }
+    cnt = (int64_t)wave_sum_u64((uint64_t)cnt);
+    if (lane_id() == 0) s_c[threadIdx.x >> 6] = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const int64_t t = __shfl_xor(m, o, 64);
@@ -395,6 +426,7 @@ __global__ __launch_bounds__(kBlock) void max_kernel(const void *__restrict__ v,
         for (int w = 1; w < kWavesPerBlock; ++w)
             if (cmp_i64(s_m[w], m, 4, uns)) m = s_m[w];
         block_out[blockIdx.x] = m;
+        block_out[gridDim.x + blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
     }
 }
 
@@ -485,6 +517,7 @@ uint64_t pow2_at_least(uint64_t v) {
 // ---- ORDER BY: order-preserving 64-bit sub-keys in the current row order, their range, the 32-bit digits a radix sort takes
 // chunk: Utf8 only -- -1 = the value's length, c >= 0 = bytes [8c, 8c + 8) big-endian, zero padded
 __device__ __forceinline__ uint64_t sort_norm(const void *__restrict__ v, const int32_t *__restrict__ off, int32_t type, int64_t r, int32_t chunk) {
+    if (chunk == -2) return static_cast<const uint8_t *>(v)[r] ? 1u : 0u;   // a validity column: NULL = 0, valid = 1
     switch (type) {
         case (int32_t)ColType::I32: return (uint64_t)((int64_t) static_cast<const int32_t *>(v)[r]) ^ (uint64_t(1) << 63);
         case (int32_t)ColType::I64: return (uint64_t) static_cast<const int64_t *>(v)[r] ^ (uint64_t(1) << 63);
@@ -506,12 +539,14 @@ __device__ __forceinline__ uint64_t sort_norm(const void *__restrict__ v, const 
         }
     }
 }
-__global__ __launch_bounds__(kBlock) void sort_norm_kernel(const void *__restrict__ v, const int32_t *__restrict__ off, int32_t type,
-                                                           const int32_t *__restrict__ perm, int64_t n, int32_t chunk, int32_t descending,
+__global__ __launch_bounds__(kBlock) void sort_norm_kernel(const void *__restrict__ v, const int32_t *__restrict__ off, const uint8_t *__restrict__ valid,
+                                                           int32_t type, const int32_t *__restrict__ perm, int64_t n, int32_t chunk, int32_t descending,
                                                            uint64_t *__restrict__ out, uint64_t *__restrict__ minmax) {
     uint64_t mn = ~uint64_t(0), mx = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        uint64_t k = sort_norm(v, off, type, perm ? perm[i] : i, chunk);
+        const int64_t r = perm ? perm[i] : i;
+        // (the slot of a NULL holds an unspecified value: all NULLs tie on the value passes, so they keep their input order)
+        uint64_t k = valid && chunk != -2 && !valid[r] ? 0u : sort_norm(v, off, type, r, chunk);
         if (descending) k = ~k;
         out[i] = k;
         mn = k < mn ? k : mn;
@@ -594,8 +629,8 @@ int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_ke
     // one stable pass over a 64-bit sub-key of column `k` (chunk: Utf8 only)
     auto pass = [&](const SortKey &k, int32_t chunk) -> int {
         hipLaunchKernelGGL(sort_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_mm);
-        hipLaunchKernelGGL(sort_norm_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, k.col.values, k.col.offsets, (int32_t)k.col.type, cur, rows, chunk,
-                           k.descending ? 1 : 0, nk, d_mm);
+        hipLaunchKernelGGL(sort_norm_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, k.col.values, k.col.offsets, k.col.valid, (int32_t)k.col.type, cur, rows,
+                           chunk, k.descending ? 1 : 0, nk, d_mm);
         FG_TRY(check_launch(ctx, "sort_norm_kernel"));
         FG_TRY(read_range());
         const uint64_t lo = h_mm[0], span = h_mm[1] - h_mm[0];
@@ -618,11 +653,21 @@ int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_ke
         at ^= 1;
         return FLOCKGPU_OK;
     };
+    // where a key's NULLs go: one more stable pass on its validity byte, AFTER the value passes (more significant than the value)
+    auto null_pass = [&](const SortKey &k) -> int {
+        if (!k.col.valid) return FLOCKGPU_OK;
+        SortKey v;
+        v.col.type = ColType::I32;   // unused by the validity chunk
+        v.col.values = k.col.valid;
+        v.descending = !k.nulls_first;   // the pass orders NULL = 0 before valid = 1: ascending puts the NULLs first, "nulls last" inverts it
+        return pass(v, -2);
+    };
     for (int ki = n_keys - 1; ki >= 0; --ki) {
         const SortKey &k = keys[ki];
         if (k.col.all_null) continue;
         if (k.col.type != ColType::UTF8) {
             FG_TRY(pass(k, 0));
+            FG_TRY(null_pass(k));
             continue;
         }
         hipLaunchKernelGGL(sort_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_mm);
@@ -632,6 +677,7 @@ int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_ke
         const int64_t max_len = (int64_t)h_mm[1];
         FG_TRY(pass(k, -1));                                            // length: decides between a string and its zero-padded twin
         for (int32_t c = (int32_t)((max_len + 7) / 8) - 1; c >= 0; --c) FG_TRY(pass(k, c));
+        FG_TRY(null_pass(k));
     }
     if (!cur) {   // no key moved anything: the identity
         hipLaunchKernelGGL(iota_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, perm[0], rows);
@@ -743,11 +789,39 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
     return FLOCKGPU_OK;
 }
 
+int gather_u8(flockgpu_ctx *ctx, const uint8_t *src, const int32_t *rows, int64_t n, uint8_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "gather_u8_kernel", gather_u8_kernel, n, src, rows, n, out);
+    return FLOCKGPU_OK;
+}
+int mask_and_valid(flockgpu_ctx *ctx, uint8_t *mask, const uint8_t *valid, int64_t rows) {
+    if (rows <= 0 || !valid) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "mask_and_valid_kernel", mask_and_valid_kernel, rows, mask, valid, rows);
+    return FLOCKGPU_OK;
+}
+int replace_invalid_i64(flockgpu_ctx *ctx, int64_t *keys, const uint8_t *valid, int64_t rows, int64_t sentinel) {
+    if (rows <= 0 || !valid) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "replace_invalid_kernel", replace_invalid_kernel, rows, keys, valid, rows, sentinel);
+    return FLOCKGPU_OK;
+}
+int valid_from_i64(flockgpu_ctx *ctx, const int64_t *keys, int64_t n, int64_t sentinel, uint8_t *out) {
+    if (n <= 0) return FLOCKGPU_OK;
+    RELOPS_LAUNCH(ctx, "valid_from_i64_kernel", valid_from_i64_kernel, n, keys, n, sentinel, out);
+    return FLOCKGPU_OK;
+}
+
 int take_column(flockgpu_ctx *ctx, const char *name, const DevColumn &src, const int32_t *rows, int64_t n, DevColumn *out) {
     *out = src;
     out->values = nullptr;
     out->offsets = nullptr;
     out->bytes = 0;
+    out->valid = nullptr;
+    if (src.valid) {
+        uint8_t *v = nullptr;
+        FG_TRY(arena_get_t(ctx, (std::string(name) + ".valid").c_str(), (size_t)std::max<int64_t>(n, 0) + 16, &v));
+        FG_TRY(gather_u8(ctx, src.valid, rows, n, v));
+        out->valid = v;
+    }
     if (src.type == ColType::UTF8) {
         flockgpu_utf8 u{}, s{src.offsets, static_cast<const uint8_t *>(src.values)};
         int64_t nbytes = 0;
@@ -816,8 +890,11 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
     if (rows >= (int64_t(1) << 30)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^30 rows in a generic GROUP BY", name);
     AggSpecs sp{};
     sp.n = n_specs;
+    bool track = false;
     for (int a = 0; a < n_specs; ++a) {
         sp.values[a] = specs[a].values;
+        sp.valid[a] = specs[a].valid;
+        track = track || specs[a].valid != nullptr;
         sp.op[a] = (int32_t)specs[a].op;
         sp.type[a] = (int32_t)specs[a].type;
         if (specs[a].op != AggOp::COUNT && !specs[a].values && rows > 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: accumulator without a value column", name);
@@ -841,6 +918,11 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
     FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
     FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
     FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    sp.seen = nullptr;
+    if (track) {
+        FG_TRY(arena_get_t(ctx, (base + ".seen").c_str(), (size_t)slots * (size_t)width, &sp.seen));
+        RELOPS_LAUNCH(ctx, "zero_u32_kernel", zero_u32_kernel, slots * width, sp.seen, slots * (int64_t)width);
+    }
     RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
     if (rows > 0) RELOPS_LAUNCH(ctx, "group_insert_n_kernel", group_insert_n_kernel, rows, keys, rows, sp, tk, ta, tf, cap, d_err);
     RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
@@ -859,6 +941,10 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
     for (int a = 0; a < n_specs; ++a) {
         FG_TRY(arena_get_t(ctx, (base + ".oa" + std::to_string(a)).c_str(), (size_t)n_groups + 2, &o.out[a]));
         out->agg[a] = o.out[a];
+        if (specs[a].valid) {
+            FG_TRY(arena_get_t(ctx, (base + ".ov" + std::to_string(a)).c_str(), (size_t)n_groups + 16, &o.valid[a]));
+            out->agg_valid[a] = o.valid[a];
+        }
     }
     if (n_specs > 0 && n_groups > 0) RELOPS_LAUNCH(ctx, "group_collect_n_kernel", group_collect_n_kernel, n_groups, ta, slot_rows, n_groups, sp, o);
     out->n_groups = n_groups;
@@ -935,20 +1021,24 @@ int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *o
     if (rows <= 0) return FLOCKGPU_OK;
     const unsigned blocks = std::min<unsigned>(grid_for(ctx, rows), 1024);
     int64_t *d = nullptr, *h = nullptr;
-    FG_TRY(arena_get_t(ctx, "relops.max", 1024, &d));
-    FG_TRY(pinned_get_t(ctx, "relops.max", 1024, &h));
+    FG_TRY(arena_get_t(ctx, "relops.max", 2048, &d));
+    FG_TRY(pinned_get_t(ctx, "relops.max", 2048, &h));
     {
         LaunchScope ls(ctx, "max_kernel");
-        hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, (int32_t)col.type, rows, d);
+        hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, col.valid, (int32_t)col.type, rows, d);
     }
     FG_TRY(check_launch(ctx, "max_kernel"));
-    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * 2 * blocks, hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool uns = col.type == ColType::U64;
-    int64_t m = h[0];
-    for (unsigned b = 1; b < blocks; ++b)
+    int64_t m = uns ? 0 : INT64_MIN, seen = 0;
+    for (unsigned b = 0; b < blocks; ++b) {
+        if (h[blocks + b] == 0) continue;   // (a block that saw no valid row holds the identity)
+        seen += h[blocks + b];
         if (uns ? (uint64_t)h[b] > (uint64_t)m : h[b] > m) m = h[b];
-    *out = m;
+    }
+    *any = seen > 0;   // MAX over nothing but NULLs is NULL, as over no rows
+    *out = seen > 0 ? m : 0;
     return FLOCKGPU_OK;
 }
 

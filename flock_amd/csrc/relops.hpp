@@ -24,6 +24,9 @@ struct DevColumn {
     bool is_ts = false;     // Timestamp(Millisecond): Int64 storage, exported as "tsm:"
     bool nullable = false;  // schema flag only
     bool all_null = false;  // the single row of a global aggregate over no input (MAX -> NULL)
+    // NULLs (round 4): one byte per row, 1 = valid; nullptr = every row valid (all NEXMark fields; the fused pipelines take only such
+    // columns).  The slot of a NULL holds an unspecified value (a Utf8 NULL an empty or arbitrary range): every consumer looks here first.
+    const uint8_t *valid = nullptr;
     const void *values = nullptr;      // fixed width values, or Utf8 bytes
     const int32_t *offsets = nullptr;  // Utf8 only, rows + 1 entries
     int64_t bytes = 0;                 // Utf8 only
@@ -46,8 +49,16 @@ int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t 
 // rows with mask != 0, in order.  *out_rows: ctx-owned (arena key `name`), n_out through ONE synchronisation.
 int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64_t rows, int32_t **out_rows, int64_t *n_out);
 
-// ---- take
+// ---- take (a column's validity bytes are taken along)
 int take_column(flockgpu_ctx *ctx, const char *name, const DevColumn &src, const int32_t *rows, int64_t n, DevColumn *out);
+int gather_u8(flockgpu_ctx *ctx, const uint8_t *src, const int32_t *rows, int64_t n, uint8_t *out);
+// mask[i] &= valid[i]: a comparison with NULL is NULL, and a NULL predicate keeps no row -- through AND and OR alike when every leaf
+// comparison is treated as false (NULL OR TRUE = TRUE, NULL OR FALSE = NULL: dropped either way it evaluates)
+int mask_and_valid(flockgpu_ctx *ctx, uint8_t *mask, const uint8_t *valid, int64_t rows);
+// keys[i] = sentinel where valid[i] == 0: NULL group keys form ONE group (DataFusion groups NULLs together), NULL hash-partition keys one place
+int replace_invalid_i64(flockgpu_ctx *ctx, int64_t *keys, const uint8_t *valid, int64_t rows, int64_t sentinel);
+// out[i] = keys[i] != sentinel (the validity of a group-key column that went through replace_invalid_i64); out[i] = count[i] != 0 (AVG over no valid value)
+int valid_from_i64(flockgpu_ctx *ctx, const int64_t *keys, int64_t n, int64_t sentinel, uint8_t *out);
 
 // ---- GROUP BY one integer key (as int64): distinct keys + SUM / MAX of `values` (null: SUM counts rows) per key.
 // Outputs are ctx-owned: keys[n_groups], agg[n_groups], first_row[n_groups] (smallest input row of the group).
@@ -71,11 +82,15 @@ struct AggSpec {
     AggOp op = AggOp::COUNT;
     const void *values = nullptr;  // null for COUNT
     ColType type = ColType::I64;   // storage type of `values`
+    // validity of the argument (may be null): a NULL contributes to no accumulator -- COUNT(col) counts the valid rows, MIN / MAX / SUM
+    // skip it (DataFusion's accumulators); a group none of whose values is valid comes out NULL (agg_valid)
+    const uint8_t *valid = nullptr;
 };
 struct GroupResultN {
     int64_t n_groups = 0;
     int64_t *keys = nullptr;
     uint64_t *agg[kMaxGroupAggs] = {};  // 64-bit patterns: int64 / uint64 / double by AggOp
+    uint8_t *agg_valid[kMaxGroupAggs] = {};  // per group: 1 when a valid value reached accumulator a; null when its spec carried no validity
     int32_t *first_row = nullptr;
 };
 int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
@@ -99,7 +114,7 @@ int avg_finish(flockgpu_ctx *ctx, const double *sum, const uint64_t *count, int6
 // ascending.
 int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, const flockgpu_utf8 &text, int64_t rows,
                       int32_t **out_rows, int64_t *n_out);
-// MAX of an integer column (signed, or unsigned for UInt64) as its 64-bit pattern, on the host; *any = 0 when there is no row.
+// MAX of an integer column (signed, or unsigned for UInt64) as its 64-bit pattern, on the host; *any = 0 when there is no (valid) row.
 int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out, int *any);
 
 // ---- inner equi-join on one 64-bit key: every (left_row, right_row) pair with equal keys, ordered by right row
@@ -125,6 +140,7 @@ int partition_rows_key64(flockgpu_ctx *ctx, const char *name, const int64_t *key
 struct SortKey {
     DevColumn col;
     bool descending = false;
+    bool nulls_first = false;   // where the rows whose col.valid is 0 go (SortOptions of the plan; DESC does not move them)
 };
 int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows);
 

@@ -132,10 +132,17 @@ def hash_join_inner(left: Table, right: Table, on: Sequence[Tuple[str, str]]) ->
 
 
 # -- SortExec / GlobalLimitExec ------------------------------------------------------------------
-def sort_exec(t: Table, by: Sequence[Tuple[str, bool]]) -> Table:
+def sort_exec(t: Table, by) -> Table:
+    """by = [(column, descending[, nulls_first])], first key most significant; stable.  NULLs go where `nulls_first` says (arrow-rs
+    SortOptions; DESC does not move them) and tie among themselves."""
     idx = list(range(num_rows(t)))
-    for col, desc in reversed(list(by)):
-        idx.sort(key=lambda i: t[col][i], reverse=desc)
+    for spec in reversed(list(by)):
+        col, desc = spec[0], spec[1]
+        nulls_first = spec[2] if len(spec) > 2 else False
+        vals = [i for i in idx if t[col][i] is not None]
+        nulls = [i for i in idx if t[col][i] is None]
+        vals.sort(key=lambda i: t[col][i], reverse=desc)
+        idx = nulls + vals if nulls_first else vals + nulls
     return {k: [v[i] for i in idx] for k, v in t.items()}
 
 

@@ -394,3 +394,126 @@ def test_mixed_hash_placement_is_rejected_not_silently_wrong(gpu):
         jc.feed_data_sources([[[foreign]]])
     assert "datafusion/ahash-0000" in str(e.value)
     jc.close()
+
+
+# ------------------------------------------------------------------ GPU: NULLs (validity bitmaps in, validity bitmaps out)
+_NF = [_field("k", "Int32", True), _field("v", "Int64", True), _field("f", "Float64", True), _field("s", "Utf8", True)]
+
+
+def _scan(fields=None):
+    fields = fields or _NF
+    return {"execution_plan": "memory_exec", "schema": {"fields": fields, "metadata": {}}, "projection": list(range(len(fields)))}
+
+
+def _c(name, fields=None):
+    names = [f["name"] for f in (fields or _NF)]
+    return {"physical_expr": "column", "name": name, "index": names.index(name)}
+
+
+def _null_table(n, seed, null_every=(3, 4, 5, 7)):
+    r = np.random.default_rng(seed)
+    k = [None if i % null_every[0] == 1 else int(x) for i, x in enumerate(r.integers(-3, 6, n))]
+    v = [None if i % null_every[1] == 2 else int(x) for i, x in enumerate(r.integers(-50, 50, n))]
+    f = [None if i % null_every[2] == 0 else float(x) for i, x in enumerate(np.round(r.normal(0, 10, n)))]
+    s = [None if i % null_every[3] == 3 else "s%d" % x for i, x in enumerate(r.integers(0, 9, n))]
+    if n > 20:
+        for i in range(n):                      # key 5: every value NULL -> MAX / MIN / SUM / AVG of that group are NULL, COUNT(v) is 0
+            if k[i] == 5:
+                v[i], f[i] = None, None
+    return {"k": k, "v": v, "f": f, "s": s}
+
+
+def _null_batches(t, chunk):
+    n = len(t["k"])
+    out = []
+    for a in range(0, n, chunk):
+        out.append(pa.record_batch([pa.array(t["k"][a:a + chunk], pa.int32()), pa.array(t["v"][a:a + chunk], pa.int64()),
+                                    pa.array(t["f"][a:a + chunk], pa.float64()), pa.array(t["s"][a:a + chunk], pa.string())], names=["k", "v", "f", "s"]))
+    return out
+
+
+def _agg_plan(aggs):
+    """Partial -> Hash([k]) -> FinalPartitioned GROUP BY k with `aggs` = [(fn, column or None, data_type)], as DataFusion plans a GROUP BY."""
+    def expr(fn, col, dt):
+        arg = _c(col) if col else {"physical_expr": "literal", "value": {"UInt8": 1}}
+        name = "%s(%s)" % (fn.upper(), col or "UInt8(1)")
+        return {"aggregate_expr": fn, "name": name, "data_type": dt, "nullable": True, "expr": arg}
+    ae = [expr(*a) for a in aggs]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[_c("k"), "k"]], "aggr_expr": ae, "input": _scan(),
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[{"physical_expr": "column", "name": "k", "index": 0}], 4]}}
+    return {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[{"physical_expr": "column", "name": "k", "index": 0}, "k"]],
+            "aggr_expr": ae, "input": {"execution_plan": "coalesce_batches_exec", "input": rep, "target_batch_size": 4096},
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+
+
+def _pyrows(rb):
+    return list(zip(*[rb[c].to_pylist() for c in rb.schema.names]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,chunk", [(40, 40), (5_000, 1_300), (60_000, 60_000)])
+def test_aggregates_skip_nulls_and_group_null_keys(gpu, n, chunk):
+    """COUNT(col) counts the non-NULL values, MIN / MAX / SUM / AVG skip NULLs and are NULL over nothing but NULLs,
+    COUNT(*) counts rows, NULL group keys form one group -- validity bitmaps in (only some batches hold NULLs), validity bitmaps out."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = _null_table(n, 7)
+    for aggs in ([("count", "v", "UInt64"), ("max", "v", "Int64"), ("min", "f", "Float64"), ("count", None, "UInt64")],
+                 [("avg", "v", "Float64"), ("sum", "v", "Int64")]):
+        ctx = ExecutionContext([_agg_plan(aggs)], gpu=gpu)
+        rb = collect(ctx, [[_null_batches(t, chunk)]])[0][0]
+        ctx.close()
+        want = g.hash_aggregate_exec(t, ["k"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+        key = lambda r: (r[0] is None, r[0])
+        assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key)
+        assert rb.schema.names == list(want)
+        if n > 20:
+            assert any(r[0] is None for r in _pyrows(rb)) and any(r[1] is None or r[1] == 0 for r in _pyrows(rb))
+
+
+@pytest.mark.gpu
+def test_filter_projection_and_sort_carry_nulls(gpu):
+    """A NULL comparison keeps no row -- under OR, too (NULL OR TRUE is TRUE) --, NULLs in projected columns come back as NULLs, and
+    ORDER BY places them where the plan's SortOptions say."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = _null_table(3_000, 11)
+    lit = lambda kind, x: {"physical_expr": "literal", "value": {kind: x}}
+    cast = lambda e, ty: {"physical_expr": "cast_expr", "expr": e, "cast_type": ty}
+    pred = {"physical_expr": "binary_expr", "op": "Or",
+            "left": {"physical_expr": "binary_expr", "op": "Lt", "left": _c("v"), "right": lit("Int64", 5)},
+            "right": {"physical_expr": "binary_expr", "op": "Gt", "left": _c("f"), "right": lit("Float64", 0.5)}}
+    filt = {"execution_plan": "filter_exec", "predicate": pred, "input": _scan()}
+    proj = {"execution_plan": "projection_exec", "input": filt, "schema": {"fields": [_NF[3], _NF[1], _NF[0]], "metadata": {}},
+            "expr": [[_c("s"), "s"], [_c("v"), "v"], [_c("k"), "k"]]}
+    for desc, nulls_first in ((False, False), (False, True), (True, True), (True, False)):
+        plan = {"execution_plan": "sort_exec", "input": proj,
+                "expr": [{"expr": {"physical_expr": "column", "name": "v", "index": 1}, "options": {"descending": desc, "nulls_first": nulls_first}},
+                         {"expr": {"physical_expr": "column", "name": "s", "index": 0}, "options": {"descending": False, "nulls_first": False}}]}
+        ctx = ExecutionContext([plan], gpu=gpu)
+        rb = collect(ctx, [[_null_batches(t, 700)]])[0][0]
+        ctx.close()
+        kept = g.filter_exec(t, lambda r: (None if r["v"] is None else r["v"] < 5) or (None if r["f"] is None else r["f"] > 0.5) or None)
+        # (python's `or` over None: None or True -> True, None or False -> False/None -> not True: dropped, as SQL's three-valued OR)
+        want = g.sort_exec({"s": kept["s"], "v": kept["v"], "k": kept["k"]}, [("v", desc, nulls_first), ("s", False, False)])
+        assert _pyrows(rb) == g.rows(want) and rb.num_rows > 500
+        assert rb["v"].null_count > 0 and rb["s"].null_count > 0 and rb["k"].null_count > 0
+
+
+@pytest.mark.gpu
+def test_join_with_null_keys_and_null_payloads(gpu):
+    """Inner hash join: NULL keys never match (their rows are left out at feed), NULLs in the other columns travel to the output."""
+    from flock_amd.runtime import ExecutionContext, collect
+    left, right = _null_table(2_000, 3), _null_table(1_500, 4, null_every=(5, 3, 4, 2))
+    rf = [_field("k2", "Int32", True), _field("v2", "Int64", True), _field("f2", "Float64", True), _field("s2", "Utf8", True)]
+    side = lambda scan, key, fields: {"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096,
+                                      "input": {"execution_plan": "repartition_exec", "input": scan, "partitioning": {"Hash": [[_c(key, fields)], 4]}}}
+    plan = {"execution_plan": "hash_join_exec", "left": side(_scan(), "k", _NF), "right": side(_scan(rf), "k2", rf), "join_type": "Inner", "mode": "Partitioned",
+            "on": [[_c("k"), _c("k2", rf)]], "schema": {"fields": _NF + rf, "metadata": {}}}
+    rbs = [pa.record_batch([b[c] for c in b.schema.names], names=["k2", "v2", "f2", "s2"]) for b in _null_batches(right, 400)]
+    ctx = ExecutionContext([plan], gpu=gpu)
+    rb = collect(ctx, [[_null_batches(left, 900)], [rbs]])[0][0]
+    ctx.close()
+    want = g.hash_join_inner(left, {"k2": right["k"], "v2": right["v"], "f2": right["f"], "s2": right["s"]}, [("k", "k2")])
+    key = lambda r: tuple((x is None, x) for x in r)
+    assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key) and rb.num_rows > 1000
+    assert rb["v"].null_count > 0 and rb["s2"].null_count > 0 and rb["k"].null_count == 0
