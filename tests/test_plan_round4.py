@@ -516,4 +516,4 @@ def test_join_with_null_keys_and_null_payloads(gpu):
     want = g.hash_join_inner(left, {"k2": right["k"], "v2": right["v"], "f2": right["f"], "s2": right["s"]}, [("k", "k2")])
     key = lambda r: tuple((x is None, x) for x in r)
     assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key) and rb.num_rows > 1000
-    assert rb["v"].null_count > 0 and rb["s2"].null_count > 0 and rb["k"].null_count == 0
+    assert rb["v"].null_count > 0 and rb["s"].null_count > 0 and rb["f2"].null_count > 0 and rb["k"].null_count == 0 and rb["k2"].null_count == 0
