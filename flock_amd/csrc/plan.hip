@@ -2270,17 +2270,22 @@ static int ring_q5_partial(flockgpu_plan *plan) {
         int32_t lo[1] = {0}, hi[1] = {1};
         flockgpu_bid_cols bc{static_cast<const int32_t *>(ld->cols[(size_t)col].values), nullptr, nullptr, nullptr, ld->rows};
         flockgpu_windows w{off, 1, lo, hi, 1};
-        flockgpu_q5_partial_result r{};
-        FG_TRY(flockgpu_q5_partial_counts(ctx, &bc, &w, &r));
-        groups = r.rows;
+        // The Partial stage per 8192-row TILE (q5.hip: q5_partial_tile_kernel -- one pass, one wait; a tile stands for one input partition
+        // of HashAggregateExec(Partial), so an auction may leave the pane in several (auction, count) groups, which the Final side merges).
+        // Going through flockgpu_q5_partial_counts instead made every window TWO full q5 calls of different kinds on one ctx -- each
+        // re-uploading the other's schedule and declining its speculation: 1.48 ms per window against 1.21 ms for the whole-window feed
+        // (bench, round 4).
+        Q5TilePartial part;
+        FG_TRY(q5_partial_by_tile(ctx, &bc, &w, &part));
+        groups = part.offsets[1] - part.offsets[0];
         void *a = nullptr, *c = nullptr;
         FG_TRY(grow(ctx, leaf_key(plan, 0, 0, "ring.q5a"), (size_t)before * 4, (size_t)(before + groups) * 4 + 64, &a));
         FG_TRY(grow(ctx, leaf_key(plan, 0, 0, "ring.q5c"), (size_t)before * 4, (size_t)(before + groups) * 4 + 64, &c));
         plan->ring_auction = static_cast<int32_t *>(a);
         plan->ring_count = static_cast<uint32_t *>(c);
         if (groups) {
-            FG_HIP(ctx, hipMemcpyAsync(plan->ring_auction + before, r.auction, (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            FG_HIP(ctx, hipMemcpyAsync(plan->ring_count + before, r.count, (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(plan->ring_auction + before, part.auction + part.offsets[0], (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            FG_HIP(ctx, hipMemcpyAsync(plan->ring_count + before, part.count + part.offsets[0], (size_t)groups * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
     }
     plan->ring_groups.back() = groups;

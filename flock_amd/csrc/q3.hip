@@ -564,6 +564,48 @@ __global__ __launch_bounds__(kBlock) void q3_table_unique_kernel(const WinTable 
     if (threadIdx.x == 0 && s_red[0] + s_red[1] + s_red[2] + s_red[3] != (uint64_t)(seg_off[2 * blockIdx.x + 1] - seg_off[2 * blockIdx.x])) atomicOr(err, 1u);
 }
 
+// RANGE path, windows whose id range fits LDS (NEXMark's 1-s epochs: 20 000 persons = 80 KB): ONE workgroup per window inverts the
+// window's persons -- table[p_id - min] = row where the state filter kept the person (its bit in `bits`, written by the streaming build
+// kernel), -1 where it did not -- in LDS and writes the finished table out with coalesced stores.  Scattering the rows straight into the
+// global table (q3_build_kernel<dense, table>) costs one 32-byte sector read-modify-write per person once the ids are in no order:
+// 0.36 ms per 2e7 persons against 0.09 ms ordered.  The slots that stay unwritten are counted on the way out: as many written slots as
+// persons <=> the window's ids are pairwise different (else the call is void and the hash join decides).
+constexpr int kInvertBlock = 1024;
+constexpr int kInvertMaxRange = 28 * 1024;   // entries: 112 KB of the CU's 160 KB
+__global__ __launch_bounds__(kInvertBlock) void q3_invert_window_kernel(const int32_t *__restrict__ p_id, const int64_t *__restrict__ seg_off,
+                                                                        const WinTable *__restrict__ wins, const uint32_t *__restrict__ bits,
+                                                                        int32_t *__restrict__ direct, uint32_t *err) {
+    __shared__ int32_t s_tab[kInvertMaxRange];
+    __shared__ uint32_t s_cnt[kInvertBlock / 64];
+    const int32_t w = (int32_t)blockIdx.x;
+    const WinTable wt = wins[w];
+    const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
+    if (hi <= lo || wt.range == 0) return;
+    for (uint32_t i = threadIdx.x; i < wt.range; i += kInvertBlock) s_tab[i] = kUnwritten;
+    __syncthreads();
+    const uint32_t *wbits = bits + (size_t)wt.first_tile * (kFlagTile / 32);
+    for (int64_t r = lo + threadIdx.x; r < hi; r += kInvertBlock) {
+        const uint32_t idx = (uint32_t)p_id[r] - (uint32_t)wt.base, rel = wt.lead + (uint32_t)(r - lo);
+        const bool hit = (wbits[rel >> 5] >> (rel & 31u)) & 1u;
+        if (idx < wt.range) s_tab[idx] = hit ? (int32_t)r : -1;   // (two persons with one id: one slot -- the count below notices)
+    }
+    __syncthreads();
+    uint32_t written = 0;
+    for (uint32_t i = threadIdx.x; i < wt.range; i += kInvertBlock) {
+        const int32_t v = s_tab[i];
+        written += v != kUnwritten ? 1u : 0u;
+        direct[wt.off + i] = v;
+    }
+    written = (uint32_t)wave_sum_u64(written);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = written;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tot = 0;
+        for (int k = 0; k < kInvertBlock / 64; ++k) tot += s_cnt[k];
+        if (tot != (uint64_t)(hi - lo)) atomicOr(err, 1u);
+    }
+}
+
 // direct[0 .. info[0]) = -1 when info[2] says some slot is written by no person; the grid covers the arena's bound, workgroups past
 // the entries in use (or all of them, without gaps) leave at once
 __global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restrict__ direct, const uint64_t *__restrict__ info) {
@@ -996,12 +1038,17 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         // the multimap's returning compare-and-swaps cost 0.51 ms per 2e7 persons and its probe ran at 28 % of the HBM rate with 2.7x the
         // algorithmic traffic.
         std::vector<WinTable> h_wins((size_t)n_win);
-        uint64_t entries = 0;
+        uint64_t entries = 0, max_range = 0;
+        int32_t tile_at = 0;
         for (int w = 0; w < n_win; ++w) {
             const uint64_t range = pe[w] > pb[w] ? (uint64_t)((int64_t)h_stats[n_win + w] - (int64_t)h_stats[w] + 1) : 0;
-            h_wins[(size_t)w] = WinTable{pe[w] > pb[w] ? h_stats[w] : 0, (uint32_t)range, entries, 0, 0, 0u, 0u};
+            // (first_tile / lead: where the window's rows sit in the row-indexed bit blocks of the streaming build kernel)
+            h_wins[(size_t)w] = WinTable{pe[w] > pb[w] ? h_stats[w] : 0, (uint32_t)range, entries, (int32_t)pb[w], tile_at, (uint32_t)(pb[w] - (pb[w] & ~int64_t(3))), 0u};
             entries += range;
+            max_range = std::max(max_range, range);
+            if (pe[w] > pb[w]) tile_at += (int32_t)div_up(pe[w] - (pb[w] & ~int64_t(3)), kFlagTile);
         }
+        const bool invert_in_lds = max_range <= (uint64_t)kInvertMaxRange;   // every window's table fits a workgroup's LDS
         const size_t bound_pairs = (size_t)auction->rows;
         WinTable *d_wins = nullptr, *p_wins = nullptr;
         int32_t *direct = nullptr;
@@ -1016,9 +1063,26 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(arena_get_t(ctx, "q3.out_a_id", bound_pairs + 1, &o_aid));
         std::copy(h_wins.begin(), h_wins.end(), p_wins);   // (the staging was last read under the statistics' synchronisation)
         FG_HIP(ctx, hipMemcpyAsync(d_wins, p_wins, sizeof(WinTable) * (size_t)n_win, hipMemcpyHostToDevice, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(direct, 0xFE, sizeof(int32_t) * ((size_t)entries + 4), ctx->stream));
         FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-        if (st_p.n_tiles > 0) {
+        if (st_p.n_tiles > 0 && invert_in_lds) {
+            // the state filter as a stream (one bit per person ROW, q3_build_kernel<dense, bits>: no scatter), then one workgroup per window
+            // inverts its persons in LDS and writes the finished table with coalesced stores
+            uint32_t *bits = nullptr;
+            FG_TRY(arena_get_t(ctx, "q3.state_bits", (size_t)std::max(st_p.n_tiles, 1) * (kFlagTile / 32) + 4, &bits));
+            {
+                LaunchScope ls(ctx, "q3_build_kernel");
+                hipLaunchKernelGGL((q3_build_kernel<true, true, false, true>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream, person->p_id,
+                                   person->state.offsets, person->state.data, person->rows, st_p, lits, d_wins, nullptr, bits, nullptr, 0u, nullptr, d_err, build_y_shift,
+                                   (WinTable *)nullptr);
+            }
+            FG_TRY(check_launch(ctx, "q3_build_kernel"));
+            {
+                LaunchScope ls(ctx, "q3_invert_window_kernel");
+                hipLaunchKernelGGL(q3_invert_window_kernel, dim3((unsigned)n_win), dim3(kInvertBlock), 0, ctx->stream, person->p_id, st_p.seg_off, d_wins, bits, direct, d_err);
+            }
+            FG_TRY(check_launch(ctx, "q3_invert_window_kernel"));
+        } else if (st_p.n_tiles > 0) {
+            FG_HIP(ctx, hipMemsetAsync(direct, 0xFE, sizeof(int32_t) * ((size_t)entries + 4), ctx->stream));
             {
                 LaunchScope ls(ctx, "q3_build_kernel");
                 hipLaunchKernelGGL((q3_build_kernel<true, false, false, true>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream, person->p_id,

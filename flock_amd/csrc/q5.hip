@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(kBlock) void q5_part_count_kernel(const int32_t *__
 
 __global__ __launch_bounds__(kBlock) void q5_part_emit_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
                                                               const int32_t *__restrict__ pane_win_ptr, uint32_t nd, const int32_t *__restrict__ hist_incl,
-                                                              int32_t *__restrict__ keys_out) {
+                                                              int32_t *__restrict__ keys_out, uint16_t *__restrict__ low_out) {
     __shared__ uint32_t s_wh[kWavesPerBlock][kPartMaxDigits];  // running digit counts of a wave, then its base inside the digit
     __shared__ uint32_t s_dig_off[kPartMaxDigits];             // tile-local position of the digit's first row
     __shared__ uint32_t s_glob[kPartMaxDigits];                // output position of the digit's first row of this tile
@@ -1214,15 +1214,22 @@ __global__ __launch_bounds__(kBlock) void q5_part_emit_kernel(const int32_t *__r
     const int32_t first_valid = (int32_t)(tr.lo - tr.tile_begin);
     const int32_t tile_n = (int32_t)(tr.hi - tr.lo);
     (void)first_valid;
+    // Inside a bucket only the key's low kPartShift bits are news (the digit IS the bucket), so a partitioned key travels as 16 bits: the
+    // pass writes 2 B per row instead of 4 and the bucket pass reads 2 (round 4: 2.45 + 0.97 ms of q5_uniform's 4.9 were these 8 + 4 GB).
+    // The straggler bucket -- keys outside the pane's estimated range -- keeps whole keys, in the int32 array at the same positions (an
+    // array as long as the column, touched only where stragglers sit).
     for (int32_t j = threadIdx.x; j < tile_n; j += kBlock) {
         const int32_t key = s_keys[j];
         const uint32_t d = part_digit(key, pd, nd - 1);
-        keys_out[s_glob[d] + ((uint32_t)j - s_dig_off[d])] = key;
+        const uint32_t pos = s_glob[d] + ((uint32_t)j - s_dig_off[d]);
+        if (d == nd - 1) keys_out[pos] = key;
+        else low_out[pos] = (uint16_t)(((uint32_t)key - (uint32_t)pd.base) & ((1u << kPartShift) - 1));
     }
 }
 
 // One workgroup per (digit, pane) bucket: rows [start, end) of the partitioned keys, all inside [base + digit << shift, + 2^shift).
-__global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *__restrict__ keys, SegTiles st, const PaneDesc *__restrict__ panes,
+__global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *__restrict__ keys, const uint16_t *__restrict__ low, SegTiles st,
+                                                                 const PaneDesc *__restrict__ panes,
                                                                  const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx,
                                                                  uint32_t nd, const int32_t *__restrict__ hist_incl, uint32_t *counters, uint64_t *tables,
                                                                  uint32_t cap, uint32_t *tab_used, uint32_t *err) {
@@ -1254,29 +1261,38 @@ __global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *
         for (int i = threadIdx.x; i < (1 << kPartShift) / 4; i += kBlock) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    const uint32_t key0 = (uint32_t)(int32_t)(pd.base + ((int64_t)d << kPartShift));
-    constexpr int kUnroll = 8;
-    for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += (int64_t)kBlock * kUnroll) {
-        int32_t k[kUnroll];
+    // the bucket's rows as 16-bit bins: a head up to the next 8-byte boundary, then FOUR bins per 8-byte load (512 B per wave instruction)
+    auto add = [&](uint32_t bin, bool valid) {
+        // the first lane's key once per instruction: half of NEXMark's bids name one auction, wherever they sit
+        const uint32_t hot = __builtin_amdgcn_readfirstlane(bin);
+        const uint64_t b = __ballot(valid && bin == hot);
+        if (valid && bin == hot) {
+            if (mbcnt(b) == 0) atomicAdd(&s_hist[hot], (uint32_t)__popcll((unsigned long long)b));
+        } else if (valid) {
+            atomicAdd(&s_hist[bin], 1u);
+        }
+    };
+    const int64_t body0 = std::min<int64_t>(end, (begin + 3) & ~int64_t(3));   // (the array is 8-byte aligned: row 4k starts a quad)
+    for (int64_t i = begin + threadIdx.x; i < body0; i += kBlock) add(low[i], true);   // (at most three rows: one trip, lanes 0..2)
+    const int64_t quads = (end - body0) >> 2;
+    constexpr int kUnroll = 4;
+    for (int64_t q0 = threadIdx.x; q0 < quads; q0 += (int64_t)kBlock * kUnroll) {
+        uint2 v[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const int64_t i = i0 + (int64_t)u * kBlock;
-            k[u] = keys[i < end ? i : end - 1];
+            const int64_t q = q0 + (int64_t)u * kBlock;
+            v[u] = *reinterpret_cast<const uint2 *>(low + body0 + 4 * (q < quads ? q : quads - 1));
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const bool valid = i0 + (int64_t)u * kBlock < end;
-            const uint32_t bin = ((uint32_t)k[u] - key0) & ((1u << kPartShift) - 1);
-            // the first lane's key once per instruction: half of NEXMark's bids name one auction, wherever they sit
-            const uint32_t hot = __builtin_amdgcn_readfirstlane(bin);
-            const uint64_t b = __ballot(valid && bin == hot);
-            if (valid && bin == hot) {
-                if (mbcnt(b) == 0) atomicAdd(&s_hist[hot], (uint32_t)__popcll((unsigned long long)b));
-            } else if (valid) {
-                atomicAdd(&s_hist[bin], 1u);
-            }
+            const bool valid = q0 + (int64_t)u * kBlock < quads;
+            add(v[u].x & 0xFFFFu, valid);
+            add(v[u].x >> 16, valid);
+            add(v[u].y & 0xFFFFu, valid);
+            add(v[u].y >> 16, valid);
         }
     }
+    for (int64_t i = body0 + 4 * quads + threadIdx.x; i < end; i += kBlock) add(low[i], true);
     __syncthreads();
     const uint64_t idx0 = (uint64_t)d << kPartShift;
     for (uint32_t i = threadIdx.x; i < (1u << kPartShift); i += kBlock) {
@@ -1630,8 +1646,10 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             const int64_t slots = (int64_t)st4.n_tiles * nd;
             if (slots >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: too many (pane, digit, tile) slots for the partition pass");
             int32_t *hist = nullptr, *part_keys = nullptr;
+            uint16_t *part_low = nullptr;
             FG_TRY(arena_get_t(ctx, "q5.part_hist", (size_t)slots + 4, &hist));
-            FG_TRY(arena_get_t(ctx, "q5.part_keys", (size_t)rows + 4, &part_keys));
+            FG_TRY(arena_get_t(ctx, "q5.part_keys", (size_t)rows + 4, &part_keys));   // (whole keys of the straggler buckets only: sparse use)
+            FG_TRY(arena_get_t(ctx, "q5.part_low", (size_t)rows + 8, &part_low));
             FG_HIP(ctx, hipMemsetAsync(d_sample, 0, 2 * sizeof(uint32_t), ctx->stream));
             {
                 LaunchScope ls(ctx, "q5_part_count_kernel");
@@ -1641,12 +1659,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_TRY(inclusive_scan_i32(ctx, "q5.part_scan", hist, slots));
             {
                 LaunchScope ls(ctx, "q5_part_emit_kernel");
-                hipLaunchKernelGGL(q5_part_emit_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, part_keys);
+                hipLaunchKernelGGL(q5_part_emit_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, part_keys, part_low);
             }
             FG_TRY(check_launch(ctx, "q5_part_emit_kernel"));
             {
                 LaunchScope ls(ctx, "q5_bucket_count_kernel");
-                hipLaunchKernelGGL(q5_bucket_count_kernel, dim3(nd, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, part_keys, st4, d_panes, d_ptr, d_idx, nd, hist,
+                hipLaunchKernelGGL(q5_bucket_count_kernel, dim3(nd, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, part_keys, part_low, st4, d_panes, d_ptr, d_idx, nd, hist,
                                    counters, tables, cap, d_used, d_err);
             }
             FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));

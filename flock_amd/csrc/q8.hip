@@ -73,14 +73,14 @@ __device__ __forceinline__ GaplessWin gapless_window(const int32_t *__restrict__
 // what reaches memory is still one fire-and-forget OR per touched WORD, consecutive words per wave instruction, not one per row.
 template <int kWords>
 __device__ __forceinline__ void sellers_bitmap_tile(const int32_t *__restrict__ seller, int64_t n_rows, const TileRange &tr, const WinBitmap wb,
-                                                    uint32_t *bitmaps, uint32_t *s_bm, uint32_t *s_red) {
+                                                    uint32_t *bitmaps, uint32_t *s_bm, uint32_t *s_red, int32_t (&a)[kFlagIters][4]) {
+    // (`a`: the tile's keys, requested by the caller BEFORE it looked its window's layout up: the layout is two or three dependent loads,
+    // and a workgroup that waits for them before it asks for its 32 KB of keys pays their latency twice -- 57 vs 53 us per 6e7 auctions)
     {
         uint4 *z = reinterpret_cast<uint4 *>(s_bm);
         for (int s = threadIdx.x; s < kWords / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
     }
     if (wb.n_bits == 0) return;
-    int32_t a[kFlagIters][4];
-    load_flag_tile(seller, n_rows, tr, a);
     const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
     const int32_t rel0 = flag_rel0();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -174,16 +174,86 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_kernel(const int32_t
     __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWords];
     __shared__ uint32_t s_red[2 * kWavesPerBlock];
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
-    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, wins[tr.seg], bitmaps, s_bm, s_red);
+    int32_t a[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, a);
+    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, wins[tr.seg], bitmaps, s_bm, s_red, a);
 }
-// keys in any order: the wide LDS stage (range path; also builds the persons' presence bitmap)
+// keys in any order (range path): the wide LDS stage, kept over up to kWideTiles consecutive tiles of ONE window.  A tile of shuffled ids
+// touches nearly every word of its window's bitmap (8192 rows over ~6250 words), so a flush per tile was 15e6 word ORs for 2e7 persons
+// (0.12 ms); a workgroup that keeps the stage over four tiles of the window flushes a quarter of that.
 constexpr int kBmLdsWordsWide = 8192;
+constexpr int kWideTiles = 4;
+__device__ __forceinline__ void key_bitmap_wide(const int32_t *__restrict__ key, int64_t n_rows, const SegTiles &st, const WinBitmap *__restrict__ wins,
+                                                uint32_t *bitmaps, uint32_t *s_bm) {
+    const int32_t t0 = (int32_t)blockIdx.x * kWideTiles, t1 = min(t0 + kWideTiles, st.n_tiles);
+    int32_t seg = -1;
+    WinBitmap wb{0, 0u, 0};
+    uint32_t n_words = 0;
+    bool staged = false, dirty = false;
+    auto flush = [&]() {   // (block-uniform)
+        if (staged && dirty) {
+            __syncthreads();
+            uint32_t *gbm = bitmaps + wb.word_off;
+            for (uint32_t s = threadIdx.x; s < n_words; s += kBlock) {
+                const uint32_t bits = s_bm[s];
+                if (bits) {
+                    bitmap_or_global(gbm + s, bits);
+                    s_bm[s] = 0;
+                }
+            }
+            __syncthreads();
+        }
+        dirty = false;
+    };
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_bm);
+        for (int s = threadIdx.x; s < kBmLdsWordsWide / 4; s += kBlock) z[s] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int32_t t = t0; t < t1; ++t) {
+        const TileRange tr = locate_tile(st, t, kFlagTile);
+        int32_t a[kFlagIters][4];
+        load_flag_tile(key, n_rows, tr, a);
+        if (tr.seg != seg) {
+            flush();
+            seg = tr.seg;
+            wb = wins[seg];
+            n_words = (wb.n_bits + 31) >> 5;
+            staged = n_words <= (uint32_t)kBmLdsWordsWide;
+        }
+        if (wb.n_bits == 0) continue;
+        const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin), rel0 = flag_rel0();
+        uint32_t *gbm = bitmaps + wb.word_off;
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t rel = rel0 + it * 256 + j;
+                const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)wb.base;
+                if (!(rel >= rel_lo && rel < rel_hi && idx < wb.n_bits)) continue;
+                const uint32_t bit = 1u << (idx & 31);
+                if (staged) {
+                    uint32_t *w = &s_bm[idx >> 5];
+                    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)) atomicOr(w, bit);
+                } else {
+                    bitmap_or_global(gbm + (idx >> 5), bit);
+                }
+            }
+        dirty = true;
+    }
+    flush();
+}
 __global__ __launch_bounds__(kBlock) void q8_key_bitmap_wide_kernel(const int32_t *__restrict__ key, int64_t n_rows, SegTiles st,
                                                                     const WinBitmap *__restrict__ wins, uint32_t *bitmaps) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWordsWide];
-    __shared__ uint32_t s_red[2 * kWavesPerBlock];
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
-    sellers_bitmap_tile<kBmLdsWordsWide>(key, n_rows, tr, wins[tr.seg], bitmaps, s_bm, s_red);
+    key_bitmap_wide(key, n_rows, st, wins, bitmaps, s_bm);
+}
+// (the same pass over the persons' ids -- the presence bitmap of the uniqueness check -- under a name of its own, so that profiles tell
+// the two launches apart)
+__global__ __launch_bounds__(kBlock) void q8_person_bitmap_wide_kernel(const int32_t *__restrict__ key, int64_t n_rows, SegTiles st,
+                                                                       const WinBitmap *__restrict__ wins, uint32_t *bitmaps) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWordsWide];
+    key_bitmap_wide(key, n_rows, st, wins, bitmaps, s_bm);
 }
 // the same with the gapless layout derived in place (the auction tile's window index names the person window)
 __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_inline_kernel(const int32_t *__restrict__ seller, int64_t n_rows, SegTiles st,
@@ -192,8 +262,10 @@ __global__ __launch_bounds__(kBlock) void q8_sellers_bitmap_inline_kernel(const 
     __shared__ __attribute__((aligned(16))) uint32_t s_bm[kBmLdsWords];
     __shared__ uint32_t s_red[2 * kWavesPerBlock];
     const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kFlagTile);
+    int32_t a[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, a);
     const GaplessWin g = gapless_window(p_id, person_seg_off, tr.seg, h_flags);
-    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, g.wb, bitmaps, s_bm, s_red);
+    sellers_bitmap_tile<kBmLdsWords>(seller, n_rows, tr, g.wb, bitmaps, s_bm, s_red, a);
 }
 
 // kOrdered: the layout came from the windows' first and last ids and every row is taken for DISTINCT -- both hold for strictly increasing
@@ -516,8 +588,6 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_fast_kernel(const int3
     __shared__ uint32_t s_tot[2][kWavesPerBlock];
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
-    const GaplessWin g = gapless_window(p_id, st.seg_off, tr.seg, h_flags);
-    const WinBitmap wb = g.wb;
     const int32_t rel0 = flag_rel0();
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     int32_t a[kFlagIters][4];
@@ -543,6 +613,9 @@ __global__ __launch_bounds__(kBlock) void q8_persons_flag_fast_kernel(const int3
             }
         }
     }
+    // (the window's layout -- two dependent loads -- only after the tile's ids and offsets have been asked for)
+    const GaplessWin g = gapless_window(p_id, st.seg_off, tr.seg, h_flags);
+    const WinBitmap wb = g.wb;
     const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
     const uint32_t *gbm = bitmaps + wb.word_off;
     uint32_t flags = 0, my_bytes = 0;
@@ -1066,15 +1139,17 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
         if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q8_sellers_bitmap_kernel");
-            hipLaunchKernelGGL(q8_key_bitmap_wide_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller, auction->rows, st_a, d_wins, sellers);
+            hipLaunchKernelGGL(q8_key_bitmap_wide_kernel, dim3((unsigned)div_up(st_a.n_tiles, kWideTiles)), dim3(kBlock), 0, ctx->stream, auction->seller, auction->rows, st_a, d_wins,
+                               sellers);
         }
         FG_TRY(check_launch(ctx, "q8_sellers_bitmap_kernel"));
         if (st_p.n_tiles > 0) {
             {
-                LaunchScope ls(ctx, "q8_key_bitmap_wide_kernel");
-                hipLaunchKernelGGL(q8_key_bitmap_wide_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p, d_wins, present);
+                LaunchScope ls(ctx, "q8_person_bitmap_wide_kernel");
+                hipLaunchKernelGGL(q8_person_bitmap_wide_kernel, dim3((unsigned)div_up(st_p.n_tiles, kWideTiles)), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p,
+                                   d_wins, present);
             }
-            FG_TRY(check_launch(ctx, "q8_key_bitmap_wide_kernel"));
+            FG_TRY(check_launch(ctx, "q8_person_bitmap_wide_kernel"));
             LaunchScope ls(ctx, "q8_persons_flag_kernel");
             const unsigned grid = (unsigned)std::min<int64_t>(st_p.n_tiles, (int64_t)ctx->num_cus * kStreamBlocksPerCu);
             hipLaunchKernelGGL(q8_persons_flag_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p, d_wins, sellers, flag_words,

@@ -14,14 +14,15 @@ src, dst = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profile
 os.makedirs(dst, exist_ok=True)
 for f in sorted(os.listdir(src)):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-DOMINANT = {5: "q5_count_kernel", 2: "q2_flag_kernel", 3: "q3_probe_flag_kernel", 8: "q8_sellers_bitmap_kernel", 7: "q7_max_kernel", 9: "aq_final_kernel",
+DOMINANT = {5: "q5_count_kernel", 2: "q2_flag_kernel", 3: "q3_probe_flag_kernel", 8: "q8_sellers_bitmap_inline_kernel", 7: "q7_max_kernel", 9: "aq_final_kernel",
             13: "q13_flag_kernel"}
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, "
                        "tools/gpu_profile.sh): bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 reports half of a 16 B/lane coalesced stream, "
                        "MI355X_MICROARCH.md HBM section) + WRITE_SIZE_KB * 1024.  Source CSVs: profiles/%s/q*_pmc_*.csv" % tag}
 # (file prefix, kernel): the query rows, the "next" side entries and the general-path rows
-ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
-                                                            ("q3_general", "q3_probe_general_kernel"), ("q8_general", "q8_sellers_set_kernel"),
+ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q8", "q8_sellers_bitmap_kernel")] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
+                                                            ("q3_general", "q3_probe_flag_kernel"), ("q8_general", "q8_key_bitmap_wide_kernel"),
+                                                            ("q3_hash", "q3_probe_general_kernel"), ("q8_hash", "q8_sellers_set_kernel"),
                                                             ("q5_uniform", "q5_part_emit_kernel"), ("q4", "aq_final_kernel"),
                                                             ("q3_1e8", "q3_probe_flag_small_kernel")]
 for q, kern in ROWS:
@@ -37,11 +38,20 @@ for q, kern in ROWS:
                 launches += int(r["launches"])
         if launches:
             vals[c] = tot / launches
-    name = kern if not q.endswith(("_general", "_uniform")) and q not in ("q4", "q3_1e8") else f"{kern}@{q}"
+    # bench.py's LaunchScope labels (the key it looks traffic up under): the inline / wide / small variants run under the plain names
+    label = {"q3_probe_flag_small_kernel": "q3_probe_flag_kernel", "q8_key_bitmap_wide_kernel": "q8_sellers_bitmap_kernel", "q8_sellers_bitmap_inline_kernel": "q8_sellers_bitmap_kernel",
+             "q3_probe_general_kernel": "q3_probe_count_kernel"}.get(kern, kern)
+    name = label if not q.endswith(("_general", "_uniform", "_hash")) and q not in ("q4", "q3_1e8") else f"{label}@{q}"
     if q == "q3_1e8":
-        name = "q3_probe_flag_kernel@1e8_events"   # (bench.py's label of both probe kernels)
+        name = "q3_probe_flag_kernel@1e8_events"
     if len(vals) == 2 and name not in traffic:
         traffic[name] = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
-        traffic[name + "_detail"] = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
+        detail = {"fetch_KB_raw": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"]}
+        try:   # the algorithmic bytes of the profiled run: bench.py attaches the entry only to a run of the same size
+            under = json.load(open(os.path.join(dst, f"{q}_bench_under_rocprof.json")))
+            detail["alg_bytes"] = (under.get("roofline") or {}).get("algorithmic_bytes_per_launch")
+        except Exception:
+            pass
+        traffic[name + "_detail"] = detail
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -22,9 +22,10 @@ with open(out, "w") as o:
         o.write('"%s",%d,%.3f\n' % (k, n, v / n))
 PY
 }
-for q in ${QUERIES:-5 2 8 3 7 9 13}; do
+for q in ${QUERIES:-5 2 8 3 3_1e8 7 9 13}; do
   extra=""; [ "$q" = "3" ] && extra="--seconds 1000"
-  cmd="python bench.py --query $q $extra --steps 3 --warmup 1 --no-also --no-cpu"
+  qa=$q; [ "$q" = "3_1e8" ] && qa=3
+  cmd="python bench.py --query $qa $extra --steps 6 --warmup 3 --no-also --no-cpu"
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $cmd > "$OUT/q${q}_stats_run.log" 2>&1
   f=$(find /tmp/prof_q$q -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/q${q}_kernel_stats.csv"
   grep '^{' "$OUT/q${q}_stats_run.log" | tail -1 > "$OUT/q${q}_bench_under_rocprof.json"
@@ -46,7 +47,7 @@ for side in ${SIDES:-q11 ysb json}; do
   done
   rm -f "$OUT"/${side}_*_run.log
 done
-for gen in ${GENERALS:-q3_general q8_general q5_uniform}; do
+for gen in ${GENERALS:-q3_general q8_general q5_uniform q3_hash q8_hash}; do
   cmd="python bench.py --only-general $gen --steps 3"
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$gen -- $cmd > "$OUT/${gen}_stats_run.log" 2>&1
   f=$(find /tmp/prof_$gen -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${gen}_kernel_stats.csv"

@@ -8,7 +8,7 @@ for q in 8 3; do
 import json
 try:
     d=json.loads(open("$OUT/q$q.json").read()); r=d["roofline"]
-    print("q$q", "ms/step", d["ms_per_step"], "frac", r["frac"], r["kernels_ms"])
+    print("q$q", "ms/step", d["ms_per_step"], "frac", r["frac"], r.get("avg_launch_ms"))
 except Exception as e:
     print("q$q failed", e); print(open("$OUT/q$q.err").read()[-1500:])
 PY
