@@ -631,6 +631,49 @@ def test_q3_five_launch_sequence_equals_the_general_one():
     c.close()
 
 
+def test_q3_every_row_joins_long_strings_many_tiles():
+    """q3's steady-state sequence on what NEXMark never shows it: EVERY auction joins (8192 joined rows per tile), names of 0 .. 70 bytes
+    (values beyond the take's 16-byte head, tiles of the take beyond its LDS stage), hundreds of tiles (self-scans over several rounds),
+    ragged window edges inside tiles, a window without auctions, and the same ctx called again and again with the selectivity changing
+    under it (estimates too large, then too small: the take is redone)."""
+    from flock_amd import Auctions, GpuContext, Persons, WindowSchedule
+    c = GpuContext(0)
+    rng = np.random.default_rng(17)
+    npn, na = 50_000, 2_600_000                       # 318 auction tiles
+    p_id = np.arange(npn, dtype=np.int32) + 7
+    st = rng.choice(np.array([b"or", b"id", b"ca"], dtype=object), npn)
+    state = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32), np.frombuffer(b"".join(st), np.uint8).copy())
+    lens = rng.choice(np.array([0, 1, 3, 15, 16, 17, 33, 70]), npn)
+    nm = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in lens]
+    name = oracle.Utf8(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), np.frombuffer(b"".join(nm), np.uint8).copy())
+    cy = [b"c%d" % (i % 97) for i in range(npn)]
+    city = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in cy])]).astype(np.int32), np.frombuffer(b"".join(cy), np.uint8).copy())
+    p_edges = np.array([0, 10_001, 10_001 + 8192 * 2, 40_003, npn])
+    a_edges = np.array([0, 700_003, 700_003, 1_900_001, na])          # the third window has persons and no auctions
+    pw = WindowSchedule(p_edges, np.arange(4), np.arange(1, 5))
+    aw = WindowSchedule(a_edges, np.arange(4), np.arange(1, 5))
+    seller = np.empty(na, np.int32)
+    for w in range(4):
+        seller[a_edges[w]:a_edges[w + 1]] = rng.integers(p_id[p_edges[w]], p_id[p_edges[w + 1] - 1] + 1, a_edges[w + 1] - a_edges[w])
+    a_id = (np.arange(na, dtype=np.int64) * 5 + 3).astype(np.int32)
+    persons = Persons(_dev(p_id), _utf8(name), _utf8(city), _utf8(state), npn)
+    for variant in ("all", "tenth", "all"):
+        category = np.full(na, 10, np.int32) if variant == "all" else rng.choice(np.array([10] + [11] * 9, np.int32), na)
+        for call in range(3):     # general sequence, steady-state sequence with estimates from it, and again
+            out = c.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw, persons, pw).to_host()
+            keep = np.flatnonzero(category == 10)
+            assert np.array_equal(out["auction_row"], keep), (variant, call)      # auction order, every row once (all states pass)
+            assert np.array_equal(out["a_id"], a_id[keep]) and np.array_equal(out["person_row"], seller[keep] - 7)
+            assert out["offsets"].tolist() == [int(np.searchsorted(keep, e)) for e in a_edges], (variant, call)
+            for k, src in (("name", name), ("city", city), ("state", state)):
+                off, data = out[k]
+                want_len = (src.offsets[1:] - src.offsets[:-1])[out["person_row"]]
+                assert np.array_equal(np.diff(off), want_len) and off[0] == 0, (k, variant, call)
+                pos = np.repeat(src.offsets[:-1][out["person_row"]] - off[:-1], want_len) + np.arange(off[-1])
+                assert np.array_equal(data[:off[-1]], src.data[pos]), (k, variant, call)
+    c.close()
+
+
 def _q8_check(out, pw, aw, p_id, name, nm, seller, tag):
     g_names, off = _str_rows(*out["name"]), out["offsets"]
     total = 0
