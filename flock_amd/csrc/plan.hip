@@ -9,6 +9,9 @@
 // every other node -- the STAGE plans either side of a `RepartitionExec Hash` -- runs on the generic operators of
 // relops.hpp.  Host-side code only; all compute goes through those two layers.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <map>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -21,6 +24,34 @@ using namespace flockgpu;
 using namespace flockgpu::ir;
 
 namespace {
+#ifdef FLOCKGPU_EXPERIMENTAL
+// (A/B builds: wall time per entry point, printed by flockgpu_plan_ring_close when FLOCKGPU_PLAN_TIMES is set)
+struct ApiClock {
+    const char *what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    static std::map<std::string, std::pair<double, long>> &acc() {
+        static std::map<std::string, std::pair<double, long>> m;
+        return m;
+    }
+    explicit ApiClock(const char *w) : what(w) {}
+    ~ApiClock() {
+        auto &e = acc()[what];
+        e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        e.second += 1;
+    }
+    static void dump() {
+        if (!flockgpu::exp_env("FLOCKGPU_PLAN_TIMES")) return;
+        for (auto &kv : acc()) fprintf(stderr, "[plan times] %-28s %8ld calls %10.1f us/call\n", kv.first.c_str(), kv.second.second, kv.second.first / std::max(1L, kv.second.second));
+        acc().clear();
+    }
+};
+#define API_CLOCK(name) ApiClock api_clock_(name)
+#define API_CLOCK2(var, name) ApiClock var(name)
+#else
+#define API_CLOCK(name) do {} while (0)
+#define API_CLOCK2(var, name) do {} while (0)
+#endif
+
 
 // ------------------------------------------------------------------ pinned host memory, pooled
 // Output batches live in pinned host memory (one block per execute); blocks return to a process-wide pool when the
@@ -1040,6 +1071,7 @@ struct Exec {
                     for (int64_t g : pl->ring_groups) total += g;
                     flockgpu_windows w = whole(total, off_a, lo_a, hi_a);
                     flockgpu_q5_result r{};
+                    API_CLOCK("ring.q5_weighted");
                     FG_TRY(flockgpu_q5_hot_items_weighted(ctx, pl->ring_auction, pl->ring_count, total, &w, &r));
                     place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::U64, r.num)}, r.rows, t);
                     return FLOCKGPU_OK;
@@ -1051,6 +1083,7 @@ struct Exec {
                 flockgpu_bid_cols bc{leaf_col<int32_t>(leaf, col), nullptr, nullptr, nullptr, rows};
                 flockgpu_windows w = whole(rows, off_a, lo_a, hi_a);
                 flockgpu_q5_result r{};
+                API_CLOCK("q5_hot_items");
                 FG_TRY(flockgpu_q5_hot_items(ctx, &bc, &w, &r));
                 place(n, fi, {dev_col(ColType::I32, r.auction), dev_col(ColType::U64, r.num)}, r.rows, t);
                 return FLOCKGPU_OK;
@@ -1921,6 +1954,9 @@ int flockgpu_plan_explain(const char *plan_json, size_t len, char *out, size_t c
 
 void flockgpu_plan_destroy(flockgpu_plan *plan) {
     if (!plan) return;
+#ifdef FLOCKGPU_EXPERIMENTAL
+    if (plan->ring_ppw) ApiClock::dump();
+#endif
     flockgpu_ctx *ctx = plan->ctx;
     if (plan->async_pending) {   // an execute nobody waited for: let it finish, drop what it produced
         if (ctx_wait(ctx) == FLOCKGPU_OK) {
@@ -2180,10 +2216,14 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
 // ------------------------------------------------------------------ pane ring
 // Drops the oldest pane: the rows (bytes) of the panes that stay move to the front of a second buffer, which then trades places
 // with the first (source and destination of one hipMemcpyAsync must not overlap); q5's group arrays likewise.
-static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *src, size_t keep_bytes, size_t cap_bytes, void **out) {
+// The retained tail of a leaf buffer moves to the front of the buffer's twin, and the two swap names.  The twin is asked for the KEPT bytes
+// only: what the next pane adds is the feed's business (grow), so in the steady state both twins have reached the size two panes need and
+// nothing is allocated.  (Asking for the current buffer's capacity made every window reallocate: the arena over-allocates by an eighth when
+// it grows, so each twin was always an eighth smaller than the other -- 0.39 ms of hipFree + hipMalloc per window, growing without bound.)
+static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *src, size_t keep_bytes, size_t /*cap_bytes*/, void **out) {
     const std::string alt = key + ".alt";
     void *p = nullptr;
-    FG_TRY(arena_get(ctx, alt.c_str(), std::max<size_t>(cap_bytes, 64), &p));
+    FG_TRY(arena_get(ctx, alt.c_str(), std::max<size_t>(keep_bytes, 64), &p));
     if (keep_bytes) FG_HIP(ctx, hipMemcpyAsync(p, src, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     std::swap(ctx->arena[key], ctx->arena[alt]);
     *out = p;
@@ -2192,6 +2232,7 @@ static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *s
 static int ring_drop_oldest(flockgpu_plan *plan) {
     flockgpu_ctx *ctx = plan->ctx;
     if (plan->ring_n == 0) return FLOCKGPU_OK;
+    API_CLOCK("ring_drop_oldest");
     if (plan->ring_q5) {
         const int64_t d = plan->ring_groups.empty() ? 0 : plan->ring_groups[0];
         int64_t total = 0;
@@ -2252,6 +2293,7 @@ static int ring_drop_oldest(flockgpu_plan *plan) {
 static int ring_q5_partial(flockgpu_plan *plan) {
     flockgpu_ctx *ctx = plan->ctx;
     if (plan->ring_newest_done || plan->ring_n == 0) return FLOCKGPU_OK;
+    API_CLOCK("ring_q5_partial");
     // the bids sit in whichever of the plan's two `bid` leaves was fed (both scan the same relation)
     const LeafData *ld = nullptr;
     int col = -1;
@@ -2303,7 +2345,7 @@ int flockgpu_plan_ring_open(flockgpu_plan *plan, int panes_per_window) {
     plan->ring_ppw = panes_per_window;
     plan->ring_first = 0;
     plan->ring_n = 0;
-    plan->ring_q5 = plan->query == 5 && !plan->generic_only;
+    plan->ring_q5 = plan->query == 5 && !plan->generic_only && !exp_env("FLOCKGPU_RING_ROWS");   // (A/B knob: the rows ring for q5, too)
     plan->ring_groups.clear();
     plan->ring_newest_done = false;
     return FLOCKGPU_OK;
@@ -2322,6 +2364,7 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
     if (!plan) return FLOCKGPU_ERR_INVALID;
     flockgpu_ctx *ctx = plan->ctx;
     if (!plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the plan has no open ring (flockgpu_plan_ring_open)");
+    API_CLOCK("feed_pane");
     if (input < 0 || input >= (int)plan->leaves.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: bad argument");
     const int64_t newest = plan->ring_first + plan->ring_n - 1;
     const bool begin = plan->ring_n == 0 || pane_id == newest + 1;
@@ -2332,7 +2375,10 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the ring is full (%d panes): flockgpu_plan_reset retires the oldest before pane %lld begins",
                     plan->ring_ppw, (long long)pane_id);
     // every check of the feed first: a refused feed must leave the ring as it was
-    if (n_batches > 0 || schema) FG_TRY(feed_impl(plan, input, schema, batches, n_batches, true));
+    {
+        API_CLOCK2(c1, "feed_pane.validate");
+        if (n_batches > 0 || schema) FG_TRY(feed_impl(plan, input, schema, batches, n_batches, true));
+    }
     if (begin) {
         if (plan->ring_q5 && plan->ring_n > 0) {   // the pane that closes leaves its groups behind, its rows go
             FG_TRY(ring_q5_partial(plan));
@@ -2357,7 +2403,10 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
     const int64_t rows_before = ld.rows;
     std::vector<int64_t> bytes_before(ld.cols.size());
     for (size_t c = 0; c < ld.cols.size(); ++c) bytes_before[c] = ld.cols[c].bytes;
-    FG_TRY(feed_impl(plan, input, schema, batches, n_batches, false));
+    {
+        API_CLOCK2(c2, "feed_pane.feed");
+        FG_TRY(feed_impl(plan, input, schema, batches, n_batches, false));
+    }
     ld.pane_rows.back() += ld.rows - rows_before;
     for (size_t c = 0; c < ld.cols.size(); ++c) ld.pane_bytes.back()[c] += ld.cols[c].bytes - bytes_before[c];
     plan->ring_newest_done = false;   // (more rows of the newest pane: its groups are counted again from its rows)
@@ -2368,6 +2417,9 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
 int flockgpu_plan_ring_close(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "ring_close: an asynchronous execute is in flight");
+#ifdef FLOCKGPU_EXPERIMENTAL
+    ApiClock::dump();
+#endif
     plan->ring_ppw = 0;
     plan->ring_n = 0;
     plan->ring_q5 = false;
@@ -2379,6 +2431,7 @@ int flockgpu_plan_ring_close(flockgpu_plan *plan) {
 int flockgpu_plan_reset(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_reset: an asynchronous execute is in flight (flockgpu_plan_wait first)");
+    API_CLOCK("reset");
     // borrowed pinned buffers may still be read by the DMA engine: the caller is about to drop them
     if (plan->fed_bytes) (void)hipStreamSynchronize(plan->ctx->stream);
     plan->fed_bytes = 0;
@@ -2537,6 +2590,7 @@ int flockgpu_plan_execute(flockgpu_plan *plan, struct ArrowSchema *out_schema, s
     if (!out_schema || !out_batch) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute: null output");
     if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_execute: an asynchronous execute is in flight (flockgpu_plan_wait first)");
     int n = 0;
+    API_CLOCK("execute");
     return run_plan(plan, false, out_schema, out_batch, 1, &n);
 }
 

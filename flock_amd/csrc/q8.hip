@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 #pragma unroll
         for (int it = 0; it < kFlagIters; ++it) {
             const int64_t r = tr.tile_begin + (rel0 - lane * 4) + it * 256 - 1;
-            before[it] = p_id[r < 0 ? 0 : r];
+            before[it] = p_id[r < 0 ? 0 : (r < n_rows ? r : n_rows - 1)];   // (clamped into the column: the chunks of a ragged last tile lie past its end)
         }
         const WinBitmap wb = wins[tr.seg];
         const int32_t next = tile + (int32_t)gridDim.x;
