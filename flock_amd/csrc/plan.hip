@@ -147,7 +147,7 @@ struct FusedInfo {
     std::vector<std::string> strs;    // q3 state literals
 };
 
-constexpr int kStageLanes = 8;                     // at most this many host threads fill pinned chunks side by side (FLOCKGPU_STAGE_LANES, default 4)
+constexpr int kStageLanes = 8;                     // at most this many host threads fill pinned chunks side by side (four do; FLOCKGPU_STAGE_LANES in experimental builds)
 constexpr int kStageChunks = kStageLanes * 2;      // two chunks per lane: one is filled while the other is in flight
 constexpr size_t kStageChunk = size_t(4) << 20;
 
@@ -855,7 +855,8 @@ int flush_jobs(flockgpu_plan *pl) {
         }
     pl->jobs.clear();
     // small feeds stay on the calling thread; from a few MB on the lanes pay for their start-up
-    static const int want_lanes = getenv("FLOCKGPU_STAGE_LANES") ? std::max(1, std::min(kStageLanes, atoi(getenv("FLOCKGPU_STAGE_LANES")))) : 4;
+    // (2 / 4 / 6 / 8 lanes: 1.12 / 1.09-1.13 / 1.09 / 1.12 ms per 36.8 MB window, round 4 -- the transfer, not the host copy, is what is left)
+    static const int want_lanes = exp_env("FLOCKGPU_STAGE_LANES") ? std::max(1, std::min(kStageLanes, atoi(exp_env("FLOCKGPU_STAGE_LANES")))) : 4;
     const int n_lanes = total < (size_t(2) << 20) ? 1 : (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(1, std::thread::hardware_concurrency()));
     if (n_lanes == 1) {
         if (stage_lane(pl, 0, pieces, 1) != FLOCKGPU_OK) return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: staged host-to-device copy failed");
