@@ -49,6 +49,28 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
 
 
+def test_shipped_library_reads_no_environment():
+    """Experiment knobs exist only in -DFLOCKGPU_EXPERIMENTAL builds (common.hpp exp_env): the one getenv of the kernels' sources sits
+    under that switch, and the shipped library does not import the symbol at all."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "flock_amd", "csrc")
+    uses = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            for n, line in enumerate(open(os.path.join(csrc, f), errors="ignore"), 1):
+                if re.search(r"(?<![_a-zA-Z])getenv\s*\(", line):
+                    uses.append((f, n))
+    assert [f for f, _ in uses] == ["common.hpp"], uses
+    text = open(os.path.join(csrc, "common.hpp")).read()
+    at = text.index("getenv(")
+    assert "#ifdef FLOCKGPU_EXPERIMENTAL" in text[max(0, at - 400):at]
+    so = os.path.join(ROOT, "flock_amd", "libflockgpu.so")
+    if os.path.exists(so):
+        dyn = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+        assert not re.search(r"\bgetenv\b", dyn), "libflockgpu.so imports getenv"
+
+
 def test_counts_closed_form_matches_oracle():
     # host-only entry point (no GPU needed): event-kind counts of a stream slice
     import oracle
