@@ -156,6 +156,8 @@ SYMBOLS = {
     "flockgpu_malloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "flockgpu_free": (_i, [_vp, _vp]),
     "flockgpu_memcpy": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
+    "flockgpu_malloc_guarded": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "flockgpu_free_guarded": (_i, [_vp, _vp]),
     "flockgpu_profile_enable": (_i, [_vp, _i]),
     "flockgpu_profile_only": (_i, [_vp, C.c_char_p]),
     "flockgpu_profile_reset": (_i, [_vp]),

@@ -26,6 +26,11 @@ struct KernelStat {
     double total_ms = 0.0;
 };
 
+struct GuardedAlloc {
+    void *base = nullptr;
+    size_t reserved = 0, mapped = 0;
+    hipMemGenericAllocationHandle_t handle{};
+};
 struct PendingEvent {
     const char *name;
     hipEvent_t start, stop;
@@ -59,6 +64,8 @@ struct flockgpu_ctx {
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, flockgpu::KernelStat> stats;
     flockgpu::AsyncWorker *worker = nullptr;  // created by the first asynchronous call
+    // flockgpu_malloc_guarded: pointer handed out -> {reserved base, reserved bytes, mapped bytes, allocation handle}
+    std::map<void *, flockgpu::GuardedAlloc> guarded;
 };
 
 namespace flockgpu {
@@ -87,6 +94,32 @@ inline int fail(flockgpu_ctx *ctx, int code, const char *fmt, ...) {
         if (rc_ != FLOCKGPU_OK) return rc_; \
     } while (0)
 
+// Experiment knobs (A/B switches the tools/gpu_*.sh scripts flip through the environment) exist only in builds made with
+// -DFLOCKGPU_EXPERIMENTAL (`FLOCKGPU_BUILD_EXPERIMENTAL=1 python -m flock_amd.build`, which writes libflockgpu_experimental.so): the
+// shipped library never reads them, so no untested configuration is reachable from a production host's environment.
+#ifdef FLOCKGPU_EXPERIMENTAL
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
+// The library's own device buffers.  Experimental builds with FLOCKGPU_GUARD_ARENA set place every one of them at the END of mapped
+// address space (flockgpu_malloc_guarded) and give it exactly the bytes that were asked for: a kernel that reads or writes past what its
+// host code requested for it faults (tools/gpu_guard_arena.sh runs the GPU tests that way).
+inline bool guard_arena() {
+    static const bool on = exp_env("FLOCKGPU_GUARD_ARENA") != nullptr;
+    return on;
+}
+inline hipError_t dev_alloc(flockgpu_ctx *ctx, void **ptr, size_t bytes) {
+    if (guard_arena()) return flockgpu_malloc_guarded(ctx, bytes, ptr) == FLOCKGPU_OK ? hipSuccess : hipErrorOutOfMemory;
+    return hipMalloc(ptr, bytes);
+}
+inline void dev_free(flockgpu_ctx *ctx, void *ptr) {
+    if (!ptr) return;
+    if (guard_arena() && ctx->guarded.count(ptr)) (void)flockgpu_free_guarded(ctx, ptr);
+    else (void)hipFree(ptr);
+}
+
 // Grow-only device buffer.  Contents are NOT preserved across a grow.
 inline int arena_get(flockgpu_ctx *ctx, const char *name, size_t bytes, void **out) {
     DeviceBuf &b = ctx->arena[name];
@@ -95,13 +128,21 @@ inline int arena_get(flockgpu_ctx *ctx, const char *name, size_t bytes, void **o
         if (b.ptr) {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_HIP, "sync before arena grow: %s", hipGetErrorString(e));
-            (void)hipFree(b.ptr);
+            dev_free(ctx, b.ptr);
             b.ptr = nullptr;
             b.cap = 0;
         }
         size_t want = bytes + bytes / 8;  // slack so that slowly growing windows do not reallocate every call
         want = (want + 255) & ~size_t(255);
-        hipError_t e = hipMalloc(&b.ptr, want);
+        if (exp_env("FLOCKGPU_ARENA_EXACT")) want = bytes;   // (ordinary memory, no slack: every growth reallocates -- address recycling without the guard)
+        if (guard_arena()) {   // exactly what was asked for, its end at the end of the mapping
+            // (FLOCKGPU_GUARD_SLACK = a substring: buffers whose name contains it keep the usual slack -- how the buffer behind a failing
+            // guarded run is found; FLOCKGPU_GUARD_TRACE: every (re)allocation on stderr)
+            const char *keep = exp_env("FLOCKGPU_GUARD_SLACK");
+            if (!(keep && strstr(name, keep))) want = bytes;
+            if (exp_env("FLOCKGPU_GUARD_TRACE")) fprintf(stderr, "[guard arena] %s %zu -> %zu\n", name, bytes, want);
+        }
+        hipError_t e = dev_alloc(ctx, &b.ptr, want);
         if (e != hipSuccess) {
             b.ptr = nullptr;
             return fail(ctx, FLOCKGPU_ERR_OOM, "arena '%s': hipMalloc(%zu) failed: %s", name, want, hipGetErrorString(e));
@@ -205,15 +246,6 @@ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // FLOCKGPU_ERR_INVALID when a call is already in flight; ctx_wait returns the call's status (FLOCKGPU_ERR_INVALID: none submitted).
 int ctx_submit(flockgpu_ctx *ctx, std::function<int()> fn);
 int ctx_wait(flockgpu_ctx *ctx);
-
-// Experiment knobs (A/B switches the tools/gpu_*.sh scripts flip through the environment) exist only in builds made with
-// -DFLOCKGPU_EXPERIMENTAL (`FLOCKGPU_BUILD_EXPERIMENTAL=1 python -m flock_amd.build`, which writes libflockgpu_experimental.so): the
-// shipped library never reads them, so no untested configuration is reachable from a production host's environment.
-#ifdef FLOCKGPU_EXPERIMENTAL
-inline const char *exp_env(const char *name) { return getenv(name); }
-#else
-inline const char *exp_env(const char *) { return nullptr; }
-#endif
 
 // Validates a window schedule against a relation of `rows` rows.
 inline int check_windows(flockgpu_ctx *ctx, const flockgpu_windows *w, int64_t rows, const char *what) {

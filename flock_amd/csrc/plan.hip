@@ -764,16 +764,17 @@ int grow(flockgpu_ctx *ctx, const std::string &key, size_t keep_bytes, size_t wa
     if (b.cap >= want_bytes && b.ptr) { *ptr = b.ptr; return FLOCKGPU_OK; }
     size_t cap = std::max<size_t>(want_bytes + want_bytes / 2, 1024);
     cap = (cap + 255) & ~size_t(255);
+    if (guard_arena()) cap = want_bytes;   // (experimental builds: exactly what was asked for, at the end of mapped memory)
     void *np = nullptr;
-    hipError_t e = hipMalloc(&np, cap);
+    hipError_t e = dev_alloc(ctx, &np, cap);
     if (e != hipSuccess) return fail(ctx, FLOCKGPU_ERR_OOM, "plan feed: hipMalloc(%zu): %s", cap, hipGetErrorString(e));
     if (b.ptr) {
         if (keep_bytes) {
             e = hipMemcpyAsync(np, b.ptr, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e != hipSuccess) { (void)hipFree(np); return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: grow copy: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) { dev_free(ctx, np); return fail(ctx, FLOCKGPU_ERR_HIP, "plan feed: grow copy: %s", hipGetErrorString(e)); }
         }
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(b.ptr);
+        dev_free(ctx, b.ptr);
     }
     b.ptr = np;
     b.cap = cap;
@@ -1972,7 +1973,7 @@ void flockgpu_plan_destroy(flockgpu_plan *plan) {
     snprintf(prefix, sizeof prefix, "plan%p.", (const void *)plan);
     for (auto it = ctx->arena.begin(); it != ctx->arena.end();) {
         if (it->first.compare(0, strlen(prefix), prefix) == 0) {
-            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            if (it->second.ptr) dev_free(ctx, it->second.ptr);
             it = ctx->arena.erase(it);
         } else {
             ++it;

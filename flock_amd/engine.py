@@ -408,6 +408,33 @@ class Comm:
 
 
 # ------------------------------------------------------------------ the context
+class GuardedBuffer:
+    """A device column in guarded memory (GpuContext.guarded): pointer, element count, numpy dtype."""
+
+    def __init__(self, ptr: int, count: int, dtype, owner=None):
+        self._ptr, self._count, self.dtype, self._owner = ptr, count, dtype, owner
+
+    def cpu(self):
+        """The buffer's contents as a host torch tensor (what the tests ask of a device tensor)."""
+        import torch
+        return torch.from_numpy(self._owner.d2h(self._ptr, self._count, self.dtype))
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def numel(self) -> int:
+        return self._count
+
+    def __len__(self) -> int:
+        return self._count
+
+    def __getitem__(self, key):   # contiguous slices only: a view of the same memory
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise TypeError("GuardedBuffer: contiguous slices only")
+        lo, hi, _ = key.indices(self._count)
+        return GuardedBuffer(self._ptr + lo * np.dtype(self.dtype).itemsize, max(hi - lo, 0), self.dtype, self._owner)
+
+
 class GpuContext:
     """Owns a `flockgpu_ctx`.  `stream` defaults to torch's current stream on `device`."""
 
@@ -454,6 +481,18 @@ class GpuContext:
         if count:
             self._check(self._lib.flockgpu_memcpy(self._h, out.ctypes.data_as(C.c_void_p), dev_ptr, out.nbytes, _ffi.D2H))
         return out
+
+    def guarded(self, host: np.ndarray) -> "GuardedBuffer":
+        """`host` copied into device memory that ENDS where mapped address space ends (flockgpu_malloc_guarded): a column placed
+        there turns a kernel's read past its end into a fault.  The object stands in for a device tensor wherever the engine only
+        asks for `data_ptr()` (the column structs); it lives until the ctx closes."""
+        host = np.ascontiguousarray(host)
+        p = C.c_void_p()
+        self._check(self._lib.flockgpu_malloc_guarded(self._h, max(host.nbytes, 1), C.byref(p)))
+        # (16-byte aligned start; up to 12 bytes of mapped slack behind a column whose size is not a multiple of 16)
+        if host.nbytes:
+            self._check(self._lib.flockgpu_memcpy(self._h, p, host.ctypes.data_as(C.c_void_p), host.nbytes, _ffi.H2D))
+        return GuardedBuffer(p.value, host.size, host.dtype, self)
 
     def profile(self, on: bool):
         self._check(self._lib.flockgpu_profile_enable(self._h, 1 if on else 0))

@@ -61,6 +61,13 @@ int flockgpu_malloc(flockgpu_ctx *ctx, size_t bytes, void **out_device_ptr);
 int flockgpu_free(flockgpu_ctx *ctx, void *device_ptr);
 /* Copies on the ctx stream and waits for completion. */
 int flockgpu_memcpy(flockgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int kind);
+/* Testing aid: device memory that ENDS where mapped address space ends (`bytes` rounded up to 16, placed at the tail of its own
+ * physical allocation; the address granule behind it is reserved and left unmapped).  A kernel that touches memory past the end of a
+ * column placed there faults -- with ordinary allocations it reads whatever lies next to it and nobody notices.  Freed with
+ * flockgpu_free_guarded (or with the ctx): the physical memory goes back, the address range stays reserved for the life of the
+ * process, so that no guarded address is ever handed out twice. */
+int flockgpu_malloc_guarded(flockgpu_ctx *ctx, size_t bytes, void **out_device_ptr);
+int flockgpu_free_guarded(flockgpu_ctx *ctx, void *device_ptr);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  When enabled, every kernel launch of
  * the ctx is bracketed by hipEvents on the ctx stream; totals are read back per kernel name. */

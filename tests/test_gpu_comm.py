@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _dev(a):
-    import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    from devmem import dev
+    return dev(a)          # (a torch tensor; guarded memory under FLOCK_TEST_GUARDED=1: tests/test_gpu_guard.py)
 
 
 def _utf8_dev(u):

@@ -19,8 +19,8 @@ def ctx():
 
 
 def _dev(a):
-    import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    from devmem import dev
+    return dev(a)          # (a torch tensor; guarded memory under FLOCK_TEST_GUARDED=1: tests/test_gpu_guard.py)
 
 
 def _utf8(u):
@@ -36,8 +36,9 @@ def _host_stream(seed, eps, seconds, first=0):
 
 
 def _gpu_stream(ctx, seed, eps, seconds, window, first=0):
+    from devmem import guard_stream
     from flock_amd import NEXMarkSource
-    return NEXMarkSource(seconds, eps, window, seed=seed, first_event_id=first).generate_data(ctx)
+    return guard_stream(NEXMarkSource(seconds, eps, window, seed=seed, first_event_id=first).generate_data(ctx))
 
 
 def _str_rows(off, data, rows=None):
@@ -285,8 +286,9 @@ def test_q7_ties_negatives_and_empty_windows(ctx):
 
 # ------------------------------------------------------------------ q4 / q9 ("next" queries: join + BETWEEN + MAX / AVG)
 def _gpu_stream_times(ctx, seed, eps, seconds, window):
+    from devmem import guard_stream
     from flock_amd import NEXMarkSource
-    return NEXMarkSource(seconds, eps, window, seed=seed).generate_data(ctx, relations=("bid", "auction"), auction_times=True)
+    return guard_stream(NEXMarkSource(seconds, eps, window, seed=seed).generate_data(ctx, relations=("bid", "auction"), auction_times=True))
 
 
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 5), (7, 5000, 4), (42, 50_000, 6), (5, 1_000_000, 2)])

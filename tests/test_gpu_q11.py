@@ -18,8 +18,8 @@ def ctx():
 
 
 def _dev(a):
-    import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    from devmem import dev
+    return dev(a)          # (a torch tensor; guarded memory under FLOCK_TEST_GUARDED=1: tests/test_gpu_guard.py)
 
 
 @pytest.mark.parametrize("n,lo,hi,seed", [(1, 5, 6, 0), (63, -3, 4, 1), (4096, 0, 1, 2), (4097, 1000, 1256, 3), (100_003, -70_000, 70_000, 4),
