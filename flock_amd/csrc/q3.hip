@@ -67,6 +67,13 @@ __device__ __forceinline__ uint64_t utf8_head8(const uint8_t *__restrict__ data,
     return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1));
 }
 
+// offsets[r], offsets[r + 1] through one 8-byte load (dword-aligned is all the hardware asks)
+__device__ __forceinline__ int2 load_off_pair_q3(const int32_t *__restrict__ off, int64_t r) {
+    int2 v;
+    __builtin_memcpy(&v, off + r, 8);
+    return v;
+}
+
 __device__ __forceinline__ bool lits_hit(uint64_t v, uint32_t len, const Utf8Lits &lits) {
     bool hit = false;
 #pragma unroll
@@ -608,6 +615,50 @@ __global__ __launch_bounds__(kInvertBlock) void q3_invert_window_kernel(const in
 
 // direct[0 .. info[0]) = -1 when info[2] says some slot is written by no person; the grid covers the arena's bound, workgroups past
 // the entries in use (or all of them, without gaps) leave at once
+// ---- GENERAL path, build side in LDS: one workgroup per window inserts the window's persons that pass the state filter into a multimap in
+// LDS (the same {key, head row} slots and `next[]` chains as the global build: hashtab.hpp) and streams the finished table out with
+// coalesced stores.  The global build was 1e7 compare-and-swaps on 240 MB of tables that a memset had to fill first (0.51 + 0.07 ms per 1e9
+// events); a window's table is a few thousand live slots -- LDS-sized.  `cap` <= kLdsBuildCap slots: the host's usual 1.5 slots per person
+// of the largest window when that fits, else kLdsBuildCap on the bet that the filter drops enough of them (NEXMark: half) -- a window
+// that does not fit raises `err` and the host builds in global memory with the full capacity.
+constexpr int kLdsBuildThreads = 1024;
+constexpr uint32_t kLdsBuildCap = 18432;   // 144 KB of the CU's 160
+__global__ __launch_bounds__(kLdsBuildThreads) void q3_build_window_lds_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ state_off,
+                                                                               const uint8_t *__restrict__ state_data, const int64_t *__restrict__ seg_off,
+                                                                               Utf8Lits lits, uint64_t *__restrict__ tables, uint32_t cap,
+                                                                               int32_t *__restrict__ next, uint32_t *err) {
+    __shared__ uint64_t s_tab[kLdsBuildCap];
+    const int32_t w = (int32_t)blockIdx.x;
+    const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
+    for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) s_tab[i] = kEmpty64;
+    __syncthreads();
+    constexpr int kPer = 4;   // rows of a thread in flight together
+    for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += (int64_t)kLdsBuildThreads * kPer) {
+        int32_t key[kPer], b[kPer];
+        uint32_t len[kPer];
+        uint64_t v[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
+            const bool in = r < hi;
+            const int2 o = load_off_pair_q3(state_off, in ? r : lo);
+            key[k] = p_id[in ? r : lo];
+            b[k] = o.x;
+            len[k] = in ? (uint32_t)(o.y - o.x) : 0xffffffffu;   // (a row past the window passes no literal)
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = utf8_head8(state_data, len[k] && len[k] <= 8 ? b[k] : 0, len[k] <= 8 ? len[k] : 0u);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
+            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert(s_tab, cap, next, key[k], (int32_t)r)) atomicOr(err, 1u);
+        }
+    }
+    __syncthreads();
+    uint64_t *dst = tables + (size_t)w * cap;
+    for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) dst[i] = s_tab[i];
+}
+
 __global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restrict__ direct, const uint64_t *__restrict__ info) {
     if (!info[2]) return;
     const uint64_t n = info[0] + 4;
@@ -1135,33 +1186,57 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         regime[0] = 0;
         const uint64_t cap64 = std::max<uint64_t>(64, (uint64_t)max_person_rows * 3 / 2 + 8);
         if (cap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: window too large for one table region");
-        const uint32_t cap = (uint32_t)cap64;
+        // build in LDS, one workgroup per window (q3_build_window_lds_kernel), while the tables fit -- or may fit once the state filter has
+        // dropped its share; a ctx whose last such bet was lost builds in global memory until its windows shrink
+        std::vector<int64_t> &lds_state = ctx->host_i64["q3.lds_build"];   // {rows of the largest window when a bet was lost}
+        if (lds_state.empty()) lds_state.push_back(0);
+        static const bool no_lds_build = exp_env("FLOCKGPU_Q3_NO_LDS_BUILD") != nullptr;   // (A/B knob)
+        bool lds_build = !no_lds_build && n_win > 0 && st_p.n_tiles > 0 && max_person_rows <= 2 * (int64_t)kLdsBuildCap &&
+                         (cap64 <= kLdsBuildCap || lds_state[0] == 0 || max_person_rows < lds_state[0]);
+        uint32_t cap = 0;
         uint64_t *tables = nullptr;
         int32_t *next = nullptr;
-        FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
         FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
-        FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
-        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-        if (st_p.n_tiles > 0) {
-            LaunchScope ls(ctx, "q3_build_kernel");
-            hipLaunchKernelGGL((q3_build_kernel<false, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
-                               person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, nullptr,
-                               tables, cap, next, d_err, build_y_shift, (WinTable *)nullptr);
+        for (;;) {
+            cap = lds_build ? (uint32_t)std::min<uint64_t>(cap64, kLdsBuildCap) : (uint32_t)cap64;
+            FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
+            FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+            if (lds_build) {
+                LaunchScope ls(ctx, "q3_build_kernel");
+                hipLaunchKernelGGL(q3_build_window_lds_kernel, dim3((unsigned)n_win), dim3(kLdsBuildThreads), 0, ctx->stream, person->p_id, person->state.offsets,
+                                   person->state.data, st_p.seg_off, lits, tables, cap, next, d_err);
+            } else {
+                FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
+                if (st_p.n_tiles > 0) {
+                    LaunchScope ls(ctx, "q3_build_kernel");
+                    hipLaunchKernelGGL((q3_build_kernel<false, false>), dim3((unsigned)st_p.n_tiles, 8u >> build_y_shift), dim3(kBlock), 0, ctx->stream,
+                                       person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, nullptr,
+                                       tables, cap, next, d_err, build_y_shift, (WinTable *)nullptr);
+                }
+            }
+            FG_TRY(check_launch(ctx, "q3_build_kernel"));
+            // (the bet's verdict arrives with the counts, in the call's usual synchronisation: a lost bet costs one count pass over garbage)
+            if (st_a.n_tiles > 0) {
+                LaunchScope ls(ctx, "q3_probe_count_kernel");
+                hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                                   auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
+                                   next, counts, nullptr, nullptr, nullptr, nullptr);
+            }
+            FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
+            FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
+            FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const bool overflow = *reinterpret_cast<uint32_t *>(h_off + n_win + 1) != 0;
+            if (overflow && lds_build && cap64 > kLdsBuildCap) {   // the bet was lost: the same sequence with the full-capacity tables in global memory
+                lds_state[0] = max_person_rows;
+                lds_build = false;
+                continue;
+            }
+            if (overflow) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
+            if (lds_build) lds_state[0] = 0;
+            break;
         }
-        FG_TRY(check_launch(ctx, "q3_build_kernel"));
-        if (st_a.n_tiles > 0) {
-            LaunchScope ls(ctx, "q3_probe_count_kernel");
-            hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
-                               auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
-                               next, counts, nullptr, nullptr, nullptr, nullptr);
-        }
-        FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
-        FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
-        FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
-        FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (*reinterpret_cast<uint32_t *>(h_off + n_win + 1))
-            return fail(ctx, FLOCKGPU_ERR_CAPACITY, "q3: build table overflow (cap %u)", cap);
         offs.assign(h_off, h_off + n_win + 1);
         n_pairs = (uint64_t)offs[n_win];
         if (n_pairs >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: join output exceeds 2^31 rows");

@@ -573,6 +573,43 @@ def test_q3_every_path_is_exact(ctx, case):
     assert total == len(out["a_id"]) and total > 1000
 
 
+def test_q3_hash_path_tables_built_in_lds_and_the_lost_bet():
+    """The hash path builds each window's multimap in LDS (one workgroup per window, q3_build_window_lds_kernel) and streams it out.
+    A window of up to 12 K persons gets its usual 1.5 slots per person; a larger one (up to 36 K) the LDS-sized table on the bet that
+    the state filter drops enough persons -- here first every person passes (20 K into 18 K slots: the bet is lost, the same call answers
+    from tables built in global memory), then the usual mix on the same ctx (no new bet at that size), then smaller windows (no bet
+    needed).  Sparse ids with duplicates on both sides, so only the hash path can answer."""
+    from flock_amd import Auctions, GpuContext, Persons, WindowSchedule
+    c = GpuContext(0)
+    rng = np.random.default_rng(23)
+    npn, na = 40_000, 150_000
+    p_id = _sorted_keys(rng, npn, 50_000)
+    p_id[5_000:5_040] = p_id[5_000]                                   # a 40-fold duplicate key on the build side
+    nm = [b"n%d" % (i % 911) for i in range(npn)]
+    name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32), np.frombuffer(b"".join(nm), np.uint8).copy())
+    seller = rng.choice(p_id, na).astype(np.int32)
+    category = rng.integers(10, 12, na).astype(np.int32)
+    a_id = (np.arange(na) * 3 + 1).astype(np.int32)
+    for states, edges in (([b"or"], [0, 20_000, npn]), ([b"or", b"wa", b"tx", b"id"], [0, 20_000, npn]), ([b"or", b"wa"], [0, 9_000, 20_000, 31_000, npn])):
+        st = rng.choice(np.array(states, dtype=object), npn)
+        state = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in st])]).astype(np.int32), np.frombuffer(b"".join(st), np.uint8).copy())
+        n_w = len(edges) - 1
+        a_edges = np.linspace(0, na, n_w + 1).astype(np.int64)
+        pw = WindowSchedule(np.array(edges), np.arange(n_w), np.arange(1, n_w + 1))
+        aw = WindowSchedule(a_edges, np.arange(n_w), np.arange(1, n_w + 1))
+        for _ in range(2):
+            out = c.q3_join(Auctions(_dev(a_id), _dev(seller), _dev(category), na), aw, Persons(_dev(p_id), _utf8(name), _utf8(name), _utf8(state), npn), pw).to_host()
+            off, total = out["offsets"], 0
+            for w in range(n_w):
+                (alo, ahi), (plo, phi) = aw.window_rows(w), pw.window_rows(w)
+                ar, pr = oracle.q3_join(seller[alo:ahi], category[alo:ahi], p_id[plo:phi], state.slice(plo, phi))
+                sl = slice(off[w], off[w + 1])
+                assert sorted(zip((out["auction_row"][sl] - alo).tolist(), (out["person_row"][sl] - plo).tolist())) == sorted(zip(ar.tolist(), pr.tolist())), (states, w)
+                total += len(ar)
+            assert total == len(out["a_id"]) > 1000
+    c.close()
+
+
 def test_q3_q8_follow_the_data_on_one_ctx(ctx):
     """The dense paths are speculated from what the previous call on the ctx saw (bit blocks / row table / general path, sizes of
     the Utf8 takes): after the hostile inputs above the same ctx must come back to exact answers on generator data, small then
