@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kLdsBuildThreads) void q3_build_window_lds_kernel(c
     const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
     for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) s_tab[i] = kEmpty64;
     __syncthreads();
-    constexpr int kPer = 4;   // rows of a thread in flight together
+    constexpr int kPer = 4;   // rows of a thread in flight together (8: no faster -- 0.228 vs 0.215 ms per 1000 windows of 2e4 persons)
     for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += (int64_t)kLdsBuildThreads * kPer) {
         int32_t key[kPer], b[kPer];
         uint32_t len[kPer];
