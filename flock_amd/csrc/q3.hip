@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void q3_build_kernel(const int32_t *__restr
                     }
                 }
                 if (kBits) nib |= (hit ? 1u : 0u) << (4 * (lane & 7) + j);
-            } else if (hit && !multimap_insert(tab, cap, next, key[it][j], (int32_t)r)) {
+            } else if (hit && !multimap_insert_marked(tab, cap, next, key[it][j], (int32_t)r)) {
                 atomicOr(err, 1u);
             }
         }
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
         int32_t sv[kFlagIters][4], cv[kFlagIters][4];   // (only row `it` is used: the whole tile in registers ran 10-20 % slower)
         load4_i32(seller, r0, n_rows, sv[it]);
         load4_i32(category, r0, n_rows, cv[it]);
-        int32_t head[4];
+        uint32_t head[4];   // the chain's first link: row | "has a successor" (hashtab.hpp); kNoHead: no partner
+        constexpr uint32_t kNoHead = 0xFFFFFFFFu;   // (never a link: row 2^31 - 1 does not exist)
         uint32_t slot[4];
         uint64_t first[4];
         bool need[4];
@@ -463,33 +464,40 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
         uint32_t mine = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            head[j] = -1;
+            head[j] = kNoHead;
             if (!need[j]) continue;
             uint64_t cur = first[j];
             uint32_t sl = slot[j];
             for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
                 if (cur == kEmpty64) break;
                 if ((int32_t)(cur >> 32) == sv[it][j]) {
-                    head[j] = (int32_t)(uint32_t)cur;
+                    head[j] = (uint32_t)cur;
                     break;
                 }
                 sl = (sl + 1 == cap) ? 0 : sl + 1;
                 cur = tab[sl];
             }
-            for (int32_t p = head[j]; p >= 0; p = next[p]) ++mine;
+            if (head[j] != kNoHead)
+                for (uint32_t c = head[j];; c = (uint32_t)next[c & kChainRow]) {
+                    ++mine;
+                    if (!(c & kChainMore)) break;
+                }
         }
         const uint32_t incl = wave_incl_scan_u32(mine);
         const uint32_t it_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (kEmit && it_total) {
             uint64_t p = pos + (incl - mine);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                for (int32_t q = head[j]; q >= 0; q = next[q]) {
+            for (int j = 0; j < 4; ++j) {
+                if (head[j] == kNoHead) continue;
+                for (uint32_t c = head[j];; c = (uint32_t)next[c & kChainRow]) {
                     out_auction_row[p] = (int32_t)(r0 + j);
-                    out_person_row[p] = q;
+                    out_person_row[p] = (int32_t)(c & kChainRow);
                     out_a_id[p] = a_id[r0 + j];
                     ++p;
+                    if (!(c & kChainMore)) break;
                 }
+            }
         }
         pos += it_total;
         wave_total += it_total;
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(kLdsBuildThreads) void q3_build_window_lds_kernel(c
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
-            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert(s_tab, cap, next, key[k], (int32_t)r)) atomicOr(err, 1u);
+            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert_marked(s_tab, cap, next, key[k], (int32_t)r)) atomicOr(err, 1u);
         }
     }
     __syncthreads();
