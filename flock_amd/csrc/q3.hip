@@ -428,10 +428,14 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
                                                                   uint32_t *counts, const uint64_t *__restrict__ tile_base,
                                                                   int32_t *__restrict__ out_auction_row,
                                                                   int32_t *__restrict__ out_person_row,
-                                                                  int32_t *__restrict__ out_a_id) {
+                                                                  int32_t *__restrict__ out_a_id, uint32_t *__restrict__ heads) {
+    // heads[tile * 8192 + position in the tile]: what the COUNT pass found for every row -- the first link of its partners' chain, or
+    // kNoHead -- so that the EMIT pass does not hash and probe again (it read seller, category and the tables a second time: 0.376 ms of
+    // random lookups per 6e7 auctions, against 0.24 GB written here and read there, both coalesced)
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
     const uint64_t *tab = tables + (size_t)tr.seg * cap;
+    uint32_t *tile_heads = heads + (size_t)tile * kFlagTile + flag_rel0();
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int64_t wbase = tr.tile_begin + flag_rel0();
     uint64_t pos = 0;
@@ -446,43 +450,51 @@ __global__ __launch_bounds__(kBlock) void q3_probe_general_kernel(const int32_t 
 #pragma unroll 1
     for (int it = 0; it < kFlagIters; ++it) {
         const int64_t r0 = wbase + it * 256;
-        int32_t sv[kFlagIters][4], cv[kFlagIters][4];   // (only row `it` is used: the whole tile in registers ran 10-20 % slower)
-        load4_i32(seller, r0, n_rows, sv[it]);
-        load4_i32(category, r0, n_rows, cv[it]);
         uint32_t head[4];   // the chain's first link: row | "has a successor" (hashtab.hpp); kNoHead: no partner
         constexpr uint32_t kNoHead = 0xFFFFFFFFu;   // (never a link: row 2^31 - 1 does not exist)
-        uint32_t slot[4];
-        uint64_t first[4];
-        bool need[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t r = r0 + j;
-            need[j] = r >= tr.lo && r < tr.hi && (int64_t)cv[it][j] == category_lit;
-            slot[j] = slot_of((uint32_t)sv[it][j], cap);
-            first[j] = tab[need[j] ? slot[j] : 0u];
-        }
         uint32_t mine = 0;
+        if (kEmit) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(tile_heads + it * 256);
+            head[0] = h.x; head[1] = h.y; head[2] = h.z; head[3] = h.w;
+        } else {
+            int32_t sv[kFlagIters][4], cv[kFlagIters][4];   // (only row `it` is used: the whole tile in registers ran 10-20 % slower)
+            load4_i32(seller, r0, n_rows, sv[it]);
+            load4_i32(category, r0, n_rows, cv[it]);
+            uint32_t slot[4];
+            uint64_t first[4];
+            bool need[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            head[j] = kNoHead;
-            if (!need[j]) continue;
-            uint64_t cur = first[j];
-            uint32_t sl = slot[j];
-            for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
-                if (cur == kEmpty64) break;
-                if ((int32_t)(cur >> 32) == sv[it][j]) {
-                    head[j] = (uint32_t)cur;
-                    break;
-                }
-                sl = (sl + 1 == cap) ? 0 : sl + 1;
-                cur = tab[sl];
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = r0 + j;
+                need[j] = r >= tr.lo && r < tr.hi && (int64_t)cv[it][j] == category_lit;
+                slot[j] = slot_of((uint32_t)sv[it][j], cap);
+                first[j] = tab[need[j] ? slot[j] : 0u];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                head[j] = kNoHead;
+                if (!need[j]) continue;
+                uint64_t cur = first[j];
+                uint32_t sl = slot[j];
+                for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
+                    if (cur == kEmpty64) break;
+                    if ((int32_t)(cur >> 32) == sv[it][j]) {
+                        head[j] = (uint32_t)cur;
+                        break;
+                    }
+                    sl = (sl + 1 == cap) ? 0 : sl + 1;
+                    cur = tab[sl];
+                }
+            }
+            *reinterpret_cast<uint4 *>(tile_heads + it * 256) = make_uint4(head[0], head[1], head[2], head[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
             if (head[j] != kNoHead)
                 for (uint32_t c = head[j];; c = (uint32_t)next[c & kChainRow]) {
                     ++mine;
                     if (!(c & kChainMore)) break;
                 }
-        }
         const uint32_t incl = wave_incl_scan_u32(mine);
         const uint32_t it_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (kEmit && it_total) {
@@ -1205,6 +1217,8 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         uint64_t *tables = nullptr;
         int32_t *next = nullptr;
         FG_TRY(arena_get_t(ctx, "q3.next", (size_t)person->rows + 1, &next));
+        uint32_t *heads = nullptr;   // per auction row (tile layout): the join partners the count pass found
+        FG_TRY(arena_get_t(ctx, "q3.heads", (size_t)std::max(st_a.n_tiles, 1) * kFlagTile, &heads));
         for (;;) {
             cap = lds_build ? (uint32_t)std::min<uint64_t>(cap64, kLdsBuildCap) : (uint32_t)cap64;
             FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
@@ -1228,7 +1242,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
                 LaunchScope ls(ctx, "q3_probe_count_kernel");
                 hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
                                    auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
-                                   next, counts, nullptr, nullptr, nullptr, nullptr);
+                                   next, counts, nullptr, nullptr, nullptr, nullptr, heads);
             }
             FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1255,7 +1269,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             LaunchScope ls(ctx, "q3_probe_emit_kernel");
             hipLaunchKernelGGL(q3_probe_general_kernel<true>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
                                auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
-                               next, counts, tile_base, o_ar, o_pr, o_aid);
+                               next, counts, tile_base, o_ar, o_pr, o_aid, heads);
         }
         FG_TRY(check_launch(ctx, "q3_probe_emit_kernel"));
         FG_TRY(gather_utf8_multi_begin(ctx, "q3.out_text", text_cols, 3, o_pr, (int64_t)n_pairs, &g_text));
