@@ -131,10 +131,13 @@ __global__ __launch_bounds__(kBlock) void group_init_kernel(int64_t *__restrict_
     }
 }
 // slot of `key` in an open-addressing table of `cap` (power of two) slots, claiming an empty one; -1: table full
+// (probing is cut off after kClaimProbes slots: in a table at most half full a longer run does not happen, and in one sized from a hint
+// that turned out too small -- group_by_key64_n -- it must end in "full", not in a walk over the whole table per row)
+constexpr uint64_t kClaimProbes = 4096;
 __device__ __forceinline__ int64_t claim_slot(int64_t *tk, uint64_t cap, int64_t key) {
     if (key == kEmptyKey) return (int64_t)cap;
     uint64_t s = mix64((uint64_t)key) & (cap - 1);
-    for (uint64_t probe = 0; probe < cap; ++probe) {
+    for (uint64_t probe = 0, lim = cap < kClaimProbes ? cap : kClaimProbes; probe < lim; ++probe) {
         int64_t cur = __hip_atomic_load(&tk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == kEmptyKey) {
             int64_t expected = kEmptyKey;
@@ -982,33 +985,44 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
         if (bad) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: accumulator over a column of the wrong type", name);
     }
     const int width = std::max(n_specs, 1);
-    const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
-    const int64_t slots = (int64_t)cap + 1;
+    // The table: two slots per row cannot overflow, but it is 2^25 slots of 20+ bytes for 9.2e6 rows that form 6e5 groups -- 0.2 ms to
+    // initialise and every probe a miss.  A name that has been here before is sized for three slots per group it had then (a streaming host
+    // sends window after window of the same shape); an overflow -- probing is cut off, claim_slot -- repeats the pass with four times the
+    // slots, up to the two per row that always hold.
+    const uint64_t full = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
+    std::vector<int64_t> &hint = ctx->host_i64[base + ".groups_hint"];   // {groups of the last call under this name + 1}
+    uint64_t cap = hint.empty() || hint[0] <= 0 ? full : std::min(full, pow2_at_least((uint64_t)std::max<int64_t>((hint[0] - 1) * 3, 1024)));
     int64_t *tk = nullptr;
     uint64_t *ta = nullptr;
     int32_t *tf = nullptr;
     uint8_t *live = nullptr;
     uint32_t *d_err = nullptr, *h_err = nullptr;
-    FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
-    FG_TRY(arena_get_t(ctx, (base + ".tan").c_str(), (size_t)slots * (size_t)width, &ta));
-    FG_TRY(arena_get_t(ctx, (base + ".tf").c_str(), (size_t)slots, &tf));
-    FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
-    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-    sp.seen = nullptr;
-    if (track) {
-        FG_TRY(arena_get_t(ctx, (base + ".seen").c_str(), (size_t)slots * (size_t)width, &sp.seen));
-        RELOPS_LAUNCH(ctx, "zero_u32_kernel", zero_u32_kernel, slots * width, sp.seen, slots * (int64_t)width);
-    }
-    RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
-    if (rows > 0) RELOPS_LAUNCH(ctx, "group_insert_n_kernel", group_insert_n_kernel, rows, keys, rows, sp, tk, ta, tf, cap, d_err);
-    RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
     int32_t *slot_rows = nullptr;
     int64_t n_groups = 0;
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
-    if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
+    for (;;) {
+        const int64_t slots = (int64_t)cap + 1;
+        FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
+        FG_TRY(arena_get_t(ctx, (base + ".tan").c_str(), (size_t)slots * (size_t)width, &ta));
+        FG_TRY(arena_get_t(ctx, (base + ".tf").c_str(), (size_t)slots, &tf));
+        FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
+        FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+        FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+        sp.seen = nullptr;
+        if (track) {
+            FG_TRY(arena_get_t(ctx, (base + ".seen").c_str(), (size_t)slots * (size_t)width, &sp.seen));
+            RELOPS_LAUNCH(ctx, "zero_u32_kernel", zero_u32_kernel, slots * width, sp.seen, slots * (int64_t)width);
+        }
+        RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
+        if (rows > 0) RELOPS_LAUNCH(ctx, "group_insert_n_kernel", group_insert_n_kernel, rows, keys, rows, sp, tk, ta, tf, cap, d_err);
+        RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
+        FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
+        if (!*h_err) break;
+        if (cap >= full) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
+        cap = std::min(full, cap * 4);
+    }
+    hint.assign(1, n_groups + 1);
     int64_t *ok = nullptr;
     int32_t *of = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".ok").c_str(), (size_t)n_groups + 2, &ok));

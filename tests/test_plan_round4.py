@@ -472,6 +472,26 @@ def test_aggregates_skip_nulls_and_group_null_keys(gpu, n, chunk):
 
 
 @pytest.mark.gpu
+def test_group_table_sized_from_the_last_call_regrows_when_the_groups_multiply(gpu):
+    """The generic GROUP BY sizes its table for three slots per group of the plan's PREVIOUS execute (relops.hip group_by_key64_n): the same
+    plan sees 7 groups, then 90 000 (the hinted table overflows; the pass is repeated with more slots, twice), then 7 again, then skewed
+    keys (most rows share one key: the wave-level reduction of that key) -- every answer equals the oracle."""
+    from flock_amd.runtime import ExecutionContext, collect
+    aggs = [("count", None, "UInt64"), ("sum", "v", "Int64"), ("max", "v", "Int64"), ("min", "f", "Float64")]
+    ctx = ExecutionContext([_agg_plan(aggs)], gpu=gpu)
+    r = np.random.default_rng(3)
+    for n, n_keys, hot in ((3_000, 7, 0.0), (200_000, 90_000, 0.0), (3_000, 7, 0.0), (150_000, 5_000, 0.7), (150_000, 5_000, 0.0)):
+        k = r.integers(0, n_keys, n)
+        k[r.random(n) < hot] = 42
+        t = {"k": [int(x) for x in k], "v": [int(x) for x in r.integers(-1000, 1000, n)], "f": [float(x) for x in np.round(r.normal(0, 50, n))], "s": ["x"] * n}
+        rb = collect(ctx, [[_null_batches(t, 70_000)]])[0][0]
+        want = g.hash_aggregate_exec(t, ["k"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+        assert sorted(_pyrows(rb)) == sorted(g.rows(want)), (n, n_keys, hot)
+        assert rb.num_rows == len(set(t["k"]))
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_filter_projection_and_sort_carry_nulls(gpu):
     """A NULL comparison keeps no row -- under OR, too (NULL OR TRUE is TRUE) --, NULLs in projected columns come back as NULLs, and
     ORDER BY places them where the plan's SortOptions say."""
