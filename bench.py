@@ -77,7 +77,7 @@ def parse():
                          "inside libflockgpu as the headline; auto = windows, with the exchange attached as `exchange` at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
-    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -986,6 +986,55 @@ def plan_collect_pcie(gpu, eps, steps):
     return out
 
 
+def plan_generic(gpu, eps, steps):
+    """What a plan WITHOUT a fused pipeline costs: the whole-query plans of q3 / q5 / q8 through `collect` on the generic operators
+    (`FLOCKGPU_PLAN_GENERIC_ONLY`: relops.hip -- filter, projection, hash join, the three-level GROUP BY) against the same plans on their
+    fused pipelines, one window each (q3 one epoch, q5 / q8 ten) at `eps` events/s, host Arrow batches in and out.  `value` counts q5's
+    bids per second on the generic operators; `generic_over_fused` is the worst ratio of the three."""
+    import numpy as np
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext, collect
+    out, worst = {}, 0.0
+    for q, seconds in ((3, 1), (5, 10), (8, 10)):
+        plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", f"q{q}.json")))
+        g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=11).generate_data(gpu)
+
+        def utf8(u, n):
+            off = u.offsets.cpu().numpy()[: n + 1]
+            return pa.StringArray.from_buffers(n, pa.py_buffer(off.tobytes()), pa.py_buffer(u.data.cpu().numpy()[: int(off[-1])].tobytes()))
+        if q == 5:
+            b = g.bids
+            rel = [pa.record_batch([pa.array(b.auction.cpu().numpy()), pa.array(b.bidder.cpu().numpy()), pa.array(b.price.cpu().numpy()),
+                                    pa.array(b.b_date_time.cpu().numpy()).cast(pa.timestamp("ms"))], names=["auction", "bidder", "price", "b_date_time"])]
+        else:
+            a, p = g.auctions, g.persons
+            ra = pa.record_batch([pa.array(a.a_id.cpu().numpy()), pa.array(a.seller.cpu().numpy()), pa.array(a.category.cpu().numpy())], names=["a_id", "seller", "category"])
+            rp = pa.record_batch([pa.array(p.p_id.cpu().numpy()), utf8(p.name, p.rows), utf8(p.city, p.rows), utf8(p.state, p.rows)], names=["p_id", "name", "city", "state"])
+            rel = [ra, rp] if q == 3 else [rp, ra]
+        rows = sum(r.num_rows for r in rel)
+        src = [[[rb]] for rb in rel]
+        e = {"input_rows": int(rows)}
+        for mode in ("fused", "generic"):
+            ctx = ExecutionContext([plan], gpu=gpu, generic_only=(mode == "generic"))
+            n = sum(b.num_rows for b in collect(ctx, src)[0])
+            collect(ctx, src)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                collect(ctx, src)
+            e[mode + "_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+            e[mode + "_result_rows"] = int(n)
+            ctx.close()
+        if e["fused_result_rows"] != e["generic_result_rows"]:
+            raise RuntimeError(f"q{q}: the generic operators return {e['generic_result_rows']} rows, the fused pipeline {e['fused_result_rows']}")
+        e["generic_over_fused"] = round(e["generic_ms"] / e["fused_ms"], 2)
+        worst = max(worst, e["generic_over_fused"])
+        out[f"q{q}"] = e
+    out.update({"value": round(out["q5"]["input_rows"] / (out["q5"]["generic_ms"] * 1e-3), 1), "unit": "rows/s", "ms_per_step": out["q5"]["generic_ms"],
+                "generic_over_fused": worst, "note": "value / ms_per_step: q5's window on the generic operators (PCIe upload included, as in plan_collect_pcie)"})
+    return out
+
+
 def plan_stages(gpu, eps, steps):
     """The reference's distributed mode through the plan ABI: q3 / q5 / q8 cut into their stage plans (flock_amd.stages.build_query_dag =
     flock/src/distributed_plan/stage.rs:269-367), every stage a function group with 8 hash partitions, run in one process
@@ -1225,6 +1274,8 @@ def final_line(out):
             if "sync_ms_per_step" in e:                  # two calls in flight: [rows/s, ms per call, -, ms per call one at a time]
                 return [_sig(float(e["value"])), e.get("ms_per_step"), None, e["sync_ms_per_step"]]
             r = e.get("roofline") or {}
+            if "generic_over_fused" in e:                # plans on the generic operators: [q5 rows/s, q5 ms per window, -, worst generic / fused]
+                return [_sig(float(e["value"])), e.get("ms_per_step"), None, e["generic_over_fused"]]
             return [_sig(float(e["value"])), e.get("ms_per_step"), r.get("frac")]
         for k, e in also.items():
             if k == "exchange_1rank" and isinstance(e, dict) and "error" not in e:
@@ -1293,7 +1344,7 @@ def main():
         n = max(args.steps, 3)
         e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True),
              "plan_stages": lambda: plan_stages(g, args.eps, n), "plan_collect": lambda: plan_collect_pcie(g, args.eps, max(n, 5)),
-             "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps)}[args.only_side]()
+             "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps), "plan_generic": lambda: plan_generic(g, args.eps, n)}[args.only_side]()
         print(json.dumps(e))
         return
     if args.only_general:
@@ -1508,7 +1559,8 @@ def main():
                           ("ysb_next", lambda: ysb_side(ctx, args.eps, steps2, args.no_cpu, args.cpu_threads)),
                           ("q5_pcie_inclusive", lambda: pcie_inclusive_q5(ctx, args.eps)),
                           ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2)),
-                          ("plan_stages", lambda: plan_stages(ctx, args.eps, 5))):
+                          ("plan_stages", lambda: plan_stages(ctx, args.eps, 5)),
+                          ("plan_generic", lambda: plan_generic(ctx, args.eps, 10))):
             try:
                 also[label] = fn()
             except Exception as e:
