@@ -1514,22 +1514,25 @@ struct Exec {
         const TCol &k = in.cols[(size_t)n->group[0]];
         int64_t *keys = nullptr;
         // NULL group keys form ONE group (DataFusion groups NULLs together): an Int32 key column widened to 64 bits has room for a value
-        // no Int32 takes; other key types with NULLs are handed back
+        // no Int32 takes, and so have a Utf8 column's dictionary codes (row numbers); other key types with NULLs are handed back
         constexpr int64_t kNullKey = int64_t(1) << 40;
         const bool null_keys = k.c.valid != nullptr;
-        if (null_keys && (pair || k.c.type != ColType::I32))
-            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 column");
+        if (null_keys && (pair || (k.c.type != ColType::I32 && k.c.type != ColType::UTF8)))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 or Utf8 column");
         if (pair) {
             const TCol &k2 = in.cols[(size_t)n->group[1]];
             if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
-            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 column");
+            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 or Utf8 column");
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
             FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
         } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
             if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
             FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), k.c, in.rows, keys, nullptr, 0, nullptr));
+            // (a NULL's bytes are whatever its slot holds -- usually nothing, which is also the empty string's code: NULLs get their own key;
+            // the group's key comes out NULL through the validity of its first row, take_column below)
+            if (null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
         } else {
             if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
             FG_TRY(key_i64(n, k, in.rows, "gk", &keys));

@@ -472,6 +472,34 @@ def test_aggregates_skip_nulls_and_group_null_keys(gpu, n, chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,chunk", [(60, 60), (9_000, 2_100)])
+def test_null_utf8_group_keys_form_one_group(gpu, n, chunk):
+    """GROUP BY a Utf8 column that holds NULLs: the NULLs are ONE group -- not the empty string's, which the table also holds -- and the
+    group's key comes back NULL."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = _null_table(n, 19)
+    t["s"] = [None if s is None else ("" if s == "s3" else s) for s in t["s"]]          # real empty strings next to the NULLs
+    aggs = [("count", None, "UInt64"), ("max", "v", "Int64"), ("count", "v", "UInt64")]
+    def expr(fn, col, dt):
+        arg = _c(col) if col else {"physical_expr": "literal", "value": {"UInt8": 1}}
+        return {"aggregate_expr": fn, "name": "%s(%s)" % (fn.upper(), col or "UInt8(1)"), "data_type": dt, "nullable": True, "expr": arg}
+    ae = [expr(*a) for a in aggs]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[_c("s"), "s"]], "aggr_expr": ae, "input": _scan(),
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[{"physical_expr": "column", "name": "s", "index": 0}], 4]}}
+    plan = {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[{"physical_expr": "column", "name": "s", "index": 0}, "s"]],
+            "aggr_expr": ae, "input": {"execution_plan": "coalesce_batches_exec", "input": rep, "target_batch_size": 4096},
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    ctx = ExecutionContext([plan], gpu=gpu)
+    rb = collect(ctx, [[_null_batches(t, chunk)]])[0][0]
+    ctx.close()
+    want = g.hash_aggregate_exec(t, ["s"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+    key = lambda r: (r[0] is None, r[0] or "")
+    assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key)
+    assert sum(r[0] is None for r in _pyrows(rb)) == 1 and any(r[0] == "" for r in _pyrows(rb))
+
+
+@pytest.mark.gpu
 def test_group_table_sized_from_the_last_call_regrows_when_the_groups_multiply(gpu):
     """The generic GROUP BY sizes its table for three slots per group of the plan's PREVIOUS execute (relops.hip group_by_key64_n): the same
     plan sees 7 groups, then 90 000 (the hinted table overflows; the pass is repeated with more slots, twice), then 7 again, then skewed
