@@ -1517,13 +1517,14 @@ struct Exec {
         // no Int32 takes, and so have a Utf8 column's dictionary codes (row numbers); other key types with NULLs are handed back
         constexpr int64_t kNullKey = int64_t(1) << 40;
         const bool null_keys = k.c.valid != nullptr;
-        if (null_keys && (pair || (k.c.type != ColType::I32 && k.c.type != ColType::UTF8)))
-            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 or Utf8 column");
+        // ... and a 64-bit key (Int64 / UInt64 / Timestamp) hands its validity to the GROUP BY itself, which keeps the NULLs in a slot of their own
+        const bool wide_null_keys = null_keys && !pair && k.c.type != ColType::I32 && k.c.type != ColType::UTF8 && k.c.type != ColType::F64;
+        if (null_keys && pair) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a two-column GROUP BY key");
         if (pair) {
             const TCol &k2 = in.cols[(size_t)n->group[1]];
             if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
-            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a GROUP BY key other than one Int32 or Utf8 column");
+            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a two-column GROUP BY key");
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
             FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
         } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
@@ -1536,7 +1537,7 @@ struct Exec {
         } else {
             if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
             FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
-            if (null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
+            if (null_keys && !wide_null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
         }
         AggSpec specs[kMaxGroupAggs];
         int n_specs = 0;
@@ -1589,7 +1590,7 @@ struct Exec {
             outs.push_back(o);
         }
         GroupResultN g;
-        FG_TRY(group_by_key64_n(ctx, node_key(pl, n, "grp").c_str(), keys, in.rows, specs, n_specs, &g));
+        FG_TRY(group_by_key64_n(ctx, node_key(pl, n, "grp").c_str(), keys, in.rows, specs, n_specs, &g, wide_null_keys ? k.c.valid : nullptr));
         t->rows = g.n_groups;
         // ---- key columns
         if (pair) {
@@ -1616,6 +1617,7 @@ struct Exec {
             }
         } else {
             t->cols[0] = dev_col(k.c.type, g.keys, nullptr, 0, k.c.is_ts);
+            if (wide_null_keys) t->cols[0].c.valid = g.key_valid;
         }
         t->cols[0].c.nullable = n->schema[0].nullable;
         // ---- aggregate / state columns

@@ -272,9 +272,11 @@ struct GroupTable {
     int32_t *tf;
     uint64_t cap;
     uint32_t *err;
+    const uint8_t *key_valid;   // null: no NULL keys; else the rows whose key is NULL share ONE group, slot cap + 1 (slot cap: the key INT64_MIN)
 };
-__device__ __forceinline__ void group_update_global(const GroupTable &g, const AggSpecs &sp, int64_t key, int32_t first, const uint64_t *val, const uint32_t *cnt) {
-    const int64_t s = claim_slot(g.tk, g.cap, key);
+__device__ __forceinline__ void group_update_global(const GroupTable &g, const AggSpecs &sp, int64_t key, bool key_null, int32_t first, const uint64_t *val,
+                                                    const uint32_t *cnt) {
+    const int64_t s = key_null ? (int64_t)g.cap + 1 : claim_slot(g.tk, g.cap, key);
     if (s < 0) {
         atomicOr(g.err, 1u);
         return;
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
         __syncthreads();
     }
     // a partial -- one row or a wave's reduction -- goes into the workgroup's table when it finds room there, else to the global one
-    auto update = [&](int64_t key, int32_t first, const uint64_t *val, const uint32_t *cnt) {
-        if (kLds && key != kEmptyKey) {
+    auto update = [&](int64_t key, bool key_null, int32_t first, const uint64_t *val, const uint32_t *cnt) {
+        if (kLds && key != kEmptyKey && !key_null) {
             uint32_t s = (uint32_t)mix64((uint64_t)key) & (lds_slots - 1);
             for (int probe = 0; probe < kLdsGroupProbes; ++probe) {
                 int64_t cur = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
                 s = (s + 1) & (lds_slots - 1);
             }
         }
-        group_update_global(g, sp, key, first, val, cnt);
+        group_update_global(g, sp, key, key_null, first, val, cnt);
     };
     const int64_t lo = kLds ? (int64_t)blockIdx.x * rows_per_wg : 0, hi = kLds ? (lo + rows_per_wg < n ? lo + rows_per_wg : n) : n;
     const int64_t start = kLds ? lo + (threadIdx.x & ~63) : (int64_t)blockIdx.x * kBlock + (threadIdx.x & ~63);
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
     for (int64_t base = start; base < hi; base += stride) {   // (wave-uniform)
         const int64_t i = base + lane;
         const bool live = i < hi;
-        const int64_t key = live ? keys[i] : 0;
+        const bool knull = live && g.key_valid && !g.key_valid[i];
+        const int64_t key = live && !knull ? keys[i] : 0;   // (a NULL's key bits mean nothing: all NULLs are one key)
         uint64_t val[kMaxGroupAggs];
         uint32_t cnt[kMaxGroupAggs];
         for (int a = 0; a < sp.n; ++a) {
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
             val[a] = ok ? agg_row_value(sp.op[a], sp, a, i) : agg_identity(sp.op[a]);
         }
         const int64_t k0 = (int64_t)wave_bcast_u64((uint64_t)key, 0);   // (lane 0 is live: base < hi)
-        const uint64_t same = __ballot(live && key == k0);
+        const bool knull0 = __builtin_amdgcn_readlane((int)knull, 0) != 0;
+        const uint64_t same = __ballot(live && key == k0 && knull == knull0);
         const bool combine = __popcll((unsigned long long)same) >= kCombineMin;
         const bool in_group = combine && ((same >> lane) & 1);
         if (combine) {   // the rows that share the first row's key: one partial, carried on by lane 0 (which holds the smallest row number)
@@ -360,9 +364,9 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
                 gv[a] = v;
                 gc[a] = (uint32_t)__popcll((unsigned long long)__ballot(in_group && cnt[a]));
             }
-            if (lane == 0) update(k0, (int32_t)i, gv, gc);
+            if (lane == 0) update(k0, knull0, (int32_t)i, gv, gc);
         }
-        if (live && !in_group) update(key, (int32_t)i, val, cnt);
+        if (live && !in_group) update(key, knull, (int32_t)i, val, cnt);
     }
     if (!kLds) return;
     __syncthreads();
@@ -375,8 +379,13 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
             val[a] = s_acc[s * sp.n + a];
             cnt[a] = s_seen[s * sp.n + a];
         }
-        group_update_global(g, sp, key, s_first[s], val, cnt);
+        group_update_global(g, sp, key, false, s_first[s], val, cnt);
     }
+}
+// key_valid[g] = 0 for the group that sits in slot `null_slot` (the NULL keys' group)
+__global__ __launch_bounds__(kBlock) void key_valid_from_slot_kernel(const int32_t *__restrict__ slot_rows, int64_t n_groups, int32_t null_slot,
+                                                                     uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_groups; i += (int64_t)gridDim.x * kBlock) out[i] = slot_rows[i] != null_slot ? 1 : 0;
 }
 // out[a][g] = ta[slot_rows[g] * n + a]
 struct AggOuts {
@@ -1014,7 +1023,7 @@ int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, con
 }
 
 int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
-                     GroupResultN *out) {
+                     GroupResultN *out, const uint8_t *key_valid) {
     *out = GroupResultN{};
     const std::string base = name;
     if (n_specs < 0 || n_specs > kMaxGroupAggs) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than %d accumulators per group", name, kMaxGroupAggs);
@@ -1050,7 +1059,7 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
     int32_t *slot_rows = nullptr;
     int64_t n_groups = 0;
     for (;;) {
-        const int64_t slots = (int64_t)cap + 1;
+        const int64_t slots = (int64_t)cap + 2;   // + the key INT64_MIN's slot + the NULL keys' slot
         FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
         FG_TRY(arena_get_t(ctx, (base + ".tan").c_str(), (size_t)slots * (size_t)width, &ta));
         FG_TRY(arena_get_t(ctx, (base + ".tf").c_str(), (size_t)slots, &tf));
@@ -1066,7 +1075,7 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
         RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
         if (rows > 0) {
             // the workgroup-level table (LDS): 2048 slots for one or two accumulators, 1024 beyond; four rows per slot
-            const GroupTable gt{tk, ta, tf, cap, d_err};
+            const GroupTable gt{tk, ta, tf, cap, d_err, key_valid};
             const uint32_t lds_slots = width <= 2 ? 2048u : 1024u;
             const size_t lds_bytes = (size_t)lds_slots * (8 + 8 * (size_t)sp.n + 4 + 4 * (size_t)sp.n);
             const int64_t rows_per_wg = (int64_t)lds_slots * 4;   // (NEXMark bids by auction: ~110 + 0.065 x rows distinct keys per run of rows; 16 / 8 / 4 rows per slot: 1.38 / 0.67 / 0.54 ms per 9.2e6 bids)
@@ -1103,6 +1112,13 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
         }
     }
     if (n_specs > 0 && n_groups > 0) RELOPS_LAUNCH(ctx, "group_collect_n_kernel", group_collect_n_kernel, n_groups, ta, slot_rows, n_groups, sp, o);
+    if (key_valid) {
+        if (cap + 1 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: group table too large for NULL keys", name);
+        uint8_t *kv = nullptr;
+        FG_TRY(arena_get_t(ctx, (base + ".okv").c_str(), (size_t)n_groups + 16, &kv));
+        if (n_groups > 0) RELOPS_LAUNCH(ctx, "key_valid_from_slot_kernel", key_valid_from_slot_kernel, n_groups, slot_rows, n_groups, (int32_t)(cap + 1), kv);
+        out->key_valid = kv;
+    }
     out->n_groups = n_groups;
     out->keys = ok;
     out->first_row = of;

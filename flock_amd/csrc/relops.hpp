@@ -92,9 +92,11 @@ struct GroupResultN {
     uint64_t *agg[kMaxGroupAggs] = {};  // 64-bit patterns: int64 / uint64 / double by AggOp
     uint8_t *agg_valid[kMaxGroupAggs] = {};  // per group: 1 when a valid value reached accumulator a; null when its spec carried no validity
     int32_t *first_row = nullptr;
+    uint8_t *key_valid = nullptr;   // per group, when the call was given key validity: 0 for the NULL keys' group
 };
+// key_valid (may be null): rows whose key is NULL -- whatever their key bits -- form one group of their own
 int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
-                     GroupResultN *out);
+                     GroupResultN *out, const uint8_t *key_valid = nullptr);
 // ---- Utf8 keys (YSB joins and groups on UUID strings, flock/src/distributed_plan/planner.rs:298-346)
 // out[i] = 64-bit hash of row i's bytes: equal strings -> equal keys (enough for a hash repartition; NOT an equality test)
 int hash_utf8_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);

@@ -118,10 +118,10 @@ int flockgpu_plan_output_partitions(const flockgpu_plan *plan);
  * only compared under AND -- is left out at the feed; every other column that holds NULLs travels with one validity byte per
  * row and the device operators honour it the way DataFusion's do: a comparison with NULL
  * keeps no row (through OR, too), COUNT(col) counts the non-NULL values, MIN / MAX / SUM / AVG skip NULLs and are NULL over
- * nothing but NULLs, NULL values of an Int32 or Utf8 GROUP BY key form one group, ORDER BY places NULLs by the plan's `nulls_first`,
+ * nothing but NULLs, NULL values of a GROUP BY key column form one group, ORDER BY places NULLs by the plan's `nulls_first`,
  * NULLs in projected / joined-along columns come back as NULLs (validity bitmap + null_count on the exported arrays).  The fused
  * NEXMark pipelines read plain columns: an invocation whose leaf holds such NULLs runs on the generic operators.  Handed back
- * as FLOCKGPU_ERR_UNSUPPORTED at execute: NULLs in a GROUP BY key of another type (Int64 / Timestamp / two columns), in DISTINCT
+ * as FLOCKGPU_ERR_UNSUPPORTED at execute: NULLs in a two-column GROUP BY key, in DISTINCT
  * columns, in a computed join key; FLOCKGPU_ERR_UNSUPPORTED at feed: such NULLs on a plan with an open pane ring. */
 int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema,
                        const struct ArrowArray *const *batches, int n_batches);

@@ -500,6 +500,36 @@ def test_null_utf8_group_keys_form_one_group(gpu, n, chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,chunk", [(50, 50), (7_000, 1_900), (80_000, 80_000)])
+def test_null_int64_group_keys_form_one_group(gpu, n, chunk):
+    """GROUP BY an Int64 column that holds NULLs: no 64-bit value is free to stand for NULL, so the GROUP BY keeps the NULL keys in a slot
+    of their own (relops.hip: key validity into group_by_key64_n) -- next to the key INT64_MIN, which has its own, too."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = _null_table(n, 29)
+    t["v"] = [None if v is None else (-2**63 if v == 7 else (2**63 - 1 if v == 8 else v % 11)) for v in t["v"]]     # few groups, both extremes among them
+    aggs = [("count", None, "UInt64"), ("max", "k", "Int32"), ("count", "k", "UInt64"), ("min", "f", "Float64")]
+    def expr(fn, col, dt):
+        arg = _c(col) if col else {"physical_expr": "literal", "value": {"UInt8": 1}}
+        return {"aggregate_expr": fn, "name": "%s(%s)" % (fn.upper(), col or "UInt8(1)"), "data_type": dt, "nullable": True, "expr": arg}
+    ae = [expr(*a) for a in aggs]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[_c("v"), "v"]], "aggr_expr": ae, "input": _scan(),
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[{"physical_expr": "column", "name": "v", "index": 0}], 4]}}
+    plan = {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[{"physical_expr": "column", "name": "v", "index": 0}, "v"]],
+            "aggr_expr": ae, "input": {"execution_plan": "coalesce_batches_exec", "input": rep, "target_batch_size": 4096},
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    ctx = ExecutionContext([plan], gpu=gpu)
+    rb = collect(ctx, [[_null_batches(t, chunk)]])[0][0]
+    ctx.close()
+    want = g.hash_aggregate_exec(t, ["v"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+    key = lambda r: (r[0] is None, r[0] or 0)
+    assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key)
+    assert sum(r[0] is None for r in _pyrows(rb)) == 1
+    if n > 1000:
+        assert any(r[0] == -2**63 for r in _pyrows(rb)) and any(r[0] == 2**63 - 1 for r in _pyrows(rb))
+
+
+@pytest.mark.gpu
 def test_group_table_sized_from_the_last_call_regrows_when_the_groups_multiply(gpu):
     """The generic GROUP BY sizes its table for three slots per group of the plan's PREVIOUS execute (relops.hip group_by_key64_n): the same
     plan sees 7 groups, then 90 000 (the hinted table overflows; the pass is repeated with more slots, twice), then 7 again, then skewed
