@@ -2089,8 +2089,8 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
             // global aggregate) the row is left out here; everywhere else the column travels with a validity byte per row and the
             // operators honour it (NULLs skipped by COUNT(col) / MIN / MAX / SUM / AVG, one group for NULL keys, NULLs in the output)
             if (!lf.null_droppable[c]) {
-                if (plan->ring_ppw)
-                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs that reach the output; the pane ring retains no validity", lf.schema[c].name.c_str());
+                if (plan->ring_ppw && plan->ring_q5)   // (q5's ring keeps Partial COUNT groups of plain columns; the rows ring carries validity along)
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: column '%s' holds NULLs that reach the output; q5's pane ring keeps no validity", lf.schema[c].name.c_str());
                 with_valid[(size_t)b * lf.schema.size() + c] = 1;
                 continue;
             }
@@ -2139,7 +2139,16 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
             FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "val"), (size_t)ld.rows * w, (size_t)(ld.rows + add_rows) * w + 16, &p));
             dc.values = p;
         }
+        // a column that already carries validity keeps room for every row of the leaf: the scan fills the rows fed after the last NULL with
+        // "valid" up to the leaf's row count (a batch without NULLs behind one with NULLs wrote past the validity buffer before: refused by
+        // the runtime as an invalid memset, found by the rows ring's exactly-sized buffers)
+        if (dc.valid && dc.valid_rows > 0) {
+            void *vp = nullptr;
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)(ld.rows + add_rows) + 64, &vp));
+            dc.valid = static_cast<uint8_t *>(vp);
+        }
     }
+    const int64_t rows_end = ld.rows + add_rows;   // the leaf's rows once this feed is in
     std::vector<uint8_t> tmp_vals, tmp_bytes;
     std::vector<int32_t> tmp_off;
     struct Rebase { int32_t *data; int64_t n; int32_t delta; };
@@ -2161,7 +2170,7 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
                 if (filt) for (int64_t i : k) vb.push_back((bits[(off + i) >> 3] >> ((off + i) & 7)) & 1);
                 else for (int64_t i = 0; i < n; ++i) vb.push_back((bits[(off + i) >> 3] >> ((off + i) & 7)) & 1);
                 void *vp = nullptr;
-                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)(ld.rows + (int64_t)vb.size()) + 64, &vp));
+                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)rows_end + 64, &vp));   // (room for every row of this feed)
                 dc.valid = static_cast<uint8_t *>(vp);
                 if (dc.valid_rows < ld.rows) FG_HIP(ctx, hipMemsetAsync(dc.valid + dc.valid_rows, 1, (size_t)(ld.rows - dc.valid_rows), ctx->stream));
                 FG_TRY(h2d(plan, dc.valid + ld.rows, vb.data(), vb.size()));
@@ -2227,10 +2236,11 @@ int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema 
 // only: what the next pane adds is the feed's business (grow), so in the steady state both twins have reached the size two panes need and
 // nothing is allocated.  (Asking for the current buffer's capacity made every window reallocate: the arena over-allocates by an eighth when
 // it grows, so each twin was always an eighth smaller than the other -- 0.39 ms of hipFree + hipMalloc per window, growing without bound.)
-static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *src, size_t keep_bytes, size_t /*cap_bytes*/, void **out) {
+// (min_bytes: room the twin must have beyond what is kept -- a validity column is written up to the leaf's row count when it is scanned)
+static int ring_swap_in(flockgpu_ctx *ctx, const std::string &key, const void *src, size_t keep_bytes, size_t min_bytes, void **out) {
     const std::string alt = key + ".alt";
     void *p = nullptr;
-    FG_TRY(arena_get(ctx, alt.c_str(), std::max<size_t>(keep_bytes, 64), &p));
+    FG_TRY(arena_get(ctx, alt.c_str(), std::max<size_t>(std::max(keep_bytes, min_bytes), 64), &p));
     if (keep_bytes) FG_HIP(ctx, hipMemcpyAsync(p, src, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     std::swap(ctx->arena[key], ctx->arena[alt]);
     *out = p;
@@ -2246,9 +2256,8 @@ static int ring_drop_oldest(flockgpu_plan *plan) {
         for (int64_t g : plan->ring_groups) total += g;
         if (d && total > d) {
             void *a = nullptr, *c = nullptr;
-            const size_t cap = ctx->arena[leaf_key(plan, 0, 0, "ring.q5a")].cap;
-            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5a"), plan->ring_auction + d, (size_t)(total - d) * 4, cap, &a));
-            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5c"), plan->ring_count + d, (size_t)(total - d) * 4, cap, &c));
+            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5a"), plan->ring_auction + d, (size_t)(total - d) * 4, 0, &a));
+            FG_TRY(ring_swap_in(ctx, leaf_key(plan, 0, 0, "ring.q5c"), plan->ring_count + d, (size_t)(total - d) * 4, 0, &c));
             plan->ring_auction = static_cast<int32_t *>(a);
             plan->ring_count = static_cast<uint32_t *>(c);
         }
@@ -2263,13 +2272,21 @@ static int ring_drop_oldest(flockgpu_plan *plan) {
         for (size_t c = 0; c < ld.cols.size(); ++c) {
             DevBuf &dc = ld.cols[c];
             if (!dc.values) continue;
+            if (dc.valid && dc.valid_rows > 0) {   // the validity bytes of the rows that stay (rows beyond valid_rows are valid by convention)
+                const int64_t left = std::max<int64_t>(dc.valid_rows - d, 0);
+                if (left > 0 && d > 0) {
+                    void *nv = nullptr;
+                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "valid"), dc.valid + d, (size_t)left, (size_t)keep + 64, &nv));
+                    dc.valid = static_cast<uint8_t *>(nv);
+                }
+                dc.valid_rows = left;
+            }
             if (lf.schema[c].type == ColType::UTF8) {
                 const int64_t db = ld.pane_bytes[0][c];
                 if (keep > 0 && d > 0) {
                     void *no = nullptr, *nb = nullptr;
-                    const size_t ocap = ctx->arena[leaf_key(plan, (int)l, (int)c, "off")].cap, bcap = ctx->arena[leaf_key(plan, (int)l, (int)c, "bytes")].cap;
-                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "off"), dc.offsets + d, (size_t)(keep + 1) * 4, ocap, &no));
-                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "bytes"), static_cast<uint8_t *>(dc.values) + db, (size_t)(dc.bytes - db), bcap, &nb));
+                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "off"), dc.offsets + d, (size_t)(keep + 1) * 4, 0, &no));
+                    FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "bytes"), static_cast<uint8_t *>(dc.values) + db, (size_t)(dc.bytes - db), 0, &nb));
                     dc.offsets = static_cast<int32_t *>(no);
                     dc.values = nb;
                     if (db) FG_TRY(add_i32(ctx, dc.offsets, keep + 1, (int32_t)-db));
@@ -2280,8 +2297,7 @@ static int ring_drop_oldest(flockgpu_plan *plan) {
             } else if (keep > 0 && d > 0) {
                 const size_t w = col_width(lf.schema[c].type);
                 void *nv = nullptr;
-                const size_t cap = ctx->arena[leaf_key(plan, (int)l, (int)c, "val")].cap;
-                FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "val"), static_cast<uint8_t *>(dc.values) + (size_t)d * w, (size_t)keep * w, cap, &nv));
+                FG_TRY(ring_swap_in(ctx, leaf_key(plan, (int)l, (int)c, "val"), static_cast<uint8_t *>(dc.values) + (size_t)d * w, (size_t)keep * w, 0, &nv));
                 dc.values = nv;
             }
         }

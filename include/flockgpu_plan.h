@@ -122,7 +122,8 @@ int flockgpu_plan_output_partitions(const flockgpu_plan *plan);
  * NULLs in projected / joined-along columns come back as NULLs (validity bitmap + null_count on the exported arrays).  The fused
  * NEXMark pipelines read plain columns: an invocation whose leaf holds such NULLs runs on the generic operators.  Handed back
  * as FLOCKGPU_ERR_UNSUPPORTED at execute: NULLs in a two-column GROUP BY key, in DISTINCT
- * columns, in a computed join key; FLOCKGPU_ERR_UNSUPPORTED at feed: such NULLs on a plan with an open pane ring. */
+ * columns, in a computed join key; FLOCKGPU_ERR_UNSUPPORTED at feed: such NULLs on the q5 plan with an open pane ring (its ring keeps
+ * Partial COUNT groups of plain columns; every other plan's ring keeps rows, validity included). */
 int flockgpu_plan_feed(flockgpu_plan *plan, int input, const struct ArrowSchema *schema,
                        const struct ArrowArray *const *batches, int n_batches);
 

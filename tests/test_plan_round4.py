@@ -286,6 +286,52 @@ def test_two_relation_utf8_plan_through_the_rows_ring(gpu):
     whole.close()
 
 
+@pytest.mark.gpu
+def test_large_batches_without_nulls_behind_a_small_one_with_nulls(gpu):
+    """Validity is materialised from the first batch that holds a NULL on; batches fed afterwards without any NULL are valid by convention and
+    filled in when the leaf is scanned -- for which the validity buffer must have room for every row of the leaf, not only for the rows
+    of the last batch that held a NULL (it had not: a 20 000-row batch behind a 50-row one was an invalid memset)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    aggs = [("count", "v", "UInt64"), ("max", "v", "Int64"), ("count", None, "UInt64")]
+    small = _null_table(50, 41)
+    r = np.random.default_rng(41)
+    big = {"k": [int(x) for x in r.integers(-3, 6, 20_000)], "v": [int(x) for x in r.integers(-50, 50, 20_000)],
+           "f": [float(x) for x in np.round(r.normal(0, 10, 20_000))], "s": ["s1"] * 20_000}
+    ctx = ExecutionContext([_agg_plan(aggs)], gpu=gpu)
+    rb = collect(ctx, [[_null_batches(small, 50) + _null_batches(big, 20_000) + _null_batches(big, 7_000)]])[0][0]
+    ctx.close()
+    t = {c: small[c] + big[c] + big[c] for c in ("k", "v", "f", "s")}
+    want = g.hash_aggregate_exec(t, ["k"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+    key = lambda r: (r[0] is None, r[0] or 0)
+    assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key)
+
+
+@pytest.mark.gpu
+def test_rows_ring_carries_validity(gpu):
+    """A GROUP BY with NULL keys and NULL values over Hopping(3 panes) through the rows ring: the validity bytes of the held panes stay with
+    their rows when the oldest pane goes (some panes hold no NULL at all: their rows are valid by convention, before and after the shift);
+    every window equals the oracle over the rows of the panes it holds."""
+    from flock_amd.runtime import ExecutionContext, collect
+    aggs = [("count", "v", "UInt64"), ("max", "v", "Int64"), ("min", "f", "Float64"), ("count", None, "UInt64")]
+    ring = ExecutionContext([_agg_plan(aggs)], name="agg-ring", gpu=gpu)
+    ring.open_window_ring(3)
+    panes = []
+    for p in range(7):
+        t = _null_table(400 + 37 * p, 100 + p)
+        if p in (2, 5):                                                # panes without a single NULL
+            r = np.random.default_rng(p)
+            t = {"k": [int(x) for x in r.integers(-3, 6, 300)], "v": [int(x) for x in r.integers(-50, 50, 300)],
+                 "f": [float(x) for x in np.round(r.normal(0, 10, 300))], "s": ["s1"] * 300}
+        panes.append(t)
+        rb = collect(ring, [[_null_batches(t, 150)]], pane=p)[0][0]
+        held = panes[max(0, p - 2): p + 1]
+        window = {c: [x for q in held for x in q[c]] for c in ("k", "v", "f", "s")}
+        want = g.hash_aggregate_exec(window, ["k"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+        key = lambda r: (r[0] is None, r[0] or 0)
+        assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key), p
+    ring.close()
+
+
 # ------------------------------------------------------------------ GPU: asynchronous execute
 @pytest.mark.gpu
 def test_plans_on_their_own_contexts_execute_side_by_side(gpu):
