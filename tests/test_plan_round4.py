@@ -306,6 +306,60 @@ def test_large_batches_without_nulls_behind_a_small_one_with_nulls(gpu):
     assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key)
 
 
+def _group_plan(key, aggs):
+    """_agg_plan with the GROUP BY column as a parameter (Partial -> Hash([key]) -> FinalPartitioned)."""
+    def expr(fn, col, dt):
+        arg = _c(col) if col else {"physical_expr": "literal", "value": {"UInt8": 1}}
+        return {"aggregate_expr": fn, "name": "%s(%s)" % (fn.upper(), col or "UInt8(1)"), "data_type": dt, "nullable": True, "expr": arg}
+    ae = [expr(*a) for a in aggs]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[_c(key), key]], "aggr_expr": ae, "input": _scan(),
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[{"physical_expr": "column", "name": key, "index": 0}], 4]}}
+    return {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[{"physical_expr": "column", "name": key, "index": 0}, key]],
+            "aggr_expr": ae, "input": {"execution_plan": "coalesce_batches_exec", "input": rep, "target_batch_size": 4096},
+            "input_schema": {"fields": _NF, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(20))
+def test_group_by_at_random(gpu, seed):
+    """The generic GROUP BY (wave reduction of a skewed key -> LDS table per workgroup -> global table sized from the node's last run) over
+    seeded random tables: key column of every supported type, any set of aggregates that fits the four accumulators, NULLs from none to
+    nearly all in keys and values, one hot key or none, from a dozen rows to past the size where the LDS level switches on, several
+    executes per plan so that the table's sizing hint sees the groups shrink and multiply.  Values are integral, so sums and averages are
+    exact whatever the order of the additions."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(1000 + seed)
+    key = ["k", "v", "s"][seed % 3]
+    pool = [("count", None, "UInt64"), ("count", "v" if key != "v" else "k", "UInt64"), ("sum", "v" if key != "v" else "k", "Int64"),
+            ("max", "v" if key != "v" else "k", "Int64" if key != "v" else "Int32"), ("min", "f", "Float64"), ("max", "f", "Float64"), ("avg", "k" if key != "k" else "v", "Float64")]
+    aggs, used = [], 0
+    for i in r.permutation(len(pool)):
+        cost = 2 if pool[i][0] == "avg" else 1
+        if used + cost <= 4 and r.random() < 0.7:
+            aggs.append(pool[i])
+            used += cost
+    if not aggs:
+        aggs = [pool[0]]
+    ctx = ExecutionContext([_group_plan(key, aggs)], gpu=gpu)
+    for n in [int(x) for x in r.choice([12, 700, 40_000, 140_000], 3)]:
+        n_keys = int(r.choice([3, 200, max(4, n // 2)]))
+        null_p = float(r.choice([0.0, 0.1, 0.9]))
+        hot = float(r.choice([0.0, 0.6]))
+        kk = r.integers(-n_keys // 2, n_keys, n)
+        kk[r.random(n) < hot] = 1
+        nul = lambda col, p: [None if r.random() < p else x for x in col]
+        t = {"k": nul([int(x) for x in (kk if key == "k" else r.integers(-40, 40, n))], null_p if key == "k" else null_p / 2),
+             "v": nul([int(x) * (10**12 if key == "v" else 1) for x in (kk if key == "v" else r.integers(-10**6, 10**6, n))], null_p if key == "v" else null_p / 2),
+             "f": nul([float(x) for x in np.round(r.normal(0, 100, n))], null_p / 2),
+             "s": nul(["" if x == 0 else "key%d" % x for x in (kk if key == "s" else r.integers(0, 5, n))], null_p if key == "s" else 0.0)}
+        rb = collect(ctx, [[_null_batches(t, int(r.choice([n, max(1, n // 3)])))]])[0][0]
+        want = g.hash_aggregate_exec(t, [key], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+        order = lambda row: (row[0] is None, row[0] if row[0] is not None else 0) if key != "s" else (row[0] is None, row[0] or "")
+        assert sorted(_pyrows(rb), key=order) == sorted(g.rows(want), key=order), (seed, key, aggs, n, n_keys, null_p, hot)
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_rows_ring_carries_validity(gpu):
     """A GROUP BY with NULL keys and NULL values over Hopping(3 panes) through the rows ring: the validity bytes of the held panes stay with
