@@ -1,7 +1,8 @@
 /* A C99 consumer of the drop-in boundary (include/flockgpu.h, include/flockgpu_plan.h) -- no ctypes, no C++: what a Rust
  * `extern "C"` block binds is exactly what this file calls.  It restates one `actor::collect`
  * (flock-function/src/aws/actor.rs:54-79): plan JSON in, feed two hand-built Arrow batches, execute, walk the returned
- * ArrowArray, release it, reset, run a second invocation, destroy.
+ * ArrowArray, release it, reset, run a second invocation; then the round-4 surface (pane ring, asynchronous execute + wait, the
+ * partition-scheme check, guarded memory); destroy.
  *
  *   consumer <plan.json> <modulus>      (the plan is NEXMark q2: Filter auction % modulus = 0 -> [auction, price])
  *
@@ -143,6 +144,43 @@ int main(int argc, char **argv) {
     /* errors are statuses with a message, never aborts */
     if (flockgpu_plan_feed(plan, 3, &schema, batches, 2) != FLOCKGPU_ERR_INVALID || strlen(flockgpu_last_error(ctx)) == 0)
         return fail(ctx, "a bad input index must be FLOCKGPU_ERR_INVALID with a message", -1);
+    /* round-4 surface, from C as a Rust host would drive it: the pane ring (one pane per invocation, the window = the panes held),
+     * an asynchronous execute waited for later, and the guarded allocation */
+    {
+        int pane, n_parts = 0, held = 0, ppw = 0;
+        int64_t first_pane = -1;
+        void *guarded = NULL;
+        if ((rc = flockgpu_plan_ring_open(plan, 2)) != FLOCKGPU_OK) return fail(ctx, "ring_open", rc);
+        for (pane = 0; pane < 3; ++pane) {
+            int64_t expect = 0;
+            for (i = 0; i < 64; ++i) {
+                auction[i] = 123 * (i + 1 + 64 * pane) * ((i % 4) == 0 ? 1 : 0) + ((i % 4) == 0 ? 0 : 1);   /* every fourth row passes */
+                price[i] = 1000 * pane + i;
+            }
+            make_batch(&b0, auction, price, 64, 0);
+            batches[0] = &b0.batch;
+            if ((rc = flockgpu_plan_feed_pane(plan, 0, (int64_t)pane, &schema, batches, 1)) != FLOCKGPU_OK) return fail(ctx, "feed_pane", rc);
+            if ((rc = flockgpu_plan_ring_state(plan, &first_pane, &held, &ppw)) != FLOCKGPU_OK) return fail(ctx, "ring_state", rc);
+            if (ppw != 2 || held != (pane == 0 ? 1 : 2) || first_pane != (pane == 0 ? 0 : pane - 1)) return fail(ctx, "ring holds the wrong panes", held);
+            memset(&out, 0, sizeof out);
+            memset(&out_schema, 0, sizeof out_schema);
+            if ((rc = flockgpu_plan_execute_async(plan, 0)) != FLOCKGPU_OK) return fail(ctx, "execute_async", rc);
+            if ((rc = flockgpu_plan_wait(plan, &out_schema, &out, 1, &n_parts)) != FLOCKGPU_OK || n_parts != 1) return fail(ctx, "plan_wait", rc);
+            expect = 16 * (pane == 0 ? 1 : 2);       /* the rows of the panes held that pass the filter (modulus 123) */
+            if (modulus == 123 && out.length != expect) return fail(ctx, "ring window row count", (int)out.length);
+            printf("ring pane %d rows %d\n", pane, (int)out.length);
+            out.release(&out);
+            out_schema.release(&out_schema);
+            if ((rc = flockgpu_plan_reset(plan)) != FLOCKGPU_OK) return fail(ctx, "ring reset", rc);
+        }
+        if (flockgpu_plan_feed_pane(plan, 0, 7, &schema, batches, 1) != FLOCKGPU_ERR_INVALID) return fail(ctx, "a skipped pane must be refused", -1);
+        if ((rc = flockgpu_plan_ring_close(plan)) != FLOCKGPU_OK) return fail(ctx, "ring_close", rc);
+        if ((rc = flockgpu_malloc_guarded(ctx, 4096, &guarded)) != FLOCKGPU_OK || !guarded || ((size_t)guarded & 15)) return fail(ctx, "malloc_guarded", rc);
+        if ((rc = flockgpu_memcpy(ctx, guarded, auction, sizeof auction, FLOCKGPU_H2D)) != FLOCKGPU_OK) return fail(ctx, "copy into guarded memory", rc);
+        if ((rc = flockgpu_free_guarded(ctx, guarded)) != FLOCKGPU_OK) return fail(ctx, "free_guarded", rc);
+        if (flockgpu_plan_check_partition_scheme(flockgpu_plan_partition_scheme()) != FLOCKGPU_OK) return fail(ctx, "the library's own scheme must check", -1);
+        if (flockgpu_plan_check_partition_scheme("datafusion/ahash-0000") == FLOCKGPU_OK) return fail(ctx, "a foreign scheme must not check", -1);
+    }
     printf("partition scheme %s\n", flockgpu_plan_partition_scheme());
     flockgpu_plan_destroy(plan);
     flockgpu_ctx_destroy(ctx);

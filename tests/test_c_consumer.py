@@ -1,5 +1,6 @@
 """A non-Python consumer of the C ABI: tests/c_abi/consumer.c is C99, includes only include/*.h, and drives
-create -> feed two Arrow batches -> execute -> walk the Arrow structs -> release -> reset -> destroy.
+create -> feed two Arrow batches -> execute -> walk the Arrow structs -> release -> reset, then the pane ring with asynchronous executes,
+the partition-scheme check and the guarded allocation -> destroy.
 CPU: the headers compile as strict C99 and the consumer links against libflockgpu.so.  GPU: it runs, and its rows equal a plain loop."""
 import os
 import subprocess
@@ -38,7 +39,9 @@ def test_c_consumer_runs_one_collect_twice():
     p = subprocess.run([exe, plan, "123"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     blocks = p.stdout.split("--\n")
-    assert blocks[-1].startswith("partition scheme flockgpu/")
+    tail = blocks[-1].splitlines()
+    assert tail[:3] == ["ring pane 0 rows 16", "ring pane 1 rows 32", "ring pane 2 rows 32"]      # pane ring + asynchronous execute, from C
+    assert tail[-1].startswith("partition scheme flockgpu/")
     for inv in range(2):
         want = [(984 + 41 * i * (inv + 1), 7 * i + inv) for i in range(60) if (984 + 41 * i * (inv + 1)) % 123 == 0]
         got = [tuple(map(int, line.split())) for line in blocks[inv].splitlines()]
