@@ -695,3 +695,41 @@ def test_join_with_null_keys_and_null_payloads(gpu):
     key = lambda r: tuple((x is None, x) for x in r)
     assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key) and rb.num_rows > 1000
     assert rb["v"].null_count > 0 and rb["s"].null_count > 0 and rb["f2"].null_count > 0 and rb["k"].null_count == 0 and rb["k2"].null_count == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_inner_join_at_random(gpu, seed):
+    """The generic inner hash join over seeded random tables: Int32 or Utf8 keys, duplicates on both sides (every pair comes out), NULL keys
+    (never match), NULLs in the columns carried along, empty and one-sided inputs, a few hundred to tens of thousands of rows, the same
+    plan executed three times with different shapes."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(2000 + seed)
+    on = "k" if seed % 2 == 0 else "s"
+    rf = [_field("k2", "Int32", True), _field("v2", "Int64", True), _field("f2", "Float64", True), _field("s2", "Utf8", True)]
+    side = lambda scan, key, fields: {"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096,
+                                      "input": {"execution_plan": "repartition_exec", "input": scan, "partitioning": {"Hash": [[_c(key, fields)], 4]}}}
+    plan = {"execution_plan": "hash_join_exec", "left": side(_scan(), on, _NF), "right": side(_scan(rf), on + "2", rf), "join_type": "Inner", "mode": "Partitioned",
+            "on": [[_c(on), _c(on + "2", rf)]], "schema": {"fields": _NF + rf, "metadata": {}}}
+    ctx = ExecutionContext([plan], gpu=gpu)
+
+    def table(n, n_keys, null_p):
+        nul = lambda col, p: [None if r.random() < p else x for x in col]
+        kk = r.integers(0, max(n_keys, 1), n)
+        return {"k": nul([int(x) for x in kk], null_p), "v": nul([int(x) for x in r.integers(-10**9, 10**9, n)], null_p / 2),
+                "f": nul([float(x) for x in np.round(r.normal(0, 100, n))], null_p / 2),
+                "s": nul(["" if x == 0 else "name-%d" % x for x in (kk if on == "s" else r.integers(0, 7, n))], null_p if on == "s" else null_p / 2)}
+    for _ in range(3):
+        nl, nr = int(r.choice([0, 300, 4_000, 30_000])), int(r.choice([1, 500, 9_000]))
+        n_keys = int(r.choice([5, 400, 20_000]))
+        if nl * nr // max(n_keys, 1) > 3_000_000:      # (keep the oracle's nested loops in seconds)
+            n_keys = 20_000
+        left, right = table(nl, n_keys, float(r.choice([0.0, 0.2]))), table(nr, n_keys, float(r.choice([0.0, 0.3])))
+        lb = _null_batches(left, max(1, nl // 2)) if nl else [pa.record_batch([pa.array([], pa.int32()), pa.array([], pa.int64()), pa.array([], pa.float64()), pa.array([], pa.string())], names=["k", "v", "f", "s"])]
+        rbs = [pa.record_batch([b[c] for c in b.schema.names], names=["k2", "v2", "f2", "s2"]) for b in _null_batches(right, max(1, nr // 3))]
+        rb = collect(ctx, [[lb], [rbs]])[0][0]
+        want = g.hash_join_inner(left, {"k2": right["k"], "v2": right["v"], "f2": right["f"], "s2": right["s"]}, [(on, on + "2")])
+        key = lambda row: tuple((x is None, x if x is not None else 0) if not isinstance(x, str) else (False, x) for x in row)
+        assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key), (seed, on, nl, nr, n_keys)
+    ctx.close()
+
