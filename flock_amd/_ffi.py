@@ -246,6 +246,7 @@ SYMBOLS = {
     "flockgpu_plan_ring_close": (_i, [_vp]),
     "flockgpu_plan_ring_state": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     "flockgpu_plan_feed_pane": (_i, [_vp, _i, _i64, _vp, C.POINTER(_vp), _i]),
+    "flockgpu_plan_prefetch_pane": (_i, [_vp, _i, _i64, _vp, C.POINTER(_vp), _i]),
     "flockgpu_plan_partition_scheme": (C.c_char_p, []),
     "flockgpu_plan_check_partition_scheme": (_i, [C.c_char_p]),
     # asynchronous twins of the batched-window calls (one call in flight per ctx)

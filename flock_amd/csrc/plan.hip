@@ -180,6 +180,19 @@ struct flockgpu_plan {
     bool ring_q5 = false;
     std::vector<int64_t> ring_groups;   // groups per held pane (the newest pane's entry is valid when ring_newest_done)
     bool ring_newest_done = false;
+    // flockgpu_plan_prefetch_pane: the NEXT pane's bytes on their way into side buffers (a stream of their own, host staging on threads of
+    // their own) while the current window executes; flockgpu_plan_feed_pane(.., NULL, NULL, 0) for that pane appends them device to device
+    struct Prefetch {
+        bool active = false;
+        int input = -1;
+        int64_t pane = 0, rows = 0;
+        std::vector<void *> dev;        // per leaf column: the side buffer (null: not prefetched)
+        std::vector<std::thread> workers;
+        std::vector<int> rc;
+    } pre;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr, append_done = nullptr;   // the pane's copies are queued / its side buffers have been read
+    bool copy_done_set = false, append_done_set = false;
     int32_t *ring_auction = nullptr;
     uint32_t *ring_count = nullptr;
     // ---- flockgpu_plan_execute_async: the finished call's outputs, handed over by flockgpu_plan_wait
@@ -885,6 +898,7 @@ bool validity_has_nulls(const ArrowArray *a, int64_t offset, int64_t n) {
 }  // namespace
 extern "C" {
 static int ring_q5_partial(flockgpu_plan *plan);   // (pane ring, below)
+static void prefetch_drop(flockgpu_plan *plan);
 }
 namespace {
 
@@ -1965,6 +1979,13 @@ void flockgpu_plan_destroy(flockgpu_plan *plan) {
     if (plan->ring_ppw) ApiClock::dump();
 #endif
     flockgpu_ctx *ctx = plan->ctx;
+    prefetch_drop(plan);
+    if (plan->copy_stream) {
+        (void)hipStreamSynchronize(plan->copy_stream);
+        (void)hipStreamDestroy(plan->copy_stream);
+        (void)hipEventDestroy(plan->copy_done);
+        (void)hipEventDestroy(plan->append_done);
+    }
     if (plan->async_pending) {   // an execute nobody waited for: let it finish, drop what it produced
         if (ctx_wait(ctx) == FLOCKGPU_OK) {
             for (int i = 0; i < plan->async_n; ++i)
@@ -2382,6 +2403,137 @@ int flockgpu_plan_ring_state(const flockgpu_plan *plan, int64_t *first_pane, int
     return FLOCKGPU_OK;
 }
 
+// Ends a prefetch's host side: the staging threads are joined (every copy is queued on the copy stream by then).  Returns their status.
+static int prefetch_join(flockgpu_plan *plan) {
+    int rc = FLOCKGPU_OK;
+    for (auto &w : plan->pre.workers)
+        if (w.joinable()) w.join();
+    plan->pre.workers.clear();
+    for (int r : plan->pre.rc)
+        if (r != FLOCKGPU_OK) rc = r;
+    plan->pre.rc.clear();
+    return rc;
+}
+// Drops a pending prefetch (ring close, reset of a plan without a ring, destroy): nothing of it reaches the leaf.
+static void prefetch_drop(flockgpu_plan *plan) {
+    if (!plan->pre.active) return;
+    (void)prefetch_join(plan);
+    if (plan->copy_stream) (void)hipStreamSynchronize(plan->copy_stream);
+    plan->pre.active = false;
+}
+
+int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id, const struct ArrowSchema *schema, const struct ArrowArray *const *batches,
+                                int n_batches) {
+    if (!plan) return FLOCKGPU_ERR_INVALID;
+    flockgpu_ctx *ctx = plan->ctx;
+    if (!plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: the plan has no open ring (flockgpu_plan_ring_open)");
+    if (input < 0 || input >= (int)plan->leaves.size() || !schema || !batches || n_batches < 1) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: bad argument");
+    if (plan->pre.active) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: pane %lld of input %d is already on its way", (long long)plan->pre.pane, plan->pre.input);
+    const int64_t newest = plan->ring_first + plan->ring_n - 1;
+    if (plan->ring_n > 0 && pane_id != newest + 1)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: pane %lld is not the next one (the ring holds [%lld, %lld])", (long long)pane_id, (long long)plan->ring_first,
+                    (long long)newest);
+    const Leaf &lf = plan->ir.leaves[(size_t)input];
+    if (plan->leaves[(size_t)input].borrowed) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: input %d shares another plan's relation", input);
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    // what the pane holds: fixed-width columns without NULLs (anything else takes the ordinary feed, which knows how to rebase and filter)
+    std::vector<int> child(lf.schema.size(), -1);
+    int64_t rows = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        if (!batches[b] || batches[b]->n_children < schema->n_children) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: batch %d does not match the schema", b);
+        rows += batches[b]->length;
+    }
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (!lf.needed[c]) continue;
+        if (lf.schema[c].type == ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: Utf8 column '%s' (feed the pane the ordinary way)", lf.schema[c].name.c_str());
+        child[c] = find_child(schema, lf.schema[c].name);
+        if (child[c] < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: column '%s' missing from the fed schema", lf.schema[c].name.c_str());
+        if (!format_ok(lf.schema[c], schema->children[child[c]]->format))
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: column '%s' has Arrow format '%s', the plan scans %s", lf.schema[c].name.c_str(),
+                        schema->children[child[c]]->format, type_name(lf.schema[c]));
+        for (int b = 0; b < n_batches; ++b) {
+            const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
+            if (!a || a->length < rb->offset + rb->length || a->n_buffers < 2 || (rb->length > 0 && !a->buffers[1]))
+                return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: column '%s' of batch %d is malformed", lf.schema[c].name.c_str(), b);
+            if (validity_has_nulls(a, a->offset + rb->offset, rb->length))
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: column '%s' holds NULLs (feed the pane the ordinary way)", lf.schema[c].name.c_str());
+        }
+    }
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: more than 2^31 rows");
+    if (!plan->copy_stream) {
+        FG_HIP(ctx, hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking));
+        FG_HIP(ctx, hipEventCreateWithFlags(&plan->copy_done, hipEventDisableTiming));
+        FG_HIP(ctx, hipEventCreateWithFlags(&plan->append_done, hipEventDisableTiming));
+    }
+    // the side buffers and the pinned mirror are the previous prefetch's, too: its copies must have left the mirror (host wait: they were
+    // queued a whole window ago) and its appends must have read the side buffers (device-side wait of the copy stream)
+    if (plan->copy_done_set) FG_HIP(ctx, hipEventSynchronize(plan->copy_done));
+    if (plan->append_done_set) FG_HIP(ctx, hipStreamWaitEvent(plan->copy_stream, plan->append_done, 0));
+    // side buffers; pinned sources go straight to the DMA engine, pageable ones through a pinned mirror filled by staging threads
+    plan->pre.dev.assign(lf.schema.size(), nullptr);
+    std::vector<flockgpu_plan::CopyJob> pieces;   // pageable pieces: dst (device), src (host), bytes
+    size_t pageable = 0;
+    for (size_t c = 0; c < lf.schema.size(); ++c) {
+        if (child[c] < 0) continue;
+        const size_t w = col_width(lf.schema[c].type);
+        void *d = nullptr;
+        FG_TRY(arena_get(ctx, leaf_key(plan, input, (int)c, "pre").c_str(), (size_t)rows * w + 16, &d));
+        plan->pre.dev[c] = d;
+        size_t at = 0;
+        for (int b = 0; b < n_batches; ++b) {
+            const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
+            const size_t bytes = (size_t)rb->length * w;
+            if (!bytes) continue;
+            const uint8_t *src = static_cast<const uint8_t *>(a->buffers[1]) + (size_t)(a->offset + rb->offset) * w;
+            uint8_t *dst = static_cast<uint8_t *>(d) + at;
+            at += bytes;
+            if (host_is_pinned(src) && host_is_pinned(src + bytes - 1)) {
+                FG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, plan->copy_stream));
+            } else {
+                for (size_t done = 0; done < bytes; done += kStageChunk) {
+                    const size_t n = std::min(kStageChunk, bytes - done);
+                    pieces.push_back(flockgpu_plan::CopyJob{dst + done, src + done, n});
+                    pageable += n;
+                }
+            }
+        }
+    }
+    plan->pre.input = input;
+    plan->pre.pane = pane_id;
+    plan->pre.rows = rows;
+    plan->pre.active = true;
+    if (pieces.empty()) return FLOCKGPU_OK;
+    uint8_t *mirror = nullptr;
+    FG_TRY(pinned_get_t(ctx, leaf_key(plan, input, 0, "pre.stage").c_str(), pageable + 64, &mirror));
+    // (the mirror may still feed the previous prefetch's copies: they were waited for when that pane was appended -- feed_pane orders the
+    // ctx stream behind the copy stream, and a host synchronises the ctx stream in every execute)
+    const int n_lanes = (int)std::min<size_t>(4, pieces.size());
+    auto shared = std::make_shared<std::vector<flockgpu_plan::CopyJob>>(std::move(pieces));
+    plan->pre.rc.assign((size_t)n_lanes, FLOCKGPU_OK);
+    std::vector<size_t> offs(shared->size());
+    size_t run = 0;
+    for (size_t i = 0; i < shared->size(); ++i) {
+        offs[i] = run;
+        run += (*shared)[i].bytes;
+    }
+    auto offsets = std::make_shared<std::vector<size_t>>(std::move(offs));
+    const int device = ctx->device;
+    hipStream_t stream = plan->copy_stream;
+    for (int l = 0; l < n_lanes; ++l)
+        plan->pre.workers.emplace_back([plan, shared, offsets, mirror, l, n_lanes, device, stream] {
+            if (hipSetDevice(device) != hipSuccess) {
+                plan->pre.rc[(size_t)l] = FLOCKGPU_ERR_HIP;
+                return;
+            }
+            for (size_t i = (size_t)l; i < shared->size(); i += (size_t)n_lanes) {
+                const flockgpu_plan::CopyJob &j = (*shared)[i];
+                std::memcpy(mirror + (*offsets)[i], j.src, j.bytes);
+                if (hipMemcpyAsync(j.dst, mirror + (*offsets)[i], j.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) plan->pre.rc[(size_t)l] = FLOCKGPU_ERR_HIP;
+            }
+        });
+    return FLOCKGPU_OK;
+}
+
 int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, const struct ArrowSchema *schema,
                             const struct ArrowArray *const *batches, int n_batches) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
@@ -2397,6 +2549,17 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
     if (begin && plan->ring_n == plan->ring_ppw)
         return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the ring is full (%d panes): flockgpu_plan_reset retires the oldest before pane %lld begins",
                     plan->ring_ppw, (long long)pane_id);
+    // a pane that flockgpu_plan_prefetch_pane already brought over: its side buffers are appended below, device to device
+    const bool from_prefetch = n_batches == 0 && !schema && plan->pre.active && plan->pre.input == input && plan->pre.pane == pane_id;
+    if (plan->pre.active && !from_prefetch && plan->pre.input == input)
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: pane %lld of input %d was prefetched: feed it with (NULL, NULL, 0) first", (long long)plan->pre.pane, plan->pre.input);
+    if (from_prefetch) {
+        const int rc_pre = prefetch_join(plan);
+        if (rc_pre != FLOCKGPU_OK) {
+            plan->pre.active = false;
+            return fail(ctx, rc_pre, "feed_pane: the prefetch of pane %lld failed while staging", (long long)pane_id);
+        }
+    }
     // every check of the feed first: a refused feed must leave the ring as it was
     {
         API_CLOCK2(c1, "feed_pane.validate");
@@ -2421,6 +2584,32 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         if (plan->ring_q5) plan->ring_groups.push_back(0);
         plan->ring_newest_done = false;
     }
+    if (from_prefetch) {
+        LeafData &ld = plan->leaves[(size_t)input];
+        const Leaf &lf = plan->ir.leaves[(size_t)input];
+        FG_HIP(ctx, hipEventRecord(plan->copy_done, plan->copy_stream));           // every copy of the pane is queued (prefetch_join)
+        plan->copy_done_set = true;
+        FG_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->copy_done, 0));          // ... and the appends wait for them on the device
+        for (size_t c = 0; c < lf.schema.size(); ++c) {
+            if (!plan->pre.dev[c]) continue;
+            const size_t w = col_width(lf.schema[c].type);
+            void *p = nullptr;
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "val"), (size_t)ld.rows * w, (size_t)(ld.rows + plan->pre.rows) * w + 16, &p));
+            ld.cols[c].values = p;
+            if (plan->pre.rows)
+                FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(p) + (size_t)ld.rows * w, plan->pre.dev[c], (size_t)plan->pre.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        FG_HIP(ctx, hipEventRecord(plan->append_done, ctx->stream));
+        plan->append_done_set = true;
+        ld.rows += plan->pre.rows;
+        ld.pane_rows.back() += plan->pre.rows;
+        plan->has_retained = false;
+        plan->fed_bytes += 1;   // (reset waits for the stream before the host's buffers may go)
+        plan->pre.active = false;
+        plan->ring_newest_done = false;
+        if (plan->ring_q5) plan->ring_groups.back() = 0;
+        return FLOCKGPU_OK;
+    }
     if (n_batches == 0) return FLOCKGPU_OK;   // an empty pane still advances the ring
     LeafData &ld = plan->leaves[(size_t)input];
     const int64_t rows_before = ld.rows;
@@ -2440,6 +2629,7 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
 int flockgpu_plan_ring_close(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "ring_close: an asynchronous execute is in flight");
+    prefetch_drop(plan);
 #ifdef FLOCKGPU_EXPERIMENTAL
     ApiClock::dump();
 #endif

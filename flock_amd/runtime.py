@@ -114,6 +114,36 @@ class _Plan:
             _release(C.addressof(sbuf), 56)
         self.gpu._check(rc)
 
+    def prefetch(self, i: int, batches: Sequence, pane: int) -> bool:
+        """The NEXT pane's batches of leaf i start moving to the device now, beside whatever the plan is executing
+        (flockgpu_plan_prefetch_pane); `feed_prefetched(i, pane)` appends them when the pane's turn has come.  False -- nothing was
+        started -- when the pane holds what a prefetch does not take (Utf8 columns, NULLs): feed it the ordinary way then."""
+        batches = [b for b in batches if b is not None]
+        if not batches:
+            return False
+        sbuf = C.create_string_buffer(_ARROW_SCHEMA_BYTES)
+        batches[0].schema._export_to_c(C.addressof(sbuf))
+        abufs = [C.create_string_buffer(_ARROW_ARRAY_BYTES) for _ in batches]
+        for b, ab in zip(batches, abufs):
+            b._export_to_c(C.addressof(ab))
+        ptrs = (C.c_void_p * len(batches))(*[C.addressof(ab) for ab in abufs])
+        try:
+            rc = self._lib.flockgpu_plan_prefetch_pane(self.h, i, pane, C.cast(sbuf, C.c_void_p), ptrs, len(batches))
+        finally:
+            for ab in abufs:
+                _release(C.addressof(ab), 64)
+            _release(C.addressof(sbuf), 56)
+        if rc == _ffi.ERR_UNSUPPORTED:
+            return False
+        self.gpu._check(rc)
+        self._prefetched = batches     # borrowed until the reset after the pane's feed
+        return True
+
+    def feed_prefetched(self, i: int, pane: int):
+        self.gpu._check(self._lib.flockgpu_plan_feed_pane(self.h, i, pane, None, None, 0))
+        self._fed.append(getattr(self, "_prefetched", None))
+        self._prefetched = None
+
     def feed_shared(self, i: int, donor: "_Plan", donor_input: int) -> bool:
         """Leaf i reads the relation `donor`'s leaf was fed, in place (flockgpu_plan_feed_shared).  False -- and nothing changed --
         when the donor does not hold what this plan reads."""
@@ -217,7 +247,9 @@ class ExecutionContext:
     def close_window_ring(self):
         for plan in self.plans:
             plan.ring_close()
+            plan._prefetched = None
         self._ring = 0
+        self._pre = None
 
     # -- context.rs:257-325
     def feed_data_sources(self, sources, pane: Optional[int] = None):
@@ -226,6 +258,24 @@ class ExecutionContext:
         a match stays an empty relation (context.rs:305-314).  `pane`: see open_window_ring."""
         if (pane is None) != (not self._ring):
             raise ValueError("feed_data_sources: `pane` goes with an open window ring")
+        pre = getattr(self, "_pre", None)
+        if sources is None:   # the pane prefetch_data_sources announced
+            if pre is None or pre["pane"] != pane:
+                raise ValueError("feed_data_sources(None, pane): no prefetch for this pane")
+            self._pre = None   # (whatever happens below, the announcement is used up)
+            touched = set()
+            for plan, i, batches in pre["later"]:
+                plan.feed(i, batches, pane)
+                touched.add(id(plan))
+            for plan, i in pre["moving"]:
+                plan.feed_prefetched(i, pane)
+                touched.add(id(plan))
+            for plan in self.plans:
+                if id(plan) not in touched and plan.inputs:
+                    plan.feed(0, [], pane)
+            return
+        if pre is not None:
+            raise ValueError("feed_data_sources: pane %d was prefetched -- feed it with sources=None first" % pre["pane"])
         sources = [list(s) for s in sources]
         for plan in self.plans:
             fed_a_pane = False
@@ -244,6 +294,33 @@ class ExecutionContext:
                     fed_a_pane = True
             if pane is not None and not fed_a_pane and plan.inputs:   # nothing arrived in this pane: the ring still advances
                 plan.feed(0, [], pane)
+
+    def prefetch_data_sources(self, sources, pane: int):
+        """The sources of pane `pane` -- the ring's NEXT pane -- matched to the leaves as feed_data_sources matches them; what a prefetch
+        takes (fixed-width columns without NULLs, one leaf per plan) starts crossing PCIe now, beside the current window's execute, the
+        rest is kept and fed the ordinary way by `feed_data_sources(None, pane)`."""
+        if not self._ring:
+            raise ValueError("prefetch_data_sources: open a window ring first")
+        pre = {"pane": pane, "moving": [], "later": []}
+        sources = [list(s) for s in sources]
+        for plan in self.plans:
+            started = False
+            for i in range(len(plan.inputs)):
+                found = None
+                for si, partitions in enumerate(sources):
+                    first = next((b for part in partitions for b in part), None)
+                    if first is not None and plan.matches(i, first.schema):
+                        found = si
+                        break
+                if found is None:
+                    continue
+                batches = [b for part in sources.pop(found) for b in part]
+                if not started and plan.prefetch(i, batches, pane):
+                    started = True
+                    pre["moving"].append((plan, i))
+                else:
+                    pre["later"].append((plan, i, batches))
+        self._pre = pre
 
     def share_data_sources(self, donor: "ExecutionContext") -> bool:
         """Instead of feed_data_sources: every leaf reads, in place, the relation of the same name that `donor` (another function

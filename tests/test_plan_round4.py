@@ -258,6 +258,86 @@ def test_ring_refuses_out_of_order_and_skipped_panes(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("generic_only", [False, True])
+def test_prefetched_panes_equal_fed_panes(gpu, generic_only):
+    """flockgpu_plan_prefetch_pane: pane p + 1 crosses PCIe into side buffers while window p executes, and is appended device to device when
+    its turn comes.  Same windows as feeding every pane the ordinary way, on q5's state ring and on the rows ring (generic operators);
+    panes of different sizes, an empty pane in between, pageable batches cut into several pieces."""
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=12, eps=3_000)
+    sizes = [3_000, 9_000, 0, 4_500, 30_000, 3_000, 3_000]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    pane = lambda p: [[_bid_batches(s, int(starts[p]), int(starts[p + 1]), 2_500)]] if sizes[p] else [[[]]]
+    plain = ExecutionContext([_plan(5)], name="q5-plain", gpu=gpu, generic_only=generic_only)
+    ahead = ExecutionContext([_plan(5)], name="q5-ahead", gpu=gpu, generic_only=generic_only)
+    plain.open_window_ring(2)
+    ahead.open_window_ring(2)
+    ahead.feed_data_sources(pane(0), pane=0)
+    for p in range(len(sizes)):
+        want = collect(plain, pane(p), pane=p)[0][0]
+        if p + 1 < len(sizes) and sizes[p + 1]:
+            ahead.prefetch_data_sources(pane(p + 1), pane=p + 1)          # ... on its way while window p executes
+        got = ahead.execute()[0][0]
+        ahead.clean_data_sources()
+        assert _q5_rows(got) == _q5_rows(want), p
+        host = s.bids(int(starts[max(p - 1, 0)]), int(starts[p + 1]))["auction"]
+        if len(host):
+            oa, on = oracle.q5_hot_items(host)
+            assert _q5_rows(got) == sorted(zip(oa.tolist(), on.tolist())), p
+        if p + 1 < len(sizes):
+            if sizes[p + 1]:
+                ahead.feed_data_sources(None, pane=p + 1)
+            else:
+                ahead.feed_data_sources(pane(p + 1), pane=p + 1)
+    plain.close()
+    ahead.close()
+
+
+@pytest.mark.gpu
+def test_prefetch_refusals_leave_the_ring_as_it_was(gpu):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext
+    s = oracle.NexmarkStream(seed=13, eps=2_000)
+    b = lambda p: [[_bid_batches(s, p * 2_000, (p + 1) * 2_000, 2_000)]]
+    ctx = ExecutionContext([_plan(5)], gpu=gpu)
+    with pytest.raises(ValueError):
+        ctx.prefetch_data_sources(b(0), pane=0)                             # no ring open
+    ctx.open_window_ring(2)
+    ctx.feed_data_sources(b(0), pane=0)
+    with pytest.raises(FlockGpuError) as e:
+        ctx.prefetch_data_sources(b(3), pane=3)                             # not the next pane
+    assert e.value.code == _ffi.ERR_INVALID and "next" in str(e.value)
+    ctx.prefetch_data_sources(b(1), pane=1)
+    with pytest.raises(FlockGpuError) as e:
+        ctx.plans[0].prefetch(0, b(1)[0][0], 1)                             # one pane at a time
+    assert e.value.code == _ffi.ERR_INVALID
+    with pytest.raises(ValueError):
+        ctx.feed_data_sources(b(1), pane=1)                                 # the prefetched pane is fed from its side buffers
+    want0 = _q5_rows(ctx.execute()[0][0])
+    ctx.clean_data_sources()
+    ctx.feed_data_sources(None, pane=1)
+    host = s.bids(0, 4_000)["auction"]
+    oa, on = oracle.q5_hot_items(host)
+    assert _q5_rows(ctx.execute()[0][0]) == sorted(zip(oa.tolist(), on.tolist())) and want0
+    ctx.clean_data_sources()
+    # NULLs (and Utf8 columns) are not prefetched: the pane is kept for the ordinary feed -- which, on q5's state ring, refuses these NULLs
+    # and leaves the ring as it was
+    nulls = pa.record_batch([pa.array([1, None, 3, 1, 1], pa.int32())], names=["auction"])
+    ctx.prefetch_data_sources([[[nulls]]], pane=2)
+    assert ctx._pre["moving"] == [] and len(ctx._pre["later"]) == 1
+    with pytest.raises(FlockGpuError) as e:
+        ctx.feed_data_sources(None, pane=2)
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and ctx.plans[0].ring_state() == (1, 1, 2)
+    ctx.prefetch_data_sources(b(2), pane=2)
+    ctx.feed_data_sources(None, pane=2)
+    assert ctx.plans[0].ring_state() == (1, 2, 2)
+    ctx.clean_data_sources()
+    ctx.prefetch_data_sources(b(3), pane=3)
+    ctx.close_window_ring()                                                 # a prefetch that was never fed is dropped with the ring
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_two_relation_utf8_plan_through_the_rows_ring(gpu):
     """q8 (persons with a Utf8 column + auctions) over Hopping(3 panes): the generic rows ring keeps both relations' panes on the
     device (Utf8 offsets rebased when the oldest pane goes) and every window equals the whole-window feed and the oracle."""
