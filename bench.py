@@ -959,6 +959,28 @@ def plan_collect_pcie(gpu, eps, steps):
         c.close()
         return dt, rows
 
+    def run_ring_prefetch():
+        # the same ring with the NEXT pane's upload started before the current window executes (flockgpu_plan_prefetch_pane)
+        c = ExecutionContext([plan], gpu=GpuContext(gpu.device, own_stream=True))
+        c.open_window_ring(2)
+        c.feed_data_sources([[panes[0]]], pane=0)
+        rows = 0
+
+        def window(k):
+            c.prefetch_data_sources([[panes[(k + 1) & 1]]], pane=k + 1)
+            out = c.execute()[0][0]
+            c.clean_data_sources()
+            c.feed_data_sources(None, pane=k + 1)
+            return out.num_rows
+        for k in range(3):
+            rows = window(k)
+        t0 = time.perf_counter()
+        for k in range(3, 3 + steps):
+            window(k)
+        dt = (time.perf_counter() - t0) / steps
+        c.close()
+        return dt, rows
+
     def ring_variant(dt, rows):
         b = 4.0 * (pane_rows[0] + pane_rows[1]) / 2 + 12.0 * rows     # one pane in, the winners out
         return {"ms_per_window": round(dt * 1e3, 3), "value": round(n / dt, 1), "bytes_over_pcie_per_window": int(b), "pcie_GBps": round(b / dt / 1e9, 2),
@@ -966,6 +988,7 @@ def plan_collect_pcie(gpu, eps, steps):
                 "note": "value counts the WINDOW's bids (both panes) per second, like the whole-window rows: the same windows, half the upload"}
     try:
         out["ring_one_instance_pageable"] = ring_variant(*run_ring())
+        out["ring_prefetch_pageable"] = ring_variant(*run_ring_prefetch())
     except Exception as ex:
         out["ring_error"] = repr(ex)
     try:
@@ -979,6 +1002,7 @@ def plan_collect_pcie(gpu, eps, steps):
         out["one_instance_registered"] = variant(run(1))
         out["two_instances_registered"] = variant(run(2))
         out["ring_one_instance_registered"] = ring_variant(*run_ring())
+        out["ring_prefetch_registered"] = ring_variant(*run_ring_prefetch())
         for ptr in regs:
             lib.flockgpu_host_unregister(C.c_void_p(ptr))
     except Exception as ex:   # a side measurement must never hide the rest
@@ -1289,6 +1313,9 @@ def final_line(out):
                 ring = e.get("ring_one_instance_pageable") if isinstance(e, dict) else None
                 if isinstance(ring, dict):   # the pane ring: [window rows/s, ms per window, PCIe fraction, x the whole-window feed]
                     terse[k + "_ring"] = [_sig(float(ring["value"])), ring.get("ms_per_window"), ring.get("pcie_frac"), ring.get("vs_whole_window_feed")]
+                    ahead = e.get("ring_prefetch_pageable")
+                    if isinstance(ahead, dict):   # ... with the next pane prefetched while the window executes
+                        terse[k + "_ring_prefetch"] = [_sig(float(ahead["value"])), ahead.get("ms_per_window"), ahead.get("pcie_frac"), ahead.get("vs_whole_window_feed")]
         line["also_fields"] = ["rows_per_s", "ms_per_step", "roofline_frac"]
         line["also"] = terse
         line["also_file"] = out.get("also_file")

@@ -2479,6 +2479,9 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
         void *d = nullptr;
         FG_TRY(arena_get(ctx, leaf_key(plan, input, (int)c, "pre").c_str(), (size_t)rows * w + 16, &d));
         plan->pre.dev[c] = d;
+        // the column's batches as runs: batches that continue each other in host memory (slices of one allocation -- the reference's own
+        // event_bytes_to_batch output is) travel as ONE copy (26 copies of 0.7 MB are 0.4 ms of set-up on the calling thread)
+        std::vector<flockgpu_plan::CopyJob> runs;
         size_t at = 0;
         for (int b = 0; b < n_batches; ++b) {
             const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
@@ -2487,11 +2490,17 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
             const uint8_t *src = static_cast<const uint8_t *>(a->buffers[1]) + (size_t)(a->offset + rb->offset) * w;
             uint8_t *dst = static_cast<uint8_t *>(d) + at;
             at += bytes;
-            if (host_is_pinned(src) && host_is_pinned(src + bytes - 1)) {
-                FG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, plan->copy_stream));
+            if (!runs.empty() && static_cast<const uint8_t *>(runs.back().src) + runs.back().bytes == src) runs.back().bytes += bytes;
+            else runs.push_back(flockgpu_plan::CopyJob{dst, src, bytes});
+        }
+        for (auto &r : runs) {
+            const uint8_t *src = static_cast<const uint8_t *>(r.src);
+            uint8_t *dst = static_cast<uint8_t *>(r.dst);
+            if (host_is_pinned(src) && host_is_pinned(src + r.bytes - 1)) {
+                FG_HIP(ctx, hipMemcpyAsync(dst, src, r.bytes, hipMemcpyHostToDevice, plan->copy_stream));
             } else {
-                for (size_t done = 0; done < bytes; done += kStageChunk) {
-                    const size_t n = std::min(kStageChunk, bytes - done);
+                for (size_t done = 0; done < r.bytes; done += kStageChunk) {
+                    const size_t n = std::min(kStageChunk, r.bytes - done);
                     pieces.push_back(flockgpu_plan::CopyJob{dst + done, src + done, n});
                     pageable += n;
                 }
