@@ -504,6 +504,459 @@ __global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
 
+// ---- hash path, partitioned (round 4) ------------------------------------------------------------------------------------------
+// The tables above live in global memory: every distinct seller and every selling person is a RETURNING compare-and-swap on a slot of a
+// 240 MB / 120 MB arena (~1e10 of them per second: 0.63 + 1.09 ms per 1e9 events).  Here both relations are first grouped by
+// (window, hash bucket) -- per 8192-row tile, in LDS, into the tile's own region of a side buffer: no global cursors, no atomics on global
+// memory -- with buckets small enough that one workgroup per (window, bucket) holds the bucket's DISTINCT seller set and its
+// {p_id, row} table in LDS.  All compare-and-swaps become LDS instructions; global memory sees streaming reads and writes and one
+// fire-and-forget OR per result row.  A bucket that does not fit (skewed hashes, a window of same-id persons with different names)
+// raises `err`: the host repeats the call on the global tables.
+constexpr int kPartMaxLog2 = 10;         // up to 1024 buckets per window
+constexpr int kPartMaxBuckets = 1 << kPartMaxLog2;
+constexpr int kJoinSlots = 1024;         // LDS slots of a bucket's table of FURTHER names under an id that already has a person (8 KB)
+constexpr int kJoinSellLog2 = 12, kJoinSellLog2Large = 14;   // LDS slots of a bucket's seller set {key, first person}: 4096 (32 KB: three
+                                                             // workgroups per CU), or 16384 (128 KB: one) once a call of the ctx has
+                                                             // overflowed the small one
+constexpr int kJoinProbes = 128;
+constexpr uint32_t kPartErrSellers = 1u, kPartErrPersons = 2u;
+constexpr int kJoinBlock = 512;          // threads of a (window, bucket) workgroup: three of them per CU
+constexpr int kJoinWaves = kJoinBlock / 64;
+// what the host sizes the bucket count for (averages of the largest window): the person table is then at most ~40 % full; the seller
+// set holds DISTINCT sellers, of which NEXMark has ~700 per 8192 auctions -- a window whose auctions all name different sellers needs the
+// large set
+constexpr int64_t kPartPersonsPerBucket = 1600, kPartAuctionsPerBucket = 6144;
+
+__device__ __forceinline__ uint32_t part_bucket(uint32_t k, int log2nb) { return log2nb ? (k * kFibHash) >> (32 - log2nb) : 0u; }
+__device__ __forceinline__ uint32_t part_slot(uint32_t k, int log2nb, int log2slots) {   // the hash bits below the bucket's
+    return ((k * kFibHash) >> (32 - log2nb - log2slots)) & ((1u << log2slots) - 1u);
+}
+
+// s_cnt[0 .. nb) -> its exclusive prefix, in place (nb <= 4 * kBlock); returns the total.  Ends with a barrier.
+__device__ __forceinline__ uint32_t block_excl_scan_lds(uint32_t *s_cnt, int nb, uint32_t *s_red) {
+    const int t = (int)threadIdx.x;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = t * 4 + j < nb ? s_cnt[t * 4 + j] : 0u;
+        sum += v[j];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s_red[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int w = 0; w < (t >> 6); ++w) base += s_red[w];
+    const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (t * 4 + j < nb) s_cnt[t * 4 + j] = base;
+        base += v[j];
+    }
+    __syncthreads();
+    return total;
+}
+
+// A tile's grouped list leaves LDS as 16-byte stores into the tile's region (8192 entries; what lies behind `total` is never read).
+__device__ __forceinline__ void part_copy_out_u32(const uint32_t *s_k, uint32_t total, uint32_t *dst) {
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(s_k);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = threadIdx.x; i < (total + 3) / 4; i += kBlock) dst4[i] = src4[i];
+}
+
+// Sellers of one tile: DISTINCT in an LDS set first (as q8_sellers_set_kernel; a key that finds no room there is listed as it is -- the
+// bucket's set takes duplicates), the distinct keys grouped by bucket: skeys[tile * 8192 + soff[tile][b] .. soff[tile][b + 1]).  The lane
+// whose compare-and-swap put a key into the set is the one that lists it: it takes the key's rank in its bucket right then, so the set is
+// never walked.  A wave's LDS round trips are what this pass costs (nearly every step has SOME lane with a new key): the four rows of a
+// lane's load are probed, claimed and ranked side by side.
+__global__ __launch_bounds__(kBlock) void q8_sellers_part_kernel(const int32_t *__restrict__ seller, int64_t n_rows, SegTiles st, int log2nb,
+                                                                 uint32_t *__restrict__ skeys, uint16_t *__restrict__ soff) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_set[kLdsSetSlots];   // the tile's set; later the grouped list
+    __shared__ uint32_t s_cnt[kPartMaxBuckets];
+    __shared__ uint32_t s_red[kWavesPerBlock];
+    __shared__ uint32_t s_has_m1;
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int nb = 1 << log2nb;
+    int32_t key[kFlagIters][4];
+    load_flag_tile(seller, n_rows, tr, key);
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(s_set);
+        for (int i = threadIdx.x; i < kLdsSetSlots / 4; i += kBlock) z[i] = make_uint4(kEmpty32, kEmpty32, kEmpty32, kEmpty32);
+        for (int i = threadIdx.x; i < nb; i += kBlock) s_cnt[i] = 0;
+        if (threadIdx.x == 0) s_has_m1 = 0;
+    }
+    __syncthreads();
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin), rel0 = flag_rel0();
+    uint32_t listed = 0;   // rows whose key this lane lists: it put the key into the set, or the key found no room there
+    uint16_t rank[kFlagIters][4];
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        bool live[4];
+        uint32_t first[4], old[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            live[j] = rel >= rel_lo && rel < rel_hi;
+            const uint32_t k = (uint32_t)key[it][j];
+            // the key most lanes hold (3/4 of a window's auctions name one of a few sellers) is inserted by one lane
+            const uint32_t hot = __builtin_amdgcn_readfirstlane(k);
+            const uint64_t same = __ballot(live[j] && k == hot);
+            if (live[j] && k == hot && mbcnt(same) != 0) live[j] = false;
+            if (live[j] && k == kEmpty32) {   // -1 is the empty mark of the LDS slots: kept aside
+                s_has_m1 = 1;
+                live[j] = false;
+            }
+            first[j] = s_set[live[j] ? (k * kFibHash) >> (32 - 13) : 0u];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = (uint32_t)key[it][j];
+            old[j] = first[j];
+            if (live[j] && first[j] == kEmpty32) old[j] = atomicCAS(&s_set[(k * kFibHash) >> (32 - 13)], kEmpty32, k);
+        }
+        bool mine[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = (uint32_t)key[it][j];
+            mine[j] = false;
+            rank[it][j] = 0;
+            if (!live[j]) continue;
+            bool won = first[j] == kEmpty32 && old[j] == kEmpty32, placed = won || old[j] == k;
+            if (!placed) {   // the home slot holds another key: on from the next one
+                uint32_t sl = (((k * kFibHash) >> (32 - 13)) + 1) & (kLdsSetSlots - 1);
+                for (int probe = 1; probe < kLdsSetMaxProbe; ++probe) {
+                    const uint32_t cur = s_set[sl];
+                    if (cur == k) { placed = true; break; }
+                    if (cur == kEmpty32) {
+                        const uint32_t o = atomicCAS(&s_set[sl], kEmpty32, k);
+                        if (o == kEmpty32) { placed = won = true; break; }
+                        if (o == k) { placed = true; break; }
+                    }
+                    sl = (sl + 1) & (kLdsSetSlots - 1);
+                }
+            }
+            mine[j] = won || !placed;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (mine[j]) {
+                listed |= 1u << (it * 4 + j);
+                rank[it][j] = (uint16_t)atomicAdd(&s_cnt[part_bucket((uint32_t)key[it][j], log2nb)], 1u);
+            }
+    }
+    __syncthreads();
+    uint32_t rank_m1 = 0;
+    if (threadIdx.x == 0 && s_has_m1) rank_m1 = atomicAdd(&s_cnt[part_bucket(kEmpty32, log2nb)], 1u);
+    __syncthreads();
+    const uint32_t total = block_excl_scan_lds(s_cnt, nb, s_red);   // (everyone is done with the set: its memory takes the grouped list)
+    uint16_t *off = soff + (size_t)tile * (size_t)(nb + 1);
+    for (int i = threadIdx.x; i < nb; i += kBlock) off[i] = (uint16_t)s_cnt[i];
+    if (threadIdx.x == 0) off[nb] = (uint16_t)total;
+    if (listed) {
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (listed & (1u << (it * 4 + j))) s_set[s_cnt[part_bucket((uint32_t)key[it][j], log2nb)] + rank[it][j]] = (uint32_t)key[it][j];
+    }
+    if (threadIdx.x == 0 && s_has_m1) s_set[s_cnt[part_bucket(kEmpty32, log2nb)] + rank_m1] = kEmpty32;
+    __syncthreads();
+    part_copy_out_u32(s_set, total, skeys + (size_t)tile * kFlagTile);
+}
+
+// Persons of one tile grouped by bucket: {p_id, row within the tile} at pkeys / prel[tile * 8192 + poff[tile][b] ..).  Also zeroes the
+// tile's flag BYTES, one per row (the bucket workgroups set the result rows': plain stores -- 1e7 agent-scope ORs into flag words cost
+// 0.12 ms per 1e9 events; the bytes are packed into flag words by q8_flag_pack_kernel).
+__global__ __launch_bounds__(kBlock) void q8_persons_part_kernel(const int32_t *__restrict__ p_id, int64_t n_rows, SegTiles st, int log2nb,
+                                                                 uint32_t *__restrict__ pkeys, uint16_t *__restrict__ prel,
+                                                                 uint16_t *__restrict__ poff, uint8_t *__restrict__ flag_bytes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_k[kFlagTile];
+    __shared__ __attribute__((aligned(16))) uint16_t s_r[kFlagTile];
+    __shared__ uint32_t s_cnt[kPartMaxBuckets];
+    __shared__ uint32_t s_red[kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int nb = 1 << log2nb;
+    int32_t key[kFlagIters][4];
+    load_flag_tile(p_id, n_rows, tr, key);
+    for (int i = threadIdx.x; i < nb; i += kBlock) s_cnt[i] = 0;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(flag_bytes + (size_t)tile * kFlagTile);
+        z[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        z[threadIdx.x + kBlock] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin), rel0 = flag_rel0();
+    uint16_t rank[kFlagIters][4];
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            rank[it][j] = 0;
+            if (rel >= rel_lo && rel < rel_hi) rank[it][j] = (uint16_t)atomicAdd(&s_cnt[part_bucket((uint32_t)key[it][j], log2nb)], 1u);
+        }
+    __syncthreads();
+    const uint32_t total = block_excl_scan_lds(s_cnt, nb, s_red);
+    uint16_t *off = poff + (size_t)tile * (size_t)(nb + 1);
+    for (int i = threadIdx.x; i < nb; i += kBlock) off[i] = (uint16_t)s_cnt[i];
+    if (threadIdx.x == 0) off[nb] = (uint16_t)total;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t rel = rel0 + it * 256 + j;
+            if (rel >= rel_lo && rel < rel_hi) {
+                const uint32_t pos = s_cnt[part_bucket((uint32_t)key[it][j], log2nb)] + rank[it][j];
+                s_k[pos] = (uint32_t)key[it][j];
+                s_r[pos] = (uint16_t)rel;
+            }
+        }
+    __syncthreads();
+    part_copy_out_u32(s_k, total, pkeys + (size_t)tile * kFlagTile);
+    {
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(s_r);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(prel + (size_t)tile * kFlagTile);
+        for (uint32_t i = threadIdx.x; i < (total + 7) / 8; i += kBlock) dst4[i] = src4[i];
+    }
+}
+
+// The runs of bucket `b` in up to kJoinChunk consecutive tiles [t0, t1) as ONE index space: pref = exclusive prefix of the run lengths
+// (pref[n .. kJoinChunk] = the total), o0 = where each run begins in its tile's region.  Loading a chunk's offsets and publishing them are
+// two steps, so that both relations' offsets travel together.
+constexpr int kJoinChunk = 256;   // tiles of one relation a workgroup indexes at a time
+constexpr int kJoinPre = 4;       // person entries per thread requested BEFORE the sellers are inserted (4 x 512: an average bucket whole)
+struct PartRun {
+    uint32_t len, o0;
+};
+__device__ __forceinline__ PartRun part_run_load(const uint16_t *__restrict__ offs, int nb, int b, int32_t t0, int32_t n) {
+    PartRun r{0u, 0u};
+    if ((int32_t)threadIdx.x < n) {
+        const uint16_t *o = offs + (size_t)(t0 + (int32_t)threadIdx.x) * (size_t)(nb + 1) + b;
+        r.o0 = o[0];
+        r.len = (uint32_t)o[1] - r.o0;
+    }
+    return r;
+}
+// Returns the entries of the chunk; ends with a barrier.
+__device__ __forceinline__ uint32_t part_run_publish(const PartRun &r, uint32_t *pref, uint16_t *o0, uint32_t *s_red) {
+    const uint32_t incl = wave_incl_scan_u32(r.len);
+    if (lane_id() == 63) s_red[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kJoinWaves; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += s_red[w];
+        total += s_red[w];
+    }
+    if (threadIdx.x < kJoinChunk) {
+        pref[threadIdx.x] = base + incl - r.len;
+        o0[threadIdx.x] = (uint16_t)r.o0;
+    }
+    if (threadIdx.x == 0) pref[kJoinChunk] = total;
+    __syncthreads();
+    return total;
+}
+// entry e of the chunk -> the run it lies in (the last i < n with pref[i] <= e: a run of no entries is never chosen)
+__device__ __forceinline__ int part_find_run(const uint32_t *pref, int n, uint32_t e) {
+    int lo = 0, hi = n;   // pref[lo] <= e < pref[hi]
+    while (hi - lo > 1) {   // (the same trips for every lane)
+        const int mid = (lo + hi) >> 1;
+        if (pref[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One workgroup per (window, bucket): the bucket's distinct sellers into an LDS set, then every person of the bucket -- is its id in
+// the set?  then DISTINCT (p_id, name) by claiming a slot of the LDS table keyed p_id (names compared with the claimant's in global
+// memory: only for persons that share an id) -- and the first claimant's row flag is set.  A workgroup's life is a chain of memory
+// round trips, so both relations' offsets are requested first and together, and the persons' keys and rows are on their way while the
+// sellers are inserted.
+__global__ __launch_bounds__(kJoinBlock) void q8_bucket_join_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ name_off,
+                                                                    const uint8_t *__restrict__ name, SegTiles st_a, SegTiles st_p, int log2nb,
+                                                                    const uint32_t *__restrict__ skeys, const uint16_t *__restrict__ soff,
+                                                                    const uint32_t *__restrict__ pkeys, const uint16_t *__restrict__ prel,
+                                                                    const uint16_t *__restrict__ poff, uint8_t *__restrict__ flag_bytes,
+                                                                    int log2sell, uint32_t *err) {
+    extern __shared__ uint32_t s_sell[];   // 1 << log2sell keys, then as many + 1 rows: the first person seen under the key (the last: under -1)
+    __shared__ uint64_t s_pers[kJoinSlots];
+    __shared__ uint32_t ss_pref[kJoinChunk + 1], sp_pref[kJoinChunk + 1], sp_tbeg[kJoinChunk];
+    __shared__ uint16_t ss_o0[kJoinChunk], sp_o0[kJoinChunk];
+    __shared__ uint32_t s_red[kJoinWaves];
+    __shared__ uint32_t s_m1;
+    const int nb = 1 << log2nb;
+    const int32_t w = (int32_t)(blockIdx.x >> log2nb), b = (int32_t)(blockIdx.x & (uint32_t)(nb - 1));
+    const int32_t ta0 = st_a.tile_first[w], ta1 = st_a.tile_first[w + 1], tp0 = st_p.tile_first[w], tp1 = st_p.tile_first[w + 1];
+    if (ta0 == ta1 || tp0 == tp1) return;   // no auctions: nobody sells; no persons: nothing to flag (the flag words are zero)
+    const int32_t na0 = ta1 - ta0 < kJoinChunk ? ta1 - ta0 : kJoinChunk, np0 = tp1 - tp0 < kJoinChunk ? tp1 - tp0 : kJoinChunk;
+    const PartRun rs0 = part_run_load(soff, nb, b, ta0, na0);
+    const PartRun rp0 = part_run_load(poff, nb, b, tp0, np0);
+    if ((int32_t)threadIdx.x < np0) sp_tbeg[threadIdx.x] = (uint32_t)st_p.tiles[tp0 + (int32_t)threadIdx.x].tile_begin;   // (rows < 2^31)
+    const uint32_t sell_mask = (1u << log2sell) - 1u;
+    uint32_t *s_own = s_sell + (1 << log2sell);
+    for (int i = threadIdx.x; i < (2 << log2sell) + 1; i += kJoinBlock) s_sell[i] = kEmpty32;
+    for (int i = threadIdx.x; i < kJoinSlots; i += kJoinBlock) s_pers[i] = kEmpty64;
+    if (threadIdx.x == 0) s_m1 = 0;
+    const uint32_t tot_s0 = part_run_publish(rs0, ss_pref, ss_o0, s_red);   // (the barriers also cover the tables' initialisation)
+    const uint32_t tot_p0 = part_run_publish(rp0, sp_pref, sp_o0, s_red);
+    uint32_t pk[kJoinPre], pr[kJoinPre], pt[kJoinPre];   // key, row within the tile | index of the tile in the chunk << 16
+#pragma unroll
+    for (int j = 0; j < kJoinPre; ++j) {
+        const uint32_t e = threadIdx.x + j * kJoinBlock;
+        pk[j] = pr[j] = pt[j] = 0;
+        if (e < tot_p0) {
+            const int i = part_find_run(sp_pref, np0, e);
+            const uint64_t at = (uint64_t)(tp0 + i) * kFlagTile + sp_o0[i] + (e - sp_pref[i]);
+            pk[j] = pkeys[at];
+            pr[j] = prel[at];
+            pt[j] = (uint32_t)i;
+        }
+    }
+    uint32_t bad = 0;
+    for (int32_t c0 = ta0; c0 < ta1; c0 += kJoinChunk) {
+        const int32_t n = ta1 - c0 < kJoinChunk ? ta1 - c0 : kJoinChunk;
+        uint32_t total = tot_s0;
+        if (c0 != ta0) {
+            __syncthreads();   // (everyone is done with the previous chunk's index)
+            total = part_run_publish(part_run_load(soff, nb, b, c0, n), ss_pref, ss_o0, s_red);
+        }
+        for (uint32_t e0 = threadIdx.x; e0 < total; e0 += kJoinPre * kJoinBlock) {   // kJoinPre keys requested together, then inserted
+            uint32_t sk[kJoinPre];
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                const uint32_t e = e0 + j * kJoinBlock;
+                sk[j] = kEmpty32;
+                if (e < total) {
+                    const int i = part_find_run(ss_pref, n, e);
+                    sk[j] = skeys[(uint64_t)(c0 + i) * kFlagTile + ss_o0[i] + (e - ss_pref[i])];
+                    if (sk[j] == kEmpty32) s_m1 = 1;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kJoinPre; ++j) {
+                const uint32_t k = sk[j];
+                if (k == kEmpty32) continue;
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(Q8_JSTOP)
+                if (Q8_JSTOP == 1) { if (k == 0x1234567u) s_m1 = 2; continue; }
+#endif
+                uint32_t sl = part_slot(k, log2nb, log2sell);
+                bool placed = false;
+                for (int probe = 0; probe < kJoinProbes; ++probe) {
+                    const uint32_t cur = s_sell[sl];
+                    if (cur == k) { placed = true; break; }
+                    if (cur == kEmpty32) {
+                        const uint32_t old = atomicCAS(&s_sell[sl], kEmpty32, k);
+                        if (old == kEmpty32 || old == k) { placed = true; break; }
+                    }
+                    sl = (sl + 1) & sell_mask;
+                }
+                if (!placed) bad |= kPartErrSellers;
+            }
+        }
+    }
+    __syncthreads();   // the set is complete
+    // The slot of the id in the set, or -1.  `first` = what the key's home slot held (read by the caller, several persons' at once).
+    auto seller_slot = [&](uint32_t k, uint32_t first) -> int32_t {
+        if (k == kEmpty32) return s_m1 ? (int32_t)(1 << log2sell) : -1;
+        uint32_t sl = part_slot(k, log2nb, log2sell), cur = first;
+        for (int probe = 0; probe < kJoinProbes; ++probe) {
+            if (cur == k) return (int32_t)sl;
+            if (cur == kEmpty32) return -1;
+            sl = (sl + 1) & sell_mask;
+            cur = s_sell[sl];
+        }
+        return -1;   // (a run this long has raised the sellers' error bit when it was built)
+    };
+    // DISTINCT (p_id, name) of a person that sells.  The FIRST person seen under an id owns the id's slot of the set (one compare-and-swap
+    // at a slot that is already known: nothing to probe) -- `owner` = what that compare-and-swap returned.  Another person under the same
+    // id is compared with the owner's name; a different name goes through the small table of further names.
+    auto settle = [&](uint32_t k, uint32_t rel, int32_t tile, uint32_t row, uint32_t owner) {
+        bool unique = owner == kEmpty32;
+        if (!unique && !same_person(p_id, name_off, name, (int64_t)row, (int64_t)owner)) {
+            const uint64_t mine = ((uint64_t)k << 32) | row;
+            uint32_t sl = part_slot(k, log2nb, 10);
+            bool done = false;
+#pragma unroll 1
+            for (int probe = 0; probe < kJoinProbes; ++probe) {
+                uint64_t cur = __hip_atomic_load(&s_pers[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == kEmpty64) {
+                    cur = atomicCAS(reinterpret_cast<unsigned long long *>(&s_pers[sl]), (unsigned long long)kEmpty64, (unsigned long long)mine);
+                    if (cur == kEmpty64) {
+                        unique = done = true;
+                        break;
+                    }
+                }
+                if ((uint32_t)(cur >> 32) == k && same_person(p_id, name_off, name, (int64_t)row, (int64_t)(uint32_t)cur)) {
+                    done = true;   // duplicate of an earlier claimant
+                    break;
+                }
+                sl = (sl + 1) & (uint32_t)(kJoinSlots - 1);
+            }
+            if (!done) bad |= kPartErrPersons;
+        }
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(Q8_JSTOP)
+        if (Q8_JSTOP == 3) { if (unique && rel == 0xFFFFFu) atomicOr(err, 4u); return; }
+#endif
+        if (unique) flag_bytes[(size_t)tile * kFlagTile + rel] = 1;
+    };
+    {   // the requested entries: every stage for all of them together (LDS round trips in flight side by side)
+        int32_t slot[kJoinPre];
+        uint32_t first[kJoinPre], owner[kJoinPre];
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j) {
+            slot[j] = threadIdx.x + j * kJoinBlock < tot_p0 ? 0 : -1;
+            first[j] = s_sell[slot[j] == 0 && pk[j] != kEmpty32 ? part_slot(pk[j], log2nb, log2sell) : 0u];
+        }
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j)
+            if (slot[j] == 0) slot[j] = seller_slot(pk[j], first[j]);
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(Q8_JSTOP)
+        if (Q8_JSTOP == 2) {
+            uint32_t c_ = 0;
+            for (int j = 0; j < kJoinPre; ++j) c_ += slot[j] >= 0;
+            if (c_ == 77u) atomicOr(err, 4u);
+            return;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j) owner[j] = slot[j] >= 0 ? atomicCAS(&s_own[slot[j]], kEmpty32, sp_tbeg[pt[j]] + pr[j]) : 0u;
+#pragma unroll
+        for (int j = 0; j < kJoinPre; ++j)
+            if (slot[j] >= 0) settle(pk[j], pr[j], tp0 + (int32_t)pt[j], sp_tbeg[pt[j]] + pr[j], owner[j]);
+    }
+    for (int32_t c0 = tp0; c0 < tp1; c0 += kJoinChunk) {
+        const int32_t n = tp1 - c0 < kJoinChunk ? tp1 - c0 : kJoinChunk;
+        uint32_t total = tot_p0, e = threadIdx.x + kJoinPre * kJoinBlock;   // (chunk 0: what lies beyond the requested entries)
+        if (c0 != tp0) {
+            __syncthreads();
+            if ((int32_t)threadIdx.x < n) sp_tbeg[threadIdx.x] = (uint32_t)st_p.tiles[c0 + (int32_t)threadIdx.x].tile_begin;
+            total = part_run_publish(part_run_load(poff, nb, b, c0, n), sp_pref, sp_o0, s_red);
+            e = threadIdx.x;
+        }
+        for (; e < total; e += kJoinBlock) {
+            const int i = part_find_run(sp_pref, n, e);
+            const uint64_t at = (uint64_t)(c0 + i) * kFlagTile + sp_o0[i] + (e - sp_pref[i]);
+            const uint32_t k = pkeys[at], rel = prel[at];
+            const int32_t sl = seller_slot(k, k != kEmpty32 ? s_sell[part_slot(k, log2nb, log2sell)] : 0u);
+            if (sl >= 0) settle(k, rel, c0 + i, sp_tbeg[i] + rel, atomicCAS(&s_own[sl], kEmpty32, sp_tbeg[i] + rel));
+        }
+    }
+    if (bad) atomicOr(err, bad);
+}
+
+// One flag byte per row -> the flag words and wave counts of scan.hpp's flag tiles (what the tile scan and the row emit read).
+__global__ __launch_bounds__(kBlock) void q8_flag_pack_kernel(const uint8_t *__restrict__ flag_bytes, uint32_t *__restrict__ flag_words,
+                                                              uint32_t *__restrict__ counts) {
+    const uint32_t *b4 = reinterpret_cast<const uint32_t *>(flag_bytes + (size_t)blockIdx.x * kFlagTile + flag_rel0());
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const uint32_t v = b4[it * 64];   // the lane's four rows of this 256-row group, a byte each (0 or 1)
+        flags |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (it * 4);
+    }
+    store_flags_and_counts(flags, (int32_t)blockIdx.x, flag_words, counts);
+}
+
 // Range path: the persons arrive in any order, so "every flagged row is a DISTINCT (p_id, name)" is not given -- it holds when no
 // two flagged persons of a window share an id, i.e. when the window's flagged ROWS are as many as the ids present in BOTH bitmaps
 // (sellers S, persons P; both built with fire-and-forget ORs).  One workgroup per window counts popc(S & P) and compares; a window
@@ -1180,7 +1633,93 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
             rows_hint[0] = n_out + n_out / 8 + 4096;
         }
     }
-    if (mode == 0) {
+    bool parted = false;
+    if (mode == 0 && st_a.n_tiles > 0 && st_p.n_tiles > 0) {
+        // ---- the hash path with both relations grouped by (window, hash bucket): every table in LDS (kernels above).  The bucket count
+        // is sized for the LARGEST window's averages; a bucket that overflows its LDS tables voids the attempt (the global tables
+        // below decide) and keeps this ctx off the partitioned path for a while.
+        std::vector<int64_t> &skip = ctx->host_i64["q8.part_skip"];
+        if (skip.empty()) skip.push_back(0);
+        int log2nb = 0;
+        while (log2nb < kPartMaxLog2 && ((max_p >> log2nb) > kPartPersonsPerBucket || (max_a >> log2nb) > kPartAuctionsPerBucket)) ++log2nb;
+        const bool fits = (max_p >> log2nb) <= kPartPersonsPerBucket && (max_a >> log2nb) <= kPartAuctionsPerBucket &&
+                          ((int64_t)n_win << log2nb) < (int64_t(1) << 30) && (reinterpret_cast<uintptr_t>(person->name.offsets) & 3) == 0;
+        std::vector<int64_t> &large = ctx->host_i64["q8.part_large_set"];   // a call of this ctx needed the large seller set
+        if (large.empty()) large.push_back(0);
+        if (skip[0] > 0) {
+            --skip[0];
+        } else if (fits) {
+            const int nb = 1 << log2nb;
+            uint32_t *skeys = nullptr, *pkeys = nullptr, *d_err = nullptr;
+            uint16_t *soff = nullptr, *poff = nullptr, *prel = nullptr;
+            uint8_t *flag_bytes = nullptr;
+            FG_TRY(arena_get_t(ctx, "q8.part_skeys", (size_t)st_a.n_tiles * kFlagTile, &skeys));
+            FG_TRY(arena_get_t(ctx, "q8.part_soff", (size_t)st_a.n_tiles * (size_t)(nb + 1) + 8, &soff));
+            FG_TRY(arena_get_t(ctx, "q8.part_pkeys", (size_t)st_p.n_tiles * kFlagTile, &pkeys));
+            FG_TRY(arena_get_t(ctx, "q8.part_prel", (size_t)st_p.n_tiles * kFlagTile, &prel));
+            FG_TRY(arena_get_t(ctx, "q8.part_poff", (size_t)st_p.n_tiles * (size_t)(nb + 1) + 8, &poff));
+            FG_TRY(arena_get_t(ctx, "q8.part_flag_bytes", (size_t)st_p.n_tiles * kFlagTile, &flag_bytes));
+            FG_TRY(arena_get_t(ctx, "q8.err", 4, &d_err));
+            FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+            {
+                LaunchScope ls(ctx, "q8_sellers_part_kernel");
+                hipLaunchKernelGGL(q8_sellers_part_kernel, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream, auction->seller, auction->rows, st_a,
+                                   log2nb, skeys, soff);
+            }
+            FG_TRY(check_launch(ctx, "q8_sellers_part_kernel"));
+            {
+                LaunchScope ls(ctx, "q8_persons_part_kernel");
+                hipLaunchKernelGGL(q8_persons_part_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->p_id, person->rows, st_p, log2nb,
+                                   pkeys, prel, poff, flag_bytes);
+            }
+            FG_TRY(check_launch(ctx, "q8_persons_part_kernel"));
+            std::vector<int64_t> &rows_hint = ctx->host_i64["q8.rows_hint"];
+            if (rows_hint.empty()) rows_hint.push_back(0);
+            const int64_t take_rows = rows_hint[0] > 0 ? std::min<int64_t>(out_cap - 16, rows_hint[0]) : out_cap - 16;
+            uint32_t perr = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const int log2sell = large[0] ? kJoinSellLog2Large : kJoinSellLog2;
+                const size_t lds_bytes = sizeof(uint32_t) * ((size_t(2) << log2sell) + 4);
+                if (large[0])
+                    FG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&q8_bucket_join_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)lds_bytes));
+                {
+                    LaunchScope ls(ctx, "q8_bucket_join_kernel");
+                    hipLaunchKernelGGL(q8_bucket_join_kernel, dim3((unsigned)((int64_t)n_win << log2nb)), dim3(kJoinBlock), lds_bytes, ctx->stream, person->p_id, person->name.offsets, person->name.data, st_a, st_p, log2nb, skeys, soff, pkeys, prel,
+                                       poff, flag_bytes, log2sell, d_err);
+                }
+                FG_TRY(check_launch(ctx, "q8_bucket_join_kernel"));
+                hipLaunchKernelGGL(q8_flag_pack_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, flag_bytes, flag_words, counts);
+                FG_TRY(check_launch(ctx, "q8_flag_pack_kernel"));
+                FG_TRY(launch_tile_scan(ctx, counts, st_p.n_tiles, tile_base, st_p.tile_first, st_p.n_seg, d_off));
+                FG_TRY(emit_flagged_rows(ctx, st_p, flag_words, counts, tile_base, o_pr));
+                FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, take_rows, &g_name, tile_base + st_p.n_tiles));
+                FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));
+                FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                perr = *reinterpret_cast<uint32_t *>(h_off + n_win + 1);
+                if (perr != kPartErrSellers || large[0]) break;
+                // only seller sets overflowed, and only the small ones were tried: the grouped lists stand, the join alone runs again
+                large[0] = 1;
+                FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+                FG_HIP(ctx, hipMemsetAsync(flag_bytes, 0, (size_t)st_p.n_tiles * kFlagTile, ctx->stream));
+            }
+            if (perr) {
+                skip[0] = 16;
+            } else {
+                offs.assign(h_off, h_off + n_win + 1);
+                n_out = offs[n_win];
+                if (n_out > take_rows) {
+                    FG_TRY(gather_utf8_begin(ctx, "q8.out_name", person->name, o_pr, n_out, &g_name, nullptr));
+                    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                gather_utf8_narrow(&g_name, n_out);
+                rows_hint[0] = n_out + n_out / 8 + 4096;
+                parted = true;
+            }
+        }
+    }
+    if (mode == 0 && !parted) {
         const uint64_t pcap64 = std::max<uint64_t>(64, (uint64_t)max_p * 3 / 2 + 8);
         if (pcap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q8: window too large");
         const uint32_t pcap = (uint32_t)pcap64;

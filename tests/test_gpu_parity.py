@@ -783,6 +783,95 @@ def test_q8_three_launch_sequence_and_the_range_path():
     c.close()
 
 
+def _q8_part_log2(max_p, max_a):
+    """The bucket count q8.hip's partitioned hash path picks (kPartPersonsPerBucket / kPartAuctionsPerBucket)."""
+    l = 0
+    while l < 10 and ((max_p >> l) > 1600 or (max_a >> l) > 6144):
+        l += 1
+    return l
+
+
+def _q8_part_bucket(k, log2nb):
+    return ((np.asarray(k).astype(np.uint32) * np.uint32(0x9E3779B1)) >> np.uint32(32 - log2nb)).astype(np.int64)
+
+
+def test_q8_hash_path_grouped_by_bucket():
+    """Ids over the whole int32 range in no order (no bitmap is affordable): both relations are grouped by (window, hash bucket), every
+    bucket's DISTINCT seller set and {p_id, row} table live in LDS (q8_sellers_part / q8_persons_part / q8_bucket_join kernels).
+    Duplicates (same id and name), persons that share an id under different names, the keys -1 / INT_MIN / INT_MAX on both sides, a hot
+    seller, windows without persons or without auctions, ragged tiles, one bucket and many buckets -- and a bucket that does NOT fit
+    its LDS tables: seller sets that overflow are built again four times as large; a person table that overflows voids the attempt,
+    the global tables answer, and the ctx stays off the partitioned path for a while."""
+    from flock_amd import Auctions, GpuContext, Persons, WindowSchedule
+    c = GpuContext(0)
+    rng = np.random.default_rng(33)
+
+    def run(p_id, nm, seller, pw, aw, tag, expect):
+        name = oracle.Utf8(np.concatenate([[0], np.cumsum([len(x) for x in nm])]).astype(np.int32),
+                           np.frombuffer(b"".join(nm) or b"\0", np.uint8).copy())
+        per = Persons(_dev(p_id), _utf8(name), None, None, len(p_id))
+        auc = Auctions(None, _dev(seller), None, len(seller))
+        c.profile_reset()
+        c.profile(True)
+        out = c.q8_join(per, pw, auc, aw).to_host()
+        st = c.profile_read()
+        c.profile(False)
+        total = _q8_check(out, pw, aw, p_id, name, nm, seller, tag)
+        for k, want in expect.items():
+            assert (k in st) == want, (tag, k, sorted(st))
+        return total
+
+    for npn, na, bounds_p, bounds_a in ((3_000, 9_000, [0, 1_000, 1_000, 2_200, 3_000], [0, 4_001, 6_000, 6_000, 9_000]),            # one bucket
+                                        (140_000, 400_000, [0, 50_000, 50_000, 95_001, 140_000], [0, 150_001, 230_000, 230_000, 400_000])):
+        pw = WindowSchedule(np.array(bounds_p), np.arange(4), np.arange(1, 5))        # window 1: no persons
+        aw = WindowSchedule(np.array(bounds_a), np.arange(4), np.arange(1, 5))        # window 2: no auctions
+        p_id = rng.integers(-2**31, 2**31 - 1, npn).astype(np.int32)
+        p_id[5:npn:97] = p_id[4:npn - 1:97]                                          # neighbours share an id ...
+        nm = [b"who-%d" % (i % 3989) if i % 13 else b"" for i in range(npn)]
+        for i in range(5, npn, 194):
+            nm[i] = nm[i - 1]                                                         # ... half of them under the same name: duplicates
+        p_id[[7, 8, npn - 1]] = [-1, -2**31, 2**31 - 1]
+        p_id[npn - 2] = -1                                                            # -1 twice in the last window, different names
+        seller = rng.choice(p_id, na).astype(np.int32)
+        seller[::9] = rng.integers(-2**31, 2**31 - 1, len(seller[::9])).astype(np.int32)
+        seller[500:na // 3:2] = p_id[321]
+        seller[[11, na - 1, na - 2]] = [-1, -1, 2**31 - 1]
+        seller[12] = -2**31
+        for rep in range(2):
+            total = run(p_id, nm, seller, pw, aw, (npn, rep), {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": False})
+            assert total > 500
+    # buckets that do not fit: 6000 distinct sellers of ONE bucket in one window (more than the small seller set's 4096 slots), and --
+    # second data set -- one id under 300 names (a chain the person table's bounded probing gives up on)
+    npn, na = 60_000, 100_000
+    pw = WindowSchedule(np.array([0, 30_000, npn]), np.arange(2), np.arange(1, 3))
+    aw = WindowSchedule(np.array([0, 50_000, na]), np.arange(2), np.arange(1, 3))
+    log2nb = _q8_part_log2(30_000, 50_000)
+    assert log2nb >= 4
+    pool = rng.integers(-2**31, 2**31 - 1, 400_000).astype(np.int32)
+    crowd = np.unique(pool[_q8_part_bucket(pool, log2nb) == 3])[:6000]
+    assert len(crowd) == 6000
+    for case in ("crowded_bucket", "one_id_many_names"):
+        p_id = rng.integers(-2**31, 2**31 - 1, npn).astype(np.int32)
+        nm = [b"n%d" % i for i in range(npn)]
+        seller = rng.choice(p_id, na).astype(np.int32)
+        if case == "crowded_bucket":
+            seller[:6000] = crowd
+            p_id[1000:1500] = crowd[:500]
+        else:
+            p_id[1000:1300] = 424242                                                   # (a chain the LDS table's bounded probing gives up on)
+            seller[77] = 424242
+        if case == "crowded_bucket":      # the join alone is repeated with the large seller sets, which this ctx then keeps
+            first = later = {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": False}
+        else:
+            first = {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": True}      # tried, void, answered by the global tables
+            later = {"q8_bucket_join_kernel": False, "q8_persons_general_kernel": True}     # not tried again right away
+        assert run(p_id, nm, seller, pw, aw, (case, 0), first) > 300
+        assert run(p_id, nm, seller, pw, aw, (case, 1), later) > 300
+        c.close()
+        c = GpuContext(0)
+    c.close()
+
+
 def test_q3_range_path_ids_in_any_order():
     """q3 with the persons' ids shuffled inside every window (dense range, no order): the row table laid out from exact statistics
     (q3.hip "RANGE path"); duplicates in a window void it for the hash join; gapless data afterwards returns to the bit blocks."""
