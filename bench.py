@@ -797,7 +797,7 @@ def alternating_entry(gpu, q, eps, steps):
 #   *_hash: keys SPREAD (id -> id * 1009 inside int32: a range no bitmap or row table can afford) and shuffled: the hash join / hash
 #     set kernels themselves -- exact for any input, and measured so that this fall-back stays a number.
 GENERAL = {"q3_general": (3, 1000, "q3_probe_flag_kernel", 8.0, "auction", "shuffle"), "q8_general": (8, 1000, "q8_sellers_bitmap_kernel", 4.0, "auction", "shuffle"),
-           "q5_uniform": (5, 1087, "q5_part_emit_kernel", 8.0, "bid", "shuffle"),     # the partition's emit pass: every key read and written once
+           "q5_uniform": (5, 1087, "q5_part_tile_kernel", 6.0, "bid", "shuffle"),     # the partition pass: every key read (4 B) and written as its 16 low bits (2 B)
            "q3_hash": (3, 1000, "q3_probe_count_kernel", 8.0, "auction", "spread"), "q8_hash": (8, 1000, "q8_sellers_part_kernel", 4.0, "auction", "spread")}
 
 

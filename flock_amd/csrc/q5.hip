@@ -1066,61 +1066,95 @@ __device__ __forceinline__ uint32_t part_digit(int32_t key, const PaneDesc &pd, 
     return idx < (uint64_t)pd.range ? (uint32_t)(idx >> kPartShift) : straggler;
 }
 
-// hist[(tile_first[pane] * nd) + digit * tiles_of_pane + tile_in_pane]
-__global__ __launch_bounds__(kBlock) void q5_part_count_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
-                                                               const int32_t *__restrict__ pane_win_ptr, uint32_t nd, int32_t *__restrict__ hist,
-                                                               uint32_t *__restrict__ sample) {
-    __shared__ uint32_t s_h[kPartMaxDigits];
+// Round 4: the partition keeps every tile's rows in the tile's OWN region of the side buffer -- grouped by digit there, with the digits'
+// start offsets in a small matrix  off[(tile_first[pane] * (nd + 1)) + digit * tiles_of_pane + tile_in_pane]  (row nd: the tile's rows) --
+// so no output position depends on another tile: the count pass over the column (0.93 ms per 1e9 bids), the scan of its histogram matrix
+// and the ballot matching that kept rows in order are gone (COUNT does not care in which order a bucket's rows arrive: a row's rank in
+// its digit is what one returning LDS add says).  A bucket's workgroup reads its digit's row of the matrix and the next one -- both
+// contiguous -- and streams the runs they delimit.
+__global__ __launch_bounds__(kBlock) void q5_part_tile_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
+                                                              const int32_t *__restrict__ pane_win_ptr, uint32_t nd, int32_t *__restrict__ off_mat,
+                                                              int32_t *__restrict__ keys_out, uint16_t *__restrict__ low_out,
+                                                              uint32_t *__restrict__ sample) {
+    __shared__ uint32_t s_cnt[kPartMaxDigits];
+    __shared__ __attribute__((aligned(16))) uint16_t s_low[kPartTile];
+    __shared__ uint32_t s_wave_total[kWavesPerBlock];
     __shared__ int32_t s_red[2 * kWavesPerBlock];
-    s_h[threadIdx.x] = 0;
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kPartTile);
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    s_cnt[threadIdx.x] = 0;
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kPartTile);
+    if (pane_win_ptr[tr.seg] == pane_win_ptr[tr.seg + 1]) return;   // (block-uniform) the pane is in no window: its buckets are not counted
     const int32_t t0 = st.tile_first[tr.seg], tiles_p = st.tile_first[tr.seg + 1] - t0;
-    int32_t *out = hist + (size_t)t0 * nd + ((int32_t)blockIdx.x - t0);
-    const bool used = pane_win_ptr[tr.seg] != pane_win_ptr[tr.seg + 1];
+    int32_t *off = off_mat + (size_t)t0 * (nd + 1) + (tile - t0);
     const PaneDesc pd = panes[tr.seg];
-    __syncthreads();
-    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
-    if (used) {
+    int32_t k[kPartItems];
 #pragma unroll
-        for (int it = 0; it < kPartItems / 4; ++it) {
-            const int64_t r0 = tr.tile_begin + (int64_t)(it * kBlock + threadIdx.x) * 4;
-            int32_t k[4];
-            if (r0 >= tr.lo && r0 + 4 <= tr.hi) {
-                const int4 t = *reinterpret_cast<const int4 *>(auction + r0);
-                k[0] = t.x; k[1] = t.y; k[2] = t.z; k[3] = t.w;
-            } else {
+    for (int it = 0; it < kPartItems / 4; ++it) {
+        const int64_t r0 = tr.tile_begin + (int64_t)(it * kBlock + threadIdx.x) * 4;
+        if (r0 >= tr.lo && r0 + 4 <= tr.hi) {
+            const int4 t = stream_load4(auction + r0);
+            k[it * 4 + 0] = t.x; k[it * 4 + 1] = t.y; k[it * 4 + 2] = t.z; k[it * 4 + 3] = t.w;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) k[j] = (r0 + j >= tr.lo && r0 + j < tr.hi) ? auction[r0 + j] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool valid = r0 + j >= tr.lo && r0 + j < tr.hi;
-                const uint32_t d = part_digit(k[j], pd, nd - 1);
-                if (valid) {
-                    mn = min(mn, k[j]);
-                    mx = max(mx, k[j]);
-                }
-                const uint32_t hot = __builtin_amdgcn_readfirstlane(d);
-                const uint64_t b = __ballot(valid && d == hot);
-                if (valid && d == hot) {
-                    if (mbcnt(b) == 0) atomicAdd(&s_h[hot], (uint32_t)__popcll((unsigned long long)b));
-                } else if (valid) {
-                    atomicAdd(&s_h[d], 1u);
-                }
-            }
+            for (int j = 0; j < 4; ++j) k[it * 4 + j] = (r0 + j >= tr.lo && r0 + j < tr.hi) ? auction[r0 + j] : 0;
         }
     }
     __syncthreads();
-    if (threadIdx.x < nd) out[(size_t)threadIdx.x * tiles_p] = (int32_t)s_h[threadIdx.x];
+    uint16_t rank[kPartItems];
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        const int64_t r = tr.tile_begin + (int64_t)((i >> 2) * kBlock + threadIdx.x) * 4 + (i & 3);
+        rank[i] = 0;
+        if (r >= tr.lo && r < tr.hi) {
+            rank[i] = (uint16_t)atomicAdd(&s_cnt[part_digit(k[i], pd, nd - 1)], 1u);
+            mn = min(mn, k[i]);
+            mx = max(mx, k[i]);
+        }
+    }
+    __syncthreads();
+    {   // thread d: where digit d's rows start in the tile
+        const uint32_t c = s_cnt[threadIdx.x];
+        const uint32_t in = wave_incl_scan_u32(c);
+        if (lane == 63) s_wave_total[wave] = in;
+        __syncthreads();
+        uint32_t o = in - c;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) o += w < wave ? s_wave_total[w] : 0u;
+        s_cnt[threadIdx.x] = o;
+        if (threadIdx.x < nd) off[(size_t)threadIdx.x * tiles_p] = (int32_t)o;
+        if (threadIdx.x == 0) off[(size_t)nd * tiles_p] = (int32_t)(tr.hi - tr.lo);
+    }
+    __syncthreads();
+    // Inside a bucket only the key's low kPartShift bits are news (the digit IS the bucket), so a partitioned key travels as 16 bits.  The
+    // straggler bucket -- keys outside the pane's estimated range -- keeps whole keys, in the int32 array at the same positions (touched
+    // only where stragglers sit).
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        const int64_t r = tr.tile_begin + (int64_t)((i >> 2) * kBlock + threadIdx.x) * 4 + (i & 3);
+        if (r >= tr.lo && r < tr.hi) {
+            const uint32_t d = part_digit(k[i], pd, nd - 1), pos = s_cnt[d] + rank[i];
+            if (d == nd - 1) keys_out[(size_t)tile * kPartTile + pos] = k[i];
+            else s_low[pos] = (uint16_t)(((uint32_t)k[i] - (uint32_t)pd.base) & ((1u << kPartShift) - 1));
+        }
+    }
+    __syncthreads();
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_low);
+        uint4 *dst = reinterpret_cast<uint4 *>(low_out + (size_t)tile * kPartTile);
+        const uint32_t n16 = ((uint32_t)(tr.hi - tr.lo) + 7u) >> 3;
+        for (uint32_t i = threadIdx.x; i < n16; i += kBlock) stream_store4(dst + i, src[i]);
+    }
     if ((blockIdx.x & 63u) == 0) {   // a sample of the tiles reports whether the fast kernel would have taken it (span below its histogram)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             mn = min(mn, __shfl_xor(mn, o, 64));
             mx = max(mx, __shfl_xor(mx, o, 64));
         }
-        if (lane_id() == 0) {
-            s_red[threadIdx.x >> 6] = mn;
-            s_red[kWavesPerBlock + (threadIdx.x >> 6)] = mx;
+        if (lane == 0) {
+            s_red[wave] = mn;
+            s_red[kWavesPerBlock + wave] = mx;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1134,115 +1168,22 @@ __global__ __launch_bounds__(kBlock) void q5_part_count_kernel(const int32_t *__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void q5_part_emit_kernel(const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes,
-                                                              const int32_t *__restrict__ pane_win_ptr, uint32_t nd, const int32_t *__restrict__ hist_incl,
-                                                              int32_t *__restrict__ keys_out, uint16_t *__restrict__ low_out) {
-    __shared__ uint32_t s_wh[kWavesPerBlock][kPartMaxDigits];  // running digit counts of a wave, then its base inside the digit
-    __shared__ uint32_t s_dig_off[kPartMaxDigits];             // tile-local position of the digit's first row
-    __shared__ uint32_t s_glob[kPartMaxDigits];                // output position of the digit's first row of this tile
-    __shared__ uint32_t s_wave_total[kWavesPerBlock];
-    __shared__ int32_t s_keys[kPartTile];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) s_wh[w][threadIdx.x] = 0;
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kPartTile);
-    if (pane_win_ptr[tr.seg] == pane_win_ptr[tr.seg + 1]) return;   // (block-uniform) the pane is in no window: nothing was counted
-    const int32_t t0 = st.tile_first[tr.seg], tiles_p = st.tile_first[tr.seg + 1] - t0;
-    const int32_t *incl = hist_incl + (size_t)t0 * nd + ((int32_t)blockIdx.x - t0);
-    const PaneDesc pd = panes[tr.seg];
-    const int64_t wave_begin = tr.tile_begin + (int64_t)wave * kPartWaveRows;
-    int32_t k[kPartItems];
-    uint32_t rank[kPartItems];
-#pragma unroll
-    for (int it = 0; it < kPartItems; ++it) {
-        const int64_t r = wave_begin + it * 64 + lane;
-        k[it] = auction[r < tr.lo ? tr.lo : (r >= tr.hi ? tr.hi - 1 : r)];   // clamped: no load under a per-row branch
-    }
-    __syncthreads();
-    uint32_t *wh = s_wh[wave];  // written and read by this wave only, in program order (LDS instructions: a volatile pointer here
-                                // compiled to system-scope FLAT loads and stores, each waited for)
-#pragma unroll
-    for (int it = 0; it < kPartItems; ++it) {
-        const int64_t r = wave_begin + it * 64 + lane;
-        const bool valid = r >= tr.lo && r < tr.hi;
-        const uint32_t d = part_digit(k[it], pd, nd - 1);
-        // lanes that hold my digit: keep, per digit bit, the lanes whose bit equals mine = ~(ballot ^ t), t = 0 / ~0 for my bit
-        const uint64_t live = __ballot(valid);
-        uint32_t m_lo = (uint32_t)live, m_hi = (uint32_t)(live >> 32);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);
-            const uint64_t bal = __ballot(t != 0u);
-            m_lo &= ~((uint32_t)bal ^ t);
-            m_hi &= ~((uint32_t)(bal >> 32) ^ t);
-        }
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-        const uint32_t before = __hip_atomic_load(&wh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        rank[it] = before + below;
-        if (valid && below == 0)
-            __hip_atomic_store(&wh[d], before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    __syncthreads();
-    {   // thread d: wave bases of digit d, tile-local and global start of the digit
-        const uint32_t d = threadIdx.x;
-        uint32_t total = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            const uint32_t c = s_wh[w][d];
-            s_wh[w][d] = total;
-            total += c;
-        }
-        const uint32_t in = wave_incl_scan_u32(total);
-        if (lane == 63) s_wave_total[wave] = in;
-        __syncthreads();
-        uint32_t off = in - total;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) off += w < wave ? s_wave_total[w] : 0u;
-        s_dig_off[d] = off;
-        s_glob[d] = d < nd ? (uint32_t)incl[(size_t)d * tiles_p] - total : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < kPartItems; ++it) {
-        const int64_t r = wave_begin + it * 64 + lane;
-        if (r >= tr.lo && r < tr.hi) {
-            const uint32_t d = part_digit(k[it], pd, nd - 1);
-            s_keys[s_dig_off[d] + s_wh[wave][d] + rank[it]] = k[it];
-        }
-    }
-    __syncthreads();
-    const int32_t first_valid = (int32_t)(tr.lo - tr.tile_begin);
-    const int32_t tile_n = (int32_t)(tr.hi - tr.lo);
-    (void)first_valid;
-    // Inside a bucket only the key's low kPartShift bits are news (the digit IS the bucket), so a partitioned key travels as 16 bits: the
-    // pass writes 2 B per row instead of 4 and the bucket pass reads 2 (round 4: 2.45 + 0.97 ms of q5_uniform's 4.9 were these 8 + 4 GB).
-    // The straggler bucket -- keys outside the pane's estimated range -- keeps whole keys, in the int32 array at the same positions (an
-    // array as long as the column, touched only where stragglers sit).
-    for (int32_t j = threadIdx.x; j < tile_n; j += kBlock) {
-        const int32_t key = s_keys[j];
-        const uint32_t d = part_digit(key, pd, nd - 1);
-        const uint32_t pos = s_glob[d] + ((uint32_t)j - s_dig_off[d]);
-        if (d == nd - 1) keys_out[pos] = key;
-        else low_out[pos] = (uint16_t)(((uint32_t)key - (uint32_t)pd.base) & ((1u << kPartShift) - 1));
-    }
-}
-
-// One workgroup per (digit, pane) bucket: rows [start, end) of the partitioned keys, all inside [base + digit << shift, + 2^shift).
+// One workgroup per (digit, pane) bucket: the runs [off[d][t], off[d + 1][t]) of the pane's tile regions, all keys inside
+// [base + digit << shift, + 2^shift).
 __global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *__restrict__ keys, const uint16_t *__restrict__ low, SegTiles st,
                                                                  const PaneDesc *__restrict__ panes,
                                                                  const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx,
-                                                                 uint32_t nd, const int32_t *__restrict__ hist_incl, uint32_t *counters, uint64_t *tables,
+                                                                 uint32_t nd, const int32_t *__restrict__ off_mat, uint32_t *counters, uint64_t *tables,
                                                                  uint32_t cap, uint32_t *tab_used, uint32_t *err) {
     __shared__ uint32_t s_hist[1 << kPartShift];
     const uint32_t d = blockIdx.x;
     const int32_t p = blockIdx.y;
     const int32_t t0 = st.tile_first[p], tiles_p = st.tile_first[p + 1] - t0;
     if (tiles_p == 0 || pane_win_ptr[p] == pane_win_ptr[p + 1]) return;
-    const size_t slot0 = (size_t)t0 * nd + (size_t)d * tiles_p;
-    const int64_t begin = slot0 == 0 ? 0 : (int64_t)hist_incl[slot0 - 1], end = (int64_t)hist_incl[slot0 + tiles_p - 1];
-    if (end <= begin) return;
+    const int32_t *lo_row = off_mat + (size_t)t0 * (nd + 1) + (size_t)d * tiles_p, *hi_row = lo_row + tiles_p;
     const PaneDesc pd = panes[p];
-    if (d == nd - 1) {   // keys outside the pane's estimated range: the windows' straggler tables, row by row
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (d == nd - 1) {   // keys outside the pane's estimated range: the windows' straggler tables, row by row (a wave per tile)
         FlushArgs f;
         f.wp0 = pane_win_ptr[p];
         f.wp1 = pane_win_ptr[p + 1];
@@ -1253,7 +1194,10 @@ __global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *
         f.cap = cap;
         f.tab_used = tab_used;
         f.err = err;
-        for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) emit_pair(keys[i], 1u, f);
+        for (int32_t t = wave; t < tiles_p; t += kWavesPerBlock) {
+            const int32_t a = lo_row[t], b = hi_row[t];
+            for (int32_t i = a + lane; i < b; i += 64) emit_pair(keys[(size_t)(t0 + t) * kPartTile + i], 1u, f);
+        }
         return;
     }
     {
@@ -1261,7 +1205,6 @@ __global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *
         for (int i = threadIdx.x; i < (1 << kPartShift) / 4; i += kBlock) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    // the bucket's rows as 16-bit bins: a head up to the next 8-byte boundary, then FOUR bins per 8-byte load (512 B per wave instruction)
     auto add = [&](uint32_t bin, bool valid) {
         // the first lane's key once per instruction: half of NEXMark's bids name one auction, wherever they sit
         const uint32_t hot = __builtin_amdgcn_readfirstlane(bin);
@@ -1272,27 +1215,63 @@ __global__ __launch_bounds__(kBlock) void q5_bucket_count_kernel(const int32_t *
             atomicAdd(&s_hist[bin], 1u);
         }
     };
-    const int64_t body0 = std::min<int64_t>(end, (begin + 3) & ~int64_t(3));   // (the array is 8-byte aligned: row 4k starts a quad)
-    for (int64_t i = begin + threadIdx.x; i < body0; i += kBlock) add(low[i], true);   // (at most three rows: one trip, lanes 0..2)
-    const int64_t quads = (end - body0) >> 2;
-    constexpr int kUnroll = 4;
-    for (int64_t q0 = threadIdx.x; q0 < quads; q0 += (int64_t)kBlock * kUnroll) {
-        uint2 v[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int64_t q = q0 + (int64_t)u * kBlock;
-            v[u] = *reinterpret_cast<const uint2 *>(low + body0 + 4 * (q < quads ? q : quads - 1));
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const bool valid = q0 + (int64_t)u * kBlock < quads;
-            add(v[u].x & 0xFFFFu, valid);
-            add(v[u].x >> 16, valid);
-            add(v[u].y & 0xFFFFu, valid);
-            add(v[u].y >> 16, valid);
-        }
+    auto add4 = [&](uint2 v, int32_t q, int32_t a, int32_t b, bool act) {   // bins 4q .. 4q + 3 of a tile region, those inside [a, b)
+        add(v.x & 0xFFFFu, act && 4 * q >= a && 4 * q < b);
+        add(v.x >> 16, act && 4 * q + 1 >= a && 4 * q + 1 < b);
+        add(v.y & 0xFFFFu, act && 4 * q + 2 >= a && 4 * q + 2 < b);
+        add(v.y >> 16, act && 4 * q + 3 >= a && 4 * q + 3 < b);
+    };
+    // A wave takes 64 tiles at a time: lane l fetches tile l's run bounds (the next 64 tiles' while these are streamed), then the runs
+    // are streamed two at a time (one per half-wave: a run of ~4096 / nd rows is a few dozen 8-byte quads) through kDepth slots: a slot
+    // is counted and at once requested again for the pair kDepth further on, so kDepth - 1 loads are in flight under every count.
+    constexpr int kDepth = 8;
+    const int half = lane >> 5, hl = lane & 31;
+    int32_t c0 = wave * 64;
+    int32_t ra = 0, rb = 0;
+    if (c0 + lane < tiles_p) {
+        ra = lo_row[c0 + lane];
+        rb = hi_row[c0 + lane];
     }
-    for (int64_t i = body0 + 4 * quads + threadIdx.x; i < end; i += kBlock) add(low[i], true);
+    for (; c0 < tiles_p; c0 += kWavesPerBlock * 64) {
+        const int32_t cn = c0 + kWavesPerBlock * 64;
+        int32_t na = 0, nb2 = 0;
+        if (cn + lane < tiles_p) {
+            na = lo_row[cn + lane];
+            nb2 = hi_row[cn + lane];
+        }
+        int32_t a[kDepth], b[kDepth], q[kDepth];
+        const uint16_t *base[kDepth];
+        uint2 v[kDepth];
+        bool act[kDepth];
+        auto request = [&](int g, int pair) {   // pair = 0 .. 31 of this chunk; beyond: an empty run
+            const int rr = 2 * pair + half;
+            a[g] = __shfl(ra, rr & 63, 64);
+            b[g] = __shfl(rb, rr & 63, 64);
+            if (pair >= 32) a[g] = b[g] = 0;
+            base[g] = low + (size_t)(t0 + c0 + (rr & 63)) * kPartTile;
+            q[g] = (a[g] >> 2) + hl;
+            act[g] = 4 * q[g] < b[g];
+            v[g] = act[g] ? *reinterpret_cast<const uint2 *>(base[g] + 4 * q[g]) : make_uint2(0u, 0u);
+        };
+#pragma unroll
+        for (int g = 0; g < kDepth; ++g) request(g, g);
+        for (int p0 = 0; p0 < 32; p0 += kDepth) {
+#pragma unroll
+            for (int g = 0; g < kDepth; ++g) {
+                add4(v[g], q[g], a[g], b[g], act[g]);
+                for (;;) {   // runs of more than 128 - 3 rows: on, 32 quads at a time (the same trips for the whole wave)
+                    q[g] += 32;
+                    const bool more = 4 * q[g] < b[g];
+                    if (!__ballot(more)) break;
+                    const uint2 w = more ? *reinterpret_cast<const uint2 *>(base[g] + 4 * q[g]) : make_uint2(0u, 0u);
+                    add4(w, q[g], a[g], b[g], more);
+                }
+                request(g, p0 + kDepth + g);
+            }
+        }
+        ra = na;
+        rb = nb2;
+    }
     __syncthreads();
     const uint64_t idx0 = (uint64_t)d << kPartShift;
     for (uint32_t i = threadIdx.x; i < (1u << kPartShift); i += kBlock) {
@@ -1643,29 +1622,24 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         if (wide) {
             SegTiles st4;
             FG_TRY(build_seg_tiles(ctx, "q5.part", sb.data(), se.data(), n_panes, kPartTile, &st4));
-            const int64_t slots = (int64_t)st4.n_tiles * nd;
+            const int64_t slots = (int64_t)st4.n_tiles * (nd + 1);
             if (slots >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q5: too many (pane, digit, tile) slots for the partition pass");
-            int32_t *hist = nullptr, *part_keys = nullptr;
+            int32_t *off_mat = nullptr, *part_keys = nullptr;
             uint16_t *part_low = nullptr;
-            FG_TRY(arena_get_t(ctx, "q5.part_hist", (size_t)slots + 4, &hist));
-            FG_TRY(arena_get_t(ctx, "q5.part_keys", (size_t)rows + 4, &part_keys));   // (whole keys of the straggler buckets only: sparse use)
-            FG_TRY(arena_get_t(ctx, "q5.part_low", (size_t)rows + 8, &part_low));
+            FG_TRY(arena_get_t(ctx, "q5.part_hist", (size_t)slots + 4, &off_mat));
+            FG_TRY(arena_get_t(ctx, "q5.part_keys", (size_t)st4.n_tiles * kPartTile + 4, &part_keys));   // (whole keys of the straggler buckets only: sparse use)
+            FG_TRY(arena_get_t(ctx, "q5.part_low", (size_t)st4.n_tiles * kPartTile + 8, &part_low));
             FG_HIP(ctx, hipMemsetAsync(d_sample, 0, 2 * sizeof(uint32_t), ctx->stream));
             {
-                LaunchScope ls(ctx, "q5_part_count_kernel");
-                hipLaunchKernelGGL(q5_part_count_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, d_sample);
+                LaunchScope ls(ctx, "q5_part_tile_kernel");
+                hipLaunchKernelGGL(q5_part_tile_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, off_mat, part_keys,
+                                   part_low, d_sample);
             }
-            FG_TRY(check_launch(ctx, "q5_part_count_kernel"));
-            FG_TRY(inclusive_scan_i32(ctx, "q5.part_scan", hist, slots));
-            {
-                LaunchScope ls(ctx, "q5_part_emit_kernel");
-                hipLaunchKernelGGL(q5_part_emit_kernel, dim3((unsigned)st4.n_tiles), dim3(kBlock), 0, ctx->stream, auction, st4, d_panes, d_ptr, nd, hist, part_keys, part_low);
-            }
-            FG_TRY(check_launch(ctx, "q5_part_emit_kernel"));
+            FG_TRY(check_launch(ctx, "q5_part_tile_kernel"));
             {
                 LaunchScope ls(ctx, "q5_bucket_count_kernel");
-                hipLaunchKernelGGL(q5_bucket_count_kernel, dim3(nd, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, part_keys, part_low, st4, d_panes, d_ptr, d_idx, nd, hist,
-                                   counters, tables, cap, d_used, d_err);
+                hipLaunchKernelGGL(q5_bucket_count_kernel, dim3(nd, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, part_keys, part_low, st4, d_panes, d_ptr, d_idx, nd,
+                                   off_mat, counters, tables, cap, d_used, d_err);
             }
             FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

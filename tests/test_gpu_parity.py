@@ -444,7 +444,7 @@ def test_q8_duplicates_collapse(ctx):
 def test_q5_keys_in_no_order_take_the_partitioned_count():
     """Keys spread over the whole pane range make every tile wider than the fast kernel's LDS histogram.  The first such call on a ctx
     goes through the general per-tile kernel and notes it; from the second call on the pane's rows are partitioned by key range and
-    counted in LDS (q5_part_count / q5_part_emit / q5_bucket_count).  Exact either way -- hot keys, keys outside the sampled range and
+    counted in LDS (q5_part_tile / q5_bucket_count).  Exact either way -- hot keys, keys outside the sampled range and
     ragged panes included -- and a ctx that sees time-ordered keys again goes back to the fast kernel."""
     from flock_amd import Bids, GpuContext, WindowSchedule
     c = GpuContext(0)

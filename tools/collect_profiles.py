@@ -23,7 +23,7 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate
 ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q8", "q8_sellers_bitmap_kernel")] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
                                                             ("q3_general", "q3_probe_flag_kernel"), ("q8_general", "q8_key_bitmap_wide_kernel"),
                                                             ("q3_hash", "q3_probe_general_kernel"), ("q8_hash", "q8_sellers_part_kernel"),
-                                                            ("q5_uniform", "q5_part_emit_kernel"), ("q4", "aq_final_kernel"),
+                                                            ("q5_uniform", "q5_part_tile_kernel"), ("q4", "aq_final_kernel"),
                                                             ("q3_1e8", "q3_probe_flag_small_kernel")]
 for q, kern in ROWS:
     vals = {}
