@@ -924,22 +924,14 @@ __global__ __launch_bounds__(kJoinBlock) void q8_bucket_join_kernel(const int32_
         for (int j = 0; j < kJoinPre; ++j)
             if (slot[j] >= 0) settle(pk[j], pr[j], tp0 + (int32_t)pt[j], sp_tbeg[pt[j]] + pr[j], owner[j]);
     }
-    for (int32_t c0 = tp0; c0 < tp1; c0 += kJoinChunk) {
-        const int32_t n = tp1 - c0 < kJoinChunk ? tp1 - c0 : kJoinChunk;
-        uint32_t total = tot_p0, e = threadIdx.x + kJoinPre * kJoinBlock;   // (chunk 0: what lies beyond the requested entries)
-        if (c0 != tp0) {
-            __syncthreads();
-            if ((int32_t)threadIdx.x < n) sp_tbeg[threadIdx.x] = (uint32_t)st_p.tiles[c0 + (int32_t)threadIdx.x].tile_begin;
-            total = part_run_publish(part_run_load(poff, nb, b, c0, n), sp_pref, sp_o0, s_red);
-            e = threadIdx.x;
-        }
-        for (; e < total; e += kJoinBlock) {
-            const int i = part_find_run(sp_pref, n, e);
-            const uint64_t at = (uint64_t)(c0 + i) * kFlagTile + sp_o0[i] + (e - sp_pref[i]);
-            const uint32_t k = pkeys[at], rel = prel[at];
-            const int32_t sl = seller_slot(k, k != kEmpty32 ? s_sell[part_slot(k, log2nb, log2sell)] : 0u);
-            if (sl >= 0) settle(k, rel, c0 + i, sp_tbeg[i] + rel, atomicCAS(&s_own[sl], kEmpty32, sp_tbeg[i] + rel));
-        }
+    // what the bucket holds beyond the requested entries (a bucket far above the average).  A window's person tiles fit ONE chunk: the
+    // host takes this path only then (at most 1600 x 1024 persons per window: 200 tiles).
+    for (uint32_t e = threadIdx.x + kJoinPre * kJoinBlock; e < tot_p0; e += kJoinBlock) {
+        const int i = part_find_run(sp_pref, np0, e);
+        const uint64_t at = (uint64_t)(tp0 + i) * kFlagTile + sp_o0[i] + (e - sp_pref[i]);
+        const uint32_t k = pkeys[at], rel = prel[at];
+        const int32_t sl = seller_slot(k, k != kEmpty32 ? s_sell[part_slot(k, log2nb, log2sell)] : 0u);
+        if (sl >= 0) settle(k, rel, tp0 + i, sp_tbeg[i] + rel, atomicCAS(&s_own[sl], kEmpty32, sp_tbeg[i] + rel));
     }
     if (bad) atomicOr(err, bad);
 }
@@ -1643,7 +1635,7 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         int log2nb = 0;
         while (log2nb < kPartMaxLog2 && ((max_p >> log2nb) > kPartPersonsPerBucket || (max_a >> log2nb) > kPartAuctionsPerBucket)) ++log2nb;
         const bool fits = (max_p >> log2nb) <= kPartPersonsPerBucket && (max_a >> log2nb) <= kPartAuctionsPerBucket &&
-                          ((int64_t)n_win << log2nb) < (int64_t(1) << 30) && (reinterpret_cast<uintptr_t>(person->name.offsets) & 3) == 0;
+                          ((int64_t)n_win << log2nb) < (int64_t(1) << 30) && div_up(max_p, (int64_t)kFlagTile) + 1 <= kJoinChunk;
         std::vector<int64_t> &large = ctx->host_i64["q8.part_large_set"];   // a call of this ctx needed the large seller set
         if (large.empty()) large.push_back(0);
         if (skip[0] > 0) {

@@ -173,6 +173,24 @@ int main(int argc, char **argv) {
             out_schema.release(&out_schema);
             if ((rc = flockgpu_plan_reset(plan)) != FLOCKGPU_OK) return fail(ctx, "ring reset", rc);
         }
+        /* pane 3 crosses the bus ahead of its turn (a host that reads ahead), then takes its place with no batches handed over */
+        for (i = 0; i < 64; ++i) {
+            auction[i] = 123 * (i + 1);              /* every row passes */
+            price[i] = 3000 + i;
+        }
+        make_batch(&b0, auction, price, 64, 0);
+        batches[0] = &b0.batch;
+        if ((rc = flockgpu_plan_prefetch_pane(plan, 0, 3, &schema, batches, 1)) != FLOCKGPU_OK) return fail(ctx, "prefetch_pane", rc);
+        if (flockgpu_plan_prefetch_pane(plan, 0, 3, &schema, batches, 1) == FLOCKGPU_OK) return fail(ctx, "one prefetch at a time", -1);
+        if ((rc = flockgpu_plan_feed_pane(plan, 0, 3, NULL, NULL, 0)) != FLOCKGPU_OK) return fail(ctx, "feed of the prefetched pane", rc);
+        memset(&out, 0, sizeof out);
+        memset(&out_schema, 0, sizeof out_schema);
+        if ((rc = flockgpu_plan_execute(plan, &out_schema, &out)) != FLOCKGPU_OK) return fail(ctx, "execute over a prefetched pane", rc);
+        if (modulus == 123 && out.length != 16 + 64) return fail(ctx, "prefetched window row count", (int)out.length);
+        printf("ring pane 3 rows %d (prefetched)\n", (int)out.length);
+        out.release(&out);
+        out_schema.release(&out_schema);
+        if ((rc = flockgpu_plan_reset(plan)) != FLOCKGPU_OK) return fail(ctx, "ring reset", rc);
         if (flockgpu_plan_feed_pane(plan, 0, 7, &schema, batches, 1) != FLOCKGPU_ERR_INVALID) return fail(ctx, "a skipped pane must be refused", -1);
         if ((rc = flockgpu_plan_ring_close(plan)) != FLOCKGPU_OK) return fail(ctx, "ring_close", rc);
         if ((rc = flockgpu_malloc_guarded(ctx, 4096, &guarded)) != FLOCKGPU_OK || !guarded || ((size_t)guarded & 15)) return fail(ctx, "malloc_guarded", rc);

@@ -41,6 +41,7 @@ def test_c_consumer_runs_one_collect_twice():
     blocks = p.stdout.split("--\n")
     tail = blocks[-1].splitlines()
     assert tail[:3] == ["ring pane 0 rows 16", "ring pane 1 rows 32", "ring pane 2 rows 32"]      # pane ring + asynchronous execute, from C
+    assert tail[3] == "ring pane 3 rows 80 (prefetched)"                                          # the next pane uploaded ahead of its turn
     assert tail[-1].startswith("partition scheme flockgpu/")
     for inv in range(2):
         want = [(984 + 41 * i * (inv + 1), 7 * i + inv) for i in range(60) if (984 + 41 * i * (inv + 1)) % 123 == 0]

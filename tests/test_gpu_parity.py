@@ -840,6 +840,29 @@ def test_q8_hash_path_grouped_by_bucket():
         for rep in range(2):
             total = run(p_id, nm, seller, pw, aw, (npn, rep), {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": False})
             assert total > 500
+    # a window of 281 auction tiles (the bucket workgroups index a relation's tiles 256 at a time), and a bucket with four times the
+    # average number of persons (more than a workgroup requests ahead)
+    npn, na = 60_000, 2_310_000
+    pw = WindowSchedule(np.array([0, 30_000, npn]), np.arange(2), np.arange(1, 3))
+    aw = WindowSchedule(np.array([0, 2_300_000, na]), np.arange(2), np.arange(1, 3))
+    p_id = rng.integers(-2**31, 2**31 - 1, npn).astype(np.int32)
+    nm = [b"m%d" % (i % 7919) for i in range(npn)]
+    seller = rng.choice(p_id[::3], na).astype(np.int32)
+    seller[::11] = rng.integers(-2**31, 2**31 - 1, len(seller[::11])).astype(np.int32)
+    assert run(p_id, nm, seller, pw, aw, "many_auction_tiles", {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": False}) > 10_000
+    npn, na = 60_000, 100_000
+    pw = WindowSchedule(np.array([0, 30_000, npn]), np.arange(2), np.arange(1, 3))
+    aw = WindowSchedule(np.array([0, 50_000, na]), np.arange(2), np.arange(1, 3))
+    log2nb = _q8_part_log2(30_000, 50_000)
+    pool = rng.integers(-2**31, 2**31 - 1, 400_000).astype(np.int32)
+    fat = np.unique(pool[_q8_part_bucket(pool, log2nb) == 5])[:3000]
+    assert len(fat) == 3000 and log2nb >= 4
+    p_id = rng.integers(-2**31, 2**31 - 1, npn).astype(np.int32)
+    p_id[31_000:34_000] = fat
+    nm = [b"f%d" % i for i in range(npn)]
+    seller = rng.choice(p_id, na).astype(np.int32)
+    seller[60_000:61_000] = fat[::3]
+    assert run(p_id, nm, seller, pw, aw, "fat_bucket", {"q8_bucket_join_kernel": True, "q8_persons_general_kernel": False}) > 10_000
     # buckets that do not fit: 6000 distinct sellers of ONE bucket in one window (more than the small seller set's 4096 slots), and --
     # second data set -- one id under 300 names (a chain the person table's bounded probing gives up on)
     npn, na = 60_000, 100_000
