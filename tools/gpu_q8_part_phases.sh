@@ -1,6 +1,6 @@
 #!/bin/bash
-# gpurun helper: q8's grouped hash path -- the tests, then also.q8_hash with the shipped library and with the sellers' grouping pass cut
-# short after each of its phases (experimental builds: FLOCKGPU_BUILD_DEFINES="-DQ8_STOP=n", n = 1 .. 4)
+# gpurun helper: q8's grouped hash path -- the tests, then also.q8_hash with the shipped library and with the bucket join cut
+# short after each of its phases (experimental builds: FLOCKGPU_BUILD_DEFINES="-DQ8_JSTOP=n": the bucket join without seller inserts (1), up to "is the id a seller" (2), without the flag stores (3))
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 OUT=gpurun_out/${TAG:-q8part}; mkdir -p $OUT
 [ -n "$SKIP_TESTS" ] || timeout 600 python -m pytest tests/test_gpu_parity.py -k q8 -q -m gpu -p no:cacheprovider -x > $OUT/tests.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests.log
