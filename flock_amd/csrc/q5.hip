@@ -1057,7 +1057,6 @@ __global__ __launch_bounds__(kFinishThreads) void q5_finish_kernel(const uint64_
 // ctx saw (most tiles wide) and left again when a sample of the partition's tiles turns out narrow.
 constexpr int kPartItems = 16;
 constexpr int kPartTile = kBlock * kPartItems;           // 4096 rows
-constexpr int kPartWaveRows = kPartTile / kWavesPerBlock;
 constexpr int kPartShift = 13;                           // 8192 counters = 32 KB of LDS per bucket: four workgroups per CU (64 KB: two, 1.78 vs 0.97 ms)
 constexpr int kPartMaxDigits = 256;
 
