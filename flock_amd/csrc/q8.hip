@@ -1636,8 +1636,11 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
         while (log2nb < kPartMaxLog2 && ((max_p >> log2nb) > kPartPersonsPerBucket || (max_a >> log2nb) > kPartAuctionsPerBucket)) ++log2nb;
         const bool fits = (max_p >> log2nb) <= kPartPersonsPerBucket && (max_a >> log2nb) <= kPartAuctionsPerBucket &&
                           ((int64_t)n_win << log2nb) < (int64_t(1) << 30) && div_up(max_p, (int64_t)kFlagTile) + 1 <= kJoinChunk;
-        std::vector<int64_t> &large = ctx->host_i64["q8.part_large_set"];   // a call of this ctx needed the large seller set
-        if (large.empty()) large.push_back(0);
+        // {a call of this ctx needed the large seller sets, calls since}: one workgroup per CU instead of three, so the small sets are
+        // tried again now and then (a miss costs one more launch of the join)
+        std::vector<int64_t> &large = ctx->host_i64["q8.part_large_set"];
+        if (large.size() != 2) large.assign(2, 0);
+        if (large[0] && ++large[1] >= 64) large[0] = large[1] = 0;
         if (skip[0] > 0) {
             --skip[0];
         } else if (fits) {
@@ -1693,6 +1696,7 @@ int flockgpu_q8_join(flockgpu_ctx *ctx, const flockgpu_person_cols *person, cons
                 if (perr != kPartErrSellers || large[0]) break;
                 // only seller sets overflowed, and only the small ones were tried: the grouped lists stand, the join alone runs again
                 large[0] = 1;
+                large[1] = 0;
                 FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
                 FG_HIP(ctx, hipMemsetAsync(flag_bytes, 0, (size_t)st_p.n_tiles * kFlagTile, ctx->stream));
             }
