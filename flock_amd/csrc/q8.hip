@@ -14,7 +14,8 @@
 //             LDS) and flushes the non-zero words with fire-and-forget atomicOr: ~1 global atomic per 16 ids.
 //   persons : one bit test per person; the 32 row flags of a lane go out as one word (flag tiles, scan.hpp).
 // GENERAL path (any window with unsorted / duplicate p_ids, or a sparse key range): DISTINCT seller as a hash set,
-//   DISTINCT (p_id, name) by claiming a slot keyed p_id and comparing full keys with the claimant.
+//   DISTINCT (p_id, name) by claiming a slot keyed p_id and comparing full keys with the claimant -- both relations grouped by
+//   (window, hash bucket) first so that every table lives in LDS ("hash path, partitioned" below); global tables when a bucket does not fit.
 // Both paths leave flag words; tile scan -> row list -> take() of p_id and name finish the query.
 #include <algorithm>
 
