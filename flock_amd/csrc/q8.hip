@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void q8_persons_general_kernel(const int32_
 // raises `err`: the host repeats the call on the global tables.
 constexpr int kPartMaxLog2 = 10;         // up to 1024 buckets per window
 constexpr int kPartMaxBuckets = 1 << kPartMaxLog2;
-constexpr int kJoinSlots = 1024;         // LDS slots of a bucket's table of FURTHER names under an id that already has a person (8 KB)
+constexpr int kJoinSlotsLog2 = 10, kJoinSlots = 1 << kJoinSlotsLog2;   // LDS slots of a bucket's table of FURTHER names under an id that already has a person (8 KB)
 constexpr int kJoinSellLog2 = 12, kJoinSellLog2Large = 14;   // LDS slots of a bucket's seller set {key, first person}: 4096 (32 KB: three
                                                              // workgroups per CU), or 16384 (128 KB: one) once a call of the ctx has
                                                              // overflowed the small one
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(kJoinBlock) void q8_bucket_join_kernel(const int32_
         bool unique = owner == kEmpty32;
         if (!unique && !same_person(p_id, name_off, name, (int64_t)row, (int64_t)owner)) {
             const uint64_t mine = ((uint64_t)k << 32) | row;
-            uint32_t sl = part_slot(k, log2nb, 10);
+            uint32_t sl = part_slot(k, log2nb, kJoinSlotsLog2);
             bool done = false;
 #pragma unroll 1
             for (int probe = 0; probe < kJoinProbes; ++probe) {
