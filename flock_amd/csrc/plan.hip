@@ -2507,13 +2507,13 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
             }
         }
     }
+    uint8_t *mirror = nullptr;   // (before the prefetch counts as under way: a refusal here must leave nothing behind that a feed would append)
+    if (!pieces.empty()) FG_TRY(pinned_get_t(ctx, leaf_key(plan, input, 0, "pre.stage").c_str(), pageable + 64, &mirror));
     plan->pre.input = input;
     plan->pre.pane = pane_id;
     plan->pre.rows = rows;
     plan->pre.active = true;
     if (pieces.empty()) return FLOCKGPU_OK;
-    uint8_t *mirror = nullptr;
-    FG_TRY(pinned_get_t(ctx, leaf_key(plan, input, 0, "pre.stage").c_str(), pageable + 64, &mirror));
     // (the mirror may still feed the previous prefetch's copies: they were waited for when that pane was appended -- feed_pane orders the
     // ctx stream behind the copy stream, and a host synchronises the ctx stream in every execute)
     const int n_lanes = (int)std::min<size_t>(4, pieces.size());
