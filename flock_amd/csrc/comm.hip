@@ -85,7 +85,7 @@ struct flockgpu_comm {
     std::vector<std::string> phase_order;
     int inject = 0;      // flockgpu_comm_inject_failure: 1 = the next exchange's preparation fails, 2 = its data movement fails
     int64_t max_piece = kMaxPeerBytes;   // flockgpu_comm_set_max_piece_bytes
-    double timeout_s = 120.0;   // flockgpu_comm_set_timeout: how long a wait behind RCCL work may last before the peers are given up
+    double timeout_s = 600.0;   // flockgpu_comm_set_timeout: how long ONE wait behind RCCL work may last, start to end, before the peers are given up
 };
 
 namespace {
@@ -166,7 +166,7 @@ int comm_stream_wait(flockgpu_ctx *ctx, flockgpu_comm *c, const char *what) {
         if (waited > c->timeout_s) {
             kill_comm(c);
             (void)hipStreamSynchronize(ctx->stream);
-            return fail(ctx, FLOCKGPU_ERR_PEER, "%s: no progress behind a collective for %.0f s: a peer is gone (flockgpu_comm_set_timeout)", what, waited);
+            return fail(ctx, FLOCKGPU_ERR_PEER, "%s: the wait behind a collective has lasted %.0f s, the communicator's limit: a peer is taken for gone (flockgpu_comm_set_timeout)", what, waited);
         }
         if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(spin > 20000 ? 1000 : 50));   // the first ~ms is a busy poll: the common case ends there
     }

@@ -64,6 +64,7 @@ struct flockgpu_ctx {
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, flockgpu::KernelStat> stats;
     flockgpu::AsyncWorker *worker = nullptr;  // created by the first asynchronous call
+    const void *plan_in_flight = nullptr;     // the plan whose flockgpu_plan_execute_async is pending: only flockgpu_plan_wait may collect that call
     // flockgpu_malloc_guarded: pointer handed out -> {reserved base, reserved bytes, mapped bytes, allocation handle}
     std::map<void *, flockgpu::GuardedAlloc> guarded;
 };

@@ -141,6 +141,8 @@ int flockgpu_ctx_synchronize(flockgpu_ctx *ctx) {
 
 int flockgpu_ctx_wait(flockgpu_ctx *ctx) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;
+    // a plan's asynchronous execute parks its Arrow outputs in the plan: collecting its call from here would orphan them
+    if (ctx->plan_in_flight) return fail(ctx, FLOCKGPU_ERR_INVALID, "ctx_wait: the call in flight is a plan's execute (flockgpu_plan_wait collects it)");
     return ctx_wait(ctx);
 }
 

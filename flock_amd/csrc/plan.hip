@@ -1993,6 +1993,7 @@ void flockgpu_plan_destroy(flockgpu_plan *plan) {
             if (plan->async_schema.release) plan->async_schema.release(&plan->async_schema);
         }
         plan->async_pending = false;
+        if (ctx->plan_in_flight == plan) ctx->plan_in_flight = nullptr;
     }
     (void)hipStreamSynchronize(ctx->stream);
     char prefix[64];
@@ -2574,6 +2575,22 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         API_CLOCK2(c1, "feed_pane.validate");
         if (n_batches > 0 || schema) FG_TRY(feed_impl(plan, input, schema, batches, n_batches, true));
     }
+    // what `begin` changes, kept so that a feed that fails AFTER its validation (allocation, HIP error, staging) leaves the rows ring as it
+    // was.  q5's state ring cannot go back -- the closing pane's rows are folded into its groups by then -- so there a failed
+    // first feed leaves the new pane begun and empty: the same pane id is simply fed again.
+    const int ring_n_before = plan->ring_n;
+    const int64_t ring_first_before = plan->ring_first;
+    const bool newest_done_before = plan->ring_newest_done;
+    auto undo_begin = [&]() {
+        if (!begin || plan->ring_q5) return;
+        plan->ring_n = ring_n_before;
+        plan->ring_first = ring_first_before;
+        plan->ring_newest_done = newest_done_before;
+        for (auto &l : plan->leaves) {
+            if (!l.pane_rows.empty()) l.pane_rows.pop_back();
+            if (!l.pane_bytes.empty()) l.pane_bytes.pop_back();
+        }
+    };
     if (begin) {
         if (plan->ring_q5 && plan->ring_n > 0) {   // the pane that closes leaves its groups behind, its rows go
             FG_TRY(ring_q5_partial(plan));
@@ -2594,6 +2611,7 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         plan->ring_newest_done = false;
     }
     if (from_prefetch) {
+      const int rc_append = [&]() -> int {
         LeafData &ld = plan->leaves[(size_t)input];
         const Leaf &lf = plan->ir.leaves[(size_t)input];
         FG_HIP(ctx, hipEventRecord(plan->copy_done, plan->copy_stream));           // every copy of the pane is queued (prefetch_join)
@@ -2607,6 +2625,15 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
             ld.cols[c].values = p;
             if (plan->pre.rows)
                 FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(p) + (size_t)ld.rows * w, plan->pre.dev[c], (size_t)plan->pre.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
+            // a column that carries validity from an earlier, ordinarily fed pane keeps room for every row of the leaf, exactly as feed_impl
+            // does: the scan fills the rows behind the last NULL with "valid" up to the leaf's row count (the prefetched rows were
+            // appended to the values only, and that fill ran past a validity buffer sized for the panes before)
+            DevBuf &dc = ld.cols[c];
+            if (dc.valid && dc.valid_rows > 0) {
+                void *vp = nullptr;
+                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)(ld.rows + plan->pre.rows) + 64, &vp));
+                dc.valid = static_cast<uint8_t *>(vp);
+            }
         }
         FG_HIP(ctx, hipEventRecord(plan->append_done, ctx->stream));
         plan->append_done_set = true;
@@ -2618,6 +2645,9 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         plan->ring_newest_done = false;
         if (plan->ring_q5) plan->ring_groups.back() = 0;
         return FLOCKGPU_OK;
+      }();
+      if (rc_append != FLOCKGPU_OK) undo_begin();   // (the prefetch stays pending: the same call can be repeated)
+      return rc_append;
     }
     if (n_batches == 0) return FLOCKGPU_OK;   // an empty pane still advances the ring
     LeafData &ld = plan->leaves[(size_t)input];
@@ -2626,7 +2656,19 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
     for (size_t c = 0; c < ld.cols.size(); ++c) bytes_before[c] = ld.cols[c].bytes;
     {
         API_CLOCK2(c2, "feed_pane.feed");
-        FG_TRY(feed_impl(plan, input, schema, batches, n_batches, false));
+        const int rc_feed = feed_impl(plan, input, schema, batches, n_batches, false);
+        if (rc_feed != FLOCKGPU_OK) {
+            // (rows of batches that did get through stay appended to the leaf's buffers but are not counted: ld.rows is what the ring reads)
+            if (!plan->ring_q5) {
+                ld.rows = rows_before;
+                for (size_t c = 0; c < ld.cols.size(); ++c) {
+                    ld.cols[c].bytes = bytes_before[c];
+                    ld.cols[c].valid_rows = std::min(ld.cols[c].valid_rows, rows_before);
+                }
+            }
+            undo_begin();
+            return rc_feed;
+        }
     }
     ld.pane_rows.back() += ld.rows - rows_before;
     for (size_t c = 0; c < ld.cols.size(); ++c) ld.pane_bytes.back()[c] += ld.cols[c].bytes - bytes_before[c];
@@ -2837,6 +2879,7 @@ int flockgpu_plan_execute_async(flockgpu_plan *plan, int partitioned) {
         return run_plan(plan, partitioned != 0, &plan->async_schema, plan->async_batches.data(), cap, &plan->async_n);
     }));
     plan->async_pending = true;
+    ctx->plan_in_flight = plan;
     return FLOCKGPU_OK;
 }
 
@@ -2846,12 +2889,16 @@ int flockgpu_plan_wait(flockgpu_plan *plan, struct ArrowSchema *out_schema, stru
     if (!plan->async_pending) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_wait: no asynchronous execute was started on this plan");
     const int rc = ctx_wait(ctx);
     plan->async_pending = false;
-    if (rc != FLOCKGPU_OK) return rc;
+    ctx->plan_in_flight = nullptr;
     auto drop = [&] {
         for (int i = 0; i < plan->async_n; ++i)
             if (plan->async_batches[(size_t)i].release) plan->async_batches[(size_t)i].release(&plan->async_batches[(size_t)i]);
         if (plan->async_schema.release) plan->async_schema.release(&plan->async_schema);
     };
+    if (rc != FLOCKGPU_OK) {   // (a failed run_plan exports nothing; whatever it did export is released, never leaked)
+        drop();
+        return rc;
+    }
     if (!out_schema || !out_batches || capacity < plan->async_n) {
         drop();
         return fail(ctx, FLOCKGPU_ERR_INVALID, "plan_wait: %d output batches, room for %d", plan->async_n, capacity);

@@ -338,6 +338,9 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
     const int64_t start = kLds ? lo + (threadIdx.x & ~63) : (int64_t)blockIdx.x * kBlock + (threadIdx.x & ~63);
     const int64_t stride = kLds ? kBlock : (int64_t)gridDim.x * kBlock;
     for (int64_t base = start; base < hi; base += stride) {   // (wave-uniform)
+        // a table that filled up (sized from a hint the data outgrew) is known to every wave one load later: the pass is void, and its
+        // remaining rows would each walk kClaimProbes occupied slots before giving up
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
         const int64_t i = base + lane;
         const bool live = i < hi;
         const bool knull = live && g.key_valid && !g.key_valid[i];
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(kBlock) void group_insert_n_kernel(const int64_t *_
     }
     if (!kLds) return;
     __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (void pass: nothing worth flushing)
     for (uint32_t s = threadIdx.x; s < lds_slots; s += kBlock) {
         const int64_t key = s_key[s];
         if (key == kEmptyKey) continue;
@@ -1093,7 +1097,7 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
         FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
         if (!*h_err) break;
         if (cap >= full) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
-        cap = std::min(full, cap * 4);
+        cap = full;   // the hint was wrong: two slots per row always hold -- ONE more pass, not a ladder of x4 retries over every row
     }
     hint.assign(1, n_groups + 1);
     int64_t *ok = nullptr;

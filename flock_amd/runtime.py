@@ -360,19 +360,44 @@ class ExecutionContext:
         return len(self.plans) > 1 and len({id(p.gpu) for p in self.plans}) == len(self.plans)
 
     # -- context.rs:172-191: one task per plan, then join them all
+    def _join_all(self, started, unwrap):
+        """Joins EVERY started plan, then raises the first error: a plan whose execute is never waited for keeps `async_pending` and refuses
+        every later feed / reset / execute (ADVICE r4) -- the reference's `futures::join_all` also awaits every task before `?`."""
+        out, first = [], None
+        for plan in started:
+            try:
+                out.append(unwrap(plan.wait()))
+            except Exception as e:   # noqa: BLE001 -- collected, re-raised below
+                first = first or e
+                out.append(None)
+        if first is not None:
+            raise first
+        return out
+
+    def _start_all(self, partitioned: bool):
+        started = []
+        try:
+            for plan in self.plans:
+                plan.execute_async(partitioned)
+                started.append(plan)
+        except Exception:
+            for plan in started:   # what did start is joined before the error leaves
+                try:
+                    plan.wait()
+                except Exception:   # noqa: BLE001
+                    pass
+            raise
+        return started
+
     def execute(self):
         if self._concurrent():
-            for plan in self.plans:
-                plan.execute_async(False)
-            return [[plan.wait()] for plan in self.plans]
+            return self._join_all(self._start_all(False), lambda b: [b])
         return [[plan.execute()] for plan in self.plans]
 
     # -- context.rs:197-216: [plan][partition][batch]; a shuffling stage returns its P hash partitions
     def execute_partitioned(self):
         if self._concurrent():
-            for plan in self.plans:
-                plan.execute_async(True)
-            return [[[b] for b in plan.wait()] for plan in self.plans]
+            return self._join_all(self._start_all(True), lambda bs: [[b] for b in bs])
         return [[[b] for b in plan.execute_partitioned()] for plan in self.plans]
 
     # -- context.rs:227-254

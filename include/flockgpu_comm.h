@@ -85,10 +85,11 @@ int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm);
 int flockgpu_comm_inject_failure(flockgpu_comm *comm, int where);
 
 /* Every host wait behind RCCL work (counts exchange, all-to-all, all-reduce) polls the stream together with the communicator's
- * asynchronous error state instead of blocking blindly: when RCCL reports an error, or nothing completes for `seconds` (default
- * 120), this rank aborts its communicator -- its own queued sends / receives are cancelled, the stream drains -- and the call
- * returns FLOCKGPU_ERR_PEER.  So a rank that died AFTER the counts agreement (process killed, device lost) costs its peers at most
- * the time-out, never a hang. */
+ * asynchronous error state instead of blocking blindly: when RCCL reports an error, or ONE such wait lasts longer than `seconds`
+ * (default 600; the clock starts when the wait begins and covers everything queued ahead of the collective on the ctx stream,
+ * so a host that shares a busy stream with the ctx must size it for that), this rank aborts its communicator -- its own queued
+ * sends / receives are cancelled, the stream drains -- and the call returns FLOCKGPU_ERR_PEER.  So a rank that died AFTER the
+ * counts agreement (process killed, device lost) costs its peers at most the time-out, never a hang. */
 int flockgpu_comm_set_timeout(flockgpu_comm *comm, double seconds);
 /* The largest single transfer per (source, destination) pair; a longer run crosses in several rounds, each side walking the same
  * pieces.  Default (and maximum) 1 GiB.  Every rank of a communicator must set the same value; lowering it to a few KiB is how the

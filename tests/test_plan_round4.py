@@ -466,6 +466,36 @@ def test_rows_ring_carries_validity(gpu):
     ring.close()
 
 
+@pytest.mark.gpu
+def test_prefetched_pane_behind_a_pane_with_nulls_on_the_rows_ring(gpu):
+    """ADVICE r4 (plan.hip, feed_pane's prefetch append): a small pane WITH NULLs fed the ordinary way leaves validity bytes on its columns;
+    the next, much larger pane holds no NULL and arrives by prefetch -- its rows are appended device to device, and the scan then fills
+    "valid" up to the leaf's row count.  The validity buffer has to have grown with the values (it used to be written past its end)."""
+    from flock_amd.runtime import ExecutionContext
+    aggs = [("count", "v", "UInt64"), ("max", "v", "Int64"), ("count", None, "UInt64")]
+    ring = ExecutionContext([_agg_plan(aggs)], name="agg-ring-pre", gpu=gpu)
+    ring.open_window_ring(2)
+    panes = [_null_table(50, 7)]
+    r = np.random.default_rng(8)
+    for n in (20_000, 45_000):
+        panes.append({"k": [int(x) for x in r.integers(-3, 6, n)], "v": [int(x) for x in r.integers(-50, 50, n)],
+                      "f": [float(x) for x in np.round(r.normal(0, 10, n))], "s": ["s1"] * n})
+    ring.feed_data_sources([[_null_batches(panes[0], 50)]], pane=0)
+    for p in range(len(panes)):
+        if p + 1 < len(panes):
+            ring.prefetch_data_sources([[_null_batches(panes[p + 1], 7_000)]], pane=p + 1)
+        rb = ring.execute()[0][0]
+        ring.clean_data_sources()
+        held = panes[max(0, p - 1): p + 1]
+        window = {c: [x for q in held for x in q[c]] for c in ("k", "v", "f", "s")}
+        want = g.hash_aggregate_exec(window, ["k"], [("%s(%s)" % (fn.upper(), col or "UInt8(1)"), fn, col) for fn, col, _ in aggs])
+        key = lambda r: (r[0] is None, r[0] or 0)
+        assert sorted(_pyrows(rb), key=key) == sorted(g.rows(want), key=key), p
+        if p + 1 < len(panes):
+            ring.feed_data_sources(None, pane=p + 1)
+    ring.close()
+
+
 # ------------------------------------------------------------------ GPU: asynchronous execute
 @pytest.mark.gpu
 def test_plans_on_their_own_contexts_execute_side_by_side(gpu):
