@@ -77,7 +77,7 @@ def parse():
                          "inside libflockgpu as the headline; auto = windows, with the exchange attached as `exchange` at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
-    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic", "arch"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -1059,6 +1059,122 @@ def plan_generic(gpu, eps, steps):
     return out
 
 
+# the reference's operator harness: plan -> (generic dominant kernel, fused dominant kernel, algorithmic bytes per bid of that kernel)
+ARCH_OPS = {
+    "filter": ("pred_flag_kernel", "q2_flag_kernel", 4.0),        # the predicate reads `auction` once
+    "groupby": ("dense_group_kernel", "q5_partial_tile_kernel", 4.0),
+    "join": ("join_probe_dense_kernel", "join_probe_dense_kernel", 4.0),   # the probe side's key column (count pass + emit pass: launched twice)
+    "sort": ("sort_emit_kernel", "sort_emit_kernel", 16.0),       # one radix pass: key + row number in and out
+}
+
+
+def arch_ops(gpu, eps, steps, no_cpu, seconds=100):
+    """flock-function/src/aws/arch/source.rs:25-65 -- the reference's own operator timing harness: `arch/ops/{filter,join,group-by,sort}.sql`
+    each planned ONCE, fed ONCE (outside the timed region there, too), executed 10 times, mean -- through `flockgpu_plan_*` on the
+    bids / auctions of `seconds` x `eps` NEXMark events.  Every execute leaves its result in HBM (`flockgpu_plan_execute_retain`: inputs
+    and outputs device-resident, as `value` is defined; the join's result is ~16 GB -- exporting it would time PCIe).  Each plan runs
+    twice: fused pipelines allowed (filter.sql IS q2's statement, group-by.sql q5's inner query) and on the generic operators only
+    (`FLOCKGPU_PLAN_GENERIC_ONLY`), which is what a plan outside the recognised NEXMark shapes gets.  `value` / `ms_per_step` /
+    `roofline`: the GROUP BY on the generic operators (the row VERDICT r4 singled out at 0.9 % of the HBM rate)."""
+    import numpy as np
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext
+    g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=11).generate_data(gpu, relations=("bid", "auction"), auction_times=True)
+    b, a = g.bids, g.auctions
+    ts = pa.timestamp("ms")
+    rng = np.random.default_rng(11)
+
+    def words(n, lo, hi):   # the device generator carries the auctions' numeric columns; the two strings are synthesised at the widths of
+        # flock/src/datasource/nexmark/event.rs:220-245 (item_name up to 19 bytes, description up to 99)
+        lens = rng.integers(lo, hi + 1, n).astype(np.int32)
+        off = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=off[1:])
+        data = rng.integers(97, 123, int(off[-1]), dtype=np.uint8)
+        return pa.StringArray.from_buffers(n, pa.py_buffer(off.tobytes()), pa.py_buffer(data.tobytes()))
+    bid_rb = pa.record_batch([pa.array(b.auction.cpu().numpy()), pa.array(b.bidder.cpu().numpy()), pa.array(b.price.cpu().numpy()),
+                              pa.array(b.b_date_time.cpu().numpy()).cast(ts)], names=["auction", "bidder", "price", "b_date_time"])
+    auc_rb = pa.record_batch([pa.array(a.a_id.cpu().numpy()), words(a.rows, 8, 19), words(a.rows, 50, 99), pa.array(rng.integers(1, 10_000, a.rows).astype(np.int32)),
+                              pa.array(rng.integers(1, 20_000, a.rows).astype(np.int32)), pa.array(a.a_date_time.cpu().numpy()).cast(ts),
+                              pa.array(a.expires.cpu().numpy()).cast(ts), pa.array(a.seller.cpu().numpy()), pa.array(a.category.cpu().numpy())],
+                             names=["a_id", "item_name", "description", "initial_bid", "reserve", "a_date_time", "expires", "seller", "category"])
+    n_bids, n_auc = bid_rb.num_rows, auc_rb.num_rows
+    del g, b, a
+    out = {"input": {"bids": int(n_bids), "auctions": int(n_auc)}, "recipe": "source.rs:36-63: plan once, feed once, 10 timed executes, mean"}
+    in_bytes = {"filter": 8.0 * n_bids, "groupby": 4.0 * n_bids, "sort": 20.0 * n_bids, "join": float(bid_rb.nbytes + auc_rb.nbytes)}
+    for name in ("filter", "groupby", "join", "sort"):
+        plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", f"arch_{name}.json")))
+        e = {}
+        for mode in ("fused", "generic"):
+            ctx = ExecutionContext([plan], gpu=gpu, generic_only=(mode == "generic"))
+            try:
+                ctx.feed_data_sources([[[bid_rb]], [[auc_rb]]])
+                pl = ctx.plans[0]
+                gpu.synchronize()
+                t0 = time.perf_counter()
+                rows = pl.execute_retain()
+                gpu.synchronize()
+                first = time.perf_counter() - t0          # (column statistics, table sizing hints, arena growth: paid by the first execute after a feed)
+                times = []
+                for _ in range(max(steps, 3)):
+                    t0 = time.perf_counter()
+                    rows = pl.execute_retain()
+                    gpu.synchronize()
+                    times.append(time.perf_counter() - t0)
+                gpu.profile_reset()
+                gpu.profile_only(None)
+                gpu.profile(True)
+                for _ in range(2):
+                    pl.execute_retain()
+                gpu.synchronize()
+                stats = gpu.profile_read()
+                gpu.profile(False)
+                ms = sum(times) / len(times) * 1e3
+                kern = ARCH_OPS[name][0 if mode == "generic" else 1]
+                st = stats.get(kern)
+                m = {"ms_per_execute": round(ms, 4), "first_execute_ms": round(first * 1e3, 3), "result_rows": int(rows), "rows_per_s": round(n_bids / (ms * 1e-3), 1),
+                     "kernels_ms_per_execute": {k: round(v["total_ms"] / 2, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
+                if st and st["launches"]:
+                    avg = st["total_ms"] / st["launches"]
+                    alg = ARCH_OPS[name][2] * n_bids
+                    m["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_launch": int(alg),
+                                     "traffic": traffic_of(kern, alg, f"arch_{name}")}
+                e[mode] = m
+            except Exception as ex:
+                e[mode] = {"error": repr(ex)}
+            ctx.close()
+        if "error" not in e.get("fused", {}) and "error" not in e.get("generic", {}):
+            if e["fused"]["result_rows"] != e["generic"]["result_rows"]:
+                raise RuntimeError(f"arch {name}: the generic operators return {e['generic']['result_rows']} rows, the fused path {e['fused']['result_rows']}")
+            e["generic_over_fused"] = round(e["generic"]["ms_per_execute"] / e["fused"]["ms_per_execute"], 2)
+            # whole-operator view: every input column the statement names once + the result once, over the generic path's time
+            e["whole_op_input_bytes"] = int(in_bytes[name])
+        out[name] = e
+    if not no_cpu:
+        try:   # Arrow C++ / Acero on the host's cores over a bounded sample of the same relations (the first 1e7 bids)
+            import pyarrow.compute as pc
+            n = min(n_bids, 10_000_000)
+            bt, at = pa.Table.from_batches([bid_rb.slice(0, n)]), pa.Table.from_batches([auc_rb])
+            cpu = {}
+            for name, fn in (("filter", lambda: bt.filter(pc.equal(pc.subtract(bt["auction"], pc.multiply(pc.divide(bt["auction"], 123), 123)), 0)).select(["auction", "price"])),
+                             ("groupby", lambda: bt.group_by("auction").aggregate([([], "count_all")])),
+                             ("join", lambda: at.join(bt, keys="a_id", right_keys="auction", join_type="inner")),
+                             ("sort", lambda: bt.take(pc.sort_indices(bt, [("bidder", "ascending")])))):
+                fn()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fn()
+                cpu[name] = round(n / ((time.perf_counter() - t0) / 3), 1)
+            out["cpu_baseline"] = {"engine": "pyarrow / Acero", "unit": "rows/s", "cores": os.cpu_count(), "sample": f"the first {n} bids (and every auction)", "rows_per_s": cpu}
+        except Exception as ex:
+            out["cpu_baseline"] = {"error": repr(ex)}
+    gb = out.get("groupby", {}).get("generic", {})
+    if "ms_per_execute" in gb:
+        out.update({"value": gb["rows_per_s"], "unit": "rows/s", "ms_per_step": gb["ms_per_execute"], "roofline": gb.get("roofline")})
+    return out
+
+
 def plan_stages(gpu, eps, steps):
     """The reference's distributed mode through the plan ABI: q3 / q5 / q8 cut into their stage plans (flock_amd.stages.build_query_dag =
     flock/src/distributed_plan/stage.rs:269-367), every stage a function group with 8 hash partitions, run in one process
@@ -1371,7 +1487,8 @@ def main():
         n = max(args.steps, 3)
         e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True),
              "plan_stages": lambda: plan_stages(g, args.eps, n), "plan_collect": lambda: plan_collect_pcie(g, args.eps, max(n, 5)),
-             "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps), "plan_generic": lambda: plan_generic(g, args.eps, n)}[args.only_side]()
+             "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps), "plan_generic": lambda: plan_generic(g, args.eps, n),
+             "arch": lambda: arch_ops(g, args.eps, 10, args.no_cpu, seconds=args.seconds or 100)}[args.only_side]()
         print(json.dumps(e))
         return
     if args.only_general:
@@ -1587,7 +1704,8 @@ def main():
                           ("q5_pcie_inclusive", lambda: pcie_inclusive_q5(ctx, args.eps)),
                           ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2)),
                           ("plan_stages", lambda: plan_stages(ctx, args.eps, 5)),
-                          ("plan_generic", lambda: plan_generic(ctx, args.eps, 10))):
+                          ("plan_generic", lambda: plan_generic(ctx, args.eps, 10)),
+                          ("arch_ops", lambda: arch_ops(ctx, args.eps, 10, args.no_cpu))):
             try:
                 also[label] = fn()
             except Exception as e:

@@ -10,6 +10,7 @@
 // relops.hpp.  Host-side code only; all compute goes through those two layers.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <map>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "../../include/flockgpu_plan.h"
 #include "plan_ir.hpp"
+#include "pred.hpp"
 
 using namespace flockgpu;
 using namespace flockgpu::ir;
@@ -200,6 +202,12 @@ struct flockgpu_plan {
     ArrowSchema async_schema{};
     std::vector<ArrowArray> async_batches;
     int async_n = 0;
+    // ---- exact (min, max) of integer LEAF columns, computed when an operator first asks (the dense GROUP BY / join paths size their
+    // direct-address tables from it) and kept while the leaf's contents stay what they were: every feed / reset / ring step drops them.
+    // The reference's arch harness feeds once and executes ten times (flock-function/src/aws/arch/source.rs:25-65); a streaming host
+    // pays one 4-byte-per-row pass per fed window.
+    struct ColStat { int64_t rows, mn, mx; };
+    std::map<const void *, ColStat> col_stats;
     // ---- hash-placement guard: the scheme tag of the co-partitioned inputs fed since the last reset (-1: none fed yet)
     int scheme_state = -1;       // 0: untagged batches, 1: tagged with scheme_tag
     std::string scheme_tag;
@@ -1203,43 +1211,209 @@ struct Exec {
             if (op == e.n) { *out = flip ? e.flipped : e.a; return true; }
         return false;
     }
-    int eval_pred(const Node *n, const Expr *e, const Table &in, int *next, uint8_t **out) {
-        uint8_t *mask = nullptr;
-        FG_TRY(arena_get_t(ctx, node_key(pl, n, "mask", (*next)++).c_str(), (size_t)in.rows + 16, &mask));
-        *out = mask;
-        if (e->kind != EKind::Bin) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate is not a comparison");
-        if (e->s == "And" || e->s == "Or") {
-            uint8_t *a = nullptr, *b = nullptr;
-            FG_TRY(eval_pred(n, e->l.get(), in, next, &a));
-            FG_TRY(eval_pred(n, e->r.get(), in, next, &b));
-            return mask_combine(ctx, a, b, in.rows, e->s == "And", mask);
+    // FilterExec's predicate -> the postfix program of pred.hpp (ONE kernel evaluates it per flag tile).  Leaves: a column against a
+    // literal or another column (integers, Float64, Utf8 `=` / `<>`), `column % literal` against a literal, IS [NOT] NULL, a boolean
+    // literal; IN lists become OR chains of `=` leaves; NOT / AND / OR combine in three-valued logic on the device.  AND / OR push
+    // their deeper operand first (they commute), so the operand stack stays at log2(leaves) + 1.
+    struct Operand {
+        enum K { COL, INT, FLT, STR, MOD, NUL, BAD } k = BAD;
+        const TCol *col = nullptr;
+        int64_t i = 0;
+        double f = 0;
+        std::string s;
+        int64_t modulus = 0;
+    };
+    Operand operand(const Expr *e, const Table &in) const {
+        Operand o;
+        bool neg = false;
+        e = uncast(e);
+        while (e->kind == EKind::Neg) {   // -literal: folded here (a negated column is not taken)
+            neg = !neg;
+            e = uncast(e->l.get());
         }
-        const Expr *l = uncast(e->l.get()), *r = uncast(e->r.get());
-        bool flip = false;
-        if (l->kind == EKind::LitI || l->kind == EKind::LitS || l->kind == EKind::LitF) { std::swap(l, r); flip = true; }
-        CmpOp op;
-        if (!cmp_of(e->s, &op, flip)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: operator '%s' in a predicate", e->s.c_str());
-        auto column = [&](const Expr *x) -> const TCol * { return x->kind == EKind::Col && in.cols[(size_t)x->col].present ? &in.cols[(size_t)x->col] : nullptr; };
-        // a comparison with NULL is NULL, and a NULL predicate keeps no row: the comparison's mask is cleared where an operand is NULL
-        // (exact through AND and OR: NULL OR TRUE is TRUE, NULL OR FALSE is NULL -- dropped -- just as FALSE OR x evaluates)
-        auto nulls_out = [&](int rc, const TCol *a, const TCol *b = nullptr) -> int {
-            if (rc != FLOCKGPU_OK) return rc;
-            if (a && a->c.valid) FG_TRY(mask_and_valid(ctx, mask, a->c.valid, in.rows));
-            if (b && b->c.valid) FG_TRY(mask_and_valid(ctx, mask, b->c.valid, in.rows));
-            return FLOCKGPU_OK;
+        auto column = [&](const Expr *x) -> const TCol * {
+            const TCol &c = in.cols[(size_t)x->col];
+            return c.present || c.c.all_null ? &c : nullptr;
         };
-        if (l->kind == EKind::Col && (r->kind == EKind::LitI || r->kind == EKind::LitF) && column(l) && column(l)->c.type == ColType::F64)
-            return nulls_out(mask_cmp_f64_lit(ctx, column(l)->c, in.rows, op, r->kind == EKind::LitF ? r->f : (double)r->i, mask), column(l));
-        if (l->kind == EKind::Col && r->kind == EKind::LitI && column(l)) return nulls_out(mask_cmp_lit(ctx, column(l)->c, in.rows, op, r->i, mask), column(l));
-        if (l->kind == EKind::Col && r->kind == EKind::LitS && column(l) && (op == CmpOp::EQ || op == CmpOp::NE))
-            return nulls_out(mask_utf8_eq(ctx, column(l)->c, in.rows, r->s, op == CmpOp::NE, mask), column(l));
-        if (l->kind == EKind::Col && r->kind == EKind::Col && column(l) && column(r))
-            return nulls_out(mask_cmp_col(ctx, column(l)->c, column(r)->c, in.rows, op, mask), column(l), column(r));
-        if (is_bin(l, "Modulo") && r->kind == EKind::LitI) {
-            const Expr *c = uncast(l->l.get()), *m = uncast(l->r.get());
-            if (c->kind == EKind::Col && m->kind == EKind::LitI && column(c)) return nulls_out(mask_mod_cmp(ctx, column(c)->c, in.rows, m->i, op, r->i, mask), column(c));
+        switch (e->kind) {
+            case EKind::LitI: o.k = Operand::INT; o.i = neg ? (int64_t)(0 - (uint64_t)e->i) : e->i; return o;
+            case EKind::LitF: o.k = Operand::FLT; o.f = neg ? -e->f : e->f; return o;
+            case EKind::LitS: if (!neg) { o.k = Operand::STR; o.s = e->s; } return o;
+            case EKind::LitNull: o.k = Operand::NUL; return o;
+            case EKind::Col:
+                if (!neg && (o.col = column(e))) o.k = o.col->c.all_null ? Operand::NUL : Operand::COL;
+                return o;
+            case EKind::Bin:
+                if (!neg && e->s == "Modulo") {
+                    const Expr *c = uncast(e->l.get()), *m = uncast(e->r.get());
+                    if (c->kind == EKind::Col && m->kind == EKind::LitI && (o.col = column(c))) {
+                        o.k = o.col->c.all_null ? Operand::NUL : Operand::MOD;
+                        o.modulus = m->i;
+                    }
+                }
+                return o;
+            default: return o;
         }
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate shape is not supported");
+    }
+    static int pred_need(const Expr *e) {   // operand-stack slots the sub-tree needs when its deeper side goes first
+        if (e->kind == EKind::Not) return pred_need(e->l.get());
+        if (e->kind == EKind::Bin && (e->s == "And" || e->s == "Or")) {
+            const int a = pred_need(e->l.get()), b = pred_need(e->r.get());
+            return a == b ? a + 1 : std::max(a, b);
+        }
+        return e->kind == EKind::InList ? 2 : 1;
+    }
+    int pred_full() { return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate beyond %d comparisons / %d columns / %d literal bytes", kPredMaxLeaves, kPredMaxCols, kPredLitPool); }
+    int pred_const(PredBuilder &b, int v) {   // 0 FALSE, 1 TRUE, 2 NULL
+        PredLeafDesc l{};
+        l.kind = (uint8_t)PredLeafKind::Const;
+        l.lit = v;
+        return b.add_leaf(l) ? FLOCKGPU_OK : pred_full();
+    }
+    // `x op y` with the literal (if any) on the right
+    int pred_compare(const std::string &opname, const Expr *le, const Expr *re, const Table &in, PredBuilder &b) {
+        Operand l = operand(le, in), r = operand(re, in);
+        bool flip = false;
+        if (l.k == Operand::INT || l.k == Operand::FLT || l.k == Operand::STR) { std::swap(l, r); flip = true; }
+        CmpOp op;
+        if (!cmp_of(opname, &op, flip)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: operator '%s' in a predicate", opname.c_str());
+        if (l.k == Operand::BAD || r.k == Operand::BAD) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate shape is not supported");
+        if (l.k == Operand::NUL || r.k == Operand::NUL) return pred_const(b, 2);   // a comparison with NULL is NULL
+        PredLeafDesc d{};
+        d.cmp = (uint8_t)op;
+        auto is_int = [](const TCol *c) { return c->c.type == ColType::I32 || c->c.type == ColType::I64 || c->c.type == ColType::U64; };
+        if (l.k == Operand::COL && r.k == Operand::COL) {
+            const bool fa = l.col->c.type == ColType::F64, fb = r.col->c.type == ColType::F64;
+            if (fa != fb || !(fa || (is_int(l.col) && is_int(r.col))) || ((l.col->c.type == ColType::U64) != (r.col->c.type == ColType::U64)))
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: column comparison needs two integer columns of one signedness, or two Float64 columns");
+            d.kind = (uint8_t)(fa ? PredLeafKind::CmpF64Col : PredLeafKind::CmpIntCol);
+            d.uns = l.col->c.type == ColType::U64;
+            const int ia = b.add_col(l.col->c), ib = b.add_col(r.col->c);
+            if (ia < 0 || ib < 0) return pred_full();
+            d.a = (uint8_t)ia;
+            d.b = (uint8_t)ib;
+            return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
+        }
+        if (l.k != Operand::COL && l.k != Operand::MOD) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a comparison of two literals");
+        const ColType ct = l.col->c.type;
+        if (r.k == Operand::STR) {
+            if (ct != ColType::UTF8 || l.k == Operand::MOD || (op != CmpOp::EQ && op != CmpOp::NE))
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a Utf8 literal compares with a Utf8 column by = or <>");
+            d.kind = (uint8_t)PredLeafKind::Utf8Eq;
+            d.negate = op == CmpOp::NE;
+            d.lit_len = (int32_t)r.s.size();
+            const int ia = b.add_col(l.col->c);
+            if (ia < 0 || !b.add_literal(r.s, &d.lit_off)) return pred_full();
+            d.a = (uint8_t)ia;
+            return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
+        }
+        if (ct == ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a Utf8 column against a number");
+        if (ct == ColType::F64) {
+            if (l.k == Operand::MOD) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: modulo of a Float64 column");
+            d.kind = (uint8_t)PredLeafKind::CmpF64Lit;
+            const double lit = r.k == Operand::FLT ? r.f : (double)r.i;
+            std::memcpy(&d.lit, &lit, sizeof d.lit);
+            const int ia = b.add_col(l.col->c);
+            if (ia < 0) return pred_full();
+            d.a = (uint8_t)ia;
+            return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
+        }
+        // an integer column (or its remainder) against a number
+        int64_t lit = r.i;
+        if (r.k == Operand::FLT) {
+            // CAST(int AS Float64) op f: exact as an integer comparison while the cast is (Int32 always; wider columns are not taken)
+            if (ct != ColType::I32 || l.k == Operand::MOD || r.f != r.f) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: an Int64 column against a Float64 literal");
+            const double fl = std::floor(r.f), ce = std::ceil(r.f);
+            const bool whole = fl == r.f;
+            if (!whole && (op == CmpOp::EQ || op == CmpOp::NE)) return pred_const_valid(b, l.col, op == CmpOp::NE);
+            const double pick = (op == CmpOp::LT || op == CmpOp::GE) ? ce : fl;   // x < f <=> x < ceil f;  x <= f <=> x <= floor f;  x > f <=> x > floor f;  x >= f <=> x >= ceil f
+            if (pick > 4e18) lit = INT64_MAX; else if (pick < -4e18) lit = INT64_MIN; else lit = (int64_t)pick;
+        }
+        d.kind = (uint8_t)PredLeafKind::CmpIntLit;
+        d.uns = ct == ColType::U64;
+        if (l.k == Operand::MOD) {
+            if (ct == ColType::U64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: modulo needs a signed integer column");
+            if (l.modulus == 0) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: modulo by zero (the reference raises a DataFusion error)");
+            // x % -1 == 0 for every x (and INT64_MIN % -1 traps in hardware): the remainder by |m| has the same value
+            const int64_t m = l.modulus == INT64_MIN ? l.modulus : (l.modulus < 0 ? -l.modulus : l.modulus);
+            d.modulus = m;
+            if (ct == ColType::I32 && m > 0 && m <= 0x7fffffffll) {
+                d.mod_kind = 1;
+                d.mod = umod32_make((uint32_t)m);
+            } else {
+                d.mod_kind = 2;
+            }
+        }
+        if (ct == ColType::I32 && d.mod_kind != 2 && (lit > INT32_MAX || lit < INT32_MIN)) {
+            // no Int32 (and no remainder by |m| < 2^31) reaches the literal: the comparison is the same for every non-NULL row
+            const bool above = lit > INT32_MAX;
+            const bool v = op == CmpOp::NE ? true : op == CmpOp::EQ ? false : (op == CmpOp::LT || op == CmpOp::LE) ? above : !above;
+            return pred_const_valid(b, l.col, v);
+        }
+        d.lit = lit;
+        const int ia = b.add_col(l.col->c);
+        if (ia < 0) return pred_full();
+        d.a = (uint8_t)ia;
+        return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
+    }
+    // a comparison whose outcome is `v` for every row whose column is not NULL (NULL where it is): `col IS NOT NULL` when v, else NOT of it AND NULL...
+    // expressed with the leaves at hand: v ? (col IS NOT NULL OR NULL) : (col IS NULL AND NULL)
+    int pred_const_valid(PredBuilder &b, const TCol *col, bool v) {
+        if (!col->c.valid) return pred_const(b, v ? 1 : 0);
+        PredLeafDesc d{};
+        d.kind = (uint8_t)PredLeafKind::IsNull;
+        d.negate = v ? 1 : 0;
+        const int ia = b.add_col(col->c);
+        if (ia < 0) return pred_full();
+        d.a = (uint8_t)ia;
+        if (!b.add_leaf(d)) return pred_full();
+        FG_TRY(pred_const(b, 2));
+        return b.push(v ? PredOpKind::Or : PredOpKind::And) ? FLOCKGPU_OK : pred_full();
+    }
+    int compile_pred(const Expr *e, const Table &in, PredBuilder &b) {
+        switch (e->kind) {
+            case EKind::LitB: return pred_const(b, e->i ? 1 : 0);
+            case EKind::LitNull: return pred_const(b, 2);
+            case EKind::Not:
+                FG_TRY(compile_pred(e->l.get(), in, b));
+                return b.push(PredOpKind::Not) ? FLOCKGPU_OK : pred_full();
+            case EKind::IsNull:
+            case EKind::IsNotNull: {
+                const Expr *a = uncast(e->l.get());
+                if (a->kind != EKind::Col) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: IS [NOT] NULL of something other than a column");
+                const TCol &c = in.cols[(size_t)a->col];
+                if (c.c.all_null) return pred_const(b, e->kind == EKind::IsNull ? 1 : 0);
+                if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: predicate column was not materialised");
+                if (!c.c.valid) return pred_const(b, e->kind == EKind::IsNull ? 0 : 1);
+                PredLeafDesc d{};
+                d.kind = (uint8_t)PredLeafKind::IsNull;
+                d.negate = e->kind == EKind::IsNotNull;
+                const int ia = b.add_col(c.c);
+                if (ia < 0) return pred_full();
+                d.a = (uint8_t)ia;
+                return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
+            }
+            case EKind::InList: {   // x IN (a, b, ...) = (x = a) OR (x = b) OR ...; NOT IN = NOT of that (NULL when x is)
+                for (size_t i = 0; i < e->list.size(); ++i) {
+                    FG_TRY(pred_compare("Eq", e->l.get(), e->list[i].get(), in, b));
+                    if (i > 0 && !b.push(PredOpKind::Or)) return pred_full();
+                }
+                if (e->negated && !b.push(PredOpKind::Not)) return pred_full();
+                return FLOCKGPU_OK;
+            }
+            case EKind::Bin: {
+                if (e->s == "And" || e->s == "Or") {
+                    const Expr *first = e->l.get(), *second = e->r.get();
+                    if (pred_need(second) > pred_need(first)) std::swap(first, second);
+                    FG_TRY(compile_pred(first, in, b));
+                    FG_TRY(compile_pred(second, in, b));
+                    return b.push(e->s == "And" ? PredOpKind::And : PredOpKind::Or) ? FLOCKGPU_OK : pred_full();
+                }
+                return pred_compare(e->s, e->l.get(), e->r.get(), in, b);
+            }
+            default:
+                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: predicate is not a comparison");
+        }
     }
 
     // The Utf8 columns of one take share their row list: up to four of them go through ONE length pass, ONE scan, ONE host wait and
@@ -1294,6 +1468,25 @@ struct Exec {
         return FLOCKGPU_OK;
     }
 
+    // exact (min, max) of an integer column; a LEAF column's are remembered until the leaf changes (flockgpu_plan::col_stats)
+    int int_col_stats(const TCol &c, int64_t rows, int64_t *mn, int64_t *mx) {
+        bool leaf_col = false;
+        for (auto &ld : pl->leaves)
+            if (!ld.borrowed)
+                for (auto &b : ld.cols) leaf_col = leaf_col || (b.values && b.values == c.c.values);
+        if (leaf_col) {
+            auto it = pl->col_stats.find(c.c.values);
+            if (it != pl->col_stats.end() && it->second.rows == rows) {
+                *mn = it->second.mn;
+                *mx = it->second.mx;
+                return FLOCKGPU_OK;
+            }
+        }
+        FG_TRY(column_minmax(ctx, c.c, rows, mn, mx));
+        if (leaf_col) pl->col_stats[c.c.values] = flockgpu_plan::ColStat{rows, *mn, *mx};
+        return FLOCKGPU_OK;
+    }
+
     int key_i64(const Node *n, const TCol &c, int64_t rows, const char *what, int64_t **out) {
         if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
         FG_TRY(arena_get_t(ctx, node_key(pl, n, what).c_str(), (size_t)rows + 2, out));
@@ -1303,10 +1496,9 @@ struct Exec {
     // FilterExec as a row selection: the input table and the rows of it the predicate keeps (input order)
     int filter_rows(const Node *n, Table *in, int32_t **rows, int64_t *n_out) {
         FG_TRY(exec(n->in[0].get(), in));
-        uint8_t *mask = nullptr;
-        int next = 0;
-        FG_TRY(eval_pred(n, n->pred.get(), *in, &next, &mask));
-        return mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in->rows, rows, n_out);
+        PredBuilder b;
+        FG_TRY(compile_pred(n->pred.get(), *in, b));
+        return pred_to_rows(ctx, node_key(pl, n, "sel").c_str(), b.p, in->rows, rows, n_out);
     }
 
     int exec(const Node *n, Table *t) {
@@ -1392,6 +1584,24 @@ struct Exec {
                 // validity bytes -- a grouped MIN / MAX over nothing but NULLs joined on -- is not taken)
                 if (lk.c.valid || rk.c.valid || (n->on_l2 >= 0 && (L.cols[(size_t)n->on_l2].c.valid || R.cols[(size_t)n->on_r2].c.valid)))
                     return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join on a computed column that holds NULLs");
+                int32_t *lrows = nullptr, *rrows = nullptr;
+                int64_t pairs = 0;
+                // one integer key pair whose build side is dense: chain heads addressed by key - min (relops.hpp "dense integer keys").  The
+                // table goes on the smaller side, as in join_key64 (which side is hashed is unobservable in the pair multiset).
+                if (!text_keys && n->on_l2 < 0 && lk.present && rk.present && nl > 0 && nr > 0) {
+                    const bool build_right = nl > 4 * nr && nl > 4096;
+                    const TCol &bk = build_right ? rk : lk, &pk = build_right ? lk : rk;
+                    const int64_t nb = build_right ? nr : nl, np = build_right ? nl : nr;
+                    int64_t kmin = 0, kmax = 0;
+                    FG_TRY(int_col_stats(bk, nb, &kmin, &kmax));
+                    if (dense_range_ok(kmin, kmax, nb, bk.c.type == ColType::U64)) {
+                        FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
+                                          &pairs));
+                        t->rows = pairs;
+                        FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
+                        return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+                    }
+                }
                 int64_t *kl = nullptr, *kr = nullptr;
                 if (text_keys) {  // equal strings <-> equal dictionary codes (exact: full byte compare inside utf8_codes)
                     if (!lk.present || !rk.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
@@ -1414,8 +1624,6 @@ struct Exec {
                     FG_TRY(key_i64(n, lk, nl, "kl", &kl));
                     FG_TRY(key_i64(n, rk, nr, "kr", &kr));
                 }
-                int32_t *lrows = nullptr, *rrows = nullptr;
-                int64_t pairs = 0;
                 FG_TRY(join_key64(ctx, node_key(pl, n, "join").c_str(), kl, nl, kr, nr, &lrows, &rrows, &pairs));
                 t->rows = pairs;
                 FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
@@ -1534,25 +1742,29 @@ struct Exec {
         // ... and a 64-bit key (Int64 / UInt64 / Timestamp) hands its validity to the GROUP BY itself, which keeps the NULLs in a slot of their own
         const bool wide_null_keys = null_keys && !pair && k.c.type != ColType::I32 && k.c.type != ColType::UTF8 && k.c.type != ColType::F64;
         if (null_keys && pair) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a two-column GROUP BY key");
-        if (pair) {
-            const TCol &k2 = in.cols[(size_t)n->group[1]];
-            if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
-                return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
-            if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a two-column GROUP BY key");
-            FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
-            FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
-        } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
-            if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
-            FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
-            FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), k.c, in.rows, keys, nullptr, 0, nullptr));
-            // (a NULL's bytes are whatever its slot holds -- usually nothing, which is also the empty string's code: NULLs get their own key;
-            // the group's key comes out NULL through the validity of its first row, take_column below)
-            if (null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
-        } else {
-            if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
-            FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
-            if (null_keys && !wide_null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
-        }
+        // the generic table's keys: every key column normalised to one int64 per row (not needed by the dense path below)
+        auto prepare_keys = [&]() -> int {
+            if (pair) {
+                const TCol &k2 = in.cols[(size_t)n->group[1]];
+                if (k.c.type != ColType::I32 || k2.c.type != ColType::I32 || !k.present || !k2.present)
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Int32) / (Int32, Utf8)");
+                if (k2.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: NULLs in a two-column GROUP BY key");
+                FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
+                FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(k.c.values), static_cast<const int32_t *>(k2.c.values), in.rows, keys));
+            } else if (k.c.type == ColType::UTF8) {  // group on the strings' dictionary codes; the key column is taken from the first rows
+                if (!k.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+                FG_TRY(arena_get_t(ctx, node_key(pl, n, "gk").c_str(), (size_t)in.rows + 2, &keys));
+                FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), k.c, in.rows, keys, nullptr, 0, nullptr));
+                // (a NULL's bytes are whatever its slot holds -- usually nothing, which is also the empty string's code: NULLs get their own key;
+                // the group's key comes out NULL through the validity of its first row, take_column below)
+                if (null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
+            } else {
+                if (k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: GROUP BY a Float64 column");
+                FG_TRY(key_i64(n, k, in.rows, "gk", &keys));
+                if (null_keys && !wide_null_keys) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, in.rows, kNullKey));
+            }
+            return FLOCKGPU_OK;
+        };
         AggSpec specs[kMaxGroupAggs];
         int n_specs = 0;
         struct Out { int first = 0, count = 1; };  // accumulators of aggregate a
@@ -1604,7 +1816,23 @@ struct Exec {
             outs.push_back(o);
         }
         GroupResultN g;
-        FG_TRY(group_by_key64_n(ctx, node_key(pl, n, "grp").c_str(), keys, in.rows, specs, n_specs, &g, wide_null_keys ? k.c.valid : nullptr));
+        // A dense integer key without NULLs under integer accumulators without NULLs: the perfect-hash GROUP BY (relops.hpp "dense integer
+        // keys") -- slot = key - min over the column's exact range, no hashing, no int64 copy of the key column.  Everything else (Utf8 /
+        // two-column keys, NULLs, Float64 accumulators, keys spread wider than their row count) takes the hash table.
+        bool dense = !pair && !null_keys && k.present && in.rows > 0 && (k.c.type == ColType::I32 || k.c.type == ColType::I64 || k.c.type == ColType::U64);
+        for (int a = 0; a < n_specs && dense; ++a)
+            dense = !specs[a].valid && specs[a].op != AggOp::SUM_F64 && specs[a].op != AggOp::MAX_F64 && specs[a].op != AggOp::MIN_F64;
+        int64_t kmin = 0, kmax = 0;
+        if (dense) {
+            FG_TRY(int_col_stats(k, in.rows, &kmin, &kmax));
+            dense = dense_range_ok(kmin, kmax, in.rows, k.c.type == ColType::U64);
+        }
+        if (dense) {
+            FG_TRY(group_by_dense(ctx, node_key(pl, n, "grp").c_str(), k.c, in.rows, kmin, kmax, specs, n_specs, &g));
+        } else {
+            FG_TRY(prepare_keys());
+            FG_TRY(group_by_key64_n(ctx, node_key(pl, n, "grp").c_str(), keys, in.rows, specs, n_specs, &g, wide_null_keys ? k.c.valid : nullptr));
+        }
         t->rows = g.n_groups;
         // ---- key columns
         if (pair) {
@@ -2144,6 +2372,7 @@ static int feed_impl(flockgpu_plan *plan, int input, const struct ArrowSchema *s
             return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan_feed: Utf8 column exceeds 2^31 bytes");
     if (validate_only) return FLOCKGPU_OK;
     plan->has_retained = false;
+    plan->col_stats.clear();
     plan->scheme_state = scheme_state;
     plan->scheme_tag = scheme_tag;
     for (size_t c = 0; c < lf.schema.size(); ++c) {
@@ -2550,6 +2779,7 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
     flockgpu_ctx *ctx = plan->ctx;
     if (!plan->ring_ppw) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: the plan has no open ring (flockgpu_plan_ring_open)");
     API_CLOCK("feed_pane");
+    plan->col_stats.clear();
     if (input < 0 || input >= (int)plan->leaves.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "feed_pane: bad argument");
     const int64_t newest = plan->ring_first + plan->ring_n - 1;
     const bool begin = plan->ring_n == 0 || pane_id == newest + 1;
@@ -2695,6 +2925,7 @@ int flockgpu_plan_ring_close(flockgpu_plan *plan) {
 int flockgpu_plan_reset(flockgpu_plan *plan) {
     if (!plan) return FLOCKGPU_ERR_INVALID;
     if (plan->async_pending) return fail(plan->ctx, FLOCKGPU_ERR_INVALID, "plan_reset: an asynchronous execute is in flight (flockgpu_plan_wait first)");
+    plan->col_stats.clear();
     API_CLOCK("reset");
     // borrowed pinned buffers may still be read by the DMA engine: the caller is about to drop them
     if (plan->fed_bytes) (void)hipStreamSynchronize(plan->ctx->stream);

@@ -25,15 +25,19 @@ struct Field {
     bool nullable = false;
 };
 
-enum class EKind { Col, LitI, LitF, LitS, Bin, Cast };
+// Expression dialect (SURVEY.md appendix C + the unary / list expressions of the fork's expressions/*.rs, upstream DataFusion ~6:
+// IsNullExpr{arg}, IsNotNullExpr{arg}, NotExpr{arg}, NegativeExpr{arg}, InListExpr{expr, list, negated}).
+enum class EKind { Col, LitI, LitF, LitS, LitB, LitNull, Bin, Cast, Not, IsNull, IsNotNull, Neg, InList };
 struct Expr {
     EKind kind = EKind::Col;
     int col = -1;  // Col: index into the input schema
-    int64_t i = 0;
+    int64_t i = 0;   // LitI value / LitB 0 | 1
     double f = 0;
     std::string s;   // LitS value / Bin operator (Rust enum ident: Eq, NotEq, Lt, LtEq, Gt, GtEq, And, Or, Modulo, Multiply)
     ColType cast_to = ColType::I64;
-    std::unique_ptr<Expr> l, r;  // Bin operands; Cast operand in l
+    std::unique_ptr<Expr> l, r;  // Bin operands; the operand of Cast / Not / IsNull / IsNotNull / Neg / InList in l
+    std::vector<std::unique_ptr<Expr>> list;   // InList: the literals
+    bool negated = false;                      // InList: NOT IN
 };
 
 enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit };
@@ -195,6 +199,8 @@ struct Builder {
                 val = val->obj[0].second.get();
             }
             if (!val) { fail("literal without value"); return nullptr; }
+            if (val->kind == JValue::Null) { x->kind = EKind::LitNull; return x; }   // ScalarValue::Int32(None) and its siblings
+            if (val->kind == JValue::Bool) { x->kind = EKind::LitB; x->i = val->b ? 1 : 0; return x; }
             if (val->kind == JValue::Str) { x->kind = EKind::LitS; x->s = val->str; return x; }
             if (val->kind == JValue::Num) {
                 if (val->is_int && kind.find("Float") == std::string::npos) { x->kind = EKind::LitI; x->i = val->inum; }
@@ -217,6 +223,25 @@ struct Builder {
             x->l = expr(e->get("left"), schema);
             x->r = expr(e->get("right"), schema);
             return x->l && x->r ? std::move(x) : nullptr;
+        }
+        if (t == "not_expr" || t == "is_null_expr" || t == "is_not_null_expr" || t == "negative_expr") {
+            x->kind = t == "not_expr" ? EKind::Not : t == "is_null_expr" ? EKind::IsNull : t == "is_not_null_expr" ? EKind::IsNotNull : EKind::Neg;
+            const JValue *arg = e->get("arg");
+            x->l = expr(arg ? arg : e->get("expr"), schema);
+            return x->l ? std::move(x) : nullptr;
+        }
+        if (t == "in_list_expr") {
+            x->kind = EKind::InList;
+            x->l = expr(e->get("expr"), schema);
+            const JValue *list = e->get("list"), *neg = e->get("negated");
+            if (!x->l || !list || list->kind != JValue::Arr || list->arr.empty()) { if (x->l) fail("in_list_expr without a list"); return nullptr; }
+            x->negated = neg && neg->kind == JValue::Bool && neg->b;
+            for (auto &item : list->arr) {
+                auto li = expr(item.get(), schema);
+                if (!li) return nullptr;
+                x->list.push_back(std::move(li));
+            }
+            return x;
         }
         fail("physical_expr '" + t + "' is not supported");
         return nullptr;
@@ -468,6 +493,7 @@ inline void expr_cols(const Expr *e, std::set<int> *out) {
     if (e->kind == EKind::Col) out->insert(e->col);
     expr_cols(e->l.get(), out);
     expr_cols(e->r.get(), out);
+    for (auto &li : e->list) expr_cols(li.get(), out);
 }
 
 // Marks, top-down, the output columns of every node that something above it reads; leaves learn which of their

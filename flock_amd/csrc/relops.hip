@@ -441,6 +441,268 @@ __global__ __launch_bounds__(kBlock) void avg_finish_kernel(const double *__rest
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = sum[i] / (double)count[i];
 }
 
+
+// ---- column statistics: per-block minimum / maximum of an integer column (signed order, or unsigned for UInt64), folded on the host
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const void *__restrict__ v, int32_t type, int64_t n, int64_t *__restrict__ block_out) {
+    __shared__ int64_t s_mn[kWavesPerBlock], s_mx[kWavesPerBlock];
+    const bool uns = type == (int32_t)ColType::U64;
+    const uint64_t flip = uns ? 0ull : (1ull << 63);   // both orders as unsigned order
+    uint64_t mn = ~0ull, mx = 0ull;
+    if (type == (int32_t)ColType::I32) {
+        const int32_t *col = static_cast<const int32_t *>(v);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+            const int4 t = *reinterpret_cast<const int4 *>(col + 4 * i);
+            const int32_t lo = min(min(t.x, t.y), min(t.z, t.w)), hi = max(max(t.x, t.y), max(t.z, t.w));
+            const uint64_t a = (uint64_t)(int64_t)lo ^ flip, b = (uint64_t)(int64_t)hi ^ flip;
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const uint64_t a = (uint64_t)(int64_t)col[4 * n4 + threadIdx.x] ^ flip;
+            mn = a < mn ? a : mn;
+            mx = a > mx ? a : mx;
+        }
+    } else {
+        const int64_t *col = static_cast<const int64_t *>(v);
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+            const uint64_t a = (uint64_t)col[i] ^ flip;
+            mn = a < mn ? a : mn;
+            mx = a > mx ? a : mx;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = wave_xor_u64(mn, o), b = wave_xor_u64(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) {
+        s_mn[threadIdx.x >> 6] = (int64_t)mn;
+        s_mx[threadIdx.x >> 6] = (int64_t)mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            mn = (uint64_t)s_mn[w] < mn ? (uint64_t)s_mn[w] : mn;
+            mx = (uint64_t)s_mx[w] > mx ? (uint64_t)s_mx[w] : mx;
+        }
+        block_out[blockIdx.x] = (int64_t)(mn ^ flip);
+        block_out[gridDim.x + blockIdx.x] = (int64_t)(mx ^ flip);
+    }
+}
+
+// ---- GROUP BY over a DENSE integer key (group_by_dense): the key's offset from the column minimum IS its slot -- no hashing, no claim,
+// no probing.  One workgroup per 8192 consecutive rows:
+//   * the tile's slots and their range; when the range fits kDenseBins (NEXMark: an 8192-bid tile names ~600 consecutive auctions; any
+//     stream whose keys cluster in time) the tile is aggregated in LDS and flushed as one run of consecutive slots -- a few cache lines of
+//     fire-and-forget atomics per wave instruction; a wider tile sends every row's update to the global table directly;
+//   * the rows that carry the wave's most frequent slot (half of NEXMark's bids name one auction) never reach an atomic: counted by
+//     ballot + popcount, their values folded per lane and reduced once per wave.
+constexpr int kDenseBins = 2048;
+constexpr int kDenseTile = 8192;
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+// kAcc: some accumulator besides the row count (COUNT-only GROUP BYs -- the reference's arch/ops/group-by.sql, q5's inner query -- run the
+// instance without the accumulator paths' registers)
+template <bool kKey64, bool kAcc>
+__global__ __launch_bounds__(kBlock) void dense_group_kernel(const void *__restrict__ keys, int64_t n_rows, int64_t kmin, uint32_t range, AggSpecs sp,
+                                                             uint32_t *__restrict__ g_cnt, uint64_t *__restrict__ g_acc, uint32_t *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_mem[];   // accumulators [n_acc][kDenseBins] | row counts [kDenseBins]
+    uint64_t *s_acc = s_mem;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mem + (size_t)(kAcc ? sp.n : 0) * kDenseBins);
+    __shared__ uint32_t s_red[2][kWavesPerBlock];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int n_acc = kAcc ? sp.n : 0;
+    for (uint32_t i = threadIdx.x; i < kDenseBins; i += kBlock) {
+        s_cnt[i] = 0;
+        for (int a = 0; a < n_acc; ++a) s_acc[(size_t)a * kDenseBins + i] = agg_identity(sp.op[a]);
+    }
+    // the tile's slots: wave w holds rows [t0 + w * 2048, + 2048), lane l of iteration it the four rows at + it * 256 + 4 l
+    const int64_t t0 = (int64_t)blockIdx.x * kDenseTile + wave * (kDenseTile / kWavesPerBlock) + lane * 4;
+    constexpr uint32_t kNone = 0xffffffffu;
+    uint32_t s[kFlagIters][4];
+    uint32_t mn = kNone, mx = 0, bad = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = t0 + it * 256;
+        uint32_t d[4];      // key - kmin (mod 2^32)
+        uint32_t wide = 0;  // bit j: the 64-bit difference does not fit 32 bits (64-bit keys only; an Int32 column's differences always do)
+        if (kKey64) {
+            uint64_t k[4];
+            if (r0 + 4 <= n_rows) {
+                const int4 a = *reinterpret_cast<const int4 *>(static_cast<const int64_t *>(keys) + r0), b = *reinterpret_cast<const int4 *>(static_cast<const int64_t *>(keys) + r0 + 2);
+                k[0] = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+                k[1] = ((uint64_t)(uint32_t)a.w << 32) | (uint32_t)a.z;
+                k[2] = ((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x;
+                k[3] = ((uint64_t)(uint32_t)b.w << 32) | (uint32_t)b.z;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k[j] = r0 + j < n_rows ? (uint64_t) static_cast<const int64_t *>(keys)[r0 + j] : (uint64_t)kmin;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t x = k[j] - (uint64_t)kmin;
+                d[j] = (uint32_t)x;
+                wide |= (uint32_t)((x >> 32) != 0) << j;
+            }
+        } else {
+            const int32_t *col = static_cast<const int32_t *>(keys);
+            int32_t k[4];
+            if (r0 + 4 <= n_rows) {
+                const int4 a = stream_load4(col + r0);
+                k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k[j] = r0 + j < n_rows ? col[r0 + j] : (int32_t)kmin;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (uint32_t)k[j] - (uint32_t)(int32_t)kmin;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = r0 + j < n_rows;
+            const bool in = d[j] < range && !((wide >> j) & 1u);
+            bad |= (uint32_t)(live && !in);
+            const uint32_t sl = live && in ? d[j] : kNone;
+            s[it][j] = sl;
+            mn = sl < mn ? sl : mn;
+            mx = sl != kNone && sl > mx ? sl : mx;
+        }
+    }
+    if (__ballot(bad != 0) && lane == 0) atomicOr(err, 1u);   // (a key outside the statistics the table was sized from: the call is void)
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if (lane == 0) {
+        s_red[0][wave] = mn;
+        s_red[1][wave] = mx;
+    }
+    __syncthreads();   // (also: the bins are initialised)
+    uint32_t tmin = s_red[0][0], tmax = s_red[1][0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+        tmin = s_red[0][w] < tmin ? s_red[0][w] : tmin;
+        tmax = s_red[1][w] > tmax ? s_red[1][w] : tmax;
+    }
+    if (tmin == kNone) return;   // no live row in the tile (block-uniform)
+    const bool in_lds = tmax - tmin < (uint32_t)kDenseBins;   // block-uniform
+    // the wave's hot slot: the most frequent of three candidates among the first iteration's rows
+    uint32_t hot = kNone;
+    {
+        int best = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)s[0][0], c * 21);
+            const int cnt = cand == kNone ? 0 : __popcll((unsigned long long)__ballot(s[0][0] == cand));
+            if (cnt > best) {
+                best = cnt;
+                hot = cand;
+            }
+        }
+        if (best < 8) hot = kNone;   // nothing worth the wave-level path
+    }
+    uint32_t hot_cnt = 0;
+    uint64_t hv[kMaxGroupAggs];
+    for (int a = 0; a < n_acc; ++a) hv[a] = agg_identity(sp.op[a]);
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = t0 + it * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t sl = s[it][j];
+            const bool live = sl != kNone;
+            const bool is_hot = live && sl == hot;
+            hot_cnt += (uint32_t)__popcll((unsigned long long)__ballot(is_hot));
+            if (kAcc) {
+                uint64_t val[kMaxGroupAggs];
+                for (int a = 0; a < n_acc; ++a) val[a] = live ? agg_row_value(sp.op[a], sp, a, r0 + j) : agg_identity(sp.op[a]);
+                if (is_hot)
+                    for (int a = 0; a < n_acc; ++a) hv[a] = agg_combine(sp.op[a], hv[a], val[a]);
+                if (live && !is_hot) {
+                    if (in_lds) {
+                        atomicAdd(&s_cnt[sl - tmin], 1u);
+                        for (int a = 0; a < n_acc; ++a) agg_merge(&s_acc[(size_t)a * kDenseBins + (sl - tmin)], sp.op[a], val[a]);
+                    } else {
+                        atomicAdd(&g_cnt[sl], 1u);
+                        for (int a = 0; a < n_acc; ++a) agg_merge(&g_acc[(size_t)a * range + sl], sp.op[a], val[a]);
+                    }
+                }
+            } else if (live && !is_hot) {
+                if (in_lds) atomicAdd(&s_cnt[sl - tmin], 1u);
+                else atomicAdd(&g_cnt[sl], 1u);
+            }
+        }
+    }
+    if (hot_cnt) {   // (wave-uniform) the hot slot's rows: one update for the wave
+        for (int a = 0; a < n_acc; ++a) {
+            uint64_t v = hv[a];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = agg_combine(sp.op[a], v, wave_xor_u64(v, o));
+            hv[a] = v;
+        }
+        if (lane == 0) {
+            if (in_lds) {
+                atomicAdd(&s_cnt[hot - tmin], hot_cnt);
+                for (int a = 0; a < n_acc; ++a) agg_merge(&s_acc[(size_t)a * kDenseBins + (hot - tmin)], sp.op[a], hv[a]);
+            } else {
+                atomicAdd(&g_cnt[hot], hot_cnt);
+                for (int a = 0; a < n_acc; ++a) agg_merge(&g_acc[(size_t)a * range + hot], sp.op[a], hv[a]);
+            }
+        }
+    }
+    if (!in_lds) return;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= tmax - tmin; b += kBlock) {
+        const uint32_t c = s_cnt[b];
+        if (!c) continue;
+        atomicAdd(&g_cnt[tmin + b], c);
+        for (int a = 0; a < n_acc; ++a) agg_merge(&g_acc[(size_t)a * range + tmin + b], sp.op[a], s_acc[(size_t)a * kDenseBins + b]);
+    }
+}
+// live slots (count != 0) as flag words in the flag-tile geometry: a lane's four consecutive slots are one 16-byte load
+__global__ __launch_bounds__(kBlock) void dense_live_flag_kernel(const uint32_t *__restrict__ cnt, int64_t n_slots, SegTiles st, uint32_t *__restrict__ flag_words,
+                                                                 uint32_t *__restrict__ counts) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        const int64_t r0 = wbase + it * 256;
+        if (r0 + 4 <= n_slots) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(cnt + r0);
+            flags |= ((uint32_t)(t.x != 0) | ((uint32_t)(t.y != 0) << 1) | ((uint32_t)(t.z != 0) << 2) | ((uint32_t)(t.w != 0) << 3)) << (it * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) flags |= (uint32_t)(r0 + j < n_slots && cnt[r0 + j] != 0) << (it * 4 + j);
+        }
+    }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+struct DenseOuts {
+    uint64_t *out[kMaxGroupAggs];
+    int32_t acc_of[kMaxGroupAggs];   // -1: the row count itself (COUNT)
+    int32_t n;
+};
+__global__ __launch_bounds__(kBlock) void dense_collect_kernel(const int32_t *__restrict__ slots, int64_t n_groups, int64_t kmin, uint32_t range,
+                                                               const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ acc, int64_t *__restrict__ keys,
+                                                               DenseOuts o) {
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * kBlock) {
+        const uint32_t sl = (uint32_t)slots[g];
+        keys[g] = (int64_t)((uint64_t)kmin + sl);
+        for (int a = 0; a < o.n; ++a) o.out[a][g] = o.acc_of[a] < 0 ? (uint64_t)cnt[sl] : acc[(size_t)o.acc_of[a] * range + sl];
+    }
+}
+__global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t *__restrict__ p, int64_t n, uint64_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+
 // ---- distinct (int32, Utf8)
 __device__ __forceinline__ bool same_pair(const int32_t *key, const int32_t *off, const uint8_t *bytes, int32_t a, int32_t b) {
     if (key[a] != key[b]) return false;
@@ -620,6 +882,50 @@ __global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__res
             }
         }
         if (!kEmit) {
+            counts[i] = c;
+            mine += (unsigned long long)c;
+        }
+    }
+    if (!kEmit) {
+        mine = wave_sum_u64(mine);
+        if (lane_id() == 0 && mine) atomicAdd(total64, mine);
+    }
+}
+// ---- join on a DENSE integer key (join_dense): the build side's key offsets from their minimum address the chain heads directly -- the
+// multimap of join_build_kernel without a key table, a claim or a probe walk.  Keys are read in their column's own type (no int64 copy).
+__global__ __launch_bounds__(kBlock) void join_build_dense_kernel(const void *__restrict__ keys, int32_t type, int64_t n, int64_t kmin, uint32_t range,
+                                                                  int32_t *head, int32_t *__restrict__ next, uint32_t *err) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t d = (uint64_t)load_as_i64(keys, type, i) - (uint64_t)kmin;
+        if (d >= range) {   // (outside the statistics the table was sized from: the call is void)
+            atomicOr(err, 1u);
+            continue;
+        }
+        next[i] = atomicExch(&head[d], (int32_t)i);  // push front: the chain is walked only after the kernel boundary
+    }
+}
+template <bool kEmit>
+__global__ __launch_bounds__(kBlock) void join_probe_dense_kernel(const void *__restrict__ keys, int32_t type, int64_t n, int64_t kmin, uint32_t range,
+                                                                  const int32_t *__restrict__ head, const int32_t *__restrict__ next,
+                                                                  int32_t *__restrict__ counts, int32_t *__restrict__ out_left, int32_t *__restrict__ out_right,
+                                                                  unsigned long long *__restrict__ total64) {
+    unsigned long long mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t d = (uint64_t)load_as_i64(keys, type, i) - (uint64_t)kmin;
+        int32_t c = 0;
+        int32_t r = d < range ? head[d] : -1;
+        if (kEmit) {
+            if (r >= 0) {
+                int32_t m = 0;
+                for (int32_t q = r; q >= 0; q = next[q]) ++m;
+                const int64_t at = (int64_t)counts[i] - m;   // (inclusive scan: this row's pairs end at counts[i])
+                for (; r >= 0; r = next[r], ++c) {
+                    out_left[at + c] = r;
+                    out_right[at + c] = (int32_t)i;
+                }
+            }
+        } else {
+            for (; r >= 0; r = next[r]) ++c;
             counts[i] = c;
             mine += (unsigned long long)c;
         }
@@ -1129,6 +1435,131 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
     return FLOCKGPU_OK;
 }
 
+int column_minmax(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *mn, int64_t *mx) {
+    *mn = *mx = 0;
+    if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "column statistics need an integer column");
+    if (rows <= 0) return FLOCKGPU_OK;
+    const unsigned blocks = std::min<unsigned>(grid_for(ctx, rows / 4 + 1), 1024);
+    int64_t *d = nullptr, *h = nullptr;
+    FG_TRY(arena_get_t(ctx, "relops.minmax", 2048, &d));
+    FG_TRY(pinned_get_t(ctx, "relops.minmax", 2048, &h));
+    {
+        LaunchScope ls(ctx, "minmax_kernel");
+        hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, (int32_t)col.type, rows, d);
+    }
+    FG_TRY(check_launch(ctx, "minmax_kernel"));
+    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * 2 * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool uns = col.type == ColType::U64;
+    int64_t lo = h[0], hi = h[blocks];
+    for (unsigned b = 1; b < blocks; ++b) {
+        if (uns ? (uint64_t)h[b] < (uint64_t)lo : h[b] < lo) lo = h[b];
+        if (uns ? (uint64_t)h[blocks + b] > (uint64_t)hi : h[blocks + b] > hi) hi = h[blocks + b];
+    }
+    *mn = lo;
+    *mx = hi;
+    return FLOCKGPU_OK;
+}
+
+bool dense_range_ok(int64_t kmin, int64_t kmax, int64_t rows, bool uns) {
+    const uint64_t span = (uint64_t)kmax - (uint64_t)kmin;   // (mod 2^64: the true span for either signedness when kmin <= kmax in its order)
+    if (uns ? (uint64_t)kmax < (uint64_t)kmin : kmax < kmin) return false;
+    // a slot per key value: affordable while there is about a row per slot (clearing and compacting the table costs 4-12 bytes per slot)
+    return span < (uint64_t)std::max<int64_t>(int64_t(1) << 16, rows) && span < (uint64_t(1) << 31) - 1;
+}
+
+int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, int64_t rows, int64_t kmin, int64_t kmax, const AggSpec *specs, int n_specs,
+                   GroupResultN *out) {
+    *out = GroupResultN{};
+    const std::string base = name;
+    if (n_specs < 0 || n_specs > kMaxGroupAggs) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than %d accumulators per group", name, kMaxGroupAggs);
+    if (key.valid || (key.type != ColType::I32 && key.type != ColType::I64 && key.type != ColType::U64) || rows <= 0 || rows >= (int64_t(1) << 31) ||
+        !dense_range_ok(kmin, kmax, rows, key.type == ColType::U64))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: not a dense integer key", name);
+    const uint32_t range = (uint32_t)((uint64_t)kmax - (uint64_t)kmin + 1);
+    AggSpecs sp{};
+    DenseOuts o{};
+    o.n = n_specs;
+    for (int a = 0; a < n_specs; ++a) {
+        if (specs[a].valid) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: the dense path takes arguments without NULLs", name);
+        if (specs[a].op == AggOp::COUNT) {
+            o.acc_of[a] = -1;
+            continue;
+        }
+        if (specs[a].op == AggOp::SUM_F64 || specs[a].op == AggOp::MAX_F64 || specs[a].op == AggOp::MIN_F64 || !specs[a].values ||
+            specs[a].type == ColType::F64 || specs[a].type == ColType::UTF8)
+            return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: the dense path takes integer accumulators", name);
+        o.acc_of[a] = sp.n;
+        sp.values[sp.n] = specs[a].values;
+        sp.op[sp.n] = (int32_t)specs[a].op;
+        sp.type[sp.n] = (int32_t)specs[a].type;
+        ++sp.n;
+    }
+    uint32_t *cnt = nullptr, *d_err = nullptr, *h_err = nullptr;
+    uint64_t *acc = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".dcnt").c_str(), (size_t)range + 8, &cnt));
+    FG_TRY(arena_get_t(ctx, (base + ".dacc").c_str(), (size_t)range * (size_t)std::max(sp.n, 1) + 2, &acc));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)range, ctx->stream));
+    for (int a = 0; a < sp.n; ++a) {
+        const uint64_t id = sp.op[a] == (int32_t)AggOp::MAX_S ? (uint64_t)INT64_MIN : sp.op[a] == (int32_t)AggOp::MIN_S ? (uint64_t)INT64_MAX : sp.op[a] == (int32_t)AggOp::MIN_U ? ~0ull : 0ull;
+        if (id == 0) FG_HIP(ctx, hipMemsetAsync(acc + (size_t)a * range, 0, sizeof(uint64_t) * (size_t)range, ctx->stream));
+        else RELOPS_LAUNCH(ctx, "fill_u64_kernel", fill_u64_kernel, (int64_t)range, acc + (size_t)a * range, (int64_t)range, id);
+    }
+    {
+        const size_t lds = (size_t)kDenseBins * (4 + 8 * (size_t)sp.n);
+        const unsigned tiles = (unsigned)div_up(rows, kDenseTile);
+        LaunchScope ls(ctx, "dense_group_kernel");
+        const bool k64 = key.type != ColType::I32;
+        if (sp.n == 0) {
+            if (k64) hipLaunchKernelGGL((dense_group_kernel<true, false>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);
+            else hipLaunchKernelGGL((dense_group_kernel<false, false>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);
+        } else {
+            if (k64) hipLaunchKernelGGL((dense_group_kernel<true, true>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);
+            else hipLaunchKernelGGL((dense_group_kernel<false, true>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);
+        }
+    }
+    FG_TRY(check_launch(ctx, "dense_group_kernel"));
+    // the live slots, in key order
+    int64_t sb = 0, se = (int64_t)range;
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, (base + ".dtiles").c_str(), &sb, &se, 1, kFlagTile, &st));
+    uint32_t *flags = nullptr, *counts = nullptr;
+    uint64_t *tile_base = nullptr;
+    int64_t *d_off = nullptr, *h_off = nullptr;
+    int32_t *slots = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".dflags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
+    FG_TRY(arena_get_t(ctx, (base + ".dcounts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (base + ".dbase").c_str(), (size_t)st.n_tiles + 1, &tile_base));
+    FG_TRY(arena_get_t(ctx, (base + ".doff").c_str(), 2, &d_off));
+    FG_TRY(pinned_get_t(ctx, (base + ".doff").c_str(), 2, &h_off));
+    FG_TRY(arena_get_t(ctx, (base + ".dslots").c_str(), (size_t)std::min<int64_t>(range, rows) + 4, &slots));
+    {
+        LaunchScope ls(ctx, "dense_live_flag_kernel");
+        hipLaunchKernelGGL(dense_live_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, cnt, (int64_t)range, st, flags, counts);
+    }
+    FG_TRY(check_launch(ctx, "dense_live_flag_kernel"));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, slots));
+    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
+    const int64_t n_groups = h_off[1];
+    int64_t *ok = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".ok").c_str(), (size_t)n_groups + 2, &ok));
+    for (int a = 0; a < n_specs; ++a) {
+        FG_TRY(arena_get_t(ctx, (base + ".oa" + std::to_string(a)).c_str(), (size_t)n_groups + 2, &o.out[a]));
+        out->agg[a] = o.out[a];
+    }
+    if (n_groups > 0) RELOPS_LAUNCH(ctx, "dense_collect_kernel", dense_collect_kernel, n_groups, slots, n_groups, kmin, range, cnt, acc, ok, o);
+    out->n_groups = n_groups;
+    out->keys = ok;
+    return FLOCKGPU_OK;
+}
+
 int pack_i32_pair(flockgpu_ctx *ctx, const int32_t *a, const int32_t *b, int64_t n, int64_t *out) {
     if (n <= 0) return FLOCKGPU_OK;
     RELOPS_LAUNCH(ctx, "pack_pair_kernel", pack_pair_kernel, n, a, b, n, out);
@@ -1273,6 +1704,57 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     if (total > 0)
         RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<true>, n_right, right, n_right, tk, head, next, cap, counts, ol, orr,
                       (unsigned long long *)nullptr);
+    *left_rows = ol;
+    *right_rows = orr;
+    *n_pairs = total;
+    return FLOCKGPU_OK;
+}
+
+int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64_t n_left, int64_t kmin, int64_t kmax, const DevColumn &right, int64_t n_right,
+               int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs) {
+    const std::string base = name;
+    *n_pairs = 0;
+    *left_rows = *right_rows = nullptr;
+    auto is_int = [](const DevColumn &c) { return c.type == ColType::I32 || c.type == ColType::I64 || c.type == ColType::U64; };
+    if (!is_int(left) || !is_int(right) || left.valid || right.valid || ((left.type == ColType::U64) != (right.type == ColType::U64)) ||
+        !dense_range_ok(kmin, kmax, n_left, left.type == ColType::U64) || n_left >= (int64_t(1) << 31) || n_right >= (int64_t(1) << 31))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: not a dense integer join key", name);
+    const uint32_t range = (uint32_t)((uint64_t)kmax - (uint64_t)kmin + 1);
+    int32_t *head = nullptr, *next = nullptr, *counts = nullptr, *ol = nullptr, *orr = nullptr;
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    unsigned long long *d_tot64 = nullptr, *h_tot64 = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".dhead").c_str(), (size_t)range + 4, &head));
+    FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
+    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot64));
+    FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot64));
+    if (n_left <= 0 || n_right <= 0) {
+        FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
+        FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), 4, &orr));
+        *left_rows = ol;
+        *right_rows = orr;
+        return FLOCKGPU_OK;
+    }
+    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(d_tot64, 0, sizeof(unsigned long long), ctx->stream));
+    FG_HIP(ctx, hipMemsetAsync(head, 0xff, sizeof(int32_t) * (size_t)range, ctx->stream));   // -1: empty chain
+    RELOPS_LAUNCH(ctx, "join_build_dense_kernel", join_build_dense_kernel, n_left, left.values, (int32_t)left.type, n_left, kmin, range, head, next, d_err);
+    RELOPS_LAUNCH(ctx, "join_probe_dense_kernel", join_probe_dense_kernel<false>, n_right, right.values, (int32_t)right.type, n_right, kmin, range, head, next, counts,
+                  (int32_t *)nullptr, (int32_t *)nullptr, d_tot64);
+    FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
+    FG_HIP(ctx, hipMemcpyAsync(h_tot64, d_tot64, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a build key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
+    if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);
+    const int64_t total = (int64_t)h_tot64[0];
+    FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)total + 4, &ol));
+    FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)total + 4, &orr));
+    if (total > 0)
+        RELOPS_LAUNCH(ctx, "join_probe_dense_kernel", join_probe_dense_kernel<true>, n_right, right.values, (int32_t)right.type, n_right, kmin, range, head, next, counts, ol,
+                      orr, (unsigned long long *)nullptr);
     *left_rows = ol;
     *right_rows = orr;
     *n_pairs = total;

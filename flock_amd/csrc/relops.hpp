@@ -97,6 +97,15 @@ struct GroupResultN {
 // key_valid (may be null): rows whose key is NULL -- whatever their key bits -- form one group of their own
 int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, int64_t rows, const AggSpec *specs, int n_specs,
                      GroupResultN *out, const uint8_t *key_valid = nullptr);
+// ---- dense integer keys: the perfect-hash variants of GROUP BY and JOIN.  Exact minimum / maximum of an integer column (signed order;
+// unsigned for UInt64), through ONE synchronisation; `dense_range_ok`: the key range is affordable as a direct-address table for `rows` rows.
+int column_minmax(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *mn, int64_t *mx);
+bool dense_range_ok(int64_t kmin, int64_t kmax, int64_t rows, bool uns);
+// GROUP BY `key` (Int32 / Int64 / UInt64, no NULLs, every key inside [kmin, kmax]) with COUNT / SUM_INT / MIN / MAX accumulators over
+// integer columns without NULLs: slot = key - kmin, tiles aggregated in LDS, groups come out in key order.  first_row / validity outputs
+// are not produced (nothing on this path needs them).  A key outside [kmin, kmax] voids the call (FLOCKGPU_ERR_INVALID).
+int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, int64_t rows, int64_t kmin, int64_t kmax, const AggSpec *specs, int n_specs,
+                   GroupResultN *out);
 // ---- Utf8 keys (YSB joins and groups on UUID strings, flock/src/distributed_plan/planner.rs:298-346)
 // out[i] = 64-bit hash of row i's bytes: equal strings -> equal keys (enough for a hash repartition; NOT an equality test)
 int hash_utf8_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);
@@ -124,6 +133,11 @@ int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *o
 // inserts) -- callers compare multisets, as the reference does (test_util.rs:61-90).  Builds on the left (DataFusion's build side).
 // More than 2^31 - 1 pairs: FLOCKGPU_ERR_UNSUPPORTED, decided from a 64-bit total before anything is emitted.
 int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
+               int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
+
+// The same join when the BUILD side's keys are dense (every key of `left` inside [kmin, kmax], range affordable: dense_range_ok): chain heads
+// addressed by key - kmin, keys read in their columns' own types.  Pairs ordered by right row, as join_key64's.
+int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64_t n_left, int64_t kmin, int64_t kmax, const DevColumn &right, int64_t n_right,
                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
 
 // ---- hash partition: rows grouped by destination (input order kept): dest = (fmix32(fold(key)) * n) >> 32, the

@@ -47,6 +47,90 @@ def filter_exec(t: Table, pred: Callable[[dict], bool]) -> Table:
     return {k: [v[i] for i in keep] for k, v in t.items()}
 
 
+# -- physical expressions of the plan-JSON dialect, SQL three-valued logic ------------------------------------
+def _trunc_mod(a, m):
+    """Rust / Arrow `%` on integers: the remainder of the TRUNCATED quotient (sign of the dividend)."""
+    q = abs(a) // abs(m)
+    q = q if (a >= 0) == (m >= 0) else -q
+    return a - q * m
+
+
+def eval_physical_expr(e: dict, row: dict):
+    """Value of one serialised PhysicalExpr for one row (a dict column name -> python value, None = NULL): `column`, `literal`,
+    `cast_expr` / `try_cast_expr`, `binary_expr` (Eq NotEq Lt LtEq Gt GtEq And Or Modulo Multiply Plus Minus), `not_expr`,
+    `is_null_expr`, `is_not_null_expr`, `negative_expr`, `in_list_expr`.  Semantics: upstream DataFusion ~6:
+    a comparison / arithmetic with NULL is NULL; AND is FALSE as soon as one side is, OR is TRUE as soon as one side is (Kleene);
+    NOT NULL is NULL; x IN (..) is TRUE on a match, NULL when x is NULL, else FALSE; IS NULL never yields NULL."""
+    t = e["physical_expr"]
+    if t == "column":
+        return row[e["name"]]
+    if t == "literal":
+        v = e["value"]
+        return next(iter(v.values())) if isinstance(v, dict) else v
+    if t in ("cast_expr", "try_cast_expr"):
+        v = eval_physical_expr(e["expr"], row)
+        if v is None:
+            return None
+        ty = e["cast_type"]
+        if ty in ("Float64", "Float32"):
+            return float(v)
+        if isinstance(ty, str) and ty.startswith(("Int", "UInt")):
+            return int(v)
+        return v
+    if t == "not_expr":
+        v = eval_physical_expr(e.get("arg", e.get("expr")), row)
+        return None if v is None else (not v)
+    if t == "is_null_expr":
+        return eval_physical_expr(e.get("arg", e.get("expr")), row) is None
+    if t == "is_not_null_expr":
+        return eval_physical_expr(e.get("arg", e.get("expr")), row) is not None
+    if t == "negative_expr":
+        v = eval_physical_expr(e.get("arg", e.get("expr")), row)
+        return None if v is None else -v
+    if t == "in_list_expr":
+        v = eval_physical_expr(e["expr"], row)
+        if v is None:
+            return None
+        hit = any(v == eval_physical_expr(x, row) for x in e["list"])
+        return (not hit) if e.get("negated") else hit
+    if t == "binary_expr":
+        op = e["op"]
+        a, b = eval_physical_expr(e["left"], row), eval_physical_expr(e["right"], row)
+        if op == "And":
+            return False if (a is False or b is False) else (None if (a is None or b is None) else True)
+        if op == "Or":
+            return True if (a is True or b is True) else (None if (a is None or b is None) else False)
+        if a is None or b is None:
+            return None
+        if op == "Eq":
+            return a == b
+        if op == "NotEq":
+            return a != b
+        if op == "Lt":
+            return a < b
+        if op == "LtEq":
+            return a <= b
+        if op == "Gt":
+            return a > b
+        if op == "GtEq":
+            return a >= b
+        if op == "Modulo":
+            return _trunc_mod(a, b)
+        if op == "Multiply":
+            return a * b
+        if op == "Plus":
+            return a + b
+        if op == "Minus":
+            return a - b
+        raise ValueError("binary operator " + op)
+    raise ValueError("physical_expr " + t)
+
+
+def filter_by_expr(t: Table, pred: dict) -> Table:
+    """FilterExec with a serialised predicate: the rows for which it is TRUE."""
+    return filter_exec(t, lambda r: eval_physical_expr(pred, r))
+
+
 # -- ProjectionExec ---------------------------------------------------------------------------------
 def projection_exec(t: Table, exprs: Sequence[Tuple[str, Callable[[dict], object]]]) -> Table:
     names = list(t)

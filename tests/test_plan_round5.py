@@ -1,0 +1,339 @@
+"""Round-5 additions to the plan path (include/flockgpu_plan.h), each against the oracle:
+  * FilterExec predicates as ONE pass (pred.hip): the whole expression dialect -- comparisons, `%`, Utf8 = / <> / IN, IS [NOT] NULL, NOT,
+    -literal, AND / OR in three-valued logic -- on random expression trees over nullable columns;
+  * the dense (perfect-hash) GROUP BY and JOIN next to the hash-table ones: the same plans over keys that are dense and keys that are
+    spread far wider than their row count;
+  * the reference's operator harness, flock-function/src/aws/arch/ops/{filter,group-by,join,sort}.sql (source.rs:25-65: feed once,
+    execute repeatedly), on NEXMark events, fused pipelines allowed and generic operators only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import oracle
+from oracle import generic_ops as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLANS = os.path.join(ROOT, "tests", "golden", "plans")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def _field(name, dt, nullable=True):
+    return {"data_type": dt, "dict_id": 0, "dict_is_ordered": False, "name": name, "nullable": nullable}
+
+
+_TS = {"Timestamp": ["Millisecond", None]}
+F = [_field("i", "Int32"), _field("j", "Int32", False), _field("l", "Int64"), _field("f", "Float64"), _field("s", "Utf8"), _field("u", "UInt64", False)]
+NAMES = [f["name"] for f in F]
+WORDS = ["", "or", "id", "ca", "view", "a-longer-string-of-27-bytes", "exactly8", "nine-byte", "x" * 47]
+
+
+def col(name):
+    return {"physical_expr": "column", "name": name, "index": NAMES.index(name)}
+
+
+def lit(kind, v):
+    return {"physical_expr": "literal", "value": {kind: v}}
+
+
+def binary(l, op, r):
+    return {"physical_expr": "binary_expr", "left": l, "op": op, "right": r}
+
+
+def unary(tag, arg):
+    return {"physical_expr": tag, "arg": arg}
+
+
+def cast(e, t):
+    return {"physical_expr": "cast_expr", "expr": e, "cast_type": t}
+
+
+def scan():
+    return {"execution_plan": "memory_exec", "schema": {"fields": F, "metadata": {}}, "projection": list(range(len(F)))}
+
+
+def table(n, r, null_p=0.15):
+    nul = lambda xs, p: [None if r.random() < p else x for x in xs]
+    return {"i": nul([int(x) for x in r.integers(-40, 400, n)], null_p), "j": [int(x) for x in r.integers(-2**31, 2**31 - 1, n)],
+            "l": nul([int(x) for x in r.integers(-2**40, 2**40, n)], null_p), "f": nul([float(x) for x in np.round(r.normal(0, 50, n), 1)], null_p),
+            "s": nul([WORDS[int(x)] for x in r.integers(0, len(WORDS), n)], null_p), "u": [int(x) for x in r.integers(0, 2**63, n, dtype=np.uint64) * 2 + r.integers(0, 2, n, dtype=np.uint64)]}
+
+
+TYPES = [pa.int32(), pa.int32(), pa.int64(), pa.float64(), pa.string(), pa.uint64()]
+
+
+def batches(t, chunk):
+    n = len(t["i"])
+    return [pa.record_batch([pa.array(t[c][a:a + chunk], ty) for c, ty in zip(NAMES, TYPES)], names=NAMES) for a in range(0, max(n, 1), chunk)]
+
+
+def pyrows(rb):
+    return list(zip(*[rb[c].to_pylist() for c in rb.schema.names]))
+
+
+CMP = ["Eq", "NotEq", "Lt", "LtEq", "Gt", "GtEq"]
+
+
+def random_leaf(r):
+    k = int(r.integers(0, 12))
+    op = CMP[int(r.integers(0, 6))]
+    if k == 0:
+        return binary(col("i"), op, lit("Int32", int(r.integers(-50, 410))))
+    if k == 1:   # CAST(i AS Int64) % m op x -- the q2 shape, negative moduli, literals on the left
+        e = binary(cast(col("j"), "Int64"), "Modulo", lit("Int64", int(r.choice([123, 7, -5, 1, 2**31 - 1, 2**33 + 9, 4096]))))
+        x = lit("Int64", int(r.integers(-6, 7)))
+        return binary(x, op, e) if r.random() < 0.3 else binary(e, op, x)
+    if k == 2:
+        return binary(col("l"), op, lit("Int64", int(r.integers(-2**40, 2**40))))
+    if k == 3:
+        return binary(col("f"), op, lit("Float64", float(np.round(r.normal(0, 50), 1))))
+    if k == 4:
+        return binary(col("s"), "Eq" if r.random() < 0.6 else "NotEq", lit("Utf8", WORDS[int(r.integers(0, len(WORDS)))] if r.random() < 0.9 else "absent"))
+    if k == 5:
+        return unary("is_null_expr" if r.random() < 0.5 else "is_not_null_expr", col(str(r.choice(["i", "l", "f", "s", "j"]))))
+    if k == 6:
+        return {"physical_expr": "in_list_expr", "expr": col("s"), "negated": bool(r.random() < 0.4),
+                "list": [lit("Utf8", WORDS[int(x)]) for x in r.choice(len(WORDS), size=int(r.integers(1, 4)), replace=False)]}
+    if k == 7:
+        return {"physical_expr": "in_list_expr", "expr": col("i"), "negated": bool(r.random() < 0.4), "list": [lit("Int32", int(x)) for x in r.integers(-40, 400, int(r.integers(1, 5)))]}
+    if k == 8:   # column against column, mixed widths
+        a, b = r.choice(["i", "j", "l"], size=2, replace=False)
+        return binary(col(str(a)), op, col(str(b)))
+    if k == 9:   # CAST(int AS Float64) against a fractional literal; -literal
+        return binary(cast(col("i"), "Float64"), op, unary("negative_expr", lit("Float64", float(r.choice([-10.5, 0.0, 3.25, -399.0])))))
+    if k == 10:
+        return binary(col("u"), op, lit("UInt64", int(r.integers(0, 2**63, dtype=np.uint64)) * 2))
+    return binary(col("j"), op, lit("Int64", int(r.choice([0, -2**31, 2**31 - 1, 2**40, -2**40, 17]))))   # literals beyond the Int32 range fold to constants
+
+
+def random_pred(r, depth):
+    if depth == 0 or r.random() < 0.25:
+        return random_leaf(r)
+    k = r.random()
+    if k < 0.2:
+        return unary("not_expr", random_pred(r, depth - 1))
+    return binary(random_pred(r, depth - 1), "And" if k < 0.6 else "Or", random_pred(r, depth - 1))
+
+
+# ------------------------------------------------------------------ CPU
+def test_multiply_high_remainder_against_the_hardware():
+    """flock_amd/csrc/divmagic.hpp (what `col % m` compiles to on an Int32 column) against `%`, with g++ on the CPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "divmagic_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "flock_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "divmagic_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_oracle_three_valued_logic():
+    t = {"i": [1, None, 3, -7], "s": ["a", None, "b", "a"]}
+    c = lambda n: {"physical_expr": "column", "name": n}
+    lt2 = binary(c("i"), "Lt", lit("Int64", 2))
+    assert g.filter_by_expr(t, lt2)["i"] == [1, -7]
+    assert g.filter_by_expr(t, unary("not_expr", lt2))["i"] == [3]                                   # NOT NULL is NULL: the NULL row stays out
+    assert g.filter_by_expr(t, binary(lt2, "Or", unary("is_null_expr", c("i"))))["i"] == [1, None, -7]
+    assert g.filter_by_expr(t, binary(unary("not_expr", lt2), "And", unary("is_not_null_expr", c("s"))))["i"] == [3]
+    assert g.filter_by_expr(t, {"physical_expr": "in_list_expr", "expr": c("s"), "negated": True, "list": [lit("Utf8", "a")]})["s"] == ["b"]
+    assert g.filter_by_expr(t, binary(binary(cast(c("i"), "Int64"), "Modulo", lit("Int64", 3)), "Eq", lit("Int64", -1)))["i"] == [-7]   # truncated remainder
+    assert g.filter_by_expr(t, binary(lit("Boolean", False), "Or", binary(c("i"), "Gt", unary("negative_expr", lit("Int64", 8)))))["i"] == [1, 3, -7]
+
+
+def test_arch_plans_parse_into_the_operator_tree():
+    from flock_amd.runtime import explain
+    txt = {n: explain(json.load(open(os.path.join(PLANS, f"arch_{n}.json")))) for n in ("filter", "groupby", "join", "sort")}
+    assert "Filter" in txt["filter"] and "Aggregate(FinalPartitioned)" in txt["groupby"] and "Join" in txt["join"] and "Sort(bidder ASC)" in txt["sort"]
+    from flock_amd import FlockGpuError
+    with pytest.raises(FlockGpuError) as e:   # an expression outside the dialect names itself
+        explain({"execution_plan": "filter_exec", "input": scan(), "predicate": {"physical_expr": "case_expr"}})
+    assert "case_expr" in str(e.value)
+
+
+def test_new_expression_tags_parse():
+    from flock_amd.runtime import explain
+    pred = binary(unary("not_expr", unary("is_null_expr", col("i"))), "And",
+                  {"physical_expr": "in_list_expr", "expr": col("s"), "negated": False, "list": [lit("Utf8", "or"), lit("Utf8", "id")]})
+    txt = explain({"execution_plan": "filter_exec", "input": scan(), "predicate": pred})
+    assert "Filter" in txt and "not supported" not in txt
+
+
+# ------------------------------------------------------------------ GPU: predicates
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_predicates_at_random(gpu, seed):
+    """Random expression trees (up to depth 3) over nullable Int32 / Int64 / Float64 / Utf8 columns, a non-nullable Int32 and a UInt64:
+    the kept rows, IN ORDER, equal the oracle's three-valued evaluation.  Sizes cover the one ragged tile, whole tiles + a ragged one,
+    and whole tiles only (the two kernel instances of pred.hip)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(9000 + seed)
+    n = [1, 700, 8192, 8193, 30_000, 16_384][seed % 6]
+    t = table(n, r, null_p=[0.0, 0.15, 0.5][seed % 3])
+    for trial in range(3):
+        pred = random_pred(r, 3)
+        plan = {"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096, "input": {"execution_plan": "filter_exec", "predicate": pred, "input": scan()}}
+        ctx = ExecutionContext([plan], gpu=gpu)
+        rb = collect(ctx, [[batches(t, max(1, n // 3))]])[0][0]
+        ctx.close()
+        want = g.filter_by_expr(t, pred)
+        assert pyrows(rb) == g.rows(want), (seed, trial, json.dumps(pred))
+
+
+@pytest.mark.gpu
+def test_predicate_limits_are_refused_not_truncated(gpu):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(1)
+    t = table(100, r)
+    pred = binary(col("i"), "Eq", lit("Int32", 0))
+    for k in range(1, 40):   # 40 comparisons: beyond one pass's leaves
+        pred = binary(pred, "Or", binary(col("i"), "Eq", lit("Int32", k)))
+    ctx = ExecutionContext([{"execution_plan": "filter_exec", "predicate": pred, "input": scan()}], gpu=gpu)
+    with pytest.raises(FlockGpuError) as e:
+        collect(ctx, [[batches(t, 100)]])
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and "predicate beyond" in str(e.value)
+    ctx.close()
+
+
+# ------------------------------------------------------------------ GPU: dense and hashed GROUP BY / JOIN
+def _agg_plan(key, aggs):
+    c = lambda n: {"physical_expr": "column", "name": n, "index": NAMES.index(n)}
+
+    def expr(fn, arg, dt):
+        a = c(arg) if arg else lit("UInt8", 1)
+        return {"aggregate_expr": fn, "name": "%s(%s)" % (fn.upper(), arg or "UInt8(1)"), "data_type": dt, "nullable": True, "expr": a}
+    ae = [expr(*a) for a in aggs]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[c(key), key]], "aggr_expr": ae, "input": scan(),
+            "input_schema": {"fields": F, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[{"physical_expr": "column", "name": key, "index": 0}], 4]}}
+    return {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[{"physical_expr": "column", "name": key, "index": 0}, key]],
+            "aggr_expr": ae, "input": rep, "input_schema": {"fields": F, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["j", "l"])
+@pytest.mark.parametrize("spread", [1, 1_000_003])
+@pytest.mark.parametrize("shape", ["hot", "clustered", "uniform", "wide_tiles"])
+def test_group_by_dense_and_hashed(gpu, key, spread, shape):
+    """The same GROUP BY over keys that are dense (perfect-hash path: slot = key - min) and keys spread a million times wider than their
+    count (hash table), on an Int32 and an Int64 key: half the rows on one key, keys that drift with the row number (a tile names a
+    narrow range: the LDS path), keys in no order over a narrow and over a wide range (every tile wider than the LDS bins: direct
+    global updates).  COUNT(*) alone and with SUM / MIN / MAX of an Int32 and an Int64 column; results equal the oracle's."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(hash((key, spread, shape)) % 2**31)
+    n = 70_000
+    base = int(r.integers(-5000, 5000))
+    if shape == "hot":
+        k = np.where(r.random(n) < 0.5, 77, r.integers(0, 300, n))
+    elif shape == "clustered":
+        k = np.arange(n) // 13 + r.integers(0, 40, n)
+    elif shape == "uniform":
+        k = r.integers(0, 1500, n)
+    else:
+        k = r.integers(0, 60_000, n)
+    k = (k + base) * spread
+    if key == "j":
+        k = np.clip(k, -2**31, 2**31 - 1) if spread > 1 else k
+    t = table(n, r, null_p=0.0)
+    t[key] = [int(x) for x in k]
+    t["i"] = [int(x) for x in r.integers(-1000, 1000, n)]
+    for aggs in ([("count", None, "UInt64")], [("count", None, "UInt64"), ("sum", "i", "Int64"), ("min", "l" if key == "j" else "j", "Int64" if key == "j" else "Int32"), ("max", "i", "Int32")]):
+        ctx = ExecutionContext([_agg_plan(key, aggs)], gpu=gpu)
+        rb = collect(ctx, [[batches(t, 25_000)]])[0][0]
+        again = collect(ctx, [[batches(t, 70_000)]])[0][0]          # the same plan a second time: cached statistics and table hints are per feed
+        ctx.close()
+        want = g.hash_aggregate_exec(t, [key], [("%s(%s)" % (fn.upper(), c or "UInt8(1)"), fn, c) for fn, c, _ in aggs])
+        assert sorted(pyrows(rb)) == sorted(g.rows(want)), (key, spread, shape, aggs)
+        assert sorted(pyrows(again)) == sorted(pyrows(rb))
+
+
+def _join_plan(lf, rf, lk, rk):
+    c = lambda n, fs: {"physical_expr": "column", "name": n, "index": [f["name"] for f in fs].index(n)}
+    sc = lambda fs: {"execution_plan": "memory_exec", "schema": {"fields": fs, "metadata": {}}, "projection": list(range(len(fs)))}
+    side = lambda fs, k: {"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096,
+                          "input": {"execution_plan": "repartition_exec", "input": sc(fs), "partitioning": {"Hash": [[c(k, fs)], 4]}}}
+    return {"execution_plan": "hash_join_exec", "left": side(lf, lk), "right": side(rf, rk), "join_type": "Inner", "mode": "Partitioned",
+            "on": [[c(lk, lf), c(rk, rf)]], "schema": {"fields": lf + rf, "metadata": {}}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spread", [1, 1_000_003])
+@pytest.mark.parametrize("ktype", ["Int32", "Int64"])
+@pytest.mark.parametrize("nl,nr", [(2_000, 60_000), (60_000, 2_000), (30_000, 30_000), (1, 9_000)])
+def test_inner_join_dense_and_hashed(gpu, spread, ktype, nl, nr):
+    """Inner join on an Int32 / Int64 key whose build side is dense (chain heads addressed by key - min) or spread (hash table): duplicate
+    keys on both sides, keys of one side missing on the other, the table on whichever side is smaller; every pair, as a multiset."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(hash((spread, ktype, nl, nr)) % 2**31)
+    lf = [_field("a", ktype, False), _field("x", "Int32", False), _field("name", "Utf8", False)]
+    rf = [_field("b", ktype, False), _field("y", "Int64", False)]
+    n_keys = max(3, min(nl, nr) // 2)
+    ka = (r.integers(0, n_keys, nl) - 100) * spread
+    kb = (r.integers(n_keys // 4, n_keys + n_keys // 4, nr) - 100) * spread      # half-overlapping key ranges
+    pat = pa.int32() if ktype == "Int32" else pa.int64()
+    left = {"a": [int(x) for x in ka], "x": [int(x) for x in r.integers(-9, 9, nl)], "name": ["n%d" % (x % 11) for x in range(nl)]}
+    right = {"b": [int(x) for x in kb], "y": [int(x) for x in r.integers(-2**40, 2**40, nr)]}
+    lb = [pa.record_batch([pa.array(left["a"], pat), pa.array(left["x"], pa.int32()), pa.array(left["name"], pa.string())], names=["a", "x", "name"])]
+    rb_in = [pa.record_batch([pa.array(right["b"], pat), pa.array(right["y"], pa.int64())], names=["b", "y"])]
+    ctx = ExecutionContext([_join_plan(lf, rf, "a", "b")], gpu=gpu)
+    out = collect(ctx, [[lb], [rb_in]])[0][0]
+    ctx.close()
+    want = g.hash_join_inner(left, right, [("a", "b")])
+    assert sorted(pyrows(out)) == sorted(g.rows(want)) and out.num_rows > 0, (spread, ktype, nl, nr)
+
+
+# ------------------------------------------------------------------ GPU: the reference's operator harness
+def _nexmark_tables(seed, seconds, eps):
+    s = oracle.NexmarkStream(seed=seed, eps=eps)
+    n = seconds * eps
+    b, a = s.bids(0, n), s.auctions(0, n, strings=True)
+    bid = {"auction": b["auction"].tolist(), "bidder": b["bidder"].tolist(), "price": b["price"].tolist(), "b_date_time": b["b_date_time"].tolist()}
+    auc = {"a_id": a["a_id"].tolist(), "item_name": a["item_name"].to_pylist(), "description": a["description"].to_pylist(), "initial_bid": a["initial_bid"].tolist(),
+           "reserve": a["reserve"].tolist(), "a_date_time": a["a_date_time"].tolist(), "expires": a["expires"].tolist(), "seller": a["seller"].tolist(),
+           "category": a["category"].tolist()}
+    ts = pa.timestamp("ms")
+    bid_rb = pa.record_batch([pa.array(bid["auction"], pa.int32()), pa.array(bid["bidder"], pa.int32()), pa.array(bid["price"], pa.int32()),
+                              pa.array(bid["b_date_time"], pa.int64()).cast(ts)], names=list(bid))
+    auc_rb = pa.record_batch([pa.array(auc["a_id"], pa.int32()), pa.array(auc["item_name"], pa.string()), pa.array(auc["description"], pa.string()),
+                              pa.array(auc["initial_bid"], pa.int32()), pa.array(auc["reserve"], pa.int32()), pa.array(auc["a_date_time"], pa.int64()).cast(ts),
+                              pa.array(auc["expires"], pa.int64()).cast(ts), pa.array(auc["seller"], pa.int32()), pa.array(auc["category"], pa.int32())], names=list(auc))
+    return bid, auc, bid_rb, auc_rb
+
+
+def _plain(rb):
+    cols = []
+    for c in rb.schema.names:
+        a = rb[c]
+        cols.append(a.cast(pa.int64()).to_pylist() if pa.types.is_timestamp(a.type) else a.to_pylist())
+    return list(zip(*cols))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("generic_only", [False, True])
+def test_reference_operator_harness_plans(gpu, generic_only):
+    """arch/ops/{filter,join,group-by,sort}.sql as the harness runs them -- feed once, execute repeatedly (source.rs:36-47) -- over one
+    NEXMark second: every execute returns the oracle's rows (sort: in order, ties in input order)."""
+    from flock_amd.runtime import ExecutionContext
+    bid, auc, bid_rb, auc_rb = _nexmark_tables(31, 2, 30_000)
+    want = {
+        "filter": g.rows(g.nexmark_q2(bid)),
+        "groupby": sorted(g.rows(g.hash_aggregate_exec({"auction": bid["auction"]}, ["auction"], [("n", "count", None)]))),
+        "join": sorted(g.rows(g.hash_join_inner(auc, bid, [("a_id", "auction")]))),
+        "sort": g.rows(g.sort_exec(bid, [("bidder", False)])),
+    }
+    assert len(want["join"]) > 10_000 and len(want["filter"]) > 100
+    for name in ("filter", "groupby", "join", "sort"):
+        ctx = ExecutionContext([json.load(open(os.path.join(PLANS, f"arch_{name}.json")))], gpu=gpu, generic_only=generic_only)
+        ctx.feed_data_sources([[[bid_rb]], [[auc_rb]]])
+        for _ in range(3):
+            rows = _plain(ctx.execute()[0][0])
+            assert (rows if name in ("filter", "sort") else sorted(rows)) == want[name], (name, generic_only)
+        ctx.close()

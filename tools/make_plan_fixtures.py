@@ -351,10 +351,36 @@ def q3_sorted():
     return sort_by({"execution_plan": "coalesce_partitions_exec", "input": q3()}, [(col("a_id", 3), False)])
 
 
+def arch_groupby():
+    """flock-function/src/aws/arch/ops/group-by.sql: `SELECT auction, Count(*) FROM bid GROUP BY auction` -- the two-phase aggregate of
+    q5's inner query under its projection."""
+    out = [field("auction", "Int32"), field("COUNT(UInt8(1))", "UInt64", True)]
+    return proj(count_by_auction(), [(col("auction", 0), "auction"), (col("COUNT(UInt8(1))", 1), "COUNT(UInt8(1))")], out)
+
+
+def arch_join():
+    """flock-function/src/aws/arch/ops/join.sql: `SELECT * FROM auction INNER JOIN bid ON a_id = auction` -- HashJoinExec Partitioned,
+    both sides hash-repartitioned on the key, every column of both relations in the output (two Utf8 columns among them)."""
+    left = coalesce(hashp(rr(memory(AUCTION, list(range(9)), "auction")), [col("a_id", 0)]))
+    right = coalesce(hashp(rr(memory(BID, [0, 1, 2, 3], "bid")), [col("auction", 0)]))
+    j = join(left, right, [(("a_id", 0), ("auction", 0))], AUCTION + BID)
+    return proj(coalesce(j), [(col(f["name"], i), f["name"]) for i, f in enumerate(AUCTION + BID)], AUCTION + BID)
+
+
+def arch_sort():
+    """flock-function/src/aws/arch/ops/sort.sql: `SELECT * FROM bid ORDER BY bidder`."""
+    return sort_by({"execution_plan": "coalesce_partitions_exec", "input": memory(BID, [0, 1, 2, 3], "bid")}, [(col("bidder", 1), False)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("golden_aggregate", golden_aggregate), ("golden_join", golden_join), ("golden_aggregate_sorted", golden_aggregate_sorted),
                      ("golden_join_sorted", golden_join_sorted), ("q3_sorted", q3_sorted)):
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(fn(), f, indent=1, sort_keys=True)
+            f.write("\n")
+    # the reference's operator harness (flock-function/src/aws/arch/ops/*.sql, source.rs:25-65); filter.sql is q2's statement
+    for name, fn in (("arch_filter", q2), ("arch_groupby", arch_groupby), ("arch_join", arch_join), ("arch_sort", arch_sort)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
