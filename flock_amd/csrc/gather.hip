@@ -403,6 +403,46 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
     if (tile_bytes == 0) return;
     const uint32_t phase = (uint32_t)(base & 15);  // LDS byte i holds output byte (base - phase) + i
     const bool staged = phase + tile_bytes <= (uint32_t)kStageBytes;  // block-uniform
+    if (!staged) {
+        // A tile of LONG values (an auction's description: ~75 bytes a value, 77 KB a tile): the tile's output range goes through the
+        // stage in rounds of kStageBytes -- every value writes the bytes of it that fall into the round's window, the window is
+        // streamed out with aligned 16-byte stores.  (Byte-granular global stores, what this case did until round 5, ran the
+        // reference's join.sql at 0.12 TB/s: 14 of its 15 ms.)
+        const uint32_t end = phase + tile_bytes;
+        uint8_t *gout = out + (base - phase);  // 16-byte aligned
+        for (uint32_t w0 = 0; w0 < end; w0 += (uint32_t)kStageBytes) {   // (block-uniform)
+            const uint32_t w1 = w0 + (uint32_t)kStageBytes < end ? w0 + (uint32_t)kStageBytes : end;
+#pragma unroll
+            for (int k = 0; k < kLenItems; ++k) {
+                const uint32_t p0 = phase + excl[k], p1 = p0 + len[k];
+                const uint32_t lo = p0 > w0 ? p0 : w0, hi = p1 < w1 ? p1 : w1;
+                if (lo >= hi) continue;
+                const uintptr_t a = reinterpret_cast<uintptr_t>(src) + (uint32_t)b[k] + (lo - p0);
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+                uint32_t cur = *w++ >> (8 * (uint32_t)(a & 3)), have = 4 - (uint32_t)(a & 3);
+                uint8_t *dst = s_stage + (lo - w0);
+                for (uint32_t done = 0, todo = hi - lo; done < todo; ++done) {
+                    if (have == 0) {
+                        cur = *w++;
+                        have = 4;
+                    }
+                    dst[done] = (uint8_t)cur;
+                    cur >>= 8;
+                    --have;
+                }
+            }
+            __syncthreads();
+            for (uint32_t o = w0 + threadIdx.x * 16; o < w1; o += kBlock * 16) {
+                if (o >= phase && o + 16 <= end) {
+                    stream_store4(gout + o, *reinterpret_cast<const uint4 *>(s_stage + (o - w0)));
+                } else {  // the tile's first / last chunk is shared with the neighbouring tile: only this tile's bytes
+                    for (uint32_t c = (o < phase ? phase : o); c < o + 16 && c < end; ++c) gout[c] = s_stage[c - w0];
+                }
+            }
+            __syncthreads();   // (the next round overwrites the stage)
+        }
+        return;
+    }
     // The first 16 bytes of every value through ONE or TWO 16-byte ALIGNED loads (a string starts at any byte), all of them requested
     // together, before any is used: one memory round trip for the whole tile.  An aligned 16-byte chunk that holds at least one byte
     // of the value never crosses a page, so nothing is read that could fault; the second chunk is asked for only by the lanes whose
@@ -431,7 +471,7 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
         uint32_t d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = __funnelshift_r(V[i], V[i + 1], sh);
-        uint8_t *dst = staged ? s_stage + phase + excl[k] : out + base + excl[k];
+        uint8_t *dst = s_stage + phase + excl[k];
         const uint32_t head = 16;  // bytes in d[]
 #pragma unroll
         for (int c = 0; c < 16; ++c)
@@ -451,7 +491,6 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
             }
         }
     }
-    if (!staged) return;
     __syncthreads();
     uint8_t *gout = out + (base - phase);  // 16-byte aligned
     const uint32_t end = phase + tile_bytes;

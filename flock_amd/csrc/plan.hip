@@ -1222,6 +1222,7 @@ struct Exec {
         double f = 0;
         std::string s;
         int64_t modulus = 0;
+        bool big = false;   // INT: a UInt64 literal above INT64_MAX (`i` is its bit pattern)
     };
     Operand operand(const Expr *e, const Table &in) const {
         Operand o;
@@ -1236,7 +1237,12 @@ struct Exec {
             return c.present || c.c.all_null ? &c : nullptr;
         };
         switch (e->kind) {
-            case EKind::LitI: o.k = Operand::INT; o.i = neg ? (int64_t)(0 - (uint64_t)e->i) : e->i; return o;
+            case EKind::LitI:
+                if (e->big_unsigned && neg) return o;   // -(a UInt64 beyond 2^63) is below every Int64: not a value any column type holds
+                o.k = Operand::INT;
+                o.i = neg ? (int64_t)(0 - (uint64_t)e->i) : e->i;
+                o.big = e->big_unsigned;
+                return o;
             case EKind::LitF: o.k = Operand::FLT; o.f = neg ? -e->f : e->f; return o;
             case EKind::LitS: if (!neg) { o.k = Operand::STR; o.s = e->s; } return o;
             case EKind::LitNull: o.k = Operand::NUL; return o;
@@ -1329,6 +1335,10 @@ struct Exec {
             const double pick = (op == CmpOp::LT || op == CmpOp::GE) ? ce : fl;   // x < f <=> x < ceil f;  x <= f <=> x <= floor f;  x > f <=> x > floor f;  x >= f <=> x >= ceil f
             if (pick > 4e18) lit = INT64_MAX; else if (pick < -4e18) lit = INT64_MIN; else lit = (int64_t)pick;
         }
+        if (r.k == Operand::INT && r.big && (ct != ColType::U64 || l.k == Operand::MOD))   // above every signed value (and every remainder)
+            return pred_const_valid(b, l.col, op == CmpOp::NE || op == CmpOp::LT || op == CmpOp::LE);
+        if (ct == ColType::U64 && !r.big && lit < 0)   // a negative literal is below every UInt64
+            return pred_const_valid(b, l.col, op == CmpOp::NE || op == CmpOp::GT || op == CmpOp::GE);
         d.kind = (uint8_t)PredLeafKind::CmpIntLit;
         d.uns = ct == ColType::U64;
         if (l.k == Operand::MOD) {
@@ -1468,6 +1478,17 @@ struct Exec {
         return FLOCKGPU_OK;
     }
 
+    // The statistics of a column that is NOT a leaf's cost a pass and a host wait on every execute (~20 us): worth it from a few tens of
+    // thousands of rows on, where the dense paths save more than that; below, the hash table answers (a stage plan's operators run on a
+    // few thousand filtered rows, and at that size the waits ARE the cost -- DESIGN section 3a).  A leaf column's are cached.
+    bool stats_worth_it(const TCol &c, int64_t rows) const {
+        if (rows >= (int64_t(1) << 15)) return true;
+        for (auto &ld : pl->leaves)
+            if (!ld.borrowed)
+                for (auto &b : ld.cols)
+                    if (b.values && b.values == c.c.values) return true;
+        return false;
+    }
     // exact (min, max) of an integer column; a LEAF column's are remembered until the leaf changes (flockgpu_plan::col_stats)
     int int_col_stats(const TCol &c, int64_t rows, int64_t *mn, int64_t *mx) {
         bool leaf_col = false;
@@ -1593,8 +1614,9 @@ struct Exec {
                     const TCol &bk = build_right ? rk : lk, &pk = build_right ? lk : rk;
                     const int64_t nb = build_right ? nr : nl, np = build_right ? nl : nr;
                     int64_t kmin = 0, kmax = 0;
-                    FG_TRY(int_col_stats(bk, nb, &kmin, &kmax));
-                    if (dense_range_ok(kmin, kmax, nb, bk.c.type == ColType::U64)) {
+                    const bool look = stats_worth_it(bk, nb + np);
+                    if (look) FG_TRY(int_col_stats(bk, nb, &kmin, &kmax));
+                    if (look && dense_range_ok(kmin, kmax, nb, bk.c.type == ColType::U64)) {
                         FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
                                           &pairs));
                         t->rows = pairs;
@@ -1823,6 +1845,7 @@ struct Exec {
         for (int a = 0; a < n_specs && dense; ++a)
             dense = !specs[a].valid && specs[a].op != AggOp::SUM_F64 && specs[a].op != AggOp::MAX_F64 && specs[a].op != AggOp::MIN_F64;
         int64_t kmin = 0, kmax = 0;
+        if (dense && !stats_worth_it(k, in.rows)) dense = false;
         if (dense) {
             FG_TRY(int_col_stats(k, in.rows, &kmin, &kmax));
             dense = dense_range_ok(kmin, kmax, in.rows, k.c.type == ColType::U64);

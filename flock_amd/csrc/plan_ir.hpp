@@ -38,6 +38,7 @@ struct Expr {
     std::unique_ptr<Expr> l, r;  // Bin operands; the operand of Cast / Not / IsNull / IsNotNull / Neg / InList in l
     std::vector<std::unique_ptr<Expr>> list;   // InList: the literals
     bool negated = false;                      // InList: NOT IN
+    bool big_unsigned = false;                 // LitI: `i` is the bit pattern of a UInt64 above INT64_MAX
 };
 
 enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit };
@@ -203,7 +204,7 @@ struct Builder {
             if (val->kind == JValue::Bool) { x->kind = EKind::LitB; x->i = val->b ? 1 : 0; return x; }
             if (val->kind == JValue::Str) { x->kind = EKind::LitS; x->s = val->str; return x; }
             if (val->kind == JValue::Num) {
-                if (val->is_int && kind.find("Float") == std::string::npos) { x->kind = EKind::LitI; x->i = val->inum; }
+                if (val->is_int && kind.find("Float") == std::string::npos) { x->kind = EKind::LitI; x->i = val->inum; x->big_unsigned = val->is_big_unsigned; }
                 else { x->kind = EKind::LitF; x->f = val->num; }
                 return x;
             }

@@ -20,6 +20,7 @@ struct JValue {
     double num = 0;
     int64_t inum = 0;
     bool is_int = false;
+    bool is_big_unsigned = false;   // inum holds the bit pattern of an unsigned value above INT64_MAX
     std::string str;
     std::vector<JPtr> arr;
     std::vector<std::pair<std::string, JPtr>> obj;
@@ -126,7 +127,13 @@ struct JParser {
         out->kind = JValue::Num;
         out->num = strtod(tok.c_str(), nullptr);
         out->is_int = is_int;
-        if (is_int) out->inum = strtoll(tok.c_str(), nullptr, 10);
+        if (is_int) {
+            out->inum = strtoll(tok.c_str(), nullptr, 10);
+            if (tok[0] != '-' && out->inum == INT64_MAX && tok != "9223372036854775807") {   // a UInt64 beyond 2^63: its bit pattern
+                out->inum = (int64_t)strtoull(tok.c_str(), nullptr, 10);
+                out->is_big_unsigned = true;
+            }
+        }
         p = q;
         return true;
     }

@@ -53,54 +53,6 @@ __global__ __launch_bounds__(kBlock) void widen_kernel(const void *__restrict__ 
 __global__ __launch_bounds__(kBlock) void widen_u32_kernel(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = in[i];
 }
-__global__ __launch_bounds__(kBlock) void mask_cmp_lit_kernel(const void *__restrict__ v, int32_t type, int64_t n, int32_t op,
-                                                              int64_t lit, int64_t modulus, uint8_t *__restrict__ mask) {
-    const bool uns = type == (int32_t)ColType::U64;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int64_t x = load_as_i64(v, type, i);
-        if (modulus) x = x % modulus;  // truncated remainder, as Rust's / Arrow's `%` on Int64
-        mask[i] = cmp_i64(x, lit, op, uns && !modulus) ? 1 : 0;
-    }
-}
-__global__ __launch_bounds__(kBlock) void mask_cmp_f64_kernel(const double *__restrict__ v, int64_t n, int32_t op, double lit,
-                                                              uint8_t *__restrict__ mask) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double x = v[i];
-        bool r;
-        switch (op) {
-            case 0: r = x == lit; break;
-            case 1: r = x != lit; break;
-            case 2: r = x < lit; break;
-            case 3: r = x <= lit; break;
-            case 4: r = x > lit; break;
-            default: r = x >= lit; break;
-        }
-        mask[i] = r ? 1 : 0;
-    }
-}
-__global__ __launch_bounds__(kBlock) void mask_cmp_col_kernel(const void *__restrict__ a, int32_t ta, const void *__restrict__ b, int32_t tb,
-                                                              int64_t n, int32_t op, uint8_t *__restrict__ mask) {
-    const bool uns = ta == (int32_t)ColType::U64 && tb == (int32_t)ColType::U64;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        mask[i] = cmp_i64(load_as_i64(a, ta, i), load_as_i64(b, tb, i), op, uns) ? 1 : 0;
-}
-struct Lit48 {
-    uint8_t b[48];
-};
-__global__ __launch_bounds__(kBlock) void mask_utf8_eq_kernel(const int32_t *__restrict__ off, const uint8_t *__restrict__ bytes, int64_t n,
-                                                              Lit48 lit, int32_t len, int32_t negate, uint8_t *__restrict__ mask) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int32_t b0 = off[i], l = off[i + 1] - b0;
-        bool eq = l == len;
-        for (int32_t k = 0; eq && k < len; ++k) eq = bytes[b0 + k] == lit.b[k];
-        mask[i] = (eq != (negate != 0)) ? 1 : 0;
-    }
-}
-__global__ __launch_bounds__(kBlock) void mask_combine_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t n,
-                                                              int32_t is_and, uint8_t *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        out[i] = is_and ? (a[i] & b[i]) : (a[i] | b[i]);
-}
 // mask bytes -> flag words in the flag-tile geometry (scan.hpp): the lane's four consecutive rows are one 32-bit load
 __global__ __launch_bounds__(kBlock) void mask_flag_kernel(const uint8_t *__restrict__ mask, int64_t n_rows, SegTiles st,
                                                            uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
@@ -407,9 +359,6 @@ __global__ __launch_bounds__(kBlock) void group_collect_n_kernel(const uint64_t 
 }
 __global__ __launch_bounds__(kBlock) void gather_u8_kernel(const uint8_t *__restrict__ src, const int32_t *__restrict__ rows, int64_t n, uint8_t *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = src[rows[i]];
-}
-__global__ __launch_bounds__(kBlock) void mask_and_valid_kernel(uint8_t *__restrict__ mask, const uint8_t *__restrict__ valid, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) mask[i] = mask[i] && valid[i] ? 1 : 0;
 }
 __global__ __launch_bounds__(kBlock) void replace_invalid_kernel(int64_t *__restrict__ keys, const uint8_t *__restrict__ valid, int64_t n, int64_t sentinel) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
@@ -1156,57 +1105,6 @@ int add_i32(flockgpu_ctx *ctx, int32_t *data, int64_t n, int32_t delta) {
     return FLOCKGPU_OK;
 }
 
-int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, int64_t lit, uint8_t *mask) {
-    if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "comparison needs an integer column");
-    if (rows <= 0) return FLOCKGPU_OK;
-    RELOPS_LAUNCH(ctx, "mask_cmp_lit_kernel", mask_cmp_lit_kernel, rows, col.values, (int32_t)col.type, rows, (int32_t)op, lit, (int64_t)0, mask);
-    return FLOCKGPU_OK;
-}
-
-int mask_cmp_f64_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, double lit, uint8_t *mask) {
-    if (col.type != ColType::F64) return fail(ctx, FLOCKGPU_ERR_INVALID, "Float64 comparison on a column of another type");
-    if (rows <= 0) return FLOCKGPU_OK;
-    RELOPS_LAUNCH(ctx, "mask_cmp_f64_kernel", mask_cmp_f64_kernel, rows, static_cast<const double *>(col.values), rows, (int32_t)op, lit, mask);
-    return FLOCKGPU_OK;
-}
-
-int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask) {
-    if (col.type == ColType::UTF8 || col.type == ColType::F64 || col.type == ColType::U64)
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "modulo needs a signed integer column");
-    if (modulus == 0) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "modulo by zero (the reference raises a DataFusion error)");
-    if (rows <= 0) return FLOCKGPU_OK;
-    // x % -1 == 0 for every x (and INT64_MIN % -1 traps in hardware): the remainder by |m| has the same value
-    const int64_t m = modulus == INT64_MIN ? modulus : (modulus < 0 ? -modulus : modulus);
-    RELOPS_LAUNCH(ctx, "mask_cmp_lit_kernel", mask_cmp_lit_kernel, rows, col.values, (int32_t)col.type, rows, (int32_t)op, lit, m, mask);
-    return FLOCKGPU_OK;
-}
-
-int mask_cmp_col(flockgpu_ctx *ctx, const DevColumn &a, const DevColumn &b, int64_t rows, CmpOp op, uint8_t *mask) {
-    auto bad = [](const DevColumn &c) { return c.type == ColType::UTF8 || c.type == ColType::F64; };
-    if (bad(a) || bad(b) || ((a.type == ColType::U64) != (b.type == ColType::U64)))
-        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "column comparison needs two integer columns of the same signedness");
-    if (rows <= 0) return FLOCKGPU_OK;
-    RELOPS_LAUNCH(ctx, "mask_cmp_col_kernel", mask_cmp_col_kernel, rows, a.values, (int32_t)a.type, b.values, (int32_t)b.type, rows, (int32_t)op, mask);
-    return FLOCKGPU_OK;
-}
-
-int mask_utf8_eq(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, const std::string &lit, bool negate, uint8_t *mask) {
-    if (col.type != ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "string comparison needs a Utf8 column");
-    if (lit.size() > sizeof(Lit48)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "Utf8 literal longer than %zu bytes", sizeof(Lit48));
-    if (rows <= 0) return FLOCKGPU_OK;
-    Lit48 l{};
-    std::memcpy(l.b, lit.data(), lit.size());
-    RELOPS_LAUNCH(ctx, "mask_utf8_eq_kernel", mask_utf8_eq_kernel, rows, col.offsets, static_cast<const uint8_t *>(col.values), rows, l,
-                  (int32_t)lit.size(), (int32_t)negate, mask);
-    return FLOCKGPU_OK;
-}
-
-int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t rows, bool is_and, uint8_t *out) {
-    if (rows <= 0) return FLOCKGPU_OK;
-    RELOPS_LAUNCH(ctx, "mask_combine_kernel", mask_combine_kernel, rows, a, b, rows, (int32_t)is_and, out);
-    return FLOCKGPU_OK;
-}
-
 int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64_t rows, int32_t **out_rows, int64_t *n_out) {
     const std::string base = name;
     int32_t *o_rows = nullptr;
@@ -1242,11 +1140,6 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
 int gather_u8(flockgpu_ctx *ctx, const uint8_t *src, const int32_t *rows, int64_t n, uint8_t *out) {
     if (n <= 0) return FLOCKGPU_OK;
     RELOPS_LAUNCH(ctx, "gather_u8_kernel", gather_u8_kernel, n, src, rows, n, out);
-    return FLOCKGPU_OK;
-}
-int mask_and_valid(flockgpu_ctx *ctx, uint8_t *mask, const uint8_t *valid, int64_t rows) {
-    if (rows <= 0 || !valid) return FLOCKGPU_OK;
-    RELOPS_LAUNCH(ctx, "mask_and_valid_kernel", mask_and_valid_kernel, rows, mask, valid, rows);
     return FLOCKGPU_OK;
 }
 int replace_invalid_i64(flockgpu_ctx *ctx, int64_t *keys, const uint8_t *valid, int64_t rows, int64_t sentinel) {

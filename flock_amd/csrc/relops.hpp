@@ -38,23 +38,13 @@ enum class AggKind : int32_t { NONE = 0, SUM = 1, MAX = 2 };
 // keys of an integer column as int64 (I32 sign-extended; I64 / U64 bit pattern): out[rows]
 int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);
 
-// ---- predicates: one byte per row (1 = true)
-int mask_cmp_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, int64_t lit, uint8_t *mask);
-int mask_mod_cmp(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t modulus, CmpOp op, int64_t lit, uint8_t *mask);
-// Float64 column against a literal (IEEE comparison; NaN compares false except for !=)
-int mask_cmp_f64_lit(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, CmpOp op, double lit, uint8_t *mask);
-int mask_cmp_col(flockgpu_ctx *ctx, const DevColumn &a, const DevColumn &b, int64_t rows, CmpOp op, uint8_t *mask);
-int mask_utf8_eq(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, const std::string &lit, bool negate, uint8_t *mask);
-int mask_combine(flockgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, int64_t rows, bool is_and, uint8_t *out);
+// ---- predicates: pred.hpp (one pass per FilterExec).  A byte mask (1 = keep) -> its rows, for the operators' own bookkeeping:
 // rows with mask != 0, in order.  *out_rows: ctx-owned (arena key `name`), n_out through ONE synchronisation.
 int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64_t rows, int32_t **out_rows, int64_t *n_out);
 
 // ---- take (a column's validity bytes are taken along)
 int take_column(flockgpu_ctx *ctx, const char *name, const DevColumn &src, const int32_t *rows, int64_t n, DevColumn *out);
 int gather_u8(flockgpu_ctx *ctx, const uint8_t *src, const int32_t *rows, int64_t n, uint8_t *out);
-// mask[i] &= valid[i]: a comparison with NULL is NULL, and a NULL predicate keeps no row -- through AND and OR alike when every leaf
-// comparison is treated as false (NULL OR TRUE = TRUE, NULL OR FALSE = NULL: dropped either way it evaluates)
-int mask_and_valid(flockgpu_ctx *ctx, uint8_t *mask, const uint8_t *valid, int64_t rows);
 // keys[i] = sentinel where valid[i] == 0: NULL group keys form ONE group (DataFusion groups NULLs together), NULL hash-partition keys one place
 int replace_invalid_i64(flockgpu_ctx *ctx, int64_t *keys, const uint8_t *valid, int64_t rows, int64_t sentinel);
 // out[i] = keys[i] != sentinel (the validity of a group-key column that went through replace_invalid_i64); out[i] = count[i] != 0 (AVG over no valid value)

@@ -276,8 +276,11 @@ def test_inner_join_dense_and_hashed(gpu, spread, ktype, nl, nr):
     lf = [_field("a", ktype, False), _field("x", "Int32", False), _field("name", "Utf8", False)]
     rf = [_field("b", ktype, False), _field("y", "Int64", False)]
     n_keys = max(3, min(nl, nr) // 2)
-    ka = (r.integers(0, n_keys, nl) - 100) * spread
-    kb = (r.integers(n_keys // 4, n_keys + n_keys // 4, nr) - 100) * spread      # half-overlapping key ranges
+    shift = 100
+    if ktype == "Int32" and spread > 1:
+        spread, shift = 2**31 // (4 * n_keys), n_keys // 2      # (as wide as an Int32 key gets, both signs)
+    ka = (r.integers(0, n_keys, nl) - shift) * spread
+    kb = (r.integers(n_keys // 4, n_keys + n_keys // 4, nr) - shift) * spread      # half-overlapping key ranges
     pat = pa.int32() if ktype == "Int32" else pa.int64()
     left = {"a": [int(x) for x in ka], "x": [int(x) for x in r.integers(-9, 9, nl)], "name": ["n%d" % (x % 11) for x in range(nl)]}
     right = {"b": [int(x) for x in kb], "y": [int(x) for x in r.integers(-2**40, 2**40, nr)]}
