@@ -199,6 +199,8 @@ struct LaunchScope {
     bool on = false;
     LaunchScope(flockgpu_ctx *c, const char *n) : ctx(c), name(n) {
         on = ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only == n);
+        if (ctx->profiling && !on && ctx->profile_only.find('|') != std::string::npos)   // "a|b": the kernels a call may choose between for one step
+            on = ("|" + ctx->profile_only + "|").find("|" + std::string(n) + "|") != std::string::npos;
         if (!on) return;
         auto take = [&]() {
             hipEvent_t e = nullptr;

@@ -956,7 +956,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
-            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            LaunchScope ls(ctx, "q3_probe_flag_small_kernel");
             launch_probe_small<true>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, nullptr, bits, flag_words, counts);
         } else {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");
@@ -1051,7 +1051,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         }
         FG_TRY(check_launch(ctx, "q3_build_kernel"));
         if (st_a.n_tiles > 0 && st_a.n_tiles < (int64_t)ctx->num_cus * 6) {   // few tiles: sixteen waves per tile
-            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            LaunchScope ls(ctx, "q3_probe_flag_small_kernel");
             if (bits_mode) launch_probe_small<true>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
             else launch_probe_small<false>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, bits, flag_words, counts);
         } else if (st_a.n_tiles > 0) {
@@ -1165,7 +1165,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             FG_TRY(check_launch(ctx, "q3_table_unique_kernel"));
         }
         if (st_a.n_tiles > 0 && st_a.n_tiles < (int64_t)ctx->num_cus * 6) {
-            LaunchScope ls(ctx, "q3_probe_flag_kernel");
+            LaunchScope ls(ctx, "q3_probe_flag_small_kernel");
             launch_probe_small<false>(ctx, st_a.n_tiles, auction->seller, auction->category, auction->rows, category_lit, st_a, d_wins, direct, nullptr, flag_words, counts);
         } else if (st_a.n_tiles > 0) {
             LaunchScope ls(ctx, "q3_probe_flag_kernel");

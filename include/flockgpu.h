@@ -72,8 +72,10 @@ int flockgpu_free_guarded(flockgpu_ctx *ctx, void *device_ptr);
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  When enabled, every kernel launch of
  * the ctx is bracketed by hipEvents on the ctx stream; totals are read back per kernel name. */
 int flockgpu_profile_enable(flockgpu_ctx *ctx, int on);
-/* Restricts the bracketing to launches of one kernel (NULL: every kernel again).  Two event records per launch are
- * markers on the stream: bracketing all ~20 launches of a small-batch query costs as much as its kernels. */
+/* Restricts the bracketing to launches of one kernel (NULL: every kernel again), or of any of several: "a|b" -- the kernels a call
+ * chooses between for one step (q3's probe runs `q3_probe_flag_small_kernel` while all its tiles are resident at once, else
+ * `q3_probe_flag_kernel`).  Two event records per launch are markers on the stream: bracketing all ~20 launches of a small-batch
+ * query costs as much as its kernels. */
 int flockgpu_profile_only(flockgpu_ctx *ctx, const char *kernel_name);
 int flockgpu_profile_reset(flockgpu_ctx *ctx);
 /* Fills up to `cap` entries; returns the number of distinct kernels seen in *n. */

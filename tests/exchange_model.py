@@ -1,4 +1,9 @@
-"""Multi-GPU execution of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+"""TEST MODEL of the in-library exchange (flock_amd/csrc/comm.hip) on `torch.distributed` collectives -- not product code: no product
+path imports it (it lived in the package until round 5).  It states the exchange protocol in Python so that the protocol's logic --
+split sizes, regrouping, window bookkeeping -- runs at world size 2 on `gloo` here (tests/test_distributed.py), and so that the HIP
+partition / take kernels can be checked bit for bit against its numpy stand-ins (tests/test_gpu_exchange.py).
+
+Multi-GPU execution of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
 
 The reference scales the path in two ways (SURVEY.md section 8 e), both mirrored here:
 
@@ -31,7 +36,7 @@ from typing import Dict, Optional, Tuple, Union
 
 import numpy as np
 
-from .engine import Auctions, DeviceUtf8, GpuContext, Persons, WindowSchedule
+from flock_amd.engine import Auctions, DeviceUtf8, GpuContext, Persons, WindowSchedule
 
 
 def _torch():

@@ -28,7 +28,8 @@ def test_every_kernel_the_bench_names_exists():
     # (LaunchScope labels of q3_probe_general_kernel<false> and json_parse_kernel<n, retry = true>)
     kernels = _kernel_names() | {"q3_probe_count_kernel", "json_parse_retry_kernel"}
     for q, (name, bytes_per_row, relation) in bench.DOMINANT.items():
-        assert name in kernels, (q, name)
+        for one in name.split("|"):     # "a|b": the kernels a step chooses between by batch size
+            assert one in kernels, (q, one)
         assert bytes_per_row > 0 and relation in ("bid", "auction")
     src = open(os.path.join(ROOT, "bench.py")).read()
     for name in re.findall(r'"(\w+_kernel)"', src):
@@ -84,24 +85,49 @@ def test_last_line_is_short_and_carries_roofline_and_cpu_baseline():
     assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] > 0
 
 
-def test_n_ranks_line_keeps_the_weak_headline_and_carries_the_exchange():
-    """N > 1: the headline is the same per-GPU job as N = 1 ("weak", what a scaling curve compares); the key-partitioned exchange of
-    north_star is its own object with "strong" and the phase timeline -- or an `exchange_error` string."""
+def test_n_ranks_line_reports_the_configured_total_and_carries_exchange_and_weak():
+    """N > 1: the headline is BASELINE.json configs[3] -- 1e9 bids IN TOTAL over the N GPUs, window-sharded, "strong"; the
+    key-partitioned exchange of north_star is its own object with "strong" and the phase timeline -- or an `exchange_error` string; the
+    N x 1e9-bid job of earlier rounds rides along as `weak`."""
     import json
     import bench
     out = _fat_out()
     out["n_gpus"] = 8
+    out["scaling"] = "strong"
+    out["config"] = {"workload": "NEXMark q5 hopping(10,5) over 1087 s x 1000000 events/s: 1000040000 input rows in total over 8 GPUs (BASELINE.json configs[3])",
+                     "query": "q5", "input_rows_total": 1000040000, "windows_total": 216, "windows_this_rank": 27,
+                     "parallelism": "window-sharded x8: contiguous runs of windows per GPU, no data-path collective"}
+    out["weak"] = {"value": 8.1e12, "ms_per_step": 0.98, "scaling": "weak", "workload": "NEXMark q5 hopping(10,5) over 1087 s x 1000000 events/s per GPU", "roofline_frac": 0.66}
     out["exchange"] = {"value": 3.1e12, "unit": "rows/s", "scaling": "strong", "ms_per_step": 0.32, "input_rows_all_gpus": 998200000, "ranks": 8, "transport": "rccl",
                        "phases_ms": {"partial": 0.11, "partition+take": 0.08, "counts": 0.01, "all_to_all+regroup": 0.05, "final": 0.07}, "roofline": {"frac": 0.55},
                        "kernels_ms_rank0": {f"k{i}": 0.1 for i in range(40)}, "workload": "w" * 200}
     d = json.loads(bench.final_line(out))
-    assert d["scaling"] == "weak" and d["n_gpus"] == 8 and d["roofline"]["frac"] <= 1
+    assert d["scaling"] == "strong" and d["n_gpus"] == 8 and d["roofline"]["frac"] <= 1 and "in total over 8 GPUs" in d["config"]["workload"]
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] == 8.1e12
     assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] == 3.1e12 and d["exchange"]["phases_ms"]["final"] == 0.07
     assert "kernels_ms_rank0" not in d["exchange"] and len(bench.final_line(out)) < 4096
     out.pop("exchange")
     out["exchange_error"] = "RuntimeError('ncclCommInitRank: unhandled system error')" + "x" * 1000
     d = json.loads(bench.final_line(out))
     assert d["exchange_error"].startswith("RuntimeError") and len(d["exchange_error"]) <= 300 and d["value"] == 9.8e11
+
+
+def test_windows_are_dealt_to_the_ranks_in_contiguous_runs():
+    """`bench.window_shard`: the 216 Hopping(10, 5) windows of 1087 s over 1 / 2 / 4 / 8 / 300 ranks -- every window exactly once, each rank's
+    slice of seconds holding exactly its windows (q5), and likewise q8's tumbling and q3's element-wise windows."""
+    import bench
+    from flock_amd import query_window
+    from flock_amd.nexmark import window_epochs
+    for q, seconds in ((5, 1087), (8, 1000), (3, 100), (5, 12)):
+        wins = window_epochs(query_window(q), seconds)
+        for world in (1, 2, 4, 8, 300):
+            got = []
+            for rank in range(world):
+                first, secs, n = bench.window_shard(q, seconds, rank, world)
+                local = window_epochs(query_window(q), secs) if secs else []
+                assert len(local) == n
+                got += [(a + first, b + first) for a, b in local]
+            assert got == wins, (q, seconds, world)
 
 
 def test_exchange_mode_bills_the_kernels_that_read_the_raw_rows():
@@ -203,7 +229,7 @@ def test_bench_prints_one_short_line_on_the_gpu(tmp_path):
 @__import__("pytest").mark.gpu
 def test_two_ranks_on_one_gpu_keep_the_headline_when_the_exchange_cannot_start(tmp_path):
     """`--gpus 2` with both ranks on the one visible device (FLOCK_BENCH_SHARED_GPU, gloo for the barrier): RCCL refuses two ranks on one
-    device, so the exchange cannot start -- the line must still be the window-sharded headline of two ranks, with `exchange_error`
+    device, so the exchange cannot start -- the line must still be the window-sharded headline of two ranks (the configured total, "strong"), with `exchange_error`
     (or, should a transport accept it, an `exchange` object)."""
     import json
     import subprocess
@@ -215,7 +241,10 @@ def test_two_ranks_on_one_gpu_keep_the_headline_when_the_exchange_cannot_start(t
     last = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
     assert len(last) < 4096
     d = json.loads(last)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"].startswith("window-sharded x2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["parallelism"].startswith("window-sharded x2")
+    # the configured workload: ONE stream of 60 s in total, its windows dealt to the two ranks; the two-slices job rides along as `weak`
+    assert "in total over 2 GPUs" in d["config"]["workload"] and d["config"]["windows_total"] == 11 and d["config"]["input_rows_total"] == 60 * 1_000_000 // 50 * 46
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
     assert ("exchange_error" in d) != ("exchange" in d)
     if "exchange" in d:
         assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] > 0

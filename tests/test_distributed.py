@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world-size-2 `gloo` runs of the key-partitioned exchange (flock_amd/distributed.py).
+"""N > 1 path on CPU: world-size-2 `gloo` runs of the key-partitioned exchange (tests/exchange_model.py).
 
 The exchange logic (counts all-to-all, per-column all_to_all_single with uneven splits, regrouping into
 window-major order, window bookkeeping, q5's all_reduce(MAX)) is the product code; the three device steps it calls
@@ -37,7 +37,7 @@ def part_of(keys, n_parts):
 
 
 class NumpyOps:
-    """Same contract as flock_amd.distributed.GpuOps, on CPU tensors."""
+    """Same contract as exchange_model.GpuOps, on CPU tensors."""
 
     def partition(self, keys, schedule: WindowSchedule, n_parts: int):
         k = keys.numpy()
@@ -164,7 +164,7 @@ def _local_rows(offsets_fn, windows, rank, world):
 
 # ---------------------------------------------------------------- tests
 def _q8_rank(rank, world):
-    from flock_amd.distributed import shuffle_relation
+    from exchange_model import shuffle_relation
     s = oracle.NexmarkStream(seed=SEED, eps=EPS)
     n = EPS * SECONDS
     au, pe = s.auctions(0, n), s.persons(0, n)
@@ -203,7 +203,7 @@ def test_q8_join_shuffle_world2():
 
 
 def _q3_rank(rank, world):
-    from flock_amd.distributed import shuffle_relation
+    from exchange_model import shuffle_relation
     s = oracle.NexmarkStream(seed=SEED + 1, eps=EPS)
     n = EPS * 6
     au, pe = s.auctions(0, n), s.persons(0, n)
@@ -250,7 +250,7 @@ def _q5_rank(rank, world):
     """q5_exchange itself (partial groups -> hash repartition -> weighted final -> all_reduce(MAX)) with numpy stand-ins
     for the device steps."""
     from flock_amd import Bids
-    from flock_amd.distributed import q5_exchange
+    from exchange_model import q5_exchange
     s = oracle.NexmarkStream(seed=SEED + 2, eps=EPS)
     b = s.bids(0, EPS * SECONDS, columns=("auction",))["auction"]
     b_off = lambda e: s.counts(0, e * EPS)[2]
@@ -277,7 +277,7 @@ def test_q5_repartition_and_global_max_world2():
 
 
 def _merge_rank(rank, world):
-    from flock_amd.distributed import q5_merge_window_winners
+    from exchange_model import q5_merge_window_winners
     # window-sharded mode: rank r owns windows [3r, 3r + 3) with r + 1 winner rows each
     a = np.arange(3 * (rank + 1), dtype=np.int32) + 100 * rank
     n = (np.arange(3 * (rank + 1)) + 7).astype(np.uint64)
@@ -293,7 +293,7 @@ def test_window_sharded_merge_world2():
 
 
 def test_regroup_index_orders_by_window_then_source():
-    from flock_amd.distributed import regroup_index
+    from exchange_model import regroup_index
     recv = np.array([[2, 0, 1], [1, 3, 0]])                     # [source][window]
     idx, win_off = regroup_index(recv, "cpu")
     # received buffer: s0w0 s0w0 s0w2 | s1w0 s1w1 s1w1 s1w1
@@ -301,7 +301,7 @@ def test_regroup_index_orders_by_window_then_source():
 
 
 def _chunked_rank(rank, world):
-    import flock_amd.distributed as D
+    import exchange_model as D
     D._MAX_PEER_BYTES = 64            # 16 int32 per peer and round: forces several rounds with ragged tails
     rng = np.random.default_rng(rank)
     send_splits = np.array([37, 5]) if rank == 0 else np.array([0, 50])

@@ -95,7 +95,7 @@ def test_take_matches_numpy(ctx):
 def test_exchange_queries_one_rank(ctx, world1):
     """q3 / q5 / q8 through partition -> take -> RCCL all_to_all -> regroup -> local operator, world size 1."""
     from flock_amd import NEXMarkSource, Window
-    from flock_amd.distributed import q3_exchange, q5_exchange, q8_exchange
+    from exchange_model import q3_exchange, q5_exchange, q8_exchange
     seed, eps, seconds = 21, 20_000, 20
     g = NEXMarkSource(seconds, eps, Window.tumbling(10), seed=seed).generate_data(ctx)
     host = oracle.NexmarkStream(seed=seed, eps=eps)
@@ -219,7 +219,7 @@ def test_q5_partial_then_weighted_equals_hot_items(ctx, case):
 def test_q5_exchange_world1_uses_partial_groups(ctx, world1):
     """q5_exchange end to end on one rank through RCCL: identical to the single-GPU operator."""
     from flock_amd import Bids, NEXMarkSource, Window
-    from flock_amd.distributed import q5_exchange
+    from exchange_model import q5_exchange
     w = Window.hopping(10, 5)
     g = NEXMarkSource(40, 30_000, w, seed=5).generate_data(ctx, relations=("bid",), bid_columns=("auction",))
     sched = g.window_schedule("bid", w)
