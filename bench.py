@@ -814,7 +814,9 @@ def alternating_entry(gpu, q, eps, steps):
 #     set kernels themselves -- exact for any input, and measured so that this fall-back stays a number.
 GENERAL = {"q3_general": (3, 1000, "q3_probe_flag_kernel|q3_probe_flag_small_kernel", 8.0, "auction", "shuffle"), "q8_general": (8, 1000, "q8_sellers_bitmap_kernel", 4.0, "auction", "shuffle"),
            "q5_uniform": (5, 1087, "q5_part_tile_kernel", 6.0, "bid", "shuffle"),     # the partition pass: every key read (4 B) and written as its 16 low bits (2 B)
-           "q3_hash": (3, 1000, "q3_probe_count_kernel", 8.0, "auction", "spread"), "q8_hash": (8, 1000, "q8_sellers_part_kernel", 4.0, "auction", "spread")}
+           # q3's hash path builds AND probes a window in one kernel: 8 B per auction + ~10 B per person (a third as many persons as auctions)
+           "q3_hash": (3, 1000, "q3_window_join_lds_kernel|q3_probe_count_kernel", 8.0 + 10.0 / 3, "auction", "spread"),
+           "q8_hash": (8, 1000, "q8_sellers_part_kernel", 4.0, "auction", "spread")}
 
 
 def shuffle_within_segments(col, seg_off, seed):

@@ -1478,11 +1478,11 @@ struct Exec {
         return FLOCKGPU_OK;
     }
 
-    // The statistics of a column that is NOT a leaf's cost a pass and a host wait on every execute (~20 us): worth it from a few tens of
-    // thousands of rows on, where the dense paths save more than that; below, the hash table answers (a stage plan's operators run on a
+    // The statistics of a column that is NOT a leaf's cost a pass and a host wait on every execute (~20 us): worth it from several
+    // thousand rows on, where the dense paths save more than that; below, the hash table answers (a stage plan's operators run on a
     // few thousand filtered rows, and at that size the waits ARE the cost -- DESIGN section 3a).  A leaf column's are cached.
     bool stats_worth_it(const TCol &c, int64_t rows) const {
-        if (rows >= (int64_t(1) << 15)) return true;
+        if (rows >= (int64_t(1) << 13)) return true;   // (up to 4096 build rows the one-workgroup LDS join answers without any statistics)
         for (auto &ld : pl->leaves)
             if (!ld.borrowed)
                 for (auto &b : ld.cols)

@@ -635,24 +635,32 @@ __global__ __launch_bounds__(kInvertBlock) void q3_invert_window_kernel(const in
 
 // direct[0 .. info[0]) = -1 when info[2] says some slot is written by no person; the grid covers the arena's bound, workgroups past
 // the entries in use (or all of them, without gaps) leave at once
-// ---- GENERAL path, build side in LDS: one workgroup per window inserts the window's persons that pass the state filter into a multimap in
-// LDS (the same {key, head row} slots and `next[]` chains as the global build: hashtab.hpp) and streams the finished table out with
-// coalesced stores.  The global build was 1e7 compare-and-swaps on 240 MB of tables that a memset had to fill first (0.51 + 0.07 ms per 1e9
-// events); a window's table is a few thousand live slots -- LDS-sized.  `cap` <= kLdsBuildCap slots: the host's usual 1.5 slots per person
-// of the largest window when that fits, else kLdsBuildCap on the bet that the filter drops enough of them (NEXMark: half) -- a window
-// that does not fit raises `err` and the host builds in global memory with the full capacity.
+// ---- GENERAL path, the window's hash table in LDS.  The global build was 1e7 compare-and-swaps on 240 MB of tables that a memset had to
+// fill first (0.51 + 0.07 ms per 1e9 events); a window's table is a few thousand live slots -- LDS-sized (the same {key, head row} slots and
+// `next[]` chains as the global build: hashtab.hpp).  `cap` <= kLdsBuildCap slots: the host's usual 1.5 slots per person of the largest
+// window when that fits, else kLdsBuildCap on the bet that the filter drops enough of them (NEXMark: half) -- a window that does not fit
+// raises `err` and the host builds AND probes in global memory with the full capacity.
 constexpr int kLdsBuildThreads = 1024;
 constexpr uint32_t kLdsBuildCap = 18432;   // 144 KB of the CU's 160
-__global__ __launch_bounds__(kLdsBuildThreads) void q3_build_window_lds_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ state_off,
-                                                                               const uint8_t *__restrict__ state_data, const int64_t *__restrict__ seg_off,
-                                                                               Utf8Lits lits, uint64_t *__restrict__ tables, uint32_t cap,
-                                                                               int32_t *__restrict__ next, uint32_t *err) {
+// The hash join of a window where its table is BUILT: one 1024-thread workgroup per window inserts the window's persons that pass the
+// state filter into the LDS multimap and then walks the window's auction tiles -- four at a time, a
+// 256-thread quarter of the workgroup standing for the tile's workgroup of q3_probe_general_kernel<count> -- probing the table IN LDS:
+// the category filter, the first link of every passing row's partner chain into `heads`, the tiles' wave counts.  The table never
+// leaves the CU: no 144 KB write-out per window, and none of the ~1.2e7 random 8-byte reads of a global table the count pass made
+// (0.17 of its 0.30 ms, at the memory side's random-access rate: DESIGN section 10).  The emit pass reads `heads` and `next[]` as before.
+__global__ __launch_bounds__(kLdsBuildThreads) void q3_window_join_lds_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ state_off,
+                                                                              const uint8_t *__restrict__ state_data, const int64_t *__restrict__ seg_off,
+                                                                              Utf8Lits lits, uint32_t cap, int32_t *__restrict__ next, uint32_t *err,
+                                                                              const int32_t *__restrict__ seller, const int32_t *__restrict__ category, int64_t n_rows,
+                                                                              int64_t category_lit, SegTiles st, uint32_t *__restrict__ counts,
+                                                                              uint32_t *__restrict__ heads) {
     __shared__ uint64_t s_tab[kLdsBuildCap];
     const int32_t w = (int32_t)blockIdx.x;
     const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
     for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) s_tab[i] = kEmpty64;
     __syncthreads();
-    constexpr int kPer = 4;   // rows of a thread in flight together (8: no faster -- 0.228 vs 0.215 ms per 1000 windows of 2e4 persons)
+    constexpr int kPer = 4;
+    bool full = false;
     for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += (int64_t)kLdsBuildThreads * kPer) {
         int32_t key[kPer], b[kPer];
         uint32_t len[kPer];
@@ -671,12 +679,65 @@ __global__ __launch_bounds__(kLdsBuildThreads) void q3_build_window_lds_kernel(c
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
-            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert_marked(s_tab, cap, next, key[k], (int32_t)r)) atomicOr(err, 1u);
+            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert_marked(s_tab, cap, next, key[k], (int32_t)r)) full = true;
         }
     }
-    __syncthreads();
-    uint64_t *dst = tables + (size_t)w * cap;
-    for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) dst[i] = s_tab[i];
+    if (__syncthreads_or(full)) {   // the window's persons do not fit the LDS table: the host repeats the call on the global tables
+        if (threadIdx.x == 0) atomicOr(err, 1u);
+        return;
+    }
+    // ---- probe: quarter q of the workgroup takes tile first + 4 g + q of the window
+    const int32_t t_first = st.tile_first[w], t_end = st.tile_first[w + 1];
+    const int quarter = threadIdx.x >> 8, lt = threadIdx.x & 255, lwave = lt >> 6, lane = lane_id();
+    const int32_t rel0 = lwave * kFlagWaveRows + lane * 4;
+    constexpr uint32_t kNoHead = 0xFFFFFFFFu;
+    for (int32_t tile = t_first + quarter; tile < t_end; tile += kLdsBuildThreads / kBlock) {
+        const TileRange tr = st.tiles[tile];
+        uint32_t *tile_heads = heads + (size_t)tile * kFlagTile + rel0;
+        const int64_t wbase = tr.tile_begin + rel0;
+        uint32_t wave_total = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {   // four iterations' columns requested together, then probed
+            int32_t sv[4][4], cv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                load4_i32(seller, wbase + (half * 4 + i) * 256, n_rows, sv[i]);
+                load4_i32(category, wbase + (half * 4 + i) * 256, n_rows, cv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t r0 = wbase + (half * 4 + i) * 256;
+                uint32_t head[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + j;
+                    head[j] = kNoHead;
+                    if (!(r >= tr.lo && r < tr.hi && (int64_t)cv[i][j] == category_lit)) continue;
+                    uint32_t sl = slot_of((uint32_t)sv[i][j], cap);
+                    for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
+                        const uint64_t cur = s_tab[sl];
+                        if (cur == kEmpty64) break;
+                        if ((int32_t)(cur >> 32) == sv[i][j]) {
+                            head[j] = (uint32_t)cur;
+                            break;
+                        }
+                        sl = (sl + 1 == cap) ? 0 : sl + 1;
+                    }
+                }
+                *reinterpret_cast<uint4 *>(tile_heads + (half * 4 + i) * 256) = make_uint4(head[0], head[1], head[2], head[3]);
+                uint32_t mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (head[j] != kNoHead)
+                        for (uint32_t c = head[j];; c = (uint32_t)next[c & kChainRow]) {
+                            ++mine;
+                            if (!(c & kChainMore)) break;
+                        }
+                wave_total += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(mine), 63);
+            }
+        }
+        if (lane == 0) counts[(size_t)tile * kWavesPerBlock + lwave] = wave_total;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void q3_fill_direct_kernel(int32_t *__restrict__ direct, const uint64_t *__restrict__ info) {
@@ -1206,7 +1267,7 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         regime[0] = 0;
         const uint64_t cap64 = std::max<uint64_t>(64, (uint64_t)max_person_rows * 3 / 2 + 8);
         if (cap64 >= (uint64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "q3: window too large for one table region");
-        // build in LDS, one workgroup per window (q3_build_window_lds_kernel), while the tables fit -- or may fit once the state filter has
+        // build and probe in LDS, one workgroup per window (q3_window_join_lds_kernel), while the tables fit -- or may fit once the state filter has
         // dropped its share; a ctx whose last such bet was lost builds in global memory until its windows shrink
         std::vector<int64_t> &lds_state = ctx->host_i64["q3.lds_build"];   // {rows of the largest window when a bet was lost}
         if (lds_state.empty()) lds_state.push_back(0);
@@ -1221,13 +1282,17 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
         FG_TRY(arena_get_t(ctx, "q3.heads", (size_t)std::max(st_a.n_tiles, 1) * kFlagTile, &heads));
         for (;;) {
             cap = lds_build ? (uint32_t)std::min<uint64_t>(cap64, kLdsBuildCap) : (uint32_t)cap64;
-            FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
             FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
             if (lds_build) {
-                LaunchScope ls(ctx, "q3_build_kernel");
-                hipLaunchKernelGGL(q3_build_window_lds_kernel, dim3((unsigned)n_win), dim3(kLdsBuildThreads), 0, ctx->stream, person->p_id, person->state.offsets,
-                                   person->state.data, st_p.seg_off, lits, tables, cap, next, d_err);
+                // build AND count in one kernel, the window's table in LDS from the first insert to the last probe (round 5; round 4 built in
+                // LDS, streamed the table out and probed it from global memory)
+                LaunchScope ls(ctx, "q3_window_join_lds_kernel");
+                hipLaunchKernelGGL(q3_window_join_lds_kernel, dim3((unsigned)n_win), dim3(kLdsBuildThreads), 0, ctx->stream, person->p_id, person->state.offsets,
+                                   person->state.data, st_p.seg_off, lits, cap, next, d_err, auction->seller, auction->category, auction->rows, category_lit, st_a,
+                                   counts, heads);
+                FG_TRY(check_launch(ctx, "q3_window_join_lds_kernel"));
             } else {
+                FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
                 FG_HIP(ctx, hipMemsetAsync(tables, 0xFF, sizeof(uint64_t) * (size_t)cap * n_win, ctx->stream));
                 if (st_p.n_tiles > 0) {
                     LaunchScope ls(ctx, "q3_build_kernel");
@@ -1235,16 +1300,15 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
                                        person->p_id, person->state.offsets, person->state.data, person->rows, st_p, lits, nullptr, nullptr, nullptr,
                                        tables, cap, next, d_err, build_y_shift, (WinTable *)nullptr);
                 }
+                FG_TRY(check_launch(ctx, "q3_build_kernel"));
+                if (st_a.n_tiles > 0) {
+                    LaunchScope ls(ctx, "q3_probe_count_kernel");
+                    hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
+                                       auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
+                                       next, counts, nullptr, nullptr, nullptr, nullptr, heads);
+                }
+                FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
             }
-            FG_TRY(check_launch(ctx, "q3_build_kernel"));
-            // (the bet's verdict arrives with the counts, in the call's usual synchronisation: a lost bet costs one count pass over garbage)
-            if (st_a.n_tiles > 0) {
-                LaunchScope ls(ctx, "q3_probe_count_kernel");
-                hipLaunchKernelGGL(q3_probe_general_kernel<false>, dim3((unsigned)st_a.n_tiles), dim3(kBlock), 0, ctx->stream,
-                                   auction->seller, auction->category, auction->a_id, auction->rows, category_lit, st_a, tables, cap,
-                                   next, counts, nullptr, nullptr, nullptr, nullptr, heads);
-            }
-            FG_TRY(check_launch(ctx, "q3_probe_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_off + n_win + 1, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             FG_TRY(launch_tile_scan(ctx, counts, st_a.n_tiles, tile_base, st_a.tile_first, st_a.n_seg, d_off));
             FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * ((size_t)n_win + 1), hipMemcpyDeviceToHost, ctx->stream));

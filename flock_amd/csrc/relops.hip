@@ -541,27 +541,49 @@ __global__ __launch_bounds__(kBlock) void dense_group_kernel(const void *__restr
     }
     if (tmin == kNone) return;   // no live row in the tile (block-uniform)
     const bool in_lds = tmax - tmin < (uint32_t)kDenseBins;   // block-uniform
-    // the wave's hot slot: the most frequent of three candidates among the first iteration's rows
-    uint32_t hot = kNone;
-    {
-        int best = 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)s[0][0], c * 21);
-            const int cnt = cand == kNone ? 0 : __popcll((unsigned long long)__ballot(s[0][0] == cand));
-            if (cnt > best) {
-                best = cnt;
-                hot = cand;
-            }
-        }
-        if (best < 8) hot = kNone;   // nothing worth the wave-level path
-    }
-    uint32_t hot_cnt = 0;
+    // The wave's hot slot, kept across iterations and re-elected when it goes cold (NEXMark's hot auction moves on every hundred auctions:
+    // a wave's 2048 rows see one or two of them).  Its rows never reach an atomic: counted by ballot + popcount, their values folded per
+    // lane; when the slot changes -- and at the end -- the wave hands the partial over in one update.
+    uint32_t hot = kNone, hot_cnt = 0;
     uint64_t hv[kMaxGroupAggs];
     for (int a = 0; a < n_acc; ++a) hv[a] = agg_identity(sp.op[a]);
+    auto flush_hot = [&]() {   // (wave-uniform)
+        if (!hot_cnt) return;
+        for (int a = 0; a < n_acc; ++a) {
+            uint64_t v = hv[a];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = agg_combine(sp.op[a], v, wave_xor_u64(v, o));
+            hv[a] = v;
+        }
+        if (lane == 0) {
+            if (in_lds) {
+                atomicAdd(&s_cnt[hot - tmin], hot_cnt);
+                for (int a = 0; a < n_acc; ++a) agg_merge(&s_acc[(size_t)a * kDenseBins + (hot - tmin)], sp.op[a], hv[a]);
+            } else {
+                atomicAdd(&g_cnt[hot], hot_cnt);
+                for (int a = 0; a < n_acc; ++a) agg_merge(&g_acc[(size_t)a * range + hot], sp.op[a], hv[a]);
+            }
+        }
+        hot_cnt = 0;
+        for (int a = 0; a < n_acc; ++a) hv[a] = agg_identity(sp.op[a]);
+    };
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it) {
         const int64_t r0 = t0 + it * 256;
+        if (hot == kNone || __popcll((unsigned long long)__ballot(s[it][0] == hot)) < 8) {   // (wave-uniform) cold, or none yet: the best of three candidates
+            flush_hot();
+            hot = kNone;
+            int best = 7;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)s[it][0], c * 21);
+                const int n = cand == kNone ? 0 : __popcll((unsigned long long)__ballot(s[it][0] == cand));
+                if (n > best) {
+                    best = n;
+                    hot = cand;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t sl = s[it][j];
@@ -588,23 +610,7 @@ __global__ __launch_bounds__(kBlock) void dense_group_kernel(const void *__restr
             }
         }
     }
-    if (hot_cnt) {   // (wave-uniform) the hot slot's rows: one update for the wave
-        for (int a = 0; a < n_acc; ++a) {
-            uint64_t v = hv[a];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = agg_combine(sp.op[a], v, wave_xor_u64(v, o));
-            hv[a] = v;
-        }
-        if (lane == 0) {
-            if (in_lds) {
-                atomicAdd(&s_cnt[hot - tmin], hot_cnt);
-                for (int a = 0; a < n_acc; ++a) agg_merge(&s_acc[(size_t)a * kDenseBins + (hot - tmin)], sp.op[a], hv[a]);
-            } else {
-                atomicAdd(&g_cnt[hot], hot_cnt);
-                for (int a = 0; a < n_acc; ++a) agg_merge(&g_acc[(size_t)a * range + hot], sp.op[a], hv[a]);
-            }
-        }
-    }
+    flush_hot();
     if (!in_lds) return;
     __syncthreads();
     for (uint32_t b = threadIdx.x; b <= tmax - tmin; b += kBlock) {
@@ -883,6 +889,87 @@ __global__ __launch_bounds__(kBlock) void join_probe_dense_kernel(const void *__
         mine = wave_sum_u64(mine);
         if (lane_id() == 0 && mine) atomicAdd(total64, mine);
     }
+}
+// ---- join, both sides small (join_tiny): ONE workgroup builds the smaller side's multimap in LDS -- keys, chain heads and the chain links
+// themselves -- and walks the other side through it in chunks of its own size: matches counted, scanned across the workgroup and written
+// at their final places in the same pass.  One launch and one host wait for a join of a stage plan's few thousand filtered rows (the
+// global-table join is a table fill, a build, a count pass, a three-launch scan and an emit pass: at that size the launches ARE the cost,
+// DESIGN section 3a).  Pairs come out ordered by probe row, a key's build rows in chain order -- as join_key64's.
+constexpr int kTinyBuild = 4096, kTinySlots = 8192, kTinyThreads = 1024, kTinyProbe = 1 << 16;
+__global__ __launch_bounds__(kTinyThreads) void join_tiny_kernel(const int64_t *__restrict__ bkeys, int32_t n_build, const int64_t *__restrict__ pkeys, int32_t n_probe,
+                                                                 int32_t *__restrict__ out_build, int32_t *__restrict__ out_probe, uint32_t cap_pairs,
+                                                                 unsigned long long *__restrict__ total) {
+    __shared__ int64_t s_key[kTinySlots + 1];     // (+ 1: the slot of the key that doubles as the empty mark)
+    __shared__ int32_t s_head[kTinySlots + 1];
+    __shared__ int32_t s_next[kTinyBuild];
+    __shared__ uint32_t s_wave[kTinyThreads / 64];
+    for (int i = threadIdx.x; i <= kTinySlots; i += kTinyThreads) {
+        s_key[i] = kEmptyKey;
+        s_head[i] = -1;
+    }
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < n_build; i += kTinyThreads) {
+        const int64_t key = bkeys[i];
+        uint32_t s = kTinySlots;
+        if (key != kEmptyKey) {
+            s = (uint32_t)mix64((uint64_t)key) & (kTinySlots - 1);
+            for (;;) {   // at most half the slots are ever taken: an empty one is always reached
+                int64_t cur = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == kEmptyKey) {
+                    int64_t expected = kEmptyKey;
+                    if (__hip_atomic_compare_exchange_strong(&s_key[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    cur = expected;
+                }
+                if (cur == key) break;
+                s = (s + 1) & (kTinySlots - 1);
+            }
+        }
+        s_next[i] = atomicExch(&s_head[s], i);
+    }
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long running = 0;   // pairs of the chunks before this one (the same in every thread)
+    for (int32_t base = 0; base < n_probe; base += kTinyThreads) {
+        const int32_t i = base + (int32_t)threadIdx.x;
+        int32_t head = -1;
+        uint32_t c = 0;
+        if (i < n_probe) {
+            const int64_t key = pkeys[i];
+            if (key == kEmptyKey) {
+                head = s_head[kTinySlots];
+            } else {
+                uint32_t s = (uint32_t)mix64((uint64_t)key) & (kTinySlots - 1);
+                for (;;) {
+                    const int64_t cur = s_key[s];
+                    if (cur == key) {
+                        head = s_head[s];
+                        break;
+                    }
+                    if (cur == kEmptyKey) break;
+                    s = (s + 1) & (kTinySlots - 1);
+                }
+            }
+            for (int32_t r = head; r >= 0; r = s_next[r]) ++c;
+        }
+        const uint32_t incl = wave_incl_scan_u32(c);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < kTinyThreads / 64; ++w) {
+            before += w < wave ? s_wave[w] : 0u;
+            chunk += s_wave[w];
+        }
+        unsigned long long pos = running + before + (incl - c);
+        if (pos + c <= cap_pairs)   // (beyond the buffers the host sized from its estimate: counted, not written -- the host repeats the call)
+            for (int32_t r = head; r >= 0; r = s_next[r], ++pos) {
+                out_build[pos] = r;
+                out_probe[pos] = i;
+            }
+        running += chunk;
+        __syncthreads();   // (s_wave is rewritten by the next chunk)
+    }
+    if (threadIdx.x == 0) *total = running;
 }
 __global__ __launch_bounds__(kBlock) void fold_key_kernel(const int64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -1553,6 +1640,38 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     if (n_left > 4 * n_right && n_left > 4096) {
         const int rc = join_key64(ctx, (base + ".swapped").c_str(), right, n_right, left, n_left, right_rows, left_rows, n_pairs);
         return rc;
+    }
+    if (n_left > 0 && n_right > 0 && std::min(n_left, n_right) <= kTinyBuild && std::max(n_left, n_right) <= kTinyProbe) {
+        // both sides small: the whole join is one workgroup's work (join_tiny_kernel); the table goes on the smaller side
+        const bool build_left = n_left <= n_right;
+        const int64_t *bk = build_left ? left : right, *pk = build_left ? right : left;
+        const int64_t nb = build_left ? n_left : n_right, np = build_left ? n_right : n_left;
+        std::vector<int64_t> &hint = ctx->host_i64[base + ".pairs_hint"];   // {pairs of the last call under this name}
+        uint64_t cap_pairs = (uint64_t)std::max<int64_t>(np + 1024, hint.empty() ? 0 : hint[0] + hint[0] / 4 + 1024);
+        unsigned long long *d_tot = nullptr, *h_tot = nullptr;
+        FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot));
+        FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot));
+        int32_t *ob = nullptr, *op = nullptr;
+        for (;;) {
+            FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)cap_pairs + 4, &ob));
+            FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)cap_pairs + 4, &op));
+            {
+                LaunchScope ls(ctx, "join_tiny_kernel");
+                hipLaunchKernelGGL(join_tiny_kernel, dim3(1), dim3(kTinyThreads), 0, ctx->stream, bk, (int32_t)nb, pk, (int32_t)np, ob, op,
+                                   (uint32_t)std::min<uint64_t>(cap_pairs, 0x7fffffffu), d_tot);
+            }
+            FG_TRY(check_launch(ctx, "join_tiny_kernel"));
+            FG_HIP(ctx, hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (h_tot[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot[0]);
+            if (h_tot[0] <= cap_pairs) break;
+            cap_pairs = h_tot[0];   // the estimate was too small: once more, with room for every pair
+        }
+        hint.assign(1, (int64_t)h_tot[0]);
+        *left_rows = build_left ? ob : op;
+        *right_rows = build_left ? op : ob;
+        *n_pairs = (int64_t)h_tot[0];
+        return FLOCKGPU_OK;
     }
     if (n_left >= (int64_t(1) << 30) || n_right >= (int64_t(1) << 31))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relation too large for the generic join", name);

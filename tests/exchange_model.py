@@ -73,7 +73,7 @@ class GpuOps:
 
     def q5_partial(self, auction, schedule: WindowSchedule):
         """(auction, count, pane_out_offsets): the groups of every pane (q5.dag HashAggregateExec mode=Partial)."""
-        from .engine import Bids
+        from flock_amd.engine import Bids
         return self.ctx.q5_partial_counts(Bids(auction=auction, rows=int(auction.numel())), schedule)
 
     def q5_weighted(self, auction, count, schedule: WindowSchedule):

@@ -90,3 +90,21 @@ def test_window_schedules_match_reference_launchers():
     assert window_epochs(Window.hopping(10, 5), 27) == oracle.hopping_windows(27, 10, 5) == [(0, 10), (5, 15), (10, 20), (15, 25)]
     # hopping.rs:40-45: seconds < window_size -> no window at all
     assert window_epochs(Window.hopping(10, 5), 7) == []
+
+
+@pytest.mark.gpu
+def test_one_hip_runtime_and_one_rccl_per_process():
+    """libflockgpu.so is built by /opt/rocm's hipcc (RUNPATH /opt/rocm/lib), the PyTorch wheel bundles its own libamdhip64 / librccl
+    under the SAME SONAMEs: whichever is mapped first serves both.  `_ffi.load()` imports torch first, so in a Python host the wheel's
+    runtime is THE runtime (torch is the allocator and stream provider) -- one HIP runtime, one RCCL, whatever the import order the
+    host used.  (A C host without torch resolves /opt/rocm's through the RUNPATH: tests/c_abi/consumer.c.)  DESIGN section 8."""
+    import flock_amd
+    from flock_amd import GpuContext
+    flock_amd.load()
+    c = GpuContext(0)
+    c.close()
+    maps = open("/proc/self/maps").read()
+    for stem in ("libamdhip64.so", "librccl.so"):
+        paths = {line.split()[-1] for line in maps.splitlines() if stem in line}
+        assert len(paths) == 1, (stem, paths)
+        assert "/torch/lib/" in next(iter(paths)), paths

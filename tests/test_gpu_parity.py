@@ -574,7 +574,7 @@ def test_q3_every_path_is_exact(ctx, case):
 
 
 def test_q3_hash_path_tables_built_in_lds_and_the_lost_bet():
-    """The hash path builds each window's multimap in LDS (one workgroup per window, q3_build_window_lds_kernel) and streams it out.
+    """The hash path builds each window's multimap in LDS and probes it there (one workgroup per window, q3_window_join_lds_kernel).
     A window of up to 12 K persons gets its usual 1.5 slots per person; a larger one (up to 36 K) the LDS-sized table on the bet that
     the state filter drops enough persons -- here first every person passes (20 K into 18 K slots: the bet is lost, the same call answers
     from tables built in global memory), then the usual mix on the same ctx (no new bet at that size), then smaller windows (no bet
