@@ -1580,8 +1580,8 @@ def main():
 
     def make_comm():
         import ctypes as C
-        if world > 1:
-            return Comm.from_torch_distributed(ctx)
+        if world > 1:   # (several ranks on ONE device -- the one-GPU test hook -- cannot use RCCL: the same protocol over the ipc transport)
+            return Comm.from_torch_distributed(ctx, transport="ipc" if shared_gpu else "rccl")
         lib = _ffi.load()
         buf = C.create_string_buffer(128)
         if lib.flockgpu_comm_unique_id(buf) != 0:

@@ -218,6 +218,7 @@ SYMBOLS = {
     "flockgpu_comm_unique_id": (_i, [C.c_char_p]),
     "flockgpu_comm_init_rank": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "flockgpu_comm_init_local": (_i, [_i, C.POINTER(_vp)]),
+    "flockgpu_comm_init_ipc": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "flockgpu_comm_destroy": (None, [_vp]),
     "flockgpu_comm_rank": (_i, [_vp]),
     "flockgpu_comm_size": (_i, [_vp]),

@@ -4,10 +4,19 @@
 //           point-to-point: one message per peer per column buffer, never one per window), counts exchanged the same way
 //   local : n ranks = n host threads of one process; buffers move with device-to-device copies on each rank's stream,
 //           the ranks meet at host barriers (also how the exchange logic is exercised on a one-GPU box)
+//   ipc   : n ranks = n PROCESSES on one node (round 5): every rank publishes a hipIpcMemHandle of its send buffer in a POSIX shared-memory
+//           segment named after the 128-byte id, peers map it and pull their runs device to device; counts / reductions and the barriers
+//           go through the same segment.  The protocol above it is the RCCL transport's, rank for rank and process for process: how the
+//           multi-process exchange runs end to end where RCCL cannot (several ranks on one device -- a one-GPU box)
 // Everything above the transport -- partition, send order, counts, regroup, the q3 / q5 / q8 drivers -- is shared.
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -54,6 +63,61 @@ struct LocalGroup {
     }
 };
 
+// ---- ipc transport: the ranks are processes; what LocalGroup keeps in process memory lives in a POSIX shared-memory segment
+constexpr int kIpcMaxRanks = 16;
+constexpr size_t kIpcMsgWords = size_t(1) << 20;   // per rank: the counts / reduction message (8 MB: n ranks x (windows x (1 + Utf8 columns)) values)
+struct IpcRankSlot {
+    hipIpcMemHandle_t handle;     // of the ALLOCATION the send buffer lies in
+    uint64_t handle_off;          // send buffer - allocation base
+    int64_t send_off[kIpcMaxRanks + 1];
+    int64_t msg[kIpcMsgWords];
+};
+struct IpcShared {
+    std::atomic<uint32_t> ready;        // rank 0 has initialised the segment
+    std::atomic<uint32_t> failed;       // a rank left a collective with an error: nobody waits for it again
+    std::atomic<uint32_t> arrived, generation, attached;
+    int32_t n;
+    IpcRankSlot rank[1];                // n of them
+};
+static_assert(std::atomic<uint32_t>::is_always_lock_free, "the segment's atomics must work across processes");
+struct IpcGroup {
+    int n = 0, rank = 0;
+    IpcShared *sh = nullptr;
+    size_t bytes = 0;
+    std::string name;
+    double *timeout_s = nullptr;        // the communicator's (flockgpu_comm_set_timeout)
+    IpcRankSlot &slot(int r) { return *reinterpret_cast<IpcRankSlot *>(reinterpret_cast<uint8_t *>(sh->rank) + sizeof(IpcRankSlot) * (size_t)r); }
+    // false: a rank failed, or did not arrive within the time-out (it is taken for gone: the group is dead from then on)
+    bool barrier() {
+        if (sh->failed.load()) return false;
+        const uint32_t gen = sh->generation.load();
+        if (sh->arrived.fetch_add(1) + 1 == (uint32_t)n) {
+            sh->arrived.store(0);
+            sh->generation.fetch_add(1);
+            return true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spin = 0; sh->generation.load() == gen; ++spin) {
+            if (sh->failed.load()) return false;
+            if (spin > 4000) {
+                std::this_thread::sleep_for(std::chrono::microseconds(spin > 40000 ? 500 : 20));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (timeout_s ? *timeout_s : 600.0)) {
+                    sh->failed.store(1);
+                    return false;
+                }
+            }
+        }
+        return true;
+    }
+    void poison() { if (sh) sh->failed.store(1); }
+    ~IpcGroup() {
+        if (!sh) return;
+        const bool last = sh->attached.fetch_sub(1) == 1;
+        munmap(sh, bytes);
+        if (last || rank == 0) shm_unlink(name.c_str());   // (unlinking twice is harmless; the mapping of the others stays valid)
+    }
+};
+
 constexpr int64_t kMaxPeerBytes = int64_t(1) << 30;  // RCCL transfers above 2 GiB per peer arrived corrupted (round 1): stay well below
 // Piece k of a (source, destination) pair of `bytes` bytes: [lo, hi).  Both ends of a pair know its size from the counts exchange, so
 // they walk the same pieces -- no agreement on a global round count is needed.  `cap`: the communicator's piece limit (kMaxPeerBytes;
@@ -77,6 +141,7 @@ struct flockgpu_comm {
     bool dead = false;   // a collective failed on this rank: every later call returns an error at once (the peers' state is unknown)
     ncclComm_t nccl = nullptr;
     std::shared_ptr<LocalGroup> local;
+    std::shared_ptr<IpcGroup> ipc;
     // per-phase stream timeline of the exchange calls (flockgpu_comm_phase_*): events on the ctx stream at the phase boundaries
     bool phases_on = false;
     std::vector<PhaseMark> marks;
@@ -98,6 +163,7 @@ void kill_comm(flockgpu_comm *c) {
     if (c->dead) return;
     c->dead = true;
     if (c->local) c->local->poison();
+    if (c->ipc) c->ipc->poison();
     if (c->nccl) {
         (void)ncclCommAbort(c->nccl);
         c->nccl = nullptr;
@@ -186,6 +252,15 @@ int exchange_counts(flockgpu_ctx *ctx, flockgpu_comm *c, const int64_t *send, in
         std::copy(send, send + m, recv);
         return FLOCKGPU_OK;
     }
+    if (c->ipc) {
+        IpcGroup &g = *c->ipc;
+        if ((size_t)n * m > kIpcMsgWords) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "exchange: a counts message of %zu values exceeds the ipc transport's %zu", (size_t)n * m, kIpcMsgWords);
+        std::copy(send, send + (size_t)n * m, g.slot(c->rank).msg);
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the ipc group failed");
+        for (int s = 0; s < n; ++s) std::copy(g.slot(s).msg + (size_t)c->rank * m, g.slot(s).msg + (size_t)(c->rank + 1) * m, recv + (size_t)s * m);
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the ipc group failed");
+        return FLOCKGPU_OK;
+    }
     if (!c->is_rccl) {
         LocalGroup &g = *c->local;
         g.counts[(size_t)c->rank] = send;
@@ -222,6 +297,62 @@ int all_to_all(flockgpu_ctx *ctx, flockgpu_comm *c, const void *send, const int6
     if (n == 1) {
         if (send_off[1] > send_off[0] && !skip_self) FG_HIP(ctx, hipMemcpyAsync(r8 + recv_off[0], s8 + send_off[0], (size_t)(send_off[1] - send_off[0]), hipMemcpyDeviceToDevice, ctx->stream));
         return FLOCKGPU_OK;
+    }
+    if (c->ipc) {
+        IpcGroup &g = *c->ipc;
+        // (as the local transport below: a failure between the two barriers still arrives at the second one, then reports)
+        int rc = FLOCKGPU_OK;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: stream synchronisation before the all-to-all failed");
+        IpcRankSlot &me = g.slot(c->rank);
+        std::copy(send_off, send_off + n + 1, me.send_off);
+        me.handle_off = 0;
+        std::memset(&me.handle, 0, sizeof me.handle);
+        if (rc == FLOCKGPU_OK && send_off[n] > send_off[0]) {
+            void *alloc_base = nullptr;
+            size_t alloc_bytes = 0;
+            if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&alloc_base), &alloc_bytes, const_cast<void *>(send)) != hipSuccess ||
+                hipIpcGetMemHandle(&me.handle, alloc_base) != hipSuccess)
+                rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: no ipc handle for the send buffer (HSA_ENABLE_IPC_MODE_LEGACY=0 ?)");
+            else
+                me.handle_off = (uint64_t)(s8 - static_cast<const uint8_t *>(alloc_base));
+        }
+        if (!g.barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the ipc group failed");
+        std::vector<void *> opened;
+        for (int s = 0; s < n && rc == FLOCKGPU_OK; ++s) {
+            const IpcRankSlot &peer = g.slot(s);
+            const int64_t *so = peer.send_off;
+            const int64_t bytes = so[c->rank + 1] - so[c->rank];
+            if (bytes != recv_off[s + 1] - recv_off[s]) {
+                rc = fail(ctx, FLOCKGPU_ERR_INVALID, "exchange: rank %d announced %lld bytes, sends %lld", s, (long long)(recv_off[s + 1] - recv_off[s]), (long long)bytes);
+                break;
+            }
+            if (!bytes || (skip_self && s == c->rank)) continue;
+            const uint8_t *src = nullptr;
+            if (s == c->rank) {
+                src = s8;
+            } else {
+                void *mapped = nullptr;
+                hipIpcMemHandle_t h = peer.handle;
+                if (hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                    rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: rank %d's send buffer cannot be mapped (hipIpcOpenMemHandle)", s);
+                    break;
+                }
+                opened.push_back(mapped);
+                src = static_cast<const uint8_t *>(mapped) + peer.handle_off;
+            }
+            for (uint64_t k = 0;; ++k) {   // in the pieces the RCCL transport would post
+                int64_t lo, hi;
+                peer_piece(bytes, k, c->max_piece, &lo, &hi);
+                if (hi <= lo) break;
+                const hipError_t e = hipMemcpyAsync(r8 + recv_off[s] + lo, src + so[c->rank] + lo, (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream);
+                if (e != hipSuccess) { rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: copy from rank %d failed: %s", s, hipGetErrorString(e)); break; }
+            }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == FLOCKGPU_OK) rc = fail(ctx, FLOCKGPU_ERR_HIP, "exchange: stream synchronisation after the all-to-all failed");
+        for (void *m : opened) (void)hipIpcCloseMemHandle(m);
+        const bool met = g.barrier();  // every rank has pulled its runs: send buffers may be reused
+        if (rc != FLOCKGPU_OK) return rc;
+        return met ? FLOCKGPU_OK : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the ipc group failed");
     }
     if (!c->is_rccl) {
         LocalGroup &g = *c->local;
@@ -286,7 +417,20 @@ int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, uint64_t *
     buf.assign(vals, vals + m);
     buf.push_back((uint64_t)entry_rc);
     const int mm = m + 1;
-    if (!c->is_rccl) {
+    if (c->ipc) {
+        IpcGroup &g = *c->ipc;
+        bool met = (size_t)mm <= kIpcMsgWords;
+        if (met) {
+            std::copy(buf.begin(), buf.end(), reinterpret_cast<uint64_t *>(g.slot(c->rank).msg));
+            met = g.barrier();
+        }
+        std::vector<uint64_t> mx(buf);
+        for (int s = 0; s < n && met; ++s)
+            for (int j = 0; j < mm; ++j) mx[(size_t)j] = std::max(mx[(size_t)j], reinterpret_cast<const uint64_t *>(g.slot(s).msg)[j]);
+        met = met && g.barrier();  // everyone has read the inputs
+        if (!met) return entry_rc != FLOCKGPU_OK ? entry_rc : fail(ctx, FLOCKGPU_ERR_PEER, "exchange: a rank of the ipc group failed");
+        buf = mx;
+    } else if (!c->is_rccl) {
         LocalGroup &g = *c->local;
         g.reduce[(size_t)c->rank] = buf.data();
         bool met = g.barrier();
@@ -839,6 +983,68 @@ int flockgpu_comm_init_local(int n_ranks, flockgpu_comm **out) {
     return FLOCKGPU_OK;
 }
 
+int flockgpu_comm_init_ipc(flockgpu_ctx *ctx, const uint8_t id[FLOCKGPU_COMM_ID_BYTES], int n_ranks, int rank, flockgpu_comm **out) {
+    if (!ctx) return FLOCKGPU_ERR_INVALID;
+    if (!id || !out || n_ranks < 1 || n_ranks > kIpcMaxRanks || rank < 0 || rank >= n_ranks) return fail(ctx, FLOCKGPU_ERR_INVALID, "comm_init_ipc: bad argument (1 to %d ranks)", kIpcMaxRanks);
+    *out = nullptr;
+    FG_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t h = 0xCBF29CE484222325ull;   // the segment's name: a hash of the id every rank was handed
+    for (int i = 0; i < FLOCKGPU_COMM_ID_BYTES; ++i) h = (h ^ id[i]) * 0x100000001B3ull;
+    auto g = std::make_shared<IpcGroup>();
+    g->n = n_ranks;
+    g->rank = rank;
+    char name[64];
+    std::snprintf(name, sizeof name, "/flockgpu-%016llx", (unsigned long long)h);
+    g->name = name;
+    g->bytes = sizeof(IpcShared) + sizeof(IpcRankSlot) * (size_t)n_ranks;
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)g->bytes) != 0) {
+            if (fd >= 0) close(fd);
+            return fail(ctx, FLOCKGPU_ERR_OOM, "comm_init_ipc: cannot create the shared segment %s (%zu bytes)", name, g->bytes);
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {   // rank 0 may not be there yet
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= g->bytes) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+                return fail(ctx, FLOCKGPU_ERR_PEER, "comm_init_ipc: rank 0's shared segment %s did not appear", name);
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    void *p = mmap(nullptr, g->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(ctx, FLOCKGPU_ERR_OOM, "comm_init_ipc: cannot map the shared segment");
+    g->sh = static_cast<IpcShared *>(p);
+    if (rank == 0) {   // (a fresh segment is all zero: the counters start at 0)
+        g->sh->n = n_ranks;
+        g->sh->attached.store(1);
+        g->sh->ready.store(1);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!g->sh->ready.load()) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) return fail(ctx, FLOCKGPU_ERR_PEER, "comm_init_ipc: rank 0 never initialised the segment");
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (g->sh->n != n_ranks) return fail(ctx, FLOCKGPU_ERR_INVALID, "comm_init_ipc: the group has %d ranks, this rank was told %d", g->sh->n, n_ranks);
+        g->sh->attached.fetch_add(1);
+    }
+    std::unique_ptr<flockgpu_comm> c(new flockgpu_comm());
+    c->n = n_ranks;
+    c->rank = rank;
+    c->ipc = g;
+    g->timeout_s = &c->timeout_s;
+    if (!g->barrier()) return fail(ctx, FLOCKGPU_ERR_PEER, "comm_init_ipc: not every rank of the group arrived");   // collective, like ncclCommInitRank
+    *out = c.release();
+    return FLOCKGPU_OK;
+}
+
 void flockgpu_comm_destroy(flockgpu_comm *comm) {
     if (!comm) return;
     if (comm->nccl) (void)ncclCommDestroy(comm->nccl);
@@ -848,7 +1054,7 @@ void flockgpu_comm_destroy(flockgpu_comm *comm) {
 }
 int flockgpu_comm_rank(const flockgpu_comm *comm) { return comm ? comm->rank : -1; }
 int flockgpu_comm_size(const flockgpu_comm *comm) { return comm ? comm->n : 0; }
-const char *flockgpu_comm_transport(const flockgpu_comm *comm) { return !comm ? "" : (comm->is_rccl ? "rccl" : "local"); }
+const char *flockgpu_comm_transport(const flockgpu_comm *comm) { return !comm ? "" : (comm->is_rccl ? "rccl" : comm->ipc ? "ipc" : "local"); }
 
 int flockgpu_comm_barrier(flockgpu_ctx *ctx, flockgpu_comm *comm) {
     if (!ctx) return FLOCKGPU_ERR_INVALID;

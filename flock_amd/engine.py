@@ -389,9 +389,10 @@ class Comm:
         return [Comm(C.c_void_p(h), lib) for h in hs]
 
     @staticmethod
-    def from_torch_distributed(ctx: "GpuContext", group=None):
-        """One process per GPU: rank 0 draws the RCCL id, torch.distributed (the host's own channel) ships its 128 bytes,
-        every rank calls flockgpu_comm_init_rank collectively."""
+    def from_torch_distributed(ctx: "GpuContext", group=None, transport: str = "rccl"):
+        """One process per rank: rank 0 draws the id, torch.distributed (the host's own channel) ships its 128 bytes, every rank calls
+        flockgpu_comm_init_rank collectively -- one GPU per process, RCCL -- or, `transport="ipc"`, flockgpu_comm_init_ipc: the same
+        protocol between processes that may share a device (hipIpc mappings + a shared-memory segment; RCCL refuses that)."""
         import torch.distributed as dist
         lib = _ffi.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -403,8 +404,26 @@ class Comm:
         box = [bytes(buf.raw)]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         h = C.c_void_p()
-        ctx._check(lib.flockgpu_comm_init_rank(ctx._h, box[0], world, rank, C.byref(h)))
+        init = {"rccl": lib.flockgpu_comm_init_rank, "ipc": lib.flockgpu_comm_init_ipc}[transport]
+        ctx._check(init(ctx._h, box[0], world, rank, C.byref(h)))
         return Comm(h, lib)
+
+    @staticmethod
+    def ipc(ctx: "GpuContext", comm_id: bytes, n_ranks: int, rank: int):
+        """flockgpu_comm_init_ipc with an id the host shipped itself (rank 0: `Comm.unique_id()`)."""
+        lib = _ffi.load()
+        h = C.c_void_p()
+        ctx._check(lib.flockgpu_comm_init_ipc(ctx._h, comm_id, n_ranks, rank, C.byref(h)))
+        return Comm(h, lib)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _ffi.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.flockgpu_comm_unique_id(buf)
+        if rc != _ffi.OK:
+            raise FlockGpuError(rc, "flockgpu_comm_unique_id failed")
+        return bytes(buf.raw)
 
 
 # ------------------------------------------------------------------ the context

@@ -38,10 +38,17 @@ int flockgpu_comm_init_rank(flockgpu_ctx *ctx, const uint8_t id[FLOCKGPU_COMM_ID
  * out[r] is rank r's handle, used with rank r's ctx.  Ranks may sit on different devices or share one (how the exchange
  * is tested on a one-GPU box); buffers move with device-to-device copies, the ranks meet at host barriers. */
 int flockgpu_comm_init_local(int n_ranks, flockgpu_comm **out /* n_ranks entries */);
+/* n_ranks PROCESSES of one node, each with a ctx of its own -- on different devices or all on ONE (RCCL refuses several ranks per
+ * device): the same call sequence as flockgpu_comm_init_rank (rank 0 draws the id, the host ships its 128 bytes, every rank calls
+ * this: collective), but the bytes move through hipIpc mappings of the peers' send buffers and the counts / reductions / barriers
+ * through a POSIX shared-memory segment named after the id.  Up to 16 ranks; the processes need HSA_ENABLE_IPC_MODE_LEGACY=0 where
+ * the driver only offers dmabuf handles.  What it is for: the exchange protocol end to end across processes where no second GPU is
+ * at hand (tests, a one-GPU box). */
+int flockgpu_comm_init_ipc(flockgpu_ctx *ctx, const uint8_t id[FLOCKGPU_COMM_ID_BYTES], int n_ranks, int rank, flockgpu_comm **out);
 void flockgpu_comm_destroy(flockgpu_comm *comm);
 int flockgpu_comm_rank(const flockgpu_comm *comm);
 int flockgpu_comm_size(const flockgpu_comm *comm);
-/* "rccl" | "local" */
+/* "rccl" | "local" | "ipc" */
 const char *flockgpu_comm_transport(const flockgpu_comm *comm);
 
 /* ---- q5 as q5.dag runs it: HashAggregateExec(Partial) COUNT on this rank's rows, per 8192-row tile of every pane (a tile stands for one
