@@ -642,50 +642,46 @@ __global__ __launch_bounds__(kInvertBlock) void q3_invert_window_kernel(const in
 // raises `err` and the host builds AND probes in global memory with the full capacity.
 constexpr int kLdsBuildThreads = 1024;
 constexpr uint32_t kLdsBuildCap = 18432;   // 144 KB of the CU's 160
-// The hash join of a window where its table is BUILT: one 1024-thread workgroup per window inserts the window's persons that pass the
+// The hash join of a window where its table is BUILT: one 1024-thread workgroup per window inserts the window's persons that passed the
 // state filter into the LDS multimap and then walks the window's auction tiles -- four at a time, a
 // 256-thread quarter of the workgroup standing for the tile's workgroup of q3_probe_general_kernel<count> -- probing the table IN LDS:
 // the category filter, the first link of every passing row's partner chain into `heads`, the tiles' wave counts.  The table never
 // leaves the CU: no 144 KB write-out per window, and none of the ~1.2e7 random 8-byte reads of a global table the count pass made
 // (0.17 of its 0.30 ms, at the memory side's random-access rate: DESIGN section 10).  The emit pass reads `heads` and `next[]` as before.
-__global__ __launch_bounds__(kLdsBuildThreads) void q3_window_join_lds_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ state_off,
-                                                                              const uint8_t *__restrict__ state_data, const int64_t *__restrict__ seg_off,
-                                                                              Utf8Lits lits, uint32_t cap, int32_t *__restrict__ next, uint32_t *err,
-                                                                              const int32_t *__restrict__ seller, const int32_t *__restrict__ category, int64_t n_rows,
-                                                                              int64_t category_lit, SegTiles st, uint32_t *__restrict__ counts,
-                                                                              uint32_t *__restrict__ heads) {
+__global__ __launch_bounds__(kLdsBuildThreads) void q3_window_join_lds_kernel(const int32_t *__restrict__ p_id, const int32_t *__restrict__ kept_rows,
+                                                                              const int64_t *__restrict__ kept_off, uint32_t cap, int32_t *__restrict__ next,
+                                                                              uint32_t *err, const int32_t *__restrict__ seller, const int32_t *__restrict__ category,
+                                                                              int64_t n_rows, int64_t category_lit, SegTiles st, uint32_t *__restrict__ counts,
+                                                                              uint32_t *__restrict__ heads, int32_t ab_mode) {
     __shared__ uint64_t s_tab[kLdsBuildCap];
     const int32_t w = (int32_t)blockIdx.x;
-    const int64_t lo = seg_off[2 * w], hi = seg_off[2 * w + 1];
+    // (ab_mode: phase cut-outs of experimental builds -- 1: no probe phase, 2: no inserts, 3: probe without table lookups; 0 in the shipped library)
+    // the window's persons that passed the state filter: a compact row list a streaming pass wrote (q3_state_flag_kernel -> scan -> emit;
+    // with the filter inside this kernel its dependent loads -- offsets, then the state's bytes -- were the workgroup's whole build phase:
+    // one workgroup per CU hides no latency)
+    const int64_t lo = kept_off[w], hi = kept_off[w + 1];
     for (uint32_t i = threadIdx.x; i < cap; i += kLdsBuildThreads) s_tab[i] = kEmpty64;
     __syncthreads();
     constexpr int kPer = 4;
     bool full = false;
-    for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += (int64_t)kLdsBuildThreads * kPer) {
-        int32_t key[kPer], b[kPer];
-        uint32_t len[kPer];
-        uint64_t v[kPer];
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)kLdsBuildThreads * kPer) {
+        int32_t row[kPer], key[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
-            const bool in = r < hi;
-            const int2 o = load_off_pair_q3(state_off, in ? r : lo);
-            key[k] = p_id[in ? r : lo];
-            b[k] = o.x;
-            len[k] = in ? (uint32_t)(o.y - o.x) : 0xffffffffu;   // (a row past the window passes no literal)
+            const int64_t i = i0 + (int64_t)k * kLdsBuildThreads;
+            row[k] = i < hi ? kept_rows[i] : -1;
         }
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) v[k] = utf8_head8(state_data, len[k] && len[k] <= 8 ? b[k] : 0, len[k] <= 8 ? len[k] : 0u);
+        for (int k = 0; k < kPer; ++k) key[k] = p_id[row[k] < 0 ? 0 : row[k]];
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int64_t r = r0 + (int64_t)k * kLdsBuildThreads;
-            if (len[k] <= 8 && lits_hit(v[k], len[k], lits) && !multimap_insert_marked(s_tab, cap, next, key[k], (int32_t)r)) full = true;
-        }
+        for (int k = 0; k < kPer; ++k)
+            if (row[k] >= 0 && ab_mode != 2 && !multimap_insert_marked(s_tab, cap, next, key[k], row[k])) full = true;
     }
     if (__syncthreads_or(full)) {   // the window's persons do not fit the LDS table: the host repeats the call on the global tables
         if (threadIdx.x == 0) atomicOr(err, 1u);
         return;
     }
+    if (ab_mode == 1) return;
     // ---- probe: quarter q of the workgroup takes tile first + 4 g + q of the window
     const int32_t t_first = st.tile_first[w], t_end = st.tile_first[w + 1];
     const int quarter = threadIdx.x >> 8, lt = threadIdx.x & 255, lwave = lt >> 6, lane = lane_id();
@@ -707,21 +703,32 @@ __global__ __launch_bounds__(kLdsBuildThreads) void q3_window_join_lds_kernel(co
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t r0 = wbase + (half * 4 + i) * 256;
-                uint32_t head[4];
+                // the FIRST probe of the lane's four rows goes out together (four LDS reads in flight instead of a chain of them): at the load
+                // factor the host sizes for it settles most rows; what is left walks on row by row
+                uint32_t head[4], slot[4];
+                uint64_t first[4];
+                bool need[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t r = r0 + j;
+                    need[j] = r >= tr.lo && r < tr.hi && (int64_t)cv[i][j] == category_lit && ab_mode != 3;
+                    slot[j] = slot_of((uint32_t)sv[i][j], cap);
+                    first[j] = s_tab[need[j] ? slot[j] : 0u];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
                     head[j] = kNoHead;
-                    if (!(r >= tr.lo && r < tr.hi && (int64_t)cv[i][j] == category_lit)) continue;
-                    uint32_t sl = slot_of((uint32_t)sv[i][j], cap);
+                    if (!need[j]) continue;
+                    uint64_t cur = first[j];
+                    uint32_t sl = slot[j];
                     for (uint32_t probe = 0, lim = probe_limit(cap); probe < lim; ++probe) {
-                        const uint64_t cur = s_tab[sl];
                         if (cur == kEmpty64) break;
                         if ((int32_t)(cur >> 32) == sv[i][j]) {
                             head[j] = (uint32_t)cur;
                             break;
                         }
                         sl = (sl + 1 == cap) ? 0 : sl + 1;
+                        cur = s_tab[sl];
                     }
                 }
                 *reinterpret_cast<uint4 *>(tile_heads + (half * 4 + i) * 256) = make_uint4(head[0], head[1], head[2], head[3]);
@@ -1284,12 +1291,30 @@ int flockgpu_q3_join(flockgpu_ctx *ctx, const flockgpu_auction_cols *auction, co
             cap = lds_build ? (uint32_t)std::min<uint64_t>(cap64, kLdsBuildCap) : (uint32_t)cap64;
             FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
             if (lds_build) {
-                // build AND count in one kernel, the window's table in LDS from the first insert to the last probe (round 5; round 4 built in
-                // LDS, streamed the table out and probed it from global memory)
+                // the state filter as a streaming pass of its own (flag tiles -> scan -> compact row list with per-window offsets), then build AND
+                // count in one kernel, the window's table in LDS from the first insert to the last probe (round 5; round 4 built in LDS,
+                // streamed the table out and probed it from global memory)
+                uint32_t *p_flags = nullptr, *p_counts = nullptr;
+                uint64_t *p_base = nullptr;
+                int64_t *p_off = nullptr;
+                int32_t *p_rows = nullptr;
+                FG_TRY(arena_get_t(ctx, "q3.kept_flags", (size_t)st_p.n_tiles * kBlock + 4, &p_flags));
+                FG_TRY(arena_get_t(ctx, "q3.kept_counts", (size_t)st_p.n_tiles * kWavesPerBlock + 4, &p_counts));
+                FG_TRY(arena_get_t(ctx, "q3.kept_base", (size_t)st_p.n_tiles + 1, &p_base));
+                FG_TRY(arena_get_t(ctx, "q3.kept_off", (size_t)n_win + 2, &p_off));
+                FG_TRY(arena_get_t(ctx, "q3.kept_rows", (size_t)person->rows + 4, &p_rows));
+                {
+                    LaunchScope ls(ctx, "q3_state_flag_kernel");
+                    hipLaunchKernelGGL(q3_state_flag_kernel, dim3((unsigned)st_p.n_tiles), dim3(kBlock), 0, ctx->stream, person->state.offsets, person->state.data,
+                                       person->rows, st_p, lits, p_flags, p_counts);
+                }
+                FG_TRY(check_launch(ctx, "q3_state_flag_kernel"));
+                FG_TRY(launch_tile_scan(ctx, p_counts, st_p.n_tiles, p_base, st_p.tile_first, st_p.n_seg, p_off));
+                FG_TRY(emit_flagged_rows(ctx, st_p, p_flags, p_counts, p_base, p_rows));
                 LaunchScope ls(ctx, "q3_window_join_lds_kernel");
-                hipLaunchKernelGGL(q3_window_join_lds_kernel, dim3((unsigned)n_win), dim3(kLdsBuildThreads), 0, ctx->stream, person->p_id, person->state.offsets,
-                                   person->state.data, st_p.seg_off, lits, cap, next, d_err, auction->seller, auction->category, auction->rows, category_lit, st_a,
-                                   counts, heads);
+                hipLaunchKernelGGL(q3_window_join_lds_kernel, dim3((unsigned)n_win), dim3(kLdsBuildThreads), 0, ctx->stream, person->p_id, p_rows, p_off, cap, next,
+                                   d_err, auction->seller, auction->category, auction->rows, category_lit, st_a, counts, heads,
+                                   exp_env("FLOCKGPU_Q3W_MODE") ? atoi(exp_env("FLOCKGPU_Q3W_MODE")) : 0);
                 FG_TRY(check_launch(ctx, "q3_window_join_lds_kernel"));
             } else {
                 FG_TRY(arena_get_t(ctx, "q3.tables", (size_t)cap * std::max(n_win, 1), &tables));
