@@ -188,7 +188,11 @@ struct flockgpu_plan {
         bool active = false;
         int input = -1;
         int64_t pane = 0, rows = 0;
-        std::vector<void *> dev;        // per leaf column: the side buffer (null: not prefetched)
+        std::vector<void *> dev;        // per leaf column: the side buffer (null: not prefetched); a Utf8 column's: its bytes
+        std::vector<void *> dev_off;    // Utf8 columns: the pane's `rows` raw END offsets, batch by batch (rebased when the pane is appended)
+        std::vector<int64_t> bytes;     // Utf8 columns: bytes in the side buffer
+        struct Rebase { int col; int64_t row0, n; int64_t delta; };   // rows [row0, row0 + n) of column col: + delta turns a raw offset into a pane-relative one
+        std::vector<Rebase> rebase;
         std::vector<std::thread> workers;
         std::vector<int> rc;
     } pre;
@@ -2698,7 +2702,6 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
     }
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (!lf.needed[c]) continue;
-        if (lf.schema[c].type == ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: Utf8 column '%s' (feed the pane the ordinary way)", lf.schema[c].name.c_str());
         child[c] = find_child(schema, lf.schema[c].name);
         if (child[c] < 0) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: column '%s' missing from the fed schema", lf.schema[c].name.c_str());
         if (!format_ok(lf.schema[c], schema->children[child[c]]->format))
@@ -2706,7 +2709,7 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
                         schema->children[child[c]]->format, type_name(lf.schema[c]));
         for (int b = 0; b < n_batches; ++b) {
             const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
-            if (!a || a->length < rb->offset + rb->length || a->n_buffers < 2 || (rb->length > 0 && !a->buffers[1]))
+            if (!a || a->length < rb->offset + rb->length || a->n_buffers < (lf.schema[c].type == ColType::UTF8 ? 3 : 2) || (rb->length > 0 && !a->buffers[1]))
                 return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: column '%s' of batch %d is malformed", lf.schema[c].name.c_str(), b);
             if (validity_has_nulls(a, a->offset + rb->offset, rb->length))
                 return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: column '%s' holds NULLs (feed the pane the ordinary way)", lf.schema[c].name.c_str());
@@ -2724,10 +2727,76 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
     if (plan->append_done_set) FG_HIP(ctx, hipStreamWaitEvent(plan->copy_stream, plan->append_done, 0));
     // side buffers; pinned sources go straight to the DMA engine, pageable ones through a pinned mirror filled by staging threads
     plan->pre.dev.assign(lf.schema.size(), nullptr);
+    plan->pre.dev_off.assign(lf.schema.size(), nullptr);
+    plan->pre.bytes.assign(lf.schema.size(), 0);
+    plan->pre.rebase.clear();
     std::vector<flockgpu_plan::CopyJob> pieces;   // pageable pieces: dst (device), src (host), bytes
     size_t pageable = 0;
+    auto queue_runs = [&](std::vector<flockgpu_plan::CopyJob> &runs) -> int {   // pinned sources straight to the DMA engine, pageable ones in staged chunks
+        for (auto &r : runs) {
+            const uint8_t *src = static_cast<const uint8_t *>(r.src);
+            uint8_t *dst = static_cast<uint8_t *>(r.dst);
+            if (host_is_pinned(src) && host_is_pinned(src + r.bytes - 1)) {
+                FG_HIP(ctx, hipMemcpyAsync(dst, src, r.bytes, hipMemcpyHostToDevice, plan->copy_stream));
+            } else {
+                for (size_t done = 0; done < r.bytes; done += kStageChunk) {
+                    const size_t n = std::min(kStageChunk, r.bytes - done);
+                    pieces.push_back(flockgpu_plan::CopyJob{dst + done, src + done, n});
+                    pageable += n;
+                }
+            }
+        }
+        return FLOCKGPU_OK;
+    };
     for (size_t c = 0; c < lf.schema.size(); ++c) {
         if (child[c] < 0) continue;
+        if (lf.schema[c].type == ColType::UTF8) {
+            // offsets: every batch's END offsets, raw, one after the other (rebased onto the column's byte cursor when the pane is appended: a run
+            // of batches that are slices of one allocation shares its delta); bytes: every batch's byte range, back to back
+            int64_t total = 0;
+            for (int b = 0; b < n_batches; ++b) {
+                const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
+                if (!rb->length) continue;
+                const int32_t *so = static_cast<const int32_t *>(a->buffers[1]) + a->offset + rb->offset;
+                total += (int64_t)so[rb->length] - so[0];
+            }
+            if (total >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "prefetch_pane: Utf8 column exceeds 2^31 bytes");
+            void *d_off = nullptr, *d_bytes = nullptr;
+            FG_TRY(arena_get(ctx, leaf_key(plan, input, (int)c, "pre.off").c_str(), (size_t)rows * 4 + 16, &d_off));
+            FG_TRY(arena_get(ctx, leaf_key(plan, input, (int)c, "pre").c_str(), (size_t)total + 16, &d_bytes));
+            plan->pre.dev[c] = d_bytes;
+            plan->pre.dev_off[c] = d_off;
+            plan->pre.bytes[c] = total;
+            std::vector<flockgpu_plan::CopyJob> off_runs, byte_runs;
+            int64_t row_at = 0, byte_at = 0;
+            for (int b = 0; b < n_batches; ++b) {
+                const ArrowArray *rb = batches[b], *a = rb->children[child[c]];
+                const int64_t n = rb->length;
+                if (!n) continue;
+                const int32_t *so = static_cast<const int32_t *>(a->buffers[1]) + a->offset + rb->offset;
+                const uint8_t *sb = static_cast<const uint8_t *>(a->buffers[2]);
+                const int64_t nbytes = (int64_t)so[n] - so[0], delta = byte_at - so[0];
+                if (nbytes && !sb) return fail(ctx, FLOCKGPU_ERR_INVALID, "prefetch_pane: Utf8 column '%s' without a data buffer", lf.schema[c].name.c_str());
+                const uint8_t *osrc = reinterpret_cast<const uint8_t *>(so + 1);
+                uint8_t *odst = static_cast<uint8_t *>(d_off) + (size_t)row_at * 4;
+                if (!off_runs.empty() && static_cast<const uint8_t *>(off_runs.back().src) + off_runs.back().bytes == osrc) off_runs.back().bytes += (size_t)n * 4;
+                else off_runs.push_back(flockgpu_plan::CopyJob{odst, osrc, (size_t)n * 4});
+                if (nbytes) {
+                    const uint8_t *bsrc = sb + so[0];
+                    uint8_t *bdst = static_cast<uint8_t *>(d_bytes) + byte_at;
+                    if (!byte_runs.empty() && static_cast<const uint8_t *>(byte_runs.back().src) + byte_runs.back().bytes == bsrc) byte_runs.back().bytes += (size_t)nbytes;
+                    else byte_runs.push_back(flockgpu_plan::CopyJob{bdst, bsrc, (size_t)nbytes});
+                }
+                auto &rbs = plan->pre.rebase;
+                if (!rbs.empty() && rbs.back().col == (int)c && rbs.back().delta == delta && rbs.back().row0 + rbs.back().n == row_at) rbs.back().n += n;
+                else rbs.push_back(flockgpu_plan::Prefetch::Rebase{(int)c, row_at, n, delta});
+                row_at += n;
+                byte_at += nbytes;
+            }
+            FG_TRY(queue_runs(off_runs));
+            FG_TRY(queue_runs(byte_runs));
+            continue;
+        }
         const size_t w = col_width(lf.schema[c].type);
         void *d = nullptr;
         FG_TRY(arena_get(ctx, leaf_key(plan, input, (int)c, "pre").c_str(), (size_t)rows * w + 16, &d));
@@ -2746,19 +2815,7 @@ int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id,
             if (!runs.empty() && static_cast<const uint8_t *>(runs.back().src) + runs.back().bytes == src) runs.back().bytes += bytes;
             else runs.push_back(flockgpu_plan::CopyJob{dst, src, bytes});
         }
-        for (auto &r : runs) {
-            const uint8_t *src = static_cast<const uint8_t *>(r.src);
-            uint8_t *dst = static_cast<uint8_t *>(r.dst);
-            if (host_is_pinned(src) && host_is_pinned(src + r.bytes - 1)) {
-                FG_HIP(ctx, hipMemcpyAsync(dst, src, r.bytes, hipMemcpyHostToDevice, plan->copy_stream));
-            } else {
-                for (size_t done = 0; done < r.bytes; done += kStageChunk) {
-                    const size_t n = std::min(kStageChunk, r.bytes - done);
-                    pieces.push_back(flockgpu_plan::CopyJob{dst + done, src + done, n});
-                    pageable += n;
-                }
-            }
-        }
+        FG_TRY(queue_runs(runs));
     }
     uint8_t *mirror = nullptr;   // (before the prefetch counts as under way: a refusal here must leave nothing behind that a feed would append)
     if (!pieces.empty()) FG_TRY(pinned_get_t(ctx, leaf_key(plan, input, 0, "pre.stage").c_str(), pageable + 64, &mirror));
@@ -2872,12 +2929,6 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         FG_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->copy_done, 0));          // ... and the appends wait for them on the device
         for (size_t c = 0; c < lf.schema.size(); ++c) {
             if (!plan->pre.dev[c]) continue;
-            const size_t w = col_width(lf.schema[c].type);
-            void *p = nullptr;
-            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "val"), (size_t)ld.rows * w, (size_t)(ld.rows + plan->pre.rows) * w + 16, &p));
-            ld.cols[c].values = p;
-            if (plan->pre.rows)
-                FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(p) + (size_t)ld.rows * w, plan->pre.dev[c], (size_t)plan->pre.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
             // a column that carries validity from an earlier, ordinarily fed pane keeps room for every row of the leaf, exactly as feed_impl
             // does: the scan fills the rows behind the last NULL with "valid" up to the leaf's row count (the prefetched rows were
             // appended to the values only, and that fill ran past a validity buffer sized for the panes before)
@@ -2887,6 +2938,31 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
                 FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "valid"), (size_t)dc.valid_rows, (size_t)(ld.rows + plan->pre.rows) + 64, &vp));
                 dc.valid = static_cast<uint8_t *>(vp);
             }
+            if (lf.schema[c].type == ColType::UTF8) {   // offsets behind the leaf's, rebased onto its byte cursor run by run; bytes behind its bytes
+                void *po = nullptr, *pb = nullptr;
+                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "off"), (size_t)(ld.rows + 1) * 4, (size_t)(ld.rows + plan->pre.rows + 1) * 4 + 16, &po));
+                if (!dc.offsets) FG_HIP(ctx, hipMemsetAsync(po, 0, 4, ctx->stream));
+                dc.offsets = static_cast<int32_t *>(po);
+                FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "bytes"), (size_t)dc.bytes, (size_t)(dc.bytes + plan->pre.bytes[c]) + 16, &pb));
+                dc.values = pb;
+                if (dc.bytes + plan->pre.bytes[c] >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "feed_pane: Utf8 column exceeds 2^31 bytes");
+                if (plan->pre.rows) {
+                    FG_HIP(ctx, hipMemcpyAsync(dc.offsets + ld.rows + 1, plan->pre.dev_off[c], (size_t)plan->pre.rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    for (auto &rb : plan->pre.rebase)
+                        if (rb.col == (int)c) FG_TRY(add_i32(ctx, dc.offsets + ld.rows + 1 + rb.row0, rb.n, (int32_t)(dc.bytes + rb.delta)));
+                }
+                if (plan->pre.bytes[c])
+                    FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(pb) + dc.bytes, plan->pre.dev[c], (size_t)plan->pre.bytes[c], hipMemcpyDeviceToDevice, ctx->stream));
+                dc.bytes += plan->pre.bytes[c];
+                ld.pane_bytes.back()[c] += plan->pre.bytes[c];
+                continue;
+            }
+            const size_t w = col_width(lf.schema[c].type);
+            void *p = nullptr;
+            FG_TRY(grow(ctx, leaf_key(plan, input, (int)c, "val"), (size_t)ld.rows * w, (size_t)(ld.rows + plan->pre.rows) * w + 16, &p));
+            ld.cols[c].values = p;
+            if (plan->pre.rows)
+                FG_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(p) + (size_t)ld.rows * w, plan->pre.dev[c], (size_t)plan->pre.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
         }
         FG_HIP(ctx, hipEventRecord(plan->append_done, ctx->stream));
         plan->append_done_set = true;

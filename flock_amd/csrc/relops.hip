@@ -1058,6 +1058,18 @@ __global__ __launch_bounds__(kBlock) void sort_digit_kernel(const uint64_t *__re
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         out[i] = (int32_t)(uint32_t)((key[order ? order[i] : i] - base) >> shift);
 }
+// digits[i] = bits [shift, shift + 32) of (norm(key[order ? order[i] : i]) - lo), norm = the integer's order-preserving unsigned form (complemented
+// when descending): ORDER BY one integer column without NULLs skips the 64-bit normalised copy of the column (sort_norm_kernel: 12 bytes of
+// traffic per row and a pass of its own)
+__global__ __launch_bounds__(kBlock) void sort_int_digit_kernel(const void *__restrict__ v, int32_t type, const uint32_t *__restrict__ order, int64_t n,
+                                                                int32_t descending, uint64_t lo, int32_t shift, int32_t *__restrict__ out) {
+    const uint64_t flip = type == (int32_t)ColType::U64 ? 0ull : (uint64_t(1) << 63);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        uint64_t k = (uint64_t)load_as_i64(v, type, order ? order[i] : i) ^ flip;
+        if (descending) k = ~k;
+        out[i] = (int32_t)(uint32_t)((k - lo) >> shift);
+    }
+}
 __global__ __launch_bounds__(kBlock) void iota_i32_kernel(int32_t *__restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = (int32_t)i;
 }
@@ -1105,6 +1117,51 @@ int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_ke
     FG_TRY(arena_get_t(ctx, (base + ".minmax").c_str(), 2, &d_mm));
     FG_TRY(pinned_get_t(ctx, (base + ".minmax").c_str(), 2, &h_mm));
     const unsigned grid = grid_for(ctx, rows);
+    // ORDER BY ONE integer column without NULLs -- `SELECT * FROM bid ORDER BY bidder`, the reference's arch/ops/sort.sql --: the column's exact
+    // range (one 4-byte-per-row pass) sizes the radix sort, whose first pass reads the COLUMN itself when it is an ascending Int32 (bias =
+    // minimum); other integer keys go through one digit pass per 32 bits.  No normalised 64-bit copy, no composition of permutations: the
+    // sort's row numbers ARE the result.  (The general sequence below: 0.53 + 0.21 + 0.16 ms of such passes per 9.2e7 bids.)
+    if (n_keys == 1 && !keys[0].col.valid && !keys[0].col.all_null &&
+        (keys[0].col.type == ColType::I32 || keys[0].col.type == ColType::I64 || keys[0].col.type == ColType::U64)) {
+        const SortKey &k = keys[0];
+        int64_t mn = 0, mx = 0;
+        FG_TRY(column_minmax(ctx, k.col, rows, &mn, &mx));
+        const uint64_t flip = k.col.type == ColType::U64 ? 0ull : (uint64_t(1) << 63);
+        uint64_t lo = (uint64_t)mn ^ flip, hi = (uint64_t)mx ^ flip;
+        if (k.descending) {
+            const uint64_t t = ~hi;
+            hi = ~lo;
+            lo = t;
+        }
+        const uint64_t span = hi - lo;
+        int bits = 0;
+        while (bits < 64 && (span >> bits)) ++bits;
+        const uint32_t *order = nullptr;
+        int32_t *sk = nullptr;
+        uint32_t *sv = nullptr;
+        if (bits == 0) {   // every row ties: the identity
+            hipLaunchKernelGGL(iota_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, perm[0], rows);
+            FG_TRY(check_launch(ctx, "iota_i32_kernel"));
+            return FLOCKGPU_OK;
+        }
+        if (k.col.type == ColType::I32 && !k.descending && bits <= 32) {
+            FG_TRY(radix_sort_pairs(ctx, (base + ".lo").c_str(), static_cast<const int32_t *>(k.col.values), nullptr, rows, (int32_t)mn, bits, &sk, &sv));
+            order = sv;
+        } else {
+            for (int shift = 0; shift < bits; shift += 32) {
+                {
+                    LaunchScope ls(ctx, "sort_int_digit_kernel");
+                    hipLaunchKernelGGL(sort_int_digit_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, k.col.values, (int32_t)k.col.type, order, rows,
+                                       k.descending ? 1 : 0, lo, shift, digits);
+                }
+                FG_TRY(check_launch(ctx, "sort_int_digit_kernel"));
+                FG_TRY(radix_sort_pairs(ctx, (base + (shift ? ".hi" : ".lo")).c_str(), digits, order, rows, 0, std::min(32, bits - shift), &sk, &sv));
+                order = sv;
+            }
+        }
+        *out_rows = reinterpret_cast<int32_t *>(const_cast<uint32_t *>(order));   // (row numbers below 2^31: the same bits)
+        return FLOCKGPU_OK;
+    }
     const int32_t *cur = nullptr;   // null: the identity
     int at = 0;                     // perm[at] receives the next order
     auto read_range = [&]() -> int {

@@ -117,7 +117,7 @@ class _Plan:
     def prefetch(self, i: int, batches: Sequence, pane: int) -> bool:
         """The NEXT pane's batches of leaf i start moving to the device now, beside whatever the plan is executing
         (flockgpu_plan_prefetch_pane); `feed_prefetched(i, pane)` appends them when the pane's turn has come.  False -- nothing was
-        started -- when the pane holds what a prefetch does not take (Utf8 columns, NULLs): feed it the ordinary way then."""
+        started -- when the pane holds what a prefetch does not take (NULLs): feed it the ordinary way then."""
         batches = [b for b in batches if b is not None]
         if not batches:
             return False
@@ -297,7 +297,7 @@ class ExecutionContext:
 
     def prefetch_data_sources(self, sources, pane: int):
         """The sources of pane `pane` -- the ring's NEXT pane -- matched to the leaves as feed_data_sources matches them; what a prefetch
-        takes (fixed-width columns without NULLs, one leaf per plan) starts crossing PCIe now, beside the current window's execute, the
+        takes (columns without NULLs, one leaf per plan) starts crossing PCIe now, beside the current window's execute, the
         rest is kept and fed the ordinary way by `feed_data_sources(None, pane)`."""
         if not self._ring:
             raise ValueError("prefetch_data_sources: open a window ring first")

@@ -195,7 +195,8 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
 /* Overlap of the NEXT pane's upload with the current window's execute: brings the batches of pane `pane_id` (the ring's next pane) of
  * `input` into side buffers -- on a stream of the plan's own; pageable memory is staged by threads of the plan's own -- and returns at
  * once; the ring does not change.  The pane is then fed with flockgpu_plan_feed_pane(plan, input, pane_id, NULL, NULL, 0), which
- * appends the prefetched rows device to device.  One pane of one input at a time; fixed-width columns without NULLs
+ * appends the prefetched rows device to device.  One pane of one input at a time; fixed-width and (since round 5) Utf8 columns -- offsets
+ * and bytes travel raw, the offsets are rebased onto the column's byte cursor when the pane is appended -- without NULLs
  * (FLOCKGPU_ERR_UNSUPPORTED otherwise: feed that pane the ordinary way).  The batches stay borrowed until the flockgpu_plan_reset that
  * follows the pane's feed; flockgpu_plan_ring_close / flockgpu_plan_destroy drop a prefetch that was never fed. */
 int flockgpu_plan_prefetch_pane(flockgpu_plan *plan, int input, int64_t pane_id, const struct ArrowSchema *schema,

@@ -340,3 +340,47 @@ def test_reference_operator_harness_plans(gpu, generic_only):
             rows = _plain(ctx.execute()[0][0])
             assert (rows if name in ("filter", "sort") else sorted(rows)) == want[name], (name, generic_only)
         ctx.close()
+
+
+# ------------------------------------------------------------------ GPU: Utf8 columns in the pane prefetch
+@pytest.mark.gpu
+def test_prefetched_panes_with_utf8_columns_equal_fed_panes(gpu):
+    """q8 over Hopping(3 panes) on the rows ring with every next pane PREFETCHED: the persons leaf (p_id + a Utf8 name: offsets and bytes travel
+    raw into side buffers, the offsets are rebased onto the column's byte cursor at the append) moves beside the current window's execute, the
+    auctions take the ordinary feed; batches that are slices of one allocation and batches of their own; every window equals the whole-window
+    feed and the oracle."""
+    from flock_amd.runtime import ExecutionContext, collect
+    from test_plan_boundary import _auction_batches, _person_batches, _plan, _utf8
+    eps, n_panes, ppw = 30_000, 6, 3
+    s = oracle.NexmarkStream(seed=18, eps=eps)
+    pers = []
+    for p in range(n_panes):
+        bs = _person_batches(s, p * eps, (p + 1) * eps, eps if p % 2 else 9_000)
+        if p % 3 == 2 and len(bs) == 1:       # slices of ONE allocation: their offsets continue each other (one rebase run)
+            bs = [bs[0].slice(0, bs[0].num_rows // 3), bs[0].slice(bs[0].num_rows // 3)]
+        pers.append(bs)
+    aucs = [_auction_batches(s, p * eps, (p + 1) * eps, 11_000) for p in range(n_panes)]
+    ring = ExecutionContext([_plan(8)], name="q8-ring-pre", gpu=gpu)
+    whole = ExecutionContext([_plan(8)], name="q8-whole-pre", gpu=gpu)
+    ring.open_window_ring(ppw)
+    ring.feed_data_sources([[pers[0]], [aucs[0]]], pane=0)
+    moved = 0
+    for p in range(n_panes):
+        if p + 1 < n_panes:
+            ring.prefetch_data_sources([[pers[p + 1]], [aucs[p + 1]]], pane=p + 1)
+            moved += len(ring._pre["moving"])
+        rb = ring.execute()[0][0]
+        ring.clean_data_sources()
+        lo = max(0, p - ppw + 1)
+        ref = collect(whole, [[[b for q in range(lo, p + 1) for b in pers[q]]], [[b for q in range(lo, p + 1) for b in aucs[q]]]])[0][0]
+        hp, ha = s.persons(lo * eps, (p + 1) * eps), s.auctions(lo * eps, (p + 1) * eps)
+        rows = oracle.q8_join(hp["p_id"], hp["name"], ha["seller"])
+        names = _utf8(hp["name"]).to_pylist()
+        want = sorted((int(hp["p_id"][r]), names[r]) for r in rows)
+        got = sorted(zip(rb["p_id"].to_pylist(), rb["name"].to_pylist()))
+        assert got == sorted(zip(ref["p_id"].to_pylist(), ref["name"].to_pylist())) == want and want, p
+        if p + 1 < n_panes:
+            ring.feed_data_sources(None, pane=p + 1)
+    assert moved == n_panes - 1          # the Utf8-carrying leaf did move ahead every time (round 4 refused it and fed it the ordinary way)
+    ring.close()
+    whole.close()

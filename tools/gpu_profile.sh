@@ -37,7 +37,7 @@ for q in ${QUERIES:-5 2 8 3 3_1e8 7 9 13}; do
 done
 # the side entries bench.py reports under `also` (q11, YSB, JSON ingest) and the general-path rows: kernel stats + PMC passes each
 for side in ${SIDES:-q11 ysb json}; do
-  cmd="python bench.py --only-side $side --steps 3"
+  cmd="python bench.py --only-side $side --steps 3 --no-cpu"
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$side -- $cmd > "$OUT/${side}_stats_run.log" 2>&1
   f=$(find /tmp/prof_$side -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${side}_kernel_stats.csv"
   grep '^{' "$OUT/${side}_stats_run.log" | tail -1 > "$OUT/${side}_bench_under_rocprof.json"
