@@ -1686,6 +1686,10 @@ int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *o
     return FLOCKGPU_OK;
 }
 
+bool join_is_tiny(int64_t n_left, int64_t n_right) {
+    return n_left > 0 && n_right > 0 && std::min(n_left, n_right) <= kTinyBuild && std::max(n_left, n_right) <= kTinyProbe;
+}
+
 int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs) {
     const std::string base = name;
@@ -1698,7 +1702,7 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         const int rc = join_key64(ctx, (base + ".swapped").c_str(), right, n_right, left, n_left, right_rows, left_rows, n_pairs);
         return rc;
     }
-    if (n_left > 0 && n_right > 0 && std::min(n_left, n_right) <= kTinyBuild && std::max(n_left, n_right) <= kTinyProbe) {
+    if (join_is_tiny(n_left, n_right)) {
         // both sides small: the whole join is one workgroup's work (join_tiny_kernel); the table goes on the smaller side
         const bool build_left = n_left <= n_right;
         const int64_t *bk = build_left ? left : right, *pk = build_left ? right : left;
