@@ -1635,6 +1635,18 @@ struct Exec {
                     FG_TRY(arena_get_t(ctx, node_key(pl, n, "kl").c_str(), (size_t)nl + 2, &kl));
                     FG_TRY(arena_get_t(ctx, node_key(pl, n, "kr").c_str(), (size_t)nr + 2, &kr));
                     FG_TRY(utf8_codes(ctx, node_key(pl, n, "codes").c_str(), lk.c, nl, kl, &rk.c, nr, kr));
+                    // the codes are row numbers of the left relation -- dense by construction, [0, nl) -- and a right string the left does not
+                    // hold gets a negative one: chain heads addressed by the code itself, no second hash table behind the dictionary's
+                    if (nl > 0 && nr > 0 && !join_is_tiny(nl, nr)) {
+                        DevColumn cl, cr;
+                        cl.type = cr.type = ColType::I64;
+                        cl.values = kl;
+                        cr.values = kr;
+                        FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), cl, nl, 0, nl - 1, cr, nr, &lrows, &rrows, &pairs));
+                        t->rows = pairs;
+                        FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
+                        return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+                    }
                 } else if (n->on_l2 >= 0) {  // two Int32 pairs compare as one 64-bit key
                     const TCol &lk2 = L.cols[(size_t)n->on_l2], &rk2 = R.cols[(size_t)n->on_r2];
                     if (lk.c.type != ColType::I32 || rk.c.type != ColType::I32 || lk2.c.type != ColType::I32 || rk2.c.type != ColType::I32)
@@ -1855,7 +1867,22 @@ struct Exec {
             FG_TRY(int_col_stats(k, in.rows, &kmin, &kmax));
             dense = dense_range_ok(kmin, kmax, in.rows, k.c.type == ColType::U64);
         }
-        if (dense) {
+        // A Utf8 key's dictionary codes are row numbers of its own relation: dense by construction.  The code of a group IS a row that
+        // carries the group's string, so it also stands in for the first row the key column is taken from.
+        bool dense_codes = !pair && !null_keys && k.present && k.c.type == ColType::UTF8 && in.rows > 0 && in.rows < (int64_t(1) << 31);
+        for (int a = 0; a < n_specs && dense_codes; ++a)
+            dense_codes = !specs[a].valid && specs[a].op != AggOp::SUM_F64 && specs[a].op != AggOp::MAX_F64 && specs[a].op != AggOp::MIN_F64;
+        if (dense_codes) {
+            FG_TRY(prepare_keys());   // (utf8_codes)
+            DevColumn codes;
+            codes.type = ColType::I64;
+            codes.values = keys;
+            FG_TRY(group_by_dense(ctx, node_key(pl, n, "grp").c_str(), codes, in.rows, 0, in.rows - 1, specs, n_specs, &g));
+            int32_t *rep = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, "rep").c_str(), (size_t)g.n_groups + 4, &rep));
+            FG_TRY(narrow_i64_to_i32(ctx, g.keys, g.n_groups, rep));
+            g.first_row = rep;
+        } else if (dense) {
             FG_TRY(group_by_dense(ctx, node_key(pl, n, "grp").c_str(), k.c, in.rows, kmin, kmax, specs, n_specs, &g));
         } else {
             FG_TRY(prepare_keys());

@@ -1501,8 +1501,10 @@ int column_minmax(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t
 bool dense_range_ok(int64_t kmin, int64_t kmax, int64_t rows, bool uns) {
     const uint64_t span = (uint64_t)kmax - (uint64_t)kmin;   // (mod 2^64: the true span for either signedness when kmin <= kmax in its order)
     if (uns ? (uint64_t)kmax < (uint64_t)kmin : kmax < kmin) return false;
-    // a slot per key value: affordable while there is about a row per slot (clearing and compacting the table costs 4-12 bytes per slot)
-    return span < (uint64_t)std::max<int64_t>(int64_t(1) << 16, rows) && span < (uint64_t(1) << 31) - 1;
+    // a slot per key value: affordable while the range is within 16x the rows -- clearing and compacting the table is 4-12 bytes of STREAMING
+    // per slot, a hash table's claim a random returning atomic per row; one of P = 8 hash partitions of a dense id column is 8x as wide as
+    // its rows (the stage plans' joins and Final aggregates)
+    return span < (uint64_t)std::max<int64_t>(int64_t(1) << 16, 16 * rows) && span < (uint64_t(1) << 31) - 1;
 }
 
 int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, int64_t rows, int64_t kmin, int64_t kmax, const AggSpec *specs, int n_specs,
@@ -1572,7 +1574,7 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
     FG_TRY(arena_get_t(ctx, (base + ".dbase").c_str(), (size_t)st.n_tiles + 1, &tile_base));
     FG_TRY(arena_get_t(ctx, (base + ".doff").c_str(), 2, &d_off));
     FG_TRY(pinned_get_t(ctx, (base + ".doff").c_str(), 2, &h_off));
-    FG_TRY(arena_get_t(ctx, (base + ".dslots").c_str(), (size_t)std::min<int64_t>(range, rows) + 4, &slots));
+    FG_TRY(arena_get_t(ctx, (base + ".dslots").c_str(), (size_t)std::min<int64_t>(range, rows) + 4, &slots));   // (at most one live slot per row)
     {
         LaunchScope ls(ctx, "dense_live_flag_kernel");
         hipLaunchKernelGGL(dense_live_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, cnt, (int64_t)range, st, flags, counts);
