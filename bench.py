@@ -195,6 +195,9 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
     if os.environ.get("FLOCK_BENCH_STEP_TIMES"):
         print("step wall ms:", [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     stats = ctx.profile_read()
+    timed = set(only.split("|")) if only is not None else set(stats)
+    for k in timed & set(stats):
+        stats[k]["samples"] = ctx.profile_samples(k)
     if only is not None:
         extra = 2
         ctx.profile_reset()
@@ -203,7 +206,7 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
             res = step()
         torch.cuda.synchronize()
         for k, v in ctx.profile_read().items():
-            if k != only:
+            if k not in timed:      # the timed region's own launches of the bracketed kernel(s) stay
                 stats[k] = {"launches": int(round(v["launches"] * steps / extra)), "total_ms": v["total_ms"] * steps / extra}
         barrier()
     ctx.profile(False)
@@ -224,8 +227,10 @@ def roofline(q, stats, rel_rows, table=None, workload=None):
     avg_ms = st["total_ms"] / st["launches"]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = traffic_of(name, alg_bytes, workload)   # PMC-derived HBM bytes per launch, measured in separate profiled runs of the same workload
+    smp = sorted(st.get("samples") or [])
+    spread = {"min": round(smp[0], 4), "median": round(smp[len(smp) // 2], 4), "max": round(smp[-1], 4), "n": len(smp)} if smp else None
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launch_ms_spread": spread,
             "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, not this one)" if traffic else None,
             "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes), "launches": st["launches"],
@@ -1388,7 +1393,7 @@ def _sig(x, digits=4):
 def _terse_roofline(r):
     if not r:
         return None
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch", "launches")
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launch_ms_spread", "algorithmic_bytes_per_launch", "launches")
     return {k: r[k] for k in keep if k in r}
 
 

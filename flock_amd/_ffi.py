@@ -162,6 +162,7 @@ SYMBOLS = {
     "flockgpu_profile_only": (_i, [_vp, C.c_char_p]),
     "flockgpu_profile_reset": (_i, [_vp]),
     "flockgpu_profile_read": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
+    "flockgpu_profile_samples": (_i, [_vp, C.c_char_p, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "flockgpu_q1_project": (_i, [_vp, C.POINTER(BidCols), C.c_double, _vp]),
     "flockgpu_q2_filter": (_i, [_vp, C.POINTER(BidCols), C.POINTER(Windows), _i64, C.POINTER(Q2Result)]),
     "flockgpu_q3_join": (_i, [_vp, C.POINTER(AuctionCols), C.POINTER(Windows), C.POINTER(PersonCols),

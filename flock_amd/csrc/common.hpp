@@ -63,6 +63,7 @@ struct flockgpu_ctx {
     std::vector<flockgpu::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, flockgpu::KernelStat> stats;
+    std::map<std::string, std::vector<float>> launch_ms;   // per-launch durations (flockgpu_profile_samples), at most 4096 per kernel
     flockgpu::AsyncWorker *worker = nullptr;  // created by the first asynchronous call
     const void *plan_in_flight = nullptr;     // the plan whose flockgpu_plan_execute_async is pending: only flockgpu_plan_wait may collect that call
     // flockgpu_malloc_guarded: pointer handed out -> {reserved base, reserved bytes, mapped bytes, allocation handle}
@@ -236,6 +237,8 @@ inline void profile_drain(flockgpu_ctx *ctx) {
             KernelStat &s = ctx->stats[p.name];
             s.launches += 1;
             s.total_ms += ms;
+            auto &v = ctx->launch_ms[p.name];
+            if (v.size() < 4096) v.push_back(ms);
         }
         ctx->event_pool.push_back(p.start);
         ctx->event_pool.push_back(p.stop);

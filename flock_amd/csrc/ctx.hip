@@ -289,6 +289,7 @@ int flockgpu_profile_reset(flockgpu_ctx *ctx) {
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     profile_drain(ctx);
     ctx->stats.clear();
+    ctx->launch_ms.clear();
     return FLOCKGPU_OK;
 }
 
@@ -307,6 +308,17 @@ int flockgpu_profile_read(flockgpu_ctx *ctx, flockgpu_kernel_stat *out, int cap,
         ++i;
     }
     *n = i;
+    return FLOCKGPU_OK;
+}
+
+int flockgpu_profile_samples(flockgpu_ctx *ctx, const char *kernel_name, float *out_ms, int cap, int *n) {
+    if (!ctx || !n || !kernel_name || cap < 0) return FLOCKGPU_ERR_INVALID;
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    profile_drain(ctx);
+    auto it = ctx->launch_ms.find(kernel_name);
+    const int have = it == ctx->launch_ms.end() ? 0 : (int)it->second.size();
+    for (int i = 0; out_ms && i < have && i < cap; ++i) out_ms[i] = it->second[i];
+    *n = have;
     return FLOCKGPU_OK;
 }
 

@@ -530,6 +530,13 @@ class GpuContext:
         return {buf[i].name.decode(): {"launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
                 for i in range(min(n.value, 64))}
 
+    def profile_samples(self, kernel_name: str) -> list:
+        """Per-launch durations (ms, launch order) of one kernel since the last reset."""
+        n = C.c_int(0)
+        buf = (C.c_float * 4096)()
+        self._check(self._lib.flockgpu_profile_samples(self._h, kernel_name.encode(), buf, 4096, C.byref(n)))
+        return [float(buf[i]) for i in range(min(n.value, 4096))]
+
     # -- operators
     def q1_project(self, bids: Bids, factor: float = 0.908):
         """q1 ProjectionExec (planner.rs:90): returns the Float64 `price` column (device tensor);

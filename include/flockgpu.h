@@ -85,6 +85,11 @@ typedef struct {
     double total_ms;
 } flockgpu_kernel_stat;
 int flockgpu_profile_read(flockgpu_ctx *ctx, flockgpu_kernel_stat *out, int cap, int *n);
+/* The per-launch durations behind one kernel's total, in launch order (the first 4096 since the last reset): *n = how many
+   exist, out_ms receives min(*n, cap) of them.  A HIP-event pair also spans the host's gap between recording the start event and
+   enqueueing the kernel when the stream is idle, so for 10-microsecond kernels one preempted launch can double a 20-launch mean;
+   the spread (bench.py reports min / median / max beside the mean) shows it. */
+int flockgpu_profile_samples(flockgpu_ctx *ctx, const char *kernel_name, float *out_ms, int cap, int *n);
 
 /* ---- column views (device pointers, Arrow buffer layout) -------------------------------------- */
 typedef struct { /* Bid::schema, event.rs:336-352 */
