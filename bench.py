@@ -509,12 +509,12 @@ def q11_side(ctx, eps, steps, no_cpu, seconds=109):
     out = {"value": round(n * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3), "input_rows": int(n),
            "epochs": seconds, "result_rows": int(res.rows), "sessions_total": int(res.sessions_total)}
     if st and st["launches"]:
-        # a radix pass reads key + row number and writes both (16 B / row; the first pass of the bid sort makes the row
-        # numbers itself: 12 B); launches = passes of the bid sort + passes of the (much smaller) session sort
+        # a radix pass reads key + payload and writes both (16 B / row; since round 5 the payload is the packed (epoch, time) word of
+        # q11_pack_kernel, read by the first pass too); launches = passes of the bid sort + passes of the (much smaller) session sort
         avg_ms = st["total_ms"] / st["launches"]
         per_step = st["launches"] // max(steps, 1)
         passes = max(per_step - 1, 1)                     # the session sort is one pass for < 256 epochs
-        alg = (16.0 * passes - 4.0) * n + 16.0 * res.sessions_total
+        alg = 16.0 * passes * n + 16.0 * res.sessions_total
         alg_per_launch = alg / per_step
         out["roofline"] = {"bound": "hbm", "kernel": "sort_emit_kernel", "achieved": round(alg_per_launch / (avg_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

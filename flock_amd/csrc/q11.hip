@@ -13,7 +13,9 @@
 // Every decision above only looks at two NEIGHBOURING partitions of one bidder, so the walk unrolls into data-parallel
 // passes over the bids grouped by bidder (HBM-bound integer work, no MFMA):
 //   group  : stable radix sort of (bidder, row) (sort.hip)
-//   gather : b_date_time and epoch of every sorted row
+//   pack   : (epoch, b_date_time - reference) of every row in 32 bits, carried through the sort as its payload, so that the sorted
+//            rows need no 8-byte gather at random afterwards (round 5; 32-byte sectors for 8-byte values: 3.2 GB for 0.8 GB);
+//            a stream whose times or epoch count do not fit takes  gather : b_date_time and epoch of every sorted row
 //   cut    : boundary j between sorted rows j-1 and j is a cut when the bidder changes, or the epoch changes and
 //            (a) the session timed out before the next partition's epoch: max(ep_a, sec_a - base_s + timeout + 1) < ep_b
 //            or (b) sec_b - sec_a > timeout.                 count -> scan -> emit over 2048-boundary tiles
@@ -37,6 +39,7 @@ struct SessionParams {
     int64_t base_s;     // BASE_TIME / 1000
     int32_t timeout_s;
     int32_t n_epochs;
+    int32_t t_bits;     // packed payload: low t_bits = b_date_time - *t_ref, the bits above = epoch (0: rows carry ts_s / ep_s instead)
 };
 
 __device__ __forceinline__ int64_t close_clock(int32_t ep_a, int64_t ts_a, const SessionParams &p) {
@@ -68,6 +71,109 @@ __global__ __launch_bounds__(kBlock) void q11_gather_kernel(const int64_t *__res
     ep_s[i] = lo;
 }
 
+// Packed payload of row i:  epoch << t_bits | (b_date_time[i] - t_ref),  t_ref = b_date_time[0] - 2^(t_bits-1)  (the stream's first
+// time in the middle of the representable span; all arithmetic modulo 2^64, so a value that fits is restored exactly).  A row that does
+// not fit raises `unfit` and the host falls back to the gather.  Rows arrive in epoch order, so a thread finds its first row's epoch by
+// bisection and walks on from there.  The pass reads the bidder column as well and leaves its minimum / maximum (the sort's digit range):
+// one launch instead of key_min_max's.
+constexpr int kPackItems = 8;
+constexpr int kPackTile = kBlock * kPackItems;   // 2048 rows per workgroup
+constexpr int kPackSlots = 64, kPackSlotStride = 32, kPackSlot0 = 32;   // bidder minimum / maximum: slot s at minmax[kPackSlot0 + s * kPackSlotStride]
+constexpr int kPackWords = kPackSlot0 + kPackSlots * kPackSlotStride;
+__global__ __launch_bounds__(kBlock) void q11_pack_kernel(const int32_t *__restrict__ keys, const int64_t *__restrict__ dt, int64_t n,
+                                                          const int64_t *__restrict__ epoch_off, int32_t n_epochs, int32_t t_bits,
+                                                          uint32_t *__restrict__ pay, int32_t *minmax, uint64_t *t_ref_out,
+                                                          uint32_t *unfit, int mode) {
+    __shared__ int32_t s_red[2 * kWavesPerBlock];
+    const uint64_t half = uint64_t(1) << (t_bits - 1), t_ref = (uint64_t)dt[0] - half, lim = uint64_t(1) << t_bits;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t_ref_out = t_ref;
+    // the workgroup's first row decides where its rows start looking (uniform: scalar loads); nearly every workgroup lies inside one
+    // epoch and inside the relation: that case is sixteen-byte loads and stores with nothing to decide per row
+    const int64_t rb = (int64_t)blockIdx.x * kPackTile;
+    int32_t e0 = 0, hi = n_epochs;        // epoch_off[e0] <= rb < epoch_off[hi]
+    while (hi - e0 > 1 && !(mode & 2)) {
+        const int32_t mid = (e0 + hi) >> 1;
+        if (epoch_off[mid] <= rb) e0 = mid;
+        else hi = mid;
+    }
+    const int64_t next0 = (mode & 2) ? INT64_MAX : e0 + 1 < n_epochs ? epoch_off[e0 + 1] : INT64_MAX;
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+    bool bad = false;
+    if (rb + kPackTile <= n && next0 >= rb + kPackTile && !(reinterpret_cast<uintptr_t>(dt) & 15)) {   // (block-uniform)
+        const uint32_t e_word = (uint32_t)e0 << t_bits;
+        int4 kk[2];
+        int4 tt[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int64_t r = rb + it * (kBlock * 4) + threadIdx.x * 4;
+            kk[it] = *reinterpret_cast<const int4 *>(keys + r);       // (the sort reads the keys next: left in the caches)
+            const int32_t *tp = reinterpret_cast<const int32_t *>(dt + r);
+            tt[it][0] = stream_load4(tp);
+            tt[it][1] = stream_load4(tp + 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int64_t r = rb + it * (kBlock * 4) + threadIdx.x * 4;
+            const uint64_t d0 = (((uint64_t)(uint32_t)tt[it][0].y << 32) | (uint32_t)tt[it][0].x) - t_ref;
+            const uint64_t d1 = (((uint64_t)(uint32_t)tt[it][0].w << 32) | (uint32_t)tt[it][0].z) - t_ref;
+            const uint64_t d2 = (((uint64_t)(uint32_t)tt[it][1].y << 32) | (uint32_t)tt[it][1].x) - t_ref;
+            const uint64_t d3 = (((uint64_t)(uint32_t)tt[it][1].w << 32) | (uint32_t)tt[it][1].z) - t_ref;
+            bad |= (d0 | d1 | d2 | d3) >= lim;
+            if (!(mode & 4)) *reinterpret_cast<uint4 *>(pay + r) = make_uint4(e_word | (uint32_t)d0, e_word | (uint32_t)d1, e_word | (uint32_t)d2, e_word | (uint32_t)d3);
+            mn = min(mn, min(min(kk[it].x, kk[it].y), min(kk[it].z, kk[it].w)));
+            mx = max(mx, max(max(kk[it].x, kk[it].y), max(kk[it].z, kk[it].w)));
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < kPackItems; ++i) {
+            const int64_t r = rb + (int64_t)i * kBlock + threadIdx.x;
+            if (r >= n) break;
+            int32_t e = e0;
+            if (r >= next0) {
+                ++e;
+                while (e + 1 < n_epochs && epoch_off[e + 1] <= r) ++e;
+            }
+            const uint64_t d = (uint64_t)dt[r] - t_ref;
+            const int32_t k = keys[r];
+            bad |= d >= lim;
+            pay[r] = ((uint32_t)e << t_bits) | (uint32_t)d;
+            mn = min(mn, k);
+            mx = max(mx, k);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (__ballot(bad) && lane_id() == 0) *unfit = 1u;
+    if (lane_id() == 0) {
+        s_red[threadIdx.x >> 6] = mn;
+        s_red[kWavesPerBlock + (threadIdx.x >> 6)] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            mn = min(mn, s_red[w]);
+            mx = max(mx, s_red[kWavesPerBlock + w]);
+        }
+        // (1e5 workgroups on ONE pair of words took 1.28 ms of a 1.53 ms kernel -- accesses to one address are served one after the other,
+        // ~13 ns each, whether atomic or a load that looks before it leaps: 64 pairs, a cache line apart, the host folds them)
+        if (mn <= mx && !(mode & 1)) {
+            int32_t *slot = minmax + kPackSlot0 + (blockIdx.x % kPackSlots) * kPackSlotStride;
+            atomicMin(&slot[0], mn);
+            atomicMax(&slot[1], mx);
+        }
+    }
+}
+
+__global__ void q11_pack_init_kernel(int32_t *minmax, uint32_t *unfit) {
+    int32_t *slot = minmax + kPackSlot0 + threadIdx.x * kPackSlotStride;   // (kPackSlots threads)
+    slot[0] = 0x7fffffff;
+    slot[1] = (int32_t)0x80000000;
+    if (threadIdx.x == 0) *unfit = 0u;
+}
+
 struct CutRows {  // the nine sorted rows around a thread's eight boundaries
     int32_t key[kCutItems + 1], ep[kCutItems + 1];
     int64_t ts[kCutItems + 1];
@@ -75,8 +181,50 @@ struct CutRows {  // the nine sorted rows around a thread's eight boundaries
 
 // boundaries j0 .. j0+7 need rows j0-1 .. j0+7, clamped into [0, n): the lane's own eight rows through 16-byte loads
 // (j0 is a multiple of 8), row j0-1 from the lane below (lane 0 reads it)
+// (kPacked: `ep_s` is the sorted payload column of q11_pack_kernel, `ts_s` the one-word t_ref: 8 bytes per row instead of 16)
+template <bool kPacked>
 __device__ __forceinline__ void load_cut_rows(const int32_t *__restrict__ keys, const int64_t *__restrict__ ts_s,
-                                              const int32_t *__restrict__ ep_s, int64_t n, int64_t j0, CutRows &c) {
+                                              const int32_t *__restrict__ ep_s, int64_t n, int64_t j0, const SessionParams &p, CutRows &c) {
+    if (kPacked) {
+        const uint32_t *__restrict__ pay = reinterpret_cast<const uint32_t *>(ep_s);
+        const uint64_t t_ref = *reinterpret_cast<const uint64_t *>(ts_s);
+        const uint32_t t_mask = (1u << p.t_bits) - 1u;
+        int32_t k_prev = 0;
+        uint32_t p_prev = 0;
+        if (lane_id() == 0) {
+            const int64_t r = j0 > 0 ? (j0 - 1 < n ? j0 - 1 : n - 1) : 0;
+            k_prev = keys[r];
+            p_prev = pay[r];
+        }
+        uint32_t w[kCutItems + 1];
+        if (j0 + kCutItems <= n) {
+            const int4 k0 = *reinterpret_cast<const int4 *>(keys + j0), k1 = *reinterpret_cast<const int4 *>(keys + j0 + 4);
+            const uint4 p0 = *reinterpret_cast<const uint4 *>(pay + j0), p1 = *reinterpret_cast<const uint4 *>(pay + j0 + 4);
+            c.key[1] = k0.x; c.key[2] = k0.y; c.key[3] = k0.z; c.key[4] = k0.w;
+            c.key[5] = k1.x; c.key[6] = k1.y; c.key[7] = k1.z; c.key[8] = k1.w;
+            w[1] = p0.x; w[2] = p0.y; w[3] = p0.z; w[4] = p0.w;
+            w[5] = p1.x; w[6] = p1.y; w[7] = p1.z; w[8] = p1.w;
+        } else {
+#pragma unroll
+            for (int i = 1; i <= kCutItems; ++i) {
+                int64_t r = j0 - 1 + i;
+                r = r >= n ? n - 1 : r;
+                c.key[i] = keys[r];
+                w[i] = pay[r];
+            }
+        }
+        const int32_t pk = __shfl_up(c.key[kCutItems], 1, 64);
+        const uint32_t pw = __shfl_up(w[kCutItems], 1, 64);
+        const bool first = lane_id() == 0;
+        c.key[0] = first ? k_prev : pk;
+        w[0] = first ? p_prev : pw;
+#pragma unroll
+        for (int i = 0; i <= kCutItems; ++i) {
+            c.ep[i] = (int32_t)(w[i] >> p.t_bits);
+            c.ts[i] = (int64_t)(t_ref + (uint64_t)(w[i] & t_mask));
+        }
+        return;
+    }
     // lane 0's row j0 - 1 is asked for FIRST, so that it is in flight together with the rows below instead of after the shuffles
     // (a second memory round trip per workgroup of a kernel that makes one pass over 2048 boundaries and leaves)
     int32_t k_prev = 0, e_prev = 0;
@@ -132,17 +280,19 @@ __device__ __forceinline__ uint32_t cut_mask(const CutRows &c, int64_t n, int64_
     return m;
 }
 
+template <bool kPacked>
 __global__ __launch_bounds__(kBlock) void q11_cut_count_kernel(const int32_t *__restrict__ keys, const int64_t *__restrict__ ts_s,
                                                                const int32_t *__restrict__ ep_s, int64_t n, SessionParams p,
                                                                uint32_t *__restrict__ counts) {
     const int64_t j0 = (int64_t)blockIdx.x * kCutTile + (int64_t)threadIdx.x * kCutItems;
     CutRows c;
-    load_cut_rows(keys, ts_s, ep_s, n, j0, c);
+    load_cut_rows<kPacked>(keys, ts_s, ep_s, n, j0, p, c);
     const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(cut_mask(c, n, j0, p)));
     if (lane_id() == 63) counts[(size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = incl;
 }
 
 // Session s = sorted rows [cut_pos[s], cut_pos[s+1]).  close[s]: epoch in which it is closed, -1 = never.
+template <bool kPacked>
 __global__ __launch_bounds__(kBlock) void q11_cut_emit_kernel(const int32_t *__restrict__ keys, const int64_t *__restrict__ ts_s,
                                                               const int32_t *__restrict__ ep_s, int64_t n, SessionParams p,
                                                               const uint32_t *__restrict__ counts,
@@ -151,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void q11_cut_emit_kernel(const int32_t *__r
                                                               unsigned long long *s_min, unsigned long long *s_max) {
     const int64_t j0 = (int64_t)blockIdx.x * kCutTile + (int64_t)threadIdx.x * kCutItems;
     CutRows c;
-    load_cut_rows(keys, ts_s, ep_s, n, j0, c);
+    load_cut_rows<kPacked>(keys, ts_s, ep_s, n, j0, p, c);
     const uint32_t m = cut_mask(c, n, j0, p);
     const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
     const int wave = threadIdx.x >> 6;
@@ -300,23 +450,54 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
     if (n == 0 || n_epochs == 0) return FLOCKGPU_OK;
     const int32_t *keys = bid->bidder + r0;
     const int64_t *dt = bid->b_date_time + r0;
-    const SessionParams p{base_time_ms / 1000, timeout_s, n_epochs};
+    SessionParams p{base_time_ms / 1000, timeout_s, n_epochs, 0};
 
     // epoch offsets relative to the run, on the device
     int64_t *d_eoff = nullptr, *h_eoff = nullptr;
     FG_TRY(arena_get_t(ctx, "q11.epoch_off", (size_t)n_epochs + 1, &d_eoff));
     FG_TRY(pinned_get_t(ctx, "q11.epoch_off", (size_t)n_epochs + 1, &h_eoff));
     int32_t *d_mm = nullptr, *h_mm = nullptr;
-    FG_TRY(arena_get_t(ctx, "q11.minmax", 4, &d_mm));
-    FG_TRY(pinned_get_t(ctx, "q11.minmax", 4, &h_mm));
+    FG_TRY(arena_get_t(ctx, "q11.minmax", (size_t)kPackWords, &d_mm));     // [0..1] bidder min / max, [2] "a row does not fit the payload", [4..5] t_ref, slots
+    FG_TRY(pinned_get_t(ctx, "q11.minmax", (size_t)kPackWords, &h_mm));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned staging may be in flight from the previous call
     for (int32_t t = 0; t <= n_epochs; ++t) h_eoff[t] = epoch_row_offsets[t] - r0;
     FG_HIP(ctx, hipMemcpyAsync(d_eoff, h_eoff, sizeof(int64_t) * ((size_t)n_epochs + 1), hipMemcpyHostToDevice, ctx->stream));
 
-    // ---- group the bids by bidder
-    FG_TRY(key_min_max(ctx, keys, n, d_mm));
-    FG_HIP(ctx, hipMemcpyAsync(h_mm, d_mm, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    // ---- the payload the sort carries: (epoch, time) in 32 bits when the run allows it, else the row number (gathered afterwards)
+    int e_bits = 1;
+    while (e_bits < 31 && ((uint32_t)(n_epochs - 1) >> e_bits)) ++e_bits;
+    int t_bits = 32 - e_bits;
+    if (t_bits < 12 || exp_env("FLOCKGPU_Q11_GATHER") != nullptr) t_bits = 0;   // (A/B knob of the experimental build)
+    uint32_t *pay = nullptr;
+    uint32_t *d_unfit = reinterpret_cast<uint32_t *>(d_mm + 2);
+    uint64_t *d_tref = reinterpret_cast<uint64_t *>(d_mm + 4);
+    if (t_bits) {
+        FG_TRY(arena_get_t(ctx, "q11.payload", (size_t)n + 4, &pay));
+        hipLaunchKernelGGL(q11_pack_init_kernel, dim3(1), dim3(kPackSlots), 0, ctx->stream, d_mm, d_unfit);
+        FG_TRY(check_launch(ctx, "q11_pack_init_kernel"));
+        {
+            LaunchScope ls(ctx, "q11_pack_kernel");
+            hipLaunchKernelGGL(q11_pack_kernel, dim3((unsigned)div_up(n, (int64_t)kPackTile)), dim3(kBlock), 0, ctx->stream, keys, dt, n,
+                               d_eoff, n_epochs, t_bits, pay, d_mm, d_tref, d_unfit, exp_env("FLOCKGPU_Q11_PACK_MODE") ? atoi(exp_env("FLOCKGPU_Q11_PACK_MODE")) : 0);
+        }
+        FG_TRY(check_launch(ctx, "q11_pack_kernel"));
+    } else {
+        FG_TRY(key_min_max(ctx, keys, n, d_mm));
+    }
+    FG_HIP(ctx, hipMemcpyAsync(h_mm, d_mm, (t_bits ? (size_t)kPackWords : 3) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (t_bits) {
+        h_mm[0] = 0x7fffffff;
+        h_mm[1] = (int32_t)0x80000000;
+        for (int sl = 0; sl < kPackSlots; ++sl) {
+            h_mm[0] = std::min(h_mm[0], h_mm[kPackSlot0 + sl * kPackSlotStride]);
+            h_mm[1] = std::max(h_mm[1], h_mm[kPackSlot0 + sl * kPackSlotStride + 1]);
+        }
+        if (h_mm[2]) t_bits = 0;   // a time outside the payload's span: this run takes the gather
+    }
+    p.t_bits = t_bits;
+
+    // ---- group the bids by bidder
     int bits = 1;
     {
         const uint64_t span = (uint64_t)((int64_t)h_mm[1] - (int64_t)h_mm[0]);
@@ -324,18 +505,27 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
     }
     int32_t *sk = nullptr;
     uint32_t *sv = nullptr;
-    FG_TRY(radix_sort_pairs(ctx, "q11.rows", keys, nullptr, n, h_mm[0], bits, &sk, &sv));
+    FG_TRY(radix_sort_pairs(ctx, "q11.rows", keys, t_bits ? pay : nullptr, n, h_mm[0], bits, &sk, &sv));
 
-    int64_t *ts_s = nullptr;
-    int32_t *ep_s = nullptr;
-    FG_TRY(arena_get_t(ctx, "q11.ts_sorted", (size_t)n, &ts_s));
-    FG_TRY(arena_get_t(ctx, "q11.ep_sorted", (size_t)n, &ep_s));
-    {
-        LaunchScope ls(ctx, "q11_gather_kernel");
-        hipLaunchKernelGGL(q11_gather_kernel, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, dt,
-                           reinterpret_cast<const int32_t *>(sv), n, d_eoff, n_epochs, ts_s, ep_s);
+    const int64_t *ts_s = nullptr;
+    const int32_t *ep_s = nullptr;
+    if (t_bits) {
+        ts_s = reinterpret_cast<const int64_t *>(d_tref);
+        ep_s = reinterpret_cast<const int32_t *>(sv);
+    } else {
+        int64_t *ts_g = nullptr;
+        int32_t *ep_g = nullptr;
+        FG_TRY(arena_get_t(ctx, "q11.ts_sorted", (size_t)n, &ts_g));
+        FG_TRY(arena_get_t(ctx, "q11.ep_sorted", (size_t)n, &ep_g));
+        {
+            LaunchScope ls(ctx, "q11_gather_kernel");
+            hipLaunchKernelGGL(q11_gather_kernel, dim3((unsigned)div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, dt,
+                               reinterpret_cast<const int32_t *>(sv), n, d_eoff, n_epochs, ts_g, ep_g);
+        }
+        FG_TRY(check_launch(ctx, "q11_gather_kernel"));
+        ts_s = ts_g;
+        ep_s = ep_g;
     }
-    FG_TRY(check_launch(ctx, "q11_gather_kernel"));
 
     // ---- cuts: count -> scan -> emit over the n + 1 boundaries
     const int64_t tiles = div_up(n + 1, kCutTile);
@@ -346,7 +536,8 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
     FG_TRY(pinned_get_t(ctx, "q11.cut_total", 1, &h_total));
     {
         LaunchScope ls(ctx, "q11_cut_count_kernel");
-        hipLaunchKernelGGL(q11_cut_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, sk, ts_s, ep_s, n, p, counts);
+        hipLaunchKernelGGL(t_bits ? q11_cut_count_kernel<true> : q11_cut_count_kernel<false>, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, sk,
+                           ts_s, ep_s, n, p, counts);
     }
     FG_TRY(check_launch(ctx, "q11_cut_count_kernel"));
     FG_TRY(launch_tile_scan(ctx, counts, (int32_t)tiles, tile_base, nullptr, 0, nullptr));
@@ -373,7 +564,8 @@ int flockgpu_q11_user_sessions(flockgpu_ctx *ctx, const flockgpu_bid_cols *bid, 
     FG_HIP(ctx, hipMemsetAsync(s_max, 0, sizeof(unsigned long long) * (ns + 1), ctx->stream));
     {
         LaunchScope ls(ctx, "q11_cut_emit_kernel");
-        hipLaunchKernelGGL(q11_cut_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, sk, ts_s, ep_s, n, p, counts,
+        hipLaunchKernelGGL(t_bits ? q11_cut_emit_kernel<true> : q11_cut_emit_kernel<false>, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, sk,
+                           ts_s, ep_s, n, p, counts,
                            tile_base, cut_pos, s_bidder, s_close, s_min, s_max);
     }
     FG_TRY(check_launch(ctx, "q11_cut_emit_kernel"));

@@ -117,3 +117,57 @@ def test_q11_generated_stream(ctx):
     assert np.array_equal(got["bidder"], w_b) and np.array_equal(got["bid_count"], w_c)
     assert np.array_equal(got["start_time"], w_mn) and np.array_equal(got["end_time"], w_mx)
     assert int(got["bid_count"].sum()) <= len(bidder)
+
+
+def _columnar_equal(res, want):
+    got = res.to_host()
+    w_off, w_b, w_c, w_mn, w_mx = want
+    assert np.array_equal(got["offsets"], w_off)
+    assert np.array_equal(got["bidder"], w_b) and np.array_equal(got["bid_count"], w_c)
+    assert np.array_equal(got["start_time"], w_mn) and np.array_equal(got["end_time"], w_mx)
+
+
+@pytest.mark.parametrize("seed,shape", [(0, "far"), (1, "far_first"), (2, "extremes"), (3, "edge_of_span"), (4, "many_epochs")])
+def test_q11_times_and_epochs_outside_the_sorted_payload(ctx, seed, shape):
+    """Round 5: the sort carries (epoch, b_date_time - reference) as its 32-bit payload (q11.hip, q11_pack_kernel).  Runs whose times do
+    not fit that span around the first row's time -- one row is enough --, or whose epoch count leaves the time too few bits, take the
+    row-number payload and the gather instead; a time exactly on either end of the span still packs.  Same rows either way."""
+    rng = np.random.default_rng(seed)
+    n_epochs, per = 24, 700
+    counts = rng.integers(1, per + 1, n_epochs)
+    off = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    n = int(off[-1])
+    ep = np.repeat(np.arange(n_epochs), counts)
+    ts = BASE + ep * 1000 + np.concatenate([np.sort(rng.integers(0, 1000, c)) for c in counts]).astype(np.int64)
+    bidder = rng.integers(50, 400, n).astype(np.int32)
+    if shape == "far":                    # a few late rows, ~2 years ahead: they are sessions of their own (never closed inside the run)
+        ts[rng.integers(1, n, 5)] += 1 << 36
+    elif shape == "far_first":            # the reference row itself is the odd one
+        ts[0] += 1 << 40
+    elif shape == "extremes":             # the ends of the int64 range next to ordinary times
+        ts[n // 2] = np.iinfo(np.int64).max
+        ts[n // 3] = 0
+    elif shape == "edge_of_span":         # 24 epochs -> 5 epoch bits, 27 time bits: first time - 2^26 and first time + 2^26 - 1 both fit
+        ts[n // 2] = ts[0] - (1 << 26)
+        ts[n // 3] = ts[0] + (1 << 26) - 1
+    elif shape == "many_epochs":          # 2^21 + 3 epochs, nearly all empty: 22 epoch bits leave 10 for the time
+        big = (1 << 21) + 3
+        where = np.sort(rng.choice(big, n_epochs, replace=False))
+        c2 = np.zeros(big, np.int64)
+        c2[where] = counts
+        off = np.r_[0, np.cumsum(c2)].astype(np.int64)
+        ts = BASE + np.repeat(where, counts) * 1000 + (ts - BASE) % 1000
+    timeout = 3
+    want = oracle.q11_user_sessions_columnar(bidder, ts, off, timeout, BASE)
+    ctx.profile_reset()
+    ctx.profile(True)
+    try:
+        _columnar_equal(ctx.q11_user_sessions(_bids(ctx, bidder, ts), off, timeout, BASE), want)
+        ran = ctx.profile_read()
+    finally:
+        ctx.profile(False)
+    gathered = "q11_gather_kernel" in ran
+    assert gathered == (shape != "edge_of_span") and ("q11_pack_kernel" in ran) == (shape != "many_epochs"), sorted(ran)
+    if shape in ("far", "extremes"):      # the columnar restatement against the literal walk on exactly these rows
+        walk = oracle.q11_user_sessions(bidder, ts, off, timeout, BASE)
+        assert [sorted(d) for d in walk] == [want[1][want[0][t]:want[0][t + 1]].tolist() for t in range(n_epochs)]
