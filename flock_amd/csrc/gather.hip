@@ -355,8 +355,14 @@ __global__ __launch_bounds__(kBlock) void utf8_len_multi_kernel(Utf8Cols cols, c
     }
 }
 // col_base[c] = tile_base[c * tiles_stride], c = 0 .. k: where column c's bytes start in the scan over all columns
-__global__ void utf8_col_bases_kernel(const uint64_t *__restrict__ tile_base, int64_t tiles_stride, int32_t k, uint64_t *__restrict__ col_base) {
-    if ((int)threadIdx.x <= k) col_base[threadIdx.x] = tile_base[(int64_t)threadIdx.x * tiles_stride];
+// (h_col_base: the host's pinned copy, written by the same threads instead of a copy call behind the kernel)
+__global__ void utf8_col_bases_kernel(const uint64_t *__restrict__ tile_base, int64_t tiles_stride, int32_t k, uint64_t *__restrict__ col_base,
+                                      uint64_t *__restrict__ h_col_base) {
+    if ((int)threadIdx.x <= k) {
+        const uint64_t b = tile_base[(int64_t)threadIdx.x * tiles_stride];
+        col_base[threadIdx.x] = b;
+        h_col_base[threadIdx.x] = b;
+    }
 }
 
 // Writes out_off and the bytes.  The tile's bytes form ONE contiguous range of the output, so they are assembled
@@ -596,6 +602,29 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(int32_t *data, int64
     }
 }
 
+
+// ---- fill_words / publish_words (gather.hpp)
+__global__ __launch_bounds__(kBlock) void fill_words_kernel(FillList f) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
+    for (int r = 0; r < f.n; ++r) {
+        uint32_t *p = static_cast<uint32_t *>(f.p[r]);
+        const uint32_t v = f.v[r];
+        const uint64_t n = f.words[r];
+        // the 16-byte aligned middle with 16-byte stores, the ragged ends word by word
+        const uint64_t head = std::min<uint64_t>(n, (4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3);
+        const uint64_t n4 = (n - head) >> 2;
+        if (t0 < head) p[t0] = v;
+        uint4 *q = reinterpret_cast<uint4 *>(p + head);
+        for (uint64_t i = t0; i < n4; i += stride) q[i] = make_uint4(v, v, v, v);
+        const uint64_t tail0 = head + 4 * n4;
+        if (t0 < n - tail0) p[tail0 + t0] = v;
+    }
+}
+__global__ void publish_words_kernel(PublishList l) {
+    for (int r = 0; r < l.n; ++r)
+        if ((int)threadIdx.x < l.words[r]) static_cast<uint32_t *>(l.h[r])[threadIdx.x] = static_cast<const uint32_t *>(l.d[r])[threadIdx.x];
+}
+
 }  // namespace
 
 namespace flockgpu {
@@ -731,8 +760,7 @@ int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &
     }
     FG_TRY(check_launch(ctx, "utf8_len_kernel"));
     FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)g->tiles, g->tile_base, nullptr, 0, nullptr));
-    FG_HIP(ctx, hipMemcpyAsync(g->h_total, g->tile_base + g->tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    return FLOCKGPU_OK;
+    return publish_words(ctx, PublishList().add(g->h_total, g->tile_base + g->tiles, 2));   // (one small kernel instead of a copy call)
 }
 
 void gather_utf8_narrow(Utf8Gather *g, int64_t n) {
@@ -805,10 +833,8 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
     }
     FG_TRY(check_launch(ctx, "utf8_len_multi_kernel"));
     FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)all, g->tile_base, nullptr, 0, nullptr));
-    hipLaunchKernelGGL(utf8_col_bases_kernel, dim3(1), dim3(64), 0, ctx->stream, g->tile_base, g->tiles_stride, k, d_col_base);
-    FG_TRY(check_launch(ctx, "utf8_col_bases_kernel"));
-    FG_HIP(ctx, hipMemcpyAsync(g->h_col_base, d_col_base, sizeof(uint64_t) * ((size_t)k + 1), hipMemcpyDeviceToHost, ctx->stream));
-    return FLOCKGPU_OK;
+    hipLaunchKernelGGL(utf8_col_bases_kernel, dim3(1), dim3(64), 0, ctx->stream, g->tile_base, g->tiles_stride, k, d_col_base, g->h_col_base);
+    return check_launch(ctx, "utf8_col_bases_kernel");
 }
 
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n) {
@@ -897,6 +923,29 @@ int gather_utf8(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, c
     FG_TRY(gather_utf8_begin(ctx, name, src, rows, n, &g));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return gather_utf8_finish(ctx, g, out, n_bytes);
+}
+
+int fill_words(flockgpu_ctx *ctx, const FillList &f) {
+    uint64_t most = 0;
+    for (int r = 0; r < f.n; ++r) most = std::max(most, f.words[r]);
+    if (!most) return FLOCKGPU_OK;
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(div_up((int64_t)most, (int64_t)kBlock * 4), 1), (uint64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "fill_words_kernel");
+        hipLaunchKernelGGL(fill_words_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+    }
+    return check_launch(ctx, "fill_words_kernel");
+}
+
+int publish_words(flockgpu_ctx *ctx, const PublishList &l) {
+    if (!l.n) return FLOCKGPU_OK;
+    for (int r = 0; r < l.n; ++r)
+        if (l.words[r] > 64) return fail(ctx, FLOCKGPU_ERR_INVALID, "publish_words: at most 64 words per run");
+    {
+        LaunchScope ls(ctx, "publish_words_kernel");
+        hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, ctx->stream, l);
+    }
+    return check_launch(ctx, "publish_words_kernel");
 }
 
 }  // namespace flockgpu

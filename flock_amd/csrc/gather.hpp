@@ -91,6 +91,35 @@ struct Utf8FastGather {
 int gather_utf8_multi_fast(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n_bound,
                            const uint64_t *d_n, const int64_t *cap_bytes, Utf8FastGather *g);
 
+// ---- small-scalar plumbing of the operators that end in a host wait (round 5).  One execute of a generic plan made 7 hipMemsetAsync
+// and 11 small device-to-host hipMemcpyAsync calls (rocprofv3 --hip-trace: ~10 us of host time each, a 5.5 us copy kernel per
+// memcpy on the stream) around 23 kernels; these two replace them:
+// fill_words: up to four regions of 32-bit words, each with its own value, in ONE launch (error flags, totals, counters, chain heads);
+// publish_words: up to four runs of <= 64 words copied into pinned host memory by one 64-thread kernel (read them after the
+// stream synchronises).  (A tile scan's segment offsets need neither: launch_tile_scan takes a pinned pointer for them.)
+struct FillList {
+    void *p[4]{};
+    uint32_t v[4]{};
+    uint64_t words[4]{};
+    int n = 0;
+    FillList &add(void *ptr, uint32_t value, uint64_t n_words) {
+        if (n < 4 && n_words) { p[n] = ptr; v[n] = value; words[n] = n_words; ++n; }
+        return *this;
+    }
+};
+int fill_words(flockgpu_ctx *ctx, const FillList &f);
+struct PublishList {
+    void *h[4]{};
+    const void *d[4]{};
+    int words[4]{};
+    int n = 0;
+    PublishList &add(void *h_pinned, const void *dev, int n_words) {
+        if (n < 4 && n_words > 0) { h[n] = h_pinned; d[n] = dev; words[n] = n_words; ++n; }
+        return *this;
+    }
+};
+int publish_words(flockgpu_ctx *ctx, const PublishList &l);
+
 // Utf8 gather whose total byte count the caller already knows (a permutation of a column of known size): no host wait.
 int gather_utf8_finish_known(flockgpu_ctx *ctx, Utf8Gather &g, int64_t total_bytes, flockgpu_utf8 *out);
 

@@ -1740,12 +1740,10 @@ struct Exec {
             int64_t mx = 0;
             int any = 0;
             if (!a.c.all_null) FG_TRY(reduce_max(ctx, a.c, in.rows, &mx, &any));
-            int64_t *d = nullptr, *h = nullptr;
+            int64_t *d = nullptr;
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "max").c_str(), 2, &d));
-            FG_TRY(pinned_get_t(ctx, node_key(pl, n, "max").c_str(), 2, &h));
-            if (at == ColType::I32) *reinterpret_cast<int32_t *>(h) = (int32_t)mx;
-            else h[0] = mx;
-            FG_HIP(ctx, hipMemcpyAsync(d, h, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+            // the one value travels as kernel arguments (a host-to-device copy call costs ~10 us of host time; Int32 reads the low word)
+            FG_TRY(fill_words(ctx, FillList().add(d, (uint32_t)(uint64_t)mx, 1).add(reinterpret_cast<uint32_t *>(d) + 1, (uint32_t)((uint64_t)mx >> 32), 1)));
             t->rows = 1;
             t->cols[0] = dev_col(at, d, nullptr, 0, a.c.is_ts);
             t->cols[0].c.nullable = true;

@@ -349,11 +349,10 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
     FG_TRY(build_seg_tiles(ctx, (base + ".tiles").c_str(), &sb, &se, 1, kFlagTile, &st));
     uint32_t *flags = nullptr, *counts = nullptr;
     uint64_t *tile_base = nullptr;
-    int64_t *d_off = nullptr, *h_off = nullptr;
+    int64_t *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".flags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
-    FG_TRY(arena_get_t(ctx, (base + ".off").c_str(), 2, &d_off));
     FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
     bool wide = false;
     for (int i = 0; i < prog.n_leaves; ++i) {
@@ -376,9 +375,8 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
         }
     }
     FG_TRY(check_launch(ctx, "pred_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the selected-row count goes straight into pinned memory)
     FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
-    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = h_off[1];
     return FLOCKGPU_OK;

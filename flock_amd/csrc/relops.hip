@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kBlock) void mask_flag_kernel(const uint8_t *__rest
 
 // ---- group by
 __global__ __launch_bounds__(kBlock) void group_init_kernel(int64_t *__restrict__ tk, uint64_t *__restrict__ ta, int32_t *__restrict__ tf,
-                                                            int64_t slots) {
+                                                            int64_t slots, uint32_t *__restrict__ err) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0u;   // (instead of a hipMemsetAsync of its own: ~10 us of host time each)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
         tk[i] = kEmptyKey;
         ta[i] = 0;
@@ -130,7 +131,10 @@ __global__ __launch_bounds__(kBlock) void group_insert_kernel(const int64_t *__r
         else if (kind == (int32_t)AggKind::MAX) atomicMax(reinterpret_cast<unsigned long long *>(&ta[s]), (unsigned long long)v);
     }
 }
-__global__ __launch_bounds__(kBlock) void live_slot_mask_kernel(const int32_t *__restrict__ tf, int64_t slots, uint8_t *__restrict__ mask) {
+// (the pass that runs behind the inserts also hands their error word to the host: `h_err` is pinned memory, read after the next wait)
+__global__ __launch_bounds__(kBlock) void live_slot_mask_kernel(const int32_t *__restrict__ tf, int64_t slots, uint8_t *__restrict__ mask,
+                                                                const uint32_t *__restrict__ err, uint32_t *__restrict__ h_err) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *h_err = *err;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) mask[i] = tf[i] != 0x7fffffff;
 }
 
@@ -158,7 +162,8 @@ __device__ __forceinline__ uint64_t agg_identity(int32_t op) {
     }
 }
 __global__ __launch_bounds__(kBlock) void group_init_n_kernel(int64_t *__restrict__ tk, uint64_t *__restrict__ ta, int32_t *__restrict__ tf,
-                                                              int64_t slots, AggSpecs sp) {
+                                                              int64_t slots, AggSpecs sp, uint32_t *__restrict__ err) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0u;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
         tk[i] = kEmptyKey;
         tf[i] = 0x7fffffff;
@@ -622,7 +627,8 @@ __global__ __launch_bounds__(kBlock) void dense_group_kernel(const void *__restr
 }
 // live slots (count != 0) as flag words in the flag-tile geometry: a lane's four consecutive slots are one 16-byte load
 __global__ __launch_bounds__(kBlock) void dense_live_flag_kernel(const uint32_t *__restrict__ cnt, int64_t n_slots, SegTiles st, uint32_t *__restrict__ flag_words,
-                                                                 uint32_t *__restrict__ counts) {
+                                                                 uint32_t *__restrict__ counts, const uint32_t *__restrict__ err, uint32_t *__restrict__ h_err) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *h_err = *err;   // (the count pass's error word, handed to the host's pinned copy by the pass behind it)
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
     const int64_t wbase = tr.tile_begin + flag_rel0();
@@ -1262,20 +1268,18 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
     FG_TRY(build_seg_tiles(ctx, (base + ".tiles").c_str(), &sb, &se, 1, kFlagTile, &st));
     uint32_t *flags = nullptr, *counts = nullptr;
     uint64_t *tile_base = nullptr;
-    int64_t *d_off = nullptr, *h_off = nullptr;
+    int64_t *h_off = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".flags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
-    FG_TRY(arena_get_t(ctx, (base + ".off").c_str(), 2, &d_off));
     FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
     {
         LaunchScope ls(ctx, "mask_flag_kernel");
         hipLaunchKernelGGL(mask_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, mask, rows, st, flags, counts);
     }
     FG_TRY(check_launch(ctx, "mask_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the scan writes its segment offsets straight into pinned memory)
     FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
-    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = h_off[1];
     return FLOCKGPU_OK;
@@ -1343,14 +1347,12 @@ int group_by_key64(flockgpu_ctx *ctx, const char *name, const int64_t *keys, con
     FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
     FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
     FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-    RELOPS_LAUNCH(ctx, "group_init_kernel", group_init_kernel, slots, tk, ta, tf, slots);
+    RELOPS_LAUNCH(ctx, "group_init_kernel", group_init_kernel, slots, tk, ta, tf, slots, d_err);
     if (rows > 0)
         RELOPS_LAUNCH(ctx, "group_insert_kernel", group_insert_kernel, rows, keys, values, (int32_t)kind, rows, tk, ta, tf, cap, d_err);
-    RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
+    RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live, d_err, h_err);
     int32_t *slot_rows = nullptr;
     int64_t n_groups = 0;
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
     int64_t *ok = nullptr;
@@ -1413,13 +1415,12 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
         FG_TRY(arena_get_t(ctx, (base + ".live").c_str(), (size_t)slots + 16, &live));
         FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
         FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-        FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
         sp.seen = nullptr;
         if (track) {
             FG_TRY(arena_get_t(ctx, (base + ".seen").c_str(), (size_t)slots * (size_t)width, &sp.seen));
             RELOPS_LAUNCH(ctx, "zero_u32_kernel", zero_u32_kernel, slots * width, sp.seen, slots * (int64_t)width);
         }
-        RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp);
+        RELOPS_LAUNCH(ctx, "group_init_n_kernel", group_init_n_kernel, slots, tk, ta, tf, slots, sp, d_err);
         if (rows > 0) {
             // the workgroup-level table (LDS): 2048 slots for one or two accumulators, 1024 beyond; four rows per slot
             const GroupTable gt{tk, ta, tf, cap, d_err, key_valid};
@@ -1435,8 +1436,7 @@ int group_by_key64_n(flockgpu_ctx *ctx, const char *name, const int64_t *keys, i
             }
         }
         FG_TRY(check_launch(ctx, "group_insert_n_kernel"));
-        RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live);
-        FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RELOPS_LAUNCH(ctx, "live_slot_mask_kernel", live_slot_mask_kernel, slots, tf, slots, live, d_err, h_err);
         FG_TRY(mask_to_rows(ctx, (base + ".sel").c_str(), live, slots, &slot_rows, &n_groups));  // synchronises
         if (!*h_err) break;
         if (cap >= full) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: group table overflow", name);
@@ -1477,15 +1477,13 @@ int column_minmax(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t
     if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "column statistics need an integer column");
     if (rows <= 0) return FLOCKGPU_OK;
     const unsigned blocks = std::min<unsigned>(grid_for(ctx, rows / 4 + 1), 1024);
-    int64_t *d = nullptr, *h = nullptr;
-    FG_TRY(arena_get_t(ctx, "relops.minmax", 2048, &d));
+    int64_t *h = nullptr;
     FG_TRY(pinned_get_t(ctx, "relops.minmax", 2048, &h));
     {
-        LaunchScope ls(ctx, "minmax_kernel");
-        hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, (int32_t)col.type, rows, d);
+        LaunchScope ls(ctx, "minmax_kernel");   // (the per-block results go straight into pinned memory: no copy call behind the kernel)
+        hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, (int32_t)col.type, rows, h);
     }
     FG_TRY(check_launch(ctx, "minmax_kernel"));
-    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * 2 * blocks, hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool uns = col.type == ColType::U64;
     int64_t lo = h[0], hi = h[blocks];
@@ -1540,12 +1538,15 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
     FG_TRY(arena_get_t(ctx, (base + ".dacc").c_str(), (size_t)range * (size_t)std::max(sp.n, 1) + 2, &acc));
     FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
     FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)range, ctx->stream));
-    for (int a = 0; a < sp.n; ++a) {
-        const uint64_t id = sp.op[a] == (int32_t)AggOp::MAX_S ? (uint64_t)INT64_MIN : sp.op[a] == (int32_t)AggOp::MIN_S ? (uint64_t)INT64_MAX : sp.op[a] == (int32_t)AggOp::MIN_U ? ~0ull : 0ull;
-        if (id == 0) FG_HIP(ctx, hipMemsetAsync(acc + (size_t)a * range, 0, sizeof(uint64_t) * (size_t)range, ctx->stream));
-        else RELOPS_LAUNCH(ctx, "fill_u64_kernel", fill_u64_kernel, (int64_t)range, acc + (size_t)a * range, (int64_t)range, id);
+    {   // the error word, the counters and every accumulator whose identity is zero (or all ones): one launch; the signed extremes keep theirs
+        FillList fl;
+        fl.add(d_err, 0u, 1).add(cnt, 0u, range);
+        for (int a = 0; a < sp.n; ++a) {
+            const uint64_t id = sp.op[a] == (int32_t)AggOp::MAX_S ? (uint64_t)INT64_MIN : sp.op[a] == (int32_t)AggOp::MIN_S ? (uint64_t)INT64_MAX : sp.op[a] == (int32_t)AggOp::MIN_U ? ~0ull : 0ull;
+            if ((id == 0 || id == ~0ull) && fl.n < 4) fl.add(acc + (size_t)a * range, (uint32_t)id, (uint64_t)range * 2);
+            else RELOPS_LAUNCH(ctx, "fill_u64_kernel", fill_u64_kernel, (int64_t)range, acc + (size_t)a * range, (int64_t)range, id);
+        }
+        FG_TRY(fill_words(ctx, fl));
     }
     {
         const size_t lds = (size_t)kDenseBins * (4 + 8 * (size_t)sp.n);
@@ -1567,23 +1568,20 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
     FG_TRY(build_seg_tiles(ctx, (base + ".dtiles").c_str(), &sb, &se, 1, kFlagTile, &st));
     uint32_t *flags = nullptr, *counts = nullptr;
     uint64_t *tile_base = nullptr;
-    int64_t *d_off = nullptr, *h_off = nullptr;
+    int64_t *h_off = nullptr;
     int32_t *slots = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".dflags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
     FG_TRY(arena_get_t(ctx, (base + ".dcounts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".dbase").c_str(), (size_t)st.n_tiles + 1, &tile_base));
-    FG_TRY(arena_get_t(ctx, (base + ".doff").c_str(), 2, &d_off));
     FG_TRY(pinned_get_t(ctx, (base + ".doff").c_str(), 2, &h_off));
     FG_TRY(arena_get_t(ctx, (base + ".dslots").c_str(), (size_t)std::min<int64_t>(range, rows) + 4, &slots));   // (at most one live slot per row)
     {
         LaunchScope ls(ctx, "dense_live_flag_kernel");
-        hipLaunchKernelGGL(dense_live_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, cnt, (int64_t)range, st, flags, counts);
+        hipLaunchKernelGGL(dense_live_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, cnt, (int64_t)range, st, flags, counts, d_err, h_err);
     }
     FG_TRY(check_launch(ctx, "dense_live_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, d_off));
+    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (segment offsets straight into pinned memory)
     FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, slots));
-    FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     const int64_t n_groups = h_off[1];
@@ -1666,15 +1664,13 @@ int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *o
     if (col.type == ColType::UTF8 || col.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "MAX needs an integer column");
     if (rows <= 0) return FLOCKGPU_OK;
     const unsigned blocks = std::min<unsigned>(grid_for(ctx, rows), 1024);
-    int64_t *d = nullptr, *h = nullptr;
-    FG_TRY(arena_get_t(ctx, "relops.max", 2048, &d));
+    int64_t *h = nullptr;
     FG_TRY(pinned_get_t(ctx, "relops.max", 2048, &h));
     {
-        LaunchScope ls(ctx, "max_kernel");
-        hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, col.valid, (int32_t)col.type, rows, d);
+        LaunchScope ls(ctx, "max_kernel");      // (per-block results straight into pinned memory)
+        hipLaunchKernelGGL(max_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, col.values, col.valid, (int32_t)col.type, rows, h);
     }
     FG_TRY(check_launch(ctx, "max_kernel"));
-    FG_HIP(ctx, hipMemcpyAsync(h, d, sizeof(int64_t) * 2 * blocks, hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool uns = col.type == ColType::U64;
     int64_t m = uns ? 0 : INT64_MIN, seen = 0;
@@ -1711,8 +1707,7 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         const int64_t nb = build_left ? n_left : n_right, np = build_left ? n_right : n_left;
         std::vector<int64_t> &hint = ctx->host_i64[base + ".pairs_hint"];   // {pairs of the last call under this name}
         uint64_t cap_pairs = (uint64_t)std::max<int64_t>(np + 1024, hint.empty() ? 0 : hint[0] + hint[0] / 4 + 1024);
-        unsigned long long *d_tot = nullptr, *h_tot = nullptr;
-        FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot));
+        unsigned long long *h_tot = nullptr;   // (pinned: the kernel's one thread stores the total where the host reads it)
         FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot));
         int32_t *ob = nullptr, *op = nullptr;
         for (;;) {
@@ -1721,10 +1716,9 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
             {
                 LaunchScope ls(ctx, "join_tiny_kernel");
                 hipLaunchKernelGGL(join_tiny_kernel, dim3(1), dim3(kTinyThreads), 0, ctx->stream, bk, (int32_t)nb, pk, (int32_t)np, ob, op,
-                                   (uint32_t)std::min<uint64_t>(cap_pairs, 0x7fffffffu), d_tot);
+                                   (uint32_t)std::min<uint64_t>(cap_pairs, 0x7fffffffu), h_tot);
             }
             FG_TRY(check_launch(ctx, "join_tiny_kernel"));
-            FG_HIP(ctx, hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (h_tot[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot[0]);
             if (h_tot[0] <= cap_pairs) break;
@@ -1742,13 +1736,14 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     const int64_t slots = (int64_t)cap + 1;
     int64_t *tk = nullptr;
     int32_t *head = nullptr, *next = nullptr, *counts = nullptr;
+    // the call's scalars, one block on the device and one in pinned memory: [0] error word, [2..3] 64-bit pair total
     uint32_t *d_err = nullptr, *h_err = nullptr;
     FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
     FG_TRY(arena_get_t(ctx, (base + ".head").c_str(), (size_t)slots, &head));
     FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
-    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 4, &h_err));
     int32_t *ol = nullptr, *orr = nullptr;
     if (n_left <= 0 || n_right <= 0) {
         FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
@@ -1757,18 +1752,14 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         *right_rows = orr;
         return FLOCKGPU_OK;
     }
-    unsigned long long *d_tot64 = nullptr, *h_tot64 = nullptr;
-    FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot64));
-    FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot64));
-    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(d_tot64, 0, sizeof(unsigned long long), ctx->stream));
+    unsigned long long *d_tot64 = reinterpret_cast<unsigned long long *>(d_err + 2), *h_tot64 = reinterpret_cast<unsigned long long *>(h_err + 2);
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 4)));
     RELOPS_LAUNCH(ctx, "join_init_kernel", join_init_kernel, slots, tk, head, slots);
     RELOPS_LAUNCH(ctx, "join_build_kernel", join_build_kernel, n_left, left, n_left, tk, head, next, cap, d_err);
     RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
                   (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
-    FG_HIP(ctx, hipMemcpyAsync(h_tot64, d_tot64, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 4)));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
     // the 64-bit total decides: the 32-bit inclusive scan of `counts` is only read when it cannot have wrapped
@@ -1801,10 +1792,10 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
     FG_TRY(arena_get_t(ctx, (base + ".dhead").c_str(), (size_t)range + 4, &head));
     FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
-    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_TRY(arena_get_t(ctx, (base + ".tot64").c_str(), 2, &d_tot64));
-    FG_TRY(pinned_get_t(ctx, (base + ".tot64").c_str(), 2, &h_tot64));
+    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 4, &d_err));     // [0] error word, [2..3] 64-bit pair total
+    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 4, &h_err));
+    d_tot64 = reinterpret_cast<unsigned long long *>(d_err + 2);
+    h_tot64 = reinterpret_cast<unsigned long long *>(h_err + 2);
     if (n_left <= 0 || n_right <= 0) {
         FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
         FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), 4, &orr));
@@ -1812,15 +1803,12 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
         *right_rows = orr;
         return FLOCKGPU_OK;
     }
-    FG_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(uint32_t), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(d_tot64, 0, sizeof(unsigned long long), ctx->stream));
-    FG_HIP(ctx, hipMemsetAsync(head, 0xff, sizeof(int32_t) * (size_t)range, ctx->stream));   // -1: empty chain
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 4).add(head, 0xffffffffu, range)));   // scalars 0; chain heads -1 (empty): one launch
     RELOPS_LAUNCH(ctx, "join_build_dense_kernel", join_build_dense_kernel, n_left, left.values, (int32_t)left.type, n_left, kmin, range, head, next, d_err);
     RELOPS_LAUNCH(ctx, "join_probe_dense_kernel", join_probe_dense_kernel<false>, n_right, right.values, (int32_t)right.type, n_right, kmin, range, head, next, counts,
                   (int32_t *)nullptr, (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
-    FG_HIP(ctx, hipMemcpyAsync(h_tot64, d_tot64, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    FG_HIP(ctx, hipMemcpyAsync(h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 4)));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a build key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);

@@ -303,7 +303,7 @@ int flockgpu_group_rows_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t r
     FG_TRY(arena_get_t(ctx, "group_rows.minmax", 4, &d_mm));
     FG_TRY(pinned_get_t(ctx, "group_rows.minmax", 4, &h_mm));
     FG_TRY(key_min_max(ctx, keys, rows, d_mm));
-    FG_HIP(ctx, hipMemcpyAsync(h_mm, d_mm, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FG_TRY(publish_words(ctx, PublishList().add(h_mm, d_mm, 2)));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int bits = 1;
     int32_t bias = 0;
