@@ -114,6 +114,9 @@ struct HostBlock {  // shared by the partitions of one execute
 struct TCol {
     DevColumn c;
     bool present = false;
+    // every value of this column is a value of the column at `subset_of` (it was taken from it by a filter, a join or as a GROUP BY's keys): when
+    // that column is a leaf's, its cached minimum / maximum BOUND this one's -- enough to size the dense paths without a pass and a wait of its own
+    const void *subset_of = nullptr;
 };
 struct Table {
     std::vector<TCol> cols;
@@ -1447,6 +1450,7 @@ struct Exec {
             }
             FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
             o.present = true;
+            o.subset_of = in.cols[i].subset_of ? in.cols[i].subset_of : in.cols[i].c.values;
         }
         for (size_t g0 = 0; g0 < utf8.size(); g0 += 4) {
             const int k = (int)std::min<size_t>(4, utf8.size() - g0);
@@ -1485,31 +1489,44 @@ struct Exec {
     // The statistics of a column that is NOT a leaf's cost a pass and a host wait on every execute (~20 us): worth it from several
     // thousand rows on, where the dense paths save more than that; below, the hash table answers (a stage plan's operators run on a
     // few thousand filtered rows, and at that size the waits ARE the cost -- DESIGN section 3a).  A leaf column's are cached.
-    bool stats_worth_it(const TCol &c, int64_t rows) const {
-        if (rows >= (int64_t(1) << 13)) return true;   // (up to 4096 build rows the one-workgroup LDS join answers without any statistics)
+    // rows of the leaf whose column lives at `values` (-1: no leaf's column)
+    int64_t leaf_rows_of(const void *values) const {
+        if (!values) return -1;
         for (auto &ld : pl->leaves)
             if (!ld.borrowed)
                 for (auto &b : ld.cols)
-                    if (b.values && b.values == c.c.values) return true;
-        return false;
+                    if (b.values && b.values == values) return ld.rows;
+        return -1;
     }
-    // exact (min, max) of an integer column; a LEAF column's are remembered until the leaf changes (flockgpu_plan::col_stats)
-    int int_col_stats(const TCol &c, int64_t rows, int64_t *mn, int64_t *mx) {
-        bool leaf_col = false;
-        for (auto &ld : pl->leaves)
-            if (!ld.borrowed)
-                for (auto &b : ld.cols) leaf_col = leaf_col || (b.values && b.values == c.c.values);
-        if (leaf_col) {
-            auto it = pl->col_stats.find(c.c.values);
-            if (it != pl->col_stats.end() && it->second.rows == rows) {
-                *mn = it->second.mn;
-                *mx = it->second.mx;
-                return FLOCKGPU_OK;
-            }
+    bool stats_worth_it(const TCol &c, int64_t rows) const {
+        if (rows >= (int64_t(1) << 13)) return true;   // (up to 4096 build rows the one-workgroup LDS join answers without any statistics)
+        return leaf_rows_of(c.c.values) >= 0 || leaf_rows_of(c.subset_of) >= 0;
+    }
+    // (min, max) of an integer column for sizing the dense paths.  A LEAF column's are exact and remembered until the leaf changes
+    // (flockgpu_plan::col_stats); a column taken FROM a leaf column (TCol::subset_of) gets the leaf's as bounds when the range they span is
+    // still dense for its row count -- no pass, no wait --, its own exact ones otherwise.
+    int leaf_col_stats(const void *values, ColType type, int64_t rows, int64_t *mn, int64_t *mx) {
+        auto it = pl->col_stats.find(values);
+        if (it != pl->col_stats.end() && it->second.rows == rows) {
+            *mn = it->second.mn;
+            *mx = it->second.mx;
+            return FLOCKGPU_OK;
         }
-        FG_TRY(column_minmax(ctx, c.c, rows, mn, mx));
-        if (leaf_col) pl->col_stats[c.c.values] = flockgpu_plan::ColStat{rows, *mn, *mx};
+        DevColumn c;
+        c.type = type;
+        c.values = values;
+        FG_TRY(column_minmax(ctx, c, rows, mn, mx));
+        pl->col_stats[values] = flockgpu_plan::ColStat{rows, *mn, *mx};
         return FLOCKGPU_OK;
+    }
+    int int_col_stats(const TCol &c, int64_t rows, int64_t *mn, int64_t *mx) {
+        if (leaf_rows_of(c.c.values) >= 0) return leaf_col_stats(c.c.values, c.c.type, rows, mn, mx);
+        const int64_t src_rows = c.subset_of && c.subset_of != c.c.values ? leaf_rows_of(c.subset_of) : -1;
+        if (src_rows > 0 && rows > 0) {
+            FG_TRY(leaf_col_stats(c.subset_of, c.c.type, src_rows, mn, mx));
+            if (dense_range_ok(*mn, *mx, rows, c.c.type == ColType::U64)) return FLOCKGPU_OK;
+        }
+        return column_minmax(ctx, c.c, rows, mn, mx);
     }
 
     int key_i64(const Node *n, const TCol &c, int64_t rows, const char *what, int64_t **out) {
@@ -1904,6 +1921,7 @@ struct Exec {
             FG_TRY(arena_get_t(ctx, node_key(pl, n, "nk").c_str(), (size_t)g.n_groups + 4, &nk));
             FG_TRY(narrow_i64_to_i32(ctx, g.keys, g.n_groups, nk));
             t->cols[0] = dev_col(ColType::I32, nk);
+            if (!null_keys) t->cols[0].subset_of = k.subset_of ? k.subset_of : k.c.values;   // (a group's key is one of the input's keys)
             if (null_keys) {   // the NULL group's key is NULL again
                 uint8_t *kv = nullptr;
                 FG_TRY(arena_get_t(ctx, node_key(pl, n, "nkv").c_str(), (size_t)g.n_groups + 16, &kv));
@@ -1913,6 +1931,7 @@ struct Exec {
         } else {
             t->cols[0] = dev_col(k.c.type, g.keys, nullptr, 0, k.c.is_ts);
             if (wide_null_keys) t->cols[0].c.valid = g.key_valid;
+            else if (!null_keys) t->cols[0].subset_of = k.subset_of ? k.subset_of : k.c.values;
         }
         t->cols[0].c.nullable = n->schema[0].nullable;
         // ---- aggregate / state columns
