@@ -1635,8 +1635,9 @@ struct Exec {
                     const TCol &bk = build_right ? rk : lk, &pk = build_right ? lk : rk;
                     const int64_t nb = build_right ? nr : nl, np = build_right ? nl : nr;
                     int64_t kmin = 0, kmax = 0;
-                    // (a join the one-workgroup LDS kernel takes needs no statistics; anything larger is worth the pass, leaf or not)
-                    const bool look = !join_is_tiny(nl, nr) || stats_worth_it(bk, nb + np);
+                    // (a join the one-workgroup LDS kernel takes is ONE launch and one wait -- the dense path's fill, build, count, scan and emit
+                    // are eight and a wait, whatever the statistics cost; anything larger is worth the pass, leaf or not)
+                    const bool look = !join_is_tiny(nl, nr);
                     if (look) FG_TRY(int_col_stats(bk, nb, &kmin, &kmax));
                     if (look && dense_range_ok(kmin, kmax, nb, bk.c.type == ColType::U64)) {
                         FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
