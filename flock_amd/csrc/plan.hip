@@ -21,6 +21,7 @@
 #include "../../include/flockgpu_plan.h"
 #include "plan_ir.hpp"
 #include "pred.hpp"
+#include "valprog.hpp"
 
 using namespace flockgpu;
 using namespace flockgpu::ir;
@@ -1231,13 +1232,27 @@ struct Exec {
         int64_t modulus = 0;
         bool big = false;   // INT: a UInt64 literal above INT64_MAX (`i` is its bit pattern)
     };
+    // `e` without the casts that change no value (and no NULL): to the operand's own type, Int32 -> Int64 / Float64, an integer literal to any
+    // numeric type.  A cast that may truncate, overflow or -- TRY_CAST -- turn a value into NULL stays: the one-pass predicate program has
+    // no leaf for it and the general evaluator (valprog.hpp) takes the predicate.
+    const Expr *uncast_exact(const Expr *e, const Table &in) const {
+        while (e && e->kind == EKind::Cast) {
+            const Expr *x = e->l.get();
+            const int from = val_type_of(x, in);
+            const bool exact = from == (int)e->cast_to || (from == 0 && (e->cast_to == ColType::I64 || e->cast_to == ColType::F64)) || x->kind == EKind::LitI ||
+                               (x->kind == EKind::LitF && e->cast_to == ColType::F64) || x->kind == EKind::LitNull;
+            if (!exact) break;
+            e = x;
+        }
+        return e;
+    }
     Operand operand(const Expr *e, const Table &in) const {
         Operand o;
         bool neg = false;
-        e = uncast(e);
+        e = uncast_exact(e, in);
         while (e->kind == EKind::Neg) {   // -literal: folded here (a negated column is not taken)
             neg = !neg;
-            e = uncast(e->l.get());
+            e = uncast_exact(e->l.get(), in);
         }
         auto column = [&](const Expr *x) -> const TCol * {
             const TCol &c = in.cols[(size_t)x->col];
@@ -1258,7 +1273,7 @@ struct Exec {
                 return o;
             case EKind::Bin:
                 if (!neg && e->s == "Modulo") {
-                    const Expr *c = uncast(e->l.get()), *m = uncast(e->r.get());
+                    const Expr *c = uncast_exact(e->l.get(), in), *m = uncast_exact(e->r.get(), in);
                     if (c->kind == EKind::Col && m->kind == EKind::LitI && (o.col = column(c))) {
                         o.k = o.col->c.all_null ? Operand::NUL : Operand::MOD;
                         o.modulus = m->i;
@@ -1396,7 +1411,7 @@ struct Exec {
                 return b.push(PredOpKind::Not) ? FLOCKGPU_OK : pred_full();
             case EKind::IsNull:
             case EKind::IsNotNull: {
-                const Expr *a = uncast(e->l.get());
+                const Expr *a = uncast_exact(e->l.get(), in);
                 if (a->kind != EKind::Col) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: IS [NOT] NULL of something other than a column");
                 const TCol &c = in.cols[(size_t)a->col];
                 if (c.c.all_null) return pred_const(b, e->kind == EKind::IsNull ? 1 : 0);
@@ -1536,11 +1551,199 @@ struct Exec {
     }
 
     // FilterExec as a row selection: the input table and the rows of it the predicate keeps (input order)
+    // ---- the general expression evaluator (valprog.hpp): an expression tree -> its postfix program over the columns of `in`
+    int val_unsupported(const char *what) { return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: %s", what); }
+    int val_full() { return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: expression too large for one program (%d operators, %d columns, %d constants, depth %d)", kValMaxOps, kValMaxCols, kValMaxConsts, kValMaxStack); }
+    // static type of `e` over the table's columns (expr_static_type's codes)
+    int val_type_of(const Expr *e, const Table &in) const {
+        std::vector<Field> sch(in.cols.size());
+        for (size_t i = 0; i < in.cols.size(); ++i) sch[i].type = in.cols[i].c.type;
+        return expr_static_type(e, sch);
+    }
+    // the type two operands meet in: the typed one's; two untyped literals take `hint`, else Float64 if one is written as one, else Int64
+    int val_common_type(const Expr *a, const Expr *b, const Table &in, int hint) {
+        const int ta = val_type_of(a, in), tb = val_type_of(b, in);
+        if (ta == -2 || tb == -2 || ta == 4 || tb == 4) return -2;
+        if (ta >= 0 && tb >= 0) return ta == tb ? ta : -2;
+        if (ta >= 0) return ta;
+        if (tb >= 0) return tb;
+        if (hint >= 0 && hint <= 3) return hint;
+        return (a->kind == EKind::LitF || b->kind == EKind::LitF) ? 3 : 1;
+    }
+    // pushes `e` (typed `want` where it is an untyped literal); *vt = what was pushed (0..3, 5)
+    int val_compile(const Expr *e, const Table &in, ValBuilder &b, int want, int *vt, bool *may_null) {
+        auto arith_op = [](const std::string &op) {
+            return op == "Plus" ? ValOpKind::Add : op == "Minus" ? ValOpKind::Sub : op == "Multiply" ? ValOpKind::Mul : op == "Divide" ? ValOpKind::Div : ValOpKind::Mod;
+        };
+        auto cmp_op = [](const std::string &op, ValOpKind *k) {
+            if (op == "Eq") *k = ValOpKind::Eq; else if (op == "NotEq") *k = ValOpKind::Ne; else if (op == "Lt") *k = ValOpKind::Lt;
+            else if (op == "LtEq") *k = ValOpKind::Le; else if (op == "Gt") *k = ValOpKind::Gt; else if (op == "GtEq") *k = ValOpKind::Ge;
+            else return false;
+            return true;
+        };
+        switch (e->kind) {
+            case EKind::Col: {
+                const TCol &c = in.cols[(size_t)e->col];
+                if (c.c.type == ColType::UTF8) return val_unsupported("a Utf8 column inside a computed expression");
+                *vt = (int)c.c.type;
+                if (c.c.all_null) {
+                    *may_null = true;
+                    return b.push(ValOpKind::Null, (ValType)*vt, 0) ? FLOCKGPU_OK : val_full();
+                }
+                if (!c.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: expression column was not materialised");
+                *may_null = *may_null || c.c.valid != nullptr;
+                return b.push(ValOpKind::Col, (ValType)*vt, 0, b.add_col(c.c)) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::LitI: case EKind::LitF: {
+                int ty = val_type_of(e, in);
+                if (ty < 0) ty = want >= 0 && want <= 3 ? want : (e->kind == EKind::LitF ? 3 : 1);
+                uint64_t bits = 0;
+                if (e->kind == EKind::LitF) {
+                    if (ty != 3) return val_unsupported("a Float64 literal against an integer operand (the planner casts the column)");
+                    std::memcpy(&bits, &e->f, 8);
+                } else if (ty == 3) {
+                    const double d = e->big_unsigned ? (double)(uint64_t)e->i : (double)e->i;
+                    std::memcpy(&bits, &d, 8);
+                } else {
+                    if (e->big_unsigned && ty != 2) return val_unsupported("a UInt64 literal above 2^63 against a signed operand");
+                    if (ty == 0 && (e->i < INT32_MIN || e->i > INT32_MAX)) return val_unsupported("a literal beyond the Int32 range of its operand");
+                    if (ty == 2 && !e->big_unsigned && e->i < 0) return val_unsupported("a negative literal against a UInt64 operand");
+                    bits = (uint64_t)e->i;
+                }
+                *vt = ty;
+                return b.push(ValOpKind::Const, (ValType)ty, 0, b.add_const(bits)) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::LitB:
+                *vt = 5;
+                return b.push(ValOpKind::Const, ValType::BOOL, 0, b.add_const(e->i ? 1 : 0)) ? FLOCKGPU_OK : val_full();
+            case EKind::LitNull:
+                *vt = want >= 0 ? want : 1;
+                *may_null = true;
+                return b.push(ValOpKind::Null, (ValType)*vt, 0) ? FLOCKGPU_OK : val_full();
+            case EKind::LitS:
+                return val_unsupported("a Utf8 literal inside a computed expression");
+            case EKind::Cast: {
+                int from = -1;
+                FG_TRY(val_compile(e->l.get(), in, b, -1, &from, may_null));
+                if (from > 3 || (int)e->cast_to > 3) return val_unsupported("CAST between other than numeric types inside a computed expression");
+                *vt = (int)e->cast_to;
+                if (e->try_cast) *may_null = true;
+                if (from == *vt) return FLOCKGPU_OK;
+                return b.push(e->try_cast ? ValOpKind::TryCast : ValOpKind::Cast, (ValType)from, 1, 0, (ValType)*vt) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::Neg: {
+                FG_TRY(val_compile(e->l.get(), in, b, want, vt, may_null));
+                if (*vt == 2 || *vt > 3) return val_unsupported("unary minus of an unsigned or Boolean value");
+                return b.push(ValOpKind::Neg, (ValType)*vt, 1) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::Not: {
+                FG_TRY(val_compile(e->l.get(), in, b, 5, vt, may_null));
+                if (*vt != 5) return val_unsupported("NOT of a value that is not Boolean");
+                return b.push(ValOpKind::Not, ValType::BOOL, 1) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::IsNull: case EKind::IsNotNull: {
+                int ty = -1;
+                bool inner_null = false;
+                FG_TRY(val_compile(e->l.get(), in, b, -1, &ty, &inner_null));
+                *vt = 5;
+                return b.push(e->kind == EKind::IsNull ? ValOpKind::IsNull : ValOpKind::IsNotNull, (ValType)ty, 1) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::InList: {   // (x = a) OR (x = b) OR ..., x evaluated once per item; NULL when x is
+                for (size_t i = 0; i < e->list.size(); ++i) {
+                    const int ty = val_common_type(e->l.get(), e->list[i].get(), in, -1);
+                    if (ty < 0 || ty > 3) return val_unsupported("IN over operands without one numeric type");
+                    int ta = -1, tb = -1;
+                    FG_TRY(val_compile(e->l.get(), in, b, ty, &ta, may_null));
+                    FG_TRY(val_compile(e->list[i].get(), in, b, ty, &tb, may_null));
+                    if (ta != ty || tb != ty) return val_unsupported("IN over operands of different types");
+                    if (!b.push(ValOpKind::Eq, (ValType)ty, 2)) return val_full();
+                    if (i > 0 && !b.push(ValOpKind::Or, ValType::BOOL, 2)) return val_full();
+                }
+                if (e->negated && !b.push(ValOpKind::Not, ValType::BOOL, 1)) return val_full();
+                *vt = 5;
+                return FLOCKGPU_OK;
+            }
+            case EKind::Bin: {
+                if (e->s == "And" || e->s == "Or") {
+                    int ta = -1, tb = -1;
+                    FG_TRY(val_compile(e->l.get(), in, b, 5, &ta, may_null));
+                    FG_TRY(val_compile(e->r.get(), in, b, 5, &tb, may_null));
+                    if (ta != 5 || tb != 5) return val_unsupported("AND / OR of values that are not Boolean");
+                    *vt = 5;
+                    return b.push(e->s == "And" ? ValOpKind::And : ValOpKind::Or, ValType::BOOL, 2) ? FLOCKGPU_OK : val_full();
+                }
+                ValOpKind ck;
+                const bool is_cmp = cmp_op(e->s, &ck);
+                if (!is_cmp && e->s != "Plus" && e->s != "Minus" && e->s != "Multiply" && e->s != "Divide" && e->s != "Modulo")
+                    return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: binary operator '%s'", e->s.c_str());
+                const int ty = val_common_type(e->l.get(), e->r.get(), in, is_cmp ? -1 : want);
+                if (ty == 5 && is_cmp && (ck == ValOpKind::Eq || ck == ValOpKind::Ne)) {
+                    // Boolean = Boolean
+                } else if (ty < 0 || ty > 3) {
+                    return val_unsupported("a binary operator over operands without one numeric type (the planner casts them to one)");
+                }
+                int ta = -1, tb = -1;
+                FG_TRY(val_compile(e->l.get(), in, b, ty, &ta, may_null));
+                FG_TRY(val_compile(e->r.get(), in, b, ty, &tb, may_null));
+                if (ta != ty || tb != ty) return val_unsupported("a binary operator over operands of different types");
+                *vt = is_cmp ? 5 : ty;
+                return b.push(is_cmp ? ck : arith_op(e->s), (ValType)(ty == 5 ? 1 : ty), 2) ? FLOCKGPU_OK : val_full();
+            }
+            case EKind::Case: {   // ELSE (or NULL), then from the LAST branch to the first: WHEN, THEN, Select -- the first TRUE WHEN wins
+                int ty = val_type_of(e, in);
+                if (ty == -1) ty = want >= 0 ? want : 1;
+                if (ty < 0 || ty > 3) return val_unsupported("CASE without one numeric result type");
+                int te = -1;
+                if (e->r) {
+                    FG_TRY(val_compile(e->r.get(), in, b, ty, &te, may_null));
+                    if (te != ty) return val_unsupported("CASE branches of different types");
+                } else {
+                    *may_null = true;
+                    if (!b.push(ValOpKind::Null, (ValType)ty, 0)) return val_full();
+                }
+                for (size_t i = e->list.size(); i >= 2; i -= 2) {
+                    const Expr *w = e->list[i - 2].get(), *th = e->list[i - 1].get();
+                    int tw = -1, tt = -1;
+                    if (e->l) {   // CASE x WHEN v: x = v
+                        const int tc = val_common_type(e->l.get(), w, in, -1);
+                        if (tc < 0 || tc > 3) return val_unsupported("CASE operand and WHEN value without one numeric type");
+                        int t1 = -1, t2 = -1;
+                        FG_TRY(val_compile(e->l.get(), in, b, tc, &t1, may_null));
+                        FG_TRY(val_compile(w, in, b, tc, &t2, may_null));
+                        if (t1 != tc || t2 != tc) return val_unsupported("CASE operand and WHEN value of different types");
+                        if (!b.push(ValOpKind::Eq, (ValType)tc, 2)) return val_full();
+                    } else {
+                        FG_TRY(val_compile(w, in, b, 5, &tw, may_null));
+                        if (tw != 5) return val_unsupported("a WHEN that is not Boolean");
+                    }
+                    FG_TRY(val_compile(th, in, b, ty, &tt, may_null));
+                    if (tt != ty) return val_unsupported("CASE branches of different types");
+                    if (!b.push(ValOpKind::Select, (ValType)ty, 3)) return val_full();
+                }
+                *vt = ty;
+                return FLOCKGPU_OK;
+            }
+        }
+        return val_unsupported("an expression of an unknown kind");
+    }
+
     int filter_rows(const Node *n, Table *in, int32_t **rows, int64_t *n_out) {
         FG_TRY(exec(n->in[0].get(), in));
         PredBuilder b;
-        FG_TRY(compile_pred(n->pred.get(), *in, b));
-        return pred_to_rows(ctx, node_key(pl, n, "sel").c_str(), b.p, in->rows, rows, n_out);
+        const int rc = compile_pred(n->pred.get(), *in, b);
+        if (rc == FLOCKGPU_OK) return pred_to_rows(ctx, node_key(pl, n, "sel").c_str(), b.p, in->rows, rows, n_out);
+        if (rc != FLOCKGPU_ERR_UNSUPPORTED) return rc;
+        // a predicate the one-pass program has no leaf for (arithmetic inside a comparison, CASE, casts of computed values): the general
+        // evaluator writes a byte mask, the mask goes through the same count -> scan -> emit
+        ValBuilder vb;
+        int vt = -1;
+        bool may_null = false;
+        FG_TRY(val_compile(n->pred.get(), *in, vb, 5, &vt, &may_null));
+        if (vt != 5) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a filter predicate that is not Boolean");
+        uint8_t *mask = nullptr;
+        FG_TRY(arena_get_t(ctx, node_key(pl, n, "vmask").c_str(), (size_t)std::max<int64_t>(in->rows, 0) + 16, &mask));
+        FG_TRY(valprog_to_mask(ctx, node_key(pl, n, "vprog").c_str(), vb.p, in->rows, mask));
+        return mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in->rows, rows, n_out);
     }
 
     int exec(const Node *n, Table *t) {
@@ -1582,12 +1785,27 @@ struct Exec {
                         continue;
                     }
                     // literal * CAST(Int32 column AS Float64): q1's currency conversion (planner.rs:90), one IEEE multiply
-                    const Expr *l = e->l.get(), *r = e->r.get();
-                    if (l->kind != EKind::LitF && l->kind != EKind::LitI) std::swap(l, r);
-                    const Expr *c = uncast(r);
-                    if (!is_bin(e, "Multiply") || (l->kind != EKind::LitF && l->kind != EKind::LitI) || c->kind != EKind::Col ||
-                        in.cols[(size_t)c->col].c.type != ColType::I32 || !in.cols[(size_t)c->col].present)
-                        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: computed projection other than `literal * Int32 column`");
+                    const Expr *l = is_bin(e, "Multiply") ? e->l.get() : nullptr, *r = l ? e->r.get() : nullptr;
+                    if (l && l->kind != EKind::LitF && l->kind != EKind::LitI) std::swap(l, r);
+                    const Expr *c = r ? uncast(r) : nullptr;
+                    if (!l || n->schema[i].type != ColType::F64 || (l->kind != EKind::LitF && l->kind != EKind::LitI) || c->kind != EKind::Col ||
+                        in.cols[(size_t)c->col].c.type != ColType::I32 || !in.cols[(size_t)c->col].present) {
+                        // anything else: the general evaluator (valprog.hpp), one kernel per output column
+                        ValBuilder vb;
+                        int vt = -1;
+                        bool may_null = false;
+                        FG_TRY(val_compile(e, in, vb, (int)n->schema[i].type, &vt, &may_null));
+                        if (vt != (int)n->schema[i].type) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a computed projection whose type is not its column's");
+                        void *vals = nullptr;
+                        uint8_t *vv = nullptr;
+                        FG_TRY(arena_get(ctx, node_key(pl, n, "val", (int)i).c_str(), ((size_t)std::max<int64_t>(in.rows, 0) + 2) * 8, &vals));
+                        if (may_null) FG_TRY(arena_get_t(ctx, node_key(pl, n, "valv", (int)i).c_str(), (size_t)std::max<int64_t>(in.rows, 0) + 16, &vv));
+                        FG_TRY(valprog_to_column(ctx, node_key(pl, n, "vprog", (int)i).c_str(), vb.p, in.rows, n->schema[i].type, vals, vv));
+                        o = dev_col(n->schema[i].type, vals, nullptr, 0, n->schema[i].is_ts);
+                        o.c.valid = vv;
+                        o.c.nullable = true;
+                        continue;
+                    }
                     double *d = nullptr;
                     FG_TRY(arena_get_t(ctx, node_key(pl, n, "f64", (int)i).c_str(), (size_t)in.rows + 2, &d));
                     flockgpu_bid_cols bc{nullptr, nullptr, static_cast<const int32_t *>(in.cols[(size_t)c->col].c.values), nullptr, in.rows};

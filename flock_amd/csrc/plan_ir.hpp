@@ -27,7 +27,7 @@ struct Field {
 
 // Expression dialect (SURVEY.md appendix C + the unary / list expressions of the fork's expressions/*.rs, upstream DataFusion ~6:
 // IsNullExpr{arg}, IsNotNullExpr{arg}, NotExpr{arg}, NegativeExpr{arg}, InListExpr{expr, list, negated}).
-enum class EKind { Col, LitI, LitF, LitS, LitB, LitNull, Bin, Cast, Not, IsNull, IsNotNull, Neg, InList };
+enum class EKind { Col, LitI, LitF, LitS, LitB, LitNull, Bin, Cast, Not, IsNull, IsNotNull, Neg, InList, Case };
 struct Expr {
     EKind kind = EKind::Col;
     int col = -1;  // Col: index into the input schema
@@ -36,10 +36,47 @@ struct Expr {
     std::string s;   // LitS value / Bin operator (Rust enum ident: Eq, NotEq, Lt, LtEq, Gt, GtEq, And, Or, Modulo, Multiply)
     ColType cast_to = ColType::I64;
     std::unique_ptr<Expr> l, r;  // Bin operands; the operand of Cast / Not / IsNull / IsNotNull / Neg / InList in l
-    std::vector<std::unique_ptr<Expr>> list;   // InList: the literals
+    std::vector<std::unique_ptr<Expr>> list;   // InList: the literals; Case: WHEN, THEN, WHEN, THEN, ... (base expression in l, ELSE in r; either may be null)
     bool negated = false;                      // InList: NOT IN
     bool big_unsigned = false;                 // LitI: `i` is the bit pattern of a UInt64 above INT64_MAX
+    bool cast_ts = false;                      // Cast: the target is Timestamp(Millisecond) (Int64 storage)
+    bool try_cast = false;                     // Cast: try_cast_expr (a value that does not fit becomes NULL instead of failing the call)
+    std::string lit_kind;                      // literals: the ScalarValue variant ("Int32", "Float64", ...; empty: a bare JSON value)
 };
+
+// Static type of an expression over `schema`: 0..3 = ColType I32 / I64 / U64 / F64, 4 = Utf8, 5 = Boolean, -1 = an untyped literal (it takes
+// the type of whatever it meets), -2 = no consistent type.  (valprog.hpp: both operands of a binary operator have one type.)
+inline int expr_static_type(const Expr *e, const std::vector<Field> &schema) {
+    auto arith = [](const std::string &op) { return op == "Plus" || op == "Minus" || op == "Multiply" || op == "Divide" || op == "Modulo"; };
+    switch (e->kind) {
+        case EKind::Col: return e->col >= 0 && (size_t)e->col < schema.size() ? (int)schema[(size_t)e->col].type : -2;
+        case EKind::LitI: return e->lit_kind == "Int32" ? 0 : e->lit_kind == "Int64" ? 1 : e->lit_kind == "UInt64" ? 2 : -1;
+        case EKind::LitF: return 3;
+        case EKind::LitS: return 4;
+        case EKind::LitB: return 5;
+        case EKind::LitNull: return -1;
+        case EKind::Cast: return (int)e->cast_to;
+        case EKind::Neg: return expr_static_type(e->l.get(), schema);
+        case EKind::Not: case EKind::IsNull: case EKind::IsNotNull: case EKind::InList: return 5;
+        case EKind::Bin: {
+            if (!arith(e->s)) return 5;
+            const int a = expr_static_type(e->l.get(), schema), b = expr_static_type(e->r.get(), schema);
+            if (a == -2 || b == -2 || a >= 4 || b >= 4) return -2;
+            if (a == -1) return b;
+            if (b == -1 || a == b) return a;
+            // (fixtures of older fork revisions write q1's conversion as `Float64 literal * Int32 column` without the cast the planner inserts)
+            if (e->s == "Multiply" && (e->l->kind == EKind::LitF || e->r->kind == EKind::LitF)) return 3;
+            return -2;
+        }
+        case EKind::Case: {
+            int t = -1;
+            for (size_t i = 1; i < e->list.size() && t == -1; i += 2) t = expr_static_type(e->list[i].get(), schema);
+            if (t == -1 && e->r) t = expr_static_type(e->r.get(), schema);
+            return t;
+        }
+    }
+    return -2;
+}
 
 enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit };
 struct SortCol {
@@ -200,6 +237,7 @@ struct Builder {
                 val = val->obj[0].second.get();
             }
             if (!val) { fail("literal without value"); return nullptr; }
+            x->lit_kind = kind;
             if (val->kind == JValue::Null) { x->kind = EKind::LitNull; return x; }   // ScalarValue::Int32(None) and its siblings
             if (val->kind == JValue::Bool) { x->kind = EKind::LitB; x->i = val->b ? 1 : 0; return x; }
             if (val->kind == JValue::Str) { x->kind = EKind::LitS; x->s = val->str; return x; }
@@ -213,8 +251,10 @@ struct Builder {
         }
         if (t == "cast_expr" || t == "try_cast_expr") {
             x->kind = EKind::Cast;
+            x->try_cast = t == "try_cast_expr";
             bool ts = false;
             if (!parse_type(e->get("cast_type"), &x->cast_to, &ts)) { fail("cast to an unsupported type"); return nullptr; }
+            x->cast_ts = ts;
             x->l = expr(e->get("expr"), schema);
             return x->l ? std::move(x) : nullptr;
         }
@@ -241,6 +281,21 @@ struct Builder {
                 auto li = expr(item.get(), schema);
                 if (!li) return nullptr;
                 x->list.push_back(std::move(li));
+            }
+            return x;
+        }
+        if (t == "case_expr") {   // CaseExpr { expr: Option, when_then_expr: Vec<(when, then)>, else_expr: Option }
+            x->kind = EKind::Case;
+            const JValue *base = e->get("expr"), *wt = e->get("when_then_expr"), *el = e->get("else_expr");
+            if (!wt || wt->kind != JValue::Arr || wt->arr.empty()) { fail("case_expr without when_then_expr"); return nullptr; }
+            if (base && base->kind != JValue::Null && !(x->l = expr(base, schema))) return nullptr;
+            if (el && el->kind != JValue::Null && !(x->r = expr(el, schema))) return nullptr;
+            for (auto &pair : wt->arr) {
+                if (pair->kind != JValue::Arr || pair->arr.size() != 2) { fail("malformed when_then_expr"); return nullptr; }
+                auto w = expr(pair->arr[0].get(), schema), th = expr(pair->arr[1].get(), schema);
+                if (!w || !th) return nullptr;
+                x->list.push_back(std::move(w));
+                x->list.push_back(std::move(th));
             }
             return x;
         }
@@ -330,11 +385,12 @@ struct Builder {
                 if (e->kind == EKind::Col) {
                     const Field &src = in->schema[(size_t)e->col];
                     f.type = src.type; f.is_ts = src.is_ts; f.nullable = src.nullable;
-                } else if (e->kind == EKind::Bin && e->s == "Multiply") {
-                    f.type = ColType::F64;
-                } else {
-                    fail("projection expression other than a column or `literal * column`");
-                    return nullptr;
+                } else {   // computed: q1's `literal * column` kernel, or the general evaluator (valprog.hpp) -- a numeric result either way
+                    const int ty = expr_static_type(e.get(), in->schema);
+                    if (ty < 0 || ty > 3) { fail(ty == 5 ? "projection of a Boolean expression (no Boolean columns at this boundary)" : "projection expression without a numeric type"); return nullptr; }
+                    f.type = (ColType)ty;
+                    f.nullable = true;
+                    f.is_ts = e->kind == EKind::Cast && e->cast_ts;   // CAST(x AS Timestamp(Millisecond))
                 }
                 n->proj.emplace_back(std::move(e), f.name);
                 n->schema.push_back(f);
@@ -564,6 +620,22 @@ inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
     }
 }
 
+// The columns whose NULL makes `e` NULL: reached through arithmetic, comparisons, casts and unary minus only.  A column under CASE, IS [NOT] NULL,
+// IN, NOT, AND / OR does not count -- `CASE WHEN f <= f THEN 100 ELSE i END` has a value where f is NULL.
+inline void strict_cols(const Expr *e, std::set<int> *out) {
+    if (!e) return;
+    switch (e->kind) {
+        case EKind::Col: out->insert(e->col); return;
+        case EKind::Cast: case EKind::Neg: strict_cols(e->l.get(), out); return;
+        case EKind::Bin:
+            if (e->s == "And" || e->s == "Or") return;
+            strict_cols(e->l.get(), out);
+            strict_cols(e->r.get(), out);
+            return;
+        default: return;
+    }
+}
+
 // droppable[c]: dropping the rows of `n`'s output whose column c is NULL leaves the plan's result unchanged.
 inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> &droppable) {
     switch (n->kind) {
@@ -583,7 +655,7 @@ inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> 
                 if (e->kind == EKind::Bin && e->s == "And") { stack.push_back(e->l.get()); stack.push_back(e->r.get()); continue; }
                 if (e->kind == EKind::Bin && e->s != "Or") {
                     std::set<int> cs;
-                    expr_cols(e, &cs);
+                    strict_cols(e, &cs);
                     for (int c : cs) d[(size_t)c] = 1;
                 }
             }

@@ -126,6 +126,174 @@ def eval_physical_expr(e: dict, row: dict):
     raise ValueError("physical_expr " + t)
 
 
+# -- the same dialect WITH its types: arithmetic that wraps at the operand type's width, checked casts, division, CASE ---------------------
+# (the general expression evaluator of the HIP path, flock_amd/csrc/valprog.hpp, states the assumptions; this is their twin: upstream
+# DataFusion ~6 / arrow-rs 6 semantics, not pinned by reference-held vectors)
+class ExprError(Exception):
+    """An expression that fails the whole call: integer division by zero (ArrowError::DivideByZero), a CAST that does not fit."""
+
+
+_INT_RANGE = {"Int32": (-2**31, 2**31 - 1), "Int64": (-2**63, 2**63 - 1), "UInt64": (0, 2**64 - 1)}
+_ARITH = ("Plus", "Minus", "Multiply", "Divide", "Modulo")
+
+
+def _type_name(t):
+    return "Int64" if isinstance(t, dict) and "Timestamp" in t else t
+
+
+def static_type(e: dict, types: dict):
+    """Type of an expression: 'Int32' | 'Int64' | 'UInt64' | 'Float64' | 'Utf8' | 'Boolean', None for a literal that takes the type of what
+    it meets (a bare NULL, a literal of a width the boundary has no column for)."""
+    t = e["physical_expr"]
+    if t == "column":
+        return _type_name(types[e["name"]])
+    if t == "literal":
+        v = e["value"]
+        kind = next(iter(v)) if isinstance(v, dict) else None
+        val = next(iter(v.values())) if isinstance(v, dict) else v
+        if val is None:
+            return None
+        if kind == "Boolean" or isinstance(val, bool):
+            return "Boolean"
+        if kind == "Utf8" or isinstance(val, str):
+            return "Utf8"
+        if kind in ("Float64", "Float32") or isinstance(val, float):
+            return "Float64"
+        return kind if kind in _INT_RANGE else None
+    if t in ("cast_expr", "try_cast_expr"):
+        return _type_name(e["cast_type"])
+    if t == "negative_expr":
+        return static_type(e.get("arg", e.get("expr")), types)
+    if t in ("not_expr", "is_null_expr", "is_not_null_expr", "in_list_expr"):
+        return "Boolean"
+    if t == "binary_expr":
+        if e["op"] not in _ARITH:
+            return "Boolean"
+        a, b = static_type(e["left"], types), static_type(e["right"], types)
+        return a if a is not None else b
+    if t == "case_expr":
+        for _, th in e["when_then_expr"]:
+            ty = static_type(th, types)
+            if ty is not None:
+                return ty
+        return static_type(e["else_expr"], types) if e.get("else_expr") else None
+    raise ValueError("physical_expr " + t)
+
+
+def _wrap(v, ty):
+    if ty in _INT_RANGE:
+        lo, hi = _INT_RANGE[ty]
+        return (v - lo) % (hi - lo + 1) + lo
+    return v
+
+
+def _cast(v, ty, safe):
+    """arrow's numeric cast: a value that does not fit is an error (CAST, safe = false) or NULL (TRY_CAST)."""
+    import math
+    if ty == "Float64":
+        return float(v)
+    if ty in _INT_RANGE:
+        lo, hi = _INT_RANGE[ty]
+        if isinstance(v, float):
+            if math.isnan(v) or math.isinf(v):
+                v = None
+            else:
+                v = int(v)   # truncates towards zero
+        if v is None or v < lo or v > hi:
+            if safe:
+                return None
+            raise ExprError("a value does not fit the type it is cast to")
+        return v
+    return v
+
+
+def eval_typed(e: dict, row: dict, types: dict, want=None):
+    """eval_physical_expr with the column types at hand: + - * and unary - wrap at the operand type's width, integer / and % truncate
+    towards zero and fail the call on a zero divisor in a row whose operands are not NULL, Float64 arithmetic is numpy's (IEEE: x / 0.0 is an
+    infinity or a NaN), CAST is checked, CASE picks the first WHEN that is TRUE (every branch is evaluated for every row, as the fork's
+    CaseExpr evaluates them over the whole batch).  `want`: the type an untyped literal takes."""
+    import numpy as np
+    t = e["physical_expr"]
+    if t in ("column", "literal"):
+        v = eval_physical_expr(e, row)
+        if t == "literal" and isinstance(v, int) and not isinstance(v, bool) and (static_type(e, types) or want) == "Float64":
+            return float(v)
+        return v
+    if t in ("cast_expr", "try_cast_expr"):
+        v = eval_typed(e["expr"], row, types)
+        return None if v is None else _cast(v, _type_name(e["cast_type"]), t == "try_cast_expr")
+    if t == "negative_expr":
+        a = e.get("arg", e.get("expr"))
+        v = eval_typed(a, row, types, want)
+        return None if v is None else _wrap(-v, static_type(a, types) or want)
+    if t == "not_expr":
+        v = eval_typed(e.get("arg", e.get("expr")), row, types, "Boolean")
+        return None if v is None else (not v)
+    if t == "is_null_expr":
+        return eval_typed(e.get("arg", e.get("expr")), row, types) is None
+    if t == "is_not_null_expr":
+        return eval_typed(e.get("arg", e.get("expr")), row, types) is not None
+    if t == "in_list_expr":
+        ty = static_type(e["expr"], types)
+        v = eval_typed(e["expr"], row, types)
+        if v is None:
+            return None
+        hit = any(v == eval_typed(x, row, types, ty) for x in e["list"])
+        return (not hit) if e.get("negated") else hit
+    if t == "case_expr":
+        ty = static_type(e, types) or want
+        out = eval_typed(e["else_expr"], row, types, ty) if e.get("else_expr") else None
+        for w, th in reversed(e["when_then_expr"]):
+            then = eval_typed(th, row, types, ty)
+            if e.get("expr"):
+                tb = static_type(e["expr"], types) or static_type(w, types)
+                a, b = eval_typed(e["expr"], row, types, tb), eval_typed(w, row, types, tb)
+                cond = None if a is None or b is None else a == b
+            else:
+                cond = eval_typed(w, row, types, "Boolean")
+            if cond is True:
+                out = then
+        return out
+    if t == "binary_expr":
+        op = e["op"]
+        if op in ("And", "Or"):
+            a, b = eval_typed(e["left"], row, types, "Boolean"), eval_typed(e["right"], row, types, "Boolean")
+            if op == "And":
+                return False if (a is False or b is False) else (None if (a is None or b is None) else True)
+            return True if (a is True or b is True) else (None if (a is None or b is None) else False)
+        ty = static_type(e["left"], types) or static_type(e["right"], types) or (want if op in _ARITH else None)
+        a, b = eval_typed(e["left"], row, types, ty), eval_typed(e["right"], row, types, ty)
+        if a is None or b is None:
+            return None
+        if op not in _ARITH:
+            return {"Eq": a == b, "NotEq": a != b, "Lt": a < b, "LtEq": a <= b, "Gt": a > b, "GtEq": a >= b}[op]
+        if ty == "Float64" or isinstance(a, float) or isinstance(b, float):
+            x, y = np.float64(a), np.float64(b)
+            with np.errstate(all="ignore"):
+                return float({"Plus": x + y, "Minus": x - y, "Multiply": x * y, "Divide": x / y, "Modulo": np.fmod(x, y)}[op])
+        if op in ("Divide", "Modulo"):
+            if b == 0:
+                raise ExprError("division by zero")
+            if op == "Modulo":
+                return _wrap(_trunc_mod(a, b), ty)
+            q = abs(a) // abs(b)
+            return _wrap(q if (a >= 0) == (b >= 0) else -q, ty)
+        return _wrap({"Plus": a + b, "Minus": a - b, "Multiply": a * b}[op], ty)
+    raise ValueError("physical_expr " + t)
+
+
+def filter_by_typed_expr(t: Table, pred: dict, types: dict) -> Table:
+    """FilterExec through eval_typed."""
+    return filter_exec(t, lambda r: eval_typed(pred, r, types, "Boolean"))
+
+
+def project_typed(t: Table, exprs: Sequence[Tuple[dict, str]], types: dict) -> Table:
+    """ProjectionExec over serialised expressions: [(expr, output name)]."""
+    names = list(t)
+    rs = [dict(zip(names, r)) for r in rows(t)]
+    return {out: [eval_typed(e, r, types, static_type(e, types)) for r in rs] for e, out in exprs}
+
+
 def filter_by_expr(t: Table, pred: dict) -> Table:
     """FilterExec with a serialised predicate: the rows for which it is TRUE."""
     return filter_exec(t, lambda r: eval_physical_expr(pred, r))

@@ -79,6 +79,29 @@ def test_q1_projection_bit_exact(ctx, seed, eps, seconds):
     assert got.dtype == np.float64 and got.tobytes() == want.tobytes()
 
 
+def test_profile_samples_are_the_launches_behind_the_totals(ctx):
+    """flockgpu_profile_samples (round 5): the per-launch durations of one kernel, in launch order, add up to flockgpu_profile_read's total;
+    `profile_only` takes "a|b" for a step that runs one of several kernels; a kernel that never ran has no samples."""
+    from flock_amd import Window, run_query
+    g = _gpu_stream(ctx, 5, 200_000, 3, Window.element_wise())
+    ctx.profile_reset()
+    ctx.profile_only("q2_flag_kernel|no_such_kernel")
+    ctx.profile(True)
+    try:
+        for _ in range(5):
+            run_query(ctx, 2, g)
+        st = ctx.profile_read()
+        smp = ctx.profile_samples("q2_flag_kernel")
+    finally:
+        ctx.profile(False)
+        ctx.profile_only(None)
+    assert sorted(st) == ["q2_flag_kernel"] and st["q2_flag_kernel"]["launches"] == 5 == len(smp)
+    assert all(0 < x < 50 for x in smp) and abs(sum(smp) - st["q2_flag_kernel"]["total_ms"]) < 1e-3
+    assert ctx.profile_samples("no_such_kernel") == []
+    ctx.profile_reset()
+    assert ctx.profile_samples("q2_flag_kernel") == []
+
+
 @pytest.mark.parametrize("seed,eps,seconds", CASES)
 def test_q2_filter_exact_per_epoch(ctx, seed, eps, seconds):
     from flock_amd import Window, run_query

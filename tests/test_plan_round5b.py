@@ -1,0 +1,259 @@
+"""Computed expressions in general (flock_amd/csrc/valprog.hpp, round 5): ProjectionExec columns and FilterExec predicates built from
+arithmetic (+ - * / %, unary -), CAST / TRY_CAST between the numeric types, comparisons of computed values, IN, IS [NOT] NULL and
+CASE -- random expression trees over nullable Int32 / Int64 / Float64 columns, row for row against the oracle's typed evaluator
+(oracle/generic_ops.py: eval_typed, the twin of the assumptions valprog.hpp states: wrapping integer arithmetic, truncating division,
+a zero divisor or a CAST that does not fit fails the call, TRY_CAST yields NULL, Kleene logic, CASE picks the first TRUE WHEN)."""
+import json
+import math
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from oracle import generic_ops as g
+from test_plan_round5 import F, NAMES, batches, binary, cast, col, lit, pyrows, scan, table, unary
+
+TYPES = {f["name"]: f["data_type"] for f in F}
+COLS = {"Int32": ["i", "j"], "Int64": ["l"], "Float64": ["f"]}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from flock_amd import GpuContext
+    c = GpuContext(0)
+    yield c
+    c.close()
+
+
+def try_cast(e, t):
+    return {"physical_expr": "try_cast_expr", "expr": e, "cast_type": t}
+
+
+def case(whens, els=None, base=None):
+    return {"physical_expr": "case_expr", "expr": base, "when_then_expr": [[w, t] for w, t in whens], "else_expr": els}
+
+
+def rand_lit(r, ty, nonzero=False):
+    if ty == "Float64":
+        v = float(r.choice([0.5, -2.0, 3.25, 10.0, -0.1, 1e9]))
+        return lit("Float64", v)
+    v = int(r.choice([1, -1, 2, 3, 7, -13, 100, 65_537, 2**31 - 1] if ty == "Int32" else [1, -1, 2, 5, -9, 1000, 2**33 + 1, 2**62]))
+    if not nonzero and r.random() < 0.15:
+        v = 0
+    return lit(ty, v)
+
+
+def rand_value(r, ty, depth):
+    """An expression of type `ty`; divisors are non-zero literals or columns wrapped in CASE WHEN x = 0 THEN 1 ELSE x END."""
+    if depth == 0 or r.random() < 0.2:
+        return col(str(r.choice(COLS[ty]))) if r.random() < 0.7 else rand_lit(r, ty)
+    k = r.random()
+    if k < 0.45:
+        op = str(r.choice(["Plus", "Minus", "Multiply"]))
+        return binary(rand_value(r, ty, depth - 1), op, rand_value(r, ty, depth - 1))
+    if k < 0.6:
+        op = str(r.choice(["Divide", "Modulo"]))
+        if ty == "Float64" or r.random() < 0.5:
+            d = rand_lit(r, ty, nonzero=True)
+        else:
+            c = col(str(r.choice(COLS[ty])))
+            d = case([(binary(c, "Eq", lit(ty, 0)), lit(ty, 1))], c)
+        return binary(rand_value(r, ty, depth - 1), op, d)
+    if k < 0.7:
+        return unary("negative_expr", rand_value(r, ty, depth - 1))
+    if k < 0.85:   # a cast from another type: widening ones checked, narrowing ones TRY_CAST (NULL where the value does not fit)
+        src = str(r.choice([t for t in COLS if t != ty]))
+        inner = rand_value(r, src, depth - 1)
+        widening = (src, ty) in (("Int32", "Int64"), ("Int32", "Float64"), ("Int64", "Float64"))
+        return cast(inner, ty) if widening else try_cast(inner, ty)
+    whens = [(rand_bool(r, depth - 1), rand_value(r, ty, depth - 1)) for _ in range(int(r.integers(1, 3)))]
+    return case(whens, rand_value(r, ty, depth - 1) if r.random() < 0.6 else None)
+
+
+def rand_bool(r, depth):
+    k = r.random()
+    if depth == 0 or k < 0.5:
+        ty = str(r.choice(list(COLS)))
+        op = str(r.choice(["Eq", "NotEq", "Lt", "LtEq", "Gt", "GtEq"]))
+        return binary(rand_value(r, ty, max(depth - 1, 0)), op, rand_value(r, ty, max(depth - 1, 0)))
+    if k < 0.6:
+        return unary("is_null_expr" if r.random() < 0.5 else "is_not_null_expr", rand_value(r, str(r.choice(list(COLS))), depth - 1))
+    if k < 0.7:
+        ty = str(r.choice(["Int32", "Int64"]))
+        return {"physical_expr": "in_list_expr", "expr": rand_value(r, ty, depth - 1), "negated": bool(r.random() < 0.4),
+                "list": [rand_lit(r, ty) for _ in range(int(r.integers(1, 4)))]}
+    if k < 0.8:
+        return unary("not_expr", rand_bool(r, depth - 1))
+    return binary(rand_bool(r, depth - 1), "And" if k < 0.9 else "Or", rand_bool(r, depth - 1))
+
+
+def norm(rows):
+    """NaN compares unequal to itself: rows with their NaNs named."""
+    return [tuple("nan" if isinstance(v, float) and math.isnan(v) else v for v in row) for row in rows]
+
+
+def out_field(name, ty):
+    return {"data_type": ty, "dict_id": 0, "dict_is_ordered": False, "name": name, "nullable": True}
+
+
+def projection(exprs):
+    fields = [out_field(n, g.static_type(e, TYPES) or "Int64") for e, n in exprs]
+    return {"execution_plan": "projection_exec", "expr": [[e, n] for e, n in exprs], "input": scan(), "schema": {"fields": fields, "metadata": {}}}
+
+
+# ------------------------------------------------------------------ CPU: the oracle's typed evaluator on hand-worked rows
+def test_oracle_typed_arithmetic_by_hand():
+    row = {"i": 2**31 - 1, "j": -2**31, "l": -7, "f": 2.5, "s": None, "u": 2**64 - 1}
+    ev = lambda e: g.eval_typed(e, row, TYPES)
+    assert ev(binary(col("i"), "Plus", lit("Int32", 1))) == -2**31                      # wraps at the operand's width
+    assert ev(binary(col("j"), "Divide", lit("Int32", -1))) == -2**31                   # INT_MIN / -1 wraps
+    assert ev(binary(cast(col("i"), "Int64"), "Plus", lit("Int64", 1))) == 2**31        # ... and does not after the widening cast
+    assert ev(binary(col("l"), "Divide", lit("Int64", 2))) == -3 and ev(binary(col("l"), "Modulo", lit("Int64", 2))) == -1   # truncation
+    assert ev(binary(col("u"), "Plus", lit("UInt64", 2))) == 1
+    assert ev(binary(col("f"), "Divide", lit("Float64", 0.0))) == math.inf and math.isnan(ev(binary(lit("Float64", 0.0), "Divide", lit("Float64", 0.0))))
+    assert ev(binary(col("f"), "Modulo", lit("Float64", -2.0))) == 0.5
+    with pytest.raises(g.ExprError):
+        ev(binary(col("l"), "Divide", lit("Int64", 0)))
+    assert g.eval_typed(binary(col("l"), "Divide", lit("Int64", 0)), dict(row, l=None), TYPES) is None   # a NULL row never looks at the divisor
+    with pytest.raises(g.ExprError):
+        ev(cast(binary(cast(col("i"), "Int64"), "Plus", lit("Int64", 1)), "Int32"))
+    assert ev(try_cast(binary(cast(col("i"), "Int64"), "Plus", lit("Int64", 1)), "Int32")) is None
+    assert ev(cast(binary(col("f"), "Multiply", lit("Float64", -1.0)), "Int64")) == -2 and ev(try_cast(lit("Float64", -0.9), "UInt64")) == 0
+    c = case([(binary(col("l"), "Lt", lit("Int64", -10)), lit("Int64", 1)), (binary(col("l"), "Lt", lit("Int64", 0)), lit("Int64", 2))])
+    assert ev(c) == 2 and g.eval_typed(c, dict(row, l=5), TYPES) is None and g.eval_typed(c, dict(row, l=None), TYPES) is None
+    assert ev(case([(lit("Int64", -7), lit("Int32", 1))], lit("Int32", 0), base=col("l"))) == 1        # CASE l WHEN -7 THEN 1 ELSE 0
+    assert g.static_type(binary(lit("Int64", 1), "Plus", col("l")), TYPES) == "Int64" and g.static_type(c, TYPES) == "Int64"
+
+
+def test_expression_tags_of_the_general_evaluator_parse():
+    from flock_amd import FlockGpuError
+    from flock_amd.runtime import explain
+    e1 = binary(binary(col("i"), "Plus", col("j")), "Divide", lit("Int32", 3))
+    e2 = case([(binary(col("l"), "Gt", lit("Int64", 0)), cast(col("i"), "Float64"))], col("f"))
+    txt = explain(projection([(col("j"), "j"), (e1, "x"), (e2, "y"), (try_cast(col("f"), "Int64"), "z")]))
+    assert "Project" in txt
+    with pytest.raises(FlockGpuError) as e:   # no Boolean columns at this boundary
+        explain(projection([(binary(col("i"), "Lt", col("j")), "b")]))
+    assert "Boolean" in str(e.value)
+    with pytest.raises(FlockGpuError) as e:
+        explain(projection([(binary(col("i"), "Plus", col("l")), "x")]))        # Int32 + Int64: the planner would have cast
+    assert "numeric type" in str(e.value)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_projections_and_filters_over_random_expressions(gpu, seed):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(7000 + seed)
+    n = [1, 300, 4097, 20_000][seed % 4]
+    t = table(n, r, null_p=[0.0, 0.2, 0.5][seed % 3])
+    ran = 0
+
+    def run(plan, chunk):   # None: the tree outgrew one program (96 operators, stack of 8) -- refused by name, never truncated
+        ctx = ExecutionContext([plan], gpu=gpu)
+        try:
+            return collect(ctx, [[batches(t, chunk)]])[0][0]
+        except FlockGpuError as e:
+            assert e.code == _ffi.ERR_UNSUPPORTED and "expression too large" in str(e), str(e)
+            return None
+        finally:
+            ctx.close()
+    for trial in range(3):
+        exprs = [(col("j"), "j")] + [(rand_value(r, str(r.choice(list(COLS))), 3), "x%d" % k) for k in range(int(r.integers(1, 4)))]
+        rb = run(projection(exprs), max(1, n // 2))
+        if rb is not None:
+            ran += 1
+            want = g.project_typed(t, exprs, TYPES)
+            assert norm(pyrows(rb)) == norm(g.rows(want)), (seed, trial, json.dumps(exprs))
+            assert [str(f.type) for f in rb.schema] == [{"Int32": "int32", "Int64": "int64", "Float64": "double"}[g.static_type(e, TYPES)] for e, _ in exprs]
+        pred = rand_bool(r, 3)
+        rb = run({"execution_plan": "filter_exec", "predicate": pred, "input": scan()}, max(1, n // 3))
+        if rb is not None:
+            ran += 1
+            assert norm(pyrows(rb)) == norm(g.rows(g.filter_by_typed_expr(t, pred, TYPES))), (seed, trial, json.dumps(pred))
+    assert ran >= 4, ran
+
+
+@pytest.mark.gpu
+def test_a_zero_divisor_or_an_unfit_cast_fails_the_call_and_try_cast_does_not(gpu):
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(3)
+    t = table(5000, r, null_p=0.3)
+    t["i"][1234] = 0
+    t["l"][77] = 2**35
+
+    def run(plan):
+        ctx = ExecutionContext([plan], gpu=gpu)
+        try:
+            return collect(ctx, [[batches(t, 2500)]])[0][0]
+        finally:
+            ctx.close()
+    for bad, what in ((binary(col("j"), "Divide", col("i")), "division by zero"), (binary(col("l"), "Modulo", lit("Int64", 0)), "division by zero"),
+                      (cast(col("l"), "Int32"), "does not fit")):
+        with pytest.raises(FlockGpuError) as e:
+            run(projection([(bad, "x")]))
+        assert e.value.code == _ffi.ERR_INVALID and what in str(e.value), str(e.value)
+    # the same divisor with its zero (and only its zero) made NULL: the row is NULL, the call stands
+    t["i"][1234] = None
+    e = binary(col("j"), "Divide", col("i"))
+    exprs = [(e, "q"), (try_cast(col("l"), "Int32"), "n"), (binary(col("f"), "Divide", lit("Float64", 0.0)), "inf")]
+    if all(v != 0 for v in t["i"] if v is not None):
+        assert norm(pyrows(run(projection(exprs)))) == norm(g.rows(g.project_typed(t, exprs, TYPES)))
+    else:   # the generator drew another zero: the error it is
+        with pytest.raises(FlockGpuError):
+            run(projection(exprs))
+    # in a filter: rows an error sits in fail the call even when another conjunct would have dropped them (the whole batch is evaluated)
+    with pytest.raises(FlockGpuError):
+        run({"execution_plan": "filter_exec", "predicate": binary(binary(col("l"), "Divide", lit("Int64", 0)), "Gt", lit("Int64", 1)), "input": scan()})
+
+
+@pytest.mark.gpu
+def test_q1_conversion_keeps_its_own_kernel_and_other_products_take_the_evaluator(gpu):
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(5)
+    t = table(3000, r, null_p=0.1)
+    q1 = binary(lit("Float64", 0.908), "Multiply", cast(col("j"), "Float64"))
+    other = binary(lit("Float64", 0.908), "Multiply", cast(col("l"), "Float64"))
+    for e, kernel in ((q1, "q1_project_kernel"), (other, "valprog_kernel")):
+        ctx = ExecutionContext([projection([(e, "x")])], gpu=gpu)
+        gpu.profile_reset()
+        gpu.profile(True)
+        try:
+            rb = collect(ctx, [[batches(t, 3000)]])[0][0]
+            ran = gpu.profile_read()
+        finally:
+            gpu.profile(False)
+            ctx.close()
+        assert kernel in ran and ("valprog_kernel" in ran) == (kernel == "valprog_kernel"), sorted(ran)
+        assert norm(pyrows(rb)) == norm(g.rows(g.project_typed(t, [(e, "x")], TYPES)))
+
+
+@pytest.mark.gpu
+def test_casts_that_change_values_are_not_looked_through_in_predicates(gpu):
+    """The one-pass predicate program compares a column through casts that change nothing (Int32 -> Int64 / Float64); a cast that truncates
+    (Float64 -> Int64), may not fit (TRY_CAST Int64 -> Int32: NULL) or changes signedness goes to the general evaluator with its value."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(11)
+    t = table(6000, r, null_p=0.2)
+    preds = [binary(cast(col("f"), "Int64"), "Eq", lit("Int64", 3)),                          # 3.0 .. 3.9 all match
+             binary(try_cast(col("l"), "Int32"), "Lt", lit("Int32", 5)),                      # |l| >= 2^31: NULL, dropped
+             unary("is_null_expr", try_cast(col("l"), "Int32")),                              # ... and IS NULL sees exactly those (and the NULLs)
+             binary(try_cast(col("u"), "Int64"), "GtEq", lit("Int64", 0)),                    # UInt64 above 2^63 - 1: NULL
+             binary(cast(col("i"), "Int64"), "Lt", lit("Int64", 7)),                          # (value-preserving: the one-pass program's)
+             binary(binary(cast(col("i"), "Float64"), "Divide", lit("Float64", 4.0)), "Gt", lit("Float64", 10.1))]
+    for pred in preds:
+        ctx = ExecutionContext([{"execution_plan": "filter_exec", "predicate": pred, "input": scan()}], gpu=gpu)
+        gpu.profile_reset()
+        gpu.profile(True)
+        try:
+            rb = collect(ctx, [[batches(t, 2000)]])[0][0]
+            ran = gpu.profile_read()
+        finally:
+            gpu.profile(False)
+            ctx.close()
+        want = g.rows(g.filter_by_typed_expr(t, pred, TYPES))
+        assert norm(pyrows(rb)) == norm(want) and 0 < len(want) < 6000, json.dumps(pred)
+        assert ("pred_flag_kernel" in ran) == (pred is preds[4]) and ("valprog_kernel" in ran) == (pred is not preds[4]), (json.dumps(pred), sorted(ran))
