@@ -82,7 +82,13 @@ struct ArrowArray {
 typedef struct flockgpu_plan flockgpu_plan;
 
 /* Parses the plan JSON and builds the operator tree.  FLOCKGPU_ERR_PLAN: not JSON; FLOCKGPU_ERR_UNSUPPORTED: a node,
- * expression or type the engine does not execute (flockgpu_last_error names it). */
+ * expression or type the engine does not execute (flockgpu_last_error names it).
+ * Expressions (`physical_expr` tags): column, literal, cast_expr, try_cast_expr, binary_expr (Eq NotEq Lt LtEq Gt GtEq And Or Plus Minus
+ * Multiply Divide Modulo), not_expr, is_null_expr, is_not_null_expr, negative_expr, in_list_expr, case_expr -- over Int32 / Int64 / UInt64 /
+ * Float64 / Timestamp(Millisecond) values (Utf8: =, <>, IN, IS NULL against literals).  Both operands of a binary operator have one type,
+ * as the reference's planner leaves them.  At execute, integer division / modulo by zero in a row whose operands are not NULL and a
+ * CAST whose value does not fit its target are FLOCKGPU_ERR_INVALID for the call (the reference's execute fails with an ArrowError);
+ * TRY_CAST yields NULL instead. */
 int flockgpu_plan_create(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan **out);
 /* The same with options.  FLOCKGPU_PLAN_GENERIC_ONLY: no sub-tree is handed to a fused NEXMark pipeline, every node runs on the
  * generic device operators -- how the tests run every reference plan both ways and require identical rows. */
