@@ -403,6 +403,40 @@ struct Builder {
             auto in = node(j->get("input"), depth + 1);
             if (!in) return nullptr;
             const bool is_final = n->mode != "Partial";
+            // A group key or an aggregate argument that is an EXPRESSION (GROUP BY a % 10, SUM(price * 2)): the stage that evaluates it
+            // (Partial) gets a projection underneath that carries every input column through and the expression's value beside them
+            // (the general evaluator, valprog.hpp); the aggregate then reads a column, as ever.  -1: refused (plan->why says why).
+            bool wrapped = false;
+            auto computed = [&](const JValue *e, const char *what) -> int {
+                if (!wrapped) {
+                    std::unique_ptr<Node> w(new Node());
+                    w->kind = NKind::Project;
+                    w->id = plan->n_nodes++;
+                    w->schema = in->schema;
+                    for (size_t i = 0; i < in->schema.size(); ++i) {
+                        std::unique_ptr<Expr> c(new Expr());
+                        c->kind = EKind::Col;
+                        c->col = (int)i;
+                        w->proj.emplace_back(std::move(c), in->schema[i].name);
+                    }
+                    w->in.push_back(std::move(in));
+                    in = std::move(w);
+                    wrapped = true;
+                }
+                const std::vector<Field> &below = in->in[0]->schema;
+                auto x = expr(e, below);
+                if (!x) return -1;
+                const int ty = expr_static_type(x.get(), below);
+                if (ty < 0 || ty > 3) { fail(std::string(what) + " over an expression without a numeric type"); return -1; }
+                Field f;
+                f.name = "#" + std::to_string(in->schema.size());
+                f.type = (ColType)ty;
+                f.nullable = true;
+                f.is_ts = x->kind == EKind::Cast && x->cast_ts;
+                in->proj.emplace_back(std::move(x), f.name);
+                in->schema.push_back(f);
+                return (int)in->schema.size() - 1;
+            };
             const JValue *ge = j->get("group_expr");
             size_t gi = 0;
             if (ge && ge->kind == JValue::Arr)
@@ -413,7 +447,8 @@ struct Builder {
                     int c = -1;
                     if (is_final && gi < in->schema.size()) c = (int)gi;
                     else if (etag(pair->arr[0].get()) == "column") c = resolve(pair->arr[0].get(), in->schema);
-                    if (c < 0) { fail("GROUP BY on something other than an input column"); return nullptr; }
+                    else if (!is_final) c = computed(pair->arr[0].get(), "GROUP BY");
+                    if (c < 0) { fail("GROUP BY on something that is neither an input column nor a numeric expression"); return nullptr; }
                     n->group.push_back(c);
                     Field f = in->schema[(size_t)c];
                     f.name = pair->arr[1]->kind == JValue::Str ? pair->arr[1]->str : f.name;
@@ -443,8 +478,11 @@ struct Builder {
                         if (arg && etag(arg) == "column") {
                             a.arg = resolve(arg, in->schema);
                             if (a.arg < 0) { fail("aggregate argument not in the input schema"); return nullptr; }
+                        } else if (arg && etag(arg) != "literal") {   // SUM(price * 2), COUNT(CASE ...): the expression becomes a column underneath
+                            a.arg = computed(arg, ("aggregate '" + a.fn + "'").c_str());
+                            if (a.arg < 0) return nullptr;
                         } else if (a.fn != "count") {
-                            fail("aggregate '" + a.fn + "' over a computed expression");
+                            fail("aggregate '" + a.fn + "' over a literal");
                             return nullptr;
                         }
                     }

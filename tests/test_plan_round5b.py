@@ -257,3 +257,48 @@ def test_casts_that_change_values_are_not_looked_through_in_predicates(gpu):
         want = g.rows(g.filter_by_typed_expr(t, pred, TYPES))
         assert norm(pyrows(rb)) == norm(want) and 0 < len(want) < 6000, json.dumps(pred)
         assert ("pred_flag_kernel" in ran) == (pred is preds[4]) and ("valprog_kernel" in ran) == (pred is not preds[4]), (json.dumps(pred), sorted(ran))
+
+
+def _agg_over_expressions(key_expr, aggs):
+    """GROUP BY <expression> with aggregates over expressions: Partial -> Hash -> FinalPartitioned, as the reference's planner lays it out
+    (the Final stage reads the Partial stage's columns by position)."""
+    def ae(fn, arg, dt, k):
+        return {"aggregate_expr": fn, "name": "%s(#%d)" % (fn.upper(), k), "data_type": dt, "nullable": True, "expr": arg if arg is not None else lit("UInt8", 1)}
+    exprs = [ae(fn, arg, dt, k) for k, (fn, arg, dt) in enumerate(aggs)]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[key_expr, "k"]], "aggr_expr": exprs, "input": scan(),
+            "input_schema": {"fields": F, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+    kc = {"physical_expr": "column", "name": "k", "index": 0}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[kc], 4]}}
+    return {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[kc, "k"]], "aggr_expr": exprs, "input": rep,
+            "input_schema": {"fields": F, "metadata": {}}, "schema": {"fields": [], "metadata": {}}}
+
+
+def test_aggregates_over_expressions_parse_with_a_projection_underneath():
+    from flock_amd.runtime import explain
+    txt = explain(_agg_over_expressions(binary(col("j"), "Modulo", lit("Int32", 10)), [("sum", binary(cast(col("i"), "Int64"), "Multiply", lit("Int64", 2)), "Int64")]))
+    assert txt.count("Aggregate") == 2 and "Project" in txt, txt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_group_by_and_aggregates_over_expressions(gpu, seed):
+    """GROUP BY j % 10 / CASE ... with COUNT(*), COUNT(expr), SUM / MIN / MAX(expr): the expressions become columns of a projection under
+    the Partial stage; groups equal the oracle's GROUP BY over its own projected columns (NULL keys form one group, NULL arguments are
+    skipped)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(400 + seed)
+    n = [500, 9000, 40_000, 9000][seed]
+    t = table(n, r, null_p=[0.0, 0.2, 0.4, 0.2][seed])
+    key = [binary(col("j"), "Modulo", lit("Int32", 10)),
+           binary(cast(col("i"), "Int64"), "Divide", lit("Int64", 7)),                                         # NULL where i is
+           case([(binary(col("l"), "Lt", lit("Int64", 0)), lit("Int32", -1)), (binary(col("f"), "Gt", lit("Float64", 10.0)), lit("Int32", 1))], lit("Int32", 0)),
+           binary(binary(col("j"), "Modulo", lit("Int32", 1000)), "Multiply", lit("Int32", 1_000_003))][seed]   # keys spread wide: the hash table
+    aggs = [("count", None, "UInt64"), ("count", binary(col("i"), "Plus", lit("Int32", 1)), "UInt64"),
+            ("sum", binary(cast(col("i"), "Int64"), "Multiply", lit("Int64", 3)), "Int64"),
+            [("max", binary(col("l"), "Minus", cast(col("j"), "Int64")), "Int64"), ("min", unary("negative_expr", col("i")), "Int32")][seed % 2]]   # (four accumulators per GROUP BY)
+    ctx = ExecutionContext([_agg_over_expressions(key, aggs)], gpu=gpu)
+    rb = collect(ctx, [[batches(t, max(1, n // 2))]])[0][0]
+    ctx.close()
+    cols = g.project_typed(t, [(key, "k")] + [(a if a is not None else lit("Int32", 1), "a%d" % k) for k, (_, a, _) in enumerate(aggs)], TYPES)
+    want = g.hash_aggregate_exec(cols, ["k"], [("o%d" % k, fn, None if a is None else "a%d" % k) for k, (fn, a, _) in enumerate(aggs)])
+    assert sorted(norm(pyrows(rb)), key=repr) == sorted(norm(g.rows(want)), key=repr), (seed, len(rb), len(want["k"]))
