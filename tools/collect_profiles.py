@@ -10,6 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+if tag.startswith("-"):
+    sys.exit("usage: collect_profiles.py <tag, e.g. r05>")
 src, dst = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 for f in sorted(os.listdir(src)):
@@ -63,5 +65,11 @@ for q, kern in ROWS:
         except Exception:
             pass
         traffic[name + "_detail"] = detail
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+# rows whose PMC passes were not part of this collection keep the entry of the collection that had them (a partial re-profile -- QUERIES / SIDES /
+# GENERALS of tools/gpu_profile.sh -- must not drop the others' traffic)
+_path = os.path.join(ROOT, "profiles", "traffic.json")
+if os.path.exists(_path):
+    for k, v in json.load(open(_path)).items():
+        traffic.setdefault(k, v)
+json.dump(traffic, open(_path, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
