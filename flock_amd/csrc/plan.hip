@@ -216,6 +216,11 @@ struct flockgpu_plan {
     // pays one 4-byte-per-row pass per fed window.
     struct ColStat { int64_t rows, mn, mx; };
     std::map<const void *, ColStat> col_stats;
+    // ---- common sub-plans: the signature of every Aggregate sub-tree that occurs more than once in the plan (q5's SQL names its
+    // COUNT(*) GROUP BY auction subquery in both join inputs, q5_plan.fmt:6,13) and the scan leaves underneath it, by node id; an execute
+    // runs such a sub-tree once per (signature, leaves its scans resolve to) and hands the table to its twins (Exec::memo)
+    std::vector<std::string> twin_sig;               // empty: the node has no twin
+    std::vector<std::vector<int>> twin_leaves;
     // ---- hash-placement guard: the scheme tag of the co-partitioned inputs fed since the last reset (-1: none fed yet)
     int scheme_state = -1;       // 0: untagged batches, 1: tagged with scheme_tag
     std::string scheme_tag;
@@ -730,6 +735,62 @@ int classify(const flockgpu_plan *pl) {
     }
 }
 
+// ---- structural signatures (flockgpu_plan::twin_sig): everything about a sub-tree that decides the table it produces, leaves by their
+// scanned columns (which leaf DATA a scan reads is decided per execute: Exec::resolve_leaf)
+void expr_sig(const Expr *e, std::string *o) {
+    if (!e) { *o += "~"; return; }
+    *o += "(" + std::to_string((int)e->kind) + "," + std::to_string(e->col) + "," + std::to_string(e->i) + "," + std::to_string(e->f) + "," + e->s + "," +
+          std::to_string((int)e->cast_to) + (e->negated ? "n" : "") + (e->big_unsigned ? "u" : "") + (e->try_cast ? "t" : "") + (e->cast_ts ? "s" : "") + "," + e->lit_kind;
+    expr_sig(e->l.get(), o);
+    expr_sig(e->r.get(), o);
+    for (auto &x : e->list) expr_sig(x.get(), o);
+    *o += ")";
+}
+void node_sig(const flockgpu_plan *pl, const Node *n, bool top, std::string *o, std::vector<int> *leaves) {
+    *o += "[" + std::to_string((int)n->kind) + ":";
+    for (size_t i = 0; i < n->schema.size(); ++i)
+        *o += n->schema[i].name + "/" + std::to_string((int)n->schema[i].type) + (n->schema[i].is_ts ? "t" : "") + (n->schema[i].nullable ? "?" : "") +
+              (!top && i < n->required.size() && n->required[i] ? "!" : "") + ",";   // (an Aggregate computes every output column: its own `required` does not matter)
+    *o += "|" + n->mode + "|";
+    for (int c : n->group) *o += std::to_string(c) + ",";
+    for (auto &a : n->aggs) *o += a.fn + "." + std::to_string(a.arg) + "." + std::to_string(a.arg2) + "." + std::to_string((int)a.type) + ",";
+    *o += "|" + std::to_string(n->on_l) + "," + std::to_string(n->on_r) + "," + std::to_string(n->on_l2) + "," + std::to_string(n->on_r2) + (n->join_partitioned ? "p" : "") + "|";
+    for (int c : n->hash_cols) *o += std::to_string(c) + ",";
+    *o += std::to_string(n->n_parts) + "|";
+    for (auto &k : n->sort_cols) *o += std::to_string(k.col) + (k.descending ? "d" : "a") + (k.nulls_first ? "f" : "l") + ",";
+    *o += std::to_string(n->limit) + "|";
+    expr_sig(n->pred.get(), o);
+    for (auto &pr : n->proj) { expr_sig(pr.first.get(), o); *o += pr.second + ","; }
+    if (n->kind == NKind::Scan) {
+        leaves->push_back(n->leaf);
+        *o += pl->ir.leaves[(size_t)n->leaf].relation;
+    }
+    for (auto &c : n->in) node_sig(pl, c.get(), false, o, leaves);
+    *o += "]";
+}
+void find_twins(flockgpu_plan *pl) {
+    pl->twin_sig.assign((size_t)pl->ir.n_nodes, std::string());
+    pl->twin_leaves.assign((size_t)pl->ir.n_nodes, std::vector<int>());
+    std::map<std::string, std::vector<const Node *>> by_sig;
+    std::vector<std::vector<int>> leaves((size_t)pl->ir.n_nodes);
+    std::vector<const Node *> walk{pl->ir.root.get()};
+    while (!walk.empty()) {
+        const Node *n = walk.back();
+        walk.pop_back();
+        for (auto &c : n->in) walk.push_back(c.get());
+        if (n->kind != NKind::Aggregate) continue;
+        std::string sig;
+        node_sig(pl, n, true, &sig, &leaves[(size_t)n->id]);
+        by_sig[sig].push_back(n);
+    }
+    for (auto &kv : by_sig)
+        if (kv.second.size() > 1)
+            for (const Node *n : kv.second) {
+                pl->twin_sig[(size_t)n->id] = kv.first;
+                pl->twin_leaves[(size_t)n->id] = leaves[(size_t)n->id];
+            }
+}
+
 int parse_and_build(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockgpu_plan *pl, uint32_t flags = 0) {
     JParser jp{plan_json, plan_json + len, {}};
     JPtr root;
@@ -740,6 +801,7 @@ int parse_and_build(flockgpu_ctx *ctx, const char *plan_json, size_t len, flockg
     pl->fused.assign((size_t)pl->ir.n_nodes, FusedInfo{});
     recognise_fused(pl, pl->ir.root.get());
     pl->query = classify(pl);
+    find_twins(pl);
     std::ostringstream os;
     describe(pl, pl->ir.root.get(), 0, os);
     pl->description = os.str();
@@ -922,6 +984,7 @@ namespace {
 struct Exec {
     flockgpu_plan *pl;
     flockgpu_ctx *ctx;
+    std::map<std::string, Table> memo;   // this execute's tables of the sub-trees that have twins (flockgpu_plan::twin_sig)
 
     // A relation the SQL scans twice (q5 and q7 read `bid` in both join inputs, q5_plan.fmt:6,13) has two MemoryExec leaves
     // but arrives as ONE source, which feed_data_sources hands to the first matching leaf (context.rs:273-300) -- the
@@ -1815,8 +1878,22 @@ struct Exec {
                 }
                 return FLOCKGPU_OK;
             }
-            case NKind::Aggregate:
-                return exec_aggregate(n, t);
+            case NKind::Aggregate: {
+                const std::string &sig = pl->twin_sig[(size_t)n->id];
+                if (sig.empty()) return exec_aggregate(n, t);
+                // the sub-tree occurs more than once: one run per (signature, the leaves its scans read today); the twins get the table --
+                // views of the first run's buffers, which nothing writes again before the next execute
+                std::string key = sig;
+                for (int leaf : pl->twin_leaves[(size_t)n->id]) key += "#" + std::to_string(resolve_leaf(leaf));
+                auto it = memo.find(key);
+                if (it != memo.end()) {
+                    *t = it->second;
+                    return FLOCKGPU_OK;
+                }
+                FG_TRY(exec_aggregate(n, t));
+                memo[key] = *t;
+                return FLOCKGPU_OK;
+            }
             case NKind::Sort:
                 return exec_sort(n, -1, t);
             case NKind::Limit: {

@@ -302,3 +302,31 @@ def test_group_by_and_aggregates_over_expressions(gpu, seed):
     cols = g.project_typed(t, [(key, "k")] + [(a if a is not None else lit("Int32", 1), "a%d" % k) for k, (_, a, _) in enumerate(aggs)], TYPES)
     want = g.hash_aggregate_exec(cols, ["k"], [("o%d" % k, fn, None if a is None else "a%d" % k) for k, (fn, a, _) in enumerate(aggs)])
     assert sorted(norm(pyrows(rb)), key=repr) == sorted(norm(g.rows(want)), key=repr), (seed, len(rb), len(want["k"]))
+
+
+@pytest.mark.gpu
+def test_a_subquery_named_twice_runs_once(gpu):
+    """q5's SQL names its COUNT(*) GROUP BY auction subquery in both join inputs (q5_plan.fmt:6,13), and only one of the plan's two `bid`
+    leaves is ever fed: on the generic operators the aggregate sub-tree runs ONCE per execute (a memo keyed on the sub-tree's signature and
+    the leaves its scans resolve to) and the result is the fused pipeline's."""
+    import os
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext, collect
+    plan = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "plans", "q5.json")))
+    b = NEXMarkSource(4, 50_000, Window.element_wise(), seed=3).generate_data(gpu).bids
+    rel = pa.record_batch([pa.array(b.auction.cpu().numpy()), pa.array(b.bidder.cpu().numpy()), pa.array(b.price.cpu().numpy()),
+                           pa.array(b.b_date_time.cpu().numpy()).cast(pa.timestamp("ms"))], names=["auction", "bidder", "price", "b_date_time"])
+    rows = {}
+    for mode in ("generic", "fused"):
+        ctx = ExecutionContext([plan], gpu=gpu, generic_only=(mode == "generic"))
+        gpu.profile_reset()
+        gpu.profile(True)
+        try:
+            rows[mode] = sorted(pyrows(collect(ctx, [[[rel]]])[0][0]))
+            ran = gpu.profile_read()
+        finally:
+            gpu.profile(False)
+            ctx.close()
+        if mode == "generic":
+            assert ran["dense_group_kernel"]["launches"] == 1, ran
+    assert rows["generic"] == rows["fused"] and len(rows["fused"]) >= 1
