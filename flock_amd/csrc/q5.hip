@@ -316,18 +316,12 @@ __global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__
 // kWeighted: every row carries a count (the FinalPartitioned side of q5.dag: rows are the partial groups another
 // partition sent); keys are then (nearly) distinct inside a tile, so no hot-key bookkeeping.
 template <bool kWeighted>
-__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, const uint32_t *__restrict__ weight,
-                                                          SegTiles st, const PaneDesc *__restrict__ panes,
-                                                          const int32_t *__restrict__ pane_win_ptr,
-                                                          const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
-                                                          uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
-                                                          int32_t *slow_list, const uint64_t *__restrict__ spec_info,
-                                                          unsigned long long *pane_wsum) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[kWeighted ? 4 : kHist + kHistPad];
-    __shared__ int32_t s_red[8];
-    __shared__ unsigned long long s_w[kWavesPerBlock];
-    if (spec_info && !spec_info[2]) return;  // the device layout declined this call
-    const TileRange tr = locate_tile(st, (int32_t)blockIdx.x, kQ5Tile);
+__device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auction, const uint32_t *__restrict__ weight, const SegTiles &st,
+                                              const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_win_ptr,
+                                              const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap,
+                                              uint32_t *tab_used, uint32_t *err, int32_t *slow_list, unsigned long long *pane_wsum, const int32_t tile,
+                                              uint32_t *hist, int32_t *s_red, unsigned long long *s_w) {
+    const TileRange tr = locate_tile(st, tile, kQ5Tile);
     FlushArgs f;
     f.wp0 = pane_win_ptr[tr.seg];
     f.wp1 = pane_win_ptr[tr.seg + 1];
@@ -424,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     mx = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
     const uint32_t span = (uint32_t)mx - (uint32_t)mn;
     if (span >= (uint32_t)kHist) {  // keys spread wider than the histogram: general path in q5_count_slow_kernel
-        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)(blockIdx.x | kWideTile);
+        if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)((uint32_t)tile | kWideTile);
         return;
     }
     // hot key of this wave, kept in scalar registers across iterations
@@ -485,6 +479,28 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
         }
         if (c) emit_pair((int32_t)((uint32_t)mn + s), c, f);
     }
+}
+
+template <bool kWeighted>
+__global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restrict__ auction, const uint32_t *__restrict__ weight,
+                                                          SegTiles st, const PaneDesc *__restrict__ panes,
+                                                          const int32_t *__restrict__ pane_win_ptr,
+                                                          const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
+                                                          uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
+                                                          int32_t *slow_list, const uint64_t *__restrict__ spec_info,
+                                                          unsigned long long *pane_wsum) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kWeighted ? 4 : kHist + kHistPad];
+    __shared__ int32_t s_red[8];
+    __shared__ unsigned long long s_w[kWavesPerBlock];
+    if (spec_info && !spec_info[2]) return;  // the device layout declined this call
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)   // (A/B builds only: num_cus x 8 workgroups walk the tiles)
+    for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
+        q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w);
+        __syncthreads();   // the next tile zeroes the histogram and rewrites the reduction slots
+    }
+#else
+    q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, (int32_t)blockIdx.x, hist, s_red, s_w);
+#endif
 }
 
 // ---- Partial COUNT per tile (the exchange's stage 0): the histogram phase of q5_count_kernel, then the tile's bins are written as
@@ -1645,7 +1661,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         } else if (st.n_tiles > 0 && n_win > 0) {
             {
                 LaunchScope ls(ctx, "q5_count_kernel");
-                hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0,
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)
+                const unsigned count_grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * (exp_env("FLOCKGPU_Q5_PERSIST_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_PERSIST_PER_CU")) : 8));
+#else
+                const unsigned count_grid = (unsigned)st.n_tiles;
+#endif
+                hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3(count_grid), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
                                    slow_list, spec_info, d_wsum);
             }
