@@ -49,11 +49,13 @@ __device__ __forceinline__ void rows4_int(const PredCol &c, int64_t r0, int64_t 
     }
 }
 
-__device__ __forceinline__ uint32_t valid_bits(const uint8_t *__restrict__ valid, int64_t wbase, int64_t n_rows, bool full) {
+// (sub >= 0: only iteration `sub` of the tile's eight is this workgroup's -- pred_flag_kernel's kSplit instance; the other rows' bits stay 0)
+__device__ __forceinline__ uint32_t valid_bits(const uint8_t *__restrict__ valid, int64_t wbase, int64_t n_rows, bool full, int sub = -1) {
     if (!valid) return ~0u;
     uint32_t bits = 0;
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it) {
+        if (sub >= 0 && it != sub) continue;
         const int64_t r0 = wbase + it * 256;
         uint32_t w = 0;
         if (full) {
@@ -88,7 +90,7 @@ __device__ __forceinline__ uint32_t cmp_from_masks(int32_t op, uint32_t lt, uint
 }
 
 template <bool kWide>
-__device__ __forceinline__ TN leaf_cmp_int_lit(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full) {
+__device__ __forceinline__ TN leaf_cmp_int_lit(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full, int sub) {
     const PredCol &c = P.cols[L.a];
     uint32_t lt = 0, eq = 0;
     if (c.type == (int32_t)ColType::I32) {
@@ -97,7 +99,10 @@ __device__ __forceinline__ TN leaf_cmp_int_lit(const PredProgram &P, const PredL
         const int32_t lit = (int32_t)L.lit;
         int32_t a[kFlagIters][4];
 #pragma unroll
-        for (int it = 0; it < kFlagIters; ++it) rows4_i32(col, wbase + it * 256, n_rows, full, c.uses == 1, a[it]);
+        for (int it = 0; it < kFlagIters; ++it) {
+            if (sub >= 0 && it != sub) { a[it][0] = a[it][1] = a[it][2] = a[it][3] = 0; continue; }
+            rows4_i32(col, wbase + it * 256, n_rows, full, c.uses == 1, a[it]);
+        }
         if (L.mod_kind == 1) {   // remainder and comparison row by row: the 32 values die as they are used
             const UMod32 mm = L.mod;
 #pragma unroll
@@ -136,6 +141,7 @@ __device__ __forceinline__ TN leaf_cmp_int_lit(const PredProgram &P, const PredL
         const uint64_t lit = (uint64_t)L.lit ^ flip;
 #pragma unroll 1
         for (int it = 0; it < kFlagIters; ++it) {
+            if (sub >= 0 && it != sub) continue;
             int64_t v[4];
             rows4_i64(col, wbase + it * 256, n_rows, full, v);
             if (L.mod_kind == 2) {   // ONE software division in flight (four side by side take ~160 registers)
@@ -156,17 +162,18 @@ __device__ __forceinline__ TN leaf_cmp_int_lit(const PredProgram &P, const PredL
             }
         }
     }
-    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full);
+    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full, sub);
     return TN{cmp_from_masks(L.cmp, lt, eq, ~(lt | eq)) & valid, ~valid};
 }
 
-__device__ __forceinline__ TN leaf_cmp_f64_lit(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full) {
+__device__ __forceinline__ TN leaf_cmp_f64_lit(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full, int sub) {
     const PredCol &c = P.cols[L.a];
     const int64_t *col = static_cast<const int64_t *>(c.values);
     const double lit = __longlong_as_double(L.lit);
     uint32_t lt = 0, eq = 0, gt = 0;   // IEEE: a NaN is none of the three, so only != holds for it
 #pragma unroll 1
     for (int it = 0; it < kFlagIters; ++it) {
+        if (sub >= 0 && it != sub) continue;
         int64_t v[4];
         rows4_i64(col, wbase + it * 256, n_rows, full, v);
 #pragma unroll
@@ -177,16 +184,17 @@ __device__ __forceinline__ TN leaf_cmp_f64_lit(const PredProgram &P, const PredL
             gt |= (uint32_t)(x > lit) << (it * 4 + j);
         }
     }
-    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full);
+    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full, sub);
     return TN{cmp_from_masks(L.cmp, lt, eq, gt) & valid, ~valid};
 }
 
-__device__ __forceinline__ TN leaf_cmp_col(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full, bool f64) {
+__device__ __forceinline__ TN leaf_cmp_col(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full, bool f64, int sub) {
     const PredCol &ca = P.cols[L.a], &cb = P.cols[L.b];
     const uint64_t flip = L.uns ? 0ull : (1ull << 63);
     uint32_t lt = 0, eq = 0, gt = 0;
 #pragma unroll 1
     for (int it = 0; it < kFlagIters; ++it) {
+        if (sub >= 0 && it != sub) continue;
         int64_t x[4], y[4];
         rows4_int(ca, wbase + it * 256, n_rows, full, x);
         rows4_int(cb, wbase + it * 256, n_rows, full, y);
@@ -205,13 +213,13 @@ __device__ __forceinline__ TN leaf_cmp_col(const PredProgram &P, const PredLeafD
             }
         }
     }
-    const uint32_t valid = valid_bits(ca.valid, wbase, n_rows, full) & valid_bits(cb.valid, wbase, n_rows, full);
+    const uint32_t valid = valid_bits(ca.valid, wbase, n_rows, full, sub) & valid_bits(cb.valid, wbase, n_rows, full, sub);
     return TN{cmp_from_masks(L.cmp, lt, eq, gt) & valid, ~valid};
 }
 
 // Utf8 column = literal: the length first, then the literal's bytes eight at a time -- each word read from an address clamped into
 // the byte buffer (never under a per-row branch: DESIGN section 3) and shifted into place.
-__device__ __forceinline__ TN leaf_utf8_eq(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full) {
+__device__ __forceinline__ TN leaf_utf8_eq(const PredProgram &P, const PredLeafDesc &L, int64_t wbase, int64_t n_rows, bool full, int sub) {
     const PredCol &c = P.cols[L.a];
     const int32_t *__restrict__ off = c.offsets;
     const uint8_t *__restrict__ bytes = static_cast<const uint8_t *>(c.values);
@@ -220,6 +228,7 @@ __device__ __forceinline__ TN leaf_utf8_eq(const PredProgram &P, const PredLeafD
     uint32_t bits = 0;
 #pragma unroll 1
     for (int it = 0; it < kFlagIters; ++it) {
+        if (sub >= 0 && it != sub) continue;
         const int64_t r0 = wbase + it * 256;
         int32_t o[5];
         if (full) {   // rows r0 .. r0 + 3 exist, so offsets r0 .. r0 + 4 do
@@ -253,7 +262,7 @@ __device__ __forceinline__ TN leaf_utf8_eq(const PredProgram &P, const PredLeafD
             bits |= (uint32_t)(eq != (L.negate != 0)) << (it * 4 + j);
         }
     }
-    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full);
+    const uint32_t valid = valid_bits(c.valid, wbase, n_rows, full, sub);
     return TN{bits & valid, ~valid};
 }
 
@@ -261,16 +270,16 @@ __device__ __forceinline__ TN leaf_utf8_eq(const PredProgram &P, const PredLeafD
 // more than 2^31).  Programs without one -- Int32 and Utf8 columns against literals, what NEXMark's filters are -- run the instance
 // that does not carry those paths' registers (78 against 190 VGPRs: occupancy is what a streaming pass lives on).
 template <bool kWide>
-__device__ __forceinline__ TN eval_leaf(const PredProgram &P, int which, int64_t wbase, int64_t n_rows, bool full) {
+__device__ __forceinline__ TN eval_leaf(const PredProgram &P, int which, int64_t wbase, int64_t n_rows, bool full, int sub) {
     const PredLeafDesc &L = P.leaves[which];
     switch (L.kind) {   // (uniform)
-        case (uint8_t)PredLeafKind::CmpIntLit: return leaf_cmp_int_lit<kWide>(P, L, wbase, n_rows, full);
-        case (uint8_t)PredLeafKind::CmpF64Lit: return kWide ? leaf_cmp_f64_lit(P, L, wbase, n_rows, full) : TN{0u, 0u};
-        case (uint8_t)PredLeafKind::CmpIntCol: return kWide ? leaf_cmp_col(P, L, wbase, n_rows, full, false) : TN{0u, 0u};
-        case (uint8_t)PredLeafKind::CmpF64Col: return kWide ? leaf_cmp_col(P, L, wbase, n_rows, full, true) : TN{0u, 0u};
-        case (uint8_t)PredLeafKind::Utf8Eq: return leaf_utf8_eq(P, L, wbase, n_rows, full);
+        case (uint8_t)PredLeafKind::CmpIntLit: return leaf_cmp_int_lit<kWide>(P, L, wbase, n_rows, full, sub);
+        case (uint8_t)PredLeafKind::CmpF64Lit: return kWide ? leaf_cmp_f64_lit(P, L, wbase, n_rows, full, sub) : TN{0u, 0u};
+        case (uint8_t)PredLeafKind::CmpIntCol: return kWide ? leaf_cmp_col(P, L, wbase, n_rows, full, false, sub) : TN{0u, 0u};
+        case (uint8_t)PredLeafKind::CmpF64Col: return kWide ? leaf_cmp_col(P, L, wbase, n_rows, full, true, sub) : TN{0u, 0u};
+        case (uint8_t)PredLeafKind::Utf8Eq: return leaf_utf8_eq(P, L, wbase, n_rows, full, sub);
         case (uint8_t)PredLeafKind::IsNull: {
-            const uint32_t valid = valid_bits(P.cols[L.a].valid, wbase, n_rows, full);
+            const uint32_t valid = valid_bits(P.cols[L.a].valid, wbase, n_rows, full, sub);
             return TN{L.negate ? valid : ~valid, 0u};
         }
         default: return TN{L.lit == 1 ? ~0u : 0u, L.lit == 2 ? ~0u : 0u};
@@ -279,9 +288,14 @@ __device__ __forceinline__ TN eval_leaf(const PredProgram &P, int which, int64_t
 
 // kFull: every tile of the launch lies inside the relation (the grid's tiles first_tile .. ); the relation's last, ragged tile is a
 // launch of its own with the guarded loads -- carrying both load paths in one kernel doubled its registers.
-template <bool kFull, bool kWide>
+// kSplit (small relations; kFull = false): the grid is (tiles, 8) and workgroup (t, s) evaluates only iteration s of tile t -- 1024 rows, four per
+// lane -- and ORs / adds its share into the tile's flag words / wave counts (cleared by the host).  A leaf's eight iterations are eight
+// DEPENDENT rounds of loads (offsets, then bytes; a 64-bit software division at a time), which a streaming pass hides behind its other
+// workgroups and a relation of a few tiles does not: q3's two filters over 6e4 auctions and 2e4 persons took 21 us per launch.
+template <bool kFull, bool kWide, bool kSplit = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kFull ? (kWide ? 3 : 4) : 1))) void pred_flag_kernel(const PredProgram P, int64_t n_rows, SegTiles st, int32_t first_tile,
                                                            uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts) {
+    const int sub = kSplit ? (int)blockIdx.y : -1;
     // operands waiting below the top of the stack: one column of words per thread, touched by that thread only (no barrier)
     __shared__ uint32_t s_t[kPredMaxStack][kBlock], s_n[kPredMaxStack][kBlock];
     const int32_t tile = first_tile + (int32_t)blockIdx.x;
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kFull ? 
                 s_t[sp - 1][threadIdx.x] = top.t;
                 s_n[sp - 1][threadIdx.x] = top.n;
             }
-            top = eval_leaf<kWide>(P, P.arg[i], wbase, n_rows, full);
+            top = eval_leaf<kWide>(P, P.arg[i], wbase, n_rows, full, sub);
             ++sp;
         } else if (op == (uint8_t)PredOpKind::Not) {
             top.t = ~top.t & ~top.n;
@@ -327,6 +341,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kFull ? 
                 in |= (uint32_t)(r >= tr.lo && r < tr.hi) << (it * 4 + j);
             }
         flags &= in;
+    }
+    if (kSplit) {
+        flags &= 0xFu << (4 * sub);
+        if (flags) atomicOr(&flag_words[(size_t)tile * kBlock + threadIdx.x], flags);
+        const uint32_t c = (uint32_t)wave_sum_u64((uint64_t)__popc(flags));
+        if (lane_id() == 0 && c) atomicAdd(&counts[(size_t)tile * kWavesPerBlock + (threadIdx.x >> 6)], c);
+        return;
     }
     store_flags_and_counts(flags, tile, flag_words, counts);
 }
@@ -363,7 +384,12 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
     }
     // the tiles that lie inside the relation, then -- a launch of its own -- the ragged last one (one segment: there is at most one)
     const int32_t n_full = (int32_t)(rows / kFlagTile);
-    {
+    if (st.n_tiles < 4 * ctx->num_cus) {   // a few tiles only: every tile's eight iterations on workgroups of their own (kSplit)
+        FG_TRY(fill_words(ctx, FillList().add(flags, 0u, (uint64_t)st.n_tiles * kBlock).add(counts, 0u, (uint64_t)st.n_tiles * kWavesPerBlock)));
+        LaunchScope ls(ctx, "pred_flag_kernel");
+        if (wide) hipLaunchKernelGGL((pred_flag_kernel<false, true, true>), dim3((unsigned)st.n_tiles, kFlagIters), dim3(kBlock), 0, ctx->stream, prog, rows, st, 0, flags, counts);
+        else hipLaunchKernelGGL((pred_flag_kernel<false, false, true>), dim3((unsigned)st.n_tiles, kFlagIters), dim3(kBlock), 0, ctx->stream, prog, rows, st, 0, flags, counts);
+    } else {
         LaunchScope ls(ctx, "pred_flag_kernel");
         if (n_full > 0) {
             if (wide) hipLaunchKernelGGL((pred_flag_kernel<true, true>), dim3((unsigned)n_full), dim3(kBlock), 0, ctx->stream, prog, rows, st, 0, flags, counts);
