@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void group_init_kernel(int64_t *__restrict_
 // (probing is cut off after kClaimProbes slots: in a table at most half full a longer run does not happen, and in one sized from a hint
 // that turned out too small -- group_by_key64_n -- it must end in "full", not in a walk over the whole table per row)
 constexpr uint64_t kClaimProbes = 4096;
+constexpr int kJoinTotalSlots = 32;   // the probe passes' 64-bit pair total, spread over this many words (summed by the host)
 __device__ __forceinline__ int64_t claim_slot(int64_t *tk, uint64_t cap, int64_t key) {
     if (key == kEmptyKey) return (int64_t)cap;
     uint64_t s = mix64((uint64_t)key) & (cap - 1);
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__res
     }
     if (!kEmit) {
         mine = wave_sum_u64(mine);
-        if (lane_id() == 0 && mine) atomicAdd(total64, mine);
+        if (lane_id() == 0 && mine) atomicAdd(total64 + (blockIdx.x & (kJoinTotalSlots - 1)), mine);   // (one of 32 words: a wave per 64 rows on ONE word is ~4.5 ns each, 22 us per 3e5 rows)
     }
 }
 // ---- join on a DENSE integer key (join_dense): the build side's key offsets from their minimum address the chain heads directly -- the
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void join_probe_dense_kernel(const void *__
     }
     if (!kEmit) {
         mine = wave_sum_u64(mine);
-        if (lane_id() == 0 && mine) atomicAdd(total64, mine);
+        if (lane_id() == 0 && mine) atomicAdd(total64 + (blockIdx.x & (kJoinTotalSlots - 1)), mine);   // (one of 32 words: a wave per 64 rows on ONE word is ~4.5 ns each, 22 us per 3e5 rows)
     }
 }
 // ---- join, both sides small (join_tiny): ONE workgroup builds the smaller side's multimap in LDS -- keys, chain heads and the chain links
@@ -1742,8 +1743,8 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     FG_TRY(arena_get_t(ctx, (base + ".head").c_str(), (size_t)slots, &head));
     FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
-    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 4, &d_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 4, &h_err));
+    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &h_err));
     int32_t *ol = nullptr, *orr = nullptr;
     if (n_left <= 0 || n_right <= 0) {
         FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
@@ -1753,14 +1754,15 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         return FLOCKGPU_OK;
     }
     unsigned long long *d_tot64 = reinterpret_cast<unsigned long long *>(d_err + 2), *h_tot64 = reinterpret_cast<unsigned long long *>(h_err + 2);
-    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 4)));
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 2 + 2 * kJoinTotalSlots)));
     RELOPS_LAUNCH(ctx, "join_init_kernel", join_init_kernel, slots, tk, head, slots);
     RELOPS_LAUNCH(ctx, "join_build_kernel", join_build_kernel, n_left, left, n_left, tk, head, next, cap, d_err);
     RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
                   (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
-    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 4)));
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2).add(h_tot64, d_tot64, 2 * kJoinTotalSlots)));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int sl = 1; sl < kJoinTotalSlots; ++sl) h_tot64[0] += h_tot64[sl];
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
     // the 64-bit total decides: the 32-bit inclusive scan of `counts` is only read when it cannot have wrapped
     if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);
@@ -1792,8 +1794,8 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
     FG_TRY(arena_get_t(ctx, (base + ".dhead").c_str(), (size_t)range + 4, &head));
     FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
-    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 4, &d_err));     // [0] error word, [2..3] 64-bit pair total
-    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 4, &h_err));
+    FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &d_err));     // [0] error word, [2..] the 64-bit pair total in kJoinTotalSlots words
+    FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &h_err));
     d_tot64 = reinterpret_cast<unsigned long long *>(d_err + 2);
     h_tot64 = reinterpret_cast<unsigned long long *>(h_err + 2);
     if (n_left <= 0 || n_right <= 0) {
@@ -1803,13 +1805,14 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
         *right_rows = orr;
         return FLOCKGPU_OK;
     }
-    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 4).add(head, 0xffffffffu, range)));   // scalars 0; chain heads -1 (empty): one launch
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 2 + 2 * kJoinTotalSlots).add(head, 0xffffffffu, range)));   // scalars 0; chain heads -1 (empty): one launch
     RELOPS_LAUNCH(ctx, "join_build_dense_kernel", join_build_dense_kernel, n_left, left.values, (int32_t)left.type, n_left, kmin, range, head, next, d_err);
     RELOPS_LAUNCH(ctx, "join_probe_dense_kernel", join_probe_dense_kernel<false>, n_right, right.values, (int32_t)right.type, n_right, kmin, range, head, next, counts,
                   (int32_t *)nullptr, (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
-    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 4)));
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2).add(h_tot64, d_tot64, 2 * kJoinTotalSlots)));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int sl = 1; sl < kJoinTotalSlots; ++sl) h_tot64[0] += h_tot64[sl];
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a build key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);
     const int64_t total = (int64_t)h_tot64[0];
