@@ -1804,7 +1804,7 @@ def main():
             for label, q2 in (("q5", 5), ("q3", 3), ("q8", 8)):
                 try:
                     # (q3 at 1e9 events: at its 1e8-event BASELINE size the whole query is three host synchronisations long)
-                    e = exchange_entry(ctx, comm, q2, 1000 if q2 == 3 else DEFAULT_SECONDS[q2], args.eps, steps2, 2, 0, 1, barrier, reduce_max_sum)
+                    e = exchange_entry(ctx, comm, q2, 1000 if q2 == 3 else DEFAULT_SECONDS[q2], args.eps, steps2, 4, 0, 1, barrier, reduce_max_sum)   # (four warm-up calls: the speculative sizes of the stages settle over the first three)
                     base = out if q2 == q else (also.get("q3_1e9_events") if q2 == 3 else also.get(f"q{q2}"))
                     if base and "ms_per_step" in base:
                         e["over_window_sharded_step"] = round(e["ms_per_step"] / base["ms_per_step"], 2)
