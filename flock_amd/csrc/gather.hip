@@ -186,6 +186,26 @@ __global__ __launch_bounds__(kBlock) void emit_rows_kernel(SegTiles st, const ui
     for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
 }
 
+// The same without a scan launch in front (ONE segment, a relation of up to kSelfScanMaxTiles tiles): the workgroup sums the counts of the lower
+// tiles itself (block_base_of_tile); the last tile reports the total where the host reads it (pinned: off[0] = 0, off[1] = selected rows).
+__global__ __launch_bounds__(kBlock) void emit_rows_self_kernel(SegTiles st, const uint32_t *__restrict__ flag_words, const uint32_t *__restrict__ counts,
+                                                                int32_t *__restrict__ out_rows, int64_t *__restrict__ h_off) {
+    __shared__ uint16_t s_list[kFlagTile];
+    __shared__ uint64_t s_red[kWavesPerBlock];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const uint64_t base = block_base_of_tile(counts, tile, s_red);
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)tile * kWavesPerBlock);
+    if (tile == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
+        h_off[0] = 0;
+        h_off[1] = (int64_t)(base + wc.x + wc.y + wc.z + wc.w);
+    }
+    if (wc.x + wc.y + wc.z + wc.w == 0) return;
+    const uint32_t total = build_flag_list(flag_words[(size_t)tile * kBlock + threadIdx.x], wc, s_list);
+    __syncthreads();
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) out_rows[base + i] = (int32_t)(tr.tile_begin + s_list[i]);
+}
+
 __global__ __launch_bounds__(kBlock) void emit_bids_kernel(const int32_t *__restrict__ auction, const int32_t *__restrict__ price,
                                                            const int32_t *__restrict__ bidder,
                                                            const int64_t *__restrict__ b_date_time, SegTiles st,
@@ -667,6 +687,15 @@ int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *fla
                            counts, tile_base, out_rows);
     }
     return check_launch(ctx, "emit_rows_kernel");
+}
+
+int emit_flagged_rows_self(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts, int32_t *out_rows, int64_t *h_off) {
+    if (st.n_seg != 1 || st.n_tiles <= 0 || st.n_tiles > kSelfScanMaxTiles) return fail(ctx, FLOCKGPU_ERR_INVALID, "emit_flagged_rows_self: one segment of 1 .. %d tiles", kSelfScanMaxTiles);
+    {
+        LaunchScope ls(ctx, "emit_rows_kernel");
+        hipLaunchKernelGGL(emit_rows_self_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, st, flag_words, counts, out_rows, h_off);
+    }
+    return check_launch(ctx, "emit_rows_self_kernel");
 }
 
 int emit_flagged_bids(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,

@@ -15,6 +15,9 @@ namespace flockgpu {
 // flag_words / counts as written by store_flags_and_counts (scan.hpp) over kFlagTile-row tiles of `st`.
 int emit_flagged_rows(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts,
                       const uint64_t *tile_base, int32_t *out_rows);
+// One segment of up to kSelfScanMaxTiles tiles: no tile scan in front -- every workgroup sums the lower tiles' counts itself, the last one stores
+// {0, selected rows} into the PINNED h_off (read it after the stream synchronises).
+int emit_flagged_rows_self(flockgpu_ctx *ctx, const SegTiles &st, const uint32_t *flag_words, const uint32_t *counts, int32_t *out_rows, int64_t *h_off);
 
 // Copies (auction, price, bidder, b_date_time) of every flagged bid row to out_*[tile_base[tile] + i], row order kept
 // (the Projection [auction, price, bidder, b_date_time] of q7 / q9 over the rows that survive the join).

@@ -401,8 +401,12 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
         }
     }
     FG_TRY(check_launch(ctx, "pred_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the selected-row count goes straight into pinned memory)
-    FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    if (st.n_tiles <= 2048) {   // a relation of up to 1.7e7 rows: the emit sums the lower tiles' counts itself (one launch less; 16 B per lower tile from L2)
+        FG_TRY(emit_flagged_rows_self(ctx, st, flags, counts, o_rows, h_off));
+    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the selected-row count goes straight into pinned memory)
+        FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    }
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = h_off[1];
     return FLOCKGPU_OK;

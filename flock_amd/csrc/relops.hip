@@ -1279,8 +1279,12 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
         hipLaunchKernelGGL(mask_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, mask, rows, st, flags, counts);
     }
     FG_TRY(check_launch(ctx, "mask_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the scan writes its segment offsets straight into pinned memory)
-    FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    if (st.n_tiles <= 2048) {   // (no scan launch for relations of up to 1.7e7 rows: gather.hpp, emit_flagged_rows_self)
+        FG_TRY(emit_flagged_rows_self(ctx, st, flags, counts, o_rows, h_off));
+    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the scan writes its segment offsets straight into pinned memory)
+        FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    }
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = h_off[1];
     return FLOCKGPU_OK;
@@ -1581,8 +1585,12 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
         hipLaunchKernelGGL(dense_live_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, cnt, (int64_t)range, st, flags, counts, d_err, h_err);
     }
     FG_TRY(check_launch(ctx, "dense_live_flag_kernel"));
-    FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (segment offsets straight into pinned memory)
-    FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, slots));
+    if (st.n_tiles <= 2048) {
+        FG_TRY(emit_flagged_rows_self(ctx, st, flags, counts, slots, h_off));
+    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (segment offsets straight into pinned memory)
+        FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, slots));
+    }
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     const int64_t n_groups = h_off[1];
