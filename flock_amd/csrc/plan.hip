@@ -690,12 +690,18 @@ const char *fused_name(Fused f) {
     }
 }
 void describe(const flockgpu_plan *pl, const Node *n, int depth, std::ostringstream &os) {
-    static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition", "Sort", "Limit"};
+    static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition", "Sort", "Limit", "Window"};
     os << std::string((size_t)depth * 2, ' ') << kinds[(int)n->kind];
     if (n->kind == NKind::Aggregate) os << "(" << n->mode << ")";
     if (n->kind == NKind::Repartition) os << "(Hash, " << n->n_parts << ")";
     if (n->kind == NKind::Scan) os << "(" << pl->ir.leaves[(size_t)n->leaf].relation << ")";
     if (n->kind == NKind::Limit) os << "(" << n->limit << ")";
+    if (n->kind == NKind::Window)
+        for (size_t w = 0; w < n->win_part.size(); ++w) {
+            os << (w ? ", " : "(") << "ROW_NUMBER PARTITION BY";
+            for (int c : n->win_part[w]) os << " " << n->in[0]->schema[(size_t)c].name;
+            if (w + 1 == n->win_part.size()) os << ")";
+        }
     if (n->kind == NKind::Sort) {
         os << "(";
         for (size_t i = 0; i < n->sort_cols.size(); ++i)
@@ -1896,6 +1902,37 @@ struct Exec {
             }
             case NKind::Sort:
                 return exec_sort(n, -1, t);
+            case NKind::Window: {   // ROW_NUMBER() columns first, then the input's (q6_plan.fmt: the WindowAggr schemas)
+                Table in;
+                FG_TRY(exec(n->in[0].get(), &in));
+                const size_t nw = n->win_part.size();
+                t->rows = in.rows;
+                t->cols.assign(n->schema.size(), TCol{});
+                for (size_t w = 0; w < nw; ++w) {
+                    t->cols[w].c.type = ColType::U64;
+                    t->cols[w].c.nullable = true;
+                    if (!n->required[w]) continue;
+                    DevColumn keys[4];
+                    if (n->win_part[w].size() > 4) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: PARTITION BY more than four columns");
+                    for (size_t c = 0; c < n->win_part[w].size(); ++c) {
+                        const TCol &k = in.cols[(size_t)n->win_part[w][c]];
+                        if (!k.present && !k.c.all_null) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: PARTITION BY column was not materialised");
+                        keys[c] = k.c;
+                        if (k.c.all_null) { keys[c].type = ColType::I32; keys[c].values = nullptr; }   // every row NULL: one run as far as this key goes
+                    }
+                    int nk = 0;
+                    DevColumn live[4];
+                    for (size_t c = 0; c < n->win_part[w].size(); ++c)
+                        if (keys[c].values) live[nk++] = keys[c];
+                    uint64_t *rank = nullptr;
+                    FG_TRY(arena_get_t(ctx, node_key(pl, n, "rank", (int)w).c_str(), (size_t)std::max<int64_t>(in.rows, 0) + 2, &rank));
+                    FG_TRY(row_number_runs(ctx, node_key(pl, n, "rn", (int)w).c_str(), live, nk, in.rows, rank));
+                    t->cols[w] = dev_col(ColType::U64, rank);
+                    t->cols[w].c.nullable = true;
+                }
+                for (size_t i = 0; i < in.cols.size(); ++i) t->cols[nw + i] = in.cols[i];
+                return FLOCKGPU_OK;
+            }
             case NKind::Limit: {
                 // ORDER BY ... LIMIT n (context.rs:549-550): the order is computed for every row, only the first n are taken
                 const Node *c = n->in[0].get();

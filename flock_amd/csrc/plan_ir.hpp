@@ -9,6 +9,8 @@
 // neither the row multiset nor the schema and are dropped.  Anything else (window functions, outer
 // joins, unknown expressions / types) makes the plan UNSUPPORTED: the host keeps its own engine for it.
 #pragma once
+#include <algorithm>
+#include <cctype>
 #include <set>
 #include <sstream>
 
@@ -78,7 +80,7 @@ inline int expr_static_type(const Expr *e, const std::vector<Field> &schema) {
     return -2;
 }
 
-enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit };
+enum class NKind { Scan, Filter, Project, Aggregate, Join, Repartition, Sort, Limit, Window };
 struct SortCol {
     int col = -1;            // input column
     bool descending = false;
@@ -112,6 +114,7 @@ struct Node {
     int n_parts = 0;
     std::vector<SortCol> sort_cols; // Sort: ORDER BY keys, most significant first
     int64_t limit = -1;             // Limit: rows kept
+    std::vector<std::vector<int>> win_part;   // Window: per ROW_NUMBER() column (they come FIRST in the schema), the input columns of its PARTITION BY
     std::vector<char> required;     // per output column: needed by an ancestor (or by the plan output)
 };
 
@@ -565,6 +568,50 @@ struct Builder {
                 n->sort_cols.push_back(sc);
             }
             n->in.push_back(std::move(in));
+        } else if (t == "window_agg_exec") {
+            // WindowAggExec (q6.sql: ROW_NUMBER() OVER (PARTITION BY a_id ORDER BY price DESC), benchmarks/src/nexmark/query/q6_plan.fmt:6,11).
+            // The physical planner sorts the input by (PARTITION BY, ORDER BY) underneath (a sort_exec); the operator numbers the rows of every
+            // RUN of equal partition keys 1, 2, ... in the order they arrive -- what DataFusion's partition points over a sorted batch give.
+            // Output: the window columns first (UInt64), then the input's (q6_plan.fmt's schemas).  Only ROW_NUMBER is taken.
+            n->kind = NKind::Window;
+            auto in = node(j->get("input"), depth + 1);
+            if (!in) return nullptr;
+            const JValue *we = j->get("window_expr");
+            if (!we || we->kind != JValue::Arr || we->arr.empty()) { fail("window_agg_exec without window_expr"); return nullptr; }
+            std::vector<Field> wf;
+            for (auto &w : we->arr) {
+                if (w->kind != JValue::Obj) { fail("malformed window_expr"); return nullptr; }
+                std::string fun;
+                for (const char *key : {"fun", "function", "window_function", "built_in", "expr", "name"}) {
+                    const JValue *f = w->get(key);
+                    if (!f) continue;
+                    std::string v = f->kind == JValue::Str ? f->str : (f->kind == JValue::Obj && !f->obj.empty() ? f->obj[0].first : std::string());
+                    for (auto &ch : v) ch = (char)std::tolower((unsigned char)ch);
+                    v.erase(std::remove(v.begin(), v.end(), '_'), v.end());
+                    if (v.find("rownumber") != std::string::npos) { fun = "row_number"; break; }
+                    if (fun.empty() && !v.empty()) fun = v;
+                }
+                if (fun != "row_number") { fail("window function '" + fun + "' (supported: ROW_NUMBER)"); return nullptr; }
+                std::vector<int> part;
+                const JValue *pb = w->get("partition_by");
+                if (pb && pb->kind == JValue::Arr)
+                    for (auto &e : pb->arr) {
+                        if (etag(e.get()) != "column") { fail("PARTITION BY on something other than a column"); return nullptr; }
+                        const int c = resolve(e.get(), in->schema);
+                        if (c < 0) { fail("PARTITION BY column not in the input schema"); return nullptr; }
+                        part.push_back(c);
+                    }
+                n->win_part.push_back(part);
+                Field f;
+                const JValue *nm = w->get("name");
+                f.name = nm && nm->kind == JValue::Str ? nm->str : "ROW_NUMBER()";
+                f.type = ColType::U64;
+                f.nullable = true;
+                wf.push_back(f);
+            }
+            n->schema = wf;
+            n->schema.insert(n->schema.end(), in->schema.begin(), in->schema.end());
+            n->in.push_back(std::move(in));
         } else if (t == "global_limit_exec" || t == "local_limit_exec") {
             n->kind = NKind::Limit;
             auto in = node(j->get("input"), depth + 1);
@@ -655,6 +702,14 @@ inline void mark_required(Plan *p, Node *n, const std::vector<char> &req) {
         case NKind::Limit:
             mark_required(p, n->in[0].get(), req);
             break;
+        case NKind::Window: {
+            const size_t nw = n->win_part.size();
+            std::vector<char> r(req.begin() + (long)nw, req.end());
+            for (auto &part : n->win_part)
+                for (int c : part) need(r, c);
+            mark_required(p, n->in[0].get(), r);
+            break;
+        }
     }
 }
 
@@ -730,6 +785,7 @@ inline void mark_null_droppable(Plan *p, const Node *n, const std::vector<char> 
             mark_null_droppable(p, n->in[0].get(), droppable);
             break;
         case NKind::Limit:  // WHICH rows make the first n depends on every row below: nothing may be dropped early
+        case NKind::Window: // ... and so does every row's number
             mark_null_droppable(p, n->in[0].get(), std::vector<char>(n->in[0]->schema.size(), 0));
             break;
     }

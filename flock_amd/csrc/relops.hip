@@ -1098,6 +1098,34 @@ __global__ __launch_bounds__(kBlock) void utf8_max_len_kernel(const int32_t *__r
     if (lane_id() == 0) atomicMax(reinterpret_cast<unsigned long long *>(&minmax[1]), (unsigned long long)mx);
 }
 
+// ---- ROW_NUMBER over runs of equal partition keys (row_number_runs)
+struct RunKeys {
+    const void *v[4];
+    const uint8_t *valid[4];
+    int32_t type[4];
+    int32_t n;
+};
+__global__ __launch_bounds__(kBlock) void run_start_kernel(RunKeys k, int64_t n, int32_t *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        bool start = i == 0;
+        for (int c = 0; c < k.n && !start; ++c) {
+            const bool va = !k.valid[c] || k.valid[c][i], vb = !k.valid[c] || k.valid[c][i - 1];
+            if (va != vb) start = true;
+            else if (va) start = k.type[c] == (int32_t)ColType::I32 ? static_cast<const int32_t *>(k.v[c])[i] != static_cast<const int32_t *>(k.v[c])[i - 1]
+                                                                    : static_cast<const uint64_t *>(k.v[c])[i] != static_cast<const uint64_t *>(k.v[c])[i - 1];
+        }
+        flag[i] = start ? 1 : 0;
+    }
+}
+// run[i] = number of the run row i lies in (1-based: the inclusive scan of the start flags)
+__global__ __launch_bounds__(kBlock) void run_first_kernel(const int32_t *__restrict__ run, int64_t n, int32_t *__restrict__ first) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (i == 0 || run[i] != run[i - 1]) first[run[i] - 1] = (int32_t)i;
+}
+__global__ __launch_bounds__(kBlock) void run_rank_kernel(const int32_t *__restrict__ run, const int32_t *__restrict__ first, int64_t n, uint64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (uint64_t)(i - first[run[i] - 1]) + 1;
+}
+
 }  // namespace
 
 namespace flockgpu {
@@ -1832,6 +1860,29 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
     *left_rows = ol;
     *right_rows = orr;
     *n_pairs = total;
+    return FLOCKGPU_OK;
+}
+
+int row_number_runs(flockgpu_ctx *ctx, const char *name, const DevColumn *cols, int n_cols, int64_t rows, uint64_t *out) {
+    if (n_cols < 0 || n_cols > 4) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: PARTITION BY more than four columns", name);
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^31 rows", name);
+    if (rows <= 0) return FLOCKGPU_OK;
+    RunKeys k{};
+    k.n = n_cols;
+    for (int c = 0; c < n_cols; ++c) {
+        if (cols[c].type == ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: PARTITION BY a Utf8 column", name);
+        k.v[c] = cols[c].values;
+        k.valid[c] = cols[c].valid;
+        k.type[c] = (int32_t)cols[c].type;
+    }
+    const std::string base = name;
+    int32_t *run = nullptr, *first = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".run").c_str(), (size_t)rows + 4, &run));
+    FG_TRY(arena_get_t(ctx, (base + ".first").c_str(), (size_t)rows + 4, &first));
+    RELOPS_LAUNCH(ctx, "run_start_kernel", run_start_kernel, rows, k, rows, run);
+    FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), run, rows));
+    RELOPS_LAUNCH(ctx, "run_first_kernel", run_first_kernel, rows, run, rows, first);
+    RELOPS_LAUNCH(ctx, "run_rank_kernel", run_rank_kernel, rows, run, first, rows, out);
     return FLOCKGPU_OK;
 }
 

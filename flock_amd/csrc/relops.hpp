@@ -35,6 +35,11 @@ struct DevColumn {
 enum class CmpOp : int32_t { EQ = 0, NE = 1, LT = 2, LE = 3, GT = 4, GE = 5 };
 enum class AggKind : int32_t { NONE = 0, SUM = 1, MAX = 2 };
 
+// ROW_NUMBER() of WindowAggExec over an input that arrives sorted by (PARTITION BY, ORDER BY): out[i] = 1 + i - (first row of the RUN of equal
+// partition keys row i lies in); a run ends where any of the up to four key columns changes (NULL equals NULL; Float64 by its bits; Utf8 keys are
+// refused).  No key column: the whole input is one run.  Launches only -- the caller's next wait covers it.
+int row_number_runs(flockgpu_ctx *ctx, const char *name, const DevColumn *cols, int n_cols, int64_t rows, uint64_t *out);
+
 // keys of an integer column as int64 (I32 sign-extended; I64 / U64 bit pattern): out[rows]
 int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *out);
 

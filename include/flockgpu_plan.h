@@ -83,6 +83,9 @@ typedef struct flockgpu_plan flockgpu_plan;
 
 /* Parses the plan JSON and builds the operator tree.  FLOCKGPU_ERR_PLAN: not JSON; FLOCKGPU_ERR_UNSUPPORTED: a node,
  * expression or type the engine does not execute (flockgpu_last_error names it).
+ * Nodes (`execution_plan` tags): memory_exec, filter_exec, projection_exec, hash_aggregate_exec (Partial / Final / FinalPartitioned: count, max, min,
+ * sum, avg), hash_join_exec (Inner), repartition_exec, coalesce_batches_exec / coalesce_partitions_exec / merge_exec (transparent), sort_exec,
+ * global_limit_exec / local_limit_exec, window_agg_exec (ROW_NUMBER()).
  * Expressions (`physical_expr` tags): column, literal, cast_expr, try_cast_expr, binary_expr (Eq NotEq Lt LtEq Gt GtEq And Or Plus Minus
  * Multiply Divide Modulo), not_expr, is_null_expr, is_not_null_expr, negative_expr, in_list_expr, case_expr -- over Int32 / Int64 / UInt64 /
  * Float64 / Timestamp(Millisecond) values (Utf8: =, <>, IN, IS NULL against literals).  Both operands of a binary operator have one type,

@@ -291,6 +291,33 @@ def q9_winning_bids(a_id, a_date_time, expires, b_auction, b_price, b_date_time)
     return np.nonzero(keep)[0].astype(np.int64)
 
 
+def q6_avg_price_by_seller(a_id, a_date_time, expires, seller, b_auction, b_price, b_date_time, last=10):
+    """(seller Int32, AVG(price) Float64) rows of q6 for one window, ordered by seller (benchmarks/src/nexmark/query/q6.sql, q6_plan.fmt): per auction the
+    winning bid -- ROW_NUMBER() OVER (PARTITION BY a_id ORDER BY price DESC) = 1 among the bids placed while the auction was open; equal top
+    prices: the first in (auction row, bid row) order --, per seller the `last` winners with the latest b_date_time (ROW_NUMBER() OVER (PARTITION BY seller
+    ORDER BY b_date_time DESC) <= last; equal times: the earlier auction id first), AVG over their prices as Float64 sum / UInt64 count.
+    Whole-column numpy; oracle/generic_ops.py: nexmark_q6 walks the same plan operator by operator (tests/test_oracle_q6.py)."""
+    ar, br = _auction_bid_pairs(a_id, a_date_time, expires, b_auction, b_date_time)
+    if len(ar) == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.float64)
+    a_id, seller = np.asarray(a_id, np.int64), np.asarray(seller, np.int64)
+    price, when = np.asarray(b_price, np.int64)[br], np.asarray(b_date_time, np.int64)[br]
+    o = np.lexsort((-price, a_id[ar]))                       # stable: a_id ASC, price DESC, then pair order
+    first = np.r_[True, a_id[ar][o][1:] != a_id[ar][o][:-1]]
+    w = o[first]                                             # the winning pair of every auction, by a_id
+    ws, wp, wt = seller[ar][w], price[w], when[w]
+    o2 = np.lexsort((-wt, ws))                               # stable: seller ASC, b_date_time DESC, then a_id order
+    s2 = ws[o2]
+    start = np.flatnonzero(np.r_[True, s2[1:] != s2[:-1]])
+    rank = np.arange(len(s2)) - np.repeat(start, np.diff(np.r_[start, len(s2)])) + 1
+    keep = rank <= last
+    ks, kp = s2[keep], wp[o2][keep]
+    sellers, st = np.unique(ks, return_index=True)
+    sums = np.add.reduceat(kp, st)
+    counts = np.diff(np.r_[st, len(ks)])
+    return sellers.astype(np.int32), sums.astype(np.float64) / counts.astype(np.float64)
+
+
 def q4_avg_final_by_category(a_id, category, a_date_time, expires, b_auction, b_price, b_date_time):
     """(category Int32, AVG(final) Float64) rows of q4 for one window, ordered by category (q4.sql; stages in
     flock/src/distributed_plan/planner.rs:218-256).  Inner groups are (a_id, category); AVG = Float64 sum / UInt64 count

@@ -398,6 +398,21 @@ def sort_exec(t: Table, by) -> Table:
     return {k: [v[i] for i in idx] for k, v in t.items()}
 
 
+def window_row_number(t: Table, partition_by: Sequence[str], name: str = "ROW_NUMBER()") -> Table:
+    """WindowAggExec with ROW_NUMBER() over an input that arrives sorted by (PARTITION BY, ORDER BY) -- the physical planner puts the SortExec
+    underneath: the rows of every RUN of equal partition keys are numbered 1, 2, ... in arrival order (NULL keys equal each other); the window
+    column comes FIRST (benchmarks/src/nexmark/query/q6_plan.fmt: the WindowAggr schemas)."""
+    out, prev, k = [], object(), 0
+    for r in range(num_rows(t)):
+        key = tuple(t[c][r] for c in partition_by)
+        k = k + 1 if (r > 0 and key == prev) else 1
+        prev = key
+        out.append(k)
+    res: Table = {name: out}
+    res.update(t)
+    return res
+
+
 def limit_exec(t: Table, n: int) -> Table:
     return {k: v[:n] for k, v in t.items()}
 
@@ -480,3 +495,17 @@ def nexmark_q8(person: Table, auction: Table) -> Table:
     a = hash_aggregate_exec({"seller": auction["seller"]}, ["seller"], [])
     j = hash_join_inner(p, a, [("p_id", "seller")])
     return {"p_id": j["p_id"], "name": j["name"]}
+
+
+def nexmark_q6(auction: Table, bid: Table, last: int = 10) -> Table:
+    """benchmarks/src/nexmark/query/q6.sql (q6_plan.fmt) operator by operator: the join with its BETWEEN, ROW_NUMBER by price per auction (= 1: the
+    winning bid; ties in input order -- the reference's sort is not stable, so which of two equal top bids wins there is unspecified), ROW_NUMBER by
+    b_date_time DESC per seller (<= `last`), AVG(price) per seller.  Rows in first-appearance order of the sellers."""
+    j = hash_join_inner(auction, bid, [("a_id", "auction")])
+    j = filter_exec(j, lambda r: r["a_date_time"] <= r["b_date_time"] <= r["expires"])
+    w = window_row_number(sort_exec(j, [("a_id", False), ("price", True, True)]), ["a_id"], "price_rank")
+    q = filter_exec(w, lambda r: r["price_rank"] == 1)
+    q = sort_exec(q, [("a_id", False), ("price", True, True)])
+    w2 = window_row_number(sort_exec(q, [("seller", False), ("b_date_time", True, True)]), ["seller"], "time_rank")
+    r = filter_exec(w2, lambda x: x["time_rank"] <= last)
+    return hash_aggregate_exec({"seller": r["seller"], "price": r["price"]}, ["seller"], [("AVG(R.price)", "avg", "price")])

@@ -263,6 +263,47 @@ def q9():
                               (col("b_date_time", 3), "b_date_time")], BID)
 
 
+def window_row_number(inp, partition, order, name):
+    """window_agg_exec with one ROW_NUMBER() (q6_plan.fmt: WindowAggr windowExpr=[[ROW_NUMBER() PARTITION BY [..] ORDER BY [..]]]) over the sort_exec the
+    physical planner puts underneath (PARTITION BY keys, then ORDER BY keys).  The serde shape of the fork's WindowAggExec is not in the reference
+    tree: this dialect is authored here (a `window_expr` list of {fun, name, partition_by, order_by}) and accepted with tolerance by plan_ir.hpp."""
+    srt = sort_by(inp, [(p, False) for p in partition] + list(order))
+    return {"execution_plan": "window_agg_exec", "input": srt,
+            "window_expr": [{"window_expr": "built_in_window_expr", "fun": "RowNumber", "name": name, "partition_by": list(partition),
+                             "order_by": [{"expr": k, "options": {"descending": bool(d), "nulls_first": bool(d)}} for k, d in order]}]}
+
+
+def q6():
+    # benchmarks/src/nexmark/query/q6.sql + q6_plan.fmt (a logical plan; the physical operators as the planner lays them out for the other queries)
+    af = [AUCTION[0], AUCTION[5], AUCTION[6], AUCTION[7]]                  # a_id, a_date_time, expires, seller
+    bf = [BID[0], BID[2], BID[3]]                                          # auction, price, b_date_time
+    jf = af + bf
+    j = join(coalesce(hashp(rr(memory(AUCTION, [0, 5, 6, 7], "auction")), [col("a_id", 0)])), coalesce(hashp(rr(memory(BID, [0, 2, 3], "bid")), [col("auction", 0)])),
+             [(("a_id", 0), ("auction", 0))], jf)
+    bdt = col("b_date_time", 6)
+    between = binary(binary(bdt, "GtEq", col("a_date_time", 1)), "And", binary(bdt, "LtEq", col("expires", 2)))
+    rn1 = "ROW_NUMBER() PARTITION BY [#auction.a_id] ORDER BY [#bid.price DESC NULLS FIRST]"
+    w1 = window_row_number(coalesce(filt(coalesce(j), between)), [col("a_id", 0)], [(col("price", 5), True)], rn1)     # [rn, a_id, a_date_time, expires, seller, auction, price, b_date_time]
+    top = filt(w1, binary(cast(col(rn1, 0), "Int64"), "Eq", lit("Int64", 1)))
+    qf = [field("seller", "Int32"), field("a_id", "Int32"), field("price", "Int32"), field("b_date_time", TS), field("price_rank", "UInt64", True)]
+    q = proj(top, [(col("seller", 4), "seller"), (col("a_id", 1), "a_id"), (col("price", 6), "price"), (col("b_date_time", 7), "b_date_time"), (col(rn1, 0), "price_rank")], qf)
+    q = sort_by(q, [(col("a_id", 1), False), (col("price", 2), True)])                                                     # the subquery's own ORDER BY
+    qf2 = [qf[0], qf[2], qf[3], qf[4]]
+    q = proj(q, [(col("seller", 0), "seller"), (col("price", 2), "price"), (col("b_date_time", 3), "b_date_time"), (col("price_rank", 4), "price_rank")], qf2)
+    rn2 = "ROW_NUMBER() PARTITION BY [#Q.seller] ORDER BY [#Q.b_date_time DESC NULLS FIRST]"
+    w2 = window_row_number(coalesce(hashp(q, [col("seller", 0)])), [col("seller", 0)], [(col("b_date_time", 2), True)], rn2)   # [rn, seller, price, b_date_time, price_rank]
+    recent = filt(w2, binary(cast(col(rn2, 0), "Int64"), "LtEq", lit("Int64", 10)))
+    rf = [field("seller", "Int32"), field("price", "Int32"), field("time_rank", "UInt64", True)]
+    r = proj(proj(recent, [(col("seller", 1), "seller"), (col("price", 2), "price"), (col(rn2, 0), "time_rank")], rf),
+             [(col("seller", 0), "seller"), (col("price", 1), "price"), (col("time_rank", 2), "time_rank")], rf)
+    avg = [{"aggregate_expr": "avg", "name": "AVG(R.price)", "data_type": "Float64", "nullable": True, "expr": col("price", 1)}]
+    part = [field("seller", "Int32"), field("AVG(R.price)[count]", "UInt64", True), field("AVG(R.price)[sum]", "Float64", True)]
+    out = [field("seller", "Int32"), field("AVG(R.price)", "Float64", True)]
+    partial = agg(r, "Partial", [(col("seller", 0), "seller")], avg, rf, part)
+    final = agg(coalesce(hashp(partial, [col("seller", 0)])), "FinalPartitioned", [(col("seller", 0), "seller")], avg, rf, out)
+    return proj(final, [(col("seller", 0), "seller"), (col("AVG(R.price)", 1), "AVG(R.price)")], out)
+
+
 AD_EVENT = [field("user_id", "Utf8"), field("page_id", "Utf8"), field("ad_id", "Utf8"), field("ad_type", "Utf8"),
             field("event_type", "Utf8"), field("event_time", TS), field("ip_address", "Utf8")]
 CAMPAIGN = [field("c_ad_id", "Utf8"), field("campaign_id", "Utf8")]
@@ -384,7 +425,7 @@ def main():
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
-    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13), ("q4", q4), ("q9", q9), ("q11", q11), ("ysb", ysb)):
+    for name, fn in (("q1", q1), ("q2", q2), ("q3", q3), ("q5", q5), ("q8", q8), ("q7", q7), ("q13", q13), ("q4", q4), ("q9", q9), ("q11", q11), ("ysb", ysb), ("q6", q6)):
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1, sort_keys=True)
             f.write("\n")
