@@ -77,7 +77,7 @@ def parse():
                          "inside libflockgpu as the headline; auto = windows, with the exchange attached as `exchange` at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
-    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic", "arch"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic", "arch", "q6"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -1219,6 +1219,62 @@ def arch_ops(gpu, eps, steps, no_cpu, seconds=100):
     return out
 
 
+def q6_side(gpu, eps, steps, no_cpu, seconds=10):
+    """q6 (benchmarks/src/nexmark/query/q6.sql: the average selling price of a seller's last ten auctions) through the plan ABI -- the one NEXMark query
+    with WindowAggExec, on the generic operators (join, BETWEEN, two-key sorts, ROW_NUMBER() runs, AVG): `seconds` x `eps` events fed once, the plan
+    executed `steps` times with the result left in HBM (the arch harness's recipe, source.rs:36-63), mean.  `kernels_ms_per_execute`: the top kernels
+    of one more, fully bracketed execute."""
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext
+    g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=11).generate_data(gpu, relations=("bid", "auction"), auction_times=True)
+    b, a = g.bids, g.auctions
+    ts = pa.timestamp("ms")
+    host = {"a_id": a.a_id.cpu().numpy(), "a_date_time": a.a_date_time.cpu().numpy(), "expires": a.expires.cpu().numpy(), "seller": a.seller.cpu().numpy(),
+            "auction": b.auction.cpu().numpy(), "price": b.price.cpu().numpy(), "b_date_time": b.b_date_time.cpu().numpy()}
+    auc = pa.record_batch([pa.array(host["a_id"]), pa.array(host["a_date_time"]).cast(ts), pa.array(host["expires"]).cast(ts), pa.array(host["seller"])],
+                          names=["a_id", "a_date_time", "expires", "seller"])
+    bid = pa.record_batch([pa.array(host["auction"]), pa.array(host["price"]), pa.array(host["b_date_time"]).cast(ts)], names=["auction", "price", "b_date_time"])
+    del g, a, b
+    plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", "q6.json")))
+    ctx = ExecutionContext([plan], gpu=gpu)
+    try:
+        ctx.feed_data_sources([[[auc]], [[bid]]])
+        pl = ctx.plans[0]
+        rows = pl.execute_retain()
+        gpu.synchronize()
+        times = []
+        for _ in range(max(steps, 3)):
+            t0 = time.perf_counter()
+            rows = pl.execute_retain()
+            gpu.synchronize()
+            times.append(time.perf_counter() - t0)
+        gpu.profile_reset()
+        gpu.profile_only(None)
+        gpu.profile(True)
+        pl.execute_retain()
+        stats = gpu.profile_read()
+        gpu.profile(False)
+    finally:
+        ctx.clean_data_sources()
+        ctx.close()
+    ms = sum(times) / len(times) * 1e3
+    n = auc.num_rows + bid.num_rows
+    top = sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+    out = {"value": round(n / (ms * 1e-3), 1), "unit": "rows/s", "ms_per_step": round(ms, 3), "input_rows": int(n), "auctions": int(auc.num_rows), "bids": int(bid.num_rows),
+           "result_rows": int(rows), "boundary": "plan ABI (tests/golden/plans/q6.json), fed once, executes with the result retained in HBM",
+           "kernels_ms_per_execute": {k: round(v["total_ms"], 4) for k, v in top}, "launches_per_execute": int(sum(v["launches"] for v in stats.values()))}
+    if not no_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        s, _ = oracle.q6_avg_price_by_seller(host["a_id"], host["a_date_time"], host["expires"], host["seller"], host["auction"], host["price"], host["b_date_time"])
+        d = time.perf_counter() - t0
+        if len(s) != rows:
+            raise RuntimeError(f"q6: the plan returns {rows} sellers, the oracle {len(s)}")
+        out["cpu_baseline"] = {"value": round(n / d, 1), "unit": "rows/s", "cores": 1, "kind": "port", "sample": f"the same {n} events, whole-column numpy restatement", "seconds": round(d, 2)}
+    return out
+
+
 def plan_stages(gpu, eps, steps):
     """The reference's distributed mode through the plan ABI: q3 / q5 / q8 cut into their stage plans (flock_amd.stages.build_query_dag =
     flock/src/distributed_plan/stage.rs:269-367), every stage a function group with 8 hash partitions, run in one process
@@ -1534,7 +1590,8 @@ def main():
         e = {"q11": lambda: q11_side(g, args.eps, n, True), "ysb": lambda: ysb_side(g, args.eps, n, True, 0), "json": lambda: json_side(g, n, True),
              "plan_stages": lambda: plan_stages(g, args.eps, n), "plan_collect": lambda: plan_collect_pcie(g, args.eps, max(n, 5)),
              "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps), "plan_generic": lambda: plan_generic(g, args.eps, n),
-             "arch": lambda: arch_ops(g, args.eps, 10, args.no_cpu, seconds=args.seconds or 100)}[args.only_side]()
+             "arch": lambda: arch_ops(g, args.eps, 10, args.no_cpu, seconds=args.seconds or 100),
+             "q6": lambda: q6_side(g, args.eps, n, args.no_cpu, seconds=args.seconds or 10)}[args.only_side]()
         print(json.dumps(e))
         return
     if args.only_general:
@@ -1792,7 +1849,8 @@ def main():
                           ("plan_collect_pcie", lambda: plan_collect_pcie_both(ctx, args.eps, steps2)),
                           ("plan_stages", lambda: plan_stages(ctx, args.eps, 5)),
                           ("plan_generic", lambda: plan_generic(ctx, args.eps, 10)),
-                          ("arch_ops", lambda: arch_ops(ctx, args.eps, 10, args.no_cpu))):
+                          ("arch_ops", lambda: arch_ops(ctx, args.eps, 10, args.no_cpu)),
+                          ("q6_next", lambda: q6_side(ctx, args.eps, 5, args.no_cpu))):
             try:
                 also[label] = fn()
             except Exception as e:
