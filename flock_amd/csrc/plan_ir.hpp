@@ -306,6 +306,40 @@ struct Builder {
         return nullptr;
     }
 
+    // An EXPRESSION where an operator reads a column (GROUP BY a % 10, SUM(price * 2), ORDER BY a + b): `in` gets a projection on top (once:
+    // `wrapped`) that carries every column through and the expression's value beside them (the general evaluator, valprog.hpp); returns the
+    // new column's index in the wrapped schema, -1 when refused (`err` says why).
+    int computed_column(std::unique_ptr<Node> &in, bool &wrapped, const JValue *e, const char *what) {
+        if (!wrapped) {
+            std::unique_ptr<Node> w(new Node());
+            w->kind = NKind::Project;
+            w->id = plan->n_nodes++;
+            w->schema = in->schema;
+            for (size_t i = 0; i < in->schema.size(); ++i) {
+                std::unique_ptr<Expr> c(new Expr());
+                c->kind = EKind::Col;
+                c->col = (int)i;
+                w->proj.emplace_back(std::move(c), in->schema[i].name);
+            }
+            w->in.push_back(std::move(in));
+            in = std::move(w);
+            wrapped = true;
+        }
+        const std::vector<Field> &below = in->in[0]->schema;
+        auto x = expr(e, below);
+        if (!x) return -1;
+        const int ty = expr_static_type(x.get(), below);
+        if (ty < 0 || ty > 3) { fail(std::string(what) + " over an expression without a numeric type"); return -1; }
+        Field f;
+        f.name = "#" + std::to_string(in->schema.size());
+        f.type = (ColType)ty;
+        f.nullable = true;
+        f.is_ts = x->kind == EKind::Cast && x->cast_ts;
+        in->proj.emplace_back(std::move(x), f.name);
+        in->schema.push_back(f);
+        return (int)in->schema.size() - 1;
+    }
+
     static std::string guess_relation(const std::vector<Field> &f) {
         auto has = [&](const char *n) { return std::any_of(f.begin(), f.end(), [&](const Field &x) { return x.name == n; }); };
         if (has("auction") || has("bidder") || has("price")) return "bid";
@@ -410,36 +444,7 @@ struct Builder {
             // (Partial) gets a projection underneath that carries every input column through and the expression's value beside them
             // (the general evaluator, valprog.hpp); the aggregate then reads a column, as ever.  -1: refused (plan->why says why).
             bool wrapped = false;
-            auto computed = [&](const JValue *e, const char *what) -> int {
-                if (!wrapped) {
-                    std::unique_ptr<Node> w(new Node());
-                    w->kind = NKind::Project;
-                    w->id = plan->n_nodes++;
-                    w->schema = in->schema;
-                    for (size_t i = 0; i < in->schema.size(); ++i) {
-                        std::unique_ptr<Expr> c(new Expr());
-                        c->kind = EKind::Col;
-                        c->col = (int)i;
-                        w->proj.emplace_back(std::move(c), in->schema[i].name);
-                    }
-                    w->in.push_back(std::move(in));
-                    in = std::move(w);
-                    wrapped = true;
-                }
-                const std::vector<Field> &below = in->in[0]->schema;
-                auto x = expr(e, below);
-                if (!x) return -1;
-                const int ty = expr_static_type(x.get(), below);
-                if (ty < 0 || ty > 3) { fail(std::string(what) + " over an expression without a numeric type"); return -1; }
-                Field f;
-                f.name = "#" + std::to_string(in->schema.size());
-                f.type = (ColType)ty;
-                f.nullable = true;
-                f.is_ts = x->kind == EKind::Cast && x->cast_ts;
-                in->proj.emplace_back(std::move(x), f.name);
-                in->schema.push_back(f);
-                return (int)in->schema.size() - 1;
-            };
+            auto computed = [&](const JValue *e, const char *what) -> int { return computed_column(in, wrapped, e, what); };
             const JValue *ge = j->get("group_expr");
             size_t gi = 0;
             if (ge && ge->kind == JValue::Arr)
@@ -552,22 +557,39 @@ struct Builder {
             n->kind = NKind::Sort;
             auto in = node(j->get("input"), depth + 1);
             if (!in) return nullptr;
-            n->schema = in->schema;
+            const size_t n_in = in->schema.size();
+            bool wrapped = false;
             const JValue *ex = j->get("expr");
             if (!ex || ex->kind != JValue::Arr || ex->arr.empty()) { fail("sort_exec without expr"); return nullptr; }
             for (auto &k : ex->arr) {
                 const JValue *e = k->get("expr");
-                if (!e || etag(e) != "column") { fail("ORDER BY on something other than a column"); return nullptr; }
+                if (!e) { fail("sort_exec key without expr"); return nullptr; }
                 SortCol sc;
-                sc.col = resolve(e, n->schema);
-                if (sc.col < 0) { fail("ORDER BY column '" + e->s("name") + "' not in the input schema"); return nullptr; }
+                // ORDER BY an expression: its value becomes a column underneath (computed_column) and is dropped again above the sort
+                sc.col = etag(e) == "column" ? resolve(e, in->schema) : computed_column(in, wrapped, e, "ORDER BY");
+                if (sc.col < 0) { if (err.empty()) fail("ORDER BY column '" + e->s("name") + "' not in the input schema"); return nullptr; }
                 const JValue *opt = k->get("options");
                 const JValue *d = opt ? opt->get("descending") : nullptr, *nf = opt ? opt->get("nulls_first") : nullptr;
                 sc.descending = d && d->kind == JValue::Bool && d->b;
                 sc.nulls_first = nf && nf->kind == JValue::Bool && nf->b;
                 n->sort_cols.push_back(sc);
             }
+            n->schema = in->schema;
             n->in.push_back(std::move(in));
+            if (wrapped) {   // the sort's own columns only: a projection on top takes the computed keys out again
+                n->id = plan->n_nodes++;
+                std::unique_ptr<Node> top(new Node());
+                top->kind = NKind::Project;
+                for (size_t i = 0; i < n_in; ++i) {
+                    std::unique_ptr<Expr> c(new Expr());
+                    c->kind = EKind::Col;
+                    c->col = (int)i;
+                    top->proj.emplace_back(std::move(c), n->schema[i].name);
+                    top->schema.push_back(n->schema[i]);
+                }
+                top->in.push_back(std::move(n));
+                n = std::move(top);
+            }
         } else if (t == "window_agg_exec") {
             // WindowAggExec (q6.sql: ROW_NUMBER() OVER (PARTITION BY a_id ORDER BY price DESC), benchmarks/src/nexmark/query/q6_plan.fmt:6,11).
             // The physical planner sorts the input by (PARTITION BY, ORDER BY) underneath (a sort_exec); the operator numbers the rows of every

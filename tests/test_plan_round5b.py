@@ -330,3 +330,36 @@ def test_a_subquery_named_twice_runs_once(gpu):
         if mode == "generic":
             assert ran["dense_group_kernel"]["launches"] == 1, ran
     assert rows["generic"] == rows["fused"] and len(rows["fused"]) >= 1
+
+
+def _sort_plan(keys):
+    return {"execution_plan": "sort_exec", "input": scan(), "expr": [{"expr": e, "options": {"descending": bool(d), "nulls_first": bool(nf)}} for e, d, nf in keys]}
+
+
+def test_order_by_an_expression_parses_with_projections_around_the_sort():
+    from flock_amd.runtime import explain
+    txt = explain(_sort_plan([(binary(cast(col("i"), "Int64"), "Plus", col("l")), True, True), (col("j"), False, False)]))
+    lines = [l.strip() for l in txt.splitlines()]
+    assert lines[0].startswith("Project") and lines[1].startswith("Sort(#") and lines[2].startswith("Project") and lines[0].count(":") == len(F), txt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_order_by_expressions(gpu, seed):
+    """ORDER BY <expression> [DESC], <column>: rows IN ORDER equal the oracle's stable sort over the expression's values (NULLs where the options put
+    them); the output carries the input's columns only."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(90 + seed)
+    t = table([40, 3000, 9000][seed], r, null_p=0.25)
+    e1 = [binary(cast(col("i"), "Int64"), "Plus", col("l")), binary(col("f"), "Multiply", lit("Float64", -1.5)),
+          case([(binary(col("i"), "Lt", lit("Int32", 100)), lit("Int32", 0))], binary(col("i"), "Modulo", lit("Int32", 7)))][seed]
+    keys = [(e1, seed != 1, seed == 0), (col("j"), False, False)]
+    ctx = ExecutionContext([_sort_plan(keys)], gpu=gpu)
+    rb = collect(ctx, [[batches(t, 2000)]])[0][0]
+    ctx.close()
+    assert rb.schema.names == NAMES
+    tmp = dict(t)
+    tmp["#k"] = g.project_typed(t, [(e1, "#k")], TYPES)["#k"]
+    want = g.sort_exec(tmp, [("#k", keys[0][1], keys[0][2]), ("j", False, False)])
+    del want["#k"]
+    assert norm(pyrows(rb)) == norm(g.rows(want))
