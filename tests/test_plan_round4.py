@@ -79,13 +79,18 @@ def test_sort_and_limit_parse_into_the_operator_tree():
     from flock_amd.runtime import explain
     text = explain(_sort_plan([("s", False), ("i", True)], limit=7))
     assert text.splitlines()[0].startswith("Limit(7)") and "Sort(s ASC, i DESC)" in text.splitlines()[1]
-    # ORDER BY a computed expression is handed back, never mis-executed
+    # ORDER BY a numeric expression: its value as a column under the sort, dropped again above it (round 5, tests/test_plan_round5b.py); an
+    # expression without a numeric type (a comparison) is handed back, never mis-executed
     from flock_amd import FlockGpuError, _ffi
+    ok = _sort_plan([("i", False)])
+    key = ok["expr"][0]["expr"]
+    ok["expr"][0]["expr"] = {"physical_expr": "binary_expr", "op": "Plus", "left": key, "right": key}
+    assert [l.split()[0].split("(")[0] for l in explain(ok).splitlines()[:3]] == ["Project", "Sort", "Project"]
     bad = _sort_plan([("i", False)])
-    bad["expr"][0]["expr"] = {"physical_expr": "binary_expr", "op": "Plus", "left": bad["expr"][0]["expr"], "right": bad["expr"][0]["expr"]}
+    bad["expr"][0]["expr"] = {"physical_expr": "binary_expr", "op": "Lt", "left": key, "right": key}
     with pytest.raises(FlockGpuError) as e:
         explain(bad)
-    assert e.value.code == _ffi.ERR_UNSUPPORTED
+    assert e.value.code == _ffi.ERR_UNSUPPORTED and "ORDER BY" in str(e.value)
 
 
 def test_partition_scheme_is_named_and_checked():
