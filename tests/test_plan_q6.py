@@ -134,3 +134,23 @@ def test_q6_stage_by_stage_equals_the_whole_plan(instances, on_device):
         assert got == list(zip(s.tolist(), a.tolist()))
     run.close()
     gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [0, 10])
+def test_pass_through_queries_q0_and_q10(q):
+    """benchmarks/src/nexmark/query/q0.sql (`SELECT * FROM bid`) and q10.sql (the four bid columns by name): one projection over the scan (q0_plan.fmt,
+    q10_plan.fmt).  The batches that come back hold the rows that went in, in order, with the schema's types (Timestamp(Millisecond) stays one)."""
+    from flock_amd import GpuContext
+    from flock_amd.runtime import ExecutionContext, collect
+    s = oracle.NexmarkStream(seed=2, eps=30_000)
+    bi = s.bids(0, 60_000)
+    bid = pa.record_batch([pa.array(bi["auction"]), pa.array(bi["bidder"]), pa.array(bi["price"]), pa.array(bi["b_date_time"]).cast(TS)], names=["auction", "bidder", "price", "b_date_time"])
+    gpu = GpuContext(0)
+    ctx = ExecutionContext([json.load(open(os.path.join(ROOT, "tests", "golden", "plans", f"q{q}.json")))], gpu=gpu)
+    out = collect(ctx, [[[bid.slice(0, 20_000), bid.slice(20_000)]]])[0]
+    got = pa.Table.from_batches(out).combine_chunks().to_batches()[0]
+    assert got.schema.names == bid.schema.names and got.schema.field("b_date_time").type == TS
+    assert all(got[c].equals(bid[c]) for c in bid.schema.names)       # (the plan's fields are NOT NULL, pyarrow's inferred ones nullable: columns, not batches)
+    ctx.close()
+    gpu.close()
