@@ -363,3 +363,28 @@ def test_order_by_expressions(gpu, seed):
     want = g.sort_exec(tmp, [("#k", keys[0][1], keys[0][2]), ("j", False, False)])
     del want["#k"]
     assert norm(pyrows(rb)) == norm(g.rows(want))
+
+
+@pytest.mark.gpu
+def test_the_new_operators_on_an_empty_relation(gpu):
+    """No rows in: computed projections, a predicate of the general evaluator, GROUP BY / aggregates over expressions, ORDER BY an expression and
+    ROW_NUMBER() all hand back an empty batch of the right schema (an ungrouped aggregate is not among them: MAX over nothing is one NULL row)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    t = {n: [] for n in NAMES}
+    e = binary(cast(col("i"), "Int64"), "Plus", col("l"))
+    srt = _sort_plan([(e, True, True)])
+    plans = {
+        "projection": (projection([(col("j"), "j"), (e, "x"), (case([(binary(col("f"), "Gt", lit("Float64", 0.0)), col("f"))]), "y")]), ["j", "x", "y"]),
+        "filter": ({"execution_plan": "filter_exec", "predicate": binary(binary(col("i"), "Divide", lit("Int32", 3)), "Gt", lit("Int32", 1)), "input": scan()}, NAMES),
+        "aggregate": (_agg_over_expressions(binary(col("j"), "Modulo", lit("Int32", 10)), [("count", None, "UInt64"), ("sum", e, "Int64")]), None),
+        "sort": (srt, NAMES),
+        "window": ({"execution_plan": "window_agg_exec", "input": srt, "window_expr": [{"fun": "RowNumber", "name": "rn", "partition_by": [col("i")], "order_by": []}]}, ["rn"] + NAMES),
+    }
+    for name, (plan, names) in plans.items():
+        ctx = ExecutionContext([plan], gpu=gpu)
+        for feed in ([[batches(t, 1)]], [[batches(t, 1)]]):     # twice: the second execute finds the first one's (empty) arenas
+            out = collect(ctx, feed)[0]
+            assert sum(b.num_rows for b in out) == 0, name
+            if names is not None:
+                assert out[0].schema.names == names, (name, out[0].schema.names)
+        ctx.close()
