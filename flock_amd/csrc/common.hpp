@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -246,6 +247,42 @@ inline void profile_drain(flockgpu_ctx *ctx) {
     ctx->pending.clear();
 }
 
+// The host's wait for an answer a kernel writes into PINNED memory (a selected-row count, byte totals, a pair total): the words hold
+// kPinnedPending when the kernel is queued -- every one of them is written exactly once by the kernel, with a value that is never
+// kPinnedPending -- and the host spins until none does.  It learns of such a store ~6 us after it, of a finished stream (hipStreamSynchronize)
+// ~12 us after (tools/micro/sync_latency.hip); no fence is asked of the kernel (a system-scope release there writes the L2 back: DESIGN
+// section 10), every word is its own "ready" mark.  What the host reads afterwards are these words only; everything else the call wrote stays
+// on the device, behind the stream's order.  A kernel that never answers (a fault) ends the spin after 2 ms in hipStreamSynchronize, which
+// reports it.
+constexpr uint64_t kPinnedPending = ~uint64_t(0);
+inline void pinned_pending(uint64_t *words, int n) {
+    for (int i = 0; i < n; ++i) __atomic_store_n(&words[i], kPinnedPending, __ATOMIC_RELAXED);
+}
+template <typename W>
+inline int wait_pinned_words(flockgpu_ctx *ctx, const W *words, int n, W pending) {
+    static const bool no_poll = exp_env("FLOCKGPU_NO_POLL") != nullptr;   // (A/B knob of the experimental build)
+    if (!no_poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            int i = 0;
+            while (i < n && __atomic_load_n(&words[i], __ATOMIC_ACQUIRE) != pending) ++i;
+            if (i == n) return FLOCKGPU_OK;
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLOCKGPU_OK;
+}
+// (32-bit words -- error words, the halves of a published 64-bit total: a half that happens to BE 0xFFFFFFFF keeps the host spinning for its
+// 2 ms and then in hipStreamSynchronize; right, only slow, and it takes a total no operator accepts)
+constexpr uint32_t kPinnedPending32 = ~uint32_t(0);
+inline void pinned_pending32(uint32_t *words, int n) {
+    for (int i = 0; i < n; ++i) __atomic_store_n(&words[i], kPinnedPending32, __ATOMIC_RELAXED);
+}
+inline int wait_pinned32(flockgpu_ctx *ctx, const uint32_t *words, int n) { return wait_pinned_words<uint32_t>(ctx, words, n, kPinnedPending32); }
+inline int wait_pinned(flockgpu_ctx *ctx, const uint64_t *words, int n) {
+    return wait_pinned_words<uint64_t>(ctx, words, n, kPinnedPending);
+}
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Asynchronous calls (flockgpu.h): `fn` runs on the ctx's worker thread, one call in flight per ctx.  ctx_submit returns

@@ -847,6 +847,7 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
     FG_TRY(pinned_get_t(ctx, (g->name + ".totals").c_str(), (size_t)kMaxUtf8Multi + 1, &g->h_col_base));
     for (int c = 0; c <= kMaxUtf8Multi; ++c) g->h_col_base[c] = 0;
     if (n <= 0) return FLOCKGPU_OK;
+    pinned_pending(g->h_col_base, k + 1);   // (utf8_col_bases_kernel writes each of them once: gather_utf8_multi_wait)
     const int64_t all = g->tiles_stride * k;
     if (all > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
     uint64_t *d_col_base = nullptr;
@@ -864,6 +865,11 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
     FG_TRY(launch_tile_scan(ctx, g->counts, (int32_t)all, g->tile_base, nullptr, 0, nullptr));
     hipLaunchKernelGGL(utf8_col_bases_kernel, dim3(1), dim3(64), 0, ctx->stream, g->tile_base, g->tiles_stride, k, d_col_base, g->h_col_base);
     return check_launch(ctx, "utf8_col_bases_kernel");
+}
+
+int gather_utf8_multi_wait(flockgpu_ctx *ctx, const Utf8MultiGather &g) {
+    if (g.n <= 0) return FLOCKGPU_OK;   // (nothing was queued)
+    return wait_pinned(ctx, g.h_col_base, g.k + 1);
 }
 
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n) {

@@ -75,6 +75,8 @@ struct Utf8MultiGather {
 };
 int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n,
                             Utf8MultiGather *g, const uint64_t *d_n = nullptr);
+// The wait between begin and finish when nothing else has to finish with it: polls the byte totals in pinned memory (common.hpp: wait_pinned).
+int gather_utf8_multi_wait(flockgpu_ctx *ctx, const Utf8MultiGather &g);
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n);
 int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockgpu_utf8 *outs, int64_t *n_bytes, const int64_t *known_bytes = nullptr);
 
@@ -93,7 +95,6 @@ struct Utf8FastGather {
 };
 int gather_utf8_multi_fast(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 *srcs, int k, const int32_t *rows, int64_t n_bound,
                            const uint64_t *d_n, const int64_t *cap_bytes, Utf8FastGather *g);
-
 // ---- small-scalar plumbing of the operators that end in a host wait (round 5).  One execute of a generic plan made 7 hipMemsetAsync
 // and 11 small device-to-host hipMemcpyAsync calls (rocprofv3 --hip-trace: ~10 us of host time each, a 5.5 us copy kernel per
 // memcpy on the stream) around 23 kernels; these two replace them:

@@ -1550,7 +1550,7 @@ struct Exec {
             for (int j = 0; j < k; ++j) srcs[j] = flockgpu_utf8{in.cols[utf8[g0 + (size_t)j]].c.offsets, static_cast<const uint8_t *>(in.cols[utf8[g0 + (size_t)j]].c.values)};
             Utf8MultiGather g;
             FG_TRY(gather_utf8_multi_begin(ctx, node_key(pl, n, "mtake", first_out + (int)utf8[g0]).c_str(), srcs, k, rows, n_rows, &g));
-            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FG_TRY(gather_utf8_multi_wait(ctx, g));
             FG_TRY(gather_utf8_multi_finish(ctx, g, outs, nb));
             for (int j = 0; j < k; ++j) {
                 const size_t i = utf8[g0 + (size_t)j];

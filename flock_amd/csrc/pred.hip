@@ -375,6 +375,7 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
     FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
+    pinned_pending(reinterpret_cast<uint64_t *>(h_off), 2);   // (wait_pinned below)
     bool wide = false;
     for (int i = 0; i < prog.n_leaves; ++i) {
         const PredLeafDesc &l = prog.leaves[i];
@@ -407,7 +408,7 @@ int pred_to_rows(flockgpu_ctx *ctx, const char *name, const PredProgram &prog, i
         FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the selected-row count goes straight into pinned memory)
         FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
     }
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_off), 2));
     *n_out = h_off[1];
     return FLOCKGPU_OK;
 }

@@ -1302,6 +1302,7 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
     FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
     FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
+    pinned_pending(reinterpret_cast<uint64_t *>(h_off), 2);
     {
         LaunchScope ls(ctx, "mask_flag_kernel");
         hipLaunchKernelGGL(mask_flag_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, mask, rows, st, flags, counts);
@@ -1313,7 +1314,7 @@ int mask_to_rows(flockgpu_ctx *ctx, const char *name, const uint8_t *mask, int64
         FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (the scan writes its segment offsets straight into pinned memory)
         FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
     }
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_off), 2));
     *n_out = h_off[1];
     return FLOCKGPU_OK;
 }
@@ -1607,6 +1608,7 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
     FG_TRY(arena_get_t(ctx, (base + ".dcounts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".dbase").c_str(), (size_t)st.n_tiles + 1, &tile_base));
     FG_TRY(pinned_get_t(ctx, (base + ".doff").c_str(), 2, &h_off));
+    pinned_pending(reinterpret_cast<uint64_t *>(h_off), 2);
     FG_TRY(arena_get_t(ctx, (base + ".dslots").c_str(), (size_t)std::min<int64_t>(range, rows) + 4, &slots));   // (at most one live slot per row)
     {
         LaunchScope ls(ctx, "dense_live_flag_kernel");
@@ -1619,7 +1621,7 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
         FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));   // (segment offsets straight into pinned memory)
         FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, slots));
     }
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_off), 2));   // (h_err: written by dense_live_flag_kernel, a kernel earlier on the stream)
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     const int64_t n_groups = h_off[1];
     int64_t *ok = nullptr;
@@ -1750,13 +1752,14 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         for (;;) {
             FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)cap_pairs + 4, &ob));
             FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)cap_pairs + 4, &op));
+            pinned_pending(reinterpret_cast<uint64_t *>(h_tot), 1);
             {
                 LaunchScope ls(ctx, "join_tiny_kernel");
                 hipLaunchKernelGGL(join_tiny_kernel, dim3(1), dim3(kTinyThreads), 0, ctx->stream, bk, (int32_t)nb, pk, (int32_t)np, ob, op,
                                    (uint32_t)std::min<uint64_t>(cap_pairs, 0x7fffffffu), h_tot);
             }
             FG_TRY(check_launch(ctx, "join_tiny_kernel"));
-            FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_tot), 1));
             if (h_tot[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot[0]);
             if (h_tot[0] <= cap_pairs) break;
             cap_pairs = h_tot[0];   // the estimate was too small: once more, with room for every pair
@@ -1796,8 +1799,9 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
                   (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
+    pinned_pending32(h_err, 2 + 2 * kJoinTotalSlots);
     FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2).add(h_tot64, d_tot64, 2 * kJoinTotalSlots)));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned32(ctx, h_err, 2 + 2 * kJoinTotalSlots));
     for (int sl = 1; sl < kJoinTotalSlots; ++sl) h_tot64[0] += h_tot64[sl];
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
     // the 64-bit total decides: the 32-bit inclusive scan of `counts` is only read when it cannot have wrapped
@@ -1846,8 +1850,9 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
     RELOPS_LAUNCH(ctx, "join_probe_dense_kernel", join_probe_dense_kernel<false>, n_right, right.values, (int32_t)right.type, n_right, kmin, range, head, next, counts,
                   (int32_t *)nullptr, (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
+    pinned_pending32(h_err, 2 + 2 * kJoinTotalSlots);
     FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2).add(h_tot64, d_tot64, 2 * kJoinTotalSlots)));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned32(ctx, h_err, 2 + 2 * kJoinTotalSlots));
     for (int sl = 1; sl < kJoinTotalSlots; ++sl) h_tot64[0] += h_tot64[sl];
     if (*h_err) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a build key outside the column statistics [%lld, %lld] the table was sized from", name, (long long)kmin, (long long)kmax);
     if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);

@@ -233,8 +233,9 @@ int run(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t row
         else hipLaunchKernelGGL(valprog_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, prog, rows, out_values, out_valid, (int32_t)out_type, d_err);
     }
     FG_TRY(check_launch(ctx, "valprog_kernel"));
+    pinned_pending32(h_err, 1);
     FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 1)));
-    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FG_TRY(wait_pinned32(ctx, h_err, 1));
     if (*h_err & kErrDivZero) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: division by zero", name);
     if (*h_err & kErrCast) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a value does not fit the type it is cast to", name);
     if (*h_err & kErrNull) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a NULL result where the expression was taken not to produce one", name);
