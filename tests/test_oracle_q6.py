@@ -44,3 +44,24 @@ def test_q6_numpy_equals_the_operator_walk_on_nexmark_events(seed, eps, seconds)
     walk = g.nexmark_q6(auction, bid)
     s, a = oracle.q6_avg_price_by_seller(au["a_id"], au["a_date_time"], au["expires"], au["seller"], bi["auction"], bi["price"], bi["b_date_time"])
     assert len(s) > 20 and sorted(zip(walk["seller"], walk["AVG(R.price)"])) == list(zip(s.tolist(), a.tolist()))
+
+
+@pytest.mark.parametrize("seed,eps,seconds", [(2, 4000, 3), (9, 20_000, 2)])
+def test_q6_numpy_equals_an_independent_pandas_formulation(seed, eps, seconds):
+    """A third engine: pandas (merge, boolean filter, stable sort_values + groupby().cumcount() as ROW_NUMBER, groupby().mean()) over the same events
+    -- the way the other queries' oracles are cross-checked against pyarrow / Acero (tests/test_oracle_cross.py)."""
+    pd = pytest.importorskip("pandas")
+    au, bi, _, _ = _tables(seed, eps, seconds)
+    a = pd.DataFrame({k: np.asarray(au[k]) for k in ("a_id", "a_date_time", "expires", "seller")})
+    b = pd.DataFrame({k: np.asarray(bi[k]) for k in ("auction", "price", "b_date_time")})
+    j = a.merge(b, left_on="a_id", right_on="auction", how="inner", sort=False)
+    j = j[(j.b_date_time >= j.a_date_time) & (j.b_date_time <= j.expires)]
+    j = j.sort_values(["a_id", "price"], ascending=[True, False], kind="stable")
+    q = j[j.groupby("a_id").cumcount() == 0]
+    q = q.sort_values(["seller", "b_date_time"], ascending=[True, False], kind="stable")
+    r = q[q.groupby("seller").cumcount() < 10]
+    want = r.groupby("seller")["price"].mean()
+    s, avg = oracle.q6_avg_price_by_seller(au["a_id"], au["a_date_time"], au["expires"], au["seller"], bi["auction"], bi["price"], bi["b_date_time"])
+    # (ties: pandas' merge keeps the left rows' order and, within one, the right rows' -- the (auction row, bid row) order of the numpy restatement)
+    assert len(s) > 50 and s.tolist() == want.index.tolist()
+    assert np.allclose(avg, want.to_numpy(), rtol=0, atol=1e-9) and np.array_equal(avg, want.to_numpy())
