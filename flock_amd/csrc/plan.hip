@@ -745,7 +745,9 @@ int classify(const flockgpu_plan *pl) {
 // scanned columns (which leaf DATA a scan reads is decided per execute: Exec::resolve_leaf)
 void expr_sig(const Expr *e, std::string *o) {
     if (!e) { *o += "~"; return; }
-    *o += "(" + std::to_string((int)e->kind) + "," + std::to_string(e->col) + "," + std::to_string(e->i) + "," + std::to_string(e->f) + "," + e->s + "," +
+    uint64_t fbits = 0;   // (the literal's bits: std::to_string keeps six decimals, and two literals that differ beyond them are two tables)
+    std::memcpy(&fbits, &e->f, sizeof fbits);
+    *o += "(" + std::to_string((int)e->kind) + "," + std::to_string(e->col) + "," + std::to_string(e->i) + "," + std::to_string(fbits) + "," + e->s + "," +
           std::to_string((int)e->cast_to) + (e->negated ? "n" : "") + (e->big_unsigned ? "u" : "") + (e->try_cast ? "t" : "") + (e->cast_ts ? "s" : "") + "," + e->lit_kind;
     expr_sig(e->l.get(), o);
     expr_sig(e->r.get(), o);
@@ -765,6 +767,11 @@ void node_sig(const flockgpu_plan *pl, const Node *n, bool top, std::string *o, 
     *o += std::to_string(n->n_parts) + "|";
     for (auto &k : n->sort_cols) *o += std::to_string(k.col) + (k.descending ? "d" : "a") + (k.nulls_first ? "f" : "l") + ",";
     *o += std::to_string(n->limit) + "|";
+    for (auto &part : n->win_part) {   // (Window: the PARTITION BY columns of each ROW_NUMBER())
+        for (int c : part) *o += std::to_string(c) + ",";
+        *o += ";";
+    }
+    *o += "|";
     expr_sig(n->pred.get(), o);
     for (auto &pr : n->proj) { expr_sig(pr.first.get(), o); *o += pr.second + ","; }
     if (n->kind == NKind::Scan) {
@@ -1392,6 +1399,10 @@ struct Exec {
             return b.add_leaf(d) ? FLOCKGPU_OK : pred_full();
         }
         if (l.k != Operand::COL && l.k != Operand::MOD) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a comparison of two literals");
+        // from here on the right side is read as a literal: `a % 3 = b`, `a = b % 3`, `a % 2 = b % 2` have no one-pass leaf (the general
+        // evaluator takes them) -- without this guard they would compare against r.i's default 0
+        if (r.k != Operand::INT && r.k != Operand::FLT && r.k != Operand::STR)
+            return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a column (or its remainder) against a non-literal has no one-pass leaf");
         const ColType ct = l.col->c.type;
         if (r.k == Operand::STR) {
             if (ct != ColType::UTF8 || l.k == Operand::MOD || (op != CmpOp::EQ && op != CmpOp::NE))
@@ -3299,6 +3310,10 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         plan->ring_newest_done = false;
     }
     if (from_prefetch) {
+      // a later column's failure must not leave an earlier column's byte cursor advanced: the retry would append behind the orphaned bytes
+      // while offsets[ld.rows] still names the old end
+      std::vector<int64_t> pre_bytes_before(plan->leaves[(size_t)input].cols.size());
+      for (size_t c = 0; c < pre_bytes_before.size(); ++c) pre_bytes_before[c] = plan->leaves[(size_t)input].cols[c].bytes;
       const int rc_append = [&]() -> int {
         LeafData &ld = plan->leaves[(size_t)input];
         const Leaf &lf = plan->ir.leaves[(size_t)input];
@@ -3353,7 +3368,14 @@ int flockgpu_plan_feed_pane(flockgpu_plan *plan, int input, int64_t pane_id, con
         if (plan->ring_q5) plan->ring_groups.back() = 0;
         return FLOCKGPU_OK;
       }();
-      if (rc_append != FLOCKGPU_OK) undo_begin();   // (the prefetch stays pending: the same call can be repeated)
+      if (rc_append != FLOCKGPU_OK) {   // (the prefetch stays pending: the same call can be repeated)
+          LeafData &ld = plan->leaves[(size_t)input];
+          for (size_t c = 0; c < pre_bytes_before.size(); ++c) {
+              if (!ld.pane_bytes.empty()) ld.pane_bytes.back()[c] -= ld.cols[c].bytes - pre_bytes_before[c];
+              ld.cols[c].bytes = pre_bytes_before[c];
+          }
+          undo_begin();
+      }
       return rc_append;
     }
     if (n_batches == 0) return FLOCKGPU_OK;   // an empty pane still advances the ring

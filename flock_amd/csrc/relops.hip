@@ -1585,8 +1585,12 @@ int group_by_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &key, in
     {
         const size_t lds = (size_t)kDenseBins * (4 + 8 * (size_t)sp.n);
         const unsigned tiles = (unsigned)div_up(rows, kDenseTile);
-        LaunchScope ls(ctx, "dense_group_kernel");
         const bool k64 = key.type != ColType::I32;
+        // four non-COUNT accumulators need 72 KB of the CU's 160 KB: above the 64 KB a launch gets without asking
+        if (lds > 64 * 1024)
+            FG_HIP(ctx, hipFuncSetAttribute(k64 ? reinterpret_cast<const void *>(&dense_group_kernel<true, true>) : reinterpret_cast<const void *>(&dense_group_kernel<false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LaunchScope ls(ctx, "dense_group_kernel");
         if (sp.n == 0) {
             if (k64) hipLaunchKernelGGL((dense_group_kernel<true, false>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);
             else hipLaunchKernelGGL((dense_group_kernel<false, false>), dim3(tiles), dim3(kBlock), lds, ctx->stream, key.values, rows, kmin, range, sp, cnt, acc, d_err);

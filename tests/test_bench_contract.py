@@ -106,6 +106,18 @@ def test_n_ranks_line_reports_the_configured_total_and_carries_exchange_and_weak
     assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] == 8.1e12
     assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] == 3.1e12 and d["exchange"]["phases_ms"]["final"] == 0.07
     assert "kernels_ms_rank0" not in d["exchange"] and len(bench.final_line(out)) < 4096
+    # round 6: the join configs ride on the N > 1 line window-sharded and "strong", each with its own roofline and cpu_baseline; the collective
+    # that ran is named at the top level
+    for k, cfg in (("q3", 2), ("q8", 4)):
+        out[k] = {"value": 2.2e12, "unit": "rows/s", "n_gpus": 8, "ms_per_step": 0.04, "scaling": "strong", "roofline": dict(out["roofline"], frac=0.51),
+                  "cpu_baseline": dict(out["cpu_baseline"]), "config": {"workload": f"NEXMark q{k[1]} ... 80000000 input rows in total over 8 GPUs (BASELINE.json configs[{cfg}])"}}
+    out["collective"] = {"library": "RCCL (ncclSend / ncclRecv groups inside libflockgpu)", "ranks": 8, "transport": "rccl"}
+    d = json.loads(bench.final_line(out))
+    assert d["cpu_baseline"]["value"] > 0 and d["collective"]["ranks"] == 8 and d["collective"]["transport"] == "rccl"
+    for k, cfg in (("q3", "configs[2]"), ("q8", "configs[4]")):
+        assert d[k]["scaling"] == "strong" and d[k]["n_gpus"] == 8 and d[k]["value"] == 2.2e12 and cfg in d[k]["workload"]
+        assert d[k]["roofline"]["frac"] == 0.51 and d[k]["cpu_baseline"]["value"] > 0
+    assert len(bench.final_line(out)) < 4096
     out.pop("exchange")
     out["exchange_error"] = "RuntimeError('ncclCommInitRank: unhandled system error')" + "x" * 1000
     d = json.loads(bench.final_line(out))
@@ -234,9 +246,9 @@ def test_two_ranks_on_one_gpu_run_the_configured_workload_and_the_exchange(tmp_p
     import json
     import subprocess
     env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, FLOCK_BENCH_ALSO=str(tmp_path / "also.json"),
-               FLOCK_BENCH_SHARED_GPU="1", FLOCK_BENCH_EXCHANGE_TIMEOUT="90", FLOCK_BENCH_SPAWN_TIMEOUT="400")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--seconds", "60", "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu"],
-                       capture_output=True, text=True, timeout=600, env=env)
+               FLOCK_BENCH_SHARED_GPU="1", FLOCK_BENCH_EXCHANGE_TIMEOUT="90", FLOCK_BENCH_SPAWN_TIMEOUT="500", FLOCK_BENCH_STRONG_JOINS="20,40")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--seconds", "60", "--steps", "2", "--warmup", "1", "--no-also", "--cpu-threads", "4"],
+                       capture_output=True, text=True, timeout=700, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     last = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
     assert len(last) < 4096
@@ -245,6 +257,13 @@ def test_two_ranks_on_one_gpu_run_the_configured_workload_and_the_exchange(tmp_p
     # the configured workload: ONE stream of 60 s in total, its windows dealt to the two ranks; the two-slices job rides along as `weak`
     assert "in total over 2 GPUs" in d["config"]["workload"] and d["config"]["windows_total"] == 11 and d["config"]["input_rows_total"] == 60 * 1_000_000 // 50 * 46
     assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
+    # a SCALE line is judged like the N = 1 line: the CPU baseline (rank 0's host cores, bounded sample) and the roofline ride on it, and the
+    # join configs the metric names (q3: configs[2], q8: configs[4]) are there window-sharded and "strong", each with its own pair
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["roofline"]["frac"] > 0
+    for k, cfg in (("q3", "configs[2]"), ("q8", "configs[4]")):
+        assert d[k]["scaling"] == "strong" and d[k]["value"] > 0 and d[k]["n_gpus"] == 2 and cfg in d[k]["workload"], d[k]
+        assert d[k]["cpu_baseline"]["value"] > 0 and d[k]["roofline"]["frac"] > 0, d[k]
+    assert d["collective"]["ranks"] == 2 and d["collective"]["transport"] == "ipc"
     # two processes on one device: RCCL refuses that, the ipc transport (flockgpu_comm_init_ipc) carries the same exchange end to end
     assert "exchange_error" not in d, d.get("exchange_error")
     assert d["exchange"]["scaling"] == "strong" and d["exchange"]["value"] > 0 and d["exchange"]["transport"] == "ipc" and d["exchange"]["ranks"] == 2
