@@ -47,6 +47,9 @@ constexpr int kQ5Variant = FLOCKGPU_AB_Q5_VARIANT;
 #else
 constexpr int kQ5Variant = 1;
 #endif
+constexpr int kQ5WaveForm = 0;                  // count kernel form of the shipped build: 0 = one workgroup per tile, 1 / 2 / 4 = one WAVE per tile, that many waves per workgroup
+constexpr bool kQ5XcdLocal = false;             // count kernel: a pane's tiles dealt to the blocks of ONE XCD, flush atomics in that XCD's L2
+constexpr int kQ5WavesPerCu = 20;               // persistent wave form: waves per CU in the grid (8 KB of LDS each)
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
 constexpr uint32_t kWideTile = 0x40000000u;     // slow-list tag: declined for its key spread (not for being ragged)
@@ -133,6 +136,7 @@ struct FlushArgs {
     uint32_t cap;
     uint32_t *tab_used;        // per window: non-zero once its hash table holds an entry
     uint32_t *err;
+    bool xcd_local = false;    // every workgroup that adds to this pane's counters runs on ONE XCD: the adds stay in that XCD's L2 (see q5_count_kernel)
 };
 
 // Adds one aggregated (key, count) pair of a tile: one atomic on the pane's counters, or -- for a key outside the
@@ -140,7 +144,8 @@ struct FlushArgs {
 __device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, const FlushArgs &f) {
     const uint64_t idx = (uint64_t)((int64_t)key - f.pane.base);
     if (idx < (uint64_t)f.pane.range) {
-        __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.xcd_local) __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     for (int wi = f.wp0; wi < f.wp1; ++wi) {
@@ -320,9 +325,10 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
                                               const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_win_ptr,
                                               const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap,
                                               uint32_t *tab_used, uint32_t *err, int32_t *slow_list, unsigned long long *pane_wsum, const int32_t tile,
-                                              uint32_t *hist, int32_t *s_red, unsigned long long *s_w) {
+                                              uint32_t *hist, int32_t *s_red, unsigned long long *s_w, const bool xcd_local = false) {
     const TileRange tr = locate_tile(st, tile, kQ5Tile);
     FlushArgs f;
+    f.xcd_local = xcd_local;
     f.wp0 = pane_win_ptr[tr.seg];
     f.wp1 = pane_win_ptr[tr.seg + 1];
     if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
@@ -465,6 +471,9 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
     }
     if (hot_cnt && lane == 0) atomicAdd(&hist[((uint32_t)hot - (uint32_t)mn) * rmul], hot_cnt);
     __syncthreads();
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_ABLATE)   // (ablation builds, WRONG results by design: what the flush costs)
+    if (hist[threadIdx.x] != 0x7fffffffu) return;
+#endif
     if (!full_tile) {   // hand the copies of key0 back (block-uniform branch; with replicas the SUM over a bin's four comes out right)
         if (threadIdx.x == 0) hist[((uint32_t)key0 - (uint32_t)mn) * rmul] -= (uint32_t)(kQ5Tile - (tr.hi - tr.lo));
         __syncthreads();
@@ -488,11 +497,27 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                           uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
                                                           int32_t *slow_list, const uint64_t *__restrict__ spec_info,
-                                                          unsigned long long *pane_wsum) {
+                                                          unsigned long long *pane_wsum, const int32_t *__restrict__ xcd_tile) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[kWeighted ? 4 : kHist + kHistPad];
     __shared__ int32_t s_red[8];
     __shared__ unsigned long long s_w[kWavesPerBlock];
     if (spec_info && !spec_info[2]) return;  // the device layout declined this call
+    if (xcd_tile) {
+        // XCD-local panes: block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md "Workgroup dispatch"; CHECKED here against the
+        // hardware's XCC_ID -- a block that finds itself elsewhere flags the call, the host repeats it the ordinary way), and xcd_tile deals
+        // every pane's tiles to the blocks of ONE XCD.  A pane's counters are then updated from one XCD only, so the flush atomics need no
+        // device scope: they execute in that XCD's L2 instead of being forwarded to the memory side one by one, and the lines go out once,
+        // as ordinary write-backs, at the latest when the kernel ends.
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // hwreg(HW_REG_XCC_ID, 0, 4)
+        if (xcc != (blockIdx.x & 7u)) {
+            if (threadIdx.x == 0) atomicOr(err, 4u);
+            return;
+        }
+        const int32_t tile = xcd_tile[blockIdx.x];
+        if (tile < 0) return;
+        q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w, true);
+        return;
+    }
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)   // (A/B builds only: num_cus x 8 workgroups walk the tiles)
     for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
         q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w);
@@ -501,6 +526,290 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
 #else
     q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, (int32_t)blockIdx.x, hist, s_red, s_w);
 #endif
+}
+
+// ---- count, wave-private form (round 6) ------------------------------------------------------------------------------------------
+// The workgroup form above is co-bound by its LDS atomics (~53 % of the kernel's cycles) BECAUSE its phases are serial per workgroup: eight
+// 16-byte loads per lane, a barrier (a workgroup-scope fence: `s_waitcnt vmcnt(0)` on gfx9), the 32 LDS adds per lane, a barrier, the
+// flush -- while a workgroup counts it has nothing in flight, and the eight workgroups of a CU cover for each other only on average.
+// Here a tile belongs to ONE wave with a private 2048-bin histogram (8 KB of LDS): no barrier anywhere (a wave's DS operations complete in
+// order), so the wave streams its 8192 rows as four chunks of eight loads, the next chunk's loads in flight under the current chunk's
+// LDS adds (`vmcnt(8)`, never 0), and nothing but the wave itself waits for its flush.  Bins are indexed by the key's low 11 bits, so no
+// minimum has to be known before the first add; the tile's span (max - min, reduced over the wave at the end) says afterwards whether two
+// keys shared a bin -- such a tile adds nothing and goes to the slow list, as the tiles wider than the workgroup form's histogram do.
+constexpr int kWaveHist = 2048;
+constexpr int kWaveChunks = 4, kWaveChunkIters = kQ5Iters * (kBlock / 64) / kWaveChunks;   // 4 chunks x 8 loads x 64 lanes x 4 keys = 8192 rows
+static_assert(kWaveChunks * kWaveChunkIters * 64 * 4 == kQ5Tile, "a wave tile is a q5 tile");
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+struct WaveCountState {
+    int32_t hot;
+    uint32_t hot_cnt;
+    int32_t mn, mx;
+};
+
+// one chunk: eight iterations of the hot-key ballot + LDS adds of q5_count_tile, bins by the key's low bits
+__device__ __forceinline__ void q5_wave_chunk(const int32_t (&k)[kWaveChunkIters][4], uint32_t *hist, WaveCountState &s, const int lane) {
+#pragma unroll
+    for (int it = 0; it < kWaveChunkIters; ++it) {
+        s.mn = min(s.mn, min(min(k[it][0], k[it][1]), min(k[it][2], k[it][3])));
+        s.mx = max(s.mx, max(max(k[it][0], k[it][1]), max(k[it][2], k[it][3])));
+        uint64_t b0 = __ballot(k[it][0] == s.hot);
+        if (__popcll((unsigned long long)b0) < kHotMin) {
+            if (s.hot_cnt) {   // the candidate went cold: park its count
+                if (lane == 0) atomicAdd(&hist[(uint32_t)s.hot & (kWaveHist - 1)], s.hot_cnt);
+                s.hot_cnt = 0;
+            }
+            const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
+            const uint64_t m1 = __ballot(k[it][0] == c1);
+            s.hot = c1;
+            b0 = m1;
+            if (__popcll((unsigned long long)m1) < kHotMin && ~m1) {
+                const int l2 = __ffsll((unsigned long long)~m1) - 1;
+                const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                const uint64_t m2 = __ballot(k[it][0] == c2);
+                if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                    s.hot = c2;
+                    b0 = m2;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool is_hot = k[it][j] == s.hot;
+            const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
+            s.hot_cnt += (uint32_t)__popcll((unsigned long long)b);
+            if (!is_hot) atomicAdd(&hist[(uint32_t)k[it][j] & (kWaveHist - 1)], 1u);
+        }
+    }
+}
+
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 5))) void q5_count_wave_kernel(
+    const int32_t *__restrict__ auction, SegTiles st, const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_win_ptr,
+    const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
+    int32_t *slow_list, const uint64_t *__restrict__ spec_info) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[kWaves][kWaveHist];
+    if (spec_info && !spec_info[2]) return;  // the device layout declined this call
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int32_t tile = (int32_t)blockIdx.x * kWaves + wave;
+    if (tile >= st.n_tiles) return;
+    uint32_t *hist = s_hist[wave];
+    const TileRange tr = locate_tile(st, tile, kQ5Tile);
+    const bool full_tile = tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile;
+    // a uniform base (SGPRs) + one loop-invariant 32-bit lane offset: the loads then need no address VGPRs of their own
+    const char *base = reinterpret_cast<const char *>(auction + tr.tile_begin);
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    int32_t ka[kWaveChunkIters][4], kb[kWaveChunkIters][4];
+    if (!full_tile) {   // the first / last tile of a pane (~430 of 122 K at 1e9 bids): the general path
+        if (lane == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = tile;
+        return;
+    }
+    // two loop-carried 32-bit lane offsets (the 13-bit immediate reaches 4 KB), advanced once per chunk, on ONE scalar base: no address
+    // temporaries that the register allocator could place in a key register whose load the waitcnt pass still tracks
+    uint32_t o0 = lane_off, o1 = lane_off + 4096u;
+    auto load_chunk = [&](int32_t (&k)[kWaveChunkIters][4], int) {
+        asm volatile("" : "+v"(o0), "+v"(o1));
+#pragma unroll
+        for (int it = 0; it < kWaveChunkIters; ++it) {
+            const int4 t = stream_load4(reinterpret_cast<const int32_t *>(base + (it < 4 ? o0 : o1) + (it & 3) * 1024));
+            k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
+        }
+        o0 += kWaveChunkIters * 1024;
+        o1 += kWaveChunkIters * 1024;
+    };
+    load_chunk(ka, 0);
+    {   // the histogram is zeroed under the first chunk's loads
+        uint4 *z = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+        for (int i = 0; i < kWaveHist / 4 / 64; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
+    FlushArgs f;
+    f.wp0 = pane_win_ptr[tr.seg];
+    f.wp1 = pane_win_ptr[tr.seg + 1];
+    if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
+    f.pane = panes[tr.seg];
+    f.pane_win_idx = pane_win_idx;
+    f.counters = counters;
+    f.tables = tables;
+    f.cap = cap;
+    f.tab_used = tab_used;
+    f.err = err;
+    WaveCountState s;
+    s.hot_cnt = 0;
+    s.mn = 0x7fffffff;
+    s.mx = (int32_t)0x80000000;
+    s.hot = 0;
+    // a rolled loop over chunk pairs: ka / kb are loop-carried, so the register allocator keeps TWO chunks of keys (64 VGPRs), not four
+#pragma unroll 1
+    for (int c = 0;; c += 2) {
+        load_chunk(kb, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        q5_wave_chunk(ka, hist, s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 >= kWaveChunks) break;
+        load_chunk(ka, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        q5_wave_chunk(kb, hist, s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    q5_wave_chunk(kb, hist, s, lane);
+    if (s.hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)s.hot & (kWaveHist - 1)], s.hot_cnt);
+    const int32_t mn = wave_min_i32(s.mn), mx = wave_max_i32(s.mx);
+    const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+    if (span >= (uint32_t)kWaveHist) {  // two keys may have shared a bin: nothing is flushed, the general path counts the tile
+        if (lane == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)((uint32_t)tile | kWideTile);
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the lanes' adds before the lanes' reads: one wave, DS operations in order)
+    for (uint32_t o = lane; o <= span; o += 64) {
+        const uint32_t key = (uint32_t)mn + o, c = hist[key & (kWaveHist - 1)];
+        if (c) emit_pair((int32_t)key, c, f);
+    }
+}
+
+// The same, PERSISTENT: wave g of G walks tiles g, g + G, ... and its loads never stop -- chunk 0 of the NEXT tile is requested before the
+// last chunk of the current one is counted, so the flush (LDS reads, ~10 global atomics per lane) and the next tile's descriptor run under
+// eight loads in flight.  The flush zeroes the bins it reads (only [min, max] can be non-zero), so the histogram is cleared once per wave.
+// ONE rolled loop over chunk PAIRS across tiles (two copies of the chunk body, two key buffers = 64 VGPRs), the flush under a uniform branch.
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 5))) void q5_count_wavep_kernel(
+    const int32_t *__restrict__ auction, const TileRange *__restrict__ tiles, int32_t n_tiles, const PaneDesc *__restrict__ panes,
+    const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap,
+    uint32_t *tab_used, uint32_t *err, int32_t *slow_list, const uint64_t *__restrict__ spec_info) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[kWaves][kWaveHist];
+    if (spec_info && !spec_info[2]) return;  // the device layout declined this call
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int32_t stride = (int32_t)gridDim.x * kWaves;
+    uint32_t *hist = s_hist[wave];
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+        for (int i = 0; i < kWaveHist / 4 / 64; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
+    // two loop-invariant 32-bit lane offsets (the 13-bit immediate reaches 4 KB) on a scalar base per chunk, opaque to the compiler so that no
+    // address arithmetic is re-materialised into a key register whose load the waitcnt pass still tracks
+    uint32_t o0 = (uint32_t)lane * 16u, o1 = o0 + 4096u;
+    asm volatile("" : "+v"(o0), "+v"(o1));
+    // BUFFER loads: the tile's rows as a buffer resource in SGPRs, the chunk as the scalar offset, the lane as a 32-bit VGPR offset, the load
+    // within the chunk as the immediate -- no address arithmetic in VGPRs at all
+    auto load_chunk = [&](int32_t (&k)[kWaveChunkIters][4], __amdgpu_buffer_rsrc_t rs, int chunk) {
+#pragma unroll
+        for (int it = 0; it < kWaveChunkIters; ++it) {
+            const flockgpu_v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, (it < 4 ? o0 : o1) + (uint32_t)((it & 3) * 1024), chunk * (kWaveChunkIters * 1024), 2 /* nt */);
+            k[it][0] = (int32_t)t.x; k[it][1] = (int32_t)t.y; k[it][2] = (int32_t)t.z; k[it][3] = (int32_t)t.w;
+        }
+    };
+    FlushArgs f;
+    f.pane_win_idx = pane_win_idx;
+    f.counters = counters;
+    f.tables = tables;
+    f.cap = cap;
+    f.tab_used = tab_used;
+    f.err = err;
+    WaveCountState s;
+    s.hot = 0;
+    s.hot_cnt = 0;
+    s.mn = 0x7fffffff;
+    s.mx = (int32_t)0x80000000;
+    int32_t ka[kWaveChunkIters][4], kb[kWaveChunkIters][4];
+    // the tiles this wave streams: full tiles of panes that belong to a window; the others (a pane's first / last tile: the general path; panes
+    // of no window: nothing) are settled on the way, without loads.  t: the candidate; result: tile (-1: none), its rows' address, its pane.
+    // (`tiles` is a __restrict__ parameter of its own, not SegTiles' member: the descriptors then come through the scalar cache although
+    // the loop stores in between)
+    int32_t tile = -1, seg = 0;
+    __amdgpu_buffer_rsrc_t tbase = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(auction), 0, 0, 0x00020000);   // the tile's rows as a buffer resource
+    auto advance = [&](int32_t t) {
+        tile = -1;
+        for (;;) {
+            t = __builtin_amdgcn_readfirstlane(t);   // (wave-uniform by construction)
+            if (t >= n_tiles) return;
+            const TileRange tr = tiles[t];
+            if (pane_win_ptr[tr.seg] != pane_win_ptr[tr.seg + 1]) {
+                if (tr.lo == tr.tile_begin && tr.hi == tr.tile_begin + kQ5Tile) {
+                    tile = t;
+                    seg = tr.seg;
+                    tbase = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(auction + tr.tile_begin), 0, kQ5Tile * 4, 0x00020000);
+                    return;
+                }
+                if (lane == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = t;
+            }
+            t += stride;
+        }
+    };
+    auto flush = [&](int32_t this_tile, int32_t this_seg) {
+        if (s.hot_cnt) {   // the tile's counts are flushed: the hot key's share goes with them (the candidate itself stays)
+            if (lane == 0) atomicAdd(&hist[(uint32_t)s.hot & (kWaveHist - 1)], s.hot_cnt);
+            s.hot_cnt = 0;
+        }
+        const int32_t mn = wave_min_i32(s.mn), mx = wave_max_i32(s.mx);
+        s.mn = 0x7fffffff;
+        s.mx = (int32_t)0x80000000;
+        const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the lanes' adds before the lanes' reads: one wave, DS operations in order)
+        if (span >= (uint32_t)kWaveHist) {  // two keys may have shared a bin: nothing is flushed, the general path counts the tile
+            if (lane == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)((uint32_t)this_tile | kWideTile);
+            uint4 *z = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+            for (int i = 0; i < kWaveHist / 4 / 64; ++i) z[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        } else {
+            f.wp0 = pane_win_ptr[this_seg];
+            f.wp1 = pane_win_ptr[this_seg + 1];
+            f.pane = panes[this_seg];
+#pragma unroll 1
+            for (uint32_t i = lane; i <= span; i += 64) {
+                const uint32_t key = (uint32_t)mn + i, cnt = hist[key & (kWaveHist - 1)];
+                if (cnt) {
+                    hist[key & (kWaveHist - 1)] = 0;
+                    emit_pair((int32_t)key, cnt, f);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    advance((int32_t)blockIdx.x * kWaves + wave);
+    if (tile < 0) return;
+    load_chunk(ka, tbase, 0);
+    int c = 0;   // the chunk pair of the current tile: chunks (c, c + 1), c = 0 or 2
+    // every trip issues exactly eight loads before each chunk body (so the waits stay `vmcnt(8 + n)`): the trip that finds no further tile
+    // leaves the loop before its second half, and the tail below counts the last chunk
+#pragma unroll 1
+    for (;;) {
+        load_chunk(kb, tbase, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        q5_wave_chunk(ka, hist, s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const int32_t this_tile = tile, this_seg = seg;
+        const bool last_pair = c != 0;
+        if (last_pair) {
+            advance(tile + stride);
+            if (tile < 0) {
+                tile = this_tile;
+                seg = this_seg;
+                break;
+            }
+        }
+        c ^= 2;
+        load_chunk(ka, tbase, c);
+        __builtin_amdgcn_sched_barrier(0);
+        q5_wave_chunk(kb, hist, s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (last_pair) flush(this_tile, this_seg);
+    }
+    q5_wave_chunk(kb, hist, s, lane);
+    flush(tile, seg);
 }
 
 // ---- Partial COUNT per tile (the exchange's stage 0): the histogram phase of q5_count_kernel, then the tile's bins are written as
@@ -1354,6 +1663,40 @@ __global__ __launch_bounds__(kBlock) void q5_partial_emit_kernel(SegTiles sx, co
 
 
 
+// Block -> tile map of the XCD-local count pass: XCD x = pane % 8 takes its panes' tiles in order, its j-th tile goes to block 8 j + x (the
+// block the hardware places on XCD x); -1 pads the XCDs that hold fewer tiles.  Cached per ctx under the pane row ranges it was built from.
+static int q5_xcd_tile_map(flockgpu_ctx *ctx, int n_panes, const int64_t *sb, const int64_t *se, const int32_t **out, unsigned *grid) {
+    constexpr int kXcds = 8;
+    std::vector<int64_t> &sig = ctx->host_i64["q5.xcd_tile_sig"];
+    std::vector<int64_t> now;
+    now.reserve((size_t)2 * n_panes + 2);
+    std::vector<int32_t> per[kXcds];
+    int32_t t = 0;
+    for (int p = 0; p < n_panes; ++p) {
+        now.push_back(sb[p]);
+        now.push_back(se[p]);
+        if (se[p] <= sb[p]) continue;
+        const int64_t n = div_up(se[p] - (sb[p] & ~int64_t(3)), (int64_t)kQ5Tile);   // (as build_seg_tiles counts them)
+        for (int64_t i = 0; i < n; ++i) per[p % kXcds].push_back(t++);
+    }
+    size_t most = 0;
+    for (auto &v : per) most = std::max(most, v.size());
+    const size_t n_map = most * kXcds;
+    int32_t *d_map = nullptr, *h_map = nullptr;
+    FG_TRY(arena_get_t(ctx, "q5.xcd_tile", n_map + 1, &d_map));
+    FG_TRY(pinned_get_t(ctx, "q5.xcd_tile", n_map + 1, &h_map));
+    now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_map));
+    if (sig != now) {
+        for (size_t j = 0; j < most; ++j)
+            for (int x = 0; x < kXcds; ++x) h_map[j * kXcds + x] = j < per[x].size() ? per[x][j] : -1;
+        FG_HIP(ctx, hipMemcpyAsync(d_map, h_map, n_map * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        sig = now;
+    }
+    *out = d_map;
+    *grid = (unsigned)n_map;
+    return FLOCKGPU_OK;
+}
+
 // The three entry points share one driver:
 //   hot items          : rows = bids, weight = nullptr, `out` set
 //   weighted hot items : rows = partial groups (auction, count) received from the other partitions, `out` set
@@ -1556,8 +1899,11 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                 wsig = wnow;
             }
         }
-        hipLaunchKernelGGL(q5_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes,
-                           d_wins, d_info);
+        {
+            LaunchScope ls(ctx, "q5_layout_kernel");
+            hipLaunchKernelGGL(q5_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes,
+                               d_wins, d_info);
+        }
         FG_TRY(check_launch(ctx, "q5_layout_kernel"));
         cnt_total = (uint64_t)hint[0];   // (provisional: sizes launches; the true values come back with the results)
         scan_total = (uint64_t)hint[1];
@@ -1616,9 +1962,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         {   // one clear for everything this attempt writes into
             const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, n_block_max});
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
-            hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
-                               (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
-                               slow_list, block_max, n_block_max, plain_clear ? 1 : 0);
+            {
+                LaunchScope ls(ctx, "q5_clear_kernel");
+                hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
+                                   (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
+                                   slow_list, block_max, n_block_max, plain_clear ? 1 : 0);
+            }
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
         if (d_wsum) FG_HIP(ctx, hipMemsetAsync(d_wsum, 0, sizeof(unsigned long long) * (size_t)n_panes, ctx->stream));
@@ -1659,16 +2008,42 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         } else if (st.n_tiles > 0 && n_win > 0) {
-            {
+            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
+            static const char *count_form_env = exp_env("FLOCKGPU_Q5_COUNT");
+            const int wave_form = weight ? 0 : count_form_env ? (!strcmp(count_form_env, "wave1") ? 1 : !strcmp(count_form_env, "wave2") ? 2 : !strcmp(count_form_env, "wave4") ? 4 :
+                                                                   !strcmp(count_form_env, "wavep1") ? 101 : !strcmp(count_form_env, "wavep4") ? 104 : 0) : kQ5WaveForm;
+            if (wave_form > 100) {
+                LaunchScope ls(ctx, "q5_count_kernel");
+                const int kw = wave_form - 100;
+                static const int per_cu = exp_env("FLOCKGPU_Q5_WAVES_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_WAVES_PER_CU")) : kQ5WavesPerCu;
+                const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)st.n_tiles, kw), (int64_t)ctx->num_cus * per_cu / kw));
+                if (kw == 1)
+                    hipLaunchKernelGGL(q5_count_wavep_kernel<1>, dim3(g), dim3(64), 0, ctx->stream, auction, st.tiles, st.n_tiles, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+                else
+                    hipLaunchKernelGGL(q5_count_wavep_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, auction, st.tiles, st.n_tiles, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+            } else if (wave_form) {
+                LaunchScope ls(ctx, "q5_count_kernel");
+                const unsigned g = (unsigned)div_up((int64_t)st.n_tiles, wave_form);
+                if (wave_form == 1)
+                    hipLaunchKernelGGL(q5_count_wave_kernel<1>, dim3(g), dim3(64), 0, ctx->stream, auction, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+                else if (wave_form == 2)
+                    hipLaunchKernelGGL(q5_count_wave_kernel<2>, dim3(g), dim3(128), 0, ctx->stream, auction, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+                else
+                    hipLaunchKernelGGL(q5_count_wave_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, auction, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+            } else {
+                const bool xcd_form = !weight && (count_form_env ? !strcmp(count_form_env, "wgx") : kQ5XcdLocal) && ctx->host_i64["q5.no_xcd_local"].empty();
+                const int32_t *xcd_tile = nullptr;
+                unsigned xcd_grid = 0;
+                if (xcd_form) FG_TRY(q5_xcd_tile_map(ctx, n_panes, sb.data(), se.data(), &xcd_tile, &xcd_grid));
                 LaunchScope ls(ctx, "q5_count_kernel");
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)
                 const unsigned count_grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * (exp_env("FLOCKGPU_Q5_PERSIST_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_PERSIST_PER_CU")) : 8));
 #else
-                const unsigned count_grid = (unsigned)st.n_tiles;
+                const unsigned count_grid = xcd_tile ? xcd_grid : (unsigned)st.n_tiles;
 #endif
                 hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3(count_grid), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list, spec_info, d_wsum);
+                                   slow_list, spec_info, d_wsum, xcd_tile);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
             if (d_wsum) FG_HIP(ctx, hipMemcpyAsync(h_wsum, d_wsum, sizeof(unsigned long long) * (size_t)n_panes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1773,8 +2148,11 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         FG_TRY(pinned_get_t(ctx, "q5.finish", n_meta + 8 + (size_t)n_win + 2, &h_fin));
         FG_TRY(arena_get_t(ctx, "q5.out_auction", (size_t)kFinishMax + 1, &fin_a));
         FG_TRY(arena_get_t(ctx, "q5.out_num", (size_t)kFinishMax + 1, &fin_n));
-        hipLaunchKernelGGL(q5_finish_kernel, dim3(1), dim3(kFinishThreads), 0, ctx->stream, d_meta, (uint32_t)n_meta, n_win, spec_info, slow_list, o_win, o_key, out_cap,
-                           fin_a, fin_n, h_fin);
+        {
+            LaunchScope ls(ctx, "q5_finish_kernel");
+            hipLaunchKernelGGL(q5_finish_kernel, dim3(1), dim3(kFinishThreads), 0, ctx->stream, d_meta, (uint32_t)n_meta, n_win, spec_info, slow_list, o_win, o_key, out_cap,
+                               fin_a, fin_n, h_fin);
+        }
         FG_TRY(check_launch(ctx, "q5_finish_kernel"));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::copy(h_fin, h_fin + n_meta, h_meta);
@@ -1806,6 +2184,10 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
         n_sel = tail[0];
+        if (tail[1] & 4u) {   // a block of the XCD-local count pass ran on another XCD than its index says: this ctx counts the ordinary way from now on
+            ctx->host_i64["q5.no_xcd_local"].assign(1, 1);
+            continue;
+        }
         if (tail[1]) {  // a window table filled up: the group-count hint was too optimistic
             cap64 *= 4;
             continue;
@@ -1943,9 +2325,12 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     if (speculate && dense && cnt_total > 0 && !no_preclean) {   // clean up after use (see `preclean` above); the results above are already on their way
         int32_t *slow_list = nullptr;
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
-        const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)cnt_total / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
-        hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
-                           uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0);
+        {
+            LaunchScope ls(ctx, "q5_clear_kernel");
+            const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)cnt_total / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
+            hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
+                               uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0);
+        }
         FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         preclean[0] = (int64_t)reinterpret_cast<uintptr_t>(counters);
         preclean[1] = (int64_t)std::max<uint64_t>(clean_upto, cnt_total);
