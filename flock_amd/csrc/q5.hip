@@ -48,7 +48,6 @@ constexpr int kQ5Variant = FLOCKGPU_AB_Q5_VARIANT;
 constexpr int kQ5Variant = 1;
 #endif
 constexpr int kQ5WaveForm = 0;                  // count kernel form of the shipped build: 0 = one workgroup per tile, 1 / 2 / 4 = one WAVE per tile, that many waves per workgroup
-constexpr bool kQ5XcdLocal = false;             // count kernel: a pane's tiles dealt to the blocks of ONE XCD, flush atomics in that XCD's L2
 constexpr int kQ5WavesPerCu = 20;               // persistent wave form: waves per CU in the grid (8 KB of LDS each)
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
@@ -502,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
     __shared__ int32_t s_red[8];
     __shared__ unsigned long long s_w[kWavesPerBlock];
     if (spec_info && !spec_info[2]) return;  // the device layout declined this call
+#ifdef FLOCKGPU_EXPERIMENTAL   // (measured in round 6, slower: profiles/r06/q5_variants_ab.md)
     if (xcd_tile) {
         // XCD-local panes: block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md "Workgroup dispatch"; CHECKED here against the
         // hardware's XCC_ID -- a block that finds itself elsewhere flags the call, the host repeats it the ordinary way), and xcd_tile deals
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
         q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w, true);
         return;
     }
+#endif
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)   // (A/B builds only: num_cus x 8 workgroups walk the tiles)
     for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
         q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w);
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
 #endif
 }
 
+#ifdef FLOCKGPU_EXPERIMENTAL   // (the count pass's other forms: measured in round 6, profiles/r06/q5_variants_ab.md; none beat the workgroup form)
 // ---- count, wave-private form (round 6) ------------------------------------------------------------------------------------------
 // The workgroup form above is co-bound by its LDS atomics (~53 % of the kernel's cycles) BECAUSE its phases are serial per workgroup: eight
 // 16-byte loads per lane, a barrier (a workgroup-scope fence: `s_waitcnt vmcnt(0)` on gfx9), the 32 LDS adds per lane, a barrier, the
@@ -811,6 +813,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     q5_wave_chunk(kb, hist, s, lane);
     flush(tile, seg);
 }
+
+#endif
 
 // ---- Partial COUNT per tile (the exchange's stage 0): the histogram phase of q5_count_kernel, then the tile's bins are written as
 // (key, count) pairs at a position claimed with ONE atomic per tile on the pane's cursor.  Ragged tiles and tiles whose keys spread wider than the histogram hand their rows out as
@@ -1663,6 +1667,7 @@ __global__ __launch_bounds__(kBlock) void q5_partial_emit_kernel(SegTiles sx, co
 
 
 
+#ifdef FLOCKGPU_EXPERIMENTAL
 // Block -> tile map of the XCD-local count pass: XCD x = pane % 8 takes its panes' tiles in order, its j-th tile goes to block 8 j + x (the
 // block the hardware places on XCD x); -1 pads the XCDs that hold fewer tiles.  Cached per ctx under the pane row ranges it was built from.
 static int q5_xcd_tile_map(flockgpu_ctx *ctx, int n_panes, const int64_t *sb, const int64_t *se, const int32_t **out, unsigned *grid) {
@@ -1696,6 +1701,8 @@ static int q5_xcd_tile_map(flockgpu_ctx *ctx, int n_panes, const int64_t *sb, co
     *grid = (unsigned)n_map;
     return FLOCKGPU_OK;
 }
+
+#endif
 
 // The three entry points share one driver:
 //   hot items          : rows = bids, weight = nullptr, `out` set
@@ -2008,8 +2015,13 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         } else if (st.n_tiles > 0 && n_win > 0) {
-            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
+            const int32_t *xcd_tile = nullptr;
+            unsigned xcd_grid = 0;
+#ifdef FLOCKGPU_EXPERIMENTAL
+            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wgx | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
             static const char *count_form_env = exp_env("FLOCKGPU_Q5_COUNT");
+            if (!weight && count_form_env && !strcmp(count_form_env, "wgx") && ctx->host_i64["q5.no_xcd_local"].empty())
+                FG_TRY(q5_xcd_tile_map(ctx, n_panes, sb.data(), se.data(), &xcd_tile, &xcd_grid));
             const int wave_form = weight ? 0 : count_form_env ? (!strcmp(count_form_env, "wave1") ? 1 : !strcmp(count_form_env, "wave2") ? 2 : !strcmp(count_form_env, "wave4") ? 4 :
                                                                    !strcmp(count_form_env, "wavep1") ? 101 : !strcmp(count_form_env, "wavep4") ? 104 : 0) : kQ5WaveForm;
             if (wave_form > 100) {
@@ -2030,11 +2042,9 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                     hipLaunchKernelGGL(q5_count_wave_kernel<2>, dim3(g), dim3(128), 0, ctx->stream, auction, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
                 else
                     hipLaunchKernelGGL(q5_count_wave_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, auction, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
-            } else {
-                const bool xcd_form = !weight && (count_form_env ? !strcmp(count_form_env, "wgx") : kQ5XcdLocal) && ctx->host_i64["q5.no_xcd_local"].empty();
-                const int32_t *xcd_tile = nullptr;
-                unsigned xcd_grid = 0;
-                if (xcd_form) FG_TRY(q5_xcd_tile_map(ctx, n_panes, sb.data(), se.data(), &xcd_tile, &xcd_grid));
+            } else
+#endif
+            {
                 LaunchScope ls(ctx, "q5_count_kernel");
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)
                 const unsigned count_grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * (exp_env("FLOCKGPU_Q5_PERSIST_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_PERSIST_PER_CU")) : 8));
