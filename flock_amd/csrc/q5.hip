@@ -49,14 +49,20 @@ constexpr int kQ5Variant = 1;
 #endif
 constexpr int kQ5WaveForm = 0;                  // count kernel form of the shipped build: 0 = one workgroup per tile, 1 / 2 / 4 = one WAVE per tile, that many waves per workgroup
 constexpr int kQ5WavesPerCu = 20;               // persistent wave form: waves per CU in the grid (8 KB of LDS each)
+// 16-bit counters (round 6): two keys share a 32-bit word of the counter arena (key - base even: low half).  What bounds the q5 step is the
+// bytes it moves, reads and writes together (profiles/r06/q5_variants_ab.md): half-width counters halve the zeroes stored per call, the max /
+// select sweeps and the lines the flush atomics touch.  A (pane, key) count above 65535 carries into its neighbour or out of the word --
+// either way the pane's counter SUM comes out below its row count, which the max pass adds up anyway: q5_finish_kernel compares, and a
+// mismatch makes the host repeat the call with 32-bit counters and keep them for this ctx (NEXMark's hottest auction draws ~770 bids).
+constexpr bool kQ5Counters16 = true;
 constexpr int kHotMin = 16;                     // a candidate seen in fewer lanes than this is not "hot"
 constexpr int kMaxWinPanes = 8;                 // windows of more panes use the hash tables only
 constexpr uint32_t kWideTile = 0x40000000u;     // slow-list tag: declined for its key spread (not for being ragged)
 
 struct PaneDesc {
-    int64_t base;      // first key of the pane's direct-address range (multiple of 4)
-    uint64_t cnt_off;  // offset of the pane's counters in the counter arena (u32 units, multiple of 4)
-    uint32_t range;    // number of counters (multiple of 4; 0: every key of this pane goes to the hash tables)
+    int64_t base;      // first key of the pane's direct-address range (multiple of 8)
+    uint64_t cnt_off;  // offset of the pane's counters in the counter arena (in counters, multiple of 8)
+    uint32_t range;    // number of counters (multiple of 8; 0: every key of this pane goes to the hash tables)
     uint32_t pad;
 };
 
@@ -135,7 +141,8 @@ struct FlushArgs {
     uint32_t cap;
     uint32_t *tab_used;        // per window: non-zero once its hash table holds an entry
     uint32_t *err;
-    bool xcd_local = false;    // every workgroup that adds to this pane's counters runs on ONE XCD: the adds stay in that XCD's L2 (see q5_count_kernel)
+    bool c16 = false;                        // 16-bit counters, two per word of `counters`
+    unsigned long long *tab_rows = nullptr;  // c16: this pane's rows that went to the straggler tables instead of its counters (the sum check leaves them out)
 };
 
 // Adds one aggregated (key, count) pair of a tile: one atomic on the pane's counters, or -- for a key outside the
@@ -143,14 +150,27 @@ struct FlushArgs {
 __device__ __forceinline__ void emit_pair(int32_t key, uint32_t c, const FlushArgs &f) {
     const uint64_t idx = (uint64_t)((int64_t)key - f.pane.base);
     if (idx < (uint64_t)f.pane.range) {
-        if (f.xcd_local) __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (f.c16) __hip_atomic_fetch_add(&f.counters[(f.pane.cnt_off + idx) >> 1], c << (16u * ((uint32_t)idx & 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_add(&f.counters[f.pane.cnt_off + idx], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (f.tab_rows) atomicAdd(f.tab_rows, (unsigned long long)c);
     for (int wi = f.wp0; wi < f.wp1; ++wi) {
         const int32_t w = f.pane_win_idx[wi];
         table_add(f.tables + (size_t)w * f.cap, f.cap, (uint32_t)key, c, &f.tab_used[w], f.err);
     }
+}
+
+// 16-bit counters: the counts of an EVEN key and its successor as ONE atomic on their shared word (bases and ranges are multiples of 8, so the
+// two are inside or outside a pane's range together)
+__device__ __forceinline__ void emit_pair16(int32_t even_key, uint32_t c0, uint32_t c1, const FlushArgs &f) {
+    const uint64_t idx = (uint64_t)((int64_t)even_key - f.pane.base);
+    if (idx < (uint64_t)f.pane.range) {
+        __hip_atomic_fetch_add(&f.counters[(f.pane.cnt_off + idx) >> 1], c0 | (c1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (c0) emit_pair(even_key, c0, f);
+    if (c1) emit_pair(even_key + 1, c1, f);
 }
 
 // ---- pane key-range estimate: kRangeBlocks x 256 lanes x 4 strided 16-byte samples per pane (<1 % of a pane) ------
@@ -200,8 +220,8 @@ __global__ __launch_bounds__(kBlock) void q5_range_kernel(const int32_t *__restr
 // The layout rules, shared by the host (first call, Partial stage, fallback) and the device (speculated calls).
 __host__ __device__ inline bool q5_pane_layout(int64_t lo, int64_t hi, int64_t *base, int64_t *range) {
     const int64_t span = hi - lo, margin = span / 16 > 4096 ? span / 16 : 4096;
-    *base = (lo - margin) & ~int64_t(3);
-    *range = ((hi + margin + 1 - *base) + 3) & ~int64_t(3);
+    *base = (lo - margin) & ~int64_t(7);   // (multiples of 8: an aligned 16-byte group of counters -- four 32-bit, eight 16-bit -- is inside a pane's range as a whole or not at all)
+    *range = ((hi + margin + 1 - *base) + 7) & ~int64_t(7);
     return *range < (int64_t(1) << 31);
 }
 
@@ -210,10 +230,22 @@ __host__ __device__ inline bool q5_pane_layout(int64_t lo, int64_t hi, int64_t *
 // info[0] = counters in use, info[1] = window-range total, info[2] = 1 when the layout is dense, affordable and fits the
 // `capacity` counters the host allocated from the previous call's size; 0 declines the call (every kernel behind returns at
 // once; the host sees it at its single synchronisation and repeats the call the slow way).
-__global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__restrict__ rng, const int32_t *__restrict__ pane_win_ptr,
-                                                           const int64_t *__restrict__ seg_off, int32_t n_panes, int32_t n_win,
-                                                           uint64_t capacity, uint64_t budget_bytes, PaneDesc *__restrict__ panes,
-                                                           WinDesc *__restrict__ wins, uint64_t *__restrict__ info) {
+// (Round 6: not a launch of its own any more -- workgroup 0 of q5_clear_kernel runs it, the other workgroups of that launch zero what they
+// zero without looking at its verdict: one 7 us launch less per call.)
+struct LayoutArgs {
+    const int32_t *rng;   // null: the layout was made on the host
+    const int32_t *pane_win_ptr;
+    const int64_t *seg_off;
+    int32_t n_panes, n_win;
+    uint64_t capacity, budget_bytes;
+    PaneDesc *panes;
+    WinDesc *wins;
+    uint64_t *info;
+};
+__device__ __forceinline__ void q5_layout_block(const int32_t *__restrict__ rng, const int32_t *__restrict__ pane_win_ptr,
+                                                const int64_t *__restrict__ seg_off, int32_t n_panes, int32_t n_win,
+                                                uint64_t capacity, uint64_t budget_bytes, PaneDesc *__restrict__ panes,
+                                                WinDesc *__restrict__ wins, uint64_t *__restrict__ info) {
     __shared__ uint64_t s_wave[kWavesPerBlock];
     __shared__ uint64_t s_carry;
     __shared__ int s_ok;
@@ -287,12 +319,14 @@ __global__ __launch_bounds__(kBlock) void q5_layout_kernel(const int32_t *__rest
 
 // One launch instead of five memsets: the counters in use (their number from the device when the layout was made there),
 // the window tables, the scalars, the slow list head and the per-workgroup maxima.
-// cnt_from: the counters below it are known to be zero already (the previous call cleaned up after itself, see q5_run).
-__global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, const uint64_t *__restrict__ info, uint64_t cnt_host,
+// cnt_from: the words below it are known to be zero already (the previous call cleaned up after itself, see q5_run).
+__global__ __launch_bounds__(kBlock) void q5_clear_kernel(uint32_t *__restrict__ counters, uint64_t cnt_host,
                                                           uint64_t cnt_from, uint64_t *__restrict__ tables, uint64_t table_words,
                                                           uint64_t *__restrict__ meta, uint64_t meta_words, int32_t *__restrict__ slow_list,
-                                                          uint32_t *__restrict__ block_max, uint64_t block_max_words, int plain_stores) {
-    const uint64_t cnt = info ? (info[2] ? info[0] : 0) : cnt_host;
+                                                          uint32_t *__restrict__ block_max, uint64_t block_max_words, int plain_stores, int c16, LayoutArgs lay) {
+    if (lay.rng && blockIdx.x == 0) q5_layout_block(lay.rng, lay.pane_win_ptr, lay.seg_off, lay.n_panes, lay.n_win, lay.capacity, lay.budget_bytes, lay.panes, lay.wins, lay.info);
+    uint64_t cnt = cnt_host;                // counters to zero (a speculating call: all the arena holds -- the layout is being made next door) ...
+    if (c16) cnt = (cnt + 1) / 2;           // ... and the 32-bit words that hold them (cnt_from is in words, too)
     const uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
     const uint4 z = make_uint4(0, 0, 0, 0);
     // (non-temporal: the zeroes go to HBM as they are written instead of lingering as dirty lines whose write-back lands on the kernel that
@@ -324,10 +358,11 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
                                               const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_win_ptr,
                                               const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap,
                                               uint32_t *tab_used, uint32_t *err, int32_t *slow_list, unsigned long long *pane_wsum, const int32_t tile,
-                                              uint32_t *hist, int32_t *s_red, unsigned long long *s_w, const bool xcd_local = false) {
+                                              uint32_t *hist, int32_t *s_red, unsigned long long *s_w, const bool c16, unsigned long long *tab_rows) {
     const TileRange tr = locate_tile(st, tile, kQ5Tile);
     FlushArgs f;
-    f.xcd_local = xcd_local;
+    f.c16 = c16;
+    f.tab_rows = tab_rows ? tab_rows + tr.seg : nullptr;
     f.wp0 = pane_win_ptr[tr.seg];
     f.wp1 = pane_win_ptr[tr.seg + 1];
     if (f.wp0 == f.wp1) return;  // pane belongs to no (full) window
@@ -477,6 +512,14 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
         if (threadIdx.x == 0) hist[((uint32_t)key0 - (uint32_t)mn) * rmul] -= (uint32_t)(kQ5Tile - (tr.hi - tr.lo));
         __syncthreads();
     }
+    if (c16 && kQ5Variant != 2) {   // (block-uniform) an even key and its successor: one atomic on the word they share
+        const uint32_t d = (uint32_t)mn & 1u;   // bins are indexed from mn, pairs from the even key at or below it (offsets, so that a range across 0 needs no care)
+        for (uint32_t s = threadIdx.x * 2; s <= span + d; s += kBlock * 2) {
+            const uint32_t c0 = s >= d ? hist[s - d] : 0u, c1 = s + 1 - d <= span ? hist[s + 1 - d] : 0u;
+            if (c0 | c1) emit_pair16((int32_t)((uint32_t)mn - d + s), c0, c1, f);
+        }
+        return;
+    }
     for (uint32_t s = threadIdx.x; s <= span; s += kBlock) {
         uint32_t c;
         if (rep) {
@@ -496,36 +539,18 @@ __global__ __launch_bounds__(kBlock) void q5_count_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                           uint64_t *tables, uint32_t cap, uint32_t *tab_used, uint32_t *err,
                                                           int32_t *slow_list, const uint64_t *__restrict__ spec_info,
-                                                          unsigned long long *pane_wsum, const int32_t *__restrict__ xcd_tile) {
+                                                          unsigned long long *pane_wsum, int c16, unsigned long long *tab_rows) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[kWeighted ? 4 : kHist + kHistPad];
     __shared__ int32_t s_red[8];
     __shared__ unsigned long long s_w[kWavesPerBlock];
     if (spec_info && !spec_info[2]) return;  // the device layout declined this call
-#ifdef FLOCKGPU_EXPERIMENTAL   // (measured in round 6, slower: profiles/r06/q5_variants_ab.md)
-    if (xcd_tile) {
-        // XCD-local panes: block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md "Workgroup dispatch"; CHECKED here against the
-        // hardware's XCC_ID -- a block that finds itself elsewhere flags the call, the host repeats it the ordinary way), and xcd_tile deals
-        // every pane's tiles to the blocks of ONE XCD.  A pane's counters are then updated from one XCD only, so the flush atomics need no
-        // device scope: they execute in that XCD's L2 instead of being forwarded to the memory side one by one, and the lines go out once,
-        // as ordinary write-backs, at the latest when the kernel ends.
-        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // hwreg(HW_REG_XCC_ID, 0, 4)
-        if (xcc != (blockIdx.x & 7u)) {
-            if (threadIdx.x == 0) atomicOr(err, 4u);
-            return;
-        }
-        const int32_t tile = xcd_tile[blockIdx.x];
-        if (tile < 0) return;
-        q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w, true);
-        return;
-    }
-#endif
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)   // (A/B builds only: num_cus x 8 workgroups walk the tiles)
     for (int32_t tile = (int32_t)blockIdx.x; tile < st.n_tiles; tile += (int32_t)gridDim.x) {
-        q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w);
+        q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, tile, hist, s_red, s_w, c16 != 0, tab_rows);
         __syncthreads();   // the next tile zeroes the histogram and rewrites the reduction slots
     }
 #else
-    q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, (int32_t)blockIdx.x, hist, s_red, s_w);
+    q5_count_tile<kWeighted>(auction, weight, st, panes, pane_win_ptr, pane_win_idx, counters, tables, cap, tab_used, err, slow_list, pane_wsum, (int32_t)blockIdx.x, hist, s_red, s_w, c16 != 0, tab_rows);
 #endif
 }
 
@@ -946,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
                                                                const int32_t *__restrict__ pane_win_idx, uint32_t *counters,
                                                                uint64_t *tables, uint32_t cap, uint32_t *tab_used,
                                                                uint32_t *err, const int32_t *__restrict__ slow_list,
-                                                               const uint64_t *__restrict__ spec_info) {
+                                                               const uint64_t *__restrict__ spec_info, int c16, unsigned long long *tab_rows) {
     __shared__ __attribute__((aligned(16))) uint64_t slots[kSlots];
     if (spec_info && !spec_info[2]) return;
     __shared__ uint32_t s_fill;  // slots claimed so far (approximate while lanes race: only steers the bypass)
@@ -968,6 +993,8 @@ __global__ __launch_bounds__(kBlock) void q5_count_slow_kernel(const int32_t *__
         f.cap = cap;
         f.tab_used = tab_used;
         f.err = err;
+        f.c16 = c16 != 0;
+        f.tab_rows = tab_rows ? tab_rows + tr.seg : nullptr;
         __syncthreads();
         if (kWeighted) {  // one (key, count) row per lane and trip: LDS hash while it has room, else straight out
 #pragma unroll 1
@@ -1188,14 +1215,18 @@ __global__ __launch_bounds__(kBlock) void q5_scan_kernel(const WinDesc *__restri
 //   as the SECOND pane of window wa = (p - 1, p): only the keys pane p - 1 does NOT cover (the others were accounted by its sweep).
 // A generic version of this (any number of panes per window and windows per pane, descriptors in LDS) measured 0.134 + 0.048 ms
 // against 0.105 + 0.015 ms of the window walk: instruction overhead ate the saved traffic.  This one is specialised to the two roles.
-template <bool SELECT>
+// k16: 16-bit counters, two per word (see kQ5Counters16) -- a lane's 16-byte group holds EIGHT keys; the max pass then also adds up
+// every counter of the pane it reads (pane_sum: the overflow check of q5_finish_kernel).
+template <bool SELECT, bool k16>
 __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__restrict__ panes, const int32_t *__restrict__ pane_wa,
                                                               const int32_t *__restrict__ pane_wb, const uint32_t *__restrict__ counters,
                                                               const uint64_t *__restrict__ tables, uint32_t cap, const uint32_t *__restrict__ tab_used,
                                                               uint64_t *win_max, uint64_t *win_groups, uint32_t *block_max, uint32_t *cursor,
-                                                              uint32_t out_cap, int32_t *out_win, int32_t *out_key, const uint64_t *__restrict__ spec_info) {
+                                                              uint32_t out_cap, int32_t *out_win, int32_t *out_key, const uint64_t *__restrict__ spec_info,
+                                                              unsigned long long *pane_sum) {
+    constexpr int G = k16 ? 8 : 4;   // keys per 16-byte group of counters
     __shared__ uint32_t s_best[2][kWavesPerBlock];
-    __shared__ uint64_t s_groups[2][kWavesPerBlock];
+    __shared__ uint64_t s_groups[3][kWavesPerBlock];
     if (spec_info && !spec_info[2]) return;
     const int32_t p = blockIdx.y;
     const int32_t wa = pane_wa[p], wb = pane_wb[p];
@@ -1215,6 +1246,7 @@ __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__
     const bool tab_a = wa >= 0 && tab_used[wa] != 0, tab_b = wb >= 0 && tab_used[wb] != 0;
     const uint64_t *ta = tables + (size_t)(wa >= 0 ? wa : 0) * cap, *tb = tables + (size_t)(wb >= 0 ? wb : 0) * cap;
     uint32_t best_a = 0, best_b = 0, groups_a = 0, groups_b = 0;
+    uint64_t sum = 0;
     auto take = [&](uint32_t c, int32_t key, int32_t w, uint32_t mx, uint32_t &best, uint32_t &groups) {
         if (SELECT) {
             const bool hit = c == mx;
@@ -1235,32 +1267,56 @@ __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__
             groups += c != 0;
         }
     };
-    const uint32_t n4 = pd.range / 4;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n4; i += gridDim.x * kBlock) {
-        const int64_t k0 = pd.base + (int64_t)i * 4;
-        const uint4 me = *reinterpret_cast<const uint4 *>(counters + pd.cnt_off + (uint64_t)i * 4);
+    auto unpack = [&](const uint4 v, uint32_t (&c)[G]) {
+        if constexpr (k16) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[2 * j] = w[j] & 0xFFFFu;
+                c[2 * j + 1] = w[j] >> 16;
+            }
+        } else {
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        }
+    };
+    const uint32_t ng = pd.range / G;   // (ranges are multiples of 8)
+    const uint32_t *mine = counters + (k16 ? pd.cnt_off / 2 : pd.cnt_off), *theirs = counters + (k16 ? next.cnt_off / 2 : next.cnt_off);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ng; i += gridDim.x * kBlock) {
+        const int64_t k0 = pd.base + (int64_t)i * G;
+        uint32_t me[G];
+        unpack(*reinterpret_cast<const uint4 *>(mine + (uint64_t)i * 4), me);
+        if (k16 && !SELECT) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) sum += me[j];
+        }
         if (act_b) {   // (block-uniform)
-            uint32_t c[4] = {me.x, me.y, me.z, me.w};
+            uint32_t c[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) c[j] = me[j];
             const uint64_t idx = (uint64_t)(k0 - next.base);
-            if (idx < (uint64_t)next.range) {   // (bases and ranges are multiples of 4: the aligned group is covered as a whole or not at all)
-                const uint4 o = *reinterpret_cast<const uint4 *>(counters + next.cnt_off + idx);
-                c[0] += o.x; c[1] += o.y; c[2] += o.z; c[3] += o.w;
+            if (idx < (uint64_t)next.range) {   // (bases and ranges are multiples of 8: the aligned group is covered as a whole or not at all)
+                uint32_t o[G];
+                unpack(*reinterpret_cast<const uint4 *>(theirs + (k16 ? idx / 2 : idx)), o);
+#pragma unroll
+                for (int j = 0; j < G; ++j) c[j] += o[j];
             }
             if (tab_b) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] += table_find(tb, cap, (uint32_t)(int32_t)(k0 + j));
+                for (int j = 0; j < G; ++j) c[j] += table_find(tb, cap, (uint32_t)(int32_t)(k0 + j));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) take(c[j], (int32_t)(k0 + j), wb, mx_b, best_b, groups_b);
+            for (int j = 0; j < G; ++j) take(c[j], (int32_t)(k0 + j), wb, mx_b, best_b, groups_b);
         }
         if (act_a && !((uint64_t)(k0 - prev.base) < (uint64_t)prev.range)) {
-            uint32_t c[4] = {me.x, me.y, me.z, me.w};
+            uint32_t c[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) c[j] = me[j];
             if (tab_a) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] += table_find(ta, cap, (uint32_t)(int32_t)(k0 + j));
+                for (int j = 0; j < G; ++j) c[j] += table_find(ta, cap, (uint32_t)(int32_t)(k0 + j));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) take(c[j], (int32_t)(k0 + j), wa, mx_a, best_a, groups_a);
+            for (int j = 0; j < G; ++j) take(c[j], (int32_t)(k0 + j), wa, mx_a, best_a, groups_a);
         }
     }
     if (tab_b && act_b) {   // straggler-table entries of wb that neither of its panes covers: complete on their own
@@ -1285,12 +1341,13 @@ __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__
     }
     if (!SELECT) {   // one update per workgroup and window
         const uint32_t ba = wave_max_u32(best_a), bb = wave_max_u32(best_b);
-        const uint64_t ga = wave_sum_u64(groups_a), gb = wave_sum_u64(groups_b);
+        const uint64_t ga = wave_sum_u64(groups_a), gb = wave_sum_u64(groups_b), gs = k16 ? wave_sum_u64(sum) : 0;
         if (lane_id() == 0) {
             s_best[0][threadIdx.x >> 6] = ba;
             s_best[1][threadIdx.x >> 6] = bb;
             s_groups[0][threadIdx.x >> 6] = ga;
             s_groups[1][threadIdx.x >> 6] = gb;
+            s_groups[2][threadIdx.x >> 6] = gs;
         }
         __syncthreads();
         if (threadIdx.x < 2) {
@@ -1309,6 +1366,12 @@ __global__ __launch_bounds__(kBlock) void q5_hop2_scan_kernel(const PaneDesc *__
                 if (g) atomicAdd(reinterpret_cast<unsigned long long *>(&win_groups[w]), (unsigned long long)g);
             }
         }
+        if (k16 && threadIdx.x == 2) {   // this workgroup's share of the pane's counter sum
+            uint64_t t = 0;
+#pragma unroll
+            for (int v = 0; v < kWavesPerBlock; ++v) t += s_groups[2][v];
+            if (t) atomicAdd(&pane_sum[p], (unsigned long long)t);
+        }
     }
 }
 
@@ -1324,14 +1387,26 @@ constexpr uint32_t kFinishMax = 1024;
 __global__ __launch_bounds__(kFinishThreads) void q5_finish_kernel(const uint64_t *__restrict__ meta, uint32_t n_meta, int32_t n_win, const uint64_t *__restrict__ info,
                                                                    const int32_t *__restrict__ slow_list, const int32_t *__restrict__ sel_win,
                                                                    const int32_t *__restrict__ sel_key, uint32_t out_cap, int32_t *__restrict__ out_auction,
-                                                                   uint64_t *__restrict__ out_num, uint64_t *__restrict__ h_fin) {
+                                                                   uint64_t *__restrict__ out_num, uint64_t *__restrict__ h_fin,
+                                                                   const unsigned long long *__restrict__ pane_sum, const unsigned long long *__restrict__ tab_rows,
+                                                                   const int64_t *__restrict__ seg_off, const int32_t *__restrict__ pane_win_ptr, int32_t n_panes) {
     __shared__ uint64_t s_k[kFinishMax];
+    __shared__ uint32_t s_bad;
     const uint32_t *tail = reinterpret_cast<const uint32_t *>(meta + 2 * (size_t)n_win);
     const uint32_t n_sel = tail[0], err = tail[1];
+    // 16-bit counters: every counted pane's counters (added up by the max pass) + the rows it sent to the straggler tables = its rows, unless a
+    // count outgrew its 16 bits (kQ5Counters16).  (A call the device layout declined counted nothing: the host repeats it anyway.)
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if (pane_sum && (!info || info[2]))
+        for (int32_t p = threadIdx.x; p < n_panes; p += kFinishThreads)
+            if (pane_win_ptr[p + 1] != pane_win_ptr[p] && pane_sum[p] + tab_rows[p] != (unsigned long long)(seg_off[2 * p + 1] - seg_off[2 * p])) s_bad = 1;
+    __syncthreads();
+    const uint32_t bad16 = s_bad;
     for (uint32_t i = threadIdx.x; i < n_meta; i += kFinishThreads) h_fin[i] = meta[i];
     if (threadIdx.x < 3) h_fin[n_meta + threadIdx.x] = info ? info[threadIdx.x] : 0;
-    if (threadIdx.x == 3) h_fin[n_meta + 3] = (uint64_t)(uint32_t)slow_list[0];
-    const bool sortable = !err && n_sel <= kFinishMax && n_sel <= out_cap && (!info || info[2]);
+    if (threadIdx.x == 3) h_fin[n_meta + 3] = (uint64_t)(uint32_t)slow_list[0] | ((uint64_t)bad16 << 32);
+    const bool sortable = !err && !bad16 && n_sel <= kFinishMax && n_sel <= out_cap && (!info || info[2]);
     if (threadIdx.x == 4) h_fin[n_meta + 4] = sortable ? 1 : 0;
     int64_t *h_off = reinterpret_cast<int64_t *>(h_fin + n_meta + 5);
     if (!sortable) return;   // (block-uniform)
@@ -1667,43 +1742,6 @@ __global__ __launch_bounds__(kBlock) void q5_partial_emit_kernel(SegTiles sx, co
 
 
 
-#ifdef FLOCKGPU_EXPERIMENTAL
-// Block -> tile map of the XCD-local count pass: XCD x = pane % 8 takes its panes' tiles in order, its j-th tile goes to block 8 j + x (the
-// block the hardware places on XCD x); -1 pads the XCDs that hold fewer tiles.  Cached per ctx under the pane row ranges it was built from.
-static int q5_xcd_tile_map(flockgpu_ctx *ctx, int n_panes, const int64_t *sb, const int64_t *se, const int32_t **out, unsigned *grid) {
-    constexpr int kXcds = 8;
-    std::vector<int64_t> &sig = ctx->host_i64["q5.xcd_tile_sig"];
-    std::vector<int64_t> now;
-    now.reserve((size_t)2 * n_panes + 2);
-    std::vector<int32_t> per[kXcds];
-    int32_t t = 0;
-    for (int p = 0; p < n_panes; ++p) {
-        now.push_back(sb[p]);
-        now.push_back(se[p]);
-        if (se[p] <= sb[p]) continue;
-        const int64_t n = div_up(se[p] - (sb[p] & ~int64_t(3)), (int64_t)kQ5Tile);   // (as build_seg_tiles counts them)
-        for (int64_t i = 0; i < n; ++i) per[p % kXcds].push_back(t++);
-    }
-    size_t most = 0;
-    for (auto &v : per) most = std::max(most, v.size());
-    const size_t n_map = most * kXcds;
-    int32_t *d_map = nullptr, *h_map = nullptr;
-    FG_TRY(arena_get_t(ctx, "q5.xcd_tile", n_map + 1, &d_map));
-    FG_TRY(pinned_get_t(ctx, "q5.xcd_tile", n_map + 1, &h_map));
-    now.push_back((int64_t)reinterpret_cast<uintptr_t>(d_map));
-    if (sig != now) {
-        for (size_t j = 0; j < most; ++j)
-            for (int x = 0; x < kXcds; ++x) h_map[j * kXcds + x] = j < per[x].size() ? per[x][j] : -1;
-        FG_HIP(ctx, hipMemcpyAsync(d_map, h_map, n_map * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        sig = now;
-    }
-    *out = d_map;
-    *grid = (unsigned)n_map;
-    return FLOCKGPU_OK;
-}
-
-#endif
-
 // The three entry points share one driver:
 //   hot items          : rows = bids, weight = nullptr, `out` set
 //   weighted hot items : rows = partial groups (auction, count) received from the other partitions, `out` set
@@ -1885,11 +1923,18 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
     // a call on the host-layout path or a regrown arena leave it void, and the next call clears everything itself.
     std::vector<int64_t> &preclean = ctx->host_i64["q5.preclean"];
     if (preclean.size() != 2) preclean.assign(2, 0);
-    uint64_t clean_upto = 0;
+    LayoutArgs lay{};
+    uint64_t clean_upto = 0;   // (in 32-bit WORDS of the arena, as preclean[1]: whatever the counters' width was when they were zeroed)
+    // 16-bit counters (kQ5Counters16): the bid path over windows of one or two panes, until a call's sum check fails on this ctx
+    static const bool no_hop2 = exp_env("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
+    static const bool no_c16 = exp_env("FLOCKGPU_Q5_NO_C16") != nullptr;         // (A/B knob: 32-bit counters, as in rounds 1-5)
+    const bool c16 = kQ5Counters16 && kQ5Variant != 2 && !no_c16 && !weight && !part && !wide_mode && hop2 && !no_hop2 && ctx->host_i64["q5.no_c16"].empty() &&
+                     !exp_env("FLOCKGPU_Q5_COUNT");   // (the experimental count forms keep 32-bit counters)
+    auto words_of = [&](uint64_t n_counters) -> uint64_t { return c16 ? (n_counters + 1) / 2 : n_counters; };
     if (speculate) {
         // window pane ranges for the device pass (bases / ranges are filled in there); counters for the previous call's size + 1/8
-        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)hint[0] + (size_t)hint[0] / 8 + 4, &counters));
-        capacity = ctx->arena["q5.counters"].cap / sizeof(uint32_t) - 4;
+        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)words_of((uint64_t)hint[0] + (uint64_t)hint[0] / 8) + 8, &counters));
+        capacity = (ctx->arena["q5.counters"].cap / sizeof(uint32_t) - 8) * (c16 ? 2 : 1);
         if (preclean[0] == (int64_t)reinterpret_cast<uintptr_t>(counters)) clean_upto = (uint64_t)preclean[1];
         {   // the windows' pane ranges: uploaded when the schedule or the buffer changed (the layout kernel rewrites base / range, never lo / hi)
             std::vector<int64_t> &wsig = ctx->host_i64["q5.wins_sig"];   // (one buffer, one record of what it holds)
@@ -1906,24 +1951,21 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                 wsig = wnow;
             }
         }
-        {
-            LaunchScope ls(ctx, "q5_layout_kernel");
-            hipLaunchKernelGGL(q5_layout_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes,
-                               d_wins, d_info);
-        }
-        FG_TRY(check_launch(ctx, "q5_layout_kernel"));
+        lay = LayoutArgs{d_rng, d_ptr, st.seg_off, n_panes, n_win, capacity, budget, d_panes, d_wins, d_info};   // (runs as workgroup 0 of the clear below)
         cnt_total = (uint64_t)hint[0];   // (provisional: sizes launches; the true values come back with the results)
         scan_total = (uint64_t)hint[1];
     } else {
         FG_TRY(upload_layout());
-        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+        FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)words_of(cnt_total) + 8, &counters));
     }
     preclean[0] = preclean[1] = 0;
 
     // device scalars: [0, n_win) win_max, [n_win, 2 n_win) win_groups, then cursor + err (2 x u32), then tab_used (u32 x n_win)
     const size_t n_meta = (size_t)2 * n_win + 1 + ((size_t)n_win + 1) / 2 + 1;
+    const size_t n_meta_all = n_meta + (size_t)2 * std::max(n_panes, 0);   // ... then, for 16-bit counters, per pane: counter sum, rows sent to the tables (u64 each)
     uint64_t *d_meta = nullptr, *h_meta = nullptr;
-    FG_TRY(arena_get_t(ctx, "q5.meta", n_meta, &d_meta));
+    FG_TRY(arena_get_t(ctx, "q5.meta", n_meta_all, &d_meta));
+    unsigned long long *d_pane_sum = reinterpret_cast<unsigned long long *>(d_meta + n_meta), *d_tab_rows = d_pane_sum + std::max(n_panes, 0);
     FG_TRY(pinned_get_t(ctx, "q5.meta", n_meta, &h_meta));
     uint32_t *d_cursor = reinterpret_cast<uint32_t *>(d_meta + 2 * n_win), *d_err = d_cursor + 1, *d_used = d_cursor + 2;
 
@@ -1958,22 +2000,24 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         // 64 workgroups per window: max + select measured 0.158 / 0.122 / 0.119 / 0.145 ms with 8 / 32 / 64 / 128
         // (fewer: select cannot skip finely; more: per-workgroup prologue and the per-window atomics)
         const uint64_t per_win = n_win > 0 ? std::max<uint64_t>(cap, scan_total / n_win / 4) : cap;
-        static const bool no_hop2 = exp_env("FLOCKGPU_Q5_WINDOW_SCAN") != nullptr;   // (A/B knob: the window-walking passes)
         const bool pane_walk = hop2 && !no_hop2;
         const uint64_t per_pane = n_panes > 0 ? std::max<uint64_t>(cap, cnt_total / (uint64_t)n_panes / 4) : cap;
-        static const int hop2_blocks = exp_env("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(exp_env("FLOCKGPU_Q5_HOP2_BLOCKS")) : 32;   // (max pass 0.062 / 0.073 / 0.108 ms with 32 / 64 / 128 per pane)
+        // (32-bit counters: max pass 0.062 / 0.073 / 0.108 ms with 32 / 64 / 128 workgroups per pane; 16-bit: max + select 0.052 / 0.050 / 0.051 / 0.056 / 0.066 ms with 8 / 16 / 24 / 32 / 48)
+        static const int hop2_blocks_env = exp_env("FLOCKGPU_Q5_HOP2_BLOCKS") ? atoi(exp_env("FLOCKGPU_Q5_HOP2_BLOCKS")) : 0;
+        const int hop2_blocks = hop2_blocks_env ? hop2_blocks_env : c16 ? 16 : 32;
         const unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(div_up((int64_t)(pane_walk ? per_pane : per_win), kBlock * 2), 1), pane_walk ? hop2_blocks : 64);
         uint32_t *block_max = nullptr;
         const uint64_t n_block_max = (uint64_t)gx * std::max(n_win, 1) * (pane_walk ? 2 : 1);
         FG_TRY(arena_get_t(ctx, "q5.block_max", (size_t)n_block_max, &block_max));
         {   // one clear for everything this attempt writes into
-            const uint64_t clear_words = std::max<uint64_t>({speculate ? capacity : cnt_total, (uint64_t)cap * n_win, (uint64_t)n_meta, n_block_max});
+            const uint64_t clear_words = std::max<uint64_t>({words_of(speculate ? capacity : cnt_total), (uint64_t)cap * n_win, (uint64_t)n_meta_all, n_block_max});
             const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)clear_words / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
             {
                 LaunchScope ls(ctx, "q5_clear_kernel");
-                hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, spec_info, cnt_total,
-                                   (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta,
-                                   slow_list, block_max, n_block_max, plain_clear ? 1 : 0);
+                hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, speculate ? capacity : cnt_total,
+                                   (attempt == 0 && speculate) ? (clean_upto & ~uint64_t(3)) : uint64_t(0), tables, (uint64_t)cap * n_win, d_meta, (uint64_t)n_meta_all,
+                                   slow_list, block_max, n_block_max, plain_clear ? 1 : 0, c16 ? 1 : 0, speculate ? lay : LayoutArgs{});
+                if (speculate) clean_upto = std::max(clean_upto, words_of(capacity));   // (the arena is zero up to there now; only [0, counters in use) gets dirty)
             }
             FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         }
@@ -2015,13 +2059,9 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_TRY(check_launch(ctx, "q5_bucket_count_kernel"));
             FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         } else if (st.n_tiles > 0 && n_win > 0) {
-            const int32_t *xcd_tile = nullptr;
-            unsigned xcd_grid = 0;
 #ifdef FLOCKGPU_EXPERIMENTAL
-            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wgx | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
+            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
             static const char *count_form_env = exp_env("FLOCKGPU_Q5_COUNT");
-            if (!weight && count_form_env && !strcmp(count_form_env, "wgx") && ctx->host_i64["q5.no_xcd_local"].empty())
-                FG_TRY(q5_xcd_tile_map(ctx, n_panes, sb.data(), se.data(), &xcd_tile, &xcd_grid));
             const int wave_form = weight ? 0 : count_form_env ? (!strcmp(count_form_env, "wave1") ? 1 : !strcmp(count_form_env, "wave2") ? 2 : !strcmp(count_form_env, "wave4") ? 4 :
                                                                    !strcmp(count_form_env, "wavep1") ? 101 : !strcmp(count_form_env, "wavep4") ? 104 : 0) : kQ5WaveForm;
             if (wave_form > 100) {
@@ -2049,11 +2089,11 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_PERSIST)
                 const unsigned count_grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * (exp_env("FLOCKGPU_Q5_PERSIST_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_PERSIST_PER_CU")) : 8));
 #else
-                const unsigned count_grid = xcd_tile ? xcd_grid : (unsigned)st.n_tiles;
+                const unsigned count_grid = (unsigned)st.n_tiles;
 #endif
                 hipLaunchKernelGGL(weight ? q5_count_kernel<true> : q5_count_kernel<false>, dim3(count_grid), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list, spec_info, d_wsum, xcd_tile);
+                                   slow_list, spec_info, d_wsum, c16 ? 1 : 0, c16 ? d_tab_rows : (unsigned long long *)nullptr);
             }
             FG_TRY(check_launch(ctx, "q5_count_kernel"));
             if (d_wsum) FG_HIP(ctx, hipMemcpyAsync(h_wsum, d_wsum, sizeof(unsigned long long) * (size_t)n_panes, hipMemcpyDeviceToHost, ctx->stream));
@@ -2062,7 +2102,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                 const unsigned gs = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
                 hipLaunchKernelGGL(weight ? q5_count_slow_kernel<true> : q5_count_slow_kernel<false>, dim3(gs), dim3(kBlock), 0,
                                    ctx->stream, auction, weight, st, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err,
-                                   slow_list, spec_info);
+                                   slow_list, spec_info, c16 ? 1 : 0, c16 ? d_tab_rows : (unsigned long long *)nullptr);
             }
             FG_TRY(check_launch(ctx, "q5_count_slow_kernel"));
         }
@@ -2123,14 +2163,14 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         if (n_win > 0 && pane_walk) {
             {
                 LaunchScope ls(ctx, "q5_max_kernel");
-                hipLaunchKernelGGL(q5_hop2_scan_kernel<false>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles, d_roles + role_a.size(), counters,
-                                   tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
+                hipLaunchKernelGGL((c16 ? q5_hop2_scan_kernel<false, true> : q5_hop2_scan_kernel<false, false>), dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles,
+                                   d_roles + role_a.size(), counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info, d_pane_sum);
             }
             FG_TRY(check_launch(ctx, "q5_max_kernel"));
             {
                 LaunchScope ls(ctx, "q5_select_kernel");
-                hipLaunchKernelGGL(q5_hop2_scan_kernel<true>, dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles, d_roles + role_a.size(), counters,
-                                   tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info);
+                hipLaunchKernelGGL((c16 ? q5_hop2_scan_kernel<true, true> : q5_hop2_scan_kernel<true, false>), dim3(gx, (unsigned)n_panes), dim3(kBlock), 0, ctx->stream, d_panes, d_roles,
+                                   d_roles + role_a.size(), counters, tables, cap, d_used, d_meta, d_meta + n_win, block_max, d_cursor, out_cap, o_win, o_key, spec_info, d_pane_sum);
             }
             FG_TRY(check_launch(ctx, "q5_select_kernel"));
         } else if (n_win > 0) {
@@ -2161,13 +2201,17 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         {
             LaunchScope ls(ctx, "q5_finish_kernel");
             hipLaunchKernelGGL(q5_finish_kernel, dim3(1), dim3(kFinishThreads), 0, ctx->stream, d_meta, (uint32_t)n_meta, n_win, spec_info, slow_list, o_win, o_key, out_cap,
-                               fin_a, fin_n, h_fin);
+                               fin_a, fin_n, h_fin, c16 && pane_walk ? d_pane_sum : (const unsigned long long *)nullptr, d_tab_rows, st.seg_off, d_ptr, n_panes);
         }
         FG_TRY(check_launch(ctx, "q5_finish_kernel"));
         FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::copy(h_fin, h_fin + n_meta, h_meta);
         if (speculate) std::copy(h_fin + n_meta, h_fin + n_meta + 3, h_info);
         h_slow_count = (uint32_t)h_fin[n_meta + 3];
+        if (h_fin[n_meta + 3] >> 32) {   // a pane's 16-bit counters do not add up to its rows: some count outgrew 65535 -- 32-bit counters for this ctx from here on
+            ctx->host_i64["q5.no_c16"].assign(1, 1);
+            return q5_run(ctx, auction, weight, rows, win, out, part);   // (preclean is void by now: the repeat clears everything itself)
+        }
         fin_sorted = h_fin[n_meta + 4] != 0;
         fin_off = reinterpret_cast<const int64_t *>(h_fin + n_meta + 5);
         if (speculate) {
@@ -2176,7 +2220,7 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
                 hint[2] = 0;
                 FG_TRY(host_layout());
                 FG_TRY(upload_layout());
-                FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)cnt_total + 4, &counters));
+                FG_TRY(arena_get_t(ctx, "q5.counters", (size_t)words_of(cnt_total) + 8, &counters));
                 cap64 = dense ? 1024 : std::max<uint64_t>(1024, (uint64_t)((double)max_win_rows / rpg * 2.0) + 64);
                 --attempt;
                 continue;
@@ -2194,10 +2238,6 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         }
         const uint32_t *tail = reinterpret_cast<const uint32_t *>(h_meta + 2 * n_win);
         n_sel = tail[0];
-        if (tail[1] & 4u) {   // a block of the XCD-local count pass ran on another XCD than its index says: this ctx counts the ordinary way from now on
-            ctx->host_i64["q5.no_xcd_local"].assign(1, 1);
-            continue;
-        }
         if (tail[1]) {  // a window table filled up: the group-count hint was too optimistic
             cap64 *= 4;
             continue;
@@ -2337,13 +2377,13 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
         FG_TRY(arena_get_t(ctx, "q5.slow_list", (size_t)st.n_tiles + 2, &slow_list));
         {
             LaunchScope ls(ctx, "q5_clear_kernel");
-            const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)cnt_total / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
-            hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, (const uint64_t *)nullptr, cnt_total, uint64_t(0), (uint64_t *)nullptr,
-                               uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0);
+            const unsigned cg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up((int64_t)words_of(cnt_total) / 4 + 1, kBlock), (int64_t)ctx->num_cus * 16));
+            hipLaunchKernelGGL(q5_clear_kernel, dim3(cg), dim3(kBlock), 0, ctx->stream, counters, cnt_total, uint64_t(0), (uint64_t *)nullptr,
+                               uint64_t(0), (uint64_t *)nullptr, uint64_t(0), slow_list, (uint32_t *)nullptr, uint64_t(0), plain_clear ? 1 : 0, c16 ? 1 : 0, LayoutArgs{});
         }
         FG_TRY(check_launch(ctx, "q5_clear_kernel"));
         preclean[0] = (int64_t)reinterpret_cast<uintptr_t>(counters);
-        preclean[1] = (int64_t)std::max<uint64_t>(clean_upto, cnt_total);
+        preclean[1] = (int64_t)std::max<uint64_t>(clean_upto, words_of(cnt_total));
     }
     return FLOCKGPU_OK;
 }

@@ -256,6 +256,29 @@ def test_q5_ties_uniform_keys_and_extremes(ctx):
         assert off[4] == off[3], name          # empty window -> MAX is NULL -> no rows
 
 
+@pytest.mark.parametrize("case", ["even_at_limit", "even_over", "odd_over", "both_over"])
+def test_q5_counts_around_the_16_bit_counter_limit(case):
+    """Round 6: the bid path counts into 16-bit counters, two keys per word, and checks every pane's counter sum against its rows; a count
+    of 65535 fits, 65536 carries into the odd neighbour (even key) or out of the word (odd key) -- the call is then repeated with 32-bit
+    counters.  A fresh context per case, so that no earlier fallback hides the 16-bit pass; two calls each (the second one runs with
+    whatever the first one left: cleaned counters, the kept counter width)."""
+    from flock_amd import Bids, GpuContext, WindowSchedule
+    rng = np.random.default_rng(16)
+    even, odd = {"even_at_limit": (65535, 9), "even_over": (65536, 9), "odd_over": (40, 65536), "both_over": (70_000, 131_073)}[case]
+    n_other = 150_000
+    auction = np.concatenate([np.full(even, 1000, np.int32), np.full(odd, 1001, np.int32), (1002 + rng.integers(0, 3000, n_other)).astype(np.int32)])
+    rng.shuffle(auction)
+    n = len(auction)
+    half = n // 2 + 5
+    sched = WindowSchedule(np.array([0, half, n]), np.array([0, 1]), np.array([2, 2]))   # panes [0, half), [half, n); windows {0, 1}, {1}: the hopping shape
+    c = GpuContext(0)
+    try:
+        for _ in range(2):
+            _q5_check(c, Bids(auction=_dev(auction), rows=n), sched, auction)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ q7 (first "next" query, SURVEY.md section 8 f)
 @pytest.mark.parametrize("seed,eps,seconds", [(1, 1000, 30), (7, 5000, 20), (42, 50_000, 30), (5, 1_000_000, 20)])
 def test_q7_tumbling_windows(ctx, seed, eps, seconds):

@@ -60,8 +60,8 @@ def test_dense_group_by_with_four_accumulators(gpu, key):
     n = 60_000
     t = table(n, r, null_p=0.0)
     t[key] = [int(x) for x in (1000 + np.sort(r.integers(0, 5000, n)))]
-    aggs = [("sum", "j" if key != "j" else "i", "Int64"), ("min", "i", "Int32"), ("max", "l" if key != "l" else "i", "Int64" if key != "l" else "Int32"),
-            ("sum", "i", "Int64")]   # (kMaxGroupAggs = 4 accumulators per GROUP BY)
+    other = "l" if key == "j" else "j"
+    aggs = [("sum", "i", "Int64"), ("min", other, "Int64" if other == "l" else "Int32"), ("max", "i", "Int32"), ("sum", other, "Int64")]   # (kMaxGroupAggs = 4 accumulators per GROUP BY)
     plan = _agg_plan(key, aggs)
     ctx = ExecutionContext([plan], gpu=gpu)
     gpu.profile_reset()

@@ -20,4 +20,4 @@ except Exception as e:
 PY
 done; done
 cp /tmp/shipped.so flock_amd/libflockgpu.so
-if [ -n "$TESTS" ]; then timeout 1500 python -m pytest $TESTS -q -m gpu -x -p no:cacheprovider 2>&1 | tail -5; fi
+if [ -n "$TESTS" ]; then timeout 1500 python -m pytest $TESTS -q -m gpu -x -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error|assert" | tail -8; fi
