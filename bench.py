@@ -77,7 +77,7 @@ def parse():
                          "inside libflockgpu as the headline; auto = windows, with the exchange attached as `exchange` at N > 1")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements")
     ap.add_argument("--only-general", default="", help=argparse.SUPPRESS)   # (one general-path row on its own: tools/gpu_profile.sh)
-    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic", "arch", "q6"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
+    ap.add_argument("--only-side", default="", choices=["", "q11", "ysb", "json", "plan_stages", "plan_collect", "q5_pcie", "plan_generic", "arch", "q6", "expr"], help=argparse.SUPPRESS)   # (one "next" side entry on its own)
     ap.add_argument("--only-plan-collect", action="store_true", help=argparse.SUPPRESS)   # (the fresh-process leg of also.plan_collect_pcie)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, host cores))")
@@ -1219,6 +1219,96 @@ def arch_ops(gpu, eps, steps, no_cpu, seconds=100):
     return out
 
 
+def expr_side(gpu, eps, steps, no_cpu, seconds=100):
+    """The general expression evaluator (flock_amd/csrc/valprog.hpp: what a computed projection or an arithmetic predicate outside the fused
+    shapes takes) through the plan ABI, the arch harness's recipe (source.rs:36-63: plan once, feed once, timed executes with the result left
+    in HBM, mean) on the bids of `seconds` x `eps` events:
+      expr_project : SELECT price * 2 + 1 FROM bid            (the planner's types: CAST(price AS Int64) * 2 + 1 -> Int64)
+      expr_filter  : SELECT auction, price FROM bid WHERE price / 100 > 5 AND auction % 7 = 1
+    roofline: valprog_kernel's algorithmic bytes -- the columns the expression reads once + what it writes once (projection: 4 B in + 8 B out per
+    bid; filter: 8 B in per bid, flag words aside) -- over its average launch.  cpu_baseline: Arrow C++ (pyarrow.compute) on the host's cores over a
+    bounded sample of the same bids."""
+    import pyarrow as pa
+    from flock_amd import NEXMarkSource, Window
+    from flock_amd.runtime import ExecutionContext
+    g = NEXMarkSource(seconds, eps, Window.element_wise(), seed=11).generate_data(gpu, relations=("bid",), bid_columns=("auction", "price"))
+    bid_rb = pa.record_batch([pa.array(g.bids.auction.cpu().numpy()), pa.array(g.bids.price.cpu().numpy())], names=["auction", "price"])
+    n = bid_rb.num_rows
+    del g
+    fld = lambda name, dt: {"data_type": dt, "dict_id": 0, "dict_is_ordered": False, "name": name, "nullable": False}
+    fields = [fld("auction", "Int32"), fld("price", "Int32")]
+    scan = {"execution_plan": "memory_exec", "schema": {"fields": fields, "metadata": {}}, "projection": [0, 1]}
+    c = lambda name: {"physical_expr": "column", "name": name, "index": [f["name"] for f in fields].index(name)}
+    lit = lambda kind, v: {"physical_expr": "literal", "value": {kind: v}}
+    b = lambda l, op, r: {"physical_expr": "binary_expr", "left": l, "op": op, "right": r}
+    i64 = lambda e: {"physical_expr": "cast_expr", "expr": e, "cast_type": "Int64"}
+    proj_e = b(b(i64(c("price")), "Multiply", lit("Int64", 2)), "Plus", lit("Int64", 1))
+    plans = {"expr_project": ({"execution_plan": "projection_exec", "expr": [[proj_e, "x"]], "input": scan, "schema": {"fields": [fld("x", "Int64")], "metadata": {}}}, 12.0),
+             "expr_filter": ({"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096,
+                              "input": {"execution_plan": "filter_exec", "input": scan,
+                                        "predicate": b(b(b(i64(c("price")), "Divide", lit("Int64", 100)), "Gt", lit("Int64", 5)), "And",
+                                                       b(b(i64(c("auction")), "Modulo", lit("Int64", 7)), "Eq", lit("Int64", 1)))}}, 8.0)}
+    out = {"input": {"bids": int(n)}, "recipe": "source.rs:36-63: plan once, feed once, timed executes (results left in HBM), mean"}
+    for name, (plan, bytes_per_row) in plans.items():
+        ctx = ExecutionContext([plan], gpu=gpu, generic_only=True)
+        try:
+            ctx.feed_data_sources([[[bid_rb]]])
+            pl = ctx.plans[0]
+            rows = pl.execute_retain()
+            gpu.synchronize()
+            times = []
+            for _ in range(max(steps, 3)):
+                t0 = time.perf_counter()
+                rows = pl.execute_retain()
+                gpu.synchronize()
+                times.append(time.perf_counter() - t0)
+            gpu.profile_reset()
+            gpu.profile_only(None)
+            gpu.profile(True)
+            for _ in range(3):
+                pl.execute_retain()
+            gpu.synchronize()
+            stats = gpu.profile_read()
+            gpu.profile(False)
+            ms = sum(times) / len(times) * 1e3
+            e = {"value": round(n / (ms * 1e-3), 1), "unit": "rows/s", "ms_per_step": round(ms, 4), "input_rows": int(n), "result_rows": int(rows),
+                 "kernels_ms_per_execute": {k: round(v["total_ms"] / 3, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
+            st = stats.get("valprog_kernel")
+            if st and st["launches"]:
+                avg, alg = st["total_ms"] / st["launches"], bytes_per_row * n
+                e["roofline"] = {"bound": "hbm", "kernel": "valprog_kernel", "achieved": round(alg / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 4), "algorithmic_bytes_per_launch": int(alg),
+                                 "traffic": traffic_of("valprog_kernel", alg, name)}
+            out[name] = e
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
+        ctx.close()
+    if not no_cpu:
+        try:
+            import pyarrow.compute as pc
+            m = min(n, 20_000_000)
+            price, auction = pc.cast(bid_rb["price"].slice(0, m), pa.int64()), pc.cast(bid_rb["auction"].slice(0, m), pa.int64())
+            tb = pa.Table.from_batches([bid_rb.slice(0, m)])
+
+            def filt():
+                rem = pc.subtract(auction, pc.multiply(pc.divide(auction, 7), 7))
+                return tb.filter(pc.and_(pc.greater(pc.divide(price, 100), 5), pc.equal(rem, 1))).num_rows
+            cpu = {}
+            for name, fn in (("expr_project", lambda: pc.add(pc.multiply(price, 2), 1)), ("expr_filter", filt)):
+                fn()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fn()
+                cpu[name] = round(m / ((time.perf_counter() - t0) / 3), 1)
+            for name in cpu:
+                if "error" not in out.get(name, {}):
+                    out[name]["cpu_baseline"] = {"value": cpu[name], "unit": "rows/s", "cores": pa.cpu_count(), "kind": "port",
+                                                 "sample": f"pyarrow {pa.__version__} compute over the first {m} bids (Int64 operands already cast), 3 timed passes (mean)"}
+        except Exception as ex:
+            out["cpu_baseline_error"] = repr(ex)
+    return out
+
+
 def q6_side(gpu, eps, steps, no_cpu, seconds=10):
     """q6 (benchmarks/src/nexmark/query/q6.sql: the average selling price of a seller's last ten auctions) through the plan ABI -- the one NEXMark query
     with WindowAggExec, on the generic operators (join, BETWEEN, two-key sorts, ROW_NUMBER() runs, AVG): `seconds` x `eps` events fed once, the plan
@@ -1600,7 +1690,8 @@ def main():
              "plan_stages": lambda: plan_stages(g, args.eps, n), "plan_collect": lambda: plan_collect_pcie(g, args.eps, max(n, 5)),
              "q5_pcie": lambda: pcie_inclusive_q5(g, args.eps), "plan_generic": lambda: plan_generic(g, args.eps, n),
              "arch": lambda: arch_ops(g, args.eps, 10, args.no_cpu, seconds=args.seconds or 100),
-             "q6": lambda: q6_side(g, args.eps, n, args.no_cpu, seconds=args.seconds or 10)}[args.only_side]()
+             "q6": lambda: q6_side(g, args.eps, n, args.no_cpu, seconds=args.seconds or 10),
+             "expr": lambda: expr_side(g, args.eps, max(n, 5), args.no_cpu, seconds=args.seconds or 100)}[args.only_side]()
         print(json.dumps(e))
         return
     if args.only_general:
@@ -1886,6 +1977,12 @@ def main():
                 also[label] = fn()
             except Exception as e:
                 also[label] = {"error": repr(e)}
+        try:   # the general expression evaluator: two rows of their own (expr_project, expr_filter)
+            ex = expr_side(ctx, args.eps, 10, args.no_cpu)
+            for k in ("expr_project", "expr_filter"):
+                also[k] = ex.get(k, {"error": "missing"})
+        except Exception as e:
+            also["expr_project"] = also["expr_filter"] = {"error": repr(e)}
         # what the exchange costs over the plain operators on one rank (same relations, RCCL communicator of one rank)
         ex = {}
         try:

@@ -1814,16 +1814,13 @@ struct Exec {
         if (rc == FLOCKGPU_OK) return pred_to_rows(ctx, node_key(pl, n, "sel").c_str(), b.p, in->rows, rows, n_out);
         if (rc != FLOCKGPU_ERR_UNSUPPORTED) return rc;
         // a predicate the one-pass program has no leaf for (arithmetic inside a comparison, CASE, casts of computed values): the general
-        // evaluator writes a byte mask, the mask goes through the same count -> scan -> emit
+        // evaluator writes the same flag words + wave counts, which go through the same scan -> emit
         ValBuilder vb;
         int vt = -1;
         bool may_null = false;
         FG_TRY(val_compile(n->pred.get(), *in, vb, 5, &vt, &may_null));
         if (vt != 5) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a filter predicate that is not Boolean");
-        uint8_t *mask = nullptr;
-        FG_TRY(arena_get_t(ctx, node_key(pl, n, "vmask").c_str(), (size_t)std::max<int64_t>(in->rows, 0) + 16, &mask));
-        FG_TRY(valprog_to_mask(ctx, node_key(pl, n, "vprog").c_str(), vb.p, in->rows, mask));
-        return mask_to_rows(ctx, node_key(pl, n, "sel").c_str(), mask, in->rows, rows, n_out);
+        return valprog_to_rows(ctx, node_key(pl, n, "vprog").c_str(), vb.p, in->rows, rows, n_out);
     }
 
     int exec(const Node *n, Table *t) {

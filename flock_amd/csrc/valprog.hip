@@ -5,7 +5,7 @@ using namespace flockgpu;
 
 namespace {
 
-constexpr uint32_t kErrDivZero = 1u, kErrCast = 2u, kErrNull = 4u;
+constexpr uint32_t kErrDivZero = 1u, kErrCast = 2u, kErrNull = 4u, kErrOverflow = 8u;
 
 __device__ __forceinline__ double as_f64(uint64_t b) { return __longlong_as_double((long long)b); }
 __device__ __forceinline__ uint64_t f64_bits(double d) { return (uint64_t)__double_as_longlong(d); }
@@ -53,32 +53,57 @@ __device__ __forceinline__ bool cast_value(uint64_t v, uint8_t from, uint8_t to,
     return false;
 }
 
+__device__ __forceinline__ uint64_t wrap_to(uint8_t type, uint64_t r) { return type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(uint32_t)r : r; }
+
 __device__ __forceinline__ uint64_t arith(uint8_t kind, uint8_t type, uint64_t a, uint64_t b, uint32_t *bad) {
     const uint8_t ADD = (uint8_t)ValOpKind::Add, SUB = (uint8_t)ValOpKind::Sub, MUL = (uint8_t)ValOpKind::Mul, DIV = (uint8_t)ValOpKind::Div;
     if (type == (uint8_t)ValType::F64) {
         const double x = as_f64(a), y = as_f64(b);
+        if ((kind == DIV || kind == (uint8_t)ValOpKind::Mod) && y == 0.0) {   // (A-V3: arrow-rs tests is_zero() for floats, too; -0.0 == 0.0)
+            *bad |= kErrDivZero;
+            return 0;
+        }
         return f64_bits(kind == ADD ? x + y : kind == SUB ? x - y : kind == MUL ? x * y : kind == DIV ? x / y : fmod(x, y));
     }
-    if (kind == ADD || kind == SUB || kind == MUL) {
-        const uint64_t r = kind == ADD ? a + b : kind == SUB ? a - b : a * b;
-        return type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(uint32_t)r : r;   // wraps at the type's width
-    }
+    if (kind == ADD || kind == SUB || kind == MUL) return wrap_to(type, kind == ADD ? a + b : kind == SUB ? a - b : a * b);   // wraps at the type's width
     if (b == 0) {
         *bad |= kErrDivZero;
         return 0;
     }
     if (type == (uint8_t)ValType::U64) return kind == DIV ? a / b : a % b;
     const int64_t x = (int64_t)a, y = (int64_t)b;
-    if (y == -1) {   // (INT_MIN / -1 wraps; x % -1 is 0)
-        if (kind != DIV) return 0;
-        const uint64_t r = 0 - a;
-        return type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(uint32_t)r : r;
+    if (y == -1) {   // (A-V4: INT_MIN / -1 and INT_MIN % -1 overflow; any other x: -x, 0)
+        if (x == (type == (uint8_t)ValType::I32 ? (int64_t)INT32_MIN : INT64_MIN)) *bad |= kErrOverflow;
+        return kind == DIV ? wrap_to(type, 0 - a) : 0;
     }
     if (type == (uint8_t)ValType::I32) {
         const int32_t x32 = (int32_t)x, y32 = (int32_t)y;
         return (uint64_t)(int64_t)(kind == DIV ? x32 / y32 : x32 % y32);
     }
     return (uint64_t)(kind == DIV ? x / y : x % y);
+}
+
+// x / c and x % c for an integer literal c != 0 through the reciprocal the host made (ValBuilder::fuse_immediate): unsigned quotient of the
+// absolute values, then the signs (truncation towards zero; the remainder takes the dividend's sign)
+__device__ __forceinline__ uint64_t div_by_const(uint8_t kind, uint8_t type, uint64_t a, uint64_t c, uint64_t magic, uint32_t sh, uint32_t *bad) {
+    const bool is_div = kind == (uint8_t)ValOpKind::Div;
+    const uint32_t shift = sh & 63u;
+    const bool add = (sh >> 8) != 0;
+    auto udiv = [&](uint64_t n) -> uint64_t {
+        if (magic == 0) return n >> shift;   // a power of two
+        const uint64_t hi = __umul64hi(n, magic);
+        return add ? (((n - hi) >> 1) + hi) >> shift : hi >> shift;
+    };
+    if (type == (uint8_t)ValType::U64) {
+        const uint64_t q = udiv(a);
+        return is_div ? q : a - q * c;
+    }
+    const int64_t x = (int64_t)a, y = (int64_t)c;
+    if (y == -1 && x == (type == (uint8_t)ValType::I32 ? (int64_t)INT32_MIN : INT64_MIN)) *bad |= kErrOverflow;
+    const uint64_t ax = x < 0 ? 0 - a : a, ad = y < 0 ? 0 - c : c;
+    const uint64_t q = udiv(ax), r = ax - q * ad;
+    if (is_div) return wrap_to(type, (x < 0) != (y < 0) ? 0 - q : q);
+    return x < 0 ? 0 - r : r;
 }
 
 __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, uint64_t b) {
@@ -105,140 +130,250 @@ __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, 
     }
 }
 
-// kMask: out_values is the byte mask (1 = TRUE); else a value column of `out_type` + out_valid (null: a NULL result is an error)
+// One pass of the program over FOUR consecutive rows per lane.  Values on the stack: 4 x 64 bits + 4 validity bits; the top of the stack in
+// registers (tv / tok), what waits below it in the lane's own columns of `s_v` / `s_ok` (no bank conflicts, no barrier).  r0: the lane's
+// first row; rows at or beyond n load nothing and come out NULL.
+struct Vec4 {
+    uint64_t v[4];
+    uint32_t ok;   // bit j: row j holds a value
+};
+
+__device__ __forceinline__ Vec4 load_col4(const ValCol &c, int64_t r0, int64_t n, bool whole) {
+    Vec4 x;
+    x.ok = 0;
+    if (whole) {   // (block-uniform) the tile lies inside the relation: 16-byte loads (columns are 16-byte aligned: arena / Arrow buffers)
+        if (c.type == (int32_t)ColType::I32) {
+            const int4 t = stream_load4(static_cast<const int32_t *>(c.values) + r0);
+            x.v[0] = (uint64_t)(int64_t)t.x; x.v[1] = (uint64_t)(int64_t)t.y; x.v[2] = (uint64_t)(int64_t)t.z; x.v[3] = (uint64_t)(int64_t)t.w;
+        } else {
+            const uint4 lo = stream_load4u(reinterpret_cast<const uint32_t *>(static_cast<const uint64_t *>(c.values) + r0));
+            const uint4 hi = stream_load4u(reinterpret_cast<const uint32_t *>(static_cast<const uint64_t *>(c.values) + r0 + 2));
+            x.v[0] = ((uint64_t)lo.y << 32) | lo.x; x.v[1] = ((uint64_t)lo.w << 32) | lo.z;
+            x.v[2] = ((uint64_t)hi.y << 32) | hi.x; x.v[3] = ((uint64_t)hi.w << 32) | hi.z;
+        }
+        if (c.valid) {
+            const uint32_t vb = *reinterpret_cast<const uint32_t *>(c.valid + r0);   // (r0 is a multiple of 4)
+            x.ok = (vb & 0xFFu ? 1u : 0u) | (vb & 0xFF00u ? 2u : 0u) | (vb & 0xFF0000u ? 4u : 0u) | (vb & 0xFF000000u ? 8u : 0u);
+        } else {
+            x.ok = 15u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r0 + j;
+            const bool ok = r < n && (!c.valid || c.valid[r]);
+            x.v[j] = ok ? load_value(c, r) : 0;
+            x.ok |= (ok ? 1u : 0u) << j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!((x.ok >> j) & 1u)) x.v[j] = 0;   // (the slot of a NULL holds 0: no arithmetic on garbage, no spurious division by zero)
+    return x;
+}
+
 template <bool kMask>
-__global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n, void *__restrict__ out_values, uint8_t *__restrict__ out_valid,
-                                                         int32_t out_type, uint32_t *err) {
-    __shared__ uint64_t s_v[kValMaxStack][kBlock];
-    __shared__ uint8_t s_ok[kValMaxStack][kBlock];
+__global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n, int32_t n_tiles, void *__restrict__ out_values, uint8_t *__restrict__ out_valid,
+                                                         int32_t out_type, uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts, uint32_t *err) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_dyn[];   // [max_stack - 1][4][kBlock] values, then [max_stack - 1][kBlock] validity nibbles
     const int t = threadIdx.x;
+    const int below = p.max_stack > 1 ? p.max_stack - 1 : 0;
+    uint64_t *s_v = s_dyn;
+    uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_dyn + (size_t)below * 4 * kBlock);
     uint32_t bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + t; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int sp = 0;
-        for (int o = 0; o < p.n_ops; ++o) {
-            const ValOp op = p.ops[o];
-            switch ((ValOpKind)op.kind) {
-                case ValOpKind::Col: {
-                    const ValCol &c = p.cols[op.arg];
-                    const bool ok = !c.valid || c.valid[i];
-                    s_v[sp][t] = ok ? load_value(c, i) : 0;   // (the slot of a NULL holds an unspecified value)
-                    s_ok[sp][t] = ok;
-                    ++sp;
-                    break;
+    for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
+        const int64_t tile_begin = (int64_t)tile * kFlagTile;
+        const bool whole = tile_begin + kFlagTile <= n;   // (block-uniform)
+        uint32_t flags = 0;
+#pragma unroll 1
+        for (int it = 0; it < kFlagIters; ++it) {
+            const int64_t r0 = tile_begin + flag_rel0() + it * 256;
+            Vec4 top;
+            top.ok = 0;
+            top.v[0] = top.v[1] = top.v[2] = top.v[3] = 0;
+            int sp = 0;   // operands on the stack, the top one in `top`
+            auto spill = [&]() {   // a push over a live top: it goes to its slot below
+                if (sp > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s_v[((size_t)(sp - 1) * 4 + j) * kBlock + t] = top.v[j];
+                    s_ok[(size_t)(sp - 1) * kBlock + t] = (uint8_t)top.ok;
                 }
-                case ValOpKind::Const:
-                    s_v[sp][t] = p.consts[op.arg];
-                    s_ok[sp][t] = 1;
-                    ++sp;
-                    break;
-                case ValOpKind::Null:
-                    s_v[sp][t] = 0;
-                    s_ok[sp][t] = 0;
-                    ++sp;
-                    break;
-                case ValOpKind::Add: case ValOpKind::Sub: case ValOpKind::Mul: case ValOpKind::Div: case ValOpKind::Mod: {
-                    --sp;
-                    const bool ok = s_ok[sp - 1][t] && s_ok[sp][t];
-                    s_v[sp - 1][t] = ok ? arith(op.kind, op.type, s_v[sp - 1][t], s_v[sp][t], &bad) : 0;
-                    s_ok[sp - 1][t] = ok;
-                    break;
-                }
-                case ValOpKind::Neg: {
-                    const uint64_t a = s_v[sp - 1][t];
-                    s_v[sp - 1][t] = op.type == (uint8_t)ValType::F64 ? f64_bits(-as_f64(a))
-                                     : op.type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(0u - (uint32_t)a) : 0 - a;
-                    break;
-                }
-                case ValOpKind::Cast: case ValOpKind::TryCast: {
-                    if (s_ok[sp - 1][t]) {
-                        uint64_t r = 0;
-                        if (cast_value(s_v[sp - 1][t], op.type, op.to, &r)) {
-                            s_v[sp - 1][t] = r;
+            };
+            auto second = [&]() -> Vec4 {   // the operand below the top
+                Vec4 a;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a.v[j] = s_v[((size_t)(sp - 2) * 4 + j) * kBlock + t];
+                a.ok = s_ok[(size_t)(sp - 2) * kBlock + t];
+                return a;
+            };
+#pragma unroll 1
+            for (int o = 0; o < p.n_ops; ++o) {
+                const ValOp op = p.ops[o];
+                const bool imm = op.to == kValImm;
+                switch ((ValOpKind)op.kind) {
+                    case ValOpKind::Col:
+                        spill();
+                        top = load_col4(p.cols[op.arg], r0, n, whole);
+                        ++sp;
+                        break;
+                    case ValOpKind::Const:
+                        spill();
+                        top.v[0] = top.v[1] = top.v[2] = top.v[3] = p.consts[op.arg];
+                        top.ok = 15u;
+                        ++sp;
+                        break;
+                    case ValOpKind::Null:
+                        spill();
+                        top.v[0] = top.v[1] = top.v[2] = top.v[3] = 0;
+                        top.ok = 0;
+                        ++sp;
+                        break;
+                    case ValOpKind::Add: case ValOpKind::Sub: case ValOpKind::Mul: case ValOpKind::Div: case ValOpKind::Mod: {
+                        if (imm) {   // left = top, right = the literal
+                            const uint64_t c = p.consts[op.arg];
+                            const bool by_recip = ((ValOpKind)op.kind == ValOpKind::Div || (ValOpKind)op.kind == ValOpKind::Mod) && op.type != (uint8_t)ValType::F64;
+                            const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
+                            const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if ((top.ok >> j) & 1u) top.v[j] = by_recip ? div_by_const(op.kind, op.type, top.v[j], c, magic, sh, &bad) : arith(op.kind, op.type, top.v[j], c, &bad);
                         } else {
-                            s_v[sp - 1][t] = 0;
-                            s_ok[sp - 1][t] = 0;
-                            if ((ValOpKind)op.kind == ValOpKind::Cast) bad |= kErrCast;
+                            const Vec4 a = second();
+                            const uint32_t ok = a.ok & top.ok;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top.v[j] = (ok >> j) & 1u ? arith(op.kind, op.type, a.v[j], top.v[j], &bad) : 0;
+                            top.ok = ok;
+                            --sp;
                         }
+                        break;
                     }
-                    break;
-                }
-                case ValOpKind::Eq: case ValOpKind::Ne: case ValOpKind::Lt: case ValOpKind::Le: case ValOpKind::Gt: case ValOpKind::Ge: {
-                    --sp;
-                    const bool ok = s_ok[sp - 1][t] && s_ok[sp][t];
-                    s_v[sp - 1][t] = ok && compare(op.kind, op.type, s_v[sp - 1][t], s_v[sp][t]) ? 1 : 0;
-                    s_ok[sp - 1][t] = ok;
-                    break;
-                }
-                case ValOpKind::And: case ValOpKind::Or: {
-                    --sp;
-                    const bool oa = s_ok[sp - 1][t], ob = s_ok[sp][t], va = oa && s_v[sp - 1][t], vb = ob && s_v[sp][t];
-                    bool v, ok;
-                    if ((ValOpKind)op.kind == ValOpKind::And) {
-                        const bool is_false = (oa && !va) || (ob && !vb);
-                        ok = is_false || (oa && ob);
-                        v = !is_false && oa && ob;
-                    } else {
-                        const bool is_true = va || vb;
-                        ok = is_true || (oa && ob);
-                        v = is_true;
+                    case ValOpKind::Neg:
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint64_t a = top.v[j];
+                            top.v[j] = op.type == (uint8_t)ValType::F64 ? ((top.ok >> j) & 1u ? f64_bits(-as_f64(a)) : 0)
+                                       : op.type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(0u - (uint32_t)a) : 0 - a;
+                        }
+                        break;
+                    case ValOpKind::Cast: case ValOpKind::TryCast:
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((top.ok >> j) & 1u) {
+                                uint64_t r = 0;
+                                if (cast_value(top.v[j], op.type, op.to, &r)) {
+                                    top.v[j] = r;
+                                } else {
+                                    top.v[j] = 0;
+                                    top.ok &= ~(1u << j);
+                                    if ((ValOpKind)op.kind == ValOpKind::Cast) bad |= kErrCast;
+                                }
+                            }
+                        break;
+                    case ValOpKind::Eq: case ValOpKind::Ne: case ValOpKind::Lt: case ValOpKind::Le: case ValOpKind::Gt: case ValOpKind::Ge: {
+                        if (imm) {
+                            const uint64_t c = p.consts[op.arg];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top.v[j] = ((top.ok >> j) & 1u) && compare(op.kind, op.type, top.v[j], c) ? 1 : 0;
+                        } else {
+                            const Vec4 a = second();
+                            const uint32_t ok = a.ok & top.ok;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top.v[j] = ((ok >> j) & 1u) && compare(op.kind, op.type, a.v[j], top.v[j]) ? 1 : 0;
+                            top.ok = ok;
+                            --sp;
+                        }
+                        break;
                     }
-                    s_v[sp - 1][t] = v ? 1 : 0;
-                    s_ok[sp - 1][t] = ok;
-                    break;
-                }
-                case ValOpKind::Not:
-                    s_v[sp - 1][t] = s_ok[sp - 1][t] && !s_v[sp - 1][t] ? 1 : 0;
-                    break;
-                case ValOpKind::IsNull: case ValOpKind::IsNotNull:
-                    s_v[sp - 1][t] = (s_ok[sp - 1][t] != 0) == ((ValOpKind)op.kind == ValOpKind::IsNotNull) ? 1 : 0;
-                    s_ok[sp - 1][t] = 1;
-                    break;
-                case ValOpKind::Select: {   // [.. ELSE WHEN THEN]
-                    sp -= 2;
-                    const bool take = s_ok[sp][t] && s_v[sp][t];
-                    if (take) {
-                        s_v[sp - 1][t] = s_v[sp + 1][t];
-                        s_ok[sp - 1][t] = s_ok[sp + 1][t];
+                    case ValOpKind::And: case ValOpKind::Or: {
+                        const Vec4 a = second();
+                        uint32_t ok_out = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool oa = (a.ok >> j) & 1u, ob = (top.ok >> j) & 1u, va = oa && a.v[j], vb = ob && top.v[j];
+                            bool v, ok;
+                            if ((ValOpKind)op.kind == ValOpKind::And) {
+                                const bool is_false = (oa && !va) || (ob && !vb);
+                                ok = is_false || (oa && ob);
+                                v = !is_false && oa && ob;
+                            } else {
+                                const bool is_true = va || vb;
+                                ok = is_true || (oa && ob);
+                                v = is_true;
+                            }
+                            top.v[j] = v ? 1 : 0;
+                            ok_out |= (ok ? 1u : 0u) << j;
+                        }
+                        top.ok = ok_out;
+                        --sp;
+                        break;
                     }
-                    break;
+                    case ValOpKind::Not:
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) top.v[j] = ((top.ok >> j) & 1u) && !top.v[j] ? 1 : 0;
+                        break;
+                    case ValOpKind::IsNull: case ValOpKind::IsNotNull:
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) top.v[j] = (((top.ok >> j) & 1u) != 0) == ((ValOpKind)op.kind == ValOpKind::IsNotNull) ? 1 : 0;
+                        top.ok = 15u;
+                        break;
+                    case ValOpKind::Select: {   // [.. ELSE WHEN THEN]: THEN = top, WHEN below it, ELSE below that
+                        const Vec4 when = second();
+                        --sp;
+                        const Vec4 els = second();
+                        --sp;
+                        uint32_t ok_out = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool take = ((when.ok >> j) & 1u) && when.v[j];
+                            if (!take) top.v[j] = els.v[j];
+                            ok_out |= ((take ? top.ok : els.ok) >> j & 1u) << j;
+                        }
+                        top.ok = ok_out;
+                        break;
+                    }
+                }
+            }
+            if (kMask) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) flags |= (uint32_t)(((top.ok >> j) & 1u) && top.v[j] && r0 + j < n) << (it * 4 + j);
+            } else if (whole) {
+                if (out_type == (int32_t)ColType::I32) {
+                    *reinterpret_cast<int4 *>(static_cast<int32_t *>(out_values) + r0) = make_int4((int32_t)top.v[0], (int32_t)top.v[1], (int32_t)top.v[2], (int32_t)top.v[3]);
+                } else {
+                    uint4 *dst = reinterpret_cast<uint4 *>(static_cast<uint64_t *>(out_values) + r0);
+                    dst[0] = make_uint4((uint32_t)top.v[0], (uint32_t)(top.v[0] >> 32), (uint32_t)top.v[1], (uint32_t)(top.v[1] >> 32));
+                    dst[1] = make_uint4((uint32_t)top.v[2], (uint32_t)(top.v[2] >> 32), (uint32_t)top.v[3], (uint32_t)(top.v[3] >> 32));
+                }
+                if (out_valid) *reinterpret_cast<uint32_t *>(out_valid + r0) = (top.ok & 1u) | ((top.ok & 2u) << 7) | ((top.ok & 4u) << 14) | ((top.ok & 8u) << 21);
+                else if (top.ok != 15u) bad |= kErrNull;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + j;
+                    if (r >= n) continue;
+                    const bool ok = (top.ok >> j) & 1u;
+                    if (out_type == (int32_t)ColType::I32) static_cast<int32_t *>(out_values)[r] = (int32_t)top.v[j];
+                    else static_cast<uint64_t *>(out_values)[r] = top.v[j];
+                    if (out_valid) out_valid[r] = ok;
+                    else if (!ok) bad |= kErrNull;
                 }
             }
         }
-        const bool ok = s_ok[0][t];
-        const uint64_t v = ok ? s_v[0][t] : 0;
-        if (kMask) {
-            static_cast<uint8_t *>(out_values)[i] = ok && v ? 1 : 0;
-        } else {
-            if (out_type == (int32_t)ColType::I32) static_cast<int32_t *>(out_values)[i] = (int32_t)v;
-            else static_cast<uint64_t *>(out_values)[i] = v;
-            if (out_valid) out_valid[i] = ok;
-            else if (!ok) bad |= kErrNull;
-        }
+        if (kMask) store_flags_and_counts(flags, tile, flag_words, counts);
     }
     if (bad) atomicOr(err, bad);
 }
 
-int run(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, bool mask, ColType out_type, void *out_values, uint8_t *out_valid) {
-    if (prog.n_ops < 1 || prog.max_stack > kValMaxStack) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: malformed expression program", name);
-    if (rows <= 0) return FLOCKGPU_OK;
-    const std::string base = name;
-    uint32_t *d_err = nullptr, *h_err = nullptr;
-    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
-    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
-    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 1)));
-    const unsigned grid = (unsigned)std::min<int64_t>(div_up(rows, kBlock), (int64_t)ctx->num_cus * 8);
-    {
-        LaunchScope ls(ctx, "valprog_kernel");
-        if (mask) hipLaunchKernelGGL(valprog_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, prog, rows, out_values, (uint8_t *)nullptr, 0, d_err);
-        else hipLaunchKernelGGL(valprog_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, prog, rows, out_values, out_valid, (int32_t)out_type, d_err);
-    }
-    FG_TRY(check_launch(ctx, "valprog_kernel"));
-    pinned_pending32(h_err, 1);
-    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 1)));
-    FG_TRY(wait_pinned32(ctx, h_err, 1));
-    if (*h_err & kErrDivZero) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: division by zero", name);
-    if (*h_err & kErrCast) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a value does not fit the type it is cast to", name);
-    if (*h_err & kErrNull) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a NULL result where the expression was taken not to produce one", name);
+size_t stack_bytes(const ValProgram &prog) {
+    const size_t below = prog.max_stack > 1 ? (size_t)prog.max_stack - 1 : 0;
+    return below * (4 * kBlock * sizeof(uint64_t) + kBlock) + 16;
+}
+
+int report(flockgpu_ctx *ctx, const char *name, uint32_t e) {
+    if (e & kErrDivZero) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: division by zero", name);
+    if (e & kErrOverflow) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: INT_MIN / -1 overflows (the reference's arithmetic panics there)", name);
+    if (e & kErrCast) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a value does not fit the type it is cast to", name);
+    if (e & kErrNull) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: a NULL result where the expression was taken not to produce one", name);
     return FLOCKGPU_OK;
 }
 
@@ -248,11 +383,71 @@ namespace flockgpu {
 
 int valprog_to_column(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, ColType out_type, void *out_values, uint8_t *out_valid) {
     if (out_type == ColType::UTF8) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: a computed Utf8 column", name);
-    return run(ctx, name, prog, rows, false, out_type, out_values, out_valid);
+    if (prog.n_ops < 1 || prog.max_stack > kValMaxStack) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: malformed expression program", name);
+    if (rows <= 0) return FLOCKGPU_OK;
+    if (rows >= (int64_t(1) << 44)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many rows", name);
+    const std::string base = name;
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 1)));
+    const int32_t n_tiles = (int32_t)div_up(rows, (int64_t)kFlagTile);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "valprog_kernel");
+        hipLaunchKernelGGL(valprog_kernel<false>, dim3(grid), dim3(kBlock), stack_bytes(prog), ctx->stream, prog, rows, n_tiles, out_values, out_valid, (int32_t)out_type,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, d_err);
+    }
+    FG_TRY(check_launch(ctx, "valprog_kernel"));
+    pinned_pending32(h_err, 1);
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 1)));
+    FG_TRY(wait_pinned32(ctx, h_err, 1));
+    return report(ctx, name, *h_err);
 }
 
-int valprog_to_mask(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, uint8_t *mask) {
-    return run(ctx, name, prog, rows, true, ColType::I32, mask, nullptr);
+int valprog_to_rows(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, int32_t **out_rows, int64_t *n_out) {
+    const std::string base = name;
+    int32_t *o_rows = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".rows").c_str(), (size_t)std::max<int64_t>(rows, 0) + 4, &o_rows));
+    *out_rows = o_rows;
+    *n_out = 0;
+    if (prog.n_ops < 1 || prog.max_stack > kValMaxStack) return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: malformed expression program", name);
+    if (rows <= 0) return FLOCKGPU_OK;
+    if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: more than 2^31 rows", name);
+    int64_t sb = 0, se = rows;
+    SegTiles st;
+    FG_TRY(build_seg_tiles(ctx, (base + ".tiles").c_str(), &sb, &se, 1, kFlagTile, &st));   // (one segment from row 0: tile t = rows [8192 t, 8192 (t + 1)), as the kernel walks them)
+    uint32_t *flags = nullptr, *counts = nullptr, *d_err = nullptr, *h_err = nullptr;
+    uint64_t *tile_base = nullptr;
+    int64_t *h_off = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".flags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
+    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &counts));
+    FG_TRY(arena_get_t(ctx, (base + ".base").c_str(), (size_t)st.n_tiles + 1, &tile_base));
+    FG_TRY(arena_get_t(ctx, (base + ".err").c_str(), 4, &d_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".err").c_str(), 4, &h_err));
+    FG_TRY(pinned_get_t(ctx, (base + ".off").c_str(), 2, &h_off));
+    pinned_pending(reinterpret_cast<uint64_t *>(h_off), 2);   // (wait_pinned below)
+    FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 1)));
+    const unsigned grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "valprog_kernel");
+        hipLaunchKernelGGL(valprog_kernel<true>, dim3(grid), dim3(kBlock), stack_bytes(prog), ctx->stream, prog, rows, st.n_tiles, (void *)nullptr, (uint8_t *)nullptr, 0, flags, counts,
+                           d_err);
+    }
+    FG_TRY(check_launch(ctx, "valprog_kernel"));
+    pinned_pending32(h_err, 1);
+    FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 1)));
+    if (st.n_tiles <= 2048) {
+        FG_TRY(emit_flagged_rows_self(ctx, st, flags, counts, o_rows, h_off));
+    } else {
+        FG_TRY(launch_tile_scan(ctx, counts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));
+        FG_TRY(emit_flagged_rows(ctx, st, flags, counts, tile_base, o_rows));
+    }
+    FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_off), 2));
+    FG_TRY(wait_pinned32(ctx, h_err, 1));   // (published before the emit was queued: there by now)
+    FG_TRY(report(ctx, name, *h_err));
+    *n_out = h_off[1];
+    return FLOCKGPU_OK;
 }
 
 }  // namespace flockgpu

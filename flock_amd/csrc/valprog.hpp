@@ -1,24 +1,32 @@
 // Computed expressions of ProjectionExec / FilterExec in general (valprog.hip): what neither the column pass-through, q1's
 // `literal * Int32 column` kernel nor the one-pass predicate program (pred.hpp) covers -- arithmetic over columns (+ - * / %, unary -),
 // CAST / TRY_CAST between the numeric types, comparisons of computed values, CASE WHEN ... THEN ... ELSE ... END -- runs as ONE kernel
-// per expression: the tree is flattened on the host into a postfix program (passed by value), every thread walks it for its rows
-// with an operand stack in LDS (a column of (value, valid) slots per thread: no bank conflicts, no barrier), the result is a value
-// column + validity bytes (projection) or a byte mask (filter: 1 where the predicate is TRUE).  An interpreter, not a code
-// generator: ~25 instructions per operator and row, i.e. HBM-bound up to a handful of operators and issue-bound beyond -- the fast
-// paths stay in front of it.
+// per expression: the tree is flattened on the host into a postfix program (passed by value) and interpreted in the FLAG-TILE geometry
+// of the selecting kernels (scan.hpp: 8192-row tiles, a lane's 32 rows = eight 16-byte loads per Int32 column).  Round 6: a pass of
+// the program evaluates FOUR rows per lane (one 16-byte load per column operand, one scalar dispatch per operator and four rows), the top
+// of the operand stack lives in registers (LDS only holds what waits below it), an operator whose right operand is a literal takes it as
+// an immediate (no push, no pop), and division / remainder by a literal is a multiply-high by a host-made reciprocal (a 64-bit division is
+// ~150 instructions per row on gfx950).  The filter form writes the flag words and wave counts the row-emitting machinery reads
+// (no byte mask, no pass over one): profiles/r06/expr_*.
 //
-// Semantics restated from upstream DataFusion ~6 / arrow-rs 6 (the fork's expressions/*.rs are not in the
-// reference tree: assumptions, not pinned by reference-held vectors -- tests/test_plan_round5b.py checks them against the oracle's
-// twin, oracle/generic_ops.py: eval_physical_expr, and q1's reference-held projection stays on its own kernel):
-//   * both operands of a binary operator have ONE type (the planner inserts the casts); an untyped literal takes the other side's;
-//   * + - * and unary - on integers wrap at the type's width (arrow's unchecked kernels); Float64 is IEEE (no contraction: -ffp-contract=off);
-//   * integer / and % truncate towards zero; a zero divisor in a VALID row is an error for the whole call (ArrowError::DivideByZero),
-//     a NULL operand makes the row NULL before the divisor is looked at; INT_MIN / -1 wraps (arrow-rs would panic);
-//   * CAST fails the call when a valid value does not fit the target (DataFusion casts with safe = false), TRY_CAST yields NULL;
-//     Float64 -> integer truncates towards zero, NaN does not fit; integer -> Float64 rounds to nearest even;
-//   * comparisons yield NULL when an operand is NULL; AND / OR / NOT are Kleene; IS [NOT] NULL never yields NULL;
-//   * CASE evaluates every branch for every row (as the fork's CaseExpr does over the whole batch) and picks the first WHEN that is
-//     TRUE, else ELSE, else NULL.
+// Semantics restated from upstream DataFusion ~6 / arrow-rs ~8 (the fork's expressions/*.rs are not in the
+// reference tree: ASSUMPTIONS, not pinned by reference-held vectors -- tests/test_plan_round5b.py checks them against the oracle's
+// twin, oracle/generic_ops.py: eval_typed, and q1's reference-held projection stays on its own kernel):
+//   A-V1 both operands of a binary operator have ONE type (the planner inserts the casts); an untyped literal takes the other side's;
+//   A-V2 + - * and unary - on integers wrap at the type's width (arrow's unchecked kernels `add` / `subtract` / `multiply`); Float64 + - *
+//        are IEEE (no contraction: -ffp-contract=off);
+//   A-V3 / and %: arrow-rs `divide` / `modulus` = `math_checked_divide_op` (and `divide_scalar` / `modulus_scalar`, and the `simd` feature's
+//        `simd_checked_divide` the fork enables, flock/Cargo.toml:12) test `is_zero()` on the divisor of every VALID row for EVERY native
+//        type: a zero divisor -- integer 0, Float64 0.0 or -0.0 -- fails the whole call with ArrowError::DivideByZero.  (Arrow C++ /
+//        pyarrow return +-inf / NaN for floats: a difference between the two Arrows, the fork runs arrow-rs.)  A NULL operand makes the
+//        row NULL before the divisor is looked at.  Integer / and % truncate towards zero;
+//   A-V4 INT_MIN / -1 and INT_MIN % -1 (Int32 and Int64): Rust's `/` and `%` panic ("attempt to divide with overflow"), and the fork's
+//        release profile aborts on panic (Cargo.toml:27): the invocation dies.  Here: the call fails with FLOCKGPU_ERR_INVALID;
+//   A-V5 CAST fails the call when a valid value does not fit the target (DataFusion casts with safe = false), TRY_CAST yields NULL;
+//        Float64 -> integer truncates towards zero, NaN does not fit; integer -> Float64 rounds to nearest even;
+//   A-V6 comparisons yield NULL when an operand is NULL; AND / OR / NOT are Kleene; IS [NOT] NULL never yields NULL;
+//   A-V7 CASE evaluates every branch for every row (as the fork's CaseExpr does over the whole batch) and picks the first WHEN that is
+//        TRUE, else ELSE, else NULL.
 #pragma once
 #include "relops.hpp"
 
@@ -39,8 +47,9 @@ enum class ValOpKind : uint8_t {
     Select                                        // pops THEN, WHEN, ELSE (pushed in the order ELSE, WHEN, THEN)
 };
 struct ValOp {
-    uint8_t kind, type, to, arg;   // ValOpKind; operand ValType; Cast target; Col / Const index
-};
+    uint8_t kind, type, to, arg;   // ValOpKind; operand ValType; Cast target -- or, on a binary operator, kValImm: the right operand is consts[arg]
+};                                 // (Div / Mod with kValImm: consts[arg] = divisor, [arg + 1] = reciprocal, [arg + 2] = shift | add << 8: ValBuilder::fuse_immediate)
+constexpr uint8_t kValImm = 0x80;
 struct ValCol {
     const void *values;
     const uint8_t *valid;
@@ -75,18 +84,56 @@ struct ValBuilder {
     // pops: operands the operator takes off the stack; every operator pushes one result
     bool push(ValOpKind k, ValType type, int pops, int arg = 0, ValType to = ValType::NONE) {
         if (p.n_ops >= kValMaxOps || arg < 0) return false;
+        if (pops == 2 && fuse_immediate(k, type)) return true;
         p.ops[p.n_ops++] = ValOp{(uint8_t)k, (uint8_t)type, (uint8_t)to, (uint8_t)arg};
         depth += 1 - pops;
         if (depth > p.max_stack) p.max_stack = depth;
         return depth >= 1 && depth <= kValMaxStack;
     }
+    // A binary operator whose RIGHT operand was just pushed as a literal takes it as an immediate: the Const push goes, the operator
+    // reads consts[arg].  Division / remainder by a non-zero integer literal get the reciprocal of |divisor| next to it (Granlund /
+    // Montgomery, round-up variant, 64-bit: q = mulhi(n, m) >> s, or the 65-bit multiplier form ((n - hi) >> 1) + hi) >> s).
+    bool fuse_immediate(ValOpKind k, ValType type) {
+        if (p.n_ops < 1 || p.ops[p.n_ops - 1].kind != (uint8_t)ValOpKind::Const) return false;
+        const bool arith = k == ValOpKind::Add || k == ValOpKind::Sub || k == ValOpKind::Mul || k == ValOpKind::Div || k == ValOpKind::Mod;
+        const bool cmp = k == ValOpKind::Eq || k == ValOpKind::Ne || k == ValOpKind::Lt || k == ValOpKind::Le || k == ValOpKind::Gt || k == ValOpKind::Ge;
+        if (!arith && !cmp) return false;
+        int arg = p.ops[p.n_ops - 1].arg;
+        const uint64_t c = p.consts[arg];
+        if ((k == ValOpKind::Div || k == ValOpKind::Mod) && type != ValType::F64) {
+            if (c == 0) return false;   // (a zero divisor: the generic operator reports it -- for the valid rows only)
+            uint64_t d = c;
+            if (type != ValType::U64 && (int64_t)c < 0) d = 0 - c;   // |divisor| (2^63 for INT64_MIN)
+            uint64_t magic = 0, shift = 63, add = 0;
+            while (!((d >> shift) & 1u)) --shift;   // floor(log2 d)
+            if (d & (d - 1)) {
+                const unsigned __int128 two = (unsigned __int128)1 << (64 + shift);
+                unsigned __int128 pm = two / d;
+                const unsigned __int128 rem = two - pm * d;
+                if ((unsigned __int128)d - rem >= ((unsigned __int128)1 << shift)) {   // one more bit of multiplier
+                    pm = pm * 2 + (rem * 2 >= d ? 1 : 0);
+                    add = 1;
+                }
+                magic = (uint64_t)(pm + 1);
+            }
+            if (p.n_consts + 3 > kValMaxConsts) return false;
+            arg = p.n_consts;
+            p.consts[p.n_consts++] = c;
+            p.consts[p.n_consts++] = magic;
+            p.consts[p.n_consts++] = shift | (add << 8);
+        }
+        p.ops[p.n_ops - 1] = ValOp{(uint8_t)k, (uint8_t)type, kValImm, (uint8_t)arg};
+        depth -= 1;   // (the literal's push is taken back; the operator replaces its left operand in place)
+        return true;
+    }
 };
 
 // out_type: the value column's type (I32 / I64 / U64 / F64).  out_valid (may be null when the caller knows the result holds no NULL:
 // then a NULL result is an error) receives one byte per row.  Error codes come back as FLOCKGPU_ERR_INVALID with the reason
-// (division by zero / a value that does not fit its CAST).  One host wait.
+// (division by zero / INT_MIN / -1 / a value that does not fit its CAST).  One host wait.
 int valprog_to_column(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, ColType out_type, void *out_values, uint8_t *out_valid);
-// mask[i] = 1 where the BOOL result is TRUE (FALSE and NULL: 0).  One host wait (the error word).
-int valprog_to_mask(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, uint8_t *mask);
+// FilterExec: the rows where the BOOL result is TRUE (FALSE and NULL: dropped), in order -- flag words + wave counts from the evaluating
+// kernel itself, then the scan / emit of pred_to_rows.  One host wait (row count + error word).
+int valprog_to_rows(flockgpu_ctx *ctx, const char *name, const ValProgram &prog, int64_t rows, int32_t **out_rows, int64_t *n_out);
 
 }  // namespace flockgpu

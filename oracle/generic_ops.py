@@ -209,9 +209,12 @@ def _cast(v, ty, safe):
 
 def eval_typed(e: dict, row: dict, types: dict, want=None):
     """eval_physical_expr with the column types at hand: + - * and unary - wrap at the operand type's width, integer / and % truncate
-    towards zero and fail the call on a zero divisor in a row whose operands are not NULL, Float64 arithmetic is numpy's (IEEE: x / 0.0 is an
-    infinity or a NaN), CAST is checked, CASE picks the first WHEN that is TRUE (every branch is evaluated for every row, as the fork's
-    CaseExpr evaluates them over the whole batch).  `want`: the type an untyped literal takes."""
+    towards zero; a zero divisor in a row whose operands are not NULL fails the call FOR EVERY TYPE -- Float64 0.0 / -0.0 included: arrow-rs's
+    `divide` / `modulus` (math_checked_divide_op, divide_scalar, the simd feature's simd_checked_divide) test is_zero() on every native type and
+    return ArrowError::DivideByZero (Arrow C++ / pyarrow answer +-inf / NaN there: the two Arrows differ, the fork runs arrow-rs); INT_MIN / -1
+    and INT_MIN % -1 fail the call, too (Rust's `/` / `%` panic and the fork's release profile aborts on panic).  Other Float64 arithmetic is
+    numpy's (IEEE), CAST is checked, CASE picks the first WHEN that is TRUE (every branch is evaluated for every row, as the fork's CaseExpr
+    evaluates them over the whole batch).  `want`: the type an untyped literal takes.  (Assumptions A-V1..7 of flock_amd/csrc/valprog.hpp.)"""
     import numpy as np
     t = e["physical_expr"]
     if t in ("column", "literal"):
@@ -269,11 +272,15 @@ def eval_typed(e: dict, row: dict, types: dict, want=None):
             return {"Eq": a == b, "NotEq": a != b, "Lt": a < b, "LtEq": a <= b, "Gt": a > b, "GtEq": a >= b}[op]
         if ty == "Float64" or isinstance(a, float) or isinstance(b, float):
             x, y = np.float64(a), np.float64(b)
+            if op in ("Divide", "Modulo") and y == 0:
+                raise ExprError("division by zero")
             with np.errstate(all="ignore"):
                 return float({"Plus": x + y, "Minus": x - y, "Multiply": x * y, "Divide": x / y, "Modulo": np.fmod(x, y)}[op])
         if op in ("Divide", "Modulo"):
             if b == 0:
                 raise ExprError("division by zero")
+            if b == -1 and ty in _INT_RANGE and ty != "UInt64" and a == _INT_RANGE[ty][0]:
+                raise ExprError("INT_MIN / -1 overflows")
             if op == "Modulo":
                 return _wrap(_trunc_mod(a, b), ty)
             q = abs(a) // abs(b)

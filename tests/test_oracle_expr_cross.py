@@ -32,7 +32,7 @@ def table(n, r):
     nul = lambda xs: [None if r.random() < 0.2 else x for x in xs]
     return {"i": nul([int(x) for x in r.integers(-2**31, 2**31 - 1, n)]), "j": nul([int(x) for x in r.integers(-50, 50, n)]),
             "l": nul([int(x) for x in r.integers(-2**63, 2**63 - 1, n)]), "m": nul([int(x) for x in r.integers(-9, 9, n)]),
-            "f": nul([float(x) for x in r.normal(0, 1e3, n)]), "h": nul([float(x) for x in r.choice([0.0, -0.0, 1.5, -2.25, 1e300, np.inf], n)])}
+            "f": nul([float(x) for x in r.normal(0, 1e3, n)]), "h": nul([float(x) for x in r.choice([0.25, -0.5, 1.5, -2.25, 1e300, np.inf], n)])}   # (no zeroes: a Float64 zero divisor is an error, below)
 
 
 def rand_value(r, ty, depth):
@@ -98,18 +98,20 @@ def to_arrow(e, t):
         return pc.case_when(pc.make_struct(*[pc.fill_null(full(c), False) for c in conds]), *args)     # a NULL WHEN does not match
     a, b = to_arrow(e["left"], t), to_arrow(e["right"], t)
     op = e["op"]
-    if op == "Divide" and pa.types.is_integer(a.type):
-        bb = b if isinstance(b, (pa.Array, pa.ChunkedArray)) else pa.array([b.as_py()] * len(next(iter(t.values()))), b.type)
-        aa = a if isinstance(a, (pa.Array, pa.ChunkedArray)) else pa.array([a.as_py()] * len(bb), a.type)
+    if op == "Divide":
+        n = len(next(iter(t.values())))
+        bb = b if isinstance(b, (pa.Array, pa.ChunkedArray)) else pa.array([b.as_py()] * n, b.type)
+        aa = a if isinstance(a, (pa.Array, pa.ChunkedArray)) else pa.array([a.as_py()] * n, a.type)
         both = pc.and_(pc.is_valid(aa), pc.is_valid(bb))
+        # a zero divisor in a valid row fails the call for EVERY type (arrow-rs: math_checked_divide_op; Arrow C++ would answer +-inf / NaN for
+        # floats -- the one place the two Arrows differ here), and so does INT_MIN / -1 (a panic in arrow-rs, an abort of the fork's release build)
         if pc.any(pc.and_(both, pc.equal(pc.fill_null(bb, 1), 0))).as_py():
             raise DivideByZero()
-        # INT_MIN / -1 overflows in Arrow C++'s kernel as it would in arrow-rs (a panic there); eval_typed wraps: keep such rows out of the comparison
-        lo = pa.scalar(-2**31 if a.type == pa.int32() else -2**63, a.type)
-        overflow = pc.and_(pc.equal(pc.fill_null(aa, 0), lo), pc.equal(pc.fill_null(bb, 1), -1))
-        safe_b = pc.if_else(pc.or_(overflow, pc.equal(pc.fill_null(bb, 1), 0)), pa.scalar(1, b.type), bb)
-        q = pc.divide(aa, safe_b)
-        return pc.if_else(overflow, pc.if_else(both, aa, pa.scalar(None, a.type)), q)      # (wraps back to INT_MIN)
+        if pa.types.is_integer(a.type):
+            lo = pa.scalar(-2**31 if a.type == pa.int32() else -2**63, a.type)
+            if pc.any(pc.and_(both, pc.and_(pc.equal(pc.fill_null(aa, 0), lo), pc.equal(pc.fill_null(bb, 1), -1)))).as_py():
+                raise DivideByZero()
+        return pc.divide(aa, bb)
     fn = {"Plus": pc.add, "Minus": pc.subtract, "Multiply": pc.multiply, "Divide": pc.divide, "Eq": pc.equal, "NotEq": pc.not_equal, "Lt": pc.less,
           "LtEq": pc.less_equal, "Gt": pc.greater, "GtEq": pc.greater_equal, "And": pc.and_kleene, "Or": pc.or_kleene}[op]
     return fn(a, b)
@@ -145,3 +147,23 @@ def test_eval_typed_equals_arrow_compute(seed):
         assert not bad, (seed, trial, e, rows[bad[0]], got[bad[0]], want[bad[0]])
         checked += 1
     assert checked >= 15
+
+
+def test_a_float64_zero_divisor_fails_the_call_where_arrow_cpp_answers_infinity():
+    """Assumption A-V3 of valprog.hpp, stated as a test: arrow-rs's divide / modulus check is_zero() for floats as well (ArrowError::DivideByZero),
+    Arrow C++ follows IEEE.  The oracle (and the HIP evaluator, tests/test_plan_round5b.py) take arrow-rs's side; a NULL divisor or dividend
+    makes the row NULL before the divisor is looked at."""
+    e = binary(col("f"), "Divide", col("h"))
+    for zero in (0.0, -0.0):
+        with pytest.raises(g.ExprError):
+            g.eval_typed(e, {"f": 1.5, "h": zero}, TYPES)
+        with pytest.raises(g.ExprError):
+            g.eval_typed(binary(col("f"), "Modulo", col("h")), {"f": 1.5, "h": zero}, TYPES)
+        assert g.eval_typed(e, {"f": None, "h": zero}, TYPES) is None
+        assert pc.divide(pa.array([1.5]), pa.array([zero])).to_pylist()[0] in (np.inf, -np.inf)
+    assert g.eval_typed(e, {"f": 3.0, "h": None}, TYPES) is None
+    with pytest.raises(g.ExprError):
+        g.eval_typed(binary(col("i"), "Divide", col("j")), {"i": -2**31, "j": -1}, TYPES)
+    with pytest.raises(g.ExprError):
+        g.eval_typed(binary(col("l"), "Modulo", col("m")), {"l": -2**63, "m": -1}, TYPES)
+    assert g.eval_typed(binary(col("i"), "Divide", col("j")), {"i": -2**31 + 1, "j": -1}, TYPES) == 2**31 - 1

@@ -106,11 +106,15 @@ def test_oracle_typed_arithmetic_by_hand():
     row = {"i": 2**31 - 1, "j": -2**31, "l": -7, "f": 2.5, "s": None, "u": 2**64 - 1}
     ev = lambda e: g.eval_typed(e, row, TYPES)
     assert ev(binary(col("i"), "Plus", lit("Int32", 1))) == -2**31                      # wraps at the operand's width
-    assert ev(binary(col("j"), "Divide", lit("Int32", -1))) == -2**31                   # INT_MIN / -1 wraps
+    with pytest.raises(g.ExprError):
+        ev(binary(col("j"), "Divide", lit("Int32", -1)))                                    # INT_MIN / -1: the reference's arithmetic panics (valprog.hpp A-V4)
     assert ev(binary(cast(col("i"), "Int64"), "Plus", lit("Int64", 1))) == 2**31        # ... and does not after the widening cast
     assert ev(binary(col("l"), "Divide", lit("Int64", 2))) == -3 and ev(binary(col("l"), "Modulo", lit("Int64", 2))) == -1   # truncation
     assert ev(binary(col("u"), "Plus", lit("UInt64", 2))) == 1
-    assert ev(binary(col("f"), "Divide", lit("Float64", 0.0))) == math.inf and math.isnan(ev(binary(lit("Float64", 0.0), "Divide", lit("Float64", 0.0))))
+    for zero in (0.0, -0.0):   # a Float64 zero divisor is the same error (valprog.hpp A-V3: arrow-rs tests is_zero() for every native type)
+        with pytest.raises(g.ExprError):
+            ev(binary(col("f"), "Divide", lit("Float64", zero)))
+    assert ev(binary(col("f"), "Divide", lit("Float64", math.inf))) == 0.0 and math.isnan(ev(binary(lit("Float64", math.inf), "Divide", lit("Float64", math.inf))))
     assert ev(binary(col("f"), "Modulo", lit("Float64", -2.0))) == 0.5
     with pytest.raises(g.ExprError):
         ev(binary(col("l"), "Divide", lit("Int64", 0)))
@@ -199,12 +203,34 @@ def test_a_zero_divisor_or_an_unfit_cast_fails_the_call_and_try_cast_does_not(gp
     # the same divisor with its zero (and only its zero) made NULL: the row is NULL, the call stands
     t["i"][1234] = None
     e = binary(col("j"), "Divide", col("i"))
-    exprs = [(e, "q"), (try_cast(col("l"), "Int32"), "n"), (binary(col("f"), "Divide", lit("Float64", 0.0)), "inf")]
+    exprs = [(e, "q"), (try_cast(col("l"), "Int32"), "n"), (binary(col("f"), "Divide", lit("Float64", 4.0)), "quarter")]
     if all(v != 0 for v in t["i"] if v is not None):
         assert norm(pyrows(run(projection(exprs)))) == norm(g.rows(g.project_typed(t, exprs, TYPES)))
     else:   # the generator drew another zero: the error it is
         with pytest.raises(FlockGpuError):
             run(projection(exprs))
+    # Float64: a zero divisor -- 0.0 or -0.0 -- is the same error (valprog.hpp A-V3: arrow-rs tests is_zero() for floats, too); and INT_MIN / -1
+    # fails the call (A-V4: the reference's arithmetic panics there)
+    for bad, what in ((binary(col("f"), "Divide", lit("Float64", 0.0)), "division by zero"), (binary(col("f"), "Modulo", lit("Float64", -0.0)), "division by zero"),
+                      (binary(cast(col("i"), "Float64"), "Divide", col("f")), "division by zero")):
+        if bad["right"]["physical_expr"] == "column":
+            t["f"][10], t["i"][10] = 0.0, 5
+        with pytest.raises(FlockGpuError) as e2:
+            run(projection([(bad, "x")]))
+        assert e2.value.code == _ffi.ERR_INVALID and what in str(e2.value), str(e2.value)
+    t["f"][10] = 1.0
+    t["j"][3], t["l"][4] = -2**31, -2**63
+    t["i"] = [-1 if v is not None else None for v in t["i"]]            # a column of -1 (and NULLs) as the divisor of the column / column case
+    for bad in (binary(col("j"), "Divide", lit("Int32", -1)), binary(col("l"), "Modulo", lit("Int64", -1)), binary(col("j"), "Divide", col("i")),
+                binary(col("l"), "Modulo", cast(col("i"), "Int64"))):
+        t["i"][3] = t["i"][4] = -1
+        with pytest.raises(FlockGpuError) as e3:
+            run(projection([(bad, "x")]))
+        assert e3.value.code == _ffi.ERR_INVALID and "overflows" in str(e3.value), str(e3.value)
+    t["j"][3], t["l"][4] = -2**31 + 1, -2**63 + 1                         # one above the minimum: -x, no error
+    exprs = [(binary(col("j"), "Divide", lit("Int32", -1)), "a"), (binary(col("l"), "Divide", cast(col("i"), "Int64")), "b"), (binary(col("l"), "Modulo", lit("Int64", -1)), "c")]
+    assert norm(pyrows(run(projection(exprs)))) == norm(g.rows(g.project_typed(t, exprs, TYPES)))
+    t = table(5000, r, null_p=0.3)
     # in a filter: rows an error sits in fail the call even when another conjunct would have dropped them (the whole batch is evaluated)
     with pytest.raises(FlockGpuError):
         run({"execution_plan": "filter_exec", "predicate": binary(binary(col("l"), "Divide", lit("Int64", 0)), "Gt", lit("Int64", 1)), "input": scan()})

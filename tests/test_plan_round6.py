@@ -75,3 +75,47 @@ def test_dense_group_by_with_four_accumulators(gpu, key):
     assert "dense_group_kernel" in ran, sorted(ran)
     want = g.hash_aggregate_exec(t, [key], [("%s(%s)" % (fn.upper(), c or "UInt8(1)"), fn, c) for fn, c, _ in aggs])
     assert sorted(pyrows(rb)) == sorted(g.rows(want))
+
+
+@pytest.mark.gpu
+def test_division_and_remainder_by_literals_at_the_edges(gpu):
+    """Round 6: `x / c` and `x % c` with a literal c run as a multiply-high by a host-made reciprocal (valprog.hpp, ValBuilder::fuse_immediate).
+    Every divisor class -- powers of two, the 64- and 65-bit multiplier forms, negative divisors, INT_MIN as the divisor, UInt64 divisors above
+    2^63 -- over dividends at the edges of their types and around multiples of the divisor, against the oracle's truncating division."""
+    from flock_amd.runtime import ExecutionContext, collect
+    from test_plan_round5b import projection
+    r = np.random.default_rng(64)
+    n = 4096
+    t = table(n, r, null_p=0.1)
+    div32 = [1, 2, 3, 7, -7, 10, 100, 123, 641, 65_536, 65_537, 2**31 - 1, -2**31, -3]
+    div64 = [1, 2, 3, 7, -7, 10, 1000, 2**32, 2**32 + 1, 2**33 + 9, 2**62, 2**62 + 1, 2**63 - 1, -2**63, -1_000_003, 6_700_417]
+    divu = [1, 2, 3, 10, 2**32 + 1, 2**63, 2**63 + 5, 2**64 - 1, 2**64 - 59]
+    edge32 = [0, 1, -1, 2**31 - 1, -2**31 + 1, -2**31, 65_535, 65_536, -65_537]
+    edge64 = [0, 1, -1, 2**63 - 1, -2**63 + 1, -2**63, 2**32, -2**32 - 1, 2**62, 2**62 + 1]
+    edgeu = [0, 1, 2**63 - 1, 2**63, 2**63 + 5, 2**64 - 1, 2**64 - 60, 2**32]
+    for k, d in enumerate(div32):
+        for m in (-2, -1, 0, 1, 2, 1000):
+            edge32.append(max(-2**31 + 1, min(2**31 - 1, m * d + int(r.integers(-1, 2)))))
+    for k, d in enumerate(div64):
+        for m in (-3, -1, 0, 1, 2, 77):
+            edge64.append(max(-2**63 + 1, min(2**63 - 1, m * d + int(r.integers(-1, 2)))))
+    t["j"][:len(edge32)] = edge32
+    t["l"][:len(edge64)] = edge64
+    t["u"][:len(edgeu)] = edgeu
+    exprs = []
+    for d in div32:
+        if d != -1:
+            exprs += [(binary(col("j"), "Divide", lit("Int32", d)), "q32_%d" % d), (binary(col("j"), "Modulo", lit("Int32", d)), "r32_%d" % d)]
+    for d in div64:
+        exprs += [(binary(col("l"), "Divide", lit("Int64", d)), "q64_%d" % d), (binary(col("l"), "Modulo", lit("Int64", d)), "r64_%d" % d)]
+    for d in divu:
+        exprs += [(binary(col("u"), "Divide", lit("UInt64", d)), "qu_%d" % d), (binary(col("u"), "Modulo", lit("UInt64", d)), "ru_%d" % d)]
+    # -2^31 / -2^31 and -2^63 / -2^63 are 1, no overflow; only a divisor of -1 overflows (tests/test_plan_round5b.py)
+    for lo in range(0, len(exprs), 6):   # (a projection per six expressions: every one its own program)
+        part = exprs[lo:lo + 6]
+        ctx = ExecutionContext([projection(part)], gpu=gpu)
+        try:
+            rb = collect(ctx, [[batches(t, n)]])[0][0]
+        finally:
+            ctx.close()
+        assert norm(pyrows(rb)) == norm(g.rows(g.project_typed(t, part, TYPES))), [nm for _, nm in part]
