@@ -1,10 +1,13 @@
 // The general expression evaluator of the plan layer: a postfix program per expression, interpreted per row (valprog.hpp).
+#include <type_traits>
+
 #include "valprog.hpp"
 
 using namespace flockgpu;
 
 namespace {
 
+constexpr int kValGroups = 2;   // 16-byte groups of rows per pass of the program (see valprog_kernel; 1 / 2 / 4 measured: profiles/r06/expr_groups_ab.txt)
 constexpr uint32_t kErrDivZero = 1u, kErrCast = 2u, kErrNull = 4u, kErrOverflow = 8u;
 
 __device__ __forceinline__ double as_f64(uint64_t b) { return __longlong_as_double((long long)b); }
@@ -130,6 +133,38 @@ __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, 
     }
 }
 
+// Operator kind and operand type are the same for every lane and every row of a pass: the interpreter branches on them ONCE per operator and
+// pass (scalar branches) into code in which both are compile-time constants -- the per-value functions above then fold to the few
+// instructions of the one case (a dispatch per VALUE made the kernel issue-bound: 0.39 ms for `price * 2 + 1` over 9.2e7 rows).
+template <uint8_t V> using U8 = std::integral_constant<uint8_t, V>;
+template <class F> __device__ __forceinline__ void with_type(uint8_t t, F &&f) {
+    switch (t) {
+        case (uint8_t)ValType::I32: f(U8<(uint8_t)ValType::I32>{}); break;
+        case (uint8_t)ValType::I64: f(U8<(uint8_t)ValType::I64>{}); break;
+        case (uint8_t)ValType::U64: f(U8<(uint8_t)ValType::U64>{}); break;
+        default: f(U8<(uint8_t)ValType::F64>{}); break;
+    }
+}
+template <class F> __device__ __forceinline__ void with_arith(uint8_t k, F &&f) {
+    switch ((ValOpKind)k) {
+        case ValOpKind::Add: f(U8<(uint8_t)ValOpKind::Add>{}); break;
+        case ValOpKind::Sub: f(U8<(uint8_t)ValOpKind::Sub>{}); break;
+        case ValOpKind::Mul: f(U8<(uint8_t)ValOpKind::Mul>{}); break;
+        case ValOpKind::Div: f(U8<(uint8_t)ValOpKind::Div>{}); break;
+        default: f(U8<(uint8_t)ValOpKind::Mod>{}); break;
+    }
+}
+template <class F> __device__ __forceinline__ void with_cmp(uint8_t k, F &&f) {
+    switch ((ValOpKind)k) {
+        case ValOpKind::Eq: f(U8<(uint8_t)ValOpKind::Eq>{}); break;
+        case ValOpKind::Ne: f(U8<(uint8_t)ValOpKind::Ne>{}); break;
+        case ValOpKind::Lt: f(U8<(uint8_t)ValOpKind::Lt>{}); break;
+        case ValOpKind::Le: f(U8<(uint8_t)ValOpKind::Le>{}); break;
+        case ValOpKind::Gt: f(U8<(uint8_t)ValOpKind::Gt>{}); break;
+        default: f(U8<(uint8_t)ValOpKind::Ge>{}); break;
+    }
+}
+
 // One pass of the program over FOUR consecutive rows per lane.  Values on the stack: 4 x 64 bits + 4 validity bits; the top of the stack in
 // registers (tv / tok), what waits below it in the lane's own columns of `s_v` / `s_ok` (no bank conflicts, no barrier).  r0: the lane's
 // first row; rows at or beyond n load nothing and come out NULL.
@@ -172,38 +207,46 @@ __device__ __forceinline__ Vec4 load_col4(const ValCol &c, int64_t r0, int64_t n
     return x;
 }
 
-template <bool kMask>
+// kG: 16-byte groups per pass -- a pass of the program evaluates 4 kG rows per lane (kG = 4: a lane has four loads per column operand in
+// flight and one scalar dispatch per operator and sixteen rows; kG = 1 for programs whose operand stack would not fit the LDS otherwise).
+template <bool kMask, int kG>
 __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n, int32_t n_tiles, void *__restrict__ out_values, uint8_t *__restrict__ out_valid,
                                                          int32_t out_type, uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts, uint32_t *err) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_dyn[];   // [max_stack - 1][4][kBlock] values, then [max_stack - 1][kBlock] validity nibbles
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_dyn[];   // [max_stack - 1][kG][4][kBlock] values, then [max_stack - 1][kG][kBlock] validity nibbles
     const int t = threadIdx.x;
     const int below = p.max_stack > 1 ? p.max_stack - 1 : 0;
     uint64_t *s_v = s_dyn;
-    uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_dyn + (size_t)below * 4 * kBlock);
+    uint8_t *s_ok = reinterpret_cast<uint8_t *>(s_dyn + (size_t)below * kG * 4 * kBlock);
     uint32_t bad = 0;
     for (int32_t tile = (int32_t)blockIdx.x; tile < n_tiles; tile += (int32_t)gridDim.x) {
         const int64_t tile_begin = (int64_t)tile * kFlagTile;
         const bool whole = tile_begin + kFlagTile <= n;   // (block-uniform)
         uint32_t flags = 0;
 #pragma unroll 1
-        for (int it = 0; it < kFlagIters; ++it) {
-            const int64_t r0 = tile_begin + flag_rel0() + it * 256;
-            Vec4 top;
-            top.ok = 0;
-            top.v[0] = top.v[1] = top.v[2] = top.v[3] = 0;
+        for (int it0 = 0; it0 < kFlagIters; it0 += kG) {
+            const int64_t r0 = tile_begin + flag_rel0() + it0 * 256;   // group g: rows r0 + 256 g .. + 3
+            Vec4 top[kG];
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                top[g].ok = 0;
+                top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = 0;
+            }
             int sp = 0;   // operands on the stack, the top one in `top`
             auto spill = [&]() {   // a push over a live top: it goes to its slot below
                 if (sp > 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s_v[((size_t)(sp - 1) * 4 + j) * kBlock + t] = top.v[j];
-                    s_ok[(size_t)(sp - 1) * kBlock + t] = (uint8_t)top.ok;
+                    for (int g = 0; g < kG; ++g) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s_v[(((size_t)(sp - 1) * kG + g) * 4 + j) * kBlock + t] = top[g].v[j];
+                        s_ok[((size_t)(sp - 1) * kG + g) * kBlock + t] = (uint8_t)top[g].ok;
+                    }
                 }
             };
-            auto second = [&]() -> Vec4 {   // the operand below the top
+            auto second = [&](int g) -> Vec4 {   // group g of the operand below the top
                 Vec4 a;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a.v[j] = s_v[((size_t)(sp - 2) * 4 + j) * kBlock + t];
-                a.ok = s_ok[(size_t)(sp - 2) * kBlock + t];
+                for (int j = 0; j < 4; ++j) a.v[j] = s_v[(((size_t)(sp - 2) * kG + g) * 4 + j) * kBlock + t];
+                a.ok = s_ok[((size_t)(sp - 2) * kG + g) * kBlock + t];
                 return a;
             };
 #pragma unroll 1
@@ -213,149 +256,206 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                 switch ((ValOpKind)op.kind) {
                     case ValOpKind::Col:
                         spill();
-                        top = load_col4(p.cols[op.arg], r0, n, whole);
+#pragma unroll
+                        for (int g = 0; g < kG; ++g) top[g] = load_col4(p.cols[op.arg], r0 + g * 256, n, whole);
                         ++sp;
                         break;
                     case ValOpKind::Const:
                         spill();
-                        top.v[0] = top.v[1] = top.v[2] = top.v[3] = p.consts[op.arg];
-                        top.ok = 15u;
+#pragma unroll
+                        for (int g = 0; g < kG; ++g) {
+                            top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = p.consts[op.arg];
+                            top[g].ok = 15u;
+                        }
                         ++sp;
                         break;
                     case ValOpKind::Null:
                         spill();
-                        top.v[0] = top.v[1] = top.v[2] = top.v[3] = 0;
-                        top.ok = 0;
+#pragma unroll
+                        for (int g = 0; g < kG; ++g) {
+                            top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = 0;
+                            top[g].ok = 0;
+                        }
                         ++sp;
                         break;
                     case ValOpKind::Add: case ValOpKind::Sub: case ValOpKind::Mul: case ValOpKind::Div: case ValOpKind::Mod: {
-                        if (imm) {   // left = top, right = the literal
-                            const uint64_t c = p.consts[op.arg];
-                            const bool by_recip = ((ValOpKind)op.kind == ValOpKind::Div || (ValOpKind)op.kind == ValOpKind::Mod) && op.type != (uint8_t)ValType::F64;
-                            const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
-                            const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
+                        with_type(op.type, [&](auto T) {
+                            with_arith(op.kind, [&](auto K) {
+                                constexpr uint8_t ty = decltype(T)::value, kd = decltype(K)::value;
+                                if (imm) {   // left = top, right = the literal
+                                    const uint64_t c = p.consts[op.arg];
+                                    constexpr bool by_recip = (kd == (uint8_t)ValOpKind::Div || kd == (uint8_t)ValOpKind::Mod) && ty != (uint8_t)ValType::F64;
+                                    const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
+                                    const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if ((top.ok >> j) & 1u) top.v[j] = by_recip ? div_by_const(op.kind, op.type, top.v[j], c, magic, sh, &bad) : arith(op.kind, op.type, top.v[j], c, &bad);
-                        } else {
-                            const Vec4 a = second();
-                            const uint32_t ok = a.ok & top.ok;
+                                    for (int g = 0; g < kG; ++g)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) top.v[j] = (ok >> j) & 1u ? arith(op.kind, op.type, a.v[j], top.v[j], &bad) : 0;
-                            top.ok = ok;
-                            --sp;
-                        }
+                                        for (int j = 0; j < 4; ++j)
+                                            if ((top[g].ok >> j) & 1u) top[g].v[j] = by_recip ? div_by_const(kd, ty, top[g].v[j], c, magic, sh, &bad) : arith(kd, ty, top[g].v[j], c, &bad);
+                                } else {
+#pragma unroll
+                                    for (int g = 0; g < kG; ++g) {
+                                        const Vec4 a = second(g);
+                                        const uint32_t ok = a.ok & top[g].ok;
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = (ok >> j) & 1u ? arith(kd, ty, a.v[j], top[g].v[j], &bad) : 0;
+                                        top[g].ok = ok;
+                                    }
+                                }
+                            });
+                        });
+                        if (!imm) --sp;
                         break;
                     }
                     case ValOpKind::Neg:
+                        with_type(op.type, [&](auto T) {
+                            constexpr uint8_t ty = decltype(T)::value;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint64_t a = top.v[j];
-                            top.v[j] = op.type == (uint8_t)ValType::F64 ? ((top.ok >> j) & 1u ? f64_bits(-as_f64(a)) : 0)
-                                       : op.type == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(0u - (uint32_t)a) : 0 - a;
-                        }
-                        break;
-                    case ValOpKind::Cast: case ValOpKind::TryCast:
+                            for (int g = 0; g < kG; ++g)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if ((top.ok >> j) & 1u) {
-                                uint64_t r = 0;
-                                if (cast_value(top.v[j], op.type, op.to, &r)) {
-                                    top.v[j] = r;
-                                } else {
-                                    top.v[j] = 0;
-                                    top.ok &= ~(1u << j);
-                                    if ((ValOpKind)op.kind == ValOpKind::Cast) bad |= kErrCast;
+                                for (int j = 0; j < 4; ++j) {
+                                    const uint64_t a = top[g].v[j];
+                                    top[g].v[j] = ty == (uint8_t)ValType::F64 ? ((top[g].ok >> j) & 1u ? f64_bits(-as_f64(a)) : 0)
+                                                  : ty == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)(int32_t)(0u - (uint32_t)a) : 0 - a;
                                 }
-                            }
+                        });
                         break;
+                    case ValOpKind::Cast: case ValOpKind::TryCast: {
+                        const bool checked = (ValOpKind)op.kind == ValOpKind::Cast;
+                        with_type(op.type, [&](auto F) {
+                            with_type(op.to, [&](auto T) {
+                                constexpr uint8_t from = decltype(F)::value, to = decltype(T)::value;
+#pragma unroll
+                                for (int g = 0; g < kG; ++g)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if ((top[g].ok >> j) & 1u) {
+                                            uint64_t r = 0;
+                                            if (cast_value(top[g].v[j], from, to, &r)) {
+                                                top[g].v[j] = r;
+                                            } else {
+                                                top[g].v[j] = 0;
+                                                top[g].ok &= ~(1u << j);
+                                                if (checked) bad |= kErrCast;
+                                            }
+                                        }
+                            });
+                        });
+                        break;
+                    }
                     case ValOpKind::Eq: case ValOpKind::Ne: case ValOpKind::Lt: case ValOpKind::Le: case ValOpKind::Gt: case ValOpKind::Ge: {
-                        if (imm) {
-                            const uint64_t c = p.consts[op.arg];
+                        with_type(op.type, [&](auto T) {
+                            with_cmp(op.kind, [&](auto K) {
+                                constexpr uint8_t ty = decltype(T)::value, kd = decltype(K)::value;
+                                if (imm) {
+                                    const uint64_t c = p.consts[op.arg];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) top.v[j] = ((top.ok >> j) & 1u) && compare(op.kind, op.type, top.v[j], c) ? 1 : 0;
-                        } else {
-                            const Vec4 a = second();
-                            const uint32_t ok = a.ok & top.ok;
+                                    for (int g = 0; g < kG; ++g)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) top.v[j] = ((ok >> j) & 1u) && compare(op.kind, op.type, a.v[j], top.v[j]) ? 1 : 0;
-                            top.ok = ok;
-                            --sp;
-                        }
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = ((top[g].ok >> j) & 1u) && compare(kd, ty, top[g].v[j], c) ? 1 : 0;
+                                } else {
+#pragma unroll
+                                    for (int g = 0; g < kG; ++g) {
+                                        const Vec4 a = second(g);
+                                        const uint32_t ok = a.ok & top[g].ok;
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = ((ok >> j) & 1u) && compare(kd, ty, a.v[j], top[g].v[j]) ? 1 : 0;
+                                        top[g].ok = ok;
+                                    }
+                                }
+                            });
+                        });
+                        if (!imm) --sp;
                         break;
                     }
                     case ValOpKind::And: case ValOpKind::Or: {
-                        const Vec4 a = second();
-                        uint32_t ok_out = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool oa = (a.ok >> j) & 1u, ob = (top.ok >> j) & 1u, va = oa && a.v[j], vb = ob && top.v[j];
-                            bool v, ok;
-                            if ((ValOpKind)op.kind == ValOpKind::And) {
-                                const bool is_false = (oa && !va) || (ob && !vb);
-                                ok = is_false || (oa && ob);
-                                v = !is_false && oa && ob;
-                            } else {
-                                const bool is_true = va || vb;
-                                ok = is_true || (oa && ob);
-                                v = is_true;
+                        for (int g = 0; g < kG; ++g) {
+                            const Vec4 a = second(g);
+                            uint32_t ok_out = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool oa = (a.ok >> j) & 1u, ob = (top[g].ok >> j) & 1u, va = oa && a.v[j], vb = ob && top[g].v[j];
+                                bool v, ok;
+                                if ((ValOpKind)op.kind == ValOpKind::And) {
+                                    const bool is_false = (oa && !va) || (ob && !vb);
+                                    ok = is_false || (oa && ob);
+                                    v = !is_false && oa && ob;
+                                } else {
+                                    const bool is_true = va || vb;
+                                    ok = is_true || (oa && ob);
+                                    v = is_true;
+                                }
+                                top[g].v[j] = v ? 1 : 0;
+                                ok_out |= (ok ? 1u : 0u) << j;
                             }
-                            top.v[j] = v ? 1 : 0;
-                            ok_out |= (ok ? 1u : 0u) << j;
+                            top[g].ok = ok_out;
                         }
-                        top.ok = ok_out;
                         --sp;
                         break;
                     }
                     case ValOpKind::Not:
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) top.v[j] = ((top.ok >> j) & 1u) && !top.v[j] ? 1 : 0;
+                        for (int g = 0; g < kG; ++g)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top[g].v[j] = ((top[g].ok >> j) & 1u) && !top[g].v[j] ? 1 : 0;
                         break;
                     case ValOpKind::IsNull: case ValOpKind::IsNotNull:
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) top.v[j] = (((top.ok >> j) & 1u) != 0) == ((ValOpKind)op.kind == ValOpKind::IsNotNull) ? 1 : 0;
-                        top.ok = 15u;
+                        for (int g = 0; g < kG; ++g) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top[g].v[j] = (((top[g].ok >> j) & 1u) != 0) == ((ValOpKind)op.kind == ValOpKind::IsNotNull) ? 1 : 0;
+                            top[g].ok = 15u;
+                        }
                         break;
                     case ValOpKind::Select: {   // [.. ELSE WHEN THEN]: THEN = top, WHEN below it, ELSE below that
-                        const Vec4 when = second();
-                        --sp;
-                        const Vec4 els = second();
-                        --sp;
-                        uint32_t ok_out = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool take = ((when.ok >> j) & 1u) && when.v[j];
-                            if (!take) top.v[j] = els.v[j];
-                            ok_out |= ((take ? top.ok : els.ok) >> j & 1u) << j;
+                        for (int g = 0; g < kG; ++g) {
+                            const Vec4 when = second(g);
+                            --sp;
+                            const Vec4 els = second(g);
+                            ++sp;
+                            uint32_t ok_out = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool take = ((when.ok >> j) & 1u) && when.v[j];
+                                if (!take) top[g].v[j] = els.v[j];
+                                ok_out |= ((take ? top[g].ok : els.ok) >> j & 1u) << j;
+                            }
+                            top[g].ok = ok_out;
                         }
-                        top.ok = ok_out;
+                        sp -= 2;
                         break;
                     }
                 }
             }
-            if (kMask) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) flags |= (uint32_t)(((top.ok >> j) & 1u) && top.v[j] && r0 + j < n) << (it * 4 + j);
-            } else if (whole) {
-                if (out_type == (int32_t)ColType::I32) {
-                    *reinterpret_cast<int4 *>(static_cast<int32_t *>(out_values) + r0) = make_int4((int32_t)top.v[0], (int32_t)top.v[1], (int32_t)top.v[2], (int32_t)top.v[3]);
+            for (int g = 0; g < kG; ++g) {
+                const int64_t rg = r0 + g * 256;
+                if (kMask) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) flags |= (uint32_t)(((top[g].ok >> j) & 1u) && top[g].v[j] && rg + j < n) << ((it0 + g) * 4 + j);
+                } else if (whole) {
+                    if (out_type == (int32_t)ColType::I32) {
+                        *reinterpret_cast<int4 *>(static_cast<int32_t *>(out_values) + rg) = make_int4((int32_t)top[g].v[0], (int32_t)top[g].v[1], (int32_t)top[g].v[2], (int32_t)top[g].v[3]);
+                    } else {
+                        uint4 *dst = reinterpret_cast<uint4 *>(static_cast<uint64_t *>(out_values) + rg);
+                        dst[0] = make_uint4((uint32_t)top[g].v[0], (uint32_t)(top[g].v[0] >> 32), (uint32_t)top[g].v[1], (uint32_t)(top[g].v[1] >> 32));
+                        dst[1] = make_uint4((uint32_t)top[g].v[2], (uint32_t)(top[g].v[2] >> 32), (uint32_t)top[g].v[3], (uint32_t)(top[g].v[3] >> 32));
+                    }
+                    if (out_valid) *reinterpret_cast<uint32_t *>(out_valid + rg) = (top[g].ok & 1u) | ((top[g].ok & 2u) << 7) | ((top[g].ok & 4u) << 14) | ((top[g].ok & 8u) << 21);
+                    else if (top[g].ok != 15u) bad |= kErrNull;
                 } else {
-                    uint4 *dst = reinterpret_cast<uint4 *>(static_cast<uint64_t *>(out_values) + r0);
-                    dst[0] = make_uint4((uint32_t)top.v[0], (uint32_t)(top.v[0] >> 32), (uint32_t)top.v[1], (uint32_t)(top.v[1] >> 32));
-                    dst[1] = make_uint4((uint32_t)top.v[2], (uint32_t)(top.v[2] >> 32), (uint32_t)top.v[3], (uint32_t)(top.v[3] >> 32));
-                }
-                if (out_valid) *reinterpret_cast<uint32_t *>(out_valid + r0) = (top.ok & 1u) | ((top.ok & 2u) << 7) | ((top.ok & 4u) << 14) | ((top.ok & 8u) << 21);
-                else if (top.ok != 15u) bad |= kErrNull;
-            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t r = r0 + j;
-                    if (r >= n) continue;
-                    const bool ok = (top.ok >> j) & 1u;
-                    if (out_type == (int32_t)ColType::I32) static_cast<int32_t *>(out_values)[r] = (int32_t)top.v[j];
-                    else static_cast<uint64_t *>(out_values)[r] = top.v[j];
-                    if (out_valid) out_valid[r] = ok;
-                    else if (!ok) bad |= kErrNull;
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t r = rg + j;
+                        if (r >= n) continue;
+                        const bool ok = (top[g].ok >> j) & 1u;
+                        if (out_type == (int32_t)ColType::I32) static_cast<int32_t *>(out_values)[r] = (int32_t)top[g].v[j];
+                        else static_cast<uint64_t *>(out_values)[r] = top[g].v[j];
+                        if (out_valid) out_valid[r] = ok;
+                        else if (!ok) bad |= kErrNull;
+                    }
                 }
             }
         }
@@ -364,9 +464,25 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
     if (bad) atomicOr(err, bad);
 }
 
+size_t stack_bytes(const ValProgram &prog);
+// groups per pass: four (two) while the operand stack below the top fits half the 64 KB a launch gets without asking
+int groups_of(const ValProgram &prog) {
+    static const int forced = exp_env("FLOCKGPU_VALPROG_GROUPS") ? atoi(exp_env("FLOCKGPU_VALPROG_GROUPS")) : 0;   // (A/B knob)
+    const int g = forced ? forced : kValGroups;
+    return prog.max_stack <= 2 ? g : prog.max_stack <= 3 && g > 2 ? 2 : 1;
+}
+template <bool kMask>
+void launch(flockgpu_ctx *ctx, const ValProgram &prog, unsigned grid, int64_t rows, int32_t n_tiles, void *out_values, uint8_t *out_valid, int32_t out_type, uint32_t *flags,
+            uint32_t *counts, uint32_t *d_err) {
+    const int g = groups_of(prog);
+    const size_t lds = stack_bytes(prog);
+    if (g == 4) hipLaunchKernelGGL((valprog_kernel<kMask, 4>), dim3(grid), dim3(kBlock), lds, ctx->stream, prog, rows, n_tiles, out_values, out_valid, out_type, flags, counts, d_err);
+    else if (g == 2) hipLaunchKernelGGL((valprog_kernel<kMask, 2>), dim3(grid), dim3(kBlock), lds, ctx->stream, prog, rows, n_tiles, out_values, out_valid, out_type, flags, counts, d_err);
+    else hipLaunchKernelGGL((valprog_kernel<kMask, 1>), dim3(grid), dim3(kBlock), lds, ctx->stream, prog, rows, n_tiles, out_values, out_valid, out_type, flags, counts, d_err);
+}
 size_t stack_bytes(const ValProgram &prog) {
     const size_t below = prog.max_stack > 1 ? (size_t)prog.max_stack - 1 : 0;
-    return below * (4 * kBlock * sizeof(uint64_t) + kBlock) + 16;
+    return below * (size_t)groups_of(prog) * (4 * kBlock * sizeof(uint64_t) + kBlock) + 16;
 }
 
 int report(flockgpu_ctx *ctx, const char *name, uint32_t e) {
@@ -395,8 +511,7 @@ int valprog_to_column(flockgpu_ctx *ctx, const char *name, const ValProgram &pro
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 8);
     {
         LaunchScope ls(ctx, "valprog_kernel");
-        hipLaunchKernelGGL(valprog_kernel<false>, dim3(grid), dim3(kBlock), stack_bytes(prog), ctx->stream, prog, rows, n_tiles, out_values, out_valid, (int32_t)out_type,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, d_err);
+        launch<false>(ctx, prog, grid, rows, n_tiles, out_values, out_valid, (int32_t)out_type, nullptr, nullptr, d_err);
     }
     FG_TRY(check_launch(ctx, "valprog_kernel"));
     pinned_pending32(h_err, 1);
@@ -431,8 +546,7 @@ int valprog_to_rows(flockgpu_ctx *ctx, const char *name, const ValProgram &prog,
     const unsigned grid = (unsigned)std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * 8);
     {
         LaunchScope ls(ctx, "valprog_kernel");
-        hipLaunchKernelGGL(valprog_kernel<true>, dim3(grid), dim3(kBlock), stack_bytes(prog), ctx->stream, prog, rows, st.n_tiles, (void *)nullptr, (uint8_t *)nullptr, 0, flags, counts,
-                           d_err);
+        launch<true>(ctx, prog, grid, rows, st.n_tiles, nullptr, nullptr, 0, flags, counts, d_err);
     }
     FG_TRY(check_launch(ctx, "valprog_kernel"));
     pinned_pending32(h_err, 1);
