@@ -133,6 +133,28 @@ __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, 
     }
 }
 
+// The same for a dividend known to fit Int32 and |c| < 2^32 (r32: magic | shift << 32 | add << 40, ValBuilder::fuse_immediate)
+__device__ __forceinline__ uint64_t div_by_const32(uint8_t kind, uint8_t type, uint64_t a, uint64_t c, uint64_t r32, uint32_t *bad) {
+    const bool is_div = kind == (uint8_t)ValOpKind::Div;
+    const uint32_t magic = (uint32_t)r32, shift = (uint32_t)(r32 >> 32) & 31u;
+    const bool add = ((r32 >> 40) & 1u) != 0;
+    const bool sgn = type != (uint8_t)ValType::U64;
+    const int64_t x = (int64_t)a, y = (int64_t)c;
+    if (type == (uint8_t)ValType::I32 && y == -1 && x == (int64_t)INT32_MIN) *bad |= kErrOverflow;   // (Int64: -2^31 / -1 = 2^31 fits)
+    const uint32_t n = (uint32_t)(sgn && x < 0 ? 0 - a : a), d = (uint32_t)(sgn && y < 0 ? 0 - c : c);
+    uint32_t q;
+    if (magic == 0) {
+        q = n >> shift;
+    } else {
+        const uint32_t hi = __umulhi(n, magic);
+        q = add ? (((n - hi) >> 1) + hi) >> shift : hi >> shift;
+    }
+    const uint32_t r = n - q * d;
+    if (!sgn) return is_div ? q : r;
+    if (is_div) return wrap_to(type, (x < 0) != (y < 0) ? 0 - (uint64_t)q : (uint64_t)q);
+    return x < 0 ? 0 - (uint64_t)r : (uint64_t)r;
+}
+
 // Operator kind and operand type are the same for every lane and every row of a pass: the interpreter branches on them ONCE per operator and
 // pass (scalar branches) into code in which both are compile-time constants -- the per-value functions above then fold to the few
 // instructions of the one case (a dispatch per VALUE made the kernel issue-bound: 0.39 ms for `price * 2 + 1` over 9.2e7 rows).
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
 #pragma unroll 1
             for (int o = 0; o < p.n_ops; ++o) {
                 const ValOp op = p.ops[o];
-                const bool imm = op.to == kValImm;
+                const bool imm = op.to == kValImm || op.to == kValImm32;
                 switch ((ValOpKind)op.kind) {
                     case ValOpKind::Col:
                         spill();
@@ -285,13 +307,22 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                                 if (imm) {   // left = top, right = the literal
                                     const uint64_t c = p.consts[op.arg];
                                     constexpr bool by_recip = (kd == (uint8_t)ValOpKind::Div || kd == (uint8_t)ValOpKind::Mod) && ty != (uint8_t)ValType::F64;
-                                    const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
-                                    const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
+                                    if (by_recip && op.to == kValImm32) {   // the dividend is known to fit Int32
+                                        const uint64_t r32 = p.consts[op.arg + 3];
 #pragma unroll
-                                    for (int g = 0; g < kG; ++g)
+                                        for (int g = 0; g < kG; ++g)
 #pragma unroll
-                                        for (int j = 0; j < 4; ++j)
-                                            if ((top[g].ok >> j) & 1u) top[g].v[j] = by_recip ? div_by_const(kd, ty, top[g].v[j], c, magic, sh, &bad) : arith(kd, ty, top[g].v[j], c, &bad);
+                                            for (int j = 0; j < 4; ++j)
+                                                if ((top[g].ok >> j) & 1u) top[g].v[j] = div_by_const32(kd, ty, top[g].v[j], c, r32, &bad);
+                                    } else {
+                                        const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
+                                        const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
+#pragma unroll
+                                        for (int g = 0; g < kG; ++g)
+#pragma unroll
+                                            for (int j = 0; j < 4; ++j)
+                                                if ((top[g].ok >> j) & 1u) top[g].v[j] = by_recip ? div_by_const(kd, ty, top[g].v[j], c, magic, sh, &bad) : arith(kd, ty, top[g].v[j], c, &bad);
+                                    }
                                 } else {
 #pragma unroll
                                     for (int g = 0; g < kG; ++g) {

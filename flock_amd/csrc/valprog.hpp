@@ -29,6 +29,7 @@
 //        TRUE, else ELSE, else NULL.
 #pragma once
 #include "relops.hpp"
+#include "divmagic.hpp"
 
 namespace flockgpu {
 
@@ -48,8 +49,9 @@ enum class ValOpKind : uint8_t {
 };
 struct ValOp {
     uint8_t kind, type, to, arg;   // ValOpKind; operand ValType; Cast target -- or, on a binary operator, kValImm: the right operand is consts[arg]
-};                                 // (Div / Mod with kValImm: consts[arg] = divisor, [arg + 1] = reciprocal, [arg + 2] = shift | add << 8: ValBuilder::fuse_immediate)
+};                                 // (Div / Mod with kValImm: consts[arg] = divisor, [arg + 1] = reciprocal, [arg + 2] = shift | add << 8, [arg + 3]: see kValImm32; ValBuilder::fuse_immediate)
 constexpr uint8_t kValImm = 0x80;
+constexpr uint8_t kValImm32 = 0x81;   // Div / Mod by a literal |c| < 2^32 whose dividend is KNOWN to fit Int32 (ValBuilder::narrow): consts[arg + 3] = the 32-bit reciprocal
 struct ValCol {
     const void *values;
     const uint8_t *valid;
@@ -67,6 +69,7 @@ struct ValProgram {
 struct ValBuilder {
     ValProgram p{};
     int depth = 0;
+    uint32_t narrow = 0;   // bit i: the value in stack slot i is known to lie in [-2^31, 2^31) whatever its type (an Int32 column behind the planner's CAST to Int64, a small literal, a remainder of such)
     int add_col(const DevColumn &c) {
         for (int i = 0; i < p.n_cols; ++i)
             if (p.cols[i].values == c.values && p.cols[i].valid == c.valid) return i;
@@ -84,11 +87,31 @@ struct ValBuilder {
     // pops: operands the operator takes off the stack; every operator pushes one result
     bool push(ValOpKind k, ValType type, int pops, int arg = 0, ValType to = ValType::NONE) {
         if (p.n_ops >= kValMaxOps || arg < 0) return false;
-        if (pops == 2 && fuse_immediate(k, type)) return true;
+        const bool fits = result_fits_i32(k, type, pops, arg, to);   // (looks at the operands: before anything moves)
+        if (pops == 2 && fuse_immediate(k, type)) {
+            set_narrow(depth - 1, fits);
+            return true;
+        }
         p.ops[p.n_ops++] = ValOp{(uint8_t)k, (uint8_t)type, (uint8_t)to, (uint8_t)arg};
         depth += 1 - pops;
         if (depth > p.max_stack) p.max_stack = depth;
+        if (depth >= 1 && depth <= kValMaxStack) set_narrow(depth - 1, fits);
         return depth >= 1 && depth <= kValMaxStack;
+    }
+    void set_narrow(int slot, bool v) { narrow = v ? narrow | (1u << slot) : narrow & ~(1u << slot); }
+    bool is_narrow(int slot) const { return slot >= 0 && ((narrow >> slot) & 1u); }
+    // whether the operator's result is known to lie in the Int32 range (operands: slots depth - pops .. depth - 1)
+    bool result_fits_i32(ValOpKind k, ValType type, int pops, int arg, ValType to) const {
+        switch (k) {
+            case ValOpKind::Col: return p.cols[arg].type == (int32_t)ColType::I32;
+            case ValOpKind::Const: return type != ValType::F64 && (int64_t)p.consts[arg] >= INT32_MIN && (int64_t)p.consts[arg] <= INT32_MAX && !(type == ValType::U64 && (int64_t)p.consts[arg] < 0);
+            case ValOpKind::Null: return true;
+            case ValOpKind::Add: case ValOpKind::Sub: case ValOpKind::Mul: case ValOpKind::Neg: case ValOpKind::Div: return type == ValType::I32;   // (an Int32 result is wrapped to its width)
+            case ValOpKind::Mod: return type == ValType::I32 || (type != ValType::F64 && is_narrow(depth - 2));   // |x % y| <= |x|
+            case ValOpKind::Cast: case ValOpKind::TryCast: return to == ValType::I32 || (type != ValType::F64 && to != ValType::F64 && is_narrow(depth - 1) && !(to == ValType::U64));
+            case ValOpKind::Select: return is_narrow(depth - 1) && is_narrow(depth - 3);   // THEN and ELSE
+            default: return true;   // comparisons and logic: 0 / 1
+        }
     }
     // A binary operator whose RIGHT operand was just pushed as a literal takes it as an immediate: the Const push goes, the operator
     // reads consts[arg].  Division / remainder by a non-zero integer literal get the reciprocal of |divisor| next to it (Granlund /
@@ -99,6 +122,7 @@ struct ValBuilder {
         const bool cmp = k == ValOpKind::Eq || k == ValOpKind::Ne || k == ValOpKind::Lt || k == ValOpKind::Le || k == ValOpKind::Gt || k == ValOpKind::Ge;
         if (!arith && !cmp) return false;
         int arg = p.ops[p.n_ops - 1].arg;
+        uint8_t imm_kind = kValImm;
         const uint64_t c = p.consts[arg];
         if ((k == ValOpKind::Div || k == ValOpKind::Mod) && type != ValType::F64) {
             if (c == 0) return false;   // (a zero divisor: the generic operator reports it -- for the valid rows only)
@@ -116,13 +140,22 @@ struct ValBuilder {
                 }
                 magic = (uint64_t)(pm + 1);
             }
-            if (p.n_consts + 3 > kValMaxConsts) return false;
+            if (p.n_consts + 4 > kValMaxConsts) return false;
             arg = p.n_consts;
             p.consts[p.n_consts++] = c;
             p.consts[p.n_consts++] = magic;
             p.consts[p.n_consts++] = shift | (add << 8);
+            // a dividend known to fit Int32 (the slot below the literal's) and |divisor| < 2^32: ONE 32 x 32 -> high-32 multiply per row
+            // (divmagic.hpp) instead of the four of the 64-bit form
+            uint64_t r32 = 0;
+            if (d < (uint64_t(1) << 32) && is_narrow(depth - 2)) {
+                const UMod32 m = umod32_make((uint32_t)d);
+                r32 = (uint64_t)m.magic | ((uint64_t)m.shift << 32) | ((uint64_t)m.add << 40);
+                imm_kind = kValImm32;
+            }
+            p.consts[p.n_consts++] = r32;
         }
-        p.ops[p.n_ops - 1] = ValOp{(uint8_t)k, (uint8_t)type, kValImm, (uint8_t)arg};
+        p.ops[p.n_ops - 1] = ValOp{(uint8_t)k, (uint8_t)type, imm_kind, (uint8_t)arg};
         depth -= 1;   // (the literal's push is taken back; the operator replaces its left operand in place)
         return true;
     }
