@@ -1098,7 +1098,7 @@ def plan_generic(gpu, eps, steps):
 ARCH_OPS = {
     "filter": ("pred_flag_kernel", "q2_flag_kernel", 4.0),        # the predicate reads `auction` once
     "groupby": ("dense_group_kernel", "q5_partial_tile_kernel", 4.0),
-    "join": ("join_probe_dense_kernel", "join_probe_dense_kernel", 4.0),   # the probe side's key column (count pass + emit pass: launched twice)
+    "join": ("join_probe_unique_flag_kernel", "join_probe_unique_flag_kernel", 4.0),   # the probe side's key column, once (unique build keys: the flag-tile probe)
     "sort": ("sort_emit_kernel", "sort_emit_kernel", 16.0),       # one radix pass: key + row number in and out
 }
 
