@@ -7,7 +7,8 @@ using namespace flockgpu;
 
 namespace {
 
-constexpr int kValGroups = 2;   // 16-byte groups of rows per pass of the program (see valprog_kernel; 1 / 2 / 4 measured: profiles/r06/expr_groups_ab.txt)
+constexpr int kPre = 2;         // Int32 columns (the program's first) requested at the top of every pass
+constexpr int kValGroups = 4;   // 16-byte groups of rows per pass of the program (see valprog_kernel; 1 / 2 / 4 measured: profiles/r06/expr_groups_ab.txt)
 constexpr uint32_t kErrDivZero = 1u, kErrCast = 2u, kErrNull = 4u, kErrOverflow = 8u;
 
 __device__ __forceinline__ double as_f64(uint64_t b) { return __longlong_as_double((long long)b); }
@@ -86,29 +87,6 @@ __device__ __forceinline__ uint64_t arith(uint8_t kind, uint8_t type, uint64_t a
     return (uint64_t)(kind == DIV ? x / y : x % y);
 }
 
-// x / c and x % c for an integer literal c != 0 through the reciprocal the host made (ValBuilder::fuse_immediate): unsigned quotient of the
-// absolute values, then the signs (truncation towards zero; the remainder takes the dividend's sign)
-__device__ __forceinline__ uint64_t div_by_const(uint8_t kind, uint8_t type, uint64_t a, uint64_t c, uint64_t magic, uint32_t sh, uint32_t *bad) {
-    const bool is_div = kind == (uint8_t)ValOpKind::Div;
-    const uint32_t shift = sh & 63u;
-    const bool add = (sh >> 8) != 0;
-    auto udiv = [&](uint64_t n) -> uint64_t {
-        if (magic == 0) return n >> shift;   // a power of two
-        const uint64_t hi = __umul64hi(n, magic);
-        return add ? (((n - hi) >> 1) + hi) >> shift : hi >> shift;
-    };
-    if (type == (uint8_t)ValType::U64) {
-        const uint64_t q = udiv(a);
-        return is_div ? q : a - q * c;
-    }
-    const int64_t x = (int64_t)a, y = (int64_t)c;
-    if (y == -1 && x == (type == (uint8_t)ValType::I32 ? (int64_t)INT32_MIN : INT64_MIN)) *bad |= kErrOverflow;
-    const uint64_t ax = x < 0 ? 0 - a : a, ad = y < 0 ? 0 - c : c;
-    const uint64_t q = udiv(ax), r = ax - q * ad;
-    if (is_div) return wrap_to(type, (x < 0) != (y < 0) ? 0 - q : q);
-    return x < 0 ? 0 - r : r;
-}
-
 __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, uint64_t b) {
     bool lt, eq;
     if (type == (uint8_t)ValType::F64) {
@@ -133,26 +111,43 @@ __device__ __forceinline__ bool compare(uint8_t kind, uint8_t type, uint64_t a, 
     }
 }
 
-// The same for a dividend known to fit Int32 and |c| < 2^32 (r32: magic | shift << 32 | add << 40, ValBuilder::fuse_immediate)
-__device__ __forceinline__ uint64_t div_by_const32(uint8_t kind, uint8_t type, uint64_t a, uint64_t c, uint64_t r32, uint32_t *bad) {
-    const bool is_div = kind == (uint8_t)ValOpKind::Div;
-    const uint32_t magic = (uint32_t)r32, shift = (uint32_t)(r32 >> 32) & 31u;
-    const bool add = ((r32 >> 40) & 1u) != 0;
-    const bool sgn = type != (uint8_t)ValType::U64;
-    const int64_t x = (int64_t)a, y = (int64_t)c;
-    if (type == (uint8_t)ValType::I32 && y == -1 && x == (int64_t)INT32_MIN) *bad |= kErrOverflow;   // (Int64: -2^31 / -1 = 2^31 fits)
-    const uint32_t n = (uint32_t)(sgn && x < 0 ? 0 - a : a), d = (uint32_t)(sgn && y < 0 ? 0 - c : c);
+// x / c and x % c for an integer literal c != 0 through the reciprocal the host made (ValBuilder::fuse_immediate): unsigned quotient of the
+// absolute values, then the signs (truncation towards zero; the remainder takes the dividend's sign).  Everything that depends on the LITERAL
+// only (power of two, the 65-bit multiplier form, the divisor's sign) is uniform and arrives as template / scalar arguments, so the per-value code
+// is straight-line: selects, no branches (a branch per value was an exec-mask save / restore per value -- the kernel was bound by its SCALAR
+// instruction stream: 1120 SALU against 860 VALU instructions per pass of `expr_filter`, profiles/r06/expr_groups_ab.txt).
+// kForm: 0 = power of two (shift), 1 = multiplier, 2 = multiplier with the add step.
+template <uint8_t KIND, uint8_t TYPE, int kForm>
+__device__ __forceinline__ uint64_t div_recip64(uint64_t a, uint64_t c, uint64_t ad, bool neg_c, uint64_t magic, uint32_t shift) {
+    constexpr bool sgn = TYPE != (uint8_t)ValType::U64;
+    const bool neg_a = sgn && (int64_t)a < 0;
+    const uint64_t ax = neg_a ? 0 - a : a;
+    uint64_t q;
+    if (kForm == 0) {
+        q = ax >> shift;
+    } else {
+        const uint64_t hi = __umul64hi(ax, magic);
+        q = kForm == 2 ? (((ax - hi) >> 1) + hi) >> shift : hi >> shift;
+    }
+    if (KIND == (uint8_t)ValOpKind::Div) return wrap_to(TYPE, sgn && (neg_a != neg_c) ? 0 - q : q);
+    const uint64_t r = ax - q * ad;
+    return neg_a ? 0 - r : r;
+}
+template <uint8_t KIND, uint8_t TYPE, int kForm>
+__device__ __forceinline__ uint64_t div_recip32(uint64_t a, uint32_t d, bool neg_c, uint32_t magic, uint32_t shift) {
+    constexpr bool sgn = TYPE != (uint8_t)ValType::U64;
+    const bool neg_a = sgn && (int64_t)a < 0;
+    const uint32_t n = (uint32_t)(neg_a ? 0 - a : a);
     uint32_t q;
-    if (magic == 0) {
+    if (kForm == 0) {
         q = n >> shift;
     } else {
         const uint32_t hi = __umulhi(n, magic);
-        q = add ? (((n - hi) >> 1) + hi) >> shift : hi >> shift;
+        q = kForm == 2 ? (((n - hi) >> 1) + hi) >> shift : hi >> shift;
     }
+    if (KIND == (uint8_t)ValOpKind::Div) return wrap_to(TYPE, sgn && (neg_a != neg_c) ? 0 - (uint64_t)q : (uint64_t)q);
     const uint32_t r = n - q * d;
-    if (!sgn) return is_div ? q : r;
-    if (is_div) return wrap_to(type, (x < 0) != (y < 0) ? 0 - (uint64_t)q : (uint64_t)q);
-    return x < 0 ? 0 - (uint64_t)r : (uint64_t)r;
+    return neg_a ? 0 - (uint64_t)r : (uint64_t)r;
 }
 
 // Operator kind and operand type are the same for every lane and every row of a pass: the interpreter branches on them ONCE per operator and
@@ -253,6 +248,32 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                 top[g].ok = 0;
                 top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = 0;
             }
+            // every Int32 column among the program's first kPre is ASKED FOR here, before the first operator: a pass that reads two columns
+            // then has both in flight together instead of waiting for them one after the other (expr_filter: 0.50 -> see profiles/r06)
+            int4 raw[kPre][kG];
+            if (whole) {
+#pragma unroll
+                for (int c = 0; c < kPre; ++c)
+                    if (c < p.n_cols && p.cols[c].type == (int32_t)ColType::I32) {
+#pragma unroll
+                        for (int g = 0; g < kG; ++g) raw[c][g] = stream_load4(static_cast<const int32_t *>(p.cols[c].values) + r0 + g * 256);
+                    }
+            }
+            auto prefetched = [&](int c, int g) -> Vec4 {   // column c < kPre, Int32, tile inside the relation
+                const int4 t4 = c == 0 ? raw[0][g] : raw[kPre - 1][g];
+                Vec4 x;
+                x.v[0] = (uint64_t)(int64_t)t4.x; x.v[1] = (uint64_t)(int64_t)t4.y; x.v[2] = (uint64_t)(int64_t)t4.z; x.v[3] = (uint64_t)(int64_t)t4.w;
+                x.ok = 15u;
+                const uint8_t *valid = p.cols[c].valid;
+                if (valid) {
+                    const uint32_t vb = *reinterpret_cast<const uint32_t *>(valid + r0 + g * 256);
+                    x.ok = (vb & 0xFFu ? 1u : 0u) | (vb & 0xFF00u ? 2u : 0u) | (vb & 0xFF0000u ? 4u : 0u) | (vb & 0xFF000000u ? 8u : 0u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!((x.ok >> j) & 1u)) x.v[j] = 0;
+                }
+                return x;
+            };
             int sp = 0;   // operands on the stack, the top one in `top`
             auto spill = [&]() {   // a push over a live top: it goes to its slot below
                 if (sp > 0) {
@@ -274,19 +295,26 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
 #pragma unroll 1
             for (int o = 0; o < p.n_ops; ++o) {
                 const ValOp op = p.ops[o];
+                const uint32_t at = op.arg & 31u;   // (fetching the NEXT operator and its constants ahead of its turn measured slower: profiles/r06/expr_groups_ab.txt)
+                const uint64_t k0 = p.consts[at], k1 = p.consts[at + 1], k2 = p.consts[at + 2], k3 = p.consts[at + 3];
                 const bool imm = op.to == kValImm || op.to == kValImm32;
                 switch ((ValOpKind)op.kind) {
                     case ValOpKind::Col:
                         spill();
+                        if (whole && op.arg < kPre && p.cols[op.arg].type == (int32_t)ColType::I32) {
 #pragma unroll
-                        for (int g = 0; g < kG; ++g) top[g] = load_col4(p.cols[op.arg], r0 + g * 256, n, whole);
+                            for (int g = 0; g < kG; ++g) top[g] = prefetched(op.arg, g);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < kG; ++g) top[g] = load_col4(p.cols[op.arg], r0 + g * 256, n, whole);
+                        }
                         ++sp;
                         break;
                     case ValOpKind::Const:
                         spill();
 #pragma unroll
                         for (int g = 0; g < kG; ++g) {
-                            top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = p.consts[op.arg];
+                            top[g].v[0] = top[g].v[1] = top[g].v[2] = top[g].v[3] = k0;
                             top[g].ok = 15u;
                         }
                         ++sp;
@@ -304,32 +332,62 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                         with_type(op.type, [&](auto T) {
                             with_arith(op.kind, [&](auto K) {
                                 constexpr uint8_t ty = decltype(T)::value, kd = decltype(K)::value;
-                                if (imm) {   // left = top, right = the literal
-                                    const uint64_t c = p.consts[op.arg];
-                                    constexpr bool by_recip = (kd == (uint8_t)ValOpKind::Div || kd == (uint8_t)ValOpKind::Mod) && ty != (uint8_t)ValType::F64;
-                                    if (by_recip && op.to == kValImm32) {   // the dividend is known to fit Int32
-                                        const uint64_t r32 = p.consts[op.arg + 3];
+                                constexpr bool by_recip = (kd == (uint8_t)ValOpKind::Div || kd == (uint8_t)ValOpKind::Mod) && ty != (uint8_t)ValType::F64;
+                                // f(value) for every row of the pass, NULL rows kept at 0: straight-line code, no branch per value
+                                auto each = [&](auto &&f) {
+#pragma unroll
+                                    for (int g = 0; g < kG; ++g)
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = f(top[g].v[j]) & (0 - (uint64_t)((top[g].ok >> j) & 1u));
+                                };
+                                if (imm && by_recip) {   // left = top, right = a non-zero integer literal: multiply by its reciprocal
+                                    const uint64_t c = k0;
+                                    const bool neg_c = ty != (uint8_t)ValType::U64 && (int64_t)c < 0;
+                                    const uint64_t ad = neg_c ? 0 - c : c;
+                                    if (neg_c && ad == 1) {   // (uniform) c = -1: INT_MIN / -1 and INT_MIN % -1 overflow (A-V4)
+                                        const uint64_t lowest = ty == (uint8_t)ValType::I32 ? (uint64_t)(int64_t)INT32_MIN : (uint64_t)INT64_MIN;
 #pragma unroll
                                         for (int g = 0; g < kG; ++g)
 #pragma unroll
-                                            for (int j = 0; j < 4; ++j)
-                                                if ((top[g].ok >> j) & 1u) top[g].v[j] = div_by_const32(kd, ty, top[g].v[j], c, r32, &bad);
-                                    } else {
-                                        const uint64_t magic = by_recip ? p.consts[op.arg + 1] : 0;
-                                        const uint32_t sh = by_recip ? (uint32_t)p.consts[op.arg + 2] : 0;
-#pragma unroll
-                                        for (int g = 0; g < kG; ++g)
-#pragma unroll
-                                            for (int j = 0; j < 4; ++j)
-                                                if ((top[g].ok >> j) & 1u) top[g].v[j] = by_recip ? div_by_const(kd, ty, top[g].v[j], c, magic, sh, &bad) : arith(kd, ty, top[g].v[j], c, &bad);
+                                            for (int j = 0; j < 4; ++j) bad |= (top[g].v[j] == lowest && ((top[g].ok >> j) & 1u)) ? kErrOverflow : 0u;
                                     }
+                                    if (op.to == kValImm32) {   // the dividend is known to fit Int32
+                                        const uint64_t r32 = k3;
+                                        const uint32_t magic = (uint32_t)r32, shift = (uint32_t)(r32 >> 32) & 31u, d = (uint32_t)ad;
+                                        if (magic == 0) each([&](uint64_t a) { return div_recip32<kd, ty, 0>(a, d, neg_c, magic, shift); });
+                                        else if ((r32 >> 40) & 1u) each([&](uint64_t a) { return div_recip32<kd, ty, 2>(a, d, neg_c, magic, shift); });
+                                        else each([&](uint64_t a) { return div_recip32<kd, ty, 1>(a, d, neg_c, magic, shift); });
+                                    } else {
+                                        const uint64_t magic = k1;
+                                        const uint32_t sh = (uint32_t)k2, shift = sh & 63u;
+                                        if (magic == 0) each([&](uint64_t a) { return div_recip64<kd, ty, 0>(a, c, ad, neg_c, magic, shift); });
+                                        else if (sh >> 8) each([&](uint64_t a) { return div_recip64<kd, ty, 2>(a, c, ad, neg_c, magic, shift); });
+                                        else each([&](uint64_t a) { return div_recip64<kd, ty, 1>(a, c, ad, neg_c, magic, shift); });
+                                    }
+                                } else if (imm && (kd == (uint8_t)ValOpKind::Add || kd == (uint8_t)ValOpKind::Sub || kd == (uint8_t)ValOpKind::Mul)) {
+                                    const uint64_t c = k0;
+                                    uint32_t none = 0;   // (+ - * raise nothing)
+                                    each([&](uint64_t a) { return arith(kd, ty, a, c, &none); });
+                                } else if (imm) {   // Float64 / and % by a literal (a zero literal: the error, for the valid rows)
+                                    const uint64_t c = k0;
+#pragma unroll
+                                    for (int g = 0; g < kG; ++g)
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            if ((top[g].ok >> j) & 1u) top[g].v[j] = arith(kd, ty, top[g].v[j], c, &bad);
                                 } else {
 #pragma unroll
                                     for (int g = 0; g < kG; ++g) {
                                         const Vec4 a = second(g);
                                         const uint32_t ok = a.ok & top[g].ok;
+                                        if (kd == (uint8_t)ValOpKind::Add || kd == (uint8_t)ValOpKind::Sub || kd == (uint8_t)ValOpKind::Mul) {
+                                            uint32_t none = 0;
 #pragma unroll
-                                        for (int j = 0; j < 4; ++j) top[g].v[j] = (ok >> j) & 1u ? arith(kd, ty, a.v[j], top[g].v[j], &bad) : 0;
+                                            for (int j = 0; j < 4; ++j) top[g].v[j] = arith(kd, ty, a.v[j], top[g].v[j], &none) & (0 - (uint64_t)((ok >> j) & 1u));
+                                        } else {
+#pragma unroll
+                                            for (int j = 0; j < 4; ++j) top[g].v[j] = (ok >> j) & 1u ? arith(kd, ty, a.v[j], top[g].v[j], &bad) : 0;
+                                        }
                                         top[g].ok = ok;
                                     }
                                 }
@@ -378,19 +436,19 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                         with_type(op.type, [&](auto T) {
                             with_cmp(op.kind, [&](auto K) {
                                 constexpr uint8_t ty = decltype(T)::value, kd = decltype(K)::value;
-                                if (imm) {
-                                    const uint64_t c = p.consts[op.arg];
+                                if (imm) {   // (results as integers and bit arithmetic: Boolean `&&` of lane conditions is scalar-unit work)
+                                    const uint64_t c = k0;
 #pragma unroll
                                     for (int g = 0; g < kG; ++g)
 #pragma unroll
-                                        for (int j = 0; j < 4; ++j) top[g].v[j] = ((top[g].ok >> j) & 1u) && compare(kd, ty, top[g].v[j], c) ? 1 : 0;
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = (compare(kd, ty, top[g].v[j], c) ? 1u : 0u) & (top[g].ok >> j);
                                 } else {
 #pragma unroll
                                     for (int g = 0; g < kG; ++g) {
                                         const Vec4 a = second(g);
                                         const uint32_t ok = a.ok & top[g].ok;
 #pragma unroll
-                                        for (int j = 0; j < 4; ++j) top[g].v[j] = ((ok >> j) & 1u) && compare(kd, ty, a.v[j], top[g].v[j]) ? 1 : 0;
+                                        for (int j = 0; j < 4; ++j) top[g].v[j] = (compare(kd, ty, a.v[j], top[g].v[j]) ? 1u : 0u) & (ok >> j);
                                         top[g].ok = ok;
                                     }
                                 }
@@ -399,28 +457,24 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
                         if (!imm) --sp;
                         break;
                     }
-                    case ValOpKind::And: case ValOpKind::Or: {
+                    case ValOpKind::And: case ValOpKind::Or: {   // Kleene, on nibbles: bit j = row j (values are 0 / 1)
 #pragma unroll
                         for (int g = 0; g < kG; ++g) {
                             const Vec4 a = second(g);
-                            uint32_t ok_out = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const bool oa = (a.ok >> j) & 1u, ob = (top[g].ok >> j) & 1u, va = oa && a.v[j], vb = ob && top[g].v[j];
-                                bool v, ok;
-                                if ((ValOpKind)op.kind == ValOpKind::And) {
-                                    const bool is_false = (oa && !va) || (ob && !vb);
-                                    ok = is_false || (oa && ob);
-                                    v = !is_false && oa && ob;
-                                } else {
-                                    const bool is_true = va || vb;
-                                    ok = is_true || (oa && ob);
-                                    v = is_true;
-                                }
-                                top[g].v[j] = v ? 1 : 0;
-                                ok_out |= (ok ? 1u : 0u) << j;
+                            const uint32_t va = ((uint32_t)a.v[0] & 1u) | (((uint32_t)a.v[1] & 1u) << 1) | (((uint32_t)a.v[2] & 1u) << 2) | (((uint32_t)a.v[3] & 1u) << 3);
+                            const uint32_t vb = ((uint32_t)top[g].v[0] & 1u) | (((uint32_t)top[g].v[1] & 1u) << 1) | (((uint32_t)top[g].v[2] & 1u) << 2) | (((uint32_t)top[g].v[3] & 1u) << 3);
+                            const uint32_t oa = a.ok, ob = top[g].ok, ta = va & oa, tb = vb & ob, fa = ~va & oa, fb = ~vb & ob;   // TRUE / FALSE per side
+                            uint32_t v, ok;
+                            if ((ValOpKind)op.kind == ValOpKind::And) {
+                                v = ta & tb;
+                                ok = fa | fb | (oa & ob);
+                            } else {
+                                v = ta | tb;
+                                ok = v | (oa & ob);
                             }
-                            top[g].ok = ok_out;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) top[g].v[j] = (v >> j) & 1u;
+                            top[g].ok = ok & 15u;
                         }
                         --sp;
                         break;
@@ -429,16 +483,18 @@ __global__ __launch_bounds__(kBlock) void valprog_kernel(ValProgram p, int64_t n
 #pragma unroll
                         for (int g = 0; g < kG; ++g)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) top[g].v[j] = ((top[g].ok >> j) & 1u) && !top[g].v[j] ? 1 : 0;
+                            for (int j = 0; j < 4; ++j) top[g].v[j] = ((uint32_t)top[g].v[j] ^ 1u) & (top[g].ok >> j) & 1u;
                         break;
-                    case ValOpKind::IsNull: case ValOpKind::IsNotNull:
+                    case ValOpKind::IsNull: case ValOpKind::IsNotNull: {
+                        const uint32_t flip = (ValOpKind)op.kind == ValOpKind::IsNotNull ? 0u : 1u;
 #pragma unroll
                         for (int g = 0; g < kG; ++g) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) top[g].v[j] = (((top[g].ok >> j) & 1u) != 0) == ((ValOpKind)op.kind == ValOpKind::IsNotNull) ? 1 : 0;
+                            for (int j = 0; j < 4; ++j) top[g].v[j] = ((top[g].ok >> j) & 1u) ^ flip;
                             top[g].ok = 15u;
                         }
                         break;
+                    }
                     case ValOpKind::Select: {   // [.. ELSE WHEN THEN]: THEN = top, WHEN below it, ELSE below that
 #pragma unroll
                         for (int g = 0; g < kG; ++g) {

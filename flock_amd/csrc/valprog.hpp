@@ -60,7 +60,7 @@ struct ValCol {
 };
 struct ValProgram {
     ValCol cols[kValMaxCols];
-    uint64_t consts[kValMaxConsts];
+    uint64_t consts[kValMaxConsts + 3];   // (+ 3: the interpreter fetches consts[arg .. arg + 3] for every operator ahead of its turn)
     ValOp ops[kValMaxOps];
     int32_t n_cols = 0, n_consts = 0, n_ops = 0, max_stack = 0;
 };
