@@ -307,6 +307,33 @@ __global__ __launch_bounds__(kBlock) void gather_i64_kernel(const int64_t *__res
         out[i] = src[rows[i]];
 }
 
+__global__ __launch_bounds__(kBlock) void gather_multi_kernel(GatherCols cols, const int32_t *__restrict__ rows, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n4; q += (int64_t)gridDim.x * kBlock) {
+        const int4 r = *reinterpret_cast<const int4 *>(rows + q * 4);   // (the list is an arena buffer: 16-byte aligned)
+        for (int c = 0; c < cols.n; ++c) {   // (uniform trip count; every column's loads are independent of the others')
+            if (cols.width[c] == 4) {
+                const int32_t *s = static_cast<const int32_t *>(cols.src[c]);
+                const int4 v = make_int4(s[r.x], s[r.y], s[r.z], s[r.w]);
+                *reinterpret_cast<int4 *>(static_cast<int32_t *>(cols.out[c]) + q * 4) = v;
+            } else {
+                const int64_t *s = static_cast<const int64_t *>(cols.src[c]);
+                const int64_t a = s[r.x], b = s[r.y], d = s[r.z], e = s[r.w];
+                int64_t *o = static_cast<int64_t *>(cols.out[c]) + q * 4;
+                *reinterpret_cast<longlong2 *>(o) = make_longlong2(a, b);
+                *reinterpret_cast<longlong2 *>(o + 2) = make_longlong2(d, e);
+            }
+        }
+    }
+    // the up to three rows behind the last whole group of four
+    const int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (blockIdx.x == 0 && i < n)
+        for (int c = 0; c < cols.n; ++c) {
+            if (cols.width[c] == 4) static_cast<int32_t *>(cols.out[c])[i] = static_cast<const int32_t *>(cols.src[c])[rows[i]];
+            else static_cast<int64_t *>(cols.out[c])[i] = static_cast<const int64_t *>(cols.src[c])[rows[i]];
+        }
+}
+
 // ---- Utf8 take: lengths (count) -> tile scan -> offsets + bytes (emit) --------------------------------------------
 // Tile = 1024 values; value  it*256 + tid  of the tile belongs to thread tid (it = 0..3): the row list and the
 // source offsets are read coalesced.  counts[tile*4 + wave] = bytes of the wave's values.
@@ -765,6 +792,26 @@ int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64
         hipLaunchKernelGGL(gather_i64_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, src, rows, n, out);
     }
     return check_launch(ctx, "gather_i64_kernel");
+}
+
+int gather_fixed_multi(flockgpu_ctx *ctx, const GatherCols &cols, const int32_t *rows, int64_t n) {
+    if (n <= 0 || cols.n <= 0) return FLOCKGPU_OK;
+    if (cols.n > kGatherMulti) return fail(ctx, FLOCKGPU_ERR_INVALID, "gather_fixed_multi: more than %d columns", kGatherMulti);
+    bool aligned = (reinterpret_cast<uintptr_t>(rows) & 15) == 0;
+    for (int c = 0; c < cols.n; ++c) aligned = aligned && (reinterpret_cast<uintptr_t>(cols.out[c]) & 15) == 0;
+    if (!aligned) {   // (a row list or an output that is not a buffer of its own: column by column, as before)
+        for (int c = 0; c < cols.n; ++c) {
+            if (cols.width[c] == 4) FG_TRY(gather_i32(ctx, static_cast<const int32_t *>(cols.src[c]), rows, n, static_cast<int32_t *>(cols.out[c])));
+            else FG_TRY(gather_i64(ctx, static_cast<const int64_t *>(cols.src[c]), rows, n, static_cast<int64_t *>(cols.out[c])));
+        }
+        return FLOCKGPU_OK;
+    }
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(div_up(n, 4), kBlock), (int64_t)ctx->num_cus * 8);
+    {
+        LaunchScope ls(ctx, "gather_multi_kernel");
+        hipLaunchKernelGGL(gather_multi_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, cols, rows, n);
+    }
+    return check_launch(ctx, "gather_multi_kernel");
 }
 
 int gather_utf8_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_utf8 &src, const int32_t *rows, int64_t n,

@@ -33,6 +33,17 @@ int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, con
 
 int gather_i32(flockgpu_ctx *ctx, const int32_t *src, const int32_t *rows, int64_t n, int32_t *out);
 int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64_t n, int64_t *out);
+// Up to kGatherMulti fixed-width columns (4 or 8 bytes) taken at ONE row list in one launch: the row list is read once (four rows per lane, one
+// 16-byte load), every column's four values are in flight together and leave as 16-byte stores.  A take of a bid's four columns was four
+// launches that each re-read the list and kept one 4-byte load per lane in flight.  out[c] must be 16-byte aligned (arena buffers are).
+constexpr int kGatherMulti = 8;
+struct GatherCols {
+    const void *src[kGatherMulti];
+    void *out[kGatherMulti];
+    int32_t width[kGatherMulti];   // 4 | 8
+    int32_t n = 0;
+};
+int gather_fixed_multi(flockgpu_ctx *ctx, const GatherCols &cols, const int32_t *rows, int64_t n);
 
 // Gathers `n` Utf8 values in two phases so that several columns share ONE host synchronisation:
 //   begin  : lengths -> tile scan; queues the D2H copy of the total byte count (the host needs it to size the

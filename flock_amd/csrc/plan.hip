@@ -1533,6 +1533,7 @@ struct Exec {
     // tables many times over (filter, join output, one take per repartition), and at that size the waits ARE the cost.
     int take_table(const Node *n, const Table &in, const std::vector<char> &required, const int32_t *rows, int64_t n_rows, int first_out, Table *out) {
         std::vector<size_t> utf8;
+        GatherCols batch;
         for (size_t i = 0; i < in.cols.size(); ++i) {
             TCol &o = out->cols[(size_t)first_out + i];
             o.c.type = in.cols[i].c.type;
@@ -1543,10 +1544,27 @@ struct Exec {
                 utf8.push_back(i);
                 continue;
             }
-            FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
             o.present = true;
             o.subset_of = in.cols[i].subset_of ? in.cols[i].subset_of : in.cols[i].c.values;
+            if (!in.cols[i].c.valid && n_rows > 0) {   // a fixed-width column without NULLs: one launch takes up to eight of them (gather_fixed_multi)
+                void *pv = nullptr;
+                FG_TRY(arena_get(ctx, (node_key(pl, n, "take", first_out + (int)i) + ".val").c_str(), (size_t)n_rows * col_width(in.cols[i].c.type) + 16, &pv));
+                o.c = in.cols[i].c;
+                o.c.values = pv;
+                o.c.offsets = nullptr;
+                o.c.bytes = 0;
+                batch.src[batch.n] = in.cols[i].c.values;
+                batch.out[batch.n] = pv;
+                batch.width[batch.n] = (int32_t)col_width(in.cols[i].c.type);
+                if (++batch.n == kGatherMulti) {
+                    FG_TRY(gather_fixed_multi(ctx, batch, rows, n_rows));
+                    batch.n = 0;
+                }
+                continue;
+            }
+            FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
         }
+        if (batch.n) FG_TRY(gather_fixed_multi(ctx, batch, rows, n_rows));
         for (size_t g0 = 0; g0 < utf8.size(); g0 += 4) {
             const int k = (int)std::min<size_t>(4, utf8.size() - g0);
             if (k == 1) {
