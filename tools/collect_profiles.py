@@ -25,7 +25,8 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate
 ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q8", "q8_sellers_bitmap_kernel")] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
                                                             ("q3_general", "q3_probe_flag_kernel"), ("q8_general", "q8_key_bitmap_wide_kernel"),
                                                             ("q3_hash", "q3_window_join_lds_kernel"), ("q8_hash", "q8_sellers_part_kernel"),
-                                                            ("arch", "pred_flag_kernel"), ("arch", "dense_group_kernel"), ("arch", "join_probe_dense_kernel"),
+                                                            ("arch", "pred_flag_kernel"), ("arch", "dense_group_kernel"), ("arch", "join_probe_unique_flag_kernel"),
+                                                            ("expr", "valprog_kernel<false"), ("expr", "valprog_kernel<true"),
                                                             ("arch", "sort_emit_kernel"), ("arch", "utf8_emit_kernel"), ("arch", "gather_i32_kernel"),
                                                             ("q5_uniform", "q5_part_tile_kernel"), ("q4", "aq_final_kernel"),
                                                             ("q3_1e8", "q3_probe_flag_small_kernel")]
@@ -37,7 +38,7 @@ for q, kern in ROWS:
             continue
         tot, launches = 0.0, 0   # every instantiation of a template kernel, weighted by its launches (what bench.py's average is)
         for r in csv.DictReader(open(p)):
-            match = kern + "(" in r["kernel"] or kern + "<" in r["kernel"]
+            match = kern + "(" in r["kernel"] or kern + "<" in r["kernel"] or ("<" in kern and kern in r["kernel"])
             if kern == "pred_flag_kernel":   # (the relation's one ragged tile is a launch of its own, `<false, ..>`: the full-tile instance is the pass)
                 match = "pred_flag_kernel<true" in r["kernel"]
             if match:
@@ -51,7 +52,10 @@ for q, kern in ROWS:
     name = label if not q.endswith(("_general", "_uniform", "_hash")) and q not in ("q4", "q3_1e8") else f"{label}@{q}"
     if q == "q3_1e8":   # (round 5: the small instance runs under its own LaunchScope label)
         name = "q3_probe_flag_small_kernel@1e8_events"
-    arch_op = {"pred_flag_kernel": "filter", "dense_group_kernel": "groupby", "join_probe_dense_kernel": "join", "sort_emit_kernel": "sort"}.get(kern) if q == "arch" else None
+    arch_op = {"pred_flag_kernel": "filter", "dense_group_kernel": "groupby", "join_probe_unique_flag_kernel": "join", "sort_emit_kernel": "sort"}.get(kern) if q == "arch" else None
+    expr_row = {"valprog_kernel<false": "expr_project", "valprog_kernel<true": "expr_filter"}.get(kern) if q == "expr" else None
+    if expr_row:   # the expression evaluator's two bench rows: one profiled run, the projection and the filter instance of one kernel
+        name = f"valprog_kernel@{expr_row}"
     if q == "arch":   # the reference's operator harness: one profiled run holds all four plans
         name = f"{kern}@arch_{arch_op}" if arch_op else f"{kern}@arch"
     if len(vals) == 2 and name not in traffic:
@@ -62,6 +66,8 @@ for q, kern in ROWS:
             detail["alg_bytes"] = (under.get("roofline") or {}).get("algorithmic_bytes_per_launch")
             if arch_op:
                 detail["alg_bytes"] = ((under.get(arch_op) or {}).get("generic", {}).get("roofline") or {}).get("algorithmic_bytes_per_launch")
+            if expr_row:
+                detail["alg_bytes"] = ((under.get(expr_row) or {}).get("roofline") or {}).get("algorithmic_bytes_per_launch")
         except Exception:
             pass
         traffic[name + "_detail"] = detail
