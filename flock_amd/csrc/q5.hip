@@ -839,6 +839,132 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     flush(tile, seg);
 }
 
+// The workgroup form made PERSISTENT with the next tile's loads in flight under the LDS phase and the flush (the round-2 attempts at this died
+// on `__syncthreads()`: a workgroup-scope fence, i.e. `s_waitcnt vmcnt(0)` -- the prefetch was waited for at the first barrier).  Here the
+// barriers are raw: `s_waitcnt lgkmcnt(0); s_barrier` (the LDS traffic of a wave is what the other waves must see; nothing in flight from
+// memory is anybody else's business).  Workgroup b walks tiles b, b + G, ...
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 6))) void q5_count_wgp_kernel(
+    const int32_t *__restrict__ auction, const TileRange *__restrict__ tiles, int32_t n_tiles, const PaneDesc *__restrict__ panes,
+    const int32_t *__restrict__ pane_win_ptr, const int32_t *__restrict__ pane_win_idx, uint32_t *counters, uint64_t *tables, uint32_t cap,
+    uint32_t *tab_used, uint32_t *err, int32_t *slow_list, const uint64_t *__restrict__ spec_info) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[kHist + kHistPad];
+    __shared__ int32_t s_red[2][8];
+    if (spec_info && !spec_info[2]) return;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    FlushArgs f;
+    f.pane_win_idx = pane_win_idx;
+    f.counters = counters;
+    f.tables = tables;
+    f.cap = cap;
+    f.tab_used = tab_used;
+    f.err = err;
+    // full tiles of counted panes are streamed; ragged ones go to the general path (as the wave forms do)
+    auto next_streamed = [&](int32_t t, TileRange *tr) -> int32_t {
+        for (; t < n_tiles; t += (int32_t)gridDim.x) {
+            *tr = tiles[t];
+            if (pane_win_ptr[tr->seg] == pane_win_ptr[tr->seg + 1]) continue;
+            if (tr->lo == tr->tile_begin && tr->hi == tr->tile_begin + kQ5Tile) return t;
+            if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = t;
+        }
+        return -1;
+    };
+    auto load_tile = [&](int32_t (&k)[kQ5Iters][4], const TileRange &tr) {
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            const int4 t = stream_load4(auction + tr.tile_begin + it * (kBlock * 4) + threadIdx.x * 4);
+            k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
+        }
+    };
+    TileRange tr;
+    int32_t tile = next_streamed((int32_t)blockIdx.x, &tr);
+    if (tile < 0) return;
+    int32_t k[kQ5Iters][4], kn[kQ5Iters][4];
+    load_tile(k, tr);
+    int par = 0;
+#pragma unroll 1
+    for (;;) {
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(hist);
+            for (int s2 = threadIdx.x; s2 < (kHist + kHistPad) / 4; s2 += kBlock) z[s2] = make_uint4(0, 0, 0, 0);
+        }
+        int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            mn = min(mn, min(min(k[it][0], k[it][1]), min(k[it][2], k[it][3])));
+            mx = max(mx, max(max(k[it][0], k[it][1]), max(k[it][2], k[it][3])));
+        }
+        // the next tile: its descriptor, then its rows -- in flight from here to the top of the next trip
+        TileRange trn;
+        const int32_t next = next_streamed(tile + (int32_t)gridDim.x, &trn);
+        if (next >= 0) load_tile(kn, trn);
+        mn = wave_min_i32(mn);
+        mx = wave_max_i32(mx);
+        if (lane == 0) {
+            s_red[par][wave] = mn;
+            s_red[par][4 + wave] = mx;
+        }
+        lds_barrier();   // (histogram zeroed, extrema posted)
+        mn = min(min(s_red[par][0], s_red[par][1]), min(s_red[par][2], s_red[par][3]));
+        mx = max(max(s_red[par][4], s_red[par][5]), max(s_red[par][6], s_red[par][7]));
+        par ^= 1;
+        const uint32_t span = (uint32_t)mx - (uint32_t)mn;
+        if (span >= (uint32_t)kHist) {   // (block-uniform)
+            if (threadIdx.x == 0) slow_list[1 + atomicAdd(&slow_list[0], 1)] = (int32_t)((uint32_t)tile | kWideTile);
+        } else {
+            int32_t hot = __builtin_amdgcn_readfirstlane(k[0][0]);
+            uint32_t hot_cnt = 0;
+#pragma unroll
+            for (int it = 0; it < kQ5Iters; ++it) {
+                uint64_t b0 = __ballot(k[it][0] == hot);
+                if (__popcll((unsigned long long)b0) < kHotMin) {
+                    if (hot_cnt) {
+                        if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+                        hot_cnt = 0;
+                    }
+                    const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
+                    const uint64_t m1 = __ballot(k[it][0] == c1);
+                    hot = c1;
+                    b0 = m1;
+                    if (__popcll((unsigned long long)m1) < kHotMin && ~m1) {
+                        const int l2 = __ffsll((unsigned long long)~m1) - 1;
+                        const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                        const uint64_t m2 = __ballot(k[it][0] == c2);
+                        if (__popcll((unsigned long long)m2) > __popcll((unsigned long long)m1)) {
+                            hot = c2;
+                            b0 = m2;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool is_hot = k[it][j] == hot;
+                    const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
+                    hot_cnt += (uint32_t)__popcll((unsigned long long)b);
+                    if (!is_hot) atomicAdd(&hist[(uint32_t)k[it][j] - (uint32_t)mn], 1u);
+                }
+            }
+            if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
+            lds_barrier();   // (every wave's adds are in)
+            f.wp0 = pane_win_ptr[tr.seg];
+            f.wp1 = pane_win_ptr[tr.seg + 1];
+            f.pane = panes[tr.seg];
+            for (uint32_t s2 = threadIdx.x; s2 <= span; s2 += kBlock) {
+                const uint32_t c = hist[s2];
+                if (c) emit_pair((int32_t)((uint32_t)mn + s2), c, f);
+            }
+        }
+        if (next < 0) break;
+        lds_barrier();   // (the bins are read: the next trip may zero them)
+        tile = next;
+        tr = trn;
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[it][j] = kn[it][j];
+    }
+}
+
 #endif
 
 // ---- Partial COUNT per tile (the exchange's stage 0): the histogram phase of q5_count_kernel, then the tile's bins are written as
@@ -2060,11 +2186,16 @@ static int q5_run(flockgpu_ctx *ctx, const int32_t *auction, const uint32_t *wei
             FG_HIP(ctx, hipMemcpyAsync(h_sample, d_sample, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         } else if (st.n_tiles > 0 && n_win > 0) {
 #ifdef FLOCKGPU_EXPERIMENTAL
-            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wave1 | wave2 | wave4 | wavep1 | wavep4, FLOCKGPU_Q5_WAVES_PER_CU)
+            // (A/B knob, experimental builds: FLOCKGPU_Q5_COUNT = wg | wave1 | wave2 | wave4 | wavep1 | wavep4 | wgp, FLOCKGPU_Q5_WAVES_PER_CU)
             static const char *count_form_env = exp_env("FLOCKGPU_Q5_COUNT");
             const int wave_form = weight ? 0 : count_form_env ? (!strcmp(count_form_env, "wave1") ? 1 : !strcmp(count_form_env, "wave2") ? 2 : !strcmp(count_form_env, "wave4") ? 4 :
-                                                                   !strcmp(count_form_env, "wavep1") ? 101 : !strcmp(count_form_env, "wavep4") ? 104 : 0) : kQ5WaveForm;
-            if (wave_form > 100) {
+                                                                   !strcmp(count_form_env, "wavep1") ? 101 : !strcmp(count_form_env, "wavep4") ? 104 : !strcmp(count_form_env, "wgp") ? 200 : 0) : kQ5WaveForm;
+            if (wave_form == 200) {
+                LaunchScope ls(ctx, "q5_count_kernel");
+                static const int per_cu = exp_env("FLOCKGPU_Q5_WAVES_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_WAVES_PER_CU")) : 5;   // (workgroups per CU here)
+                const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(st.n_tiles, (int64_t)ctx->num_cus * per_cu));
+                hipLaunchKernelGGL(q5_count_wgp_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, auction, st.tiles, st.n_tiles, d_panes, d_ptr, d_idx, counters, tables, cap, d_used, d_err, slow_list, spec_info);
+            } else if (wave_form > 100) {
                 LaunchScope ls(ctx, "q5_count_kernel");
                 const int kw = wave_form - 100;
                 static const int per_cu = exp_env("FLOCKGPU_Q5_WAVES_PER_CU") ? atoi(exp_env("FLOCKGPU_Q5_WAVES_PER_CU")) : kQ5WavesPerCu;
