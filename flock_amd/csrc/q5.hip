@@ -897,7 +897,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 6))) 
         // the next tile: its descriptor, then its rows -- in flight from here to the top of the next trip
         TileRange trn;
         const int32_t next = next_streamed(tile + (int32_t)gridDim.x, &trn);
-        if (next >= 0) load_tile(kn, trn);
+        if (next >= 0) {
+            load_tile(kn, trn);
+            __builtin_amdgcn_sched_barrier(0);   // (the requests stay HERE: the scheduler would sink them below the LDS phase to save registers)
+        }
+        __builtin_amdgcn_sched_barrier(0);
         mn = wave_min_i32(mn);
         mx = wave_max_i32(mx);
         if (lane == 0) {
