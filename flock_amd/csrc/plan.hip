@@ -1841,6 +1841,52 @@ struct Exec {
         return valprog_to_rows(ctx, node_key(pl, n, "vprog").c_str(), vb.p, in->rows, rows, n_out);
     }
 
+    // A FilterExec directly under a join (round 6): the filter's surviving rows as a ROW LIST over its input table -- nothing is taken yet.  The
+    // join reads the key column through the list, and its result rows compose with it (via[pair row]), so the columns that only travel
+    // through -- q3's three Utf8 columns of a person -- are gathered ONCE, at the join's output, instead of after the filter and again after
+    // the join (a Utf8 take is three launches and a host wait).  `via` null: `base` is the table itself.
+    struct Lazy {
+        Table base;
+        const int32_t *via = nullptr;
+        int64_t rows = 0;
+    };
+    int exec_lazy(const Node *n, Lazy *z) {
+        if (pl->fused[(size_t)n->id].kind == kNone) {
+            if (n->kind == NKind::Repartition) return exec_lazy(n->in[0].get(), z);
+            if (n->kind == NKind::Filter) {
+                int32_t *rows = nullptr;
+                int64_t n_out = 0;
+                FG_TRY(filter_rows(n, &z->base, &rows, &n_out));
+                z->via = rows;
+                z->rows = n_out;
+                return FLOCKGPU_OK;
+            }
+        }
+        FG_TRY(exec(n, &z->base));
+        z->rows = z->base.rows;
+        return FLOCKGPU_OK;
+    }
+    // column `c` of a lazy table as the join sees it: taken through the row list when there is one
+    int lazy_key(const Node *n, const Lazy &z, int c, const char *what, TCol *out) {
+        *out = z.base.cols[(size_t)c];
+        if (!z.via || !out->present) return FLOCKGPU_OK;
+        const TCol &src = z.base.cols[(size_t)c];
+        FG_TRY(take_column(ctx, node_key(pl, n, what).c_str(), src.c, z.via, z.rows, &out->c));
+        out->subset_of = src.subset_of ? src.subset_of : src.c.values;
+        return FLOCKGPU_OK;
+    }
+    // the join's result rows of one side: the pair rows composed with the side's row list, then ONE take of what the output needs
+    int take_lazy(const Node *n, const Lazy &z, const int32_t *pair_rows, int64_t pairs, int first_out, const char *what, Table *t) {
+        const int32_t *rows = pair_rows;
+        if (z.via && pairs > 0) {
+            int32_t *composed = nullptr;
+            FG_TRY(arena_get_t(ctx, node_key(pl, n, what).c_str(), (size_t)pairs + 4, &composed));
+            FG_TRY(gather_i32(ctx, z.via, pair_rows, pairs, composed));
+            rows = composed;
+        }
+        return take_table(n, z.base, n->required, rows, pairs, first_out, t);
+    }
+
     int exec(const Node *n, Table *t) {
         const FusedInfo &fi = pl->fused[(size_t)n->id];
         if (fi.kind != kNone && !leaf_has_validity(fi.leaf_a) && !leaf_has_validity(fi.leaf_b)) {
@@ -1968,16 +2014,19 @@ struct Exec {
                 return FLOCKGPU_OK;
             }
             case NKind::Join: {
-                Table L, R;
-                FG_TRY(exec(n->in[0].get(), &L));
-                FG_TRY(exec(n->in[1].get(), &R));
+                Lazy ZL, ZR;
+                FG_TRY(exec_lazy(n->in[0].get(), &ZL));
+                FG_TRY(exec_lazy(n->in[1].get(), &ZR));
+                const Table &L = ZL.base, &R = ZR.base;
                 t->cols.assign(n->schema.size(), TCol{});
-                const TCol &lk = L.cols[(size_t)n->on_l], &rk = R.cols[(size_t)n->on_r];
+                TCol lk, rk;
+                FG_TRY(lazy_key(n, ZL, n->on_l, "lzkl", &lk));
+                FG_TRY(lazy_key(n, ZR, n->on_r, "lzkr", &rk));
                 const bool text_keys = lk.c.type == ColType::UTF8 && rk.c.type == ColType::UTF8 && n->on_l2 < 0;
                 if (!text_keys && ((lk.c.type == ColType::U64) != (rk.c.type == ColType::U64) || lk.c.type == ColType::UTF8 || rk.c.type == ColType::UTF8 ||
                                    lk.c.type == ColType::F64 || rk.c.type == ColType::F64))
                     return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: join keys must be integer columns of one signedness, or two Utf8 columns");
-                int64_t nl = L.rows, nr = R.rows;
+                int64_t nl = ZL.rows, nr = ZR.rows;
                 if (lk.c.all_null) nl = 0;  // NULL keys never match
                 if (rk.c.all_null) nr = 0;
                 // (NULLs in a LEAF's key column were left out at feed: inner-join keys are null-droppable.  A computed key column that carries
@@ -2001,8 +2050,8 @@ struct Exec {
                         FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
                                           &pairs));
                         t->rows = pairs;
-                        FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
-                        return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+                        FG_TRY(take_lazy(n, ZL, lrows, pairs, 0, "lzrl", t));
+                        return take_lazy(n, ZR, rrows, pairs, (int)L.cols.size(), "lzrr", t);
                     }
                 }
                 int64_t *kl = nullptr, *kr = nullptr;
@@ -2020,11 +2069,13 @@ struct Exec {
                         cr.values = kr;
                         FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), cl, nl, 0, nl - 1, cr, nr, &lrows, &rrows, &pairs));
                         t->rows = pairs;
-                        FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
-                        return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+                        FG_TRY(take_lazy(n, ZL, lrows, pairs, 0, "lzrl", t));
+                        return take_lazy(n, ZR, rrows, pairs, (int)L.cols.size(), "lzrr", t);
                     }
                 } else if (n->on_l2 >= 0) {  // two Int32 pairs compare as one 64-bit key
-                    const TCol &lk2 = L.cols[(size_t)n->on_l2], &rk2 = R.cols[(size_t)n->on_r2];
+                    TCol lk2, rk2;
+                    FG_TRY(lazy_key(n, ZL, n->on_l2, "lzkl2", &lk2));
+                    FG_TRY(lazy_key(n, ZR, n->on_r2, "lzkr2", &rk2));
                     if (lk.c.type != ColType::I32 || rk.c.type != ColType::I32 || lk2.c.type != ColType::I32 || rk2.c.type != ColType::I32)
                         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: a two-key join needs Int32 key columns");
                     if (!lk.present || !rk.present || !lk2.present || !rk2.present)
@@ -2041,8 +2092,8 @@ struct Exec {
                 }
                 FG_TRY(join_key64(ctx, node_key(pl, n, "join").c_str(), kl, nl, kr, nr, &lrows, &rrows, &pairs));
                 t->rows = pairs;
-                FG_TRY(take_table(n, L, n->required, lrows, pairs, 0, t));
-                return take_table(n, R, n->required, rrows, pairs, (int)L.cols.size(), t);
+                FG_TRY(take_lazy(n, ZL, lrows, pairs, 0, "lzrl", t));
+                return take_lazy(n, ZR, rrows, pairs, (int)L.cols.size(), "lzrr", t);
             }
         }
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: unknown node");
