@@ -693,7 +693,7 @@ void describe(const flockgpu_plan *pl, const Node *n, int depth, std::ostringstr
     static const char *kinds[] = {"Scan", "Filter", "Project", "Aggregate", "Join", "Repartition", "Sort", "Limit", "Window"};
     os << std::string((size_t)depth * 2, ' ') << kinds[(int)n->kind];
     if (n->kind == NKind::Aggregate) os << "(" << n->mode << ")";
-    if (n->kind == NKind::Repartition) os << "(Hash, " << n->n_parts << ")";
+    if (n->kind == NKind::Repartition) os << (n->hash_diff ? "(HashDiff, " : "(Hash, ") << n->n_parts << ")";
     if (n->kind == NKind::Scan) os << "(" << pl->ir.leaves[(size_t)n->leaf].relation << ")";
     if (n->kind == NKind::Limit) os << "(" << n->limit << ")";
     if (n->kind == NKind::Window)
@@ -764,7 +764,7 @@ void node_sig(const flockgpu_plan *pl, const Node *n, bool top, std::string *o, 
     for (auto &a : n->aggs) *o += a.fn + "." + std::to_string(a.arg) + "." + std::to_string(a.arg2) + "." + std::to_string((int)a.type) + ",";
     *o += "|" + std::to_string(n->on_l) + "," + std::to_string(n->on_r) + "," + std::to_string(n->on_l2) + "," + std::to_string(n->on_r2) + (n->join_partitioned ? "p" : "") + "|";
     for (int c : n->hash_cols) *o += std::to_string(c) + ",";
-    *o += std::to_string(n->n_parts) + "|";
+    *o += std::to_string(n->n_parts) + (n->hash_diff ? "d" : "") + "|";
     for (auto &k : n->sort_cols) *o += std::to_string(k.col) + (k.descending ? "d" : "a") + (k.nulls_first ? "f" : "l") + ",";
     *o += std::to_string(n->limit) + "|";
     for (auto &part : n->win_part) {   // (Window: the PARTITION BY columns of each ROW_NUMBER())
@@ -2623,6 +2623,29 @@ int run_plan(flockgpu_plan *plan, bool partitioned, ArrowSchema *out_schema, Arr
         }
         if (k.c.valid) FG_TRY(replace_invalid_i64(ctx, keys, k.c.valid, n_rows, 0));   // (NULL keys: one key as far as placement goes; the slot's bytes are unspecified)
         int32_t *rows = nullptr;
+        if (root->hash_diff) {
+            // HashDiff(exprs, n): every DISTINCT key a partition of its own (session.rs:236-253: n is COUNT(DISTINCT key), counted by the host
+            // just before).  A stable sort of the rows by the key groups them, input order kept inside a key; the partitions come out in key
+            // order (which partition a key gets is as unobservable as under Hash).  More distinct keys than n: the host's count does not fit
+            // the data -- refused; fewer: the partitions behind the last key are empty.
+            if (k.c.type == ColType::UTF8 || k.c.type == ColType::F64) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: HashDiff on a key that is not an integer column");
+            if (k.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: HashDiff on a key column that holds NULLs");
+            if (root->hash_cols.size() != 1) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: HashDiff on more than one key column");
+            const SortKey sk{k.c, false, false};
+            FG_TRY(sort_rows(ctx, node_key(plan, root, "hdsort").c_str(), &sk, 1, n_rows, &rows));
+            int32_t *starts = nullptr;
+            int64_t n_keys = 0;
+            FG_TRY(key_run_starts(ctx, node_key(plan, root, "hdruns").c_str(), keys, rows, n_rows, &starts, &n_keys));
+            if (n_keys > root->n_parts)
+                return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: HashDiff names %d partitions, the key column holds %lld distinct keys", root->n_parts, (long long)n_keys);
+            std::vector<int32_t> h_starts((size_t)n_keys);
+            if (n_keys) {
+                FG_HIP(ctx, hipMemcpyAsync(h_starts.data(), starts, sizeof(int32_t) * (size_t)n_keys, hipMemcpyDeviceToHost, ctx->stream));
+                FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            part_off.assign((size_t)root->n_parts + 1, n_rows);
+            for (int64_t g = 0; g < n_keys; ++g) part_off[(size_t)g] = h_starts[(size_t)g];
+        } else
         FG_TRY(partition_rows_key64(ctx, node_key(plan, root, "part").c_str(), keys, n_rows, root->n_parts, &rows, &part_off));
         if (compose) {   // send order over the filter's input: sel[rows[i]]
             int32_t *composed = nullptr;

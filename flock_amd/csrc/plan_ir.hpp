@@ -112,6 +112,7 @@ struct Node {
     bool join_partitioned = false;  // Join: mode=Partitioned (both inputs arrive hash-partitioned on the keys)
     std::vector<int> hash_cols;     // Repartition
     int n_parts = 0;
+    bool hash_diff = false;         // Repartition: HashDiff -- one partition per DISTINCT key (n_parts = what the host counted)
     std::vector<SortCol> sort_cols; // Sort: ORDER BY keys, most significant first
     int64_t limit = -1;             // Limit: rows kept
     std::vector<std::vector<int>> win_part;   // Window: per ROW_NUMBER() column (they come FIRST in the schema), the input columns of its PARTITION BY
@@ -360,6 +361,12 @@ struct Builder {
         if (t == "repartition_exec") {
             const JValue *part = j->get("partitioning");
             const JValue *hash = part ? part->get("Hash") : nullptr;
+            // HashDiff(exprs, n): the fork's own variant (flock-function/src/aws/window/session.rs:252, global.rs:234; datasource/nexmark/queries/
+            // q6.rs:128, q11.rs:168, q12.rs:136): n = COUNT(DISTINCT key), "each partition has a unique key after repartition execution"
+            if (!hash && part && part->get("HashDiff")) {
+                hash = part->get("HashDiff");
+                n->hash_diff = true;
+            }
             if (!hash) return node(j->get("input"), depth + 1);  // RoundRobinBatch(n)
             if (hash->kind != JValue::Arr || hash->arr.size() != 2 || hash->arr[0]->kind != JValue::Arr || hash->arr[1]->kind != JValue::Num) {
                 fail("malformed Hash partitioning");

@@ -798,6 +798,12 @@ __global__ __launch_bounds__(kBlock) void max_kernel(const void *__restrict__ v,
     }
 }
 
+// mask[i] = 1 where position i of the sorted order begins a new key (HashDiff's partition boundaries)
+__global__ __launch_bounds__(kBlock) void key_run_start_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ order, int64_t n, uint8_t *__restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        mask[i] = i == 0 || keys[order[i]] != keys[order[i - 1]] ? 1 : 0;
+}
+
 // ---- join
 __global__ __launch_bounds__(kBlock) void join_init_kernel(int64_t *__restrict__ tk, int32_t *__restrict__ head, int64_t slots) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
@@ -1964,6 +1970,17 @@ int join_dense(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64
     *right_rows = orr;
     *n_pairs = total;
     return FLOCKGPU_OK;
+}
+
+int key_run_starts(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const int32_t *order, int64_t rows, int32_t **starts, int64_t *n_keys) {
+    const std::string base = name;
+    *starts = nullptr;
+    *n_keys = 0;
+    if (rows <= 0) return FLOCKGPU_OK;
+    uint8_t *mask = nullptr;
+    FG_TRY(arena_get_t(ctx, (base + ".mask").c_str(), (size_t)rows + 16, &mask));
+    RELOPS_LAUNCH(ctx, "key_run_start_kernel", key_run_start_kernel, rows, keys, order, rows, mask);
+    return mask_to_rows(ctx, (base + ".sel").c_str(), mask, rows, starts, n_keys);
 }
 
 int row_number_runs(flockgpu_ctx *ctx, const char *name, const DevColumn *cols, int n_cols, int64_t rows, uint64_t *out) {

@@ -156,6 +156,9 @@ struct SortKey {
     bool nulls_first = false;   // where the rows whose col.valid is 0 go (SortOptions of the plan; DESC does not move them)
 };
 int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows);
+// keys[order[i]] is non-decreasing in i (sort_rows' output): starts = the positions i where a new key begins (ascending; device), *n_keys of them.
+// One host wait.
+int key_run_starts(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const int32_t *order, int64_t rows, int32_t **starts, int64_t *n_keys);
 
 // u32 -> u64 (COUNT partial states are UInt64 in the reference's schemas)
 int widen_u32_to_u64(flockgpu_ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out);

@@ -466,6 +466,22 @@ def repartition_hash(partitions: Sequence[Sequence[Table]], key: str, n: int,
     return out
 
 
+def repartition_hash_diff(t: Table, key: str, n: int) -> List[Table]:
+    """HashDiff(exprs, n) -- the fork's own Partitioning variant (flock-function/src/aws/window/session.rs:236-253, global.rs:234; datasource/nexmark/
+    queries/q6.rs:128, q11.rs:168): n is COUNT(DISTINCT key), counted by the host just before, and "each partition has a unique key after repartition
+    execution".  The implementation lives in the absent DataFusion fork; what the call sites rely on -- and all this restates -- is: every distinct key
+    a partition of its own, rows in input order inside it, which partition a key gets unobservable (the session code keys its map by the partition's
+    first row, session.rs:262-280).  Here: partitions in ascending key order, empty ones behind them when n exceeds the distinct count."""
+    keys = sorted(set(t[key]))
+    if len(keys) > n:
+        raise ValueError("HashDiff: more distinct keys than partitions")
+    out: List[Table] = []
+    for k in keys:
+        sel = [i for i, v in enumerate(t[key]) if v == k]
+        out.append({c: [v[i] for i in sel] for c, v in t.items()})
+    return out + [{c: [] for c in t} for _ in range(n - len(keys))]
+
+
 # -- the five NEXMark plans on top of the generic operators ------------------------------------------
 def nexmark_q1(bid: Table) -> Table:
     return projection_exec(bid, [("auction", lambda r: r["auction"]), ("bidder", lambda r: r["bidder"]),

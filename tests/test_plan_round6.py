@@ -119,3 +119,57 @@ def test_division_and_remainder_by_literals_at_the_edges(gpu):
         finally:
             ctx.close()
         assert norm(pyrows(rb)) == norm(g.rows(g.project_typed(t, part, TYPES))), [nm for _, nm in part]
+
+
+def _hash_diff_plan(key, n, below=None):
+    return {"execution_plan": "repartition_exec", "input": below or scan(), "partitioning": {"HashDiff": [[col(key)], n]}}
+
+
+def test_hash_diff_partitioning_parses_and_the_oracle_gives_every_key_its_partition():
+    """`Partitioning::HashDiff(exprs, n)` (the fork's variant: flock-function/src/aws/window/session.rs:252) is part of the plan dialect since
+    round 6; the oracle's restatement: one partition per distinct key, input order inside."""
+    from flock_amd.runtime import explain
+    t = {"i": [3, 1, 3, 2, 1, 3], "x": [10, 11, 12, 13, 14, 15]}
+    parts = g.repartition_hash_diff(t, "i", 4)
+    assert [p["i"] for p in parts] == [[1, 1], [2], [3, 3, 3], []] and [p["x"] for p in parts] == [[11, 14], [13], [10, 12, 15], []]
+    with pytest.raises(ValueError):
+        g.repartition_hash_diff(t, "i", 2)
+    txt = explain(_hash_diff_plan("i", 4))
+    assert "HashDiff, 4" in txt and "not supported" not in txt, txt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["i", "j", "l"])
+def test_hash_diff_repartition_gives_every_distinct_key_a_partition(gpu, key):
+    """The session / global window launchers repartition a window's rows by `HashDiff(key, COUNT(DISTINCT key))` (session.rs:236-253): every
+    distinct key one partition, rows in input order inside it.  Also under a FilterExec (the composed send order), and with more partitions
+    named than keys exist (empty partitions behind) or fewer (refused)."""
+    from flock_amd import FlockGpuError, _ffi
+    from flock_amd.runtime import ExecutionContext
+    r = np.random.default_rng(252)
+    n = 30_000
+    t = table(n, r, null_p=0.0)
+    t[key] = [int(x) for x in r.choice(np.array([-7, 0, 5, 11, 2**20, 2**20 + 1, 99]) if key != "l" else np.array([-2**40, -1, 0, 3, 2**35, 2**35 + 7]), n)]
+    distinct = len(set(t[key]))
+
+    def run(plan):
+        ctx = ExecutionContext([plan], gpu=gpu)
+        try:
+            ctx.feed_data_sources([[batches(t, 7_000)]])
+            assert ctx.is_shuffling()
+            return [pyrows(b[0]) for b in ctx.execute_partitioned()[0]]
+        finally:
+            ctx.close()
+    for n_parts in (distinct, distinct + 3):
+        got = run(_hash_diff_plan(key, n_parts))
+        want = [g.rows(p) for p in g.repartition_hash_diff(t, key, n_parts)]
+        assert len(got) == n_parts and sorted(map(tuple, (norm(p) for p in got))) == sorted(map(tuple, (norm(p) for p in want)))
+        assert sum(len(p) for p in got) == n and all(len({row[NAMES.index(key)] for row in p}) <= 1 for p in got)
+    pred = binary(col("j" if key != "j" else "i"), "Gt", lit("Int32", 0))
+    got = run(_hash_diff_plan(key, distinct, {"execution_plan": "filter_exec", "predicate": pred, "input": scan()}))
+    kept = g.filter_by_expr(t, pred)
+    want = [g.rows(p) for p in g.repartition_hash_diff(kept, key, distinct)]
+    assert sorted(map(tuple, (norm(p) for p in got))) == sorted(map(tuple, (norm(p) for p in want)))
+    with pytest.raises(FlockGpuError) as e:
+        run(_hash_diff_plan(key, distinct - 1))
+    assert e.value.code == _ffi.ERR_INVALID and "distinct keys" in str(e.value)
