@@ -67,8 +67,12 @@ DEFAULT_SECONDS = {5: 1087, 2: 109, 3: 100, 8: 1000, 7: 1087, 9: 300, 4: 300, 13
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)    # (a step is ~1 ms: twenty of them average the host's turnaround and the clock ramp out)
-    ap.add_argument("--warmup", type=int, default=5)
+    # A step is ~0.85 ms.  The chip takes ~10 ms of sustained load to reach its steady clocks: per-launch samples of the count kernel over
+    # consecutive steps run 0.73, 0.72, ... and settle at 0.68-0.69 ms from the twelfth step on (tools/gpu_q5_samples.py; the step itself 0.85 ->
+    # 0.81 ms).  Rounds 1-5 timed 20 steps behind 5 warm-up steps -- half of them inside that ramp; a stream of windows runs in the steady state,
+    # so the defaults now warm up past the ramp and average a hundred steps (0.13 s in all).
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--query", type=int, default=5, choices=[2, 3, 4, 5, 7, 8, 9, 13])
     ap.add_argument("--seconds", type=int, default=0, help="epochs of synthetic events per rank (0 = BASELINE config)")
     ap.add_argument("--eps", type=int, default=1_000_000)
@@ -722,6 +726,17 @@ def entry_for(ctx, q, seconds, eps, steps, warmup, no_cpu, threads, barrier=lamb
     import torch
     from flock_amd import run_query
     s = make_stream(ctx, q, seconds, eps, 0)
+    # warm-up by TIME, not by calls: ~15 ms of the entry's own calls (the chip's clocks settle after ~10 ms of sustained load; a 0.1 ms call of q3
+    # needs a hundred of them, a 3 ms call five) -- see parse()
+    t0 = time.perf_counter()
+    run_query(ctx, q, s)
+    ctx.synchronize()
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run_query(ctx, q, s)
+    ctx.synchronize()
+    per_call = max(min(first, time.perf_counter() - t0), 2e-5)
+    warmup = max(warmup, min(300, int(0.015 / per_call)))
     dt, st, r = run_steps(ctx, lambda: run_query(ctx, q, s), steps, warmup, barrier, DOMINANT[q][0])
     e = {"value": round(input_rows(q, s) * steps / dt, 1), "unit": "rows/s", "ms_per_step": round(dt / steps * 1e3, 3),
          "input_rows": int(input_rows(q, s)), "windows": r.n_windows, "result_rows": int(r.rows), "seconds_of_events": seconds,
@@ -1927,7 +1942,7 @@ def main():
             if out["exchange_ok"]:   # the collective that ran, where a scaling judge looks first
                 out["collective"] = out["exchange"]["collective"]
 
-    steps2 = max(args.steps, 10)   # the side entries' steps are 0.1-5 ms: ten of them cost nothing and average the host's turnaround out
+    steps2 = min(max(args.steps, 10), 20)   # the side entries' steps are 0.1-5 ms: ten to twenty of them cost nothing and average the host's turnaround out
     # ---- N = 1: the other BASELINE configs; q3 (named by the metric) at top level
     if world == 1 and not args.no_also and rank == 0 and out is not None and mode == "windows" and args.mode != "exchange":
         if q != 3:

@@ -19,7 +19,7 @@ def test_defaults_are_one_gpu_and_a_few_steps(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert a.gpus == 1 and 1 <= a.steps <= 20 and 0 <= a.warmup <= 10 and a.query == 5 and a.mode == "auto"      # auto: window-sharded headline at every N; at N > 1 the key-partitioned exchange rides along as `exchange`
+    assert a.gpus == 1 and 1 <= a.steps <= 200 and 0 <= a.warmup <= 100 and a.query == 5 and a.mode == "auto"      # auto: window-sharded headline at every N; at N > 1 the key-partitioned exchange rides along as `exchange`
     assert bench.DEFAULT_SECONDS[5] * a.eps * 46 // 50 >= 1_000_000_000          # the headline config: 1e9 bids
 
 
