@@ -1115,6 +1115,9 @@ ARCH_OPS = {
     "groupby": ("dense_group_kernel", "q5_partial_tile_kernel", 4.0),
     "join": ("join_probe_unique_flag_kernel", "join_probe_unique_flag_kernel", 4.0),   # the probe side's key column, once (unique build keys: the flag-tile probe)
     "sort": ("sort_emit_kernel", "sort_emit_kernel", 16.0),       # one radix pass: key + row number in and out
+    # join.sql with its keys scrambled (id * 2654435761 mod 2^32, a bijection: the same pairs) so that no dense range covers them: the generic
+    # hash join (relops.hpp join_key64).  The probe reads a widened 8-byte key per bid and one 16-byte table slot per bid at a hashed position.
+    "join_sparse": ("join_hash_probe_flag_kernel", "join_hash_probe_flag_kernel", 24.0),
 }
 
 
@@ -1159,14 +1162,19 @@ def arch_ops(gpu, eps, steps, no_cpu, seconds=100):
     join_bids, join_aucs = bid_rb.slice(0, jn // 50 * 46), auc_rb.slice(0, jn // 50 * 3)
     out["input"]["join"] = {"bids": int(join_bids.num_rows), "auctions": int(join_aucs.num_rows)}
     in_bytes["join"] = float(join_bids.nbytes + join_aucs.nbytes)
-    for name in ("filter", "groupby", "join", "sort"):
-        plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", f"arch_{name}.json")))
+    def scrambled(rb, col):   # the same relation with its key column multiplied by an odd constant mod 2^32 (read back as Int32)
+        k = (rb.column(col).to_numpy().astype(np.uint32) * np.uint32(2654435761)).view(np.int32)
+        return rb.set_column(rb.schema.get_field_index(col), col, pa.array(k))
+    sparse_bids, sparse_aucs = scrambled(join_bids, "auction"), scrambled(join_aucs, "a_id")
+    in_bytes["join_sparse"] = in_bytes["join"]
+    for name in ("filter", "groupby", "join", "join_sparse", "sort"):
+        plan = json.load(open(os.path.join(ROOT, "tests", "golden", "plans", "arch_%s.json" % name.split("_")[0])))
         e = {}
-        n_bids = join_bids.num_rows if name == "join" else bid_rb.num_rows
+        n_bids = join_bids.num_rows if name.startswith("join") else bid_rb.num_rows
         for mode in ("fused", "generic"):
             ctx = ExecutionContext([plan], gpu=gpu, generic_only=(mode == "generic"))
             try:
-                ctx.feed_data_sources([[[join_bids]], [[join_aucs]]] if name == "join" else [[[bid_rb]], [[auc_rb]]])
+                ctx.feed_data_sources([[[join_bids]], [[join_aucs]]] if name == "join" else [[[sparse_bids]], [[sparse_aucs]]] if name == "join_sparse" else [[[bid_rb]], [[auc_rb]]])
                 pl = ctx.plans[0]
                 gpu.synchronize()
                 t0 = time.perf_counter()

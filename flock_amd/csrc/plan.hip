@@ -2086,6 +2086,13 @@ struct Exec {
                     FG_TRY(arena_get_t(ctx, node_key(pl, n, "kr").c_str(), (size_t)nr + 2, &kr));
                     FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(lk.c.values), static_cast<const int32_t *>(lk2.c.values), nl, kl));
                     FG_TRY(pack_i32_pair(ctx, static_cast<const int32_t *>(rk.c.values), static_cast<const int32_t *>(rk2.c.values), nr, kr));
+                } else if (!join_is_tiny(nl, nr) && nl > 0 && nr > 0 && (lk.c.type == ColType::I32 || lk.c.type == ColType::I64 || lk.c.type == ColType::U64) &&
+                           (rk.c.type == ColType::I32 || rk.c.type == ColType::I64 || rk.c.type == ColType::U64)) {   // one integer key pair, not dense: the hashed table, keys read in their own types
+                    if (!lk.present || !rk.present) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: key column was not materialised");
+                    FG_TRY(join_hashed(ctx, node_key(pl, n, "join").c_str(), lk.c, nl, rk.c, nr, &lrows, &rrows, &pairs));
+                    t->rows = pairs;
+                    FG_TRY(take_lazy(n, ZL, lrows, pairs, 0, "lzrl", t));
+                    return take_lazy(n, ZR, rrows, pairs, (int)L.cols.size(), "lzrr", t);
                 } else {
                     FG_TRY(key_i64(n, lk, nl, "kl", &kl));
                     FG_TRY(key_i64(n, rk, nr, "kr", &kr));

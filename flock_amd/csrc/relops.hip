@@ -804,49 +804,150 @@ __global__ __launch_bounds__(kBlock) void key_run_start_kernel(const int64_t *__
         mask[i] = i == 0 || keys[order[i]] != keys[order[i - 1]] ? 1 : 0;
 }
 
-// ---- join
-__global__ __launch_bounds__(kBlock) void join_init_kernel(int64_t *__restrict__ tk, int32_t *__restrict__ head, int64_t slots) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < slots; i += (int64_t)gridDim.x * kBlock) {
-        tk[i] = kEmptyKey;
-        head[i] = -1;
-    }
+// ---- join on a hashed key (join_hashed): an open-addressing table of 16-byte slots -- the key, the build row that claimed the slot, the head of
+// the chain of the key's FURTHER build rows -- so that a probe is ONE 16-byte read at a hashed position (plus the linear-probe steps of a table at
+// most half full), and a build row of a key nobody else holds is one compare-and-swap and a plain store.  (Rounds 2-5 kept keys, chain heads and
+// links in three arrays: a claim, an exchange and a link store per build row, three dependent reads per probe row, the chain walked twice.)
+struct __attribute__((aligned(16))) JoinSlot {
+    int64_t key;     // kEmptyKey: free (the key INT64_MIN itself lives in the extra slot `cap`, claimed through `first`)
+    int32_t first;   // the build row whose insert claimed the slot (written by that insert alone); -1 while free
+    int32_t head;    // chain of the key's other build rows (push front, links in next[]); -1: none -- the build keys seen so far are unique
+};
+__global__ __launch_bounds__(kBlock) void join_hash_init_kernel(JoinSlot *__restrict__ slots, int64_t n_slots) {
+    const int4 e = make_int4((int32_t)(uint32_t)(uint64_t)kEmptyKey, (int32_t)((uint64_t)kEmptyKey >> 32), -1, -1);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * kBlock) reinterpret_cast<int4 *>(slots)[i] = e;
 }
-__global__ __launch_bounds__(kBlock) void join_build_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t *tk, int32_t *head,
-                                                            int32_t *__restrict__ next, uint64_t cap, uint32_t *err) {
+__global__ __launch_bounds__(kBlock) void join_hash_build_kernel(const void *__restrict__ keys, int32_t type, int64_t n, JoinSlot *slots, uint64_t cap,
+                                                                 int32_t *__restrict__ next, uint32_t *err) {
+    bool dup = false;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t key = keys[i];
-        const int64_t s = claim_slot(tk, cap, key);
-        if (s < 0) {
+        const int64_t key = load_as_i64(keys, type, i);
+        uint64_t s = cap;
+        bool mine = false, placed = true;
+        if (key == kEmptyKey) {
+            mine = atomicCAS(&slots[cap].first, -1, (int32_t)i) == -1;
+            if (mine) continue;   // (`first` holds the row already)
+        } else {
+            placed = false;
+            s = mix64((uint64_t)key) & (cap - 1);
+            for (uint64_t probe = 0; probe < cap; ++probe) {
+                // (the swap first, no look before it: in a table at most half full most home slots are free, and a failed swap returns what a
+                // load would have -- one trip to the memory side per step instead of two)
+                int64_t cur = kEmptyKey;
+                if (__hip_atomic_compare_exchange_strong(&slots[s].key, &cur, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    mine = placed = true;
+                    break;
+                }
+                if (cur == key) {
+                    placed = true;
+                    break;
+                }
+                s = (s + 1) & (cap - 1);
+            }
+        }
+        if (!placed) {   // (cannot happen in a table at most half full)
             atomicOr(err, 1u);
             continue;
         }
-        if (s == (int64_t)cap) tk[s] = key;
-        next[i] = atomicExch(&head[s], (int32_t)i);  // push front: the chain is walked only after the kernel boundary
+        if (mine) slots[s].first = (int32_t)i;   // only the claiming insert writes here; read after the kernel boundary
+        else {
+            next[i] = atomicExch(&slots[s].head, (int32_t)i);  // push front: the chain is walked only after the kernel boundary
+            dup = true;
+        }
     }
+    if (dup) atomicOr(err + 1, 1u);   // (err[1]: some key occurs twice on the build side -- the probe then counts and walks chains)
 }
+// the slot of `key`: its claiming row (>= 0) and chain head, or -1
+__device__ __forceinline__ int32_t join_hash_find(const JoinSlot *__restrict__ slots, uint64_t cap, int64_t key, int4 v, uint64_t s, int32_t *head) {
+    // v = the slot at s, already loaded (callers issue several rows' first loads together)
+    for (uint64_t probe = 0; probe < cap; ++probe) {
+        const int64_t k = (int64_t)((uint64_t)(uint32_t)v.x | ((uint64_t)(uint32_t)v.y << 32));
+        if (k == key) {
+            *head = v.w;
+            return v.z;
+        }
+        if (k == kEmptyKey) return -1;
+        s = (s + 1) & (cap - 1);
+        v = reinterpret_cast<const int4 *>(slots)[s];
+    }
+    return -1;
+}
+__device__ __forceinline__ uint64_t join_hash_home(uint64_t cap, int64_t key) { return key == kEmptyKey ? cap : mix64((uint64_t)key) & (cap - 1); }
+__device__ __forceinline__ int32_t join_hash_lookup(const JoinSlot *__restrict__ slots, uint64_t cap, int64_t key, int32_t *head) {
+    const uint64_t s = join_hash_home(cap, key);
+    const int4 v = reinterpret_cast<const int4 *>(slots)[s];
+    if (key == kEmptyKey) {
+        *head = v.w;
+        return v.z;
+    }
+    return join_hash_find(slots, cap, key, v, s, head);
+}
+// ---- probe of a hashed table whose build keys are UNIQUE: as join_probe_unique_flag_kernel below -- the join is a filter of the probe side in the
+// flag-tile geometry -- with the matching build row of every probe row stored beside the flags (match[row], coalesced), so that the build side's
+// row list is one gather of `match` at the emitted rows instead of a second walk through the table.  A lane's four rows of one iteration have their
+// slots requested together: four independent 16-byte reads in flight per lane before the first is looked at.
+template <bool kI32>
+__global__ __launch_bounds__(kBlock) void join_hash_probe_flag_kernel(const void *__restrict__ keys, int64_t n, SegTiles st, const JoinSlot *__restrict__ slots, uint64_t cap,
+                                                                      uint32_t *__restrict__ flag_words, uint32_t *__restrict__ counts, int32_t *__restrict__ match) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int64_t wbase = tr.tile_begin + flag_rel0();
+    uint32_t flags = 0;
+    int32_t a[kFlagIters][4];
+    if (kI32) load_flag_tile(static_cast<const int32_t *>(keys), n, tr, a);
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) {
+        int64_t key[4];
+        uint64_t home[4];
+        int4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = wbase + it * 256 + j;
+            key[j] = kI32 ? (int64_t)a[it][j] : (r < n ? static_cast<const int64_t *>(keys)[r] : 0);
+            home[j] = join_hash_home(cap, key[j]);
+            v[j] = reinterpret_cast<const int4 *>(slots)[home[j]];
+        }
+        int32_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = wbase + it * 256 + j;
+            int32_t head;
+            m[j] = key[j] == kEmptyKey ? v[j].z : join_hash_find(slots, cap, key[j], v[j], home[j], &head);
+            if (r >= n) m[j] = -1;
+            flags |= (uint32_t)(m[j] >= 0) << (it * 4 + j);
+        }
+        const int64_t r0 = wbase + it * 256;
+        if (r0 + 4 <= n) *reinterpret_cast<int4 *>(match + r0) = make_int4(m[0], m[1], m[2], m[3]);   // (r0 is a multiple of 4, `match` 16-byte aligned)
+        else
+            for (int j = 0; j < 4; ++j)
+                if (r0 + j < n) match[r0 + j] = m[j];
+    }
+    store_flags_and_counts(flags, tile, flag_words, counts);
+}
+__global__ __launch_bounds__(kBlock) void join_match_take_kernel(const int32_t *__restrict__ match, const int32_t *__restrict__ right, int64_t n_pairs, int32_t *__restrict__ left) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * kBlock) left[i] = match[right[i]];
+}
+// build keys that repeat: pairs per probe row counted (the claiming row + its chain), scanned, emitted -- a key's build rows in chain order
 template <bool kEmit>
-__global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__restrict__ keys, int64_t n, const int64_t *__restrict__ tk,
-                                                            const int32_t *__restrict__ head, const int32_t *__restrict__ next, uint64_t cap,
-                                                            int32_t *__restrict__ counts, int32_t *__restrict__ out_left,
-                                                            int32_t *__restrict__ out_right, unsigned long long *__restrict__ total64) {
+__global__ __launch_bounds__(kBlock) void join_hash_probe_kernel(const void *__restrict__ keys, int32_t type, int64_t n, const JoinSlot *__restrict__ slots, uint64_t cap,
+                                                                 const int32_t *__restrict__ next, int32_t *__restrict__ counts, int32_t *__restrict__ out_left,
+                                                                 int32_t *__restrict__ out_right, unsigned long long *__restrict__ total64) {
     unsigned long long mine = 0;   // count pass: the pair total in 64 bits (the 32-bit scan of `counts` wraps beyond 2^32 pairs)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t s = find_slot(tk, cap, keys[i]);
+        int32_t head = -1;
+        const int32_t first = join_hash_lookup(slots, cap, load_as_i64(keys, type, i), &head);
         int32_t c = 0;
-        if (s >= 0) {
-            // (inclusive scan in `counts` when emitting: this row's pairs end at counts[i])
-            int64_t at = 0;
+        if (first >= 0) {
+            c = 1;
+            for (int32_t r = head; r >= 0; r = next[r]) ++c;
             if (kEmit) {
-                int32_t m = 0;
-                for (int32_t r = head[s]; r >= 0; r = next[r]) ++m;
-                at = (int64_t)counts[i] - m;
-            }
-            for (int32_t r = head[s]; r >= 0; r = next[r]) {
-                if (kEmit) {
-                    out_left[at + c] = r;
-                    out_right[at + c] = (int32_t)i;
+                int64_t at = (int64_t)counts[i] - c;   // (inclusive scan: this row's pairs end at counts[i])
+                out_left[at] = first;
+                out_right[at++] = (int32_t)i;
+                for (int32_t r = head; r >= 0; r = next[r]) {
+                    out_left[at] = r;
+                    out_right[at++] = (int32_t)i;
                 }
-                ++c;
             }
         }
         if (!kEmit) {
@@ -860,7 +961,7 @@ __global__ __launch_bounds__(kBlock) void join_probe_kernel(const int64_t *__res
     }
 }
 // ---- join on a DENSE integer key (join_dense): the build side's key offsets from their minimum address the chain heads directly -- the
-// multimap of join_build_kernel without a key table, a claim or a probe walk.  Keys are read in their column's own type (no int64 copy).
+// multimap of join_hash_build_kernel without a key table, a claim or a probe walk.  Keys are read in their column's own type (no int64 copy).
 __global__ __launch_bounds__(kBlock) void join_build_dense_kernel(const void *__restrict__ keys, int32_t type, int64_t n, int64_t kmin, uint32_t range,
                                                                   int32_t *head, int32_t *__restrict__ next, uint32_t *err) {
     bool dup = false;
@@ -1827,21 +1928,35 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
         *n_pairs = (int64_t)h_tot[0];
         return FLOCKGPU_OK;
     }
+    DevColumn cl, cr;
+    cl.type = cr.type = ColType::I64;
+    cl.values = left;
+    cr.values = right;
+    return join_hashed(ctx, name, cl, n_left, cr, n_right, left_rows, right_rows, n_pairs);
+}
+
+int join_hashed(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64_t n_left, const DevColumn &right, int64_t n_right,
+                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs) {
+    const std::string base = name;
+    *n_pairs = 0;
+    *left_rows = *right_rows = nullptr;
+    auto is_int = [](const DevColumn &c) { return c.type == ColType::I32 || c.type == ColType::I64 || c.type == ColType::U64; };
+    if (!is_int(left) || !is_int(right) || left.valid || right.valid || ((left.type == ColType::U64) != (right.type == ColType::U64)))
+        return fail(ctx, FLOCKGPU_ERR_INVALID, "%s: join keys must be integer columns of one signedness without NULLs", name);
+    if (n_left > 4 * n_right && n_left > 4096)   // the table goes on the smaller side (see join_key64)
+        return join_hashed(ctx, (base + ".swapped").c_str(), right, n_right, left, n_left, right_rows, left_rows, n_pairs);
     if (n_left >= (int64_t(1) << 30) || n_right >= (int64_t(1) << 31))
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relation too large for the generic join", name);
     const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(n_left, 1) * 2);
-    const int64_t slots = (int64_t)cap + 1;
-    int64_t *tk = nullptr;
-    int32_t *head = nullptr, *next = nullptr, *counts = nullptr;
-    // the call's scalars, one block on the device and one in pinned memory: [0] error word, [2..3] 64-bit pair total
+    const int64_t n_slots = (int64_t)cap + 1;
+    JoinSlot *slots = nullptr;
+    int32_t *next = nullptr, *counts = nullptr, *ol = nullptr, *orr = nullptr;
+    // the call's scalars, one block on the device and one in pinned memory: [0] error word, [1] duplicate build keys, [2..] the 64-bit pair total
     uint32_t *d_err = nullptr, *h_err = nullptr;
-    FG_TRY(arena_get_t(ctx, (base + ".tk").c_str(), (size_t)slots, &tk));
-    FG_TRY(arena_get_t(ctx, (base + ".head").c_str(), (size_t)slots, &head));
+    FG_TRY(arena_get_t(ctx, (base + ".slots").c_str(), (size_t)n_slots, &slots));
     FG_TRY(arena_get_t(ctx, (base + ".next").c_str(), (size_t)std::max<int64_t>(n_left, 0) + 4, &next));
-    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
     FG_TRY(arena_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &d_err));
     FG_TRY(pinned_get_t(ctx, (base + ".scalars").c_str(), 2 + 2 * (size_t)kJoinTotalSlots, &h_err));
-    int32_t *ol = nullptr, *orr = nullptr;
     if (n_left <= 0 || n_right <= 0) {
         FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), 4, &ol));
         FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), 4, &orr));
@@ -1851,23 +1966,72 @@ int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t
     }
     unsigned long long *d_tot64 = reinterpret_cast<unsigned long long *>(d_err + 2), *h_tot64 = reinterpret_cast<unsigned long long *>(h_err + 2);
     FG_TRY(fill_words(ctx, FillList().add(d_err, 0u, 2 + 2 * kJoinTotalSlots)));
-    RELOPS_LAUNCH(ctx, "join_init_kernel", join_init_kernel, slots, tk, head, slots);
-    RELOPS_LAUNCH(ctx, "join_build_kernel", join_build_kernel, n_left, left, n_left, tk, head, next, cap, d_err);
-    RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<false>, n_right, right, n_right, tk, head, next, cap, counts, (int32_t *)nullptr,
+    RELOPS_LAUNCH(ctx, "join_hash_init_kernel", join_hash_init_kernel, n_slots, slots, n_slots);
+    RELOPS_LAUNCH(ctx, "join_hash_build_kernel", join_hash_build_kernel, n_left, left.values, (int32_t)left.type, n_left, slots, cap, next, d_err);
+    // Unique build keys (nothing says so before the build has run: this node's previous execute is the guess): the probe as a filter in the
+    // flag-tile geometry.  The build reports duplicates in err[1]; a wrong guess repeats the probe the general way below.
+    std::vector<int64_t> &dups_seen = ctx->host_i64[base + ".dups"];
+    if (dups_seen.empty()) {
+        int64_t sb = 0, se = n_right;
+        SegTiles st;
+        FG_TRY(build_seg_tiles(ctx, (base + ".ptiles").c_str(), &sb, &se, 1, kFlagTile, &st));
+        uint32_t *flags = nullptr, *wcounts = nullptr;
+        uint64_t *tile_base = nullptr;
+        int64_t *h_off = nullptr;
+        int32_t *match = nullptr;
+        FG_TRY(arena_get_t(ctx, (base + ".pflags").c_str(), (size_t)st.n_tiles * kBlock + 4, &flags));
+        FG_TRY(arena_get_t(ctx, (base + ".pcounts").c_str(), (size_t)st.n_tiles * kWavesPerBlock + 4, &wcounts));
+        FG_TRY(arena_get_t(ctx, (base + ".pbase").c_str(), (size_t)st.n_tiles + 1, &tile_base));
+        FG_TRY(arena_get_t(ctx, (base + ".match").c_str(), (size_t)n_right + 4, &match));
+        FG_TRY(pinned_get_t(ctx, (base + ".poff").c_str(), 2, &h_off));
+        FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)n_right + 4, &orr));   // (at most one pair per probe row)
+        pinned_pending(reinterpret_cast<uint64_t *>(h_off), 2);
+        {
+            LaunchScope ls(ctx, "join_hash_probe_flag_kernel");
+            if (right.type == ColType::I32)
+                hipLaunchKernelGGL(join_hash_probe_flag_kernel<true>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, right.values, n_right, st, slots, cap, flags, wcounts, match);
+            else
+                hipLaunchKernelGGL(join_hash_probe_flag_kernel<false>, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, right.values, n_right, st, slots, cap, flags, wcounts, match);
+        }
+        FG_TRY(check_launch(ctx, "join_hash_probe_flag_kernel"));
+        pinned_pending32(h_err, 2);
+        FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2)));
+        if (st.n_tiles <= 2048) {
+            FG_TRY(emit_flagged_rows_self(ctx, st, flags, wcounts, orr, h_off));
+        } else {
+            FG_TRY(launch_tile_scan(ctx, wcounts, st.n_tiles, tile_base, st.tile_first, st.n_seg, h_off));
+            FG_TRY(emit_flagged_rows(ctx, st, flags, wcounts, tile_base, orr));
+        }
+        FG_TRY(wait_pinned(ctx, reinterpret_cast<const uint64_t *>(h_off), 2));
+        FG_TRY(wait_pinned32(ctx, h_err, 2));
+        if (h_err[0]) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
+        if (!h_err[1]) {
+            const int64_t total = h_off[1];
+            FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)total + 4, &ol));
+            if (total > 0) RELOPS_LAUNCH(ctx, "join_match_take_kernel", join_match_take_kernel, total, match, orr, total, ol);
+            *left_rows = ol;
+            *right_rows = orr;
+            *n_pairs = total;
+            return FLOCKGPU_OK;
+        }
+        dups_seen.assign(1, 1);   // duplicates on the build side: counts and chains from here on (the table and the links are built; the probe follows)
+    }
+    FG_TRY(arena_get_t(ctx, (base + ".counts").c_str(), (size_t)std::max<int64_t>(n_right, 0) + 4, &counts));
+    RELOPS_LAUNCH(ctx, "join_hash_probe_kernel", join_hash_probe_kernel<false>, n_right, right.values, (int32_t)right.type, n_right, slots, cap, next, counts, (int32_t *)nullptr,
                   (int32_t *)nullptr, d_tot64);
     FG_TRY(inclusive_scan_i32(ctx, (base + ".scan").c_str(), counts, n_right));
     pinned_pending32(h_err, 2 + 2 * kJoinTotalSlots);
     FG_TRY(publish_words(ctx, PublishList().add(h_err, d_err, 2).add(h_tot64, d_tot64, 2 * kJoinTotalSlots)));
     FG_TRY(wait_pinned32(ctx, h_err, 2 + 2 * kJoinTotalSlots));
     for (int sl = 1; sl < kJoinTotalSlots; ++sl) h_tot64[0] += h_tot64[sl];
-    if (*h_err) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
+    if (h_err[0]) return fail(ctx, FLOCKGPU_ERR_CAPACITY, "%s: join table overflow", name);
     // the 64-bit total decides: the 32-bit inclusive scan of `counts` is only read when it cannot have wrapped
     if (h_tot64[0] >= (1ull << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: join output of %llu rows exceeds 2^31", name, h_tot64[0]);
     const int64_t total = (int64_t)h_tot64[0];
     FG_TRY(arena_get_t(ctx, (base + ".ol").c_str(), (size_t)total + 4, &ol));
     FG_TRY(arena_get_t(ctx, (base + ".or").c_str(), (size_t)total + 4, &orr));
     if (total > 0)
-        RELOPS_LAUNCH(ctx, "join_probe_kernel", join_probe_kernel<true>, n_right, right, n_right, tk, head, next, cap, counts, ol, orr,
+        RELOPS_LAUNCH(ctx, "join_hash_probe_kernel", join_hash_probe_kernel<true>, n_right, right.values, (int32_t)right.type, n_right, slots, cap, next, counts, ol, orr,
                       (unsigned long long *)nullptr);
     *left_rows = ol;
     *right_rows = orr;

@@ -129,6 +129,10 @@ int reduce_max(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t *o
 // More than 2^31 - 1 pairs: FLOCKGPU_ERR_UNSUPPORTED, decided from a 64-bit total before anything is emitted.
 int join_key64(flockgpu_ctx *ctx, const char *name, const int64_t *left, int64_t n_left, const int64_t *right, int64_t n_right,
                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
+// The table path of join_key64 with the keys read in their columns' own types (Int32 / Int64 / UInt64 of one signedness, no NULLs): 16-byte
+// slots (key, claiming row, chain head), unique build keys probed as a filter in the flag-tile geometry.  Builds on the smaller side.
+int join_hashed(flockgpu_ctx *ctx, const char *name, const DevColumn &left, int64_t n_left, const DevColumn &right, int64_t n_right,
+                int32_t **left_rows, int32_t **right_rows, int64_t *n_pairs);
 // join_key64 answers this pair of sizes with ONE workgroup and one launch (table, heads and chain links in LDS): no statistics, no dense path needed
 bool join_is_tiny(int64_t n_left, int64_t n_right);
 

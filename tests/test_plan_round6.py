@@ -173,3 +173,58 @@ def test_hash_diff_repartition_gives_every_distinct_key_a_partition(gpu, key):
     with pytest.raises(FlockGpuError) as e:
         run(_hash_diff_plan(key, distinct - 1))
     assert e.value.code == _ffi.ERR_INVALID and "distinct keys" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ktypes", [("Int32", "Int32"), ("Int64", "Int64"), ("Int32", "Int64")])
+@pytest.mark.parametrize("nl,nr", [(9_000, 200_000), (200_000, 9_000), (70_000, 70_000)])
+def test_inner_join_on_spread_keys_unique_build_side_then_duplicates(gpu, ktypes, nl, nr):
+    """The hashed join (relops.hpp join_hashed: 16-byte slots, unique build keys probed as a filter in the flag-tile geometry): a primary key
+    spread over the whole key type on the smaller side (INT64_MIN, the table's free mark, among the Int64 keys), probe rows with and
+    without a partner; then the SAME plan instance fed a build side that repeats keys -- the unique guess is wrong and the call must fall back
+    to counted chains -- and once more (the guess is remembered)."""
+    import pyarrow as pa
+    from flock_amd.runtime import ExecutionContext, collect
+    from test_plan_round5 import _field, _join_plan
+    r = np.random.default_rng(hash((ktypes, nl, nr)) % 2**31)
+    lt, rt = ktypes
+    lf = [_field("a", lt, False), _field("x", "Int32", False)]
+    rf = [_field("b", rt, False), _field("y", "Int64", False)]
+    narrow = "Int32" in ktypes
+    lo, hi = (-2**31, 2**31) if narrow else (-2**63, 2**63)
+    n_small, n_big = min(nl, nr), max(nl, nr)
+    pk = r.choice(np.arange(-n_small, n_small, dtype=np.int64), n_small, replace=False) * ((hi - lo) // (2 * n_small) - 1)   # unique, both signs, the full width
+    if not narrow:
+        pk[0] = -2**63
+    fk = np.where(r.random(n_big) < 0.7, r.choice(pk, n_big), r.integers(lo, hi, n_big))
+    pa_t = lambda t: pa.int32() if t == "Int32" else pa.int64()
+
+    def tables(small, big):
+        ka, kb = (small, big) if nl <= nr else (big, small)
+        left = {"a": [int(v) for v in ka], "x": [int(v) for v in r.integers(-9, 9, len(ka))]}
+        right = {"b": [int(v) for v in kb], "y": [int(v) for v in r.integers(-2**40, 2**40, len(kb))]}
+        lb = [pa.record_batch([pa.array(left["a"], pa_t(lt)), pa.array(left["x"], pa.int32())], names=["a", "x"])]
+        rb = [pa.record_batch([pa.array(right["b"], pa_t(rt)), pa.array(right["y"], pa.int64())], names=["b", "y"])]
+        return left, right, lb, rb
+    ctx = ExecutionContext([_join_plan(lf, rf, "a", "b")], gpu=gpu)
+    gpu.profile_reset()
+    gpu.profile(True)
+    try:
+        left, right, lb, rb = tables(pk, fk)
+        out = collect(ctx, [[lb], [rb]])[0][0]
+        ran = gpu.profile_read()
+        assert "join_hash_probe_flag_kernel" in ran and "join_hash_probe_kernel" not in ran, sorted(ran)
+        want = g.hash_join_inner(left, right, [("a", "b")])
+        assert sorted(pyrows(out)) == sorted(g.rows(want)) and 0 < out.num_rows < n_big
+        dup = pk.copy()
+        dup[1:n_small // 3] = dup[n_small // 3:2 * (n_small // 3) - 1]        # a third of the build keys twice
+        for _ in range(2):
+            left, right, lb, rb = tables(dup, fk)
+            gpu.profile_reset()
+            out = collect(ctx, [[lb], [rb]])[0][0]
+            assert "join_hash_probe_kernel" in gpu.profile_read()
+            want = g.hash_join_inner(left, right, [("a", "b")])
+            assert sorted(pyrows(out)) == sorted(g.rows(want)) and out.num_rows > 0
+    finally:
+        gpu.profile(False)
+        ctx.close()

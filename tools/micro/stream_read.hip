@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void front(const int32_t *__restrict__ a, cons
 // The count pass's COMPUTE phase alone, as q5_count_tile has it (hot key in scalar registers, exec-masked LDS adds, flush), on keys made in
 // registers (kLoad = false) or loaded (kLoad = true): what the CU needs per tile when no memory is waited for.
 struct Pane { int64_t base; uint64_t cnt_off; uint32_t range, pad; };
-template <bool kLoad, bool kFlush, bool kSpec = false, bool kPaneFirst = false>
+template <bool kLoad, bool kFlush, bool kSpec = false, bool kPaneFirst = false, bool kL2 = false>
 __global__ __launch_bounds__(256) void count_like(const int32_t *__restrict__ a, const Tile *__restrict__ tiles, uint32_t *counters, unsigned long long *out,
                                                   const uint64_t *__restrict__ spec = nullptr, const int32_t *__restrict__ pane_win_ptr = nullptr, const Pane *__restrict__ panes = nullptr) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[4096 + 64];
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void count_like(const int32_t *__restrict__ a,
     if (kLoad) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(a + tr.begin + it * 1024 + threadIdx.x * 4));
+            const int64_t begin = kL2 ? (tr.begin & ((int64_t(64) << 13) - 1)) : tr.begin;   // kL2: every workgroup reads one of the first 64 tiles (2 MB: cache-resident)
+            const v4i t = kL2 ? *reinterpret_cast<const v4i *>(a + begin + it * 1024 + threadIdx.x * 4)
+                              : __builtin_nontemporal_load(reinterpret_cast<const v4i *>(a + begin + it * 1024 + threadIdx.x * 4));
             k[it][0] = t.x; k[it][1] = t.y; k[it][2] = t.z; k[it][3] = t.w;
         }
     } else {
@@ -296,6 +298,8 @@ int main() {
         report("count_like compute + flush", time_ms([&] { hipLaunchKernelGGL((count_like<false, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out); }));
         report("count_like load + compute", time_ms([&] { hipLaunchKernelGGL((count_like<true, false>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out); }));
         report("count_like load+comp+flush", time_ms([&] { hipLaunchKernelGGL((count_like<true, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out); }));
+        report("count_like cached loads+comp", time_ms([&] { hipLaunchKernelGGL((count_like<true, false, false, false, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out, spec, pwp, panes); }));
+        report("count_like cached +comp+flush", time_ms([&] { hipLaunchKernelGGL((count_like<true, true, false, false, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out, spec, pwp, panes); }));
         report("  + spec_info check", time_ms([&] { hipLaunchKernelGGL((count_like<true, true, true, false>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out, spec, pwp, panes); }));
         report("  + pane loads first", time_ms([&] { hipLaunchKernelGGL((count_like<true, true, false, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out, spec, pwp, panes); }));
         report("  + both", time_ms([&] { hipLaunchKernelGGL((count_like<true, true, true, true>), dim3((unsigned)n_tiles), dim3(256), 0, 0, a, tiles, counters, out, spec, pwp, panes); }));
