@@ -556,6 +556,164 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
     }
 }
 
+// ---- the same emit for LONG values (an auction's description: ~75 bytes a value, 77 KB a tile): no staging of bytes at all.  LDS holds the
+// values' END positions in the tile's output window and their source offsets (8 KB); every lane then makes whole 16-byte chunks of the OUTPUT:
+// it finds the value its chunk starts in (binary search over the ends), fetches the one or two ALIGNED 16-byte source chunks that hold the
+// piece, realigns them in registers and stores 16 aligned bytes.  A chunk that straddles values (one in five at 75 bytes a value) merges
+// their pieces under byte masks.  Neighbouring lanes read neighbouring source chunks of the same value and write neighbouring output chunks.
+// History (arch/ops/join.sql, 2.3e7 joined bids, 1.7 GB of descriptions): byte-wise copies through utf8_emit_tile_at's stage in rounds, 1.24 ms;
+// this kernel 0.93 ms = 1.8 TB/s written, and ALU-bound: a wave64 instruction occupies its SIMD16 for four cycles, and ~250 instructions
+// per chunk are 0.8 ms of every SIMD's time whatever the memory side does (ablations: no source loads 0.83 ms, no stores 1.20 with four
+// chunks in flight per lane).  A lane per VALUE instead (every interior chunk one unaligned 16-byte load, four funnel shifts, one store: ~16
+// instructions) was run, too: 3.8 ms with non-temporal stores, 1.48 with plain ones -- 64 lanes storing 16 bytes each 75 bytes apart cost the
+// texture path a line per lane.  What is left is in DESIGN section 10.  A kernel of its own: the short values' kernel -- q3's and q8's names
+// -- runs eight workgroups per CU on 59 VGPRs.
+__global__ __launch_bounds__(kBlock) void utf8_emit_long_kernel(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
+                                                                int64_t n, const uint32_t *__restrict__ counts, const uint64_t *__restrict__ tile_base,
+                                                                const uint64_t *__restrict__ col_base, int32_t *__restrict__ out_off, uint8_t *__restrict__ out) {
+    // (col_base: null, or where this column's bytes start in a scan that runs over several columns -- gather_utf8_multi_*)
+    __shared__ uint32_t s_end_[kLenTile];
+    __shared__ int32_t s_b_[kLenTile];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];  // bytes of (iteration, wave)
+    uint32_t *s_end = s_end_;   // [kLenTile]  value v's end in the window (window byte i = output byte (base - phase) + i)
+    int32_t *s_b = s_b_;        // [kLenTile]  value v's first byte in `src`
+    const uint64_t base = tile_base[blockIdx.x] - (col_base ? *col_base : 0);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t i0 = (int64_t)blockIdx.x * kLenTile + threadIdx.x;
+    const uint4 wc = *reinterpret_cast<const uint4 *>(counts + (size_t)blockIdx.x * kWavesPerBlock);
+    const uint32_t tile_bytes = wc.x + wc.y + wc.z + wc.w;
+    int32_t b[kLenItems];
+    uint32_t len[kLenItems], excl[kLenItems];
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+        b[k] = 0;
+        len[k] = 0;
+        if (i0 + k * kBlock < n) {
+            const int2 o = load_off_pair(src_off, rows[i0 + k * kBlock]);
+            b[k] = o.x;
+            len[k] = (uint32_t)(o.y - o.x);
+        }
+        const uint32_t incl = wave_incl_scan_u32(len[k]);
+        excl[k] = incl - len[k];
+        if (lane == 63) s_it[k * kWavesPerBlock + wave] = incl;
+    }
+    __syncthreads();
+    uint32_t run = 0;   // byte offset of (iteration k, wave) inside the tile: values are ordered iteration-major, then thread
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            if (w == wave) excl[k] += run;
+            run += s_it[k * kWavesPerBlock + w];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k)
+        if (i0 + k * kBlock < n) stream_store(&out_off[i0 + k * kBlock + 1], (int32_t)(base + excl[k] + len[k]));
+    if (tile_bytes == 0) return;
+    const uint32_t phase = (uint32_t)(base & 15);  // window byte i holds output byte (base - phase) + i
+#pragma unroll
+    for (int k = 0; k < kLenItems; ++k) {
+        s_end[k * kBlock + threadIdx.x] = phase + excl[k] + len[k];
+        s_b[k * kBlock + threadIdx.x] = b[k];
+    }
+    __syncthreads();
+    const uint32_t end = phase + tile_bytes;
+    uint8_t *gout = out + (base - phase);  // 16-byte aligned
+    const uintptr_t sbase = reinterpret_cast<uintptr_t>(src);
+    auto low_mask = [](int32_t x) -> uint32_t { return x <= 0 ? 0u : x >= 4 ? 0xffffffffu : (1u << (8 * x)) - 1u; };   // bytes 0 .. x - 1 of a dword
+    // one piece of value v into the chunk at window offset o: window bytes [pos, hi) from the two aligned source chunks c0 / c1 around them
+    auto piece_addr = [&](uint32_t v, uint32_t o) -> uintptr_t {   // the address whose byte lands on chunk byte 0 (modular: o may lie before the value's start)
+        return sbase + (uint32_t)s_b[v] + o - (v ? s_end[v - 1] : phase);
+    };
+    auto merge = [&](uint32_t (&acc)[4], uintptr_t A, const uint4 &c0, const uint4 &c1, uint32_t a, uint32_t bnd) {
+        const uint32_t sh = (uint32_t)(A & 15), qd = sh >> 2, bs = (sh & 3) * 8;
+        const uint32_t W[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        uint32_t V[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) V[j] = qd == 0 ? W[j] : qd == 1 ? W[j + 1] : qd == 2 ? W[j + 2] : W[j + 3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] |= __funnelshift_r(V[i], V[i + 1], bs) & low_mask((int32_t)bnd - 4 * i) & ~low_mask((int32_t)a - 4 * i);
+    };
+    // kU chunks per lane at a time: their searches, then their first pieces' loads, are each issued together
+    constexpr int kU = 1;   // (two and four chunks in flight per lane: 1.00 and 1.25 ms against 0.93 -- the kernel is bound by its instruction count, not by latency)
+    for (uint32_t o0 = threadIdx.x * 16; o0 < end; o0 += kU * kBlock * 16) {
+        uint32_t v[kU], pos[kU], chi[kU], acc[kU][4];
+        uintptr_t A[kU];
+        uint4 c0[kU], c1[kU];
+        uint32_t lo_i[kU], hi_i[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t o = o0 + u * kBlock * 16;
+            pos[u] = o < phase ? phase : o;                       // this tile's bytes of the chunk: [pos, chi)
+            chi[u] = o + 16 < end ? o + 16 : end;
+            if (o >= end) pos[u] = chi[u] = end;                  // (no such chunk)
+            lo_i[u] = 0;
+            hi_i[u] = (uint32_t)kLenTile - 1;   // the first value that ends behind pos (the last value ends at `end` > pos)
+        }
+#pragma unroll 1
+        for (int step = 0; step < 10; ++step) {   // (2^10 = kLenTile; the four searches side by side)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const uint32_t mid = (lo_i[u] + hi_i[u]) >> 1;
+                const bool up = s_end[mid] > pos[u];
+                if (lo_i[u] < hi_i[u]) {
+                    if (up) hi_i[u] = mid;
+                    else lo_i[u] = mid + 1;
+                }
+            }
+        }
+        static_assert(kLenTile == 1024, "ten halvings");
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t o = o0 + u * kBlock * 16;
+            v[u] = lo_i[u];
+            acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0u;
+            c0[u] = c1[u] = make_uint4(0, 0, 0, 0);
+            A[u] = 0;
+            if (pos[u] < chi[u]) {
+                const uint32_t p1 = s_end[v[u]], hi = p1 < chi[u] ? p1 : chi[u];
+                A[u] = piece_addr(v[u], o);
+                const uint32_t sh = (uint32_t)(A[u] & 15), a = pos[u] - o, bnd = hi - o;
+                // an aligned 16-byte chunk that holds at least one byte of the value never crosses a page: only such chunks are read
+                const uint4 *q = reinterpret_cast<const uint4 *>(A[u] & ~uintptr_t(15));
+                if (sh + a < 16u) c0[u] = q[0];
+                if (sh + bnd > 16u) c1[u] = q[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t o = o0 + u * kBlock * 16;
+            if (pos[u] >= chi[u]) continue;
+            {
+                const uint32_t p1 = s_end[v[u]], hi = p1 < chi[u] ? p1 : chi[u];
+                merge(acc[u], A[u], c0[u], c1[u], pos[u] - o, hi - o);
+                pos[u] = hi;
+            }
+            while (pos[u] < chi[u]) {   // the chunk straddles values: the further pieces one by one
+                const uint32_t w = ++v[u];
+                const uint32_t p1 = s_end[w], hi = p1 < chi[u] ? p1 : chi[u];
+                if (hi <= pos[u]) continue;   // (an empty value)
+                const uintptr_t B = piece_addr(w, o);
+                const uint32_t sh = (uint32_t)(B & 15), a = pos[u] - o, bnd = hi - o;
+                const uint4 *q = reinterpret_cast<const uint4 *>(B & ~uintptr_t(15));
+                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+                if (sh + a < 16u) d0 = q[0];
+                if (sh + bnd > 16u) d1 = q[1];
+                merge(acc[u], B, d0, d1, a, bnd);
+                pos[u] = hi;
+            }
+            const uint32_t c_lo = o < phase ? phase : o;
+            if (o >= phase && o + 16 <= end) {
+                stream_store4(gout + o, make_uint4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
+            } else {  // the tile's first / last chunk is shared with the neighbouring tile: only this tile's bytes
+                for (uint32_t c = c_lo; c < chi[u]; ++c) gout[c] = (uint8_t)(acc[u][(c - o) >> 2] >> (8 * ((c - o) & 3)));
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void utf8_emit_tile(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src,
                                                const int32_t *__restrict__ rows, int64_t n, const uint32_t *__restrict__ counts,
                                                const uint64_t *__restrict__ tile_base, uint64_t col_base, int32_t *__restrict__ out_off,
@@ -579,6 +737,17 @@ __global__ __launch_bounds__(kBlock) void utf8_emit_multi_kernel(Utf8Cols cols, 
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
     __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];
     const int c = blockIdx.y;
+    const size_t shift = (size_t)c * tiles_stride;
+    utf8_emit_tile(cols.src_off[c], cols.src[c], rows, n, counts + shift * kWavesPerBlock, tile_base + shift, tile_base[shift], cols.out_off[c],
+                   cols.out[c], s_stage, s_it);
+}
+
+// column c alone (its neighbours went to the long-value kernel)
+__global__ __launch_bounds__(kBlock) void utf8_emit_one_of_multi_kernel(Utf8Cols cols, int c, const int32_t *__restrict__ rows, int64_t n,
+                                                                        int64_t tiles_stride, const uint32_t *__restrict__ counts,
+                                                                        const uint64_t *__restrict__ tile_base) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStageBytes];
+    __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];
     const size_t shift = (size_t)c * tiles_stride;
     utf8_emit_tile(cols.src_off[c], cols.src[c], rows, n, counts + shift * kWavesPerBlock, tile_base + shift, tile_base[shift], cols.out_off[c],
                    cols.out[c], s_stage, s_it);
@@ -862,7 +1031,11 @@ static int gather_utf8_emit(flockgpu_ctx *ctx, const Utf8Gather &g, uint64_t tot
         return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: gathered Utf8 column exceeds 2^31 bytes (Arrow Utf8 offsets are int32)",
                     g.name.c_str());
     FG_TRY(arena_get_t(ctx, k_bytes.c_str(), (size_t)total + 16, &o_b));
-    {
+    if (total > (uint64_t)g.n * (kStageBytes / kLenTile)) {   // values longer on average than the stage holds per value: the chunk-wise kernel
+        LaunchScope ls(ctx, "utf8_emit_long_kernel");
+        hipLaunchKernelGGL(utf8_emit_long_kernel, dim3((unsigned)g.tiles), dim3(kBlock), 0, ctx->stream, g.src.offsets, g.src.data,
+                           g.rows, g.n, g.counts, g.tile_base, (const uint64_t *)nullptr, o_off, o_b);
+    } else {
         LaunchScope ls(ctx, "utf8_emit_kernel");
         hipLaunchKernelGGL(utf8_emit_kernel, dim3((unsigned)g.tiles), dim3(kBlock), 0, ctx->stream, g.src.offsets, g.src.data,
                            g.rows, g.n, g.counts, g.tile_base, o_off, o_b);
@@ -946,6 +1119,25 @@ int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockg
         n_bytes[c] = (int64_t)total;
     }
     if (g.n <= 0) return FLOCKGPU_OK;
+    // columns whose values are longer on average than the stage holds per value (an auction's description) go to the chunk-wise kernel, one
+    // launch each; the others stay together
+    bool any_long = false, any_short = false;
+    for (int c = 0; c < g.k; ++c) ((uint64_t)n_bytes[c] > (uint64_t)g.n * (kStageBytes / kLenTile) ? any_long : any_short) = true;
+    if (any_long) {
+        for (int c = 0; c < g.k; ++c) {
+            const size_t shift = (size_t)c * (size_t)g.tiles_stride;
+            if ((uint64_t)n_bytes[c] > (uint64_t)g.n * (kStageBytes / kLenTile)) {
+                LaunchScope ls(ctx, "utf8_emit_long_kernel");
+                hipLaunchKernelGGL(utf8_emit_long_kernel, dim3((unsigned)g.tiles), dim3(kBlock), 0, ctx->stream, cols.src_off[c], cols.src[c], g.rows, g.n,
+                                   g.counts + shift * kWavesPerBlock, g.tile_base + shift, g.tile_base + shift, cols.out_off[c], cols.out[c]);
+            } else {
+                LaunchScope ls(ctx, "utf8_emit_kernel");
+                hipLaunchKernelGGL(utf8_emit_one_of_multi_kernel, dim3((unsigned)g.tiles), dim3(kBlock), 0, ctx->stream, cols, c, g.rows, g.n, g.tiles_stride, g.counts, g.tile_base);
+            }
+        }
+        (void)any_short;
+        return check_launch(ctx, "utf8_emit_long_kernel");
+    }
     {
         LaunchScope ls(ctx, "utf8_emit_kernel");
         hipLaunchKernelGGL(utf8_emit_multi_kernel, dim3((unsigned)g.tiles, (unsigned)g.k), dim3(kBlock), 0, ctx->stream, cols, g.rows, g.n, g.tiles_stride,
