@@ -41,7 +41,12 @@ constexpr uint32_t kFib = 0x9E3779B1u;
 // room.  A/B on one box, alternating (tools/gpu_ab_libs.sh, round 4): 0.741 / 0.728 / 0.730 and 0.753 / 0.732 / 0.728 ms per 1e9 bids --
 // the scratch-bin adds cost 2 %, and replicas buy nothing on top: with half the lanes masked off, the ~32 that remain spread over the
 // ~110 auctions in flight collide rarely enough (the counters' "two thirds of the LDS cycles are bank conflicts" was mostly the hot
-// lanes' 64 scratch adds folding twice over the 32 banks).  Variants 0 / 2 exist in experimental builds only.
+// lanes' 64 scratch adds folding twice over the 32 banks).  Round 6, after tools/micro/stream_read.hip showed the phase costing 0.08 ms on top
+// of the stream: 3 = variant 1 with a row's instructions written out in assembly (2 VALU + 4 SALU + 1 DS per row instead of the compiler's
+// 5 + 4 + 1): 0.694 against 0.693 ms, nothing; 5 = the same without the exec mask, the hot lanes adding to scratch bins (3 + 2 + 1): 0.711
+// against 0.688; hot rows counted per lane (3 + 2 + 1, no ballot): 1.30 ms, the wave-wide sum at every change of candidate costs more than
+// the ballots.  The phase is bound by the LDS adds that are executed, lane by lane -- not by the instructions around them.  Variants other than 1
+// exist in experimental builds only.
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_VARIANT)
 constexpr int kQ5Variant = FLOCKGPU_AB_Q5_VARIANT;
 #else
@@ -466,6 +471,74 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
     uint32_t hot_cnt = 0;
     const bool rep = kQ5Variant == 2 && span * 4 + 3 < (uint32_t)kHist;   // (block-uniform) room for four replicas of every bin
     const uint32_t rmul = rep ? 4u : 1u, radd = rep ? (uint32_t)(lane & 3) : 0u;
+    if (kQ5Variant == 3 || kQ5Variant == 5) {
+        // Variant 1 with the row's instructions written out: the hot key's rows are counted as the complement of the rows that go to the
+        // histogram (one population count of the SAME mask that becomes the exec mask), a row's bin is one shift-add from its key, and the
+        // constant 1 stays in a register: 2 VALU + 4 SALU + 1 DS instruction per row where the compiler's form of variant 1 issues 5 + 4 + 1.
+        // (A wave64 instruction holds its SIMD16 for four cycles and the CU's scalar unit serves a SIMD every fourth cycle: at eight waves per
+        // SIMD this phase is bound by its instruction count, and while a workgroup is in it, it has no loads in flight -- tools/micro/stream_read.hip.
+        // Counting the cold rows per LANE instead -- 3 VALU + 2 SALU -- was run, too: the wave-wide sum it needs whenever the candidate changes
+        // costs more than it saves, the candidate changes in most iterations of NEXMark's bids: 1.30 ms against 0.71.)
+        uint32_t cold = 0;                         // (wave-uniform) rows since the last switch of candidates that were NOT the candidate's
+        uint32_t since = 0;                        // (wave-uniform) rows since that switch
+        uint32_t one = 1;
+        asm volatile("" : "+v"(one));              // (kept in a register: the compiler re-made the constant in front of every LDS add)
+        // the LDS byte address of bin 0 minus four times the tile's minimum: a key's bin is at (key << 2) + this
+        const uint32_t hist_at_mn = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)hist - ((uint32_t)mn << 2));
+#pragma unroll
+        for (int it = 0; it < kQ5Iters; ++it) {
+            const uint64_t b0 = __ballot(k[it][0] == hot);
+            if ((int)__builtin_popcountll(b0) < kHotMin) {
+                // the candidate went cold: park its count, then try this iteration's first two distinct keys
+                if (since != cold) {
+                    if (lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], since - cold);
+                }
+                cold = 0;
+                since = 0;
+                const int32_t c1 = __builtin_amdgcn_readfirstlane(k[it][0]);
+                const uint64_t m1 = __ballot(k[it][0] == c1);
+                hot = c1;
+                if ((int)__builtin_popcountll(m1) < kHotMin && ~m1) {
+                    const int l2 = __ffsll((unsigned long long)~m1) - 1;
+                    const int32_t c2 = __builtin_amdgcn_readlane(k[it][0], l2);
+                    const uint64_t m2 = __ballot(k[it][0] == c2);
+                    if (__builtin_popcountll(m2) > __builtin_popcountll(m1)) hot = c2;
+                }
+            }
+            since += 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // if (k != hot) hist[k - mn] += 1, and cold += the number of such lanes
+                uint32_t bin, n_cold;
+                unsigned long long saved;
+                if (kQ5Variant == 5) {   // (A/B builds: no exec mask -- the hot key's lanes add to a scratch bin of their own)
+                    const uint32_t scratch = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)hist + (uint32_t)(kHist + lane) * 4u;
+                    asm volatile("v_cmp_ne_u32 vcc, %[hot], %[key]\n\t"
+                                 "s_bcnt1_i32_b64 %[n_cold], vcc\n\t"
+                                 "v_lshl_add_u32 %[bin], %[key], 2, %[base]\n\t"
+                                 "v_cndmask_b32 %[bin], %[scratch], %[bin], vcc\n\t"
+                                 "ds_add_u32 %[bin], %[one]"
+                                 : [bin] "=&v"(bin), [n_cold] "=&s"(n_cold)
+                                 : [hot] "s"(hot), [key] "v"(k[it][j]), [base] "s"(hist_at_mn), [one] "v"(one), [scratch] "v"(scratch)
+                                 : "vcc", "scc", "memory");
+                    cold += n_cold;
+                    continue;
+                }
+                asm volatile("v_cmp_ne_u32 vcc, %[hot], %[key]\n\t"
+                             "s_bcnt1_i32_b64 %[n_cold], vcc\n\t"
+                             "s_and_saveexec_b64 %[saved], vcc\n\t"
+                             "v_lshl_add_u32 %[bin], %[key], 2, %[base]\n\t"
+                             "ds_add_u32 %[bin], %[one]\n\t"
+                             "s_mov_b64 exec, %[saved]"
+                             : [bin] "=&v"(bin), [saved] "=&s"(saved), [n_cold] "=&s"(n_cold)
+                             : [hot] "s"(hot), [key] "v"(k[it][j]), [base] "s"(hist_at_mn), [one] "v"(one)
+                             : "vcc", "scc", "memory");
+                cold += n_cold;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the LDS adds above are not the compiler's to count)
+        if (since != cold && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], since - cold);
+    } else {
 #pragma unroll
     for (int it = 0; it < kQ5Iters; ++it) {
         uint64_t b0 = __ballot(k[it][0] == hot);
@@ -504,6 +577,7 @@ __device__ __forceinline__ void q5_count_tile(const int32_t *__restrict__ auctio
         }
     }
     if (hot_cnt && lane == 0) atomicAdd(&hist[((uint32_t)hot - (uint32_t)mn) * rmul], hot_cnt);
+    }
     __syncthreads();
 #if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_Q5_ABLATE)   // (ablation builds, WRONG results by design: what the flush costs)
     if (hist[threadIdx.x] != 0x7fffffffu) return;
