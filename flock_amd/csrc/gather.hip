@@ -518,9 +518,14 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
         const uint32_t o = (uint32_t)(addr & 15), qd = o >> 2, sh = (o & 3) * 8;
         // bytes 0..15 of the string, realigned: d[i] = bytes 4i .. 4i+3 = dwords qd + i, qd + i + 1 of the 32 loaded bytes, shifted
         const uint32_t W[9] = {c0[k].x, c0[k].y, c0[k].z, c0[k].w, c1[k].x, c1[k].y, c1[k].z, c1[k].w, 0u};
-        uint32_t V[5];
+        // (the window of five dwords that starts qd dwords in: two rounds of bit-selects -- the four-way ?: came back from the compiler as four
+        // divergent copies of the code behind it, utf8_emit_long_kernel below)
+        const uint32_t by1 = 0u - (qd & 1u), by2 = 0u - (qd >> 1);
+        uint32_t X[7], V[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) V[j] = qd == 0 ? W[j] : qd == 1 ? W[j + 1] : qd == 2 ? W[j + 2] : W[j + 3];
+        for (int j = 0; j < 7; ++j) X[j] = (W[j + 1] & by1) | (W[j] & ~by1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) V[j] = (X[j + 2] & by2) | (X[j] & ~by2);
         uint32_t d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = __funnelshift_r(V[i], V[i + 1], sh);
@@ -557,23 +562,27 @@ __device__ __forceinline__ void utf8_emit_tile_at(const int32_t *__restrict__ sr
 }
 
 // ---- the same emit for LONG values (an auction's description: ~75 bytes a value, 77 KB a tile): no staging of bytes at all.  LDS holds the
-// values' END positions in the tile's output window and their source offsets (8 KB); every lane then makes whole 16-byte chunks of the OUTPUT:
-// it finds the value its chunk starts in (binary search over the ends), fetches the one or two ALIGNED 16-byte source chunks that hold the
-// piece, realigns them in registers and stores 16 aligned bytes.  A chunk that straddles values (one in five at 75 bytes a value) merges
-// their pieces under byte masks.  Neighbouring lanes read neighbouring source chunks of the same value and write neighbouring output chunks.
+// values' END positions in the tile's output window, their source offsets, and a map from every 16-byte chunk of the window to the value that
+// holds its first byte -- written by the values themselves, ~5 two-byte stores each.  Every lane then makes whole 16-byte chunks of the OUTPUT:
+// one read of the map, the piece of that value and the piece of the value behind it (each from the one or two ALIGNED 16-byte source chunks
+// that hold it, realigned in registers), one split mask between the two, one aligned 16-byte store.  A chunk inside one value -- four of five
+// at 75 bytes a value -- takes the same path with an empty second piece; third and further pieces (short values in a long column) are merged
+// one by one.  Neighbouring lanes read neighbouring source chunks of the same value and write neighbouring output chunks.
 // History (arch/ops/join.sql, 2.3e7 joined bids, 1.7 GB of descriptions): byte-wise copies through utf8_emit_tile_at's stage in rounds, 1.24 ms;
-// this kernel 0.93 ms = 1.8 TB/s written, and ALU-bound: a wave64 instruction occupies its SIMD16 for four cycles, and ~250 instructions
-// per chunk are 0.8 ms of every SIMD's time whatever the memory side does (ablations: no source loads 0.83 ms, no stores 1.20 with four
-// chunks in flight per lane).  A lane per VALUE instead (every interior chunk one unaligned 16-byte load, four funnel shifts, one store: ~16
-// instructions) was run, too: 3.8 ms with non-temporal stores, 1.48 with plain ones -- 64 lanes storing 16 bytes each 75 bytes apart cost the
-// texture path a line per lane.  What is left is in DESIGN section 10.  A kernel of its own: the short values' kernel -- q3's and q8's names
-// -- runs eight workgroups per CU on 59 VGPRs.
+// chunk-centric with a binary search for the chunk's value and range masks per piece, 0.93 ms and ALU-bound -- a wave64 instruction occupies its
+// SIMD16 for four cycles, and ~250 instructions per chunk were 0.8 ms of every SIMD's time whatever the memory side did (ablations: no source
+// loads 0.83 ms; no stores 1.20 with four chunks in flight per lane; 2 / 4 chunks in flight: 1.00 / 1.25); a lane per VALUE (every interior
+// chunk one unaligned 16-byte load, four funnel shifts, one store) 3.8 ms with non-temporal stores, 1.48 with plain ones -- 64 lanes storing 16
+// bytes each 75 bytes apart cost the texture path a line per lane.  A kernel of its own: the short values' kernel -- q3's and q8's names --
+// runs eight workgroups per CU on 59 VGPRs.
+constexpr int kLongMapChunks = 8192;   // 16 KB of LDS: the chunk -> value map of a 128 KB output window
 __global__ __launch_bounds__(kBlock) void utf8_emit_long_kernel(const int32_t *__restrict__ src_off, const uint8_t *__restrict__ src, const int32_t *__restrict__ rows,
                                                                 int64_t n, const uint32_t *__restrict__ counts, const uint64_t *__restrict__ tile_base,
                                                                 const uint64_t *__restrict__ col_base, int32_t *__restrict__ out_off, uint8_t *__restrict__ out) {
     // (col_base: null, or where this column's bytes start in a scan that runs over several columns -- gather_utf8_multi_*)
     __shared__ uint32_t s_end_[kLenTile];
     __shared__ int32_t s_b_[kLenTile];
+    __shared__ uint16_t s_first[kLongMapChunks];   // chunk of the output window -> the value that holds its first in-tile byte
     __shared__ uint32_t s_it[kLenItems * kWavesPerBlock];  // bytes of (iteration, wave)
     uint32_t *s_end = s_end_;   // [kLenTile]  value v's end in the window (window byte i = output byte (base - phase) + i)
     int32_t *s_b = s_b_;        // [kLenTile]  value v's first byte in `src`
@@ -618,97 +627,85 @@ __global__ __launch_bounds__(kBlock) void utf8_emit_long_kernel(const int32_t *_
         s_end[k * kBlock + threadIdx.x] = phase + excl[k] + len[k];
         s_b[k * kBlock + threadIdx.x] = b[k];
     }
-    __syncthreads();
     const uint32_t end = phase + tile_bytes;
     uint8_t *gout = out + (base - phase);  // 16-byte aligned
     const uintptr_t sbase = reinterpret_cast<uintptr_t>(src);
-    auto low_mask = [](int32_t x) -> uint32_t { return x <= 0 ? 0u : x >= 4 ? 0xffffffffu : (1u << (8 * x)) - 1u; };   // bytes 0 .. x - 1 of a dword
-    // one piece of value v into the chunk at window offset o: window bytes [pos, hi) from the two aligned source chunks c0 / c1 around them
-    auto piece_addr = [&](uint32_t v, uint32_t o) -> uintptr_t {   // the address whose byte lands on chunk byte 0 (modular: o may lie before the value's start)
-        return sbase + (uint32_t)s_b[v] + o - (v ? s_end[v - 1] : phase);
+    // bytes 0 .. x - 1 of a dword, x clamped to 0 .. 4 (no branches: a clamp, a 64-bit shift whose low word runs empty at x = 4, a complement)
+    auto low_mask = [](int32_t x) -> uint32_t {
+        const uint32_t c = (uint32_t)min(max(x, 0), 4);
+        return ~(uint32_t)(0xffffffffull << (8u * c));
     };
-    auto merge = [&](uint32_t (&acc)[4], uintptr_t A, const uint4 &c0, const uint4 &c1, uint32_t a, uint32_t bnd) {
+    // sixteen chunk bytes from address A on (the byte at A lands on chunk byte 0; only chunk bytes a .. bnd - 1 are the value's -- the rest comes
+    // back as whatever the two aligned chunks around them hold, or zero).  An aligned 16-byte chunk that holds at least one byte of the value
+    // never crosses a page: only such chunks are read.
+    auto realigned = [&](uintptr_t A, uint32_t a, uint32_t bnd, uint32_t (&V4)[4]) {
         const uint32_t sh = (uint32_t)(A & 15), qd = sh >> 2, bs = (sh & 3) * 8;
+        const uint4 *q = reinterpret_cast<const uint4 *>(A & ~uintptr_t(15));
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
+        if (bnd > a && sh + a < 16u) c0 = q[0];
+        if (bnd > a && sh + bnd > 16u) c1 = q[1];
+        // the window of five dwords that starts `qd` dwords into the eight: two rounds of bit-selects (by one dword, by two) -- a lane's qd is
+        // its own, and the four-way choice written with ?: came back from the compiler as four divergent copies of everything behind it
         const uint32_t W[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        uint32_t V[5];
+        const uint32_t by1 = 0u - (qd & 1u), by2 = 0u - (qd >> 1);
+        uint32_t X[7], V[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) V[j] = qd == 0 ? W[j] : qd == 1 ? W[j + 1] : qd == 2 ? W[j + 2] : W[j + 3];
+        for (int j = 0; j < 7; ++j) X[j] = (W[j + 1] & by1) | (W[j] & ~by1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] |= __funnelshift_r(V[i], V[i + 1], bs) & low_mask((int32_t)bnd - 4 * i) & ~low_mask((int32_t)a - 4 * i);
+        for (int j = 0; j < 5; ++j) V[j] = (X[j + 2] & by2) | (X[j] & ~by2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) V4[i] = __funnelshift_r(V[i], V[i + 1], bs);
     };
-    // kU chunks per lane at a time: their searches, then their first pieces' loads, are each issued together
-    constexpr int kU = 1;   // (two and four chunks in flight per lane: 1.00 and 1.25 ms against 0.93 -- the kernel is bound by its instruction count, not by latency)
-    for (uint32_t o0 = threadIdx.x * 16; o0 < end; o0 += kU * kBlock * 16) {
-        uint32_t v[kU], pos[kU], chi[kU], acc[kU][4];
-        uintptr_t A[kU];
-        uint4 c0[kU], c1[kU];
-        uint32_t lo_i[kU], hi_i[kU];
+    const uint32_t n_chunks = (end + 15u) >> 4;
+    for (uint32_t cbase = 0; cbase < n_chunks; cbase += (uint32_t)kLongMapChunks) {   // (one round for tiles up to 128 KB: 128 bytes a value)
+        const uint32_t cend = cbase + (uint32_t)kLongMapChunks < n_chunks ? cbase + (uint32_t)kLongMapChunks : n_chunks;
+        // ---- every value names itself in the chunks whose first in-tile byte it holds: from the first 16-byte boundary at or behind its start
+        // (the tile's very first chunk for the value that starts the tile) to the chunk of its last byte
+        __syncthreads();   // (the lists above are complete; the previous round's map has been read)
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const uint32_t o = o0 + u * kBlock * 16;
-            pos[u] = o < phase ? phase : o;                       // this tile's bytes of the chunk: [pos, chi)
-            chi[u] = o + 16 < end ? o + 16 : end;
-            if (o >= end) pos[u] = chi[u] = end;                  // (no such chunk)
-            lo_i[u] = 0;
-            hi_i[u] = (uint32_t)kLenTile - 1;   // the first value that ends behind pos (the last value ends at `end` > pos)
+        for (int k = 0; k < kLenItems; ++k) {
+            if (len[k] == 0) continue;
+            const uint32_t p0 = phase + excl[k], p1 = p0 + len[k];
+            uint32_t c = p0 == phase ? 0u : (p0 + 15u) >> 4;
+            const uint32_t c_last = (p1 - 1u) >> 4;
+            if (c < cbase) c = cbase;
+            for (; c <= c_last && c < cend; ++c) s_first[c - cbase] = (uint16_t)(k * kBlock + threadIdx.x);
         }
-#pragma unroll 1
-        for (int step = 0; step < 10; ++step) {   // (2^10 = kLenTile; the four searches side by side)
+        __syncthreads();
+        // ---- every lane makes whole chunks of the output
+        for (uint32_t ci = cbase + threadIdx.x; ci < cend; ci += kBlock) {
+            const uint32_t o = ci << 4, c_lo = o < phase ? phase : o, chi = o + 16 < end ? o + 16 : end;
+            uint32_t v = s_first[ci - cbase];
+            // the value the chunk starts in, and the one behind it: two pieces with ONE split between them is what a chunk of long values holds
+            const uint32_t p0 = v ? s_end[v - 1] : phase, p1 = s_end[v], hi1 = p1 < chi ? p1 : chi;
+            const uint32_t w = v + 1 < (uint32_t)kLenTile ? v + 1 : v;
+            const uint32_t q1 = s_end[w], hi2 = hi1 < chi ? (q1 < chi ? q1 : chi) : hi1;
+            uint32_t P1[4], P2[4], acc[4];
+            realigned(sbase + (uint32_t)s_b[v] + o - p0, c_lo - o, hi1 - o, P1);
+            realigned(sbase + (uint32_t)s_b[w] + o - p1, hi1 - o, hi2 - o, P2);
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const uint32_t mid = (lo_i[u] + hi_i[u]) >> 1;
-                const bool up = s_end[mid] > pos[u];
-                if (lo_i[u] < hi_i[u]) {
-                    if (up) hi_i[u] = mid;
-                    else lo_i[u] = mid + 1;
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t m = low_mask((int32_t)(hi1 - o) - 4 * i);   // chunk bytes below the split are the first value's
+                acc[i] = (P1[i] & m) | (P2[i] & ~m);
+            }
+            uint32_t pos = hi2;
+            if (pos < chi) {   // (short values in a long column: a third piece and more, one by one under range masks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] &= low_mask((int32_t)(pos - o) - 4 * i);
+                for (v = w + 1; pos < chi; ++v) {
+                    const uint32_t e = s_end[v], hi = e < chi ? e : chi;
+                    if (hi <= pos) continue;   // (an empty value)
+                    uint32_t P[4];
+                    realigned(sbase + (uint32_t)s_b[v] + o - s_end[v - 1], pos - o, hi - o, P);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] |= P[i] & low_mask((int32_t)(hi - o) - 4 * i) & ~low_mask((int32_t)(pos - o) - 4 * i);
+                    pos = hi;
                 }
             }
-        }
-        static_assert(kLenTile == 1024, "ten halvings");
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const uint32_t o = o0 + u * kBlock * 16;
-            v[u] = lo_i[u];
-            acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0u;
-            c0[u] = c1[u] = make_uint4(0, 0, 0, 0);
-            A[u] = 0;
-            if (pos[u] < chi[u]) {
-                const uint32_t p1 = s_end[v[u]], hi = p1 < chi[u] ? p1 : chi[u];
-                A[u] = piece_addr(v[u], o);
-                const uint32_t sh = (uint32_t)(A[u] & 15), a = pos[u] - o, bnd = hi - o;
-                // an aligned 16-byte chunk that holds at least one byte of the value never crosses a page: only such chunks are read
-                const uint4 *q = reinterpret_cast<const uint4 *>(A[u] & ~uintptr_t(15));
-                if (sh + a < 16u) c0[u] = q[0];
-                if (sh + bnd > 16u) c1[u] = q[1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const uint32_t o = o0 + u * kBlock * 16;
-            if (pos[u] >= chi[u]) continue;
-            {
-                const uint32_t p1 = s_end[v[u]], hi = p1 < chi[u] ? p1 : chi[u];
-                merge(acc[u], A[u], c0[u], c1[u], pos[u] - o, hi - o);
-                pos[u] = hi;
-            }
-            while (pos[u] < chi[u]) {   // the chunk straddles values: the further pieces one by one
-                const uint32_t w = ++v[u];
-                const uint32_t p1 = s_end[w], hi = p1 < chi[u] ? p1 : chi[u];
-                if (hi <= pos[u]) continue;   // (an empty value)
-                const uintptr_t B = piece_addr(w, o);
-                const uint32_t sh = (uint32_t)(B & 15), a = pos[u] - o, bnd = hi - o;
-                const uint4 *q = reinterpret_cast<const uint4 *>(B & ~uintptr_t(15));
-                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
-                if (sh + a < 16u) d0 = q[0];
-                if (sh + bnd > 16u) d1 = q[1];
-                merge(acc[u], B, d0, d1, a, bnd);
-                pos[u] = hi;
-            }
-            const uint32_t c_lo = o < phase ? phase : o;
             if (o >= phase && o + 16 <= end) {
-                stream_store4(gout + o, make_uint4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
+                stream_store4(gout + o, make_uint4(acc[0], acc[1], acc[2], acc[3]));
             } else {  // the tile's first / last chunk is shared with the neighbouring tile: only this tile's bytes
-                for (uint32_t c = c_lo; c < chi[u]; ++c) gout[c] = (uint8_t)(acc[u][(c - o) >> 2] >> (8 * ((c - o) & 3)));
+                for (uint32_t c = c_lo; c < chi; ++c) gout[c] = (uint8_t)(acc[(c - o) >> 2] >> (8 * ((c - o) & 3)));
             }
         }
     }

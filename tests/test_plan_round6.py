@@ -228,3 +228,40 @@ def test_inner_join_on_spread_keys_unique_build_side_then_duplicates(gpu, ktypes
     finally:
         gpu.profile(False)
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["descriptions", "mixed", "threshold", "huge"])
+def test_take_of_long_text_values(gpu, shape):
+    """A filter's take of a Utf8 column whose values average more than the short-value kernel's stage holds (gather.hip, utf8_emit_long_kernel:
+    16-byte output chunks made from realigned source chunks): descriptions of 50-99 bytes; a mix of NULLs, empty, one-to-five-byte and 200-400-byte
+    values (chunks with three and more pieces, output windows beyond one round of the chunk map); values just above the threshold; values of 2-3 KB."""
+    from flock_amd.runtime import ExecutionContext, collect
+    r = np.random.default_rng(hash(shape) % 2**31)
+    n = {"descriptions": 30_000, "mixed": 20_000, "threshold": 30_000, "huge": 3_000}[shape]
+    t = table(n, r, null_p=0.1)
+    letters = np.array(list("abcdefghijklmnopqrstuvwxyz0123456789 -"))
+
+    def text(lo, hi):
+        return "".join(r.choice(letters, int(r.integers(lo, hi + 1))))
+    if shape == "descriptions":
+        t["s"] = [text(50, 99) for _ in range(n)]
+    elif shape == "mixed":
+        t["s"] = [None if x < 0.1 else "" if x < 0.25 else text(1, 5) if x < 0.6 else text(200, 400) for x in r.random(n)]
+    elif shape == "threshold":
+        t["s"] = [text(17, 23) for _ in range(n)]
+    else:
+        t["s"] = [text(2000, 3000) for _ in range(n)]
+    pred = binary(col("j"), "Gt", lit("Int32", -2**29))     # ~5 of 8 rows
+    ctx = ExecutionContext([{"execution_plan": "filter_exec", "predicate": pred, "input": scan()}], gpu=gpu)
+    gpu.profile_reset()
+    gpu.profile(True)
+    try:
+        rb = collect(ctx, [[batches(t, 7_000)]])[0][0]
+        ran = gpu.profile_read()
+    finally:
+        gpu.profile(False)
+        ctx.close()
+    want = g.rows(g.filter_by_expr(t, pred))
+    assert norm(pyrows(rb)) == norm(want) and 0 < len(want) < n
+    assert "utf8_emit_long_kernel" in ran, sorted(ran)

@@ -25,7 +25,7 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate
 ROWS = [(f"q{q}", kern) for q, kern in DOMINANT.items()] + [("q8", "q8_sellers_bitmap_kernel")] + [("q11", "sort_emit_kernel"), ("ysb", "ysb_count_kernel"), ("json", "json_parse_kernel"),
                                                             ("q3_general", "q3_probe_flag_kernel"), ("q8_general", "q8_key_bitmap_wide_kernel"),
                                                             ("q3_hash", "q3_window_join_lds_kernel"), ("q8_hash", "q8_sellers_part_kernel"),
-                                                            ("arch", "pred_flag_kernel"), ("arch", "dense_group_kernel"), ("arch", "join_probe_unique_flag_kernel"),
+                                                            ("arch", "pred_flag_kernel"), ("arch", "dense_group_kernel"), ("arch", "join_probe_unique_flag_kernel"), ("arch", "join_hash_probe_flag_kernel"), ("arch", "utf8_emit_long_kernel"),
                                                             ("expr", "valprog_kernel<false"), ("expr", "valprog_kernel<true"),
                                                             ("arch", "sort_emit_kernel"), ("arch", "utf8_emit_kernel"), ("arch", "gather_i32_kernel"),
                                                             ("q5_uniform", "q5_part_tile_kernel"), ("q4", "aq_final_kernel"),
@@ -52,7 +52,7 @@ for q, kern in ROWS:
     name = label if not q.endswith(("_general", "_uniform", "_hash")) and q not in ("q4", "q3_1e8") else f"{label}@{q}"
     if q == "q3_1e8":   # (round 5: the small instance runs under its own LaunchScope label)
         name = "q3_probe_flag_small_kernel@1e8_events"
-    arch_op = {"pred_flag_kernel": "filter", "dense_group_kernel": "groupby", "join_probe_unique_flag_kernel": "join", "sort_emit_kernel": "sort"}.get(kern) if q == "arch" else None
+    arch_op = {"pred_flag_kernel": "filter", "dense_group_kernel": "groupby", "join_probe_unique_flag_kernel": "join", "join_hash_probe_flag_kernel": "join_sparse", "sort_emit_kernel": "sort"}.get(kern) if q == "arch" else None
     expr_row = {"valprog_kernel<false": "expr_project", "valprog_kernel<true": "expr_filter"}.get(kern) if q == "expr" else None
     if expr_row:   # the expression evaluator's two bench rows: one profiled run, the projection and the filter instance of one kernel
         name = f"valprog_kernel@{expr_row}"

@@ -26,7 +26,10 @@ for q in ${QUERIES:-5 2 8 3 3_1e8 7 9 13}; do
   extra=""; [ "$q" = "3" ] && extra="--seconds 1000"
   qa=$q; [ "$q" = "3_1e8" ] && qa=3
   cmd="python bench.py --query $qa $extra --steps 6 --warmup 3 --no-also --no-cpu"
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $cmd > "$OUT/q${q}_stats_run.log" 2>&1
+  # the kernel-stats run with bench.py's own default step counts (50 warm-up + 100 timed: the chip's clocks settle over the first dozen calls,
+  # DESIGN section 4 "The clock ramp"); the counter passes stay short (counter collection serialises the launches, the clocks do not matter to bytes)
+  scmd="python bench.py --query $qa $extra --steps ${STATS_STEPS:-100} --warmup ${STATS_WARMUP:-50} --no-also --no-cpu"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $scmd > "$OUT/q${q}_stats_run.log" 2>&1
   f=$(find /tmp/prof_q$q -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/q${q}_kernel_stats.csv"
   grep '^{' "$OUT/q${q}_stats_run.log" | tail -1 > "$OUT/q${q}_bench_under_rocprof.json"
   for c in FETCH_SIZE WRITE_SIZE; do
