@@ -2117,10 +2117,20 @@ struct Exec {
             keys.push_back(SortKey{c.c, sc.descending, sc.nulls_first});
         }
         int32_t *rows = nullptr;
-        FG_TRY(sort_rows(ctx, node_key(pl, n, "sort").c_str(), keys.data(), (int)keys.size(), in.rows, &rows));
+        const int32_t *sorted_key = nullptr;   // the first key's column in sorted order, when the sort carried it (ORDER BY one ascending Int32 column)
+        FG_TRY(sort_rows(ctx, node_key(pl, n, "sort").c_str(), keys.data(), (int)keys.size(), in.rows, &rows, &sorted_key));
         t->rows = limit >= 0 ? std::min<int64_t>(in.rows, limit) : in.rows;
         t->cols.assign(n->schema.size(), TCol{});
-        FG_TRY(take_table(n, in, n->required, rows, t->rows, 0, t));
+        std::vector<char> need = n->required;
+        const size_t kc = n->sort_cols.empty() ? 0 : (size_t)n->sort_cols[0].col;
+        if (sorted_key && kc < need.size() && need[kc]) need[kc] = 0;   // (no take of that column: 4 B / row at sorted-row positions, a quarter of sort.sql's takes)
+        FG_TRY(take_table(n, in, need, rows, t->rows, 0, t));
+        if (sorted_key && kc < need.size() && n->required[kc]) {
+            TCol &o = t->cols[kc];
+            o = dev_col(ColType::I32, const_cast<int32_t *>(sorted_key));
+            o.c.is_ts = in.cols[kc].c.is_ts;
+            o.c.nullable = in.cols[kc].c.nullable;
+        }
         for (size_t i = 0; i < t->cols.size(); ++i) t->cols[i].c.all_null = in.cols[i].c.all_null;
         return FLOCKGPU_OK;
     }

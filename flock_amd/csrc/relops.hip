@@ -1291,8 +1291,9 @@ int widen_to_i64(flockgpu_ctx *ctx, const DevColumn &col, int64_t rows, int64_t 
     return FLOCKGPU_OK;
 }
 
-int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows) {
+int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows, const int32_t **sorted_i32) {
     const std::string base(name);
+    if (sorted_i32) *sorted_i32 = nullptr;
     if (rows >= (int64_t(1) << 31)) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: relations are limited to 2^31 rows", name);
     int32_t *perm[2] = {nullptr, nullptr};   // the order so far, ping-pong
     FG_TRY(arena_get_t(ctx, (base + ".perm0").c_str(), (size_t)rows + 4, &perm[0]));
@@ -1336,6 +1337,7 @@ int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_ke
         if (k.col.type == ColType::I32 && !k.descending && bits <= 32) {
             FG_TRY(radix_sort_pairs(ctx, (base + ".lo").c_str(), static_cast<const int32_t *>(k.col.values), nullptr, rows, (int32_t)mn, bits, &sk, &sv));
             order = sv;
+            if (sorted_i32) *sorted_i32 = sk;   // the column in sorted order: what the passes carried
         } else {
             for (int shift = 0; shift < bits; shift += 32) {
                 {

@@ -159,7 +159,9 @@ struct SortKey {
     bool descending = false;
     bool nulls_first = false;   // where the rows whose col.valid is 0 go (SortOptions of the plan; DESC does not move them)
 };
-int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows);
+// sorted_i32 (may be null): set to the first key's column IN ITS SORTED ORDER when the sort made one on the way (one ascending Int32 key without
+// NULLs: the radix sort carries the column itself), else to null -- the caller's take of that column is then a pointer.
+int sort_rows(flockgpu_ctx *ctx, const char *name, const SortKey *keys, int n_keys, int64_t rows, int32_t **out_rows, const int32_t **sorted_i32 = nullptr);
 // keys[order[i]] is non-decreasing in i (sort_rows' output): starts = the positions i where a new key begins (ascending; device), *n_keys of them.
 // One host wait.
 int key_run_starts(flockgpu_ctx *ctx, const char *name, const int64_t *keys, const int32_t *order, int64_t rows, int32_t **starts, int64_t *n_keys);
