@@ -285,8 +285,32 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         TileRange trn = tr;
         if (nxt < st.n_tiles) trn = locate_tile(st, nxt, kFlagTile);
         const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
+        // (block-uniform) every row of the tile is a row of the segment: all but a segment's first and last tile.  Their rows need no position
+        // test, and the range below comes from the keys' plain minimum and maximum -- a min3 / max3 per two rows.  (The pass ran at 60 % of the
+        // HBM rate with ~20 vector instructions per row: a wave64 instruction holds its SIMD16 for four cycles, which at 4 bytes a row IS the
+        // budget of a pass that wants to stay memory-bound.)
+        const bool full = rel_lo <= 0 && rel_hi >= kFlagTile && tr.tile_begin >= 0 && tr.tile_begin + kFlagTile <= n_rows;
         // range of the wave's 2048 rows inside the bitmap
         uint32_t imin = ~0u, imax = 0;
+        if (full) {
+            int32_t mn = a[0][0], mx = a[0][0];
+#pragma unroll
+            for (int it = 0; it < kFlagIters; ++it) {
+                mn = min(mn, min(min(a[it][0], a[it][1]), min(a[it][2], a[it][3])));
+                mx = max(mx, max(max(a[it][0], a[it][1]), max(a[it][2], a[it][3])));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, __shfl_xor(mn, o, 64));
+                mx = max(mx, __shfl_xor(mx, o, 64));
+            }
+            // the keys' range cut to the bitmap's: [base, base + n_bits)
+            const int64_t lo = max((int64_t)mn, (int64_t)bm.base), hi = min((int64_t)mx, (int64_t)bm.base + (int64_t)bm.n_bits - 1);
+            if (lo <= hi) {
+                imin = (uint32_t)(lo - (int64_t)bm.base);
+                imax = (uint32_t)(hi - (int64_t)bm.base);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
@@ -303,7 +327,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             imin = min(imin, (uint32_t)__shfl_xor((int)imin, o, 64));
             imax = max(imax, (uint32_t)__shfl_xor((int)imax, o, 64));
         }
+        }
         uint32_t maybe = 0;
+        if (imin <= imax && full) {  // (wave-uniform) the same two cases as below without the rows' position tests
+            const uint32_t w0 = imin >> 5, w1 = imax >> 5;
+            if (w1 - w0 < 64u) {
+                const uint32_t word = bm.words[min(w0 + (uint32_t)lane, w1)];
+                const uint32_t w0_4 = w0 << 2;
+#pragma unroll
+                for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t idx = (uint32_t)a[it][j] - (uint32_t)bm.base;
+                        const bool in = idx - imin <= imax - imin;   // (inside the wave's words; outside them the lane index below would be another row's)
+                        // lane (idx >> 5) - w0 holds the word: ds_bpermute takes the lane's byte address; the shift by idx uses its low five bits
+                        const uint32_t wv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((idx >> 3) & ~3u) - w0_4), (int)word);
+                        maybe |= (in ? (wv >> (idx & 31u)) & 1u : 0u) << (it * 4 + j);
+                    }
+            } else {
+#pragma unroll
+                for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) maybe |= (uint32_t)q13_maybe(bm, a[it][j]) << (it * 4 + j);
+            }
+        } else
         if (imin <= imax) {  // (wave-uniform)
             const uint32_t w0 = imin >> 5, w1 = imax >> 5;
             if (w1 - w0 < 64u) {
