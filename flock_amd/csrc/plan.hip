@@ -1861,6 +1861,38 @@ struct Exec {
                 z->rows = n_out;
                 return FLOCKGPU_OK;
             }
+            // DISTINCT (Int32, Utf8) -- q8's persons: `SELECT DISTINCT p_id, name` under the join -- is a choice of rows of its input: the input's
+            // two columns and the chosen rows go up as they are, and the join takes the strings ONCE, for the rows that found a partner (the
+            // aggregate's own take of both columns -- a length pass, a scan and an emit for the names -- was the second-largest item of q8 on the
+            // generic operators)
+            if (n->kind == NKind::Aggregate && pl->twin_sig[(size_t)n->id].empty()) {
+                const Node *agg = n, *partial = nullptr;
+                if (final_is_identity(n, &partial)) agg = partial;
+                const Node *src = agg->in[0].get();
+                if (pl->fused[(size_t)agg->id].kind == kNone && pl->twin_sig[(size_t)agg->id].empty() && agg->group.size() == 2 && agg->aggs.empty() &&
+                    (size_t)agg->group[0] < src->schema.size() && (size_t)agg->group[1] < src->schema.size() &&
+                    src->schema[(size_t)agg->group[0]].type == ColType::I32 && src->schema[(size_t)agg->group[1]].type == ColType::UTF8) {
+                    Table in;
+                    FG_TRY(exec(src, &in));
+                    const TCol &k = in.cols[(size_t)agg->group[0]], &sc = in.cols[(size_t)agg->group[1]];
+                    if (k.c.type != ColType::I32 || sc.c.type != ColType::UTF8 || !k.present || !sc.present)
+                        return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: two-column GROUP BY other than (Int32, Utf8)");
+                    if (k.c.valid || sc.c.valid) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "plan execute: DISTINCT over columns that hold NULLs");
+                    int32_t *rows = nullptr;
+                    int64_t n_out = 0;
+                    FG_TRY(distinct_i32_utf8(ctx, node_key(pl, agg, "dist").c_str(), static_cast<const int32_t *>(k.c.values),
+                                             flockgpu_utf8{sc.c.offsets, static_cast<const uint8_t *>(sc.c.values)}, in.rows, &rows, &n_out));
+                    z->base.rows = in.rows;
+                    z->base.cols = {k, sc};
+                    for (size_t i = 0; i < 2 && i < n->schema.size(); ++i) {
+                        z->base.cols[i].c.is_ts = n->schema[i].is_ts;
+                        z->base.cols[i].c.nullable = n->schema[i].nullable;
+                    }
+                    z->via = rows;
+                    z->rows = n_out;
+                    return FLOCKGPU_OK;
+                }
+            }
         }
         FG_TRY(exec(n, &z->base));
         z->rows = z->base.rows;
@@ -2038,7 +2070,18 @@ struct Exec {
                 // one integer key pair whose build side is dense: chain heads addressed by key - min (relops.hpp "dense integer keys").  The
                 // table goes on the smaller side, as in join_key64 (which side is hashed is unobservable in the pair multiset).
                 if (!text_keys && n->on_l2 < 0 && lk.present && rk.present && nl > 0 && nr > 0) {
-                    const bool build_right = nl > 4 * nr && nl > 4096;
+                    bool build_right = nl > 4 * nr && nl > 4096;
+                    // Which side is a primary key nothing says -- except the previous executes of this node: a build side that repeated keys
+                    // (auctions by seller in q3) while the other side never did (persons by id) hands the table to the other side when that one is
+                    // not much larger: unique build keys are probed as a filter, one pass and no chains (relops.hpp).  Each orientation keeps its own
+                    // finding (".dups" under its own name).
+                    const std::string nm_l = node_key(pl, n, "join"), nm_r = node_key(pl, n, "joinr");
+                    auto had_dups = [&](const std::string &nm) {
+                        auto it = ctx->host_i64.find(nm + ".dups");
+                        return it != ctx->host_i64.end() && !it->second.empty();
+                    };
+                    if (!build_right && had_dups(nm_l) && !had_dups(nm_r) && nr <= 4 * nl) build_right = true;
+                    else if (build_right && had_dups(nm_r) && !had_dups(nm_l) && nl <= 16 * nr) build_right = false;
                     const TCol &bk = build_right ? rk : lk, &pk = build_right ? lk : rk;
                     const int64_t nb = build_right ? nr : nl, np = build_right ? nl : nr;
                     int64_t kmin = 0, kmax = 0;
@@ -2047,7 +2090,7 @@ struct Exec {
                     const bool look = !join_is_tiny(nl, nr);
                     if (look) FG_TRY(int_col_stats(bk, nb, &kmin, &kmax));
                     if (look && dense_range_ok(kmin, kmax, nb, bk.c.type == ColType::U64)) {
-                        FG_TRY(join_dense(ctx, node_key(pl, n, "join").c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
+                        FG_TRY(join_dense(ctx, (build_right ? nm_r : nm_l).c_str(), bk.c, nb, kmin, kmax, pk.c, np, build_right ? &rrows : &lrows, build_right ? &lrows : &rrows,
                                           &pairs));
                         t->rows = pairs;
                         FG_TRY(take_lazy(n, ZL, lrows, pairs, 0, "lzrl", t));
