@@ -678,9 +678,20 @@ __device__ __forceinline__ bool same_pair(const int32_t *key, const int32_t *off
 __global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t *__restrict__ p, int64_t n, int32_t v) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
 }
+// table[cap] (filled with -1 like the slots): stays negative while the keys are strictly increasing -- then every (key, text) pair is its own
+// representative and nothing needs hashing (q8's persons arrive in id order: 27 us of byte-wise hashing per window for a DISTINCT that keeps every row)
+__global__ __launch_bounds__(kBlock) void distinct_order_check_kernel(const int32_t *__restrict__ key, int64_t n, int32_t *flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) bad |= i > 0 && key[i] <= key[i - 1];
+    if (__ballot(bad) && lane_id() == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ __launch_bounds__(kBlock) void distinct_insert_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ off,
                                                                  const uint8_t *__restrict__ bytes, int64_t n, int32_t *table, uint64_t cap,
                                                                  uint8_t *__restrict__ is_rep) {
+    if (table[cap] < 0) {   // (grid-uniform) strictly increasing keys: every row stays
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) is_rep[i] = 1;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)key[i];
         for (int32_t b = off[i]; b < off[i + 1]; ++b) h = (h ^ bytes[b]) * 0x100000001B3ull;
@@ -1824,11 +1835,13 @@ int distinct_i32_utf8(flockgpu_ctx *ctx, const char *name, const int32_t *key, c
     const uint64_t cap = pow2_at_least((uint64_t)std::max<int64_t>(rows, 1) * 2);
     int32_t *table = nullptr;
     uint8_t *rep = nullptr;
-    FG_TRY(arena_get_t(ctx, (base + ".table").c_str(), (size_t)cap, &table));
+    FG_TRY(arena_get_t(ctx, (base + ".table").c_str(), (size_t)cap + 1, &table));   // (+ 1: the "keys are strictly increasing" mark)
     FG_TRY(arena_get_t(ctx, (base + ".rep").c_str(), (size_t)std::max<int64_t>(rows, 0) + 16, &rep));
-    RELOPS_LAUNCH(ctx, "fill_i32_kernel", fill_i32_kernel, (int64_t)cap, table, (int64_t)cap, (int32_t)-1);
-    if (rows > 0)
+    RELOPS_LAUNCH(ctx, "fill_i32_kernel", fill_i32_kernel, (int64_t)cap + 1, table, (int64_t)cap + 1, (int32_t)-1);
+    if (rows > 0) {
+        RELOPS_LAUNCH(ctx, "distinct_order_check_kernel", distinct_order_check_kernel, rows, key, rows, table + cap);
         RELOPS_LAUNCH(ctx, "distinct_insert_kernel", distinct_insert_kernel, rows, key, text.offsets, text.data, rows, table, cap, rep);
+    }
     return mask_to_rows(ctx, (base + ".sel").c_str(), rep, rows, out_rows, n_out);
 }
 

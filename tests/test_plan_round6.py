@@ -265,3 +265,63 @@ def test_take_of_long_text_values(gpu, shape):
     want = g.rows(g.filter_by_expr(t, pred))
     assert norm(pyrows(rb)) == norm(want) and 0 < len(want) < n
     assert "utf8_emit_long_kernel" in ran, sorted(ran)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["increasing", "repeats", "shuffled"])
+@pytest.mark.parametrize("under_join", [False, True])
+def test_distinct_int32_utf8_pairs_in_and_out_of_key_order(gpu, order, under_join):
+    """`SELECT DISTINCT j, s` (q8's `DISTINCT p_id, name`): strictly increasing keys keep every row without hashing (relops.hip,
+    distinct_order_check_kernel); equal neighbours -- the same pair twice, or one key under two strings -- and keys in no order go through
+    the hash set.  Alone, and under a join that takes the pairs' strings itself (plan.hip exec_lazy)."""
+    from flock_amd.runtime import ExecutionContext, collect
+    import pyarrow as pa
+    from test_plan_round5 import _field
+    r = np.random.default_rng(hash((order, under_join)) % 2**31)
+    n = 20_000
+    keys = np.cumsum(r.integers(1, 4, n)).astype(np.int64) - 7
+    if order == "repeats":
+        keys[1::3] = keys[0::3][:len(keys[1::3])]                 # every third row repeats its predecessor's key
+    names = ["n%d" % (int(k) % 97) for k in keys]
+    if order == "repeats":
+        names = [nm if i % 6 else nm + "'" for i, nm in enumerate(names)]   # ... some of them under another string
+    if order == "shuffled":
+        perm = r.permutation(n)
+        keys, names = keys[perm], [names[i] for i in perm]
+        keys = np.concatenate([keys, keys[:500]])                  # and exact duplicates far apart
+        names = names + names[:500]
+    lf = [_field("j", "Int32", False), _field("s", "Utf8", False)]
+    c = lambda nme, i: {"physical_expr": "column", "name": nme, "index": i}
+    sc = lambda fs: {"execution_plan": "memory_exec", "schema": {"fields": fs, "metadata": {}}, "projection": list(range(len(fs)))}
+    ge = [[c("j", 0), "j"], [c("s", 1), "s"]]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": ge, "aggr_expr": [], "input": sc(lf), "input_schema": {"fields": lf, "metadata": {}},
+            "schema": {"fields": lf, "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[c("j", 0), c("s", 1)], 4]}}
+    dist = {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": ge, "aggr_expr": [], "input": rep, "input_schema": {"fields": lf, "metadata": {}},
+            "schema": {"fields": lf, "metadata": {}}}
+    left_rb = [pa.record_batch([pa.array([int(k) for k in keys], pa.int32()), pa.array(names, pa.string())], names=["j", "s"])]
+    pairs = sorted(set(zip((int(k) for k in keys), names)))
+    if not under_join:
+        ctx = ExecutionContext([dist], gpu=gpu)
+        try:
+            out = collect(ctx, [[left_rb]])[0][0]
+        finally:
+            ctx.close()
+        assert sorted(pyrows(out)) == [list(p) for p in pairs] or sorted(map(tuple, pyrows(out))) == pairs
+        return
+    rf = [_field("b", "Int32", False), _field("y", "Int64", False)]
+    kb = r.choice(np.concatenate([keys, keys + 1_000_000]), 30_000)
+    right = {"b": [int(x) for x in kb], "y": [int(x) for x in r.integers(-9, 9, len(kb))]}
+    right_rb = [pa.record_batch([pa.array(right["b"], pa.int32()), pa.array(right["y"], pa.int64())], names=["b", "y"])]
+    side = lambda inner, k, fs: {"execution_plan": "coalesce_batches_exec", "target_batch_size": 4096,
+                                 "input": {"execution_plan": "repartition_exec", "input": inner, "partitioning": {"Hash": [[c(k, 0)], 4]}}}
+    join = {"execution_plan": "hash_join_exec", "left": side(dist, "j", lf), "right": side(sc(rf), "b", rf), "join_type": "Inner", "mode": "Partitioned",
+            "on": [[c("j", 0), c("b", 0)]], "schema": {"fields": lf + rf, "metadata": {}}}
+    ctx = ExecutionContext([join], gpu=gpu)
+    try:
+        for _ in range(2):   # (twice: the second execute may put the table on the other side)
+            out = collect(ctx, [[left_rb], [right_rb]])[0][0]
+            want = g.hash_join_inner({"j": [p[0] for p in pairs], "s": [p[1] for p in pairs]}, right, [("j", "b")])
+            assert sorted(map(tuple, pyrows(out))) == sorted(map(tuple, g.rows(want))) and out.num_rows > 0
+    finally:
+        ctx.close()
