@@ -1861,6 +1861,26 @@ struct Exec {
                 z->rows = n_out;
                 return FLOCKGPU_OK;
             }
+            // a projection that only names columns of its input (the planner puts two of them between q8's DISTINCT and its join): the same rows,
+            // the named columns
+            if (n->kind == NKind::Project) {
+                bool plain = !n->proj.empty();
+                for (auto &pe : n->proj) plain = plain && pe.first->kind == EKind::Col;
+                if (plain) {
+                    Lazy below;
+                    FG_TRY(exec_lazy(n->in[0].get(), &below));
+                    z->base.rows = below.base.rows;
+                    z->base.cols.assign(n->schema.size(), TCol{});
+                    for (size_t i = 0; i < n->proj.size() && i < n->schema.size(); ++i) {
+                        const size_t c = (size_t)n->proj[i].first->col;
+                        if (c >= below.base.cols.size()) return fail(ctx, FLOCKGPU_ERR_INVALID, "plan execute: a projection names a column its input does not have");
+                        z->base.cols[i] = below.base.cols[c];
+                    }
+                    z->via = below.via;
+                    z->rows = below.rows;
+                    return FLOCKGPU_OK;
+                }
+            }
             // DISTINCT (Int32, Utf8) -- q8's persons: `SELECT DISTINCT p_id, name` under the join -- is a choice of rows of its input: the input's
             // two columns and the chosen rows go up as they are, and the join takes the strings ONCE, for the rows that found a partner (the
             // aggregate's own take of both columns -- a length pass, a scan and an emit for the names -- was the second-largest item of q8 on the
