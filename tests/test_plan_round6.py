@@ -325,3 +325,41 @@ def test_distinct_int32_utf8_pairs_in_and_out_of_key_order(gpu, order, under_joi
             assert sorted(map(tuple, pyrows(out))) == sorted(map(tuple, g.rows(want))) and out.num_rows > 0
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ktype", ["Int32", "Int64"])
+@pytest.mark.parametrize("spread", [1, 7, 1_000_003])
+def test_group_by_without_aggregates_is_distinct(gpu, ktype, spread):
+    """`SELECT DISTINCT seller` (q8.dag's second aggregate: a GROUP BY with no aggregate): dense keys take the perfect-hash GROUP BY with no
+    accumulator, keys spread wider than their rows the hash table; negative keys, every key many times, one key once."""
+    from flock_amd.runtime import ExecutionContext, collect
+    import pyarrow as pa
+    from test_plan_round5 import _field
+    r = np.random.default_rng(hash((ktype, spread)) % 2**31)
+    n = 50_000
+    if ktype == "Int32":
+        spread = min(spread, 200_000)          # (9001 x 200000 still fits an Int32)
+    keys = (r.integers(-3_000, 9_000, n) * spread).astype(np.int64)
+    keys[17] = 9_001 * spread
+    f = [_field("k", ktype, False), _field("x", "Int32", False)]
+    c = {"physical_expr": "column", "name": "k", "index": 0}
+    sc = {"execution_plan": "memory_exec", "schema": {"fields": f, "metadata": {}}, "projection": [0, 1]}
+    out_f = [f[0]]
+    part = {"execution_plan": "hash_aggregate_exec", "mode": "Partial", "group_expr": [[c, "k"]], "aggr_expr": [], "input": sc, "input_schema": {"fields": f, "metadata": {}},
+            "schema": {"fields": out_f, "metadata": {}}}
+    rep = {"execution_plan": "repartition_exec", "input": part, "partitioning": {"Hash": [[c], 4]}}
+    plan = {"execution_plan": "hash_aggregate_exec", "mode": "FinalPartitioned", "group_expr": [[c, "k"]], "aggr_expr": [], "input": rep, "input_schema": {"fields": out_f, "metadata": {}},
+            "schema": {"fields": out_f, "metadata": {}}}
+    rb = [pa.record_batch([pa.array([int(v) for v in keys], pa.int32() if ktype == "Int32" else pa.int64()), pa.array([1] * n, pa.int32())], names=["k", "x"])]
+    ctx = ExecutionContext([plan], gpu=gpu)
+    gpu.profile_reset()
+    gpu.profile(True)
+    try:
+        out = collect(ctx, [[rb]])[0][0]
+        ran = gpu.profile_read()
+    finally:
+        gpu.profile(False)
+        ctx.close()
+    assert sorted(v[0] for v in pyrows(out)) == sorted(set(int(v) for v in keys))
+    assert ("dense_group_kernel" in ran) == (spread <= 7), sorted(ran)
