@@ -960,6 +960,103 @@ int gather_i64(flockgpu_ctx *ctx, const int64_t *src, const int32_t *rows, int64
     return check_launch(ctx, "gather_i64_kernel");
 }
 
+int gather_fixed_multi(flockgpu_ctx *ctx, const GatherCols &cols, const int32_t *rows, int64_t n);
+// ---- fixed-width take at rows in NO order (ORDER BY's result): the columns are first interleaved into 16-byte records -- a streaming pass --, so that
+// the take reads ONE 16-byte record per row at a random position instead of one 32-byte sector per row and column (sort.sql's auction, price and
+// b_date_time: 4 + 4 + 8 bytes; the sorted key column is not taken at all, plan.hip exec_sort).
+struct PackedCols {
+    const void *src[4];
+    void *out[4];
+    int32_t width[4];    // 4 | 8
+    int32_t offset[4];   // byte offset inside the record (8-byte fields first)
+    int32_t n = 0;
+};
+__global__ __launch_bounds__(kBlock) void pack_records_kernel(PackedCols cols, int64_t n, uint8_t *__restrict__ rec) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        // the record is made in registers and leaves as ONE 16-byte store per lane (fields stored one by one were 4-byte pieces 16 bytes apart: 0.70 ms
+        // for 9.2e7 rows); which word a field lands in is the same for every lane
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int c = 0; c < cols.n; ++c) {   // (uniform trip count)
+            uint32_t lo, hi = 0;
+            if (cols.width[c] == 4) lo = static_cast<const uint32_t *>(cols.src[c])[i];
+            else {
+                const uint64_t v = static_cast<const uint64_t *>(cols.src[c])[i];
+                lo = (uint32_t)v;
+                hi = (uint32_t)(v >> 32);
+            }
+            const int at = cols.offset[c] >> 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (at == k) w[k] = lo;
+                if (cols.width[c] == 8 && at + 1 == k) w[k] = hi;
+            }
+        }
+        stream_store4(rec + i * 16, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+}
+__device__ __forceinline__ uint32_t record_word(const uint4 &r, int w) { return w == 0 ? r.x : w == 1 ? r.y : w == 2 ? r.z : r.w; }   // (w is wave-uniform)
+__global__ __launch_bounds__(kBlock) void gather_records_kernel(PackedCols cols, const uint4 *__restrict__ rec, const int32_t *__restrict__ rows, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n4; q += (int64_t)gridDim.x * kBlock) {
+        const int4 r = *reinterpret_cast<const int4 *>(rows + q * 4);   // (the list is an arena buffer: 16-byte aligned)
+        const uint4 a = rec[r.x], b = rec[r.y], d = rec[r.z], e = rec[r.w];   // four records in flight per lane
+        for (int c = 0; c < cols.n; ++c) {
+            const int w = cols.offset[c] >> 2;
+            if (cols.width[c] == 4) {
+                *reinterpret_cast<uint4 *>(static_cast<uint32_t *>(cols.out[c]) + q * 4) = make_uint4(record_word(a, w), record_word(b, w), record_word(d, w), record_word(e, w));
+            } else {
+                uint32_t *o = reinterpret_cast<uint32_t *>(static_cast<int64_t *>(cols.out[c]) + q * 4);
+                *reinterpret_cast<uint4 *>(o) = make_uint4(record_word(a, w), record_word(a, w + 1), record_word(b, w), record_word(b, w + 1));
+                *reinterpret_cast<uint4 *>(o + 4) = make_uint4(record_word(d, w), record_word(d, w + 1), record_word(e, w), record_word(e, w + 1));
+            }
+        }
+    }
+    const int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // the up to three rows behind the last whole group of four
+    if (blockIdx.x == 0 && i < n) {
+        const uint4 a = rec[rows[i]];
+        for (int c = 0; c < cols.n; ++c) {
+            const int w = cols.offset[c] >> 2;
+            if (cols.width[c] == 4) static_cast<uint32_t *>(cols.out[c])[i] = record_word(a, w);
+            else static_cast<uint64_t *>(cols.out[c])[i] = (uint64_t)record_word(a, w) | ((uint64_t)record_word(a, w + 1) << 32);
+        }
+    }
+}
+
+int gather_fixed_packed(flockgpu_ctx *ctx, const char *name, const GatherCols &cols, int64_t in_rows, const int32_t *rows, int64_t n) {
+    int total = 0;
+    for (int c = 0; c < cols.n; ++c) total += cols.width[c];
+    bool ok = cols.n >= 2 && cols.n <= 4 && total <= 16 && n >= (int64_t(1) << 20) && n * 2 >= in_rows && (reinterpret_cast<uintptr_t>(rows) & 15) == 0;
+    for (int c = 0; c < cols.n && ok; ++c) ok = (reinterpret_cast<uintptr_t>(cols.out[c]) & 15) == 0 && (cols.width[c] == 4 || cols.width[c] == 8);
+    if (!ok) return gather_fixed_multi(ctx, cols, rows, n);   // (few rows of many, one column, wide rows: the plain take)
+    PackedCols p;
+    p.n = cols.n;
+    int at = 0, k = 0;
+    for (int pass = 0; pass < 2; ++pass)   // 8-byte fields first: every field aligned to its width
+        for (int c = 0; c < cols.n; ++c)
+            if ((cols.width[c] == 8) == (pass == 0)) {
+                p.src[k] = cols.src[c];
+                p.out[k] = cols.out[c];
+                p.width[k] = cols.width[c];
+                p.offset[k] = at;
+                at += cols.width[c];
+                ++k;
+            }
+    uint8_t *rec = nullptr;
+    FG_TRY(arena_get_t(ctx, (std::string(name) + ".rec").c_str(), ((size_t)in_rows + 1) * 16, &rec));
+    {
+        LaunchScope ls(ctx, "pack_records_kernel");
+        const unsigned blocks = (unsigned)std::min<int64_t>(div_up(in_rows, (int64_t)kBlock), (int64_t)ctx->num_cus * 16);
+        hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, in_rows, rec);
+    }
+    FG_TRY(check_launch(ctx, "pack_records_kernel"));
+    {
+        LaunchScope ls(ctx, "gather_records_kernel");
+        const unsigned blocks = (unsigned)std::min<int64_t>(div_up(div_up(n, 4), kBlock), (int64_t)ctx->num_cus * 8);
+        hipLaunchKernelGGL(gather_records_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, reinterpret_cast<const uint4 *>(rec), rows, n);
+    }
+    return check_launch(ctx, "gather_records_kernel");
+}
+
 int gather_fixed_multi(flockgpu_ctx *ctx, const GatherCols &cols, const int32_t *rows, int64_t n) {
     if (n <= 0 || cols.n <= 0) return FLOCKGPU_OK;
     if (cols.n > kGatherMulti) return fail(ctx, FLOCKGPU_ERR_INVALID, "gather_fixed_multi: more than %d columns", kGatherMulti);

@@ -44,6 +44,9 @@ struct GatherCols {
     int32_t n = 0;
 };
 int gather_fixed_multi(flockgpu_ctx *ctx, const GatherCols &cols, const int32_t *rows, int64_t n);
+// The same take for a row list in NO order that names most of the relation's `in_rows` rows (ORDER BY): two to four columns of 16 bytes in all are
+// interleaved into records first (scratch under `name`), so that the take reads one 16-byte record per row; anything else falls through to the plain take.
+int gather_fixed_packed(flockgpu_ctx *ctx, const char *name, const GatherCols &cols, int64_t in_rows, const int32_t *rows, int64_t n);
 
 // Gathers `n` Utf8 values in two phases so that several columns share ONE host synchronisation:
 //   begin  : lengths -> tile scan; queues the D2H copy of the total byte count (the host needs it to size the

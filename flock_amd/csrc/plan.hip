@@ -1531,7 +1531,8 @@ struct Exec {
     // The Utf8 columns of one take share their row list: up to four of them go through ONE length pass, ONE scan, ONE host wait and
     // ONE emit launch (gather_utf8_multi_*) instead of a take -- and a wait -- per column.  A stage plan's operators materialise small
     // tables many times over (filter, join output, one take per repartition), and at that size the waits ARE the cost.
-    int take_table(const Node *n, const Table &in, const std::vector<char> &required, const int32_t *rows, int64_t n_rows, int first_out, Table *out) {
+    // random_rows: the row list is in no order and names most rows (ORDER BY): fixed-width columns are taken as 16-byte records (gather_fixed_packed)
+    int take_table(const Node *n, const Table &in, const std::vector<char> &required, const int32_t *rows, int64_t n_rows, int first_out, Table *out, bool random_rows = false) {
         std::vector<size_t> utf8;
         GatherCols batch;
         for (size_t i = 0; i < in.cols.size(); ++i) {
@@ -1564,7 +1565,24 @@ struct Exec {
             }
             FG_TRY(take_column(ctx, node_key(pl, n, "take", first_out + (int)i).c_str(), in.cols[i].c, rows, n_rows, &o.c));
         }
-        if (batch.n) FG_TRY(gather_fixed_multi(ctx, batch, rows, n_rows));
+        if (batch.n && random_rows) {   // groups of columns that fill a 16-byte record, in order
+            int c0 = 0, grp = 0;
+            while (c0 < batch.n) {
+                GatherCols part;
+                int bytes = 0;
+                while (c0 < batch.n && part.n < 4 && bytes + batch.width[c0] <= 16) {
+                    part.src[part.n] = batch.src[c0];
+                    part.out[part.n] = batch.out[c0];
+                    part.width[part.n] = batch.width[c0];
+                    bytes += batch.width[c0];
+                    ++part.n;
+                    ++c0;
+                }
+                FG_TRY(gather_fixed_packed(ctx, node_key(pl, n, "takerec", first_out + grp++).c_str(), part, in.rows, rows, n_rows));
+            }
+        } else if (batch.n) {
+            FG_TRY(gather_fixed_multi(ctx, batch, rows, n_rows));
+        }
         for (size_t g0 = 0; g0 < utf8.size(); g0 += 4) {
             const int k = (int)std::min<size_t>(4, utf8.size() - g0);
             if (k == 1) {
@@ -2187,7 +2205,7 @@ struct Exec {
         std::vector<char> need = n->required;
         const size_t kc = n->sort_cols.empty() ? 0 : (size_t)n->sort_cols[0].col;
         if (sorted_key && kc < need.size() && need[kc]) need[kc] = 0;   // (no take of that column: 4 B / row at sorted-row positions, a quarter of sort.sql's takes)
-        FG_TRY(take_table(n, in, need, rows, t->rows, 0, t));
+        FG_TRY(take_table(n, in, need, rows, t->rows, 0, t, true));
         if (sorted_key && kc < need.size() && n->required[kc]) {
             TCol &o = t->cols[kc];
             o = dev_col(ColType::I32, const_cast<int32_t *>(sorted_key));

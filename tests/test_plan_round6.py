@@ -363,3 +363,38 @@ def test_group_by_without_aggregates_is_distinct(gpu, ktype, spread):
         ctx.close()
     assert sorted(v[0] for v in pyrows(out)) == sorted(set(int(v) for v in keys))
     assert ("dense_group_kernel" in ran) == (spread <= 7), sorted(ran)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [None, 1_000_000])
+def test_order_by_one_int32_key_over_a_million_rows(gpu, limit):
+    """arch/ops/sort.sql's shape at a size where its takes change form (gather.hpp gather_fixed_packed: above 2^20 rows the fixed-width columns are
+    interleaved into 16-byte records and taken record by record; the sorted key column comes out of the radix passes themselves): 1.3e6 rows,
+    `ORDER BY k` -- every column of every row against numpy's stable sort, ties in input order; with and without a LIMIT."""
+    from flock_amd.runtime import ExecutionContext, collect
+    import pyarrow as pa
+    from test_plan_round5 import _field
+    r = np.random.default_rng(1311 + (limit or 0))
+    n = 1_300_000
+    cols = {"a": r.integers(-2**31, 2**31 - 1, n).astype(np.int32), "k": r.integers(-5_000, 60_000, n).astype(np.int32),
+            "p": r.integers(0, 10_000_000, n).astype(np.int32), "t": r.integers(-2**60, 2**60, n).astype(np.int64), "u": r.integers(0, 2**62, n).astype(np.int64)}
+    f = [_field("a", "Int32", False), _field("k", "Int32", False), _field("p", "Int32", False), _field("t", "Int64", False), _field("u", "Int64", False)]
+    scan_ = {"execution_plan": "memory_exec", "schema": {"fields": f, "metadata": {}}, "projection": list(range(len(f)))}
+    plan = {"execution_plan": "sort_exec", "input": scan_, "expr": [{"expr": {"physical_expr": "column", "name": "k", "index": 1}, "options": {"descending": False, "nulls_first": False}}]}
+    if limit:
+        plan = {"execution_plan": "global_limit_exec", "limit": limit, "input": plan}
+    rb = [pa.record_batch([pa.array(cols[c]) for c in ("a", "k", "p", "t", "u")], names=["a", "k", "p", "t", "u"])]
+    ctx = ExecutionContext([plan], gpu=gpu)
+    gpu.profile_reset()
+    gpu.profile(True)
+    try:
+        out = collect(ctx, [[rb]])[0][0]
+        ran = gpu.profile_read()
+    finally:
+        gpu.profile(False)
+        ctx.close()
+    order = np.argsort(cols["k"], kind="stable")[:limit]
+    assert out.num_rows == len(order)
+    for i, c in enumerate(("a", "k", "p", "t", "u")):
+        assert np.array_equal(out.column(i).to_numpy(), cols[c][order]), c
+    assert ("gather_records_kernel" in ran) == (limit is None), sorted(ran)   # (a LIMIT that keeps under half the rows takes them the plain way)
