@@ -176,15 +176,18 @@ def run_steps(ctx, step, steps, warmup, barrier, only=None):
     and bracketing all ~20 launches of a small-batch query (q3 at 1e8 events) costs as much as its kernels.  The other
     kernels' durations come from two extra, untimed, fully bracketed calls, scaled to `steps` calls."""
     import torch
+    import gc
     res = None
+    # (a generation-2 collection of this process's heap is a ~40 ms pause: kept out of the timed steps -- and out of the gap between the warm-up
+    # and the timed region, too: 40 ms of idle GPU lets the chip's clocks fall back, and the first ~15 timed steps then re-climb the ramp the
+    # warm-up had just climbed (step wall 0.94-1.02 ms falling to 0.81: FLOCK_BENCH_STEP_TIMES=1))
+    gc.collect()
+    gc.disable()
     for _ in range(warmup):
         res = step()
     ctx.profile_reset()
     ctx.profile_only(only)
     ctx.profile(True)
-    import gc
-    gc.collect()          # a generation-2 collection of this process's heap is a ~40 ms pause: keep it out of the timed steps
-    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

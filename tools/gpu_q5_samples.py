@@ -6,12 +6,12 @@ from flock_amd import GpuContext, NEXMarkSource, query_window, run_query
 ctx = GpuContext(0)
 src = NEXMarkSource(1087, 1_000_000, query_window(5), seed=20260925)
 g = src.generate_data(ctx, relations=("bid",), bid_columns=("auction",))
-for _ in range(5):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
     run_query(ctx, 5, g)
 ctx.profile_reset(); ctx.profile_only("q5_count_kernel"); ctx.profile(True)
 torch.cuda.synchronize()
 marks = [time.perf_counter()]
-for _ in range(40):
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     run_query(ctx, 5, g)
     marks.append(time.perf_counter())
 torch.cuda.synchronize()
