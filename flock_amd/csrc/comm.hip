@@ -468,29 +468,7 @@ int all_reduce_max(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, uint64_t *
 }
 
 // ------------------------------------------------------------------ device helpers of the shuffle
-// bytes of the Utf8 values each destination run will carry: grid (kRunBlocks / n_runs, n_runs), block (x, d) sums the lengths of its share of
-// run d's rows and adds ONE value to sums[d] (one atomic per row -- or per wave -- on n_runs addresses is a serial chain: 3.7 ms
-// for 2e7 rows)
-constexpr int kRunBlocks = 2048;  // workgroups over all runs together: grid.x = kRunBlocks / n_runs shares per run
-__global__ __launch_bounds__(kBlock) void run_bytes_kernel(const int32_t *__restrict__ src_off, const int32_t *__restrict__ rows,
-                                                           const int64_t *__restrict__ run_start, unsigned long long *sums) {
-    __shared__ unsigned long long s_part[kWavesPerBlock];
-    const int d = blockIdx.y;
-    const int64_t lo = run_start[d], hi = run_start[d + 1];
-    unsigned long long len = 0;
-    for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kBlock) {
-        const int32_t r = rows[i];
-        len += (unsigned long long)(src_off[r + 1] - src_off[r]);
-    }
-    len = wave_sum_u64(len);
-    if (lane_id() == 0) s_part[threadIdx.x >> 6] = len;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (int w = 0; w < kWavesPerBlock; ++w) tot += s_part[w];
-        if (tot) atomicAdd(&sums[d], tot);
-    }
-}
+// (The bytes of the Utf8 values each destination run will carry come from the send take's own scan: gather.hip utf8_run_bytes_kernel.)
 // out[dst[w] + i] = in[src[w] + i] for i < len[w]: the kept windows' winners, closed up
 __global__ __launch_bounds__(kBlock) void copy_runs_kernel(const int64_t *__restrict__ src, const int64_t *__restrict__ dst, const int64_t *__restrict__ len,
                                                            const int32_t *__restrict__ in_a, const uint64_t *__restrict__ in_n, int32_t *__restrict__ out_a,
@@ -662,14 +640,13 @@ int exchange_relation(flockgpu_ctx *ctx, flockgpu_comm *c, int entry_rc, const s
             if (col.utf8()) {
                 FG_TRY(arena_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].d_run_bytes));
                 FG_TRY(pinned_get_t(ctx, (key + ".run_bytes").c_str(), (size_t)n + 1, &sent[i].h_run_bytes));
-                FG_HIP(ctx, hipMemsetAsync(sent[i].d_run_bytes, 0, sizeof(unsigned long long) * ((size_t)n + 1), ctx->stream));
-                if (n_send > 0) {
-                    LaunchScope ls(ctx, "run_bytes_kernel");
-                    hipLaunchKernelGGL(run_bytes_kernel, dim3((unsigned)std::max(1, kRunBlocks / n), (unsigned)n), dim3(kBlock), 0, ctx->stream, col.offsets, rows_of(col),
-                                       d_run_start, sent[i].d_run_bytes);
+                if (i == ucols.back()) {   // every Utf8 column's buffers are there: the runs' bytes of all of them from the take's scan, one launch
+                    unsigned long long *rb[4] = {};
+                    for (size_t j = 0; j < ucols.size(); ++j) rb[j] = sent[ucols[j]].d_run_bytes;
+                    FG_TRY(gather_utf8_multi_run_bytes(ctx, g_send, d_run_start, n, rb));
+                    for (size_t j = 0; j < ucols.size(); ++j)
+                        FG_HIP(ctx, hipMemcpyAsync(sent[ucols[j]].h_run_bytes, sent[ucols[j]].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
                 }
-                FG_TRY(check_launch(ctx, "run_bytes_kernel"));
-                FG_HIP(ctx, hipMemcpyAsync(sent[i].h_run_bytes, sent[i].d_run_bytes, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
             } else if (payload_of[i] >= 0) {
                 sent[i].values = payload.dst[payload_of[i]];
             } else {

@@ -412,6 +412,44 @@ __global__ void utf8_col_bases_kernel(const uint64_t *__restrict__ tile_base, in
     }
 }
 
+// Bytes of every Utf8 column per RUN of send-order rows (the exchange's per-destination byte counts, comm.hip) from the take's own scan: the
+// bytes in front of row b = the scanned base of b's tile + the lengths of the tile's rows below b.  Workgroup (d, c) sums at most two partial
+// tiles (rounds 2-5: a pass of its own over every row and column, 12 B of scattered reads per value -- 3 x 44 us per call of q3's exchange).
+struct RunByteOut {
+    unsigned long long *run_bytes[kMaxUtf8Multi];
+};
+__device__ __forceinline__ uint64_t utf8_bytes_before(const int32_t *__restrict__ src_off, const int32_t *__restrict__ rows, int64_t b,
+                                                      const uint64_t *__restrict__ col_tile_base) {
+    const int64_t tile = b / kLenTile;
+    uint64_t sum = 0;
+    for (int64_t i = tile * kLenTile + threadIdx.x; i < b; i += kBlock) {
+        const int2 o = load_off_pair(src_off, rows[i]);
+        sum += (uint64_t)(uint32_t)(o.y - o.x);
+    }
+    sum = wave_sum_u64(sum);   // (every lane of the wave holds it)
+    return sum + (threadIdx.x == 0 ? col_tile_base[tile] - col_tile_base[0] : 0);
+}
+__global__ __launch_bounds__(kBlock) void utf8_run_bytes_kernel(Utf8Cols cols, const int32_t *__restrict__ rows, const int64_t *__restrict__ run_start,
+                                                                const uint64_t *__restrict__ tile_base, int64_t tiles_stride, RunByteOut out) {
+    __shared__ unsigned long long s_part[2][kWavesPerBlock];
+    const int d = blockIdx.x, c = blockIdx.y;
+    const uint64_t *ctb = tile_base + (int64_t)c * tiles_stride;
+    const uint64_t lo = utf8_bytes_before(cols.src_off[c], rows, run_start[d], ctb), hi = utf8_bytes_before(cols.src_off[c], rows, run_start[d + 1], ctb);
+    if (lane_id() == 0) {
+        s_part[0][threadIdx.x >> 6] = lo;
+        s_part[1][threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            a += s_part[0][w];
+            b += s_part[1][w];
+        }
+        out.run_bytes[c][d] = b - a;
+    }
+}
+
 // Writes out_off and the bytes.  The tile's bytes form ONE contiguous range of the output, so they are assembled
 // in LDS (byte writes are cheap there) and streamed out with aligned 16-byte stores; byte-granular global stores
 // made this kernel 10x slower than everything else in q8.
@@ -1184,6 +1222,24 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
 int gather_utf8_multi_wait(flockgpu_ctx *ctx, const Utf8MultiGather &g) {
     if (g.n <= 0) return FLOCKGPU_OK;   // (nothing was queued)
     return wait_pinned(ctx, g.h_col_base, g.k + 1);
+}
+
+int gather_utf8_multi_run_bytes(flockgpu_ctx *ctx, const Utf8MultiGather &g, const int64_t *d_run_start, int n_runs, unsigned long long *const *d_run_bytes) {
+    if (n_runs <= 0) return FLOCKGPU_OK;
+    if (g.n <= 0) {
+        for (int c = 0; c < g.k; ++c) FG_HIP(ctx, hipMemsetAsync(d_run_bytes[c], 0, sizeof(unsigned long long) * (size_t)n_runs, ctx->stream));
+        return FLOCKGPU_OK;
+    }
+    Utf8Cols cols{};
+    cols.k = g.k;
+    RunByteOut out{};
+    for (int c = 0; c < g.k; ++c) {
+        cols.src_off[c] = g.src[c].offsets;
+        out.run_bytes[c] = d_run_bytes[c];
+    }
+    LaunchScope ls(ctx, "utf8_run_bytes_kernel");
+    hipLaunchKernelGGL(utf8_run_bytes_kernel, dim3((unsigned)n_runs, (unsigned)g.k), dim3(kBlock), 0, ctx->stream, cols, g.rows, d_run_start, g.tile_base, g.tiles_stride, out);
+    return check_launch(ctx, "utf8_run_bytes_kernel");
 }
 
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n) {

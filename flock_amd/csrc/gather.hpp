@@ -91,6 +91,9 @@ int gather_utf8_multi_begin(flockgpu_ctx *ctx, const char *name, const flockgpu_
                             Utf8MultiGather *g, const uint64_t *d_n = nullptr);
 // The wait between begin and finish when nothing else has to finish with it: polls the byte totals in pinned memory (common.hpp: wait_pinned).
 int gather_utf8_multi_wait(flockgpu_ctx *ctx, const Utf8MultiGather &g);
+// Between begin and finish: run_bytes[c][d] = bytes of column c over the send-order rows [run_start[d], run_start[d + 1]) (device arrays; run_start
+// ascending, its last entry <= the rows of the take), from the take's scanned tile bases + the boundary tiles' lengths.  Queued, no wait.
+int gather_utf8_multi_run_bytes(flockgpu_ctx *ctx, const Utf8MultiGather &g, const int64_t *d_run_start, int n_runs, unsigned long long *const *d_run_bytes);
 void gather_utf8_multi_narrow(Utf8MultiGather *g, int64_t n);
 int gather_utf8_multi_finish(flockgpu_ctx *ctx, const Utf8MultiGather &g, flockgpu_utf8 *outs, int64_t *n_bytes, const int64_t *known_bytes = nullptr);
 

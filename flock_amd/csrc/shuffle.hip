@@ -51,53 +51,167 @@ __device__ __forceinline__ void tile_parts(const int32_t *__restrict__ keys, int
     }
 }
 
-__device__ __forceinline__ uint32_t flags_of(const uint32_t (&d)[kFlagIters], uint32_t part) {
-    uint32_t flags = 0;
+// ---- every destination's ranks from ONE pass over the lane's rows (round 6; rounds 1-5 looped over the destinations inside every tile: flags by
+// 32 compares, a list build of eight DPP scans and two barriers PER destination -- made for <= 8 ranks and paid n times).
+// A lane counts its 32 rows of a GROUP of eight destinations in one 64-bit word of 8-bit fields (<= 32 each), spread into four words of 16-bit
+// fields (a wave's 2048 rows fit) -- so four DPP scans give every lane its offset inside every destination of the group at once.
+constexpr uint32_t kPartGroup = 8;
+
+__device__ __forceinline__ uint64_t group_counts(const uint32_t (&d)[kFlagIters], uint32_t g8) {
+    uint64_t acc = 0;
 #pragma unroll
     for (int it = 0; it < kFlagIters; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) flags |= (((d[it] >> (8 * j)) & 0xFFu) == part ? 1u : 0u) << (it * 4 + j);
-    return flags;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pg = ((d[it] >> (8 * j)) & 0xFFu) - g8;   // (0xFF = outside the window: in no group)
+            acc += pg < kPartGroup ? 1ull << (pg * 8) : 0ull;
+        }
+    return acc;
 }
 
-// counts[((part * n_tiles) + tile) * 4 + wave]
-__global__ __launch_bounds__(kBlock) void partition_count_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
-                                                                 uint32_t n_parts, uint32_t *__restrict__ counts) {
-    const int32_t tile = (int32_t)blockIdx.x;
-    const TileRange tr = locate_tile(st, tile, kFlagTile);
-    uint32_t d[kFlagIters];
-    tile_parts(keys, n_rows, tr, n_parts, d);
-    const int wave = threadIdx.x >> 6;
-#pragma unroll 1
-    for (uint32_t part = 0; part < n_parts; ++part) {
-        const uint32_t incl = wave_incl_scan_u32((uint32_t)__popc(flags_of(d, part)));
-        if (lane_id() == 63) counts[((size_t)part * st.n_tiles + tile) * kWavesPerBlock + wave] = incl;
+__device__ __forceinline__ void spread16(uint64_t acc, uint32_t (&w)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = (uint32_t)(acc >> (16 * k)) & 0xFFFFu;
+        w[k] = (t & 0xFFu) | ((t & 0xFF00u) << 8);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void partition_emit_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
-                                                                uint32_t n_parts, const uint32_t *__restrict__ counts,
-                                                                const uint64_t *__restrict__ tile_base,
-                                                                int32_t *__restrict__ out_rows, PartPayload pl) {
-    __shared__ uint16_t s_list[kFlagTile];
+// counts[((part * n_tiles) + tile) * 4 + wave]
+// dest[tile * 8192 + row of the tile]: the row's destination (0xFF outside the window), for the emit pass -- one byte per row written here
+// instead of four bytes of key read and a hash computed a second time there.
+__global__ __launch_bounds__(kBlock) void partition_count_kernel(const int32_t *__restrict__ keys, int64_t n_rows, SegTiles st,
+                                                                 uint32_t n_parts, uint32_t *__restrict__ counts, uint32_t *__restrict__ dest) {
     const int32_t tile = (int32_t)blockIdx.x;
     const TileRange tr = locate_tile(st, tile, kFlagTile);
     uint32_t d[kFlagIters];
     tile_parts(keys, n_rows, tr, n_parts, d);
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) __builtin_nontemporal_store(d[it], dest + (size_t)tile * (kFlagTile / 4) + (flag_rel0() >> 2) + it * 64);
+    const int wave = threadIdx.x >> 6;
 #pragma unroll 1
-    for (uint32_t part = 0; part < n_parts; ++part) {
-        const size_t slot = (size_t)part * st.n_tiles + tile;
-        const uint4 wc = *reinterpret_cast<const uint4 *>(counts + slot * kWavesPerBlock);
-        if (wc.x + wc.y + wc.z + wc.w == 0) continue;  // block-uniform
-        const uint32_t total = build_flag_list(flags_of(d, part), wc, s_list);
-        __syncthreads();
-        const uint64_t base = tile_base[slot];
-        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
-            const int64_t r = tr.tile_begin + s_list[i];
-            if (!pl.skip_rows) out_rows[base + i] = (int32_t)r;
-            for (int c = 0; c < pl.n; ++c) pl.dst[c][base + i] = pl.src[c][r];  // the tile's rows: L2-resident since tile_parts
+    for (uint32_t g8 = 0; g8 < n_parts; g8 += kPartGroup) {
+        uint32_t w[4];
+        spread16(group_counts(d, g8), w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t incl = wave_incl_scan_u32(w[k]);
+            if (lane_id() == 63) {
+                const uint32_t p0 = g8 + 2 * k;
+                if (p0 < n_parts) counts[((size_t)p0 * st.n_tiles + tile) * kWavesPerBlock + wave] = incl & 0xFFFFu;
+                if (p0 + 1 < n_parts) counts[((size_t)(p0 + 1) * st.n_tiles + tile) * kWavesPerBlock + wave] = incl >> 16;
+            }
         }
-        __syncthreads();  // s_list is rewritten for the next destination
+    }
+}
+
+// The tile's rows grouped by destination in LDS (row order kept inside a destination), then written out run by run: positions inside
+// the list = start of (destination, wave) + the lane's offset (the four scans) + a running count -- the last two live in ONE LDS counter per
+// (destination of the group, thread), so a row costs one returning LDS add and one 2-byte LDS store.  For that a lane takes 32 CONSECUTIVE
+// rows (two 16-byte reads of the count pass's destination bytes); the bytes are kept in LDS, where the output loop finds an entry's destination.
+__global__ __launch_bounds__(kBlock) void partition_emit_kernel(const uint32_t *__restrict__ dest, SegTiles st, uint32_t n_parts,
+                                                                const uint32_t *__restrict__ counts, const uint64_t *__restrict__ tile_base,
+                                                                int32_t *__restrict__ out_rows, PartPayload pl) {
+    __shared__ uint16_t s_list[kFlagTile];
+    __shared__ __attribute__((aligned(16))) uint32_t s_dest[kFlagTile / 4];
+    __shared__ uint32_t s_cnt[kPartGroup * kBlock];
+    __shared__ uint32_t s_start[kMaxParts * kWavesPerBlock];   // list position of (destination, wave)'s first row
+    __shared__ uint32_t s_gdelta[kMaxParts];                   // output position - list position, per destination
+    __shared__ uint32_t s_total;
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t d[kFlagIters];   // the lane's rows: wave * 2048 + lane * 32 + (0 .. 31)
+    {
+        const uint32_t *src = dest + (size_t)tile * (kFlagTile / 4) + threadIdx.x * 8;
+        const uint4 a = stream_load4u(src), b = stream_load4u(src + 4);
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        *reinterpret_cast<uint4 *>(s_dest + threadIdx.x * 8) = a;
+        *reinterpret_cast<uint4 *>(s_dest + threadIdx.x * 8 + 4) = b;
+    }
+    if (wave == 0) {   // (n_parts <= 64: one lane per destination)
+        const bool live = (uint32_t)lane < n_parts;
+        const size_t slot = (size_t)(live ? lane : 0) * st.n_tiles + tile;
+        uint4 wc = *reinterpret_cast<const uint4 *>(counts + slot * kWavesPerBlock);
+        if (!live) wc = make_uint4(0, 0, 0, 0);
+        const uint32_t total = wc.x + wc.y + wc.z + wc.w;
+        const uint32_t incl = wave_incl_scan_u32(total);
+        const uint32_t off = incl - total;
+        if (live) {
+            s_start[lane * kWavesPerBlock + 0] = off;
+            s_start[lane * kWavesPerBlock + 1] = off + wc.x;
+            s_start[lane * kWavesPerBlock + 2] = off + wc.x + wc.y;
+            s_start[lane * kWavesPerBlock + 3] = off + wc.x + wc.y + wc.z;
+            s_gdelta[lane] = (uint32_t)tile_base[slot] - off;   // (positions stay below 2^31: partition_by_key_async checks the row count)
+            if ((uint32_t)lane == n_parts - 1) s_total = incl;
+        }
+    }
+    __syncthreads();
+    const uint32_t rel_first = (uint32_t)threadIdx.x * 32;
+#pragma unroll 1
+    for (uint32_t g8 = 0; g8 < n_parts; g8 += kPartGroup) {
+        uint32_t w[4];
+        spread16(group_counts(d, g8), w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t excl = wave_incl_scan_u32(w[k]) - w[k];
+            const uint32_t p0 = g8 + 2 * k;
+            if (p0 < n_parts) s_cnt[(2 * k) * kBlock + threadIdx.x] = s_start[p0 * kWavesPerBlock + wave] + (excl & 0xFFFFu);
+            if (p0 + 1 < n_parts) s_cnt[(2 * k + 1) * kBlock + threadIdx.x] = s_start[(p0 + 1) * kWavesPerBlock + wave] + (excl >> 16);
+        }
+#pragma unroll
+        for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pg = ((d[it] >> (8 * j)) & 0xFFu) - g8;
+                if (pg < kPartGroup) {
+                    const uint32_t pos = atomicAdd(&s_cnt[pg * kBlock + threadIdx.x], 1u);   // (the thread's own counter: ds_add_rtn_u32, bank = lane)
+                    s_list[pos] = (uint16_t)(rel_first + it * 4 + j);
+                }
+            }
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    const uint8_t *s_dest_b = reinterpret_cast<const uint8_t *>(s_dest);
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const uint32_t rel = s_list[i];
+        const uint32_t pos = i + s_gdelta[s_dest_b[rel]];
+        const int64_t r = tr.tile_begin + rel;
+        if (!pl.skip_rows) out_rows[pos] = (int32_t)r;
+        for (int c = 0; c < pl.n; ++c) pl.dst[c][pos] = pl.src[c][r];
+    }
+}
+
+// Hash([key], 1): every row of a window goes to the one destination, in order -- no key is read.
+__global__ __launch_bounds__(kBlock) void partition_count_one_kernel(SegTiles st, uint32_t *__restrict__ counts) {
+    const int32_t t = (int32_t)(blockIdx.x * kBlock + threadIdx.x);   // one thread per (tile, wave)
+    if (t >= st.n_tiles * kWavesPerBlock) return;
+    const TileRange tr = st.tiles[t / kWavesPerBlock];
+    const int64_t lo = tr.tile_begin + (int64_t)(t % kWavesPerBlock) * kFlagWaveRows, hi = lo + kFlagWaveRows;
+    const int64_t a = lo > tr.lo ? lo : tr.lo, b = hi < tr.hi ? hi : tr.hi;
+    counts[t] = b > a ? (uint32_t)(b - a) : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void partition_emit_one_kernel(SegTiles st, const uint64_t *__restrict__ tile_base, int32_t *__restrict__ out_rows,
+                                                                    PartPayload pl) {
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    const uint64_t base = tile_base[tile];
+    const int32_t n = (int32_t)(tr.hi - tr.lo);
+    for (int32_t i0 = 0; i0 < n; i0 += kBlock * 4) {
+        int32_t v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t i = i0 + u * kBlock + (int32_t)threadIdx.x;
+            for (int c = 0; c < pl.n; ++c) v[u][c] = i < n ? __builtin_nontemporal_load(pl.src[c] + tr.lo + i) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t i = i0 + u * kBlock + (int32_t)threadIdx.x;
+            if (i >= n) continue;
+            if (!pl.skip_rows) out_rows[base + i] = (int32_t)(tr.lo + i);
+            for (int c = 0; c < pl.n; ++c) pl.dst[c][base + i] = v[u][c];
+        }
     }
 }
 
@@ -239,17 +353,24 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
     FG_TRY(arena_get_t(ctx, "partition.group_off", n_groups + 1, &d_off));
     FG_TRY(pinned_get_t(ctx, "partition.group_off", n_groups + 1, &h_off));
     FG_TRY(arena_get_t(ctx, "partition.rows", (size_t)covered + 1, &o_rows));
+    uint32_t *dest = nullptr;   // the rows' destination bytes, tile by tile (count pass -> emit pass)
+    if (n_parts > 1) FG_TRY(arena_get_t(ctx, "partition.dest", (size_t)st.n_tiles * (kFlagTile / 4) + 4, &dest));
+    const PartPayload pay = payload ? *payload : PartPayload{};
     if (st.n_tiles > 0) {
         LaunchScope ls(ctx, "partition_count_kernel");
-        hipLaunchKernelGGL(partition_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st,
-                           (uint32_t)n_parts, counts);
+        if (n_parts == 1)
+            hipLaunchKernelGGL(partition_count_one_kernel, dim3((unsigned)div_up((int64_t)st.n_tiles * kWavesPerBlock, kBlock)), dim3(kBlock), 0, ctx->stream, st, counts);
+        else
+            hipLaunchKernelGGL(partition_count_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st, (uint32_t)n_parts, counts, dest);
     }
     FG_TRY(check_launch(ctx, "partition_count_kernel"));
     FG_TRY(launch_tile_scan(ctx, counts, (int32_t)slots, tile_base, d_first, (int32_t)n_groups, d_off));
     if (st.n_tiles > 0) {
         LaunchScope ls(ctx, "partition_emit_kernel");
-        hipLaunchKernelGGL(partition_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, keys, rows, st,
-                           (uint32_t)n_parts, counts, tile_base, o_rows, payload ? *payload : PartPayload{});
+        if (n_parts == 1)
+            hipLaunchKernelGGL(partition_emit_one_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, st, tile_base, o_rows, pay);
+        else
+            hipLaunchKernelGGL(partition_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, dest, st, (uint32_t)n_parts, counts, tile_base, o_rows, pay);
     }
     FG_TRY(check_launch(ctx, "partition_emit_kernel"));
     FG_HIP(ctx, hipMemcpyAsync(h_off, d_off, sizeof(int64_t) * (n_groups + 1), hipMemcpyDeviceToHost, ctx->stream));

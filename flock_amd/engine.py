@@ -756,6 +756,12 @@ class GpuContext:
             self._check(self._lib.flockgpu_memcpy(self._h, rows.data_ptr(), r.row, int(r.rows) * 4, _ffi.D2D))
         return rows, np.diff(off).reshape(n_parts, windows.n_windows)
 
+    def partition_by_key_raw(self, keys, windows: WindowSchedule, n_parts: int) -> int:
+        """The same call without the copy of the row numbers out of the ctx arena (timing: tools/gpu_partition_ab.py); returns the row count."""
+        w, r = windows.ffi(), _ffi.PartitionResult()
+        self._check(self._lib.flockgpu_partition_by_key(self._h, keys.data_ptr(), keys.numel(), C.byref(w), n_parts, C.byref(r)))
+        return int(r.rows)
+
     def take(self, src, rows):
         """out[i] = src[rows[i]] for an int32 / int64 device tensor."""
         torch = _torch()
