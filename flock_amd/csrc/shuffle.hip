@@ -29,7 +29,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finaliser
 }
 
 __device__ __forceinline__ uint32_t part_of(int32_t key, uint32_t n_parts) {
+#if defined(FLOCKGPU_EXPERIMENTAL) && defined(FLOCKGPU_AB_PART_NOHASH)   // (A/B builds only: what the three integer multiplies of the hash cost the count pass)
+    return (uint32_t)key & (n_parts - 1);
+#else
     return (uint32_t)(((uint64_t)mix32((uint32_t)key) * n_parts) >> 32);
+#endif
 }
 
 // Destination of each of the lane's 32 rows, one byte each (0xFF = row outside the window), four per word.
