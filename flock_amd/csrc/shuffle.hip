@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t part_of(int32_t key, uint32_t n_parts) {
 __device__ __forceinline__ void tile_parts(const int32_t *__restrict__ keys, int64_t n_rows, const TileRange &tr,
                                            uint32_t n_parts, uint32_t (&d)[kFlagIters]) {
     int32_t a[kFlagIters][4];
-    load_flag_tile_cached(keys, n_rows, tr, a);   // (the emit pass reads the same keys right after the count pass)
+    load_flag_tile(keys, n_rows, tr, a);   // (read once: the emit pass takes the destination bytes the count pass leaves, not the keys)
     const int32_t rel_lo = (int32_t)(tr.lo - tr.tile_begin), rel_hi = (int32_t)(tr.hi - tr.tile_begin);
     const int32_t rel0 = flag_rel0();
 #pragma unroll
