@@ -1,6 +1,7 @@
 // Internal to libflockgpu: context, device arena, launch + profiling helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -193,16 +194,26 @@ inline int pinned_get_t(flockgpu_ctx *ctx, const char *name, size_t count, T **o
     return rc;
 }
 
-// Bracket one kernel launch with events when profiling is on.
+// One kernel launch (or a few) timed when profiling is on.  The two events are BOUND TO THE DISPATCH (hipExtLaunchKernelGGL): they carry the
+// kernel's own begin and end timestamps, the ones rocprofv3's kernel trace reads.  Rounds 1-5 recorded an event either side of the launch: each
+// is a packet of its own that waits for what is in front of it, which put 2-4 us on every sample (tools/micro/ext_events.hip: +1.9 us on an
+// idle stream; q3's 11.8 us probe pass read 15.4 us, q8's 54.9 us sellers pass 58.8 us between back-to-back kernels).  Several launches inside
+// one scope: start = the first's begin, stop = the last's end (the stop event is bound again by every launch: the later binding holds).
+struct LaunchScope;
+inline thread_local LaunchScope *g_launch_scope = nullptr;
 struct LaunchScope {
     flockgpu_ctx *ctx;
     const char *name;
     hipEvent_t start = nullptr, stop = nullptr;
     bool on = false;
+    int n_launch = 0;
+    LaunchScope *outer = nullptr;
     LaunchScope(flockgpu_ctx *c, const char *n) : ctx(c), name(n) {
         on = ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only == n);
         if (ctx->profiling && !on && ctx->profile_only.find('|') != std::string::npos)   // "a|b": the kernels a call may choose between for one step
             on = ("|" + ctx->profile_only + "|").find("|" + std::string(n) + "|") != std::string::npos;
+        outer = g_launch_scope;
+        g_launch_scope = on ? this : nullptr;   // (an inner scope that is not sampled must not lend its launches to an outer one)
         if (!on) return;
         auto take = [&]() {
             hipEvent_t e = nullptr;
@@ -216,14 +227,34 @@ struct LaunchScope {
         };
         start = take();
         stop = take();
-        (void)hipEventRecord(start, ctx->stream);
     }
     ~LaunchScope() {
+        g_launch_scope = outer;
         if (!on) return;
-        (void)hipEventRecord(stop, ctx->stream);
-        ctx->pending.push_back({name, start, stop});
+        if (n_launch > 0) {
+            ctx->pending.push_back({name, start, stop});
+        } else {   // nothing was launched (an error path): the events go back unused
+            ctx->event_pool.push_back(start);
+            ctx->event_pool.push_back(stop);
+        }
     }
+    LaunchScope(const LaunchScope &) = delete;
+    LaunchScope &operator=(const LaunchScope &) = delete;
 };
+
+// Every kernel launch of the library goes through here (the macro below): plain outside a sampled scope, with the scope's events bound inside one.
+template <typename K, typename... Args>
+inline void launch_scoped(K kernel, const dim3 &grid, const dim3 &block, uint32_t shmem, hipStream_t stream, Args... args) {
+    LaunchScope *s = g_launch_scope;
+    if (s) {
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, s->n_launch == 0 ? s->start : (hipEvent_t) nullptr, s->stop, 0, args...);
+        ++s->n_launch;
+    } else {
+        kernel<<<grid, block, shmem, stream>>>(args...);
+    }
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::flockgpu::launch_scoped((kernel), (grid), (block), (uint32_t)(shmem), (stream), __VA_ARGS__)
 
 inline int check_launch(flockgpu_ctx *ctx, const char *name) {
     hipError_t e = hipGetLastError();

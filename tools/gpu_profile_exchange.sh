@@ -6,6 +6,7 @@ OUT=$PWD/gpurun_out/prof_exchange
 rm -rf "$OUT"; mkdir -p "$OUT"
 for q in ${QUERIES:-8 5 3}; do
   extra=""; [ "$q" = "3" ] && extra="--seconds 1000"
+  rm -rf /tmp/px_q$q   # (a box can serve several calls: an earlier call's files must not be picked up)
   cmd="python bench.py --mode exchange --query $q $extra --steps 5 --warmup 2 --no-also --no-cpu"
   rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/px_q$q -- $cmd > "$OUT/q${q}_run.log" 2>&1
   for kind in hip_api_stats kernel_stats memory_copy_stats; do
