@@ -47,8 +47,10 @@ def main():
         prof = ctx.profile_read()
         ctx.profile(False)
         k = {name: round(v["total_ms"] / max(v["launches"], 1), 4) for name, v in prof.items()}
-        alg = a.rows * 4 * 2 + a.rows * 4                           # keys read by both passes, row numbers written
-        out[n_parts] = {"ms_per_call": round(ms, 4), "kernels_ms": k, "frac_of_8TBs_emit": round(alg / 2 / (max(k.get("partition_emit_kernel", 1e9), 1e-9) * 1e-3) / 8e12, 4)}
+        # algorithmic bytes: the count pass reads the keys and leaves a destination byte per row (n > 1), the emit pass reads that byte and writes the row number
+        cb, eb = (0, a.rows * 4) if n_parts == 1 else (a.rows * 5, a.rows * 5)
+        frac = lambda nbytes, name: round(nbytes / (max(k.get(name, 0.0), 1e-9) * 1e-3) / 8e12, 4)
+        out[n_parts] = {"ms_per_call": round(ms, 4), "kernels_ms": k, "count_frac_of_8TBs": frac(cb, "partition_count_kernel"), "emit_frac_of_8TBs": frac(eb, "partition_emit_kernel")}
         print(n_parts, json.dumps(out[n_parts]), flush=True)
     if a.check:
         sys.path.insert(0, "tests")

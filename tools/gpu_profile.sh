@@ -29,10 +29,11 @@ for q in ${QUERIES:-5 2 8 3 3_1e8 7 9 13}; do
   # the kernel-stats run with bench.py's own default step counts (50 warm-up + 100 timed: the chip's clocks settle over the first dozen calls,
   # DESIGN section 4 "The clock ramp"); the counter passes stay short (counter collection serialises the launches, the clocks do not matter to bytes)
   scmd="python bench.py --query $qa $extra --steps ${STATS_STEPS:-100} --warmup ${STATS_WARMUP:-50} --no-also --no-cpu"
+  rm -rf /tmp/prof_q$q /tmp/pmc_FETCH_SIZE_q$q /tmp/pmc_WRITE_SIZE_q$q   # (a box can serve several calls: an earlier call's files must not be picked up)
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q$q -- $scmd > "$OUT/q${q}_stats_run.log" 2>&1
   f=$(find /tmp/prof_q$q -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/q${q}_kernel_stats.csv"
   grep '^{' "$OUT/q${q}_stats_run.log" | tail -1 > "$OUT/q${q}_bench_under_rocprof.json"
-  for c in FETCH_SIZE WRITE_SIZE; do
+  for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do   # (PMC_COUNTERS="" : kernel stats only)
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${c}_q$q -- $cmd > "$OUT/q${q}_${c}_run.log" 2>&1
     summarise /tmp/pmc_${c}_q$q $c "$OUT/q${q}_pmc_${c}.csv"
   done
@@ -41,6 +42,7 @@ done
 # the side entries bench.py reports under `also` (q11, YSB, JSON ingest) and the general-path rows: kernel stats + PMC passes each
 for side in ${SIDES:-q11 ysb json}; do
   cmd="python bench.py --only-side $side --steps 3 --no-cpu"
+  rm -rf /tmp/prof_$side /tmp/pmc_FETCH_SIZE_$side /tmp/pmc_WRITE_SIZE_$side
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$side -- $cmd > "$OUT/${side}_stats_run.log" 2>&1
   f=$(find /tmp/prof_$side -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${side}_kernel_stats.csv"
   grep '^{' "$OUT/${side}_stats_run.log" | tail -1 > "$OUT/${side}_bench_under_rocprof.json"
@@ -52,6 +54,7 @@ for side in ${SIDES:-q11 ysb json}; do
 done
 for gen in ${GENERALS:-q3_general q8_general q5_uniform q3_hash q8_hash}; do
   cmd="python bench.py --only-general $gen --steps 3"
+  rm -rf /tmp/prof_$gen /tmp/pmc_FETCH_SIZE_$gen /tmp/pmc_WRITE_SIZE_$gen
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$gen -- $cmd > "$OUT/${gen}_stats_run.log" 2>&1
   f=$(find /tmp/prof_$gen -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${gen}_kernel_stats.csv"
   grep '^{' "$OUT/${gen}_stats_run.log" | tail -1 > "$OUT/${gen}_bench_under_rocprof.json"
@@ -65,6 +68,7 @@ ls -la "$OUT"
 # the "next" rows that bench.py only reports under `also` (q11, YSB, JSON ingest, q4, the 1e9 variants): one kernel-stats run
 # of the whole default bench
 if [ "${FULL:-1}" = "1" ]; then
+  rm -rf /tmp/prof_all
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_all -- python bench.py --steps 3 --warmup 1 --no-cpu > "$OUT/all_stats_run.log" 2>&1
   f=$(find /tmp/prof_all -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/all_kernel_stats.csv"
   grep '^{' "$OUT/all_stats_run.log" | tail -1 > "$OUT/all_bench_under_rocprof.json"
