@@ -20,7 +20,7 @@ COUNT / MAX / join -> all-reduce(MAX) -- reported as `exchange` ("strong") with 
 "also" then carries q8 / q3 key-partitioned the same way.  `--mode exchange` makes the exchange the headline instead.
 
 roofline: dominant kernel's ALGORITHMIC bytes / its average launch duration measured
-with HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md);
+with HIP events on the launch stream inside the timed region (bound to the kernel's dispatch: common.hpp LaunchScope); peak = 8 TB/s HBM3E (MI355X_MICROARCH.md);
 traffic = PMC-derived HBM bytes per launch from profiles/traffic.json (measured in separate rocprofv3 --pmc runs,
 "traffic_source" says so).
 cpu_baseline: the scalar C oracle (a port: the Rust/DataFusion reference cannot be built here), one window per
