@@ -42,7 +42,7 @@ def _utf8(u):
     return DeviceUtf8(_dev(u.offsets), _dev(data))
 
 
-@pytest.mark.parametrize("n_parts", [1, 2, 3, 8, 64])
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 5, 8, 9, 13, 37, 64])   # (groups of eight destinations per trip: whole, ragged, one past a group)
 def test_partition_matches_restatement(ctx, n_parts):
     import torch
     from flock_amd import WindowSchedule
