@@ -60,6 +60,7 @@ __device__ __forceinline__ void tile_parts(const int32_t *__restrict__ keys, int
 // A lane counts its 32 rows of a GROUP of eight destinations in one 64-bit word of 8-bit fields (<= 32 each), spread into four words of 16-bit
 // fields (a wave's 2048 rows fit) -- so four DPP scans give every lane its offset inside every destination of the group at once.
 constexpr uint32_t kPartGroup = 8;
+constexpr int kPartLoopMax = 4;   // up to here the emit pass loops over the destinations (partition_emit_loop_kernel)
 
 __device__ __forceinline__ uint64_t group_counts(const uint32_t (&d)[kFlagIters], uint32_t g8) {
     uint64_t acc = 0;
@@ -183,6 +184,46 @@ __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const uint32_t *
         const int64_t r = tr.tile_begin + rel;
         if (!pl.skip_rows) out_rows[pos] = (int32_t)r;
         for (int c = 0; c < pl.n; ++c) pl.dst[c][pos] = pl.src[c][r];
+    }
+}
+
+// Up to four destinations: the write-out destination by destination (the form of rounds 1-5, now on the count pass's destination bytes: no key
+// read, no hash).  Its 16 KB of LDS and 71 VGPRs keep more workgroups on a CU than the one-pass form above (34 KB, 127 VGPRs: four), and the
+// write-out with payload columns is a latency-bound gather: with two payload columns, emit pass per 8e7 rows, loop / one pass: 0.30 / 0.40 ms at
+// two destinations, 0.34 / 0.37 at four, (0.47) / 0.41 at eight (`profiles/r06/partition_ab.txt`) -- the loop's cost grows with the destinations,
+// the one pass's does not.  (Asking for the payload columns' tile as a coalesced stream first, so that the scattered reads of the write-out find
+// their lines in the L2: 0.40 -> 0.35 for the one pass at two destinations, nothing at eight, nothing for the loop -- not kept.)
+__device__ __forceinline__ uint32_t flags_of(const uint32_t (&d)[kFlagIters], uint32_t part) {
+    uint32_t flags = 0;
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) flags |= (((d[it] >> (8 * j)) & 0xFFu) == part ? 1u : 0u) << (it * 4 + j);
+    return flags;
+}
+__global__ __launch_bounds__(kBlock) void partition_emit_loop_kernel(const uint32_t *__restrict__ dest, SegTiles st, uint32_t n_parts,
+                                                                     const uint32_t *__restrict__ counts, const uint64_t *__restrict__ tile_base,
+                                                                     int32_t *__restrict__ out_rows, PartPayload pl) {
+    __shared__ uint16_t s_list[kFlagTile];
+    const int32_t tile = (int32_t)blockIdx.x;
+    const TileRange tr = locate_tile(st, tile, kFlagTile);
+    uint32_t d[kFlagIters];   // (the count pass's geometry: byte j of d[it] = row flag_rel0() + it * 256 + j)
+#pragma unroll
+    for (int it = 0; it < kFlagIters; ++it) d[it] = __builtin_nontemporal_load(dest + (size_t)tile * (kFlagTile / 4) + (flag_rel0() >> 2) + it * 64);
+#pragma unroll 1
+    for (uint32_t part = 0; part < n_parts; ++part) {
+        const size_t slot = (size_t)part * st.n_tiles + tile;
+        const uint4 wc = *reinterpret_cast<const uint4 *>(counts + slot * kWavesPerBlock);
+        if (wc.x + wc.y + wc.z + wc.w == 0) continue;  // block-uniform
+        const uint32_t total = build_flag_list(flags_of(d, part), wc, s_list);
+        __syncthreads();
+        const uint64_t base = tile_base[slot];
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+            const int64_t r = tr.tile_begin + s_list[i];
+            if (!pl.skip_rows) out_rows[base + i] = (int32_t)r;
+            for (int c = 0; c < pl.n; ++c) pl.dst[c][base + i] = pl.src[c][r];
+        }
+        __syncthreads();  // s_list is rewritten for the next destination
     }
 }
 
@@ -373,6 +414,8 @@ int partition_by_key_async(flockgpu_ctx *ctx, const int32_t *keys, int64_t rows,
         LaunchScope ls(ctx, "partition_emit_kernel");
         if (n_parts == 1)
             hipLaunchKernelGGL(partition_emit_one_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, st, tile_base, o_rows, pay);
+        else if (n_parts <= kPartLoopMax)
+            hipLaunchKernelGGL(partition_emit_loop_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, dest, st, (uint32_t)n_parts, counts, tile_base, o_rows, pay);
         else
             hipLaunchKernelGGL(partition_emit_kernel, dim3((unsigned)st.n_tiles), dim3(kBlock), 0, ctx->stream, dest, st, (uint32_t)n_parts, counts, tile_base, o_rows, pay);
     }
@@ -444,7 +487,21 @@ int flockgpu_partition_by_key(flockgpu_ctx *ctx, const int32_t *keys, int64_t ro
     const int32_t *d_rows = nullptr;
     const int64_t *d_off = nullptr, *h_off = nullptr;
     int64_t n_out = 0;
-    FG_TRY(partition_by_key_async(ctx, keys, rows, win, n_parts, &d_rows, &d_off, &h_off, &n_out));
+    const PartPayload *pay_p = nullptr;
+#if defined(FLOCKGPU_EXPERIMENTAL)   // (A/B builds only, tools/gpu_partition_ab.py --payload k: k payload columns ride in the emit pass as in comm.hip's exchange -- the key column k times)
+    PartPayload pay;
+    if (const char *e = exp_env("FLOCKGPU_AB_PART_PAYLOAD")) {
+        for (int c = 0; c < atoi(e) && c < 4; ++c) {
+            void *p = nullptr;
+            FG_TRY(arena_get(ctx, ("partition.ab_payload" + std::to_string(c)).c_str(), (size_t)rows * 4 + 16, &p));
+            pay.src[pay.n] = keys;
+            pay.dst[pay.n++] = static_cast<int32_t *>(p);
+        }
+        pay.skip_rows = true;
+        pay_p = &pay;
+    }
+#endif
+    FG_TRY(partition_by_key_async(ctx, keys, rows, win, n_parts, &d_rows, &d_off, &h_off, &n_out, pay_p));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t n_groups = (size_t)n_parts * win->n_windows;
     std::vector<int64_t> &offs = ctx->host_i64["partition.group_offsets"];
