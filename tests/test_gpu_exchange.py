@@ -242,3 +242,39 @@ def test_q5_weighted_rejects_counts_that_overflow_32_bits(ctx):
     ok = ctx.q5_hot_items_weighted(key, big, WindowSchedule(np.array([0, 16]), np.array([0], np.int32), np.array([1], np.int32)))   # 16 * 2^27 = 2^31
     a, cnt, off = ok.to_host()
     assert len(a) == 16 and (cnt == 2**27).all()
+
+
+@pytest.mark.parametrize("n_parts", [1, 4, 8])
+def test_partition_of_two_hundred_million_rows_by_its_properties(ctx, n_parts):
+    """RepartitionExec Hash([key], n) at the size of the BASELINE exchange (2e8 keys over 216 hopping-pane windows; one destination, the
+    destination-by-destination write-out and the one-pass write-out), checked through what does not depend on the size: every group (destination,
+    window) holds rows of its window only, in ascending order (so no row twice), whose keys hash to the destination; the group sizes are the
+    histogram of the destinations per window and add up to the rows."""
+    import torch
+    from flock_amd import WindowSchedule
+    n, n_win = 200_000_003, 216
+    g = torch.Generator(device="cuda").manual_seed(20 + n_parts)
+    keys = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+    offs = np.linspace(0, n, n_win + 1).astype(np.int64)
+    offs[1:-1] += 1                                                       # unaligned window starts
+    sched = WindowSchedule(offs, np.arange(n_win), np.arange(1, n_win + 1))
+    rows, counts = ctx.partition_by_key(keys, sched, n_parts)
+    assert rows.numel() == n and int(counts.sum()) == n
+    # the destinations, restated in torch (test_distributed.mix32 / part_of)
+    x = keys.to(torch.int64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 16
+    part = (x * n_parts) >> 32
+    del x
+    win_of_row = torch.bucketize(torch.arange(n, device="cuda"), torch.from_numpy(offs[1:]).cuda(), right=True)
+    want = torch.bincount(part * n_win + win_of_row, minlength=n_parts * n_win).reshape(n_parts, n_win).cpu().numpy()
+    assert np.array_equal(counts, want)
+    group_of_pos = torch.repeat_interleave(torch.arange(n_parts * n_win, device="cuda"), torch.from_numpy(counts.reshape(-1)).cuda())
+    r64 = rows.to(torch.int64)
+    assert bool((part[r64] == group_of_pos // n_win).all())               # every row sits with its destination ...
+    assert bool((win_of_row[r64] == group_of_pos % n_win).all())          # ... and its window
+    same = group_of_pos[1:] == group_of_pos[:-1]
+    assert bool((r64[1:][same] > r64[:-1][same]).all())                   # input order inside a group: ascending, hence no row twice
