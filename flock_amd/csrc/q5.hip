@@ -1146,16 +1146,15 @@ __global__ __launch_bounds__(kBlock) void q5_partial_tile_kernel(const int32_t *
             const bool is_hot = k[it][j] == hot;
             const uint64_t b = (j == 0) ? b0 : __ballot(is_hot);
             hot_cnt += (uint32_t)__popcll((unsigned long long)b);
-            const uint32_t bin = is_hot ? (uint32_t)(kHist + lane) : (uint32_t)k[it][j] - (uint32_t)mn;
-            atomicAdd(&hist[bin], 1u);
+            if (!is_hot) atomicAdd(&hist[(uint32_t)k[it][j] - (uint32_t)mn], 1u);   // (hot lanes masked, not sent to a scratch bin: the count pass's variant 1)
         }
     }
     if (hot_cnt && lane == 0) atomicAdd(&hist[(uint32_t)hot - (uint32_t)mn], hot_cnt);
     __syncthreads();
     const int64_t o = reg + s_base;
-    for (uint32_t b = threadIdx.x; b <= span; b += kBlock) {
-        out_key[o + b] = (int32_t)((uint32_t)mn + b);
-        out_cnt[o + b] = hist[b];
+    for (uint32_t b = threadIdx.x; b <= span; b += kBlock) {   // (read again only after the whole pass: kept out of the caches the bids stream through)
+        __builtin_nontemporal_store((int32_t)((uint32_t)mn + b), out_key + o + b);
+        __builtin_nontemporal_store(hist[b], out_cnt + o + b);
     }
 }
 
