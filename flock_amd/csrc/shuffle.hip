@@ -243,19 +243,47 @@ __global__ __launch_bounds__(kBlock) void partition_emit_one_kernel(SegTiles st,
     const TileRange tr = locate_tile(st, tile, kFlagTile);
     const uint64_t base = tile_base[tile];
     const int32_t n = (int32_t)(tr.hi - tr.lo);
-    for (int32_t i0 = 0; i0 < n; i0 += kBlock * 4) {
-        int32_t v[4][4];
+    // four consecutive rows per lane and step: 16-byte loads and stores at dword-aligned addresses (all the hardware asks of a global access;
+    // source and destination are offset against each other by whatever the windows in front left)
+    for (int32_t i0 = 0; i0 < n; i0 += kBlock * 8) {
+        int4 v[2][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int32_t i = i0 + u * kBlock + (int32_t)threadIdx.x;
-            for (int c = 0; c < pl.n; ++c) v[u][c] = i < n ? __builtin_nontemporal_load(pl.src[c] + tr.lo + i) : 0;
+        for (int u = 0; u < 2; ++u) {
+            const int32_t i = i0 + u * kBlock * 4 + (int32_t)threadIdx.x * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= pl.n) break;
+                if (i + 4 <= n) {
+                    __builtin_memcpy(&v[u][c], pl.src[c] + tr.lo + i, 16);
+                } else {
+                    int32_t t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = i + j < n ? pl.src[c][tr.lo + i + j] : 0;
+                    v[u][c] = make_int4(t[0], t[1], t[2], t[3]);
+                }
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int32_t i = i0 + u * kBlock + (int32_t)threadIdx.x;
+        for (int u = 0; u < 2; ++u) {
+            const int32_t i = i0 + u * kBlock * 4 + (int32_t)threadIdx.x * 4;
             if (i >= n) continue;
-            if (!pl.skip_rows) out_rows[base + i] = (int32_t)(tr.lo + i);
-            for (int c = 0; c < pl.n; ++c) pl.dst[c][base + i] = v[u][c];
+            if (i + 4 <= n) {
+                if (!pl.skip_rows) {
+                    const int32_t r0 = (int32_t)(tr.lo + i);
+                    const int4 r = make_int4(r0, r0 + 1, r0 + 2, r0 + 3);
+                    __builtin_memcpy(out_rows + base + i, &r, 16);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < pl.n) __builtin_memcpy(pl.dst[c] + base + i, &v[u][c], 16);
+            } else {
+                for (int j = 0; i + j < n; ++j) {
+                    if (!pl.skip_rows) out_rows[base + i + j] = (int32_t)(tr.lo + i + j);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < pl.n) pl.dst[c][base + i + j] = j == 0 ? v[u][c].x : j == 1 ? v[u][c].y : j == 2 ? v[u][c].z : v[u][c].w;
+                }
+            }
         }
     }
 }
