@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void regroup_index_kernel(const int64_t *__
 }
 
 // dst[out_start[run] ...] = src[src_start[run] ...] for every run, `width` bytes per row: grid = per_run shares x runs.  Runs start at
-// arbitrary rows, so the body moves 4-byte words (rows are 4 or 8 bytes wide: always whole words).
+// arbitrary rows (rows are 4 or 8 bytes wide: always whole 4-byte words, at dword-aligned addresses).
 // src_start[run] >= 0: a row of the received buffer; < 0: row -1 - src_start[run] of this rank's own send buffer (its chunk is not copied
 // to itself first).
 __global__ __launch_bounds__(kBlock) void regroup_copy_kernel(const int64_t *__restrict__ out_start, const int64_t *__restrict__ src_start,
@@ -515,7 +515,15 @@ __global__ __launch_bounds__(kBlock) void regroup_copy_kernel(const int64_t *__r
     const int64_t s0 = src_start[run];
     const uint32_t *s = reinterpret_cast<const uint32_t *>(s0 >= 0 ? src + s0 * width : self_src + (-1 - s0) * width);
     uint32_t *d = reinterpret_cast<uint32_t *>(dst + out_start[run] * width);
-    for (int64_t i = (int64_t)(blockIdx.x % (unsigned)per_run) * kBlock + threadIdx.x; i < words; i += (int64_t)per_run * kBlock) d[i] = s[i];
+    // four words per lane and step as ONE 16-byte load and store at dword-aligned addresses (all the hardware asks of a global access; source and
+    // destination are offset against each other by whatever rows lie in front of the run), the last one to three words one by one
+    const int64_t quads = words >> 2;
+    for (int64_t i = (int64_t)(blockIdx.x % (unsigned)per_run) * kBlock + threadIdx.x; i < quads; i += (int64_t)per_run * kBlock) {
+        uint4 v;
+        __builtin_memcpy(&v, s + 4 * i, 16);
+        __builtin_memcpy(d + 4 * i, &v, 16);
+    }
+    if (blockIdx.x % (unsigned)per_run == 0 && threadIdx.x < (unsigned)(words & 3)) d[4 * quads + threadIdx.x] = s[4 * quads + threadIdx.x];
 }
 
 inline unsigned grid_for(flockgpu_ctx *ctx, int64_t n) {
