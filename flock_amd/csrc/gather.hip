@@ -854,6 +854,51 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(int32_t *data, int64
 }
 
 
+// The same scan in ONE launch for inputs of a few thousand values (a radix pass's histogram over a relation of a few hundred thousand rows, the
+// offsets of a small Utf8 column): one workgroup of 1024 threads takes the input 8192 values a round (four rounds at most, all loaded up front) with a
+// running carry -- one launch instead of three and two boundaries.
+constexpr int kSmallScanBlock = 1024;
+constexpr int64_t kSmallScanMax = 4 * kSmallScanBlock * kScanItems;   // 32768 values: four rounds
+__global__ __launch_bounds__(kSmallScanBlock) void scan_small_kernel(int32_t *data, int64_t n) {
+    __shared__ uint32_t s_wave[4][kSmallScanBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr int kRounds = (int)(kSmallScanMax / ((int64_t)kSmallScanBlock * kScanItems));
+    // every round's values are asked for up front (one memory round trip for the whole input, not one per round)
+    uint32_t v[kRounds][kScanItems];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int64_t i0 = ((int64_t)r * kSmallScanBlock + threadIdx.x) * kScanItems;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) v[r][k] = (i0 + k < n) ? (uint32_t)data[i0 + k] : 0u;
+    }
+    uint32_t mine[kRounds], incl[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        mine[r] = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) mine[r] += v[r][k];
+        incl[r] = wave_incl_scan_u32(mine[r]);
+        if (lane == 63) s_wave[r][wave] = incl[r];
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const uint32_t wt = lane < kSmallScanBlock / 64 ? s_wave[r][lane] : 0u;   // (every wave scans the sixteen wave totals itself)
+        const uint32_t wincl = wave_incl_scan_u32(wt);
+        const uint32_t below = wave > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)wincl, wave - 1) : 0u;   // (wave is uniform in a wave)
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, kSmallScanBlock / 64 - 1);
+        uint32_t pos = carry + below + incl[r] - mine[r];
+        const int64_t i0 = ((int64_t)r * kSmallScanBlock + threadIdx.x) * kScanItems;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            pos += v[r][k];
+            if (i0 + k < n) data[i0 + k] = (int32_t)pos;
+        }
+        carry += total;
+    }
+}
+
 // ---- fill_words / publish_words (gather.hpp)
 __global__ __launch_bounds__(kBlock) void fill_words_kernel(FillList f) {
     const uint64_t t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
@@ -958,6 +1003,11 @@ int segment_key_stats(flockgpu_ctx *ctx, const int32_t *col, int64_t n_rows, con
 
 int inclusive_scan_i32(flockgpu_ctx *ctx, const char *name, int32_t *data, int64_t n) {
     if (n <= 0) return FLOCKGPU_OK;
+    if (n <= kSmallScanMax) {
+        LaunchScope ls(ctx, "scan_small_kernel");
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kSmallScanBlock), 0, ctx->stream, data, n);
+        return check_launch(ctx, "scan_small_kernel");
+    }
     const int64_t tiles = div_up(n, kScanTile);
     if (tiles > 0x7fffffff / 2) return fail(ctx, FLOCKGPU_ERR_UNSUPPORTED, "%s: too many tiles", name);
     const std::string k_c = std::string(name) + ".counts", k_b = std::string(name) + ".base";

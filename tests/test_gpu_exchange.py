@@ -278,3 +278,13 @@ def test_partition_of_two_hundred_million_rows_by_its_properties(ctx, n_parts):
     assert bool((win_of_row[r64] == group_of_pos % n_win).all())          # ... and its window
     same = group_of_pos[1:] == group_of_pos[:-1]
     assert bool((r64[1:][same] > r64[:-1][same]).all())                   # input order inside a group: ascending, hence no row twice
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 8191, 8192, 8193, 20_000, 32_767, 32_768, 32_769, 70_001])
+def test_inclusive_scan_around_the_one_launch_limit(ctx, n):
+    """`flockgpu_inclusive_scan_i32` through `offsets_from_lengths`: inputs up to 32768 values take one workgroup walking 8192 values a round
+    (gather.hip scan_small_kernel), larger ones the three-launch scan -- sizes either side of a round, of a wave and of the limit."""
+    rng = np.random.default_rng(n)
+    lens = rng.integers(0, 50, n).astype(np.int32)
+    got = ctx.offsets_from_lengths(_dev(lens)).cpu().numpy()
+    assert np.array_equal(got, np.concatenate(([0], np.cumsum(lens, dtype=np.int64))).astype(np.int32))
