@@ -188,9 +188,9 @@ __global__ __launch_bounds__(kBlock) void partition_emit_kernel(const uint32_t *
 }
 
 // Up to four destinations: the write-out destination by destination (the form of rounds 1-5, now on the count pass's destination bytes: no key
-// read, no hash).  Its 16 KB of LDS and 71 VGPRs keep more workgroups on a CU than the one-pass form above (34 KB, 127 VGPRs: four), and the
-// write-out with payload columns is a latency-bound gather: with two payload columns, emit pass per 8e7 rows, loop / one pass: 0.30 / 0.40 ms at
-// two destinations, 0.34 / 0.37 at four, (0.47) / 0.41 at eight (`profiles/r06/partition_ab.txt`) -- the loop's cost grows with the destinations,
+// read, no hash).  With two payload columns, emit pass per 8e7 rows, loop / one pass: 0.30 / 0.40 ms at two destinations, 0.34 / 0.37 at four,
+// (0.47) / 0.41 at eight (`profiles/r06/partition_ab.txt`) -- a workgroup of the loop reaches its first write-out after one list build, the one
+// pass after its scans and the whole scatter phase; the loop's cost grows with the destinations,
 // the one pass's does not.  (Asking for the payload columns' tile as a coalesced stream first, so that the scattered reads of the write-out find
 // their lines in the L2: 0.40 -> 0.35 for the one pass at two destinations, nothing at eight, nothing for the loop -- not kept.)
 __device__ __forceinline__ uint32_t flags_of(const uint32_t (&d)[kFlagIters], uint32_t part) {
